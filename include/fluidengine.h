@@ -1,0 +1,190 @@
+/*
+ * fluidengine.h — C ABI of the MI355X-native FluidEngine MLS-MPM core.
+ *
+ * This is the drop-in boundary for the hot path of zhouxian/FluidLab:
+ * everything `MPMSimulator` (fluidlab/fluidengine/simulators/mpm_simulator.py)
+ * did through Taichi kernels is reached through these entry points.  The
+ * reference has no FFI of its own (its "operators" are @ti.kernel methods
+ * inlined by the Taichi JIT), so each entry point cites the reference method
+ * it replaces.  Two libraries export exactly this symbol set:
+ *
+ *   fluidlab_amd/csrc/libfluidengine_hip.so   product: hand-written gfx950 HIP kernels (fe_real = float)
+ *   oracle/_build/libfe_oracle_f32.so|_f64.so test infrastructure: CPU restatement of the reference
+ *
+ * Conventions
+ *   - plain pointers and sizes only; host arrays are C-contiguous and borrowed
+ *     for the duration of the call.  Particle arrays are always indexed by the
+ *     caller's particle id (the engine may keep particles in another order).
+ *   - every int-returning function returns 0 on success, non-zero on error;
+ *     fe_last_error() gives the message.  Nothing aborts.
+ *   - one engine <-> one device <-> one HIP stream; an engine is not
+ *     thread-safe; engines are independent of each other.
+ *   - frames f are *local* substep indices in [0, max_substeps_local]
+ *     (mpm_simulator.py:225-252); f_global counts substeps since set_state.
+ */
+#ifndef FLUIDENGINE_H
+#define FLUIDENGINE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifndef FE_REAL
+#define FE_REAL float
+#endif
+typedef FE_REAL fe_real;
+
+typedef struct FeEngine FeEngine;
+
+/* material classes — fluidlab/configs/macros.py:37-41 */
+enum {
+    FE_MAT_LIQUID              = 200,
+    FE_MAT_PLASTO_ELASTIC      = 201,
+    FE_MAT_ELASTIC             = 202,
+    FE_MAT_RIGID               = 203,
+    FE_MAT_PLASTO_ELASTIC_DEMO = 204
+};
+
+/* boundaries — fluidlab/fluidengine/boundaries/boundaries.py:28-134 */
+enum { FE_BOUNDARY_CUBE = 0, FE_BOUNDARY_CYLINDER = 1 };
+
+typedef struct FeBoundary {
+    int     type;            /* FE_BOUNDARY_*                                       */
+    fe_real lower[3];        /* cube: lower corner; cylinder: (0, y_lower, 0)       */
+    fe_real upper[3];        /* cube: upper corner; cylinder: (1, y_upper, 1)       */
+    fe_real xz_center[2];    /* cylinder only                                       */
+    fe_real xz_radius;       /* cylinder only                                       */
+    fe_real restitution;     /* Boundary.__init__, boundaries.py:10-12              */
+    int     lock_dims;       /* bit d set => v[d] = 0 (lock_dims list)              */
+} FeBoundary;
+
+/* MPMSimulator.__init__ / build — mpm_simulator.py:14-71 */
+typedef struct FeConfig {
+    int        struct_size;          /* sizeof(FeConfig), ABI check                 */
+    int        n_grid;               /* 64 * quality, mpm:21                        */
+    int        n_particles;          /* mpm:54                                      */
+    int        max_substeps_local;   /* L: frames 0..L are addressable, mpm:27      */
+    int        n_substeps;           /* substeps per step, mpm:30                   */
+    int        max_action_steps;     /* horizon (action_buffer length), effector.py:48 */
+    fe_real    dt;                   /* mpm:24                                      */
+    fe_real    p_vol;                /* (dx/2)^2, mpm:25                            */
+    fe_real    gravity[3];           /* mpm:19                                      */
+    FeBoundary boundary;             /* mpm:39-45                                   */
+    int        device;               /* HIP device ordinal (ignored by the oracle)  */
+} FeConfig;
+
+/* effectors — fluidlab/fluidengine/effectors/effector.py, injector.py */
+enum { FE_EFF_PLAIN = 0, FE_EFF_INJECTOR = 1 };
+
+typedef struct FeEffectorDesc {
+    int        struct_size;
+    int        type;                 /* FE_EFF_*                                    */
+    int        action_dim;           /* 0, 3 or 6; effector.py:43                   */
+    fe_real    action_scale_v[6];    /* effector.py:54                              */
+    fe_real    action_scale_p[6];    /* effector.py:55                              */
+    FeBoundary boundary;             /* the effector's own boundary, effector.py:62 */
+    /* Injector only (injector.py:13-36) */
+    int        flux;                 /* particles injected per substep              */
+    fe_real    radius;
+    fe_real    inject_v[3];
+    fe_real    inject_p[3];
+    int        locally_random;       /* random_vector indexed by f (1) or f_global (0) */
+    int        randomize_inject_v;
+    int        random_length;        /* rows of random_vector                       */
+} FeEffectorDesc;
+
+/* ---- lifecycle -------------------------------------------------------- */
+FeEngine*   fe_create(const FeConfig* cfg);            /* NULL on failure; fe_last_error(NULL) */
+void        fe_destroy(FeEngine* h);
+const char* fe_last_error(FeEngine* h);                /* h may be NULL (creation errors)      */
+const char* fe_backend(void);                          /* "hip-gfx950", "oracle-f32", "oracle-f64" */
+int         fe_real_size(void);                        /* sizeof(fe_real)                      */
+int         fe_sync(FeEngine* h);                      /* wait for the engine's stream         */
+int         fe_set_option(FeEngine* h, const char* name, double value);  /* tunables, see DESIGN.md */
+
+/* ---- particles: init_particles_kernel, mpm:136-175 -------------------- */
+/* x[N,3]; used/mat/mat_cls/body_id[N] i32; mu/lam/rho[N].  mass = p_vol*rho.
+ * Frame 0 gets v=0, C=0, F=I. */
+int fe_init_particles(FeEngine* h, const fe_real* x, const int* used, const int* mat,
+                      const int* mat_cls, const fe_real* mu, const fe_real* lam,
+                      const fe_real* rho, const int* body_id);
+
+/* ---- the hot path: substep / substep_grad, mpm:515-552 ---------------- */
+/* act != 0 <=> `not is_none_action`: agent.act / agent.move run (mpm:318-324,507-513). */
+int fe_substep(FeEngine* h, int f, int f_global, int act);
+int fe_substep_grad(FeEngine* h, int f, int f_global, int act);
+/* n consecutive substeps in one crossing: the loops at mpm:749-751 / mpm:761-763.
+ * fe_step walks f0, f0+1, ...; fe_step_grad walks f0+n-1 down to f0. */
+int fe_step(FeEngine* h, int f0, int f_global0, int n, int act);
+int fe_step_grad(FeEngine* h, int f0, int f_global0, int n, int act);
+
+/* ---- state I/O: mpm:555-609, 646-719 ---------------------------------- */
+/* NULL pointers are skipped.  x,v [N,3]; C,F [N,3,3]; used [N] i32. */
+int fe_get_frame(FeEngine* h, int f, fe_real* x, fe_real* v, fe_real* C, fe_real* F, int* used);
+int fe_set_frame(FeEngine* h, int f, const fe_real* x, const fe_real* v, const fe_real* C,
+                 const fe_real* F, const int* used);
+int fe_copy_frame(FeEngine* h, int src, int dst);           /* mpm:588-595 */
+int fe_copy_grad(FeEngine* h, int src, int dst);            /* mpm:597-604 */
+int fe_reset_grad(FeEngine* h);                             /* mpm:203-205 (+ effectors, effector.py:76-82) */
+int fe_reset_grad_till_frame(FeEngine* h, int f);           /* mpm:606-609 (+ effector.py:178-183) */
+/* adjoint access used by losses and tests: particles.grad[f].{x,v,C,F} */
+int fe_get_grad(FeEngine* h, int f, fe_real* gx, fe_real* gv, fe_real* gC, fe_real* gF);
+int fe_add_grad(FeEngine* h, int f, const fe_real* gx, const fe_real* gv, const fe_real* gC,
+                const fe_real* gF);
+/* particles_i.mat, used by Recorder (recorder.py:59) */
+int fe_get_mat(FeEngine* h, int* mat);
+
+/* ---- effectors / agent: effector.py:157-283, injector.py:54-105 ------- */
+/* returns the effector index (>=0) or -1.  random_vector is [random_length, flux, 3]
+ * (injector.py:54-60) or NULL for FE_EFF_PLAIN. */
+int fe_add_effector(FeEngine* h, const FeEffectorDesc* desc, const fe_real* random_vector);
+int fe_eff_set_act_range(FeEngine* h, int e, const int* act_range, int n);        /* injector.py:62-68 */
+/* state = pos[3], quat[4] (wxyz), act_id — effector.py:185-208, injector.py:190-213 */
+int fe_eff_get_state(FeEngine* h, int e, int f, fe_real* state8);
+int fe_eff_set_state(FeEngine* h, int e, int f, const fe_real* state8);
+/* v[3], w[3] of frame f (checkpoint payload, effector.py:84-102) */
+int fe_eff_get_vw(FeEngine* h, int e, int f, fe_real* v3, fe_real* w3);
+int fe_eff_set_vw(FeEngine* h, int e, int f, const fe_real* v3, const fe_real* w3);
+int fe_eff_set_action(FeEngine* h, int e, int s, int s_global, int n_substeps,
+                      const fe_real* action);                                     /* effector.py:262-268 */
+int fe_eff_set_action_grad(FeEngine* h, int e, int s, int s_global, int n_substeps); /* effector.py:270-274 */
+int fe_eff_apply_action_p(FeEngine* h, int e, const fe_real* action_p);           /* effector.py:227-231 */
+int fe_eff_apply_action_p_grad(FeEngine* h, int e);                               /* effector.py:233-234 */
+/* grad is [(n+1), action_dim]: rows 0..n-1 = action_buffer.grad[s..s+n), row n = action_buffer_p.grad */
+int fe_eff_get_action_grad(FeEngine* h, int e, int s, int n, fe_real* grad);      /* effector.py:276-283 */
+int fe_agent_copy_frame(FeEngine* h, int src, int dst);                           /* agent.py:117-120 */
+int fe_agent_copy_grad(FeEngine* h, int src, int dst);                            /* agent.py:122-125 */
+
+/* ---- loss: shapematching_loss.py:64-93 -------------------------------- */
+int fe_loss_alloc(FeEngine* h, int max_loss_steps);
+int fe_loss_set_target(FeEngine* h, int s, const fe_real* x);                     /* target['x'][s], [N,3] */
+int fe_loss_clear(FeEngine* h);                                                   /* loss.py:55-61 */
+/* chamfer_loss[s] += sum_p [used[f,p] && mat[p]==matching_mat] |x[f,p]-tgt_s[p]|^2 ;
+ * step_loss[s] += chamfer_loss[s] * weight   (shapematching_loss.py:80-88) */
+int fe_loss_step(FeEngine* h, int s, int f, int matching_mat, fe_real weight);
+/* x.grad[f,p] += 2 (x-tgt) * weight * step_loss_grad  (adjoint of the two kernels above) */
+int fe_loss_step_grad(FeEngine* h, int s, int f, int matching_mat, fe_real weight,
+                      fe_real step_loss_grad);
+int fe_loss_get(FeEngine* h, fe_real* step_loss, int n);                          /* step_loss[0..n) */
+
+/* ---- measurement ------------------------------------------------------ */
+typedef struct FeStats {
+    long long n_used;          /* used particles in the last processed frame            */
+    long long n_cells_touched; /* Nc: grid nodes inside some used particle's stencil    */
+    long long n_blocks_active; /* 4^3-cell blocks holding those nodes                   */
+    long long n_slow_path;     /* particles that missed their LDS tile (global atomics) */
+    long long bytes_state;     /* device bytes held by the engine                       */
+} FeStats;
+int fe_get_stats(FeEngine* h, int f, FeStats* out);
+/* HIP-event stopwatch on the engine's stream */
+int    fe_timer_start(FeEngine* h);
+double fe_timer_stop_ms(FeEngine* h);               /* records, waits, returns elapsed ms (<0 on error) */
+/* per-kernel event timing: enable, run some substeps, then read back.
+ * names is a '\n'-separated list written into buf; ms_total/launches have `cap` slots. */
+int fe_profile_enable(FeEngine* h, int on);
+int fe_profile_read(FeEngine* h, char* buf, int buf_len, double* ms_total, long long* launches, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLUIDENGINE_H */

@@ -1,0 +1,1113 @@
+/*
+ * fe_oracle.cpp — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement of the FluidLab MLS-MPM hot path, kernel by kernel, behind the
+ * same C ABI as the HIP engine (include/fluidengine.h).  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ *
+ * PARITY UNPINNED: the reference ships no tests / golden vectors for this path and
+ * its implementation (Python + Taichi 1.1.0 JIT) can neither be imported nor built
+ * in this image.  This file follows fluidlab/fluidengine/simulators/mpm_simulator.py
+ * line by line (citations as `mpm:NNN`); the adjoints, which the reference obtains
+ * from Taichi's source-transform autodiff, are hand-derived here and validated
+ * against central finite differences of this file's own forward (tests/).
+ * Third-party arithmetic not in /root/reference: taichi==1.1.0 `ti.svd` (McAdams
+ * et al. 3x3 SVD; contract restated in svd3() below).
+ *
+ * Build: see oracle/Makefile (-DFE_REAL=float -> libfe_oracle_f32.so, double -> _f64).
+ */
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "../include/fluidengine.h"
+
+typedef fe_real R;
+
+namespace {
+
+const R EPS = (R)1e-12;   /* fluidlab/configs/macros.py:213 */
+
+struct M3 { R m[3][3]; };
+struct V3 { R v[3]; };
+
+inline M3 m_zero() { M3 a; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) a.m[i][j] = 0; return a; }
+inline M3 m_ident() { M3 a = m_zero(); a.m[0][0] = a.m[1][1] = a.m[2][2] = 1; return a; }
+inline M3 m_mul(const M3& a, const M3& b) {
+    M3 c;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+        R s = 0; for (int k = 0; k < 3; k++) s += a.m[i][k] * b.m[k][j]; c.m[i][j] = s;
+    }
+    return c;
+}
+inline M3 m_T(const M3& a) { M3 c; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) c.m[i][j] = a.m[j][i]; return c; }
+inline M3 m_add(const M3& a, const M3& b) { M3 c; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) c.m[i][j] = a.m[i][j] + b.m[i][j]; return c; }
+inline M3 m_sub(const M3& a, const M3& b) { M3 c; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) c.m[i][j] = a.m[i][j] - b.m[i][j]; return c; }
+inline M3 m_scale(const M3& a, R s) { M3 c; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) c.m[i][j] = a.m[i][j] * s; return c; }
+inline M3 m_had(const M3& a, const M3& b) { M3 c; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) c.m[i][j] = a.m[i][j] * b.m[i][j]; return c; }
+inline R m_det(const M3& a) {
+    return a.m[0][0] * (a.m[1][1] * a.m[2][2] - a.m[1][2] * a.m[2][1])
+         - a.m[0][1] * (a.m[1][0] * a.m[2][2] - a.m[1][2] * a.m[2][0])
+         + a.m[0][2] * (a.m[1][0] * a.m[2][1] - a.m[1][1] * a.m[2][0]);
+}
+inline R m_trace(const M3& a) { return a.m[0][0] + a.m[1][1] + a.m[2][2]; }
+inline M3 m_load(const R* p) { M3 a; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) a.m[i][j] = p[i * 3 + j]; return a; }
+inline void m_store(R* p, const M3& a) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) p[i * 3 + j] = a.m[i][j]; }
+inline void m_accum(R* p, const M3& a) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) p[i * 3 + j] += a.m[i][j]; }
+
+/*
+ * 3x3 SVD with the contract of taichi 1.1.0 `ti.svd` (call sites mpm:264, mpm:483):
+ * F = U diag(sig) V^T, U and V proper rotations (det = +1), |sig| sorted descending,
+ * a negative sign (det F < 0) carried by the last (smallest) singular value.
+ * Taichi's implementation is the McAdams/Sifakis fixed-sweep Jacobi; it is not in
+ * /root/reference, so the published contract is restated with a one-sided (Hestenes)
+ * Jacobi iterated to convergence.  Consumers (mpm:339-376) use only U V^T, det S and
+ * U clamp(S) V^T, which are invariant to the residual gauge freedom.
+ */
+void svd3(const M3& Fin, M3& U, M3& S, M3& V) {
+    R A[3][3];
+    R Vm[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) A[i][j] = Fin.m[i][j];
+    const R tiny = sizeof(R) == 4 ? (R)1e-30 : (R)1e-290;
+    const R tol = sizeof(R) == 4 ? (R)1e-7 : (R)1e-15;
+    for (int sweep = 0; sweep < 60; sweep++) {
+        bool rotated = false;
+        for (int p = 0; p < 2; p++) for (int q = p + 1; q < 3; q++) {
+            R alpha = 0, beta = 0, gamma = 0;
+            for (int i = 0; i < 3; i++) { alpha += A[i][p] * A[i][p]; beta += A[i][q] * A[i][q]; gamma += A[i][p] * A[i][q]; }
+            if (std::fabs(gamma) <= tol * std::sqrt(alpha * beta) || std::fabs(gamma) < tiny) continue;
+            rotated = true;
+            R zeta = (beta - alpha) / (2 * gamma);
+            R t = (zeta >= 0 ? (R)1 : (R)-1) / (std::fabs(zeta) + std::sqrt(1 + zeta * zeta));
+            R c = 1 / std::sqrt(1 + t * t), s = c * t;
+            for (int i = 0; i < 3; i++) {
+                R ap = A[i][p], aq = A[i][q];
+                A[i][p] = c * ap - s * aq; A[i][q] = s * ap + c * aq;
+                R vp = Vm[i][p], vq = Vm[i][q];
+                Vm[i][p] = c * vp - s * vq; Vm[i][q] = s * vp + c * vq;
+            }
+        }
+        if (!rotated) break;
+    }
+    R sig[3];
+    for (int j = 0; j < 3; j++) sig[j] = std::sqrt(A[0][j] * A[0][j] + A[1][j] * A[1][j] + A[2][j] * A[2][j]);
+    /* sort descending (swap columns of A, V together) */
+    for (int a = 0; a < 2; a++) for (int b = 0; b < 2 - a; b++) if (sig[b] < sig[b + 1]) {
+        std::swap(sig[b], sig[b + 1]);
+        for (int i = 0; i < 3; i++) { std::swap(A[i][b], A[i][b + 1]); std::swap(Vm[i][b], Vm[i][b + 1]); }
+    }
+    R Um[3][3];
+    /* U columns = A columns / sigma; complete rank-deficient columns orthonormally */
+    const R rel = sig[0] * (sizeof(R) == 4 ? (R)1e-6 : (R)1e-13);
+    int good = 0;
+    for (int j = 0; j < 3; j++) {
+        if (sig[j] > rel && sig[j] > tiny) { for (int i = 0; i < 3; i++) Um[i][j] = A[i][j] / sig[j]; good = j + 1; }
+        else break;
+    }
+    if (good == 0) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Um[i][j] = (i == j); good = 3; }
+    if (good == 1) {
+        /* pick any unit vector orthogonal to column 0 */
+        int k = 0; for (int i = 1; i < 3; i++) if (std::fabs(Um[i][0]) < std::fabs(Um[k][0])) k = i;
+        R e[3] = {0, 0, 0}; e[k] = 1;
+        R d = Um[k][0];
+        R w[3]; R nn = 0; for (int i = 0; i < 3; i++) { w[i] = e[i] - d * Um[i][0]; nn += w[i] * w[i]; }
+        nn = std::sqrt(nn); for (int i = 0; i < 3; i++) Um[i][1] = w[i] / nn;
+        good = 2;
+    }
+    if (good == 2) {
+        Um[0][2] = Um[1][0] * Um[2][1] - Um[2][0] * Um[1][1];
+        Um[1][2] = Um[2][0] * Um[0][1] - Um[0][0] * Um[2][1];
+        Um[2][2] = Um[0][0] * Um[1][1] - Um[1][0] * Um[0][1];
+    }
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { U.m[i][j] = Um[i][j]; V.m[i][j] = Vm[i][j]; }
+    if (m_det(U) < 0) { for (int i = 0; i < 3; i++) U.m[i][2] = -U.m[i][2]; sig[2] = -sig[2]; }
+    if (m_det(V) < 0) { for (int i = 0; i < 3; i++) V.m[i][2] = -V.m[i][2]; sig[2] = -sig[2]; }
+    S = m_zero(); S.m[0][0] = sig[0]; S.m[1][1] = sig[1]; S.m[2][2] = sig[2];
+}
+
+/* mpm:294-302 */
+inline R clamp_svd(R a) { if (a >= 0) a = std::max(a, (R)1e-8); else a = std::min(a, (R)-1e-8); return a; }
+
+/* mpm:272-292 */
+M3 backward_svd(const M3& gU, const M3& gS, const M3& gV, const M3& U, const M3& S, const M3& V) {
+    M3 vt = m_T(V), ut = m_T(U);
+    M3 S_term = m_mul(m_mul(U, gS), vt);
+    R s[3] = {S.m[0][0] * S.m[0][0], S.m[1][1] * S.m[1][1], S.m[2][2] * S.m[2][2]};
+    M3 Fm = m_zero();
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Fm.m[i][j] = (i == j) ? (R)0 : (R)1 / clamp_svd(s[j] - s[i]);
+    M3 u_term = m_mul(m_mul(U, m_mul(m_had(Fm, m_sub(m_mul(ut, gU), m_mul(m_T(gU), U))), S)), vt);
+    M3 v_term = m_mul(U, m_mul(S, m_mul(m_had(Fm, m_sub(m_mul(vt, gV), m_mul(m_T(gV), V))), vt)));
+    return m_add(m_add(u_term, v_term), S_term);
+}
+
+/* fluidlab/utils/geom.py:8-16 */
+inline void qmul(const R q[4], const R r[4], R out[4]) {
+    R t[4][4];
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) t[i][j] = r[i] * q[j];
+    R w = t[0][0] - t[1][1] - t[2][2] - t[3][3];
+    R x = t[0][1] + t[1][0] - t[2][3] + t[3][2];
+    R y = t[0][2] + t[1][3] + t[2][0] - t[3][1];
+    R z = t[0][3] - t[1][2] + t[2][1] + t[3][0];
+    R nn = std::sqrt(w * w + x * x + y * y + z * z);
+    out[0] = w / nn; out[1] = x / nn; out[2] = y / nn; out[3] = z / nn;
+}
+/* geom.py:18-28; Vector.norm(eps) = sqrt(|a|^2 + eps) */
+inline void w2quat(const R aa[3], R out[4]) {
+    R w = std::sqrt(aa[0] * aa[0] + aa[1] * aa[1] + aa[2] * aa[2] + EPS);
+    R sh = std::sin(w / 2);
+    out[0] = std::cos(w / 2); out[1] = aa[0] / w * sh; out[2] = aa[1] / w * sh; out[3] = aa[2] / w * sh;
+}
+/* geom.py:97-102 */
+inline void transform_by_quat(const R v[3], const R q[4], R out[3]) {
+    R qv[3] = {q[1], q[2], q[3]};
+    R uv[3] = {qv[1] * v[2] - qv[2] * v[1], qv[2] * v[0] - qv[0] * v[2], qv[0] * v[1] - qv[1] * v[0]};
+    R uuv[3] = {qv[1] * uv[2] - qv[2] * uv[1], qv[2] * uv[0] - qv[0] * uv[2], qv[0] * uv[1] - qv[1] * uv[0]};
+    for (int i = 0; i < 3; i++) out[i] = v[i] + 2 * (q[0] * uv[i] + uuv[i]);
+}
+
+/* Boundary.impose_x: boundaries.py:66-78 (cylinder), 123-126 (cube).  Also returns the
+ * Jacobian d x_new / d x (3x3) under Taichi's min/max adjoint rules (Appendix B of SURVEY). */
+void impose_x(const FeBoundary& b, const R x[3], R xn[3], R J[3][3]) {
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) J[i][j] = 0;
+    for (int i = 0; i < 3; i++) {
+        R m = std::min(x[i], b.upper[i]);
+        xn[i] = std::max(m, b.lower[i]);
+        /* min(a,b): adjoint to a iff a<b ; max(a,b): adjoint to a iff a>b */
+        J[i][i] = (x[i] < b.upper[i] && m > b.lower[i]) ? (R)1 : (R)0;
+    }
+    if (b.type == FE_BOUNDARY_CYLINDER) {
+        R rx = x[0] - b.xz_center[0], rz = x[2] - b.xz_center[1];
+        R nrm = std::sqrt(rx * rx + rz * rz + EPS);
+        if (nrm > b.xz_radius) {
+            xn[0] = rx / nrm * b.xz_radius + b.xz_center[0];
+            xn[2] = rz / nrm * b.xz_radius + b.xz_center[1];
+            R k = b.xz_radius / nrm, k3 = b.xz_radius / (nrm * nrm * nrm);
+            J[0][0] = k - k3 * rx * rx; J[0][2] = -k3 * rx * rz;
+            J[2][0] = -k3 * rz * rx;    J[2][2] = k - k3 * rz * rz;
+        }
+    }
+}
+
+/* Boundary.impose_x_v velocity part: boundaries.py:40-63 (cylinder), 107-121 (cube).
+ * v is modified in place; k[d] is the multiplier applied to component d (for the adjoint). */
+void impose_v(const FeBoundary& b, const R x[3], R v[3], R k[3]) {
+    k[0] = k[1] = k[2] = 1;
+    if (b.type == FE_BOUNDARY_CUBE) {
+        for (int i = 0; i < 3; i++) {
+            if (x[i] >= b.upper[i] && v[i] >= 0) k[i] = -b.restitution;
+            else if (x[i] <= b.lower[i] && v[i] <= 0) k[i] = -b.restitution;
+        }
+    } else {
+        if (x[1] > b.upper[1] && v[1] > 0) k[1] = -b.restitution;
+        else if (x[1] < b.lower[1] && v[1] < 0) k[1] = -b.restitution;
+        R rx = x[0] - b.xz_center[0], rz = x[2] - b.xz_center[1];
+        R nrm = std::sqrt(rx * rx + rz * rz + EPS);
+        if (nrm > b.xz_radius) { k[0] = 0; k[2] = 0; }
+    }
+    for (int i = 0; i < 3; i++) if (b.lock_dims & (1 << i)) k[i] = 0;
+    for (int i = 0; i < 3; i++) v[i] = (k[i] == 1) ? v[i] : ((k[i] == 0) ? (R)0 : v[i] * k[i]);
+}
+
+struct Effector {
+    FeEffectorDesc d;
+    std::vector<R> pos, quat, v, w, gpos, gquat, gv, gw;     /* [L+1] x {3,4,3,3} */
+    std::vector<R> abuf, gabuf, abuf_p, gabuf_p;              /* action buffers + grads */
+    std::vector<int> act_id;                                   /* [L+1] */
+    std::vector<R> random_vector;
+    std::vector<int> act_range;
+};
+
+} // namespace
+
+struct FeEngine {
+    FeConfig cfg;
+    int N, L, n;
+    R dx, inv_dx;
+    std::vector<R> x, v, C, F, gx, gv, gC, gF;   /* [(L+1), N, {3,3,9,9}] */
+    std::vector<int> used;                        /* [(L+1), N] */
+    std::vector<R> Ftmp, U, V, S, gFtmp, gU, gV, gS; /* per-substep temporaries [N,9] */
+    std::vector<R> mu, lam, mass;
+    std::vector<int> mat, mat_cls, body_id;
+    std::vector<R> g_vin, g_mass, g_vout, gg_vin, gg_mass, gg_vout;
+    std::vector<Effector> effs;
+    int loss_steps = 0;
+    std::vector<R> tgt;          /* [loss_steps, N, 3] */
+    std::vector<R> chamfer, step_loss;
+    std::string err;
+    int threads = 1;
+    bool initialized = false;
+    std::chrono::steady_clock::time_point t0;
+    bool prof_on = false;
+    double prof_ms[2] = {0, 0};
+    long long prof_n[2] = {0, 0};
+
+    R* X(int f) { return &x[(size_t)f * N * 3]; }
+    R* Vv(int f) { return &v[(size_t)f * N * 3]; }
+    R* Cc(int f) { return &C[(size_t)f * N * 9]; }
+    R* Ff(int f) { return &F[(size_t)f * N * 9]; }
+    R* GX(int f) { return &gx[(size_t)f * N * 3]; }
+    R* GV(int f) { return &gv[(size_t)f * N * 3]; }
+    R* GC(int f) { return &gC[(size_t)f * N * 9]; }
+    R* GF(int f) { return &gF[(size_t)f * N * 9]; }
+    int* Us(int f) { return &used[(size_t)f * N]; }
+};
+
+static std::string g_create_err;
+
+#define FE_FAIL(h, msg) do { (h)->err = (msg); return 1; } while (0)
+#define CHECK_FRAME(h, f) do { if ((f) < 0 || (f) > (h)->L) FE_FAIL(h, "frame index out of range"); } while (0)
+#define CHECK_EFF(h, e) do { if ((e) < 0 || (e) >= (int)(h)->effs.size()) FE_FAIL(h, "effector index out of range"); } while (0)
+
+namespace {
+
+inline size_t cell_index(int n, int i, int j, int k) { return ((size_t)i * n + j) * n + k; }
+
+struct Stencil { int base[3]; R fx[3]; R w[3][3]; R dw[3][3]; };
+
+/* mpm:335-337 / mpm:404-406 */
+inline void make_stencil(const R* xp, R inv_dx, Stencil& s) {
+    for (int d = 0; d < 3; d++) {
+        s.base[d] = (int)(xp[d] * inv_dx - (R)0.5);   /* C-style truncation == Taichi cast(int) */
+        s.fx[d] = xp[d] * inv_dx - (R)s.base[d];
+        R fx = s.fx[d];
+        s.w[0][d] = (R)0.5 * ((R)1.5 - fx) * ((R)1.5 - fx);
+        s.w[1][d] = (R)0.75 - (fx - 1) * (fx - 1);
+        s.w[2][d] = (R)0.5 * (fx - (R)0.5) * (fx - (R)0.5);
+        s.dw[0][d] = -((R)1.5 - fx);
+        s.dw[1][d] = -2 * (fx - 1);
+        s.dw[2][d] = fx - (R)0.5;
+    }
+}
+
+inline bool stencil_in_grid(const Stencil& s, int n) {
+    for (int d = 0; d < 3; d++) if (s.base[d] < 0 || s.base[d] + 2 >= n) return false;
+    return true;
+}
+
+/* ------------------------------------------------------------------ forward kernels */
+
+/* mpm:219-223 */
+void reset_grid_and_grad(FeEngine* h) {
+    std::fill(h->g_vin.begin(), h->g_vin.end(), (R)0);
+    std::fill(h->g_mass.begin(), h->g_mass.end(), (R)0);
+    std::fill(h->g_vout.begin(), h->g_vout.end(), (R)0);
+    std::fill(h->gg_vin.begin(), h->gg_vin.end(), (R)0);
+    std::fill(h->gg_mass.begin(), h->gg_mass.end(), (R)0);
+    std::fill(h->gg_vout.begin(), h->gg_vout.end(), (R)0);
+}
+
+/* mpm:304-307 */
+void advect_used(FeEngine* h, int f) {
+    std::memcpy(h->Us(f + 1), h->Us(f), sizeof(int) * h->N);
+}
+
+/* mpm:309-316 */
+void process_unused_particles(FeEngine* h, int f) {
+    const int N = h->N;
+#pragma omp parallel for num_threads(h->threads) schedule(static)
+    for (int p = 0; p < N; p++) {
+        if (h->Us(f)[p] == 0) {
+            for (int d = 0; d < 3; d++) { h->Vv(f + 1)[p * 3 + d] = h->Vv(f)[p * 3 + d]; h->X(f + 1)[p * 3 + d] = h->X(f)[p * 3 + d]; }
+            for (int d = 0; d < 9; d++) { h->Cc(f + 1)[p * 9 + d] = h->Cc(f)[p * 9 + d]; h->Ff(f + 1)[p * 9 + d] = h->Ff(f)[p * 9 + d]; }
+        }
+    }
+}
+
+/* Injector.act: injector.py:80-105 (called from AgentInjector.act_kernel, agent_injector.py:30-32) */
+int injector_act(FeEngine* h, Effector& e, int f, int f_global) {
+    const int flux = e.d.flux;
+    if (e.act_range.empty()) { h->err = "injector has no act_range"; return 1; }
+    const int row = e.d.locally_random ? f : f_global;
+    if (row < 0 || row >= e.d.random_length) { h->err = "injector random_vector row out of range"; return 1; }
+    /* AgentInjector.check_act_range, agent_injector.py:38-39 */
+    if (e.act_id[f] + flux > (int)e.act_range.size()) { h->err = "too many particles added"; return 1; }
+    const R* q = &e.quat[f * 4];
+    for (int i = 0; i < flux; i++) {
+        int pid = e.act_range[e.act_id[f] + i];
+        const R* rv = &e.random_vector[((size_t)row * flux + i) * 3];
+        R ip[3], iv[3];
+        transform_by_quat(e.d.inject_p, q, ip);
+        transform_by_quat(e.d.inject_v, q, iv);
+        R vnorm = std::sqrt(e.d.inject_v[0] * e.d.inject_v[0] + e.d.inject_v[1] * e.d.inject_v[1] + e.d.inject_v[2] * e.d.inject_v[2]);
+        for (int d = 0; d < 3; d++) {
+            R offset = (rv[d] * 2 - 1) * e.d.radius;
+            h->X(f + 1)[pid * 3 + d] = offset + e.pos[f * 3 + d] + ip[d];
+            if (e.d.randomize_inject_v) h->Vv(f + 1)[pid * 3 + d] = iv[d] + (rv[d] * 2 - 1) * vnorm * (R)2.0;
+            else h->Vv(f + 1)[pid * 3 + d] = iv[d];
+        }
+        h->Us(f + 1)[pid] = 1;
+    }
+    e.act_id[f + 1] = e.act_id[f] + flux;
+    return 0;
+}
+
+/* mpm:254-264: compute_F_tmp + svd */
+void compute_F_tmp_svd(FeEngine* h, int f) {
+    const int N = h->N;
+    const R dt = h->cfg.dt;
+#pragma omp parallel for num_threads(h->threads) schedule(static)
+    for (int p = 0; p < N; p++) {
+        if (!h->Us(f)[p]) continue;
+        M3 Cm = m_load(&h->Cc(f)[p * 9]), Fm = m_load(&h->Ff(f)[p * 9]);
+        M3 Ft = m_mul(m_add(m_ident(), m_scale(Cm, dt)), Fm);           /* mpm:258 */
+        M3 U, S, V;
+        svd3(Ft, U, S, V);                                               /* mpm:264 */
+        m_store(&h->Ftmp[p * 9], Ft); m_store(&h->U[p * 9], U); m_store(&h->S[p * 9], S); m_store(&h->V[p * 9], V);
+    }
+}
+
+/* the per-particle quantities p2g needs (mpm:339-344), shared by forward and adjoint */
+struct P2GLocal { M3 Ft, U, S, V, r, stress_raw, affine; R J, scale; };
+
+inline void p2g_local(FeEngine* h, int f, int p, P2GLocal& l) {
+    l.Ft = m_load(&h->Ftmp[p * 9]); l.U = m_load(&h->U[p * 9]); l.S = m_load(&h->S[p * 9]); l.V = m_load(&h->V[p * 9]);
+    l.J = m_det(l.S);                                                                   /* mpm:339 */
+    l.r = m_mul(l.U, m_T(l.V));                                                         /* mpm:341 */
+    M3 st = m_scale(m_mul(m_sub(l.Ft, l.r), m_T(l.Ft)), 2 * h->mu[p]);
+    R iso = h->lam[p] * l.J * (l.J - 1);
+    st.m[0][0] += iso; st.m[1][1] += iso; st.m[2][2] += iso;                            /* mpm:342 */
+    l.stress_raw = st;
+    l.scale = -h->cfg.dt * h->cfg.p_vol * 4 * h->inv_dx * h->inv_dx;                    /* mpm:343 */
+    l.affine = m_add(m_scale(st, l.scale), m_scale(m_load(&h->Cc(f)[p * 9]), h->mass[p])); /* mpm:344 */
+}
+
+/* mpm:331-378 */
+int p2g(FeEngine* h, int f, bool write_F) {
+    const int N = h->N, n = h->n;
+    int bad = 0;
+    const bool par = h->threads > 1;
+#pragma omp parallel for num_threads(h->threads) schedule(static) reduction(+:bad)
+    for (int p = 0; p < N; p++) {
+        if (!h->Us(f)[p]) continue;
+        Stencil s; make_stencil(&h->X(f)[p * 3], h->inv_dx, s);
+        if (!stencil_in_grid(s, n)) { bad++; continue; }
+        P2GLocal l; p2g_local(h, f, p, l);
+        const R m = h->mass[p];
+        const R* vp = &h->Vv(f)[p * 3];
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++) {
+            R dpos[3] = {(i - s.fx[0]) * h->dx, (j - s.fx[1]) * h->dx, (k - s.fx[2]) * h->dx};  /* mpm:347 */
+            R weight = (R)1.0; weight *= s.w[i][0]; weight *= s.w[j][1]; weight *= s.w[k][2];
+            size_t c = cell_index(n, s.base[0] + i, s.base[1] + j, s.base[2] + k);
+            for (int a = 0; a < 3; a++) {
+                R add = weight * (m * vp[a] + (l.affine.m[a][0] * dpos[0] + l.affine.m[a][1] * dpos[1] + l.affine.m[a][2] * dpos[2]));
+                if (par) {
+#pragma omp atomic
+                    h->g_vin[c * 3 + a] += add;                                              /* mpm:352 */
+                } else h->g_vin[c * 3 + a] += add;
+            }
+            if (par) {
+#pragma omp atomic
+                h->g_mass[c] += weight * m;                                                  /* mpm:353 */
+            } else h->g_mass[c] += weight * m;
+        }
+        if (!write_F) continue;
+        /* mpm:355-378 */
+        M3 Fn = m_zero();
+        int cls = h->mat_cls[p];
+        if (cls == FE_MAT_LIQUID) {
+            R c = std::pow(l.J, (R)(1.0 / 3.0));
+            Fn = m_scale(m_ident(), c);
+        } else if (cls == FE_MAT_ELASTIC || cls == FE_MAT_RIGID) {
+            Fn = l.Ft;
+        } else if (cls == FE_MAT_PLASTO_ELASTIC || cls == FE_MAT_PLASTO_ELASTIC_DEMO) {
+            M3 Sn = m_zero();
+            for (int d = 0; d < 3; d++) Sn.m[d][d] = std::min(std::max(l.S.m[d][d], (R)(1 - 2e-3)), (R)(1 + 3e-3));
+            Fn = m_mul(m_mul(l.U, Sn), m_T(l.V));
+        }
+        m_store(&h->Ff(f + 1)[p * 9], Fn);
+    }
+    if (bad) { h->err = "particle stencil left the grid (p2g)"; return 1; }
+    return 0;
+}
+
+/* Effector.move_kernel: effector.py:157-161 */
+void effector_move(Effector& e, int f) {
+    R xin[3] = {e.pos[f * 3] + e.v[f * 3], e.pos[f * 3 + 1] + e.v[f * 3 + 1], e.pos[f * 3 + 2] + e.v[f * 3 + 2]};
+    R xn[3], J[3][3];
+    impose_x(e.d.boundary, xin, xn, J);
+    for (int d = 0; d < 3; d++) e.pos[(f + 1) * 3 + d] = xn[d];
+    R qw[4]; w2quat(&e.w[f * 3], qw);
+    qmul(qw, &e.quat[f * 4], &e.quat[(f + 1) * 4]);
+}
+
+/* mpm:380-398 (no statics / agent colliders in this scope: LatteArt's cup has
+ * has_dynamics=False and AgentInjector.collide is the identity, agent_injector.py:34-36) */
+void grid_op(FeEngine* h) {
+    const int n = h->n;
+    const size_t n3 = (size_t)n * n * n;
+#pragma omp parallel for num_threads(h->threads) schedule(static)
+    for (long long c = 0; c < (long long)n3; c++) {
+        R m = h->g_mass[c];
+        if (m > EPS) {
+            R vo[3];
+            R inv = 1 / m;
+            for (int a = 0; a < 3; a++) vo[a] = inv * h->g_vin[c * 3 + a] + h->cfg.dt * h->cfg.gravity[a];
+            int i = (int)(c / ((size_t)n * n)), j = (int)((c / n) % n), k = (int)(c % n);
+            R xn[3] = {i * h->dx, j * h->dx, k * h->dx};
+            R kk[3];
+            impose_v(h->cfg.boundary, xn, vo, kk);
+            for (int a = 0; a < 3; a++) h->g_vout[c * 3 + a] = vo[a];
+        }
+    }
+}
+
+/* mpm:400-426 */
+int g2p(FeEngine* h, int f) {
+    const int N = h->N, n = h->n;
+    int bad = 0;
+#pragma omp parallel for num_threads(h->threads) schedule(static) reduction(+:bad)
+    for (int p = 0; p < N; p++) {
+        if (!h->Us(f)[p]) continue;
+        Stencil s; make_stencil(&h->X(f)[p * 3], h->inv_dx, s);
+        if (!stencil_in_grid(s, n)) { bad++; continue; }
+        R nv[3] = {0, 0, 0}; M3 nC = m_zero();
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++) {
+            R dpos[3] = {i - s.fx[0], j - s.fx[1], k - s.fx[2]};                            /* mpm:410 */
+            size_t c = cell_index(n, s.base[0] + i, s.base[1] + j, s.base[2] + k);
+            const R* gv = &h->g_vout[c * 3];
+            R weight = (R)1.0; weight *= s.w[i][0]; weight *= s.w[j][1]; weight *= s.w[k][2];
+            for (int a = 0; a < 3; a++) {
+                nv[a] += weight * gv[a];
+                for (int b = 0; b < 3; b++) nC.m[a][b] += 4 * h->inv_dx * weight * gv[a] * dpos[b];
+            }
+        }
+        for (int a = 0; a < 3; a++) h->Vv(f + 1)[p * 3 + a] = nv[a];
+        m_store(&h->Cc(f + 1)[p * 9], nC);
+    }
+    if (bad) { h->err = "particle stencil left the grid (g2p)"; return 1; }
+    return 0;
+}
+
+/* mpm:497-505 (non-rigid branch).  MAT_RIGID shape matching (mpm:449-495) is outside
+ * this round's scope and rejected in fe_init_particles. */
+void advect(FeEngine* h, int f) {
+    const int N = h->N;
+#pragma omp parallel for num_threads(h->threads) schedule(static)
+    for (int p = 0; p < N; p++) {
+        if (!h->Us(f)[p]) continue;
+        for (int d = 0; d < 3; d++) h->X(f + 1)[p * 3 + d] = h->X(f)[p * 3 + d] + h->cfg.dt * h->Vv(f + 1)[p * 3 + d];
+    }
+}
+
+/* ------------------------------------------------------------------ adjoint kernels */
+
+/* advect_kernel.grad (mpm:443): x[f+1] = x[f] + dt v[f+1] */
+void advect_grad(FeEngine* h, int f) {
+    const int N = h->N;
+#pragma omp parallel for num_threads(h->threads) schedule(static)
+    for (int p = 0; p < N; p++) {
+        if (!h->Us(f)[p]) continue;
+        for (int d = 0; d < 3; d++) {
+            R g = h->GX(f + 1)[p * 3 + d];
+            h->GX(f)[p * 3 + d] += g;
+            h->GV(f + 1)[p * 3 + d] += h->cfg.dt * g;
+        }
+    }
+}
+
+/* g2p.grad (mpm:538) */
+void g2p_grad(FeEngine* h, int f) {
+    const int N = h->N, n = h->n;
+    const bool par = h->threads > 1;
+#pragma omp parallel for num_threads(h->threads) schedule(static)
+    for (int p = 0; p < N; p++) {
+        if (!h->Us(f)[p]) continue;
+        Stencil s; make_stencil(&h->X(f)[p * 3], h->inv_dx, s);
+        if (!stencil_in_grid(s, n)) continue;
+        const R* gvn = &h->GV(f + 1)[p * 3];
+        M3 gCn = m_load(&h->GC(f + 1)[p * 9]);
+        R gfx[3] = {0, 0, 0};
+        const R c4 = 4 * h->inv_dx;
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++) {
+            int o[3] = {i, j, k};
+            R dpos[3] = {i - s.fx[0], j - s.fx[1], k - s.fx[2]};
+            size_t c = cell_index(n, s.base[0] + i, s.base[1] + j, s.base[2] + k);
+            const R* gv = &h->g_vout[c * 3];
+            R weight = s.w[i][0] * s.w[j][1] * s.w[k][2];
+            /* q[a] = gv_next[a] + 4 inv_dx (gC_next dpos)[a] : adjoint of g_v[a] per unit weight */
+            R q[3];
+            for (int a = 0; a < 3; a++) q[a] = gvn[a] + c4 * (gCn.m[a][0] * dpos[0] + gCn.m[a][1] * dpos[1] + gCn.m[a][2] * dpos[2]);
+            R sdot = gv[0] * q[0] + gv[1] * q[1] + gv[2] * q[2];
+            for (int a = 0; a < 3; a++) {
+                if (par) {
+#pragma omp atomic
+                    h->gg_vout[c * 3 + a] += weight * q[a];
+                } else h->gg_vout[c * 3 + a] += weight * q[a];
+            }
+            /* weight path */
+            for (int d = 0; d < 3; d++) {
+                R dW = 1;
+                for (int e = 0; e < 3; e++) dW *= (e == d) ? s.dw[o[e]][e] : s.w[o[e]][e];
+                gfx[d] += dW * sdot;
+            }
+            /* dpos path: dpos_b = o_b - fx_b */
+            for (int b = 0; b < 3; b++) gfx[b] -= c4 * weight * (gv[0] * gCn.m[0][b] + gv[1] * gCn.m[1][b] + gv[2] * gCn.m[2][b]);
+        }
+        for (int d = 0; d < 3; d++) h->GX(f)[p * 3 + d] += h->inv_dx * gfx[d];
+    }
+}
+
+/* grid_op.grad (mpm:539) */
+void grid_op_grad(FeEngine* h) {
+    const int n = h->n;
+    const size_t n3 = (size_t)n * n * n;
+#pragma omp parallel for num_threads(h->threads) schedule(static)
+    for (long long c = 0; c < (long long)n3; c++) {
+        R m = h->g_mass[c];
+        if (m > EPS) {
+            R vo[3];
+            R inv = 1 / m;
+            for (int a = 0; a < 3; a++) vo[a] = inv * h->g_vin[c * 3 + a] + h->cfg.dt * h->cfg.gravity[a];
+            int i = (int)(c / ((size_t)n * n)), j = (int)((c / n) % n), k = (int)(c % n);
+            R xn[3] = {i * h->dx, j * h->dx, k * h->dx};
+            R kk[3];
+            impose_v(h->cfg.boundary, xn, vo, kk);
+            R gm = 0;
+            for (int a = 0; a < 3; a++) {
+                R g = h->gg_vout[c * 3 + a] * kk[a];
+                h->gg_vin[c * 3 + a] += g * inv;
+                gm += -h->g_vin[c * 3 + a] * g * inv * inv;
+            }
+            h->gg_mass[c] += gm;
+        }
+    }
+}
+
+/* Effector.move_kernel.grad (effector.py:154-155).  The quaternion branch
+ * (quat[f+1] = qmul(w2quat(w[f]), quat[f])) carries no gradient to a 3-dim action
+ * (effector.py:258-260 only writes w when action_dim>3); its adjoint is not restated. */
+void effector_move_grad(Effector& e, int f) {
+    R xin[3] = {e.pos[f * 3] + e.v[f * 3], e.pos[f * 3 + 1] + e.v[f * 3 + 1], e.pos[f * 3 + 2] + e.v[f * 3 + 2]};
+    R xn[3], J[3][3];
+    impose_x(e.d.boundary, xin, xn, J);
+    for (int d = 0; d < 3; d++) {
+        R g = 0;
+        for (int i = 0; i < 3; i++) g += J[i][d] * e.gpos[(f + 1) * 3 + i];
+        e.gpos[f * 3 + d] += g;
+        e.gv[f * 3 + d] += g;
+    }
+}
+
+/* p2g.grad + svd_grad + compute_F_tmp.grad (mpm:544-546) */
+void p2g_grad(FeEngine* h, int f) {
+    const int N = h->N, n = h->n;
+    const R dt = h->cfg.dt;
+#pragma omp parallel for num_threads(h->threads) schedule(static)
+    for (int p = 0; p < N; p++) {
+        if (!h->Us(f)[p]) continue;
+        Stencil s; make_stencil(&h->X(f)[p * 3], h->inv_dx, s);
+        if (!stencil_in_grid(s, n)) continue;
+        P2GLocal l; p2g_local(h, f, p, l);
+        const R m = h->mass[p];
+        const R* vp = &h->Vv(f)[p * 3];
+        R Gv[3] = {0, 0, 0}; M3 GA = m_zero(); R gfx[3] = {0, 0, 0};
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++) {
+            int o[3] = {i, j, k};
+            R dpos[3] = {(i - s.fx[0]) * h->dx, (j - s.fx[1]) * h->dx, (k - s.fx[2]) * h->dx};
+            size_t c = cell_index(n, s.base[0] + i, s.base[1] + j, s.base[2] + k);
+            const R* gvin = &h->gg_vin[c * 3];
+            R gms = h->gg_mass[c];
+            R weight = s.w[i][0] * s.w[j][1] * s.w[k][2];
+            R mom[3];
+            for (int a = 0; a < 3; a++) mom[a] = m * vp[a] + (l.affine.m[a][0] * dpos[0] + l.affine.m[a][1] * dpos[1] + l.affine.m[a][2] * dpos[2]);
+            R sdot = gvin[0] * mom[0] + gvin[1] * mom[1] + gvin[2] * mom[2] + gms * m;
+            for (int a = 0; a < 3; a++) {
+                Gv[a] += weight * gvin[a];
+                for (int b = 0; b < 3; b++) GA.m[a][b] += weight * gvin[a] * dpos[b];
+            }
+            for (int d = 0; d < 3; d++) {
+                R dW = 1;
+                for (int e = 0; e < 3; e++) dW *= (e == d) ? s.dw[o[e]][e] : s.w[o[e]][e];
+                gfx[d] += dW * sdot;
+            }
+            for (int b = 0; b < 3; b++) gfx[b] -= h->dx * weight * (gvin[0] * l.affine.m[0][b] + gvin[1] * l.affine.m[1][b] + gvin[2] * l.affine.m[2][b]);
+        }
+        for (int d = 0; d < 3; d++) {
+            h->GX(f)[p * 3 + d] += h->inv_dx * gfx[d];
+            h->GV(f)[p * 3 + d] += m * Gv[d];
+        }
+        m_accum(&h->GC(f)[p * 9], m_scale(GA, m));                     /* affine = stress + m C */
+        /* stress adjoint */
+        M3 gs = m_scale(GA, l.scale);                                    /* adjoint of stress_raw */
+        M3 P = m_sub(l.Ft, l.r);
+        R mu2 = 2 * h->mu[p];
+        M3 gFt = m_scale(m_add(m_mul(gs, l.Ft), m_mul(m_T(gs), P)), mu2);
+        M3 gr = m_scale(m_mul(gs, l.Ft), -mu2);
+        M3 gU = m_mul(gr, l.V);
+        M3 gV = m_mul(m_T(gr), l.U);
+        R gJ = h->lam[p] * (2 * l.J - 1) * m_trace(gs);
+        M3 gS = m_zero();
+        /* F_new adjoint (mpm:355-378) */
+        M3 Fg = m_load(&h->GF(f + 1)[p * 9]);
+        int cls = h->mat_cls[p];
+        if (cls == FE_MAT_LIQUID) {
+            gJ += ((R)(1.0 / 3.0)) * std::pow(l.J, (R)(1.0 / 3.0 - 1.0)) * m_trace(Fg);
+        } else if (cls == FE_MAT_ELASTIC || cls == FE_MAT_RIGID) {
+            gFt = m_add(gFt, Fg);
+        } else if (cls == FE_MAT_PLASTO_ELASTIC || cls == FE_MAT_PLASTO_ELASTIC_DEMO) {
+            const R lo = (R)(1 - 2e-3), hi = (R)(1 + 3e-3);
+            M3 Sn = m_zero();
+            for (int d = 0; d < 3; d++) Sn.m[d][d] = std::min(std::max(l.S.m[d][d], lo), hi);
+            M3 UtFgV = m_mul(m_mul(m_T(l.U), Fg), l.V);
+            for (int d = 0; d < 3; d++) {
+                R sd = l.S.m[d][d];
+                R mx = std::max(sd, lo);
+                bool pass = (sd > lo) && (mx < hi);     /* Taichi max/min adjoint tie rules */
+                if (pass) gS.m[d][d] += UtFgV.m[d][d];
+            }
+            gU = m_add(gU, m_mul(m_mul(Fg, l.V), Sn));
+            gV = m_add(gV, m_mul(m_mul(m_T(Fg), l.U), Sn));
+        }
+        /* J = det(S) (mpm:339) */
+        gS.m[0][0] += gJ * l.S.m[1][1] * l.S.m[2][2];
+        gS.m[1][1] += gJ * l.S.m[0][0] * l.S.m[2][2];
+        gS.m[2][2] += gJ * l.S.m[0][0] * l.S.m[1][1];
+        /* svd_grad (mpm:266-270) */
+        gFt = m_add(gFt, backward_svd(gU, gS, gV, l.U, l.S, l.V));
+        /* compute_F_tmp.grad: F_tmp = (I + dt C) F (mpm:258) */
+        M3 Cm = m_load(&h->Cc(f)[p * 9]), Fm = m_load(&h->Ff(f)[p * 9]);
+        m_accum(&h->GC(f)[p * 9], m_scale(m_mul(gFt, m_T(Fm)), dt));
+        m_accum(&h->GF(f)[p * 9], m_mul(m_T(m_add(m_ident(), m_scale(Cm, dt))), gFt));
+    }
+}
+
+/* AgentInjector.act_kernel.grad (agent_injector.py:27-28): x[f+1,pid] = offset + pos[f] + R(q) inject_p,
+ * v[f+1,pid] = R(q) inject_v.  Position gradient only (see effector_move_grad). */
+void injector_act_grad(FeEngine* h, Effector& e, int f) {
+    const int flux = e.d.flux;
+    for (int i = 0; i < flux; i++) {
+        int idx = e.act_id[f] + i;
+        if (idx >= (int)e.act_range.size()) break;
+        int pid = e.act_range[idx];
+        for (int d = 0; d < 3; d++) e.gpos[f * 3 + d] += h->GX(f + 1)[pid * 3 + d];
+    }
+}
+
+/* process_unused_particles.grad (mpm:551) */
+void process_unused_particles_grad(FeEngine* h, int f) {
+    const int N = h->N;
+#pragma omp parallel for num_threads(h->threads) schedule(static)
+    for (int p = 0; p < N; p++) {
+        if (h->Us(f)[p] == 0) {
+            for (int d = 0; d < 3; d++) { h->GV(f)[p * 3 + d] += h->GV(f + 1)[p * 3 + d]; h->GX(f)[p * 3 + d] += h->GX(f + 1)[p * 3 + d]; }
+            for (int d = 0; d < 9; d++) { h->GC(f)[p * 9 + d] += h->GC(f + 1)[p * 9 + d]; h->GF(f)[p * 9 + d] += h->GF(f + 1)[p * 9 + d]; }
+        }
+    }
+}
+
+int substep(FeEngine* h, int f, int f_global, int act) {
+    /* mpm:515-533 */
+    reset_grid_and_grad(h);
+    advect_used(h, f);
+    process_unused_particles(h, f);
+    if (act) for (auto& e : h->effs) if (e.d.type == FE_EFF_INJECTOR) { if (injector_act(h, e, f, f_global)) return 1; }
+    compute_F_tmp_svd(h, f);
+    if (p2g(h, f, true)) return 1;
+    if (act) for (auto& e : h->effs) effector_move(e, f);
+    grid_op(h);
+    if (g2p(h, f)) return 1;
+    advect(h, f);
+    return 0;
+}
+
+int substep_grad(FeEngine* h, int f, int f_global, int act) {
+    /* The reference keeps grid[f] and F_tmp/U/S/V[f] of every frame (mpm:106,117); this
+     * restatement keeps one grid and recomputes those forward values of frame f first. */
+    (void)f_global;
+    reset_grid_and_grad(h);
+    compute_F_tmp_svd(h, f);
+    if (p2g(h, f, false)) return 1;
+    grid_op(h);
+    /* mpm:535-552 */
+    advect_grad(h, f);
+    g2p_grad(h, f);
+    grid_op_grad(h);
+    if (act) for (int i = (int)h->effs.size() - 1; i >= 0; i--) effector_move_grad(h->effs[i], f);
+    p2g_grad(h, f);
+    if (act) for (auto& e : h->effs) if (e.d.type == FE_EFF_INJECTOR) injector_act_grad(h, e, f);
+    process_unused_particles_grad(h, f);
+    return 0;
+}
+
+double now_ms(FeEngine* h) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h->t0).count();
+}
+
+} // namespace
+
+/* ====================================================================== C ABI */
+extern "C" {
+
+const char* fe_backend(void) { return sizeof(R) == 4 ? "oracle-f32" : "oracle-f64"; }
+int fe_real_size(void) { return (int)sizeof(R); }
+
+FeEngine* fe_create(const FeConfig* cfg) {
+    if (!cfg || cfg->struct_size != (int)sizeof(FeConfig)) { g_create_err = "FeConfig size mismatch"; return nullptr; }
+    if (cfg->n_grid < 4 || cfg->n_particles < 0 || cfg->max_substeps_local < 1 || cfg->n_substeps < 1) { g_create_err = "invalid FeConfig"; return nullptr; }
+    FeEngine* h = new FeEngine();
+    h->cfg = *cfg; h->N = cfg->n_particles; h->L = cfg->max_substeps_local; h->n = cfg->n_grid;
+    h->dx = (R)1 / cfg->n_grid; h->inv_dx = (R)cfg->n_grid;
+    size_t N = h->N, Fm = h->L + 1, n3 = (size_t)h->n * h->n * h->n;
+    try {
+        h->x.assign(Fm * N * 3, 0); h->v.assign(Fm * N * 3, 0); h->C.assign(Fm * N * 9, 0); h->F.assign(Fm * N * 9, 0);
+        h->gx.assign(Fm * N * 3, 0); h->gv.assign(Fm * N * 3, 0); h->gC.assign(Fm * N * 9, 0); h->gF.assign(Fm * N * 9, 0);
+        h->used.assign(Fm * N, 0);
+        for (auto* t : {&h->Ftmp, &h->U, &h->V, &h->S, &h->gFtmp, &h->gU, &h->gV, &h->gS}) t->assign(N * 9, 0);
+        h->mu.assign(N, 0); h->lam.assign(N, 0); h->mass.assign(N, 0);
+        h->mat.assign(N, 0); h->mat_cls.assign(N, 0); h->body_id.assign(N, 0);
+        h->g_vin.assign(n3 * 3, 0); h->g_mass.assign(n3, 0); h->g_vout.assign(n3 * 3, 0);
+        h->gg_vin.assign(n3 * 3, 0); h->gg_mass.assign(n3, 0); h->gg_vout.assign(n3 * 3, 0);
+    } catch (...) { g_create_err = "out of memory"; delete h; return nullptr; }
+    h->t0 = std::chrono::steady_clock::now();
+    return h;
+}
+
+void fe_destroy(FeEngine* h) { delete h; }
+const char* fe_last_error(FeEngine* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+int fe_sync(FeEngine*) { return 0; }
+
+int fe_set_option(FeEngine* h, const char* name, double value) {
+    if (!std::strcmp(name, "threads")) {
+        int t = (int)value;
+#ifdef _OPENMP
+        if (t <= 0) t = omp_get_max_threads();
+#else
+        t = 1;
+#endif
+        h->threads = t; return 0;
+    }
+    /* HIP-engine tunables are accepted and ignored so the same host code drives both */
+    return 0;
+}
+
+int fe_init_particles(FeEngine* h, const fe_real* x, const int* used, const int* mat, const int* mat_cls,
+                      const fe_real* mu, const fe_real* lam, const fe_real* rho, const int* body_id) {
+    const int N = h->N;
+    for (int i = 0; i < N; i++) {
+        if (mat_cls[i] == FE_MAT_RIGID) FE_FAIL(h, "MAT_RIGID shape-matching bodies are not supported yet (SURVEY 8f-4)");
+        for (int d = 0; d < 3; d++) { h->X(0)[i * 3 + d] = x[i * 3 + d]; h->Vv(0)[i * 3 + d] = 0; }   /* mpm:163-165 */
+        for (int d = 0; d < 9; d++) { h->Ff(0)[i * 9 + d] = (d % 4 == 0) ? 1 : 0; h->Cc(0)[i * 9 + d] = 0; }
+        h->Us(0)[i] = used[i];
+        h->mat[i] = mat[i]; h->mat_cls[i] = mat_cls[i]; h->mu[i] = mu[i]; h->lam[i] = lam[i];
+        h->mass[i] = h->cfg.p_vol * rho[i];                                                            /* mpm:174 */
+        h->body_id[i] = body_id ? body_id[i] : 0;
+    }
+    h->initialized = true;
+    return 0;
+}
+
+int fe_substep(FeEngine* h, int f, int f_global, int act) {
+    if (f < 0 || f >= h->L) FE_FAIL(h, "substep frame out of range");
+    double t = h->prof_on ? now_ms(h) : 0;
+    int rc = substep(h, f, f_global, act);
+    if (h->prof_on) { h->prof_ms[0] += now_ms(h) - t; h->prof_n[0]++; }
+    return rc;
+}
+int fe_substep_grad(FeEngine* h, int f, int f_global, int act) {
+    if (f < 0 || f >= h->L) FE_FAIL(h, "substep frame out of range");
+    double t = h->prof_on ? now_ms(h) : 0;
+    int rc = substep_grad(h, f, f_global, act);
+    if (h->prof_on) { h->prof_ms[1] += now_ms(h) - t; h->prof_n[1]++; }
+    return rc;
+}
+int fe_step(FeEngine* h, int f0, int f_global0, int n, int act) {
+    for (int i = 0; i < n; i++) if (fe_substep(h, f0 + i, f_global0 + i, act)) return 1;
+    return 0;
+}
+int fe_step_grad(FeEngine* h, int f0, int f_global0, int n, int act) {
+    for (int i = n - 1; i >= 0; i--) if (fe_substep_grad(h, f0 + i, f_global0 + i, act)) return 1;
+    return 0;
+}
+
+int fe_get_frame(FeEngine* h, int f, fe_real* x, fe_real* v, fe_real* C, fe_real* F, int* used) {
+    CHECK_FRAME(h, f);
+    size_t N = h->N;
+    if (x) std::memcpy(x, h->X(f), sizeof(R) * N * 3);
+    if (v) std::memcpy(v, h->Vv(f), sizeof(R) * N * 3);
+    if (C) std::memcpy(C, h->Cc(f), sizeof(R) * N * 9);
+    if (F) std::memcpy(F, h->Ff(f), sizeof(R) * N * 9);
+    if (used) std::memcpy(used, h->Us(f), sizeof(int) * N);
+    return 0;
+}
+int fe_set_frame(FeEngine* h, int f, const fe_real* x, const fe_real* v, const fe_real* C, const fe_real* F, const int* used) {
+    CHECK_FRAME(h, f);
+    size_t N = h->N;
+    if (x) std::memcpy(h->X(f), x, sizeof(R) * N * 3);
+    if (v) std::memcpy(h->Vv(f), v, sizeof(R) * N * 3);
+    if (C) std::memcpy(h->Cc(f), C, sizeof(R) * N * 9);
+    if (F) std::memcpy(h->Ff(f), F, sizeof(R) * N * 9);
+    if (used) std::memcpy(h->Us(f), used, sizeof(int) * N);
+    return 0;
+}
+int fe_copy_frame(FeEngine* h, int src, int dst) {
+    CHECK_FRAME(h, src); CHECK_FRAME(h, dst);
+    return fe_set_frame(h, dst, h->X(src), h->Vv(src), h->Cc(src), h->Ff(src), h->Us(src));
+}
+int fe_copy_grad(FeEngine* h, int src, int dst) {
+    CHECK_FRAME(h, src); CHECK_FRAME(h, dst);
+    size_t N = h->N;
+    std::memcpy(h->GX(dst), h->GX(src), sizeof(R) * N * 3); std::memcpy(h->GV(dst), h->GV(src), sizeof(R) * N * 3);
+    std::memcpy(h->GC(dst), h->GC(src), sizeof(R) * N * 9); std::memcpy(h->GF(dst), h->GF(src), sizeof(R) * N * 9);
+    std::memcpy(h->Us(dst), h->Us(src), sizeof(int) * N);    /* mpm:604 copies `used` too */
+    return 0;
+}
+int fe_reset_grad(FeEngine* h) {
+    for (auto* t : {&h->gx, &h->gv, &h->gC, &h->gF, &h->gg_vin, &h->gg_mass, &h->gg_vout}) std::fill(t->begin(), t->end(), (R)0);
+    for (auto& e : h->effs) for (auto* t : {&e.gpos, &e.gquat, &e.gv, &e.gw, &e.gabuf, &e.gabuf_p}) std::fill(t->begin(), t->end(), (R)0);
+    return 0;
+}
+int fe_reset_grad_till_frame(FeEngine* h, int f) {
+    CHECK_FRAME(h, f);
+    size_t N = h->N;
+    std::fill(h->gx.begin(), h->gx.begin() + (size_t)f * N * 3, (R)0); std::fill(h->gv.begin(), h->gv.begin() + (size_t)f * N * 3, (R)0);
+    std::fill(h->gC.begin(), h->gC.begin() + (size_t)f * N * 9, (R)0); std::fill(h->gF.begin(), h->gF.begin() + (size_t)f * N * 9, (R)0);
+    for (auto& e : h->effs) {
+        std::fill(e.gpos.begin(), e.gpos.begin() + f * 3, (R)0); std::fill(e.gquat.begin(), e.gquat.begin() + f * 4, (R)0);
+        std::fill(e.gv.begin(), e.gv.begin() + f * 3, (R)0); std::fill(e.gw.begin(), e.gw.begin() + f * 3, (R)0);
+    }
+    return 0;
+}
+int fe_get_grad(FeEngine* h, int f, fe_real* gx, fe_real* gv, fe_real* gC, fe_real* gF) {
+    CHECK_FRAME(h, f);
+    size_t N = h->N;
+    if (gx) std::memcpy(gx, h->GX(f), sizeof(R) * N * 3);
+    if (gv) std::memcpy(gv, h->GV(f), sizeof(R) * N * 3);
+    if (gC) std::memcpy(gC, h->GC(f), sizeof(R) * N * 9);
+    if (gF) std::memcpy(gF, h->GF(f), sizeof(R) * N * 9);
+    return 0;
+}
+int fe_add_grad(FeEngine* h, int f, const fe_real* gx, const fe_real* gv, const fe_real* gC, const fe_real* gF) {
+    CHECK_FRAME(h, f);
+    size_t N = h->N;
+    if (gx) for (size_t i = 0; i < N * 3; i++) h->GX(f)[i] += gx[i];
+    if (gv) for (size_t i = 0; i < N * 3; i++) h->GV(f)[i] += gv[i];
+    if (gC) for (size_t i = 0; i < N * 9; i++) h->GC(f)[i] += gC[i];
+    if (gF) for (size_t i = 0; i < N * 9; i++) h->GF(f)[i] += gF[i];
+    return 0;
+}
+int fe_get_mat(FeEngine* h, int* mat) { std::memcpy(mat, h->mat.data(), sizeof(int) * h->N); return 0; }
+
+/* ---- effectors */
+int fe_add_effector(FeEngine* h, const FeEffectorDesc* d, const fe_real* random_vector) {
+    if (!d || d->struct_size != (int)sizeof(FeEffectorDesc)) { h->err = "FeEffectorDesc size mismatch"; return -1; }
+    if (!(d->action_dim == 0 || d->action_dim == 3 || d->action_dim == 6)) { h->err = "action_dim must be 0, 3 or 6"; return -1; }
+    Effector e; e.d = *d;
+    int Fm = h->L + 1;
+    e.pos.assign(Fm * 3, 0); e.quat.assign(Fm * 4, 0); e.v.assign(Fm * 3, 0); e.w.assign(Fm * 3, 0);
+    e.gpos.assign(Fm * 3, 0); e.gquat.assign(Fm * 4, 0); e.gv.assign(Fm * 3, 0); e.gw.assign(Fm * 3, 0);
+    int ad = std::max(d->action_dim, 1);
+    e.abuf.assign((size_t)h->cfg.max_action_steps * ad, 0); e.gabuf.assign((size_t)h->cfg.max_action_steps * ad, 0);
+    e.abuf_p.assign(ad, 0); e.gabuf_p.assign(ad, 0);
+    e.act_id.assign(Fm, 0);
+    if (d->type == FE_EFF_INJECTOR) {
+        if (!random_vector || d->random_length <= 0 || d->flux <= 0) { h->err = "injector needs random_vector, random_length, flux"; return -1; }
+        e.random_vector.assign(random_vector, random_vector + (size_t)d->random_length * d->flux * 3);
+    }
+    h->effs.push_back(e);
+    return (int)h->effs.size() - 1;
+}
+int fe_eff_set_act_range(FeEngine* h, int e, const int* act_range, int n) {
+    CHECK_EFF(h, e);
+    h->effs[e].act_range.assign(act_range, act_range + n);
+    if (n > 0) h->effs[e].act_id[0] = act_range[0];        /* injector.py:68 (sic: the first pool id, not 0) */
+    return 0;
+}
+int fe_eff_get_state(FeEngine* h, int e, int f, fe_real* s) {
+    CHECK_EFF(h, e); CHECK_FRAME(h, f);
+    Effector& E = h->effs[e];
+    for (int j = 0; j < 3; j++) s[j] = E.pos[f * 3 + j];
+    for (int j = 0; j < 4; j++) s[3 + j] = E.quat[f * 4 + j];
+    s[7] = (R)E.act_id[f];
+    return 0;
+}
+int fe_eff_set_state(FeEngine* h, int e, int f, const fe_real* s) {
+    CHECK_EFF(h, e); CHECK_FRAME(h, f);
+    Effector& E = h->effs[e];
+    for (int j = 0; j < 3; j++) E.pos[f * 3 + j] = s[j];
+    for (int j = 0; j < 4; j++) E.quat[f * 4 + j] = s[3 + j];
+    E.act_id[f] = (int)s[7];
+    return 0;
+}
+int fe_eff_get_vw(FeEngine* h, int e, int f, fe_real* v3, fe_real* w3) {
+    CHECK_EFF(h, e); CHECK_FRAME(h, f);
+    for (int j = 0; j < 3; j++) { v3[j] = h->effs[e].v[f * 3 + j]; w3[j] = h->effs[e].w[f * 3 + j]; }
+    return 0;
+}
+int fe_eff_set_vw(FeEngine* h, int e, int f, const fe_real* v3, const fe_real* w3) {
+    CHECK_EFF(h, e); CHECK_FRAME(h, f);
+    for (int j = 0; j < 3; j++) { h->effs[e].v[f * 3 + j] = v3[j]; h->effs[e].w[f * 3 + j] = w3[j]; }
+    return 0;
+}
+int fe_eff_set_action(FeEngine* h, int e, int s, int s_global, int n_substeps, const fe_real* action) {
+    CHECK_EFF(h, e);
+    Effector& E = h->effs[e];
+    const int ad = E.d.action_dim;
+    if (ad == 0) return 0;
+    if (s_global < 0 || s_global >= h->cfg.max_action_steps) FE_FAIL(h, "s_global out of range");    /* effector.py:263 */
+    if (s < 0 || (s + 1) * n_substeps > h->L + 1) FE_FAIL(h, "s out of range");                         /* effector.py:264 */
+    for (int j = 0; j < ad; j++) E.abuf[(size_t)s_global * ad + j] = action[j];                        /* effector.py:218-221 */
+    for (int j = s * n_substeps; j < (s + 1) * n_substeps; j++) {                                      /* effector.py:252-260 */
+        R nf = (R)n_substeps;
+        for (int k = 0; k < 3; k++) E.v[j * 3 + k] = E.abuf[(size_t)s_global * ad + k] * E.d.action_scale_v[k] / nf;
+        if (ad > 3) for (int k = 0; k < 3; k++) E.w[j * 3 + k] = E.abuf[(size_t)s_global * ad + k + 3] * E.d.action_scale_v[k + 3] / nf;
+    }
+    return 0;
+}
+int fe_eff_set_action_grad(FeEngine* h, int e, int s, int s_global, int n_substeps) {
+    CHECK_EFF(h, e);
+    Effector& E = h->effs[e];
+    const int ad = E.d.action_dim;
+    if (ad == 0) return 0;
+    if (s_global < 0 || s_global >= h->cfg.max_action_steps) FE_FAIL(h, "s_global out of range");
+    for (int j = s * n_substeps; j < (s + 1) * n_substeps; j++) {
+        R nf = (R)n_substeps;
+        for (int k = 0; k < 3; k++) E.gabuf[(size_t)s_global * ad + k] += E.gv[j * 3 + k] * E.d.action_scale_v[k] / nf;
+        if (ad > 3) for (int k = 0; k < 3; k++) E.gabuf[(size_t)s_global * ad + k + 3] += E.gw[j * 3 + k] * E.d.action_scale_v[k + 3] / nf;
+    }
+    return 0;
+}
+int fe_eff_apply_action_p(FeEngine* h, int e, const fe_real* action_p) {
+    CHECK_EFF(h, e);
+    Effector& E = h->effs[e];
+    if (E.d.action_dim == 0) return 0;
+    for (int j = 0; j < E.d.action_dim; j++) E.abuf_p[j] = action_p[j];
+    R xin[3], xn[3], J[3][3];
+    for (int d = 0; d < 3; d++) xin[d] = E.abuf_p[d] * E.d.action_scale_p[d];                         /* effector.py:223-225 */
+    impose_x(E.d.boundary, xin, xn, J);
+    for (int d = 0; d < 3; d++) E.pos[d] = xn[d];
+    return 0;
+}
+int fe_eff_apply_action_p_grad(FeEngine* h, int e) {
+    CHECK_EFF(h, e);
+    Effector& E = h->effs[e];
+    if (E.d.action_dim == 0) return 0;
+    R xin[3], xn[3], J[3][3];
+    for (int d = 0; d < 3; d++) xin[d] = E.abuf_p[d] * E.d.action_scale_p[d];
+    impose_x(E.d.boundary, xin, xn, J);
+    for (int d = 0; d < 3; d++) {
+        R g = 0; for (int i = 0; i < 3; i++) g += J[i][d] * E.gpos[i];
+        E.gabuf_p[d] += g * E.d.action_scale_p[d];
+    }
+    return 0;
+}
+int fe_eff_get_action_grad(FeEngine* h, int e, int s, int n, fe_real* grad) {
+    CHECK_EFF(h, e);
+    Effector& E = h->effs[e];
+    const int ad = E.d.action_dim;
+    if (s < 0 || s + n > h->cfg.max_action_steps) FE_FAIL(h, "action grad range out of bounds");
+    for (int i = 0; i < n; i++) for (int j = 0; j < ad; j++) grad[i * ad + j] = E.gabuf[(size_t)(s + i) * ad + j];
+    for (int j = 0; j < ad; j++) grad[n * ad + j] = E.gabuf_p[j];
+    return 0;
+}
+int fe_agent_copy_frame(FeEngine* h, int src, int dst) {
+    CHECK_FRAME(h, src); CHECK_FRAME(h, dst);
+    for (auto& E : h->effs) {
+        for (int j = 0; j < 3; j++) { E.pos[dst * 3 + j] = E.pos[src * 3 + j]; E.v[dst * 3 + j] = E.v[src * 3 + j]; E.w[dst * 3 + j] = E.w[src * 3 + j]; }
+        for (int j = 0; j < 4; j++) E.quat[dst * 4 + j] = E.quat[src * 4 + j];
+        if (E.d.type == FE_EFF_INJECTOR) E.act_id[dst] = E.act_id[src];       /* injector.py:174-179 */
+    }
+    return 0;
+}
+int fe_agent_copy_grad(FeEngine* h, int src, int dst) {
+    CHECK_FRAME(h, src); CHECK_FRAME(h, dst);
+    for (auto& E : h->effs) {
+        for (int j = 0; j < 3; j++) { E.gpos[dst * 3 + j] = E.gpos[src * 3 + j]; E.gv[dst * 3 + j] = E.gv[src * 3 + j]; E.gw[dst * 3 + j] = E.gw[src * 3 + j]; }
+        for (int j = 0; j < 4; j++) E.gquat[dst * 4 + j] = E.gquat[src * 4 + j];
+    }
+    return 0;
+}
+
+/* ---- loss */
+int fe_loss_alloc(FeEngine* h, int max_loss_steps) {
+    h->loss_steps = max_loss_steps;
+    h->tgt.assign((size_t)max_loss_steps * h->N * 3, 0);
+    h->chamfer.assign(max_loss_steps, 0); h->step_loss.assign(max_loss_steps, 0);
+    return 0;
+}
+int fe_loss_set_target(FeEngine* h, int s, const fe_real* x) {
+    if (s < 0 || s >= h->loss_steps) FE_FAIL(h, "loss step out of range");
+    std::memcpy(&h->tgt[(size_t)s * h->N * 3], x, sizeof(R) * h->N * 3);
+    return 0;
+}
+int fe_loss_clear(FeEngine* h) {
+    std::fill(h->chamfer.begin(), h->chamfer.end(), (R)0); std::fill(h->step_loss.begin(), h->step_loss.end(), (R)0);
+    return 0;
+}
+int fe_loss_step(FeEngine* h, int s, int f, int matching_mat, fe_real weight) {
+    if (s < 0 || s >= h->loss_steps) FE_FAIL(h, "loss step out of range");
+    CHECK_FRAME(h, f);
+    const R* t = &h->tgt[(size_t)s * h->N * 3];
+    R acc = 0;
+    for (int p = 0; p < h->N; p++) {
+        if (h->Us(f)[p] && h->mat[p] == matching_mat) {                                   /* shapematching_loss.py:83 */
+            R d0 = h->X(f)[p * 3] - t[p * 3], d1 = h->X(f)[p * 3 + 1] - t[p * 3 + 1], d2 = h->X(f)[p * 3 + 2] - t[p * 3 + 2];
+            acc += d0 * d0 + d1 * d1 + d2 * d2;
+        }
+    }
+    h->chamfer[s] += acc;
+    h->step_loss[s] += h->chamfer[s] * weight;                                            /* shapematching_loss.py:88 */
+    return 0;
+}
+int fe_loss_step_grad(FeEngine* h, int s, int f, int matching_mat, fe_real weight, fe_real step_loss_grad) {
+    if (s < 0 || s >= h->loss_steps) FE_FAIL(h, "loss step out of range");
+    CHECK_FRAME(h, f);
+    const R* t = &h->tgt[(size_t)s * h->N * 3];
+    R g = weight * step_loss_grad;
+    for (int p = 0; p < h->N; p++) {
+        if (h->Us(f)[p] && h->mat[p] == matching_mat)
+            for (int d = 0; d < 3; d++) h->GX(f)[p * 3 + d] += 2 * (h->X(f)[p * 3 + d] - t[p * 3 + d]) * g;
+    }
+    return 0;
+}
+int fe_loss_get(FeEngine* h, fe_real* step_loss, int n) {
+    if (n > h->loss_steps) FE_FAIL(h, "loss_get: n too large");
+    for (int i = 0; i < n; i++) step_loss[i] = h->step_loss[i];
+    return 0;
+}
+
+/* ---- measurement */
+int fe_get_stats(FeEngine* h, int f, FeStats* out) {
+    CHECK_FRAME(h, f);
+    const int n = h->n, nb = (n + 3) / 4;
+    std::vector<unsigned char> touched((size_t)n * n * n, 0), blk((size_t)nb * nb * nb, 0);
+    long long used = 0;
+    for (int p = 0; p < h->N; p++) {
+        if (!h->Us(f)[p]) continue;
+        used++;
+        Stencil s; make_stencil(&h->X(f)[p * 3], h->inv_dx, s);
+        if (!stencil_in_grid(s, n)) continue;
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++) {
+            int a = s.base[0] + i, b = s.base[1] + j, c = s.base[2] + k;
+            touched[cell_index(n, a, b, c)] = 1;
+            blk[((size_t)(a >> 2) * nb + (b >> 2)) * nb + (c >> 2)] = 1;
+        }
+    }
+    long long nc = 0, nbk = 0;
+    for (unsigned char t : touched) nc += t;
+    for (unsigned char t : blk) nbk += t;
+    out->n_used = used; out->n_cells_touched = nc; out->n_blocks_active = nbk; out->n_slow_path = 0;
+    out->bytes_state = (long long)((h->x.size() + h->v.size() + h->C.size() + h->F.size()) * 2 * sizeof(R) + h->used.size() * sizeof(int));
+    return 0;
+}
+static double g_timer_start_ms = 0;
+int fe_timer_start(FeEngine* h) { g_timer_start_ms = now_ms(h); return 0; }
+double fe_timer_stop_ms(FeEngine* h) { return now_ms(h) - g_timer_start_ms; }
+int fe_profile_enable(FeEngine* h, int on) {
+    h->prof_on = on != 0;
+    if (on) { h->prof_ms[0] = h->prof_ms[1] = 0; h->prof_n[0] = h->prof_n[1] = 0; }
+    return 0;
+}
+int fe_profile_read(FeEngine* h, char* buf, int buf_len, double* ms_total, long long* launches, int cap) {
+    std::snprintf(buf, buf_len, "substep\nsubstep_grad");
+    for (int i = 0; i < 2 && i < cap; i++) { ms_total[i] = h->prof_ms[i]; launches[i] = h->prof_n[i]; }
+    return 2;
+}
+
+} // extern "C"
