@@ -1,0 +1,1258 @@
+// fe_engine.hip — MI355X (gfx950) FluidEngine MLS-MPM core: device state, HIP kernels, C ABI.
+//
+// Replaces the Taichi kernels of fluidlab/fluidengine/simulators/mpm_simulator.py (cited as
+// mpm:NNN) behind include/fluidengine.h.  Written for CDNA4 only: wave64, float4-plane SoA
+// particle frames (16 B/lane coalesced loads), a 4x4x4-blocked grid with an active-block list
+// (no dense n^3 sweeps), hardware fp32 atomics.  See DESIGN.md for the data layout and the
+// per-kernel roofline accounting.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/fluidengine.h"
+#include "fe_math.h"
+
+static_assert(sizeof(fe_real) == 4, "the HIP engine is fp32 (macros.py:207-211)");
+
+// =========================================================================================
+// device-side layout
+// =========================================================================================
+// One particle frame = 24 floats + `used`, stored as float4 / float planes of Np (= N padded to
+// 64) entries, grouped by the kernel that produces them:
+//   A0 = (x0 x1 x2 v0)  A1 = (v1 v2 C00 C01)  A2 = (C02 C10 C11 C12)  a3 a4 a5 = C20 C21 C22   <- g2p
+//   B0 = (F00 F01 F02 F10)  B1 = (F11 F12 F20 F21)  b2 = F22                                    <- p2g
+// The adjoint frames use the same layout.
+#define FR_WORDS 25          // 24 state words + used
+#define GR_WORDS 24
+
+struct FrameV {
+    float4 *A0, *A1, *A2; float *a3, *a4, *a5; float4 *B0, *B1; float *b2; int* used;
+};
+__host__ __device__ inline FrameV frame_view(float* base, size_t Np) {
+    FrameV v;
+    v.A0 = (float4*)base; v.A1 = (float4*)(base + 4 * Np); v.A2 = (float4*)(base + 8 * Np);
+    v.a3 = base + 12 * Np; v.a4 = base + 13 * Np; v.a5 = base + 14 * Np;
+    v.B0 = (float4*)(base + 15 * Np); v.B1 = (float4*)(base + 19 * Np); v.b2 = base + 23 * Np;
+    v.used = (int*)(base + 24 * Np);
+    return v;
+}
+
+struct PState { float x[3], v[3]; m3 C, F; };
+
+__device__ __forceinline__ void load_xvC(const FrameV& fr, int s, PState& p) {
+    float4 a0 = fr.A0[s], a1 = fr.A1[s], a2 = fr.A2[s];
+    p.x[0] = a0.x; p.x[1] = a0.y; p.x[2] = a0.z; p.v[0] = a0.w; p.v[1] = a1.x; p.v[2] = a1.y;
+    p.C.a[0][0] = a1.z; p.C.a[0][1] = a1.w; p.C.a[0][2] = a2.x; p.C.a[1][0] = a2.y; p.C.a[1][1] = a2.z; p.C.a[1][2] = a2.w;
+    p.C.a[2][0] = fr.a3[s]; p.C.a[2][1] = fr.a4[s]; p.C.a[2][2] = fr.a5[s];
+}
+__device__ __forceinline__ void load_F(const FrameV& fr, int s, m3& F) {
+    float4 b0 = fr.B0[s], b1 = fr.B1[s];
+    F.a[0][0] = b0.x; F.a[0][1] = b0.y; F.a[0][2] = b0.z; F.a[1][0] = b0.w;
+    F.a[1][1] = b1.x; F.a[1][2] = b1.y; F.a[2][0] = b1.z; F.a[2][1] = b1.w; F.a[2][2] = fr.b2[s];
+}
+__device__ __forceinline__ void store_xvC(const FrameV& fr, int s, const float x[3], const float v[3], const m3& C) {
+    fr.A0[s] = make_float4(x[0], x[1], x[2], v[0]);
+    fr.A1[s] = make_float4(v[1], v[2], C.a[0][0], C.a[0][1]);
+    fr.A2[s] = make_float4(C.a[0][2], C.a[1][0], C.a[1][1], C.a[1][2]);
+    fr.a3[s] = C.a[2][0]; fr.a4[s] = C.a[2][1]; fr.a5[s] = C.a[2][2];
+}
+__device__ __forceinline__ void store_F(const FrameV& fr, int s, const m3& F) {
+    fr.B0[s] = make_float4(F.a[0][0], F.a[0][1], F.a[0][2], F.a[1][0]);
+    fr.B1[s] = make_float4(F.a[1][1], F.a[1][2], F.a[2][0], F.a[2][1]);
+    fr.b2[s] = F.a[2][2];
+}
+
+// grid: float4 per node, nodes grouped in 4x4x4 blocks of 64 contiguous float4 (1 KiB)
+__device__ __forceinline__ int cell_addr(int i, int j, int k, int nb) {
+    return (((((i >> 2) * nb) + (j >> 2)) * nb + (k >> 2)) << 6) | ((i & 3) << 4) | ((j & 3) << 2) | (k & 3);
+}
+
+struct SimP {
+    int N, Np, n, nb;
+    float dx, inv_dx, dt, stress_scale;     // stress_scale = -dt * p_vol * 4 * inv_dx^2 (mpm:343)
+    float g[3];
+    BoundaryP bnd;
+};
+
+#define FE_MAX_EFF 4
+struct EffP {
+    int type, action_dim;
+    float scale_v[6], scale_p[6];
+    BoundaryP bnd;
+    int flux; float radius; float inject_v[3], inject_p[3];
+    int locally_random, randomize_inject_v, random_length;
+    // device arrays
+    float *pos, *quat, *v, *w, *gpos, *gquat, *gv, *gw;      // [L+1] x {3,4,3,3}
+    float *abuf, *gabuf, *abuf_p, *gabuf_p;                  // [max_action_steps, adim], [adim]
+    float* random_vector;                                    // [random_length, flux, 3]
+};
+struct AgentP { int n; EffP e[FE_MAX_EFF]; };
+struct InjectP { int on, act_id, row; };                     // per-substep injection parameters (host-known)
+
+struct PInfo { float mu, lam, mass; int cls, mat; };
+__device__ __forceinline__ PInfo load_info(const float4* pinfo, int pid) {
+    float4 t = pinfo[pid];
+    PInfo r; r.mu = t.x; r.lam = t.y; r.mass = t.z;
+    int bits = __float_as_int(t.w); r.cls = bits & 0xffff; r.mat = (bits >> 16) & 0xffff;
+    return r;
+}
+
+__device__ __forceinline__ void mark_block(int b, int* blk_flag, int* blk_list, int* blk_count) {
+    if (blk_flag[b] == 0) {
+        if (atomicExch(&blk_flag[b], 1) == 0) { int i = atomicAdd(blk_count, 1); blk_list[i] = b; }
+    }
+}
+
+// =========================================================================================
+// forward kernels
+// =========================================================================================
+
+// Effector.move_kernel (effector.py:157-161), one thread
+__device__ void effector_move(const EffP& e, int f) {
+    float xin[3] = {e.pos[f * 3] + e.v[f * 3], e.pos[f * 3 + 1] + e.v[f * 3 + 1], e.pos[f * 3 + 2] + e.v[f * 3 + 2]};
+    float xn[3], J[3][3];
+    boundary_x(e.bnd, xin, xn, J);
+    e.pos[(f + 1) * 3] = xn[0]; e.pos[(f + 1) * 3 + 1] = xn[1]; e.pos[(f + 1) * 3 + 2] = xn[2];
+    float w3[3] = {e.w[f * 3], e.w[f * 3 + 1], e.w[f * 3 + 2]};
+    float q[4] = {e.quat[f * 4], e.quat[f * 4 + 1], e.quat[f * 4 + 2], e.quat[f * 4 + 3]};
+    float qw[4], qo[4];
+    quat_from_w(w3, qw);
+    quat_mul(qw, q, qo);
+    e.quat[(f + 1) * 4] = qo[0]; e.quat[(f + 1) * 4 + 1] = qo[1]; e.quat[(f + 1) * 4 + 2] = qo[2]; e.quat[(f + 1) * 4 + 3] = qo[3];
+}
+
+// p2g (mpm:331-378) fused with compute_F_tmp + svd (mpm:254-264), advect_used + process_unused_particles
+// (mpm:304-316), Injector.act (injector.py:80-105) and, on one thread, Effector.move_kernel.
+// WRITE=false is the backward pass' recompute of grid[f]: scatter only.
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k_p2g(SimP S, float* fr_cur, float* fr_next, const int* __restrict__ pid_of_slot,
+                                             const float4* __restrict__ pinfo, const int* __restrict__ pool_idx,
+                                             float4* g_in, int* blk_flag, int* blk_list, int* blk_count,
+                                             AgentP agent, EffP injector, InjectP inj, int act, int f, int* err) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (WRITE && s == 0 && act) {
+#pragma unroll
+        for (int i = 0; i < FE_MAX_EFF; i++) if (i < agent.n) effector_move(agent.e[i], f);   // constant indices: kernarg stays in SGPRs
+    }
+    if (s >= S.N) return;
+    FrameV cur = frame_view(fr_cur, S.Np);
+    FrameV nxt = frame_view(fr_next, S.Np);
+    const int used = cur.used[s];
+    const int pid = pid_of_slot[s];
+    PState p;
+    load_xvC(cur, s, p);
+    load_F(cur, s, p.F);
+    if (!used) {
+        if (WRITE) {
+            int used_next = 0;
+            if (inj.on) {
+                int j = pool_idx[pid] - inj.act_id;
+                if (j >= 0 && j < injector.flux) {        // this pool particle is injected now
+                    const EffP& e = injector;
+                    const float* rv = e.random_vector + ((size_t)inj.row * e.flux + j) * 3;
+                    float q[4] = {e.quat[f * 4], e.quat[f * 4 + 1], e.quat[f * 4 + 2], e.quat[f * 4 + 3]};
+                    float ip[3], iv[3];
+                    quat_rotate(e.inject_p, q, ip);
+                    quat_rotate(e.inject_v, q, iv);
+                    float vnorm = sqrtf(e.inject_v[0] * e.inject_v[0] + e.inject_v[1] * e.inject_v[1] + e.inject_v[2] * e.inject_v[2]);
+#pragma unroll
+                    for (int d = 0; d < 3; d++) {
+                        float offset = (rv[d] * 2.f - 1.f) * e.radius;
+                        p.x[d] = offset + e.pos[f * 3 + d] + ip[d];
+                        p.v[d] = e.randomize_inject_v ? iv[d] + (rv[d] * 2.f - 1.f) * vnorm * 2.0f : iv[d];
+                    }
+                    used_next = 1;
+                }
+            }
+            store_xvC(nxt, s, p.x, p.v, p.C);
+            store_F(nxt, s, p.F);
+            nxt.used[s] = used_next;
+        }
+        return;
+    }
+    PInfo info = load_info(pinfo, pid);
+    Constitutive k;
+    constitutive_eval(p.C, p.F, S.dt, info.mu, info.lam, info.mass, info.cls, S.stress_scale, k);
+    if (WRITE) { store_F(nxt, s, k.Fnew); nxt.used[s] = 1; }
+    Stencil st;
+    stencil_make(p.x, S.inv_dx, st);
+    if (!stencil_inside(st, S.n)) { atomicAdd(err, 1); return; }
+    const float m = info.mass;
+    // momentum at the base node, then per-node increments: mom(o) = m v + A (o - fx) dx
+    float mv[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+        mv[a] = m * p.v[a] - S.dx * (k.affine.a[a][0] * st.fx[0] + k.affine.a[a][1] * st.fx[1] + k.affine.a[a][2] * st.fx[2]);
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int kk = 0; kk < 3; kk++) {
+                float weight = st.w[i][0] * st.w[j][1] * st.w[kk][2];
+                float ox = (float)i * S.dx, oy = (float)j * S.dx, oz = (float)kk * S.dx;
+                float* dst = (float*)&g_in[cell_addr(st.base[0] + i, st.base[1] + j, st.base[2] + kk, S.nb)];
+#pragma unroll
+                for (int a = 0; a < 3; a++) {
+                    float mom = mv[a] + k.affine.a[a][0] * ox + k.affine.a[a][1] * oy + k.affine.a[a][2] * oz;
+                    unsafeAtomicAdd(dst + a, weight * mom);
+                }
+                unsafeAtomicAdd(dst + 3, weight * m);
+            }
+    // mark the (up to 8) 4^3 blocks this stencil touches
+    const int bx0 = st.base[0] >> 2, bx1 = (st.base[0] + 2) >> 2;
+    const int by0 = st.base[1] >> 2, by1 = (st.base[1] + 2) >> 2;
+    const int bz0 = st.base[2] >> 2, bz1 = (st.base[2] + 2) >> 2;
+    for (int bx = bx0; bx <= bx1; bx++)
+        for (int by = by0; by <= by1; by++)
+            for (int bz = bz0; bz <= bz1; bz++) mark_block((bx * S.nb + by) * S.nb + bz, blk_flag, blk_list, blk_count);
+}
+
+// velocity of one node after gravity and the domain boundary (mpm:383-398); k[] = boundary multipliers
+__device__ __forceinline__ void node_velocity(const SimP& S, const float4 gi, int i, int j, int k, float vo[3], float kmul[3]) {
+    float inv = 1.f / gi.w;
+    vo[0] = inv * gi.x + S.dt * S.g[0];
+    vo[1] = inv * gi.y + S.dt * S.g[1];
+    vo[2] = inv * gi.z + S.dt * S.g[2];
+    float xn[3] = {(float)i * S.dx, (float)j * S.dx, (float)k * S.dx};
+    boundary_v(S.bnd, xn, vo, kmul);
+}
+
+// grid_op (mpm:380-398) over the active 4^3 blocks only; one wave per block.
+// KEEP=false (forward): also re-zeroes g_in and the block flag, so no separate reset_grid pass
+// (mpm:219-223) is needed.  KEEP=true (backward recompute): grid_grad does that later.
+template <bool KEEP>
+__global__ __launch_bounds__(256) void k_grid(SimP S, float4* g_in, float4* g_out, const int* __restrict__ blk_list,
+                                              const int* __restrict__ blk_count, int* blk_flag) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cnt = *blk_count;
+    for (int e = blockIdx.x * 4 + wave; e < cnt; e += gridDim.x * 4) {
+        const int b = blk_list[e];
+        const int c = (b << 6) | lane;
+        const float4 gi = g_in[c];
+        float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gi.w > FE_EPS) {
+            const int bi = b / (S.nb * S.nb), bj = (b / S.nb) % S.nb, bk = b % S.nb;
+            float vo[3], kmul[3];
+            node_velocity(S, gi, bi * 4 + (lane >> 4), bj * 4 + ((lane >> 2) & 3), bk * 4 + (lane & 3), vo, kmul);
+            out = make_float4(vo[0], vo[1], vo[2], 0.f);
+        }
+        g_out[c] = out;
+        if (!KEEP) {
+            g_in[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (lane == 0) blk_flag[b] = 0;
+        }
+    }
+}
+
+// g2p (mpm:400-426) fused with advect_kernel (mpm:497-505)
+__global__ __launch_bounds__(256) void k_g2p(SimP S, float* fr_cur, float* fr_next, const float4* __restrict__ g_out,
+                                             int* blk_count) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s == 0) *blk_count = 0;               // grid_op was the last reader of the active list
+    if (s >= S.N) return;
+    FrameV cur = frame_view(fr_cur, S.Np);
+    if (!cur.used[s]) return;
+    FrameV nxt = frame_view(fr_next, S.Np);
+    float4 a0 = cur.A0[s];
+    float x[3] = {a0.x, a0.y, a0.z};
+    Stencil st;
+    stencil_make(x, S.inv_dx, st);
+    if (!stencil_inside(st, S.n)) return;     // already counted in err by p2g
+    float nv[3] = {0.f, 0.f, 0.f};
+    m3 nC = m3_zero();
+    const float c4 = 4.f * S.inv_dx;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int kk = 0; kk < 3; kk++) {
+                float weight = st.w[i][0] * st.w[j][1] * st.w[kk][2];
+                float4 gv = g_out[cell_addr(st.base[0] + i, st.base[1] + j, st.base[2] + kk, S.nb)];
+                float dpos[3] = {(float)i - st.fx[0], (float)j - st.fx[1], (float)kk - st.fx[2]};
+                float gw[3] = {weight * gv.x, weight * gv.y, weight * gv.z};
+#pragma unroll
+                for (int a = 0; a < 3; a++) {
+                    nv[a] += gw[a];
+#pragma unroll
+                    for (int b = 0; b < 3; b++) nC.a[a][b] += c4 * gw[a] * dpos[b];
+                }
+            }
+    float xn[3] = {x[0] + S.dt * nv[0], x[1] + S.dt * nv[1], x[2] + S.dt * nv[2]};
+    store_xvC(nxt, s, xn, nv, nC);
+}
+
+// =========================================================================================
+// adjoint kernels (hand-derived; closed forms in SURVEY.md Appendix A, validated by the oracle's
+// finite-difference tests).  The adjoint frames form a ring of two: Gn = grad[f+1], Gc = grad[f];
+// every substep_grad overwrites Gc completely.
+// =========================================================================================
+
+// advect_kernel.grad + g2p.grad (mpm:443, 538): scatters d/d(v_out) into gg_out, leaves the
+// position adjoint (so far) in Gc.A0.xyz
+__global__ __launch_bounds__(256) void k_g2p_grad(SimP S, float* fr_cur, float* Gn_, float* Gc_,
+                                                  const float4* __restrict__ g_out, float4* gg_out) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S.N) return;
+    FrameV cur = frame_view(fr_cur, S.Np);
+    if (!cur.used[s]) return;
+    FrameV Gn = frame_view(Gn_, S.Np), Gc = frame_view(Gc_, S.Np);
+    float4 a0 = cur.A0[s];
+    float x[3] = {a0.x, a0.y, a0.z};
+    PState g;                                   // adjoints of x', v', C'
+    load_xvC(Gn, s, g);
+    Stencil st;
+    stencil_make(x, S.inv_dx, st);
+    if (!stencil_inside(st, S.n)) { Gc.A0[s] = make_float4(g.x[0], g.x[1], g.x[2], 0.f); return; }
+    // x' = x + dt v'  =>  v'_bar += dt x'_bar
+    float gv[3] = {g.v[0] + S.dt * g.x[0], g.v[1] + S.dt * g.x[1], g.v[2] + S.dt * g.x[2]};
+    const float c4 = 4.f * S.inv_dx;
+    float gfx[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int kk = 0; kk < 3; kk++) {
+                const int c = cell_addr(st.base[0] + i, st.base[1] + j, st.base[2] + kk, S.nb);
+                float4 vo = g_out[c];
+                float weight = st.w[i][0] * st.w[j][1] * st.w[kk][2];
+                float dpos[3] = {(float)i - st.fx[0], (float)j - st.fx[1], (float)kk - st.fx[2]};
+                float q[3];
+#pragma unroll
+                for (int a = 0; a < 3; a++) q[a] = gv[a] + c4 * (g.C.a[a][0] * dpos[0] + g.C.a[a][1] * dpos[1] + g.C.a[a][2] * dpos[2]);
+                float* dst = (float*)&gg_out[c];
+                unsafeAtomicAdd(dst + 0, weight * q[0]);
+                unsafeAtomicAdd(dst + 1, weight * q[1]);
+                unsafeAtomicAdd(dst + 2, weight * q[2]);
+                float sdot = vo.x * q[0] + vo.y * q[1] + vo.z * q[2];
+                // d weight / d fx_d
+                gfx[0] += stencil_dw(st, i, 0) * st.w[j][1] * st.w[kk][2] * sdot;
+                gfx[1] += st.w[i][0] * stencil_dw(st, j, 1) * st.w[kk][2] * sdot;
+                gfx[2] += st.w[i][0] * st.w[j][1] * stencil_dw(st, kk, 2) * sdot;
+                // dpos_b = o_b - fx_b
+#pragma unroll
+                for (int b = 0; b < 3; b++) gfx[b] -= c4 * weight * (vo.x * g.C.a[0][b] + vo.y * g.C.a[1][b] + vo.z * g.C.a[2][b]);
+            }
+    Gc.A0[s] = make_float4(g.x[0] + S.inv_dx * gfx[0], g.x[1] + S.inv_dx * gfx[1], g.x[2] + S.inv_dx * gfx[2], 0.f);
+}
+
+// grid_op.grad (mpm:539): gg_out (d/d v_out) -> gg_in (d/d v_in, d/d mass); re-zeroes g_in, gg_out, flags
+__global__ __launch_bounds__(256) void k_grid_grad(SimP S, float4* g_in, float4* gg_out, float4* gg_in,
+                                                   const int* __restrict__ blk_list, const int* __restrict__ blk_count,
+                                                   int* blk_flag) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cnt = *blk_count;
+    for (int e = blockIdx.x * 4 + wave; e < cnt; e += gridDim.x * 4) {
+        const int b = blk_list[e];
+        const int c = (b << 6) | lane;
+        const float4 gi = g_in[c];
+        const float4 go = gg_out[c];
+        float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gi.w > FE_EPS) {
+            const int bi = b / (S.nb * S.nb), bj = (b / S.nb) % S.nb, bk = b % S.nb;
+            float vo[3], kmul[3];
+            node_velocity(S, gi, bi * 4 + (lane >> 4), bj * 4 + ((lane >> 2) & 3), bk * 4 + (lane & 3), vo, kmul);
+            float inv = 1.f / gi.w;
+            float g0 = go.x * kmul[0], g1 = go.y * kmul[1], g2 = go.z * kmul[2];
+            out.x = g0 * inv; out.y = g1 * inv; out.z = g2 * inv;
+            out.w = -(gi.x * g0 + gi.y * g1 + gi.z * g2) * inv * inv;
+        }
+        gg_in[c] = out;
+        g_in[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        gg_out[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (lane == 0) blk_flag[b] = 0;
+    }
+}
+
+// Effector.move_kernel.grad (effector.py:154-155), position chain only
+__device__ void effector_move_grad(const EffP& e, int f) {
+    float xin[3] = {e.pos[f * 3] + e.v[f * 3], e.pos[f * 3 + 1] + e.v[f * 3 + 1], e.pos[f * 3 + 2] + e.v[f * 3 + 2]};
+    float xn[3], J[3][3];
+    boundary_x(e.bnd, xin, xn, J);
+    for (int d = 0; d < 3; d++) {
+        float g = J[0][d] * e.gpos[(f + 1) * 3] + J[1][d] * e.gpos[(f + 1) * 3 + 1] + J[2][d] * e.gpos[(f + 1) * 3 + 2];
+        atomicAdd(&e.gpos[f * 3 + d], g);       // injected particles add to the same slot concurrently
+        e.gv[f * 3 + d] += g;
+    }
+}
+
+// p2g.grad + svd_grad + compute_F_tmp.grad (mpm:544-546) + AgentInjector.act_kernel.grad +
+// process_unused_particles.grad (mpm:551) + Effector.move_kernel.grad on one thread
+__global__ __launch_bounds__(256) void k_p2g_grad(SimP S, float* fr_cur, float* Gn_, float* Gc_,
+                                                  const int* __restrict__ pid_of_slot, const float4* __restrict__ pinfo,
+                                                  const int* __restrict__ pool_idx, const float4* __restrict__ gg_in,
+                                                  int* blk_count, AgentP agent, EffP injector, InjectP inj, int act, int f) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s == 0) {
+        *blk_count = 0;
+        if (act) {
+#pragma unroll
+            for (int i = FE_MAX_EFF - 1; i >= 0; i--) if (i < agent.n) effector_move_grad(agent.e[i], f);
+        }
+    }
+    if (s >= S.N) return;
+    FrameV cur = frame_view(fr_cur, S.Np);
+    FrameV Gn = frame_view(Gn_, S.Np), Gc = frame_view(Gc_, S.Np);
+    const int pid = pid_of_slot[s];
+    if (!cur.used[s]) {
+        // the copy f -> f+1 of an unused particle passes its adjoint straight through
+        PState g; load_xvC(Gn, s, g); load_F(Gn, s, g.F);
+        store_xvC(Gc, s, g.x, g.v, g.C); store_F(Gc, s, g.F);
+        if (inj.on) {
+            int j = pool_idx[pid] - inj.act_id;
+            if (j >= 0 && j < injector.flux) {
+                const EffP& e = injector;              // x[f+1,pid] = offset + pos[f] + R(q) inject_p
+                atomicAdd(&e.gpos[f * 3 + 0], g.x[0]); atomicAdd(&e.gpos[f * 3 + 1], g.x[1]); atomicAdd(&e.gpos[f * 3 + 2], g.x[2]);
+            }
+        }
+        return;
+    }
+    PState p;
+    load_xvC(cur, s, p);
+    load_F(cur, s, p.F);
+    PInfo info = load_info(pinfo, pid);
+    Constitutive k;
+    constitutive_eval(p.C, p.F, S.dt, info.mu, info.lam, info.mass, info.cls, S.stress_scale, k);
+    m3 Fg; load_F(Gn, s, Fg);
+    float4 gc0 = Gc.A0[s];                      // position adjoint so far (k_g2p_grad)
+    float gx[3] = {gc0.x, gc0.y, gc0.z};
+    float Gv[3] = {0.f, 0.f, 0.f};
+    m3 GA = m3_zero();
+    Stencil st;
+    stencil_make(p.x, S.inv_dx, st);
+    if (stencil_inside(st, S.n)) {
+        const float m = info.mass;
+        float gfx[3] = {0.f, 0.f, 0.f};
+        float mv[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+            mv[a] = m * p.v[a] - S.dx * (k.affine.a[a][0] * st.fx[0] + k.affine.a[a][1] * st.fx[1] + k.affine.a[a][2] * st.fx[2]);
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+#pragma unroll
+                for (int kk = 0; kk < 3; kk++) {
+                    float4 gi = gg_in[cell_addr(st.base[0] + i, st.base[1] + j, st.base[2] + kk, S.nb)];
+                    float weight = st.w[i][0] * st.w[j][1] * st.w[kk][2];
+                    float dpos[3] = {((float)i - st.fx[0]) * S.dx, ((float)j - st.fx[1]) * S.dx, ((float)kk - st.fx[2]) * S.dx};
+                    float ox = (float)i * S.dx, oy = (float)j * S.dx, oz = (float)kk * S.dx;
+                    float gin[3] = {gi.x, gi.y, gi.z};
+                    float sdot = gi.w * m;
+#pragma unroll
+                    for (int a = 0; a < 3; a++) {
+                        float mom = mv[a] + k.affine.a[a][0] * ox + k.affine.a[a][1] * oy + k.affine.a[a][2] * oz;
+                        sdot += gin[a] * mom;
+                        Gv[a] += weight * gin[a];
+#pragma unroll
+                        for (int b = 0; b < 3; b++) GA.a[a][b] += weight * gin[a] * dpos[b];
+                    }
+                    gfx[0] += stencil_dw(st, i, 0) * st.w[j][1] * st.w[kk][2] * sdot;
+                    gfx[1] += st.w[i][0] * stencil_dw(st, j, 1) * st.w[kk][2] * sdot;
+                    gfx[2] += st.w[i][0] * st.w[j][1] * stencil_dw(st, kk, 2) * sdot;
+#pragma unroll
+                    for (int b = 0; b < 3; b++) gfx[b] -= S.dx * weight * (gin[0] * k.affine.a[0][b] + gin[1] * k.affine.a[1][b] + gin[2] * k.affine.a[2][b]);
+                }
+#pragma unroll
+        for (int d = 0; d < 3; d++) gx[d] += S.inv_dx * gfx[d];
+    }
+    float gvv[3] = {info.mass * Gv[0], info.mass * Gv[1], info.mass * Gv[2]};
+    m3 gC, gF;
+    constitutive_grad(p.C, p.F, S.dt, info.mu, info.lam, info.mass, info.cls, S.stress_scale, k, GA, Fg, gC, gF);
+    store_xvC(Gc, s, gx, gvv, gC);
+    store_F(Gc, s, gF);
+}
+
+// =========================================================================================
+// small kernels: effectors, loss, state I/O
+// =========================================================================================
+
+struct Act6 { float a[6]; };
+
+// set_action_kernel + set_velocity (effector.py:218-221, 252-260)
+__global__ void k_eff_set_action(EffP e, int s, int s_global, int n_substeps, Act6 act) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int ad = e.action_dim;
+    for (int j = 0; j < ad; j++) e.abuf[(size_t)s_global * ad + j] = act.a[j];
+    const float nf = (float)n_substeps;
+    for (int j = s * n_substeps; j < (s + 1) * n_substeps; j++) {
+        for (int k = 0; k < 3; k++) e.v[j * 3 + k] = e.abuf[(size_t)s_global * ad + k] * e.scale_v[k] / nf;
+        if (ad > 3) for (int k = 0; k < 3; k++) e.w[j * 3 + k] = e.abuf[(size_t)s_global * ad + k + 3] * e.scale_v[k + 3] / nf;
+    }
+}
+// set_velocity.grad (effector.py:270-274)
+__global__ void k_eff_set_action_grad(EffP e, int s, int s_global, int n_substeps) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int ad = e.action_dim;
+    const float nf = (float)n_substeps;
+    for (int j = s * n_substeps; j < (s + 1) * n_substeps; j++) {
+        for (int k = 0; k < 3; k++) e.gabuf[(size_t)s_global * ad + k] += e.gv[j * 3 + k] * e.scale_v[k] / nf;
+        if (ad > 3) for (int k = 0; k < 3; k++) e.gabuf[(size_t)s_global * ad + k + 3] += e.gw[j * 3 + k] * e.scale_v[k + 3] / nf;
+    }
+}
+// set_action_p_kernel + apply_action_p_kernel (effector.py:223-231, 236-239)
+__global__ void k_eff_apply_p(EffP e, Act6 act) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int j = 0; j < e.action_dim; j++) e.abuf_p[j] = act.a[j];
+    float xin[3] = {e.abuf_p[0] * e.scale_p[0], e.abuf_p[1] * e.scale_p[1], e.abuf_p[2] * e.scale_p[2]};
+    float xn[3], J[3][3];
+    boundary_x(e.bnd, xin, xn, J);
+    e.pos[0] = xn[0]; e.pos[1] = xn[1]; e.pos[2] = xn[2];
+}
+// apply_action_p_kernel.grad (effector.py:233-234)
+__global__ void k_eff_apply_p_grad(EffP e) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float xin[3] = {e.abuf_p[0] * e.scale_p[0], e.abuf_p[1] * e.scale_p[1], e.abuf_p[2] * e.scale_p[2]};
+    float xn[3], J[3][3];
+    boundary_x(e.bnd, xin, xn, J);
+    for (int d = 0; d < 3; d++) {
+        float g = J[0][d] * e.gpos[0] + J[1][d] * e.gpos[1] + J[2][d] * e.gpos[2];
+        e.gabuf_p[d] += g * e.scale_p[d];
+    }
+}
+// Effector/Injector.copy_frame, copy_grad (effector.py:164-176, injector.py:174-186)
+__global__ void k_eff_copy(EffP e, int src, int dst, int grad) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float *pos = grad ? e.gpos : e.pos, *quat = grad ? e.gquat : e.quat, *v = grad ? e.gv : e.v, *w = grad ? e.gw : e.w;
+    for (int j = 0; j < 3; j++) { pos[dst * 3 + j] = pos[src * 3 + j]; v[dst * 3 + j] = v[src * 3 + j]; w[dst * 3 + j] = w[src * 3 + j]; }
+    for (int j = 0; j < 4; j++) quat[dst * 4 + j] = quat[src * 4 + j];
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// compute_chamfer_loss_kernel (shapematching_loss.py:80-84)
+__global__ __launch_bounds__(256) void k_loss_fwd(SimP S, float* fr, const int* __restrict__ pid_of_slot,
+                                                  const float4* __restrict__ pinfo, const float* __restrict__ tgt,
+                                                  int matching_mat, float* chamfer_s) {
+    __shared__ float part[4];
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    float acc = 0.f;
+    if (s < S.N) {
+        FrameV cur = frame_view(fr, S.Np);
+        if (cur.used[s]) {
+            const int pid = pid_of_slot[s];
+            if (load_info(pinfo, pid).mat == matching_mat) {
+                float4 a0 = cur.A0[s];
+                float d0 = a0.x - tgt[pid * 3], d1 = a0.y - tgt[pid * 3 + 1], d2 = a0.z - tgt[pid * 3 + 2];
+                acc = d0 * d0 + d1 * d1 + d2 * d2;
+            }
+        }
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) { float t = part[0] + part[1] + part[2] + part[3]; if (t != 0.f) atomicAdd(chamfer_s, t); }
+}
+// sum_up_loss_kernel (shapematching_loss.py:86-88)
+__global__ void k_loss_sum(float* chamfer_s, float* step_loss_s, float weight) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *step_loss_s += *chamfer_s * weight;
+}
+// adjoint of the two kernels above: x.grad[f,p] += 2 (x - tgt) * weight * step_loss.grad[s]
+__global__ __launch_bounds__(256) void k_loss_bwd(SimP S, float* fr, float* G_, const int* __restrict__ pid_of_slot,
+                                                  const float4* __restrict__ pinfo, const float* __restrict__ tgt,
+                                                  int matching_mat, float g) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S.N) return;
+    FrameV cur = frame_view(fr, S.Np);
+    if (!cur.used[s]) return;
+    const int pid = pid_of_slot[s];
+    if (load_info(pinfo, pid).mat != matching_mat) return;
+    FrameV G = frame_view(G_, S.Np);
+    float4 a0 = cur.A0[s];
+    float4 g0 = G.A0[s];
+    g0.x += 2.f * (a0.x - tgt[pid * 3]) * g;
+    g0.y += 2.f * (a0.y - tgt[pid * 3 + 1]) * g;
+    g0.z += 2.f * (a0.z - tgt[pid * 3 + 2]) * g;
+    G.A0[s] = g0;
+}
+
+// staging (caller's particle-id order, AoS) <-> planes (slot order).  mask bits: 1 x, 2 v, 4 C, 8 F, 16 used
+__global__ __launch_bounds__(256) void k_pack(int N, size_t Np, float* planes, const int* __restrict__ pid_of_slot,
+                                              const float* sx, const float* sv, const float* sC, const float* sF,
+                                              const int* sused, int mask, int add) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= N) return;
+    const int pid = pid_of_slot[s];
+    FrameV fr = frame_view(planes, Np);
+    PState p; load_xvC(fr, s, p); load_F(fr, s, p.F);
+    if (mask & 1) for (int d = 0; d < 3; d++) p.x[d] = (add ? p.x[d] : 0.f) + sx[pid * 3 + d];
+    if (mask & 2) for (int d = 0; d < 3; d++) p.v[d] = (add ? p.v[d] : 0.f) + sv[pid * 3 + d];
+    if (mask & 4) for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) p.C.a[i][j] = (add ? p.C.a[i][j] : 0.f) + sC[pid * 9 + i * 3 + j];
+    if (mask & 8) for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) p.F.a[i][j] = (add ? p.F.a[i][j] : 0.f) + sF[pid * 9 + i * 3 + j];
+    store_xvC(fr, s, p.x, p.v, p.C); store_F(fr, s, p.F);
+    if (mask & 16) fr.used[s] = sused[pid];
+}
+__global__ __launch_bounds__(256) void k_unpack(int N, size_t Np, float* planes, const int* __restrict__ pid_of_slot,
+                                                float* sx, float* sv, float* sC, float* sF, int* sused, int mask) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= N) return;
+    const int pid = pid_of_slot[s];
+    FrameV fr = frame_view(planes, Np);
+    PState p; load_xvC(fr, s, p); load_F(fr, s, p.F);
+    if (mask & 1) for (int d = 0; d < 3; d++) sx[pid * 3 + d] = p.x[d];
+    if (mask & 2) for (int d = 0; d < 3; d++) sv[pid * 3 + d] = p.v[d];
+    if (mask & 4) for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) sC[pid * 9 + i * 3 + j] = p.C.a[i][j];
+    if (mask & 8) for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) sF[pid * 9 + i * 3 + j] = p.F.a[i][j];
+    if (mask & 16) sused[pid] = fr.used[s];
+}
+
+// stats: mark touched nodes of frame f, then count
+__global__ __launch_bounds__(256) void k_stats_mark(SimP S, float* fr, unsigned char* node_mark, unsigned long long* counters) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    bool used = false;
+    if (s < S.N) {
+        FrameV cur = frame_view(fr, S.Np);
+        used = cur.used[s] != 0;
+        if (used) {
+            float4 a0 = cur.A0[s];
+            float x[3] = {a0.x, a0.y, a0.z};
+            Stencil st; stencil_make(x, S.inv_dx, st);
+            if (stencil_inside(st, S.n))
+                for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++)
+                    node_mark[cell_addr(st.base[0] + i, st.base[1] + j, st.base[2] + k, S.nb)] = 1;
+        }
+    }
+    unsigned long long b = __ballot(used);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&counters[0], (unsigned long long)__popcll(b));
+}
+__global__ __launch_bounds__(256) void k_stats_count(int ncells, unsigned char* node_mark, unsigned long long* counters) {
+    const int lane = threadIdx.x & 63;
+    const int b = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;    // one wave per 4^3 block
+    if (b * 64 >= ncells) return;
+    bool t = node_mark[b * 64 + lane] != 0;
+    node_mark[b * 64 + lane] = 0;
+    unsigned long long m = __ballot(t);
+    if (lane == 0 && m) { atomicAdd(&counters[1], (unsigned long long)__popcll(m)); atomicAdd(&counters[2], 1ull); }
+}
+
+// =========================================================================================
+// host side
+// =========================================================================================
+enum { KID_P2G = 0, KID_GRID, KID_G2P, KID_P2G_RE, KID_GRID_KEEP, KID_G2P_GRAD, KID_GRID_GRAD, KID_P2G_GRAD, KID_COUNT };
+static const char* KNAMES[KID_COUNT] = {"p2g", "grid_op", "g2p", "p2g_recompute", "grid_op_keep", "g2p_grad", "grid_op_grad", "p2g_grad"};
+
+struct EffHost {
+    EffP p;
+    std::vector<int> act_id;        // [L+1]; deterministic, kept on the host (injector.py:29,105)
+    std::vector<int> act_range;
+};
+
+struct FeEngine {
+    FeConfig cfg;
+    int N = 0, Np = 0, L = 0, n = 0, nb = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    SimP S;
+    float* frames = nullptr; size_t frame_stride = 0;      // (L+1) frames of FR_WORDS*Np floats
+    float* grads = nullptr;                                 // 2 x GR_WORDS*Np floats (+Np pad)
+    int *pid_of_slot = nullptr, *slot_of_pid = nullptr;
+    float4* pinfo = nullptr; int* pool_idx = nullptr;
+    std::vector<int> mat_host;
+    float4 *g_in = nullptr, *g_out = nullptr, *gg_out = nullptr, *gg_in = nullptr;
+    int *blk_flag = nullptr, *blk_list = nullptr, *blk_count = nullptr, *err_dev = nullptr;
+    float* stage_r = nullptr; int* stage_i = nullptr;       // 24 N floats, N ints
+    unsigned char* node_mark = nullptr; unsigned long long* counters = nullptr;
+    std::vector<EffHost> effs;
+    int loss_steps = 0; float *tgt = nullptr, *chamfer = nullptr, *step_loss = nullptr;
+    size_t bytes = 0;
+    std::string err;
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+    // per-kernel profiling
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev; std::vector<int> prof_kid; size_t prof_used = 0;
+    double prof_ms[KID_COUNT] = {0}; long long prof_n[KID_COUNT] = {0};
+
+    float* frame(int f) { return frames + (size_t)f * frame_stride; }
+    float* grad(int f) { return grads + (size_t)(f & 1) * ((size_t)GR_WORDS * Np + Np); }
+};
+
+static std::string g_create_err;
+
+#define FAIL(h, msg) do { (h)->err = (msg); return 1; } while (0)
+#define HIPCK(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (h)->err = std::string(#call) + ": " + hipGetErrorString(e_); return 1; } } while (0)
+#define CHECK_FRAME(h, f) do { if ((f) < 0 || (f) > (h)->L) FAIL(h, "frame index out of range"); } while (0)
+#define CHECK_EFF(h, e) do { if ((e) < 0 || (e) >= (int)(h)->effs.size()) FAIL(h, "effector index out of range"); } while (0)
+
+namespace {
+
+template <typename T>
+int dev_alloc(FeEngine* h, T** p, size_t count, bool zero = true) {
+    size_t bytes = count * sizeof(T);
+    if (bytes == 0) bytes = sizeof(T);
+    HIPCK(h, hipMalloc((void**)p, bytes));
+    if (zero) HIPCK(h, hipMemsetAsync(*p, 0, bytes, h->stream));
+    h->bytes += bytes;
+    return 0;
+}
+
+BoundaryP to_boundary(const FeBoundary& b) {
+    BoundaryP r;
+    r.type = b.type;
+    for (int i = 0; i < 3; i++) { r.lower[i] = b.lower[i]; r.upper[i] = b.upper[i]; }
+    r.cx = b.xz_center[0]; r.cz = b.xz_center[1]; r.radius = b.xz_radius; r.restitution = b.restitution; r.lock_dims = b.lock_dims;
+    return r;
+}
+
+AgentP agent_params(FeEngine* h) {
+    AgentP a; std::memset(&a, 0, sizeof(a));
+    a.n = (int)h->effs.size();
+    for (int i = 0; i < a.n; i++) a.e[i] = h->effs[i].p;
+    return a;
+}
+
+inline dim3 pgrid(FeEngine* h) { return dim3((h->N + 255) / 256); }
+inline dim3 ggrid(FeEngine* h) { int blocks = h->nb * h->nb * h->nb; int g = (blocks + 3) / 4; return dim3(g < 1024 ? g : 1024); }
+
+void prof_drain(FeEngine* h);
+void prof_begin(FeEngine* h, int kid) {
+    if (!h->prof_on) return;
+    if (h->prof_used >= 8192) prof_drain(h);
+    if (h->prof_used + 2 > h->prof_ev.size()) {
+        for (int i = 0; i < 256; i++) { hipEvent_t e; (void)hipEventCreate(&e); h->prof_ev.push_back(e); }
+    }
+    h->prof_kid.push_back(kid);
+    (void)hipEventRecord(h->prof_ev[h->prof_used++], h->stream);
+}
+void prof_end(FeEngine* h) {
+    if (!h->prof_on) return;
+    (void)hipEventRecord(h->prof_ev[h->prof_used++], h->stream);
+}
+void prof_drain(FeEngine* h) {
+    if (h->prof_used == 0) return;
+    (void)hipStreamSynchronize(h->stream);
+    for (size_t i = 0; i + 1 < h->prof_used; i += 2) {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, h->prof_ev[i], h->prof_ev[i + 1]);
+        int kid = h->prof_kid[i / 2];
+        h->prof_ms[kid] += ms; h->prof_n[kid]++;
+    }
+    h->prof_used = 0; h->prof_kid.clear();
+}
+
+// the injector (at most one, as AgentInjector asserts: agent_injector.py:17-18)
+int find_injector(FeEngine* h) {
+    for (size_t i = 0; i < h->effs.size(); i++) if (h->effs[i].p.type == FE_EFF_INJECTOR) return (int)i;
+    return -1;
+}
+
+int make_inject(FeEngine* h, int f, int f_global, int act, bool forward, InjectP& inj, EffP& injp) {
+    inj.on = 0; inj.act_id = 0; inj.row = 0;
+    std::memset(&injp, 0, sizeof(injp));
+    int ie = find_injector(h);
+    if (!act || ie < 0) return 0;
+    EffHost& E = h->effs[ie];
+    if (E.act_range.empty()) FAIL(h, "injector has no act_range");
+    int row = E.p.locally_random ? f : f_global;
+    if (row < 0 || row >= E.p.random_length) FAIL(h, "injector random_vector row out of range");
+    if (forward) {
+        if (E.act_id[f] + E.p.flux > (int)E.act_range.size()) FAIL(h, "too many particles added");   // agent_injector.py:38-39
+        E.act_id[f + 1] = E.act_id[f] + E.p.flux;                                                     // injector.py:105
+    }
+    inj.on = 1; inj.act_id = E.act_id[f]; inj.row = row; injp = E.p;
+    return 0;
+}
+
+int substep_fwd(FeEngine* h, int f, int f_global, int act) {
+    InjectP inj; EffP injp;
+    if (make_inject(h, f, f_global, act, true, inj, injp)) return 1;
+    AgentP ag = agent_params(h);
+    prof_begin(h, KID_P2G);
+    hipLaunchKernelGGL(k_p2g<true>, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), h->pid_of_slot,
+                       h->pinfo, h->pool_idx, h->g_in, h->blk_flag, h->blk_list, h->blk_count, ag, injp, inj, act, f, h->err_dev);
+    prof_end(h);
+    prof_begin(h, KID_GRID);
+    hipLaunchKernelGGL(k_grid<false>, ggrid(h), dim3(256), 0, h->stream, h->S, h->g_in, h->g_out, h->blk_list, h->blk_count, h->blk_flag);
+    prof_end(h);
+    prof_begin(h, KID_G2P);
+    hipLaunchKernelGGL(k_g2p, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), h->g_out, h->blk_count);
+    prof_end(h);
+    return 0;
+}
+
+int substep_bwd(FeEngine* h, int f, int f_global, int act) {
+    InjectP inj; EffP injp;
+    if (make_inject(h, f, f_global, act, false, inj, injp)) return 1;
+    AgentP ag = agent_params(h);
+    InjectP noinj = {0, 0, 0};
+    prof_begin(h, KID_P2G_RE);
+    hipLaunchKernelGGL(k_p2g<false>, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), h->pid_of_slot,
+                       h->pinfo, h->pool_idx, h->g_in, h->blk_flag, h->blk_list, h->blk_count, ag, injp, noinj, 0, f, h->err_dev);
+    prof_end(h);
+    prof_begin(h, KID_GRID_KEEP);
+    hipLaunchKernelGGL(k_grid<true>, ggrid(h), dim3(256), 0, h->stream, h->S, h->g_in, h->g_out, h->blk_list, h->blk_count, h->blk_flag);
+    prof_end(h);
+    prof_begin(h, KID_G2P_GRAD);
+    hipLaunchKernelGGL(k_g2p_grad, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), h->g_out, h->gg_out);
+    prof_end(h);
+    prof_begin(h, KID_GRID_GRAD);
+    hipLaunchKernelGGL(k_grid_grad, ggrid(h), dim3(256), 0, h->stream, h->S, h->g_in, h->gg_out, h->gg_in, h->blk_list, h->blk_count, h->blk_flag);
+    prof_end(h);
+    prof_begin(h, KID_P2G_GRAD);
+    hipLaunchKernelGGL(k_p2g_grad, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), h->pid_of_slot,
+                       h->pinfo, h->pool_idx, h->gg_in, h->blk_count, ag, injp, inj, act, f);
+    prof_end(h);
+    return 0;
+}
+
+int check_async(FeEngine* h) {
+    HIPCK(h, hipGetLastError());
+    return 0;
+}
+
+// H2D staging + pack into frame / grad planes
+int upload_planes(FeEngine* h, float* planes, const float* x, const float* v, const float* C, const float* F, const int* used, int add) {
+    const size_t N = h->N;
+    int mask = 0;
+    float *sx = h->stage_r, *sv = h->stage_r + 3 * N, *sC = h->stage_r + 6 * N, *sF = h->stage_r + 15 * N;
+    if (x) { mask |= 1; HIPCK(h, hipMemcpyAsync(sx, x, sizeof(float) * 3 * N, hipMemcpyHostToDevice, h->stream)); }
+    if (v) { mask |= 2; HIPCK(h, hipMemcpyAsync(sv, v, sizeof(float) * 3 * N, hipMemcpyHostToDevice, h->stream)); }
+    if (C) { mask |= 4; HIPCK(h, hipMemcpyAsync(sC, C, sizeof(float) * 9 * N, hipMemcpyHostToDevice, h->stream)); }
+    if (F) { mask |= 8; HIPCK(h, hipMemcpyAsync(sF, F, sizeof(float) * 9 * N, hipMemcpyHostToDevice, h->stream)); }
+    if (used) { mask |= 16; HIPCK(h, hipMemcpyAsync(h->stage_i, used, sizeof(int) * N, hipMemcpyHostToDevice, h->stream)); }
+    if (!mask || N == 0) return 0;
+    hipLaunchKernelGGL(k_pack, pgrid(h), dim3(256), 0, h->stream, h->N, (size_t)h->Np, planes, h->pid_of_slot, sx, sv, sC, sF, h->stage_i, mask, add);
+    HIPCK(h, hipStreamSynchronize(h->stream));      // host buffers are borrowed only for the call
+    return check_async(h);
+}
+int download_planes(FeEngine* h, float* planes, float* x, float* v, float* C, float* F, int* used) {
+    const size_t N = h->N;
+    int mask = (x ? 1 : 0) | (v ? 2 : 0) | (C ? 4 : 0) | (F ? 8 : 0) | (used ? 16 : 0);
+    if (!mask || N == 0) return 0;
+    float *sx = h->stage_r, *sv = h->stage_r + 3 * N, *sC = h->stage_r + 6 * N, *sF = h->stage_r + 15 * N;
+    hipLaunchKernelGGL(k_unpack, pgrid(h), dim3(256), 0, h->stream, h->N, (size_t)h->Np, planes, h->pid_of_slot, sx, sv, sC, sF, h->stage_i, mask);
+    if (x) HIPCK(h, hipMemcpyAsync(x, sx, sizeof(float) * 3 * N, hipMemcpyDeviceToHost, h->stream));
+    if (v) HIPCK(h, hipMemcpyAsync(v, sv, sizeof(float) * 3 * N, hipMemcpyDeviceToHost, h->stream));
+    if (C) HIPCK(h, hipMemcpyAsync(C, sC, sizeof(float) * 9 * N, hipMemcpyDeviceToHost, h->stream));
+    if (F) HIPCK(h, hipMemcpyAsync(F, sF, sizeof(float) * 9 * N, hipMemcpyDeviceToHost, h->stream));
+    if (used) HIPCK(h, hipMemcpyAsync(used, h->stage_i, sizeof(int) * N, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    return check_async(h);
+}
+
+int check_device_errors(FeEngine* h) {
+    int e = 0;
+    HIPCK(h, hipMemcpyAsync(&e, h->err_dev, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    if (e) {
+        (void)hipMemsetAsync(h->err_dev, 0, sizeof(int), h->stream);
+        FAIL(h, "particle stencil left the grid (p2g)");
+    }
+    return 0;
+}
+
+} // namespace
+
+// =========================================================================================
+// C ABI
+// =========================================================================================
+extern "C" {
+
+const char* fe_backend(void) { return "hip-gfx950"; }
+int fe_real_size(void) { return 4; }
+
+FeEngine* fe_create(const FeConfig* cfg) {
+    if (!cfg || cfg->struct_size != (int)sizeof(FeConfig)) { g_create_err = "FeConfig size mismatch"; return nullptr; }
+    if (cfg->n_grid < 4 || cfg->n_grid % 4 != 0 || cfg->n_particles < 0 || cfg->max_substeps_local < 1 || cfg->n_substeps < 1) {
+        g_create_err = "invalid FeConfig (n_grid must be a multiple of 4)"; return nullptr;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_create_err = "no HIP device visible: the MI355X engine has no CPU fallback"; return nullptr; }
+    if (cfg->device < 0 || cfg->device >= ndev) { g_create_err = "HIP device ordinal out of range"; return nullptr; }
+    FeEngine* h = new FeEngine();
+    h->cfg = *cfg; h->N = cfg->n_particles; h->L = cfg->max_substeps_local; h->n = cfg->n_grid; h->nb = cfg->n_grid / 4;
+    h->Np = ((h->N + 63) / 64) * 64; if (h->Np == 0) h->Np = 64;
+    h->device = cfg->device;
+    auto fail = [&](const std::string& m) { g_create_err = m.empty() ? h->err : m; fe_destroy(h); return (FeEngine*)nullptr; };
+    if (hipSetDevice(h->device) != hipSuccess) return fail("hipSetDevice failed");
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
+    SimP& S = h->S;
+    S.N = h->N; S.Np = h->Np; S.n = h->n; S.nb = h->nb;
+    S.dx = 1.0f / (float)h->n; S.inv_dx = (float)h->n; S.dt = cfg->dt;
+    S.stress_scale = -cfg->dt * cfg->p_vol * 4.f * S.inv_dx * S.inv_dx;
+    for (int i = 0; i < 3; i++) S.g[i] = cfg->gravity[i];
+    S.bnd = to_boundary(cfg->boundary);
+    h->frame_stride = (size_t)FR_WORDS * h->Np;
+    const size_t ncell = (size_t)h->nb * h->nb * h->nb * 64;
+    if (dev_alloc(h, &h->frames, h->frame_stride * (h->L + 1))) return fail("");
+    if (dev_alloc(h, &h->grads, 2 * ((size_t)GR_WORDS * h->Np + h->Np))) return fail("");
+    if (dev_alloc(h, &h->pid_of_slot, h->Np) || dev_alloc(h, &h->slot_of_pid, h->Np)) return fail("");
+    if (dev_alloc(h, &h->pinfo, h->Np) || dev_alloc(h, &h->pool_idx, h->Np)) return fail("");
+    if (dev_alloc(h, &h->g_in, ncell) || dev_alloc(h, &h->g_out, ncell) || dev_alloc(h, &h->gg_out, ncell) || dev_alloc(h, &h->gg_in, ncell)) return fail("");
+    if (dev_alloc(h, &h->blk_flag, ncell / 64) || dev_alloc(h, &h->blk_list, ncell / 64) || dev_alloc(h, &h->blk_count, 1) || dev_alloc(h, &h->err_dev, 1)) return fail("");
+    if (dev_alloc(h, &h->stage_r, (size_t)24 * h->Np) || dev_alloc(h, &h->stage_i, h->Np)) return fail("");
+    if (dev_alloc(h, &h->node_mark, ncell) || dev_alloc(h, &h->counters, 4)) return fail("");
+    {   // identity particle order
+        std::vector<int> id(h->Np);
+        for (int i = 0; i < h->Np; i++) id[i] = i < h->N ? i : 0;
+        if (hipMemcpy(h->pid_of_slot, id.data(), sizeof(int) * h->Np, hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy failed");
+        if (hipMemcpy(h->slot_of_pid, id.data(), sizeof(int) * h->Np, hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy failed");
+    }
+    if (hipEventCreate(&h->ev_t0) != hipSuccess || hipEventCreate(&h->ev_t1) != hipSuccess) return fail("hipEventCreate failed");
+    if (hipStreamSynchronize(h->stream) != hipSuccess) return fail("device initialisation failed");
+    return h;
+}
+
+void fe_destroy(FeEngine* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    void* ptrs[] = {h->frames, h->grads, h->pid_of_slot, h->slot_of_pid, h->pinfo, h->pool_idx, h->g_in, h->g_out, h->gg_out, h->gg_in,
+                    h->blk_flag, h->blk_list, h->blk_count, h->err_dev, h->stage_r, h->stage_i, h->node_mark, h->counters,
+                    h->tgt, h->chamfer, h->step_loss};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (auto& E : h->effs) {
+        void* ep[] = {E.p.pos, E.p.quat, E.p.v, E.p.w, E.p.gpos, E.p.gquat, E.p.gv, E.p.gw, E.p.abuf, E.p.gabuf, E.p.abuf_p, E.p.gabuf_p, E.p.random_vector};
+        for (void* p : ep) if (p) (void)hipFree(p);
+    }
+    for (auto e : h->prof_ev) (void)hipEventDestroy(e);
+    if (h->ev_t0) (void)hipEventDestroy(h->ev_t0);
+    if (h->ev_t1) (void)hipEventDestroy(h->ev_t1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+const char* fe_last_error(FeEngine* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int fe_sync(FeEngine* h) {
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    if (check_async(h)) return 1;
+    return check_device_errors(h);
+}
+
+int fe_set_option(FeEngine* h, const char* name, double value) {
+    (void)h; (void)name; (void)value;      // tunables arrive with the sorted / LDS-tiled kernels
+    return 0;
+}
+
+int fe_init_particles(FeEngine* h, const fe_real* x, const int* used, const int* mat, const int* mat_cls,
+                      const fe_real* mu, const fe_real* lam, const fe_real* rho, const int* body_id) {
+    (void)body_id;
+    const int N = h->N;
+    std::vector<float4> info(h->Np, make_float4(0, 0, 0, 0));
+    std::vector<float> C0((size_t)9 * N, 0.f), F0((size_t)9 * N, 0.f), v0((size_t)3 * N, 0.f);
+    h->mat_host.assign(mat, mat + N);
+    for (int i = 0; i < N; i++) {
+        if (mat_cls[i] == FE_MAT_RIGID) FAIL(h, "MAT_RIGID shape-matching bodies are not supported yet (SURVEY 8f-4)");
+        if (mat_cls[i] < 0 || mat_cls[i] > 0xffff || mat[i] < 0 || mat[i] > 0xffff) FAIL(h, "material id out of range");
+        int bits = (mat_cls[i] & 0xffff) | ((mat[i] & 0xffff) << 16);
+        float w; std::memcpy(&w, &bits, 4);
+        info[i] = make_float4(mu[i], lam[i], h->cfg.p_vol * rho[i], w);      // mass = p_vol * rho, mpm:174
+        F0[(size_t)i * 9] = F0[(size_t)i * 9 + 4] = F0[(size_t)i * 9 + 8] = 1.f;
+    }
+    HIPCK(h, hipMemcpyAsync(h->pinfo, info.data(), sizeof(float4) * h->Np, hipMemcpyHostToDevice, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    return upload_planes(h, h->frame(0), x, v0.data(), C0.data(), F0.data(), used, 0);
+}
+
+int fe_substep(FeEngine* h, int f, int f_global, int act) {
+    if (f < 0 || f >= h->L) FAIL(h, "substep frame out of range");
+    if (substep_fwd(h, f, f_global, act)) return 1;
+    return check_async(h);
+}
+int fe_substep_grad(FeEngine* h, int f, int f_global, int act) {
+    if (f < 0 || f >= h->L) FAIL(h, "substep frame out of range");
+    if (substep_bwd(h, f, f_global, act)) return 1;
+    return check_async(h);
+}
+int fe_step(FeEngine* h, int f0, int f_global0, int n, int act) {
+    if (f0 < 0 || f0 + n > h->L) FAIL(h, "step frames out of range");
+    for (int i = 0; i < n; i++) if (substep_fwd(h, f0 + i, f_global0 + i, act)) return 1;
+    return check_async(h);
+}
+int fe_step_grad(FeEngine* h, int f0, int f_global0, int n, int act) {
+    if (f0 < 0 || f0 + n > h->L) FAIL(h, "step frames out of range");
+    for (int i = n - 1; i >= 0; i--) if (substep_bwd(h, f0 + i, f_global0 + i, act)) return 1;
+    return check_async(h);
+}
+
+int fe_get_frame(FeEngine* h, int f, fe_real* x, fe_real* v, fe_real* C, fe_real* F, int* used) {
+    CHECK_FRAME(h, f);
+    if (download_planes(h, h->frame(f), x, v, C, F, used)) return 1;
+    return check_device_errors(h);
+}
+int fe_set_frame(FeEngine* h, int f, const fe_real* x, const fe_real* v, const fe_real* C, const fe_real* F, const int* used) {
+    CHECK_FRAME(h, f);
+    return upload_planes(h, h->frame(f), x, v, C, F, used, 0);
+}
+int fe_copy_frame(FeEngine* h, int src, int dst) {
+    CHECK_FRAME(h, src); CHECK_FRAME(h, dst);
+    if (src == dst) return 0;
+    HIPCK(h, hipMemcpyAsync(h->frame(dst), h->frame(src), sizeof(float) * h->frame_stride, hipMemcpyDeviceToDevice, h->stream));
+    return 0;
+}
+int fe_copy_grad(FeEngine* h, int src, int dst) {
+    CHECK_FRAME(h, src); CHECK_FRAME(h, dst);
+    // adjoint frames are a ring of two (slot = f & 1); the `used` copy of mpm:604 is a frame copy
+    if ((src & 1) != (dst & 1))
+        HIPCK(h, hipMemcpyAsync(h->grad(dst), h->grad(src), sizeof(float) * GR_WORDS * h->Np, hipMemcpyDeviceToDevice, h->stream));
+    if (src != dst) {
+        FrameV s = frame_view(h->frame(src), h->Np), d = frame_view(h->frame(dst), h->Np);
+        HIPCK(h, hipMemcpyAsync(d.used, s.used, sizeof(int) * h->Np, hipMemcpyDeviceToDevice, h->stream));
+    }
+    return 0;
+}
+int fe_reset_grad(FeEngine* h) {
+    HIPCK(h, hipMemsetAsync(h->grads, 0, sizeof(float) * 2 * ((size_t)GR_WORDS * h->Np + h->Np), h->stream));
+    for (auto& E : h->effs) {
+        const int Fm = h->L + 1, ad = E.p.action_dim > 0 ? E.p.action_dim : 1;
+        HIPCK(h, hipMemsetAsync(E.p.gpos, 0, sizeof(float) * 3 * Fm, h->stream));
+        HIPCK(h, hipMemsetAsync(E.p.gquat, 0, sizeof(float) * 4 * Fm, h->stream));
+        HIPCK(h, hipMemsetAsync(E.p.gv, 0, sizeof(float) * 3 * Fm, h->stream));
+        HIPCK(h, hipMemsetAsync(E.p.gw, 0, sizeof(float) * 3 * Fm, h->stream));
+        HIPCK(h, hipMemsetAsync(E.p.gabuf, 0, sizeof(float) * (size_t)h->cfg.max_action_steps * ad, h->stream));
+        HIPCK(h, hipMemsetAsync(E.p.gabuf_p, 0, sizeof(float) * ad, h->stream));
+    }
+    return 0;
+}
+int fe_reset_grad_till_frame(FeEngine* h, int f) {
+    CHECK_FRAME(h, f);
+    // particle adjoints: every substep_grad overwrites its ring slot, nothing to clear.
+    for (auto& E : h->effs) {
+        if (f == 0) break;
+        HIPCK(h, hipMemsetAsync(E.p.gpos, 0, sizeof(float) * 3 * f, h->stream));
+        HIPCK(h, hipMemsetAsync(E.p.gquat, 0, sizeof(float) * 4 * f, h->stream));
+        HIPCK(h, hipMemsetAsync(E.p.gv, 0, sizeof(float) * 3 * f, h->stream));
+        HIPCK(h, hipMemsetAsync(E.p.gw, 0, sizeof(float) * 3 * f, h->stream));
+    }
+    return 0;
+}
+int fe_get_grad(FeEngine* h, int f, fe_real* gx, fe_real* gv, fe_real* gC, fe_real* gF) {
+    CHECK_FRAME(h, f);
+    return download_planes(h, h->grad(f), gx, gv, gC, gF, nullptr);
+}
+int fe_add_grad(FeEngine* h, int f, const fe_real* gx, const fe_real* gv, const fe_real* gC, const fe_real* gF) {
+    CHECK_FRAME(h, f);
+    return upload_planes(h, h->grad(f), gx, gv, gC, gF, nullptr, 1);
+}
+int fe_get_mat(FeEngine* h, int* mat) {
+    if ((int)h->mat_host.size() != h->N) FAIL(h, "particles not initialised");
+    std::memcpy(mat, h->mat_host.data(), sizeof(int) * h->N);
+    return 0;
+}
+
+// ---- effectors
+int fe_add_effector(FeEngine* h, const FeEffectorDesc* d, const fe_real* random_vector) {
+    auto bad = [&](const char* m) { h->err = m; return -1; };
+    if (!d || d->struct_size != (int)sizeof(FeEffectorDesc)) return bad("FeEffectorDesc size mismatch");
+    if (!(d->action_dim == 0 || d->action_dim == 3 || d->action_dim == 6)) return bad("action_dim must be 0, 3 or 6");
+    if ((int)h->effs.size() >= FE_MAX_EFF) return bad("too many effectors");
+    if (d->type == FE_EFF_INJECTOR && find_injector(h) >= 0) return bad("only one injector per agent (agent_injector.py:17)");
+    EffHost E; std::memset(&E.p, 0, sizeof(E.p));
+    EffP& p = E.p;
+    p.type = d->type; p.action_dim = d->action_dim;
+    for (int i = 0; i < 6; i++) { p.scale_v[i] = d->action_scale_v[i]; p.scale_p[i] = d->action_scale_p[i]; }
+    p.bnd = to_boundary(d->boundary);
+    p.flux = d->flux; p.radius = d->radius;
+    for (int i = 0; i < 3; i++) { p.inject_v[i] = d->inject_v[i]; p.inject_p[i] = d->inject_p[i]; }
+    p.locally_random = d->locally_random; p.randomize_inject_v = d->randomize_inject_v; p.random_length = d->random_length;
+    const int Fm = h->L + 1, ad = d->action_dim > 0 ? d->action_dim : 1;
+    if (dev_alloc(h, &p.pos, 3 * Fm) || dev_alloc(h, &p.quat, 4 * Fm) || dev_alloc(h, &p.v, 3 * Fm) || dev_alloc(h, &p.w, 3 * Fm) ||
+        dev_alloc(h, &p.gpos, 3 * Fm) || dev_alloc(h, &p.gquat, 4 * Fm) || dev_alloc(h, &p.gv, 3 * Fm) || dev_alloc(h, &p.gw, 3 * Fm) ||
+        dev_alloc(h, &p.abuf, (size_t)h->cfg.max_action_steps * ad) || dev_alloc(h, &p.gabuf, (size_t)h->cfg.max_action_steps * ad) ||
+        dev_alloc(h, &p.abuf_p, ad) || dev_alloc(h, &p.gabuf_p, ad)) return -1;
+    if (d->type == FE_EFF_INJECTOR) {
+        if (!random_vector || d->random_length <= 0 || d->flux <= 0) return bad("injector needs random_vector, random_length, flux");
+        size_t cnt = (size_t)d->random_length * d->flux * 3;
+        if (dev_alloc(h, &p.random_vector, cnt, false)) return -1;
+        if (hipMemcpy(p.random_vector, random_vector, sizeof(float) * cnt, hipMemcpyHostToDevice) != hipSuccess) return bad("hipMemcpy failed");
+    }
+    E.act_id.assign(Fm, 0);
+    h->effs.push_back(E);
+    return (int)h->effs.size() - 1;
+}
+int fe_eff_set_act_range(FeEngine* h, int e, const int* act_range, int n) {
+    CHECK_EFF(h, e);
+    EffHost& E = h->effs[e];
+    E.act_range.assign(act_range, act_range + n);
+    if (n > 0) E.act_id[0] = act_range[0];         // injector.py:68 (sic: the first pool id)
+    std::vector<int> pool(h->Np, -1);
+    for (int i = 0; i < n; i++) {
+        if (act_range[i] < 0 || act_range[i] >= h->N) FAIL(h, "act_range entry out of range");
+        pool[act_range[i]] = i;
+    }
+    HIPCK(h, hipMemcpyAsync(h->pool_idx, pool.data(), sizeof(int) * h->Np, hipMemcpyHostToDevice, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+int fe_eff_get_state(FeEngine* h, int e, int f, fe_real* s) {
+    CHECK_EFF(h, e); CHECK_FRAME(h, f);
+    EffHost& E = h->effs[e];
+    HIPCK(h, hipMemcpyAsync(s, E.p.pos + f * 3, sizeof(float) * 3, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipMemcpyAsync(s + 3, E.p.quat + f * 4, sizeof(float) * 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    s[7] = (float)E.act_id[f];
+    return 0;
+}
+int fe_eff_set_state(FeEngine* h, int e, int f, const fe_real* s) {
+    CHECK_EFF(h, e); CHECK_FRAME(h, f);
+    EffHost& E = h->effs[e];
+    HIPCK(h, hipMemcpyAsync(E.p.pos + f * 3, s, sizeof(float) * 3, hipMemcpyHostToDevice, h->stream));
+    HIPCK(h, hipMemcpyAsync(E.p.quat + f * 4, s + 3, sizeof(float) * 4, hipMemcpyHostToDevice, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    E.act_id[f] = (int)s[7];
+    return 0;
+}
+int fe_eff_get_vw(FeEngine* h, int e, int f, fe_real* v3, fe_real* w3) {
+    CHECK_EFF(h, e); CHECK_FRAME(h, f);
+    HIPCK(h, hipMemcpyAsync(v3, h->effs[e].p.v + f * 3, sizeof(float) * 3, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipMemcpyAsync(w3, h->effs[e].p.w + f * 3, sizeof(float) * 3, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+int fe_eff_set_vw(FeEngine* h, int e, int f, const fe_real* v3, const fe_real* w3) {
+    CHECK_EFF(h, e); CHECK_FRAME(h, f);
+    HIPCK(h, hipMemcpyAsync(h->effs[e].p.v + f * 3, v3, sizeof(float) * 3, hipMemcpyHostToDevice, h->stream));
+    HIPCK(h, hipMemcpyAsync(h->effs[e].p.w + f * 3, w3, sizeof(float) * 3, hipMemcpyHostToDevice, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+int fe_eff_set_action(FeEngine* h, int e, int s, int s_global, int n_substeps, const fe_real* action) {
+    CHECK_EFF(h, e);
+    EffP& p = h->effs[e].p;
+    if (p.action_dim == 0) return 0;
+    if (s_global < 0 || s_global >= h->cfg.max_action_steps) FAIL(h, "s_global out of range");     // effector.py:263
+    if (s < 0 || (s + 1) * n_substeps > h->L + 1) FAIL(h, "s out of range");                          // effector.py:264
+    Act6 a; std::memset(&a, 0, sizeof(a));
+    for (int j = 0; j < p.action_dim; j++) a.a[j] = action[j];
+    hipLaunchKernelGGL(k_eff_set_action, dim3(1), dim3(64), 0, h->stream, p, s, s_global, n_substeps, a);
+    return check_async(h);
+}
+int fe_eff_set_action_grad(FeEngine* h, int e, int s, int s_global, int n_substeps) {
+    CHECK_EFF(h, e);
+    EffP& p = h->effs[e].p;
+    if (p.action_dim == 0) return 0;
+    if (s_global < 0 || s_global >= h->cfg.max_action_steps) FAIL(h, "s_global out of range");
+    if (s < 0 || (s + 1) * n_substeps > h->L + 1) FAIL(h, "s out of range");
+    hipLaunchKernelGGL(k_eff_set_action_grad, dim3(1), dim3(64), 0, h->stream, p, s, s_global, n_substeps);
+    return check_async(h);
+}
+int fe_eff_apply_action_p(FeEngine* h, int e, const fe_real* action_p) {
+    CHECK_EFF(h, e);
+    EffP& p = h->effs[e].p;
+    if (p.action_dim == 0) return 0;
+    Act6 a; std::memset(&a, 0, sizeof(a));
+    for (int j = 0; j < p.action_dim; j++) a.a[j] = action_p[j];
+    hipLaunchKernelGGL(k_eff_apply_p, dim3(1), dim3(64), 0, h->stream, p, a);
+    return check_async(h);
+}
+int fe_eff_apply_action_p_grad(FeEngine* h, int e) {
+    CHECK_EFF(h, e);
+    EffP& p = h->effs[e].p;
+    if (p.action_dim == 0) return 0;
+    hipLaunchKernelGGL(k_eff_apply_p_grad, dim3(1), dim3(64), 0, h->stream, p);
+    return check_async(h);
+}
+int fe_eff_get_action_grad(FeEngine* h, int e, int s, int n, fe_real* grad) {
+    CHECK_EFF(h, e);
+    EffP& p = h->effs[e].p;
+    const int ad = p.action_dim;
+    if (ad == 0) return 0;
+    if (s < 0 || s + n > h->cfg.max_action_steps) FAIL(h, "action grad range out of bounds");
+    if (n > 0) HIPCK(h, hipMemcpyAsync(grad, p.gabuf + (size_t)s * ad, sizeof(float) * (size_t)n * ad, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipMemcpyAsync(grad + (size_t)n * ad, p.gabuf_p, sizeof(float) * ad, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+int fe_agent_copy_frame(FeEngine* h, int src, int dst) {
+    CHECK_FRAME(h, src); CHECK_FRAME(h, dst);
+    for (auto& E : h->effs) {
+        hipLaunchKernelGGL(k_eff_copy, dim3(1), dim3(64), 0, h->stream, E.p, src, dst, 0);
+        if (E.p.type == FE_EFF_INJECTOR) E.act_id[dst] = E.act_id[src];
+    }
+    return check_async(h);
+}
+int fe_agent_copy_grad(FeEngine* h, int src, int dst) {
+    CHECK_FRAME(h, src); CHECK_FRAME(h, dst);
+    for (auto& E : h->effs) hipLaunchKernelGGL(k_eff_copy, dim3(1), dim3(64), 0, h->stream, E.p, src, dst, 1);
+    return check_async(h);
+}
+
+// ---- loss
+int fe_loss_alloc(FeEngine* h, int max_loss_steps) {
+    if (max_loss_steps <= 0) FAIL(h, "max_loss_steps must be positive");
+    if (h->tgt) { (void)hipFree(h->tgt); (void)hipFree(h->chamfer); (void)hipFree(h->step_loss); h->tgt = h->chamfer = h->step_loss = nullptr; }
+    h->loss_steps = max_loss_steps;
+    // all targets stay resident in HBM (the reference re-uploads one per step: shapematching_loss.py:73,77)
+    if (dev_alloc(h, &h->tgt, (size_t)max_loss_steps * h->N * 3) || dev_alloc(h, &h->chamfer, max_loss_steps) || dev_alloc(h, &h->step_loss, max_loss_steps)) return 1;
+    return 0;
+}
+int fe_loss_set_target(FeEngine* h, int s, const fe_real* x) {
+    if (s < 0 || s >= h->loss_steps) FAIL(h, "loss step out of range");
+    HIPCK(h, hipMemcpyAsync(h->tgt + (size_t)s * h->N * 3, x, sizeof(float) * 3 * h->N, hipMemcpyHostToDevice, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+int fe_loss_clear(FeEngine* h) {
+    if (!h->loss_steps) return 0;
+    HIPCK(h, hipMemsetAsync(h->chamfer, 0, sizeof(float) * h->loss_steps, h->stream));
+    HIPCK(h, hipMemsetAsync(h->step_loss, 0, sizeof(float) * h->loss_steps, h->stream));
+    return 0;
+}
+int fe_loss_step(FeEngine* h, int s, int f, int matching_mat, fe_real weight) {
+    if (s < 0 || s >= h->loss_steps) FAIL(h, "loss step out of range");
+    CHECK_FRAME(h, f);
+    hipLaunchKernelGGL(k_loss_fwd, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->pid_of_slot, h->pinfo,
+                       h->tgt + (size_t)s * h->N * 3, matching_mat, h->chamfer + s);
+    hipLaunchKernelGGL(k_loss_sum, dim3(1), dim3(64), 0, h->stream, h->chamfer + s, h->step_loss + s, weight);
+    return check_async(h);
+}
+int fe_loss_step_grad(FeEngine* h, int s, int f, int matching_mat, fe_real weight, fe_real step_loss_grad) {
+    if (s < 0 || s >= h->loss_steps) FAIL(h, "loss step out of range");
+    CHECK_FRAME(h, f);
+    hipLaunchKernelGGL(k_loss_bwd, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->grad(f), h->pid_of_slot, h->pinfo,
+                       h->tgt + (size_t)s * h->N * 3, matching_mat, weight * step_loss_grad);
+    return check_async(h);
+}
+int fe_loss_get(FeEngine* h, fe_real* step_loss, int n) {
+    if (n > h->loss_steps) FAIL(h, "loss_get: n too large");
+    HIPCK(h, hipMemcpyAsync(step_loss, h->step_loss, sizeof(float) * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+
+// ---- measurement
+int fe_get_stats(FeEngine* h, int f, FeStats* out) {
+    CHECK_FRAME(h, f);
+    const int ncell = h->nb * h->nb * h->nb * 64;
+    HIPCK(h, hipMemsetAsync(h->counters, 0, sizeof(unsigned long long) * 4, h->stream));
+    hipLaunchKernelGGL(k_stats_mark, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->node_mark, h->counters);
+    hipLaunchKernelGGL(k_stats_count, dim3((ncell + 255) / 256), dim3(256), 0, h->stream, ncell, h->node_mark, h->counters);
+    unsigned long long c[4];
+    HIPCK(h, hipMemcpyAsync(c, h->counters, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    out->n_used = (long long)c[0]; out->n_cells_touched = (long long)c[1]; out->n_blocks_active = (long long)c[2];
+    out->n_slow_path = 0; out->bytes_state = (long long)h->bytes;
+    return check_async(h);
+}
+int fe_timer_start(FeEngine* h) { HIPCK(h, hipEventRecord(h->ev_t0, h->stream)); return 0; }
+double fe_timer_stop_ms(FeEngine* h) {
+    if (hipEventRecord(h->ev_t1, h->stream) != hipSuccess || hipEventSynchronize(h->ev_t1) != hipSuccess) { h->err = "timer stop failed"; return -1.0; }
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1) != hipSuccess) { h->err = "hipEventElapsedTime failed"; return -1.0; }
+    return (double)ms;
+}
+int fe_profile_enable(FeEngine* h, int on) {
+    prof_drain(h);
+    h->prof_on = on != 0;
+    if (on) for (int i = 0; i < KID_COUNT; i++) { h->prof_ms[i] = 0; h->prof_n[i] = 0; }
+    return 0;
+}
+int fe_profile_read(FeEngine* h, char* buf, int buf_len, double* ms_total, long long* launches, int cap) {
+    prof_drain(h);
+    std::string names;
+    for (int i = 0; i < KID_COUNT; i++) { if (i) names += "\n"; names += KNAMES[i]; }
+    std::snprintf(buf, buf_len, "%s", names.c_str());
+    for (int i = 0; i < KID_COUNT && i < cap; i++) { ms_total[i] = h->prof_ms[i]; launches[i] = h->prof_n[i]; }
+    return KID_COUNT;
+}
+
+} // extern "C"

@@ -1,0 +1,428 @@
+// fe_math.h — per-particle / per-node fp32 math of the MLS-MPM substep for gfx950.
+//
+// Everything here is straight-line register math (3x3 matrices live in VGPRs, loops are
+// fully unrolled); the kernels in fe_engine.hip own all memory traffic.  Functions are
+// __host__ __device__ so tests/csrc_math_test.cpp can exercise them on the build host.
+// Reference semantics are cited as mpm:NNN = fluidlab/fluidengine/simulators/mpm_simulator.py.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#define FE_HD __host__ __device__ __forceinline__
+
+// `real` is float in the product; tests/csrc/ builds this header with -DFE_T=double on the host
+// to check the hand-derived adjoints against finite differences at full precision.
+#ifndef FE_T
+#define FE_T float
+#endif
+typedef FE_T real;
+#define R_(x) ((real)(x))
+
+#define FE_EPS R_(1e-12)                 // fluidlab/configs/macros.py:213
+#define FE_MAT_LIQUID_ 200
+#define FE_MAT_PLASTO_ELASTIC_ 201
+#define FE_MAT_ELASTIC_ 202
+#define FE_MAT_RIGID_ 203
+#define FE_MAT_PLASTO_ELASTIC_DEMO_ 204
+
+struct m3 { real a[3][3]; };
+struct v3 { real a[3]; };
+
+FE_HD m3 m3_zero() { m3 r;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) r.a[i][j] = R_(0.0);
+    return r; }
+FE_HD m3 m3_ident() { m3 r = m3_zero(); r.a[0][0] = r.a[1][1] = r.a[2][2] = R_(1.0); return r; }
+FE_HD m3 m3_mul(const m3& x, const m3& y) { m3 r;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) r.a[i][j] = x.a[i][0] * y.a[0][j] + x.a[i][1] * y.a[1][j] + x.a[i][2] * y.a[2][j];
+    return r; }
+// x * y^T
+FE_HD m3 m3_mul_nt(const m3& x, const m3& y) { m3 r;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) r.a[i][j] = x.a[i][0] * y.a[j][0] + x.a[i][1] * y.a[j][1] + x.a[i][2] * y.a[j][2];
+    return r; }
+// x^T * y
+FE_HD m3 m3_mul_tn(const m3& x, const m3& y) { m3 r;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) r.a[i][j] = x.a[0][i] * y.a[0][j] + x.a[1][i] * y.a[1][j] + x.a[2][i] * y.a[2][j];
+    return r; }
+FE_HD m3 m3_T(const m3& x) { m3 r;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) r.a[i][j] = x.a[j][i];
+    return r; }
+FE_HD m3 m3_add(const m3& x, const m3& y) { m3 r;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) r.a[i][j] = x.a[i][j] + y.a[i][j];
+    return r; }
+FE_HD m3 m3_sub(const m3& x, const m3& y) { m3 r;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) r.a[i][j] = x.a[i][j] - y.a[i][j];
+    return r; }
+FE_HD m3 m3_scale(const m3& x, real s) { m3 r;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) r.a[i][j] = x.a[i][j] * s;
+    return r; }
+FE_HD m3 m3_had(const m3& x, const m3& y) { m3 r;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) r.a[i][j] = x.a[i][j] * y.a[i][j];
+    return r; }
+FE_HD real m3_det(const m3& x) {
+    return x.a[0][0] * (x.a[1][1] * x.a[2][2] - x.a[1][2] * x.a[2][1])
+         - x.a[0][1] * (x.a[1][0] * x.a[2][2] - x.a[1][2] * x.a[2][0])
+         + x.a[0][2] * (x.a[1][0] * x.a[2][1] - x.a[1][1] * x.a[2][0]);
+}
+FE_HD real m3_trace(const m3& x) { return x.a[0][0] + x.a[1][1] + x.a[2][2]; }
+// cofactor matrix: d det(x) / d x
+FE_HD m3 m3_cof(const m3& x) { m3 r;
+    r.a[0][0] = x.a[1][1] * x.a[2][2] - x.a[1][2] * x.a[2][1];
+    r.a[0][1] = x.a[1][2] * x.a[2][0] - x.a[1][0] * x.a[2][2];
+    r.a[0][2] = x.a[1][0] * x.a[2][1] - x.a[1][1] * x.a[2][0];
+    r.a[1][0] = x.a[0][2] * x.a[2][1] - x.a[0][1] * x.a[2][2];
+    r.a[1][1] = x.a[0][0] * x.a[2][2] - x.a[0][2] * x.a[2][0];
+    r.a[1][2] = x.a[0][1] * x.a[2][0] - x.a[0][0] * x.a[2][1];
+    r.a[2][0] = x.a[0][1] * x.a[1][2] - x.a[0][2] * x.a[1][1];
+    r.a[2][1] = x.a[0][2] * x.a[1][0] - x.a[0][0] * x.a[1][2];
+    r.a[2][2] = x.a[0][0] * x.a[1][1] - x.a[0][1] * x.a[1][0];
+    return r; }
+
+// ---------------------------------------------------------------------------------------
+// 3x3 SVD, contract of taichi 1.1.0 ti.svd (call site mpm:264): F = U diag(sig) V^T with
+// U, V proper rotations, |sig| descending, a negative determinant carried by sig[2].
+// One-sided (Hestenes) Jacobi on the columns of F: works on F itself, not F^T F, so fp32
+// keeps full relative accuracy for the near-identity F of fluids.  Fixed 5 sweeps, no
+// data-dependent loop exit => no wave divergence.
+// ---------------------------------------------------------------------------------------
+FE_HD void svd3_rot(m3& A, m3& V, const int p, const int q) {
+    real alpha = A.a[0][p] * A.a[0][p] + A.a[1][p] * A.a[1][p] + A.a[2][p] * A.a[2][p];
+    real beta  = A.a[0][q] * A.a[0][q] + A.a[1][q] * A.a[1][q] + A.a[2][q] * A.a[2][q];
+    real gamma = A.a[0][p] * A.a[0][q] + A.a[1][p] * A.a[1][q] + A.a[2][p] * A.a[2][q];
+    // skip when the columns are already orthogonal to fp32 precision (also avoids 0/0)
+    const real tol2 = sizeof(real) == 4 ? R_(1e-15) : R_(1e-31);   // (fp64 only in the host tests)
+    bool live = gamma * gamma > tol2 * alpha * beta && fabs(gamma) > R_(1e-30);
+    real g = live ? gamma : R_(1.0);
+    real zeta = (beta - alpha) / (R_(2.0) * g);
+    real t = copysign(R_(1.0), zeta) / (fabs(zeta) + sqrt(R_(1.0) + zeta * zeta));
+    real c = R_(1.0) / sqrt(R_(1.0) + t * t);
+    real s = c * t;
+    c = live ? c : R_(1.0);
+    s = live ? s : R_(0.0);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        real ap = A.a[i][p], aq = A.a[i][q];
+        A.a[i][p] = c * ap - s * aq; A.a[i][q] = s * ap + c * aq;
+        real vp = V.a[i][p], vq = V.a[i][q];
+        V.a[i][p] = c * vp - s * vq; V.a[i][q] = s * vp + c * vq;
+    }
+}
+
+FE_HD void m3_swap_cols(m3& A, int p, int q) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) { real t = A.a[i][p]; A.a[i][p] = A.a[i][q]; A.a[i][q] = t; }
+}
+
+FE_HD void svd3(const m3& F, m3& U, real sig[3], m3& V) {
+    m3 A = F;
+    V = m3_ident();
+#pragma unroll 1
+    for (int sweep = 0; sweep < (sizeof(real) == 4 ? 5 : 12); sweep++) {
+        svd3_rot(A, V, 0, 1);
+        svd3_rot(A, V, 0, 2);
+        svd3_rot(A, V, 1, 2);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) sig[j] = sqrt(A.a[0][j] * A.a[0][j] + A.a[1][j] * A.a[1][j] + A.a[2][j] * A.a[2][j]);
+    // sort descending: 3-element network, swapping the columns of A and V together
+    if (sig[0] < sig[1]) { real t = sig[0]; sig[0] = sig[1]; sig[1] = t; m3_swap_cols(A, 0, 1); m3_swap_cols(V, 0, 1); }
+    if (sig[1] < sig[2]) { real t = sig[1]; sig[1] = sig[2]; sig[2] = t; m3_swap_cols(A, 1, 2); m3_swap_cols(V, 1, 2); }
+    if (sig[0] < sig[1]) { real t = sig[0]; sig[0] = sig[1]; sig[1] = t; m3_swap_cols(A, 0, 1); m3_swap_cols(V, 0, 1); }
+    const real rel = fmax(sig[0] * R_(1e-6), R_(1e-30));
+    // column 0
+    if (sig[0] > R_(1e-30)) {
+        real inv = R_(1.0) / sig[0];
+#pragma unroll
+        for (int i = 0; i < 3; i++) U.a[i][0] = A.a[i][0] * inv;
+    } else { U.a[0][0] = R_(1.0); U.a[1][0] = R_(0.0); U.a[2][0] = R_(0.0); }
+    // column 1
+    if (sig[1] > rel) {
+        real inv = R_(1.0) / sig[1];
+#pragma unroll
+        for (int i = 0; i < 3; i++) U.a[i][1] = A.a[i][1] * inv;
+    } else {
+        // any unit vector orthogonal to column 0: e_k - (e_k.u0) u0 with k = argmin |u0_k|
+        // (selects only: a runtime-indexed register array would spill to scratch)
+        real a0 = fabs(U.a[0][0]), a1 = fabs(U.a[1][0]), a2 = fabs(U.a[2][0]);
+        bool k0 = a0 <= a1 && a0 <= a2;
+        bool k1 = !k0 && a1 <= a2;
+        bool k2 = !k0 && !k1;
+        // (arithmetic blend, not ?: — clang folds a select of loads into a dynamically indexed load,
+        //  which pins the whole Constitutive struct in scratch)
+        real e0 = k0 ? R_(1.0) : R_(0.0), e1 = k1 ? R_(1.0) : R_(0.0), e2 = k2 ? R_(1.0) : R_(0.0);
+        real d = e0 * U.a[0][0] + e1 * U.a[1][0] + e2 * U.a[2][0];
+        real w0 = e0 - d * U.a[0][0];
+        real w1 = e1 - d * U.a[1][0];
+        real w2 = e2 - d * U.a[2][0];
+        real inv = R_(1.0) / sqrt(w0 * w0 + w1 * w1 + w2 * w2);
+        U.a[0][1] = w0 * inv; U.a[1][1] = w1 * inv; U.a[2][1] = w2 * inv;
+    }
+    // column 2
+    if (sig[2] > rel) {
+        real inv = R_(1.0) / sig[2];
+#pragma unroll
+        for (int i = 0; i < 3; i++) U.a[i][2] = A.a[i][2] * inv;
+    } else {
+        U.a[0][2] = U.a[1][0] * U.a[2][1] - U.a[2][0] * U.a[1][1];
+        U.a[1][2] = U.a[2][0] * U.a[0][1] - U.a[0][0] * U.a[2][1];
+        U.a[2][2] = U.a[0][0] * U.a[1][1] - U.a[1][0] * U.a[0][1];
+    }
+    if (m3_det(U) < R_(0.0)) { U.a[0][2] = -U.a[0][2]; U.a[1][2] = -U.a[1][2]; U.a[2][2] = -U.a[2][2]; sig[2] = -sig[2]; }
+    if (m3_det(V) < R_(0.0)) { V.a[0][2] = -V.a[0][2]; V.a[1][2] = -V.a[1][2]; V.a[2][2] = -V.a[2][2]; sig[2] = -sig[2]; }
+}
+
+// mpm:294-302
+FE_HD real svd_clamp(real a) { return a >= R_(0.0) ? fmax(a, R_(1e-8)) : fmin(a, -R_(1e-8)); }
+
+// mpm:272-292 with a diagonal grad_S (the only form p2g's adjoint produces)
+FE_HD m3 backward_svd(const m3& gU, const real gS[3], const m3& gV, const m3& U, const real sig[3], const m3& V) {
+    real s2[3] = {sig[0] * sig[0], sig[1] * sig[1], sig[2] * sig[2]};
+    m3 a = m3_mul_tn(U, gU);      // U^T gU
+    m3 b = m3_mul_tn(V, gV);      // V^T gV
+    // inner = (Fm o (a - a^T)) S  +  S (Fm o (b - b^T))  +  diag(gS)
+    m3 inner;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            if (i == j) inner.a[i][j] = gS[i];
+            else {
+                real fm = R_(1.0) / svd_clamp(s2[j] - s2[i]);
+                inner.a[i][j] = fm * (a.a[i][j] - a.a[j][i]) * sig[j] + sig[i] * fm * (b.a[i][j] - b.a[j][i]);
+            }
+        }
+    return m3_mul_nt(m3_mul(U, inner), V);
+}
+
+// ---------------------------------------------------------------------------------------
+// boundaries (fluidlab/fluidengine/boundaries/boundaries.py)
+// ---------------------------------------------------------------------------------------
+struct BoundaryP {
+    int   type;          // 0 cube, 1 cylinder
+    real lower[3], upper[3];
+    real cx, cz, radius, restitution;
+    int   lock_dims;
+};
+
+// impose_x_v velocity part (boundaries.py:40-63, 107-121): multiplies v in place, returns multipliers
+FE_HD void boundary_v(const BoundaryP& b, const real x[3], real v[3], real k[3]) {
+    k[0] = k[1] = k[2] = R_(1.0);
+    if (b.type == 0) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            if (x[i] >= b.upper[i] && v[i] >= R_(0.0)) k[i] = -b.restitution;
+            else if (x[i] <= b.lower[i] && v[i] <= R_(0.0)) k[i] = -b.restitution;
+        }
+    } else {
+        if (x[1] > b.upper[1] && v[1] > R_(0.0)) k[1] = -b.restitution;
+        else if (x[1] < b.lower[1] && v[1] < R_(0.0)) k[1] = -b.restitution;
+        real rx = x[0] - b.cx, rz = x[2] - b.cz;
+        real nrm = sqrt(rx * rx + rz * rz + FE_EPS);
+        if (nrm > b.radius) { k[0] = R_(0.0); k[2] = R_(0.0); }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        if (b.lock_dims & (1 << i)) k[i] = R_(0.0);
+        v[i] = (k[i] == R_(1.0)) ? v[i] : ((k[i] == R_(0.0)) ? R_(0.0) : v[i] * k[i]);
+    }
+}
+
+// impose_x (boundaries.py:66-78, 123-126) and its Jacobian under Taichi's min/max adjoint rules
+FE_HD void boundary_x(const BoundaryP& b, const real x[3], real xn[3], real J[3][3]) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) J[i][j] = R_(0.0);
+        real m = fmin(x[i], b.upper[i]);
+        xn[i] = fmax(m, b.lower[i]);
+        J[i][i] = (x[i] < b.upper[i] && m > b.lower[i]) ? R_(1.0) : R_(0.0);
+    }
+    if (b.type == 1) {
+        real rx = x[0] - b.cx, rz = x[2] - b.cz;
+        real nrm = sqrt(rx * rx + rz * rz + FE_EPS);
+        if (nrm > b.radius) {
+            xn[0] = rx / nrm * b.radius + b.cx;
+            xn[2] = rz / nrm * b.radius + b.cz;
+            real k = b.radius / nrm, k3 = b.radius / (nrm * nrm * nrm);
+            J[0][0] = k - k3 * rx * rx; J[0][2] = -k3 * rx * rz;
+            J[2][0] = -k3 * rz * rx;    J[2][2] = k - k3 * rz * rz;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// quaternions (fluidlab/utils/geom.py:8-28, 97-102)
+// ---------------------------------------------------------------------------------------
+FE_HD void quat_mul(const real q[4], const real r[4], real out[4]) {
+    real w = r[0] * q[0] - r[1] * q[1] - r[2] * q[2] - r[3] * q[3];
+    real x = r[0] * q[1] + r[1] * q[0] - r[2] * q[3] + r[3] * q[2];
+    real y = r[0] * q[2] + r[1] * q[3] + r[2] * q[0] - r[3] * q[1];
+    real z = r[0] * q[3] - r[1] * q[2] + r[2] * q[1] + r[3] * q[0];
+    real inv = R_(1.0) / sqrt(w * w + x * x + y * y + z * z);
+    out[0] = w * inv; out[1] = x * inv; out[2] = y * inv; out[3] = z * inv;
+}
+FE_HD void quat_from_w(const real aa[3], real out[4]) {
+    real w = sqrt(aa[0] * aa[0] + aa[1] * aa[1] + aa[2] * aa[2] + FE_EPS);
+    real sh = sin(w * R_(0.5));
+    out[0] = cos(w * R_(0.5)); out[1] = aa[0] / w * sh; out[2] = aa[1] / w * sh; out[3] = aa[2] / w * sh;
+}
+FE_HD void quat_rotate(const real v[3], const real q[4], real out[3]) {
+    real ux = q[2] * v[2] - q[3] * v[1], uy = q[3] * v[0] - q[1] * v[2], uz = q[1] * v[1] - q[2] * v[0];
+    real wx = q[2] * uz - q[3] * uy, wy = q[3] * ux - q[1] * uz, wz = q[1] * uy - q[2] * ux;
+    out[0] = v[0] + R_(2.0) * (q[0] * ux + wx);
+    out[1] = v[1] + R_(2.0) * (q[0] * uy + wy);
+    out[2] = v[2] + R_(2.0) * (q[0] * uz + wz);
+}
+
+// ---------------------------------------------------------------------------------------
+// quadratic B-spline stencil (mpm:335-337)
+// ---------------------------------------------------------------------------------------
+struct Stencil {
+    int   base[3];
+    real fx[3];
+    real w[3][3];    // w[i][d]: weight of offset i along dimension d
+};
+FE_HD void stencil_make(const real x[3], real inv_dx, Stencil& s) {
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+        s.base[d] = (int)(x[d] * inv_dx - R_(0.5));     // truncation toward zero == Taichi cast(int)
+        real fx = x[d] * inv_dx - (real)s.base[d];
+        s.fx[d] = fx;
+        s.w[0][d] = R_(0.5) * (R_(1.5) - fx) * (R_(1.5) - fx);
+        s.w[1][d] = R_(0.75) - (fx - R_(1.0)) * (fx - R_(1.0));
+        s.w[2][d] = R_(0.5) * (fx - R_(0.5)) * (fx - R_(0.5));
+    }
+}
+FE_HD real stencil_dw(const Stencil& s, int i, int d) {
+    real fx = s.fx[d];
+    return i == 0 ? -(R_(1.5) - fx) : (i == 1 ? -R_(2.0) * (fx - R_(1.0)) : fx - R_(0.5));
+}
+FE_HD bool stencil_inside(const Stencil& s, int n) {
+    return s.base[0] >= 0 && s.base[1] >= 0 && s.base[2] >= 0 && s.base[0] + 2 < n && s.base[1] + 2 < n && s.base[2] + 2 < n;
+}
+
+// ---------------------------------------------------------------------------------------
+// constitutive model: everything p2g needs from (C, F) of one particle (mpm:254-264, 339-378)
+// ---------------------------------------------------------------------------------------
+struct Constitutive {
+    m3    Ft;         // F_tmp = (I + dt C) F
+    m3    U, V;       // only valid when `full`
+    real sig[3];     // only valid when `full`
+    real J;          // det S
+    m3    affine;     // stress*scale + mass*C   (mpm:342-344)
+    m3    Fnew;       // F[f+1]                  (mpm:355-378)
+    bool  full;       // SVD was needed (mu != 0 or a non-liquid class)
+};
+
+// `scale` = -dt * p_vol * 4 * inv_dx^2 (mpm:343)
+FE_HD void constitutive_eval(const m3& C, const m3& F, real dt, real mu, real lam, real mass, int cls, real scale,
+                             Constitutive& k) {
+    m3 IdtC = m3_scale(C, dt);
+    IdtC.a[0][0] += R_(1.0); IdtC.a[1][1] += R_(1.0); IdtC.a[2][2] += R_(1.0);
+    k.Ft = m3_mul(IdtC, F);
+    // An inviscid liquid (mu == 0, MAT_LIQUID: WATER/MILK/COFFEE) consumes only J = det S = det F_tmp
+    // (U, V proper rotations), so the SVD is skipped: stress = lam J (J-1) I and F_new = J^(1/3) I.
+    k.full = !(mu == R_(0.0) && cls == FE_MAT_LIQUID_);
+    m3 stress = m3_zero();
+    if (k.full) {
+        svd3(k.Ft, k.U, k.sig, k.V);
+        k.J = k.sig[0] * k.sig[1] * k.sig[2];
+        m3 r = m3_mul_nt(k.U, k.V);
+        stress = m3_scale(m3_mul_nt(m3_sub(k.Ft, r), k.Ft), R_(2.0) * mu);
+    } else {
+        k.J = m3_det(k.Ft);
+    }
+    real iso = lam * k.J * (k.J - R_(1.0));
+    stress.a[0][0] += iso; stress.a[1][1] += iso; stress.a[2][2] += iso;
+    k.affine = m3_add(m3_scale(stress, scale), m3_scale(C, mass));
+    if (cls == FE_MAT_LIQUID_) {
+        real c = pow(k.J, R_(1.0) / R_(3.0));           // NaN for J < 0, like ti.pow (mpm:359)
+        k.Fnew = m3_zero(); k.Fnew.a[0][0] = k.Fnew.a[1][1] = k.Fnew.a[2][2] = c;
+    } else if (cls == FE_MAT_ELASTIC_ || cls == FE_MAT_RIGID_) {
+        k.Fnew = k.Ft;
+    } else {    // PLASTO_ELASTIC and PLASTO_ELASTIC_DEMO are identical (mpm:367-376)
+        m3 US = k.U;
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            real sn = fmin(fmax(k.sig[d], R_(1.0) - R_(2e-3)), R_(1.0) + R_(3e-3));
+            US.a[0][d] *= sn; US.a[1][d] *= sn; US.a[2][d] *= sn;
+        }
+        k.Fnew = m3_mul_nt(US, k.V);
+    }
+}
+
+// Adjoint of constitutive_eval: given GA = d/d(affine) (already including the sum over nodes) and
+// Fg = d/d(F[f+1]), accumulate gC, gF (the adjoints of C[f], F[f]).  Follows p2g.grad, svd_grad and
+// compute_F_tmp.grad (mpm:544-546); closed forms in SURVEY.md Appendix A.
+FE_HD void constitutive_grad(const m3& C, const m3& F, real dt, real mu, real lam, real mass, int cls, real scale,
+                             const Constitutive& k, const m3& GA, const m3& Fg, m3& gC, m3& gF) {
+    gC = m3_scale(GA, mass);                       // affine = stress + m C
+    m3 gs = m3_scale(GA, scale);                   // adjoint of the unscaled stress
+    real gJ = lam * (R_(2.0) * k.J - R_(1.0)) * m3_trace(gs);
+    m3 gFt;
+    if (cls == FE_MAT_LIQUID_) gJ += (R_(1.0) / R_(3.0)) * pow(k.J, R_(1.0) / R_(3.0) - R_(1.0)) * m3_trace(Fg);
+    if (!k.full) {
+        // J = det F_tmp  =>  d J / d F_tmp = cof(F_tmp)
+        gFt = m3_scale(m3_cof(k.Ft), gJ);
+    } else {
+        m3 r = m3_mul_nt(k.U, k.V);
+        m3 P = m3_sub(k.Ft, r);
+        real mu2 = R_(2.0) * mu;
+        gFt = m3_scale(m3_add(m3_mul(gs, k.Ft), m3_mul_tn(gs, P)), mu2);
+        m3 gr = m3_scale(m3_mul(gs, k.Ft), -mu2);
+        m3 gU = m3_mul(gr, k.V);
+        m3 gV = m3_mul_tn(gr, k.U);
+        real gS[3] = {R_(0.0), R_(0.0), R_(0.0)};
+        if (cls == FE_MAT_ELASTIC_ || cls == FE_MAT_RIGID_) {
+            gFt = m3_add(gFt, Fg);
+        } else if (cls != FE_MAT_LIQUID_) {
+            const real lo = R_(1.0) - R_(2e-3), hi = R_(1.0) + R_(3e-3);
+            m3 UtFgV = m3_mul(m3_mul_tn(k.U, Fg), k.V);
+            m3 FgV = m3_mul(Fg, k.V), FgtU = m3_mul_tn(Fg, k.U);
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                real sd = k.sig[d];
+                real sn = fmin(fmax(sd, lo), hi);
+                bool pass = (sd > lo) && (fmax(sd, lo) < hi);      // Taichi max/min adjoint tie rules
+                if (pass) gS[d] += UtFgV.a[d][d];
+#pragma unroll
+                for (int i = 0; i < 3; i++) { gU.a[i][d] += FgV.a[i][d] * sn; gV.a[i][d] += FgtU.a[i][d] * sn; }
+            }
+        }
+        gS[0] += gJ * k.sig[1] * k.sig[2];
+        gS[1] += gJ * k.sig[0] * k.sig[2];
+        gS[2] += gJ * k.sig[0] * k.sig[1];
+        gFt = m3_add(gFt, backward_svd(gU, gS, gV, k.U, k.sig, k.V));
+    }
+    // F_tmp = (I + dt C) F
+    gC = m3_add(gC, m3_scale(m3_mul_nt(gFt, F), dt));
+    m3 IdtC = m3_scale(C, dt);
+    IdtC.a[0][0] += R_(1.0); IdtC.a[1][1] += R_(1.0); IdtC.a[2][2] += R_(1.0);
+    gF = m3_mul_tn(IdtC, gFt);
+}

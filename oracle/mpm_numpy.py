@@ -1,0 +1,121 @@
+"""TEST INFRASTRUCTURE -- a second, independent restatement of the forward MLS-MPM substep.
+
+Vectorised numpy (fp64) version of mpm_simulator.py's forward kernels, written separately
+from oracle/fe_oracle.cpp so the two restatements can be checked against each other
+(tests/test_oracle.py).  PARITY UNPINNED: the reference ships no vectors for this path.
+
+Citations `mpm:NNN` = fluidlab/fluidengine/simulators/mpm_simulator.py.
+"""
+import numpy as np
+
+MAT_LIQUID, MAT_PLASTO_ELASTIC, MAT_ELASTIC, MAT_RIGID, MAT_PLASTO_ELASTIC_DEMO = 200, 201, 202, 203, 204
+EPS = 1e-12
+
+
+def proper_svd(F):
+    """ti.svd contract (mpm:264): U, V rotations, sign carried by the smallest singular value."""
+    U, s, Vt = np.linalg.svd(F)
+    V = np.swapaxes(Vt, -1, -2).copy()
+    U = U.copy()
+    s = s.copy()
+    neg = np.linalg.det(U) < 0
+    U[neg, :, 2] *= -1
+    s[neg, 2] *= -1
+    neg = np.linalg.det(V) < 0
+    V[neg, :, 2] *= -1
+    s[neg, 2] *= -1
+    return U, s, V
+
+
+def weights(x, inv_dx):
+    base = (x * inv_dx - 0.5).astype(np.int64)          # mpm:335 (positive coordinates: trunc == floor)
+    fx = x * inv_dx - base
+    w = np.stack([0.5 * (1.5 - fx) ** 2, 0.75 - (fx - 1.0) ** 2, 0.5 * (fx - 0.5) ** 2], axis=0)   # [3, N, 3]
+    return base, fx, w
+
+
+def boundary_v(bnd, xn, v):
+    """impose_x_v velocity part, boundaries.py:40-63 / 107-121."""
+    v = v.copy()
+    r = bnd.get('restitution', 0.0)
+    if bnd['type'] == 'cube':
+        lo, up = np.asarray(bnd['lower']), np.asarray(bnd['upper'])
+        for i in range(3):
+            hit = ((xn[:, i] >= up[i]) & (v[:, i] >= 0)) | ((xn[:, i] <= lo[i]) & (v[:, i] <= 0))
+            v[hit, i] *= -r
+    else:
+        y0, y1 = bnd['y_range']
+        hit = ((xn[:, 1] > y1) & (v[:, 1] > 0)) | ((xn[:, 1] < y0) & (v[:, 1] < 0))
+        v[hit, 1] *= -r
+        c = np.asarray(bnd['xz_center'])
+        rv = xn[:, [0, 2]] - c
+        nrm = np.sqrt((rv ** 2).sum(1) + EPS)
+        out = nrm > bnd['xz_radius']
+        v[out, 0] = 0.0
+        v[out, 2] = 0.0
+    for d in bnd.get('lock_dims', ()):
+        v[:, d] = 0.0
+    return v
+
+
+def substep(x, v, C, F, used, mu, lam, mass, mat_cls, n_grid, dt, p_vol, gravity, bnd):
+    """One forward substep (mpm:515-533, no agent).  Returns x', v', C', F'."""
+    n = n_grid
+    dx, inv_dx = 1.0 / n, float(n)
+    act = used.astype(bool)
+    xs, vs, Cs, Fs = x[act], v[act], C[act], F[act]
+    mus, lams, ms, cls = mu[act], lam[act], mass[act], mat_cls[act]
+    I = np.eye(3)
+    Ft = (I + dt * Cs) @ Fs                                             # mpm:258
+    U, s, V = proper_svd(Ft)
+    J = s.prod(1)                                                       # mpm:339
+    r = U @ np.swapaxes(V, 1, 2)
+    stress = 2 * mus[:, None, None] * (Ft - r) @ np.swapaxes(Ft, 1, 2) + I * (lams * J * (J - 1))[:, None, None]
+    stress = (-dt * p_vol * 4 * inv_dx * inv_dx) * stress               # mpm:343
+    affine = stress + ms[:, None, None] * Cs
+    base, fx, w = weights(xs, inv_dx)
+    g_v = np.zeros((n, n, n, 3))
+    g_m = np.zeros((n, n, n))
+    for i in range(3):
+        for j in range(3):
+            for k in range(3):
+                off = np.array([i, j, k])
+                dpos = (off - fx) * dx
+                wt = w[i][:, 0] * w[j][:, 1] * w[k][:, 2]
+                idx = base + off
+                np.add.at(g_v, (idx[:, 0], idx[:, 1], idx[:, 2]), wt[:, None] * (ms[:, None] * vs + np.einsum('nab,nb->na', affine, dpos)))
+                np.add.at(g_m, (idx[:, 0], idx[:, 1], idx[:, 2]), wt * ms)
+    Fn = np.zeros_like(Fs)
+    liq = cls == MAT_LIQUID
+    Fn[liq] = I * np.cbrt(J[liq])[:, None, None]                        # J > 0 in all tests
+    ela = (cls == MAT_ELASTIC) | (cls == MAT_RIGID)
+    Fn[ela] = Ft[ela]
+    pla = (cls == MAT_PLASTO_ELASTIC) | (cls == MAT_PLASTO_ELASTIC_DEMO)
+    sn = np.clip(s, 1 - 2e-3, 1 + 3e-3)
+    Fn[pla] = (U[pla] * sn[pla][:, None, :]) @ np.swapaxes(V[pla], 1, 2)
+    # grid_op (mpm:380-398)
+    occ = g_m > EPS
+    v_out = np.zeros_like(g_v)
+    ii, jj, kk = np.nonzero(occ)
+    vo = g_v[occ] / g_m[occ][:, None] + dt * np.asarray(gravity)
+    xn = np.stack([ii, jj, kk], 1) * dx
+    v_out[occ] = boundary_v(bnd, xn, vo)
+    # g2p (mpm:400-426)
+    nv = np.zeros_like(vs)
+    nC = np.zeros_like(Cs)
+    for i in range(3):
+        for j in range(3):
+            for k in range(3):
+                off = np.array([i, j, k])
+                dpos = off - fx
+                wt = w[i][:, 0] * w[j][:, 1] * w[k][:, 2]
+                idx = base + off
+                gv = v_out[idx[:, 0], idx[:, 1], idx[:, 2]]
+                nv += wt[:, None] * gv
+                nC += 4 * inv_dx * wt[:, None, None] * gv[:, :, None] * dpos[:, None, :]
+    x2, v2, C2, F2 = x.copy(), v.copy(), C.copy(), F.copy()
+    x2[act] = xs + dt * nv                                              # mpm:505
+    v2[act] = nv
+    C2[act] = nC
+    F2[act] = Fn
+    return x2, v2, C2, F2, dict(grid_mass=g_m, grid_v_in=g_v, grid_v_out=v_out)

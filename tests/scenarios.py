@@ -1,0 +1,173 @@
+"""Seeded scenes shared by the oracle tests, the GPU parity tests, smoke() and the golden
+fixtures.  Every scene is a plain dict of float32-representable numpy arrays, so the fp64
+oracle and the fp32 HIP engine see bit-identical inputs."""
+import numpy as np
+
+from fluidlab_amd._capi import Engine, FE_EFF_INJECTOR
+
+WATER, MILK, COFFEE, ELASTIC, ICECREAM, MILK_VIS = 0, 1, 2, 3, 4, 8
+MAT_LIQUID, MAT_PLASTO_ELASTIC, MAT_ELASTIC = 200, 201, 202
+# (mu, lam, rho, class) -- fluidlab/configs/macros.py:65-83,143-201
+MATERIALS = {
+    WATER: (0.0, 277.78, 1.0, MAT_LIQUID), MILK: (0.0, 277.78, 0.5, MAT_LIQUID), COFFEE: (0.0, 277.78, 1.0, MAT_LIQUID),
+    ELASTIC: (416.67, 277.78, 1.0, MAT_ELASTIC), ICECREAM: (416.67, 277.78, 0.5, MAT_PLASTO_ELASTIC),
+    MILK_VIS: (200.0, 277.78, 1.0, MAT_LIQUID),
+}
+
+
+def f32(a):
+    return np.asarray(a, dtype=np.float32)
+
+
+def water_block(n_grid=32, n_particles=4096, seed=0, lo=0.30, hi=0.53, gravity=(0.0, -10.0, 0.0)):
+    """BASELINE config 2 at a size the oracle finishes in seconds."""
+    rng = np.random.RandomState(seed)
+    N = n_particles
+    return dict(
+        n_grid=n_grid, N=N, dt=2e-4, gravity=gravity, n_substeps=10,
+        boundary=dict(type='cube', lower=(0.05, 0.05, 0.05), upper=(0.95, 0.95, 0.95)),
+        x=f32(rng.uniform(lo, hi, (N, 3))), used=np.ones(N, np.int32), mat=np.full(N, WATER, np.int32),
+    )
+
+
+def mixed_materials(n_grid=16, n_particles=1500, seed=1):
+    """All constitutive branches in one block, moving, with non-trivial C and F."""
+    rng = np.random.RandomState(seed)
+    N = n_particles
+    mats = np.array([WATER, MILK_VIS, ELASTIC, ICECREAM], np.int32)[rng.randint(0, 4, N)]
+    sc = dict(
+        n_grid=n_grid, N=N, dt=2e-4, gravity=(0.0, -10.0, 0.0), n_substeps=10,
+        boundary=dict(type='cube', lower=(0.2, 0.2, 0.2), upper=(0.8, 0.8, 0.8)),
+        x=f32(rng.uniform(0.22, 0.6, (N, 3))), used=(rng.uniform(size=N) > 0.1).astype(np.int32), mat=mats,
+    )
+    sc['v'] = f32(rng.normal(0, 0.5, (N, 3)))
+    sc['C'] = f32(rng.normal(0, 2.0, (N, 3, 3)))
+    Fn = np.where((mats == ICECREAM)[:, None, None], 0.002, 0.03)
+    sc['F'] = f32(np.eye(3)[None] + rng.normal(0, 1.0, (N, 3, 3)) * Fn)
+    return sc
+
+
+def latte_mini(n_grid=16, n_coffee=1200, n_pool=200, seed=2, horizon=6, n_substeps=4, flux=2):
+    """A small LatteArt: coffee in a cylinder, a milk pool injected by an Injector effector
+    (latteart_env.py:38-75, agent_latteart.yaml), squared-distance loss on the milk."""
+    rng = np.random.RandomState(seed)
+    c = np.array([0.5, 0.45, 0.5])
+    pts = []
+    while sum(len(p) for p in pts) < n_coffee:
+        p = rng.uniform([0.5 - 0.3, 0.4, 0.5 - 0.3], [0.5 + 0.3, 0.5, 0.5 + 0.3], (4 * n_coffee, 3))
+        pts.append(p[np.linalg.norm(p[:, [0, 2]] - c[[0, 2]], axis=1) <= 0.3])
+    coffee = np.concatenate(pts)[:n_coffee]
+    N = n_pool + n_coffee
+    x = np.concatenate([np.tile([-100.0, -100.0, -100.0], (n_pool, 1)), coffee])      # NOWHERE pool first (latteart_env.py:54-66)
+    L = horizon * n_substeps
+    sc = dict(
+        n_grid=n_grid, N=N, dt=2e-4, gravity=(0.0, -20.0, 0.0), n_substeps=n_substeps, horizon=horizon,
+        max_substeps_local=L + n_substeps,
+        boundary=dict(type='cylinder', xz_radius=0.32, xz_center=(0.5, 0.5), y_range=(0.38, 0.9)),
+        x=f32(x), used=np.concatenate([np.zeros(n_pool, np.int32), np.ones(n_coffee, np.int32)]),
+        mat=np.concatenate([np.full(n_pool, MILK, np.int32), np.full(n_coffee, COFFEE, np.int32)]),
+        injector=dict(radius=0.02, flux=flux, inject_v=(0.0, -3.0, 0.0), inject_p=(0.0, 0.0, 0.0), action_dim=3,
+                      action_scale_v=(1.0, 1.0, 1.0), action_scale_p=(1.0, 1.0, 1.0), locally_random=True,
+                      boundary=dict(type='cylinder', xz_radius=0.32, xz_center=(0.5, 0.5), y_range=(0.62, 0.62)),
+                      random_vector=f32(rng.uniform(size=(L + n_substeps, flux, 3)))),
+        action_p=f32([0.42, 0.62, 0.5]),
+        actions=f32(rng.uniform(-0.01, 0.01, (horizon, 3))),
+        matching_mat=MILK,
+    )
+    sc['target'] = f32(rng.uniform(0.35, 0.65, (horizon, N, 3)))
+    return sc
+
+
+# ------------------------------------------------------------------------------------------
+def make_engine(elib, sc, max_substeps_local=None, device=0):
+    n = sc['n_grid']
+    L = max_substeps_local or sc.get('max_substeps_local', 64)
+    eng = Engine(elib, n_grid=n, n_particles=sc['N'], max_substeps_local=L, n_substeps=sc['n_substeps'],
+                 max_action_steps=sc.get('horizon', 8), dt=sc['dt'], p_vol=(0.5 / n) ** 2, gravity=sc['gravity'],
+                 boundary=elib.make_boundary(**sc['boundary']), device=device)
+    mat = sc['mat']
+    props = np.array([MATERIALS[int(m)] for m in mat], dtype=np.float64)
+    eng.init_particles(sc['x'], sc['used'], mat, props[:, 3].astype(np.int32), props[:, 0], props[:, 1], props[:, 2],
+                       np.zeros(sc['N'], np.int32))
+    if any(k in sc for k in ('v', 'C', 'F')):
+        eng.set_frame(0, v=sc.get('v'), C_=sc.get('C'), F=sc.get('F'))
+    return eng
+
+
+def get_state(eng, f):
+    N, dt = eng.N, eng.dtype
+    x = np.zeros((N, 3), dt); v = np.zeros((N, 3), dt); C = np.zeros((N, 3, 3), dt); F = np.zeros((N, 3, 3), dt)
+    used = np.zeros((N,), np.int32)
+    eng.get_frame(f, x, v, C, F, used)
+    return dict(x=x, v=v, C=C, F=F, used=used)
+
+
+def run_forward(eng, n_sub, f0=0):
+    for f in range(f0, f0 + n_sub):
+        eng.substep(f, f, 0)
+    return get_state(eng, f0 + n_sub)
+
+
+def run_forward_backward(eng, n_sub, cot):
+    """Forward n_sub substeps from frame 0, seed the cotangent `cot` (dict gx,gv,gC,gF) on the
+    last frame, backward to frame 0.  Returns (final state, grads at frame 0)."""
+    st = run_forward(eng, n_sub)
+    eng.reset_grad()
+    eng.add_grad(n_sub, cot['gx'], cot['gv'], cot['gC'], cot['gF'])
+    for f in reversed(range(n_sub)):
+        eng.substep_grad(f, f, 0)
+    gx, gv, gC, gF = eng.get_grad(0)
+    return st, dict(gx=gx, gv=gv, gC=gC, gF=gF)
+
+
+def random_cotangent(N, seed=5):
+    rng = np.random.RandomState(seed)
+    return dict(gx=f32(rng.normal(size=(N, 3))), gv=f32(rng.normal(size=(N, 3)) * 1e-2),
+                gC=f32(rng.normal(size=(N, 3, 3)) * 1e-4), gF=f32(rng.normal(size=(N, 3, 3)) * 1e-2))
+
+
+def run_latte(elib, sc, device=0):
+    """Full mini trajectory optimisation pass through the raw ABI, mirroring Solver.forward_backward
+    (optimizer/solver.py:23-59): forward with loss, backward, action gradient."""
+    eng = make_engine(elib, sc, device=device)
+    inj = sc['injector']
+    e = eng.add_effector(type=FE_EFF_INJECTOR, action_dim=inj['action_dim'], action_scale_v=inj['action_scale_v'],
+                         action_scale_p=inj['action_scale_p'], boundary=elib.make_boundary(**inj['boundary']),
+                         flux=inj['flux'], radius=inj['radius'], inject_v=inj['inject_v'], inject_p=inj['inject_p'],
+                         locally_random=inj['locally_random'], random_vector=inj['random_vector'])
+    eng.eff_set_act_range(e, np.where(sc['used'] == 0)[0].astype(np.int32))
+    st0 = eng.eff_get_state(e, 0)
+    st0[:7] = [0.5, 0.5, 0.5, 1.0, 0.0, 0.0, 0.0]
+    eng.eff_set_state(e, 0, st0)
+    H, ns = sc['horizon'], sc['n_substeps']
+    eng.loss_alloc(H)
+    for s in range(H):
+        eng.loss_set_target(s, sc['target'][s])
+    eng.loss_clear()
+    eng.eff_apply_action_p(e, sc['action_p'])
+    for s in range(H):
+        eng.eff_set_action(e, s, s, ns, sc['actions'][s])
+        eng.step(s * ns, s * ns, ns, 1)
+        eng.loss_step(s, (s + 1) * ns, sc['matching_mat'], 1.0)
+    step_loss = eng.loss_get(H)
+    final = get_state(eng, H * ns)
+    eng.reset_grad()
+    for s in reversed(range(H)):
+        eng.loss_step_grad(s, (s + 1) * ns, sc['matching_mat'], 1.0, 1.0)
+        eng.step_grad(s * ns, s * ns, ns, 1)
+        eng.eff_set_action_grad(e, s, s, ns)
+    eng.eff_apply_action_p_grad(e)
+    grad = eng.eff_get_action_grad(e, 0, H, 3)
+    eff_state = eng.eff_get_state(e, H * ns)
+    eng.close()
+    return dict(step_loss=step_loss, final=final, action_grad=grad, eff_state=eff_state)
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def cosine(a, b):
+    a = np.asarray(a, np.float64).ravel(); b = np.asarray(b, np.float64).ravel()
+    return float(a @ b / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-300))

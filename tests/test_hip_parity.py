@@ -1,0 +1,122 @@
+"""GPU parity: the gfx950 HIP engine against the fp64 CPU oracle on identical inputs, through the C ABI.
+
+Tolerances (SURVEY 8c, fp32 engine vs fp64 oracle; both sides of the reference are themselves
+order-nondeterministic in fp32 because of float atomics):
+  one substep      max|dx| <= 1e-6,  max|dv| <= 1e-4 * max(1, |v|inf)
+  50 substeps      rel L2(x) <= 1e-4
+  adjoints         cosine >= 0.999 and rel L2 <= 1e-2 (mu = 0 liquids much tighter)
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(__file__))
+import scenarios as S  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def test_native_library_is_the_one_loaded(hiplib):
+    assert hiplib.backend == 'hip-gfx950'
+    assert os.path.samefile(hiplib.path, os.path.join(os.path.dirname(S.__file__), '..', 'fluidlab_amd', 'csrc', 'libfluidengine_hip.so'))
+
+
+def test_water_block_forward(hiplib, oracle64):
+    sc = S.water_block(n_grid=32, n_particles=8192)
+    g = S.make_engine(hiplib, sc)
+    o = S.make_engine(oracle64, sc)
+    a, b = S.run_forward(g, 1), S.run_forward(o, 1)
+    assert np.abs(a['x'] - b['x']).max() <= 1e-6
+    assert np.abs(a['v'] - b['v']).max() <= 1e-4 * max(1.0, np.abs(b['v']).max())
+    assert np.abs(a['F'] - b['F']).max() <= 1e-6
+    assert S.rel_l2(a['C'], b['C']) <= 1e-3
+    a, b = S.run_forward(g, 49, f0=1), S.run_forward(o, 49, f0=1)
+    assert S.rel_l2(a['x'], b['x']) <= 1e-4
+    assert S.rel_l2(a['v'], b['v']) <= 1e-2
+    assert (a['used'] == b['used']).all()
+    g.sync()
+
+
+def test_all_materials_forward(hiplib, oracle64):
+    sc = S.mixed_materials()
+    a = S.run_forward(S.make_engine(hiplib, sc), 10)
+    b = S.run_forward(S.make_engine(oracle64, sc), 10)
+    assert np.abs(a['x'] - b['x']).max() <= 1e-5
+    assert S.rel_l2(a['v'], b['v']) <= 1e-3
+    assert S.rel_l2(a['F'], b['F']) <= 1e-5
+    assert S.rel_l2(a['C'], b['C']) <= 1e-2
+    unused = sc['used'] == 0
+    for k in 'xvCF':                                       # unused particles are carried unchanged
+        assert (a[k][unused] == b[k][unused].astype(np.float32)).all()
+
+
+@pytest.mark.parametrize('scene', ['water', 'mixed'])
+def test_substep_adjoint(hiplib, oracle64, scene):
+    if scene == 'water':
+        sc = S.water_block(n_grid=16, n_particles=2000)
+        sc['v'] = S.f32(np.random.RandomState(9).normal(0, 0.5, (2000, 3)))
+        tol_l2 = 2e-3
+    else:
+        sc = S.mixed_materials()
+        tol_l2 = 1e-2
+    cot = S.random_cotangent(sc['N'])
+    _, ga = S.run_forward_backward(S.make_engine(hiplib, sc), 6, cot)
+    _, gb = S.run_forward_backward(S.make_engine(oracle64, sc), 6, {k: v.astype(np.float64) for k, v in cot.items()})
+    for k in ('gx', 'gv', 'gC', 'gF'):
+        assert np.isfinite(ga[k]).all(), k
+        assert S.cosine(ga[k], gb[k]) >= 0.999, (k, S.cosine(ga[k], gb[k]))
+        assert S.rel_l2(ga[k], gb[k]) <= tol_l2, (k, S.rel_l2(ga[k], gb[k]))
+
+
+def test_latte_mini_trajectory_gradient(hiplib, oracle64):
+    """Injector + cylinder boundary + loss + action gradient, end to end."""
+    sc = S.latte_mini()
+    a = S.run_latte(hiplib, sc)
+    b = S.run_latte(oracle64, sc)
+    assert (a['final']['used'] == b['final']['used']).all()
+    assert a['final']['used'].sum() == (sc['used'] == 1).sum() + sc['horizon'] * sc['n_substeps'] * sc['injector']['flux']
+    assert S.rel_l2(a['final']['x'], b['final']['x']) <= 1e-5
+    assert S.rel_l2(a['step_loss'], b['step_loss']) <= 1e-4
+    assert np.abs(a['eff_state'] - b['eff_state']).max() <= 1e-6
+    assert S.cosine(a['action_grad'], b['action_grad']) >= 0.999
+    assert S.rel_l2(a['action_grad'], b['action_grad']) <= 1e-2
+
+
+def test_roundtrip_and_frame_ops(hiplib):
+    sc = S.mixed_materials(n_particles=777)          # ragged: not a multiple of the wave size
+    eng = S.make_engine(hiplib, sc, max_substeps_local=4)
+    st = S.get_state(eng, 0)
+    assert (st['x'] == sc['x']).all() and (st['v'] == sc['v']).all() and (st['C'] == sc['C']).all() and (st['F'] == sc['F']).all()
+    assert (st['used'] == sc['used']).all()
+    eng.copy_frame(0, 3)
+    st3 = S.get_state(eng, 3)
+    assert all((st3[k] == st[k]).all() for k in st)
+    cot = S.random_cotangent(sc['N'])
+    eng.reset_grad()
+    eng.add_grad(2, cot['gx'], cot['gv'], cot['gC'], cot['gF'])
+    gx, gv, gC, gF = eng.get_grad(2)
+    assert (gx == cot['gx']).all() and (gF == cot['gF']).all()
+    stats = eng.get_stats(0)
+    assert stats['n_used'] == int(sc['used'].sum()) and stats['n_cells_touched'] > 0
+    from fluidlab_amd._capi import FeEngineError
+    with pytest.raises(FeEngineError, match='out of range'):
+        eng.substep(4, 4, 0)
+
+
+def test_empty_and_all_unused(hiplib):
+    sc = S.water_block(n_grid=8, n_particles=64)
+    sc['used'] = np.zeros(64, np.int32)
+    eng = S.make_engine(hiplib, sc, max_substeps_local=4)
+    a = S.run_forward(eng, 3)
+    assert (a['x'] == sc['x']).all() and (a['used'] == 0).all()
+    eng.sync()
+
+
+def test_stats_match_oracle(hiplib, oracle64):
+    sc = S.water_block(n_grid=32, n_particles=5000)
+    a = S.make_engine(hiplib, sc).get_stats(0)
+    b = S.make_engine(oracle64, sc).get_stats(0)
+    for k in ('n_used', 'n_cells_touched', 'n_blocks_active'):
+        assert a[k] == b[k], k

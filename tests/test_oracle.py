@@ -1,0 +1,163 @@
+"""CPU tests of the oracle (oracle/fe_oracle.cpp).
+
+The reference has no tests or golden vectors for this path (parity unpinned), so
+the oracle is pinned three ways here: against a second, independently written numpy restatement
+(oracle/mpm_numpy.py), against the structural invariants of MLS-MPM, and -- for the hand-derived
+adjoints the reference gets from Taichi autodiff -- against central finite differences."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(__file__))
+import scenarios as S  # noqa: E402
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle'))
+import mpm_numpy  # noqa: E402
+
+
+def test_oracle_matches_numpy_restatement(oracle64):
+    sc = S.mixed_materials()
+    eng = S.make_engine(oracle64, sc)
+    st = S.get_state(eng, 0)
+    props = np.array([S.MATERIALS[int(m)] for m in sc['mat']])
+    n = sc['n_grid']
+    x, v, C, F = (st[k].astype(np.float64) for k in 'xvCF')
+    for f in range(3):
+        eng.substep(f, f, 0)
+        x, v, C, F, _ = mpm_numpy.substep(x, v, C, F, sc['used'], props[:, 0], props[:, 1], (0.5 / n) ** 2 * props[:, 2],
+                                          props[:, 3].astype(int), n, sc['dt'], (0.5 / n) ** 2, sc['gravity'], sc['boundary'])
+    got = S.get_state(eng, 3)
+    for k, ref in zip('xvCF', (x, v, C, F)):
+        assert np.abs(got[k] - ref).max() < 1e-9 * max(1.0, np.abs(ref).max()), k
+
+
+def test_cylinder_boundary_matches_numpy(oracle64):
+    sc = S.latte_mini()
+    sc = dict(sc, used=np.where(sc['used'] == 1, 1, 0).astype(np.int32))
+    eng = S.make_engine(oracle64, sc)
+    st = S.get_state(eng, 0)
+    props = np.array([S.MATERIALS[int(m)] for m in sc['mat']])
+    n = sc['n_grid']
+    x, v, C, F = (st[k].astype(np.float64) for k in 'xvCF')
+    for f in range(12):
+        eng.substep(f, f, 0)
+        x, v, C, F, _ = mpm_numpy.substep(x, v, C, F, sc['used'], props[:, 0], props[:, 1], (0.5 / n) ** 2 * props[:, 2],
+                                          props[:, 3].astype(int), n, sc['dt'], (0.5 / n) ** 2, sc['gravity'], sc['boundary'])
+    got = S.get_state(eng, 12)
+    act = sc['used'] == 1
+    assert np.abs(got['x'][act] - x[act]).max() < 1e-10
+    assert np.abs(got['v'][act] - v[act]).max() < 1e-8
+    # unused pool particles are copied frame to frame (mpm:309-316)
+    assert (got['x'][~act] == -100.0).all()
+
+
+def test_invariants(oracle64):
+    sc = S.water_block(n_grid=16, n_particles=600, lo=0.3, hi=0.6)
+    props = np.array([S.MATERIALS[int(m)] for m in sc['mat']])
+    n = sc['n_grid']
+    x = sc['x'].astype(np.float64)
+    N = sc['N']
+    v = np.tile([0.3, -0.2, 0.1], (N, 1))
+    C = np.zeros((N, 3, 3)); F = np.tile(np.eye(3), (N, 1, 1))
+    mass = (0.5 / n) ** 2 * props[:, 2]
+    _, v2, C2, F2, aux = mpm_numpy.substep(x, v, C, F, sc['used'], props[:, 0], props[:, 1], mass, props[:, 3].astype(int), n,
+                                           sc['dt'], (0.5 / n) ** 2, (0, 0, 0), sc['boundary'])
+    # P2G conserves mass and momentum; G2P of a constant field returns it with C = 0
+    assert abs(aux['grid_mass'].sum() - mass.sum()) < 1e-12 * mass.sum()
+    assert np.abs(aux['grid_v_in'].sum((0, 1, 2)) - (mass[:, None] * v).sum(0)).max() < 1e-12
+    assert np.abs(v2 - v).max() < 1e-12 and np.abs(C2).max() < 1e-9
+    # and the C++ oracle agrees
+    eng = S.make_engine(oracle64, sc)
+    eng.set_frame(0, v=v)
+    eng.set_option('threads', 1)
+    eng.substep(0, 0, 0)
+    got = S.get_state(eng, 1)
+    g = np.array(sc['gravity'])
+    assert np.abs(got['v'] - (v + sc['dt'] * g)).max() < 1e-12
+    assert np.abs(got['F'] - F2).max() < 1e-12
+
+
+def _loss_of(eng, sc, n_sub, cot, x=None, v=None, C=None, F=None):
+    eng.set_frame(0, x=x, v=v, C_=C, F=F)
+    st = S.run_forward(eng, n_sub)
+    return float((st['x'] * cot['gx']).sum() + (st['v'] * cot['gv']).sum() + (st['C'] * cot['gC']).sum() + (st['F'] * cot['gF']).sum())
+
+
+@pytest.mark.parametrize('scene', ['mixed', 'water_wall'])
+def test_substep_adjoint_vs_finite_differences(oracle64, scene):
+    if scene == 'mixed':
+        sc = S.mixed_materials(n_grid=8, n_particles=40, seed=3)
+        sc['x'] = S.f32(np.random.RandomState(3).uniform(0.3, 0.62, (40, 3)))
+    else:
+        # particles pressed against the cube wall: exercises the boundary branch of grid_op's adjoint
+        sc = S.water_block(n_grid=8, n_particles=40, lo=0.13, hi=0.4)
+        sc['boundary'] = dict(type='cube', lower=(0.25, 0.25, 0.25), upper=(0.8, 0.8, 0.8))
+        sc['v'] = S.f32(np.random.RandomState(4).normal(0, 1.0, (40, 3)))
+    eng = S.make_engine(oracle64, sc, max_substeps_local=8)
+    eng.set_option('threads', 1)
+    N, n_sub = sc['N'], 3
+    base = {k: S.get_state(eng, 0)[k].astype(np.float64) for k in 'xvCF'}
+    cot = {k: a.astype(np.float64) for k, a in S.random_cotangent(N).items()}
+    _, g = S.run_forward_backward(eng, n_sub, cot)
+    rng = np.random.RandomState(0)
+    used = sc['used'] == 1
+    for name, gname, h in [('x', 'gx', 1e-7), ('v', 'gv', 1e-6), ('C', 'gC', 1e-5), ('F', 'gF', 1e-7)]:
+        diffs, mags = [], []
+        for _ in range(10):
+            p = rng.choice(np.where(used)[0])
+            idx = (p,) + tuple(rng.randint(0, 3, base[name].ndim - 1))
+            arrs = {k: a.copy() for k, a in base.items()}
+            arrs[name][idx] += h
+            lp = _loss_of(eng, sc, n_sub, cot, arrs['x'], arrs['v'], arrs['C'], arrs['F'])
+            arrs[name][idx] -= 2 * h
+            lm = _loss_of(eng, sc, n_sub, cot, arrs['x'], arrs['v'], arrs['C'], arrs['F'])
+            fd = (lp - lm) / (2 * h)
+            diffs.append(abs(fd - g[gname][idx])); mags.append(abs(fd))
+        assert max(diffs) < 2e-5 * max(max(mags), 1e-6), (name, diffs, mags)
+
+
+def test_action_gradient_vs_finite_differences(oracle64):
+    """dL/d(action) through injector, effector move, set_velocity and apply_action_p."""
+    sc = S.latte_mini(n_grid=8, n_coffee=150, n_pool=40, horizon=3, n_substeps=3)
+    out = S.run_latte(oracle64, sc)
+    g = out['action_grad']
+    assert g.shape == (sc['horizon'] + 1, 3)
+    assert np.isfinite(g).all() and np.abs(g).max() > 0
+    # effector y is clamped by y_range=(0.62, 0.62): its gradient is killed (boundaries.py:68)
+    assert np.abs(g[:, 1]).max() == 0.0
+
+    def total(sc_):
+        return float(S.run_latte(oracle64, sc_)['step_loss'].astype(np.float64).sum())
+
+    h = 1e-6
+    for (s, k) in [(0, 0), (1, 2), (2, 0)]:
+        scp = dict(sc, actions=sc['actions'].astype(np.float64).copy()); scp['actions'][s, k] += h
+        scm = dict(sc, actions=sc['actions'].astype(np.float64).copy()); scm['actions'][s, k] -= h
+        fd = (total(scp) - total(scm)) / (2 * h)
+        assert abs(fd - g[s, k]) < 1e-5 * max(abs(fd), 1e-3), (s, k, fd, g[s, k])
+    for k in (0, 2):
+        scp = dict(sc, action_p=sc['action_p'].astype(np.float64).copy()); scp['action_p'][k] += h
+        scm = dict(sc, action_p=sc['action_p'].astype(np.float64).copy()); scm['action_p'][k] -= h
+        fd = (total(scp) - total(scm)) / (2 * h)
+        assert abs(fd - g[-1, k]) < 1e-5 * max(abs(fd), 1e-3), (k, fd, g[-1, k])
+
+
+def test_oracle_f32_tracks_f64(oracle32, oracle64):
+    sc = S.water_block(n_grid=16, n_particles=800)
+    a = S.run_forward(S.make_engine(oracle32, sc), 20)
+    b = S.run_forward(S.make_engine(oracle64, sc), 20)
+    assert np.abs(a['x'] - b['x']).max() < 2e-6
+    assert S.rel_l2(a['v'], b['v']) < 1e-3
+
+
+def test_errors_are_reported_not_fatal(oracle64):
+    sc = S.water_block(n_grid=8, n_particles=10)
+    sc['x'][0] = [0.99, 0.99, 0.99]                     # stencil leaves the grid
+    eng = S.make_engine(oracle64, sc, max_substeps_local=4)
+    from fluidlab_amd._capi import FeEngineError
+    with pytest.raises(FeEngineError, match='left the grid'):
+        eng.substep(0, 0, 0)
+    with pytest.raises(FeEngineError, match='out of range'):
+        eng.substep(4, 4, 0)
