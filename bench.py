@@ -32,6 +32,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s m
 KERNEL_BYTES = {
     'p2g': (156, 16), 'grid_op': (0, 44), 'g2p': (60, 12),
     'p2g_recompute': (116, 16), 'grid_op_keep': (0, 28), 'g2p_grad': (60, 24), 'grid_op_grad': (0, 48), 'p2g_grad': (132, 16),
+    'sort': (0, 0), 'reorder_grad': (0, 0),          # overhead of the cell-sorted layout: no algorithmic bytes credited
 }
 FWD_KERNELS = ('p2g', 'grid_op', 'g2p')
 
@@ -62,9 +63,17 @@ def cpu_baseline(budget_s=12.0):
     elib = _capi.EngineLib(path)
     L = 3
     eng, _ = build_engine(elib, 0, L=L)
-    cores = os.cpu_count() or 1
-    eng.set_option('threads', cores)
+    ncpu = os.cpu_count() or 1
     one_step(eng, 1)                                      # warm (page faults)
+    # the scatter uses float atomics: more threads is not always faster.  Use the best of a few counts.
+    best = None
+    for c in sorted({ncpu, max(1, ncpu // 2), max(1, ncpu // 4), min(ncpu, 16)}, reverse=True):
+        eng.set_option('threads', c)
+        t = time.perf_counter(); one_step(eng, 1); t = time.perf_counter() - t
+        if best is None or t < best[0]:
+            best = (t, c)
+    cores = best[1]
+    eng.set_option('threads', cores)
     t0 = time.perf_counter()
     pairs = 0
     while True:
@@ -75,7 +84,7 @@ def cpu_baseline(budget_s=12.0):
     dt = time.perf_counter() - t0
     eng.close()
     return {'value': pairs / dt, 'unit': 'substep_pairs/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{pairs} fwd+bwd substep pairs of the same 128^3/200k water block, oracle fp32 + OpenMP ({cores} threads), {dt:.1f}s'}
+            'sample': f'{pairs} fwd+bwd substep pairs of the same 128^3/200k water block, oracle fp32 + OpenMP ({cores} of {ncpu} hardware threads, fastest of a short sweep), {dt:.1f}s'}
 
 
 def main():

@@ -89,8 +89,8 @@ struct EffP {
     float *abuf, *gabuf, *abuf_p, *gabuf_p;                  // [max_action_steps, adim], [adim]
     float* random_vector;                                    // [random_length, flux, 3]
 };
-struct AgentP { int n; EffP e[FE_MAX_EFF]; };
-struct InjectP { int on, act_id, row; };                     // per-substep injection parameters (host-known)
+struct AgentP { int n; int inj; const EffP* e; };       // effector parameter blocks live in device memory (1 KiB as kernarg spilled SGPRs)
+struct InjectP { int on, act_id, row, flux; };                     // per-substep injection parameters (host-known)
 
 struct PInfo { float mu, lam, mass; int cls, mat; };
 __device__ __forceinline__ PInfo load_info(const float4* pinfo, int pid) {
@@ -104,6 +104,54 @@ __device__ __forceinline__ void mark_block(int b, int* blk_flag, int* blk_list, 
     if (blk_flag[b] == 0) {
         if (atomicExch(&blk_flag[b], 1) == 0) { int i = atomicAdd(blk_count, 1); blk_list[i] = b; }
     }
+}
+
+// -----------------------------------------------------------------------------------------
+// Particle order and work decomposition.
+// Every K substeps the particles of a frame are counting-sorted by the 4x4x4 grid block of
+// their stencil base (k_sort_*).  A sorted order ("table") carries a work list: one item per
+// occupied block (split at ITEM_MAX particles) = a contiguous slot range.  One workgroup
+// processes one item with the block's stencil footprint staged in LDS as an 8^3-node tile
+// (block + 2 halo nodes + 1 node of drift margin on each side), so the 27-node APIC scatter /
+// gather runs on ds_add_f32 / ds_read instead of global atomics / L2 gathers.  Slots behind the
+// last item ("tail": unused pool particles, particles injected since the last sort) and
+// particles that drifted out of their tile take the global path, which is always correct.
+// -----------------------------------------------------------------------------------------
+#define TILE_T 8
+#define TILE_N 512
+#define ITEM_MAX 512
+#define WG 256
+// The LDS tile of the workgroup's current item (SoA planes of TILE_N floats).  File scope, so every
+// access is a known-LDS ds_* instruction (a `float*` parameter that may also be null degrades to flat_*).
+__shared__ float s_tile[6 * TILE_N];
+// Keeps the fully unrolled 27-node stencil loops from being software-pipelined into one giant basic
+// block (which drove k_p2g_grad to 512 registers + scratch): nothing is scheduled across the fence.
+#define NODE_FENCE() __builtin_amdgcn_sched_barrier(0)
+// The 27-node stencil loops are rolled as 9 (i,j) iterations x 3 unrolled k nodes: a fully unrolled
+// 27-node body gets software-pipelined into one basic block that needs >512 registers.  Per-iteration
+// weights come from register selects (a runtime-indexed array would live in scratch).
+__device__ __forceinline__ float sel3(int i, float a, float b, float c) { return i == 0 ? a : (i == 1 ? b : c); }
+#define STW(st, i, d) sel3((i), (st).w[0][d], (st).w[1][d], (st).w[2][d])
+
+struct TableP {
+    const int*  pid_of_slot;   // [Np]
+    const int4* items;         // (block, start, count, 0)
+    const int*  meta;          // meta[0] = n_items, meta[1] = tail_start
+};
+
+struct TileO { int ox, oy, oz; };
+__device__ __forceinline__ TileO tile_origin(int block, int nb) {
+    TileO t; t.ox = (block / (nb * nb)) * 4 - 1; t.oy = ((block / nb) % nb) * 4 - 1; t.oz = (block % nb) * 4 - 1; return t;
+}
+// local index of the stencil base inside the tile, or -1 when the 3^3 stencil does not fit
+__device__ __forceinline__ int tile_base(const TileO& t, const Stencil& st) {
+    int lx = st.base[0] - t.ox, ly = st.base[1] - t.oy, lz = st.base[2] - t.oz;
+    bool in = (unsigned)lx <= TILE_T - 3 && (unsigned)ly <= TILE_T - 3 && (unsigned)lz <= TILE_T - 3;
+    return in ? (lx * TILE_T + ly) * TILE_T + lz : -1;
+}
+__device__ __forceinline__ bool tile_node(const TileO& t, int l, int n, int& i, int& j, int& k) {
+    i = t.ox + (l >> 6); j = t.oy + ((l >> 3) & 7); k = t.oz + (l & 7);
+    return (unsigned)i < (unsigned)n && (unsigned)j < (unsigned)n && (unsigned)k < (unsigned)n;
 }
 
 // =========================================================================================
@@ -124,91 +172,163 @@ __device__ void effector_move(const EffP& e, int f) {
     e.quat[(f + 1) * 4] = qo[0]; e.quat[(f + 1) * 4 + 1] = qo[1]; e.quat[(f + 1) * 4 + 2] = qo[2]; e.quat[(f + 1) * 4 + 3] = qo[3];
 }
 
-// p2g (mpm:331-378) fused with compute_F_tmp + svd (mpm:254-264), advect_used + process_unused_particles
-// (mpm:304-316), Injector.act (injector.py:80-105) and, on one thread, Effector.move_kernel.
-// WRITE=false is the backward pass' recompute of grid[f]: scatter only.
-template <bool WRITE>
-__global__ __launch_bounds__(256) void k_p2g(SimP S, float* fr_cur, float* fr_next, const int* __restrict__ pid_of_slot,
-                                             const float4* __restrict__ pinfo, const int* __restrict__ pool_idx,
-                                             float4* g_in, int* blk_flag, int* blk_list, int* blk_count,
-                                             AgentP agent, EffP injector, InjectP inj, int act, int f, int* err) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (WRITE && s == 0 && act) {
-#pragma unroll
-        for (int i = 0; i < FE_MAX_EFF; i++) if (i < agent.n) effector_move(agent.e[i], f);   // constant indices: kernarg stays in SGPRs
-    }
-    if (s >= S.N) return;
-    FrameV cur = frame_view(fr_cur, S.Np);
-    FrameV nxt = frame_view(fr_next, S.Np);
-    const int used = cur.used[s];
-    const int pid = pid_of_slot[s];
+struct GridW {            // everything a scattering particle needs of the global grid
+    float4* g_in; int* blk_flag; int* blk_list; int* blk_count; int* err; int* slow;
+};
+
+// advect_used + process_unused_particles (mpm:304-316) + Injector.act (injector.py:80-105) for one unused slot
+__device__ __forceinline__ void unused_particle_fwd(const SimP& S, const FrameV& cur, const FrameV& nxt, int s, int pid,
+                                                    const int* __restrict__ pool_idx, const AgentP& agent, const InjectP& inj, int f) {
     PState p;
     load_xvC(cur, s, p);
     load_F(cur, s, p.F);
-    if (!used) {
-        if (WRITE) {
-            int used_next = 0;
-            if (inj.on) {
-                int j = pool_idx[pid] - inj.act_id;
-                if (j >= 0 && j < injector.flux) {        // this pool particle is injected now
-                    const EffP& e = injector;
-                    const float* rv = e.random_vector + ((size_t)inj.row * e.flux + j) * 3;
-                    float q[4] = {e.quat[f * 4], e.quat[f * 4 + 1], e.quat[f * 4 + 2], e.quat[f * 4 + 3]};
-                    float ip[3], iv[3];
-                    quat_rotate(e.inject_p, q, ip);
-                    quat_rotate(e.inject_v, q, iv);
-                    float vnorm = sqrtf(e.inject_v[0] * e.inject_v[0] + e.inject_v[1] * e.inject_v[1] + e.inject_v[2] * e.inject_v[2]);
+    int used_next = 0;
+    if (inj.on) {
+        int j = pool_idx[pid] - inj.act_id;
+        if (j >= 0 && j < inj.flux) {                                 // this pool particle is injected now
+            const EffP& e = agent.e[agent.inj];
+            const float* rv = e.random_vector + ((size_t)inj.row * e.flux + j) * 3;
+            float q[4] = {e.quat[f * 4], e.quat[f * 4 + 1], e.quat[f * 4 + 2], e.quat[f * 4 + 3]};
+            float ip[3], iv[3];
+            quat_rotate(e.inject_p, q, ip);
+            quat_rotate(e.inject_v, q, iv);
+            float vnorm = sqrtf(e.inject_v[0] * e.inject_v[0] + e.inject_v[1] * e.inject_v[1] + e.inject_v[2] * e.inject_v[2]);
 #pragma unroll
-                    for (int d = 0; d < 3; d++) {
-                        float offset = (rv[d] * 2.f - 1.f) * e.radius;
-                        p.x[d] = offset + e.pos[f * 3 + d] + ip[d];
-                        p.v[d] = e.randomize_inject_v ? iv[d] + (rv[d] * 2.f - 1.f) * vnorm * 2.0f : iv[d];
-                    }
-                    used_next = 1;
-                }
+            for (int d = 0; d < 3; d++) {
+                float offset = (rv[d] * 2.f - 1.f) * e.radius;
+                p.x[d] = offset + e.pos[f * 3 + d] + ip[d];
+                p.v[d] = e.randomize_inject_v ? iv[d] + (rv[d] * 2.f - 1.f) * vnorm * 2.0f : iv[d];
             }
-            store_xvC(nxt, s, p.x, p.v, p.C);
-            store_F(nxt, s, p.F);
-            nxt.used[s] = used_next;
+            used_next = 1;
         }
-        return;
     }
+    store_xvC(nxt, s, p.x, p.v, p.C);
+    store_F(nxt, s, p.F);
+    nxt.used[s] = used_next;
+}
+
+// p2g for one used particle (mpm:331-378 + compute_F_tmp/svd mpm:254-264).  `tile` = LDS accumulators
+// (vx,vy,vz,m as four TILE_N planes) or nullptr for the global path.
+template <bool WRITE>
+__device__ __forceinline__ void used_particle_p2g(const SimP& S, const FrameV& cur, const FrameV& nxt, int s, int pid,
+                                                  const float4* __restrict__ pinfo, bool use_tile, const TileO& to, const GridW& G) {
+    PState p;
+    load_xvC(cur, s, p);
+    load_F(cur, s, p.F);
     PInfo info = load_info(pinfo, pid);
     Constitutive k;
     constitutive_eval(p.C, p.F, S.dt, info.mu, info.lam, info.mass, info.cls, S.stress_scale, k);
     if (WRITE) { store_F(nxt, s, k.Fnew); nxt.used[s] = 1; }
     Stencil st;
     stencil_make(p.x, S.inv_dx, st);
-    if (!stencil_inside(st, S.n)) { atomicAdd(err, 1); return; }
+    if (!stencil_inside(st, S.n)) { atomicAdd(G.err, 1); return; }
     const float m = info.mass;
     // momentum at the base node, then per-node increments: mom(o) = m v + A (o - fx) dx
     float mv[3];
 #pragma unroll
     for (int a = 0; a < 3; a++)
         mv[a] = m * p.v[a] - S.dx * (k.affine.a[a][0] * st.fx[0] + k.affine.a[a][1] * st.fx[1] + k.affine.a[a][2] * st.fx[2]);
+    const int lb = use_tile ? tile_base(to, st) : -1;
+    if (use_tile && lb < 0) atomicAdd(G.slow, 1);
+    if (lb >= 0) {
+#pragma unroll 1
+        for (int ij = 0; ij < 9; ij++) {
+            const int i = ij / 3, j = ij - 3 * i;
+            const float wij = STW(st, i, 0) * STW(st, j, 1);
+            const float ox = (float)i * S.dx, oy = (float)j * S.dx;
+            float mij[3];
 #pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++)
+            for (int a = 0; a < 3; a++) mij[a] = mv[a] + k.affine.a[a][0] * ox + k.affine.a[a][1] * oy;
 #pragma unroll
             for (int kk = 0; kk < 3; kk++) {
-                float weight = st.w[i][0] * st.w[j][1] * st.w[kk][2];
-                float ox = (float)i * S.dx, oy = (float)j * S.dx, oz = (float)kk * S.dx;
-                float* dst = (float*)&g_in[cell_addr(st.base[0] + i, st.base[1] + j, st.base[2] + kk, S.nb)];
+                const float weight = wij * st.w[kk][2];
+                const float oz = (float)kk * S.dx;
+                const int l = lb + (i * TILE_T + j) * TILE_T + kk;
 #pragma unroll
-                for (int a = 0; a < 3; a++) {
-                    float mom = mv[a] + k.affine.a[a][0] * ox + k.affine.a[a][1] * oy + k.affine.a[a][2] * oz;
-                    unsafeAtomicAdd(dst + a, weight * mom);
-                }
-                unsafeAtomicAdd(dst + 3, weight * m);
+                for (int a = 0; a < 3; a++) atomicAdd(&s_tile[a * TILE_N + l], weight * (mij[a] + k.affine.a[a][2] * oz));   // ds_add_f32
+                atomicAdd(&s_tile[3 * TILE_N + l], weight * m);
             }
+        }
+        return;
+    }
+#pragma unroll 1
+    for (int ij = 0; ij < 9; ij++) {
+        const int i = ij / 3, j = ij - 3 * i;
+        const float wij = STW(st, i, 0) * STW(st, j, 1);
+        const float ox = (float)i * S.dx, oy = (float)j * S.dx;
+        float mij[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) mij[a] = mv[a] + k.affine.a[a][0] * ox + k.affine.a[a][1] * oy;
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) {
+            const float weight = wij * st.w[kk][2];
+            const float oz = (float)kk * S.dx;
+            float* dst = (float*)&G.g_in[cell_addr(st.base[0] + i, st.base[1] + j, st.base[2] + kk, S.nb)];
+#pragma unroll
+            for (int a = 0; a < 3; a++) unsafeAtomicAdd(dst + a, weight * (mij[a] + k.affine.a[a][2] * oz));
+            unsafeAtomicAdd(dst + 3, weight * m);
+        }
+    }
     // mark the (up to 8) 4^3 blocks this stencil touches
     const int bx0 = st.base[0] >> 2, bx1 = (st.base[0] + 2) >> 2;
     const int by0 = st.base[1] >> 2, by1 = (st.base[1] + 2) >> 2;
     const int bz0 = st.base[2] >> 2, bz1 = (st.base[2] + 2) >> 2;
     for (int bx = bx0; bx <= bx1; bx++)
         for (int by = by0; by <= by1; by++)
-            for (int bz = bz0; bz <= bz1; bz++) mark_block((bx * S.nb + by) * S.nb + bz, blk_flag, blk_list, blk_count);
+            for (int bz = bz0; bz <= bz1; bz++) mark_block((bx * S.nb + by) * S.nb + bz, G.blk_flag, G.blk_list, G.blk_count);
+}
+
+// one slot of the p2g pass: used particles scatter, unused ones are carried / injected.  (`used` is re-read
+// here rather than implied by the work list so that host edits of a frame can never desynchronise it.)
+template <bool WRITE>
+__device__ __forceinline__ void slot_p2g(const SimP& S, const FrameV& cur, const FrameV& nxt, int s, const TableP& T,
+                                         const float4* __restrict__ pinfo, const int* __restrict__ pool_idx, bool use_tile,
+                                         const TileO& to, const GridW& G, const AgentP& agent, const InjectP& inj, int f) {
+    const int pid = T.pid_of_slot[s];
+    if (cur.used[s]) used_particle_p2g<WRITE>(S, cur, nxt, s, pid, pinfo, use_tile, to, G);
+    else if (WRITE) unused_particle_fwd(S, cur, nxt, s, pid, pool_idx, agent, inj, f);
+}
+
+// p2g (mpm:331-378) fused with compute_F_tmp + svd, advect_used + process_unused_particles, Injector.act and,
+// on one thread, Effector.move_kernel.  WRITE=false is the backward pass' recompute of grid[f]: scatter only.
+template <bool WRITE>
+__global__ __launch_bounds__(WG) void k_p2g(SimP S, float* fr_cur, float* fr_next, TableP T, const float4* __restrict__ pinfo,
+                                            const int* __restrict__ pool_idx, GridW G, AgentP agent, InjectP inj, int act, int f) {
+    const int tid = threadIdx.x;
+    if (WRITE && blockIdx.x == 0 && tid == 0 && act) {
+        for (int i = 0; i < agent.n; i++) effector_move(agent.e[i], f);
+    }
+    FrameV cur = frame_view(fr_cur, S.Np);
+    FrameV nxt = frame_view(fr_next, S.Np);
+    const int n_items = T.meta[0], tail_start = T.meta[1];
+    const int n_tail = (S.N - tail_start + WG - 1) / WG;
+    for (int w = blockIdx.x; w < n_items + n_tail; w += gridDim.x) {
+        if (w < n_items) {
+            const int4 it = T.items[w];
+            const TileO to = tile_origin(it.x, S.nb);
+            for (int l = tid; l < 4 * TILE_N; l += WG) s_tile[l] = 0.f;
+            __syncthreads();
+            for (int i = tid; i < it.z; i += WG) slot_p2g<WRITE>(S, cur, nxt, it.y + i, T, pinfo, pool_idx, true, to, G, agent, inj, f);
+            __syncthreads();
+            // flush: consecutive lanes -> consecutive nodes of a tile row
+            for (int l = tid; l < TILE_N; l += WG) {
+                float vx = s_tile[l], vy = s_tile[TILE_N + l], vz = s_tile[2 * TILE_N + l], m = s_tile[3 * TILE_N + l];
+                if (m != 0.f || vx != 0.f || vy != 0.f || vz != 0.f) {
+                    int i, j, k;
+                    if (tile_node(to, l, S.n, i, j, k)) {
+                        float* dst = (float*)&G.g_in[cell_addr(i, j, k, S.nb)];
+                        unsafeAtomicAdd(dst + 0, vx); unsafeAtomicAdd(dst + 1, vy); unsafeAtomicAdd(dst + 2, vz); unsafeAtomicAdd(dst + 3, m);
+                        mark_block((((i >> 2) * S.nb) + (j >> 2)) * S.nb + (k >> 2), G.blk_flag, G.blk_list, G.blk_count);
+                    }
+                }
+            }
+            __syncthreads();
+        } else {
+            const int s = tail_start + (w - n_items) * WG + tid;
+            TileO none = {0, 0, 0};
+            if (s < S.N) slot_p2g<WRITE>(S, cur, nxt, s, T, pinfo, pool_idx, false, none, G, agent, inj, f);
+        }
+    }
 }
 
 // velocity of one node after gravity and the domain boundary (mpm:383-398); k[] = boundary multipliers
@@ -248,42 +368,96 @@ __global__ __launch_bounds__(256) void k_grid(SimP S, float4* g_in, float4* g_ou
     }
 }
 
-// g2p (mpm:400-426) fused with advect_kernel (mpm:497-505)
-__global__ __launch_bounds__(256) void k_g2p(SimP S, float* fr_cur, float* fr_next, const float4* __restrict__ g_out,
-                                             int* blk_count) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s == 0) *blk_count = 0;               // grid_op was the last reader of the active list
-    if (s >= S.N) return;
-    FrameV cur = frame_view(fr_cur, S.Np);
+// g2p (mpm:400-426) + advect_kernel (mpm:497-505) for one used particle; TILE: v_out staged in LDS (3 planes)
+template <bool TILE>
+__device__ __forceinline__ void used_particle_g2p(const SimP& S, const FrameV& cur, const FrameV& nxt, int s,
+                                                  int lb, const Stencil& st, const float x[3],
+                                                  const float4* __restrict__ g_out) {
+    float nv[3] = {0.f, 0.f, 0.f};
+    m3 nC = m3_zero();
+    const float c4 = 4.f * S.inv_dx;
+#pragma unroll 1
+    for (int ij = 0; ij < 9; ij++) {
+        const int i = ij / 3, j = ij - 3 * i;
+        const float wij = STW(st, i, 0) * STW(st, j, 1);
+        const float dx0 = (float)i - st.fx[0], dx1 = (float)j - st.fx[1];
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) {
+            const float weight = wij * st.w[kk][2];
+            float g0, g1, g2;
+            if (TILE) {
+                const int l = lb + (i * TILE_T + j) * TILE_T + kk;
+                g0 = s_tile[l]; g1 = s_tile[TILE_N + l]; g2 = s_tile[2 * TILE_N + l];
+            } else {
+                float4 gv = g_out[cell_addr(st.base[0] + i, st.base[1] + j, st.base[2] + kk, S.nb)];
+                g0 = gv.x; g1 = gv.y; g2 = gv.z;
+            }
+            const float dpos[3] = {dx0, dx1, (float)kk - st.fx[2]};
+            const float gw[3] = {weight * g0, weight * g1, weight * g2};
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                nv[a] += gw[a];
+#pragma unroll
+                for (int b = 0; b < 3; b++) nC.a[a][b] += c4 * gw[a] * dpos[b];
+            }
+        }
+    }
+    float xn[3] = {x[0] + S.dt * nv[0], x[1] + S.dt * nv[1], x[2] + S.dt * nv[2]};
+    store_xvC(nxt, s, xn, nv, nC);
+}
+
+__device__ __forceinline__ void load_tile3(const TileO& to, const SimP& S, const float4* __restrict__ src, int tid) {
+    for (int l = tid; l < TILE_N; l += WG) {
+        int i, j, k;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tile_node(to, l, S.n, i, j, k)) v = src[cell_addr(i, j, k, S.nb)];
+        s_tile[l] = v.x; s_tile[TILE_N + l] = v.y; s_tile[2 * TILE_N + l] = v.z;
+    }
+}
+__device__ __forceinline__ void load_tile4(const TileO& to, const SimP& S, const float4* __restrict__ src, int tid) {
+    for (int l = tid; l < TILE_N; l += WG) {
+        int i, j, k;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tile_node(to, l, S.n, i, j, k)) v = src[cell_addr(i, j, k, S.nb)];
+        s_tile[l] = v.x; s_tile[TILE_N + l] = v.y; s_tile[2 * TILE_N + l] = v.z; s_tile[3 * TILE_N + l] = v.w;
+    }
+}
+
+__device__ __forceinline__ void slot_g2p(const SimP& S, const FrameV& cur, const FrameV& nxt, int s, bool use_tile,
+                                         const TileO& to, const float4* __restrict__ g_out, int* slow) {
     if (!cur.used[s]) return;
-    FrameV nxt = frame_view(fr_next, S.Np);
     float4 a0 = cur.A0[s];
     float x[3] = {a0.x, a0.y, a0.z};
     Stencil st;
     stencil_make(x, S.inv_dx, st);
-    if (!stencil_inside(st, S.n)) return;     // already counted in err by p2g
-    float nv[3] = {0.f, 0.f, 0.f};
-    m3 nC = m3_zero();
-    const float c4 = 4.f * S.inv_dx;
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++)
-#pragma unroll
-            for (int kk = 0; kk < 3; kk++) {
-                float weight = st.w[i][0] * st.w[j][1] * st.w[kk][2];
-                float4 gv = g_out[cell_addr(st.base[0] + i, st.base[1] + j, st.base[2] + kk, S.nb)];
-                float dpos[3] = {(float)i - st.fx[0], (float)j - st.fx[1], (float)kk - st.fx[2]};
-                float gw[3] = {weight * gv.x, weight * gv.y, weight * gv.z};
-#pragma unroll
-                for (int a = 0; a < 3; a++) {
-                    nv[a] += gw[a];
-#pragma unroll
-                    for (int b = 0; b < 3; b++) nC.a[a][b] += c4 * gw[a] * dpos[b];
-                }
-            }
-    float xn[3] = {x[0] + S.dt * nv[0], x[1] + S.dt * nv[1], x[2] + S.dt * nv[2]};
-    store_xvC(nxt, s, xn, nv, nC);
+    if (!stencil_inside(st, S.n)) return;                   // already counted in err by p2g
+    const int lb = use_tile ? tile_base(to, st) : -1;
+    if (lb >= 0) used_particle_g2p<true>(S, cur, nxt, s, lb, st, x, g_out);
+    else { if (use_tile) atomicAdd(slow, 1); used_particle_g2p<false>(S, cur, nxt, s, 0, st, x, g_out); }
+}
+
+__global__ __launch_bounds__(WG) void k_g2p(SimP S, float* fr_cur, float* fr_next, TableP T, const float4* __restrict__ g_out,
+                                            int* blk_count, int* slow) {
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0 && tid == 0) *blk_count = 0;          // grid_op was the last reader of the active list
+    FrameV cur = frame_view(fr_cur, S.Np);
+    FrameV nxt = frame_view(fr_next, S.Np);
+    const int n_items = T.meta[0], tail_start = T.meta[1];
+    const int n_tail = (S.N - tail_start + WG - 1) / WG;
+    for (int w = blockIdx.x; w < n_items + n_tail; w += gridDim.x) {
+        if (w < n_items) {
+            const int4 it = T.items[w];
+            const TileO to = tile_origin(it.x, S.nb);
+            load_tile3(to, S, g_out, tid);
+            __syncthreads();
+            for (int i = tid; i < it.z; i += WG) slot_g2p(S, cur, nxt, it.y + i, true, to, g_out, slow);
+            __syncthreads();
+        } else {
+            const int s = tail_start + (w - n_items) * WG + tid;
+            TileO none = {0, 0, 0};
+            if (s < S.N) slot_g2p(S, cur, nxt, s, false, none, g_out, slow);
+        }
+    }
 }
 
 // =========================================================================================
@@ -292,53 +466,106 @@ __global__ __launch_bounds__(256) void k_g2p(SimP S, float* fr_cur, float* fr_ne
 // every substep_grad overwrites Gc completely.
 // =========================================================================================
 
-// advect_kernel.grad + g2p.grad (mpm:443, 538): scatters d/d(v_out) into gg_out, leaves the
-// position adjoint (so far) in Gc.A0.xyz
-__global__ __launch_bounds__(256) void k_g2p_grad(SimP S, float* fr_cur, float* Gn_, float* Gc_,
-                                                  const float4* __restrict__ g_out, float4* gg_out) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= S.N) return;
-    FrameV cur = frame_view(fr_cur, S.Np);
-    if (!cur.used[s]) return;
-    FrameV Gn = frame_view(Gn_, S.Np), Gc = frame_view(Gc_, S.Np);
-    float4 a0 = cur.A0[s];
-    float x[3] = {a0.x, a0.y, a0.z};
+// advect_kernel.grad + g2p.grad (mpm:443, 538) for one used particle: scatters d/d(v_out), leaves the
+// position adjoint (so far) in Gc.A0.xyz.  TILE: v_out read from / d v_out accumulated into LDS (3+3 planes)
+template <bool TILE>
+__device__ __forceinline__ void used_particle_g2p_grad(const SimP& S, const FrameV& Gn, const FrameV& Gc, int s,
+                                                       int lb, const Stencil& st, const float4* __restrict__ g_out, float4* gg_out) {
     PState g;                                   // adjoints of x', v', C'
     load_xvC(Gn, s, g);
-    Stencil st;
-    stencil_make(x, S.inv_dx, st);
-    if (!stencil_inside(st, S.n)) { Gc.A0[s] = make_float4(g.x[0], g.x[1], g.x[2], 0.f); return; }
     // x' = x + dt v'  =>  v'_bar += dt x'_bar
     float gv[3] = {g.v[0] + S.dt * g.x[0], g.v[1] + S.dt * g.x[1], g.v[2] + S.dt * g.x[2]};
     const float c4 = 4.f * S.inv_dx;
     float gfx[3] = {0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int ij = 0; ij < 9; ij++) {
+        const int i = ij / 3, j = ij - 3 * i;
+        const float wi = STW(st, i, 0), wj = STW(st, j, 1);
+        const float dwi = stencil_dw(st, i, 0), dwj = stencil_dw(st, j, 1);
+        const float dx0 = (float)i - st.fx[0], dx1 = (float)j - st.fx[1];
 #pragma unroll
-    for (int i = 0; i < 3; i++)
+        for (int kk = 0; kk < 3; kk++) {
+            const float wk = st.w[kk][2];
+            const float weight = wi * wj * wk;
+            const float dpos[3] = {dx0, dx1, (float)kk - st.fx[2]};
+            float q[3];
 #pragma unroll
-        for (int j = 0; j < 3; j++)
-#pragma unroll
-            for (int kk = 0; kk < 3; kk++) {
+            for (int a = 0; a < 3; a++) q[a] = gv[a] + c4 * (g.C.a[a][0] * dpos[0] + g.C.a[a][1] * dpos[1] + g.C.a[a][2] * dpos[2]);
+            float v0, v1, v2;
+            if (TILE) {
+                const int l = lb + (i * TILE_T + j) * TILE_T + kk;
+                v0 = s_tile[l]; v1 = s_tile[TILE_N + l]; v2 = s_tile[2 * TILE_N + l];
+                atomicAdd(&s_tile[3 * TILE_N + l], weight * q[0]);
+                atomicAdd(&s_tile[4 * TILE_N + l], weight * q[1]);
+                atomicAdd(&s_tile[5 * TILE_N + l], weight * q[2]);
+            } else {
                 const int c = cell_addr(st.base[0] + i, st.base[1] + j, st.base[2] + kk, S.nb);
                 float4 vo = g_out[c];
-                float weight = st.w[i][0] * st.w[j][1] * st.w[kk][2];
-                float dpos[3] = {(float)i - st.fx[0], (float)j - st.fx[1], (float)kk - st.fx[2]};
-                float q[3];
-#pragma unroll
-                for (int a = 0; a < 3; a++) q[a] = gv[a] + c4 * (g.C.a[a][0] * dpos[0] + g.C.a[a][1] * dpos[1] + g.C.a[a][2] * dpos[2]);
+                v0 = vo.x; v1 = vo.y; v2 = vo.z;
                 float* dst = (float*)&gg_out[c];
                 unsafeAtomicAdd(dst + 0, weight * q[0]);
                 unsafeAtomicAdd(dst + 1, weight * q[1]);
                 unsafeAtomicAdd(dst + 2, weight * q[2]);
-                float sdot = vo.x * q[0] + vo.y * q[1] + vo.z * q[2];
-                // d weight / d fx_d
-                gfx[0] += stencil_dw(st, i, 0) * st.w[j][1] * st.w[kk][2] * sdot;
-                gfx[1] += st.w[i][0] * stencil_dw(st, j, 1) * st.w[kk][2] * sdot;
-                gfx[2] += st.w[i][0] * st.w[j][1] * stencil_dw(st, kk, 2) * sdot;
-                // dpos_b = o_b - fx_b
-#pragma unroll
-                for (int b = 0; b < 3; b++) gfx[b] -= c4 * weight * (vo.x * g.C.a[0][b] + vo.y * g.C.a[1][b] + vo.z * g.C.a[2][b]);
             }
+            const float sdot = v0 * q[0] + v1 * q[1] + v2 * q[2];
+            // d weight / d fx_d
+            gfx[0] += dwi * wj * wk * sdot;
+            gfx[1] += wi * dwj * wk * sdot;
+            gfx[2] += wi * wj * stencil_dw(st, kk, 2) * sdot;
+            // dpos_b = o_b - fx_b
+#pragma unroll
+            for (int b = 0; b < 3; b++) gfx[b] -= c4 * weight * (v0 * g.C.a[0][b] + v1 * g.C.a[1][b] + v2 * g.C.a[2][b]);
+        }
+    }
     Gc.A0[s] = make_float4(g.x[0] + S.inv_dx * gfx[0], g.x[1] + S.inv_dx * gfx[1], g.x[2] + S.inv_dx * gfx[2], 0.f);
+}
+
+__device__ __forceinline__ void g2p_grad_slot(const SimP& S, const FrameV& cur, const FrameV& Gn, const FrameV& Gc, int s,
+                                              bool use_tile, const TileO& to, const float4* __restrict__ g_out, float4* gg_out, int* slow) {
+    if (!cur.used[s]) return;
+    float4 a0 = cur.A0[s];
+    float x[3] = {a0.x, a0.y, a0.z};
+    Stencil st;
+    stencil_make(x, S.inv_dx, st);
+    if (!stencil_inside(st, S.n)) { float4 gx = Gn.A0[s]; Gc.A0[s] = make_float4(gx.x, gx.y, gx.z, 0.f); return; }
+    const int lb = use_tile ? tile_base(to, st) : -1;
+    if (lb >= 0) used_particle_g2p_grad<true>(S, Gn, Gc, s, lb, st, g_out, gg_out);
+    else { if (use_tile) atomicAdd(slow, 1); used_particle_g2p_grad<false>(S, Gn, Gc, s, 0, st, g_out, gg_out); }
+}
+
+__global__ __launch_bounds__(WG) void k_g2p_grad(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T,
+                                                 const float4* __restrict__ g_out, float4* gg_out, int* slow) {
+    const int tid = threadIdx.x;
+    FrameV cur = frame_view(fr_cur, S.Np);
+    FrameV Gn = frame_view(Gn_, S.Np), Gc = frame_view(Gc_, S.Np);
+    const int n_items = T.meta[0], tail_start = T.meta[1];
+    const int n_tail = (S.N - tail_start + WG - 1) / WG;
+    for (int w = blockIdx.x; w < n_items + n_tail; w += gridDim.x) {
+        if (w < n_items) {
+            const int4 it = T.items[w];
+            const TileO to = tile_origin(it.x, S.nb);
+            load_tile3(to, S, g_out, tid);
+            for (int l = tid; l < 3 * TILE_N; l += WG) s_tile[3 * TILE_N + l] = 0.f;
+            __syncthreads();
+            for (int i = tid; i < it.z; i += WG) g2p_grad_slot(S, cur, Gn, Gc, it.y + i, true, to, g_out, gg_out, slow);
+            __syncthreads();
+            for (int l = tid; l < TILE_N; l += WG) {
+                float q0 = s_tile[3 * TILE_N + l], q1 = s_tile[4 * TILE_N + l], q2 = s_tile[5 * TILE_N + l];
+                if (q0 != 0.f || q1 != 0.f || q2 != 0.f) {
+                    int i, j, k;
+                    if (tile_node(to, l, S.n, i, j, k)) {
+                        float* dst = (float*)&gg_out[cell_addr(i, j, k, S.nb)];
+                        unsafeAtomicAdd(dst + 0, q0); unsafeAtomicAdd(dst + 1, q1); unsafeAtomicAdd(dst + 2, q2);
+                    }
+                }
+            }
+            __syncthreads();
+        } else {
+            const int s = tail_start + (w - n_items) * WG + tid;
+            TileO none = {0, 0, 0};
+            if (s < S.N) g2p_grad_slot(S, cur, Gn, Gc, s, false, none, g_out, gg_out, slow);
+        }
+    }
 }
 
 // grid_op.grad (mpm:539): gg_out (d/d v_out) -> gg_in (d/d v_in, d/d mass); re-zeroes g_in, gg_out, flags
@@ -381,37 +608,11 @@ __device__ void effector_move_grad(const EffP& e, int f) {
     }
 }
 
-// p2g.grad + svd_grad + compute_F_tmp.grad (mpm:544-546) + AgentInjector.act_kernel.grad +
-// process_unused_particles.grad (mpm:551) + Effector.move_kernel.grad on one thread
-__global__ __launch_bounds__(256) void k_p2g_grad(SimP S, float* fr_cur, float* Gn_, float* Gc_,
-                                                  const int* __restrict__ pid_of_slot, const float4* __restrict__ pinfo,
-                                                  const int* __restrict__ pool_idx, const float4* __restrict__ gg_in,
-                                                  int* blk_count, AgentP agent, EffP injector, InjectP inj, int act, int f) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s == 0) {
-        *blk_count = 0;
-        if (act) {
-#pragma unroll
-            for (int i = FE_MAX_EFF - 1; i >= 0; i--) if (i < agent.n) effector_move_grad(agent.e[i], f);
-        }
-    }
-    if (s >= S.N) return;
-    FrameV cur = frame_view(fr_cur, S.Np);
-    FrameV Gn = frame_view(Gn_, S.Np), Gc = frame_view(Gc_, S.Np);
-    const int pid = pid_of_slot[s];
-    if (!cur.used[s]) {
-        // the copy f -> f+1 of an unused particle passes its adjoint straight through
-        PState g; load_xvC(Gn, s, g); load_F(Gn, s, g.F);
-        store_xvC(Gc, s, g.x, g.v, g.C); store_F(Gc, s, g.F);
-        if (inj.on) {
-            int j = pool_idx[pid] - inj.act_id;
-            if (j >= 0 && j < injector.flux) {
-                const EffP& e = injector;              // x[f+1,pid] = offset + pos[f] + R(q) inject_p
-                atomicAdd(&e.gpos[f * 3 + 0], g.x[0]); atomicAdd(&e.gpos[f * 3 + 1], g.x[1]); atomicAdd(&e.gpos[f * 3 + 2], g.x[2]);
-            }
-        }
-        return;
-    }
+// p2g.grad + svd_grad + compute_F_tmp.grad (mpm:544-546) for one used particle; TILE: (d v_in, d mass) in LDS (4 planes)
+template <bool TILE>
+__device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const FrameV& cur, const FrameV& Gn, const FrameV& Gc, int s,
+                                                       int pid, const float4* __restrict__ pinfo, const TileO& to,
+                                                       const float4* __restrict__ gg_in, int* slow) {
     PState p;
     load_xvC(cur, s, p);
     load_F(cur, s, p.F);
@@ -426,38 +627,57 @@ __global__ __launch_bounds__(256) void k_p2g_grad(SimP S, float* fr_cur, float* 
     Stencil st;
     stencil_make(p.x, S.inv_dx, st);
     if (stencil_inside(st, S.n)) {
+        const int lb = TILE ? tile_base(to, st) : -1;
+        if (TILE && lb < 0) {                   // drifted out of the tile: redo on the global path
+            atomicAdd(slow, 1);
+            used_particle_p2g_grad<false>(S, cur, Gn, Gc, s, pid, pinfo, to, gg_in, slow);
+            return;
+        }
         const float m = info.mass;
         float gfx[3] = {0.f, 0.f, 0.f};
         float mv[3];
 #pragma unroll
         for (int a = 0; a < 3; a++)
             mv[a] = m * p.v[a] - S.dx * (k.affine.a[a][0] * st.fx[0] + k.affine.a[a][1] * st.fx[1] + k.affine.a[a][2] * st.fx[2]);
+#pragma unroll 1
+        for (int ij = 0; ij < 9; ij++) {
+            const int i = ij / 3, j = ij - 3 * i;
+            const float wi = STW(st, i, 0), wj = STW(st, j, 1);
+            const float dwi = stencil_dw(st, i, 0), dwj = stencil_dw(st, j, 1);
+            const float ox = (float)i * S.dx, oy = (float)j * S.dx;
+            const float dp0 = ((float)i - st.fx[0]) * S.dx, dp1 = ((float)j - st.fx[1]) * S.dx;
+            float mij[3];
 #pragma unroll
-        for (int i = 0; i < 3; i++)
+            for (int a = 0; a < 3; a++) mij[a] = mv[a] + k.affine.a[a][0] * ox + k.affine.a[a][1] * oy;
 #pragma unroll
-            for (int j = 0; j < 3; j++)
-#pragma unroll
-                for (int kk = 0; kk < 3; kk++) {
+            for (int kk = 0; kk < 3; kk++) {
+                float gin[3], gm;
+                if (TILE) {
+                    const int l = lb + (i * TILE_T + j) * TILE_T + kk;
+                    gin[0] = s_tile[l]; gin[1] = s_tile[TILE_N + l]; gin[2] = s_tile[2 * TILE_N + l]; gm = s_tile[3 * TILE_N + l];
+                } else {
                     float4 gi = gg_in[cell_addr(st.base[0] + i, st.base[1] + j, st.base[2] + kk, S.nb)];
-                    float weight = st.w[i][0] * st.w[j][1] * st.w[kk][2];
-                    float dpos[3] = {((float)i - st.fx[0]) * S.dx, ((float)j - st.fx[1]) * S.dx, ((float)kk - st.fx[2]) * S.dx};
-                    float ox = (float)i * S.dx, oy = (float)j * S.dx, oz = (float)kk * S.dx;
-                    float gin[3] = {gi.x, gi.y, gi.z};
-                    float sdot = gi.w * m;
-#pragma unroll
-                    for (int a = 0; a < 3; a++) {
-                        float mom = mv[a] + k.affine.a[a][0] * ox + k.affine.a[a][1] * oy + k.affine.a[a][2] * oz;
-                        sdot += gin[a] * mom;
-                        Gv[a] += weight * gin[a];
-#pragma unroll
-                        for (int b = 0; b < 3; b++) GA.a[a][b] += weight * gin[a] * dpos[b];
-                    }
-                    gfx[0] += stencil_dw(st, i, 0) * st.w[j][1] * st.w[kk][2] * sdot;
-                    gfx[1] += st.w[i][0] * stencil_dw(st, j, 1) * st.w[kk][2] * sdot;
-                    gfx[2] += st.w[i][0] * st.w[j][1] * stencil_dw(st, kk, 2) * sdot;
-#pragma unroll
-                    for (int b = 0; b < 3; b++) gfx[b] -= S.dx * weight * (gin[0] * k.affine.a[0][b] + gin[1] * k.affine.a[1][b] + gin[2] * k.affine.a[2][b]);
+                    gin[0] = gi.x; gin[1] = gi.y; gin[2] = gi.z; gm = gi.w;
                 }
+                const float wk = st.w[kk][2];
+                const float weight = wi * wj * wk;
+                const float dpos[3] = {dp0, dp1, ((float)kk - st.fx[2]) * S.dx};
+                const float oz = (float)kk * S.dx;
+                float sdot = gm * m;
+#pragma unroll
+                for (int a = 0; a < 3; a++) {
+                    sdot += gin[a] * (mij[a] + k.affine.a[a][2] * oz);
+                    Gv[a] += weight * gin[a];
+#pragma unroll
+                    for (int b = 0; b < 3; b++) GA.a[a][b] += weight * gin[a] * dpos[b];
+                }
+                gfx[0] += dwi * wj * wk * sdot;
+                gfx[1] += wi * dwj * wk * sdot;
+                gfx[2] += wi * wj * stencil_dw(st, kk, 2) * sdot;
+#pragma unroll
+                for (int b = 0; b < 3; b++) gfx[b] -= S.dx * weight * (gin[0] * k.affine.a[0][b] + gin[1] * k.affine.a[1][b] + gin[2] * k.affine.a[2][b]);
+            }
+        }
 #pragma unroll
         for (int d = 0; d < 3; d++) gx[d] += S.inv_dx * gfx[d];
     }
@@ -466,6 +686,137 @@ __global__ __launch_bounds__(256) void k_p2g_grad(SimP S, float* fr_cur, float* 
     constitutive_grad(p.C, p.F, S.dt, info.mu, info.lam, info.mass, info.cls, S.stress_scale, k, GA, Fg, gC, gF);
     store_xvC(Gc, s, gx, gvv, gC);
     store_F(Gc, s, gF);
+}
+
+template <bool TILE>
+__device__ __forceinline__ void slot_p2g_grad(const SimP& S, const FrameV& cur, const FrameV& Gn, const FrameV& Gc, int s, const TableP& T,
+                                              const float4* __restrict__ pinfo, const int* __restrict__ pool_idx,
+                                              const TileO& to, const float4* __restrict__ gg_in, int* slow, const AgentP& agent,
+                                              const InjectP& inj, int f) {
+    const int pid = T.pid_of_slot[s];
+    if (cur.used[s]) { used_particle_p2g_grad<TILE>(S, cur, Gn, Gc, s, pid, pinfo, to, gg_in, slow); return; }
+    // the copy f -> f+1 of an unused particle passes its adjoint straight through (mpm:551)
+    PState g; load_xvC(Gn, s, g); load_F(Gn, s, g.F);
+    store_xvC(Gc, s, g.x, g.v, g.C); store_F(Gc, s, g.F);
+    if (inj.on) {
+        int j = pool_idx[pid] - inj.act_id;
+        if (j >= 0 && j < inj.flux) {                      // x[f+1,pid] = offset + pos[f] + R(q) inject_p
+            float* gp = agent.e[agent.inj].gpos + f * 3;
+            atomicAdd(gp + 0, g.x[0]); atomicAdd(gp + 1, g.x[1]); atomicAdd(gp + 2, g.x[2]);
+        }
+    }
+}
+
+// p2g.grad + svd_grad + compute_F_tmp.grad + AgentInjector.act_kernel.grad + process_unused_particles.grad (mpm:551)
+// + Effector.move_kernel.grad on one thread
+__global__ __launch_bounds__(WG) void k_p2g_grad(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T,
+                                                 const float4* __restrict__ pinfo, const int* __restrict__ pool_idx,
+                                                 const float4* __restrict__ gg_in, int* blk_count, int* slow, AgentP agent,
+                                                 InjectP inj, int act, int f) {
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0 && tid == 0) {
+        *blk_count = 0;
+        if (act) for (int i = agent.n - 1; i >= 0; i--) effector_move_grad(agent.e[i], f);
+    }
+    FrameV cur = frame_view(fr_cur, S.Np);
+    FrameV Gn = frame_view(Gn_, S.Np), Gc = frame_view(Gc_, S.Np);
+    const int n_items = T.meta[0], tail_start = T.meta[1];
+    const int n_tail = (S.N - tail_start + WG - 1) / WG;
+    for (int w = blockIdx.x; w < n_items + n_tail; w += gridDim.x) {
+        if (w < n_items) {
+            const int4 it = T.items[w];
+            const TileO to = tile_origin(it.x, S.nb);
+            load_tile4(to, S, gg_in, tid);
+            __syncthreads();
+            for (int i = tid; i < it.z; i += WG) slot_p2g_grad<true>(S, cur, Gn, Gc, it.y + i, T, pinfo, pool_idx, to, gg_in, slow, agent, inj, f);
+            __syncthreads();
+        } else {
+            const int s = tail_start + (w - n_items) * WG + tid;
+            TileO none = {0, 0, 0};
+            if (s < S.N) slot_p2g_grad<false>(S, cur, Gn, Gc, s, T, pinfo, pool_idx, none, gg_in, slow, agent, inj, f);
+        }
+    }
+}
+
+// =========================================================================================
+// block sort (counting sort by 4^3 block of the stencil base)
+// =========================================================================================
+__global__ __launch_bounds__(256) void k_sort_count(SimP S, float* fr, int* key, int* rank, int* cnt) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S.N) return;
+    FrameV cur = frame_view(fr, S.Np);
+    const int nblk = S.nb * S.nb * S.nb;
+    int kk = nblk;                                           // sentinel: unused / outside -> tail
+    if (cur.used[s]) {
+        float4 a0 = cur.A0[s];
+        float x[3] = {a0.x, a0.y, a0.z};
+        Stencil st;
+        stencil_make(x, S.inv_dx, st);
+        if (stencil_inside(st, S.n)) kk = (((st.base[0] >> 2) * S.nb) + (st.base[1] >> 2)) * S.nb + (st.base[2] >> 2);
+    }
+    key[s] = kk;
+    rank[s] = atomicAdd(&cnt[kk], 1);
+}
+
+// exclusive scan of the block histogram + work-list construction; one workgroup of 1024 threads
+__global__ __launch_bounds__(1024) void k_sort_scan(int nblk, int* cnt, int* start, int4* items, int* meta) {
+    __shared__ int sh_p[1024], sh_i[1024];
+    const int tid = threadIdx.x;
+    const int per = (nblk + 1 + 1023) / 1024;
+    const int lo = tid * per, hi = min(lo + per, nblk + 1);
+    int sp = 0, si = 0;
+    for (int b = lo; b < hi; b++) { int c = cnt[b]; sp += c; if (b < nblk) si += (c + ITEM_MAX - 1) / ITEM_MAX; }
+    sh_p[tid] = sp; sh_i[tid] = si;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {               // Hillis-Steele inclusive scan
+        int ap = 0, ai = 0;
+        if (tid >= off) { ap = sh_p[tid - off]; ai = sh_i[tid - off]; }
+        __syncthreads();
+        sh_p[tid] += ap; sh_i[tid] += ai;
+        __syncthreads();
+    }
+    int bp = sh_p[tid] - sp, bi = sh_i[tid] - si;             // exclusive prefixes of this thread's range
+    for (int b = lo; b < hi; b++) {
+        int c = cnt[b];
+        start[b] = bp;
+        if (b < nblk) for (int o = 0; o < c; o += ITEM_MAX) items[bi++] = make_int4(b, bp + o, min(ITEM_MAX, c - o), 0);
+        bp += c;
+        cnt[b] = 0;                                           // ready for the next sort
+    }
+    if (tid == 1023) { meta[0] = sh_i[1023]; }
+    if (hi == nblk + 1 && lo < hi) meta[1] = start[nblk];     // first tail slot
+}
+
+__global__ __launch_bounds__(256) void k_sort_perm(int N, const int* __restrict__ key, const int* __restrict__ rank,
+                                                   const int* __restrict__ start, const int* __restrict__ pid_old, int* src, int* pid_new) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= N) return;
+    const int d = start[key[s]] + rank[s];
+    src[d] = s;
+    pid_new[d] = pid_old[s];
+}
+
+// dst[s] = src[idx[s]] over all 24 planes (+ used when WITH_USED): coalesced writes, gathered 16-byte reads
+template <bool WITH_USED>
+__global__ __launch_bounds__(256) void k_perm_gather(int N, size_t Np, float* dst_, float* src_, const int* __restrict__ idx) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= N) return;
+    const int o = idx[s];
+    FrameV d = frame_view(dst_, Np), q = frame_view(src_, Np);
+    d.A0[s] = q.A0[o]; d.A1[s] = q.A1[o]; d.A2[s] = q.A2[o];
+    d.a3[s] = q.a3[o]; d.a4[s] = q.a4[o]; d.a5[s] = q.a5[o];
+    d.B0[s] = q.B0[o]; d.B1[s] = q.B1[o]; d.b2[s] = q.b2[o];
+    if (WITH_USED) d.used[s] = q.used[o];
+}
+// dst[idx[s]] = src[s]
+__global__ __launch_bounds__(256) void k_perm_scatter(int N, size_t Np, float* dst_, float* src_, const int* __restrict__ idx) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= N) return;
+    const int o = idx[s];
+    FrameV d = frame_view(dst_, Np), q = frame_view(src_, Np);
+    d.A0[o] = q.A0[s]; d.A1[o] = q.A1[s]; d.A2[o] = q.A2[s];
+    d.a3[o] = q.a3[s]; d.a4[o] = q.a4[s]; d.a5[o] = q.a5[s];
+    d.B0[o] = q.B0[s]; d.B1[o] = q.B1[s]; d.b2[o] = q.b2[s];
 }
 
 // =========================================================================================
@@ -637,8 +988,8 @@ __global__ __launch_bounds__(256) void k_stats_count(int ncells, unsigned char* 
 // =========================================================================================
 // host side
 // =========================================================================================
-enum { KID_P2G = 0, KID_GRID, KID_G2P, KID_P2G_RE, KID_GRID_KEEP, KID_G2P_GRAD, KID_GRID_GRAD, KID_P2G_GRAD, KID_COUNT };
-static const char* KNAMES[KID_COUNT] = {"p2g", "grid_op", "g2p", "p2g_recompute", "grid_op_keep", "g2p_grad", "grid_op_grad", "p2g_grad"};
+enum { KID_P2G = 0, KID_GRID, KID_G2P, KID_P2G_RE, KID_GRID_KEEP, KID_G2P_GRAD, KID_GRID_GRAD, KID_P2G_GRAD, KID_SORT, KID_REORDER_GRAD, KID_COUNT };
+static const char* KNAMES[KID_COUNT] = {"p2g", "grid_op", "g2p", "p2g_recompute", "grid_op_keep", "g2p_grad", "grid_op_grad", "p2g_grad", "sort", "reorder_grad"};
 
 struct EffHost {
     EffP p;
@@ -652,9 +1003,19 @@ struct FeEngine {
     int device = 0;
     hipStream_t stream = nullptr;
     SimP S;
-    float* frames = nullptr; size_t frame_stride = 0;      // (L+1) frames of FR_WORDS*Np floats
-    float* grads = nullptr;                                 // 2 x GR_WORDS*Np floats (+Np pad)
-    int *pid_of_slot = nullptr, *slot_of_pid = nullptr;
+    float* frames = nullptr; size_t frame_stride = 0;      // (L+2) buffers of FR_WORDS*Np floats: L+1 frames + 1 spare
+    std::vector<float*> frame_ptr;                          // frame f -> buffer (a sort swaps a frame with the spare)
+    float* grads = nullptr;                                 // 3 x (GR_WORDS*Np + Np) floats: ring of two + 1 spare
+    float* grad_ptr[3] = {nullptr, nullptr, nullptr};
+    // particle orders ("tables"): id 0 = identity; id 1+f = order produced by the sort at frame f
+    struct Table { int* pid = nullptr; int4* items = nullptr; int* meta = nullptr; };
+    std::vector<Table> tables;
+    std::vector<int> tbl_of_frame;                          // [L+1]
+    int gtbl[2] = {-1, -1};                                 // order of each adjoint ring slot; -1 = all zero
+    int sort_interval = 10;                                 // K: re-sort every K substeps (0 = never: global path only)
+    size_t items_cap = 0;
+    int *sort_key = nullptr, *sort_rank = nullptr, *sort_cnt = nullptr, *sort_start = nullptr, *sort_src = nullptr, *sort_pid = nullptr;
+    int* slow_dev = nullptr;
     float4* pinfo = nullptr; int* pool_idx = nullptr;
     std::vector<int> mat_host;
     float4 *g_in = nullptr, *g_out = nullptr, *gg_out = nullptr, *gg_in = nullptr;
@@ -662,6 +1023,7 @@ struct FeEngine {
     float* stage_r = nullptr; int* stage_i = nullptr;       // 24 N floats, N ints
     unsigned char* node_mark = nullptr; unsigned long long* counters = nullptr;
     std::vector<EffHost> effs;
+    EffP* effs_dev = nullptr;                               // [FE_MAX_EFF] parameter blocks read by the kernels
     int loss_steps = 0; float *tgt = nullptr, *chamfer = nullptr, *step_loss = nullptr;
     size_t bytes = 0;
     std::string err;
@@ -671,8 +1033,12 @@ struct FeEngine {
     std::vector<hipEvent_t> prof_ev; std::vector<int> prof_kid; size_t prof_used = 0;
     double prof_ms[KID_COUNT] = {0}; long long prof_n[KID_COUNT] = {0};
 
-    float* frame(int f) { return frames + (size_t)f * frame_stride; }
-    float* grad(int f) { return grads + (size_t)(f & 1) * ((size_t)GR_WORDS * Np + Np); }
+    float* frame(int f) { return frame_ptr[f]; }
+    float*& spare_frame() { return frame_ptr[L + 1]; }
+    float* grad(int f) { return grad_ptr[f & 1]; }
+    size_t grad_words() const { return (size_t)GR_WORDS * Np + Np; }
+    TableP tableP(int id) const { TableP t; t.pid_of_slot = tables[id].pid; t.items = tables[id].items; t.meta = tables[id].meta; return t; }
+    const int* pid_of(int f) const { return tables[tbl_of_frame[f]].pid; }
 };
 
 static std::string g_create_err;
@@ -703,13 +1069,14 @@ BoundaryP to_boundary(const FeBoundary& b) {
 }
 
 AgentP agent_params(FeEngine* h) {
-    AgentP a; std::memset(&a, 0, sizeof(a));
-    a.n = (int)h->effs.size();
-    for (int i = 0; i < a.n; i++) a.e[i] = h->effs[i].p;
+    AgentP a; a.n = (int)h->effs.size(); a.inj = 0; a.e = h->effs_dev;
+    for (size_t i = 0; i < h->effs.size(); i++) if (h->effs[i].p.type == FE_EFF_INJECTOR) a.inj = (int)i;
     return a;
 }
 
 inline dim3 pgrid(FeEngine* h) { return dim3((h->N + 255) / 256); }
+// work-list kernels loop over (items + tail chunks); the count lives on the device, so launch a bounded grid
+inline dim3 wgrid(FeEngine* h) { int g = (h->N + 63) / 64 + 8; return dim3(g < 2048 ? g : 2048); }
 inline dim3 ggrid(FeEngine* h) { int blocks = h->nb * h->nb * h->nb; int g = (blocks + 3) / 4; return dim3(g < 1024 ? g : 1024); }
 
 void prof_drain(FeEngine* h);
@@ -744,9 +1111,8 @@ int find_injector(FeEngine* h) {
     return -1;
 }
 
-int make_inject(FeEngine* h, int f, int f_global, int act, bool forward, InjectP& inj, EffP& injp) {
-    inj.on = 0; inj.act_id = 0; inj.row = 0;
-    std::memset(&injp, 0, sizeof(injp));
+int make_inject(FeEngine* h, int f, int f_global, int act, bool forward, InjectP& inj) {
+    inj.on = 0; inj.act_id = 0; inj.row = 0; inj.flux = 0;
     int ie = find_injector(h);
     if (!act || ie < 0) return 0;
     EffHost& E = h->effs[ie];
@@ -757,49 +1123,118 @@ int make_inject(FeEngine* h, int f, int f_global, int act, bool forward, InjectP
         if (E.act_id[f] + E.p.flux > (int)E.act_range.size()) FAIL(h, "too many particles added");   // agent_injector.py:38-39
         E.act_id[f + 1] = E.act_id[f] + E.p.flux;                                                     // injector.py:105
     }
-    inj.on = 1; inj.act_id = E.act_id[f]; inj.row = row; injp = E.p;
+    inj.on = 1; inj.act_id = E.act_id[f]; inj.row = row; inj.flux = E.p.flux;
     return 0;
 }
 
+int check_async(FeEngine* h);
+
+int ensure_table(FeEngine* h, int id) {
+    if ((int)h->tables.size() <= id) h->tables.resize(id + 1);
+    FeEngine::Table& t = h->tables[id];
+    if (t.pid) return 0;
+    if (dev_alloc(h, &t.pid, h->Np) || dev_alloc(h, &t.items, h->items_cap) || dev_alloc(h, &t.meta, 4)) return 1;
+    return 0;
+}
+
+// bring adjoint ring slot `slot` into particle order `to` (via the identity order; rare: once per K substeps)
+int reorder_grad(FeEngine* h, int slot, int to) {
+    const int from = h->gtbl[slot];
+    if (from == to || from < 0) { if (from >= 0) h->gtbl[slot] = to; return 0; }
+    prof_begin(h, KID_REORDER_GRAD);
+    if (from != 0) {
+        hipLaunchKernelGGL(k_perm_scatter, pgrid(h), dim3(256), 0, h->stream, h->N, (size_t)h->Np, h->grad_ptr[2], h->grad_ptr[slot], h->tables[from].pid);
+        std::swap(h->grad_ptr[2], h->grad_ptr[slot]);
+    }
+    if (to != 0) {
+        hipLaunchKernelGGL(k_perm_gather<false>, pgrid(h), dim3(256), 0, h->stream, h->N, (size_t)h->Np, h->grad_ptr[2], h->grad_ptr[slot], h->tables[to].pid);
+        std::swap(h->grad_ptr[2], h->grad_ptr[slot]);
+    }
+    prof_end(h);
+    h->gtbl[slot] = to;
+    return 0;
+}
+
+// the adjoint slot of frame f must be in the order frame f is stored in before anything accumulates into it
+int grad_order_for_frame(FeEngine* h, int f) {
+    const int t = h->tbl_of_frame[f];
+    if (h->gtbl[f & 1] < 0) { h->gtbl[f & 1] = t; return 0; }
+    return reorder_grad(h, f & 1, t);
+}
+
+// counting sort of frame f by 4^3 block; the new order becomes table 1+f
+int sort_frame(FeEngine* h, int f) {
+    const int id_new = 1 + f, id_old = h->tbl_of_frame[f];
+    if (ensure_table(h, id_new)) return 1;
+    for (int slot = 0; slot < 2; slot++)            // an adjoint slot still stored in the order about to be overwritten
+        if (h->gtbl[slot] == id_new && reorder_grad(h, slot, 0)) return 1;
+    FeEngine::Table& tn = h->tables[id_new];
+    const int nblk = h->nb * h->nb * h->nb;
+    prof_begin(h, KID_SORT);
+    hipLaunchKernelGGL(k_sort_count, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->sort_key, h->sort_rank, h->sort_cnt);
+    hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, h->stream, nblk, h->sort_cnt, h->sort_start, tn.items, tn.meta);
+    hipLaunchKernelGGL(k_sort_perm, pgrid(h), dim3(256), 0, h->stream, h->N, h->sort_key, h->sort_rank, h->sort_start,
+                       h->tables[id_old].pid, h->sort_src, h->sort_pid);
+    HIPCK(h, hipMemcpyAsync(tn.pid, h->sort_pid, sizeof(int) * h->Np, hipMemcpyDeviceToDevice, h->stream));
+    hipLaunchKernelGGL(k_perm_gather<true>, pgrid(h), dim3(256), 0, h->stream, h->N, (size_t)h->Np, h->spare_frame(), h->frame(f), h->sort_src);
+    prof_end(h);
+    std::swap(h->frame_ptr[f], h->spare_frame());
+    h->tbl_of_frame[f] = id_new;
+    return 0;
+}
+
+GridW grid_w(FeEngine* h) {
+    GridW g; g.g_in = h->g_in; g.blk_flag = h->blk_flag; g.blk_list = h->blk_list; g.blk_count = h->blk_count; g.err = h->err_dev; g.slow = h->slow_dev;
+    return g;
+}
+
 int substep_fwd(FeEngine* h, int f, int f_global, int act) {
-    InjectP inj; EffP injp;
-    if (make_inject(h, f, f_global, act, true, inj, injp)) return 1;
+    InjectP inj;
+    if (make_inject(h, f, f_global, act, true, inj)) return 1;
+    if (h->sort_interval > 0 && f % h->sort_interval == 0 && sort_frame(h, f)) return 1;
+    h->tbl_of_frame[f + 1] = h->tbl_of_frame[f];        // a substep keeps the slot order
+    const TableP T = h->tableP(h->tbl_of_frame[f]);
     AgentP ag = agent_params(h);
     prof_begin(h, KID_P2G);
-    hipLaunchKernelGGL(k_p2g<true>, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), h->pid_of_slot,
-                       h->pinfo, h->pool_idx, h->g_in, h->blk_flag, h->blk_list, h->blk_count, ag, injp, inj, act, f, h->err_dev);
+    hipLaunchKernelGGL(k_p2g<true>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T,
+                       h->pinfo, h->pool_idx, grid_w(h), ag, inj, act, f);
     prof_end(h);
     prof_begin(h, KID_GRID);
     hipLaunchKernelGGL(k_grid<false>, ggrid(h), dim3(256), 0, h->stream, h->S, h->g_in, h->g_out, h->blk_list, h->blk_count, h->blk_flag);
     prof_end(h);
     prof_begin(h, KID_G2P);
-    hipLaunchKernelGGL(k_g2p, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), h->g_out, h->blk_count);
+    hipLaunchKernelGGL(k_g2p, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T, h->g_out, h->blk_count, h->slow_dev);
     prof_end(h);
     return 0;
 }
 
 int substep_bwd(FeEngine* h, int f, int f_global, int act) {
-    InjectP inj; EffP injp;
-    if (make_inject(h, f, f_global, act, false, inj, injp)) return 1;
+    InjectP inj;
+    if (make_inject(h, f, f_global, act, false, inj)) return 1;
+    // grad[f+1] arrives in the order frame f+1 is stored in; substep f works in frame f's order
+    const int t = h->tbl_of_frame[f];
+    if (reorder_grad(h, (f + 1) & 1, t)) return 1;
+    const TableP T = h->tableP(t);
     AgentP ag = agent_params(h);
-    InjectP noinj = {0, 0, 0};
+    InjectP noinj = {0, 0, 0, 0};
     prof_begin(h, KID_P2G_RE);
-    hipLaunchKernelGGL(k_p2g<false>, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), h->pid_of_slot,
-                       h->pinfo, h->pool_idx, h->g_in, h->blk_flag, h->blk_list, h->blk_count, ag, injp, noinj, 0, f, h->err_dev);
+    hipLaunchKernelGGL(k_p2g<false>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T,
+                       h->pinfo, h->pool_idx, grid_w(h), ag, noinj, 0, f);
     prof_end(h);
     prof_begin(h, KID_GRID_KEEP);
     hipLaunchKernelGGL(k_grid<true>, ggrid(h), dim3(256), 0, h->stream, h->S, h->g_in, h->g_out, h->blk_list, h->blk_count, h->blk_flag);
     prof_end(h);
     prof_begin(h, KID_G2P_GRAD);
-    hipLaunchKernelGGL(k_g2p_grad, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), h->g_out, h->gg_out);
+    hipLaunchKernelGGL(k_g2p_grad, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slow_dev);
     prof_end(h);
     prof_begin(h, KID_GRID_GRAD);
     hipLaunchKernelGGL(k_grid_grad, ggrid(h), dim3(256), 0, h->stream, h->S, h->g_in, h->gg_out, h->gg_in, h->blk_list, h->blk_count, h->blk_flag);
     prof_end(h);
     prof_begin(h, KID_P2G_GRAD);
-    hipLaunchKernelGGL(k_p2g_grad, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), h->pid_of_slot,
-                       h->pinfo, h->pool_idx, h->gg_in, h->blk_count, ag, injp, inj, act, f);
+    hipLaunchKernelGGL(k_p2g_grad, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T,
+                       h->pinfo, h->pool_idx, h->gg_in, h->blk_count, h->slow_dev, ag, inj, act, f);
     prof_end(h);
+    h->gtbl[f & 1] = t;
     return 0;
 }
 
@@ -809,7 +1244,7 @@ int check_async(FeEngine* h) {
 }
 
 // H2D staging + pack into frame / grad planes
-int upload_planes(FeEngine* h, float* planes, const float* x, const float* v, const float* C, const float* F, const int* used, int add) {
+int upload_planes(FeEngine* h, float* planes, const int* pid, const float* x, const float* v, const float* C, const float* F, const int* used, int add) {
     const size_t N = h->N;
     int mask = 0;
     float *sx = h->stage_r, *sv = h->stage_r + 3 * N, *sC = h->stage_r + 6 * N, *sF = h->stage_r + 15 * N;
@@ -819,16 +1254,16 @@ int upload_planes(FeEngine* h, float* planes, const float* x, const float* v, co
     if (F) { mask |= 8; HIPCK(h, hipMemcpyAsync(sF, F, sizeof(float) * 9 * N, hipMemcpyHostToDevice, h->stream)); }
     if (used) { mask |= 16; HIPCK(h, hipMemcpyAsync(h->stage_i, used, sizeof(int) * N, hipMemcpyHostToDevice, h->stream)); }
     if (!mask || N == 0) return 0;
-    hipLaunchKernelGGL(k_pack, pgrid(h), dim3(256), 0, h->stream, h->N, (size_t)h->Np, planes, h->pid_of_slot, sx, sv, sC, sF, h->stage_i, mask, add);
+    hipLaunchKernelGGL(k_pack, pgrid(h), dim3(256), 0, h->stream, h->N, (size_t)h->Np, planes, pid, sx, sv, sC, sF, h->stage_i, mask, add);
     HIPCK(h, hipStreamSynchronize(h->stream));      // host buffers are borrowed only for the call
     return check_async(h);
 }
-int download_planes(FeEngine* h, float* planes, float* x, float* v, float* C, float* F, int* used) {
+int download_planes(FeEngine* h, float* planes, const int* pid, float* x, float* v, float* C, float* F, int* used) {
     const size_t N = h->N;
     int mask = (x ? 1 : 0) | (v ? 2 : 0) | (C ? 4 : 0) | (F ? 8 : 0) | (used ? 16 : 0);
     if (!mask || N == 0) return 0;
     float *sx = h->stage_r, *sv = h->stage_r + 3 * N, *sC = h->stage_r + 6 * N, *sF = h->stage_r + 15 * N;
-    hipLaunchKernelGGL(k_unpack, pgrid(h), dim3(256), 0, h->stream, h->N, (size_t)h->Np, planes, h->pid_of_slot, sx, sv, sC, sF, h->stage_i, mask);
+    hipLaunchKernelGGL(k_unpack, pgrid(h), dim3(256), 0, h->stream, h->N, (size_t)h->Np, planes, pid, sx, sv, sC, sF, h->stage_i, mask);
     if (x) HIPCK(h, hipMemcpyAsync(x, sx, sizeof(float) * 3 * N, hipMemcpyDeviceToHost, h->stream));
     if (v) HIPCK(h, hipMemcpyAsync(v, sv, sizeof(float) * 3 * N, hipMemcpyDeviceToHost, h->stream));
     if (C) HIPCK(h, hipMemcpyAsync(C, sC, sizeof(float) * 9 * N, hipMemcpyDeviceToHost, h->stream));
@@ -882,9 +1317,21 @@ FeEngine* fe_create(const FeConfig* cfg) {
     S.bnd = to_boundary(cfg->boundary);
     h->frame_stride = (size_t)FR_WORDS * h->Np;
     const size_t ncell = (size_t)h->nb * h->nb * h->nb * 64;
-    if (dev_alloc(h, &h->frames, h->frame_stride * (h->L + 1))) return fail("");
-    if (dev_alloc(h, &h->grads, 2 * ((size_t)GR_WORDS * h->Np + h->Np))) return fail("");
-    if (dev_alloc(h, &h->pid_of_slot, h->Np) || dev_alloc(h, &h->slot_of_pid, h->Np)) return fail("");
+    if (dev_alloc(h, &h->frames, h->frame_stride * (h->L + 2))) return fail("");
+    h->frame_ptr.resize(h->L + 2);
+    for (int i = 0; i < h->L + 2; i++) h->frame_ptr[i] = h->frames + (size_t)i * h->frame_stride;
+    if (dev_alloc(h, &h->grads, 3 * h->grad_words())) return fail("");
+    for (int i = 0; i < 3; i++) h->grad_ptr[i] = h->grads + (size_t)i * h->grad_words();
+    h->tbl_of_frame.assign(h->L + 1, 0);
+    {
+        const size_t nblk = (size_t)h->nb * h->nb * h->nb;
+        h->items_cap = (nblk < (size_t)h->Np ? nblk : (size_t)h->Np) + (size_t)h->Np / ITEM_MAX + 2;
+        if (dev_alloc(h, &h->sort_key, h->Np) || dev_alloc(h, &h->sort_rank, h->Np) || dev_alloc(h, &h->sort_cnt, nblk + 1) ||
+            dev_alloc(h, &h->sort_start, nblk + 1) || dev_alloc(h, &h->sort_src, h->Np) || dev_alloc(h, &h->sort_pid, h->Np) ||
+            dev_alloc(h, &h->slow_dev, 1)) return fail("");
+    }
+    if (dev_alloc(h, &h->effs_dev, FE_MAX_EFF)) return fail("");
+    if (ensure_table(h, 0)) return fail("");                 // identity order: no items, everything is "tail"
     if (dev_alloc(h, &h->pinfo, h->Np) || dev_alloc(h, &h->pool_idx, h->Np)) return fail("");
     if (dev_alloc(h, &h->g_in, ncell) || dev_alloc(h, &h->g_out, ncell) || dev_alloc(h, &h->gg_out, ncell) || dev_alloc(h, &h->gg_in, ncell)) return fail("");
     if (dev_alloc(h, &h->blk_flag, ncell / 64) || dev_alloc(h, &h->blk_list, ncell / 64) || dev_alloc(h, &h->blk_count, 1) || dev_alloc(h, &h->err_dev, 1)) return fail("");
@@ -893,8 +1340,7 @@ FeEngine* fe_create(const FeConfig* cfg) {
     {   // identity particle order
         std::vector<int> id(h->Np);
         for (int i = 0; i < h->Np; i++) id[i] = i < h->N ? i : 0;
-        if (hipMemcpy(h->pid_of_slot, id.data(), sizeof(int) * h->Np, hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy failed");
-        if (hipMemcpy(h->slot_of_pid, id.data(), sizeof(int) * h->Np, hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy failed");
+        if (hipMemcpy(h->tables[0].pid, id.data(), sizeof(int) * h->Np, hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy failed");
     }
     if (hipEventCreate(&h->ev_t0) != hipSuccess || hipEventCreate(&h->ev_t1) != hipSuccess) return fail("hipEventCreate failed");
     if (hipStreamSynchronize(h->stream) != hipSuccess) return fail("device initialisation failed");
@@ -905,7 +1351,8 @@ void fe_destroy(FeEngine* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* ptrs[] = {h->frames, h->grads, h->pid_of_slot, h->slot_of_pid, h->pinfo, h->pool_idx, h->g_in, h->g_out, h->gg_out, h->gg_in,
+    for (auto& t : h->tables) { if (t.pid) (void)hipFree(t.pid); if (t.items) (void)hipFree(t.items); if (t.meta) (void)hipFree(t.meta); }
+    void* ptrs[] = {h->frames, h->grads, h->sort_key, h->sort_rank, h->sort_cnt, h->sort_start, h->sort_src, h->sort_pid, h->slow_dev, h->effs_dev, h->pinfo, h->pool_idx, h->g_in, h->g_out, h->gg_out, h->gg_in,
                     h->blk_flag, h->blk_list, h->blk_count, h->err_dev, h->stage_r, h->stage_i, h->node_mark, h->counters,
                     h->tgt, h->chamfer, h->step_loss};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -929,8 +1376,13 @@ int fe_sync(FeEngine* h) {
 }
 
 int fe_set_option(FeEngine* h, const char* name, double value) {
-    (void)h; (void)name; (void)value;      // tunables arrive with the sorted / LDS-tiled kernels
-    return 0;
+    if (!std::strcmp(name, "sort_interval")) {
+        if (value < 0) FAIL(h, "sort_interval must be >= 0");
+        h->sort_interval = (int)value;
+        return 0;
+    }
+    if (!std::strcmp(name, "threads")) return 0;             // oracle-only tunable
+    FAIL(h, std::string("unknown option: ") + name);
 }
 
 int fe_init_particles(FeEngine* h, const fe_real* x, const int* used, const int* mat, const int* mat_cls,
@@ -950,7 +1402,8 @@ int fe_init_particles(FeEngine* h, const fe_real* x, const int* used, const int*
     }
     HIPCK(h, hipMemcpyAsync(h->pinfo, info.data(), sizeof(float4) * h->Np, hipMemcpyHostToDevice, h->stream));
     HIPCK(h, hipStreamSynchronize(h->stream));
-    return upload_planes(h, h->frame(0), x, v0.data(), C0.data(), F0.data(), used, 0);
+    h->tbl_of_frame[0] = 0;
+    return upload_planes(h, h->frame(0), h->pid_of(0), x, v0.data(), C0.data(), F0.data(), used, 0);
 }
 
 int fe_substep(FeEngine* h, int f, int f_global, int act) {
@@ -976,24 +1429,27 @@ int fe_step_grad(FeEngine* h, int f0, int f_global0, int n, int act) {
 
 int fe_get_frame(FeEngine* h, int f, fe_real* x, fe_real* v, fe_real* C, fe_real* F, int* used) {
     CHECK_FRAME(h, f);
-    if (download_planes(h, h->frame(f), x, v, C, F, used)) return 1;
+    if (download_planes(h, h->frame(f), h->pid_of(f), x, v, C, F, used)) return 1;
     return check_device_errors(h);
 }
 int fe_set_frame(FeEngine* h, int f, const fe_real* x, const fe_real* v, const fe_real* C, const fe_real* F, const int* used) {
     CHECK_FRAME(h, f);
-    return upload_planes(h, h->frame(f), x, v, C, F, used, 0);
+    return upload_planes(h, h->frame(f), h->pid_of(f), x, v, C, F, used, 0);
 }
 int fe_copy_frame(FeEngine* h, int src, int dst) {
     CHECK_FRAME(h, src); CHECK_FRAME(h, dst);
     if (src == dst) return 0;
     HIPCK(h, hipMemcpyAsync(h->frame(dst), h->frame(src), sizeof(float) * h->frame_stride, hipMemcpyDeviceToDevice, h->stream));
+    h->tbl_of_frame[dst] = h->tbl_of_frame[src];
     return 0;
 }
 int fe_copy_grad(FeEngine* h, int src, int dst) {
     CHECK_FRAME(h, src); CHECK_FRAME(h, dst);
     // adjoint frames are a ring of two (slot = f & 1); the `used` copy of mpm:604 is a frame copy
-    if ((src & 1) != (dst & 1))
+    if ((src & 1) != (dst & 1)) {
         HIPCK(h, hipMemcpyAsync(h->grad(dst), h->grad(src), sizeof(float) * GR_WORDS * h->Np, hipMemcpyDeviceToDevice, h->stream));
+        h->gtbl[dst & 1] = h->gtbl[src & 1];
+    }
     if (src != dst) {
         FrameV s = frame_view(h->frame(src), h->Np), d = frame_view(h->frame(dst), h->Np);
         HIPCK(h, hipMemcpyAsync(d.used, s.used, sizeof(int) * h->Np, hipMemcpyDeviceToDevice, h->stream));
@@ -1001,7 +1457,9 @@ int fe_copy_grad(FeEngine* h, int src, int dst) {
     return 0;
 }
 int fe_reset_grad(FeEngine* h) {
-    HIPCK(h, hipMemsetAsync(h->grads, 0, sizeof(float) * 2 * ((size_t)GR_WORDS * h->Np + h->Np), h->stream));
+    HIPCK(h, hipMemsetAsync(h->grad_ptr[0], 0, sizeof(float) * h->grad_words(), h->stream));
+    HIPCK(h, hipMemsetAsync(h->grad_ptr[1], 0, sizeof(float) * h->grad_words(), h->stream));
+    h->gtbl[0] = h->gtbl[1] = -1;
     for (auto& E : h->effs) {
         const int Fm = h->L + 1, ad = E.p.action_dim > 0 ? E.p.action_dim : 1;
         HIPCK(h, hipMemsetAsync(E.p.gpos, 0, sizeof(float) * 3 * Fm, h->stream));
@@ -1027,11 +1485,13 @@ int fe_reset_grad_till_frame(FeEngine* h, int f) {
 }
 int fe_get_grad(FeEngine* h, int f, fe_real* gx, fe_real* gv, fe_real* gC, fe_real* gF) {
     CHECK_FRAME(h, f);
-    return download_planes(h, h->grad(f), gx, gv, gC, gF, nullptr);
+    const int t = h->gtbl[f & 1] < 0 ? 0 : h->gtbl[f & 1];
+    return download_planes(h, h->grad(f), h->tables[t].pid, gx, gv, gC, gF, nullptr);
 }
 int fe_add_grad(FeEngine* h, int f, const fe_real* gx, const fe_real* gv, const fe_real* gC, const fe_real* gF) {
     CHECK_FRAME(h, f);
-    return upload_planes(h, h->grad(f), gx, gv, gC, gF, nullptr, 1);
+    if (grad_order_for_frame(h, f)) return 1;
+    return upload_planes(h, h->grad(f), h->pid_of(f), gx, gv, gC, gF, nullptr, 1);
 }
 int fe_get_mat(FeEngine* h, int* mat) {
     if ((int)h->mat_host.size() != h->N) FAIL(h, "particles not initialised");
@@ -1067,6 +1527,7 @@ int fe_add_effector(FeEngine* h, const FeEffectorDesc* d, const fe_real* random_
     }
     E.act_id.assign(Fm, 0);
     h->effs.push_back(E);
+    if (hipMemcpy(h->effs_dev + (h->effs.size() - 1), &h->effs.back().p, sizeof(EffP), hipMemcpyHostToDevice) != hipSuccess) return bad("hipMemcpy failed");
     return (int)h->effs.size() - 1;
 }
 int fe_eff_set_act_range(FeEngine* h, int e, const int* act_range, int n) {
@@ -1200,7 +1661,7 @@ int fe_loss_clear(FeEngine* h) {
 int fe_loss_step(FeEngine* h, int s, int f, int matching_mat, fe_real weight) {
     if (s < 0 || s >= h->loss_steps) FAIL(h, "loss step out of range");
     CHECK_FRAME(h, f);
-    hipLaunchKernelGGL(k_loss_fwd, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->pid_of_slot, h->pinfo,
+    hipLaunchKernelGGL(k_loss_fwd, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->pid_of(f), h->pinfo,
                        h->tgt + (size_t)s * h->N * 3, matching_mat, h->chamfer + s);
     hipLaunchKernelGGL(k_loss_sum, dim3(1), dim3(64), 0, h->stream, h->chamfer + s, h->step_loss + s, weight);
     return check_async(h);
@@ -1208,7 +1669,8 @@ int fe_loss_step(FeEngine* h, int s, int f, int matching_mat, fe_real weight) {
 int fe_loss_step_grad(FeEngine* h, int s, int f, int matching_mat, fe_real weight, fe_real step_loss_grad) {
     if (s < 0 || s >= h->loss_steps) FAIL(h, "loss step out of range");
     CHECK_FRAME(h, f);
-    hipLaunchKernelGGL(k_loss_bwd, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->grad(f), h->pid_of_slot, h->pinfo,
+    if (grad_order_for_frame(h, f)) return 1;
+    hipLaunchKernelGGL(k_loss_bwd, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->grad(f), h->pid_of(f), h->pinfo,
                        h->tgt + (size_t)s * h->N * 3, matching_mat, weight * step_loss_grad);
     return check_async(h);
 }
@@ -1227,10 +1689,13 @@ int fe_get_stats(FeEngine* h, int f, FeStats* out) {
     hipLaunchKernelGGL(k_stats_mark, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->node_mark, h->counters);
     hipLaunchKernelGGL(k_stats_count, dim3((ncell + 255) / 256), dim3(256), 0, h->stream, ncell, h->node_mark, h->counters);
     unsigned long long c[4];
+    int slow = 0;
     HIPCK(h, hipMemcpyAsync(c, h->counters, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipMemcpyAsync(&slow, h->slow_dev, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipMemsetAsync(h->slow_dev, 0, sizeof(int), h->stream));
     HIPCK(h, hipStreamSynchronize(h->stream));
     out->n_used = (long long)c[0]; out->n_cells_touched = (long long)c[1]; out->n_blocks_active = (long long)c[2];
-    out->n_slow_path = 0; out->bytes_state = (long long)h->bytes;
+    out->n_slow_path = slow; out->bytes_state = (long long)h->bytes;
     return check_async(h);
 }
 int fe_timer_start(FeEngine* h) { HIPCK(h, hipEventRecord(h->ev_t0, h->stream)); return 0; }

@@ -79,12 +79,14 @@ def latte_mini(n_grid=16, n_coffee=1200, n_pool=200, seed=2, horizon=6, n_subste
 
 
 # ------------------------------------------------------------------------------------------
-def make_engine(elib, sc, max_substeps_local=None, device=0):
+def make_engine(elib, sc, max_substeps_local=None, device=0, options=None):
     n = sc['n_grid']
     L = max_substeps_local or sc.get('max_substeps_local', 64)
     eng = Engine(elib, n_grid=n, n_particles=sc['N'], max_substeps_local=L, n_substeps=sc['n_substeps'],
                  max_action_steps=sc.get('horizon', 8), dt=sc['dt'], p_vol=(0.5 / n) ** 2, gravity=sc['gravity'],
                  boundary=elib.make_boundary(**sc['boundary']), device=device)
+    for k, v in (options or sc.get('options') or {}).items():
+        eng.set_option(k, v)
     mat = sc['mat']
     props = np.array([MATERIALS[int(m)] for m in mat], dtype=np.float64)
     eng.init_particles(sc['x'], sc['used'], mat, props[:, 3].astype(np.int32), props[:, 0], props[:, 1], props[:, 2],
@@ -126,10 +128,10 @@ def random_cotangent(N, seed=5):
                 gC=f32(rng.normal(size=(N, 3, 3)) * 1e-4), gF=f32(rng.normal(size=(N, 3, 3)) * 1e-2))
 
 
-def run_latte(elib, sc, device=0):
+def run_latte(elib, sc, device=0, options=None):
     """Full mini trajectory optimisation pass through the raw ABI, mirroring Solver.forward_backward
     (optimizer/solver.py:23-59): forward with loss, backward, action gradient."""
-    eng = make_engine(elib, sc, device=device)
+    eng = make_engine(elib, sc, device=device, options=options)
     inj = sc['injector']
     e = eng.add_effector(type=FE_EFF_INJECTOR, action_dim=inj['action_dim'], action_scale_v=inj['action_scale_v'],
                          action_scale_p=inj['action_scale_p'], boundary=elib.make_boundary(**inj['boundary']),
