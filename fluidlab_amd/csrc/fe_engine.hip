@@ -72,6 +72,7 @@ __device__ __forceinline__ int cell_addr(int i, int j, int k, int nb) {
 
 struct SimP {
     int N, Np, n, nb;
+    int ncell;                               // nb^3 * 64: plane stride of the SoA accumulator grids
     float dx, inv_dx, dt, stress_scale;     // stress_scale = -dt * p_vol * 4 * inv_dx^2 (mpm:343)
     float g[3];
     BoundaryP bnd;
@@ -123,7 +124,11 @@ __device__ __forceinline__ void mark_block(int b, int* blk_flag, int* blk_list, 
 #define WG 256
 // The LDS tile of the workgroup's current item (SoA planes of TILE_N floats).  File scope, so every
 // access is a known-LDS ds_* instruction (a `float*` parameter that may also be null degrades to flat_*).
-__shared__ float s_tile[6 * TILE_N];
+__shared__ float  s_tile[4 * TILE_N];      // gathered node values (v_out / d v_in,d m)
+// Scatter accumulators are fp64: measured on MI355X ds_add_f32 sustains ~0.2 T lane-ops/s chip-wide, ds_add_f64
+// ~1.6 T and ds_add_u64 ~2.8 T in this access pattern (profiles/r01_ubench_lds_types.txt); fp64 also makes the
+// in-tile sum insensitive to the order of the atomics.
+__shared__ double s_acc[4 * TILE_N];
 // Keeps the fully unrolled 27-node stencil loops from being software-pipelined into one giant basic
 // block (which drove k_p2g_grad to 512 registers + scratch): nothing is scheduled across the fence.
 #define NODE_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -173,7 +178,7 @@ __device__ void effector_move(const EffP& e, int f) {
 }
 
 struct GridW {            // everything a scattering particle needs of the global grid
-    float4* g_in; int* blk_flag; int* blk_list; int* blk_count; int* err; int* slow;
+    float* g_in; int ncell; int* blk_flag; int* blk_list; int* blk_count; int* err; int* slow;
 };
 
 // advect_used + process_unused_particles (mpm:304-316) + Injector.act (injector.py:80-105) for one unused slot
@@ -209,7 +214,7 @@ __device__ __forceinline__ void unused_particle_fwd(const SimP& S, const FrameV&
 
 // p2g for one used particle (mpm:331-378 + compute_F_tmp/svd mpm:254-264).  `tile` = LDS accumulators
 // (vx,vy,vz,m as four TILE_N planes) or nullptr for the global path.
-template <bool WRITE>
+template <bool WRITE, bool GENERAL>
 __device__ __forceinline__ void used_particle_p2g(const SimP& S, const FrameV& cur, const FrameV& nxt, int s, int pid,
                                                   const float4* __restrict__ pinfo, bool use_tile, const TileO& to, const GridW& G) {
     PState p;
@@ -217,7 +222,7 @@ __device__ __forceinline__ void used_particle_p2g(const SimP& S, const FrameV& c
     load_F(cur, s, p.F);
     PInfo info = load_info(pinfo, pid);
     Constitutive k;
-    constitutive_eval(p.C, p.F, S.dt, info.mu, info.lam, info.mass, info.cls, S.stress_scale, k);
+    constitutive_eval_t<GENERAL>(p.C, p.F, S.dt, info.mu, info.lam, info.mass, info.cls, S.stress_scale, k);
     if (WRITE) { store_F(nxt, s, k.Fnew); nxt.used[s] = 1; }
     Stencil st;
     stencil_make(p.x, S.inv_dx, st);
@@ -245,8 +250,8 @@ __device__ __forceinline__ void used_particle_p2g(const SimP& S, const FrameV& c
                 const float oz = (float)kk * S.dx;
                 const int l = lb + (i * TILE_T + j) * TILE_T + kk;
 #pragma unroll
-                for (int a = 0; a < 3; a++) atomicAdd(&s_tile[a * TILE_N + l], weight * (mij[a] + k.affine.a[a][2] * oz));   // ds_add_f32
-                atomicAdd(&s_tile[3 * TILE_N + l], weight * m);
+                for (int a = 0; a < 3; a++) atomicAdd(&s_acc[a * TILE_N + l], (double)(weight * (mij[a] + k.affine.a[a][2] * oz)));   // ds_add_f64
+                atomicAdd(&s_acc[3 * TILE_N + l], (double)(weight * m));
             }
         }
         return;
@@ -263,10 +268,10 @@ __device__ __forceinline__ void used_particle_p2g(const SimP& S, const FrameV& c
         for (int kk = 0; kk < 3; kk++) {
             const float weight = wij * st.w[kk][2];
             const float oz = (float)kk * S.dx;
-            float* dst = (float*)&G.g_in[cell_addr(st.base[0] + i, st.base[1] + j, st.base[2] + kk, S.nb)];
+            float* dst = G.g_in + cell_addr(st.base[0] + i, st.base[1] + j, st.base[2] + kk, S.nb);
 #pragma unroll
-            for (int a = 0; a < 3; a++) unsafeAtomicAdd(dst + a, weight * (mij[a] + k.affine.a[a][2] * oz));
-            unsafeAtomicAdd(dst + 3, weight * m);
+            for (int a = 0; a < 3; a++) unsafeAtomicAdd(dst + a * S.ncell, weight * (mij[a] + k.affine.a[a][2] * oz));
+            unsafeAtomicAdd(dst + 3 * S.ncell, weight * m);
         }
     }
     // mark the (up to 8) 4^3 blocks this stencil touches
@@ -280,18 +285,18 @@ __device__ __forceinline__ void used_particle_p2g(const SimP& S, const FrameV& c
 
 // one slot of the p2g pass: used particles scatter, unused ones are carried / injected.  (`used` is re-read
 // here rather than implied by the work list so that host edits of a frame can never desynchronise it.)
-template <bool WRITE>
+template <bool WRITE, bool GENERAL>
 __device__ __forceinline__ void slot_p2g(const SimP& S, const FrameV& cur, const FrameV& nxt, int s, const TableP& T,
                                          const float4* __restrict__ pinfo, const int* __restrict__ pool_idx, bool use_tile,
                                          const TileO& to, const GridW& G, const AgentP& agent, const InjectP& inj, int f) {
     const int pid = T.pid_of_slot[s];
-    if (cur.used[s]) used_particle_p2g<WRITE>(S, cur, nxt, s, pid, pinfo, use_tile, to, G);
+    if (cur.used[s]) used_particle_p2g<WRITE, GENERAL>(S, cur, nxt, s, pid, pinfo, use_tile, to, G);
     else if (WRITE) unused_particle_fwd(S, cur, nxt, s, pid, pool_idx, agent, inj, f);
 }
 
 // p2g (mpm:331-378) fused with compute_F_tmp + svd, advect_used + process_unused_particles, Injector.act and,
 // on one thread, Effector.move_kernel.  WRITE=false is the backward pass' recompute of grid[f]: scatter only.
-template <bool WRITE>
+template <bool WRITE, bool GENERAL>
 __global__ __launch_bounds__(WG) void k_p2g(SimP S, float* fr_cur, float* fr_next, TableP T, const float4* __restrict__ pinfo,
                                             const int* __restrict__ pool_idx, GridW G, AgentP agent, InjectP inj, int act, int f) {
     const int tid = threadIdx.x;
@@ -306,18 +311,19 @@ __global__ __launch_bounds__(WG) void k_p2g(SimP S, float* fr_cur, float* fr_nex
         if (w < n_items) {
             const int4 it = T.items[w];
             const TileO to = tile_origin(it.x, S.nb);
-            for (int l = tid; l < 4 * TILE_N; l += WG) s_tile[l] = 0.f;
+            for (int l = tid; l < 4 * TILE_N; l += WG) s_acc[l] = 0.0;
             __syncthreads();
-            for (int i = tid; i < it.z; i += WG) slot_p2g<WRITE>(S, cur, nxt, it.y + i, T, pinfo, pool_idx, true, to, G, agent, inj, f);
+            for (int i = tid; i < it.z; i += WG) slot_p2g<WRITE, GENERAL>(S, cur, nxt, it.y + i, T, pinfo, pool_idx, true, to, G, agent, inj, f);
             __syncthreads();
             // flush: consecutive lanes -> consecutive nodes of a tile row
             for (int l = tid; l < TILE_N; l += WG) {
-                float vx = s_tile[l], vy = s_tile[TILE_N + l], vz = s_tile[2 * TILE_N + l], m = s_tile[3 * TILE_N + l];
+                const float vx = (float)s_acc[l], vy = (float)s_acc[TILE_N + l], vz = (float)s_acc[2 * TILE_N + l], m = (float)s_acc[3 * TILE_N + l];
                 if (m != 0.f || vx != 0.f || vy != 0.f || vz != 0.f) {
                     int i, j, k;
                     if (tile_node(to, l, S.n, i, j, k)) {
-                        float* dst = (float*)&G.g_in[cell_addr(i, j, k, S.nb)];
-                        unsafeAtomicAdd(dst + 0, vx); unsafeAtomicAdd(dst + 1, vy); unsafeAtomicAdd(dst + 2, vz); unsafeAtomicAdd(dst + 3, m);
+                        // SoA planes: per instruction the lanes of a tile row hit consecutive floats (coalesced atomics)
+                        float* dst = G.g_in + cell_addr(i, j, k, S.nb);
+                        unsafeAtomicAdd(dst, vx); unsafeAtomicAdd(dst + S.ncell, vy); unsafeAtomicAdd(dst + 2 * S.ncell, vz); unsafeAtomicAdd(dst + 3 * S.ncell, m);
                         mark_block((((i >> 2) * S.nb) + (j >> 2)) * S.nb + (k >> 2), G.blk_flag, G.blk_list, G.blk_count);
                     }
                 }
@@ -326,7 +332,7 @@ __global__ __launch_bounds__(WG) void k_p2g(SimP S, float* fr_cur, float* fr_nex
         } else {
             const int s = tail_start + (w - n_items) * WG + tid;
             TileO none = {0, 0, 0};
-            if (s < S.N) slot_p2g<WRITE>(S, cur, nxt, s, T, pinfo, pool_idx, false, none, G, agent, inj, f);
+            if (s < S.N) slot_p2g<WRITE, GENERAL>(S, cur, nxt, s, T, pinfo, pool_idx, false, none, G, agent, inj, f);
         }
     }
 }
@@ -345,14 +351,14 @@ __device__ __forceinline__ void node_velocity(const SimP& S, const float4 gi, in
 // KEEP=false (forward): also re-zeroes g_in and the block flag, so no separate reset_grid pass
 // (mpm:219-223) is needed.  KEEP=true (backward recompute): grid_grad does that later.
 template <bool KEEP>
-__global__ __launch_bounds__(256) void k_grid(SimP S, float4* g_in, float4* g_out, const int* __restrict__ blk_list,
+__global__ __launch_bounds__(256) void k_grid(SimP S, float* g_in, float4* g_out, const int* __restrict__ blk_list,
                                               const int* __restrict__ blk_count, int* blk_flag) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int cnt = *blk_count;
     for (int e = blockIdx.x * 4 + wave; e < cnt; e += gridDim.x * 4) {
         const int b = blk_list[e];
         const int c = (b << 6) | lane;
-        const float4 gi = g_in[c];
+        const float4 gi = make_float4(g_in[c], g_in[S.ncell + c], g_in[2 * S.ncell + c], g_in[3 * S.ncell + c]);
         float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
         if (gi.w > FE_EPS) {
             const int bi = b / (S.nb * S.nb), bj = (b / S.nb) % S.nb, bk = b % S.nb;
@@ -362,7 +368,7 @@ __global__ __launch_bounds__(256) void k_grid(SimP S, float4* g_in, float4* g_ou
         }
         g_out[c] = out;
         if (!KEEP) {
-            g_in[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            g_in[c] = 0.f; g_in[S.ncell + c] = 0.f; g_in[2 * S.ncell + c] = 0.f; g_in[3 * S.ncell + c] = 0.f;
             if (lane == 0) blk_flag[b] = 0;
         }
     }
@@ -470,7 +476,7 @@ __global__ __launch_bounds__(WG) void k_g2p(SimP S, float* fr_cur, float* fr_nex
 // position adjoint (so far) in Gc.A0.xyz.  TILE: v_out read from / d v_out accumulated into LDS (3+3 planes)
 template <bool TILE>
 __device__ __forceinline__ void used_particle_g2p_grad(const SimP& S, const FrameV& Gn, const FrameV& Gc, int s,
-                                                       int lb, const Stencil& st, const float4* __restrict__ g_out, float4* gg_out) {
+                                                       int lb, const Stencil& st, const float4* __restrict__ g_out, float* gg_out) {
     PState g;                                   // adjoints of x', v', C'
     load_xvC(Gn, s, g);
     // x' = x + dt v'  =>  v'_bar += dt x'_bar
@@ -495,17 +501,17 @@ __device__ __forceinline__ void used_particle_g2p_grad(const SimP& S, const Fram
             if (TILE) {
                 const int l = lb + (i * TILE_T + j) * TILE_T + kk;
                 v0 = s_tile[l]; v1 = s_tile[TILE_N + l]; v2 = s_tile[2 * TILE_N + l];
-                atomicAdd(&s_tile[3 * TILE_N + l], weight * q[0]);
-                atomicAdd(&s_tile[4 * TILE_N + l], weight * q[1]);
-                atomicAdd(&s_tile[5 * TILE_N + l], weight * q[2]);
+                atomicAdd(&s_acc[l], (double)(weight * q[0]));                // ds_add_f64
+                atomicAdd(&s_acc[TILE_N + l], (double)(weight * q[1]));
+                atomicAdd(&s_acc[2 * TILE_N + l], (double)(weight * q[2]));
             } else {
                 const int c = cell_addr(st.base[0] + i, st.base[1] + j, st.base[2] + kk, S.nb);
                 float4 vo = g_out[c];
                 v0 = vo.x; v1 = vo.y; v2 = vo.z;
-                float* dst = (float*)&gg_out[c];
-                unsafeAtomicAdd(dst + 0, weight * q[0]);
-                unsafeAtomicAdd(dst + 1, weight * q[1]);
-                unsafeAtomicAdd(dst + 2, weight * q[2]);
+                float* dst = gg_out + c;
+                unsafeAtomicAdd(dst, weight * q[0]);
+                unsafeAtomicAdd(dst + S.ncell, weight * q[1]);
+                unsafeAtomicAdd(dst + 2 * S.ncell, weight * q[2]);
             }
             const float sdot = v0 * q[0] + v1 * q[1] + v2 * q[2];
             // d weight / d fx_d
@@ -521,7 +527,7 @@ __device__ __forceinline__ void used_particle_g2p_grad(const SimP& S, const Fram
 }
 
 __device__ __forceinline__ void g2p_grad_slot(const SimP& S, const FrameV& cur, const FrameV& Gn, const FrameV& Gc, int s,
-                                              bool use_tile, const TileO& to, const float4* __restrict__ g_out, float4* gg_out, int* slow) {
+                                              bool use_tile, const TileO& to, const float4* __restrict__ g_out, float* gg_out, int* slow) {
     if (!cur.used[s]) return;
     float4 a0 = cur.A0[s];
     float x[3] = {a0.x, a0.y, a0.z};
@@ -534,7 +540,7 @@ __device__ __forceinline__ void g2p_grad_slot(const SimP& S, const FrameV& cur, 
 }
 
 __global__ __launch_bounds__(WG) void k_g2p_grad(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T,
-                                                 const float4* __restrict__ g_out, float4* gg_out, int* slow) {
+                                                 const float4* __restrict__ g_out, float* gg_out, int* slow) {
     const int tid = threadIdx.x;
     FrameV cur = frame_view(fr_cur, S.Np);
     FrameV Gn = frame_view(Gn_, S.Np), Gc = frame_view(Gc_, S.Np);
@@ -545,17 +551,17 @@ __global__ __launch_bounds__(WG) void k_g2p_grad(SimP S, float* fr_cur, float* G
             const int4 it = T.items[w];
             const TileO to = tile_origin(it.x, S.nb);
             load_tile3(to, S, g_out, tid);
-            for (int l = tid; l < 3 * TILE_N; l += WG) s_tile[3 * TILE_N + l] = 0.f;
+            for (int l = tid; l < 3 * TILE_N; l += WG) s_acc[l] = 0.0;
             __syncthreads();
             for (int i = tid; i < it.z; i += WG) g2p_grad_slot(S, cur, Gn, Gc, it.y + i, true, to, g_out, gg_out, slow);
             __syncthreads();
             for (int l = tid; l < TILE_N; l += WG) {
-                float q0 = s_tile[3 * TILE_N + l], q1 = s_tile[4 * TILE_N + l], q2 = s_tile[5 * TILE_N + l];
+                const float q0 = (float)s_acc[l], q1 = (float)s_acc[TILE_N + l], q2 = (float)s_acc[2 * TILE_N + l];
                 if (q0 != 0.f || q1 != 0.f || q2 != 0.f) {
                     int i, j, k;
                     if (tile_node(to, l, S.n, i, j, k)) {
-                        float* dst = (float*)&gg_out[cell_addr(i, j, k, S.nb)];
-                        unsafeAtomicAdd(dst + 0, q0); unsafeAtomicAdd(dst + 1, q1); unsafeAtomicAdd(dst + 2, q2);
+                        float* dst = gg_out + cell_addr(i, j, k, S.nb);
+                        unsafeAtomicAdd(dst, q0); unsafeAtomicAdd(dst + S.ncell, q1); unsafeAtomicAdd(dst + 2 * S.ncell, q2);
                     }
                 }
             }
@@ -569,7 +575,7 @@ __global__ __launch_bounds__(WG) void k_g2p_grad(SimP S, float* fr_cur, float* G
 }
 
 // grid_op.grad (mpm:539): gg_out (d/d v_out) -> gg_in (d/d v_in, d/d mass); re-zeroes g_in, gg_out, flags
-__global__ __launch_bounds__(256) void k_grid_grad(SimP S, float4* g_in, float4* gg_out, float4* gg_in,
+__global__ __launch_bounds__(256) void k_grid_grad(SimP S, float* g_in, float* gg_out, float4* gg_in,
                                                    const int* __restrict__ blk_list, const int* __restrict__ blk_count,
                                                    int* blk_flag) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -577,8 +583,8 @@ __global__ __launch_bounds__(256) void k_grid_grad(SimP S, float4* g_in, float4*
     for (int e = blockIdx.x * 4 + wave; e < cnt; e += gridDim.x * 4) {
         const int b = blk_list[e];
         const int c = (b << 6) | lane;
-        const float4 gi = g_in[c];
-        const float4 go = gg_out[c];
+        const float4 gi = make_float4(g_in[c], g_in[S.ncell + c], g_in[2 * S.ncell + c], g_in[3 * S.ncell + c]);
+        const float4 go = make_float4(gg_out[c], gg_out[S.ncell + c], gg_out[2 * S.ncell + c], 0.f);
         float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
         if (gi.w > FE_EPS) {
             const int bi = b / (S.nb * S.nb), bj = (b / S.nb) % S.nb, bk = b % S.nb;
@@ -590,8 +596,8 @@ __global__ __launch_bounds__(256) void k_grid_grad(SimP S, float4* g_in, float4*
             out.w = -(gi.x * g0 + gi.y * g1 + gi.z * g2) * inv * inv;
         }
         gg_in[c] = out;
-        g_in[c] = make_float4(0.f, 0.f, 0.f, 0.f);
-        gg_out[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+        g_in[c] = 0.f; g_in[S.ncell + c] = 0.f; g_in[2 * S.ncell + c] = 0.f; g_in[3 * S.ncell + c] = 0.f;
+        gg_out[c] = 0.f; gg_out[S.ncell + c] = 0.f; gg_out[2 * S.ncell + c] = 0.f;
         if (lane == 0) blk_flag[b] = 0;
     }
 }
@@ -609,7 +615,7 @@ __device__ void effector_move_grad(const EffP& e, int f) {
 }
 
 // p2g.grad + svd_grad + compute_F_tmp.grad (mpm:544-546) for one used particle; TILE: (d v_in, d mass) in LDS (4 planes)
-template <bool TILE>
+template <bool TILE, bool GENERAL>
 __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const FrameV& cur, const FrameV& Gn, const FrameV& Gc, int s,
                                                        int pid, const float4* __restrict__ pinfo, const TileO& to,
                                                        const float4* __restrict__ gg_in, int* slow) {
@@ -618,7 +624,7 @@ __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const Fram
     load_F(cur, s, p.F);
     PInfo info = load_info(pinfo, pid);
     Constitutive k;
-    constitutive_eval(p.C, p.F, S.dt, info.mu, info.lam, info.mass, info.cls, S.stress_scale, k);
+    constitutive_eval_t<GENERAL>(p.C, p.F, S.dt, info.mu, info.lam, info.mass, info.cls, S.stress_scale, k);
     m3 Fg; load_F(Gn, s, Fg);
     float4 gc0 = Gc.A0[s];                      // position adjoint so far (k_g2p_grad)
     float gx[3] = {gc0.x, gc0.y, gc0.z};
@@ -630,7 +636,7 @@ __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const Fram
         const int lb = TILE ? tile_base(to, st) : -1;
         if (TILE && lb < 0) {                   // drifted out of the tile: redo on the global path
             atomicAdd(slow, 1);
-            used_particle_p2g_grad<false>(S, cur, Gn, Gc, s, pid, pinfo, to, gg_in, slow);
+            used_particle_p2g_grad<false, GENERAL>(S, cur, Gn, Gc, s, pid, pinfo, to, gg_in, slow);
             return;
         }
         const float m = info.mass;
@@ -683,18 +689,18 @@ __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const Fram
     }
     float gvv[3] = {info.mass * Gv[0], info.mass * Gv[1], info.mass * Gv[2]};
     m3 gC, gF;
-    constitutive_grad(p.C, p.F, S.dt, info.mu, info.lam, info.mass, info.cls, S.stress_scale, k, GA, Fg, gC, gF);
+    constitutive_grad_t<GENERAL>(p.C, p.F, S.dt, info.mu, info.lam, info.mass, info.cls, S.stress_scale, k, GA, Fg, gC, gF);
     store_xvC(Gc, s, gx, gvv, gC);
     store_F(Gc, s, gF);
 }
 
-template <bool TILE>
+template <bool TILE, bool GENERAL>
 __device__ __forceinline__ void slot_p2g_grad(const SimP& S, const FrameV& cur, const FrameV& Gn, const FrameV& Gc, int s, const TableP& T,
                                               const float4* __restrict__ pinfo, const int* __restrict__ pool_idx,
                                               const TileO& to, const float4* __restrict__ gg_in, int* slow, const AgentP& agent,
                                               const InjectP& inj, int f) {
     const int pid = T.pid_of_slot[s];
-    if (cur.used[s]) { used_particle_p2g_grad<TILE>(S, cur, Gn, Gc, s, pid, pinfo, to, gg_in, slow); return; }
+    if (cur.used[s]) { used_particle_p2g_grad<TILE, GENERAL>(S, cur, Gn, Gc, s, pid, pinfo, to, gg_in, slow); return; }
     // the copy f -> f+1 of an unused particle passes its adjoint straight through (mpm:551)
     PState g; load_xvC(Gn, s, g); load_F(Gn, s, g.F);
     store_xvC(Gc, s, g.x, g.v, g.C); store_F(Gc, s, g.F);
@@ -709,6 +715,7 @@ __device__ __forceinline__ void slot_p2g_grad(const SimP& S, const FrameV& cur, 
 
 // p2g.grad + svd_grad + compute_F_tmp.grad + AgentInjector.act_kernel.grad + process_unused_particles.grad (mpm:551)
 // + Effector.move_kernel.grad on one thread
+template <bool GENERAL>
 __global__ __launch_bounds__(WG) void k_p2g_grad(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T,
                                                  const float4* __restrict__ pinfo, const int* __restrict__ pool_idx,
                                                  const float4* __restrict__ gg_in, int* blk_count, int* slow, AgentP agent,
@@ -728,12 +735,12 @@ __global__ __launch_bounds__(WG) void k_p2g_grad(SimP S, float* fr_cur, float* G
             const TileO to = tile_origin(it.x, S.nb);
             load_tile4(to, S, gg_in, tid);
             __syncthreads();
-            for (int i = tid; i < it.z; i += WG) slot_p2g_grad<true>(S, cur, Gn, Gc, it.y + i, T, pinfo, pool_idx, to, gg_in, slow, agent, inj, f);
+            for (int i = tid; i < it.z; i += WG) slot_p2g_grad<true, GENERAL>(S, cur, Gn, Gc, it.y + i, T, pinfo, pool_idx, to, gg_in, slow, agent, inj, f);
             __syncthreads();
         } else {
             const int s = tail_start + (w - n_items) * WG + tid;
             TileO none = {0, 0, 0};
-            if (s < S.N) slot_p2g_grad<false>(S, cur, Gn, Gc, s, T, pinfo, pool_idx, none, gg_in, slow, agent, inj, f);
+            if (s < S.N) slot_p2g_grad<false, GENERAL>(S, cur, Gn, Gc, s, T, pinfo, pool_idx, none, gg_in, slow, agent, inj, f);
         }
     }
 }
@@ -741,50 +748,109 @@ __global__ __launch_bounds__(WG) void k_p2g_grad(SimP S, float* fr_cur, float* G
 // =========================================================================================
 // block sort (counting sort by 4^3 block of the stencil base)
 // =========================================================================================
+#define SORT_HB 2048
+// histogram + rank.  Keys of one workgroup's 256 slots are nearly always within a narrow range (the previous
+// order was block-sorted too), so ranks come from an LDS histogram (ds_add_rtn_u32) and only one global atomic per
+// distinct key per workgroup is issued; keys outside the window fall back to a global atomic.
 __global__ __launch_bounds__(256) void k_sort_count(SimP S, float* fr, int* key, int* rank, int* cnt) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= S.N) return;
-    FrameV cur = frame_view(fr, S.Np);
+    __shared__ int hist[SORT_HB];
+    __shared__ int kmin;
+    const int tid = threadIdx.x;
+    const int s = blockIdx.x * blockDim.x + tid;
+    const bool valid = s < S.N;
     const int nblk = S.nb * S.nb * S.nb;
     int kk = nblk;                                           // sentinel: unused / outside -> tail
-    if (cur.used[s]) {
-        float4 a0 = cur.A0[s];
-        float x[3] = {a0.x, a0.y, a0.z};
-        Stencil st;
-        stencil_make(x, S.inv_dx, st);
-        if (stencil_inside(st, S.n)) kk = (((st.base[0] >> 2) * S.nb) + (st.base[1] >> 2)) * S.nb + (st.base[2] >> 2);
+    if (valid) {
+        FrameV cur = frame_view(fr, S.Np);
+        if (cur.used[s]) {
+            float4 a0 = cur.A0[s];
+            float x[3] = {a0.x, a0.y, a0.z};
+            Stencil st;
+            stencil_make(x, S.inv_dx, st);
+            if (stencil_inside(st, S.n)) kk = (((st.base[0] >> 2) * S.nb) + (st.base[1] >> 2)) * S.nb + (st.base[2] >> 2);
+        }
     }
-    key[s] = kk;
-    rank[s] = atomicAdd(&cnt[kk], 1);
+    if (tid == 0) kmin = 0x7fffffff;
+    for (int l = tid; l < SORT_HB; l += 256) hist[l] = 0;
+    __syncthreads();
+    if (valid) atomicMin(&kmin, kk);
+    __syncthreads();
+    const int rel = kk - kmin;
+    const bool local = valid && rel < SORT_HB;
+    int r = 0;
+    if (local) r = atomicAdd(&hist[rel], 1);
+    else if (valid) r = atomicAdd(&cnt[kk], 1);
+    __syncthreads();
+    for (int l = tid; l < SORT_HB; l += 256) { int c = hist[l]; if (c > 0) hist[l] = atomicAdd(&cnt[kmin + l], c); }
+    __syncthreads();
+    if (local) r += hist[rel];
+    if (valid) { key[s] = kk; rank[s] = r; }
 }
 
-// exclusive scan of the block histogram + work-list construction; one workgroup of 1024 threads
-__global__ __launch_bounds__(1024) void k_sort_scan(int nblk, int* cnt, int* start, int4* items, int* meta) {
-    __shared__ int sh_p[1024], sh_i[1024];
-    const int tid = threadIdx.x;
-    const int per = (nblk + 1 + 1023) / 1024;
-    const int lo = tid * per, hi = min(lo + per, nblk + 1);
-    int sp = 0, si = 0;
-    for (int b = lo; b < hi; b++) { int c = cnt[b]; sp += c; if (b < nblk) si += (c + ITEM_MAX - 1) / ITEM_MAX; }
-    sh_p[tid] = sp; sh_i[tid] = si;
+// exclusive scan of the block histogram (nblk+1 entries) in two launches of ceil((nblk+1)/1024) workgroups:
+// per-workgroup partial sums, then every workgroup adds the partials before it and scans its own 1024 entries.
+// Also emits the work list (one item per occupied block, split at ITEM_MAX particles) and re-zeroes the histogram.
+__device__ __forceinline__ int wg_scan_excl(int v, int* sh, int tid, int& total) {   // 256 threads
+    const int lane = tid & 63, wave = tid >> 6;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+    if (lane == 63) sh[wave] = incl;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {               // Hillis-Steele inclusive scan
-        int ap = 0, ai = 0;
-        if (tid >= off) { ap = sh_p[tid - off]; ai = sh_i[tid - off]; }
-        __syncthreads();
-        sh_p[tid] += ap; sh_i[tid] += ai;
-        __syncthreads();
+    int off = 0;
+    for (int w = 0; w < wave; w++) off += sh[w];
+    total = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return off + incl - v;
+}
+
+__global__ __launch_bounds__(256) void k_scan_partial(int nblk, const int* __restrict__ cnt, int2* partial) {
+    __shared__ int sh[4];
+    const int tid = threadIdx.x;
+    const int b0 = blockIdx.x * 1024 + tid * 4;
+    int sp = 0, si = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int b = b0 + q;
+        if (b <= nblk) { int c = cnt[b]; sp += c; if (b < nblk) si += (c + ITEM_MAX - 1) / ITEM_MAX; }
     }
-    int bp = sh_p[tid] - sp, bi = sh_i[tid] - si;             // exclusive prefixes of this thread's range
-    for (int b = lo; b < hi; b++) {
-        int c = cnt[b];
+    int tp, ti;
+    wg_scan_excl(sp, sh, tid, tp);
+    wg_scan_excl(si, sh, tid, ti);
+    if (tid == 0) partial[blockIdx.x] = make_int2(tp, ti);
+}
+
+__global__ __launch_bounds__(256) void k_scan_final(int nblk, int* cnt, const int2* __restrict__ partial, int* start, int4* items, int* meta) {
+    __shared__ int sh[4];
+    const int tid = threadIdx.x;
+    int pp = 0, pi = 0;                                       // sums of the partials before this workgroup
+    for (int w = tid; w < (int)blockIdx.x; w += 256) { int2 t = partial[w]; pp += t.x; pi += t.y; }
+    int tot;
+    int e = wg_scan_excl(pp, sh, tid, tot); (void)e; const int base_p = tot;
+    e = wg_scan_excl(pi, sh, tid, tot); const int base_i = tot;
+    const int b0 = blockIdx.x * 1024 + tid * 4;
+    int c[4], sp = 0, si = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int b = b0 + q;
+        c[q] = b <= nblk ? cnt[b] : 0;
+        sp += c[q];
+        if (b < nblk) si += (c[q] + ITEM_MAX - 1) / ITEM_MAX;
+    }
+    int totp, toti;
+    int bp = base_p + wg_scan_excl(sp, sh, tid, totp);
+    int bi = base_i + wg_scan_excl(si, sh, tid, toti);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int b = b0 + q;
+        if (b > nblk) break;
         start[b] = bp;
-        if (b < nblk) for (int o = 0; o < c; o += ITEM_MAX) items[bi++] = make_int4(b, bp + o, min(ITEM_MAX, c - o), 0);
-        bp += c;
+        if (b < nblk) for (int o = 0; o < c[q]; o += ITEM_MAX) items[bi++] = make_int4(b, bp + o, min(ITEM_MAX, c[q] - o), 0);
+        else meta[1] = bp;                                    // first tail slot
+        bp += c[q];
         cnt[b] = 0;                                           // ready for the next sort
     }
-    if (tid == 1023) { meta[0] = sh_i[1023]; }
-    if (hi == nblk + 1 && lo < hi) meta[1] = start[nblk];     // first tail slot
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) meta[0] = base_i + toti;
 }
 
 __global__ __launch_bounds__(256) void k_sort_perm(int N, const int* __restrict__ key, const int* __restrict__ rank,
@@ -1016,9 +1082,12 @@ struct FeEngine {
     size_t items_cap = 0;
     int *sort_key = nullptr, *sort_rank = nullptr, *sort_cnt = nullptr, *sort_start = nullptr, *sort_src = nullptr, *sort_pid = nullptr;
     int* slow_dev = nullptr;
+    int2* sort_partial = nullptr;
     float4* pinfo = nullptr; int* pool_idx = nullptr;
     std::vector<int> mat_host;
-    float4 *g_in = nullptr, *g_out = nullptr, *gg_out = nullptr, *gg_in = nullptr;
+    float *g_in = nullptr, *gg_out = nullptr;              // SoA accumulator planes (4 and 3 x ncell floats)
+    float4 *g_out = nullptr, *gg_in = nullptr;
+    bool all_simple_liquid = false;                         // every particle is an inviscid MAT_LIQUID: SVD-free kernels
     int *blk_flag = nullptr, *blk_list = nullptr, *blk_count = nullptr, *err_dev = nullptr;
     float* stage_r = nullptr; int* stage_i = nullptr;       // 24 N floats, N ints
     unsigned char* node_mark = nullptr; unsigned long long* counters = nullptr;
@@ -1172,7 +1241,9 @@ int sort_frame(FeEngine* h, int f) {
     const int nblk = h->nb * h->nb * h->nb;
     prof_begin(h, KID_SORT);
     hipLaunchKernelGGL(k_sort_count, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->sort_key, h->sort_rank, h->sort_cnt);
-    hipLaunchKernelGGL(k_sort_scan, dim3(1), dim3(1024), 0, h->stream, nblk, h->sort_cnt, h->sort_start, tn.items, tn.meta);
+    const int scan_wgs = (nblk + 1 + 1023) / 1024;
+    hipLaunchKernelGGL(k_scan_partial, dim3(scan_wgs), dim3(256), 0, h->stream, nblk, h->sort_cnt, h->sort_partial);
+    hipLaunchKernelGGL(k_scan_final, dim3(scan_wgs), dim3(256), 0, h->stream, nblk, h->sort_cnt, h->sort_partial, h->sort_start, tn.items, tn.meta);
     hipLaunchKernelGGL(k_sort_perm, pgrid(h), dim3(256), 0, h->stream, h->N, h->sort_key, h->sort_rank, h->sort_start,
                        h->tables[id_old].pid, h->sort_src, h->sort_pid);
     HIPCK(h, hipMemcpyAsync(tn.pid, h->sort_pid, sizeof(int) * h->Np, hipMemcpyDeviceToDevice, h->stream));
@@ -1184,7 +1255,7 @@ int sort_frame(FeEngine* h, int f) {
 }
 
 GridW grid_w(FeEngine* h) {
-    GridW g; g.g_in = h->g_in; g.blk_flag = h->blk_flag; g.blk_list = h->blk_list; g.blk_count = h->blk_count; g.err = h->err_dev; g.slow = h->slow_dev;
+    GridW g; g.g_in = h->g_in; g.ncell = h->S.ncell; g.blk_flag = h->blk_flag; g.blk_list = h->blk_list; g.blk_count = h->blk_count; g.err = h->err_dev; g.slow = h->slow_dev;
     return g;
 }
 
@@ -1196,8 +1267,12 @@ int substep_fwd(FeEngine* h, int f, int f_global, int act) {
     const TableP T = h->tableP(h->tbl_of_frame[f]);
     AgentP ag = agent_params(h);
     prof_begin(h, KID_P2G);
-    hipLaunchKernelGGL(k_p2g<true>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T,
-                       h->pinfo, h->pool_idx, grid_w(h), ag, inj, act, f);
+    if (h->all_simple_liquid)
+        hipLaunchKernelGGL((k_p2g<true, false>), wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T,
+                           h->pinfo, h->pool_idx, grid_w(h), ag, inj, act, f);
+    else
+        hipLaunchKernelGGL((k_p2g<true, true>), wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T,
+                           h->pinfo, h->pool_idx, grid_w(h), ag, inj, act, f);
     prof_end(h);
     prof_begin(h, KID_GRID);
     hipLaunchKernelGGL(k_grid<false>, ggrid(h), dim3(256), 0, h->stream, h->S, h->g_in, h->g_out, h->blk_list, h->blk_count, h->blk_flag);
@@ -1218,8 +1293,12 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act) {
     AgentP ag = agent_params(h);
     InjectP noinj = {0, 0, 0, 0};
     prof_begin(h, KID_P2G_RE);
-    hipLaunchKernelGGL(k_p2g<false>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T,
-                       h->pinfo, h->pool_idx, grid_w(h), ag, noinj, 0, f);
+    if (h->all_simple_liquid)
+        hipLaunchKernelGGL((k_p2g<false, false>), wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T,
+                           h->pinfo, h->pool_idx, grid_w(h), ag, noinj, 0, f);
+    else
+        hipLaunchKernelGGL((k_p2g<false, true>), wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T,
+                           h->pinfo, h->pool_idx, grid_w(h), ag, noinj, 0, f);
     prof_end(h);
     prof_begin(h, KID_GRID_KEEP);
     hipLaunchKernelGGL(k_grid<true>, ggrid(h), dim3(256), 0, h->stream, h->S, h->g_in, h->g_out, h->blk_list, h->blk_count, h->blk_flag);
@@ -1231,8 +1310,12 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act) {
     hipLaunchKernelGGL(k_grid_grad, ggrid(h), dim3(256), 0, h->stream, h->S, h->g_in, h->gg_out, h->gg_in, h->blk_list, h->blk_count, h->blk_flag);
     prof_end(h);
     prof_begin(h, KID_P2G_GRAD);
-    hipLaunchKernelGGL(k_p2g_grad, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T,
-                       h->pinfo, h->pool_idx, h->gg_in, h->blk_count, h->slow_dev, ag, inj, act, f);
+    if (h->all_simple_liquid)
+        hipLaunchKernelGGL(k_p2g_grad<false>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T,
+                           h->pinfo, h->pool_idx, h->gg_in, h->blk_count, h->slow_dev, ag, inj, act, f);
+    else
+        hipLaunchKernelGGL(k_p2g_grad<true>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T,
+                           h->pinfo, h->pool_idx, h->gg_in, h->blk_count, h->slow_dev, ag, inj, act, f);
     prof_end(h);
     h->gtbl[f & 1] = t;
     return 0;
@@ -1310,7 +1393,7 @@ FeEngine* fe_create(const FeConfig* cfg) {
     if (hipSetDevice(h->device) != hipSuccess) return fail("hipSetDevice failed");
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
     SimP& S = h->S;
-    S.N = h->N; S.Np = h->Np; S.n = h->n; S.nb = h->nb;
+    S.N = h->N; S.Np = h->Np; S.n = h->n; S.nb = h->nb; S.ncell = h->nb * h->nb * h->nb * 64;
     S.dx = 1.0f / (float)h->n; S.inv_dx = (float)h->n; S.dt = cfg->dt;
     S.stress_scale = -cfg->dt * cfg->p_vol * 4.f * S.inv_dx * S.inv_dx;
     for (int i = 0; i < 3; i++) S.g[i] = cfg->gravity[i];
@@ -1328,12 +1411,12 @@ FeEngine* fe_create(const FeConfig* cfg) {
         h->items_cap = (nblk < (size_t)h->Np ? nblk : (size_t)h->Np) + (size_t)h->Np / ITEM_MAX + 2;
         if (dev_alloc(h, &h->sort_key, h->Np) || dev_alloc(h, &h->sort_rank, h->Np) || dev_alloc(h, &h->sort_cnt, nblk + 1) ||
             dev_alloc(h, &h->sort_start, nblk + 1) || dev_alloc(h, &h->sort_src, h->Np) || dev_alloc(h, &h->sort_pid, h->Np) ||
-            dev_alloc(h, &h->slow_dev, 1)) return fail("");
+            dev_alloc(h, &h->slow_dev, 1) || dev_alloc(h, &h->sort_partial, (nblk + 1 + 1023) / 1024 + 1)) return fail("");
     }
     if (dev_alloc(h, &h->effs_dev, FE_MAX_EFF)) return fail("");
     if (ensure_table(h, 0)) return fail("");                 // identity order: no items, everything is "tail"
     if (dev_alloc(h, &h->pinfo, h->Np) || dev_alloc(h, &h->pool_idx, h->Np)) return fail("");
-    if (dev_alloc(h, &h->g_in, ncell) || dev_alloc(h, &h->g_out, ncell) || dev_alloc(h, &h->gg_out, ncell) || dev_alloc(h, &h->gg_in, ncell)) return fail("");
+    if (dev_alloc(h, &h->g_in, 4 * ncell) || dev_alloc(h, &h->g_out, ncell) || dev_alloc(h, &h->gg_out, 3 * ncell) || dev_alloc(h, &h->gg_in, ncell)) return fail("");
     if (dev_alloc(h, &h->blk_flag, ncell / 64) || dev_alloc(h, &h->blk_list, ncell / 64) || dev_alloc(h, &h->blk_count, 1) || dev_alloc(h, &h->err_dev, 1)) return fail("");
     if (dev_alloc(h, &h->stage_r, (size_t)24 * h->Np) || dev_alloc(h, &h->stage_i, h->Np)) return fail("");
     if (dev_alloc(h, &h->node_mark, ncell) || dev_alloc(h, &h->counters, 4)) return fail("");
@@ -1352,7 +1435,7 @@ void fe_destroy(FeEngine* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto& t : h->tables) { if (t.pid) (void)hipFree(t.pid); if (t.items) (void)hipFree(t.items); if (t.meta) (void)hipFree(t.meta); }
-    void* ptrs[] = {h->frames, h->grads, h->sort_key, h->sort_rank, h->sort_cnt, h->sort_start, h->sort_src, h->sort_pid, h->slow_dev, h->effs_dev, h->pinfo, h->pool_idx, h->g_in, h->g_out, h->gg_out, h->gg_in,
+    void* ptrs[] = {h->frames, h->grads, h->sort_key, h->sort_rank, h->sort_cnt, h->sort_start, h->sort_src, h->sort_pid, h->slow_dev, h->sort_partial, h->effs_dev, h->pinfo, h->pool_idx, h->g_in, h->g_out, h->gg_out, h->gg_in,
                     h->blk_flag, h->blk_list, h->blk_count, h->err_dev, h->stage_r, h->stage_i, h->node_mark, h->counters,
                     h->tgt, h->chamfer, h->step_loss};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -1392,14 +1475,17 @@ int fe_init_particles(FeEngine* h, const fe_real* x, const int* used, const int*
     std::vector<float4> info(h->Np, make_float4(0, 0, 0, 0));
     std::vector<float> C0((size_t)9 * N, 0.f), F0((size_t)9 * N, 0.f), v0((size_t)3 * N, 0.f);
     h->mat_host.assign(mat, mat + N);
+    bool simple = true;
     for (int i = 0; i < N; i++) {
         if (mat_cls[i] == FE_MAT_RIGID) FAIL(h, "MAT_RIGID shape-matching bodies are not supported yet (SURVEY 8f-4)");
         if (mat_cls[i] < 0 || mat_cls[i] > 0xffff || mat[i] < 0 || mat[i] > 0xffff) FAIL(h, "material id out of range");
         int bits = (mat_cls[i] & 0xffff) | ((mat[i] & 0xffff) << 16);
         float w; std::memcpy(&w, &bits, 4);
         info[i] = make_float4(mu[i], lam[i], h->cfg.p_vol * rho[i], w);      // mass = p_vol * rho, mpm:174
+        simple = simple && mu[i] == 0.f && mat_cls[i] == FE_MAT_LIQUID;
         F0[(size_t)i * 9] = F0[(size_t)i * 9 + 4] = F0[(size_t)i * 9 + 8] = 1.f;
     }
+    h->all_simple_liquid = simple;
     HIPCK(h, hipMemcpyAsync(h->pinfo, info.data(), sizeof(float4) * h->Np, hipMemcpyHostToDevice, h->stream));
     HIPCK(h, hipStreamSynchronize(h->stream));
     h->tbl_of_frame[0] = 0;

@@ -340,15 +340,18 @@ struct Constitutive {
     bool  full;       // SVD was needed (mu != 0 or a non-liquid class)
 };
 
-// `scale` = -dt * p_vol * 4 * inv_dx^2 (mpm:343)
-FE_HD void constitutive_eval(const m3& C, const m3& F, real dt, real mu, real lam, real mass, int cls, real scale,
-                             Constitutive& k) {
+// `scale` = -dt * p_vol * 4 * inv_dx^2 (mpm:343).  GENERAL=false is the specialisation the engine launches when
+// every particle of the scene is an inviscid liquid: the SVD path is compiled out (fewer registers, more waves).
+template <bool GENERAL>
+FE_HD void constitutive_eval_t(const m3& C, const m3& F, real dt, real mu, real lam, real mass, int cls_, real scale,
+                               Constitutive& k) {
+    const int cls = GENERAL ? cls_ : FE_MAT_LIQUID_;
     m3 IdtC = m3_scale(C, dt);
     IdtC.a[0][0] += R_(1.0); IdtC.a[1][1] += R_(1.0); IdtC.a[2][2] += R_(1.0);
     k.Ft = m3_mul(IdtC, F);
     // An inviscid liquid (mu == 0, MAT_LIQUID: WATER/MILK/COFFEE) consumes only J = det S = det F_tmp
     // (U, V proper rotations), so the SVD is skipped: stress = lam J (J-1) I and F_new = J^(1/3) I.
-    k.full = !(mu == R_(0.0) && cls == FE_MAT_LIQUID_);
+    k.full = GENERAL && !(mu == R_(0.0) && cls == FE_MAT_LIQUID_);
     m3 stress = m3_zero();
     if (k.full) {
         svd3(k.Ft, k.U, k.sig, k.V);
@@ -377,17 +380,24 @@ FE_HD void constitutive_eval(const m3& C, const m3& F, real dt, real mu, real la
     }
 }
 
+FE_HD void constitutive_eval(const m3& C, const m3& F, real dt, real mu, real lam, real mass, int cls, real scale,
+                             Constitutive& k) {
+    constitutive_eval_t<true>(C, F, dt, mu, lam, mass, cls, scale, k);
+}
+
 // Adjoint of constitutive_eval: given GA = d/d(affine) (already including the sum over nodes) and
 // Fg = d/d(F[f+1]), accumulate gC, gF (the adjoints of C[f], F[f]).  Follows p2g.grad, svd_grad and
 // compute_F_tmp.grad (mpm:544-546); closed forms in SURVEY.md Appendix A.
-FE_HD void constitutive_grad(const m3& C, const m3& F, real dt, real mu, real lam, real mass, int cls, real scale,
-                             const Constitutive& k, const m3& GA, const m3& Fg, m3& gC, m3& gF) {
+template <bool GENERAL>
+FE_HD void constitutive_grad_t(const m3& C, const m3& F, real dt, real mu, real lam, real mass, int cls_, real scale,
+                               const Constitutive& k, const m3& GA, const m3& Fg, m3& gC, m3& gF) {
+    const int cls = GENERAL ? cls_ : FE_MAT_LIQUID_;
     gC = m3_scale(GA, mass);                       // affine = stress + m C
     m3 gs = m3_scale(GA, scale);                   // adjoint of the unscaled stress
     real gJ = lam * (R_(2.0) * k.J - R_(1.0)) * m3_trace(gs);
     m3 gFt;
     if (cls == FE_MAT_LIQUID_) gJ += (R_(1.0) / R_(3.0)) * pow(k.J, R_(1.0) / R_(3.0) - R_(1.0)) * m3_trace(Fg);
-    if (!k.full) {
+    if (!GENERAL || !k.full) {
         // J = det F_tmp  =>  d J / d F_tmp = cof(F_tmp)
         gFt = m3_scale(m3_cof(k.Ft), gJ);
     } else {
@@ -425,4 +435,9 @@ FE_HD void constitutive_grad(const m3& C, const m3& F, real dt, real mu, real la
     m3 IdtC = m3_scale(C, dt);
     IdtC.a[0][0] += R_(1.0); IdtC.a[1][1] += R_(1.0); IdtC.a[2][2] += R_(1.0);
     gF = m3_mul_tn(IdtC, gFt);
+}
+
+FE_HD void constitutive_grad(const m3& C, const m3& F, real dt, real mu, real lam, real mass, int cls, real scale,
+                             const Constitutive& k, const m3& GA, const m3& Fg, m3& gC, m3& gF) {
+    constitutive_grad_t<true>(C, F, dt, mu, lam, mass, cls, scale, k, GA, Fg, gC, gF);
 }
