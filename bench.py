@@ -93,6 +93,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--opt', action='append', default=[], help='engine option name=value (tuning sweeps)')
     args = ap.parse_args()
 
     import torch
@@ -111,6 +112,9 @@ def main():
     from fluidlab_amd import _capi
     elib = _capi.load_hip()                               # no fallback: raises without the HIP library
     eng, sc = build_engine(elib, local_rank)
+    for o in args.opt:
+        k, v = o.split('=')
+        eng.set_option(k, float(v))
     action_grad = torch.zeros((251, 3), device='cuda')    # LatteArt-sized action gradient
 
     def barrier():

@@ -120,7 +120,7 @@ __device__ __forceinline__ void mark_block(int b, int* blk_flag, int* blk_list, 
 // -----------------------------------------------------------------------------------------
 #define TILE_T 8
 #define TILE_N 512
-#define ITEM_MAX 512
+#define ITEM_MAX_CAP 512      // upper bound of the runtime `item_max` option (particles per work item)
 #define WG 256
 // The LDS tile of the workgroup's current item (SoA planes of TILE_N floats).  File scope, so every
 // access is a known-LDS ds_* instruction (a `float*` parameter that may also be null degrades to flat_*).
@@ -804,7 +804,7 @@ __device__ __forceinline__ int wg_scan_excl(int v, int* sh, int tid, int& total)
     return off + incl - v;
 }
 
-__global__ __launch_bounds__(256) void k_scan_partial(int nblk, const int* __restrict__ cnt, int2* partial) {
+__global__ __launch_bounds__(256) void k_scan_partial(int nblk, int ITEM_MAX, const int* __restrict__ cnt, int2* partial) {
     __shared__ int sh[4];
     const int tid = threadIdx.x;
     const int b0 = blockIdx.x * 1024 + tid * 4;
@@ -820,7 +820,7 @@ __global__ __launch_bounds__(256) void k_scan_partial(int nblk, const int* __res
     if (tid == 0) partial[blockIdx.x] = make_int2(tp, ti);
 }
 
-__global__ __launch_bounds__(256) void k_scan_final(int nblk, int* cnt, const int2* __restrict__ partial, int* start, int4* items, int* meta) {
+__global__ __launch_bounds__(256) void k_scan_final(int nblk, int ITEM_MAX, int* cnt, const int2* __restrict__ partial, int* start, int4* items, int* meta) {
     __shared__ int sh[4];
     const int tid = threadIdx.x;
     int pp = 0, pi = 0;                                       // sums of the partials before this workgroup
@@ -1078,6 +1078,7 @@ struct FeEngine {
     std::vector<Table> tables;
     std::vector<int> tbl_of_frame;                          // [L+1]
     int gtbl[2] = {-1, -1};                                 // order of each adjoint ring slot; -1 = all zero
+    int item_max = 256;                                     // particles per work item (<= ITEM_MAX_CAP)
     int sort_interval = 10;                                 // K: re-sort every K substeps (0 = never: global path only)
     size_t items_cap = 0;
     int *sort_key = nullptr, *sort_rank = nullptr, *sort_cnt = nullptr, *sort_start = nullptr, *sort_src = nullptr, *sort_pid = nullptr;
@@ -1242,8 +1243,8 @@ int sort_frame(FeEngine* h, int f) {
     prof_begin(h, KID_SORT);
     hipLaunchKernelGGL(k_sort_count, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->sort_key, h->sort_rank, h->sort_cnt);
     const int scan_wgs = (nblk + 1 + 1023) / 1024;
-    hipLaunchKernelGGL(k_scan_partial, dim3(scan_wgs), dim3(256), 0, h->stream, nblk, h->sort_cnt, h->sort_partial);
-    hipLaunchKernelGGL(k_scan_final, dim3(scan_wgs), dim3(256), 0, h->stream, nblk, h->sort_cnt, h->sort_partial, h->sort_start, tn.items, tn.meta);
+    hipLaunchKernelGGL(k_scan_partial, dim3(scan_wgs), dim3(256), 0, h->stream, nblk, h->item_max, h->sort_cnt, h->sort_partial);
+    hipLaunchKernelGGL(k_scan_final, dim3(scan_wgs), dim3(256), 0, h->stream, nblk, h->item_max, h->sort_cnt, h->sort_partial, h->sort_start, tn.items, tn.meta);
     hipLaunchKernelGGL(k_sort_perm, pgrid(h), dim3(256), 0, h->stream, h->N, h->sort_key, h->sort_rank, h->sort_start,
                        h->tables[id_old].pid, h->sort_src, h->sort_pid);
     HIPCK(h, hipMemcpyAsync(tn.pid, h->sort_pid, sizeof(int) * h->Np, hipMemcpyDeviceToDevice, h->stream));
@@ -1408,7 +1409,7 @@ FeEngine* fe_create(const FeConfig* cfg) {
     h->tbl_of_frame.assign(h->L + 1, 0);
     {
         const size_t nblk = (size_t)h->nb * h->nb * h->nb;
-        h->items_cap = (nblk < (size_t)h->Np ? nblk : (size_t)h->Np) + (size_t)h->Np / ITEM_MAX + 2;
+        h->items_cap = (nblk < (size_t)h->Np ? nblk : (size_t)h->Np) + (size_t)h->Np / 64 + 2;      // item_max >= 64
         if (dev_alloc(h, &h->sort_key, h->Np) || dev_alloc(h, &h->sort_rank, h->Np) || dev_alloc(h, &h->sort_cnt, nblk + 1) ||
             dev_alloc(h, &h->sort_start, nblk + 1) || dev_alloc(h, &h->sort_src, h->Np) || dev_alloc(h, &h->sort_pid, h->Np) ||
             dev_alloc(h, &h->slow_dev, 1) || dev_alloc(h, &h->sort_partial, (nblk + 1 + 1023) / 1024 + 1)) return fail("");
@@ -1462,6 +1463,11 @@ int fe_set_option(FeEngine* h, const char* name, double value) {
     if (!std::strcmp(name, "sort_interval")) {
         if (value < 0) FAIL(h, "sort_interval must be >= 0");
         h->sort_interval = (int)value;
+        return 0;
+    }
+    if (!std::strcmp(name, "item_max")) {
+        if (value < 64 || value > ITEM_MAX_CAP) FAIL(h, "item_max must be in [64, 512]");
+        h->item_max = (int)value;
         return 0;
     }
     if (!std::strcmp(name, "threads")) return 0;             // oracle-only tunable

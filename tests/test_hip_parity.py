@@ -92,8 +92,9 @@ def test_fast_particles_leave_their_tiles(hiplib, oracle64):
     """Particles that outrun the 1-node drift margin of their LDS tile between two sorts must fall
     back to the global path and still match the oracle."""
     sc = S.water_block(n_grid=32, n_particles=4000, lo=0.3, hi=0.5, gravity=(0.0, 0.0, 0.0))
-    rng = np.random.RandomState(3)
-    sc['v'] = S.f32(rng.normal(0, 6.0, (4000, 3)))            # 6 m/s * 20 substeps * 2e-4 = 0.8 cells at n=32
+    # a coherent 12 m/s drift: 12 * 20 substeps * 2e-4 * 32 = 1.5 cells between the two sorts
+    # (random per-particle velocities would be averaged away by the first P2G/G2P)
+    sc['v'] = S.f32(np.tile([12.0, -9.0, 4.0], (4000, 1)))
     g = S.make_engine(hiplib, sc, options={'sort_interval': 20})
     o = S.make_engine(oracle64, sc)
     cot = S.random_cotangent(sc['N'])
