@@ -59,7 +59,7 @@ ABI_SYMBOLS = [
     'fe_add_effector', 'fe_eff_set_act_range', 'fe_eff_get_state', 'fe_eff_set_state',
     'fe_eff_get_vw', 'fe_eff_set_vw', 'fe_eff_set_action', 'fe_eff_set_action_grad',
     'fe_eff_apply_action_p', 'fe_eff_apply_action_p_grad', 'fe_eff_get_action_grad',
-    'fe_agent_copy_frame', 'fe_agent_copy_grad', 'fe_loss_alloc', 'fe_loss_set_target',
+    'fe_agent_copy_frame', 'fe_agent_copy_grad', 'fe_agent_reset_grad_till_frame', 'fe_loss_alloc', 'fe_loss_set_target',
     'fe_loss_clear', 'fe_loss_step', 'fe_loss_step_grad', 'fe_loss_get', 'fe_get_stats',
     'fe_timer_start', 'fe_timer_stop_ms', 'fe_profile_enable', 'fe_profile_read',
 ]
@@ -351,6 +351,9 @@ class Engine:
 
     def agent_copy_grad(self, src, dst):
         self._ck(self.lib.fe_agent_copy_grad(self.h, int(src), int(dst)))
+
+    def agent_reset_grad_till_frame(self, f):
+        self._ck(self.lib.fe_agent_reset_grad_till_frame(self.h, int(f)))
 
     # ---- loss
     def loss_alloc(self, max_loss_steps):

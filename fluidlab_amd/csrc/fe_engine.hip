@@ -1566,6 +1566,10 @@ int fe_reset_grad(FeEngine* h) {
 int fe_reset_grad_till_frame(FeEngine* h, int f) {
     CHECK_FRAME(h, f);
     // particle adjoints: every substep_grad overwrites its ring slot, nothing to clear.
+    return 0;
+}
+int fe_agent_reset_grad_till_frame(FeEngine* h, int f) {
+    CHECK_FRAME(h, f);
     for (auto& E : h->effs) {
         if (f == 0) break;
         HIPCK(h, hipMemsetAsync(E.p.gpos, 0, sizeof(float) * 3 * f, h->stream));

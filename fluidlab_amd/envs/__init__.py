@@ -1,0 +1,12 @@
+"""Environment registry (fluidlab/envs/__init__.py registers with gym; gym is absent here, so `make` is local)."""
+from .fluid_env import FluidEnv
+from .latteart_env import LatteArtEnv
+from .waterblock_env import WaterBlockEnv
+
+REGISTRY = {'LatteArt-v0': LatteArtEnv, 'WaterBlock-v0': WaterBlockEnv}
+
+
+def make(env_name, **kwargs):
+    if env_name not in REGISTRY:
+        raise KeyError(f'{env_name} is not built here; available: {sorted(REGISTRY)}')
+    return REGISTRY[env_name](version=int(env_name.split('-v')[-1]), **kwargs)

@@ -1,0 +1,92 @@
+"""Agent -- a set of effectors sharing one action vector (fluidlab/fluidengine/agents/agent.py)."""
+import numpy as np
+
+from fluidlab_amd.fluidengine import effectors as _effectors
+
+
+class Agent:
+    def __init__(self, max_substeps_local, max_substeps_global, max_action_steps_global, ckpt_dest, collide_type='particle'):
+        self.max_substeps_local = max_substeps_local
+        self.max_substeps_global = max_substeps_global
+        self.max_action_steps_global = max_action_steps_global
+        self.ckpt_dest = ckpt_dest
+        self.collide_type = collide_type
+        assert self.collide_type in ['particle', 'grid', 'both']
+        self.effectors = []
+        self.action_dims = [0]
+
+    def add_effector(self, type, params, mesh_cfg, boundary_cfg):
+        cls = getattr(_effectors, type)                    # the reference eval()s the class name (agent.py:32)
+        effector = cls(max_substeps_local=self.max_substeps_local, max_substeps_global=self.max_substeps_global,
+                       max_action_steps_global=self.max_action_steps_global, ckpt_dest=self.ckpt_dest, **params)
+        if mesh_cfg is not None:
+            effector.setup_mesh(**mesh_cfg)
+        effector.setup_boundary(**boundary_cfg)
+        self.effectors.append(effector)
+        self.action_dims.append(self.action_dims[-1] + effector.action_dim)
+
+    def build(self, sim):
+        self.n_effectors = len(self.effectors)
+        self.sim = sim
+        for effector in self.effectors:
+            effector.build(sim.engine)
+
+    def reset_grad(self):
+        pass            # effector adjoints are zeroed by the engine's reset_grad (effector.py:76-82)
+
+    @property
+    def action_dim(self):
+        return self.action_dims[-1]
+
+    @property
+    def state_dim(self):
+        return sum(e.state_dim for e in self.effectors)
+
+    def _slices(self, vec):
+        vec = np.asarray(vec).reshape(-1)
+        assert len(vec) == self.action_dims[-1], 'Action length does not match agent specifications.'
+        return [vec[self.action_dims[i]:self.action_dims[i + 1]] for i in range(self.n_effectors)]
+
+    def set_action(self, s, s_global, n_substeps, action):
+        for e, a in zip(self.effectors, self._slices(action)):
+            e.set_action(s, s_global, n_substeps, a)
+
+    def set_action_grad(self, s, s_global, n_substeps, action):
+        for e, a in reversed(list(zip(self.effectors, self._slices(action)))):
+            e.set_action_grad(s, s_global, n_substeps, a)
+
+    def apply_action_p(self, action_p):
+        for e, a in zip(self.effectors, self._slices(action_p)):
+            e.apply_action_p(a)
+
+    def apply_action_p_grad(self, action_p):
+        for e, a in reversed(list(zip(self.effectors, self._slices(action_p)))):
+            e.apply_action_p_grad(a)
+
+    def get_grad(self, n):
+        grads = [g for g in (e.get_action_grad(0, n) for e in self.effectors) if g is not None]
+        return np.concatenate(grads, axis=1)
+
+    def get_state(self, f):
+        return [e.get_state(f) for e in self.effectors]
+
+    def set_state(self, f, state):
+        for e, st in zip(self.effectors, state):
+            e.set_state(f, st)
+
+    # frame bookkeeping for the chunked checkpoint protocol (agent.py:117-151)
+    def copy_frame(self, source, target):
+        self.sim.engine.agent_copy_frame(source, target)
+
+    def copy_grad(self, source, target):
+        self.sim.engine.agent_copy_grad(source, target)
+
+    def reset_grad_till_frame(self, f):
+        self.sim.engine.agent_reset_grad_till_frame(f)
+
+    def get_ckpt(self, ckpt_name=None):
+        return [e.get_ckpt() for e in self.effectors]
+
+    def set_ckpt(self, ckpt=None, ckpt_name=None):
+        for e, c in zip(self.effectors, ckpt):
+            e.set_ckpt(c)

@@ -1,0 +1,3 @@
+from .loss import Loss
+from .shapematching_loss import ShapeMatchingLoss
+from .latteart_loss import LatteArtLoss

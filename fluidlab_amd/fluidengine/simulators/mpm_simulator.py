@@ -1,0 +1,357 @@
+"""MPMSimulator -- the host-side surface of fluidlab/fluidengine/simulators/mpm_simulator.py (`mpm:NNN`)
+over the MI355X engine.
+
+What was 29 @ti.kernel's and the Taichi runtime in the reference is one C-ABI library here
+(fluidlab_amd/csrc, include/fluidengine.h) driven through ctypes.  The time indexing, action buffering,
+chunked checkpoint/recompute protocol and state I/O keep the reference's semantics so TaichiEnv, Agent,
+Loss, Solver and Recorder work against it unchanged.
+
+MI355X-first differences:
+  * `max_substeps_local=None` keeps the whole trajectory's particle frames resident in HBM (288 GB), so the
+    backward pass needs no checkpoint reload and no second forward (mpm:856-912 is then never triggered);
+  * the grid is not stored per frame: the backward pass recomputes P2G + grid_op of frame f;
+  * particle adjoints are a ring of two frames inside the engine."""
+import os
+import pickle as pkl
+import uuid
+
+import numpy as np
+
+from fluidlab_amd import _capi
+from fluidlab_amd.configs.macros import DTYPE_NP, LAMDA, MAT_CLASS, MU
+from fluidlab_amd.fluidengine.boundaries import create_boundary
+
+
+class _Field:
+    """Tiny stand-in for the Taichi fields other components peek into (`.to_numpy()`)."""
+
+    def __init__(self, getter):
+        self._getter = getter
+
+    def to_numpy(self):
+        return self._getter()
+
+
+class _Namespace:
+    pass
+
+
+class MPMSimulator:
+    def __init__(self, dim, quality, gravity, horizon, max_substeps_local, max_substeps_global, ckpt_dest,
+                 engine_lib=None, device=0):
+        assert dim == 3, 'the MI355X engine is 3-D'
+        self.dim = dim
+        self.ckpt_dest = ckpt_dest
+        self.sim_id = str(uuid.uuid4())
+        self.gravity = tuple(float(g) for g in gravity)
+
+        self.n_grid = int(64 * quality)                     # mpm:21
+        self.dx = 1 / self.n_grid
+        self.inv_dx = float(self.n_grid)
+        self.dt = 2e-4                                      # mpm:24
+        self.p_vol = (self.dx * 0.5) ** 2                   # mpm:25 (sic: squared in 3-D)
+        self.res = (self.n_grid,) * self.dim
+        self.max_substeps_global = max_substeps_global
+        self.horizon = horizon
+        self.n_substeps = int(2e-3 / self.dt)               # mpm:30
+        if max_substeps_local is None:                      # whole trajectory resident in HBM
+            max_substeps_local = self.n_substeps * (horizon + 1)
+        self.max_substeps_local = max_substeps_local
+        self.max_steps_local = int(self.max_substeps_local / self.n_substeps)
+
+        assert self.n_substeps * self.horizon < self.max_substeps_global      # mpm:33
+        assert self.max_substeps_local % self.n_substeps == 0                 # mpm:34
+
+        self.boundary = None
+        self.has_particles = False
+        self.engine = None
+        self._elib = engine_lib          # None -> the HIP library (raises when it is not built: no fallback)
+        self._device = device
+
+    def setup_boundary(self, **kwargs):
+        self.boundary = create_boundary(**kwargs)
+
+    # ------------------------------------------------------------------ build
+    def build(self, agent, smoke_field, statics, particles):
+        if self.boundary is None:
+            self.boundary = create_boundary()                # mpm:44-45
+        self.n_statics = len(statics) if statics is not None else 0
+        self.statics = statics
+        if smoke_field is not None:
+            raise NotImplementedError('SmokeField is outside this build (SURVEY 8f-3)')
+
+        if self._elib is None:
+            self._elib = _capi.load_hip()
+        elib = self._elib
+        self.dtype = elib.dtype
+
+        if particles is not None:
+            self.has_particles = True
+            self.n_particles = len(particles['x'])
+        else:
+            self.has_particles = False
+            self.n_particles = 0
+
+        self.engine = _capi.Engine(
+            elib, n_grid=self.n_grid, n_particles=self.n_particles, max_substeps_local=self.max_substeps_local,
+            n_substeps=self.n_substeps, max_action_steps=self.horizon, dt=self.dt, p_vol=self.p_vol,
+            gravity=self.gravity, boundary=self.boundary.to_abi(elib), device=self._device)
+
+        if self.has_particles:
+            self.setup_ckpt_vars()
+            self.init_particles_and_bodies(particles)
+            # shims for the attribute peeks of Agent / Loss / Recorder (agent_injector.py:21, recorder.py:59)
+            self.particles = _Namespace()
+            self.particles_i = _Namespace()
+            self.particles_i.mat = _Field(lambda: self.engine.get_mat())
+            self.particles_ng = _Namespace()
+            self.particles_ng.used = _Field(lambda: self.get_used(0)[None, :])
+        else:
+            self.particles = None
+
+        self.agent = agent
+        self.smoke_field = smoke_field
+        self.cur_substep_global = 0
+        self.disable_grad()                                  # mpm:71
+
+    def setup_ckpt_vars(self):
+        """mpm:119-134"""
+        if self.ckpt_dest == 'disk':
+            N = self.n_particles
+            self.x_np = np.zeros((N, 3), self.dtype); self.v_np = np.zeros((N, 3), self.dtype)
+            self.C_np = np.zeros((N, 3, 3), self.dtype); self.F_np = np.zeros((N, 3, 3), self.dtype)
+            self.used_np = np.zeros((N,), np.int32)
+        else:
+            self.ckpt_ram = dict()
+        self.actions_buffer = []
+        self.ckpt_dir = os.path.join('/tmp', 'fluidlab', self.sim_id)
+        os.makedirs(self.ckpt_dir, exist_ok=True)
+
+    def init_particles_and_bodies(self, particles):
+        """mpm:136-148, 177-201"""
+        mat = particles['mat'].astype(np.int32)
+        body_id = particles['body_id'].astype(np.int32)
+        self.n_bodies = particles['bodies']['n']
+        assert self.n_bodies == np.max(body_id) + 1
+        self.engine.init_particles(
+            particles['x'].astype(DTYPE_NP), particles['used'].astype(np.int32), mat,
+            np.array([MAT_CLASS[m] for m in mat], np.int32), np.array([MU[m] for m in mat]),
+            np.array([LAMDA[m] for m in mat]), particles['rho'], body_id)
+
+    # ------------------------------------------------------------------ grads
+    def reset_grad(self):
+        self.engine.reset_grad()                             # mpm:203-205 (+ effectors, done engine-side)
+
+    def enable_grad(self):
+        self.grad_enabled = True
+        self.cur_substep_global = 0
+
+    def disable_grad(self):
+        self.grad_enabled = False
+        self.cur_substep_global = 0
+
+    # ------------------------------------------------------------------ time indexing, mpm:225-252
+    def f_global_to_f_local(self, f_global):
+        return f_global % self.max_substeps_local
+
+    def f_local_to_s_local(self, f_local):
+        return f_local // self.n_substeps
+
+    def f_global_to_s_local(self, f_global):
+        return self.f_local_to_s_local(self.f_global_to_f_local(f_global))
+
+    def f_global_to_s_global(self, f_global):
+        return f_global // self.n_substeps
+
+    @property
+    def cur_substep_local(self):
+        return self.f_global_to_f_local(self.cur_substep_global)
+
+    @property
+    def cur_step_local(self):
+        return self.f_global_to_s_local(self.cur_substep_global)
+
+    @property
+    def cur_step_global(self):
+        return self.f_global_to_s_global(self.cur_substep_global)
+
+    # ------------------------------------------------------------------ the hot path
+    def substep(self, f, is_none_action):
+        self.engine.substep(f, self.cur_substep_global, not is_none_action)        # mpm:515-533
+
+    def substep_grad(self, f, is_none_action):
+        self.engine.substep_grad(f, self.cur_substep_global, not is_none_action)   # mpm:535-552
+
+    def step(self, action=None):
+        """mpm:721-732"""
+        if self.grad_enabled and self.cur_substep_local == 0:
+            self.actions_buffer = []
+        self.step_(action)
+        if self.grad_enabled:
+            self.actions_buffer.append(action)
+        if self.cur_substep_local == 0:
+            self.memory_to_cache()
+
+    def step_(self, action=None):
+        """mpm:735-753: one ABI crossing for the n_substeps loop."""
+        is_none_action = action is None
+        if not is_none_action:
+            self.agent.set_action(s=self.cur_step_local, s_global=self.cur_step_global, n_substeps=self.n_substeps, action=action)
+        self.engine.step(self.cur_substep_local, self.cur_substep_global, self.n_substeps, not is_none_action)
+        self.cur_substep_global += self.n_substeps
+        assert self.cur_substep_global <= self.max_substeps_global
+
+    def step_grad(self, action=None):
+        """mpm:755-775"""
+        if self.cur_substep_local == 0:
+            self.memory_from_cache()
+        is_none_action = action is None
+        self.cur_substep_global -= self.n_substeps
+        self.engine.step_grad(self.cur_substep_local, self.cur_substep_global, self.n_substeps, not is_none_action)
+        if not is_none_action:
+            self.agent.set_action_grad(s=self.cur_substep_local // self.n_substeps, s_global=self.cur_substep_global // self.n_substeps,
+                                       n_substeps=self.n_substeps, action=action)
+
+    # ------------------------------------------------------------------ chunked checkpointing, mpm:777-912
+    def memory_to_cache(self):
+        if self.grad_enabled:
+            ckpt_start_step = self.cur_substep_global - self.max_substeps_local
+            ckpt_name = f'{ckpt_start_step:06d}'
+            ckpt = {}
+            if self.has_particles:
+                if self.ckpt_dest == 'disk':
+                    self.readframe(0, self.x_np, self.v_np, self.C_np, self.F_np, self.used_np)
+                    ckpt.update(x=self.x_np, v=self.v_np, C=self.C_np, F=self.F_np, used=self.used_np)
+                else:
+                    st = self._frame_arrays()
+                    self.readframe(0, st['x'], st['v'], st['C'], st['F'], st['used'])
+                    ckpt.update(st)
+                ckpt['actions'] = list(self.actions_buffer)
+            if self.agent is not None:
+                ckpt['agent'] = self.agent.get_ckpt()
+            if self.ckpt_dest == 'disk':
+                ckpt_file = os.path.join(self.ckpt_dir, f'{ckpt_name}.pkl')
+                if os.path.exists(ckpt_file):
+                    os.remove(ckpt_file)
+                with open(ckpt_file, 'wb') as fh:
+                    pkl.dump(ckpt, fh)
+            elif self.ckpt_dest in ['cpu', 'gpu']:
+                self.ckpt_ram[ckpt_name] = ckpt
+            else:
+                assert False
+        # restart from frame 0 in memory (mpm:844-852)
+        if self.has_particles:
+            self.copy_frame(self.max_substeps_local, 0)
+        if self.agent is not None:
+            self.agent.copy_frame(self.max_substeps_local, 0)
+
+    def memory_from_cache(self):
+        assert self.grad_enabled
+        L = self.max_substeps_local
+        if self.has_particles:
+            self.copy_frame(0, L)
+            self.copy_grad(0, L)
+            self.reset_grad_till_frame(L)
+        if self.agent is not None:
+            self.agent.copy_frame(0, L)
+            self.agent.copy_grad(0, L)
+            self.agent.reset_grad_till_frame(L)
+
+        ckpt_start_step = self.cur_substep_global - L
+        ckpt_name = f'{ckpt_start_step:06d}'
+        if self.ckpt_dest == 'disk':
+            ckpt_file = os.path.join(self.ckpt_dir, f'{ckpt_name}.pkl')
+            assert os.path.exists(ckpt_file)
+            with open(ckpt_file, 'rb') as fh:
+                ckpt = pkl.load(fh)
+        elif self.ckpt_dest in ['cpu', 'gpu']:
+            ckpt = self.ckpt_ram[ckpt_name]
+        else:
+            assert False
+        if self.has_particles:
+            self.setframe(0, ckpt['x'], ckpt['v'], ckpt['C'], ckpt['F'], ckpt['used'])
+        if self.agent is not None:
+            self.agent.set_ckpt(ckpt['agent'])
+        # forward pass over the chunk to refill frames 1..L (mpm:906-909)
+        self.cur_substep_global = ckpt_start_step
+        for action in ckpt['actions']:
+            self.step_(action)
+
+    # ------------------------------------------------------------------ io, mpm:555-719
+    def _frame_arrays(self):
+        N = self.n_particles
+        return dict(x=np.zeros((N, 3), self.dtype), v=np.zeros((N, 3), self.dtype), C=np.zeros((N, 3, 3), self.dtype),
+                    F=np.zeros((N, 3, 3), self.dtype), used=np.zeros((N,), np.int32))
+
+    def readframe(self, f, x, v, C, F, used):
+        self.engine.get_frame(f, x, v, C, F, used)
+
+    def setframe(self, f, x, v, C, F, used):
+        self.engine.set_frame(f, x, v, C, F, used)
+
+    def set_x(self, f, x):
+        self.engine.set_frame(f, x=x)
+
+    def set_used(self, f, used):
+        self.engine.set_frame(f, used=used)
+
+    def copy_frame(self, source, target):
+        self.engine.copy_frame(source, target)
+
+    def copy_grad(self, source, target):
+        self.engine.copy_grad(source, target)
+
+    def reset_grad_till_frame(self, f):
+        self.engine.reset_grad_till_frame(f)
+
+    def get_state(self):
+        f = self.cur_substep_local
+        state = {}
+        if self.has_particles:
+            state.update(self._frame_arrays())
+            self.readframe(f, state['x'], state['v'], state['C'], state['F'], state['used'])
+        if self.agent is not None:
+            state['agent'] = self.agent.get_state(f)
+        return state
+
+    def set_state(self, f_global, state):
+        f = self.f_global_to_f_local(f_global)
+        if self.has_particles:
+            self.setframe(f, state['x'], state['v'], state['C'], state['F'], state['used'])
+        if self.agent is not None:
+            self.agent.set_state(f, state['agent'])
+
+    def get_x(self, f=None):
+        f = self.cur_substep_local if f is None else f
+        x = np.zeros((self.n_particles, self.dim), dtype=self.dtype)
+        if self.has_particles:
+            self.engine.get_frame(f, x=x)
+        return x
+
+    def get_used(self, f=None):
+        f = self.cur_substep_local if f is None else f
+        used = np.zeros((self.n_particles,), dtype=np.int32)
+        if self.has_particles:
+            self.engine.get_frame(f, used=used)
+        return used
+
+    def get_v(self, f):
+        v = np.zeros((self.n_particles, self.dim), dtype=self.dtype)
+        if self.has_particles:
+            self.engine.get_frame(f, v=v)
+        return v
+
+    def get_state_RL(self):
+        f = self.cur_substep_local
+        state = {}
+        if self.has_particles:
+            state['x'] = np.zeros((self.n_particles, 3), self.dtype)
+            state['v'] = np.zeros((self.n_particles, 3), self.dtype)
+            state['used'] = np.zeros((self.n_particles,), np.int32)
+            self.engine.get_frame(f, x=state['x'], v=state['v'], used=state['used'])
+        if self.agent is not None:
+            state['agent'] = self.agent.get_state(f)
+        return state
+
+    def get_state_render(self, f):
+        return dict(x=self.get_x(f).astype(np.float32), used=self.get_used(f))

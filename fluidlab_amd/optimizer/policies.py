@@ -1,0 +1,82 @@
+"""Open-loop action policies (fluidlab/optimizer/policies.py): replayed action lists and the trainable
+action sequence optimised by Solver.  Interactive keyboard/mouse policies need a display and are omitted."""
+import numpy as np
+
+from .optim import OPTIMIZERS
+
+
+class ActionsPolicy:
+    """comp_actions = [actions_v (horizon x dim) ; actions_p (1 x dim)]  (policies.py:10-19)"""
+
+    def __init__(self, comp_actions):
+        self.actions_v = comp_actions[:-1]
+        self.actions_p = comp_actions[-1]
+
+    def get_actions_p(self):
+        return self.actions_p
+
+    def get_action_v(self, i, **kwargs):
+        return self.actions_v[i]
+
+
+class TrainablePolicy:
+    """policies.py:131-164"""
+
+    def __init__(self, optim_cfg, init_range, action_dim, horizon, action_range, fix_dim=None):
+        self.horizon = horizon
+        self.action_dim = action_dim
+        self.actions_v = np.random.uniform(init_range.v[0], init_range.v[1], size=(horizon, action_dim))
+        self.actions_p = np.random.uniform(init_range.p[0], init_range.p[1], size=(action_dim))
+        self.action_range = action_range
+        self.comp_actions_shape = (horizon + 1, action_dim)
+        self.trainable = np.full(self.comp_actions_shape[0], True)
+        self.fix_dim = fix_dim
+        self.freeze_till = 0
+        self.optim = OPTIMIZERS[optim_cfg.type](self.comp_actions_shape, optim_cfg)
+
+    @property
+    def comp_actions(self):
+        return np.vstack([self.actions_v, self.actions_p[None, :]])
+
+    def get_actions_p(self):
+        return self.actions_p
+
+    def get_action_v(self, i, **kwargs):
+        return self.actions_v[i]
+
+    def optimize(self, grads, loss_info):
+        assert grads.shape == self.comp_actions_shape
+        grads = np.array(grads, dtype=np.float64)
+        grads[np.logical_not(self.trainable)] = 0
+        if self.fix_dim is not None:
+            grads[:, self.fix_dim] = 0
+        new_comp_actions = self.optim.step(self.comp_actions, grads)
+        self.actions_p = new_comp_actions[-1]
+        self.actions_v = new_comp_actions[:-1].clip(*self.action_range)
+
+
+class LatteArtPolicy(TrainablePolicy):
+    pass
+
+
+class IceCreamDynamicPolicy(TrainablePolicy):
+    """policies.py:196-201"""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.trainable = np.full(self.comp_actions_shape[0], False)
+        self.trainable[169:-1] = True
+
+
+class IceCreamStaticPolicy(TrainablePolicy):
+    """policies.py:204-216"""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.trainable = np.full(self.comp_actions_shape[0], False)
+        self.trainable[:-1] = True
+
+    def optimize(self, grads, loss_info):
+        super().optimize(np.clip(grads, -1e5, 1e5), loss_info)
+        if loss_info['temporal_range'] > 450:
+            self.optim.lr = self.optim.init_lr * 0.1

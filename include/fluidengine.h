@@ -126,7 +126,7 @@ int fe_set_frame(FeEngine* h, int f, const fe_real* x, const fe_real* v, const f
 int fe_copy_frame(FeEngine* h, int src, int dst);           /* mpm:588-595 */
 int fe_copy_grad(FeEngine* h, int src, int dst);            /* mpm:597-604 */
 int fe_reset_grad(FeEngine* h);                             /* mpm:203-205 (+ effectors, effector.py:76-82) */
-int fe_reset_grad_till_frame(FeEngine* h, int f);           /* mpm:606-609 (+ effector.py:178-183) */
+int fe_reset_grad_till_frame(FeEngine* h, int f);           /* mpm:606-609 */
 /* adjoint access used by losses and tests: particles.grad[f].{x,v,C,F} */
 int fe_get_grad(FeEngine* h, int f, fe_real* gx, fe_real* gv, fe_real* gC, fe_real* gF);
 int fe_add_grad(FeEngine* h, int f, const fe_real* gx, const fe_real* gv, const fe_real* gC,
@@ -154,6 +154,7 @@ int fe_eff_apply_action_p_grad(FeEngine* h, int e);                             
 int fe_eff_get_action_grad(FeEngine* h, int e, int s, int n, fe_real* grad);      /* effector.py:276-283 */
 int fe_agent_copy_frame(FeEngine* h, int src, int dst);                           /* agent.py:117-120 */
 int fe_agent_copy_grad(FeEngine* h, int src, int dst);                            /* agent.py:122-125 */
+int fe_agent_reset_grad_till_frame(FeEngine* h, int f);                            /* agent.py:127-130, effector.py:178-183 */
 
 /* ---- loss: shapematching_loss.py:64-93 -------------------------------- */
 int fe_loss_alloc(FeEngine* h, int max_loss_steps);

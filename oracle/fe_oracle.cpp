@@ -868,6 +868,10 @@ int fe_reset_grad_till_frame(FeEngine* h, int f) {
     size_t N = h->N;
     std::fill(h->gx.begin(), h->gx.begin() + (size_t)f * N * 3, (R)0); std::fill(h->gv.begin(), h->gv.begin() + (size_t)f * N * 3, (R)0);
     std::fill(h->gC.begin(), h->gC.begin() + (size_t)f * N * 9, (R)0); std::fill(h->gF.begin(), h->gF.begin() + (size_t)f * N * 9, (R)0);
+    return 0;
+}
+int fe_agent_reset_grad_till_frame(FeEngine* h, int f) {
+    CHECK_FRAME(h, f);
     for (auto& e : h->effs) {
         std::fill(e.gpos.begin(), e.gpos.begin() + f * 3, (R)0); std::fill(e.gquat.begin(), e.gquat.begin() + f * 4, (R)0);
         std::fill(e.gv.begin(), e.gv.begin() + f * 3, (R)0); std::fill(e.gw.begin(), e.gw.begin() + f * 3, (R)0);

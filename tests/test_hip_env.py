@@ -1,0 +1,60 @@
+"""GPU: the full Python stack (envs -> TaichiEnv -> MPMSimulator -> C ABI -> HIP kernels) against the same stack
+on the fp64 oracle library, including the chunked checkpoint/recompute protocol on sorted particle orders."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(__file__))
+import scenarios as S  # noqa: E402
+
+from fluidlab_amd.envs import make
+from fluidlab_amd.optimizer.recorder import Recorder
+from fluidlab_amd.optimizer.solver import Solver
+from fluidlab_amd.utils.config import load_config
+
+pytestmark = pytest.mark.gpu
+MINI = dict(quality=0.5, particle_density=4e4, n_pool=300, horizon=12, horizon_action=8)
+
+
+def _solver_cfg():
+    cfg = load_config('configs/exp_latteart.yaml').SOLVER
+    cfg.n_iters = 2
+    return cfg
+
+
+def _fwd_bwd(lib, target, seed_actions=4, **kw):
+    env = make('LatteArt-v0', seed=0, loss=True, target=target, engine_lib=lib, **MINI, **kw)
+    cfg = _solver_cfg()
+    policy = env.trainable_policy(cfg.optim, cfg.init_range)
+    policy.actions_v[:] = np.random.RandomState(seed_actions).uniform(-0.004, 0.004, policy.actions_v.shape)
+    info, g = Solver(env, None, cfg).forward_backward(env.taichi_env.get_state()['state'], policy, env.horizon, env.horizon_action)
+    return info['loss'], g, env
+
+
+def test_latteart_env_on_hip_matches_oracle(hiplib, oracle64, monkeypatch):
+    from fluidlab_amd.fluidengine.effectors import Injector
+    base = np.random.RandomState(7).uniform(size=(20, 2, 3)).astype(np.float32)
+    monkeypatch.setattr(Injector, 'random_vector_factory', staticmethod(lambda n, flux, dim: np.tile(base, (n // 20 + 1, 1, 1))[:n]))
+    tgt = Recorder(make('LatteArt-v0', seed=0, loss=False, engine_lib=oracle64, **MINI)).record(write=False)
+    tgt_gpu = Recorder(make('LatteArt-v0', seed=0, loss=False, engine_lib=None, **MINI)).record(write=False)   # None = HIP library
+    assert (tgt_gpu['used'][-1] == tgt['used'][-1]).all()
+    assert S.rel_l2(tgt_gpu['x'][-1][tgt['used'][-1] == 1], tgt['x'][-1][tgt['used'][-1] == 1]) <= 1e-5
+    tgt32 = dict(tgt, x=[np.asarray(t, np.float32) for t in tgt['x']])
+    loss_o, g_o, _ = _fwd_bwd(oracle64, tgt)
+    for kw in (dict(max_substeps_local=None), dict(max_substeps_local=20, ckpt_dest='cpu'), dict(max_substeps_local=40, ckpt_dest='disk')):
+        loss_g, g_g, env = _fwd_bwd(hiplib, tgt32, **kw)
+        assert env.taichi_env.simulator.engine.elib.backend == 'hip-gfx950'
+        assert abs(loss_g - loss_o) <= 1e-4 * abs(loss_o), kw
+        assert S.cosine(g_g, g_o) >= 0.999 and S.rel_l2(g_g, g_o) <= 1e-2, (kw, S.rel_l2(g_g, g_o))
+
+
+def test_solver_reduces_loss_on_hip(hiplib):
+    tgt = Recorder(make('LatteArt-v0', seed=0, loss=False, **MINI)).record(write=False)
+    env = make('LatteArt-v0', seed=0, loss=True, target=tgt, **MINI)
+    cfg = _solver_cfg()
+    cfg.n_iters = 3
+    losses = []
+    Solver(env, None, cfg).solve(callback=lambda it, info, pol: losses.append(info['loss']))
+    assert losses[0] > losses[1] > losses[2] > 0

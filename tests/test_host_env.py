@@ -1,0 +1,106 @@
+"""The Python host layer (MPMSimulator / TaichiEnv / Agent / Loss / Solver / envs) on CPU.
+
+The product path loads the HIP library and has no fallback; these tests hand the same host code the oracle
+build of the ABI (`engine_lib=`) so time indexing, action buffering, the chunked checkpoint protocol, the loss
+curriculum and the optimiser loop can be exercised without a GPU."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(__file__))
+
+from fluidlab_amd.envs import make
+from fluidlab_amd.optimizer.recorder import Recorder
+from fluidlab_amd.optimizer.solver import Solver
+from fluidlab_amd.utils.config import load_config
+
+MINI = dict(quality=0.5, particle_density=4e4, n_pool=300, horizon=12, horizon_action=8)
+
+
+def _cfg(n_iters=2):
+    cfg = load_config('configs/exp_latteart.yaml')
+    assert cfg.SOLVER.optim.lr == 1e-3 and cfg.SOLVER.init_range.p[0] == (0.15, 0.65, 0.5)
+    cfg.SOLVER.n_iters = n_iters
+    return cfg.SOLVER
+
+
+@pytest.fixture(scope='module')
+def mini_target(oracle32):
+    env = make('LatteArt-v0', seed=0, loss=False, engine_lib=oracle32, **MINI)
+    return Recorder(env).record(write=False)
+
+
+def test_record_then_optimise(oracle32, mini_target):
+    tgt = mini_target
+    assert len(tgt['x']) == MINI['horizon'] and tgt['x'][0].shape == (2503, 3)
+    # 8 action steps x 10 substeps x flux 2 particles were injected
+    assert int(tgt['used'][-1].sum()) - int((tgt['mat'] == 2).sum()) == 8 * 10 * 2
+    env = make('LatteArt-v0', seed=0, loss=True, target=tgt, engine_lib=oracle32, **MINI)
+    losses = []
+    Solver(env, None, _cfg(3)).solve(callback=lambda it, info, pol: losses.append(info['loss']))
+    assert losses[0] > losses[1] > losses[2] > 0
+
+
+def test_chunked_checkpointing_equals_resident_trajectory(oracle64, mini_target, tmp_path, monkeypatch):
+    """mpm:777-912: backward through 20-substep chunks (checkpoint + re-forward) must give the gradient of the
+    whole-trajectory-resident mode."""
+    from fluidlab_amd.fluidengine.effectors import Injector
+    base = np.random.RandomState(7).uniform(size=(20, 2, 3))
+    # `locally_random` noise is indexed by the local frame: make it 20-periodic so every chunking sees the same noise
+    monkeypatch.setattr(Injector, 'random_vector_factory', staticmethod(lambda n, flux, dim: np.tile(base, (n // 20 + 1, 1, 1))[:n]))
+    grads = {}
+    for mode, kw in [('resident', dict(max_substeps_local=None)), ('cpu', dict(max_substeps_local=20, ckpt_dest='cpu')),
+                     ('disk', dict(max_substeps_local=40, ckpt_dest='disk'))]:
+        env = make('LatteArt-v0', seed=0, loss=True, target=mini_target, engine_lib=oracle64, **MINI, **kw)
+        solver = Solver(env, None, _cfg())
+        policy = env.trainable_policy(_cfg().optim, _cfg().init_range)
+        policy.actions_v[:] = np.random.RandomState(4).uniform(-0.004, 0.004, policy.actions_v.shape)
+        info, g = solver.forward_backward(env.taichi_env.get_state()['state'], policy, env.horizon, env.horizon_action)
+        grads[mode] = (info['loss'], g)
+    for mode in ('cpu', 'disk'):
+        assert abs(grads[mode][0] - grads['resident'][0]) < 1e-9 * abs(grads['resident'][0])
+        assert np.abs(grads[mode][1] - grads['resident'][1]).max() < 1e-9 * np.abs(grads['resident'][1]).max()
+
+
+def test_rl_api_and_state_roundtrip(oracle32, mini_target):
+    env = make('LatteArt-v0', seed=0, loss=True, target=mini_target, engine_lib=oracle32, **MINI)
+    obs0 = env.reset()
+    assert obs0.shape == env.observation_space.shape and env.action_space.shape == (3,)
+    obs, reward, done, _ = env.step(np.array([0.5, 0.0, -0.5]))          # clipped to +-0.05
+    assert np.isfinite(reward) and not done and env.t == 1
+    sim = env.taichi_env.simulator
+    assert sim.cur_substep_global == 10 and sim.cur_step_global == 1 and sim.cur_substep_local == 10
+    st = env.taichi_env.get_state()
+    assert st['state']['agent'][0].shape == (8,) and st['state']['agent'][0][7] == 0 + 20      # act_id = act_range[0] (the first pool id, here 0) + 10 substeps x flux 2
+    obs1 = env.reset()
+    assert np.array_equal(obs0, obs1)
+
+
+def test_time_indexing_asserts():
+    from fluidlab_amd.fluidengine.simulators import MPMSimulator
+    sim = MPMSimulator(dim=3, quality=1, gravity=(0, -10, 0), horizon=330, max_substeps_local=50, max_substeps_global=100000, ckpt_dest='cpu')
+    assert (sim.n_grid, sim.n_substeps, sim.max_steps_local) == (64, 10, 5) and sim.p_vol == (0.5 / 64) ** 2
+    sim.cur_substep_global = 3217
+    assert (sim.cur_substep_local, sim.cur_step_local, sim.cur_step_global) == (17, 1, 321)
+    with pytest.raises(AssertionError):
+        MPMSimulator(dim=3, quality=1, gravity=(0, -10, 0), horizon=10, max_substeps_local=45, max_substeps_global=1000, ckpt_dest='cpu')
+    resident = MPMSimulator(dim=3, quality=2, gravity=(0, -10, 0), horizon=330, max_substeps_local=None, max_substeps_global=100000, ckpt_dest='cpu')
+    assert resident.max_substeps_local == 3310 and resident.n_grid == 128
+
+
+def test_product_path_has_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip('a GPU is visible here')
+    from fluidlab_amd._capi import FeEngineError
+    with pytest.raises(FeEngineError, match='no HIP device|no CPU fallback'):
+        make('WaterBlock-v0', quality=0.5, n_particles=500, horizon=2)
+
+
+def test_waterblock_env_matches_bench_scene(oracle32):
+    import scenarios as S
+    env = make('WaterBlock-v0', quality=0.5, n_particles=4096, horizon=3, engine_lib=oracle32)
+    sc = S.water_block(n_grid=32, n_particles=4096)
+    assert np.array_equal(env.taichi_env.simulator.get_x(0), sc['x'])      # same RNG stream as bench.py / SURVEY 8d C2
