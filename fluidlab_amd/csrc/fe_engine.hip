@@ -73,6 +73,7 @@ __device__ __forceinline__ int cell_addr(int i, int j, int k, int nb) {
 struct SimP {
     int N, Np, n, nb;
     int ncell;                               // nb^3 * 64: plane stride of the SoA accumulator grids
+    int dbg;                                 // timing experiments only (option "dbg"): 1 no LDS atomics, 2 no flush, 4 no stores
     float dx, inv_dx, dt, stress_scale;     // stress_scale = -dt * p_vol * 4 * inv_dx^2 (mpm:343)
     float g[3];
     BoundaryP bnd;
@@ -223,7 +224,7 @@ __device__ __forceinline__ void used_particle_p2g(const SimP& S, const FrameV& c
     PInfo info = load_info(pinfo, pid);
     Constitutive k;
     constitutive_eval_t<GENERAL>(p.C, p.F, S.dt, info.mu, info.lam, info.mass, info.cls, S.stress_scale, k);
-    if (WRITE) { store_F(nxt, s, k.Fnew); nxt.used[s] = 1; }
+    if (WRITE && !(S.dbg & 4)) { store_F(nxt, s, k.Fnew); nxt.used[s] = 1; }
     Stencil st;
     stencil_make(p.x, S.inv_dx, st);
     if (!stencil_inside(st, S.n)) { atomicAdd(G.err, 1); return; }
@@ -236,6 +237,7 @@ __device__ __forceinline__ void used_particle_p2g(const SimP& S, const FrameV& c
     const int lb = use_tile ? tile_base(to, st) : -1;
     if (use_tile && lb < 0) atomicAdd(G.slow, 1);
     if (lb >= 0) {
+        if (S.dbg & 1) return;
 #pragma unroll 1
         for (int ij = 0; ij < 9; ij++) {
             const int i = ij / 3, j = ij - 3 * i;
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(WG) void k_p2g(SimP S, float* fr_cur, float* fr_nex
             for (int i = tid; i < it.z; i += WG) slot_p2g<WRITE, GENERAL>(S, cur, nxt, it.y + i, T, pinfo, pool_idx, true, to, G, agent, inj, f);
             __syncthreads();
             // flush: consecutive lanes -> consecutive nodes of a tile row
-            for (int l = tid; l < TILE_N; l += WG) {
+            for (int l = tid; l < TILE_N && !(S.dbg & 2); l += WG) {
                 const float vx = (float)s_acc[l], vy = (float)s_acc[TILE_N + l], vz = (float)s_acc[2 * TILE_N + l], m = (float)s_acc[3 * TILE_N + l];
                 if (m != 0.f || vx != 0.f || vy != 0.f || vz != 0.f) {
                     int i, j, k;
@@ -1394,6 +1396,7 @@ FeEngine* fe_create(const FeConfig* cfg) {
     if (hipSetDevice(h->device) != hipSuccess) return fail("hipSetDevice failed");
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
     SimP& S = h->S;
+    S.dbg = 0;
     S.N = h->N; S.Np = h->Np; S.n = h->n; S.nb = h->nb; S.ncell = h->nb * h->nb * h->nb * 64;
     S.dx = 1.0f / (float)h->n; S.inv_dx = (float)h->n; S.dt = cfg->dt;
     S.stress_scale = -cfg->dt * cfg->p_vol * 4.f * S.inv_dx * S.inv_dx;
@@ -1470,6 +1473,7 @@ int fe_set_option(FeEngine* h, const char* name, double value) {
         h->item_max = (int)value;
         return 0;
     }
+    if (!std::strcmp(name, "dbg")) { h->S.dbg = (int)value; return 0; }     // timing experiments: results are wrong
     if (!std::strcmp(name, "threads")) return 0;             // oracle-only tunable
     FAIL(h, std::string("unknown option: ") + name);
 }
