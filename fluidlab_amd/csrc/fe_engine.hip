@@ -139,6 +139,45 @@ __shared__ double s_acc[4 * TILE_N];
 __device__ __forceinline__ float sel3(int i, float a, float b, float c) { return i == 0 ? a : (i == 1 ? b : c); }
 #define STW(st, i, d) sel3((i), (st).w[0][d], (st).w[1][d], (st).w[2][d])
 
+// -----------------------------------------------------------------------------------------
+// Wavefront aggregation of scatter contributions.  After the cell-level sort, lanes holding particles of one
+// cell are adjacent and write the same 27 nodes.  A segmented inclusive scan over the 64 lanes (DPP row_shr
+// 1/2/4/8 + row_bcast15/31: pure VALU, no LDS traffic) sums each run of equal keys; only the last lane of a run
+// issues the LDS atomic.  Measured motivation (profiles/r01e): ~30 us of a 44 us P2G launch were ds_add_f64.
+// Correct for ANY lane order: only *adjacent* equal keys are merged.
+// -----------------------------------------------------------------------------------------
+struct SegScan { float f1, f2, f4, f8, f15, f31; bool tail; };
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov(float v) {      // lanes without a source get 0
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+// must be executed by all 64 lanes of the wave
+__device__ __forceinline__ SegScan seg_setup(int key) {
+    const int lane = threadIdx.x & 63;
+    const int prev = __shfl_up(key, 1, 64);
+    const bool is_head = lane == 0 || key != prev;
+    const unsigned long long mask = __ballot(is_head);
+    const unsigned long long lower = mask & ((2ull << lane) - 1ull);       // run heads at or before this lane
+    const int head = 63 - __clzll((long long)lower);
+    const int dist = lane - head, row = lane >> 4;
+    SegScan sc;
+    sc.f1 = dist >= 1 ? 1.f : 0.f; sc.f2 = dist >= 2 ? 1.f : 0.f; sc.f4 = dist >= 4 ? 1.f : 0.f; sc.f8 = dist >= 8 ? 1.f : 0.f;
+    sc.f15 = ((row & 1) && head <= row * 16 - 1) ? 1.f : 0.f;             // run reaches back into the previous row
+    sc.f31 = (row >= 2 && head <= 31) ? 1.f : 0.f;                         // ... into the first half of the wave
+    sc.tail = lane == 63 || ((mask >> (lane + 1)) & 1ull);                 // last lane of its run
+    return sc;
+}
+__device__ __forceinline__ float seg_scan(const SegScan& sc, float v) {
+    v = fmaf(sc.f1, dpp_mov<0x111, 0xf>(v), v);          // row_shr:1
+    v = fmaf(sc.f2, dpp_mov<0x112, 0xf>(v), v);          // row_shr:2
+    v = fmaf(sc.f4, dpp_mov<0x114, 0xf>(v), v);          // row_shr:4
+    v = fmaf(sc.f8, dpp_mov<0x118, 0xf>(v), v);          // row_shr:8
+    v = fmaf(sc.f15, dpp_mov<0x142, 0xa>(v), v);         // row_bcast:15 -> rows 1,3
+    v = fmaf(sc.f31, dpp_mov<0x143, 0xc>(v), v);         // row_bcast:31 -> rows 2,3
+    return v;
+}
+
 struct TableP {
     const int*  pid_of_slot;   // [Np]
     const int4* items;         // (block, start, count, 0)
@@ -213,11 +252,13 @@ __device__ __forceinline__ void unused_particle_fwd(const SimP& S, const FrameV&
     nxt.used[s] = used_next;
 }
 
-// p2g for one used particle (mpm:331-378 + compute_F_tmp/svd mpm:254-264).  `tile` = LDS accumulators
-// (vx,vy,vz,m as four TILE_N planes) or nullptr for the global path.
+// what a used particle contributes to its 27 nodes (mpm:339-353): momentum at the stencil base + affine increments
+struct P2GPrep { Stencil st; float mv[3]; m3 affine; float m; bool inside; };
+
+// compute_F_tmp + svd + stress + F update for one used particle (mpm:254-264, 331-344, 355-378)
 template <bool WRITE, bool GENERAL>
-__device__ __forceinline__ void used_particle_p2g(const SimP& S, const FrameV& cur, const FrameV& nxt, int s, int pid,
-                                                  const float4* __restrict__ pinfo, bool use_tile, const TileO& to, const GridW& G) {
+__device__ __forceinline__ void p2g_prepare(const SimP& S, const FrameV& cur, const FrameV& nxt, int s, int pid,
+                                            const float4* __restrict__ pinfo, const GridW& G, P2GPrep& q) {
     PState p;
     load_xvC(cur, s, p);
     load_F(cur, s, p.F);
@@ -225,39 +266,20 @@ __device__ __forceinline__ void used_particle_p2g(const SimP& S, const FrameV& c
     Constitutive k;
     constitutive_eval_t<GENERAL>(p.C, p.F, S.dt, info.mu, info.lam, info.mass, info.cls, S.stress_scale, k);
     if (WRITE && !(S.dbg & 4)) { store_F(nxt, s, k.Fnew); nxt.used[s] = 1; }
-    Stencil st;
-    stencil_make(p.x, S.inv_dx, st);
-    if (!stencil_inside(st, S.n)) { atomicAdd(G.err, 1); return; }
-    const float m = info.mass;
+    stencil_make(p.x, S.inv_dx, q.st);
+    q.inside = stencil_inside(q.st, S.n);
+    if (!q.inside) atomicAdd(G.err, 1);
+    q.m = info.mass;
+    q.affine = k.affine;
     // momentum at the base node, then per-node increments: mom(o) = m v + A (o - fx) dx
-    float mv[3];
 #pragma unroll
     for (int a = 0; a < 3; a++)
-        mv[a] = m * p.v[a] - S.dx * (k.affine.a[a][0] * st.fx[0] + k.affine.a[a][1] * st.fx[1] + k.affine.a[a][2] * st.fx[2]);
-    const int lb = use_tile ? tile_base(to, st) : -1;
-    if (use_tile && lb < 0) atomicAdd(G.slow, 1);
-    if (lb >= 0) {
-        if (S.dbg & 1) return;
-#pragma unroll 1
-        for (int ij = 0; ij < 9; ij++) {
-            const int i = ij / 3, j = ij - 3 * i;
-            const float wij = STW(st, i, 0) * STW(st, j, 1);
-            const float ox = (float)i * S.dx, oy = (float)j * S.dx;
-            float mij[3];
-#pragma unroll
-            for (int a = 0; a < 3; a++) mij[a] = mv[a] + k.affine.a[a][0] * ox + k.affine.a[a][1] * oy;
-#pragma unroll
-            for (int kk = 0; kk < 3; kk++) {
-                const float weight = wij * st.w[kk][2];
-                const float oz = (float)kk * S.dx;
-                const int l = lb + (i * TILE_T + j) * TILE_T + kk;
-#pragma unroll
-                for (int a = 0; a < 3; a++) atomicAdd(&s_acc[a * TILE_N + l], (double)(weight * (mij[a] + k.affine.a[a][2] * oz)));   // ds_add_f64
-                atomicAdd(&s_acc[3 * TILE_N + l], (double)(weight * m));
-            }
-        }
-        return;
-    }
+        q.mv[a] = q.m * p.v[a] - S.dx * (k.affine.a[a][0] * q.st.fx[0] + k.affine.a[a][1] * q.st.fx[1] + k.affine.a[a][2] * q.st.fx[2]);
+}
+
+// global path: 108 scattered global atomics + active-block marking
+__device__ __forceinline__ void p2g_scatter_global(const SimP& S, const P2GPrep& q, const GridW& G) {
+    const Stencil& st = q.st;
 #pragma unroll 1
     for (int ij = 0; ij < 9; ij++) {
         const int i = ij / 3, j = ij - 3 * i;
@@ -265,15 +287,15 @@ __device__ __forceinline__ void used_particle_p2g(const SimP& S, const FrameV& c
         const float ox = (float)i * S.dx, oy = (float)j * S.dx;
         float mij[3];
 #pragma unroll
-        for (int a = 0; a < 3; a++) mij[a] = mv[a] + k.affine.a[a][0] * ox + k.affine.a[a][1] * oy;
+        for (int a = 0; a < 3; a++) mij[a] = q.mv[a] + q.affine.a[a][0] * ox + q.affine.a[a][1] * oy;
 #pragma unroll
         for (int kk = 0; kk < 3; kk++) {
             const float weight = wij * st.w[kk][2];
             const float oz = (float)kk * S.dx;
             float* dst = G.g_in + cell_addr(st.base[0] + i, st.base[1] + j, st.base[2] + kk, S.nb);
 #pragma unroll
-            for (int a = 0; a < 3; a++) unsafeAtomicAdd(dst + a * S.ncell, weight * (mij[a] + k.affine.a[a][2] * oz));
-            unsafeAtomicAdd(dst + 3 * S.ncell, weight * m);
+            for (int a = 0; a < 3; a++) unsafeAtomicAdd(dst + a * S.ncell, weight * (mij[a] + q.affine.a[a][2] * oz));
+            unsafeAtomicAdd(dst + 3 * S.ncell, weight * q.m);
         }
     }
     // mark the (up to 8) 4^3 blocks this stencil touches
@@ -285,15 +307,36 @@ __device__ __forceinline__ void used_particle_p2g(const SimP& S, const FrameV& c
             for (int bz = bz0; bz <= bz1; bz++) mark_block((bx * S.nb + by) * S.nb + bz, G.blk_flag, G.blk_list, G.blk_count);
 }
 
-// one slot of the p2g pass: used particles scatter, unused ones are carried / injected.  (`used` is re-read
-// here rather than implied by the work list so that host edits of a frame can never desynchronise it.)
-template <bool WRITE, bool GENERAL>
-__device__ __forceinline__ void slot_p2g(const SimP& S, const FrameV& cur, const FrameV& nxt, int s, const TableP& T,
-                                         const float4* __restrict__ pinfo, const int* __restrict__ pool_idx, bool use_tile,
-                                         const TileO& to, const GridW& G, const AgentP& agent, const InjectP& inj, int f) {
-    const int pid = T.pid_of_slot[s];
-    if (cur.used[s]) used_particle_p2g<WRITE, GENERAL>(S, cur, nxt, s, pid, pinfo, use_tile, to, G);
-    else if (WRITE) unused_particle_fwd(S, cur, nxt, s, pid, pool_idx, agent, inj, f);
+// tile path, executed by ALL lanes of the wave: contributions of lanes with `in_tile` are summed over runs of equal
+// stencil base (seg_scan) and the last lane of each run adds the total into the fp64 LDS accumulators
+__device__ __forceinline__ void p2g_scatter_tile(const SimP& S, const P2GPrep& q, bool in_tile, int lb) {
+    const SegScan sc = seg_setup(in_tile ? lb : (0x40000000 | (int)threadIdx.x));
+    const bool issue = sc.tail && in_tile && !(S.dbg & 1);
+    const float live = in_tile ? 1.f : 0.f;
+    const Stencil& st = q.st;
+#pragma unroll 1
+    for (int ij = 0; ij < 9; ij++) {
+        const int i = ij / 3, j = ij - 3 * i;
+        const float wij = live * STW(st, i, 0) * STW(st, j, 1);
+        const float ox = (float)i * S.dx, oy = (float)j * S.dx;
+        float mij[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) mij[a] = q.mv[a] + q.affine.a[a][0] * ox + q.affine.a[a][1] * oy;
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) {
+            const float weight = wij * st.w[kk][2];
+            const float oz = (float)kk * S.dx;
+            const int l = lb + (i * TILE_T + j) * TILE_T + kk;
+            float c[4];
+#pragma unroll
+            for (int a = 0; a < 3; a++) c[a] = seg_scan(sc, weight * (mij[a] + q.affine.a[a][2] * oz));
+            c[3] = seg_scan(sc, weight * q.m);
+            if (issue) {
+#pragma unroll
+                for (int a = 0; a < 4; a++) atomicAdd(&s_acc[a * TILE_N + l], (double)c[a]);            // ds_add_f64
+            }
+        }
+    }
 }
 
 // p2g (mpm:331-378) fused with compute_F_tmp + svd, advect_used + process_unused_particles, Injector.act and,
@@ -315,7 +358,28 @@ __global__ __launch_bounds__(WG) void k_p2g(SimP S, float* fr_cur, float* fr_nex
             const TileO to = tile_origin(it.x, S.nb);
             for (int l = tid; l < 4 * TILE_N; l += WG) s_acc[l] = 0.0;
             __syncthreads();
-            for (int i = tid; i < it.z; i += WG) slot_p2g<WRITE, GENERAL>(S, cur, nxt, it.y + i, T, pinfo, pool_idx, true, to, G, agent, inj, f);
+            for (int i0 = 0; i0 < it.z; i0 += WG) {              // uniform trip count: the DPP scan needs every lane
+                const int i = i0 + tid, s = it.y + i;
+                const bool has = i < it.z;
+                // (`used` is re-read rather than implied by the work list so host edits of a frame cannot desynchronise it)
+                const bool used = has && cur.used[s] != 0;
+                const int pid = has ? T.pid_of_slot[s] : 0;
+                P2GPrep q;
+                q.inside = false;
+                int lb = -1;
+                if (used) {
+                    p2g_prepare<WRITE, GENERAL>(S, cur, nxt, s, pid, pinfo, G, q);
+                    if (q.inside) lb = tile_base(to, q.st);
+                } else {
+                    q.m = 0.f; q.affine = m3_zero(); q.mv[0] = q.mv[1] = q.mv[2] = 0.f;
+                    float zero[3] = {0.f, 0.f, 0.f};
+                    stencil_make(zero, S.inv_dx, q.st);
+                }
+                const bool in_tile = lb >= 0;
+                p2g_scatter_tile(S, q, in_tile, in_tile ? lb : 0);
+                if (used && q.inside && !in_tile) { atomicAdd(G.slow, 1); p2g_scatter_global(S, q, G); }   // drifted out of the tile
+                if (has && !used && WRITE) unused_particle_fwd(S, cur, nxt, s, pid, pool_idx, agent, inj, f);
+            }
             __syncthreads();
             // flush: consecutive lanes -> consecutive nodes of a tile row
             for (int l = tid; l < TILE_N && !(S.dbg & 2); l += WG) {
@@ -333,8 +397,14 @@ __global__ __launch_bounds__(WG) void k_p2g(SimP S, float* fr_cur, float* fr_nex
             __syncthreads();
         } else {
             const int s = tail_start + (w - n_items) * WG + tid;
-            TileO none = {0, 0, 0};
-            if (s < S.N) slot_p2g<WRITE, GENERAL>(S, cur, nxt, s, T, pinfo, pool_idx, false, none, G, agent, inj, f);
+            if (s < S.N) {
+                const int pid = T.pid_of_slot[s];
+                if (cur.used[s]) {
+                    P2GPrep q;
+                    p2g_prepare<WRITE, GENERAL>(S, cur, nxt, s, pid, pinfo, G, q);
+                    if (q.inside) p2g_scatter_global(S, q, G);
+                } else if (WRITE) unused_particle_fwd(S, cur, nxt, s, pid, pool_idx, agent, inj, f);
+            }
         }
     }
 }
@@ -476,11 +546,17 @@ __global__ __launch_bounds__(WG) void k_g2p(SimP S, float* fr_cur, float* fr_nex
 
 // advect_kernel.grad + g2p.grad (mpm:443, 538) for one used particle: scatters d/d(v_out), leaves the
 // position adjoint (so far) in Gc.A0.xyz.  TILE: v_out read from / d v_out accumulated into LDS (3+3 planes)
+// TILE=true is executed by ALL lanes of the wave (`live` = this lane holds a used particle whose stencil fits the
+// tile); the d v_out contributions are summed over runs of equal stencil base before the LDS atomics (seg_scan).
 template <bool TILE>
 __device__ __forceinline__ void used_particle_g2p_grad(const SimP& S, const FrameV& Gn, const FrameV& Gc, int s,
-                                                       int lb, const Stencil& st, const float4* __restrict__ g_out, float* gg_out) {
+                                                       int lb, const Stencil& st, const float4* __restrict__ g_out, float* gg_out,
+                                                       bool live, const SegScan& sc) {
     PState g;                                   // adjoints of x', v', C'
-    load_xvC(Gn, s, g);
+    if (!TILE || live) load_xvC(Gn, s, g);
+    else { g.x[0] = g.x[1] = g.x[2] = g.v[0] = g.v[1] = g.v[2] = 0.f; g.C = m3_zero(); }
+    const bool issue = TILE && sc.tail && live;
+    const float livef = (!TILE || live) ? 1.f : 0.f;
     // x' = x + dt v'  =>  v'_bar += dt x'_bar
     float gv[3] = {g.v[0] + S.dt * g.x[0], g.v[1] + S.dt * g.x[1], g.v[2] + S.dt * g.x[2]};
     const float c4 = 4.f * S.inv_dx;
@@ -494,7 +570,7 @@ __device__ __forceinline__ void used_particle_g2p_grad(const SimP& S, const Fram
 #pragma unroll
         for (int kk = 0; kk < 3; kk++) {
             const float wk = st.w[kk][2];
-            const float weight = wi * wj * wk;
+            const float weight = livef * wi * wj * wk;
             const float dpos[3] = {dx0, dx1, (float)kk - st.fx[2]};
             float q[3];
 #pragma unroll
@@ -503,9 +579,12 @@ __device__ __forceinline__ void used_particle_g2p_grad(const SimP& S, const Fram
             if (TILE) {
                 const int l = lb + (i * TILE_T + j) * TILE_T + kk;
                 v0 = s_tile[l]; v1 = s_tile[TILE_N + l]; v2 = s_tile[2 * TILE_N + l];
-                atomicAdd(&s_acc[l], (double)(weight * q[0]));                // ds_add_f64
-                atomicAdd(&s_acc[TILE_N + l], (double)(weight * q[1]));
-                atomicAdd(&s_acc[2 * TILE_N + l], (double)(weight * q[2]));
+                const float c0 = seg_scan(sc, weight * q[0]), c1 = seg_scan(sc, weight * q[1]), c2 = seg_scan(sc, weight * q[2]);
+                if (issue) {
+                    atomicAdd(&s_acc[l], (double)c0);                         // ds_add_f64
+                    atomicAdd(&s_acc[TILE_N + l], (double)c1);
+                    atomicAdd(&s_acc[2 * TILE_N + l], (double)c2);
+                }
             } else {
                 const int c = cell_addr(st.base[0] + i, st.base[1] + j, st.base[2] + kk, S.nb);
                 float4 vo = g_out[c];
@@ -525,20 +604,21 @@ __device__ __forceinline__ void used_particle_g2p_grad(const SimP& S, const Fram
             for (int b = 0; b < 3; b++) gfx[b] -= c4 * weight * (v0 * g.C.a[0][b] + v1 * g.C.a[1][b] + v2 * g.C.a[2][b]);
         }
     }
-    Gc.A0[s] = make_float4(g.x[0] + S.inv_dx * gfx[0], g.x[1] + S.inv_dx * gfx[1], g.x[2] + S.inv_dx * gfx[2], 0.f);
+    if (!TILE || live) Gc.A0[s] = make_float4(g.x[0] + S.inv_dx * gfx[0], g.x[1] + S.inv_dx * gfx[1], g.x[2] + S.inv_dx * gfx[2], 0.f);
 }
 
-__device__ __forceinline__ void g2p_grad_slot(const SimP& S, const FrameV& cur, const FrameV& Gn, const FrameV& Gc, int s,
-                                              bool use_tile, const TileO& to, const float4* __restrict__ g_out, float* gg_out, int* slow) {
+// one slot on the global path (tail / sort_interval = 0)
+__device__ __forceinline__ void g2p_grad_slot_global(const SimP& S, const FrameV& cur, const FrameV& Gn, const FrameV& Gc, int s,
+                                                     const float4* __restrict__ g_out, float* gg_out) {
     if (!cur.used[s]) return;
     float4 a0 = cur.A0[s];
     float x[3] = {a0.x, a0.y, a0.z};
     Stencil st;
     stencil_make(x, S.inv_dx, st);
     if (!stencil_inside(st, S.n)) { float4 gx = Gn.A0[s]; Gc.A0[s] = make_float4(gx.x, gx.y, gx.z, 0.f); return; }
-    const int lb = use_tile ? tile_base(to, st) : -1;
-    if (lb >= 0) used_particle_g2p_grad<true>(S, Gn, Gc, s, lb, st, g_out, gg_out);
-    else { if (use_tile) atomicAdd(slow, 1); used_particle_g2p_grad<false>(S, Gn, Gc, s, 0, st, g_out, gg_out); }
+    SegScan none;
+    none.f1 = none.f2 = none.f4 = none.f8 = none.f15 = none.f31 = 0.f; none.tail = true;
+    used_particle_g2p_grad<false>(S, Gn, Gc, s, 0, st, g_out, gg_out, true, none);
 }
 
 __global__ __launch_bounds__(WG) void k_g2p_grad(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T,
@@ -555,7 +635,23 @@ __global__ __launch_bounds__(WG) void k_g2p_grad(SimP S, float* fr_cur, float* G
             load_tile3(to, S, g_out, tid);
             for (int l = tid; l < 3 * TILE_N; l += WG) s_acc[l] = 0.0;
             __syncthreads();
-            for (int i = tid; i < it.z; i += WG) g2p_grad_slot(S, cur, Gn, Gc, it.y + i, true, to, g_out, gg_out, slow);
+            for (int i0 = 0; i0 < it.z; i0 += WG) {              // uniform trip count: the DPP scan needs every lane
+                const int i = i0 + tid, s = it.y + i;
+                const bool used = i < it.z && cur.used[s] != 0;
+                float x[3] = {0.f, 0.f, 0.f};
+                if (used) { float4 a0 = cur.A0[s]; x[0] = a0.x; x[1] = a0.y; x[2] = a0.z; }
+                Stencil st;
+                stencil_make(x, S.inv_dx, st);
+                const bool inside = used && stencil_inside(st, S.n);
+                const int lb = inside ? tile_base(to, st) : -1;
+                const bool live = lb >= 0;
+                const SegScan sc = seg_setup(live ? lb : (0x40000000 | tid));
+                used_particle_g2p_grad<true>(S, Gn, Gc, s, live ? lb : 0, st, g_out, gg_out, live, sc);
+                if (used && !live) {
+                    if (inside) atomicAdd(slow, 1);
+                    g2p_grad_slot_global(S, cur, Gn, Gc, s, g_out, gg_out);
+                }
+            }
             __syncthreads();
             for (int l = tid; l < TILE_N; l += WG) {
                 const float q0 = (float)s_acc[l], q1 = (float)s_acc[TILE_N + l], q2 = (float)s_acc[2 * TILE_N + l];
@@ -570,8 +666,7 @@ __global__ __launch_bounds__(WG) void k_g2p_grad(SimP S, float* fr_cur, float* G
             __syncthreads();
         } else {
             const int s = tail_start + (w - n_items) * WG + tid;
-            TileO none = {0, 0, 0};
-            if (s < S.N) g2p_grad_slot(S, cur, Gn, Gc, s, false, none, g_out, gg_out, slow);
+            if (s < S.N) g2p_grad_slot_global(S, cur, Gn, Gc, s, g_out, gg_out);
         }
     }
 }
@@ -751,8 +846,11 @@ __global__ __launch_bounds__(WG) void k_p2g_grad(SimP S, float* fr_cur, float* G
 // block sort (counting sort by 4^3 block of the stencil base)
 // =========================================================================================
 #define SORT_HB 2048
+// Sort key = blocked cell address of the stencil base (block-major, then the 64 cells of the block): slots of one
+// block are contiguous (-> work items) AND particles of one cell are adjacent (-> the wavefront segmented scan in
+// the scatter kernels merges their contributions before touching LDS).
 // histogram + rank.  Keys of one workgroup's 256 slots are nearly always within a narrow range (the previous
-// order was block-sorted too), so ranks come from an LDS histogram (ds_add_rtn_u32) and only one global atomic per
+// order was sorted too), so ranks come from an LDS histogram (ds_add_rtn_u32) and only one global atomic per
 // distinct key per workgroup is issued; keys outside the window fall back to a global atomic.
 __global__ __launch_bounds__(256) void k_sort_count(SimP S, float* fr, int* key, int* rank, int* cnt) {
     __shared__ int hist[SORT_HB];
@@ -760,8 +858,7 @@ __global__ __launch_bounds__(256) void k_sort_count(SimP S, float* fr, int* key,
     const int tid = threadIdx.x;
     const int s = blockIdx.x * blockDim.x + tid;
     const bool valid = s < S.N;
-    const int nblk = S.nb * S.nb * S.nb;
-    int kk = nblk;                                           // sentinel: unused / outside -> tail
+    int kk = S.ncell;                                        // sentinel: unused / outside -> tail
     if (valid) {
         FrameV cur = frame_view(fr, S.Np);
         if (cur.used[s]) {
@@ -769,7 +866,7 @@ __global__ __launch_bounds__(256) void k_sort_count(SimP S, float* fr, int* key,
             float x[3] = {a0.x, a0.y, a0.z};
             Stencil st;
             stencil_make(x, S.inv_dx, st);
-            if (stencil_inside(st, S.n)) kk = (((st.base[0] >> 2) * S.nb) + (st.base[1] >> 2)) * S.nb + (st.base[2] >> 2);
+            if (stencil_inside(st, S.n)) kk = cell_addr(st.base[0], st.base[1], st.base[2], S.nb);
         }
     }
     if (tid == 0) kmin = 0x7fffffff;
@@ -789,9 +886,10 @@ __global__ __launch_bounds__(256) void k_sort_count(SimP S, float* fr, int* key,
     if (valid) { key[s] = kk; rank[s] = r; }
 }
 
-// exclusive scan of the block histogram (nblk+1 entries) in two launches of ceil((nblk+1)/1024) workgroups:
-// per-workgroup partial sums, then every workgroup adds the partials before it and scans its own 1024 entries.
-// Also emits the work list (one item per occupied block, split at ITEM_MAX particles) and re-zeroes the histogram.
+// exclusive scan of the cell histogram (ncell+1 entries) in two launches of ceil((ncell+1)/1024) workgroups:
+// per-workgroup partial sums, then every workgroup adds the partials before it and scans its own 1024 entries
+// (= 16 blocks).  Also emits the work list (one item per occupied block, split at ITEM_MAX particles) and
+// re-zeroes the histogram.
 __device__ __forceinline__ int wg_scan_excl(int v, int* sh, int tid, int& total) {   // 256 threads
     const int lane = tid & 63, wave = tid >> 6;
     int incl = v;
@@ -806,49 +904,67 @@ __device__ __forceinline__ int wg_scan_excl(int v, int* sh, int tid, int& total)
     return off + incl - v;
 }
 
-__global__ __launch_bounds__(256) void k_scan_partial(int nblk, int ITEM_MAX, const int* __restrict__ cnt, int2* partial) {
-    __shared__ int sh[4];
-    const int tid = threadIdx.x;
+// per-thread sum of its 4 histogram entries, and (threads 0..15) the particle count of block wg*16+t
+__device__ __forceinline__ int scan_load(int ncell, const int* cnt, int tid, int c[4], int* sh_sum, int& blk_cnt) {
     const int b0 = blockIdx.x * 1024 + tid * 4;
-    int sp = 0, si = 0;
+    int sp = 0, sb = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const int b = b0 + q;
-        if (b <= nblk) { int c = cnt[b]; sp += c; if (b < nblk) si += (c + ITEM_MAX - 1) / ITEM_MAX; }
+        c[q] = b <= ncell ? cnt[b] : 0;
+        sp += c[q];
+        if (b < ncell) sb += c[q];
     }
+    sh_sum[tid] = sb;
+    __syncthreads();
+    blk_cnt = 0;
+    if (tid < 16) for (int q = 0; q < 16; q++) blk_cnt += sh_sum[tid * 16 + q];
+    __syncthreads();
+    return sp;
+}
+
+__global__ __launch_bounds__(256) void k_scan_partial(int ncell, int ITEM_MAX, const int* __restrict__ cnt, int2* partial) {
+    __shared__ int sh[4];
+    __shared__ int sh_sum[256];
+    const int tid = threadIdx.x;
+    int c[4], blk_cnt;
+    const int sp = scan_load(ncell, cnt, tid, c, sh_sum, blk_cnt);
+    const int si = tid < 16 ? (blk_cnt + ITEM_MAX - 1) / ITEM_MAX : 0;
     int tp, ti;
     wg_scan_excl(sp, sh, tid, tp);
     wg_scan_excl(si, sh, tid, ti);
     if (tid == 0) partial[blockIdx.x] = make_int2(tp, ti);
 }
 
-__global__ __launch_bounds__(256) void k_scan_final(int nblk, int ITEM_MAX, int* cnt, const int2* __restrict__ partial, int* start, int4* items, int* meta) {
+__global__ __launch_bounds__(256) void k_scan_final(int ncell, int ITEM_MAX, int* cnt, const int2* __restrict__ partial, int* start, int4* items, int* meta) {
     __shared__ int sh[4];
+    __shared__ int sh_sum[256];
+    __shared__ int sh_bp[256];
     const int tid = threadIdx.x;
     int pp = 0, pi = 0;                                       // sums of the partials before this workgroup
     for (int w = tid; w < (int)blockIdx.x; w += 256) { int2 t = partial[w]; pp += t.x; pi += t.y; }
-    int tot;
-    int e = wg_scan_excl(pp, sh, tid, tot); (void)e; const int base_p = tot;
-    e = wg_scan_excl(pi, sh, tid, tot); const int base_i = tot;
-    const int b0 = blockIdx.x * 1024 + tid * 4;
-    int c[4], sp = 0, si = 0;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int b = b0 + q;
-        c[q] = b <= nblk ? cnt[b] : 0;
-        sp += c[q];
-        if (b < nblk) si += (c[q] + ITEM_MAX - 1) / ITEM_MAX;
-    }
-    int totp, toti;
-    int bp = base_p + wg_scan_excl(sp, sh, tid, totp);
+    int base_p, base_i, dummy;
+    wg_scan_excl(pp, sh, tid, base_p);
+    wg_scan_excl(pi, sh, tid, base_i);
+    int c[4], blk_cnt;
+    const int sp = scan_load(ncell, cnt, tid, c, sh_sum, blk_cnt);
+    const int si = tid < 16 ? (blk_cnt + ITEM_MAX - 1) / ITEM_MAX : 0;
+    int toti;
+    int bp = base_p + wg_scan_excl(sp, sh, tid, dummy);
     int bi = base_i + wg_scan_excl(si, sh, tid, toti);
+    sh_bp[tid] = bp;
+    __syncthreads();
+    if (tid < 16 && blk_cnt > 0) {                            // the items of block wg*16+tid: slots [bstart, bstart+blk_cnt)
+        const int blk = blockIdx.x * 16 + tid, bstart = sh_bp[tid * 16];
+        for (int o = 0; o < blk_cnt; o += ITEM_MAX) items[bi++] = make_int4(blk, bstart + o, min(ITEM_MAX, blk_cnt - o), 0);
+    }
+    const int b0 = blockIdx.x * 1024 + tid * 4;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const int b = b0 + q;
-        if (b > nblk) break;
+        if (b > ncell) break;
         start[b] = bp;
-        if (b < nblk) for (int o = 0; o < c[q]; o += ITEM_MAX) items[bi++] = make_int4(b, bp + o, min(ITEM_MAX, c[q] - o), 0);
-        else meta[1] = bp;                                    // first tail slot
+        if (b == ncell) meta[1] = bp;                         // first tail slot
         bp += c[q];
         cnt[b] = 0;                                           // ready for the next sort
     }
@@ -1241,12 +1357,12 @@ int sort_frame(FeEngine* h, int f) {
     for (int slot = 0; slot < 2; slot++)            // an adjoint slot still stored in the order about to be overwritten
         if (h->gtbl[slot] == id_new && reorder_grad(h, slot, 0)) return 1;
     FeEngine::Table& tn = h->tables[id_new];
-    const int nblk = h->nb * h->nb * h->nb;
+    const int ncell = h->S.ncell;
     prof_begin(h, KID_SORT);
     hipLaunchKernelGGL(k_sort_count, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->sort_key, h->sort_rank, h->sort_cnt);
-    const int scan_wgs = (nblk + 1 + 1023) / 1024;
-    hipLaunchKernelGGL(k_scan_partial, dim3(scan_wgs), dim3(256), 0, h->stream, nblk, h->item_max, h->sort_cnt, h->sort_partial);
-    hipLaunchKernelGGL(k_scan_final, dim3(scan_wgs), dim3(256), 0, h->stream, nblk, h->item_max, h->sort_cnt, h->sort_partial, h->sort_start, tn.items, tn.meta);
+    const int scan_wgs = (ncell + 1 + 1023) / 1024;
+    hipLaunchKernelGGL(k_scan_partial, dim3(scan_wgs), dim3(256), 0, h->stream, ncell, h->item_max, h->sort_cnt, h->sort_partial);
+    hipLaunchKernelGGL(k_scan_final, dim3(scan_wgs), dim3(256), 0, h->stream, ncell, h->item_max, h->sort_cnt, h->sort_partial, h->sort_start, tn.items, tn.meta);
     hipLaunchKernelGGL(k_sort_perm, pgrid(h), dim3(256), 0, h->stream, h->N, h->sort_key, h->sort_rank, h->sort_start,
                        h->tables[id_old].pid, h->sort_src, h->sort_pid);
     HIPCK(h, hipMemcpyAsync(tn.pid, h->sort_pid, sizeof(int) * h->Np, hipMemcpyDeviceToDevice, h->stream));
@@ -1413,9 +1529,9 @@ FeEngine* fe_create(const FeConfig* cfg) {
     {
         const size_t nblk = (size_t)h->nb * h->nb * h->nb;
         h->items_cap = (nblk < (size_t)h->Np ? nblk : (size_t)h->Np) + (size_t)h->Np / 64 + 2;      // item_max >= 64
-        if (dev_alloc(h, &h->sort_key, h->Np) || dev_alloc(h, &h->sort_rank, h->Np) || dev_alloc(h, &h->sort_cnt, nblk + 1) ||
-            dev_alloc(h, &h->sort_start, nblk + 1) || dev_alloc(h, &h->sort_src, h->Np) || dev_alloc(h, &h->sort_pid, h->Np) ||
-            dev_alloc(h, &h->slow_dev, 1) || dev_alloc(h, &h->sort_partial, (nblk + 1 + 1023) / 1024 + 1)) return fail("");
+        if (dev_alloc(h, &h->sort_key, h->Np) || dev_alloc(h, &h->sort_rank, h->Np) || dev_alloc(h, &h->sort_cnt, ncell + 1) ||
+            dev_alloc(h, &h->sort_start, ncell + 1) || dev_alloc(h, &h->sort_src, h->Np) || dev_alloc(h, &h->sort_pid, h->Np) ||
+            dev_alloc(h, &h->slow_dev, 1) || dev_alloc(h, &h->sort_partial, (ncell + 1 + 1023) / 1024 + 1)) return fail("");
     }
     if (dev_alloc(h, &h->effs_dev, FE_MAX_EFF)) return fail("");
     if (ensure_table(h, 0)) return fail("");                 // identity order: no items, everything is "tail"
