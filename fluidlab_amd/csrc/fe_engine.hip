@@ -168,6 +168,25 @@ __device__ __forceinline__ SegScan seg_setup(int key) {
     sc.tail = lane == 63 || ((mask >> (lane + 1)) & 1ull);                 // last lane of its run
     return sc;
 }
+// Four independent values at once, one v_fmac_f32_dpp per step and value (the compiler's own lowering of seg_scan
+// is v_mov_b32_dpp + v_fma_f32).  A DPP read of a VGPR written by the previous VALU needs 2 wait states, which
+// inline asm has to provide itself: within a step the 4 chains are independent, and the s_nop 1 after each step
+// covers the distance from the last write of the step to the first read of the next.
+#define SEG_STEP4(ctrl, flag) \
+    asm volatile("v_fmac_f32_dpp %0, %0, %4 " ctrl " bound_ctrl:0\n\t" \
+                 "v_fmac_f32_dpp %1, %1, %4 " ctrl " bound_ctrl:0\n\t" \
+                 "v_fmac_f32_dpp %2, %2, %4 " ctrl " bound_ctrl:0\n\t" \
+                 "v_fmac_f32_dpp %3, %3, %4 " ctrl " bound_ctrl:0\n\t" \
+                 "s_nop 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(flag))
+__device__ __forceinline__ void seg_scan4(const SegScan& sc, float& a, float& b, float& c, float& d) {
+    asm volatile("s_nop 1" ::: );                        // the inputs were just produced by VALU
+    SEG_STEP4("row_shr:1 row_mask:0xf bank_mask:0xf", sc.f1);
+    SEG_STEP4("row_shr:2 row_mask:0xf bank_mask:0xf", sc.f2);
+    SEG_STEP4("row_shr:4 row_mask:0xf bank_mask:0xf", sc.f4);
+    SEG_STEP4("row_shr:8 row_mask:0xf bank_mask:0xf", sc.f8);
+    SEG_STEP4("row_bcast:15 row_mask:0xa bank_mask:0xf", sc.f15);
+    SEG_STEP4("row_bcast:31 row_mask:0xc bank_mask:0xf", sc.f31);
+}
 __device__ __forceinline__ float seg_scan(const SegScan& sc, float v) {
     v = fmaf(sc.f1, dpp_mov<0x111, 0xf>(v), v);          // row_shr:1
     v = fmaf(sc.f2, dpp_mov<0x112, 0xf>(v), v);          // row_shr:2
@@ -329,8 +348,9 @@ __device__ __forceinline__ void p2g_scatter_tile(const SimP& S, const P2GPrep& q
             const int l = lb + (i * TILE_T + j) * TILE_T + kk;
             float c[4];
 #pragma unroll
-            for (int a = 0; a < 3; a++) c[a] = seg_scan(sc, weight * (mij[a] + q.affine.a[a][2] * oz));
-            c[3] = seg_scan(sc, weight * q.m);
+            for (int a = 0; a < 3; a++) c[a] = weight * (mij[a] + q.affine.a[a][2] * oz);
+            c[3] = weight * q.m;
+            seg_scan4(sc, c[0], c[1], c[2], c[3]);
             if (issue) {
 #pragma unroll
                 for (int a = 0; a < 4; a++) atomicAdd(&s_acc[a * TILE_N + l], (double)c[a]);            // ds_add_f64
@@ -579,7 +599,8 @@ __device__ __forceinline__ void used_particle_g2p_grad(const SimP& S, const Fram
             if (TILE) {
                 const int l = lb + (i * TILE_T + j) * TILE_T + kk;
                 v0 = s_tile[l]; v1 = s_tile[TILE_N + l]; v2 = s_tile[2 * TILE_N + l];
-                const float c0 = seg_scan(sc, weight * q[0]), c1 = seg_scan(sc, weight * q[1]), c2 = seg_scan(sc, weight * q[2]);
+                float c0 = weight * q[0], c1 = weight * q[1], c2 = weight * q[2], c3 = 0.f;
+                seg_scan4(sc, c0, c1, c2, c3);
                 if (issue) {
                     atomicAdd(&s_acc[l], (double)c0);                         // ds_add_f64
                     atomicAdd(&s_acc[TILE_N + l], (double)c1);
@@ -722,11 +743,9 @@ __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const Fram
     PInfo info = load_info(pinfo, pid);
     Constitutive k;
     constitutive_eval_t<GENERAL>(p.C, p.F, S.dt, info.mu, info.lam, info.mass, info.cls, S.stress_scale, k);
-    m3 Fg; load_F(Gn, s, Fg);
-    float4 gc0 = Gc.A0[s];                      // position adjoint so far (k_g2p_grad)
-    float gx[3] = {gc0.x, gc0.y, gc0.z};
     float Gv[3] = {0.f, 0.f, 0.f};
     m3 GA = m3_zero();
+    float gxs[3] = {0.f, 0.f, 0.f};             // inv_dx * d/d fx from the stencil
     Stencil st;
     stencil_make(p.x, S.inv_dx, st);
     if (stencil_inside(st, S.n)) {
@@ -782,8 +801,22 @@ __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const Fram
             }
         }
 #pragma unroll
-        for (int d = 0; d < 3; d++) gx[d] += S.inv_dx * gfx[d];
+        for (int d = 0; d < 3; d++) gxs[d] = S.inv_dx * gfx[d];
     }
+    if (!GENERAL) {
+        // Register diet for the SVD-free build: C and F (18 VGPRs) are not kept alive across the 27-node loop but
+        // re-read (L2-hot) behind a pointer the optimiser cannot see through; F_tmp and J are recomputed.
+        FrameV again = cur;
+        asm volatile("" : "+v"(again.A1), "+v"(again.A2), "+v"(again.a3), "+v"(again.a4), "+v"(again.a5), "+v"(again.B0), "+v"(again.B1), "+v"(again.b2));
+        float4 a1 = again.A1[s], a2 = again.A2[s];
+        p.C.a[0][0] = a1.z; p.C.a[0][1] = a1.w; p.C.a[0][2] = a2.x; p.C.a[1][0] = a2.y; p.C.a[1][1] = a2.z; p.C.a[1][2] = a2.w;
+        p.C.a[2][0] = again.a3[s]; p.C.a[2][1] = again.a4[s]; p.C.a[2][2] = again.a5[s];
+        load_F(again, s, p.F);
+        constitutive_eval_t<GENERAL>(p.C, p.F, S.dt, info.mu, info.lam, info.mass, info.cls, S.stress_scale, k);
+    }
+    m3 Fg; load_F(Gn, s, Fg);
+    float4 gc0 = Gc.A0[s];                      // position adjoint so far (k_g2p_grad)
+    float gx[3] = {gc0.x + gxs[0], gc0.y + gxs[1], gc0.z + gxs[2]};
     float gvv[3] = {info.mass * Gv[0], info.mass * Gv[1], info.mass * Gv[2]};
     m3 gC, gF;
     constitutive_grad_t<GENERAL>(p.C, p.F, S.dt, info.mu, info.lam, info.mass, info.cls, S.stress_scale, k, GA, Fg, gC, gF);
@@ -812,8 +845,8 @@ __device__ __forceinline__ void slot_p2g_grad(const SimP& S, const FrameV& cur, 
 
 // p2g.grad + svd_grad + compute_F_tmp.grad + AgentInjector.act_kernel.grad + process_unused_particles.grad (mpm:551)
 // + Effector.move_kernel.grad on one thread
-template <bool GENERAL>
-__global__ __launch_bounds__(WG) void k_p2g_grad(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T,
+template <bool GENERAL, int MINW>
+__global__ __launch_bounds__(WG, MINW) void k_p2g_grad(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T,
                                                  const float4* __restrict__ pinfo, const int* __restrict__ pool_idx,
                                                  const float4* __restrict__ gg_in, int* blk_count, int* slow, AgentP agent,
                                                  InjectP inj, int act, int f) {
@@ -1196,6 +1229,7 @@ struct FeEngine {
     std::vector<Table> tables;
     std::vector<int> tbl_of_frame;                          // [L+1]
     int gtbl[2] = {-1, -1};                                 // order of each adjoint ring slot; -1 = all zero
+    int p2g_grad_waves = 4;                                 // occupancy target of the SVD-free p2g_grad build (tuning)
     int item_max = 256;                                     // particles per work item (<= ITEM_MAX_CAP)
     int sort_interval = 10;                                 // K: re-sort every K substeps (0 = never: global path only)
     size_t items_cap = 0;
@@ -1429,12 +1463,13 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act) {
     hipLaunchKernelGGL(k_grid_grad, ggrid(h), dim3(256), 0, h->stream, h->S, h->g_in, h->gg_out, h->gg_in, h->blk_list, h->blk_count, h->blk_flag);
     prof_end(h);
     prof_begin(h, KID_P2G_GRAD);
-    if (h->all_simple_liquid)
-        hipLaunchKernelGGL(k_p2g_grad<false>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T,
-                           h->pinfo, h->pool_idx, h->gg_in, h->blk_count, h->slow_dev, ag, inj, act, f);
-    else
-        hipLaunchKernelGGL(k_p2g_grad<true>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T,
-                           h->pinfo, h->pool_idx, h->gg_in, h->blk_count, h->slow_dev, ag, inj, act, f);
+#define LAUNCH_P2G_GRAD(G, W) hipLaunchKernelGGL((k_p2g_grad<G, W>), wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), \
+                           h->grad(f), T, h->pinfo, h->pool_idx, h->gg_in, h->blk_count, h->slow_dev, ag, inj, act, f)
+    if (h->all_simple_liquid) {
+        if (h->p2g_grad_waves >= 4) LAUNCH_P2G_GRAD(false, 4);
+        else if (h->p2g_grad_waves == 3) LAUNCH_P2G_GRAD(false, 3);
+        else LAUNCH_P2G_GRAD(false, 2);
+    } else LAUNCH_P2G_GRAD(true, 1);
     prof_end(h);
     h->gtbl[f & 1] = t;
     return 0;
@@ -1589,6 +1624,7 @@ int fe_set_option(FeEngine* h, const char* name, double value) {
         h->item_max = (int)value;
         return 0;
     }
+    if (!std::strcmp(name, "p2g_grad_waves")) { h->p2g_grad_waves = (int)value; return 0; }
     if (!std::strcmp(name, "dbg")) { h->S.dbg = (int)value; return 0; }     // timing experiments: results are wrong
     if (!std::strcmp(name, "threads")) return 0;             // oracle-only tunable
     FAIL(h, std::string("unknown option: ") + name);

@@ -19,6 +19,10 @@ __global__ __launch_bounds__(256) void k_lds(int mode, int rounds, const int* __
 #pragma unroll
         for (int n = 0; n < 27; n++) {
             int node = mode == 0 ? ((tid + n * 7) & 511) : (((r >> 3) + n * 19 + it) % 216 + (n & 1));
+            // mode 2: groups of 8 adjacent lanes share one node (cell-sorted particles, no aggregation)
+            // mode 3: same nodes, but only the last lane of each group of 8 issues (after a wavefront segmented scan)
+            if (mode >= 2) node = (((tid >> 3) * 37 + n * 19 + it) % 216) + (n & 1);
+            if (mode == 3 && (tid & 7) != 7) continue;
 #pragma unroll
             for (int c = 0; c < 4; c++) atomicAdd(&tile[c * 512 + node], (T)1);
         }
@@ -60,8 +64,9 @@ int main() {
     const double ops = (double)wgs * 256 * rounds * 108;
 #define RUN(name, launch) do { launch; CK(hipEventRecord(e0)); launch; CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); \
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); printf("%-44s %8.1f us  %9.2f G lane-ops/s\n", name, ms * 1e3, ops / ms / 1e6); } while (0)
-    for (int mode = 0; mode < 2; mode++) {
-        printf("-- %s\n", mode == 0 ? "distinct words per wave" : "random of 216 nodes (P2G-like)");
+    const char* mnames[] = {"distinct words per wave", "random of 216 nodes (P2G-like)", "8 adjacent lanes share a node", "1 of 8 lanes active (aggregated); rate counts all 64 lanes"};
+    for (int mode = 0; mode < 4; mode++) {
+        printf("-- %s\n", mnames[mode]);
         RUN("ds_add_f32 (float)", hipLaunchKernelGGL(k_lds<float>, dim3(wgs), dim3(256), 0, 0, mode, rounds, rnd, out));
         RUN("ds_add_u32 (int)", hipLaunchKernelGGL(k_lds<int>, dim3(wgs), dim3(256), 0, 0, mode, rounds, rnd, out));
         RUN("ds_add_u64 (unsigned long long)", hipLaunchKernelGGL(k_lds<unsigned long long>, dim3(wgs), dim3(256), 0, 0, mode, rounds, rnd, out));
