@@ -176,6 +176,13 @@ def main():
                 b = bp * n_used + bc * nc
                 per_kernel[name] = {'avg_us': round(us, 3), 'alg_bytes': b, 'GBps': round(b / (us * 1e-6) / 1e9, 1)}
         dom = max(per_kernel, key=lambda k: per_kernel[k]['avg_us'])
+        # HBM traffic of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs)
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01j_pmc_traffic.json')))['kernels'][dom]
+            traffic = int((pmc['FETCH_SIZE_KB'] + pmc['WRITE_SIZE_KB']) * 1024)
+        except Exception:
+            pass
         b_pair = 524 * n_used + 204 * nc
         out = {
             'metric': 'MPM substeps/sec (fwd+bwd), 128^3 grid / 200k particles', 'value': round(value, 1),
@@ -186,7 +193,7 @@ def main():
                        'substeps_per_step': CHUNK, 'n_used': n_used, 'n_cells_touched': nc,
                        'parallelism': f'{world} env replica(s), one per GPU' + (', all-reduce of 251x3 action grad per step' if world > 1 else '')},
             'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': per_kernel[dom]['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(per_kernel[dom]['GBps'] / HBM_PEAK_GBS, 4), 'traffic': None,
+                         'frac': round(per_kernel[dom]['GBps'] / HBM_PEAK_GBS, 4), 'traffic': traffic,
                          'alg_bytes_per_launch': per_kernel[dom]['alg_bytes'], 'avg_launch_us': per_kernel[dom]['avg_us']},
             'pair_roofline': {'alg_bytes_per_pair': b_pair, 'achieved_GBps': round(b_pair * value / world / 1e9, 1),
                               'frac': round(b_pair * value / world / 1e9 / HBM_PEAK_GBS, 4)},

@@ -102,9 +102,10 @@ __device__ __forceinline__ PInfo load_info(const float4* pinfo, int pid) {
     return r;
 }
 
+// blk_flag: 0 untouched, 1 on the dynamic list (slow-path particles), 2 static = on the order's active list already
 __device__ __forceinline__ void mark_block(int b, int* blk_flag, int* blk_list, int* blk_count) {
     if (blk_flag[b] == 0) {
-        if (atomicExch(&blk_flag[b], 1) == 0) { int i = atomicAdd(blk_count, 1); blk_list[i] = b; }
+        if (atomicCAS(&blk_flag[b], 0, 1) == 0) { int i = atomicAdd(blk_count, 1); blk_list[i] = b; }
     }
 }
 
@@ -199,8 +200,10 @@ __device__ __forceinline__ float seg_scan(const SegScan& sc, float v) {
 
 struct TableP {
     const int*  pid_of_slot;   // [Np]
-    const int4* items;         // (block, start, count, 0)
-    const int*  meta;          // meta[0] = n_items, meta[1] = tail_start
+    const int4* items;         // (block, start, count, 0), sorted by block
+    const int*  meta;          // meta[0] = n_items, meta[1] = tail_start, meta[2] = n_active
+    const int*  blk_first;     // [nblk] first item of a block or -1
+    const int*  active;        // blocks within one block of an occupied block: every block a tile can reach
 };
 
 struct TileO { int ox, oy, oz; };
@@ -237,7 +240,7 @@ __device__ void effector_move(const EffP& e, int f) {
 }
 
 struct GridW {            // everything a scattering particle needs of the global grid
-    float* g_in; int ncell; int* blk_flag; int* blk_list; int* blk_count; int* err; int* slow;
+    float* g_in; float4* slab; int ncell; unsigned long long* ts; int* blk_flag; int* blk_list; int* blk_count; int* err; int* slow;
 };
 
 // advect_used + process_unused_particles (mpm:304-316) + Injector.act (injector.py:80-105) for one unused slot
@@ -370,14 +373,18 @@ __global__ __launch_bounds__(WG) void k_p2g(SimP S, float* fr_cur, float* fr_nex
     }
     FrameV cur = frame_view(fr_cur, S.Np);
     FrameV nxt = frame_view(fr_next, S.Np);
+#define TS(k) do { if ((S.dbg & 8) && tid == 0 && blockIdx.x < 4096) G.ts[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+    TS(0);
     const int n_items = T.meta[0], tail_start = T.meta[1];
     const int n_tail = (S.N - tail_start + WG - 1) / WG;
     for (int w = blockIdx.x; w < n_items + n_tail; w += gridDim.x) {
         if (w < n_items) {
             const int4 it = T.items[w];
             const TileO to = tile_origin(it.x, S.nb);
+            TS(1);
             for (int l = tid; l < 4 * TILE_N; l += WG) s_acc[l] = 0.0;
             __syncthreads();
+            TS(2);
             for (int i0 = 0; i0 < it.z; i0 += WG) {              // uniform trip count: the DPP scan needs every lane
                 const int i = i0 + tid, s = it.y + i;
                 const bool has = i < it.z;
@@ -401,20 +408,13 @@ __global__ __launch_bounds__(WG) void k_p2g(SimP S, float* fr_cur, float* fr_nex
                 if (has && !used && WRITE) unused_particle_fwd(S, cur, nxt, s, pid, pool_idx, agent, inj, f);
             }
             __syncthreads();
-            // flush: consecutive lanes -> consecutive nodes of a tile row
-            for (int l = tid; l < TILE_N && !(S.dbg & 2); l += WG) {
-                const float vx = (float)s_acc[l], vy = (float)s_acc[TILE_N + l], vz = (float)s_acc[2 * TILE_N + l], m = (float)s_acc[3 * TILE_N + l];
-                if (m != 0.f || vx != 0.f || vy != 0.f || vz != 0.f) {
-                    int i, j, k;
-                    if (tile_node(to, l, S.n, i, j, k)) {
-                        // SoA planes: per instruction the lanes of a tile row hit consecutive floats (coalesced atomics)
-                        float* dst = G.g_in + cell_addr(i, j, k, S.nb);
-                        unsafeAtomicAdd(dst, vx); unsafeAtomicAdd(dst + S.ncell, vy); unsafeAtomicAdd(dst + 2 * S.ncell, vz); unsafeAtomicAdd(dst + 3 * S.ncell, m);
-                        mark_block((((i >> 2) * S.nb) + (j >> 2)) * S.nb + (k >> 2), G.blk_flag, G.blk_list, G.blk_count);
-                    }
-                }
-            }
+            TS(3);
+            // hand the tile over: plain coalesced float4 stores into this item's slab.  No atomics, no waiting:
+            // k_grid sums, per node, the slabs of the (at most 8) blocks whose tiles reach it, in a fixed order.
+            for (int l = tid; l < TILE_N; l += WG)
+                G.slab[(size_t)w * TILE_N + l] = make_float4((float)s_acc[l], (float)s_acc[TILE_N + l], (float)s_acc[2 * TILE_N + l], (float)s_acc[3 * TILE_N + l]);
             __syncthreads();
+            TS(4);
         } else {
             const int s = tail_start + (w - n_items) * WG + tid;
             if (s < S.N) {
@@ -439,21 +439,63 @@ __device__ __forceinline__ void node_velocity(const SimP& S, const float4 gi, in
     boundary_v(S.bnd, xn, vo, kmul);
 }
 
+// Sum, for node (oi,oj,ok) of block b, what the work items' tiles deposited there.  A tile of block B' covers the
+// nodes [4B'-1, 4B'+7) per axis, so a node with in-block offset o receives from B'=B (tile index o+1) and from
+// B'=B-1 (index o+5) when o <= 2, or B'=B+1 (index 0) when o == 3: 8 source blocks, visited in a fixed order
+// (deterministic sums).  `slab` holds one 512-node float4 tile per item.
+__device__ __forceinline__ float4 gather_slabs(const SimP& S, const TableP& T, const float4* __restrict__ slab, int bi, int bj, int bk, int lane) {
+    const int o[3] = {lane >> 4, (lane >> 2) & 3, lane & 3};
+    const int bc[3] = {bi, bj, bk};
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int n_items = T.meta[0];
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        int sb[3], ti[3];
+        bool ok = true;
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const bool other = (c >> d) & 1;
+            const int delta = other ? (o[d] == 3 ? 1 : -1) : 0;
+            sb[d] = bc[d] + delta;
+            ti[d] = other ? (o[d] == 3 ? 0 : o[d] + 5) : o[d] + 1;
+            ok = ok && (unsigned)sb[d] < (unsigned)S.nb;
+        }
+        if (!ok) continue;
+        const int src = (sb[0] * S.nb + sb[1]) * S.nb + sb[2];
+        const int tidx = (ti[0] * TILE_T + ti[1]) * TILE_T + ti[2];
+        int it = T.blk_first[src];
+        if (it < 0) continue;
+        for (; it < n_items && T.items[it].x == src; it++) {
+            const float4 v = slab[(size_t)it * TILE_N + tidx];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    }
+    return acc;
+}
+
+// entries of the grid kernels: first the order's static active list, then the dynamic list of slow-path blocks
+__device__ __forceinline__ int grid_entry(const TableP& T, const int* __restrict__ blk_list, int e, int n_static, bool& is_static) {
+    is_static = e < n_static;
+    return is_static ? T.active[e] : blk_list[e - n_static];
+}
+
 // grid_op (mpm:380-398) over the active 4^3 blocks only; one wave per block.
-// KEEP=false (forward): also re-zeroes g_in and the block flag, so no separate reset_grid pass
-// (mpm:219-223) is needed.  KEEP=true (backward recompute): grid_grad does that later.
+// KEEP=false (forward): also re-zeroes g_in and the dynamic block flag, so no separate reset_grid pass
+// (mpm:219-223) is needed.  KEEP=true (backward recompute): stores the summed (p, m) in g_in for grid_grad.
 template <bool KEEP>
-__global__ __launch_bounds__(256) void k_grid(SimP S, float* g_in, float4* g_out, const int* __restrict__ blk_list,
-                                              const int* __restrict__ blk_count, int* blk_flag) {
+__global__ __launch_bounds__(256) void k_grid(SimP S, TableP T, const float4* __restrict__ slab, float* g_in, float4* g_out,
+                                              const int* __restrict__ blk_list, const int* __restrict__ blk_count, int* blk_flag) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int cnt = *blk_count;
+    const int n_static = T.meta[2], cnt = n_static + *blk_count;
     for (int e = blockIdx.x * 4 + wave; e < cnt; e += gridDim.x * 4) {
-        const int b = blk_list[e];
+        bool is_static;
+        const int b = grid_entry(T, blk_list, e, n_static, is_static);
         const int c = (b << 6) | lane;
-        const float4 gi = make_float4(g_in[c], g_in[S.ncell + c], g_in[2 * S.ncell + c], g_in[3 * S.ncell + c]);
+        const int bi = b / (S.nb * S.nb), bj = (b / S.nb) % S.nb, bk = b % S.nb;
+        float4 gi = make_float4(g_in[c], g_in[S.ncell + c], g_in[2 * S.ncell + c], g_in[3 * S.ncell + c]);     // slow-path atomics
+        if (is_static) { const float4 t = gather_slabs(S, T, slab, bi, bj, bk, lane); gi.x += t.x; gi.y += t.y; gi.z += t.z; gi.w += t.w; }
         float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
         if (gi.w > FE_EPS) {
-            const int bi = b / (S.nb * S.nb), bj = (b / S.nb) % S.nb, bk = b % S.nb;
             float vo[3], kmul[3];
             node_velocity(S, gi, bi * 4 + (lane >> 4), bj * 4 + ((lane >> 2) & 3), bk * 4 + (lane & 3), vo, kmul);
             out = make_float4(vo[0], vo[1], vo[2], 0.f);
@@ -461,7 +503,9 @@ __global__ __launch_bounds__(256) void k_grid(SimP S, float* g_in, float4* g_out
         g_out[c] = out;
         if (!KEEP) {
             g_in[c] = 0.f; g_in[S.ncell + c] = 0.f; g_in[2 * S.ncell + c] = 0.f; g_in[3 * S.ncell + c] = 0.f;
-            if (lane == 0) blk_flag[b] = 0;
+            if (lane == 0 && !is_static) blk_flag[b] = 0;
+        } else {
+            g_in[c] = gi.x; g_in[S.ncell + c] = gi.y; g_in[2 * S.ncell + c] = gi.z; g_in[3 * S.ncell + c] = gi.w;
         }
     }
 }
@@ -643,7 +687,7 @@ __device__ __forceinline__ void g2p_grad_slot_global(const SimP& S, const FrameV
 }
 
 __global__ __launch_bounds__(WG) void k_g2p_grad(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T,
-                                                 const float4* __restrict__ g_out, float* gg_out, int* slow) {
+                                                 const float4* __restrict__ g_out, float* gg_out, float4* slab, int* slow) {
     const int tid = threadIdx.x;
     FrameV cur = frame_view(fr_cur, S.Np);
     FrameV Gn = frame_view(Gn_, S.Np), Gc = frame_view(Gc_, S.Np);
@@ -674,16 +718,8 @@ __global__ __launch_bounds__(WG) void k_g2p_grad(SimP S, float* fr_cur, float* G
                 }
             }
             __syncthreads();
-            for (int l = tid; l < TILE_N; l += WG) {
-                const float q0 = (float)s_acc[l], q1 = (float)s_acc[TILE_N + l], q2 = (float)s_acc[2 * TILE_N + l];
-                if (q0 != 0.f || q1 != 0.f || q2 != 0.f) {
-                    int i, j, k;
-                    if (tile_node(to, l, S.n, i, j, k)) {
-                        float* dst = gg_out + cell_addr(i, j, k, S.nb);
-                        unsafeAtomicAdd(dst, q0); unsafeAtomicAdd(dst + S.ncell, q1); unsafeAtomicAdd(dst + 2 * S.ncell, q2);
-                    }
-                }
-            }
+            for (int l = tid; l < TILE_N; l += WG)
+                slab[(size_t)w * TILE_N + l] = make_float4((float)s_acc[l], (float)s_acc[TILE_N + l], (float)s_acc[2 * TILE_N + l], 0.f);
             __syncthreads();
         } else {
             const int s = tail_start + (w - n_items) * WG + tid;
@@ -692,20 +728,22 @@ __global__ __launch_bounds__(WG) void k_g2p_grad(SimP S, float* fr_cur, float* G
     }
 }
 
-// grid_op.grad (mpm:539): gg_out (d/d v_out) -> gg_in (d/d v_in, d/d mass); re-zeroes g_in, gg_out, flags
-__global__ __launch_bounds__(256) void k_grid_grad(SimP S, float* g_in, float* gg_out, float4* gg_in,
-                                                   const int* __restrict__ blk_list, const int* __restrict__ blk_count,
-                                                   int* blk_flag) {
+// grid_op.grad (mpm:539): d/d v_out (slabs of k_g2p_grad + slow-path atomics in gg_out) -> gg_in (d/d v_in, d/d mass);
+// re-zeroes g_in, gg_out and the dynamic flags
+__global__ __launch_bounds__(256) void k_grid_grad(SimP S, TableP T, const float4* __restrict__ slab, float* g_in, float* gg_out, float4* gg_in,
+                                                   const int* __restrict__ blk_list, const int* __restrict__ blk_count, int* blk_flag) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int cnt = *blk_count;
+    const int n_static = T.meta[2], cnt = n_static + *blk_count;
     for (int e = blockIdx.x * 4 + wave; e < cnt; e += gridDim.x * 4) {
-        const int b = blk_list[e];
+        bool is_static;
+        const int b = grid_entry(T, blk_list, e, n_static, is_static);
         const int c = (b << 6) | lane;
-        const float4 gi = make_float4(g_in[c], g_in[S.ncell + c], g_in[2 * S.ncell + c], g_in[3 * S.ncell + c]);
-        const float4 go = make_float4(gg_out[c], gg_out[S.ncell + c], gg_out[2 * S.ncell + c], 0.f);
+        const int bi = b / (S.nb * S.nb), bj = (b / S.nb) % S.nb, bk = b % S.nb;
+        const float4 gi = make_float4(g_in[c], g_in[S.ncell + c], g_in[2 * S.ncell + c], g_in[3 * S.ncell + c]);   // total (p, m) kept by k_grid<true>
+        float4 go = make_float4(gg_out[c], gg_out[S.ncell + c], gg_out[2 * S.ncell + c], 0.f);
+        if (is_static) { const float4 t = gather_slabs(S, T, slab, bi, bj, bk, lane); go.x += t.x; go.y += t.y; go.z += t.z; }
         float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
         if (gi.w > FE_EPS) {
-            const int bi = b / (S.nb * S.nb), bj = (b / S.nb) % S.nb, bk = b % S.nb;
             float vo[3], kmul[3];
             node_velocity(S, gi, bi * 4 + (lane >> 4), bj * 4 + ((lane >> 2) & 3), bk * 4 + (lane & 3), vo, kmul);
             float inv = 1.f / gi.w;
@@ -716,7 +754,7 @@ __global__ __launch_bounds__(256) void k_grid_grad(SimP S, float* g_in, float* g
         gg_in[c] = out;
         g_in[c] = 0.f; g_in[S.ncell + c] = 0.f; g_in[2 * S.ncell + c] = 0.f; g_in[3 * S.ncell + c] = 0.f;
         gg_out[c] = 0.f; gg_out[S.ncell + c] = 0.f; gg_out[2 * S.ncell + c] = 0.f;
-        if (lane == 0) blk_flag[b] = 0;
+        if (lane == 0 && !is_static) blk_flag[b] = 0;
     }
 }
 
@@ -969,7 +1007,7 @@ __global__ __launch_bounds__(256) void k_scan_partial(int ncell, int ITEM_MAX, c
     if (tid == 0) partial[blockIdx.x] = make_int2(tp, ti);
 }
 
-__global__ __launch_bounds__(256) void k_scan_final(int ncell, int ITEM_MAX, int* cnt, const int2* __restrict__ partial, int* start, int4* items, int* meta) {
+__global__ __launch_bounds__(256) void k_scan_final(int ncell, int ITEM_MAX, int* cnt, const int2* __restrict__ partial, int* start, int4* items, int* meta, int* blk_first) {
     __shared__ int sh[4];
     __shared__ int sh_sum[256];
     __shared__ int sh_bp[256];
@@ -987,8 +1025,9 @@ __global__ __launch_bounds__(256) void k_scan_final(int ncell, int ITEM_MAX, int
     int bi = base_i + wg_scan_excl(si, sh, tid, toti);
     sh_bp[tid] = bp;
     __syncthreads();
-    if (tid < 16 && blk_cnt > 0) {                            // the items of block wg*16+tid: slots [bstart, bstart+blk_cnt)
+    if (tid < 16 && blockIdx.x * 16 + tid < ncell / 64) {     // the items of block wg*16+tid: slots [bstart, bstart+blk_cnt)
         const int blk = blockIdx.x * 16 + tid, bstart = sh_bp[tid * 16];
+        blk_first[blk] = blk_cnt > 0 ? bi : -1;
         for (int o = 0; o < blk_cnt; o += ITEM_MAX) items[bi++] = make_int4(blk, bstart + o, min(ITEM_MAX, blk_cnt - o), 0);
     }
     const int b0 = blockIdx.x * 1024 + tid * 4;
@@ -1001,7 +1040,27 @@ __global__ __launch_bounds__(256) void k_scan_final(int ncell, int ITEM_MAX, int
         bp += c[q];
         cnt[b] = 0;                                           // ready for the next sort
     }
-    if (blockIdx.x == gridDim.x - 1 && tid == 0) meta[0] = base_i + toti;
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) { meta[0] = base_i + toti; meta[2] = 0; }
+}
+
+// the order's static active list: every block within one block of an occupied block (= every block some tile reaches)
+__global__ __launch_bounds__(256) void k_build_active(int nb, const int4* __restrict__ items, int* meta, int* blk_flag, int* active) {
+    const int n_items = meta[0];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += gridDim.x * blockDim.x) {
+        const int b = items[i].x;
+        if (i > 0 && items[i - 1].x == b) continue;           // first item of its block only
+        const int bi = b / (nb * nb), bj = (b / nb) % nb, bk = b % nb;
+        for (int di = -1; di <= 1; di++) for (int dj = -1; dj <= 1; dj++) for (int dk = -1; dk <= 1; dk++) {
+            const int i2 = bi + di, j2 = bj + dj, k2 = bk + dk;
+            if ((unsigned)i2 >= (unsigned)nb || (unsigned)j2 >= (unsigned)nb || (unsigned)k2 >= (unsigned)nb) continue;
+            const int n2 = (i2 * nb + j2) * nb + k2;
+            if (atomicCAS(&blk_flag[n2], 0, 2) == 0) active[atomicAdd(&meta[2], 1)] = n2;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_set_static(const int* __restrict__ active, const int* __restrict__ meta, int* blk_flag, int value) {
+    const int n = meta[2];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) blk_flag[active[i]] = value;
 }
 
 __global__ __launch_bounds__(256) void k_sort_perm(int N, const int* __restrict__ key, const int* __restrict__ rank,
@@ -1225,7 +1284,9 @@ struct FeEngine {
     float* grads = nullptr;                                 // 3 x (GR_WORDS*Np + Np) floats: ring of two + 1 spare
     float* grad_ptr[3] = {nullptr, nullptr, nullptr};
     // particle orders ("tables"): id 0 = identity; id 1+f = order produced by the sort at frame f
-    struct Table { int* pid = nullptr; int4* items = nullptr; int* meta = nullptr; };
+    struct Table { int* pid = nullptr; int4* items = nullptr; int* meta = nullptr; int* blk_first = nullptr; int* active = nullptr; };
+    int static_table = -1;                                  // order whose active list is currently flagged 2 in blk_flag
+    float4* slab = nullptr;                                 // one 512-node float4 tile per work item (scatter hand-over)
     std::vector<Table> tables;
     std::vector<int> tbl_of_frame;                          // [L+1]
     int gtbl[2] = {-1, -1};                                 // order of each adjoint ring slot; -1 = all zero
@@ -1235,6 +1296,7 @@ struct FeEngine {
     size_t items_cap = 0;
     int *sort_key = nullptr, *sort_rank = nullptr, *sort_cnt = nullptr, *sort_start = nullptr, *sort_src = nullptr, *sort_pid = nullptr;
     int* slow_dev = nullptr;
+    unsigned long long* ts_dev = nullptr;                   // dbg&8: per-workgroup phase timestamps of k_p2g (8 x 4096)
     int2* sort_partial = nullptr;
     float4* pinfo = nullptr; int* pool_idx = nullptr;
     std::vector<int> mat_host;
@@ -1259,7 +1321,7 @@ struct FeEngine {
     float*& spare_frame() { return frame_ptr[L + 1]; }
     float* grad(int f) { return grad_ptr[f & 1]; }
     size_t grad_words() const { return (size_t)GR_WORDS * Np + Np; }
-    TableP tableP(int id) const { TableP t; t.pid_of_slot = tables[id].pid; t.items = tables[id].items; t.meta = tables[id].meta; return t; }
+    TableP tableP(int id) const { TableP t; t.pid_of_slot = tables[id].pid; t.items = tables[id].items; t.meta = tables[id].meta; t.blk_first = tables[id].blk_first; t.active = tables[id].active; return t; }
     const int* pid_of(int f) const { return tables[tbl_of_frame[f]].pid; }
 };
 
@@ -1355,7 +1417,9 @@ int ensure_table(FeEngine* h, int id) {
     if ((int)h->tables.size() <= id) h->tables.resize(id + 1);
     FeEngine::Table& t = h->tables[id];
     if (t.pid) return 0;
-    if (dev_alloc(h, &t.pid, h->Np) || dev_alloc(h, &t.items, h->items_cap) || dev_alloc(h, &t.meta, 4)) return 1;
+    const size_t nblk = (size_t)h->nb * h->nb * h->nb;
+    if (dev_alloc(h, &t.pid, h->Np) || dev_alloc(h, &t.items, h->items_cap) || dev_alloc(h, &t.meta, 4) ||
+        dev_alloc(h, &t.blk_first, nblk) || dev_alloc(h, &t.active, nblk)) return 1;
     return 0;
 }
 
@@ -1384,6 +1448,15 @@ int grad_order_for_frame(FeEngine* h, int f) {
     return reorder_grad(h, f & 1, t);
 }
 
+// blk_flag carries the value 2 on the active list of exactly one order; switch it when another order is used
+int use_static_table(FeEngine* h, int id) {
+    if (h->static_table == id) return 0;
+    if (h->static_table > 0) { FeEngine::Table& o = h->tables[h->static_table]; hipLaunchKernelGGL(k_set_static, dim3(64), dim3(256), 0, h->stream, o.active, o.meta, h->blk_flag, 0); }
+    if (id > 0) { FeEngine::Table& n = h->tables[id]; hipLaunchKernelGGL(k_set_static, dim3(64), dim3(256), 0, h->stream, n.active, n.meta, h->blk_flag, 2); }
+    h->static_table = id;
+    return 0;
+}
+
 // counting sort of frame f by 4^3 block; the new order becomes table 1+f
 int sort_frame(FeEngine* h, int f) {
     const int id_new = 1 + f, id_old = h->tbl_of_frame[f];
@@ -1393,10 +1466,13 @@ int sort_frame(FeEngine* h, int f) {
     FeEngine::Table& tn = h->tables[id_new];
     const int ncell = h->S.ncell;
     prof_begin(h, KID_SORT);
+    use_static_table(h, 0);                          // un-flag the previous order before its lists are rebuilt
     hipLaunchKernelGGL(k_sort_count, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->sort_key, h->sort_rank, h->sort_cnt);
     const int scan_wgs = (ncell + 1 + 1023) / 1024;
     hipLaunchKernelGGL(k_scan_partial, dim3(scan_wgs), dim3(256), 0, h->stream, ncell, h->item_max, h->sort_cnt, h->sort_partial);
-    hipLaunchKernelGGL(k_scan_final, dim3(scan_wgs), dim3(256), 0, h->stream, ncell, h->item_max, h->sort_cnt, h->sort_partial, h->sort_start, tn.items, tn.meta);
+    hipLaunchKernelGGL(k_scan_final, dim3(scan_wgs), dim3(256), 0, h->stream, ncell, h->item_max, h->sort_cnt, h->sort_partial, h->sort_start, tn.items, tn.meta, tn.blk_first);
+    hipLaunchKernelGGL(k_build_active, dim3(16), dim3(256), 0, h->stream, h->nb, tn.items, tn.meta, h->blk_flag, tn.active);
+    h->static_table = id_new;
     hipLaunchKernelGGL(k_sort_perm, pgrid(h), dim3(256), 0, h->stream, h->N, h->sort_key, h->sort_rank, h->sort_start,
                        h->tables[id_old].pid, h->sort_src, h->sort_pid);
     HIPCK(h, hipMemcpyAsync(tn.pid, h->sort_pid, sizeof(int) * h->Np, hipMemcpyDeviceToDevice, h->stream));
@@ -1408,7 +1484,7 @@ int sort_frame(FeEngine* h, int f) {
 }
 
 GridW grid_w(FeEngine* h) {
-    GridW g; g.g_in = h->g_in; g.ncell = h->S.ncell; g.blk_flag = h->blk_flag; g.blk_list = h->blk_list; g.blk_count = h->blk_count; g.err = h->err_dev; g.slow = h->slow_dev;
+    GridW g; g.g_in = h->g_in; g.slab = h->slab; g.ncell = h->S.ncell; g.ts = h->ts_dev; g.blk_flag = h->blk_flag; g.blk_list = h->blk_list; g.blk_count = h->blk_count; g.err = h->err_dev; g.slow = h->slow_dev;
     return g;
 }
 
@@ -1417,6 +1493,7 @@ int substep_fwd(FeEngine* h, int f, int f_global, int act) {
     if (make_inject(h, f, f_global, act, true, inj)) return 1;
     if (h->sort_interval > 0 && f % h->sort_interval == 0 && sort_frame(h, f)) return 1;
     h->tbl_of_frame[f + 1] = h->tbl_of_frame[f];        // a substep keeps the slot order
+    use_static_table(h, h->tbl_of_frame[f]);
     const TableP T = h->tableP(h->tbl_of_frame[f]);
     AgentP ag = agent_params(h);
     prof_begin(h, KID_P2G);
@@ -1428,7 +1505,7 @@ int substep_fwd(FeEngine* h, int f, int f_global, int act) {
                            h->pinfo, h->pool_idx, grid_w(h), ag, inj, act, f);
     prof_end(h);
     prof_begin(h, KID_GRID);
-    hipLaunchKernelGGL(k_grid<false>, ggrid(h), dim3(256), 0, h->stream, h->S, h->g_in, h->g_out, h->blk_list, h->blk_count, h->blk_flag);
+    hipLaunchKernelGGL(k_grid<false>, ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, h->g_out, h->blk_list, h->blk_count, h->blk_flag);
     prof_end(h);
     prof_begin(h, KID_G2P);
     hipLaunchKernelGGL(k_g2p, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T, h->g_out, h->blk_count, h->slow_dev);
@@ -1442,6 +1519,7 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act) {
     // grad[f+1] arrives in the order frame f+1 is stored in; substep f works in frame f's order
     const int t = h->tbl_of_frame[f];
     if (reorder_grad(h, (f + 1) & 1, t)) return 1;
+    use_static_table(h, t);
     const TableP T = h->tableP(t);
     AgentP ag = agent_params(h);
     InjectP noinj = {0, 0, 0, 0};
@@ -1454,13 +1532,13 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act) {
                            h->pinfo, h->pool_idx, grid_w(h), ag, noinj, 0, f);
     prof_end(h);
     prof_begin(h, KID_GRID_KEEP);
-    hipLaunchKernelGGL(k_grid<true>, ggrid(h), dim3(256), 0, h->stream, h->S, h->g_in, h->g_out, h->blk_list, h->blk_count, h->blk_flag);
+    hipLaunchKernelGGL(k_grid<true>, ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, h->g_out, h->blk_list, h->blk_count, h->blk_flag);
     prof_end(h);
     prof_begin(h, KID_G2P_GRAD);
-    hipLaunchKernelGGL(k_g2p_grad, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slow_dev);
+    hipLaunchKernelGGL(k_g2p_grad, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev);
     prof_end(h);
     prof_begin(h, KID_GRID_GRAD);
-    hipLaunchKernelGGL(k_grid_grad, ggrid(h), dim3(256), 0, h->stream, h->S, h->g_in, h->gg_out, h->gg_in, h->blk_list, h->blk_count, h->blk_flag);
+    hipLaunchKernelGGL(k_grid_grad, ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, h->gg_out, h->gg_in, h->blk_list, h->blk_count, h->blk_flag);
     prof_end(h);
     prof_begin(h, KID_P2G_GRAD);
 #define LAUNCH_P2G_GRAD(G, W) hipLaunchKernelGGL((k_p2g_grad<G, W>), wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), \
@@ -1566,7 +1644,7 @@ FeEngine* fe_create(const FeConfig* cfg) {
         h->items_cap = (nblk < (size_t)h->Np ? nblk : (size_t)h->Np) + (size_t)h->Np / 64 + 2;      // item_max >= 64
         if (dev_alloc(h, &h->sort_key, h->Np) || dev_alloc(h, &h->sort_rank, h->Np) || dev_alloc(h, &h->sort_cnt, ncell + 1) ||
             dev_alloc(h, &h->sort_start, ncell + 1) || dev_alloc(h, &h->sort_src, h->Np) || dev_alloc(h, &h->sort_pid, h->Np) ||
-            dev_alloc(h, &h->slow_dev, 1) || dev_alloc(h, &h->sort_partial, (ncell + 1 + 1023) / 1024 + 1)) return fail("");
+            dev_alloc(h, &h->slow_dev, 1) || dev_alloc(h, &h->slab, h->items_cap * TILE_N, false) || dev_alloc(h, &h->ts_dev, 8 * 4096) || dev_alloc(h, &h->sort_partial, (ncell + 1 + 1023) / 1024 + 1)) return fail("");
     }
     if (dev_alloc(h, &h->effs_dev, FE_MAX_EFF)) return fail("");
     if (ensure_table(h, 0)) return fail("");                 // identity order: no items, everything is "tail"
@@ -1589,8 +1667,8 @@ void fe_destroy(FeEngine* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    for (auto& t : h->tables) { if (t.pid) (void)hipFree(t.pid); if (t.items) (void)hipFree(t.items); if (t.meta) (void)hipFree(t.meta); }
-    void* ptrs[] = {h->frames, h->grads, h->sort_key, h->sort_rank, h->sort_cnt, h->sort_start, h->sort_src, h->sort_pid, h->slow_dev, h->sort_partial, h->effs_dev, h->pinfo, h->pool_idx, h->g_in, h->g_out, h->gg_out, h->gg_in,
+    for (auto& t : h->tables) { for (void* q : {(void*)t.pid, (void*)t.items, (void*)t.meta, (void*)t.blk_first, (void*)t.active}) if (q) (void)hipFree(q); }
+    void* ptrs[] = {h->frames, h->grads, h->sort_key, h->sort_rank, h->sort_cnt, h->sort_start, h->sort_src, h->sort_pid, h->slow_dev, h->slab, h->ts_dev, h->sort_partial, h->effs_dev, h->pinfo, h->pool_idx, h->g_in, h->g_out, h->gg_out, h->gg_in,
                     h->blk_flag, h->blk_list, h->blk_count, h->err_dev, h->stage_r, h->stage_i, h->node_mark, h->counters,
                     h->tgt, h->chamfer, h->step_loss};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -1949,6 +2027,13 @@ int fe_get_stats(FeEngine* h, int f, FeStats* out) {
     out->n_used = (long long)c[0]; out->n_cells_touched = (long long)c[1]; out->n_blocks_active = (long long)c[2];
     out->n_slow_path = slow; out->bytes_state = (long long)h->bytes;
     return check_async(h);
+}
+// debug only (not part of include/fluidengine.h): phase timestamps written by k_p2g when option dbg & 8
+int fe_debug_timestamps(FeEngine* h, unsigned long long* out, int n) {
+    if (n > 8 * 4096) n = 8 * 4096;
+    HIPCK(h, hipMemcpyAsync(out, h->ts_dev, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    return 0;
 }
 int fe_timer_start(FeEngine* h) { HIPCK(h, hipEventRecord(h->ev_t0, h->stream)); return 0; }
 double fe_timer_stop_ms(FeEngine* h) {
