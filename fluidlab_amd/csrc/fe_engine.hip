@@ -202,8 +202,9 @@ struct TableP {
     const int*  pid_of_slot;   // [Np]
     const int4* items;         // (block, start, count, 0), sorted by block
     const int*  meta;          // meta[0] = n_items, meta[1] = tail_start, meta[2] = n_active
-    const int*  blk_first;     // [nblk] first item of a block or -1
+    const int2* blk_first;     // [nblk] (first item, item count) of a block
     const int*  active;        // blocks within one block of an occupied block: every block a tile can reach
+    const int*  blk_slot;      // [nblk] index of a block in `active`, or -1
 };
 
 struct TileO { int ox, oy, oz; };
@@ -238,6 +239,10 @@ __device__ void effector_move(const EffP& e, int f) {
     quat_mul(qw, q, qo);
     e.quat[(f + 1) * 4] = qo[0]; e.quat[(f + 1) * 4 + 1] = qo[1]; e.quat[(f + 1) * 4 + 2] = qo[2]; e.quat[(f + 1) * 4 + 3] = qo[3];
 }
+
+// Per-frame store of the forward grid (summed (p, m) and v_out of every static active block), so that the backward
+// pass can skip the recompute of P2G + grid_op when the frame had no slow-path particle (gs_flag[f] == 1).
+struct GridStore { float4* data; int* flag; int cap; };      // data: [(L+1) * cap * 128] float4, 64 (p,m) then 64 v_out per block
 
 struct GridW {            // everything a scattering particle needs of the global grid
     float* g_in; float4* slab; int ncell; unsigned long long* ts; int* blk_flag; int* blk_list; int* blk_count; int* err; int* slow;
@@ -366,7 +371,9 @@ __device__ __forceinline__ void p2g_scatter_tile(const SimP& S, const P2GPrep& q
 // on one thread, Effector.move_kernel.  WRITE=false is the backward pass' recompute of grid[f]: scatter only.
 template <bool WRITE, bool GENERAL>
 __global__ __launch_bounds__(WG) void k_p2g(SimP S, float* fr_cur, float* fr_next, TableP T, const float4* __restrict__ pinfo,
-                                            const int* __restrict__ pool_idx, GridW G, AgentP agent, InjectP inj, int act, int f) {
+                                            const int* __restrict__ pool_idx, GridW G, AgentP agent, InjectP inj, int act, int f,
+                                            GridStore GS) {
+    if (!WRITE && GS.cap > 0 && GS.flag[f]) return;      // backward: grid[f] was stored by the forward pass
     const int tid = threadIdx.x;
     if (WRITE && blockIdx.x == 0 && tid == 0 && act) {
         for (int i = 0; i < agent.n; i++) effector_move(agent.e[i], f);
@@ -442,31 +449,32 @@ __device__ __forceinline__ void node_velocity(const SimP& S, const float4 gi, in
 // Sum, for node (oi,oj,ok) of block b, what the work items' tiles deposited there.  A tile of block B' covers the
 // nodes [4B'-1, 4B'+7) per axis, so a node with in-block offset o receives from B'=B (tile index o+1) and from
 // B'=B-1 (index o+5) when o <= 2, or B'=B+1 (index 0) when o == 3: 8 source blocks, visited in a fixed order
-// (deterministic sums).  `slab` holds one 512-node float4 tile per item.
+// (deterministic sums).  `slab` holds one 512-node float4 tile per item.  The item ranges of the 27 neighbour
+// blocks are fetched once per wave (lane n < 27 loads neighbour n) and handed out by cross-lane reads, so a
+// lane's critical path is two dependent memory round trips: range -> slab values.
 __device__ __forceinline__ float4 gather_slabs(const SimP& S, const TableP& T, const float4* __restrict__ slab, int bi, int bj, int bk, int lane) {
+    int2 mine = make_int2(0, 0);
+    if (lane < 27) {
+        const int i2 = bi + lane / 9 - 1, j2 = bj + (lane / 3) % 3 - 1, k2 = bk + lane % 3 - 1;
+        if ((unsigned)i2 < (unsigned)S.nb && (unsigned)j2 < (unsigned)S.nb && (unsigned)k2 < (unsigned)S.nb)
+            mine = T.blk_first[(i2 * S.nb + j2) * S.nb + k2];
+    }
     const int o[3] = {lane >> 4, (lane >> 2) & 3, lane & 3};
-    const int bc[3] = {bi, bj, bk};
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int n_items = T.meta[0];
 #pragma unroll
     for (int c = 0; c < 8; c++) {
-        int sb[3], ti[3];
-        bool ok = true;
+        int nbr = 0, tidx = 0;                      // neighbour code (di+1)*9 + (dj+1)*3 + (dk+1), tile index
 #pragma unroll
         for (int d = 0; d < 3; d++) {
             const bool other = (c >> d) & 1;
             const int delta = other ? (o[d] == 3 ? 1 : -1) : 0;
-            sb[d] = bc[d] + delta;
-            ti[d] = other ? (o[d] == 3 ? 0 : o[d] + 5) : o[d] + 1;
-            ok = ok && (unsigned)sb[d] < (unsigned)S.nb;
+            const int ti = other ? (o[d] == 3 ? 0 : o[d] + 5) : o[d] + 1;
+            nbr = nbr * 3 + delta + 1;
+            tidx = tidx * TILE_T + ti;
         }
-        if (!ok) continue;
-        const int src = (sb[0] * S.nb + sb[1]) * S.nb + sb[2];
-        const int tidx = (ti[0] * TILE_T + ti[1]) * TILE_T + ti[2];
-        int it = T.blk_first[src];
-        if (it < 0) continue;
-        for (; it < n_items && T.items[it].x == src; it++) {
-            const float4 v = slab[(size_t)it * TILE_N + tidx];
+        const int first = __shfl(mine.x, nbr, 64), count = __shfl(mine.y, nbr, 64);
+        for (int k = 0; k < count; k++) {
+            const float4 v = slab[(size_t)(first + k) * TILE_N + tidx];
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
     }
@@ -484,9 +492,12 @@ __device__ __forceinline__ int grid_entry(const TableP& T, const int* __restrict
 // (mpm:219-223) is needed.  KEEP=true (backward recompute): stores the summed (p, m) in g_in for grid_grad.
 template <bool KEEP>
 __global__ __launch_bounds__(256) void k_grid(SimP S, TableP T, const float4* __restrict__ slab, float* g_in, float4* g_out,
-                                              const int* __restrict__ blk_list, const int* __restrict__ blk_count, int* blk_flag) {
+                                              const int* __restrict__ blk_list, const int* __restrict__ blk_count, int* blk_flag,
+                                              GridStore GS, int f) {
+    if (KEEP && GS.cap > 0 && GS.flag[f]) return;        // backward: stored by the forward pass
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n_static = T.meta[2], cnt = n_static + *blk_count;
+    if (!KEEP && GS.cap > 0 && blockIdx.x == 0 && threadIdx.x == 0) GS.flag[f] = (n_static <= GS.cap && *blk_count == 0) ? 1 : 0;
     for (int e = blockIdx.x * 4 + wave; e < cnt; e += gridDim.x * 4) {
         bool is_static;
         const int b = grid_entry(T, blk_list, e, n_static, is_static);
@@ -502,6 +513,10 @@ __global__ __launch_bounds__(256) void k_grid(SimP S, TableP T, const float4* __
         }
         g_out[c] = out;
         if (!KEEP) {
+            if (is_static && e < GS.cap) {
+                float4* dst = GS.data + ((size_t)f * GS.cap + e) * 128;
+                dst[lane] = gi; dst[64 + lane] = out;
+            }
             g_in[c] = 0.f; g_in[S.ncell + c] = 0.f; g_in[2 * S.ncell + c] = 0.f; g_in[3 * S.ncell + c] = 0.f;
             if (lane == 0 && !is_static) blk_flag[b] = 0;
         } else {
@@ -553,6 +568,18 @@ __device__ __forceinline__ void load_tile3(const TileO& to, const SimP& S, const
         int i, j, k;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (tile_node(to, l, S.n, i, j, k)) v = src[cell_addr(i, j, k, S.nb)];
+        s_tile[l] = v.x; s_tile[TILE_N + l] = v.y; s_tile[2 * TILE_N + l] = v.z;
+    }
+}
+// same, reading v_out of frame f from the grid store (blocks addressed through the order's blk_slot)
+__device__ __forceinline__ void load_tile3_store(const TileO& to, const SimP& S, const TableP& T, const float4* __restrict__ st, int tid) {
+    for (int l = tid; l < TILE_N; l += WG) {
+        int i, j, k;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tile_node(to, l, S.n, i, j, k)) {
+            const int slot = T.blk_slot[(((i >> 2) * S.nb) + (j >> 2)) * S.nb + (k >> 2)];
+            if (slot >= 0) v = st[(size_t)slot * 128 + 64 + (((i & 3) << 4) | ((j & 3) << 2) | (k & 3))];
+        }
         s_tile[l] = v.x; s_tile[TILE_N + l] = v.y; s_tile[2 * TILE_N + l] = v.z;
     }
 }
@@ -687,8 +714,10 @@ __device__ __forceinline__ void g2p_grad_slot_global(const SimP& S, const FrameV
 }
 
 __global__ __launch_bounds__(WG) void k_g2p_grad(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T,
-                                                 const float4* __restrict__ g_out, float* gg_out, float4* slab, int* slow) {
+                                                 const float4* __restrict__ g_out, float* gg_out, float4* slab, int* slow,
+                                                 GridStore GS, int f) {
     const int tid = threadIdx.x;
+    const bool stored = GS.cap > 0 && GS.flag[f];
     FrameV cur = frame_view(fr_cur, S.Np);
     FrameV Gn = frame_view(Gn_, S.Np), Gc = frame_view(Gc_, S.Np);
     const int n_items = T.meta[0], tail_start = T.meta[1];
@@ -697,7 +726,7 @@ __global__ __launch_bounds__(WG) void k_g2p_grad(SimP S, float* fr_cur, float* G
         if (w < n_items) {
             const int4 it = T.items[w];
             const TileO to = tile_origin(it.x, S.nb);
-            load_tile3(to, S, g_out, tid);
+            if (stored) load_tile3_store(to, S, T, GS.data + (size_t)f * GS.cap * 128, tid); else load_tile3(to, S, g_out, tid);
             for (int l = tid; l < 3 * TILE_N; l += WG) s_acc[l] = 0.0;
             __syncthreads();
             for (int i0 = 0; i0 < it.z; i0 += WG) {              // uniform trip count: the DPP scan needs every lane
@@ -731,15 +760,19 @@ __global__ __launch_bounds__(WG) void k_g2p_grad(SimP S, float* fr_cur, float* G
 // grid_op.grad (mpm:539): d/d v_out (slabs of k_g2p_grad + slow-path atomics in gg_out) -> gg_in (d/d v_in, d/d mass);
 // re-zeroes g_in, gg_out and the dynamic flags
 __global__ __launch_bounds__(256) void k_grid_grad(SimP S, TableP T, const float4* __restrict__ slab, float* g_in, float* gg_out, float4* gg_in,
-                                                   const int* __restrict__ blk_list, const int* __restrict__ blk_count, int* blk_flag) {
+                                                   const int* __restrict__ blk_list, const int* __restrict__ blk_count, int* blk_flag,
+                                                   GridStore GS, int f) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n_static = T.meta[2], cnt = n_static + *blk_count;
+    const bool stored = GS.cap > 0 && GS.flag[f];
     for (int e = blockIdx.x * 4 + wave; e < cnt; e += gridDim.x * 4) {
         bool is_static;
         const int b = grid_entry(T, blk_list, e, n_static, is_static);
         const int c = (b << 6) | lane;
         const int bi = b / (S.nb * S.nb), bj = (b / S.nb) % S.nb, bk = b % S.nb;
-        const float4 gi = make_float4(g_in[c], g_in[S.ncell + c], g_in[2 * S.ncell + c], g_in[3 * S.ncell + c]);   // total (p, m) kept by k_grid<true>
+        // total (p, m): from the forward pass' store, or kept in g_in by k_grid<true>
+        const float4 gi = stored ? GS.data[((size_t)f * GS.cap + e) * 128 + lane]
+                                 : make_float4(g_in[c], g_in[S.ncell + c], g_in[2 * S.ncell + c], g_in[3 * S.ncell + c]);
         float4 go = make_float4(gg_out[c], gg_out[S.ncell + c], gg_out[2 * S.ncell + c], 0.f);
         if (is_static) { const float4 t = gather_slabs(S, T, slab, bi, bj, bk, lane); go.x += t.x; go.y += t.y; go.z += t.z; }
         float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1007,7 +1040,7 @@ __global__ __launch_bounds__(256) void k_scan_partial(int ncell, int ITEM_MAX, c
     if (tid == 0) partial[blockIdx.x] = make_int2(tp, ti);
 }
 
-__global__ __launch_bounds__(256) void k_scan_final(int ncell, int ITEM_MAX, int* cnt, const int2* __restrict__ partial, int* start, int4* items, int* meta, int* blk_first) {
+__global__ __launch_bounds__(256) void k_scan_final(int ncell, int ITEM_MAX, int* cnt, const int2* __restrict__ partial, int* start, int4* items, int* meta, int2* blk_first) {
     __shared__ int sh[4];
     __shared__ int sh_sum[256];
     __shared__ int sh_bp[256];
@@ -1027,7 +1060,7 @@ __global__ __launch_bounds__(256) void k_scan_final(int ncell, int ITEM_MAX, int
     __syncthreads();
     if (tid < 16 && blockIdx.x * 16 + tid < ncell / 64) {     // the items of block wg*16+tid: slots [bstart, bstart+blk_cnt)
         const int blk = blockIdx.x * 16 + tid, bstart = sh_bp[tid * 16];
-        blk_first[blk] = blk_cnt > 0 ? bi : -1;
+        blk_first[blk] = make_int2(bi, (blk_cnt + ITEM_MAX - 1) / ITEM_MAX);
         for (int o = 0; o < blk_cnt; o += ITEM_MAX) items[bi++] = make_int4(blk, bstart + o, min(ITEM_MAX, blk_cnt - o), 0);
     }
     const int b0 = blockIdx.x * 1024 + tid * 4;
@@ -1044,7 +1077,7 @@ __global__ __launch_bounds__(256) void k_scan_final(int ncell, int ITEM_MAX, int
 }
 
 // the order's static active list: every block within one block of an occupied block (= every block some tile reaches)
-__global__ __launch_bounds__(256) void k_build_active(int nb, const int4* __restrict__ items, int* meta, int* blk_flag, int* active) {
+__global__ __launch_bounds__(256) void k_build_active(int nb, const int4* __restrict__ items, int* meta, int* blk_flag, int* active, int* blk_slot) {
     const int n_items = meta[0];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += gridDim.x * blockDim.x) {
         const int b = items[i].x;
@@ -1054,9 +1087,13 @@ __global__ __launch_bounds__(256) void k_build_active(int nb, const int4* __rest
             const int i2 = bi + di, j2 = bj + dj, k2 = bk + dk;
             if ((unsigned)i2 >= (unsigned)nb || (unsigned)j2 >= (unsigned)nb || (unsigned)k2 >= (unsigned)nb) continue;
             const int n2 = (i2 * nb + j2) * nb + k2;
-            if (atomicCAS(&blk_flag[n2], 0, 2) == 0) active[atomicAdd(&meta[2], 1)] = n2;
+            if (atomicCAS(&blk_flag[n2], 0, 2) == 0) { const int e = atomicAdd(&meta[2], 1); active[e] = n2; blk_slot[n2] = e; }
         }
     }
+}
+__global__ __launch_bounds__(256) void k_clear_slots(const int* __restrict__ active, const int* __restrict__ meta, int* blk_slot) {
+    const int n = meta[2];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) blk_slot[active[i]] = -1;
 }
 __global__ __launch_bounds__(256) void k_set_static(const int* __restrict__ active, const int* __restrict__ meta, int* blk_flag, int value) {
     const int n = meta[2];
@@ -1284,8 +1321,9 @@ struct FeEngine {
     float* grads = nullptr;                                 // 3 x (GR_WORDS*Np + Np) floats: ring of two + 1 spare
     float* grad_ptr[3] = {nullptr, nullptr, nullptr};
     // particle orders ("tables"): id 0 = identity; id 1+f = order produced by the sort at frame f
-    struct Table { int* pid = nullptr; int4* items = nullptr; int* meta = nullptr; int* blk_first = nullptr; int* active = nullptr; };
+    struct Table { int* pid = nullptr; int4* items = nullptr; int* meta = nullptr; int2* blk_first = nullptr; int* active = nullptr; int* blk_slot = nullptr; };
     int static_table = -1;                                  // order whose active list is currently flagged 2 in blk_flag
+    float4* gstore = nullptr; int* gs_flag = nullptr; int gs_cap = 0;     // forward grid store (see GridStore)
     float4* slab = nullptr;                                 // one 512-node float4 tile per work item (scatter hand-over)
     std::vector<Table> tables;
     std::vector<int> tbl_of_frame;                          // [L+1]
@@ -1321,7 +1359,7 @@ struct FeEngine {
     float*& spare_frame() { return frame_ptr[L + 1]; }
     float* grad(int f) { return grad_ptr[f & 1]; }
     size_t grad_words() const { return (size_t)GR_WORDS * Np + Np; }
-    TableP tableP(int id) const { TableP t; t.pid_of_slot = tables[id].pid; t.items = tables[id].items; t.meta = tables[id].meta; t.blk_first = tables[id].blk_first; t.active = tables[id].active; return t; }
+    TableP tableP(int id) const { TableP t; t.pid_of_slot = tables[id].pid; t.items = tables[id].items; t.meta = tables[id].meta; t.blk_first = tables[id].blk_first; t.active = tables[id].active; t.blk_slot = tables[id].blk_slot; return t; }
     const int* pid_of(int f) const { return tables[tbl_of_frame[f]].pid; }
 };
 
@@ -1419,7 +1457,8 @@ int ensure_table(FeEngine* h, int id) {
     if (t.pid) return 0;
     const size_t nblk = (size_t)h->nb * h->nb * h->nb;
     if (dev_alloc(h, &t.pid, h->Np) || dev_alloc(h, &t.items, h->items_cap) || dev_alloc(h, &t.meta, 4) ||
-        dev_alloc(h, &t.blk_first, nblk) || dev_alloc(h, &t.active, nblk)) return 1;
+        dev_alloc(h, &t.blk_first, nblk) || dev_alloc(h, &t.active, nblk) || dev_alloc(h, &t.blk_slot, nblk)) return 1;
+    HIPCK(h, hipMemsetAsync(t.blk_slot, 0xff, sizeof(int) * nblk, h->stream));
     return 0;
 }
 
@@ -1467,11 +1506,12 @@ int sort_frame(FeEngine* h, int f) {
     const int ncell = h->S.ncell;
     prof_begin(h, KID_SORT);
     use_static_table(h, 0);                          // un-flag the previous order before its lists are rebuilt
+    hipLaunchKernelGGL(k_clear_slots, dim3(64), dim3(256), 0, h->stream, tn.active, tn.meta, tn.blk_slot);
     hipLaunchKernelGGL(k_sort_count, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->sort_key, h->sort_rank, h->sort_cnt);
     const int scan_wgs = (ncell + 1 + 1023) / 1024;
     hipLaunchKernelGGL(k_scan_partial, dim3(scan_wgs), dim3(256), 0, h->stream, ncell, h->item_max, h->sort_cnt, h->sort_partial);
     hipLaunchKernelGGL(k_scan_final, dim3(scan_wgs), dim3(256), 0, h->stream, ncell, h->item_max, h->sort_cnt, h->sort_partial, h->sort_start, tn.items, tn.meta, tn.blk_first);
-    hipLaunchKernelGGL(k_build_active, dim3(16), dim3(256), 0, h->stream, h->nb, tn.items, tn.meta, h->blk_flag, tn.active);
+    hipLaunchKernelGGL(k_build_active, dim3(16), dim3(256), 0, h->stream, h->nb, tn.items, tn.meta, h->blk_flag, tn.active, tn.blk_slot);
     h->static_table = id_new;
     hipLaunchKernelGGL(k_sort_perm, pgrid(h), dim3(256), 0, h->stream, h->N, h->sort_key, h->sort_rank, h->sort_start,
                        h->tables[id_old].pid, h->sort_src, h->sort_pid);
@@ -1482,6 +1522,8 @@ int sort_frame(FeEngine* h, int f) {
     h->tbl_of_frame[f] = id_new;
     return 0;
 }
+
+GridStore grid_store(FeEngine* h) { GridStore g; g.data = h->gstore; g.flag = h->gs_flag; g.cap = h->gs_cap; return g; }
 
 GridW grid_w(FeEngine* h) {
     GridW g; g.g_in = h->g_in; g.slab = h->slab; g.ncell = h->S.ncell; g.ts = h->ts_dev; g.blk_flag = h->blk_flag; g.blk_list = h->blk_list; g.blk_count = h->blk_count; g.err = h->err_dev; g.slow = h->slow_dev;
@@ -1499,13 +1541,13 @@ int substep_fwd(FeEngine* h, int f, int f_global, int act) {
     prof_begin(h, KID_P2G);
     if (h->all_simple_liquid)
         hipLaunchKernelGGL((k_p2g<true, false>), wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T,
-                           h->pinfo, h->pool_idx, grid_w(h), ag, inj, act, f);
+                           h->pinfo, h->pool_idx, grid_w(h), ag, inj, act, f, grid_store(h));
     else
         hipLaunchKernelGGL((k_p2g<true, true>), wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T,
-                           h->pinfo, h->pool_idx, grid_w(h), ag, inj, act, f);
+                           h->pinfo, h->pool_idx, grid_w(h), ag, inj, act, f, grid_store(h));
     prof_end(h);
     prof_begin(h, KID_GRID);
-    hipLaunchKernelGGL(k_grid<false>, ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, h->g_out, h->blk_list, h->blk_count, h->blk_flag);
+    hipLaunchKernelGGL(k_grid<false>, ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, h->g_out, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f);
     prof_end(h);
     prof_begin(h, KID_G2P);
     hipLaunchKernelGGL(k_g2p, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T, h->g_out, h->blk_count, h->slow_dev);
@@ -1526,19 +1568,19 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act) {
     prof_begin(h, KID_P2G_RE);
     if (h->all_simple_liquid)
         hipLaunchKernelGGL((k_p2g<false, false>), wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T,
-                           h->pinfo, h->pool_idx, grid_w(h), ag, noinj, 0, f);
+                           h->pinfo, h->pool_idx, grid_w(h), ag, noinj, 0, f, grid_store(h));
     else
         hipLaunchKernelGGL((k_p2g<false, true>), wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T,
-                           h->pinfo, h->pool_idx, grid_w(h), ag, noinj, 0, f);
+                           h->pinfo, h->pool_idx, grid_w(h), ag, noinj, 0, f, grid_store(h));
     prof_end(h);
     prof_begin(h, KID_GRID_KEEP);
-    hipLaunchKernelGGL(k_grid<true>, ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, h->g_out, h->blk_list, h->blk_count, h->blk_flag);
+    hipLaunchKernelGGL(k_grid<true>, ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, h->g_out, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f);
     prof_end(h);
     prof_begin(h, KID_G2P_GRAD);
-    hipLaunchKernelGGL(k_g2p_grad, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev);
+    hipLaunchKernelGGL(k_g2p_grad, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev, grid_store(h), f);
     prof_end(h);
     prof_begin(h, KID_GRID_GRAD);
-    hipLaunchKernelGGL(k_grid_grad, ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, h->gg_out, h->gg_in, h->blk_list, h->blk_count, h->blk_flag);
+    hipLaunchKernelGGL(k_grid_grad, ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, h->gg_out, h->gg_in, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f);
     prof_end(h);
     prof_begin(h, KID_P2G_GRAD);
 #define LAUNCH_P2G_GRAD(G, W) hipLaunchKernelGGL((k_p2g_grad<G, W>), wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), \
@@ -1647,6 +1689,13 @@ FeEngine* fe_create(const FeConfig* cfg) {
             dev_alloc(h, &h->slow_dev, 1) || dev_alloc(h, &h->slab, h->items_cap * TILE_N, false) || dev_alloc(h, &h->ts_dev, 8 * 4096) || dev_alloc(h, &h->sort_partial, (ncell + 1 + 1023) / 1024 + 1)) return fail("");
     }
     if (dev_alloc(h, &h->effs_dev, FE_MAX_EFF)) return fail("");
+    {   // forward grid store: cap blocks per frame, 2 KiB each; bounded to 64 GiB
+        const size_t nblk = (size_t)h->nb * h->nb * h->nb;
+        size_t cap = nblk < 4096 ? nblk : 4096;
+        while (cap > 0 && (size_t)(h->L + 1) * cap * 2048 > ((size_t)64 << 30)) cap /= 2;
+        h->gs_cap = (int)cap;
+        if (cap > 0 && (dev_alloc(h, &h->gstore, (size_t)(h->L + 1) * cap * 128, false) || dev_alloc(h, &h->gs_flag, h->L + 1))) return fail("");
+    }
     if (ensure_table(h, 0)) return fail("");                 // identity order: no items, everything is "tail"
     if (dev_alloc(h, &h->pinfo, h->Np) || dev_alloc(h, &h->pool_idx, h->Np)) return fail("");
     if (dev_alloc(h, &h->g_in, 4 * ncell) || dev_alloc(h, &h->g_out, ncell) || dev_alloc(h, &h->gg_out, 3 * ncell) || dev_alloc(h, &h->gg_in, ncell)) return fail("");
@@ -1667,8 +1716,8 @@ void fe_destroy(FeEngine* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    for (auto& t : h->tables) { for (void* q : {(void*)t.pid, (void*)t.items, (void*)t.meta, (void*)t.blk_first, (void*)t.active}) if (q) (void)hipFree(q); }
-    void* ptrs[] = {h->frames, h->grads, h->sort_key, h->sort_rank, h->sort_cnt, h->sort_start, h->sort_src, h->sort_pid, h->slow_dev, h->slab, h->ts_dev, h->sort_partial, h->effs_dev, h->pinfo, h->pool_idx, h->g_in, h->g_out, h->gg_out, h->gg_in,
+    for (auto& t : h->tables) { for (void* q : {(void*)t.pid, (void*)t.items, (void*)t.meta, (void*)t.blk_first, (void*)t.active, (void*)t.blk_slot}) if (q) (void)hipFree(q); }
+    void* ptrs[] = {h->frames, h->grads, h->sort_key, h->sort_rank, h->sort_cnt, h->sort_start, h->sort_src, h->sort_pid, h->slow_dev, h->gstore, h->gs_flag, h->slab, h->ts_dev, h->sort_partial, h->effs_dev, h->pinfo, h->pool_idx, h->g_in, h->g_out, h->gg_out, h->gg_in,
                     h->blk_flag, h->blk_list, h->blk_count, h->err_dev, h->stage_r, h->stage_i, h->node_mark, h->counters,
                     h->tgt, h->chamfer, h->step_loss};
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -1700,6 +1749,10 @@ int fe_set_option(FeEngine* h, const char* name, double value) {
     if (!std::strcmp(name, "item_max")) {
         if (value < 64 || value > ITEM_MAX_CAP) FAIL(h, "item_max must be in [64, 512]");
         h->item_max = (int)value;
+        return 0;
+    }
+    if (!std::strcmp(name, "grid_store")) {                  // 0 disables the forward grid store (backward always recomputes)
+        if (value == 0) h->gs_cap = 0;
         return 0;
     }
     if (!std::strcmp(name, "p2g_grad_waves")) { h->p2g_grad_waves = (int)value; return 0; }
@@ -1760,6 +1813,7 @@ int fe_get_frame(FeEngine* h, int f, fe_real* x, fe_real* v, fe_real* C, fe_real
 }
 int fe_set_frame(FeEngine* h, int f, const fe_real* x, const fe_real* v, const fe_real* C, const fe_real* F, const int* used) {
     CHECK_FRAME(h, f);
+    if (h->gs_cap > 0) HIPCK(h, hipMemsetAsync(h->gs_flag + f, 0, sizeof(int), h->stream));     // the stored grid of this frame is stale now
     return upload_planes(h, h->frame(f), h->pid_of(f), x, v, C, F, used, 0);
 }
 int fe_copy_frame(FeEngine* h, int src, int dst) {
@@ -1767,6 +1821,7 @@ int fe_copy_frame(FeEngine* h, int src, int dst) {
     if (src == dst) return 0;
     HIPCK(h, hipMemcpyAsync(h->frame(dst), h->frame(src), sizeof(float) * h->frame_stride, hipMemcpyDeviceToDevice, h->stream));
     h->tbl_of_frame[dst] = h->tbl_of_frame[src];
+    if (h->gs_cap > 0) HIPCK(h, hipMemsetAsync(h->gs_flag + dst, 0, sizeof(int), h->stream));
     return 0;
 }
 int fe_copy_grad(FeEngine* h, int src, int dst) {
