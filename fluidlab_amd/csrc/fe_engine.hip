@@ -245,7 +245,7 @@ __device__ void effector_move(const EffP& e, int f) {
 struct GridStore { float4* data; int* flag; int cap; };      // data: [(L+1) * cap * 128] float4, 64 (p,m) then 64 v_out per block
 
 struct GridW {            // everything a scattering particle needs of the global grid
-    float* g_in; float4* slab; int ncell; unsigned long long* ts; int* blk_flag; int* blk_list; int* blk_count; int* err; int* slow;
+    float* g_in; float4* slab; int ncell; unsigned long long* ts; int* frame_slow; int* blk_flag; int* blk_list; int* blk_count; int* err; int* slow;
 };
 
 // advect_used + process_unused_particles (mpm:304-316) + Injector.act (injector.py:80-105) for one unused slot
@@ -306,6 +306,7 @@ __device__ __forceinline__ void p2g_prepare(const SimP& S, const FrameV& cur, co
 
 // global path: 108 scattered global atomics + active-block marking
 __device__ __forceinline__ void p2g_scatter_global(const SimP& S, const P2GPrep& q, const GridW& G) {
+    *G.frame_slow = 1;                          // this frame's grid cannot be served from the store in the backward pass
     const Stencil& st = q.st;
 #pragma unroll 1
     for (int ij = 0; ij < 9; ij++) {
@@ -493,11 +494,14 @@ __device__ __forceinline__ int grid_entry(const TableP& T, const int* __restrict
 template <bool KEEP>
 __global__ __launch_bounds__(256) void k_grid(SimP S, TableP T, const float4* __restrict__ slab, float* g_in, float4* g_out,
                                               const int* __restrict__ blk_list, const int* __restrict__ blk_count, int* blk_flag,
-                                              GridStore GS, int f) {
+                                              GridStore GS, int f, int* frame_slow) {
     if (KEEP && GS.cap > 0 && GS.flag[f]) return;        // backward: stored by the forward pass
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n_static = T.meta[2], cnt = n_static + *blk_count;
-    if (!KEEP && GS.cap > 0 && blockIdx.x == 0 && threadIdx.x == 0) GS.flag[f] = (n_static <= GS.cap && *blk_count == 0) ? 1 : 0;
+    if (!KEEP && blockIdx.x == 0 && threadIdx.x == 0) {
+        if (GS.cap > 0) GS.flag[f] = (n_static <= GS.cap && *frame_slow == 0) ? 1 : 0;
+        *frame_slow = 0;
+    }
     for (int e = blockIdx.x * 4 + wave; e < cnt; e += gridDim.x * 4) {
         bool is_static;
         const int b = grid_entry(T, blk_list, e, n_static, is_static);
@@ -1334,6 +1338,7 @@ struct FeEngine {
     size_t items_cap = 0;
     int *sort_key = nullptr, *sort_rank = nullptr, *sort_cnt = nullptr, *sort_start = nullptr, *sort_src = nullptr, *sort_pid = nullptr;
     int* slow_dev = nullptr;
+    int* frame_slow_dev = nullptr;                          // set by a slow-path scatter of the current forward substep
     unsigned long long* ts_dev = nullptr;                   // dbg&8: per-workgroup phase timestamps of k_p2g (8 x 4096)
     int2* sort_partial = nullptr;
     float4* pinfo = nullptr; int* pool_idx = nullptr;
@@ -1526,7 +1531,7 @@ int sort_frame(FeEngine* h, int f) {
 GridStore grid_store(FeEngine* h) { GridStore g; g.data = h->gstore; g.flag = h->gs_flag; g.cap = h->gs_cap; return g; }
 
 GridW grid_w(FeEngine* h) {
-    GridW g; g.g_in = h->g_in; g.slab = h->slab; g.ncell = h->S.ncell; g.ts = h->ts_dev; g.blk_flag = h->blk_flag; g.blk_list = h->blk_list; g.blk_count = h->blk_count; g.err = h->err_dev; g.slow = h->slow_dev;
+    GridW g; g.g_in = h->g_in; g.slab = h->slab; g.ncell = h->S.ncell; g.ts = h->ts_dev; g.frame_slow = h->frame_slow_dev; g.blk_flag = h->blk_flag; g.blk_list = h->blk_list; g.blk_count = h->blk_count; g.err = h->err_dev; g.slow = h->slow_dev;
     return g;
 }
 
@@ -1547,7 +1552,7 @@ int substep_fwd(FeEngine* h, int f, int f_global, int act) {
                            h->pinfo, h->pool_idx, grid_w(h), ag, inj, act, f, grid_store(h));
     prof_end(h);
     prof_begin(h, KID_GRID);
-    hipLaunchKernelGGL(k_grid<false>, ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, h->g_out, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f);
+    hipLaunchKernelGGL(k_grid<false>, ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, h->g_out, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f, h->frame_slow_dev);
     prof_end(h);
     prof_begin(h, KID_G2P);
     hipLaunchKernelGGL(k_g2p, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T, h->g_out, h->blk_count, h->slow_dev);
@@ -1574,7 +1579,7 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act) {
                            h->pinfo, h->pool_idx, grid_w(h), ag, noinj, 0, f, grid_store(h));
     prof_end(h);
     prof_begin(h, KID_GRID_KEEP);
-    hipLaunchKernelGGL(k_grid<true>, ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, h->g_out, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f);
+    hipLaunchKernelGGL(k_grid<true>, ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, h->g_out, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f, h->frame_slow_dev);
     prof_end(h);
     prof_begin(h, KID_G2P_GRAD);
     hipLaunchKernelGGL(k_g2p_grad, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev, grid_store(h), f);
@@ -1686,7 +1691,7 @@ FeEngine* fe_create(const FeConfig* cfg) {
         h->items_cap = (nblk < (size_t)h->Np ? nblk : (size_t)h->Np) + (size_t)h->Np / 64 + 2;      // item_max >= 64
         if (dev_alloc(h, &h->sort_key, h->Np) || dev_alloc(h, &h->sort_rank, h->Np) || dev_alloc(h, &h->sort_cnt, ncell + 1) ||
             dev_alloc(h, &h->sort_start, ncell + 1) || dev_alloc(h, &h->sort_src, h->Np) || dev_alloc(h, &h->sort_pid, h->Np) ||
-            dev_alloc(h, &h->slow_dev, 1) || dev_alloc(h, &h->slab, h->items_cap * TILE_N, false) || dev_alloc(h, &h->ts_dev, 8 * 4096) || dev_alloc(h, &h->sort_partial, (ncell + 1 + 1023) / 1024 + 1)) return fail("");
+            dev_alloc(h, &h->slow_dev, 1) || dev_alloc(h, &h->frame_slow_dev, 1) || dev_alloc(h, &h->slab, h->items_cap * TILE_N, false) || dev_alloc(h, &h->ts_dev, 8 * 4096) || dev_alloc(h, &h->sort_partial, (ncell + 1 + 1023) / 1024 + 1)) return fail("");
     }
     if (dev_alloc(h, &h->effs_dev, FE_MAX_EFF)) return fail("");
     {   // forward grid store: cap blocks per frame, 2 KiB each; bounded to 64 GiB
@@ -1717,7 +1722,7 @@ void fe_destroy(FeEngine* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     for (auto& t : h->tables) { for (void* q : {(void*)t.pid, (void*)t.items, (void*)t.meta, (void*)t.blk_first, (void*)t.active, (void*)t.blk_slot}) if (q) (void)hipFree(q); }
-    void* ptrs[] = {h->frames, h->grads, h->sort_key, h->sort_rank, h->sort_cnt, h->sort_start, h->sort_src, h->sort_pid, h->slow_dev, h->gstore, h->gs_flag, h->slab, h->ts_dev, h->sort_partial, h->effs_dev, h->pinfo, h->pool_idx, h->g_in, h->g_out, h->gg_out, h->gg_in,
+    void* ptrs[] = {h->frames, h->grads, h->sort_key, h->sort_rank, h->sort_cnt, h->sort_start, h->sort_src, h->sort_pid, h->slow_dev, h->frame_slow_dev, h->gstore, h->gs_flag, h->slab, h->ts_dev, h->sort_partial, h->effs_dev, h->pinfo, h->pool_idx, h->g_in, h->g_out, h->gg_out, h->gg_in,
                     h->blk_flag, h->blk_list, h->blk_count, h->err_dev, h->stage_r, h->stage_i, h->node_mark, h->counters,
                     h->tgt, h->chamfer, h->step_loss};
     for (void* p : ptrs) if (p) (void)hipFree(p);

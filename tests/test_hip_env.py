@@ -47,7 +47,8 @@ def test_latteart_env_on_hip_matches_oracle(hiplib, oracle64, monkeypatch):
         loss_g, g_g, env = _fwd_bwd(hiplib, tgt32, **kw)
         assert env.taichi_env.simulator.engine.elib.backend == 'hip-gfx950'
         assert abs(loss_g - loss_o) <= 1e-4 * abs(loss_o), kw
-        assert S.cosine(g_g, g_o) >= 0.999 and S.rel_l2(g_g, g_o) <= 1e-2, (kw, S.rel_l2(g_g, g_o))
+        # measured ~8e-7; a 1e-2 bound once let a 1% error of a stale-grid bug through
+        assert S.cosine(g_g, g_o) >= 0.999999 and S.rel_l2(g_g, g_o) <= 1e-4, (kw, S.rel_l2(g_g, g_o))
 
 
 def test_solver_reduces_loss_on_hip(hiplib):

@@ -60,7 +60,7 @@ def test_substep_adjoint(hiplib, oracle64, scene, K):
     if scene == 'water':
         sc = S.water_block(n_grid=16, n_particles=2000)
         sc['v'] = S.f32(np.random.RandomState(9).normal(0, 0.5, (2000, 3)))
-        tol_l2 = 2e-3
+        tol_l2 = 1e-4
     else:
         sc = S.mixed_materials()
         tol_l2 = 1e-2
@@ -84,8 +84,8 @@ def test_latte_mini_trajectory_gradient(hiplib, oracle64, K):
     assert S.rel_l2(a['final']['x'], b['final']['x']) <= 1e-5
     assert S.rel_l2(a['step_loss'], b['step_loss']) <= 1e-4
     assert np.abs(a['eff_state'] - b['eff_state']).max() <= 1e-6
-    assert S.cosine(a['action_grad'], b['action_grad']) >= 0.999
-    assert S.rel_l2(a['action_grad'], b['action_grad']) <= 1e-2
+    assert S.cosine(a['action_grad'], b['action_grad']) >= 0.999999
+    assert S.rel_l2(a['action_grad'], b['action_grad']) <= 1e-4          # inviscid liquids: measured ~2e-7
 
 
 def test_fast_particles_leave_their_tiles(hiplib, oracle64):
