@@ -174,8 +174,9 @@ def main():
                 bp, bc = KERNEL_BYTES[name]
                 us = 1e3 * ms / cnt
                 b = bp * n_used + bc * nc
-                per_kernel[name] = {'avg_us': round(us, 3), 'alg_bytes': b, 'GBps': round(b / (us * 1e-6) / 1e9, 1)}
-        dom = max(per_kernel, key=lambda k: per_kernel[k]['avg_us'])
+                per_kernel[name] = {'avg_us': round(us, 3), 'launches': cnt, 'alg_bytes': b, 'GBps': round(b / (us * 1e-6) / 1e9, 1)}
+        # dominant kernel = largest share of the measured time among the kernels that carry algorithmic bytes
+        dom = max((k for k in per_kernel if per_kernel[k]['alg_bytes'] > 0), key=lambda k: prof[k][0])
         # HBM traffic of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs)
         traffic = None
         try:

@@ -1083,16 +1083,15 @@ __global__ __launch_bounds__(256) void k_scan_final(int ncell, int ITEM_MAX, int
 // the order's static active list: every block within one block of an occupied block (= every block some tile reaches)
 __global__ __launch_bounds__(256) void k_build_active(int nb, const int4* __restrict__ items, int* meta, int* blk_flag, int* active, int* blk_slot) {
     const int n_items = meta[0];
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_items; i += gridDim.x * blockDim.x) {
+    // one thread per (item, neighbour): 27 independent CAS instead of a serial chain per block
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n_items * 27; t += gridDim.x * blockDim.x) {
+        const int i = t / 27, nbr = t - i * 27;
         const int b = items[i].x;
         if (i > 0 && items[i - 1].x == b) continue;           // first item of its block only
-        const int bi = b / (nb * nb), bj = (b / nb) % nb, bk = b % nb;
-        for (int di = -1; di <= 1; di++) for (int dj = -1; dj <= 1; dj++) for (int dk = -1; dk <= 1; dk++) {
-            const int i2 = bi + di, j2 = bj + dj, k2 = bk + dk;
-            if ((unsigned)i2 >= (unsigned)nb || (unsigned)j2 >= (unsigned)nb || (unsigned)k2 >= (unsigned)nb) continue;
-            const int n2 = (i2 * nb + j2) * nb + k2;
-            if (atomicCAS(&blk_flag[n2], 0, 2) == 0) { const int e = atomicAdd(&meta[2], 1); active[e] = n2; blk_slot[n2] = e; }
-        }
+        const int i2 = b / (nb * nb) + nbr / 9 - 1, j2 = (b / nb) % nb + (nbr / 3) % 3 - 1, k2 = b % nb + nbr % 3 - 1;
+        if ((unsigned)i2 >= (unsigned)nb || (unsigned)j2 >= (unsigned)nb || (unsigned)k2 >= (unsigned)nb) continue;
+        const int n2 = (i2 * nb + j2) * nb + k2;
+        if (atomicCAS(&blk_flag[n2], 0, 2) == 0) { const int e = atomicAdd(&meta[2], 1); active[e] = n2; blk_slot[n2] = e; }
     }
 }
 __global__ __launch_bounds__(256) void k_clear_slots(const int* __restrict__ active, const int* __restrict__ meta, int* blk_slot) {
@@ -1105,12 +1104,14 @@ __global__ __launch_bounds__(256) void k_set_static(const int* __restrict__ acti
 }
 
 __global__ __launch_bounds__(256) void k_sort_perm(int N, const int* __restrict__ key, const int* __restrict__ rank,
-                                                   const int* __restrict__ start, const int* __restrict__ pid_old, int* src, int* pid_new) {
+                                                   const int* __restrict__ start, const int* __restrict__ pid_old, int* src, int* pid_new, int* slot_of_pid) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= N) return;
     const int d = start[key[s]] + rank[s];
+    const int pid = pid_old[s];
     src[d] = s;
-    pid_new[d] = pid_old[s];
+    pid_new[d] = pid;
+    slot_of_pid[pid] = d;
 }
 
 // dst[s] = src[idx[s]] over all 24 planes (+ used when WITH_USED): coalesced writes, gathered 16-byte reads
@@ -1124,6 +1125,16 @@ __global__ __launch_bounds__(256) void k_perm_gather(int N, size_t Np, float* ds
     d.a3[s] = q.a3[o]; d.a4[s] = q.a4[o]; d.a5[s] = q.a5[o];
     d.B0[s] = q.B0[o]; d.B1[s] = q.B1[o]; d.b2[s] = q.b2[o];
     if (WITH_USED) d.used[s] = q.used[o];
+}
+// dst[s] = src[inv_from[pid_to[s]]]: adjoint frame from order `from` to order `to` in one pass
+__global__ __launch_bounds__(256) void k_perm_reorder(int N, size_t Np, float* dst_, float* src_, const int* __restrict__ pid_to, const int* __restrict__ inv_from) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= N) return;
+    const int o = inv_from[pid_to[s]];
+    FrameV d = frame_view(dst_, Np), q = frame_view(src_, Np);
+    d.A0[s] = q.A0[o]; d.A1[s] = q.A1[o]; d.A2[s] = q.A2[o];
+    d.a3[s] = q.a3[o]; d.a4[s] = q.a4[o]; d.a5[s] = q.a5[o];
+    d.B0[s] = q.B0[o]; d.B1[s] = q.B1[o]; d.b2[s] = q.b2[o];
 }
 // dst[idx[s]] = src[s]
 __global__ __launch_bounds__(256) void k_perm_scatter(int N, size_t Np, float* dst_, float* src_, const int* __restrict__ idx) {
@@ -1325,8 +1336,9 @@ struct FeEngine {
     float* grads = nullptr;                                 // 3 x (GR_WORDS*Np + Np) floats: ring of two + 1 spare
     float* grad_ptr[3] = {nullptr, nullptr, nullptr};
     // particle orders ("tables"): id 0 = identity; id 1+f = order produced by the sort at frame f
-    struct Table { int* pid = nullptr; int4* items = nullptr; int* meta = nullptr; int2* blk_first = nullptr; int* active = nullptr; int* blk_slot = nullptr; };
+    struct Table { int* pid = nullptr; int4* items = nullptr; int* meta = nullptr; int2* blk_first = nullptr; int* active = nullptr; int* blk_slot = nullptr; int* slot_of_pid = nullptr; };
     int static_table = -1;                                  // order whose active list is currently flagged 2 in blk_flag
+    std::vector<int> gs_host; bool gs_host_valid = false;   // host copy of gs_flag, refreshed once per backward sweep
     float4* gstore = nullptr; int* gs_flag = nullptr; int gs_cap = 0;     // forward grid store (see GridStore)
     float4* slab = nullptr;                                 // one 512-node float4 tile per work item (scatter hand-over)
     std::vector<Table> tables;
@@ -1462,7 +1474,7 @@ int ensure_table(FeEngine* h, int id) {
     if (t.pid) return 0;
     const size_t nblk = (size_t)h->nb * h->nb * h->nb;
     if (dev_alloc(h, &t.pid, h->Np) || dev_alloc(h, &t.items, h->items_cap) || dev_alloc(h, &t.meta, 4) ||
-        dev_alloc(h, &t.blk_first, nblk) || dev_alloc(h, &t.active, nblk) || dev_alloc(h, &t.blk_slot, nblk)) return 1;
+        dev_alloc(h, &t.blk_first, nblk) || dev_alloc(h, &t.active, nblk) || dev_alloc(h, &t.blk_slot, nblk) || dev_alloc(h, &t.slot_of_pid, h->Np)) return 1;
     HIPCK(h, hipMemsetAsync(t.blk_slot, 0xff, sizeof(int) * nblk, h->stream));
     return 0;
 }
@@ -1472,14 +1484,9 @@ int reorder_grad(FeEngine* h, int slot, int to) {
     const int from = h->gtbl[slot];
     if (from == to || from < 0) { if (from >= 0) h->gtbl[slot] = to; return 0; }
     prof_begin(h, KID_REORDER_GRAD);
-    if (from != 0) {
-        hipLaunchKernelGGL(k_perm_scatter, pgrid(h), dim3(256), 0, h->stream, h->N, (size_t)h->Np, h->grad_ptr[2], h->grad_ptr[slot], h->tables[from].pid);
-        std::swap(h->grad_ptr[2], h->grad_ptr[slot]);
-    }
-    if (to != 0) {
-        hipLaunchKernelGGL(k_perm_gather<false>, pgrid(h), dim3(256), 0, h->stream, h->N, (size_t)h->Np, h->grad_ptr[2], h->grad_ptr[slot], h->tables[to].pid);
-        std::swap(h->grad_ptr[2], h->grad_ptr[slot]);
-    }
+    hipLaunchKernelGGL(k_perm_reorder, pgrid(h), dim3(256), 0, h->stream, h->N, (size_t)h->Np, h->grad_ptr[2], h->grad_ptr[slot],
+                       h->tables[to].pid, h->tables[from].slot_of_pid);
+    std::swap(h->grad_ptr[2], h->grad_ptr[slot]);
     prof_end(h);
     h->gtbl[slot] = to;
     return 0;
@@ -1516,10 +1523,10 @@ int sort_frame(FeEngine* h, int f) {
     const int scan_wgs = (ncell + 1 + 1023) / 1024;
     hipLaunchKernelGGL(k_scan_partial, dim3(scan_wgs), dim3(256), 0, h->stream, ncell, h->item_max, h->sort_cnt, h->sort_partial);
     hipLaunchKernelGGL(k_scan_final, dim3(scan_wgs), dim3(256), 0, h->stream, ncell, h->item_max, h->sort_cnt, h->sort_partial, h->sort_start, tn.items, tn.meta, tn.blk_first);
-    hipLaunchKernelGGL(k_build_active, dim3(16), dim3(256), 0, h->stream, h->nb, tn.items, tn.meta, h->blk_flag, tn.active, tn.blk_slot);
+    hipLaunchKernelGGL(k_build_active, dim3(256), dim3(256), 0, h->stream, h->nb, tn.items, tn.meta, h->blk_flag, tn.active, tn.blk_slot);
     h->static_table = id_new;
     hipLaunchKernelGGL(k_sort_perm, pgrid(h), dim3(256), 0, h->stream, h->N, h->sort_key, h->sort_rank, h->sort_start,
-                       h->tables[id_old].pid, h->sort_src, h->sort_pid);
+                       h->tables[id_old].pid, h->sort_src, h->sort_pid, tn.slot_of_pid);
     HIPCK(h, hipMemcpyAsync(tn.pid, h->sort_pid, sizeof(int) * h->Np, hipMemcpyDeviceToDevice, h->stream));
     hipLaunchKernelGGL(k_perm_gather<true>, pgrid(h), dim3(256), 0, h->stream, h->N, (size_t)h->Np, h->spare_frame(), h->frame(f), h->sort_src);
     prof_end(h);
@@ -1536,6 +1543,7 @@ GridW grid_w(FeEngine* h) {
 }
 
 int substep_fwd(FeEngine* h, int f, int f_global, int act) {
+    h->gs_host_valid = false;
     InjectP inj;
     if (make_inject(h, f, f_global, act, true, inj)) return 1;
     if (h->sort_interval > 0 && f % h->sort_interval == 0 && sort_frame(h, f)) return 1;
@@ -1570,6 +1578,14 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act) {
     const TableP T = h->tableP(t);
     AgentP ag = agent_params(h);
     InjectP noinj = {0, 0, 0, 0};
+    if (h->gs_cap > 0 && !h->gs_host_valid) {            // one small D2H per backward sweep: which frames have a stored grid
+        h->gs_host.resize(h->L + 1);
+        HIPCK(h, hipMemcpyAsync(h->gs_host.data(), h->gs_flag, sizeof(int) * (h->L + 1), hipMemcpyDeviceToHost, h->stream));
+        HIPCK(h, hipStreamSynchronize(h->stream));
+        h->gs_host_valid = true;
+    }
+    const bool stored = h->gs_cap > 0 && h->gs_host[f] != 0;
+    if (!stored) {
     prof_begin(h, KID_P2G_RE);
     if (h->all_simple_liquid)
         hipLaunchKernelGGL((k_p2g<false, false>), wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T,
@@ -1581,6 +1597,7 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act) {
     prof_begin(h, KID_GRID_KEEP);
     hipLaunchKernelGGL(k_grid<true>, ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, h->g_out, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f, h->frame_slow_dev);
     prof_end(h);
+    }
     prof_begin(h, KID_G2P_GRAD);
     hipLaunchKernelGGL(k_g2p_grad, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev, grid_store(h), f);
     prof_end(h);
@@ -1711,6 +1728,7 @@ FeEngine* fe_create(const FeConfig* cfg) {
         std::vector<int> id(h->Np);
         for (int i = 0; i < h->Np; i++) id[i] = i < h->N ? i : 0;
         if (hipMemcpy(h->tables[0].pid, id.data(), sizeof(int) * h->Np, hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy failed");
+        if (hipMemcpy(h->tables[0].slot_of_pid, id.data(), sizeof(int) * h->Np, hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy failed");
     }
     if (hipEventCreate(&h->ev_t0) != hipSuccess || hipEventCreate(&h->ev_t1) != hipSuccess) return fail("hipEventCreate failed");
     if (hipStreamSynchronize(h->stream) != hipSuccess) return fail("device initialisation failed");
@@ -1721,7 +1739,7 @@ void fe_destroy(FeEngine* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    for (auto& t : h->tables) { for (void* q : {(void*)t.pid, (void*)t.items, (void*)t.meta, (void*)t.blk_first, (void*)t.active, (void*)t.blk_slot}) if (q) (void)hipFree(q); }
+    for (auto& t : h->tables) { for (void* q : {(void*)t.pid, (void*)t.items, (void*)t.meta, (void*)t.blk_first, (void*)t.active, (void*)t.blk_slot, (void*)t.slot_of_pid}) if (q) (void)hipFree(q); }
     void* ptrs[] = {h->frames, h->grads, h->sort_key, h->sort_rank, h->sort_cnt, h->sort_start, h->sort_src, h->sort_pid, h->slow_dev, h->frame_slow_dev, h->gstore, h->gs_flag, h->slab, h->ts_dev, h->sort_partial, h->effs_dev, h->pinfo, h->pool_idx, h->g_in, h->g_out, h->gg_out, h->gg_in,
                     h->blk_flag, h->blk_list, h->blk_count, h->err_dev, h->stage_r, h->stage_i, h->node_mark, h->counters,
                     h->tgt, h->chamfer, h->step_loss};
@@ -1758,6 +1776,7 @@ int fe_set_option(FeEngine* h, const char* name, double value) {
     }
     if (!std::strcmp(name, "grid_store")) {                  // 0 disables the forward grid store (backward always recomputes)
         if (value == 0) h->gs_cap = 0;
+        h->gs_host_valid = false;
         return 0;
     }
     if (!std::strcmp(name, "p2g_grad_waves")) { h->p2g_grad_waves = (int)value; return 0; }
@@ -1818,6 +1837,7 @@ int fe_get_frame(FeEngine* h, int f, fe_real* x, fe_real* v, fe_real* C, fe_real
 }
 int fe_set_frame(FeEngine* h, int f, const fe_real* x, const fe_real* v, const fe_real* C, const fe_real* F, const int* used) {
     CHECK_FRAME(h, f);
+    h->gs_host_valid = false;
     if (h->gs_cap > 0) HIPCK(h, hipMemsetAsync(h->gs_flag + f, 0, sizeof(int), h->stream));     // the stored grid of this frame is stale now
     return upload_planes(h, h->frame(f), h->pid_of(f), x, v, C, F, used, 0);
 }
@@ -1826,6 +1846,7 @@ int fe_copy_frame(FeEngine* h, int src, int dst) {
     if (src == dst) return 0;
     HIPCK(h, hipMemcpyAsync(h->frame(dst), h->frame(src), sizeof(float) * h->frame_stride, hipMemcpyDeviceToDevice, h->stream));
     h->tbl_of_frame[dst] = h->tbl_of_frame[src];
+    h->gs_host_valid = false;
     if (h->gs_cap > 0) HIPCK(h, hipMemsetAsync(h->gs_flag + dst, 0, sizeof(int), h->stream));
     return 0;
 }
