@@ -324,7 +324,8 @@ FE_HD real stencil_dw(const Stencil& s, int i, int d) {
     return i == 0 ? -(R_(1.5) - fx) : (i == 1 ? -R_(2.0) * (fx - R_(1.0)) : fx - R_(0.5));
 }
 FE_HD bool stencil_inside(const Stencil& s, int n) {
-    return s.base[0] >= 0 && s.base[1] >= 0 && s.base[2] >= 0 && s.base[0] + 2 < n && s.base[1] + 2 < n && s.base[2] + 2 < n;
+    // compare against n - 3, not base + 2 < n: v_cvt_i32_f32 saturates an exploded coordinate to INT_MAX and +2 would wrap
+    return s.base[0] >= 0 && s.base[1] >= 0 && s.base[2] >= 0 && s.base[0] <= n - 3 && s.base[1] <= n - 3 && s.base[2] <= n - 3;
 }
 
 // ---------------------------------------------------------------------------------------

@@ -287,7 +287,7 @@ inline void make_stencil(const R* xp, R inv_dx, Stencil& s) {
 }
 
 inline bool stencil_in_grid(const Stencil& s, int n) {
-    for (int d = 0; d < 3; d++) if (s.base[d] < 0 || s.base[d] + 2 >= n) return false;
+    for (int d = 0; d < 3; d++) if (s.base[d] < 0 || s.base[d] > n - 3) return false;
     return true;
 }
 

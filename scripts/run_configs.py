@@ -1,0 +1,79 @@
+"""BASELINE configs 3 and 5 on one MI355X through the Python stack (timing + sanity), see DESIGN.md section 6.
+
+config 3: LatteArt two-fluid at 128^3 (quality=2), ~200k particles, horizon 330 / 250 action steps, one full
+          Solver iteration = 3300 forward + 3300 backward substeps, whole trajectory resident in HBM.
+config 5: elasto-plastic (ICECREAM, SVD path) block, 256^3 grid, 1M particles, forward+backward substeps.
+"""
+import json
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import scenarios as S
+from fluidlab_amd import _capi
+from fluidlab_amd.envs import make
+from fluidlab_amd.optimizer.recorder import Recorder
+from fluidlab_amd.optimizer.solver import Solver
+from fluidlab_amd.utils.config import load_config
+
+out = {}
+which = sys.argv[1:2] or ['3', '5']
+
+if '3' in which:
+    # 128^3 with ~2 particles per cell (the reference scene has 3.8 at 64^3; SURVEY's 0.8/cell goes NaN: J < 0, mpm:359)
+    kw = dict(quality=2, particle_density=float(sys.argv[2]) if len(sys.argv) > 2 else 4e6, n_pool=60000)
+    t0 = time.time()
+    env = make('LatteArt-v0', seed=0, loss=False, **kw)
+    tgt = Recorder(env).record(write=False)
+    t_rec = time.time() - t0
+    n = env.taichi_env.n_particles
+    del env
+    env = make('LatteArt-v0', seed=0, loss=True, target=tgt, **kw)
+    eng = env.taichi_env.simulator.engine
+    cfg = load_config('configs/exp_latteart.yaml').SOLVER
+    cfg.n_iters = 3
+    infos = []
+    Solver(env, None, cfg).solve(callback=lambda it, info, pol: infos.append(dict(loss=info['loss'], fwd=info['forward_s'], bwd=info['backward_s'])))
+    st = eng.get_stats(3299)
+    sub = 3300
+    out['config3'] = dict(n_particles=int(n), n_used_end=int(st['n_used']), nc_end=int(st['n_cells_touched']), record_s=round(t_rec, 2),
+                          iters=infos, fwd_substeps_per_s=round(sub / infos[-1]['fwd'], 1), pairs_per_s=round(sub / (infos[-1]['fwd'] + infos[-1]['bwd']), 1),
+                          bytes_state_GB=round(st['bytes_state'] / 2**30, 2), slow_path=int(st['n_slow_path']))
+    print(json.dumps(out['config3']))
+    del env
+
+if '5' in which:
+    elib = _capi.load_hip()
+    N, n = 1_000_000, 256
+    rng = np.random.RandomState(0)
+    side = (N / 8.0) ** (1 / 3) / n            # ~8 particles per cell
+    x0 = S.f32(rng.uniform(0.3, 0.3 + side, (N, 3)))
+    # ICECREAM (SVD + plastic clamp) is only run for 10 substeps: with the reference's constants (p_vol = (dx/2)^2,
+    # dt = 2e-4) an elasto-plastic block is 16x stiffer per unit mass at 256^3 than at the reference's 64^3 and blows up
+    for name, mat, L in (('water', S.WATER, 40), ('icecream', S.ICECREAM, 10)):
+        sc = dict(n_grid=n, N=N, dt=2e-4, gravity=(0.0, -10.0, 0.0), n_substeps=10,
+                  boundary=dict(type='cube', lower=(0.05, 0.05, 0.05), upper=(0.95, 0.95, 0.95)),
+                  x=x0, used=np.ones(N, np.int32), mat=np.full(N, mat, np.int32))
+        eng = S.make_engine(elib, sc, max_substeps_local=L)
+        eng.loss_alloc(1); eng.loss_set_target(0, sc['x'])
+        def step():
+            eng.step(0, 0, L, 0); eng.reset_grad(); eng.loss_step_grad(0, L, mat, 1.0, 1.0); eng.step_grad(0, 0, L, 0)
+        step(); eng.sync()
+        t0 = time.time()
+        for _ in range(3):
+            step()
+        eng.sync()
+        dt = (time.time() - t0) / 3
+        eng.profile_enable(True); step(); prof = eng.profile_read(); eng.profile_enable(False)
+        st = eng.get_stats(L // 2)
+        gx = eng.get_grad(0)[0]
+        b_pair = 524 * st['n_used'] + 204 * st['n_cells_touched']
+        out['config5_' + name] = dict(n_particles=N, grid=n, substeps=L, pairs_per_s=round(L / dt, 1), ms_per_pair=round(1e3 * dt / L, 3),
+                                      nc=int(st['n_cells_touched']), bytes_state_GB=round(st['bytes_state'] / 2**30, 2),
+                                      grad_finite=bool(np.isfinite(gx).all()), pair_roofline_frac=round(b_pair * L / dt / 8e12, 4),
+                                      kernels_us={k: round(1e3 * v[0] / v[1], 1) for k, v in prof.items() if v[1]})
+        print(json.dumps(out['config5_' + name]))
+        eng.close()
+json.dump(out, open('gpurun_out/configs_3_5.json', 'w'), indent=1)
