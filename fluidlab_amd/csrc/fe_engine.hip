@@ -1382,10 +1382,21 @@ struct FeEngine {
 
 static std::string g_create_err;
 
+// The engine's stream is created hipStreamNonBlocking, so a plain hipMemcpy (null stream) is not ordered with the
+// hipMemsetAsync zero-fills dev_alloc queues on it: with a 90 GB frame buffer still being cleared, the memset of a small
+// table used to land AFTER the table had been uploaded.  All uploads go through the engine's stream.
+static hipError_t hipMemcpyOnStream(FeEngine* h, void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
+
 #define FAIL(h, msg) do { (h)->err = (msg); return 1; } while (0)
 #define HIPCK(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (h)->err = std::string(#call) + ": " + hipGetErrorString(e_); return 1; } } while (0)
 #define CHECK_FRAME(h, f) do { if ((f) < 0 || (f) > (h)->L) FAIL(h, "frame index out of range"); } while (0)
 #define CHECK_EFF(h, e) do { if ((e) < 0 || (e) >= (int)(h)->effs.size()) FAIL(h, "effector index out of range"); } while (0)
+
+static hipError_t hipMemcpyOnStream(FeEngine* h, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, h->stream);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(h->stream);
+}
 
 namespace {
 
@@ -1727,8 +1738,8 @@ FeEngine* fe_create(const FeConfig* cfg) {
     {   // identity particle order
         std::vector<int> id(h->Np);
         for (int i = 0; i < h->Np; i++) id[i] = i < h->N ? i : 0;
-        if (hipMemcpy(h->tables[0].pid, id.data(), sizeof(int) * h->Np, hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy failed");
-        if (hipMemcpy(h->tables[0].slot_of_pid, id.data(), sizeof(int) * h->Np, hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy failed");
+        if (hipMemcpyOnStream(h, h->tables[0].pid, id.data(), sizeof(int) * h->Np, hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy failed");
+        if (hipMemcpyOnStream(h, h->tables[0].slot_of_pid, id.data(), sizeof(int) * h->Np, hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy failed");
     }
     if (hipEventCreate(&h->ev_t0) != hipSuccess || hipEventCreate(&h->ev_t1) != hipSuccess) return fail("hipEventCreate failed");
     if (hipStreamSynchronize(h->stream) != hipSuccess) return fail("device initialisation failed");
@@ -1934,11 +1945,11 @@ int fe_add_effector(FeEngine* h, const FeEffectorDesc* d, const fe_real* random_
         if (!random_vector || d->random_length <= 0 || d->flux <= 0) return bad("injector needs random_vector, random_length, flux");
         size_t cnt = (size_t)d->random_length * d->flux * 3;
         if (dev_alloc(h, &p.random_vector, cnt, false)) return -1;
-        if (hipMemcpy(p.random_vector, random_vector, sizeof(float) * cnt, hipMemcpyHostToDevice) != hipSuccess) return bad("hipMemcpy failed");
+        if (hipMemcpyOnStream(h, p.random_vector, random_vector, sizeof(float) * cnt, hipMemcpyHostToDevice) != hipSuccess) return bad("hipMemcpy failed");
     }
     E.act_id.assign(Fm, 0);
     h->effs.push_back(E);
-    if (hipMemcpy(h->effs_dev + (h->effs.size() - 1), &h->effs.back().p, sizeof(EffP), hipMemcpyHostToDevice) != hipSuccess) return bad("hipMemcpy failed");
+    if (hipMemcpyOnStream(h, h->effs_dev + (h->effs.size() - 1), &h->effs.back().p, sizeof(EffP), hipMemcpyHostToDevice) != hipSuccess) return bad("hipMemcpy failed");
     return (int)h->effs.size() - 1;
 }
 int fe_eff_set_act_range(FeEngine* h, int e, const int* act_range, int n) {
