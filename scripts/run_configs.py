@@ -33,7 +33,7 @@ if '3' in which:
     env = make('LatteArt-v0', seed=0, loss=True, target=tgt, **kw)
     eng = env.taichi_env.simulator.engine
     cfg = load_config('configs/exp_latteart.yaml').SOLVER
-    cfg.n_iters = 3
+    cfg.n_iters = 2          # the third Adam iterate hits the scene's stability edge at 128^3
     infos = []
     Solver(env, None, cfg).solve(callback=lambda it, info, pol: infos.append(dict(loss=info['loss'], fwd=info['forward_s'], bwd=info['backward_s'])))
     st = eng.get_stats(3299)
@@ -42,6 +42,17 @@ if '3' in which:
                           iters=infos, fwd_substeps_per_s=round(sub / infos[-1]['fwd'], 1), pairs_per_s=round(sub / (infos[-1]['fwd'] + infos[-1]['bwd']), 1),
                           bytes_state_GB=round(st['bytes_state'] / 2**30, 2), slow_path=int(st['n_slow_path']))
     print(json.dumps(out['config3']))
+    del env, eng
+
+    # the same scene with the reference's 50-substep window + host checkpoints (latteart_env.py:31, mpm:777-912): backward
+    # re-runs every chunk's forward, state crosses PCIe at chunk boundaries
+    env = make('LatteArt-v0', seed=0, loss=True, target=tgt, max_substeps_local=50, ckpt_dest='cpu', **kw)
+    infos = []
+    Solver(env, None, cfg).solve(callback=lambda it, info, pol: infos.append(dict(loss=info['loss'], fwd=info['forward_s'], bwd=info['backward_s'])))
+    out['config3_window50_cpu_ckpt'] = dict(n_particles=int(n), iters=infos, fwd_substeps_per_s=round(sub / infos[-1]['fwd'], 1),
+                                            pairs_per_s=round(sub / (infos[-1]['fwd'] + infos[-1]['bwd']), 1),
+                                            bytes_state_GB=round(env.taichi_env.simulator.engine.get_stats(0)['bytes_state'] / 2**30, 2))
+    print(json.dumps(out['config3_window50_cpu_ckpt']))
     del env
 
 if '5' in which:

@@ -115,6 +115,23 @@ def test_forward_is_independent_of_sort_interval(hiplib):
         assert S.rel_l2(got['x'], ref['x']) <= 1e-6 and S.rel_l2(got['v'], ref['v']) <= 1e-3, K
 
 
+def test_large_window_does_not_race_uploads(hiplib):
+    """Regression: with a multi-GB frame window the zero-fill of the engine's buffers is still running on the engine's
+    (non-blocking) stream when fe_create uploads the identity particle table; a null-stream copy used to be overwritten by
+    the late memset, which only showed up at LatteArt 128^3 sizes.  K=0 keeps the identity table in use."""
+    sc = S.water_block(n_grid=32, n_particles=8192)
+    small = S.make_engine(hiplib, sc, max_substeps_local=10, options=dict(sort_interval=0))
+    a = S.run_forward(small, 5)
+    small.close()
+    big = S.make_engine(hiplib, sc, max_substeps_local=24000, options=dict(sort_interval=0))     # ~20 GB of frames
+    b = S.run_forward(big, 5)
+    st = big.get_stats(5)
+    big.close()
+    assert st['n_used'] == 8192 and st['bytes_state'] > 15e9
+    assert (a['used'] == b['used']).all()
+    assert np.abs(a['x'] - b['x']).max() <= 1e-6          # slow path float atomics: order-dependent rounding only
+
+
 def test_roundtrip_and_frame_ops(hiplib):
     sc = S.mixed_materials(n_particles=777)          # ragged: not a multiple of the wave size
     eng = S.make_engine(hiplib, sc, max_substeps_local=4)
