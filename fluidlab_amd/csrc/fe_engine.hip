@@ -1202,6 +1202,190 @@ __global__ void k_eff_copy(EffP e, int src, int dst, int grad) {
     for (int j = 0; j < 4; j++) quat[dst * 4 + j] = quat[src * 4 + j];
 }
 
+
+// =========================================================================================
+// MAT_RIGID shape matching (advect / advect_grad, mpm:428-505).  Bodies are few and their particles a small part of
+// the scene, so this is a handful of N-wide launches that only exist when a rigid body does: per-body moments are
+// reduced in fp64 (wave butterfly when the wave's rigid lanes belong to one body, plain atomics otherwise), one
+// thread per body does the 3x3 SVD.  The reference accumulates in fp32 with atomics (mpm:456-478).
+// =========================================================================================
+struct RigidBody {
+    double acc[30];      // forward  [0..2] COM_t0  [3..5] COM_t1  [6..14] H        (mpm:181-189)
+                         // backward [15..23] R.grad  [24..26] COM_t0.grad  [27..29] COM_t1.grad
+    float c0[3], c1[3], R[9], U[9], sig[3], V[9], gH[9];
+    float inv_n;         // 1 / bodies_i.n_particles (all particles of the body, used or not: mpm:201)
+    int rigid;           // bodies_i.mat_cls == MAT_RIGID
+};
+
+template <int K>
+__device__ __forceinline__ void rigid_accumulate(RigidBody* B, int b, int off, const double (&val)[K]) {
+    const unsigned long long m = __ballot(b >= 0);
+    if (m == 0) return;                                          // wave-uniform
+    const int b0 = __shfl(b, __ffsll((long long)m) - 1, 64);
+    if (__ballot(b >= 0 && b != b0) == 0) {
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            double v = b >= 0 ? val[k] : 0.0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if ((threadIdx.x & 63) == 0) atomicAdd(&B[b0].acc[off + k], v);
+        }
+    } else if (b >= 0) {
+#pragma unroll
+        for (int k = 0; k < K; k++) atomicAdd(&B[b].acc[off + k], val[k]);
+    }
+}
+
+struct RigidLane { int b; float x[3], y[3]; };
+// x = x[f], y = x[f] + dt v[f+1] of a used MAT_RIGID particle (b = -1 otherwise)
+__device__ __forceinline__ RigidLane rigid_lane(const SimP& S, const FrameV& cur, const FrameV& nxt, const int* pid_of_slot,
+                                                const int* rigid_body, int s) {
+    RigidLane l; l.b = -1;
+    if (s < S.N && cur.used[s]) l.b = rigid_body[pid_of_slot[s]];
+    if (l.b >= 0) {
+        float4 a0 = cur.A0[s], n0 = nxt.A0[s], n1 = nxt.A1[s];
+        l.x[0] = a0.x; l.x[1] = a0.y; l.x[2] = a0.z;
+        l.y[0] = a0.x + S.dt * n0.w; l.y[1] = a0.y + S.dt * n1.x; l.y[2] = a0.z + S.dt * n1.y;
+    }
+    return l;
+}
+
+__global__ __launch_bounds__(256) void k_rigid_clear(RigidBody* B, int n_bodies) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_bodies * 30) B[i / 30].acc[i % 30] = 0.0;                                  // reset_bodies_and_grad, mpm:449-454
+}
+
+// PASS 0: compute_COM (mpm:456-462); PASS 1: compute_H (mpm:464-478)
+template <int PASS>
+__global__ __launch_bounds__(256) void k_rigid_moments(SimP S, float* fr_f, float* fr_n, const int* __restrict__ pid_of_slot,
+                                                       const int* __restrict__ rigid_body, RigidBody* B) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    const RigidLane l = rigid_lane(S, frame_view(fr_f, S.Np), frame_view(fr_n, S.Np), pid_of_slot, rigid_body, s);
+    if (PASS == 0) {
+        double val[6] = {0, 0, 0, 0, 0, 0};
+        if (l.b >= 0) { const double w = B[l.b].inv_n; for (int d = 0; d < 3; d++) { val[d] = l.x[d] * w; val[3 + d] = l.y[d] * w; } }
+        rigid_accumulate(B, l.b, 0, val);
+    } else {
+        double val[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (l.b >= 0) {
+            const RigidBody& bd = B[l.b];
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) val[i * 3 + j] = ((double)l.x[i] - bd.acc[i]) * ((double)l.y[j] - bd.acc[3 + j]);
+        }
+        rigid_accumulate(B, l.b, 6, val);
+    }
+}
+
+// compute_H_svd + compute_R (mpm:480-483, 491-495): one thread per body
+__global__ void k_rigid_solve(RigidBody* B, int n_bodies) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_bodies || !B[i].rigid) return;
+    RigidBody& b = B[i];
+    m3 H, U, V; float sig[3];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) H.a[r][c] = (float)b.acc[6 + r * 3 + c];
+    svd3(H, U, sig, V);
+    const m3 R = m3_mul_nt(V, U);
+    for (int d = 0; d < 3; d++) { b.c0[d] = (float)b.acc[d]; b.c1[d] = (float)b.acc[3 + d]; b.sig[d] = sig[d]; }
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { b.R[r * 3 + c] = R.a[r][c]; b.U[r * 3 + c] = U.a[r][c]; b.V[r * 3 + c] = V.a[r][c]; }
+}
+
+// advect_kernel, rigid branch (mpm:500-502): x[f+1] = R (x[f] - COM_t0) + COM_t1 (k_g2p wrote the non-rigid x + dt v)
+__global__ __launch_bounds__(256) void k_rigid_advect(SimP S, float* fr_f, float* fr_n, const int* __restrict__ pid_of_slot,
+                                                      const int* __restrict__ rigid_body, const RigidBody* B) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    FrameV nxt = frame_view(fr_n, S.Np);
+    const RigidLane l = rigid_lane(S, frame_view(fr_f, S.Np), nxt, pid_of_slot, rigid_body, s);
+    if (l.b < 0) return;
+    const RigidBody& b = B[l.b];
+    float o[3];
+    for (int i = 0; i < 3; i++) { o[i] = b.c1[i]; for (int j = 0; j < 3; j++) o[i] += b.R[i * 3 + j] * (l.x[j] - b.c0[j]); }
+    float4 n0 = nxt.A0[s];
+    n0.x = o[0]; n0.y = o[1]; n0.z = o[2];
+    nxt.A0[s] = n0;
+}
+
+// advect_kernel.grad, rigid branch: R.grad += g (x - COM_t0)^T, COM_t0.grad -= R^T g, COM_t1.grad += g
+__global__ __launch_bounds__(256) void k_rigid_advect_grad(SimP S, float* fr_f, float* fr_n, float* G1_, const int* __restrict__ pid_of_slot,
+                                                           const int* __restrict__ rigid_body, RigidBody* B) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    const RigidLane l = rigid_lane(S, frame_view(fr_f, S.Np), frame_view(fr_n, S.Np), pid_of_slot, rigid_body, s);
+    double val[15];
+    for (int k = 0; k < 15; k++) val[k] = 0.0;
+    if (l.b >= 0) {
+        const RigidBody& b = B[l.b];
+        const float4 g0 = frame_view(G1_, S.Np).A0[s];
+        const float g[3] = {g0.x, g0.y, g0.z};
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) val[i * 3 + j] = (double)g[i] * (double)(l.x[j] - b.c0[j]);
+        for (int j = 0; j < 3; j++) {
+            float rtg = 0; for (int i = 0; i < 3; i++) rtg += b.R[i * 3 + j] * g[i];
+            val[9 + j] = -(double)rtg; val[12 + j] = g[j];
+        }
+    }
+    rigid_accumulate(B, l.b, 15, val);
+}
+
+// compute_R.grad (R = V U^T) and compute_H_svd_grad (mpm:485-489)
+__global__ void k_rigid_solve_grad(RigidBody* B, int n_bodies) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_bodies || !B[i].rigid) return;
+    RigidBody& b = B[i];
+    m3 gR, U, V;
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { gR.a[r][c] = (float)b.acc[15 + r * 3 + c]; U.a[r][c] = b.U[r * 3 + c]; V.a[r][c] = b.V[r * 3 + c]; }
+    const m3 gV = m3_mul(gR, U), gU = m3_mul_tn(gR, V);
+    const float gS[3] = {0.f, 0.f, 0.f};
+    const m3 gH = backward_svd(gU, gS, gV, U, b.sig, V);
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) b.gH[r * 3 + c] = gH.a[r][c];
+}
+
+__device__ __forceinline__ void rigid_H_adjoint(const RigidBody& b, const RigidLane& l, float ga[3], float gb[3]) {
+    float a[3], bb[3];
+    for (int d = 0; d < 3; d++) { a[d] = l.x[d] - b.c0[d]; bb[d] = l.y[d] - b.c1[d]; }
+    for (int d = 0; d < 3; d++) {
+        ga[d] = 0; gb[d] = 0;
+        for (int e = 0; e < 3; e++) { ga[d] += b.gH[d * 3 + e] * bb[e]; gb[d] += b.gH[e * 3 + d] * a[e]; }
+    }
+}
+
+// compute_H.grad, the part that flows into the COM adjoints
+__global__ __launch_bounds__(256) void k_rigid_H_grad(SimP S, float* fr_f, float* fr_n, const int* __restrict__ pid_of_slot,
+                                                      const int* __restrict__ rigid_body, RigidBody* B) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    const RigidLane l = rigid_lane(S, frame_view(fr_f, S.Np), frame_view(fr_n, S.Np), pid_of_slot, rigid_body, s);
+    double val[6] = {0, 0, 0, 0, 0, 0};
+    if (l.b >= 0) {
+        float ga[3], gb[3];
+        rigid_H_adjoint(B[l.b], l, ga, gb);
+        for (int d = 0; d < 3; d++) { val[d] = -(double)ga[d]; val[3 + d] = -(double)gb[d]; }
+    }
+    rigid_accumulate(B, l.b, 24, val);
+}
+
+// Particle side of advect_kernel.grad + compute_H.grad + compute_COM.grad.  With
+//   X = R^T g + H.grad b + H.grad^T a + (COM_t0.grad + COM_t1.grad)/n   (what x.grad[f] receives)
+//   W = H.grad^T a + COM_t1.grad/n                                       (what v.grad[f+1] receives, times dt)
+// the incoming adjoint is rewritten as x.grad[f+1] := X, v.grad[f+1] += dt (W - X), so that the generic
+// advect adjoint in k_g2p_grad (x.grad[f] += x.grad[f+1]; v.grad[f+1] += dt x.grad[f+1]) yields exactly X and dt W.
+__global__ __launch_bounds__(256) void k_rigid_final_grad(SimP S, float* fr_f, float* fr_n, float* G1_, const int* __restrict__ pid_of_slot,
+                                                          const int* __restrict__ rigid_body, const RigidBody* B) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    const RigidLane l = rigid_lane(S, frame_view(fr_f, S.Np), frame_view(fr_n, S.Np), pid_of_slot, rigid_body, s);
+    if (l.b < 0) return;
+    const RigidBody& b = B[l.b];
+    FrameV G1 = frame_view(G1_, S.Np);
+    float4 g0 = G1.A0[s], g1 = G1.A1[s];
+    const float g[3] = {g0.x, g0.y, g0.z};
+    float ga[3], gb[3], X[3], W[3];
+    rigid_H_adjoint(b, l, ga, gb);
+    for (int j = 0; j < 3; j++) {
+        float rtg = 0; for (int i = 0; i < 3; i++) rtg += b.R[i * 3 + j] * g[i];
+        const float gc0 = (float)b.acc[24 + j], gc1 = (float)b.acc[27 + j];
+        X[j] = rtg + ga[j] + gb[j] + (gc0 + gc1) * b.inv_n;
+        W[j] = gb[j] + gc1 * b.inv_n;
+    }
+    g0.x = X[0]; g0.y = X[1]; g0.z = X[2];
+    g0.w += S.dt * (W[0] - X[0]); g1.x += S.dt * (W[1] - X[1]); g1.y += S.dt * (W[2] - X[2]);
+    G1.A0[s] = g0; G1.A1[s] = g1;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
@@ -1358,6 +1542,8 @@ struct FeEngine {
     float *g_in = nullptr, *gg_out = nullptr;              // SoA accumulator planes (4 and 3 x ncell floats)
     float4 *g_out = nullptr, *gg_in = nullptr;
     bool all_simple_liquid = false;                         // every particle is an inviscid MAT_LIQUID: SVD-free kernels
+    bool has_rigid = false; int n_bodies = 0;               // MAT_RIGID shape-matching bodies (mpm:176-201)
+    int* rigid_body = nullptr; RigidBody* bodies_dev = nullptr;   // [Np] body of a MAT_RIGID particle or -1 (by particle id); [n_bodies]
     int *blk_flag = nullptr, *blk_list = nullptr, *blk_count = nullptr, *err_dev = nullptr;
     float* stage_r = nullptr; int* stage_i = nullptr;       // 24 N floats, N ints
     unsigned char* node_mark = nullptr; unsigned long long* counters = nullptr;
@@ -1553,6 +1739,14 @@ GridW grid_w(FeEngine* h) {
     return g;
 }
 
+// MAT_RIGID: forward moments + rotation of every rigid body for substep f (shared by advect and advect_grad, mpm:428-441)
+void rigid_forward(FeEngine* h, int f, const TableP& T) {
+    hipLaunchKernelGGL(k_rigid_clear, dim3((h->n_bodies * 30 + 255) / 256), dim3(256), 0, h->stream, h->bodies_dev, h->n_bodies);
+    hipLaunchKernelGGL(k_rigid_moments<0>, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T.pid_of_slot, h->rigid_body, h->bodies_dev);
+    hipLaunchKernelGGL(k_rigid_moments<1>, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T.pid_of_slot, h->rigid_body, h->bodies_dev);
+    hipLaunchKernelGGL(k_rigid_solve, dim3((h->n_bodies + 63) / 64), dim3(64), 0, h->stream, h->bodies_dev, h->n_bodies);
+}
+
 int substep_fwd(FeEngine* h, int f, int f_global, int act) {
     h->gs_host_valid = false;
     InjectP inj;
@@ -1576,6 +1770,10 @@ int substep_fwd(FeEngine* h, int f, int f_global, int act) {
     prof_begin(h, KID_G2P);
     hipLaunchKernelGGL(k_g2p, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T, h->g_out, h->blk_count, h->slow_dev);
     prof_end(h);
+    if (h->has_rigid) {
+        rigid_forward(h, f, T);
+        hipLaunchKernelGGL(k_rigid_advect, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T.pid_of_slot, h->rigid_body, h->bodies_dev);
+    }
     return 0;
 }
 
@@ -1608,6 +1806,13 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act) {
     prof_begin(h, KID_GRID_KEEP);
     hipLaunchKernelGGL(k_grid<true>, ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, h->g_out, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f, h->frame_slow_dev);
     prof_end(h);
+    }
+    if (h->has_rigid) {                                   // advect_grad (mpm:436-447) for the rigid bodies, see k_rigid_final_grad
+        rigid_forward(h, f, T);
+        hipLaunchKernelGGL(k_rigid_advect_grad, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), h->grad(f + 1), T.pid_of_slot, h->rigid_body, h->bodies_dev);
+        hipLaunchKernelGGL(k_rigid_solve_grad, dim3((h->n_bodies + 63) / 64), dim3(64), 0, h->stream, h->bodies_dev, h->n_bodies);
+        hipLaunchKernelGGL(k_rigid_H_grad, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T.pid_of_slot, h->rigid_body, h->bodies_dev);
+        hipLaunchKernelGGL(k_rigid_final_grad, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), h->grad(f + 1), T.pid_of_slot, h->rigid_body, h->bodies_dev);
     }
     prof_begin(h, KID_G2P_GRAD);
     hipLaunchKernelGGL(k_g2p_grad, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev, grid_store(h), f);
@@ -1753,7 +1958,7 @@ void fe_destroy(FeEngine* h) {
     for (auto& t : h->tables) { for (void* q : {(void*)t.pid, (void*)t.items, (void*)t.meta, (void*)t.blk_first, (void*)t.active, (void*)t.blk_slot, (void*)t.slot_of_pid}) if (q) (void)hipFree(q); }
     void* ptrs[] = {h->frames, h->grads, h->sort_key, h->sort_rank, h->sort_cnt, h->sort_start, h->sort_src, h->sort_pid, h->slow_dev, h->frame_slow_dev, h->gstore, h->gs_flag, h->slab, h->ts_dev, h->sort_partial, h->effs_dev, h->pinfo, h->pool_idx, h->g_in, h->g_out, h->gg_out, h->gg_in,
                     h->blk_flag, h->blk_list, h->blk_count, h->err_dev, h->stage_r, h->stage_i, h->node_mark, h->counters,
-                    h->tgt, h->chamfer, h->step_loss};
+                    h->tgt, h->chamfer, h->step_loss, h->rigid_body, h->bodies_dev};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& E : h->effs) {
         void* ep[] = {E.p.pos, E.p.quat, E.p.v, E.p.w, E.p.gpos, E.p.gquat, E.p.gv, E.p.gw, E.p.abuf, E.p.gabuf, E.p.abuf_p, E.p.gabuf_p, E.p.random_vector};
@@ -1798,14 +2003,12 @@ int fe_set_option(FeEngine* h, const char* name, double value) {
 
 int fe_init_particles(FeEngine* h, const fe_real* x, const int* used, const int* mat, const int* mat_cls,
                       const fe_real* mu, const fe_real* lam, const fe_real* rho, const int* body_id) {
-    (void)body_id;
     const int N = h->N;
     std::vector<float4> info(h->Np, make_float4(0, 0, 0, 0));
     std::vector<float> C0((size_t)9 * N, 0.f), F0((size_t)9 * N, 0.f), v0((size_t)3 * N, 0.f);
     h->mat_host.assign(mat, mat + N);
     bool simple = true;
     for (int i = 0; i < N; i++) {
-        if (mat_cls[i] == FE_MAT_RIGID) FAIL(h, "MAT_RIGID shape-matching bodies are not supported yet (SURVEY 8f-4)");
         if (mat_cls[i] < 0 || mat_cls[i] > 0xffff || mat[i] < 0 || mat[i] > 0xffff) FAIL(h, "material id out of range");
         int bits = (mat_cls[i] & 0xffff) | ((mat[i] & 0xffff) << 16);
         float w; std::memcpy(&w, &bits, 4);
@@ -1814,6 +2017,31 @@ int fe_init_particles(FeEngine* h, const fe_real* x, const int* used, const int*
         F0[(size_t)i * 9] = F0[(size_t)i * 9 + 4] = F0[(size_t)i * 9 + 8] = 1.f;
     }
     h->all_simple_liquid = simple;
+    // init_bodies, mpm:176-201
+    h->has_rigid = false; h->n_bodies = 0;
+    for (int i = 0; i < N; i++) {
+        const int b = body_id ? body_id[i] : 0;
+        if (b < 0) FAIL(h, "negative body_id");
+        if (b + 1 > h->n_bodies) h->n_bodies = b + 1;
+        if (mat_cls[i] == FE_MAT_RIGID) h->has_rigid = true;
+    }
+    if (h->bodies_dev) { (void)hipFree(h->bodies_dev); h->bodies_dev = nullptr; }
+    if (h->has_rigid) {
+        std::vector<RigidBody> bodies(h->n_bodies);
+        std::vector<int> cnt(h->n_bodies, 0), rb(h->Np, -1);
+        std::memset(bodies.data(), 0, sizeof(RigidBody) * bodies.size());
+        for (int i = 0; i < N; i++) {
+            const int b = body_id ? body_id[i] : 0;
+            if (cnt[b]++ == 0) bodies[b].rigid = mat_cls[i] == FE_MAT_RIGID;       // mat_cls[body_id == b][0], mpm:201
+            if (mat_cls[i] == FE_MAT_RIGID) rb[i] = b;
+        }
+        for (int b = 0; b < h->n_bodies; b++) bodies[b].inv_n = cnt[b] ? 1.f / (float)cnt[b] : 0.f;
+        if (!h->rigid_body && dev_alloc(h, &h->rigid_body, h->Np)) return 1;
+        if (dev_alloc(h, &h->bodies_dev, h->n_bodies)) return 1;
+        HIPCK(h, hipMemcpyAsync(h->rigid_body, rb.data(), sizeof(int) * h->Np, hipMemcpyHostToDevice, h->stream));
+        HIPCK(h, hipMemcpyAsync(h->bodies_dev, bodies.data(), sizeof(RigidBody) * h->n_bodies, hipMemcpyHostToDevice, h->stream));
+        HIPCK(h, hipStreamSynchronize(h->stream));
+    }
     HIPCK(h, hipMemcpyAsync(h->pinfo, info.data(), sizeof(float4) * h->Np, hipMemcpyHostToDevice, h->stream));
     HIPCK(h, hipStreamSynchronize(h->stream));
     h->tbl_of_frame[0] = 0;

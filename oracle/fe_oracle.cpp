@@ -224,6 +224,9 @@ struct Effector {
     std::vector<int> act_range;
 };
 
+/* body_state of mpm:181-189 plus its adjoint */
+struct Body { R com0[3], com1[3]; M3 H, Rm, U, S, V; R gcom0[3], gcom1[3]; M3 gH, gR, gU, gS, gV; };
+
 } // namespace
 
 struct FeEngine {
@@ -235,6 +238,11 @@ struct FeEngine {
     std::vector<R> Ftmp, U, V, S, gFtmp, gU, gV, gS; /* per-substep temporaries [N,9] */
     std::vector<R> mu, lam, mass;
     std::vector<int> mat, mat_cls, body_id;
+    /* rigid bodies, mpm:176-201: per-body particle count and class; state is transient per substep */
+    int n_bodies = 0;
+    bool has_rigid = false;
+    std::vector<int> body_n, body_cls;
+    std::vector<Body> bodies;
     std::vector<R> g_vin, g_mass, g_vout, gg_vin, gg_mass, gg_vout;
     std::vector<Effector> effs;
     int loss_steps = 0;
@@ -485,29 +493,120 @@ int g2p(FeEngine* h, int f) {
     return 0;
 }
 
-/* mpm:497-505 (non-rigid branch).  MAT_RIGID shape matching (mpm:449-495) is outside
- * this round's scope and rejected in fe_init_particles. */
+/* MAT_RIGID shape matching, forward part shared by advect and advect_grad (mpm:428-434 / 436-441):
+ * reset_bodies_and_grad (mpm:449-454), compute_COM (456-462), compute_H (464-478), compute_H_svd (480-483),
+ * compute_R (491-495).  Body accumulation runs serially in particle order. */
+void rigid_forward(FeEngine* h, int f) {
+    const int N = h->N;
+    const R dt = h->cfg.dt;
+    for (int b = 0; b < h->n_bodies; b++) if (h->body_cls[b] == FE_MAT_RIGID) std::memset(&h->bodies[b], 0, sizeof(Body));
+    for (int p = 0; p < N; p++) {
+        if (!h->Us(f)[p] || h->mat_cls[p] != FE_MAT_RIGID) continue;
+        Body& B = h->bodies[h->body_id[p]];
+        const R nb = (R)h->body_n[h->body_id[p]];
+        for (int d = 0; d < 3; d++) {
+            B.com0[d] += h->X(f)[p * 3 + d] / nb;
+            B.com1[d] += (h->X(f)[p * 3 + d] + dt * h->Vv(f + 1)[p * 3 + d]) / nb;
+        }
+    }
+    for (int p = 0; p < N; p++) {
+        if (!h->Us(f)[p] || h->mat_cls[p] != FE_MAT_RIGID) continue;
+        Body& B = h->bodies[h->body_id[p]];
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++)
+            B.H.m[i][j] += (h->X(f)[p * 3 + i] - B.com0[i]) * (h->X(f)[p * 3 + j] + dt * h->Vv(f + 1)[p * 3 + j] - B.com1[j]);
+    }
+    for (int b = 0; b < h->n_bodies; b++) {
+        if (h->body_cls[b] != FE_MAT_RIGID) continue;
+        Body& B = h->bodies[b];
+        svd3(B.H, B.U, B.S, B.V);                       /* mpm:483 */
+        B.Rm = m_mul(B.V, m_T(B.U));                    /* mpm:495 */
+    }
+}
+
+/* advect, mpm:428-434 + advect_kernel mpm:497-505 */
 void advect(FeEngine* h, int f) {
     const int N = h->N;
+    if (h->has_rigid) rigid_forward(h, f);
 #pragma omp parallel for num_threads(h->threads) schedule(static)
     for (int p = 0; p < N; p++) {
         if (!h->Us(f)[p]) continue;
-        for (int d = 0; d < 3; d++) h->X(f + 1)[p * 3 + d] = h->X(f)[p * 3 + d] + h->cfg.dt * h->Vv(f + 1)[p * 3 + d];
+        if (h->mat_cls[p] == FE_MAT_RIGID) {
+            const Body& B = h->bodies[h->body_id[p]];
+            for (int i = 0; i < 3; i++) {
+                R a = B.com1[i];
+                for (int j = 0; j < 3; j++) a += B.Rm.m[i][j] * (h->X(f)[p * 3 + j] - B.com0[j]);
+                h->X(f + 1)[p * 3 + i] = a;
+            }
+        } else {
+            for (int d = 0; d < 3; d++) h->X(f + 1)[p * 3 + d] = h->X(f)[p * 3 + d] + h->cfg.dt * h->Vv(f + 1)[p * 3 + d];
+        }
     }
 }
 
 /* ------------------------------------------------------------------ adjoint kernels */
 
-/* advect_kernel.grad (mpm:443): x[f+1] = x[f] + dt v[f+1] */
+/* advect_grad, mpm:436-447: advect_kernel.grad, compute_R.grad, compute_H_svd_grad (mpm:485-489), compute_H.grad,
+ * compute_COM.grad -- what Taichi's autodiff derives from mpm:456-505, written out by hand */
 void advect_grad(FeEngine* h, int f) {
     const int N = h->N;
-#pragma omp parallel for num_threads(h->threads) schedule(static)
+    const R dt = h->cfg.dt;
+    if (h->has_rigid) rigid_forward(h, f);
+    /* advect_kernel.grad */
     for (int p = 0; p < N; p++) {
         if (!h->Us(f)[p]) continue;
+        if (h->mat_cls[p] == FE_MAT_RIGID) {
+            Body& B = h->bodies[h->body_id[p]];
+            const R* g = &h->GX(f + 1)[p * 3];
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) B.gR.m[i][j] += g[i] * (h->X(f)[p * 3 + j] - B.com0[j]);
+            for (int j = 0; j < 3; j++) {
+                R rtg = 0;
+                for (int i = 0; i < 3; i++) rtg += B.Rm.m[i][j] * g[i];
+                h->GX(f)[p * 3 + j] += rtg;
+                B.gcom0[j] -= rtg;
+                B.gcom1[j] += g[j];
+            }
+        } else {
+            for (int d = 0; d < 3; d++) {
+                R g = h->GX(f + 1)[p * 3 + d];
+                h->GX(f)[p * 3 + d] += g;
+                h->GV(f + 1)[p * 3 + d] += dt * g;
+            }
+        }
+    }
+    if (!h->has_rigid) return;
+    for (int b = 0; b < h->n_bodies; b++) {
+        if (h->body_cls[b] != FE_MAT_RIGID) continue;
+        Body& B = h->bodies[b];
+        B.gV = m_add(B.gV, m_mul(B.gR, B.U));            /* R = V U^T */
+        B.gU = m_add(B.gU, m_mul(m_T(B.gR), B.V));
+        B.gH = backward_svd(B.gU, B.gS, B.gV, B.U, B.S, B.V);   /* mpm:489 */
+    }
+    /* compute_H.grad */
+    for (int p = 0; p < N; p++) {
+        if (!h->Us(f)[p] || h->mat_cls[p] != FE_MAT_RIGID) continue;
+        Body& B = h->bodies[h->body_id[p]];
+        R a[3], bb[3];
         for (int d = 0; d < 3; d++) {
-            R g = h->GX(f + 1)[p * 3 + d];
-            h->GX(f)[p * 3 + d] += g;
-            h->GV(f + 1)[p * 3 + d] += h->cfg.dt * g;
+            a[d] = h->X(f)[p * 3 + d] - B.com0[d];
+            bb[d] = h->X(f)[p * 3 + d] + dt * h->Vv(f + 1)[p * 3 + d] - B.com1[d];
+        }
+        for (int d = 0; d < 3; d++) {
+            R ga = 0, gb = 0;
+            for (int e = 0; e < 3; e++) { ga += B.gH.m[d][e] * bb[e]; gb += B.gH.m[e][d] * a[e]; }
+            h->GX(f)[p * 3 + d] += ga + gb;
+            h->GV(f + 1)[p * 3 + d] += dt * gb;
+            B.gcom0[d] -= ga;
+            B.gcom1[d] -= gb;
+        }
+    }
+    /* compute_COM.grad */
+    for (int p = 0; p < N; p++) {
+        if (!h->Us(f)[p] || h->mat_cls[p] != FE_MAT_RIGID) continue;
+        const Body& B = h->bodies[h->body_id[p]];
+        const R nb = (R)h->body_n[h->body_id[p]];
+        for (int d = 0; d < 3; d++) {
+            h->GX(f)[p * 3 + d] += (B.gcom0[d] + B.gcom1[d]) / nb;
+            h->GV(f + 1)[p * 3 + d] += dt * B.gcom1[d] / nb;
         }
     }
 }
@@ -791,13 +890,25 @@ int fe_init_particles(FeEngine* h, const fe_real* x, const int* used, const int*
                       const fe_real* mu, const fe_real* lam, const fe_real* rho, const int* body_id) {
     const int N = h->N;
     for (int i = 0; i < N; i++) {
-        if (mat_cls[i] == FE_MAT_RIGID) FE_FAIL(h, "MAT_RIGID shape-matching bodies are not supported yet (SURVEY 8f-4)");
         for (int d = 0; d < 3; d++) { h->X(0)[i * 3 + d] = x[i * 3 + d]; h->Vv(0)[i * 3 + d] = 0; }   /* mpm:163-165 */
         for (int d = 0; d < 9; d++) { h->Ff(0)[i * 9 + d] = (d % 4 == 0) ? 1 : 0; h->Cc(0)[i * 9 + d] = 0; }
         h->Us(0)[i] = used[i];
         h->mat[i] = mat[i]; h->mat_cls[i] = mat_cls[i]; h->mu[i] = mu[i]; h->lam[i] = lam[i];
         h->mass[i] = h->cfg.p_vol * rho[i];                                                            /* mpm:174 */
         h->body_id[i] = body_id ? body_id[i] : 0;
+    }
+    /* init_bodies, mpm:176-201 */
+    h->n_bodies = 0;
+    for (int i = 0; i < N; i++) {
+        if (h->body_id[i] < 0) FE_FAIL(h, "negative body_id");
+        h->n_bodies = std::max(h->n_bodies, h->body_id[i] + 1);
+    }
+    h->body_n.assign(h->n_bodies, 0); h->body_cls.assign(h->n_bodies, -1); h->bodies.assign(h->n_bodies, Body());
+    h->has_rigid = false;
+    for (int i = 0; i < N; i++) {
+        int b = h->body_id[i];
+        if (h->body_n[b]++ == 0) h->body_cls[b] = mat_cls[i];            /* mat_cls[body_id == i][0], mpm:201 */
+        if (mat_cls[i] == FE_MAT_RIGID) h->has_rigid = true;
     }
     h->initialized = true;
     return 0;

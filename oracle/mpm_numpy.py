@@ -58,7 +58,7 @@ def boundary_v(bnd, xn, v):
     return v
 
 
-def substep(x, v, C, F, used, mu, lam, mass, mat_cls, n_grid, dt, p_vol, gravity, bnd):
+def substep(x, v, C, F, used, mu, lam, mass, mat_cls, n_grid, dt, p_vol, gravity, bnd, body_id=None):
     """One forward substep (mpm:515-533, no agent).  Returns x', v', C', F'."""
     n = n_grid
     dx, inv_dx = 1.0 / n, float(n)
@@ -114,7 +114,21 @@ def substep(x, v, C, F, used, mu, lam, mass, mat_cls, n_grid, dt, p_vol, gravity
                 nv += wt[:, None] * gv
                 nC += 4 * inv_dx * wt[:, None, None] * gv[:, :, None] * dpos[:, None, :]
     x2, v2, C2, F2 = x.copy(), v.copy(), C.copy(), F.copy()
-    x2[act] = xs + dt * nv                                              # mpm:505
+    xn2 = xs + dt * nv                                                  # mpm:505
+    if body_id is not None and (cls == MAT_RIGID).any():
+        # MAT_RIGID shape matching, mpm:449-505: means divide by the body's TOTAL particle count (mpm:201,461)
+        bid_all = np.asarray(body_id)
+        bid = bid_all[act]
+        for b in np.unique(bid[cls == MAT_RIGID]):
+            sel = (bid == b) & (cls == MAT_RIGID)
+            nb = float((bid_all == b).sum())
+            c0 = xs[sel].sum(0) / nb
+            c1 = xn2[sel].sum(0) / nb
+            H = (xs[sel] - c0).T @ (xn2[sel] - c1)
+            Ub, _, Vb = proper_svd(H[None])
+            R = Vb[0] @ Ub[0].T
+            xn2[sel] = (xs[sel] - c0) @ R.T + c1
+    x2[act] = xn2
     v2[act] = nv
     C2[act] = nC
     F2[act] = Fn

@@ -5,13 +5,14 @@ import numpy as np
 
 from fluidlab_amd._capi import Engine, FE_EFF_INJECTOR
 
-WATER, MILK, COFFEE, ELASTIC, ICECREAM, MILK_VIS = 0, 1, 2, 3, 4, 8
-MAT_LIQUID, MAT_PLASTO_ELASTIC, MAT_ELASTIC = 200, 201, 202
+WATER, MILK, COFFEE, ELASTIC, ICECREAM, RIGID, RIGID_HEAVY, MILK_VIS = 0, 1, 2, 3, 4, 5, 6, 8
+MAT_LIQUID, MAT_PLASTO_ELASTIC, MAT_ELASTIC, MAT_RIGID = 200, 201, 202, 203
 # (mu, lam, rho, class) -- fluidlab/configs/macros.py:65-83,143-201
 MATERIALS = {
     WATER: (0.0, 277.78, 1.0, MAT_LIQUID), MILK: (0.0, 277.78, 0.5, MAT_LIQUID), COFFEE: (0.0, 277.78, 1.0, MAT_LIQUID),
     ELASTIC: (416.67, 277.78, 1.0, MAT_ELASTIC), ICECREAM: (416.67, 277.78, 0.5, MAT_PLASTO_ELASTIC),
     MILK_VIS: (200.0, 277.78, 1.0, MAT_LIQUID),
+    RIGID: (416.67, 277.78, 1.0, MAT_RIGID), RIGID_HEAVY: (416.67, 277.78, 10.0, MAT_RIGID),
 }
 
 
@@ -45,6 +46,29 @@ def mixed_materials(n_grid=16, n_particles=1500, seed=1):
     Fn = np.where((mats == ICECREAM)[:, None, None], 0.002, 0.03)
     sc['F'] = f32(np.eye(3)[None] + rng.normal(0, 1.0, (N, 3, 3)) * Fn)
     return sc
+
+
+def rigid_in_water(n_grid=16, n_water=1200, n_rigid=(150, 90), seed=5):
+    """Two MAT_RIGID shape-matching bodies (mpm:449-505) dropped into a water block, tumbling: one RIGID box, one
+    RIGID_HEAVY box with a few unused particles (the reference divides the COM by the body's total count, mpm:201,461)."""
+    rng = np.random.RandomState(seed)
+    xs = [rng.uniform(0.3, 0.7, (n_water, 3)) * [1, 0.5, 1] + [0, 0.1, 0]]
+    mats, bids, vs = [np.full(n_water, WATER)], [np.zeros(n_water)], [np.zeros((n_water, 3))]
+    centres = [(0.42, 0.55, 0.45), (0.6, 0.6, 0.58)]
+    for b, (cnt, c, m) in enumerate(zip(n_rigid, centres, (RIGID, RIGID_HEAVY))):
+        rel = rng.uniform(-1, 1, (cnt, 3)) * [0.06, 0.035, 0.05]
+        w = rng.normal(0, 6.0, 3)                                # angular velocity -> the body really rotates
+        xs.append(np.asarray(c) + rel); vs.append(np.cross(w, rel) + rng.normal(0, 0.3, 3))
+        mats.append(np.full(cnt, m)); bids.append(np.full(cnt, b + 1))
+    x = np.concatenate(xs); N = len(x)
+    used = np.ones(N, np.int32); used[-5:] = 0
+    # F away from the identity: at F_tmp = I the singular values coincide and the reference's backward_svd
+    # (1/clamp(s_j^2 - s_i^2), mpm:272-292) is not a derivative of anything
+    Fp = f32(np.eye(3)[None] + rng.normal(0, 0.03, (N, 3, 3)))
+    return dict(F=Fp, C=f32(rng.normal(0, 1.0, (N, 3, 3))), n_grid=n_grid, N=N, dt=2e-4, gravity=(0.0, -10.0, 0.0), n_substeps=10,
+                boundary=dict(type='cube', lower=(0.1, 0.1, 0.1), upper=(0.9, 0.9, 0.9)),
+                x=f32(x), v=f32(np.concatenate(vs)), used=used, mat=np.concatenate(mats).astype(np.int32),
+                body_id=np.concatenate(bids).astype(np.int32))
 
 
 def latte_mini(n_grid=16, n_coffee=1200, n_pool=200, seed=2, horizon=6, n_substeps=4, flux=2):
@@ -90,7 +114,7 @@ def make_engine(elib, sc, max_substeps_local=None, device=0, options=None):
     mat = sc['mat']
     props = np.array([MATERIALS[int(m)] for m in mat], dtype=np.float64)
     eng.init_particles(sc['x'], sc['used'], mat, props[:, 3].astype(np.int32), props[:, 0], props[:, 1], props[:, 2],
-                       np.zeros(sc['N'], np.int32))
+                       np.asarray(sc.get('body_id', np.zeros(sc['N'], np.int32)), np.int32))
     if any(k in sc for k in ('v', 'C', 'F')):
         eng.set_frame(0, v=sc.get('v'), C_=sc.get('C'), F=sc.get('F'))
     return eng

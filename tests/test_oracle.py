@@ -33,6 +33,32 @@ def test_oracle_matches_numpy_restatement(oracle64):
         assert np.abs(got[k] - ref).max() < 1e-9 * max(1.0, np.abs(ref).max()), k
 
 
+def test_rigid_shape_matching_matches_numpy(oracle64):
+    """MAT_RIGID bodies (mpm:449-505): the C++ restatement against the independent numpy one (numpy SVD), plus the
+    defining property -- a body's used particles move by one rigid motion per substep."""
+    sc = S.rigid_in_water()
+    eng = S.make_engine(oracle64, sc)
+    st = S.get_state(eng, 0)
+    props = np.array([S.MATERIALS[int(m)] for m in sc['mat']])
+    n = sc['n_grid']
+    x, v, C, F = (st[k].astype(np.float64) for k in 'xvCF')
+    for f in range(4):
+        eng.substep(f, f, 0)
+        x, v, C, F, _ = mpm_numpy.substep(x, v, C, F, sc['used'], props[:, 0], props[:, 1], (0.5 / n) ** 2 * props[:, 2],
+                                          props[:, 3].astype(int), n, sc['dt'], (0.5 / n) ** 2, sc['gravity'], sc['boundary'],
+                                          body_id=sc['body_id'])
+    got = S.get_state(eng, 4)
+    for k, ref in zip('xvCF', (x, v, C, F)):
+        assert np.abs(got[k] - ref).max() < 1e-9 * max(1.0, np.abs(ref).max()), k
+    x0 = st['x'].astype(np.float64)
+    for b in (1, 2):
+        sel = (sc['body_id'] == b) & (sc['used'] == 1)
+        d0 = np.linalg.norm(x0[sel][:, None] - x0[sel][None], axis=2)
+        d4 = np.linalg.norm(got['x'][sel][:, None] - got['x'][sel][None], axis=2)
+        assert np.abs(d4 - d0).max() < 1e-12                   # pairwise distances preserved: rigid
+        assert np.abs(got['x'][sel] - x0[sel]).max() > 1e-4    # and the body did move
+
+
 def test_cylinder_boundary_matches_numpy(oracle64):
     sc = S.latte_mini()
     sc = dict(sc, used=np.where(sc['used'] == 1, 1, 0).astype(np.int32))
@@ -85,19 +111,23 @@ def _loss_of(eng, sc, n_sub, cot, x=None, v=None, C=None, F=None):
     return float((st['x'] * cot['gx']).sum() + (st['v'] * cot['gv']).sum() + (st['C'] * cot['gC']).sum() + (st['F'] * cot['gF']).sum())
 
 
-@pytest.mark.parametrize('scene', ['mixed', 'water_wall'])
+@pytest.mark.parametrize('scene', ['mixed', 'water_wall', 'rigid'])
 def test_substep_adjoint_vs_finite_differences(oracle64, scene):
     if scene == 'mixed':
         sc = S.mixed_materials(n_grid=8, n_particles=40, seed=3)
         sc['x'] = S.f32(np.random.RandomState(3).uniform(0.3, 0.62, (40, 3)))
+    elif scene == 'rigid':
+        # MAT_RIGID shape matching: COM / covariance / SVD / rotation chain and its adjoint (mpm:436-505)
+        sc = S.rigid_in_water(n_grid=8, n_water=30, n_rigid=(12, 9), seed=6)
     else:
         # particles pressed against the cube wall: exercises the boundary branch of grid_op's adjoint
         sc = S.water_block(n_grid=8, n_particles=40, lo=0.13, hi=0.4)
         sc['boundary'] = dict(type='cube', lower=(0.25, 0.25, 0.25), upper=(0.8, 0.8, 0.8))
         sc['v'] = S.f32(np.random.RandomState(4).normal(0, 1.0, (40, 3)))
+    N = sc['N']
     eng = S.make_engine(oracle64, sc, max_substeps_local=8)
     eng.set_option('threads', 1)
-    N, n_sub = sc['N'], 3
+    n_sub = 3
     base = {k: S.get_state(eng, 0)[k].astype(np.float64) for k in 'xvCF'}
     cot = {k: a.astype(np.float64) for k, a in S.random_cotangent(N).items()}
     _, g = S.run_forward_backward(eng, n_sub, cot)
