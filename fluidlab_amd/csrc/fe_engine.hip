@@ -73,6 +73,7 @@ __device__ __forceinline__ int cell_addr(int i, int j, int k, int nb) {
 struct SimP {
     int N, Np, n, nb;
     int ncell;                               // nb^3 * 64: plane stride of the SoA accumulator grids
+    int xcd;                                 // option "xcd_map": consecutive work items on the same XCD (shared L2)
     int dbg;                                 // timing experiments only (option "dbg"): 1 no LDS atomics, 2 no flush, 4 no stores
     float dx, inv_dx, dt, stress_scale;     // stress_scale = -dt * p_vol * 4 * inv_dx^2 (mpm:343)
     float g[3];
@@ -138,6 +139,10 @@ __shared__ double s_acc[4 * TILE_N];
 // 27-node body gets software-pipelined into one basic block that needs >512 registers.  Per-iteration
 // weights come from register selects (a runtime-indexed array would live in scratch).
 __device__ __forceinline__ float sel3(int i, float a, float b, float c) { return i == 0 ? a : (i == 1 ? b : c); }
+// Workgroups are dealt round-robin to the 8 XCDs (workgroup id % 8), each with its own L2.  Work items are sorted by
+// block, and neighbouring blocks share tile halos and slabs, so workgroup `wg` takes item (wg % 8) * per + wg / 8:
+// every XCD gets one contiguous eighth of the list.  A bijection on [0, 8 * per); ids >= n_work are skipped.
+__device__ __forceinline__ int xcd_item(int wg, int per, int on) { return on ? (wg & 7) * per + (wg >> 3) : wg; }
 #define STW(st, i, d) sel3((i), (st).w[0][d], (st).w[1][d], (st).w[2][d])
 
 // -----------------------------------------------------------------------------------------
@@ -385,7 +390,10 @@ __global__ __launch_bounds__(WG) void k_p2g(SimP S, float* fr_cur, float* fr_nex
     TS(0);
     const int n_items = T.meta[0], tail_start = T.meta[1];
     const int n_tail = (S.N - tail_start + WG - 1) / WG;
-    for (int w = blockIdx.x; w < n_items + n_tail; w += gridDim.x) {
+    const int n_work = n_items + n_tail, per_xcd = (n_work + 7) >> 3;
+    for (int wg = blockIdx.x; wg < per_xcd * 8; wg += gridDim.x) {
+        const int w = xcd_item(wg, per_xcd, S.xcd);
+        if (w >= n_work) continue;
         if (w < n_items) {
             const int4 it = T.items[w];
             const TileO to = tile_origin(it.x, S.nb);
@@ -502,7 +510,10 @@ __global__ __launch_bounds__(256) void k_grid(SimP S, TableP T, const float4* __
         if (GS.cap > 0) GS.flag[f] = (n_static <= GS.cap && *frame_slow == 0) ? 1 : 0;
         *frame_slow = 0;
     }
-    for (int e = blockIdx.x * 4 + wave; e < cnt; e += gridDim.x * 4) {
+    const int per_xcd = ((cnt + 3) / 4 + 7) >> 3;
+    for (int wg = blockIdx.x; wg < per_xcd * 8; wg += gridDim.x) {
+        const int e = xcd_item(wg, per_xcd, S.xcd) * 4 + wave;
+        if (e >= cnt) continue;
         bool is_static;
         const int b = grid_entry(T, blk_list, e, n_static, is_static);
         const int c = (b << 6) | lane;
@@ -617,7 +628,10 @@ __global__ __launch_bounds__(WG) void k_g2p(SimP S, float* fr_cur, float* fr_nex
     FrameV nxt = frame_view(fr_next, S.Np);
     const int n_items = T.meta[0], tail_start = T.meta[1];
     const int n_tail = (S.N - tail_start + WG - 1) / WG;
-    for (int w = blockIdx.x; w < n_items + n_tail; w += gridDim.x) {
+    const int n_work = n_items + n_tail, per_xcd = (n_work + 7) >> 3;
+    for (int wg = blockIdx.x; wg < per_xcd * 8; wg += gridDim.x) {
+        const int w = xcd_item(wg, per_xcd, S.xcd);
+        if (w >= n_work) continue;
         if (w < n_items) {
             const int4 it = T.items[w];
             const TileO to = tile_origin(it.x, S.nb);
@@ -726,7 +740,10 @@ __global__ __launch_bounds__(WG) void k_g2p_grad(SimP S, float* fr_cur, float* G
     FrameV Gn = frame_view(Gn_, S.Np), Gc = frame_view(Gc_, S.Np);
     const int n_items = T.meta[0], tail_start = T.meta[1];
     const int n_tail = (S.N - tail_start + WG - 1) / WG;
-    for (int w = blockIdx.x; w < n_items + n_tail; w += gridDim.x) {
+    const int n_work = n_items + n_tail, per_xcd = (n_work + 7) >> 3;
+    for (int wg = blockIdx.x; wg < per_xcd * 8; wg += gridDim.x) {
+        const int w = xcd_item(wg, per_xcd, S.xcd);
+        if (w >= n_work) continue;
         if (w < n_items) {
             const int4 it = T.items[w];
             const TileO to = tile_origin(it.x, S.nb);
@@ -769,7 +786,10 @@ __global__ __launch_bounds__(256) void k_grid_grad(SimP S, TableP T, const float
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n_static = T.meta[2], cnt = n_static + *blk_count;
     const bool stored = GS.cap > 0 && GS.flag[f];
-    for (int e = blockIdx.x * 4 + wave; e < cnt; e += gridDim.x * 4) {
+    const int per_xcd = ((cnt + 3) / 4 + 7) >> 3;
+    for (int wg = blockIdx.x; wg < per_xcd * 8; wg += gridDim.x) {
+        const int e = xcd_item(wg, per_xcd, S.xcd) * 4 + wave;
+        if (e >= cnt) continue;
         bool is_static;
         const int b = grid_entry(T, blk_list, e, n_static, is_static);
         const int c = (b << 6) | lane;
@@ -934,7 +954,10 @@ __global__ __launch_bounds__(WG, MINW) void k_p2g_grad(SimP S, float* fr_cur, fl
     FrameV Gn = frame_view(Gn_, S.Np), Gc = frame_view(Gc_, S.Np);
     const int n_items = T.meta[0], tail_start = T.meta[1];
     const int n_tail = (S.N - tail_start + WG - 1) / WG;
-    for (int w = blockIdx.x; w < n_items + n_tail; w += gridDim.x) {
+    const int n_work = n_items + n_tail, per_xcd = (n_work + 7) >> 3;
+    for (int wg = blockIdx.x; wg < per_xcd * 8; wg += gridDim.x) {
+        const int w = xcd_item(wg, per_xcd, S.xcd);
+        if (w >= n_work) continue;
         if (w < n_items) {
             const int4 it = T.items[w];
             const TileO to = tile_origin(it.x, S.nb);
@@ -1905,7 +1928,7 @@ FeEngine* fe_create(const FeConfig* cfg) {
     if (hipSetDevice(h->device) != hipSuccess) return fail("hipSetDevice failed");
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
     SimP& S = h->S;
-    S.dbg = 0;
+    S.dbg = 0; S.xcd = 1;
     S.N = h->N; S.Np = h->Np; S.n = h->n; S.nb = h->nb; S.ncell = h->nb * h->nb * h->nb * 64;
     S.dx = 1.0f / (float)h->n; S.inv_dx = (float)h->n; S.dt = cfg->dt;
     S.stress_scale = -cfg->dt * cfg->p_vol * 4.f * S.inv_dx * S.inv_dx;
@@ -1996,6 +2019,7 @@ int fe_set_option(FeEngine* h, const char* name, double value) {
         return 0;
     }
     if (!std::strcmp(name, "p2g_grad_waves")) { h->p2g_grad_waves = (int)value; return 0; }
+    if (!std::strcmp(name, "xcd_map")) { h->S.xcd = value != 0; return 0; }
     if (!std::strcmp(name, "dbg")) { h->S.dbg = (int)value; return 0; }     // timing experiments: results are wrong
     if (!std::strcmp(name, "threads")) return 0;             // oracle-only tunable
     FAIL(h, std::string("unknown option: ") + name);
