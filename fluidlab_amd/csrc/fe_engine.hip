@@ -176,14 +176,15 @@ __device__ __forceinline__ SegScan seg_setup(int key) {
 }
 // Four independent values at once, one v_fmac_f32_dpp per step and value (the compiler's own lowering of seg_scan
 // is v_mov_b32_dpp + v_fma_f32).  A DPP read of a VGPR written by the previous VALU needs 2 wait states, which
-// inline asm has to provide itself: within a step the 4 chains are independent, and the s_nop 1 after each step
-// covers the distance from the last write of the step to the first read of the next.
+// inline asm has to provide itself: the 4 chains are independent, so three other VALU instructions always sit between
+// the write of a value in one step and its DPP read in the next; only the entry needs an s_nop.
+// (Cutting runs at 8-lane groups to halve the scan was measured slower: the extra ds_add_f64 lane-ops cost more than
+// the 36 v_fmac_dpp saved per 3 nodes -- p2g 21.0 -> 25.3 us.)
 #define SEG_STEP4(ctrl, flag) \
     asm volatile("v_fmac_f32_dpp %0, %0, %4 " ctrl " bound_ctrl:0\n\t" \
                  "v_fmac_f32_dpp %1, %1, %4 " ctrl " bound_ctrl:0\n\t" \
                  "v_fmac_f32_dpp %2, %2, %4 " ctrl " bound_ctrl:0\n\t" \
-                 "v_fmac_f32_dpp %3, %3, %4 " ctrl " bound_ctrl:0\n\t" \
-                 "s_nop 1" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(flag))
+                 "v_fmac_f32_dpp %3, %3, %4 " ctrl " bound_ctrl:0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(flag))
 __device__ __forceinline__ void seg_scan4(const SegScan& sc, float& a, float& b, float& c, float& d) {
     asm volatile("s_nop 1" ::: );                        // the inputs were just produced by VALU
     SEG_STEP4("row_shr:1 row_mask:0xf bank_mask:0xf", sc.f1);
@@ -419,7 +420,9 @@ __global__ __launch_bounds__(WG) void k_p2g(SimP S, float* fr_cur, float* fr_nex
                     stencil_make(zero, S.inv_dx, q.st);
                 }
                 const bool in_tile = lb >= 0;
-                p2g_scatter_tile(S, q, in_tile, in_tile ? lb : 0);
+                // a wave without any particle (items hold <= item_max particles, the workgroup always has 4 waves) skips
+                // the 27-node scan altogether; the branch is wave-uniform, as the DPP scan requires
+                if (__any(in_tile)) p2g_scatter_tile(S, q, in_tile, in_tile ? lb : 0);
                 if (used && q.inside && !in_tile) { atomicAdd(G.slow, 1); p2g_scatter_global(S, q, G); }   // drifted out of the tile
                 if (has && !used && WRITE) unused_particle_fwd(S, cur, nxt, s, pid, pool_idx, agent, inj, f);
             }
@@ -760,8 +763,10 @@ __global__ __launch_bounds__(WG) void k_g2p_grad(SimP S, float* fr_cur, float* G
                 const bool inside = used && stencil_inside(st, S.n);
                 const int lb = inside ? tile_base(to, st) : -1;
                 const bool live = lb >= 0;
-                const SegScan sc = seg_setup(live ? lb : (0x40000000 | tid));
-                used_particle_g2p_grad<true>(S, Gn, Gc, s, live ? lb : 0, st, g_out, gg_out, live, sc);
+                if (__any(live)) {                               // wave-uniform: empty waves skip the scan
+                    const SegScan sc = seg_setup(live ? lb : (0x40000000 | tid));
+                    used_particle_g2p_grad<true>(S, Gn, Gc, s, live ? lb : 0, st, g_out, gg_out, live, sc);
+                }
                 if (used && !live) {
                     if (inside) atomicAdd(slow, 1);
                     g2p_grad_slot_global(S, cur, Gn, Gc, s, g_out, gg_out);
