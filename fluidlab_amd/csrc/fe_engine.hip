@@ -472,21 +472,38 @@ __device__ __forceinline__ float4 gather_slabs(const SimP& S, const TableP& T, c
             mine = T.blk_first[(i2 * S.nb + j2) * S.nb + k2];
     }
     const int o[3] = {lane >> 4, (lane >> 2) & 3, lane & 3};
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    // The first two items of each of the 8 source blocks are loaded unconditionally-shaped (16 independent loads in
+    // flight, zero when absent): summing inside a `for k < count` loop made every load wait for the previous one, eight
+    // dependent L2/MALL round trips per node.  Blocks split into more than two items (> 2 * item_max particles) finish
+    // in the loop below.  The summation order stays fixed (source c ascending, item k ascending): deterministic.
+    int first[8], count[8], tidx[8];
+    float4 v0[8], v1[8];
 #pragma unroll
     for (int c = 0; c < 8; c++) {
-        int nbr = 0, tidx = 0;                      // neighbour code (di+1)*9 + (dj+1)*3 + (dk+1), tile index
+        int nbr = 0, ti_all = 0;                    // neighbour code (di+1)*9 + (dj+1)*3 + (dk+1), tile index
 #pragma unroll
         for (int d = 0; d < 3; d++) {
             const bool other = (c >> d) & 1;
             const int delta = other ? (o[d] == 3 ? 1 : -1) : 0;
             const int ti = other ? (o[d] == 3 ? 0 : o[d] + 5) : o[d] + 1;
             nbr = nbr * 3 + delta + 1;
-            tidx = tidx * TILE_T + ti;
+            ti_all = ti_all * TILE_T + ti;
         }
-        const int first = __shfl(mine.x, nbr, 64), count = __shfl(mine.y, nbr, 64);
-        for (int k = 0; k < count; k++) {
-            const float4 v = slab[(size_t)(first + k) * TILE_N + tidx];
+        first[c] = __shfl(mine.x, nbr, 64); count[c] = __shfl(mine.y, nbr, 64); tidx[c] = ti_all;
+    }
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        v0[c] = count[c] > 0 ? slab[(size_t)first[c] * TILE_N + tidx[c]] : zero4;
+        v1[c] = count[c] > 1 ? slab[(size_t)(first[c] + 1) * TILE_N + tidx[c]] : zero4;
+    }
+    float4 acc = zero4;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        acc.x += v0[c].x; acc.y += v0[c].y; acc.z += v0[c].z; acc.w += v0[c].w;
+        acc.x += v1[c].x; acc.y += v1[c].y; acc.z += v1[c].z; acc.w += v1[c].w;
+        for (int k = 2; k < count[c]; k++) {
+            const float4 v = slab[(size_t)(first[c] + k) * TILE_N + tidx[c]];
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
     }
