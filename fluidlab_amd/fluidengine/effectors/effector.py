@@ -8,6 +8,7 @@ import numpy as np
 from fluidlab_amd import _capi
 from fluidlab_amd.fluidengine.boundaries import create_boundary
 from fluidlab_amd.utils.geom import euler_to_quat_wxyz
+from fluidlab_amd.configs.macros import DTYPE_NP
 from fluidlab_amd.utils.misc import eval_str
 
 
@@ -63,13 +64,24 @@ class Effector:
         self.engine.eff_set_state(self.index, f, full)
 
     # ---- checkpoints (effector.py:84-140): frame-0 pose + velocities
-    def get_ckpt(self):
-        v, w = self.engine.eff_get_vw(self.index, 0)
-        return {'state': self.engine.eff_get_state(self.index, 0), 'v': v, 'w': w}
+    # checkpoint payload of frame 0, the reference's wire format (effector.py:103-140; Injector adds 'act_id',
+    # injector.py:131-171), so chunk files written by either implementation load in the other
+    has_act_id = False
 
-    def set_ckpt(self, ckpt):
-        self.engine.eff_set_state(self.index, 0, ckpt['state'])
-        self.engine.eff_set_vw(self.index, 0, ckpt['v'], ckpt['w'])
+    def get_ckpt(self, ckpt_name=None):
+        st = self.engine.eff_get_state(self.index, 0)
+        v, w = self.engine.eff_get_vw(self.index, 0)
+        dt = self.engine.dtype          # fp32 in the product (DTYPE_NP, as the reference); the fp64 oracle keeps its precision
+        ckpt = {'pos': st[:3].astype(dt), 'quat': st[3:7].astype(dt), 'v': np.asarray(v, dt), 'w': np.asarray(w, dt)}
+        if self.has_act_id:
+            ckpt['act_id'] = np.int32(round(float(st[7])))
+        return ckpt
+
+    def set_ckpt(self, ckpt=None, ckpt_name=None):
+        act_id = float(ckpt['act_id']) if 'act_id' in ckpt else float(self.engine.eff_get_state(self.index, 0)[7])
+        st = np.concatenate([np.asarray(ckpt['pos'], np.float64).reshape(3), np.asarray(ckpt['quat'], np.float64).reshape(4), [act_id]])
+        self.engine.eff_set_state(self.index, 0, st)
+        self.engine.eff_set_vw(self.index, 0, np.asarray(ckpt['v']).reshape(3), np.asarray(ckpt['w']).reshape(3))
 
     # ---- actions (effector.py:218-283)
     def set_action(self, s, s_global, n_substeps, action):

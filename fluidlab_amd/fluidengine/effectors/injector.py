@@ -12,6 +12,7 @@ from .effector import Effector
 
 class Injector(Effector):
     abi_type = _capi.FE_EFF_INJECTOR
+    has_act_id = True                  # checkpoint payload carries 'act_id' (injector.py:131-171)
 
     def __init__(self, radius=1.0, flux=1, inject_v=(0.0, 0.0, 0.0), inject_p=(0.0, 0.0, 0.0), randomize_inject_v=False,
                  locally_random=False, **kwargs):

@@ -59,6 +59,22 @@ def test_chunked_checkpointing_equals_resident_trajectory(oracle64, mini_target,
         policy.actions_v[:] = np.random.RandomState(4).uniform(-0.004, 0.004, policy.actions_v.shape)
         info, g = solver.forward_backward(env.taichi_env.get_state()['state'], policy, env.horizon, env.horizon_action)
         grads[mode] = (info['loss'], g)
+        if mode == 'disk':
+            # the chunk files follow the reference's wire format (mpm:777-803, effector.py:103-110, injector.py:131-140):
+            # <start_substep:06d>.pkl holding x, v, C, F, used, actions and one {pos, quat, v, w, act_id} per effector
+            import os
+            import pickle
+            sim = env.taichi_env.simulator
+            files = sorted(os.listdir(sim.ckpt_dir))
+            assert files and all(len(f) == 10 and f.endswith('.pkl') and f[:6].isdigit() for f in files)
+            assert [int(f[:6]) for f in files] == list(range(0, 40 * len(files), 40))
+            ck = pickle.load(open(os.path.join(sim.ckpt_dir, files[0]), 'rb'))
+            assert set(ck) == {'x', 'v', 'C', 'F', 'used', 'actions', 'agent'}
+            N = sim.n_particles
+            assert ck['x'].shape == (N, 3) and ck['C'].shape == (N, 3, 3) and ck['used'].dtype == np.int32
+            assert len(ck['actions']) == 40 // sim.n_substeps
+            assert set(ck['agent'][0]) == {'pos', 'quat', 'v', 'w', 'act_id'}
+            assert ck['agent'][0]['pos'].shape == (3,) and ck['agent'][0]['quat'].shape == (4,)
     for mode in ('cpu', 'disk'):
         assert abs(grads[mode][0] - grads['resident'][0]) < 1e-9 * abs(grads['resident'][0])
         assert np.abs(grads[mode][1] - grads['resident'][1]).max() < 1e-9 * np.abs(grads['resident'][1]).max()
