@@ -41,7 +41,11 @@ def _structs(real):
                     ('locally_random', C.c_int), ('randomize_inject_v', C.c_int),
                     ('random_length', C.c_int)]
 
-    return FeBoundary, FeConfig, FeEffectorDesc
+    class FeSdfDesc(C.Structure):
+        _fields_ = [('struct_size', C.c_int), ('res', C.c_int), ('T_mesh_to_voxels', real * 16),
+                    ('friction', real), ('softness', real)]
+
+    return FeBoundary, FeConfig, FeEffectorDesc, FeSdfDesc
 
 
 class FeStats(C.Structure):
@@ -56,7 +60,7 @@ ABI_SYMBOLS = [
     'fe_set_option', 'fe_init_particles', 'fe_substep', 'fe_substep_grad', 'fe_step',
     'fe_step_grad', 'fe_get_frame', 'fe_set_frame', 'fe_copy_frame', 'fe_copy_grad',
     'fe_reset_grad', 'fe_reset_grad_till_frame', 'fe_get_grad', 'fe_add_grad', 'fe_get_mat',
-    'fe_add_effector', 'fe_eff_set_act_range', 'fe_eff_get_state', 'fe_eff_set_state',
+    'fe_add_static', 'fe_add_effector', 'fe_eff_set_act_range', 'fe_eff_get_state', 'fe_eff_set_state',
     'fe_eff_get_vw', 'fe_eff_set_vw', 'fe_eff_set_action', 'fe_eff_set_action_grad',
     'fe_eff_apply_action_p', 'fe_eff_apply_action_p_grad', 'fe_eff_get_action_grad',
     'fe_agent_copy_frame', 'fe_agent_copy_grad', 'fe_agent_reset_grad_till_frame', 'fe_loss_alloc', 'fe_loss_set_target',
@@ -80,7 +84,7 @@ class EngineLib:
         self.backend = lib.fe_backend().decode()
         self.real = C.c_float if self.real_size == 4 else C.c_double
         self.dtype = np.float32 if self.real_size == 4 else np.float64
-        self.FeBoundary, self.FeConfig, self.FeEffectorDesc = _structs(self.real)
+        self.FeBoundary, self.FeConfig, self.FeEffectorDesc, self.FeSdfDesc = _structs(self.real)
         lib.fe_create.restype = C.c_void_p
         lib.fe_create.argtypes = [C.c_void_p]
         lib.fe_destroy.restype = None
@@ -304,6 +308,21 @@ class Engine:
         if e < 0:
             raise FeEngineError(self.lib.fe_last_error(self.h).decode())
         return e
+
+    def add_static(self, voxels, T_mesh_to_voxels, friction=0.0, softness=0.0):
+        """statics.add_static (statics.py:14): one SDF collider for grid_op; returns its index."""
+        keep, pv = self._r(voxels)
+        assert keep.ndim == 3 and keep.shape[0] == keep.shape[1] == keep.shape[2]
+        d = self.elib.FeSdfDesc()
+        d.struct_size = C.sizeof(self.elib.FeSdfDesc)
+        d.res = int(keep.shape[0])
+        d.T_mesh_to_voxels[:] = [float(t) for t in np.asarray(T_mesh_to_voxels, np.float64).reshape(16)]
+        d.friction = float(friction)
+        d.softness = float(softness)
+        i = self.lib.fe_add_static(self.h, C.byref(d), pv)
+        if i < 0:
+            raise FeEngineError(self.lib.fe_last_error(self.h).decode())
+        return i
 
     def eff_set_act_range(self, e, act_range):
         k, p = self._i(act_range)

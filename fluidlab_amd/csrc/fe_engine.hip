@@ -449,13 +449,39 @@ __global__ __launch_bounds__(WG) void k_p2g(SimP S, float* fr_cur, float* fr_nex
 }
 
 // velocity of one node after gravity and the domain boundary (mpm:383-398); k[] = boundary multipliers
-__device__ __forceinline__ void node_velocity(const SimP& S, const float4 gi, int i, int j, int k, float vo[3], float kmul[3]) {
+#define FE_MAX_STATICS 4
+struct StaticsP { int n; const SdfP* s; };          // the scene's static SDF colliders (statics.py), parameter blocks in device memory
+
+// STATICS=false keeps the collider-free kernels exactly as lean as before (the SDF code costs ~100 VGPRs)
+template <bool STATICS>
+__device__ __forceinline__ void node_velocity(const SimP& S, const StaticsP& ST, const float4 gi, int i, int j, int k, float vo[3], float kmul[3],
+                                              float (*trace)[3] = nullptr) {
     float inv = 1.f / gi.w;
     vo[0] = inv * gi.x + S.dt * S.g[0];
     vo[1] = inv * gi.y + S.dt * S.g[1];
     vo[2] = inv * gi.z + S.dt * S.g[2];
     float xn[3] = {(float)i * S.dx, (float)j * S.dx, (float)k * S.dx};
+    if (STATICS) {
+#pragma unroll
+        for (int si = 0; si < FE_MAX_STATICS; si++) {                       // collide with statics, mpm:386-390
+            if (si < ST.n) {
+                if (trace) { trace[si][0] = vo[0]; trace[si][1] = vo[1]; trace[si][2] = vo[2]; }
+                static_collide(ST.s[si], xn, vo, nullptr);
+            }
+        }
+    }
     boundary_v(S.bnd, xn, vo, kmul);
+}
+// adjoint of the collider chain for one node: g = d/d(v before the boundary) -> d/d(v after gravity)
+__device__ __forceinline__ void node_statics_grad(const SimP& S, const StaticsP& ST, int i, int j, int k, const float (*trace)[3], float g[3]) {
+    float xn[3] = {(float)i * S.dx, (float)j * S.dx, (float)k * S.dx};
+#pragma unroll
+    for (int si = FE_MAX_STATICS - 1; si >= 0; si--) {
+        if (si < ST.n) {
+            float vin[3] = {trace[si][0], trace[si][1], trace[si][2]};
+            static_collide(ST.s[si], xn, vin, g);
+        }
+    }
 }
 
 // Sum, for node (oi,oj,ok) of block b, what the work items' tiles deposited there.  A tile of block B' covers the
@@ -491,13 +517,17 @@ __device__ __forceinline__ float4 gather_slabs(const SimP& S, const TableP& T, c
         }
         first[c] = __shfl(mine.x, nbr, 64); count[c] = __shfl(mine.y, nbr, 64); tidx[c] = ti_all;
     }
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // (the loads are unconditional from a clamped, always valid slab index and masked afterwards: a conditional float4
+    // load into an array element ended up in scratch)
 #pragma unroll
     for (int c = 0; c < 8; c++) {
-        v0[c] = count[c] > 0 ? slab[(size_t)first[c] * TILE_N + tidx[c]] : zero4;
-        v1[c] = count[c] > 1 ? slab[(size_t)(first[c] + 1) * TILE_N + tidx[c]] : zero4;
+        const bool h0 = count[c] > 0, h1 = count[c] > 1;
+        const float4 a = slab[(size_t)(h0 ? first[c] : 0) * TILE_N + tidx[c]];
+        const float4 b = slab[(size_t)(h1 ? first[c] + 1 : 0) * TILE_N + tidx[c]];
+        v0[c] = make_float4(h0 ? a.x : 0.f, h0 ? a.y : 0.f, h0 ? a.z : 0.f, h0 ? a.w : 0.f);
+        v1[c] = make_float4(h1 ? b.x : 0.f, h1 ? b.y : 0.f, h1 ? b.z : 0.f, h1 ? b.w : 0.f);
     }
-    float4 acc = zero4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int c = 0; c < 8; c++) {
         acc.x += v0[c].x; acc.y += v0[c].y; acc.z += v0[c].z; acc.w += v0[c].w;
@@ -516,13 +546,13 @@ __device__ __forceinline__ int grid_entry(const TableP& T, const int* __restrict
     return is_static ? T.active[e] : blk_list[e - n_static];
 }
 
-// grid_op (mpm:380-398) over the active 4^3 blocks only; one wave per block.
+// grid_op (mpm:380-398) over the active 4^3 blocks only; one wave per block.  STATICS: the scene has SDF colliders.
 // KEEP=false (forward): also re-zeroes g_in and the dynamic block flag, so no separate reset_grid pass
 // (mpm:219-223) is needed.  KEEP=true (backward recompute): stores the summed (p, m) in g_in for grid_grad.
-template <bool KEEP>
+template <bool KEEP, bool STATICS>
 __global__ __launch_bounds__(256) void k_grid(SimP S, TableP T, const float4* __restrict__ slab, float* g_in, float4* g_out,
                                               const int* __restrict__ blk_list, const int* __restrict__ blk_count, int* blk_flag,
-                                              GridStore GS, int f, int* frame_slow) {
+                                              GridStore GS, int f, int* frame_slow, StaticsP ST) {
     if (KEEP && GS.cap > 0 && GS.flag[f]) return;        // backward: stored by the forward pass
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n_static = T.meta[2], cnt = n_static + *blk_count;
@@ -543,7 +573,7 @@ __global__ __launch_bounds__(256) void k_grid(SimP S, TableP T, const float4* __
         float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
         if (gi.w > FE_EPS) {
             float vo[3], kmul[3];
-            node_velocity(S, gi, bi * 4 + (lane >> 4), bj * 4 + ((lane >> 2) & 3), bk * 4 + (lane & 3), vo, kmul);
+            node_velocity<STATICS>(S, ST, gi, bi * 4 + (lane >> 4), bj * 4 + ((lane >> 2) & 3), bk * 4 + (lane & 3), vo, kmul);
             out = make_float4(vo[0], vo[1], vo[2], 0.f);
         }
         g_out[c] = out;
@@ -802,9 +832,10 @@ __global__ __launch_bounds__(WG) void k_g2p_grad(SimP S, float* fr_cur, float* G
 
 // grid_op.grad (mpm:539): d/d v_out (slabs of k_g2p_grad + slow-path atomics in gg_out) -> gg_in (d/d v_in, d/d mass);
 // re-zeroes g_in, gg_out and the dynamic flags
+template <bool STATICS>
 __global__ __launch_bounds__(256) void k_grid_grad(SimP S, TableP T, const float4* __restrict__ slab, float* g_in, float* gg_out, float4* gg_in,
                                                    const int* __restrict__ blk_list, const int* __restrict__ blk_count, int* blk_flag,
-                                                   GridStore GS, int f) {
+                                                   GridStore GS, int f, StaticsP ST) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n_static = T.meta[2], cnt = n_static + *blk_count;
     const bool stored = GS.cap > 0 && GS.flag[f];
@@ -824,9 +855,13 @@ __global__ __launch_bounds__(256) void k_grid_grad(SimP S, TableP T, const float
         float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
         if (gi.w > FE_EPS) {
             float vo[3], kmul[3];
-            node_velocity(S, gi, bi * 4 + (lane >> 4), bj * 4 + ((lane >> 2) & 3), bk * 4 + (lane & 3), vo, kmul);
+            float trace[FE_MAX_STATICS][3];
+            const int ni = bi * 4 + (lane >> 4), nj = bj * 4 + ((lane >> 2) & 3), nk = bk * 4 + (lane & 3);
+            node_velocity<STATICS>(S, ST, gi, ni, nj, nk, vo, kmul, trace);
             float inv = 1.f / gi.w;
-            float g0 = go.x * kmul[0], g1 = go.y * kmul[1], g2 = go.z * kmul[2];
+            float gcol[3] = {go.x * kmul[0], go.y * kmul[1], go.z * kmul[2]};
+            if (STATICS) node_statics_grad(S, ST, ni, nj, nk, trace, gcol);
+            float g0 = gcol[0], g1 = gcol[1], g2 = gcol[2];
             out.x = g0 * inv; out.y = g1 * inv; out.z = g2 * inv;
             out.w = -(gi.x * g0 + gi.y * g1 + gi.z * g2) * inv * inv;
         }
@@ -1587,6 +1622,7 @@ struct FeEngine {
     float *g_in = nullptr, *gg_out = nullptr;              // SoA accumulator planes (4 and 3 x ncell floats)
     float4 *g_out = nullptr, *gg_in = nullptr;
     bool all_simple_liquid = false;                         // every particle is an inviscid MAT_LIQUID: SVD-free kernels
+    std::vector<SdfP> statics_host; std::vector<float*> statics_vox; SdfP* statics_dev = nullptr;   // static SDF colliders
     bool has_rigid = false; int n_bodies = 0;               // MAT_RIGID shape-matching bodies (mpm:176-201)
     int* rigid_body = nullptr; RigidBody* bodies_dev = nullptr;   // [Np] body of a MAT_RIGID particle or -1 (by particle id); [n_bodies]
     int *blk_flag = nullptr, *blk_list = nullptr, *blk_count = nullptr, *err_dev = nullptr;
@@ -1777,6 +1813,8 @@ int sort_frame(FeEngine* h, int f) {
     return 0;
 }
 
+StaticsP statics_p(FeEngine* h) { StaticsP p; p.n = (int)h->statics_host.size(); p.s = h->statics_dev; return p; }
+
 GridStore grid_store(FeEngine* h) { GridStore g; g.data = h->gstore; g.flag = h->gs_flag; g.cap = h->gs_cap; return g; }
 
 GridW grid_w(FeEngine* h) {
@@ -1810,7 +1848,10 @@ int substep_fwd(FeEngine* h, int f, int f_global, int act) {
                            h->pinfo, h->pool_idx, grid_w(h), ag, inj, act, f, grid_store(h));
     prof_end(h);
     prof_begin(h, KID_GRID);
-    hipLaunchKernelGGL(k_grid<false>, ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, h->g_out, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f, h->frame_slow_dev);
+    if (h->statics_host.empty())
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid<false, false>), ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, h->g_out, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f, h->frame_slow_dev, statics_p(h));
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid<false, true>), ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, h->g_out, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f, h->frame_slow_dev, statics_p(h));
     prof_end(h);
     prof_begin(h, KID_G2P);
     hipLaunchKernelGGL(k_g2p, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T, h->g_out, h->blk_count, h->slow_dev);
@@ -1849,7 +1890,10 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act) {
                            h->pinfo, h->pool_idx, grid_w(h), ag, noinj, 0, f, grid_store(h));
     prof_end(h);
     prof_begin(h, KID_GRID_KEEP);
-    hipLaunchKernelGGL(k_grid<true>, ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, h->g_out, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f, h->frame_slow_dev);
+    if (h->statics_host.empty())
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid<true, false>), ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, h->g_out, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f, h->frame_slow_dev, statics_p(h));
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid<true, true>), ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, h->g_out, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f, h->frame_slow_dev, statics_p(h));
     prof_end(h);
     }
     if (h->has_rigid) {                                   // advect_grad (mpm:436-447) for the rigid bodies, see k_rigid_final_grad
@@ -1863,7 +1907,10 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act) {
     hipLaunchKernelGGL(k_g2p_grad, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev, grid_store(h), f);
     prof_end(h);
     prof_begin(h, KID_GRID_GRAD);
-    hipLaunchKernelGGL(k_grid_grad, ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, h->gg_out, h->gg_in, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f);
+    if (h->statics_host.empty())
+        hipLaunchKernelGGL(k_grid_grad<false>, ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, h->gg_out, h->gg_in, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f, statics_p(h));
+    else
+        hipLaunchKernelGGL(k_grid_grad<true>, ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, h->gg_out, h->gg_in, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f, statics_p(h));
     prof_end(h);
     prof_begin(h, KID_P2G_GRAD);
 #define LAUNCH_P2G_GRAD(G, W) hipLaunchKernelGGL((k_p2g_grad<G, W>), wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), \
@@ -2003,7 +2050,8 @@ void fe_destroy(FeEngine* h) {
     for (auto& t : h->tables) { for (void* q : {(void*)t.pid, (void*)t.items, (void*)t.meta, (void*)t.blk_first, (void*)t.active, (void*)t.blk_slot, (void*)t.slot_of_pid}) if (q) (void)hipFree(q); }
     void* ptrs[] = {h->frames, h->grads, h->sort_key, h->sort_rank, h->sort_cnt, h->sort_start, h->sort_src, h->sort_pid, h->slow_dev, h->frame_slow_dev, h->gstore, h->gs_flag, h->slab, h->ts_dev, h->sort_partial, h->effs_dev, h->pinfo, h->pool_idx, h->g_in, h->g_out, h->gg_out, h->gg_in,
                     h->blk_flag, h->blk_list, h->blk_count, h->err_dev, h->stage_r, h->stage_i, h->node_mark, h->counters,
-                    h->tgt, h->chamfer, h->step_loss, h->rigid_body, h->bodies_dev};
+                    h->tgt, h->chamfer, h->step_loss, h->rigid_body, h->bodies_dev, h->statics_dev};
+    for (float* v : h->statics_vox) if (v) (void)hipFree(v);
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& E : h->effs) {
         void* ep[] = {E.p.pos, E.p.quat, E.p.v, E.p.w, E.p.gpos, E.p.gquat, E.p.gv, E.p.gw, E.p.abuf, E.p.gabuf, E.p.abuf_p, E.p.gabuf_p, E.p.random_vector};
@@ -2331,6 +2379,37 @@ int fe_agent_copy_grad(FeEngine* h, int src, int dst) {
     CHECK_FRAME(h, src); CHECK_FRAME(h, dst);
     for (auto& E : h->effs) hipLaunchKernelGGL(k_eff_copy, dim3(1), dim3(64), 0, h->stream, E.p, src, dst, 1);
     return check_async(h);
+}
+
+// ---- static SDF colliders (statics.py, static.py:25-104)
+int fe_add_static(FeEngine* h, const FeSdfDesc* d, const fe_real* voxels) {
+    auto bad = [&](const char* m) { h->err = m; return -1; };
+    if (hipSetDevice(h->device) != hipSuccess) return bad("hipSetDevice failed");
+    if (!d || d->struct_size != (int)sizeof(FeSdfDesc) || d->res < 2 || !voxels) return bad("add_static: bad descriptor");
+    if ((int)h->statics_host.size() >= FE_MAX_STATICS) return bad("add_static: too many static colliders");
+    SdfP s;
+    s.res = d->res; s.friction = d->friction; s.softness = d->softness;
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) s.T[r * 4 + c] = d->T_mesh_to_voxels[r * 4 + c];
+    double A[3][3];
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) A[r][c] = d->T_mesh_to_voxels[r * 4 + c];
+    const double det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
+                       A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
+    if (det == 0.0) return bad("add_static: singular T_mesh_to_voxels");
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+        const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+        s.Rinv[j * 3 + i] = (float)((A[i1][j1] * A[i2][j2] - A[i1][j2] * A[i2][j1]) / det);
+    }
+    const size_t nv = (size_t)d->res * d->res * d->res;
+    float* vox = nullptr;
+    if (dev_alloc(h, &vox, nv, false)) return -1;
+    if (hipMemcpyOnStream(h, vox, voxels, sizeof(float) * nv, hipMemcpyHostToDevice) != hipSuccess) return bad("hipMemcpy failed");
+    s.vox = vox;
+    h->statics_vox.push_back(vox);
+    h->statics_host.push_back(s);
+    if (!h->statics_dev && dev_alloc(h, &h->statics_dev, FE_MAX_STATICS)) return -1;
+    if (hipMemcpyOnStream(h, h->statics_dev, h->statics_host.data(), sizeof(SdfP) * h->statics_host.size(), hipMemcpyHostToDevice) != hipSuccess) return bad("hipMemcpy failed");
+    h->gs_host_valid = false;
+    return (int)h->statics_host.size() - 1;
 }
 
 // ---- loss

@@ -230,6 +230,95 @@ struct BoundaryP {
     int   lock_dims;
 };
 
+// ---- SDF colliders (fluidlab/fluidengine/meshes/static.py:25-104, dynamic.py:29-122) --------------------------------
+struct SdfP {
+    int res;                 // voxels [res]^3, C order
+    const real* vox;
+    real T[12];              // rows 0..2 of T_mesh_to_voxels (mesh.py:121)
+    real Rinv[9];            // inverse(T[:3,:3]) (static.py:58)
+    real friction, softness;
+};
+// Static.sdf_ (static.py:34-49): trilinear sample in voxel coordinates, 1 outside the voxel box
+FE_HD real sdf_sample(const SdfP& s, const real pv[3]) {
+    int b[3];
+    bool outside = false;
+#pragma unroll
+    for (int d = 0; d < 3; d++) { b[d] = (int)floor(pv[d]); outside = outside || b[d] >= s.res - 1 || b[d] < 0; }
+    if (outside) return R_(1.0);
+    real f[3] = {pv[0] - (real)b[0], pv[1] - (real)b[1], pv[2] - (real)b[2]};
+    const real* v = s.vox + ((size_t)b[0] * s.res + b[1]) * s.res + b[2];
+    const size_t sy = s.res, sx = (size_t)s.res * s.res;
+    real sd = R_(0.0);
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                real w = (i ? f[0] : R_(1.0) - f[0]) * (j ? f[1] : R_(1.0) - f[1]) * (k ? f[2] : R_(1.0) - f[2]);
+                sd += w * v[i * sx + j * sy + k];
+            }
+    return sd;
+}
+FE_HD void sdf_to_voxels(const SdfP& s, const real p[3], real pv[3]) {
+    for (int d = 0; d < 3; d++) pv[d] = s.T[d * 4] * p[0] + s.T[d * 4 + 1] * p[1] + s.T[d * 4 + 2] * p[2] + s.T[d * 4 + 3];
+}
+// Static.normal (static.py:52-80): central differences (delta = 1e-2 voxels), normalised, rotated back, normalised
+FE_HD void sdf_normal(const SdfP& s, const real pv[3], real n[3]) {
+    const real delta = R_(1e-2);
+    real g[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {                    // (selects, not a runtime-indexed array: that would live in scratch)
+        const real inc[3] = {pv[0] + (d == 0 ? delta : R_(0.0)), pv[1] + (d == 1 ? delta : R_(0.0)), pv[2] + (d == 2 ? delta : R_(0.0))};
+        const real dec[3] = {pv[0] - (d == 0 ? delta : R_(0.0)), pv[1] - (d == 1 ? delta : R_(0.0)), pv[2] - (d == 2 ? delta : R_(0.0))};
+        g[d] = (sdf_sample(s, inc) - sdf_sample(s, dec)) / (R_(2.0) * delta);
+    }
+    real nn = sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2] + FE_EPS);
+    for (int d = 0; d < 3; d++) g[d] /= nn;
+    for (int d = 0; d < 3; d++) n[d] = s.Rinv[d * 3] * g[0] + s.Rinv[d * 3 + 1] * g[1] + s.Rinv[d * 3 + 2] * g[2];
+    nn = sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2] + FE_EPS);
+    for (int d = 0; d < 3; d++) n[d] /= nn;
+}
+// Contact law of Static.collide / Dynamic.collide (static.py:88-101) on the velocity relative to the collider.
+// `g`, if given, is pulled back through it in place (normal held fixed; min/max pass the gradient to the selected
+// operand).  The quotient vt/|vt| is only formed when flag = 1 (the reference's NaN * 0 for an exactly normal impact
+// is not reproduced).
+FE_HD void contact_law(const real n[3], real friction, const real rv[3], real out[3], real* g) {
+    const real nc = rv[0] * n[0] + rv[1] * n[1] + rv[2] * n[2];
+    const real a = fmin(nc, R_(0.0));
+    real vt[3] = {rv[0] - a * n[0], rv[1] - a * n[1], rv[2] - a * n[2]};
+    const real vtn = sqrt(vt[0] * vt[0] + vt[1] * vt[1] + vt[2] * vt[2]);
+    const bool flag = nc < R_(0.0) && vtn > FE_EPS;
+    const real t = vtn + nc * friction;
+    const real sc = flag ? fmax(R_(0.0), t) / vtn : R_(1.0);
+    for (int d = 0; d < 3; d++) out[d] = vt[d] * sc;
+    if (!g) return;
+    real gvt[3], gnc = R_(0.0);
+    if (flag && t > R_(0.0)) {
+        const real u[3] = {vt[0] / vtn, vt[1] / vtn, vt[2] / vtn};
+        const real ug = u[0] * g[0] + u[1] * g[1] + u[2] * g[2];
+        for (int d = 0; d < 3; d++) gvt[d] = g[d] + friction * nc * (g[d] - u[d] * ug) / vtn;
+        gnc = friction * ug;
+    } else if (flag) {
+        gvt[0] = gvt[1] = gvt[2] = R_(0.0);
+    } else {
+        for (int d = 0; d < 3; d++) gvt[d] = g[d];
+    }
+    const real ga = -(n[0] * gvt[0] + n[1] * gvt[1] + n[2] * gvt[2]);
+    if (nc < R_(0.0)) gnc += ga;
+    for (int d = 0; d < 3; d++) g[d] = gvt[d] + gnc * n[d];
+}
+// Static.collide (static.py:82-103) at world position `pos`; with g != nullptr also pulls g back
+FE_HD void static_collide(const SdfP& s, const real pos[3], real v[3], real* g) {
+    real pv[3];
+    sdf_to_voxels(s, pos, pv);
+    if (sdf_sample(s, pv) > R_(0.0)) return;
+    real n[3], out[3];
+    sdf_normal(s, pv, n);
+    contact_law(n, s.friction, v, out, g);
+    for (int d = 0; d < 3; d++) v[d] = out[d];
+}
+
 // impose_x_v velocity part (boundaries.py:40-63, 107-121): multiplies v in place, returns multipliers
 FE_HD void boundary_v(const BoundaryP& b, const real x[3], real v[3], real k[3]) {
     k[0] = k[1] = k[2] = R_(1.0);

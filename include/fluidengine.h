@@ -156,6 +156,21 @@ int fe_agent_copy_frame(FeEngine* h, int src, int dst);                         
 int fe_agent_copy_grad(FeEngine* h, int src, int dst);                            /* agent.py:122-125 */
 int fe_agent_reset_grad_till_frame(FeEngine* h, int f);                            /* agent.py:127-130, effector.py:178-183 */
 
+/* ---- static SDF colliders: fluidlab/fluidengine/meshes/static.py:25-104, statics.py, mesh.py:57-66,120-127 -------- */
+/* A collider is a signed-distance voxel grid in its own frame plus the affine map world -> voxel coordinates
+ * (Mesh.T_mesh_to_voxels after init_transform, mesh.py:121).  grid_op runs v = statics[i].collide(I*dx, v) for every
+ * static in the order they were added (mpm:386-390): inside the surface (sdf <= 0) the inward normal velocity is removed
+ * and Coulomb friction applied to the tangential part (static.py:82-103).  The normal is the normalised central
+ * difference (delta = 1e-2 voxels) of the trilinear SDF, mapped back by inverse(T[:3,:3]) (static.py:52-80). */
+typedef struct FeSdfDesc {
+    int     struct_size;
+    int     res;                     /* voxels is [res,res,res], C order                       */
+    fe_real T_mesh_to_voxels[16];    /* row-major 4x4, world/mesh position -> voxel coordinates */
+    fe_real friction;                /* FRICTION[material], macros.py:131-141                   */
+    fe_real softness;                /* Mesh.softness (dynamic colliders only)                  */
+} FeSdfDesc;
+int fe_add_static(FeEngine* h, const FeSdfDesc* desc, const fe_real* voxels);       /* returns the static's index or -1 */
+
 /* ---- loss: shapematching_loss.py:64-93 -------------------------------- */
 int fe_loss_alloc(FeEngine* h, int max_loss_steps);
 int fe_loss_set_target(FeEngine* h, int s, const fe_real* x);                     /* target['x'][s], [N,3] */

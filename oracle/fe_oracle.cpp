@@ -224,6 +224,9 @@ struct Effector {
     std::vector<int> act_range;
 };
 
+/* a Mesh with has_dynamics: SDF voxels + world->voxel map (mesh.py:57-66,120-127) */
+struct Sdf { int res; std::vector<R> vox; R T[16]; R Rinv[9]; R friction, softness; };
+
 /* body_state of mpm:181-189 plus its adjoint */
 struct Body { R com0[3], com1[3]; M3 H, Rm, U, S, V; R gcom0[3], gcom1[3]; M3 gH, gR, gU, gS, gV; };
 
@@ -245,6 +248,7 @@ struct FeEngine {
     std::vector<Body> bodies;
     std::vector<R> g_vin, g_mass, g_vout, gg_vin, gg_mass, gg_vout;
     std::vector<Effector> effs;
+    std::vector<Sdf> statics;        /* statics.py */
     int loss_steps = 0;
     std::vector<R> tgt;          /* [loss_steps, N, 3] */
     std::vector<R> chamfer, step_loss;
@@ -447,6 +451,98 @@ void effector_move(Effector& e, int f) {
 
 /* mpm:380-398 (no statics / agent colliders in this scope: LatteArt's cup has
  * has_dynamics=False and AgentInjector.collide is the identity, agent_injector.py:34-36) */
+
+/* ------------------------------------------------------------------ SDF colliders */
+
+/* Static.sdf_ (static.py:34-49): trilinear sample in voxel coordinates, 1.0 outside the voxel box */
+R sdf_sample(const Sdf& s, const R pv[3]) {
+    int base[3];
+    for (int d = 0; d < 3; d++) {
+        base[d] = (int)std::floor(pv[d]);
+        if (base[d] >= s.res - 1 || base[d] < 0) return (R)1.0;
+    }
+    R sd = 0;
+    for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) for (int k = 0; k < 2; k++) {
+        const int vp[3] = {base[0] + i, base[1] + j, base[2] + k};
+        R w = 1;
+        for (int d = 0; d < 3; d++) w *= 1 - std::fabs(pv[d] - vp[d]);
+        sd += w * s.vox[((size_t)vp[0] * s.res + vp[1]) * s.res + vp[2]];
+    }
+    return sd;
+}
+void sdf_to_voxels(const Sdf& s, const R pm[3], R pv[3]) {                     /* geom.transform_by_T_ti */
+    for (int d = 0; d < 3; d++) pv[d] = s.T[d * 4] * pm[0] + s.T[d * 4 + 1] * pm[1] + s.T[d * 4 + 2] * pm[2] + s.T[d * 4 + 3];
+}
+/* Static.normal (static.py:52-80): central differences with delta = 1e-2 in voxel space, normalised, rotated back by
+ * inverse(T[:3,:3]), normalised again; normalize(v) = v / sqrt(|v|^2 + EPS) (geom.py:93-94) */
+void sdf_normal(const Sdf& s, const R pv[3], R n[3]) {
+    const R delta = (R)1e-2;
+    R g[3];
+    for (int d = 0; d < 3; d++) {
+        R inc[3] = {pv[0], pv[1], pv[2]}, dec[3] = {pv[0], pv[1], pv[2]};
+        inc[d] += delta; dec[d] -= delta;
+        g[d] = (sdf_sample(s, inc) - sdf_sample(s, dec)) / (2 * delta);
+    }
+    R nn = std::sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2] + EPS);
+    for (int d = 0; d < 3; d++) g[d] /= nn;
+    for (int d = 0; d < 3; d++) n[d] = s.Rinv[d * 3] * g[0] + s.Rinv[d * 3 + 1] * g[1] + s.Rinv[d * 3 + 2] * g[2];
+    nn = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2] + EPS);
+    for (int d = 0; d < 3; d++) n[d] /= nn;
+}
+/* The contact law shared by Static.collide (static.py:82-103) and Dynamic.collide (dynamic.py:104-122), on the
+ * velocity relative to the collider: remove the inward normal part, Coulomb friction on the tangential part.
+ * Conscious fix: the reference evaluates rel_v_t / |rel_v_t| unconditionally and multiplies by flag = 0 when
+ * |rel_v_t| <= EPS, which is NaN * 0 = NaN for an exactly normal impact; here the quotient is only formed when flag = 1.
+ * If `g` is given it is pulled back through the law (adjoint w.r.t. rel_v with the normal held fixed; Taichi's
+ * min/max pass the gradient to the selected operand). */
+void contact_law(const R n[3], R friction, const R rv[3], R out[3], R* g) {
+    const R nc = rv[0] * n[0] + rv[1] * n[1] + rv[2] * n[2];
+    const R a = std::min(nc, (R)0);
+    R vt[3] = {rv[0] - a * n[0], rv[1] - a * n[1], rv[2] - a * n[2]};
+    const R vtn = std::sqrt(vt[0] * vt[0] + vt[1] * vt[1] + vt[2] * vt[2]);
+    const bool flag = nc < 0 && vtn > EPS;
+    const R t = vtn + nc * friction;
+    if (flag) {
+        const R sc = std::max((R)0, t) / vtn;
+        for (int d = 0; d < 3; d++) out[d] = vt[d] * sc;
+    } else {
+        for (int d = 0; d < 3; d++) out[d] = vt[d];
+    }
+    if (!g) return;
+    R gvt[3], gnc = 0;
+    if (flag && t > 0) {
+        R u[3] = {vt[0] / vtn, vt[1] / vtn, vt[2] / vtn};
+        const R ug = u[0] * g[0] + u[1] * g[1] + u[2] * g[2];
+        /* out = vt + friction * nc * u */
+        for (int d = 0; d < 3; d++) gvt[d] = g[d] + friction * nc * (g[d] - u[d] * ug) / vtn;
+        gnc = friction * ug;
+    } else if (flag) {
+        gvt[0] = gvt[1] = gvt[2] = 0;
+    } else {
+        for (int d = 0; d < 3; d++) gvt[d] = g[d];
+    }
+    const R ga = -(n[0] * gvt[0] + n[1] * gvt[1] + n[2] * gvt[2]);
+    if (nc < 0) gnc += ga;
+    for (int d = 0; d < 3; d++) g[d] = gvt[d] + gnc * n[d];
+}
+/* Static.collide (static.py:82-103); with g != nullptr also pulls g back (in place) */
+void static_collide(const Sdf& s, const R pos[3], R v[3], R* g) {
+    R pv[3];
+    sdf_to_voxels(s, pos, pv);
+    if (sdf_sample(s, pv) > 0) return;
+    R n[3], out[3];
+    sdf_normal(s, pv, n);
+    contact_law(n, s.friction, v, out, g);
+    for (int d = 0; d < 3; d++) v[d] = out[d];
+}
+/* the collider chain of grid_op (mpm:386-390) for one node; returns the velocities before each static */
+void statics_forward(FeEngine* h, const R xn[3], R vo[3], std::vector<R>* trace) {
+    for (const Sdf& s : h->statics) {
+        if (trace) { trace->push_back(vo[0]); trace->push_back(vo[1]); trace->push_back(vo[2]); }
+        static_collide(s, xn, vo, nullptr);
+    }
+}
+
 void grid_op(FeEngine* h) {
     const int n = h->n;
     const size_t n3 = (size_t)n * n * n;
@@ -460,6 +556,7 @@ void grid_op(FeEngine* h) {
             int i = (int)(c / ((size_t)n * n)), j = (int)((c / n) % n), k = (int)(c % n);
             R xn[3] = {i * h->dx, j * h->dx, k * h->dx};
             R kk[3];
+            if (!h->statics.empty()) statics_forward(h, xn, vo, nullptr);                   /* mpm:386-390 */
             impose_v(h->cfg.boundary, xn, vo, kk);
             for (int a = 0; a < 3; a++) h->g_vout[c * 3 + a] = vo[a];
         }
@@ -667,10 +764,18 @@ void grid_op_grad(FeEngine* h) {
             int i = (int)(c / ((size_t)n * n)), j = (int)((c / n) % n), k = (int)(c % n);
             R xn[3] = {i * h->dx, j * h->dx, k * h->dx};
             R kk[3];
+            std::vector<R> trace;
+            if (!h->statics.empty()) statics_forward(h, xn, vo, &trace);
             impose_v(h->cfg.boundary, xn, vo, kk);
+            R gv[3];
+            for (int a = 0; a < 3; a++) gv[a] = h->gg_vout[c * 3 + a] * kk[a];
+            for (int si = (int)h->statics.size() - 1; si >= 0; si--) {                      /* colliders, in reverse */
+                R vin[3] = {trace[si * 3], trace[si * 3 + 1], trace[si * 3 + 2]};
+                static_collide(h->statics[si], xn, vin, gv);
+            }
             R gm = 0;
             for (int a = 0; a < 3; a++) {
-                R g = h->gg_vout[c * 3 + a] * kk[a];
+                R g = gv[a];
                 h->gg_vin[c * 3 + a] += g * inv;
                 gm += -h->g_vin[c * 3 + a] * g * inv * inv;
             }
@@ -1137,6 +1242,25 @@ int fe_agent_copy_grad(FeEngine* h, int src, int dst) {
         for (int j = 0; j < 4; j++) E.gquat[dst * 4 + j] = E.gquat[src * 4 + j];
     }
     return 0;
+}
+
+int fe_add_static(FeEngine* h, const FeSdfDesc* d, const fe_real* voxels) {
+    if (!d || d->struct_size != (int)sizeof(FeSdfDesc) || d->res < 2 || !voxels) { h->err = "add_static: bad descriptor"; return -1; }
+    Sdf s;
+    s.res = d->res; s.friction = d->friction; s.softness = d->softness;
+    s.vox.assign(voxels, voxels + (size_t)d->res * d->res * d->res);
+    for (int i = 0; i < 16; i++) s.T[i] = d->T_mesh_to_voxels[i];
+    M3 A;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) A.m[i][j] = s.T[i * 4 + j];
+    const R det = A.m[0][0] * (A.m[1][1] * A.m[2][2] - A.m[1][2] * A.m[2][1]) - A.m[0][1] * (A.m[1][0] * A.m[2][2] - A.m[1][2] * A.m[2][0]) +
+                  A.m[0][2] * (A.m[1][0] * A.m[2][1] - A.m[1][1] * A.m[2][0]);
+    if (det == 0) { h->err = "add_static: singular T_mesh_to_voxels"; return -1; }
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {       /* inverse = adj / det */
+        const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+        s.Rinv[j * 3 + i] = (A.m[i1][j1] * A.m[i2][j2] - A.m[i1][j2] * A.m[i2][j1]) / det;
+    }
+    h->statics.push_back(std::move(s));
+    return (int)h->statics.size() - 1;
 }
 
 /* ---- loss */

@@ -58,7 +58,48 @@ def boundary_v(bnd, xn, v):
     return v
 
 
-def substep(x, v, C, F, used, mu, lam, mass, mat_cls, n_grid, dt, p_vol, gravity, bnd, body_id=None):
+def _sdf_sample(vox, pv):
+    """static.py:34-49, vectorised over rows of pv"""
+    res = vox.shape[0]
+    base = np.floor(pv).astype(int)
+    outside = ((base >= res - 1) | (base < 0)).any(1)
+    b = np.clip(base, 0, res - 2)
+    sd = np.zeros(len(pv))
+    for i in range(2):
+        for j in range(2):
+            for k in range(2):
+                vp = b + [i, j, k]
+                w = np.prod(1 - np.abs(pv - vp), axis=1)
+                sd += w * vox[vp[:, 0], vp[:, 1], vp[:, 2]]
+    return np.where(outside, 1.0, sd)
+
+
+def static_collide(static, xn, v):
+    """Static.collide (static.py:82-103) for node positions xn [M,3] and velocities v [M,3]"""
+    vox, T, mu_f = np.asarray(static['voxels'], np.float64), np.asarray(static['T'], np.float64), static['friction']
+    pv = xn @ T[:3, :3].T + T[:3, 3]
+    hit = _sdf_sample(vox, pv) <= 0
+    if not hit.any():
+        return v
+    pv_h, vh = pv[hit], v[hit]
+    g = np.zeros_like(pv_h)
+    for d in range(3):
+        e = np.zeros(3); e[d] = 1e-2
+        g[:, d] = (_sdf_sample(vox, pv_h + e) - _sdf_sample(vox, pv_h - e)) / 2e-2
+    g /= np.sqrt((g ** 2).sum(1) + EPS)[:, None]
+    n = g @ np.linalg.inv(T[:3, :3]).T
+    n /= np.sqrt((n ** 2).sum(1) + EPS)[:, None]
+    nc = (vh * n).sum(1)
+    vt = vh - np.minimum(nc, 0)[:, None] * n
+    vtn = np.linalg.norm(vt, axis=1)
+    flag = (nc < 0) & (vtn > EPS)
+    scale = np.where(flag, np.maximum(0, vtn + nc * mu_f) / np.where(vtn > 0, vtn, 1.0), 1.0)
+    out = v.copy()
+    out[hit] = vt * scale[:, None]
+    return out
+
+
+def substep(x, v, C, F, used, mu, lam, mass, mat_cls, n_grid, dt, p_vol, gravity, bnd, body_id=None, statics=()):
     """One forward substep (mpm:515-533, no agent).  Returns x', v', C', F'."""
     n = n_grid
     dx, inv_dx = 1.0 / n, float(n)
@@ -99,6 +140,8 @@ def substep(x, v, C, F, used, mu, lam, mass, mat_cls, n_grid, dt, p_vol, gravity
     ii, jj, kk = np.nonzero(occ)
     vo = g_v[occ] / g_m[occ][:, None] + dt * np.asarray(gravity)
     xn = np.stack([ii, jj, kk], 1) * dx
+    for st in statics:                                                  # mpm:386-390
+        vo = static_collide(st, xn, vo)
     v_out[occ] = boundary_v(bnd, xn, vo)
     # g2p (mpm:400-426)
     nv = np.zeros_like(vs)

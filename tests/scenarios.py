@@ -71,6 +71,29 @@ def rigid_in_water(n_grid=16, n_water=1200, n_rigid=(150, 90), seed=5):
                 body_id=np.concatenate(bids).astype(np.int32))
 
 
+def sphere_sdf(center, radius, res=24, lo=0.0, hi=1.0):
+    """Voxelised signed distance of a sphere over the world box [lo, hi]^3, in the layout of the reference's .sdf
+    pickles ({'voxels': [res^3], 'T_mesh_to_voxels': 4x4}, mesh.py:63-66): voxel index = (res - 1) * (x - lo) / (hi - lo)."""
+    g = np.linspace(lo, hi, res)
+    X, Y, Z = np.meshgrid(g, g, g, indexing='ij')
+    vox = np.sqrt((X - center[0]) ** 2 + (Y - center[1]) ** 2 + (Z - center[2]) ** 2) - radius
+    sc = (res - 1) / (hi - lo)
+    T = np.array([[sc, 0, 0, -lo * sc], [0, sc, 0, -lo * sc], [0, 0, sc, -lo * sc], [0, 0, 0, 1.0]])
+    return f32(vox), T
+
+
+def water_on_obstacles(n_grid=16, n_particles=1500, seed=7):
+    """A water block falling sideways onto two static SDF colliders (static.py:82-103): a frictional sphere inside the
+    block and a frictionless one it slides along -- nodes inside either surface take the contact branch."""
+    sc = water_block(n_grid=n_grid, n_particles=n_particles, seed=seed, lo=0.3, hi=0.6, gravity=(3.0, -10.0, 1.0))
+    rng = np.random.RandomState(seed)
+    sc['v'] = f32(rng.normal(0, 0.4, (n_particles, 3)) + [0.5, -1.0, 0.2])
+    v1, T1 = sphere_sdf((0.42, 0.30, 0.45), 0.12)
+    v2, T2 = sphere_sdf((0.62, 0.40, 0.50), 0.10, res=20, lo=0.2, hi=0.9)
+    sc['statics'] = [dict(voxels=v1, T=T1, friction=0.5), dict(voxels=v2, T=T2, friction=0.0)]
+    return sc
+
+
 def latte_mini(n_grid=16, n_coffee=1200, n_pool=200, seed=2, horizon=6, n_substeps=4, flux=2):
     """A small LatteArt: coffee in a cylinder, a milk pool injected by an Injector effector
     (latteart_env.py:38-75, agent_latteart.yaml), squared-distance loss on the milk."""
@@ -111,6 +134,8 @@ def make_engine(elib, sc, max_substeps_local=None, device=0, options=None):
                  boundary=elib.make_boundary(**sc['boundary']), device=device)
     for k, v in (options or sc.get('options') or {}).items():
         eng.set_option(k, v)
+    for st in sc.get('statics', ()):
+        eng.add_static(st['voxels'], st['T'], friction=st['friction'])
     mat = sc['mat']
     props = np.array([MATERIALS[int(m)] for m in mat], dtype=np.float64)
     eng.init_particles(sc['x'], sc['used'], mat, props[:, 3].astype(np.int32), props[:, 0], props[:, 1], props[:, 2],

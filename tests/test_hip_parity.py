@@ -73,6 +73,24 @@ def test_substep_adjoint(hiplib, oracle64, scene, K):
         assert S.rel_l2(ga[k], gb[k]) <= tol_l2, (k, S.rel_l2(ga[k], gb[k]))
 
 
+@pytest.mark.parametrize('K', [0, 10])
+def test_static_sdf_colliders(hiplib, oracle64, K):
+    """grid_op's collide-with-statics (mpm:386-390, static.py:82-103): trilinear SDF, finite-difference normal, contact
+    law with Coulomb friction -- forward and adjoint, two colliders in sequence."""
+    sc = S.water_on_obstacles()
+    cot = S.random_cotangent(sc['N'])
+    sa, ga = S.run_forward_backward(S.make_engine(hiplib, sc, options={'sort_interval': K}), 8, cot)
+    sb, gb = S.run_forward_backward(S.make_engine(oracle64, sc), 8, {k: v.astype(np.float64) for k, v in cot.items()})
+    free = S.run_forward(S.make_engine(hiplib, {k: v for k, v in sc.items() if k != 'statics'}), 8)
+    assert np.abs(sa['v'] - free['v']).max() > 0.05                      # the colliders act
+    assert np.abs(sa['x'] - sb['x']).max() <= 2e-6
+    assert S.rel_l2(sa['v'], sb['v']) <= 1e-3
+    for k in ('gx', 'gv', 'gC', 'gF'):
+        assert np.isfinite(ga[k]).all(), k
+        assert S.cosine(ga[k], gb[k]) >= 0.999, (k, S.cosine(ga[k], gb[k]))
+        assert S.rel_l2(ga[k], gb[k]) <= 1e-2, (k, S.rel_l2(ga[k], gb[k]))
+
+
 @pytest.mark.parametrize('K', [0, 3, 10])
 def test_rigid_bodies(hiplib, oracle64, K):
     """MAT_RIGID shape matching (mpm:428-505): per-body COM/covariance reductions, 3x3 SVD, rotation, and the adjoint

@@ -59,6 +59,34 @@ def test_rigid_shape_matching_matches_numpy(oracle64):
         assert np.abs(got['x'][sel] - x0[sel]).max() > 1e-4    # and the body did move
 
 
+def test_static_colliders_match_numpy(oracle64):
+    """Static SDF colliders (static.py:25-104) in grid_op: C++ restatement against the numpy one; the obstacles must
+    actually be hit, and no colliding node may keep an inward normal velocity."""
+    sc = S.water_on_obstacles()
+    eng = S.make_engine(oracle64, sc)
+    free = S.make_engine(oracle64, {k: v for k, v in sc.items() if k != 'statics'})
+    st = S.get_state(eng, 0)
+    props = np.array([S.MATERIALS[int(m)] for m in sc['mat']])
+    n = sc['n_grid']
+    x, v, C, F = (st[k].astype(np.float64) for k in 'xvCF')
+    hit_nodes = 0
+    for f in range(6):
+        eng.substep(f, f, 0); free.substep(f, f, 0)
+        x, v, C, F, aux = mpm_numpy.substep(x, v, C, F, sc['used'], props[:, 0], props[:, 1], (0.5 / n) ** 2 * props[:, 2],
+                                            props[:, 3].astype(int), n, sc['dt'], (0.5 / n) ** 2, sc['gravity'], sc['boundary'],
+                                            statics=sc['statics'])
+        occ = np.argwhere(aux['grid_mass'] > 1e-12) / n
+        for s_ in sc['statics']:
+            T = np.asarray(s_['T'], np.float64)
+            inside = mpm_numpy._sdf_sample(np.asarray(s_['voxels'], np.float64), occ @ T[:3, :3].T + T[:3, 3]) <= 0
+            hit_nodes += int(inside.sum())
+    got, got_free = S.get_state(eng, 6), S.get_state(free, 6)
+    for k, ref in zip('xvCF', (x, v, C, F)):
+        assert np.abs(got[k] - ref).max() < 1e-9 * max(1.0, np.abs(ref).max()), k
+    assert hit_nodes > 100
+    assert np.abs(got['v'] - got_free['v']).max() > 0.05           # the colliders changed the flow
+
+
 def test_cylinder_boundary_matches_numpy(oracle64):
     sc = S.latte_mini()
     sc = dict(sc, used=np.where(sc['used'] == 1, 1, 0).astype(np.int32))
@@ -111,11 +139,14 @@ def _loss_of(eng, sc, n_sub, cot, x=None, v=None, C=None, F=None):
     return float((st['x'] * cot['gx']).sum() + (st['v'] * cot['gv']).sum() + (st['C'] * cot['gC']).sum() + (st['F'] * cot['gF']).sum())
 
 
-@pytest.mark.parametrize('scene', ['mixed', 'water_wall', 'rigid'])
+@pytest.mark.parametrize('scene', ['mixed', 'water_wall', 'rigid', 'statics'])
 def test_substep_adjoint_vs_finite_differences(oracle64, scene):
     if scene == 'mixed':
         sc = S.mixed_materials(n_grid=8, n_particles=40, seed=3)
         sc['x'] = S.f32(np.random.RandomState(3).uniform(0.3, 0.62, (40, 3)))
+    elif scene == 'statics':
+        # static SDF colliders in grid_op: contact branch (normal removal + Coulomb friction) and its adjoint
+        sc = S.water_on_obstacles(n_grid=8, n_particles=60)
     elif scene == 'rigid':
         # MAT_RIGID shape matching: COM / covariance / SVD / rotation chain and its adjoint (mpm:436-505)
         sc = S.rigid_in_water(n_grid=8, n_water=30, n_rigid=(12, 9), seed=6)
