@@ -1,0 +1,138 @@
+"""Static SDF colliders -- fluidlab/fluidengine/meshes/{mesh,static,statics}.py.
+
+The reference turns a triangle mesh into a signed-distance voxel grid with `mesh_to_sdf` + `trimesh` (utils/mesh.py:
+63-87) and caches it as a pickle {'voxels': [res^3], 'T_mesh_to_voxels': 4x4}.  Neither package exists in this image
+and the reference ships no processed .sdf blobs, so a collider's SDF comes from one of:
+  * `sdf=<path>`   a pickle in the reference's format (produced by the reference's tooling elsewhere),
+  * `sdf=<dict>`   the same two arrays in memory,
+  * `sdf=<callable>` an analytic signed distance f(points[N,3]) -> [N] in the *mesh frame* (the normalised frame the
+    reference's meshes live in, roughly [-0.5, 0.5]^3); it is sampled on exactly the query lattice of
+    compute_sdf_data (voxels_radius 0.6, `sdf_res` points per axis), so T_mesh_to_voxels is the reference's.
+Pose handling follows Mesh.init_transform (mesh.py:97-127): T_mesh_to_voxels @ inverse(T_init), T_init = trans * rot *
+scale with euler given in degrees as (x, y, z) and composed 'zyx'.  Collision itself (sdf_, normal_, collide:
+static.py:25-104) runs inside the engine's grid_op; this class only prepares its inputs."""
+import pickle as pkl
+
+import numpy as np
+from scipy.spatial.transform import Rotation
+
+from fluidlab_amd.configs.macros import FRICTION
+from fluidlab_amd.utils.misc import eval_str
+
+VOXELS_RADIUS = 0.6          # utils/mesh.py:69
+
+
+def sample_sdf(fn, res):
+    """compute_sdf_data (utils/mesh.py:63-87) with an analytic distance instead of mesh_to_sdf."""
+    g = np.linspace(-VOXELS_RADIUS, VOXELS_RADIUS, res)
+    X, Y, Z = np.meshgrid(g, g, g, indexing='ij')
+    pts = np.stack([X, Y, Z], axis=-1).reshape((-1, 3))
+    voxels = np.asarray(fn(pts), dtype=np.float64).reshape([res, res, res])
+    T = np.eye(4)
+    T[:3, :3] *= (res - 1) / (VOXELS_RADIUS * 2)
+    T[:3, 3] = (res - 1) / 2
+    return {'voxels': voxels, 'T_mesh_to_voxels': T}
+
+
+# ---- analytic shapes in the mesh frame ---------------------------------------------------------------------------
+def sdf_sphere(radius=0.5, center=(0.0, 0.0, 0.0)):
+    c = np.asarray(center, np.float64)
+    return lambda p: np.linalg.norm(p - c, axis=1) - radius
+
+
+def sdf_box(half_extents=(0.5, 0.5, 0.5)):
+    h = np.asarray(half_extents, np.float64)
+
+    def fn(p):
+        q = np.abs(p) - h
+        return np.linalg.norm(np.maximum(q, 0), axis=1) + np.minimum(q.max(axis=1), 0)
+    return fn
+
+
+def sdf_cylinder(radius=0.5, half_height=0.5):
+    """axis along y"""
+    def fn(p):
+        d = np.stack([np.hypot(p[:, 0], p[:, 2]) - radius, np.abs(p[:, 1]) - half_height], axis=1)
+        return np.minimum(d.max(axis=1), 0) + np.linalg.norm(np.maximum(d, 0), axis=1)
+    return fn
+
+
+def sdf_cup(radius=0.5, half_height=0.5, wall=0.08):
+    """an open-top cup (the role of the reference's cup/bowl/tank meshes): outer cylinder minus an inner cavity that
+    reaches through the top"""
+    outer = sdf_cylinder(radius, half_height)
+    inner = sdf_cylinder(radius - wall, half_height)
+
+    def fn(p):
+        q = p.copy(); q[:, 1] -= wall                         # the cavity starts `wall` above the bottom
+        return np.maximum(outer(p), -inner(q))
+    return fn
+
+
+class Static:
+    """Static mesh-based collider (static.py).  Only the collision inputs are kept; vertices/colours are renderer data."""
+
+    def __init__(self, material, file=None, sdf=None, sdf_res=128, pos=(0.0, 0.0, 0.0), euler=(0.0, 0.0, 0.0),
+                 scale=(1.0, 1.0, 1.0), softness=0, has_dynamics=False, file_vis=None):
+        self.pos = np.asarray(eval_str(pos), np.float64)
+        self.euler = np.asarray(eval_str(euler), np.float64)
+        self.scale = np.asarray(eval_str(scale), np.float64) * np.ones(3)
+        self.raw_file = file
+        self.sdf_res = sdf_res
+        self.material = eval_str(material)
+        self.has_dynamics = has_dynamics
+        self.softness = softness
+        if not has_dynamics:
+            return                                             # visual only: Static.collide is the identity (static.py:83)
+        self.friction = FRICTION[self.material]                # mesh.py:60
+        if sdf is None:
+            raise NotImplementedError(
+                f'static {file!r}: mesh -> SDF conversion needs trimesh + mesh_to_sdf, which this image lacks; pass '
+                f'sdf=<pickle path | dict | analytic callable> (fluidlab_amd/fluidengine/meshes.py)')
+        if callable(sdf):
+            sdf_data = sample_sdf(sdf, sdf_res)
+        elif isinstance(sdf, dict):
+            sdf_data = sdf
+        else:
+            with open(sdf, 'rb') as fh:
+                sdf_data = pkl.load(fh)
+        self.sdf_voxels_np = np.asarray(sdf_data['voxels'], np.float64)
+        self.sdf_voxels_res = self.sdf_voxels_np.shape[0]
+        # init_transform, mesh.py:97-103,121: scale, then rotate, then translate
+        rot = Rotation.from_euler('zyx', self.euler[::-1], degrees=True).as_matrix()
+        T_init = np.eye(4)
+        T_init[:3, :3] = rot @ np.diag(self.scale)
+        T_init[:3, 3] = self.pos
+        self.T_mesh_to_voxels_np = np.asarray(sdf_data['T_mesh_to_voxels'], np.float64) @ np.linalg.inv(T_init)
+
+    def sdf(self, pos_world):
+        """host mirror of Static.sdf (static.py:26-49) for tests and scene building"""
+        T = self.T_mesh_to_voxels_np
+        pv = np.atleast_2d(pos_world) @ T[:3, :3].T + T[:3, 3]
+        res = self.sdf_voxels_res
+        base = np.floor(pv).astype(int)
+        outside = ((base >= res - 1) | (base < 0)).any(1)
+        b = np.clip(base, 0, res - 2)
+        sd = np.zeros(len(pv))
+        for i in range(2):
+            for j in range(2):
+                for k in range(2):
+                    vp = b + [i, j, k]
+                    sd += np.prod(1 - np.abs(pv - vp), axis=1) * self.sdf_voxels_np[vp[:, 0], vp[:, 1], vp[:, 2]]
+        return np.where(outside, 1.0, sd)
+
+
+class Statics:
+    """statics.py"""
+
+    def __init__(self):
+        self.statics = []
+
+    def add_static(self, **kwargs):
+        self.statics.append(Static(**kwargs))
+
+    def __getitem__(self, index):
+        return self.statics[index]
+
+    def __len__(self):
+        return len(self.statics)

@@ -109,6 +109,13 @@ class MPMSimulator:
         else:
             self.particles = None
 
+        # static SDF colliders of grid_op (mpm:386-390): voxels + world->voxel map + friction go to the engine
+        if statics is not None:
+            for st in statics:
+                if st.has_dynamics:
+                    self.engine.add_static(st.sdf_voxels_np.astype(self.dtype), st.T_mesh_to_voxels_np, friction=st.friction,
+                                           softness=st.softness)
+
         self.agent = agent
         self.smoke_field = smoke_field
         self.cur_substep_global = 0

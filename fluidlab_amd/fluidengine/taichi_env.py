@@ -1,25 +1,16 @@
 """TaichiEnv -- wires simulator, agent, bodies and loss together (fluidlab/fluidengine/taichi_env.py).
 
 The name is kept so the reference's envs / optimiser import it unchanged; there is no Taichi here
-(no ti.init, taichi_env.py:12): the simulator drives the MI355X HIP engine.  Renderers, SDF statics and the
-smoke field are outside this build (#10-#13)."""
+(no ti.init, taichi_env.py:12): the simulator drives the MI355X HIP engine.  Renderers and the smoke field are
+outside this build (#10-#13)."""
 import numpy as np
 
 from fluidlab_amd.configs.macros import DTYPE_NP
 from fluidlab_amd.fluidengine import agents as _agents
 from fluidlab_amd.fluidengine.bodies import Bodies
+from fluidlab_amd.fluidengine.meshes import Statics
 from fluidlab_amd.fluidengine.simulators import MPMSimulator
 from fluidlab_amd.utils.config import CfgNode
-
-
-class Statics(list):
-    """Static colliders.  Only has_dynamics=False statics (visual, Static.collide is the identity:
-    static.py:83) are accepted until the SDF colliders of SURVEY 8f-1 exist."""
-
-    def add_static(self, has_dynamics=False, **kwargs):
-        if has_dynamics:
-            raise NotImplementedError('SDF static colliders are not built yet (SURVEY 8f-1)')
-        self.append(dict(kwargs, has_dynamics=False))
 
 
 class TaichiEnv:

@@ -59,3 +59,14 @@ def test_solver_reduces_loss_on_hip(hiplib):
     losses = []
     Solver(env, None, cfg).solve(callback=lambda it, info, pol: losses.append(info['loss']))
     assert losses[0] > losses[1] > losses[2] > 0
+
+
+def test_static_cup_through_python_stack(hiplib, oracle32):
+    """Same analytic-cup scene on the HIP engine and on the oracle through TaichiEnv.add_static (meshes.py)."""
+    import test_host_env as H
+    a, b = H._cup_scene(None), H._cup_scene(oracle32)
+    for _ in range(60):
+        a.step(None); b.step(None)
+    xa, xb = a.get_state()['state']['x'], b.get_state()['state']['x']
+    assert np.isfinite(xa).all()
+    assert np.abs(xa - xb).max() <= 2e-4          # fp32 engine vs fp32 oracle over 600 substeps with contact

@@ -145,3 +145,45 @@ def test_rigid_body_through_the_python_stack(oracle64):
     d1 = np.linalg.norm(x1[rigid][:, None] - x1[rigid][None], axis=2)
     assert np.abs(d1 - d0).max() < 1e-10
     assert (x0[rigid][:, 1] - x1[rigid][:, 1]).min() > 1e-4        # it fell
+
+
+def _cup_scene(engine_lib, quality=0.5, density=1.5e5):
+    from fluidlab_amd.configs.macros import CUP, WATER
+    from fluidlab_amd.fluidengine.meshes import sdf_cup
+    from fluidlab_amd.fluidengine.taichi_env import TaichiEnv
+    np.random.seed(0)
+    te = TaichiEnv(dim=3, quality=quality, particle_density=density, horizon=140, gravity=(0.0, -10.0, 0.0), engine_lib=engine_lib)
+    te.setup_boundary(type='cube', lower=(0.05, 0.05, 0.05), upper=(0.95, 0.95, 0.95))
+    # a cup of outer radius 0.25 and height 0.3 standing at y in [0.2, 0.5], scaled/placed like a reference static
+    te.add_static(file='cup.obj', material=CUP, has_dynamics=True, sdf=sdf_cup(0.5, 0.5, 0.2), sdf_res=48,        # walls >= 2 dx thick: contact acts on grid nodes
+                  pos=(0.5, 0.35, 0.5), euler=(0.0, 0.0, 0.0), scale=(0.5, 0.3, 0.5))
+    te.add_body(type='cube', lower=(0.44, 0.40, 0.44), upper=(0.56, 0.62, 0.56), material=WATER)
+    te.build()
+    return te
+
+
+def test_static_cup_holds_water(oracle32):
+    """TaichiEnv.add_static -> Static (mesh.py:97-127 pose handling) -> engine colliders: water dropped into an analytic
+    cup stays inside it instead of falling to the floor of the domain."""
+    te = _cup_scene(oracle32)
+    st = te.statics[0]
+    assert st.sdf([[0.5, 0.22, 0.5]])[0] < 0 < st.sdf([[0.5, 0.40, 0.5]])[0]        # bottom plate solid, cavity empty
+    assert st.sdf([[0.5 + 0.2, 0.35, 0.5]])[0] < 0                                  # side wall solid
+    for _ in range(130):
+        te.step(None)
+    x = te.get_state()['state']['x']
+    r = np.hypot(x[:, 0] - 0.5, x[:, 2] - 0.5)
+    assert np.isfinite(x).all()
+    assert x[:, 1].min() > 0.2                      # nothing fell through the bottom (floor of the cup at y = 0.2 + wall)
+    assert (r < 0.25).mean() > 0.97                 # and the walls hold it
+    # without the cup the same water reaches the domain floor
+    from fluidlab_amd.fluidengine.taichi_env import TaichiEnv
+    from fluidlab_amd.configs.macros import WATER
+    np.random.seed(0)
+    free = TaichiEnv(dim=3, quality=0.5, particle_density=1.5e5, horizon=140, gravity=(0.0, -10.0, 0.0), engine_lib=oracle32)
+    free.setup_boundary(type='cube', lower=(0.05, 0.05, 0.05), upper=(0.95, 0.95, 0.95))
+    free.add_body(type='cube', lower=(0.44, 0.40, 0.44), upper=(0.56, 0.62, 0.56), material=WATER)
+    free.build()
+    for _ in range(130):
+        free.step(None)
+    assert free.get_state()['state']['x'][:, 1].min() < 0.2
