@@ -60,7 +60,7 @@ ABI_SYMBOLS = [
     'fe_set_option', 'fe_init_particles', 'fe_substep', 'fe_substep_grad', 'fe_step',
     'fe_step_grad', 'fe_get_frame', 'fe_set_frame', 'fe_copy_frame', 'fe_copy_grad',
     'fe_reset_grad', 'fe_reset_grad_till_frame', 'fe_get_grad', 'fe_add_grad', 'fe_get_mat',
-    'fe_add_static', 'fe_add_effector', 'fe_eff_set_act_range', 'fe_eff_get_state', 'fe_eff_set_state',
+    'fe_add_static', 'fe_eff_set_mesh', 'fe_add_effector', 'fe_eff_set_act_range', 'fe_eff_get_state', 'fe_eff_set_state',
     'fe_eff_get_vw', 'fe_eff_set_vw', 'fe_eff_set_action', 'fe_eff_set_action_grad',
     'fe_eff_apply_action_p', 'fe_eff_apply_action_p_grad', 'fe_eff_get_action_grad',
     'fe_agent_copy_frame', 'fe_agent_copy_grad', 'fe_agent_reset_grad_till_frame', 'fe_loss_alloc', 'fe_loss_set_target',
@@ -323,6 +323,18 @@ class Engine:
         if i < 0:
             raise FeEngineError(self.lib.fe_last_error(self.h).decode())
         return i
+
+    def eff_set_mesh(self, e, voxels, T_mesh_to_voxels, friction=0.0, softness=0.0):
+        """Rigid.setup_mesh (rigid.py:19-24): effector e becomes a moving SDF collider."""
+        keep, pv = self._r(voxels)
+        assert keep.ndim == 3 and keep.shape[0] == keep.shape[1] == keep.shape[2]
+        d = self.elib.FeSdfDesc()
+        d.struct_size = C.sizeof(self.elib.FeSdfDesc)
+        d.res = int(keep.shape[0])
+        d.T_mesh_to_voxels[:] = [float(t) for t in np.asarray(T_mesh_to_voxels, np.float64).reshape(16)]
+        d.friction = float(friction)
+        d.softness = float(softness)
+        self._ck(self.lib.fe_eff_set_mesh(self.h, int(e), C.byref(d), pv))
 
     def eff_set_act_range(self, e, act_range):
         k, p = self._i(act_range)

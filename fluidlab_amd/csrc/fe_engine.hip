@@ -91,6 +91,7 @@ struct EffP {
     float *pos, *quat, *v, *w, *gpos, *gquat, *gv, *gw;      // [L+1] x {3,4,3,3}
     float *abuf, *gabuf, *abuf_p, *gabuf_p;                  // [max_action_steps, adim], [adim]
     float* random_vector;                                    // [random_length, flux, 3]
+    int has_mesh; SdfP mesh;                                 // Rigid.setup_mesh (rigid.py:19-24): a moving SDF collider
 };
 struct AgentP { int n; int inj; const EffP* e; };       // effector parameter blocks live in device memory (1 KiB as kernarg spilled SGPRs)
 struct InjectP { int on, act_id, row, flux; };                     // per-substep injection parameters (host-known)
@@ -590,11 +591,78 @@ __global__ __launch_bounds__(256) void k_grid(SimP S, TableP T, const float4* __
     }
 }
 
+// agent.collide at particle level (mpm:418-422; AgentRigid.collide): every effector that carries a mesh, in order,
+// x_tmp = x + dt * new_v re-formed before each collider.
+__device__ __forceinline__ void agent_collide_particle(const SimP& S, const AgentP& agent, int f, const float x[3], float nv[3]) {
+    for (int ei = 0; ei < agent.n; ei++) {
+        const EffP& e = agent.e[ei];
+        if (!e.has_mesh) continue;
+        const float pos[3] = {x[0] + S.dt * nv[0], x[1] + S.dt * nv[1], x[2] + S.dt * nv[2]};
+        float out[3];
+        t_dynamic_collide<float>(e.mesh, e.pos + f * 3, e.quat + f * 4, e.pos + (f + 1) * 3, e.quat + (f + 1) * 4, pos, nv, S.dt, out);
+        nv[0] = out[0]; nv[1] = out[1]; nv[2] = out[2];
+    }
+}
+// Its adjoint.  g = d/d(new_v after the colliders) on entry, d/d(new_v before them) on exit; gx receives the part that
+// flows into x[f]; the effector pose adjoints (pos, quat at f and f+1) are accumulated with atomics.  One Jacobian
+// column per forward-mode pass (inputs: 0-2 new_v, 3-5 x, 6-8 pos[f], 9-12 quat[f], 13-15 pos[f+1], 16-19 quat[f+1]);
+// a particle that is not in contact leaves after the first pass.
+__device__ void agent_collide_particle_grad(const SimP& S, const AgentP& agent, int f, const float x[3], const float nv0[3],
+                                            float g[3], float gx[3]) {
+    float vin[FE_MAX_EFF][3];
+    float nv[3] = {nv0[0], nv0[1], nv0[2]};
+#pragma unroll
+    for (int ei = 0; ei < FE_MAX_EFF; ei++) {
+        if (ei < agent.n && agent.e[ei].has_mesh) {
+            const EffP& e = agent.e[ei];
+            vin[ei][0] = nv[0]; vin[ei][1] = nv[1]; vin[ei][2] = nv[2];
+            const float pos[3] = {x[0] + S.dt * nv[0], x[1] + S.dt * nv[1], x[2] + S.dt * nv[2]};
+            float out[3];
+            t_dynamic_collide<float>(e.mesh, e.pos + f * 3, e.quat + f * 4, e.pos + (f + 1) * 3, e.quat + (f + 1) * 4, pos, nv, S.dt, out);
+            nv[0] = out[0]; nv[1] = out[1]; nv[2] = out[2];
+        }
+    }
+#pragma unroll
+    for (int ei = FE_MAX_EFF - 1; ei >= 0; ei--) {
+        if (!(ei < agent.n && agent.e[ei].has_mesh)) continue;
+        const EffP& e = agent.e[ei];
+        const float v[3] = {vin[ei][0], vin[ei][1], vin[ei][2]};
+        float gin[3] = {0.f, 0.f, 0.f};
+        bool hit = true;
+#pragma unroll 1
+        for (int dir = 0; dir < 20 && hit; dir++) {
+            Dual p0[3], q0[4], p1[3], q1[4], pos[3], mv[3], out[3];
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                p0[d] = Dual(e.pos[f * 3 + d], dir == 6 + d ? 1.f : 0.f);
+                p1[d] = Dual(e.pos[(f + 1) * 3 + d], dir == 13 + d ? 1.f : 0.f);
+                mv[d] = Dual(v[d], dir == d ? 1.f : 0.f);
+                pos[d] = Dual(x[d] + S.dt * v[d], dir == d ? S.dt : (dir == 3 + d ? 1.f : 0.f));
+            }
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                q0[d] = Dual(e.quat[f * 4 + d], dir == 9 + d ? 1.f : 0.f);
+                q1[d] = Dual(e.quat[(f + 1) * 4 + d], dir == 16 + d ? 1.f : 0.f);
+            }
+            hit = t_dynamic_collide<Dual>(e.mesh, p0, q0, p1, q1, pos, mv, S.dt, out);
+            if (!hit) break;
+            const float c = g[0] * out[0].d + g[1] * out[1].d + g[2] * out[2].d;
+            if (dir < 3) { gin[0] = dir == 0 ? c : gin[0]; gin[1] = dir == 1 ? c : gin[1]; gin[2] = dir == 2 ? c : gin[2]; }   // (selects: dir is a runtime index)
+            else if (dir < 6) { gx[0] += dir == 3 ? c : 0.f; gx[1] += dir == 4 ? c : 0.f; gx[2] += dir == 5 ? c : 0.f; }
+            else if (dir < 9) atomicAdd(&e.gpos[f * 3 + dir - 6], c);
+            else if (dir < 13) atomicAdd(&e.gquat[f * 4 + dir - 9], c);
+            else if (dir < 16) atomicAdd(&e.gpos[(f + 1) * 3 + dir - 13], c);
+            else atomicAdd(&e.gquat[(f + 1) * 4 + dir - 16], c);
+        }
+        if (hit) { g[0] = gin[0]; g[1] = gin[1]; g[2] = gin[2]; }
+    }
+}
+
 // g2p (mpm:400-426) + advect_kernel (mpm:497-505) for one used particle; TILE: v_out staged in LDS (3 planes)
-template <bool TILE>
+template <bool TILE, bool COLLIDE>
 __device__ __forceinline__ void used_particle_g2p(const SimP& S, const FrameV& cur, const FrameV& nxt, int s,
                                                   int lb, const Stencil& st, const float x[3],
-                                                  const float4* __restrict__ g_out) {
+                                                  const float4* __restrict__ g_out, const AgentP& agent, int f) {
     float nv[3] = {0.f, 0.f, 0.f};
     m3 nC = m3_zero();
     const float c4 = 4.f * S.inv_dx;
@@ -624,6 +692,7 @@ __device__ __forceinline__ void used_particle_g2p(const SimP& S, const FrameV& c
             }
         }
     }
+    if (COLLIDE) agent_collide_particle(S, agent, f, x, nv);                    // mpm:418-422
     float xn[3] = {x[0] + S.dt * nv[0], x[1] + S.dt * nv[1], x[2] + S.dt * nv[2]};
     store_xvC(nxt, s, xn, nv, nC);
 }
@@ -657,8 +726,9 @@ __device__ __forceinline__ void load_tile4(const TileO& to, const SimP& S, const
     }
 }
 
+template <bool COLLIDE>
 __device__ __forceinline__ void slot_g2p(const SimP& S, const FrameV& cur, const FrameV& nxt, int s, bool use_tile,
-                                         const TileO& to, const float4* __restrict__ g_out, int* slow) {
+                                         const TileO& to, const float4* __restrict__ g_out, int* slow, const AgentP& agent, int f) {
     if (!cur.used[s]) return;
     float4 a0 = cur.A0[s];
     float x[3] = {a0.x, a0.y, a0.z};
@@ -666,12 +736,14 @@ __device__ __forceinline__ void slot_g2p(const SimP& S, const FrameV& cur, const
     stencil_make(x, S.inv_dx, st);
     if (!stencil_inside(st, S.n)) return;                   // already counted in err by p2g
     const int lb = use_tile ? tile_base(to, st) : -1;
-    if (lb >= 0) used_particle_g2p<true>(S, cur, nxt, s, lb, st, x, g_out);
-    else { if (use_tile) atomicAdd(slow, 1); used_particle_g2p<false>(S, cur, nxt, s, 0, st, x, g_out); }
+    if (lb >= 0) used_particle_g2p<true, COLLIDE>(S, cur, nxt, s, lb, st, x, g_out, agent, f);
+    else { if (use_tile) atomicAdd(slow, 1); used_particle_g2p<false, COLLIDE>(S, cur, nxt, s, 0, st, x, g_out, agent, f); }
 }
 
+// COLLIDE: some effector carries a mesh (Rigid): agent.collide runs on the gathered velocity
+template <bool COLLIDE>
 __global__ __launch_bounds__(WG) void k_g2p(SimP S, float* fr_cur, float* fr_next, TableP T, const float4* __restrict__ g_out,
-                                            int* blk_count, int* slow) {
+                                            int* blk_count, int* slow, AgentP agent, int f) {
     const int tid = threadIdx.x;
     if (blockIdx.x == 0 && tid == 0) *blk_count = 0;          // grid_op was the last reader of the active list
     FrameV cur = frame_view(fr_cur, S.Np);
@@ -687,12 +759,12 @@ __global__ __launch_bounds__(WG) void k_g2p(SimP S, float* fr_cur, float* fr_nex
             const TileO to = tile_origin(it.x, S.nb);
             load_tile3(to, S, g_out, tid);
             __syncthreads();
-            for (int i = tid; i < it.z; i += WG) slot_g2p(S, cur, nxt, it.y + i, true, to, g_out, slow);
+            for (int i = tid; i < it.z; i += WG) slot_g2p<COLLIDE>(S, cur, nxt, it.y + i, true, to, g_out, slow, agent, f);
             __syncthreads();
         } else {
             const int s = tail_start + (w - n_items) * WG + tid;
             TileO none = {0, 0, 0};
-            if (s < S.N) slot_g2p(S, cur, nxt, s, false, none, g_out, slow);
+            if (s < S.N) slot_g2p<COLLIDE>(S, cur, nxt, s, false, none, g_out, slow, agent, f);
         }
     }
 }
@@ -707,10 +779,11 @@ __global__ __launch_bounds__(WG) void k_g2p(SimP S, float* fr_cur, float* fr_nex
 // position adjoint (so far) in Gc.A0.xyz.  TILE: v_out read from / d v_out accumulated into LDS (3+3 planes)
 // TILE=true is executed by ALL lanes of the wave (`live` = this lane holds a used particle whose stencil fits the
 // tile); the d v_out contributions are summed over runs of equal stencil base before the LDS atomics (seg_scan).
-template <bool TILE>
+// cg (COLLIDE only): {d/d(gathered velocity) after agent.collide's adjoint [3], extra d/dx[f] from the colliders [3]}
+template <bool TILE, bool COLLIDE = false>
 __device__ __forceinline__ void used_particle_g2p_grad(const SimP& S, const FrameV& Gn, const FrameV& Gc, int s,
                                                        int lb, const Stencil& st, const float4* __restrict__ g_out, float* gg_out,
-                                                       bool live, const SegScan& sc) {
+                                                       bool live, const SegScan& sc, const float* cg = nullptr) {
     PState g;                                   // adjoints of x', v', C'
     if (!TILE || live) load_xvC(Gn, s, g);
     else { g.x[0] = g.x[1] = g.x[2] = g.v[0] = g.v[1] = g.v[2] = 0.f; g.C = m3_zero(); }
@@ -718,6 +791,7 @@ __device__ __forceinline__ void used_particle_g2p_grad(const SimP& S, const Fram
     const float livef = (!TILE || live) ? 1.f : 0.f;
     // x' = x + dt v'  =>  v'_bar += dt x'_bar
     float gv[3] = {g.v[0] + S.dt * g.x[0], g.v[1] + S.dt * g.x[1], g.v[2] + S.dt * g.x[2]};
+    if (COLLIDE && (!TILE || live)) { gv[0] = cg[0]; gv[1] = cg[1]; gv[2] = cg[2]; g.x[0] += cg[3]; g.x[1] += cg[4]; g.x[2] += cg[5]; }
     const float c4 = 4.f * S.inv_dx;
     float gfx[3] = {0.f, 0.f, 0.f};
 #pragma unroll 1
@@ -767,9 +841,40 @@ __device__ __forceinline__ void used_particle_g2p_grad(const SimP& S, const Fram
     if (!TILE || live) Gc.A0[s] = make_float4(g.x[0] + S.inv_dx * gfx[0], g.x[1] + S.inv_dx * gfx[1], g.x[2] + S.inv_dx * gfx[2], 0.f);
 }
 
+// agent.collide's adjoint for one used particle (first in reverse order, mpm:418-422): re-gathers the velocity the
+// colliders saw, forms d/d(v[f+1]) = v_bar' + dt x_bar', pulls it back.  cg = {g_v[3], g_x[3]} for used_particle_g2p_grad.
+template <bool TILE>
+__device__ void g2p_collide_grad(const SimP& S, const AgentP& agent, int f, const FrameV& Gn, int s, int lb, const Stencil& st,
+                                 const float x[3], const float4* __restrict__ g_out, float cg[6]) {
+    float nv[3] = {0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int ij = 0; ij < 9; ij++) {
+        const int i = ij / 3, j = ij - 3 * i;
+        const float wij = STW(st, i, 0) * STW(st, j, 1);
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) {
+            const float weight = wij * st.w[kk][2];
+            float g0, g1, g2;
+            if (TILE) {
+                const int l = lb + (i * TILE_T + j) * TILE_T + kk;
+                g0 = s_tile[l]; g1 = s_tile[TILE_N + l]; g2 = s_tile[2 * TILE_N + l];
+            } else {
+                float4 gv = g_out[cell_addr(st.base[0] + i, st.base[1] + j, st.base[2] + kk, S.nb)];
+                g0 = gv.x; g1 = gv.y; g2 = gv.z;
+            }
+            nv[0] += weight * g0; nv[1] += weight * g1; nv[2] += weight * g2;
+        }
+    }
+    const float4 a0 = Gn.A0[s], a1 = Gn.A1[s];
+    cg[0] = a0.w + S.dt * a0.x; cg[1] = a1.x + S.dt * a0.y; cg[2] = a1.y + S.dt * a0.z;
+    cg[3] = cg[4] = cg[5] = 0.f;
+    agent_collide_particle_grad(S, agent, f, x, nv, cg, cg + 3);
+}
+
 // one slot on the global path (tail / sort_interval = 0)
+template <bool COLLIDE>
 __device__ __forceinline__ void g2p_grad_slot_global(const SimP& S, const FrameV& cur, const FrameV& Gn, const FrameV& Gc, int s,
-                                                     const float4* __restrict__ g_out, float* gg_out) {
+                                                     const float4* __restrict__ g_out, float* gg_out, const AgentP& agent, int f) {
     if (!cur.used[s]) return;
     float4 a0 = cur.A0[s];
     float x[3] = {a0.x, a0.y, a0.z};
@@ -778,12 +883,15 @@ __device__ __forceinline__ void g2p_grad_slot_global(const SimP& S, const FrameV
     if (!stencil_inside(st, S.n)) { float4 gx = Gn.A0[s]; Gc.A0[s] = make_float4(gx.x, gx.y, gx.z, 0.f); return; }
     SegScan none;
     none.f1 = none.f2 = none.f4 = none.f8 = none.f15 = none.f31 = 0.f; none.tail = true;
-    used_particle_g2p_grad<false>(S, Gn, Gc, s, 0, st, g_out, gg_out, true, none);
+    float cg[6];
+    if (COLLIDE) g2p_collide_grad<false>(S, agent, f, Gn, s, 0, st, x, g_out, cg);
+    used_particle_g2p_grad<false, COLLIDE>(S, Gn, Gc, s, 0, st, g_out, gg_out, true, none, cg);
 }
 
+template <bool COLLIDE>
 __global__ __launch_bounds__(WG) void k_g2p_grad(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T,
                                                  const float4* __restrict__ g_out, float* gg_out, float4* slab, int* slow,
-                                                 GridStore GS, int f) {
+                                                 GridStore GS, int f, AgentP agent) {
     const int tid = threadIdx.x;
     const bool stored = GS.cap > 0 && GS.flag[f];
     FrameV cur = frame_view(fr_cur, S.Np);
@@ -811,12 +919,14 @@ __global__ __launch_bounds__(WG) void k_g2p_grad(SimP S, float* fr_cur, float* G
                 const int lb = inside ? tile_base(to, st) : -1;
                 const bool live = lb >= 0;
                 if (__any(live)) {                               // wave-uniform: empty waves skip the scan
+                    float cg[6];
+                    if (COLLIDE && live) g2p_collide_grad<true>(S, agent, f, Gn, s, lb, st, x, g_out, cg);     // divergent, before the scan
                     const SegScan sc = seg_setup(live ? lb : (0x40000000 | tid));
-                    used_particle_g2p_grad<true>(S, Gn, Gc, s, live ? lb : 0, st, g_out, gg_out, live, sc);
+                    used_particle_g2p_grad<true, COLLIDE>(S, Gn, Gc, s, live ? lb : 0, st, g_out, gg_out, live, sc, cg);
                 }
                 if (used && !live) {
                     if (inside) atomicAdd(slow, 1);
-                    g2p_grad_slot_global(S, cur, Gn, Gc, s, g_out, gg_out);
+                    g2p_grad_slot_global<COLLIDE>(S, cur, Gn, Gc, s, g_out, gg_out, agent, f);
                 }
             }
             __syncthreads();
@@ -825,7 +935,7 @@ __global__ __launch_bounds__(WG) void k_g2p_grad(SimP S, float* fr_cur, float* G
             __syncthreads();
         } else {
             const int s = tail_start + (w - n_items) * WG + tid;
-            if (s < S.N) g2p_grad_slot_global(S, cur, Gn, Gc, s, g_out, gg_out);
+            if (s < S.N) g2p_grad_slot_global<COLLIDE>(S, cur, Gn, Gc, s, g_out, gg_out, agent, f);
         }
     }
 }
@@ -881,6 +991,19 @@ __device__ void effector_move_grad(const EffP& e, int f) {
         float g = J[0][d] * e.gpos[(f + 1) * 3] + J[1][d] * e.gpos[(f + 1) * 3 + 1] + J[2][d] * e.gpos[(f + 1) * 3 + 2];
         atomicAdd(&e.gpos[f * 3 + d], g);       // injected particles add to the same slot concurrently
         e.gv[f * 3 + d] += g;
+    }
+    // quat[f+1] = qmul(w2quat(w[f]), quat[f]) (effector.py:161): one forward-mode pass per input (w: 3, quat: 4)
+    const float gq[4] = {e.gquat[(f + 1) * 4], e.gquat[(f + 1) * 4 + 1], e.gquat[(f + 1) * 4 + 2], e.gquat[(f + 1) * 4 + 3]};
+    if (gq[0] != 0.f || gq[1] != 0.f || gq[2] != 0.f || gq[3] != 0.f) {
+#pragma unroll 1
+        for (int dir = 0; dir < 7; dir++) {
+            Dual w[3], q[4], out[4];
+            for (int d = 0; d < 3; d++) w[d] = Dual(e.w[f * 3 + d], dir == d ? 1.f : 0.f);
+            for (int d = 0; d < 4; d++) q[d] = Dual(e.quat[f * 4 + d], dir == 3 + d ? 1.f : 0.f);
+            t_move_quat<Dual>(w, q, out);
+            const float c = gq[0] * out[0].d + gq[1] * out[1].d + gq[2] * out[2].d + gq[3] * out[3].d;
+            if (dir < 3) e.gw[f * 3 + dir] += c; else atomicAdd(&e.gquat[f * 4 + dir - 3], c);
+        }
     }
 }
 
@@ -1623,6 +1746,7 @@ struct FeEngine {
     float4 *g_out = nullptr, *gg_in = nullptr;
     bool all_simple_liquid = false;                         // every particle is an inviscid MAT_LIQUID: SVD-free kernels
     std::vector<SdfP> statics_host; std::vector<float*> statics_vox; SdfP* statics_dev = nullptr;   // static SDF colliders
+    bool has_mesh_effector = false; std::vector<float*> mesh_vox;   // Rigid effectors with an SDF mesh (dynamic.py)
     bool has_rigid = false; int n_bodies = 0;               // MAT_RIGID shape-matching bodies (mpm:176-201)
     int* rigid_body = nullptr; RigidBody* bodies_dev = nullptr;   // [Np] body of a MAT_RIGID particle or -1 (by particle id); [n_bodies]
     int *blk_flag = nullptr, *blk_list = nullptr, *blk_count = nullptr, *err_dev = nullptr;
@@ -1854,7 +1978,10 @@ int substep_fwd(FeEngine* h, int f, int f_global, int act) {
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid<false, true>), ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, h->g_out, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f, h->frame_slow_dev, statics_p(h));
     prof_end(h);
     prof_begin(h, KID_G2P);
-    hipLaunchKernelGGL(k_g2p, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T, h->g_out, h->blk_count, h->slow_dev);
+    if (h->has_mesh_effector)
+        hipLaunchKernelGGL(k_g2p<true>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T, h->g_out, h->blk_count, h->slow_dev, ag, f);
+    else
+        hipLaunchKernelGGL(k_g2p<false>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T, h->g_out, h->blk_count, h->slow_dev, ag, f);
     prof_end(h);
     if (h->has_rigid) {
         rigid_forward(h, f, T);
@@ -1904,7 +2031,10 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act) {
         hipLaunchKernelGGL(k_rigid_final_grad, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), h->grad(f + 1), T.pid_of_slot, h->rigid_body, h->bodies_dev);
     }
     prof_begin(h, KID_G2P_GRAD);
-    hipLaunchKernelGGL(k_g2p_grad, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev, grid_store(h), f);
+    if (h->has_mesh_effector)
+        hipLaunchKernelGGL(k_g2p_grad<true>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag);
+    else
+        hipLaunchKernelGGL(k_g2p_grad<false>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag);
     prof_end(h);
     prof_begin(h, KID_GRID_GRAD);
     if (h->statics_host.empty())
@@ -2052,6 +2182,7 @@ void fe_destroy(FeEngine* h) {
                     h->blk_flag, h->blk_list, h->blk_count, h->err_dev, h->stage_r, h->stage_i, h->node_mark, h->counters,
                     h->tgt, h->chamfer, h->step_loss, h->rigid_body, h->bodies_dev, h->statics_dev};
     for (float* v : h->statics_vox) if (v) (void)hipFree(v);
+    for (float* v : h->mesh_vox) if (v) (void)hipFree(v);
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& E : h->effs) {
         void* ep[] = {E.p.pos, E.p.quat, E.p.v, E.p.w, E.p.gpos, E.p.gquat, E.p.gv, E.p.gw, E.p.abuf, E.p.gabuf, E.p.abuf_p, E.p.gabuf_p, E.p.random_vector};
@@ -2381,35 +2512,49 @@ int fe_agent_copy_grad(FeEngine* h, int src, int dst) {
     return check_async(h);
 }
 
-// ---- static SDF colliders (statics.py, static.py:25-104)
-int fe_add_static(FeEngine* h, const FeSdfDesc* d, const fe_real* voxels) {
-    auto bad = [&](const char* m) { h->err = m; return -1; };
-    if (hipSetDevice(h->device) != hipSuccess) return bad("hipSetDevice failed");
-    if (!d || d->struct_size != (int)sizeof(FeSdfDesc) || d->res < 2 || !voxels) return bad("add_static: bad descriptor");
-    if ((int)h->statics_host.size() >= FE_MAX_STATICS) return bad("add_static: too many static colliders");
-    SdfP s;
+// ---- SDF colliders: statics (statics.py, static.py:25-104) and Rigid effector meshes (rigid.py:19-24, dynamic.py)
+static int build_sdf(FeEngine* h, const FeSdfDesc* d, const fe_real* voxels, SdfP& s, float** vox_out) {
+    if (hipSetDevice(h->device) != hipSuccess) FAIL(h, "hipSetDevice failed");
+    if (!d || d->struct_size != (int)sizeof(FeSdfDesc) || d->res < 2 || !voxels) FAIL(h, "bad FeSdfDesc");
     s.res = d->res; s.friction = d->friction; s.softness = d->softness;
     for (int r = 0; r < 3; r++) for (int c = 0; c < 4; c++) s.T[r * 4 + c] = d->T_mesh_to_voxels[r * 4 + c];
     double A[3][3];
     for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) A[r][c] = d->T_mesh_to_voxels[r * 4 + c];
     const double det = A[0][0] * (A[1][1] * A[2][2] - A[1][2] * A[2][1]) - A[0][1] * (A[1][0] * A[2][2] - A[1][2] * A[2][0]) +
                        A[0][2] * (A[1][0] * A[2][1] - A[1][1] * A[2][0]);
-    if (det == 0.0) return bad("add_static: singular T_mesh_to_voxels");
+    if (det == 0.0) FAIL(h, "singular T_mesh_to_voxels");
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
         const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
         s.Rinv[j * 3 + i] = (float)((A[i1][j1] * A[i2][j2] - A[i1][j2] * A[i2][j1]) / det);
     }
     const size_t nv = (size_t)d->res * d->res * d->res;
     float* vox = nullptr;
-    if (dev_alloc(h, &vox, nv, false)) return -1;
-    if (hipMemcpyOnStream(h, vox, voxels, sizeof(float) * nv, hipMemcpyHostToDevice) != hipSuccess) return bad("hipMemcpy failed");
+    if (dev_alloc(h, &vox, nv, false)) return 1;
+    HIPCK(h, hipMemcpyOnStream(h, vox, voxels, sizeof(float) * nv, hipMemcpyHostToDevice));
     s.vox = vox;
+    *vox_out = vox;
+    return 0;
+}
+int fe_add_static(FeEngine* h, const FeSdfDesc* d, const fe_real* voxels) {
+    if ((int)h->statics_host.size() >= FE_MAX_STATICS) { h->err = "add_static: too many static colliders"; return -1; }
+    SdfP s; float* vox = nullptr;
+    if (build_sdf(h, d, voxels, s, &vox)) return -1;
     h->statics_vox.push_back(vox);
     h->statics_host.push_back(s);
     if (!h->statics_dev && dev_alloc(h, &h->statics_dev, FE_MAX_STATICS)) return -1;
-    if (hipMemcpyOnStream(h, h->statics_dev, h->statics_host.data(), sizeof(SdfP) * h->statics_host.size(), hipMemcpyHostToDevice) != hipSuccess) return bad("hipMemcpy failed");
+    if (hipMemcpyOnStream(h, h->statics_dev, h->statics_host.data(), sizeof(SdfP) * h->statics_host.size(), hipMemcpyHostToDevice) != hipSuccess) { h->err = "hipMemcpy failed"; return -1; }
     h->gs_host_valid = false;
     return (int)h->statics_host.size() - 1;
+}
+int fe_eff_set_mesh(FeEngine* h, int e, const FeSdfDesc* d, const fe_real* voxels) {
+    if (e < 0 || e >= (int)h->effs.size()) FAIL(h, "effector index out of range");
+    SdfP s; float* vox = nullptr;
+    if (build_sdf(h, d, voxels, s, &vox)) return 1;
+    h->mesh_vox.push_back(vox);
+    h->effs[e].p.has_mesh = 1; h->effs[e].p.mesh = s;
+    HIPCK(h, hipMemcpyOnStream(h, h->effs_dev + e, &h->effs[e].p, sizeof(EffP), hipMemcpyHostToDevice));
+    h->has_mesh_effector = true;
+    return 0;
 }
 
 // ---- loss

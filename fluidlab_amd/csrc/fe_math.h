@@ -390,6 +390,133 @@ FE_HD void quat_rotate(const real v[3], const real q[4], real out[3]) {
 }
 
 // ---------------------------------------------------------------------------------------
+// Dynamic (moving) SDF collider of a Rigid effector -- dynamic.py:29-122 -- and the quaternion part of move_kernel
+// (effector.py:161), written over a scalar type T.  T = real evaluates; T = Dual carries one tangent, so a call yields
+// one Jacobian column and an adjoint is assembled column by column (forward mode: the collide adjoint has 20 inputs and
+// only the few particles in contact pay for it).  floor/comparisons act on values; min/max pass the tangent of the
+// selected operand (Taichi's rule); the quotient vt/|vt| is only formed when the friction branch is taken.
+// ---------------------------------------------------------------------------------------
+struct Dual {
+    real v, d;
+    FE_HD Dual() : v(R_(0.0)), d(R_(0.0)) {}
+    FE_HD Dual(real v_) : v(v_), d(R_(0.0)) {}
+    FE_HD Dual(real v_, real d_) : v(v_), d(d_) {}
+};
+FE_HD Dual operator+(Dual a, Dual b) { return Dual(a.v + b.v, a.d + b.d); }
+FE_HD Dual operator-(Dual a, Dual b) { return Dual(a.v - b.v, a.d - b.d); }
+FE_HD Dual operator-(Dual a) { return Dual(-a.v, -a.d); }
+FE_HD Dual operator*(Dual a, Dual b) { return Dual(a.v * b.v, a.d * b.v + a.v * b.d); }
+FE_HD Dual operator/(Dual a, Dual b) { real i = R_(1.0) / b.v; return Dual(a.v * i, (a.d - a.v * i * b.d) * i); }
+FE_HD Dual t_sqrt(Dual a) { real r = sqrt(a.v); return Dual(r, a.d / (R_(2.0) * r)); }
+FE_HD Dual t_exp(Dual a) { real r = exp(a.v); return Dual(r, a.d * r); }
+FE_HD Dual t_sin(Dual a) { return Dual(sin(a.v), a.d * cos(a.v)); }
+FE_HD Dual t_cos(Dual a) { return Dual(cos(a.v), -a.d * sin(a.v)); }
+FE_HD Dual t_abs(Dual a) { return a.v >= R_(0.0) ? a : -a; }
+FE_HD real t_sqrt(real a) { return sqrt(a); }
+FE_HD real t_exp(real a) { return exp(a); }
+FE_HD real t_sin(real a) { return sin(a); }
+FE_HD real t_cos(real a) { return cos(a); }
+FE_HD real t_abs(real a) { return fabs(a); }
+FE_HD real t_val(real a) { return a; }
+FE_HD real t_val(Dual a) { return a.v; }
+
+template <class T> FE_HD void t_quat_rotate(const T v[3], const T q[4], T out[3]) {              // geom.py:97-102
+    T ux = q[2] * v[2] - q[3] * v[1], uy = q[3] * v[0] - q[1] * v[2], uz = q[1] * v[1] - q[2] * v[0];
+    T wx = q[2] * uz - q[3] * uy, wy = q[3] * ux - q[1] * uz, wz = q[1] * uy - q[2] * ux;
+    out[0] = v[0] + T(R_(2.0)) * (q[0] * ux + wx);
+    out[1] = v[1] + T(R_(2.0)) * (q[0] * uy + wy);
+    out[2] = v[2] + T(R_(2.0)) * (q[0] * uz + wz);
+}
+template <class T> FE_HD T t_sdf_sample(const SdfP& s, const T pv[3]) {                          // dynamic.py:39-54
+    int b[3];
+    bool outside = false;
+#pragma unroll
+    for (int d = 0; d < 3; d++) { b[d] = (int)floor(t_val(pv[d])); outside = outside || b[d] >= s.res - 1 || b[d] < 0; }
+    if (outside) return T(R_(1.0));
+    const T f0 = pv[0] - T((real)b[0]), f1 = pv[1] - T((real)b[1]), f2 = pv[2] - T((real)b[2]);   // in [0,1): |.| is the identity
+    const T g0 = T(R_(1.0)) - f0, g1 = T(R_(1.0)) - f1, g2 = T(R_(1.0)) - f2;
+    const real* v = s.vox + ((size_t)b[0] * s.res + b[1]) * s.res + b[2];
+    const size_t sy = s.res, sx = (size_t)s.res * s.res;
+    T sd = g0 * g1 * g2 * T(v[0]);
+    sd = sd + g0 * g1 * f2 * T(v[1]);
+    sd = sd + g0 * f1 * g2 * T(v[sy]);
+    sd = sd + g0 * f1 * f2 * T(v[sy + 1]);
+    sd = sd + f0 * g1 * g2 * T(v[sx]);
+    sd = sd + f0 * g1 * f2 * T(v[sx + 1]);
+    sd = sd + f0 * f1 * g2 * T(v[sx + sy]);
+    sd = sd + f0 * f1 * f2 * T(v[sx + sy + 1]);
+    return sd;
+}
+template <class T> FE_HD void t_normalize3(T v[3]) {                                             // geom.py:93-94
+    T inv = T(R_(1.0)) / t_sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + T(FE_EPS));
+    v[0] = v[0] * inv; v[1] = v[1] * inv; v[2] = v[2] * inv;
+}
+// returns whether the contact branch was taken (otherwise out = mv)
+template <class T> FE_HD bool t_dynamic_collide(const SdfP& s, const T p0[3], const T q0[4], const T p1[3], const T q1[4],
+                                                const T pos[3], const T mv[3], real dt, T out[3]) {
+    const T rel0[3] = {pos[0] - p0[0], pos[1] - p0[1], pos[2] - p0[2]};
+    const T qn = T(R_(1.0)) / t_sqrt(q0[0] * q0[0] + q0[1] * q0[1] + q0[2] * q0[2] + q0[3] * q0[3]);     // inv_quat(...).normalized()
+    const T qi[4] = {q0[0] * qn, -(q0[1] * qn), -(q0[2] * qn), -(q0[3] * qn)};
+    T pm[3], pv[3];
+    t_quat_rotate(rel0, qi, pm);
+#pragma unroll
+    for (int d = 0; d < 3; d++) pv[d] = T(s.T[d * 4]) * pm[0] + T(s.T[d * 4 + 1]) * pm[1] + T(s.T[d * 4 + 2]) * pm[2] + T(s.T[d * 4 + 3]);
+    const T sd = t_sdf_sample(s, pv);
+    T infl = t_exp(-sd * T(s.softness));
+    if (t_val(infl) > R_(1.0)) infl = T(R_(1.0));
+    out[0] = mv[0]; out[1] = mv[1]; out[2] = mv[2];
+    if (!(t_val(sd) <= R_(0.0) || (s.softness > R_(0.0) && t_val(infl) > R_(0.1)))) return false;
+    T pn[3], cv[3];
+    t_quat_rotate(pm, q1, pn);
+    const T idt = T(R_(1.0) / dt);
+#pragma unroll
+    for (int d = 0; d < 3; d++) cv[d] = (pn[d] + p1[d] - pos[d]) * idt;                          // collider_v, dynamic.py:90-94
+    if (s.friction > R_(10.0)) { out[0] = cv[0]; out[1] = cv[1]; out[2] = cv[2]; return true; }
+    const T rel[3] = {mv[0] - cv[0], mv[1] - cv[1], mv[2] - cv[2]};
+    const real delta = R_(1e-2);
+    T g[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) {                                                                // normal_, dynamic.py:73-88
+        const T inc[3] = {pv[0] + T(d == 0 ? delta : R_(0.0)), pv[1] + T(d == 1 ? delta : R_(0.0)), pv[2] + T(d == 2 ? delta : R_(0.0))};
+        const T dec[3] = {pv[0] - T(d == 0 ? delta : R_(0.0)), pv[1] - T(d == 1 ? delta : R_(0.0)), pv[2] - T(d == 2 ? delta : R_(0.0))};
+        g[d] = (t_sdf_sample(s, inc) - t_sdf_sample(s, dec)) * T(R_(1.0) / (R_(2.0) * delta));
+    }
+    t_normalize3(g);
+    T nm[3], n[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) nm[d] = T(s.Rinv[d * 3]) * g[0] + T(s.Rinv[d * 3 + 1]) * g[1] + T(s.Rinv[d * 3 + 2]) * g[2];
+    t_quat_rotate(nm, q0, n);
+    t_normalize3(n);
+    const T nc = rel[0] * n[0] + rel[1] * n[1] + rel[2] * n[2];
+    const T a = t_val(nc) < R_(0.0) ? nc : T(R_(0.0));
+    T vt[3] = {rel[0] - a * n[0], rel[1] - a * n[1], rel[2] - a * n[2]};
+    const real vtn_v = sqrt(t_val(vt[0]) * t_val(vt[0]) + t_val(vt[1]) * t_val(vt[1]) + t_val(vt[2]) * t_val(vt[2]));
+    if (t_val(nc) < R_(0.0) && vtn_v > FE_EPS) {
+        const T vtn = t_sqrt(vt[0] * vt[0] + vt[1] * vt[1] + vt[2] * vt[2]);
+        const T t = vtn + nc * T(s.friction);
+        const T sc = t_val(t) > R_(0.0) ? t / vtn : T(R_(0.0));
+        vt[0] = vt[0] * sc; vt[1] = vt[1] * sc; vt[2] = vt[2] * sc;
+    }
+    const T keep = T(R_(1.0)) - infl;
+#pragma unroll
+    for (int d = 0; d < 3; d++) out[d] = cv[d] + vt[d] * infl + rel[d] * keep;
+    return true;
+}
+// quat[f+1] = qmul(w2quat(w[f]), quat[f])  (effector.py:161, geom.py:8-28)
+template <class T> FE_HD void t_move_quat(const T w[3], const T q[4], T out[4]) {
+    const T wn = t_sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2] + T(FE_EPS));
+    const T sh = t_sin(wn * T(R_(0.5))) / wn;
+    const T a[4] = {t_cos(wn * T(R_(0.5))), w[0] * sh, w[1] * sh, w[2] * sh};
+    T o[4];
+    o[0] = q[0] * a[0] - q[1] * a[1] - q[2] * a[2] - q[3] * a[3];
+    o[1] = q[0] * a[1] + q[1] * a[0] - q[2] * a[3] + q[3] * a[2];
+    o[2] = q[0] * a[2] + q[1] * a[3] + q[2] * a[0] - q[3] * a[1];
+    o[3] = q[0] * a[3] - q[1] * a[2] + q[2] * a[1] + q[3] * a[0];
+    const T inv = T(R_(1.0)) / t_sqrt(o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3]);
+    for (int i = 0; i < 4; i++) out[i] = o[i] * inv;
+}
+
+// ---------------------------------------------------------------------------------------
 // quadratic B-spline stencil (mpm:335-337)
 // ---------------------------------------------------------------------------------------
 struct Stencil {

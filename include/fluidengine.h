@@ -170,6 +170,12 @@ typedef struct FeSdfDesc {
     fe_real softness;                /* Mesh.softness (dynamic colliders only)                  */
 } FeSdfDesc;
 int fe_add_static(FeEngine* h, const FeSdfDesc* desc, const fe_real* voxels);       /* returns the static's index or -1 */
+/* Rigid.setup_mesh (rigid.py:19-24): give effector e a Dynamic mesh (dynamic.py:29-122).  agent.collide then runs at
+ * particle level inside g2p (mpm:418-422, collide_type 'particle', agent.py:17): the SDF is sampled in the effector's
+ * frame at f, the collider velocity comes from the pose change f -> f+1, `softness` blends the contact in, friction > 10
+ * sticks.  Its adjoint reaches the material velocity, the particle position and the effector pose at f and f+1
+ * (hence 6-dof action gradients through move_kernel's quaternion update, effector.py:157-161). */
+int fe_eff_set_mesh(FeEngine* h, int e, const FeSdfDesc* desc, const fe_real* voxels);
 
 /* ---- loss: shapematching_loss.py:64-93 -------------------------------- */
 int fe_loss_alloc(FeEngine* h, int max_loss_steps);

@@ -17,6 +17,7 @@
  * Build: see oracle/Makefile (-DFE_REAL=float -> libfe_oracle_f32.so, double -> _f64).
  */
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -222,6 +223,7 @@ struct Effector {
     std::vector<int> act_id;                                   /* [L+1] */
     std::vector<R> random_vector;
     std::vector<int> act_range;
+    int mesh = -1;                                             /* index into FeEngine::meshes (Rigid.setup_mesh, rigid.py:19-24) */
 };
 
 /* a Mesh with has_dynamics: SDF voxels + world->voxel map (mesh.py:57-66,120-127) */
@@ -249,6 +251,8 @@ struct FeEngine {
     std::vector<R> g_vin, g_mass, g_vout, gg_vin, gg_mass, gg_vout;
     std::vector<Effector> effs;
     std::vector<Sdf> statics;        /* statics.py */
+    std::vector<Sdf> meshes;         /* Dynamic meshes of Rigid effectors (dynamic.py) */
+    bool has_mesh_effector = false;
     int loss_steps = 0;
     std::vector<R> tgt;          /* [loss_steps, N, 3] */
     std::vector<R> chamfer, step_loss;
@@ -449,8 +453,6 @@ void effector_move(Effector& e, int f) {
     qmul(qw, &e.quat[f * 4], &e.quat[(f + 1) * 4]);
 }
 
-/* mpm:380-398 (no statics / agent colliders in this scope: LatteArt's cup has
- * has_dynamics=False and AgentInjector.collide is the identity, agent_injector.py:34-36) */
 
 /* ------------------------------------------------------------------ SDF colliders */
 
@@ -535,6 +537,189 @@ void static_collide(const Sdf& s, const R pos[3], R v[3], R* g) {
     contact_law(n, s.friction, v, out, g);
     for (int d = 0; d < 3; d++) v[d] = out[d];
 }
+/* ------------------------------------------------------------------ dynamic colliders (Rigid effector)
+ * Dynamic.collide (dynamic.py:29-122) is differentiated by Taichi through everything it touches: the material velocity,
+ * the query position, and the effector pose at f and f+1 (sdf, finite-difference normal, quaternion transforms, contact
+ * law, softness).  The restatement is written once over a scalar type T; with T = Dual (value + one tangent) a call
+ * returns one column of the Jacobian, and the adjoint is assembled column by column (20 inputs).  Branch semantics:
+ * floor/comparisons act on values; min/max pass the tangent of the selected operand (Taichi's rule). */
+struct Dual { R v, d; Dual() : v(0), d(0) {} Dual(R v_) : v(v_), d(0) {} Dual(R v_, R d_) : v(v_), d(d_) {} };
+inline Dual operator+(Dual a, Dual b) { return Dual(a.v + b.v, a.d + b.d); }
+inline Dual operator-(Dual a, Dual b) { return Dual(a.v - b.v, a.d - b.d); }
+inline Dual operator-(Dual a) { return Dual(-a.v, -a.d); }
+inline Dual operator*(Dual a, Dual b) { return Dual(a.v * b.v, a.d * b.v + a.v * b.d); }
+inline Dual operator/(Dual a, Dual b) { return Dual(a.v / b.v, (a.d * b.v - a.v * b.d) / (b.v * b.v)); }
+inline Dual tsqrt(Dual a) { R r = std::sqrt(a.v); return Dual(r, a.d / (2 * r)); }
+inline Dual texp(Dual a) { R r = std::exp(a.v); return Dual(r, a.d * r); }
+inline Dual tsin(Dual a) { return Dual(std::sin(a.v), a.d * std::cos(a.v)); }
+inline Dual tcos(Dual a) { return Dual(std::cos(a.v), -a.d * std::sin(a.v)); }
+inline Dual tabs(Dual a) { return a.v >= 0 ? a : -a; }
+inline R tsqrt(R a) { return std::sqrt(a); }
+inline R texp(R a) { return std::exp(a); }
+inline R tsin(R a) { return std::sin(a); }
+inline R tcos(R a) { return std::cos(a); }
+inline R tabs(R a) { return std::fabs(a); }
+inline R val(R a) { return a; }
+inline R val(Dual a) { return a.v; }
+
+template <class T> void t_quat_rot(const T v[3], const T q[4], T out[3]) {                   /* geom.py:97-102 */
+    T uv[3] = {q[2] * v[2] - q[3] * v[1], q[3] * v[0] - q[1] * v[2], q[1] * v[1] - q[2] * v[0]};
+    T uuv[3] = {q[2] * uv[2] - q[3] * uv[1], q[3] * uv[0] - q[1] * uv[2], q[1] * uv[1] - q[2] * uv[0]};
+    for (int i = 0; i < 3; i++) out[i] = v[i] + T((R)2) * (q[0] * uv[i] + uuv[i]);
+}
+template <class T> void t_inv_quat(const T q[4], T out[4]) {                                  /* geom.py:30-32, .normalized() */
+    T nn = tsqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    out[0] = q[0] / nn; out[1] = -q[1] / nn; out[2] = -q[2] / nn; out[3] = -q[3] / nn;
+}
+template <class T> T t_sdf_sample(const Sdf& s, const T pv[3]) {                              /* dynamic.py:39-54 */
+    int base[3];
+    for (int d = 0; d < 3; d++) {
+        base[d] = (int)std::floor(val(pv[d]));
+        if (base[d] >= s.res - 1 || base[d] < 0) return T((R)1.0);
+    }
+    T sd((R)0);
+    for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) for (int k = 0; k < 2; k++) {
+        const int vp[3] = {base[0] + i, base[1] + j, base[2] + k};
+        T w((R)1);
+        for (int d = 0; d < 3; d++) w = w * (T((R)1) - tabs(pv[d] - T((R)vp[d])));
+        sd = sd + w * T(s.vox[((size_t)vp[0] * s.res + vp[1]) * s.res + vp[2]]);
+    }
+    return sd;
+}
+template <class T> void t_normalize(T v[3]) {                                                  /* geom.py:93-94 */
+    T nn = tsqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + T(EPS));
+    for (int d = 0; d < 3; d++) v[d] = v[d] / nn;
+}
+template <class T> void t_sdf_normal_voxels(const Sdf& s, const T pv[3], T g[3]) {             /* dynamic.py:73-88 */
+    const R delta = (R)1e-2;
+    for (int d = 0; d < 3; d++) {
+        T inc[3] = {pv[0], pv[1], pv[2]}, dec[3] = {pv[0], pv[1], pv[2]};
+        inc[d] = inc[d] + T(delta); dec[d] = dec[d] - T(delta);
+        g[d] = (t_sdf_sample(s, inc) - t_sdf_sample(s, dec)) / T(2 * delta);
+    }
+    t_normalize(g);
+}
+/* Dynamic.collide (dynamic.py:96-122) with the pose (p0,q0) = (pos,quat)[f], (p1,q1) = (pos,quat)[f+1].  Returns whether
+ * the contact branch was taken. */
+template <class T> bool t_dynamic_collide(const Sdf& s, const T p0[3], const T q0[4], const T p1[3], const T q1[4],
+                                          const T pos[3], const T mv[3], R dt, T out[3]) {
+    T rel0[3] = {pos[0] - p0[0], pos[1] - p0[1], pos[2] - p0[2]}, qi[4], pm[3], pv[3];
+    t_inv_quat(q0, qi);
+    t_quat_rot(rel0, qi, pm);                                                                  /* inv_transform_by_trans_quat */
+    for (int d = 0; d < 3; d++) pv[d] = T(s.T[d * 4]) * pm[0] + T(s.T[d * 4 + 1]) * pm[1] + T(s.T[d * 4 + 2]) * pm[2] + T(s.T[d * 4 + 3]);
+    T sd = t_sdf_sample(s, pv);
+    T infl = texp(-sd * T(s.softness));
+    if (val(infl) > 1) infl = T((R)1);                                                          /* min(exp(..), 1) */
+    for (int d = 0; d < 3; d++) out[d] = mv[d];
+    if (!(val(sd) <= 0 || (s.softness > 0 && val(infl) > (R)0.1))) return false;
+    T pn[3], cv[3];
+    t_quat_rot(pm, q1, pn);
+    for (int d = 0; d < 3; d++) cv[d] = (pn[d] + p1[d] - pos[d]) / T(dt);                      /* collider_v, dynamic.py:90-94 */
+    if (s.friction > (R)10.0) { for (int d = 0; d < 3; d++) out[d] = cv[d]; return true; }
+    T rel[3] = {mv[0] - cv[0], mv[1] - cv[1], mv[2] - cv[2]};
+    T gvx[3], nm[3], n[3];
+    t_sdf_normal_voxels(s, pv, gvx);
+    for (int d = 0; d < 3; d++) nm[d] = T(s.Rinv[d * 3]) * gvx[0] + T(s.Rinv[d * 3 + 1]) * gvx[1] + T(s.Rinv[d * 3 + 2]) * gvx[2];
+    t_quat_rot(nm, q0, n);
+    t_normalize(n);
+    T nc = rel[0] * n[0] + rel[1] * n[1] + rel[2] * n[2];
+    T a = val(nc) < 0 ? nc : T((R)0);
+    T vt[3] = {rel[0] - a * n[0], rel[1] - a * n[1], rel[2] - a * n[2]};
+    const R vtn_v = std::sqrt(val(vt[0]) * val(vt[0]) + val(vt[1]) * val(vt[1]) + val(vt[2]) * val(vt[2]));
+    if (val(nc) < 0 && vtn_v > EPS) {                                                           /* flag; quotient only formed here */
+        T vtn = tsqrt(vt[0] * vt[0] + vt[1] * vt[1] + vt[2] * vt[2]);
+        T t = vtn + nc * T(s.friction);
+        T sc = val(t) > 0 ? t / vtn : T((R)0);
+        for (int d = 0; d < 3; d++) vt[d] = vt[d] * sc;
+    }
+    for (int d = 0; d < 3; d++) out[d] = cv[d] + vt[d] * infl + rel[d] * (T((R)1) - infl);
+    return true;
+}
+
+/* agent.collide at particle level (mpm:419-422; AgentRigid.collide, agent_rigid.py:21-23): every effector that carries
+ * a mesh, in order.  x_tmp = x + dt * new_v is re-formed from the current velocity before each collider. */
+void agent_collide_particle(FeEngine* h, int f, const R x[3], R nv[3]) {
+    const R dt = h->cfg.dt;
+    for (const Effector& e : h->effs) {
+        if (e.mesh < 0) continue;
+        R pos[3] = {x[0] + dt * nv[0], x[1] + dt * nv[1], x[2] + dt * nv[2]}, out[3];
+        t_dynamic_collide<R>(h->meshes[e.mesh], &e.pos[f * 3], &e.quat[f * 4], &e.pos[(f + 1) * 3], &e.quat[(f + 1) * 4], pos, nv, dt, out);
+        for (int d = 0; d < 3; d++) nv[d] = out[d];
+    }
+}
+/* its adjoint: g (d/d new_v after the colliders) is pulled back to d/d new_v before them; the x and pose parts are
+ * accumulated.  Effector pose adjoints are shared by all particles, hence the critical section. */
+void agent_collide_particle_grad(FeEngine* h, int f, const R x[3], const R nv0[3], R g[3], R gx[3]) {
+    const R dt = h->cfg.dt;
+    std::vector<std::array<R, 3>> vin;
+    R nv[3] = {nv0[0], nv0[1], nv0[2]};
+    for (const Effector& e : h->effs) {
+        if (e.mesh < 0) continue;
+        vin.push_back({nv[0], nv[1], nv[2]});
+        R pos[3] = {x[0] + dt * nv[0], x[1] + dt * nv[1], x[2] + dt * nv[2]}, out[3];
+        t_dynamic_collide<R>(h->meshes[e.mesh], &e.pos[f * 3], &e.quat[f * 4], &e.pos[(f + 1) * 3], &e.quat[(f + 1) * 4], pos, nv, dt, out);
+        for (int d = 0; d < 3; d++) nv[d] = out[d];
+    }
+    int k = (int)vin.size();
+    for (int ei = (int)h->effs.size() - 1; ei >= 0; ei--) {
+        Effector& e = h->effs[ei];
+        if (e.mesh < 0) continue;
+        k--;
+        const R* v = vin[k].data();
+        const Sdf& s = h->meshes[e.mesh];
+        R gin[3] = {0, 0, 0}, gpose[14];
+        /* inputs: 0-2 new_v (enters as mat_v and, times dt, in the position), 3-5 x, 6-8 pos[f], 9-12 quat[f],
+         *         13-15 pos[f+1], 16-19 quat[f+1] */
+        bool hit = true;
+        for (int dir = 0; dir < 20 && hit; dir++) {
+            Dual p0[3], q0[4], p1[3], q1[4], pos[3], mv[3], out[3];
+            for (int d = 0; d < 3; d++) {
+                p0[d] = Dual(e.pos[f * 3 + d], dir == 6 + d ? 1 : 0);
+                p1[d] = Dual(e.pos[(f + 1) * 3 + d], dir == 13 + d ? 1 : 0);
+                mv[d] = Dual(v[d], dir == d ? 1 : 0);
+                pos[d] = Dual(x[d] + dt * v[d], dir == d ? dt : (dir == 3 + d ? 1 : 0));
+            }
+            for (int d = 0; d < 4; d++) {
+                q0[d] = Dual(e.quat[f * 4 + d], dir == 9 + d ? 1 : 0);
+                q1[d] = Dual(e.quat[(f + 1) * 4 + d], dir == 16 + d ? 1 : 0);
+            }
+            hit = t_dynamic_collide<Dual>(s, p0, q0, p1, q1, pos, mv, dt, out);
+            const R c = g[0] * out[0].d + g[1] * out[1].d + g[2] * out[2].d;
+            if (dir < 3) gin[dir] = c; else if (dir < 6) gx[dir - 3] += c; else gpose[dir - 6] = c;
+        }
+        if (!hit) continue;                       /* identity: g passes through unchanged */
+        for (int d = 0; d < 3; d++) g[d] = gin[d];
+#pragma omp critical(fe_effector_grad)
+        {
+            for (int d = 0; d < 3; d++) { e.gpos[f * 3 + d] += gpose[d]; e.gpos[(f + 1) * 3 + d] += gpose[7 + d]; }
+            for (int d = 0; d < 4; d++) { e.gquat[f * 4 + d] += gpose[3 + d]; e.gquat[(f + 1) * 4 + d] += gpose[10 + d]; }
+        }
+    }
+}
+/* quaternion part of move_kernel (effector.py:161): quat[f+1] = qmul(w2quat(w[f]), quat[f]), and its adjoint */
+template <class T> void t_move_quat(const T w[3], const T q[4], T out[4]) {
+    T wn = tsqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2] + T(EPS));                            /* geom.py:18-28 */
+    T sh = tsin(wn / T((R)2)), a[4] = {tcos(wn / T((R)2)), w[0] / wn * sh, w[1] / wn * sh, w[2] / wn * sh};
+    T t[4][4];                                                                                   /* qmul(a, q), geom.py:8-16 */
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) t[i][j] = q[i] * a[j];
+    T o[4] = {t[0][0] - t[1][1] - t[2][2] - t[3][3], t[0][1] + t[1][0] - t[2][3] + t[3][2],
+              t[0][2] + t[1][3] + t[2][0] - t[3][1], t[0][3] - t[1][2] + t[2][1] + t[3][0]};
+    T nn = tsqrt(o[0] * o[0] + o[1] * o[1] + o[2] * o[2] + o[3] * o[3]);
+    for (int i = 0; i < 4; i++) out[i] = o[i] / nn;
+}
+void effector_move_quat_grad(Effector& e, int f) {
+    const R* gq = &e.gquat[(f + 1) * 4];
+    if (gq[0] == 0 && gq[1] == 0 && gq[2] == 0 && gq[3] == 0) return;
+    for (int dir = 0; dir < 7; dir++) {
+        Dual w[3], q[4], out[4];
+        for (int d = 0; d < 3; d++) w[d] = Dual(e.w[f * 3 + d], dir == d ? 1 : 0);
+        for (int d = 0; d < 4; d++) q[d] = Dual(e.quat[f * 4 + d], dir == 3 + d ? 1 : 0);
+        t_move_quat<Dual>(w, q, out);
+        const R c = gq[0] * out[0].d + gq[1] * out[1].d + gq[2] * out[2].d + gq[3] * out[3].d;
+        if (dir < 3) e.gw[f * 3 + dir] += c; else e.gquat[f * 4 + dir - 3] += c;
+    }
+}
+
 /* the collider chain of grid_op (mpm:386-390) for one node; returns the velocities before each static */
 void statics_forward(FeEngine* h, const R xn[3], R vo[3], std::vector<R>* trace) {
     for (const Sdf& s : h->statics) {
@@ -583,6 +768,7 @@ int g2p(FeEngine* h, int f) {
                 for (int b = 0; b < 3; b++) nC.m[a][b] += 4 * h->inv_dx * weight * gv[a] * dpos[b];
             }
         }
+        if (h->has_mesh_effector) agent_collide_particle(h, f, &h->X(f)[p * 3], nv);             /* mpm:418-422 */
         for (int a = 0; a < 3; a++) h->Vv(f + 1)[p * 3 + a] = nv[a];
         m_store(&h->Cc(f + 1)[p * 9], nC);
     }
@@ -717,10 +903,21 @@ void g2p_grad(FeEngine* h, int f) {
         if (!h->Us(f)[p]) continue;
         Stencil s; make_stencil(&h->X(f)[p * 3], h->inv_dx, s);
         if (!stencil_in_grid(s, n)) continue;
-        const R* gvn = &h->GV(f + 1)[p * 3];
+        R gvn[3] = {h->GV(f + 1)[p * 3], h->GV(f + 1)[p * 3 + 1], h->GV(f + 1)[p * 3 + 2]};
         M3 gCn = m_load(&h->GC(f + 1)[p * 9]);
         R gfx[3] = {0, 0, 0};
         const R c4 = 4 * h->inv_dx;
+        if (h->has_mesh_effector) {
+            /* agent.collide's adjoint (mpm:418-422) comes first in reverse order: it needs the gathered velocity again */
+            R nv[3] = {0, 0, 0}, gxc[3] = {0, 0, 0};
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++) {
+                size_t c = cell_index(n, s.base[0] + i, s.base[1] + j, s.base[2] + k);
+                R weight = (R)1.0; weight *= s.w[i][0]; weight *= s.w[j][1]; weight *= s.w[k][2];
+                for (int a = 0; a < 3; a++) nv[a] += weight * h->g_vout[c * 3 + a];
+            }
+            agent_collide_particle_grad(h, f, &h->X(f)[p * 3], nv, gvn, gxc);
+            for (int d = 0; d < 3; d++) h->GX(f)[p * 3 + d] += gxc[d];
+        }
         for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++) {
             int o[3] = {i, j, k};
             R dpos[3] = {i - s.fx[0], j - s.fx[1], k - s.fx[2]};
@@ -797,6 +994,7 @@ void effector_move_grad(Effector& e, int f) {
         e.gpos[f * 3 + d] += g;
         e.gv[f * 3 + d] += g;
     }
+    effector_move_quat_grad(e, f);
 }
 
 /* p2g.grad + svd_grad + compute_F_tmp.grad (mpm:544-546) */
@@ -1244,6 +1442,31 @@ int fe_agent_copy_grad(FeEngine* h, int src, int dst) {
     return 0;
 }
 
+static int make_sdf(FeEngine* h, const FeSdfDesc* d, const fe_real* voxels, Sdf& s) {
+    if (!d || d->struct_size != (int)sizeof(FeSdfDesc) || d->res < 2 || !voxels) { h->err = "bad FeSdfDesc"; return 1; }
+    s.res = d->res; s.friction = d->friction; s.softness = d->softness;
+    s.vox.assign(voxels, voxels + (size_t)d->res * d->res * d->res);
+    for (int i = 0; i < 16; i++) s.T[i] = d->T_mesh_to_voxels[i];
+    M3 A;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) A.m[i][j] = s.T[i * 4 + j];
+    const R det = A.m[0][0] * (A.m[1][1] * A.m[2][2] - A.m[1][2] * A.m[2][1]) - A.m[0][1] * (A.m[1][0] * A.m[2][2] - A.m[1][2] * A.m[2][0]) +
+                  A.m[0][2] * (A.m[1][0] * A.m[2][1] - A.m[1][1] * A.m[2][0]);
+    if (det == 0) { h->err = "singular T_mesh_to_voxels"; return 1; }
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {       /* inverse = adj / det */
+        const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+        s.Rinv[j * 3 + i] = (A.m[i1][j1] * A.m[i2][j2] - A.m[i1][j2] * A.m[i2][j1]) / det;
+    }
+    return 0;
+}
+int fe_eff_set_mesh(FeEngine* h, int e, const FeSdfDesc* d, const fe_real* voxels) {
+    CHECK_EFF(h, e);
+    Sdf s;
+    if (make_sdf(h, d, voxels, s)) return 1;
+    h->meshes.push_back(std::move(s));
+    h->effs[e].mesh = (int)h->meshes.size() - 1;
+    h->has_mesh_effector = true;
+    return 0;
+}
 int fe_add_static(FeEngine* h, const FeSdfDesc* d, const fe_real* voxels) {
     if (!d || d->struct_size != (int)sizeof(FeSdfDesc) || d->res < 2 || !voxels) { h->err = "add_static: bad descriptor"; return -1; }
     Sdf s;

@@ -3,7 +3,7 @@ fixtures.  Every scene is a plain dict of float32-representable numpy arrays, so
 oracle and the fp32 HIP engine see bit-identical inputs."""
 import numpy as np
 
-from fluidlab_amd._capi import Engine, FE_EFF_INJECTOR
+from fluidlab_amd._capi import Engine, FE_EFF_INJECTOR, FE_EFF_PLAIN
 
 WATER, MILK, COFFEE, ELASTIC, ICECREAM, RIGID, RIGID_HEAVY, MILK_VIS = 0, 1, 2, 3, 4, 5, 6, 8
 MAT_LIQUID, MAT_PLASTO_ELASTIC, MAT_ELASTIC, MAT_RIGID = 200, 201, 202, 203
@@ -92,6 +92,81 @@ def water_on_obstacles(n_grid=16, n_particles=1500, seed=7):
     v2, T2 = sphere_sdf((0.62, 0.40, 0.50), 0.10, res=20, lo=0.2, hi=0.9)
     sc['statics'] = [dict(voxels=v1, T=T1, friction=0.5), dict(voxels=v2, T=T2, friction=0.0)]
     return sc
+
+
+def box_sdf_mesh(half=(0.12, 0.05, 0.08), res=28, radius=0.3):
+    """SDF of a box centred at the origin of the *effector* frame, voxel box [-radius, radius]^3 (layout of
+    compute_sdf_data, utils/mesh.py:63-87)."""
+    g = np.linspace(-radius, radius, res)
+    X, Y, Z = np.meshgrid(g, g, g, indexing='ij')
+    q = np.abs(np.stack([X, Y, Z], -1)) - np.asarray(half)
+    vox = np.linalg.norm(np.maximum(q, 0), axis=-1) + np.minimum(q.max(axis=-1), 0)
+    T = np.eye(4)
+    T[:3, :3] *= (res - 1) / (2 * radius)
+    T[:3, 3] = (res - 1) / 2
+    return f32(vox), T
+
+
+def offset_sphere_sdf_mesh(center=(0.05, 0.0, 0.03), r=0.1, res=28, radius=0.3):
+    """SDF of a sphere that does not sit at the effector's origin (so rotating the effector moves it).  Unlike the box, its
+    normal field has no medial-axis jumps inside the solid: fp32 and fp64 runs stay on the same contact branches."""
+    g = np.linspace(-radius, radius, res)
+    X, Y, Z = np.meshgrid(g, g, g, indexing='ij')
+    vox = np.sqrt((X - center[0]) ** 2 + (Y - center[1]) ** 2 + (Z - center[2]) ** 2) - r
+    T = np.eye(4)
+    T[:3, :3] *= (res - 1) / (2 * radius)
+    T[:3, 3] = (res - 1) / 2
+    return f32(vox), T
+
+
+def stirrer_mini(n_grid=16, n_particles=1500, seed=11, horizon=4, n_substeps=4, friction=0.5, softness=0.0, action_dim=6, shape='box'):
+    """A Rigid effector (rigid.py, dynamic.py) -- a tilted box moving and rotating through a water block -- with a 6-dof
+    action per step: particle-level agent.collide in g2p, collider velocity from the pose change, pose/quaternion adjoints."""
+    rng = np.random.RandomState(seed)
+    sc = water_block(n_grid=n_grid, n_particles=n_particles, seed=seed, lo=0.3, hi=0.62, gravity=(0.0, -10.0, 0.0))
+    vox, T = box_sdf_mesh() if shape == 'box' else offset_sphere_sdf_mesh()
+    L = horizon * n_substeps
+    sc.update(n_substeps=n_substeps, horizon=horizon, max_substeps_local=L + n_substeps,
+              rigid=dict(action_dim=action_dim, action_scale_v=(1, 1, 1, 1, 1, 1), action_scale_p=(1, 1, 1, 1, 1, 1),
+                         boundary=dict(type='cube', lower=(0.1, 0.1, 0.1), upper=(0.9, 0.9, 0.9)),
+                         voxels=vox, T=T, friction=friction, softness=softness,
+                         init_state=[0.45, 0.47, 0.46, 0.9238795, 0.0, 0.3826834, 0.0]),       # 45 deg about y
+              action_p=f32([0.45, 0.47, 0.46, 0, 0, 0][:action_dim]),
+              actions=f32(np.concatenate([rng.uniform(-0.02, 0.02, (horizon, 3)), rng.uniform(-0.3, 0.3, (horizon, 3))], 1)[:, :action_dim]))
+    sc['v'] = f32(rng.normal(0, 0.3, (n_particles, 3)))
+    return sc
+
+
+def run_rigid(elib, sc, cot, device=0, options=None, actions=None, action_p=None):
+    """Forward over the horizon with per-step actions, cotangent `cot` on the final frame, backward, action gradient
+    [(horizon + 1), action_dim] -- the Solver's pass (solver.py:23-59) for an AgentRigid scene, through the raw ABI."""
+    eng = make_engine(elib, sc, device=device, options=options)
+    r = sc['rigid']
+    e = eng.add_effector(type=FE_EFF_PLAIN, action_dim=r['action_dim'], action_scale_v=r['action_scale_v'],
+                         action_scale_p=r['action_scale_p'], boundary=elib.make_boundary(**r['boundary']))
+    eng.eff_set_mesh(e, r['voxels'], r['T'], friction=r['friction'], softness=r['softness'])
+    st0 = eng.eff_get_state(e, 0)
+    st0[:7] = r['init_state']
+    eng.eff_set_state(e, 0, st0)
+    H, ns = sc['horizon'], sc['n_substeps']
+    actions = sc['actions'] if actions is None else actions
+    eng.eff_apply_action_p(e, sc['action_p'] if action_p is None else action_p)
+    for s in range(H):
+        eng.eff_set_action(e, s, s, ns, actions[s])
+        eng.step(s * ns, s * ns, ns, 1)
+    final = get_state(eng, H * ns)
+    eff_state = eng.eff_get_state(e, H * ns)
+    eng.reset_grad()
+    eng.add_grad(H * ns, cot['gx'], cot['gv'], cot['gC'], cot['gF'])
+    for s in reversed(range(H)):
+        eng.step_grad(s * ns, s * ns, ns, 1)
+        eng.eff_set_action_grad(e, s, s, ns)
+    eng.eff_apply_action_p_grad(e)
+    grad = eng.eff_get_action_grad(e, 0, H, r['action_dim'])
+    gx0 = eng.get_grad(0)[0]
+    eng.close()
+    loss = float(sum((final[k].astype(np.float64) * cot[g]).sum() for k, g in zip('xvCF', ('gx', 'gv', 'gC', 'gF'))))
+    return dict(final=final, action_grad=grad, eff_state=eff_state, loss=loss, gx0=gx0)
 
 
 def latte_mini(n_grid=16, n_coffee=1200, n_pool=200, seed=2, horizon=6, n_substeps=4, flux=2):
