@@ -1,2 +1,3 @@
 from .agent import Agent
 from .agent_injector import AgentInjector
+from .agent_rigid import AgentRigid

@@ -12,6 +12,9 @@ class Agent:
         self.ckpt_dest = ckpt_dest
         self.collide_type = collide_type
         assert self.collide_type in ['particle', 'grid', 'both']
+        if self.collide_type != 'particle':
+            # no reference config overrides the default (agent.py:17); grid-level agent.collide (mpm:392-395) is not built
+            raise NotImplementedError("collide_type 'grid'/'both' is not supported: agent.collide runs at particle level")
         self.effectors = []
         self.action_dims = [0]
 

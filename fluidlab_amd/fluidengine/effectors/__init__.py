@@ -1,2 +1,3 @@
 from .effector import Effector
 from .injector import Injector, BallInjector
+from .rigid import Rigid

@@ -1,0 +1,21 @@
+"""Rigid -- a rigid end-effector carrying an SDF mesh: stirrer, cone, ladle ... (fluidlab/fluidengine/effectors/rigid.py).
+
+Dynamic.collide (dynamic.py:96-122) runs inside the engine's g2p (particle level, mpm:418-422) once the mesh has been
+handed over with fe_eff_set_mesh; update_mesh_pose (rigid.py:31-33) only feeds the renderer and has no counterpart."""
+from fluidlab_amd.fluidengine.meshes import Dynamic
+from .effector import Effector
+
+
+class Rigid(Effector):
+    def __init__(self, **kwargs):
+        super().__init__(**kwargs)
+        self.mesh = None
+
+    def setup_mesh(self, **kwargs):
+        self.mesh = Dynamic(container=self, **kwargs)                        # rigid.py:19-24
+
+    def build(self, engine):
+        super().build(engine)
+        if self.mesh is not None:
+            engine.eff_set_mesh(self.index, self.mesh.sdf_voxels_np.astype(engine.dtype), self.mesh.T_mesh_to_voxels_np,
+                                friction=self.mesh.friction, softness=self.mesh.softness)

@@ -122,6 +122,16 @@ class Static:
         return np.where(outside, 1.0, sd)
 
 
+class Dynamic(Static):
+    """Dynamic mesh of a Rigid effector (dynamic.py): the same SDF + pose inputs as a Static, with has_dynamics always on;
+    the mesh frame is the effector's frame (the pose at frame f is applied by the engine, dynamic.py:29-36)."""
+
+    def __init__(self, container, **kwargs):
+        self.container = container
+        kwargs['has_dynamics'] = True
+        super().__init__(**kwargs)
+
+
 class Statics:
     """statics.py"""
 

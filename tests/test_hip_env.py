@@ -70,3 +70,25 @@ def test_static_cup_through_python_stack(hiplib, oracle32):
     xa, xb = a.get_state()['state']['x'], b.get_state()['state']['x']
     assert np.isfinite(xa).all()
     assert np.abs(xa - xb).max() <= 2e-4          # fp32 engine vs fp32 oracle over 600 substeps with contact
+
+
+def test_agent_rigid_through_python_stack(hiplib, oracle32):
+    """AgentRigid + Rigid (analytic cylinder mesh) on the HIP engine vs the oracle through TaichiEnv, forward and action
+    gradient."""
+    import test_host_env as H
+    out = []
+    for lib in (None, oracle32):
+        te = H._stir_env(lib)
+        te.set_state(te.get_state()['state'], grad_enabled=True)
+        actions = np.tile([0.02, 0.0, 0.0, 0.0, 0.3, 0.0], (6, 1))
+        for a in actions:
+            te.step(a)
+        x1 = te.get_state()['state']['x']
+        te.reset_grad()
+        te.simulator.engine.add_grad(te.simulator.cur_substep_local, np.ones_like(x1), None, None, None)
+        for a in actions[::-1]:
+            te.step_grad(a)
+        out.append((x1, te.agent.get_grad(6)))
+    (xa, ga), (xb, gb) = out
+    assert np.abs(xa - xb).max() <= 2e-5
+    assert S.cosine(ga, gb) >= 0.9999 and S.rel_l2(ga, gb) <= 2e-2
