@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HIP_LIB_PATH = os.path.join(_HERE, 'csrc', 'libfluidengine_hip.so')
 
 FE_BOUNDARY_CUBE, FE_BOUNDARY_CYLINDER = 0, 1
-FE_EFF_PLAIN, FE_EFF_INJECTOR = 0, 1
+FE_EFF_PLAIN, FE_EFF_INJECTOR, FE_EFF_AIRCON = 0, 1, 2
 
 
 class FeEngineError(RuntimeError):
@@ -35,7 +35,7 @@ def _structs(real):
 
     class FeEffectorDesc(C.Structure):
         _fields_ = [('struct_size', C.c_int), ('type', C.c_int), ('action_dim', C.c_int),
-                    ('action_scale_v', real * 6), ('action_scale_p', real * 6),
+                    ('action_scale_v', real * 8), ('action_scale_p', real * 8),
                     ('boundary', FeBoundary), ('flux', C.c_int), ('radius', real),
                     ('inject_v', real * 3), ('inject_p', real * 3),
                     ('locally_random', C.c_int), ('randomize_inject_v', C.c_int),
@@ -45,7 +45,12 @@ def _structs(real):
         _fields_ = [('struct_size', C.c_int), ('res', C.c_int), ('T_mesh_to_voxels', real * 16),
                     ('friction', real), ('softness', real)]
 
-    return FeBoundary, FeConfig, FeEffectorDesc, FeSdfDesc
+    class FeSmokeConfig(C.Structure):
+        _fields_ = [('struct_size', C.c_int), ('res', C.c_int), ('solver_iters', C.c_int), ('q_dim', C.c_int),
+                    ('max_steps_local', C.c_int), ('dt', real), ('decay', real), ('high_T', real), ('low_T', real),
+                    ('lower_y', C.c_int), ('higher_y', C.c_int)]
+
+    return FeBoundary, FeConfig, FeEffectorDesc, FeSdfDesc, FeSmokeConfig
 
 
 class FeStats(C.Structure):
@@ -61,10 +66,12 @@ ABI_SYMBOLS = [
     'fe_step_grad', 'fe_get_frame', 'fe_set_frame', 'fe_copy_frame', 'fe_copy_grad',
     'fe_reset_grad', 'fe_reset_grad_till_frame', 'fe_get_grad', 'fe_add_grad', 'fe_get_mat',
     'fe_add_static', 'fe_eff_set_mesh', 'fe_add_effector', 'fe_eff_set_act_range', 'fe_eff_get_state', 'fe_eff_set_state',
-    'fe_eff_get_vw', 'fe_eff_set_vw', 'fe_eff_set_action', 'fe_eff_set_action_grad',
+    'fe_eff_get_vw', 'fe_eff_set_vw', 'fe_eff_get_sr', 'fe_eff_set_sr', 'fe_eff_set_action', 'fe_eff_set_action_grad',
     'fe_eff_apply_action_p', 'fe_eff_apply_action_p_grad', 'fe_eff_get_action_grad',
     'fe_agent_copy_frame', 'fe_agent_copy_grad', 'fe_agent_reset_grad_till_frame', 'fe_loss_alloc', 'fe_loss_set_target',
     'fe_loss_clear', 'fe_loss_step', 'fe_loss_step_grad', 'fe_loss_get', 'fe_get_stats',
+    'fe_smoke_create', 'fe_smoke_step', 'fe_smoke_step_grad', 'fe_smoke_get_frame', 'fe_smoke_set_frame', 'fe_smoke_get_grad',
+    'fe_smoke_add_grad', 'fe_smoke_copy_frame', 'fe_smoke_copy_grad', 'fe_smoke_reset_grad', 'fe_smoke_reset_grad_till_frame',
     'fe_timer_start', 'fe_timer_stop_ms', 'fe_profile_enable', 'fe_profile_read',
 ]
 
@@ -84,7 +91,7 @@ class EngineLib:
         self.backend = lib.fe_backend().decode()
         self.real = C.c_float if self.real_size == 4 else C.c_double
         self.dtype = np.float32 if self.real_size == 4 else np.float64
-        self.FeBoundary, self.FeConfig, self.FeEffectorDesc, self.FeSdfDesc = _structs(self.real)
+        self.FeBoundary, self.FeConfig, self.FeEffectorDesc, self.FeSdfDesc, self.FeSmokeConfig = _structs(self.real)
         lib.fe_create.restype = C.c_void_p
         lib.fe_create.argtypes = [C.c_void_p]
         lib.fe_destroy.restype = None
@@ -288,10 +295,10 @@ class Engine:
         d.struct_size = C.sizeof(self.elib.FeEffectorDesc)
         d.type = int(type)
         d.action_dim = int(action_dim)
-        sv = list(action_scale_v) + [1.0] * 6
-        sp = list(action_scale_p) + [1.0] * 6
-        d.action_scale_v[:] = [float(t) for t in sv[:6]]
-        d.action_scale_p[:] = [float(t) for t in sp[:6]]
+        sv = list(action_scale_v) + [1.0] * 8
+        sp = list(action_scale_p) + [1.0] * 8
+        d.action_scale_v[:] = [float(t) for t in sv[:8]]
+        d.action_scale_p[:] = [float(t) for t in sp[:8]]
         d.boundary = boundary
         d.flux = int(flux)
         d.radius = float(radius)
@@ -323,6 +330,69 @@ class Engine:
         if i < 0:
             raise FeEngineError(self.lib.fe_last_error(self.h).decode())
         return i
+
+    # ---- AirCon strength / radius
+    def eff_get_sr(self, e, f):
+        s_, r_ = self.elib.real(), self.elib.real()
+        self._ck(self.lib.fe_eff_get_sr(self.h, int(e), int(f), C.byref(s_), C.byref(r_)))
+        return float(s_.value), float(r_.value)
+
+    def eff_set_sr(self, e, f, s, r):
+        self._ck(self.lib.fe_eff_set_sr(self.h, int(e), int(f), self.elib.real(float(s)), self.elib.real(float(r))))
+
+    # ---- smoke field (smoke_field.py)
+    def smoke_create(self, res=128, dt=0.03, solver_iters=500, q_dim=3, decay=0.99, max_steps_local=None, high_T=1.0, low_T=0.0,
+                     lower_y=60, higher_y=68):
+        c = self.elib.FeSmokeConfig()
+        c.struct_size = C.sizeof(self.elib.FeSmokeConfig)
+        c.res, c.solver_iters, c.q_dim, c.max_steps_local = int(res), int(solver_iters), int(q_dim), int(max_steps_local)
+        c.dt, c.decay, c.high_T, c.low_T = float(dt), float(decay), float(high_T), float(low_T)
+        c.lower_y, c.higher_y = int(lower_y), int(higher_y)
+        self._ck(self.lib.fe_smoke_create(self.h, C.byref(c)))
+        self.smoke_res, self.smoke_q_dim = int(res), int(q_dim)
+
+    def smoke_step(self, s, f):
+        self._ck(self.lib.fe_smoke_step(self.h, int(s), int(f)))
+
+    def smoke_step_grad(self, s, f):
+        self._ck(self.lib.fe_smoke_step_grad(self.h, int(s), int(f)))
+
+    def smoke_get_frame(self, s, fields=('v', 'q')):
+        n, qd = self.smoke_res, self.smoke_q_dim
+        shapes = dict(v=(n, n, n, 3), v_tmp=(n, n, n, 3), div=(n, n, n), p=(n, n, n), q=(n, n, n, qd))
+        out = {k: np.zeros(shapes[k], self.dtype) for k in fields}
+        ptr = [out[k].ctypes.data_as(C.c_void_p) if k in out else None for k in ('v', 'v_tmp', 'div', 'p', 'q')]
+        self._ck(self.lib.fe_smoke_get_frame(self.h, int(s), *ptr))
+        return out
+
+    def smoke_set_frame(self, s, **arrays):
+        keep = {k: np.ascontiguousarray(a, self.dtype) for k, a in arrays.items() if a is not None}
+        ptr = [keep[k].ctypes.data_as(C.c_void_p) if k in keep else None for k in ('v', 'v_tmp', 'div', 'p', 'q')]
+        self._ck(self.lib.fe_smoke_set_frame(self.h, int(s), *ptr))
+
+    def smoke_get_grad(self, s):
+        n, qd = self.smoke_res, self.smoke_q_dim
+        gv, gq = np.zeros((n, n, n, 3), self.dtype), np.zeros((n, n, n, qd), self.dtype)
+        self._ck(self.lib.fe_smoke_get_grad(self.h, int(s), gv.ctypes.data_as(C.c_void_p), gq.ctypes.data_as(C.c_void_p)))
+        return gv, gq
+
+    def smoke_add_grad(self, s, gv=None, gq=None):
+        kv = None if gv is None else np.ascontiguousarray(gv, self.dtype)
+        kq = None if gq is None else np.ascontiguousarray(gq, self.dtype)
+        self._ck(self.lib.fe_smoke_add_grad(self.h, int(s), None if kv is None else kv.ctypes.data_as(C.c_void_p),
+                                            None if kq is None else kq.ctypes.data_as(C.c_void_p)))
+
+    def smoke_copy_frame(self, src, dst):
+        self._ck(self.lib.fe_smoke_copy_frame(self.h, int(src), int(dst)))
+
+    def smoke_copy_grad(self, src, dst):
+        self._ck(self.lib.fe_smoke_copy_grad(self.h, int(src), int(dst)))
+
+    def smoke_reset_grad(self):
+        self._ck(self.lib.fe_smoke_reset_grad(self.h))
+
+    def smoke_reset_grad_till_frame(self, s):
+        self._ck(self.lib.fe_smoke_reset_grad_till_frame(self.h, int(s)))
 
     def eff_set_mesh(self, e, voxels, T_mesh_to_voxels, friction=0.0, softness=0.0):
         """Rigid.setup_mesh (rigid.py:19-24): effector e becomes a moving SDF collider."""

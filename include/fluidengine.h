@@ -74,19 +74,19 @@ typedef struct FeConfig {
 } FeConfig;
 
 /* effectors — fluidlab/fluidengine/effectors/effector.py, injector.py */
-enum { FE_EFF_PLAIN = 0, FE_EFF_INJECTOR = 1 };
+enum { FE_EFF_PLAIN = 0, FE_EFF_INJECTOR = 1, FE_EFF_AIRCON = 2 };     /* Effector/Rigid, Injector, AirCon (aircon.py) */
 
 typedef struct FeEffectorDesc {
     int        struct_size;
     int        type;                 /* FE_EFF_*                                    */
-    int        action_dim;           /* 0, 3 or 6; effector.py:43                   */
-    fe_real    action_scale_v[6];    /* effector.py:54                              */
-    fe_real    action_scale_p[6];    /* effector.py:55                              */
+    int        action_dim;           /* 0, 3 or 6 (8 for FE_EFF_AIRCON); effector.py:43 */
+    fe_real    action_scale_v[8];    /* effector.py:54                              */
+    fe_real    action_scale_p[8];    /* effector.py:55                              */
     FeBoundary boundary;             /* the effector's own boundary, effector.py:62 */
     /* Injector only (injector.py:13-36) */
     int        flux;                 /* particles injected per substep              */
     fe_real    radius;
-    fe_real    inject_v[3];
+    fe_real    inject_v[3];          /* Injector: particle velocity; AirCon: blowing direction (aircon.py:14-26) */
     fe_real    inject_p[3];
     int        locally_random;       /* random_vector indexed by f (1) or f_global (0) */
     int        randomize_inject_v;
@@ -145,6 +145,10 @@ int fe_eff_set_state(FeEngine* h, int e, int f, const fe_real* state8);
 /* v[3], w[3] of frame f (checkpoint payload, effector.py:84-102) */
 int fe_eff_get_vw(FeEngine* h, int e, int f, fe_real* v3, fe_real* w3);
 int fe_eff_set_vw(FeEngine* h, int e, int f, const fe_real* v3, const fe_real* w3);
+/* AirCon only: strength s[f] and radius r[f] (aircon.py:20-21,178-191); set by set_velocity from action[6], action[7]
+ * times their action_scale (aircon.py:211-213) */
+int fe_eff_get_sr(FeEngine* h, int e, int f, fe_real* s, fe_real* r);
+int fe_eff_set_sr(FeEngine* h, int e, int f, fe_real s, fe_real r);
 int fe_eff_set_action(FeEngine* h, int e, int s, int s_global, int n_substeps,
                       const fe_real* action);                                     /* effector.py:262-268 */
 int fe_eff_set_action_grad(FeEngine* h, int e, int s, int s_global, int n_substeps); /* effector.py:270-274 */
@@ -176,6 +180,36 @@ int fe_add_static(FeEngine* h, const FeSdfDesc* desc, const fe_real* voxels);   
  * sticks.  Its adjoint reaches the material velocity, the particle position and the effector pose at f and f+1
  * (hence 6-dof action gradients through move_kernel's quaternion update, effector.py:157-161). */
 int fe_eff_set_mesh(FeEngine* h, int e, const FeSdfDesc* desc, const fe_real* voxels);
+
+/* ---- smoke field: fluidlab/fluidengine/simulators/smoke_field.py ------------------------------------------------------ */
+/* An Eulerian smoke/temperature solver on its own res^3 grid, stepped once per *step* (mpm:745-747, 765-767): free-space
+ * mask (a y-slab minus the static colliders, 191-201), RK3 back-trace advection of velocity and temperature + the AirCon
+ * impulse (203-232, 315-360), divergence with solid-wall mirroring (234-258), `solver_iters` Jacobi sweeps (130-143),
+ * pressure-gradient subtraction (273-288); step_grad is the hand-derived adjoint of all of it (113-128).  Frames s are
+ * local step indices in [0, max_steps_local]. */
+typedef struct FeSmokeConfig {
+    int     struct_size;
+    int     res;                 /* smoke_field.py:17 (128)                         */
+    int     solver_iters;        /* :20                                              */
+    int     q_dim;               /* :21; q[0] is the temperature                     */
+    int     max_steps_local;     /* MPMSimulator.max_steps_local, :39                */
+    fe_real dt;                  /* :19 (0.03)                                       */
+    fe_real decay;               /* :22 (stored, unused by the reference's kernels)  */
+    fe_real high_T, low_T;       /* :23-24                                           */
+    int     lower_y, higher_y;   /* free slab lower_y < j < higher_y, :25-26 (60, 68) */
+} FeSmokeConfig;
+int fe_smoke_create(FeEngine* h, const FeSmokeConfig* cfg);          /* __init__, setup_fields, init_fields (:57-93) */
+int fe_smoke_step(FeEngine* h, int s, int f);                         /* step(s, f), :95-111; needs an FE_EFF_AIRCON  */
+int fe_smoke_step_grad(FeEngine* h, int s, int f);                    /* step_grad(s, f), :113-128                    */
+/* frame I/O (get_state/set_state/ckpt).  NULL pointers are skipped.  v, v_tmp [res^3,3]; div, p [res^3]; q [res^3,q_dim] */
+int fe_smoke_get_frame(FeEngine* h, int s, fe_real* v, fe_real* v_tmp, fe_real* div, fe_real* p, fe_real* q);
+int fe_smoke_set_frame(FeEngine* h, int s, const fe_real* v, const fe_real* v_tmp, const fe_real* div, const fe_real* p, const fe_real* q);
+int fe_smoke_get_grad(FeEngine* h, int s, fe_real* gv, fe_real* gq);
+int fe_smoke_add_grad(FeEngine* h, int s, const fe_real* gv, const fe_real* gq);   /* losses seed q.grad / v.grad here */
+int fe_smoke_copy_frame(FeEngine* h, int src, int dst);              /* :145-152 */
+int fe_smoke_copy_grad(FeEngine* h, int src, int dst);               /* :154-161 */
+int fe_smoke_reset_grad(FeEngine* h);                                /* :163-166 */
+int fe_smoke_reset_grad_till_frame(FeEngine* h, int s);              /* :168-171 */
 
 /* ---- loss: shapematching_loss.py:64-93 -------------------------------- */
 int fe_loss_alloc(FeEngine* h, int max_loss_steps);

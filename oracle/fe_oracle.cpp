@@ -219,6 +219,7 @@ void impose_v(const FeBoundary& b, const R x[3], R v[3], R k[3]) {
 struct Effector {
     FeEffectorDesc d;
     std::vector<R> pos, quat, v, w, gpos, gquat, gv, gw;     /* [L+1] x {3,4,3,3} */
+    std::vector<R> sa, ra, gsa, gra;                         /* AirCon strength s[f], radius r[f] + grads (aircon.py:20-21) */
     std::vector<R> abuf, gabuf, abuf_p, gabuf_p;              /* action buffers + grads */
     std::vector<int> act_id;                                   /* [L+1] */
     std::vector<R> random_vector;
@@ -229,6 +230,20 @@ struct Effector {
 /* a Mesh with has_dynamics: SDF voxels + world->voxel map (mesh.py:57-66,120-127) */
 struct Sdf { int res; std::vector<R> vox; R T[16]; R Rinv[9]; R friction, softness; };
 
+/* SmokeField state (smoke_field.py:57-84) */
+struct Smoke {
+    FeSmokeConfig c;
+    int n, S;                      /* res, max_steps_local */
+    size_t n3;
+    std::vector<R> v, vt, dv, p, q, gv, gvt, gdv, gp, gq;       /* [(S+1)][n3][{3,3,1,1,q_dim}] */
+    std::vector<unsigned char> fr;                                /* is_free [(S+1)][n3] */
+    std::vector<R> pc, pn, gpc, gpn;                              /* p_swap.cur / nxt + grads */
+    std::vector<std::vector<R>> jac;                              /* Jacobi iterates kept for nothing: the sweep is linear */
+    size_t idx(int i, int j, int k) const { return ((size_t)i * n + j) * n + k; }
+    R* F(std::vector<R>& a, int s, int comps) { return &a[(size_t)s * n3 * comps]; }
+    unsigned char* FR(int s) { return &fr[(size_t)s * n3]; }
+};
+
 /* body_state of mpm:181-189 plus its adjoint */
 struct Body { R com0[3], com1[3]; M3 H, Rm, U, S, V; R gcom0[3], gcom1[3]; M3 gH, gR, gU, gS, gV; };
 
@@ -236,6 +251,7 @@ struct Body { R com0[3], com1[3]; M3 H, Rm, U, S, V; R gcom0[3], gcom1[3]; M3 gH
 
 struct FeEngine {
     FeConfig cfg;
+    Smoke* smoke = nullptr;            /* SmokeField (smoke_field.py), optional */
     int N, L, n;
     R dx, inv_dx;
     std::vector<R> x, v, C, F, gx, gv, gC, gF;   /* [(L+1), N, {3,3,9,9}] */
@@ -1138,6 +1154,319 @@ int substep_grad(FeEngine* h, int f, int f_global, int act) {
     return 0;
 }
 
+/* ====================================================================== smoke field
+ * fluidlab/fluidengine/simulators/smoke_field.py restated kernel by kernel, with the adjoint Taichi's autodiff derives
+ * from it written out by hand.  Positions are in cell units (cell centre = index + 0.5), velocities in cells per unit
+ * time.  Conscious fix: compute_location (smoke_field.py:298-306) falls back to the *unclamped* index when the clamped
+ * cell is not free, which reads out of bounds for indices outside the grid; here the fallback is the clamped index. */
+
+static inline int sm_clampi(int a, int n) { return a < 0 ? 0 : (a > n - 1 ? n - 1 : a); }
+/* compute_location, smoke_field.py:298-306 */
+static size_t sm_loc(Smoke& m, const unsigned char* fr, int u, int v, int w, int du, int dv, int dw) {
+    int I[3] = {sm_clampi(u + du, m.n), sm_clampi(v + dv, m.n), sm_clampi(w + dw, m.n)};
+    if (!fr[m.idx(I[0], I[1], I[2])]) { I[0] = sm_clampi(u, m.n); I[1] = sm_clampi(v, m.n); I[2] = sm_clampi(w, m.n); }
+    return m.idx(I[0], I[1], I[2]);
+}
+/* is_free, smoke_field.py:309-320 */
+static int sm_isfree(Smoke& m, const unsigned char* fr, int u, int v, int w, int du, int dv, int dw) {
+    int I[3] = {u + du, v + dv, w + dw};
+    for (int d = 0; d < 3; d++) if (I[d] < 0 || I[d] > m.n - 1) return 0;
+    return fr[m.idx(I[0], I[1], I[2])] ? 1 : 0;
+}
+/* trilerp, smoke_field.py:322-343: value of a `comps`-component field at p, the 8 cells/weights used, and dw/dp */
+struct SmTri { size_t cell[8]; R w[8]; R dw[8][3]; };
+static void sm_trilerp(Smoke& m, const unsigned char* fr, const R* field, int comps, const R p[3], R* out, SmTri* t) {
+    int base[3]; R fr_[3];
+    for (int d = 0; d < 3; d++) { base[d] = (int)std::floor(p[d] - (R)0.5); fr_[d] = p[d] - (R)0.5 - base[d]; }
+    for (int c = 0; c < comps; c++) out[c] = 0;
+    R wt = 0;
+    int o = 0;
+    for (int i = 0; i < 2; i++) for (int j = 0; j < 2; j++) for (int k = 0; k < 2; k++, o++) {
+        const int off[3] = {i, j, k};
+        R wd[3], dwd[3];
+        for (int d = 0; d < 3; d++) { wd[d] = 1 - std::fabs(fr_[d] - off[d]); dwd[d] = off[d] ? (R)1 : (R)-1; }   /* fr_ in [0,1) */
+        const R w = wd[0] * wd[1] * wd[2];
+        const size_t cell = sm_loc(m, fr, base[0] + i, base[1] + j, base[2] + k, 0, 0, 0);
+        for (int c = 0; c < comps; c++) out[c] += w * field[cell * comps + c];
+        wt += w;
+        if (t) { t->cell[o] = cell; t->w[o] = w; t->dw[o][0] = dwd[0] * wd[1] * wd[2]; t->dw[o][1] = wd[0] * dwd[1] * wd[2]; t->dw[o][2] = wd[0] * wd[1] * dwd[2]; }
+    }
+    for (int c = 0; c < comps; c++) out[c] /= wt;              /* wt == 1 up to rounding: the two weights per axis sum to 1 */
+}
+/* adjoint of one trilerp: scatters g (d/d value) into gfield, returns d/dp */
+static void sm_trilerp_grad(const SmTri& t, const R* field, R* gfield, int comps, const R* g, R gp[3]) {
+    gp[0] = gp[1] = gp[2] = 0;
+    for (int o = 0; o < 8; o++) {
+        R dot = 0;
+        for (int c = 0; c < comps; c++) {
+            dot += field[t.cell[o] * comps + c] * g[c];
+            if (gfield) {
+#pragma omp atomic
+                gfield[t.cell[o] * comps + c] += t.w[o] * g[c];
+            }
+        }
+        for (int d = 0; d < 3; d++) gp[d] += t.dw[o][d] * dot;
+    }
+}
+
+/* compute_free_space, smoke_field.py:191-201 */
+static void smoke_free_space(FeEngine* h, Smoke& m, int s) {
+    unsigned char* fr = m.FR(s);
+    const R dx = (R)1 / m.n;
+#pragma omp parallel for num_threads(h->threads) schedule(static)
+    for (long long c = 0; c < (long long)m.n3; c++) {
+        const int i = (int)(c / ((size_t)m.n * m.n)), j = (int)((c / m.n) % m.n), k = (int)(c % m.n);
+        unsigned char f = (m.c.lower_y < j && j < m.c.higher_y) ? 1 : 0;
+        if (f) {
+            const R pw[3] = {(i + (R)0.5) * dx, (j + (R)0.5) * dx, (k + (R)0.5) * dx};
+            for (const Sdf& st : h->statics) { R pv[3]; sdf_to_voxels(st, pw, pv); if (sdf_sample(st, pv) <= 0) f = 0; }   /* is_collide, static.py:105-113 */
+        }
+        fr[c] = f;
+    }
+}
+static Effector* smoke_aircon(FeEngine* h) {
+    for (auto& e : h->effs) if (e.d.type == FE_EFF_AIRCON) return &e;
+    return nullptr;
+}
+/* per-cell pieces of advect_and_impulse shared by forward and adjoint */
+struct SmAdv { R p0[3], v1[3], p1[3], v2[3], p2[3], v3[3], pf[3], vf[3]; SmTri t1, t2, t3, tv, tq; R dist, factor, dir[3]; };
+static void smoke_advect_cell(Smoke& m, Effector& a, int s, int f, int i, int j, int k, SmAdv& A, R* qf) {
+    const unsigned char* fr = m.FR(s);
+    const R* vfield = m.F(m.v, s, 3);
+    const R dt = m.c.dt;
+    A.p0[0] = i + (R)0.5; A.p0[1] = j + (R)0.5; A.p0[2] = k + (R)0.5;
+    sm_trilerp(m, fr, vfield, 3, A.p0, A.v1, &A.t1);                                          /* backtrace, RK3: 347-360 */
+    for (int d = 0; d < 3; d++) A.p1[d] = A.p0[d] - (R)0.5 * dt * A.v1[d];
+    sm_trilerp(m, fr, vfield, 3, A.p1, A.v2, &A.t2);
+    for (int d = 0; d < 3; d++) A.p2[d] = A.p0[d] - (R)0.75 * dt * A.v2[d];
+    sm_trilerp(m, fr, vfield, 3, A.p2, A.v3, &A.t3);
+    for (int d = 0; d < 3; d++) A.pf[d] = A.p0[d] - dt * (((R)2 / 9) * A.v1[d] + ((R)1 / 3) * A.v2[d] + ((R)4 / 9) * A.v3[d]);
+    sm_trilerp(m, fr, vfield, 3, A.pf, A.vf, &A.tv);
+    sm_trilerp(m, fr, m.F(m.q, s, m.c.q_dim), m.c.q_dim, A.pf, qf, &A.tq);
+    /* agent impulse, 213-218 */
+    const R dx = (R)1 / m.n;
+    R dd[3] = {i - a.pos[f * 3] / dx, j - a.pos[f * 3 + 1] / dx, k - a.pos[f * 3 + 2] / dx};
+    A.dist = std::sqrt(dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2] + EPS);
+    A.factor = std::exp(-A.dist / a.ra[f]);
+    transform_by_quat(a.d.inject_v, &a.quat[f * 4], A.dir);
+}
+/* advect_and_impulse, smoke_field.py:203-232 */
+static void smoke_advect(FeEngine* h, Smoke& m, Effector& a, int s, int f) {
+    const unsigned char* fr = m.FR(s);
+    const int qd = m.c.q_dim;
+#pragma omp parallel for num_threads(h->threads) schedule(static)
+    for (long long c = 0; c < (long long)m.n3; c++) {
+        const int i = (int)(c / ((size_t)m.n * m.n)), j = (int)((c / m.n) % m.n), k = (int)(c % m.n);
+        R* vt = &m.F(m.vt, s, 3)[c * 3];
+        R* qn = &m.F(m.q, s + 1, qd)[c * qd];
+        if (fr[c]) {
+            SmAdv A; R qf[8];
+            smoke_advect_cell(m, a, s, f, i, j, k, A, qf);
+            for (int d = 0; d < 3; d++) vt[d] = A.vf[d] + A.dir[d] * a.sa[f] * A.factor * m.c.dt;
+            for (int d = 0; d < qd; d++) qn[d] = (1 - A.factor) * qf[d] + A.factor * m.c.low_T;     /* ti.Vector([low_T]) broadcasts */
+        } else {
+            vt[0] = vt[1] = vt[2] = 0;
+            for (int d = 0; d < qd; d++) qn[d] = m.F(m.q, s, qd)[c * qd + d];
+        }
+    }
+}
+static void smoke_advect_grad(FeEngine* h, Smoke& m, Effector& a, int s, int f) {
+    const unsigned char* fr = m.FR(s);
+    const int qd = m.c.q_dim;
+    const R dt = m.c.dt, dx = (R)1 / m.n;
+    R* gvfield = m.F(m.gv, s, 3);
+    R* gqfield = m.F(m.gq, s, qd);
+    const R* vfield = m.F(m.v, s, 3);
+    const R* qfield = m.F(m.q, s, qd);
+    R gpos[3] = {0, 0, 0}, gquat[4] = {0, 0, 0, 0}, gs = 0, gr = 0;
+#pragma omp parallel for num_threads(h->threads) schedule(static) reduction(+:gpos[:3], gquat[:4], gs, gr)
+    for (long long c = 0; c < (long long)m.n3; c++) {
+        const int i = (int)(c / ((size_t)m.n * m.n)), j = (int)((c / m.n) % m.n), k = (int)(c % m.n);
+        const R* gvt = &m.F(m.gvt, s, 3)[c * 3];
+        const R* gqn = &m.F(m.gq, s + 1, qd)[c * qd];
+        if (!fr[c]) {
+            for (int d = 0; d < qd; d++) {
+#pragma omp atomic
+                gqfield[c * qd + d] += gqn[d];
+            }
+            continue;
+        }
+        SmAdv A; R qf[8];
+        smoke_advect_cell(m, a, s, f, i, j, k, A, qf);
+        /* v_tmp = v_f + dir s factor dt ; q' = (1 - factor) q_f + factor low_T */
+        R gvf[3] = {gvt[0], gvt[1], gvt[2]}, gqf[8], gfac = 0, gdir[3];
+        for (int d = 0; d < qd; d++) { gqf[d] = (1 - A.factor) * gqn[d]; gfac += gqn[d] * (m.c.low_T - qf[d]); }
+        for (int d = 0; d < 3; d++) { gfac += gvt[d] * A.dir[d] * a.sa[f] * dt; gdir[d] = gvt[d] * a.sa[f] * A.factor * dt; gs += gvt[d] * A.dir[d] * A.factor * dt; }
+        /* factor = exp(-dist / r) */
+        const R gdist = gfac * A.factor * (-1 / a.ra[f]);
+        gr += gfac * A.factor * A.dist / (a.ra[f] * a.ra[f]);
+        R dd[3] = {i - a.pos[f * 3] / dx, j - a.pos[f * 3 + 1] / dx, k - a.pos[f * 3 + 2] / dx};
+        for (int d = 0; d < 3; d++) gpos[d] += gdist * (dd[d] / A.dist) * (-1 / dx);
+        /* dir = R(quat) inject_v: one forward-mode column per quaternion component */
+        for (int qc = 0; qc < 4; qc++) {
+            Dual q[4], vin[3], out[3];
+            for (int d = 0; d < 4; d++) q[d] = Dual(a.quat[f * 4 + d], d == qc ? 1 : 0);
+            for (int d = 0; d < 3; d++) vin[d] = Dual(a.d.inject_v[d]);
+            t_quat_rot(vin, q, out);
+            gquat[qc] += gdir[0] * out[0].d + gdir[1] * out[1].d + gdir[2] * out[2].d;
+        }
+        /* the two interpolations at the back-traced point, then the RK3 chain in reverse */
+        R gpf[3], t[3], gp2[3], gp1[3], gv1[3], gv2[3], gv3[3];
+        sm_trilerp_grad(A.tv, vfield, gvfield, 3, gvf, gpf);
+        sm_trilerp_grad(A.tq, qfield, gqfield, qd, gqf, t);
+        for (int d = 0; d < 3; d++) gpf[d] += t[d];
+        for (int d = 0; d < 3; d++) { gv1[d] = -dt * ((R)2 / 9) * gpf[d]; gv2[d] = -dt * ((R)1 / 3) * gpf[d]; gv3[d] = -dt * ((R)4 / 9) * gpf[d]; }
+        sm_trilerp_grad(A.t3, vfield, gvfield, 3, gv3, gp2);
+        for (int d = 0; d < 3; d++) gv2[d] += -(R)0.75 * dt * gp2[d];
+        sm_trilerp_grad(A.t2, vfield, gvfield, 3, gv2, gp1);
+        for (int d = 0; d < 3; d++) gv1[d] += -(R)0.5 * dt * gp1[d];
+        sm_trilerp_grad(A.t1, vfield, gvfield, 3, gv1, t);           /* p0 is a constant: d/dp dropped */
+    }
+    for (int d = 0; d < 3; d++) a.gpos[f * 3 + d] += gpos[d];
+    for (int d = 0; d < 4; d++) a.gquat[f * 4 + d] += gquat[d];
+    a.gsa[f] += gs; a.gra[f] += gr;
+}
+/* divergence, smoke_field.py:234-258, and its adjoint */
+static void smoke_divergence(FeEngine* h, Smoke& m, int s, bool grad) {
+    const unsigned char* fr = m.FR(s);
+    const R* vt = m.F(m.vt, s, 3);
+    R* gvt = m.F(m.gvt, s, 3);
+    static const int NB[6][3] = {{-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};
+#pragma omp parallel for num_threads(h->threads) schedule(static)
+    for (long long c = 0; c < (long long)m.n3; c++) {
+        if (!fr[c]) continue;
+        const int i = (int)(c / ((size_t)m.n * m.n)), j = (int)((c / m.n) % m.n), k = (int)(c % m.n);
+        if (!grad) {
+            R val[6];
+            for (int b = 0; b < 6; b++) {
+                const int ax = b / 2;
+                if (!sm_isfree(m, fr, i, j, k, NB[b][0], NB[b][1], NB[b][2])) val[b] = -vt[c * 3 + ax];
+                else val[b] = vt[sm_loc(m, fr, i, j, k, NB[b][0], NB[b][1], NB[b][2]) * 3 + ax];
+            }
+            m.F(m.dv, s, 1)[c] = (val[1] - val[0] + val[3] - val[2] + val[5] - val[4]) * (R)0.5;
+        } else {
+            const R g = m.F(m.gdv, s, 1)[c] * (R)0.5;
+            for (int b = 0; b < 6; b++) {
+                const int ax = b / 2;
+                const R sg = (b & 1) ? g : -g;
+                if (!sm_isfree(m, fr, i, j, k, NB[b][0], NB[b][1], NB[b][2])) {
+#pragma omp atomic
+                    gvt[c * 3 + ax] += -sg;
+                } else {
+                    const size_t cn = sm_loc(m, fr, i, j, k, NB[b][0], NB[b][1], NB[b][2]);
+#pragma omp atomic
+                    gvt[cn * 3 + ax] += sg;
+                }
+            }
+        }
+    }
+}
+/* pressure_jacobi, smoke_field.py:130-143 (new_pf only written on free cells) and its adjoint (autodiff of the same) */
+static void smoke_jacobi(FeEngine* h, Smoke& m, int s, const std::vector<R>& pf, std::vector<R>& npf) {
+    const unsigned char* fr = m.FR(s);
+    const R* dv = m.F(m.dv, s, 1);
+    static const int NB[6][3] = {{-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};
+#pragma omp parallel for num_threads(h->threads) schedule(static)
+    for (long long c = 0; c < (long long)m.n3; c++) {
+        if (!fr[c]) continue;
+        const int i = (int)(c / ((size_t)m.n * m.n)), j = (int)((c / m.n) % m.n), k = (int)(c % m.n);
+        R sum = 0;
+        for (int b = 0; b < 6; b++) sum += pf[sm_loc(m, fr, i, j, k, NB[b][0], NB[b][1], NB[b][2])];
+        npf[c] = (sum - dv[c]) / (R)6.0;
+    }
+}
+static void smoke_jacobi_grad(FeEngine* h, Smoke& m, int s, std::vector<R>& gpf, const std::vector<R>& gnpf) {
+    const unsigned char* fr = m.FR(s);
+    R* gdv = m.F(m.gdv, s, 1);
+    static const int NB[6][3] = {{-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};
+#pragma omp parallel for num_threads(h->threads) schedule(static)
+    for (long long c = 0; c < (long long)m.n3; c++) {
+        if (!fr[c]) continue;
+        const int i = (int)(c / ((size_t)m.n * m.n)), j = (int)((c / m.n) % m.n), k = (int)(c % m.n);
+        const R g = gnpf[c] / (R)6.0;
+        gdv[c] += -g;
+        for (int b = 0; b < 6; b++) {
+            const size_t cn = sm_loc(m, fr, i, j, k, NB[b][0], NB[b][1], NB[b][2]);
+#pragma omp atomic
+            gpf[cn] += g;
+        }
+    }
+}
+/* subtract_gradient, smoke_field.py:273-288 */
+static void smoke_subtract(FeEngine* h, Smoke& m, int s, bool grad) {
+    const unsigned char* fr = m.FR(s);
+    static const int NB[6][3] = {{-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1}};
+    const R* pn = m.F(m.p, s + 1, 1);
+    R* gpn = m.F(m.gp, s + 1, 1);
+#pragma omp parallel for num_threads(h->threads) schedule(static)
+    for (long long c = 0; c < (long long)m.n3; c++) {
+        const int i = (int)(c / ((size_t)m.n * m.n)), j = (int)((c / m.n) % m.n), k = (int)(c % m.n);
+        const R* vt = &m.F(m.vt, s, 3)[c * 3];
+        if (!grad) {
+            R* vn = &m.F(m.v, s + 1, 3)[c * 3];
+            for (int d = 0; d < 3; d++) vn[d] = vt[d];
+            if (fr[c]) for (int d = 0; d < 3; d++)
+                vn[d] -= (R)0.5 * (pn[sm_loc(m, fr, i, j, k, NB[2 * d + 1][0], NB[2 * d + 1][1], NB[2 * d + 1][2])] -
+                                   pn[sm_loc(m, fr, i, j, k, NB[2 * d][0], NB[2 * d][1], NB[2 * d][2])]);
+        } else {
+            const R* gvn = &m.F(m.gv, s + 1, 3)[c * 3];
+            R* gvt = &m.F(m.gvt, s, 3)[c * 3];
+            for (int d = 0; d < 3; d++) {
+#pragma omp atomic
+                gvt[d] += gvn[d];
+            }
+            if (fr[c]) for (int d = 0; d < 3; d++) {
+                const size_t cr = sm_loc(m, fr, i, j, k, NB[2 * d + 1][0], NB[2 * d + 1][1], NB[2 * d + 1][2]);
+                const size_t cl = sm_loc(m, fr, i, j, k, NB[2 * d][0], NB[2 * d][1], NB[2 * d][2]);
+#pragma omp atomic
+                gpn[cr] += -(R)0.5 * gvn[d];
+#pragma omp atomic
+                gpn[cl] += (R)0.5 * gvn[d];
+            }
+        }
+    }
+}
+/* SmokeField.step, smoke_field.py:95-111 */
+static int smoke_step(FeEngine* h, int s, int f) {
+    Smoke& m = *h->smoke;
+    Effector* a = smoke_aircon(h);
+    if (!a) FE_FAIL(h, "smoke_step needs an AirCon effector (agent.aircon, smoke_field.py:213)");
+    smoke_free_space(h, m, s);
+    smoke_advect(h, m, *a, s, f);
+    smoke_divergence(h, m, s, false);
+    const unsigned char* fr = m.FR(s);
+    std::fill(m.pc.begin(), m.pc.end(), (R)0); std::fill(m.pn.begin(), m.pn.end(), (R)0);          /* reset_swap_and_grad */
+    for (size_t c = 0; c < m.n3; c++) if (fr[c]) m.pc[c] = m.F(m.p, s, 1)[c];                     /* pressure_to_swap */
+    for (int it = 0; it < m.c.solver_iters; it++) { smoke_jacobi(h, m, s, m.pc, m.pn); std::swap(m.pc, m.pn); }
+    for (size_t c = 0; c < m.n3; c++) if (fr[c]) m.F(m.p, s + 1, 1)[c] = m.pc[c];                 /* pressure_from_swap */
+    smoke_subtract(h, m, s, false);
+    return 0;
+}
+/* SmokeField.step_grad, smoke_field.py:113-128 */
+static int smoke_step_grad(FeEngine* h, int s, int f) {
+    Smoke& m = *h->smoke;
+    Effector* a = smoke_aircon(h);
+    if (!a) FE_FAIL(h, "smoke_step_grad needs an AirCon effector");
+    smoke_free_space(h, m, s);
+    smoke_subtract(h, m, s, true);
+    const unsigned char* fr = m.FR(s);
+    std::fill(m.gpc.begin(), m.gpc.end(), (R)0); std::fill(m.gpn.begin(), m.gpn.end(), (R)0);
+    for (size_t c = 0; c < m.n3; c++) if (fr[c]) m.gpc[c] += m.F(m.gp, s + 1, 1)[c];              /* pressure_from_swap.grad */
+    for (int it = m.c.solver_iters - 1; it >= 0; it--) {
+        std::swap(m.gpc, m.gpn);                                                                    /* p_swap.swap(); cur.grad.fill(0) */
+        std::fill(m.gpc.begin(), m.gpc.end(), (R)0);
+        smoke_jacobi_grad(h, m, s, m.gpc, m.gpn);
+    }
+    for (size_t c = 0; c < m.n3; c++) if (fr[c]) m.F(m.gp, s, 1)[c] += m.gpc[c];                  /* pressure_to_swap.grad */
+    smoke_divergence(h, m, s, true);
+    smoke_advect_grad(h, m, *a, s, f);
+    return 0;
+}
+static void smoke_reset_grad(FeEngine* h) {
+    Smoke& m = *h->smoke;
+    for (auto* t : {&m.gv, &m.gvt, &m.gdv, &m.gp, &m.gq, &m.gpc, &m.gpn}) std::fill(t->begin(), t->end(), (R)0);
+}
+
 double now_ms(FeEngine* h) {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - h->t0).count();
 }
@@ -1171,7 +1500,7 @@ FeEngine* fe_create(const FeConfig* cfg) {
     return h;
 }
 
-void fe_destroy(FeEngine* h) { delete h; }
+void fe_destroy(FeEngine* h) { if (h) delete h->smoke; delete h; }
 const char* fe_last_error(FeEngine* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 int fe_sync(FeEngine*) { return 0; }
 
@@ -1274,7 +1603,8 @@ int fe_copy_grad(FeEngine* h, int src, int dst) {
 }
 int fe_reset_grad(FeEngine* h) {
     for (auto* t : {&h->gx, &h->gv, &h->gC, &h->gF, &h->gg_vin, &h->gg_mass, &h->gg_vout}) std::fill(t->begin(), t->end(), (R)0);
-    for (auto& e : h->effs) for (auto* t : {&e.gpos, &e.gquat, &e.gv, &e.gw, &e.gabuf, &e.gabuf_p}) std::fill(t->begin(), t->end(), (R)0);
+    for (auto& e : h->effs) for (auto* t : {&e.gpos, &e.gquat, &e.gv, &e.gw, &e.gabuf, &e.gabuf_p, &e.gsa, &e.gra}) std::fill(t->begin(), t->end(), (R)0);
+    if (h->smoke) smoke_reset_grad(h);
     return 0;
 }
 int fe_reset_grad_till_frame(FeEngine* h, int f) {
@@ -1289,6 +1619,7 @@ int fe_agent_reset_grad_till_frame(FeEngine* h, int f) {
     for (auto& e : h->effs) {
         std::fill(e.gpos.begin(), e.gpos.begin() + f * 3, (R)0); std::fill(e.gquat.begin(), e.gquat.begin() + f * 4, (R)0);
         std::fill(e.gv.begin(), e.gv.begin() + f * 3, (R)0); std::fill(e.gw.begin(), e.gw.begin() + f * 3, (R)0);
+        std::fill(e.gsa.begin(), e.gsa.begin() + f, (R)0); std::fill(e.gra.begin(), e.gra.begin() + f, (R)0);
     }
     return 0;
 }
@@ -1315,9 +1646,12 @@ int fe_get_mat(FeEngine* h, int* mat) { std::memcpy(mat, h->mat.data(), sizeof(i
 /* ---- effectors */
 int fe_add_effector(FeEngine* h, const FeEffectorDesc* d, const fe_real* random_vector) {
     if (!d || d->struct_size != (int)sizeof(FeEffectorDesc)) { h->err = "FeEffectorDesc size mismatch"; return -1; }
-    if (!(d->action_dim == 0 || d->action_dim == 3 || d->action_dim == 6)) { h->err = "action_dim must be 0, 3 or 6"; return -1; }
+    if (!(d->action_dim == 0 || d->action_dim == 3 || d->action_dim == 6 || (d->type == FE_EFF_AIRCON && d->action_dim == 8))) {
+        h->err = "action_dim must be 0, 3 or 6 (8 for an AirCon)"; return -1;
+    }
     Effector e; e.d = *d;
     int Fm = h->L + 1;
+    e.sa.assign(Fm, 0); e.ra.assign(Fm, 0); e.gsa.assign(Fm, 0); e.gra.assign(Fm, 0);
     e.pos.assign(Fm * 3, 0); e.quat.assign(Fm * 4, 0); e.v.assign(Fm * 3, 0); e.w.assign(Fm * 3, 0);
     e.gpos.assign(Fm * 3, 0); e.gquat.assign(Fm * 4, 0); e.gv.assign(Fm * 3, 0); e.gw.assign(Fm * 3, 0);
     int ad = std::max(d->action_dim, 1);
@@ -1375,6 +1709,10 @@ int fe_eff_set_action(FeEngine* h, int e, int s, int s_global, int n_substeps, c
         R nf = (R)n_substeps;
         for (int k = 0; k < 3; k++) E.v[j * 3 + k] = E.abuf[(size_t)s_global * ad + k] * E.d.action_scale_v[k] / nf;
         if (ad > 3) for (int k = 0; k < 3; k++) E.w[j * 3 + k] = E.abuf[(size_t)s_global * ad + k + 3] * E.d.action_scale_v[k + 3] / nf;
+        if (ad > 6) {                                                                                  /* aircon.py:211-213 */
+            E.sa[j] = E.abuf[(size_t)s_global * ad + 6] * E.d.action_scale_v[6];
+            E.ra[j] = E.abuf[(size_t)s_global * ad + 7] * E.d.action_scale_v[7];
+        }
     }
     return 0;
 }
@@ -1388,6 +1726,10 @@ int fe_eff_set_action_grad(FeEngine* h, int e, int s, int s_global, int n_subste
         R nf = (R)n_substeps;
         for (int k = 0; k < 3; k++) E.gabuf[(size_t)s_global * ad + k] += E.gv[j * 3 + k] * E.d.action_scale_v[k] / nf;
         if (ad > 3) for (int k = 0; k < 3; k++) E.gabuf[(size_t)s_global * ad + k + 3] += E.gw[j * 3 + k] * E.d.action_scale_v[k + 3] / nf;
+        if (ad > 6) {
+            E.gabuf[(size_t)s_global * ad + 6] += E.gsa[j] * E.d.action_scale_v[6];
+            E.gabuf[(size_t)s_global * ad + 7] += E.gra[j] * E.d.action_scale_v[7];
+        }
     }
     return 0;
 }
@@ -1429,6 +1771,7 @@ int fe_agent_copy_frame(FeEngine* h, int src, int dst) {
     for (auto& E : h->effs) {
         for (int j = 0; j < 3; j++) { E.pos[dst * 3 + j] = E.pos[src * 3 + j]; E.v[dst * 3 + j] = E.v[src * 3 + j]; E.w[dst * 3 + j] = E.w[src * 3 + j]; }
         for (int j = 0; j < 4; j++) E.quat[dst * 4 + j] = E.quat[src * 4 + j];
+        E.sa[dst] = E.sa[src]; E.ra[dst] = E.ra[src];                          /* aircon.py:148-155 */
         if (E.d.type == FE_EFF_INJECTOR) E.act_id[dst] = E.act_id[src];       /* injector.py:174-179 */
     }
     return 0;
@@ -1438,7 +1781,104 @@ int fe_agent_copy_grad(FeEngine* h, int src, int dst) {
     for (auto& E : h->effs) {
         for (int j = 0; j < 3; j++) { E.gpos[dst * 3 + j] = E.gpos[src * 3 + j]; E.gv[dst * 3 + j] = E.gv[src * 3 + j]; E.gw[dst * 3 + j] = E.gw[src * 3 + j]; }
         for (int j = 0; j < 4; j++) E.gquat[dst * 4 + j] = E.gquat[src * 4 + j];
+        E.gsa[dst] = E.gsa[src]; E.gra[dst] = E.gra[src];
     }
+    return 0;
+}
+
+/* ---- AirCon strength / radius (aircon.py:178-191) */
+int fe_eff_get_sr(FeEngine* h, int e, int f, fe_real* s, fe_real* r) {
+    CHECK_EFF(h, e); CHECK_FRAME(h, f);
+    *s = h->effs[e].sa[f]; *r = h->effs[e].ra[f];
+    return 0;
+}
+int fe_eff_set_sr(FeEngine* h, int e, int f, fe_real s, fe_real r) {
+    CHECK_EFF(h, e); CHECK_FRAME(h, f);
+    h->effs[e].sa[f] = s; h->effs[e].ra[f] = r;
+    return 0;
+}
+
+/* ---- smoke field (smoke_field.py) */
+#define CHECK_SMOKE(h, s) do { if (!(h)->smoke) FE_FAIL(h, "no smoke field"); if ((s) < 0 || (s) > (h)->smoke->S) FE_FAIL(h, "smoke frame out of range"); } while (0)
+int fe_smoke_create(FeEngine* h, const FeSmokeConfig* c) {
+    if (!c || c->struct_size != (int)sizeof(FeSmokeConfig)) FE_FAIL(h, "FeSmokeConfig size mismatch");
+    if (c->res < 4 || c->q_dim < 1 || c->q_dim > 8 || c->max_steps_local < 1 || c->solver_iters < 0) FE_FAIL(h, "bad smoke configuration");
+    delete h->smoke;
+    Smoke* m = new Smoke();
+    m->c = *c; m->n = c->res; m->S = c->max_steps_local; m->n3 = (size_t)c->res * c->res * c->res;
+    const size_t F = (size_t)(m->S + 1) * m->n3;
+    m->v.assign(F * 3, 0); m->vt.assign(F * 3, 0); m->dv.assign(F, 0); m->p.assign(F, 0); m->q.assign(F * c->q_dim, 0);
+    m->gv.assign(F * 3, 0); m->gvt.assign(F * 3, 0); m->gdv.assign(F, 0); m->gp.assign(F, 0); m->gq.assign(F * c->q_dim, 0);
+    m->fr.assign(F, 0);
+    m->pc.assign(m->n3, 0); m->pn.assign(m->n3, 0); m->gpc.assign(m->n3, 0); m->gpn.assign(m->n3, 0);
+    /* init_fields, smoke_field.py:86-93: q[0] = high_T in the slab (ti.Vector([high_T]) broadcasts over q_dim) */
+    for (int i = 0; i < m->n; i++) for (int j = 0; j < m->n; j++) for (int k = 0; k < m->n; k++)
+        if (c->lower_y < j && j < c->higher_y) for (int d = 0; d < c->q_dim; d++) m->q[m->idx(i, j, k) * c->q_dim + d] = c->high_T;
+    h->smoke = m;
+    return 0;
+}
+int fe_smoke_step(FeEngine* h, int s, int f) { CHECK_SMOKE(h, s); if (s >= h->smoke->S) FE_FAIL(h, "smoke step frame out of range"); CHECK_FRAME(h, f); return smoke_step(h, s, f); }
+int fe_smoke_step_grad(FeEngine* h, int s, int f) { CHECK_SMOKE(h, s); if (s >= h->smoke->S) FE_FAIL(h, "smoke step frame out of range"); CHECK_FRAME(h, f); return smoke_step_grad(h, s, f); }
+int fe_smoke_get_frame(FeEngine* h, int s, fe_real* v, fe_real* v_tmp, fe_real* div, fe_real* p, fe_real* q) {
+    CHECK_SMOKE(h, s);
+    Smoke& m = *h->smoke;
+    if (v) std::memcpy(v, m.F(m.v, s, 3), sizeof(R) * m.n3 * 3);
+    if (v_tmp) std::memcpy(v_tmp, m.F(m.vt, s, 3), sizeof(R) * m.n3 * 3);
+    if (div) std::memcpy(div, m.F(m.dv, s, 1), sizeof(R) * m.n3);
+    if (p) std::memcpy(p, m.F(m.p, s, 1), sizeof(R) * m.n3);
+    if (q) std::memcpy(q, m.F(m.q, s, m.c.q_dim), sizeof(R) * m.n3 * m.c.q_dim);
+    return 0;
+}
+int fe_smoke_set_frame(FeEngine* h, int s, const fe_real* v, const fe_real* v_tmp, const fe_real* div, const fe_real* p, const fe_real* q) {
+    CHECK_SMOKE(h, s);
+    Smoke& m = *h->smoke;
+    if (v) std::memcpy(m.F(m.v, s, 3), v, sizeof(R) * m.n3 * 3);
+    if (v_tmp) std::memcpy(m.F(m.vt, s, 3), v_tmp, sizeof(R) * m.n3 * 3);
+    if (div) std::memcpy(m.F(m.dv, s, 1), div, sizeof(R) * m.n3);
+    if (p) std::memcpy(m.F(m.p, s, 1), p, sizeof(R) * m.n3);
+    if (q) std::memcpy(m.F(m.q, s, m.c.q_dim), q, sizeof(R) * m.n3 * m.c.q_dim);
+    return 0;
+}
+int fe_smoke_get_grad(FeEngine* h, int s, fe_real* gv, fe_real* gq) {
+    CHECK_SMOKE(h, s);
+    Smoke& m = *h->smoke;
+    if (gv) std::memcpy(gv, m.F(m.gv, s, 3), sizeof(R) * m.n3 * 3);
+    if (gq) std::memcpy(gq, m.F(m.gq, s, m.c.q_dim), sizeof(R) * m.n3 * m.c.q_dim);
+    return 0;
+}
+int fe_smoke_add_grad(FeEngine* h, int s, const fe_real* gv, const fe_real* gq) {
+    CHECK_SMOKE(h, s);
+    Smoke& m = *h->smoke;
+    if (gv) for (size_t i = 0; i < m.n3 * 3; i++) m.F(m.gv, s, 3)[i] += gv[i];
+    if (gq) for (size_t i = 0; i < m.n3 * m.c.q_dim; i++) m.F(m.gq, s, m.c.q_dim)[i] += gq[i];
+    return 0;
+}
+int fe_smoke_copy_frame(FeEngine* h, int src, int dst) {
+    CHECK_SMOKE(h, src); CHECK_SMOKE(h, dst);
+    Smoke& m = *h->smoke;
+    const int qd = m.c.q_dim;
+    std::memcpy(m.F(m.v, dst, 3), m.F(m.v, src, 3), sizeof(R) * m.n3 * 3); std::memcpy(m.F(m.vt, dst, 3), m.F(m.vt, src, 3), sizeof(R) * m.n3 * 3);
+    std::memcpy(m.F(m.dv, dst, 1), m.F(m.dv, src, 1), sizeof(R) * m.n3); std::memcpy(m.F(m.p, dst, 1), m.F(m.p, src, 1), sizeof(R) * m.n3);
+    std::memcpy(m.F(m.q, dst, qd), m.F(m.q, src, qd), sizeof(R) * m.n3 * qd);
+    return 0;
+}
+int fe_smoke_copy_grad(FeEngine* h, int src, int dst) {
+    CHECK_SMOKE(h, src); CHECK_SMOKE(h, dst);
+    Smoke& m = *h->smoke;
+    const int qd = m.c.q_dim;
+    std::memcpy(m.F(m.gv, dst, 3), m.F(m.gv, src, 3), sizeof(R) * m.n3 * 3); std::memcpy(m.F(m.gvt, dst, 3), m.F(m.gvt, src, 3), sizeof(R) * m.n3 * 3);
+    std::memcpy(m.F(m.gdv, dst, 1), m.F(m.gdv, src, 1), sizeof(R) * m.n3); std::memcpy(m.F(m.gp, dst, 1), m.F(m.gp, src, 1), sizeof(R) * m.n3);
+    std::memcpy(m.F(m.gq, dst, qd), m.F(m.gq, src, qd), sizeof(R) * m.n3 * qd);
+    return 0;
+}
+int fe_smoke_reset_grad(FeEngine* h) { if (!h->smoke) FE_FAIL(h, "no smoke field"); smoke_reset_grad(h); return 0; }
+int fe_smoke_reset_grad_till_frame(FeEngine* h, int s) {
+    CHECK_SMOKE(h, s);
+    Smoke& m = *h->smoke;
+    const size_t F = (size_t)s * m.n3;
+    std::fill(m.gv.begin(), m.gv.begin() + F * 3, (R)0); std::fill(m.gvt.begin(), m.gvt.begin() + F * 3, (R)0);
+    std::fill(m.gdv.begin(), m.gdv.begin() + F, (R)0); std::fill(m.gp.begin(), m.gp.begin() + F, (R)0);
+    std::fill(m.gq.begin(), m.gq.begin() + F * m.c.q_dim, (R)0);
     return 0;
 }
 

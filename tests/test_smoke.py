@@ -1,0 +1,142 @@
+"""SmokeField (fluidlab/fluidengine/simulators/smoke_field.py) through the C ABI: CPU oracle checks (structural properties
+and finite differences of the hand-derived adjoint) and, on the GPU, HIP-vs-oracle parity."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(__file__))
+import scenarios as S  # noqa: E402
+from fluidlab_amd._capi import Engine, FE_EFF_AIRCON  # noqa: E402
+
+RES = 12
+
+
+def make_smoke_engine(elib, res=RES, steps=4, solver_iters=12, q_dim=1, device=0, obstacle=True, seed=0, perturb=None):
+    """A tiny room: free slab 3 < j < 8, one static box obstacle inside it, an AirCon blowing across."""
+    eng = Engine(elib, n_grid=8, n_particles=4, max_substeps_local=steps * 2, n_substeps=2, max_action_steps=steps, dt=2e-4,
+                 p_vol=(0.5 / 8) ** 2, gravity=(0.0, -10.0, 0.0), boundary=elib.make_boundary(), device=device)
+    eng.init_particles(S.f32(np.full((4, 3), -100.0)), np.zeros(4, np.int32), np.zeros(4, np.int32), np.full(4, 200, np.int32),
+                       np.zeros(4), np.full(4, 277.78), np.ones(4), np.zeros(4, np.int32))
+    if obstacle:
+        g = np.linspace(0, 1, 16)
+        X, Y, Z = np.meshgrid(g, g, g, indexing='ij')
+        q = np.abs(np.stack([X - 0.62, Y - 0.45, Z - 0.4], -1)) - [0.1, 0.3, 0.12]
+        vox = np.linalg.norm(np.maximum(q, 0), axis=-1) + np.minimum(q.max(-1), 0)
+        T = np.eye(4); T[:3, :3] *= 15.0
+        eng.add_static(S.f32(vox), T, friction=0.0)
+    e = eng.add_effector(type=FE_EFF_AIRCON, action_dim=8, action_scale_v=(1, 1, 1, 1, 1, 1, 40.0, 3.0), action_scale_p=(1,) * 8,
+                         boundary=elib.make_boundary(), inject_v=(-0.3, 0.1, 1.0))
+    st = eng.eff_get_state(e, 0)
+    st[:7] = [0.3, 0.45, 0.25, 0.9689124, 0.0, 0.2474040, 0.0]
+    eng.eff_set_state(e, 0, st)
+    eng.smoke_create(res=res, dt=0.03, solver_iters=solver_iters, q_dim=q_dim, max_steps_local=steps, lower_y=3, higher_y=8)
+    rng = np.random.RandomState(seed)
+    v0 = rng.normal(0, 1.5, (res, res, res, 3))
+    q0 = eng.smoke_get_frame(0, ('q',))['q'] * (1 + 0.3 * rng.normal(size=(res, res, res, q_dim)))
+    p0 = rng.normal(0, 0.3, (res, res, res))
+    if perturb is not None:                       # (field, index, delta) for finite differences
+        {'v': v0, 'q': q0, 'p': p0}[perturb[0]][perturb[1]] += perturb[2]
+    eng.smoke_set_frame(0, v=v0, q=q0, p=p0)
+    return eng, e
+
+
+def run_smoke(elib, actions, cot_v, cot_q, device=0, **kw):
+    """steps of (set_action, smoke_step, the step's substeps), loss = <cot, (v, q)[last]>, backward, action gradient."""
+    eng, e = make_smoke_engine(elib, device=device, **kw)
+    H = len(actions)
+    for s in range(H):
+        eng.eff_set_action(e, s, s, 2, actions[s])
+        eng.smoke_step(s, 2 * s)                    # smoke simulates at step level, before the substeps (mpm:744-751)
+        eng.step(2 * s, 2 * s, 2, 1)
+    fin = eng.smoke_get_frame(H, ('v', 'q', 'p'))
+    loss = float((fin['v'].astype(np.float64) * cot_v).sum() + (fin['q'].astype(np.float64) * cot_q).sum())
+    eng.reset_grad()
+    eng.smoke_add_grad(H, gv=cot_v, gq=cot_q)
+    for s in reversed(range(H)):
+        eng.step_grad(2 * s, 2 * s, 2, 1)
+        eng.smoke_step_grad(s, 2 * s)
+        eng.eff_set_action_grad(e, s, s, 2)
+    g = eng.eff_get_action_grad(e, 0, H, 8)
+    gv0, gq0 = eng.smoke_get_grad(0)
+    eng.close()
+    return dict(final=fin, loss=loss, action_grad=g, gv0=gv0, gq0=gq0)
+
+
+def _actions(H=3, seed=1):
+    rng = np.random.RandomState(seed)
+    a = np.zeros((H, 8))
+    a[:, :3] = rng.uniform(-0.02, 0.02, (H, 3)); a[:, 3:6] = rng.uniform(-0.2, 0.2, (H, 3))
+    a[:, 6] = rng.uniform(0.5, 1.0, H); a[:, 7] = rng.uniform(0.6, 1.2, H)
+    return a
+
+
+def _poisson_residual(p, div, free):
+    """|sum_nb p - 6 p - div| on free cells with compute_location's rule (smoke_field.py:298-306): a neighbour that is out of
+    range or not free is replaced by the cell itself."""
+    tot = np.zeros_like(p)
+    for ax in range(3):
+        for sh in (-1, 1):
+            nb = np.roll(p, -sh, ax)
+            ok = np.roll(free, -sh, ax)
+            idx = [slice(None)] * 3
+            idx[ax] = -1 if sh == 1 else 0
+            ok[tuple(idx)] = False                       # the wrapped-around plane is out of range
+            tot += np.where(ok, nb, p)
+    return np.abs(tot - 6 * p - div)[free]
+
+
+def test_smoke_pressure_solve_and_walls(oracle64):
+    """The Jacobi sweeps (smoke_field.py:130-143) converge to the solution of the discrete Poisson equation they iterate
+    on; non-free cells carry v_tmp = 0, keep their temperature and their velocity is v_tmp (229-232, 287-288)."""
+    res = RES
+    free = np.zeros((res, res, res), bool); free[:, 4:8] = True
+    res_norm = []
+    for iters in (2, 60, 600):
+        eng, e = make_smoke_engine(oracle64, solver_iters=iters, obstacle=False)
+        eng.eff_set_action(e, 0, 0, 2, _actions()[0])
+        q_before = eng.smoke_get_frame(0, ('q',))['q']
+        eng.smoke_step(0, 0)
+        f0 = eng.smoke_get_frame(0, ('v_tmp', 'div'))
+        f1 = eng.smoke_get_frame(1, ('v', 'q', 'p'))
+        assert (f0['v_tmp'][~free] == 0).all() and (f1['v'][~free] == 0).all()
+        assert (f1['q'][~free] == q_before[~free]).all()
+        assert np.abs(f0['v_tmp'][free]).max() > 0.1
+        res_norm.append(_poisson_residual(f1['p'].astype(np.float64), f0['div'].astype(np.float64), free).max())
+        eng.close()
+    assert res_norm[1] < 0.5 * res_norm[0] and res_norm[2] < 1e-3 * res_norm[0], res_norm
+
+
+def test_smoke_adjoint_vs_finite_differences(oracle64):
+    """dL/d(initial velocity, temperature) and dL/d(AirCon actions: translation, rotation, strength, radius) through
+    advection (RK3 back-trace of trilinear samples), impulse, divergence, Jacobi sweeps and projection."""
+    res, H = RES, 3
+    rng = np.random.RandomState(3)
+    cot_v, cot_q = rng.normal(size=(res, res, res, 3)), rng.normal(size=(res, res, res, 1))
+    acts = _actions(H)
+    out = run_smoke(oracle64, acts, cot_v, cot_q)
+    g = out['action_grad']
+    assert np.abs(g[:H, 6]).min() > 1e-6 and np.abs(g[:H, 7]).min() > 1e-6 and np.abs(g[:H, :3]).max() > 1e-6
+
+    def fd(run, exact, steps):
+        errs = []
+        for h in steps:
+            d = (run(+h) - run(-h)) / (2 * h)
+            errs.append(abs(d - exact) / max(abs(d), 1e-6))
+        return min(errs)
+
+    worst = 0.0
+    for s_, k_ in [(0, 6), (1, 7), (2, 6), (0, 0), (1, 2), (0, 4), (1, 5), (2, 7)]:
+        def run(dh, s_=s_, k_=k_):
+            a = acts.copy(); a[s_, k_] += dh
+            return run_smoke(oracle64, a, cot_v, cot_q)['loss']
+        worst = max(worst, fd(run, g[s_, k_], (1e-4, 1e-5, 1e-6)))
+    assert worst < 1e-5, worst
+    # initial velocity / temperature of cells inside and next to the free slab
+    for field, idx, exact in [('v', (5, 5, 6, 0), out['gv0'][5, 5, 6, 0]), ('v', (3, 6, 4, 2), out['gv0'][3, 6, 4, 2]),
+                              ('v', (8, 4, 8, 1), out['gv0'][8, 4, 8, 1]), ('q', (6, 5, 5, 0), out['gq0'][6, 5, 5, 0]),
+                              ('q', (2, 7, 9, 0), out['gq0'][2, 7, 9, 0])]:
+        def run(dh, field=field, idx=idx):
+            return run_smoke(oracle64, acts, cot_v, cot_q, perturb=(field, idx, dh))['loss']
+        assert fd(run, exact, (1e-4, 1e-5, 1e-6)) < 1e-5, (field, idx)
