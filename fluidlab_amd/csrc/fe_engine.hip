@@ -83,12 +83,13 @@ struct SimP {
 #define FE_MAX_EFF 4
 struct EffP {
     int type, action_dim;
-    float scale_v[6], scale_p[6];
+    float scale_v[8], scale_p[8];
     BoundaryP bnd;
     int flux; float radius; float inject_v[3], inject_p[3];
     int locally_random, randomize_inject_v, random_length;
     // device arrays
     float *pos, *quat, *v, *w, *gpos, *gquat, *gv, *gw;      // [L+1] x {3,4,3,3}
+    float *sa, *ra, *gsa, *gra;                              // AirCon strength s[f], radius r[f] + grads (aircon.py:20-21)
     float *abuf, *gabuf, *abuf_p, *gabuf_p;                  // [max_action_steps, adim], [adim]
     float* random_vector;                                    // [random_length, flux, 3]
     int has_mesh; SdfP mesh;                                 // Rigid.setup_mesh (rigid.py:19-24): a moving SDF collider
@@ -1354,7 +1355,7 @@ __global__ __launch_bounds__(256) void k_perm_scatter(int N, size_t Np, float* d
 // small kernels: effectors, loss, state I/O
 // =========================================================================================
 
-struct Act6 { float a[6]; };
+struct Act6 { float a[8]; };       // an action vector (up to 8 entries: AirCon)
 
 // set_action_kernel + set_velocity (effector.py:218-221, 252-260)
 __global__ void k_eff_set_action(EffP e, int s, int s_global, int n_substeps, Act6 act) {
@@ -1365,6 +1366,10 @@ __global__ void k_eff_set_action(EffP e, int s, int s_global, int n_substeps, Ac
     for (int j = s * n_substeps; j < (s + 1) * n_substeps; j++) {
         for (int k = 0; k < 3; k++) e.v[j * 3 + k] = e.abuf[(size_t)s_global * ad + k] * e.scale_v[k] / nf;
         if (ad > 3) for (int k = 0; k < 3; k++) e.w[j * 3 + k] = e.abuf[(size_t)s_global * ad + k + 3] * e.scale_v[k + 3] / nf;
+        if (ad > 6) {                                                                               // aircon.py:211-213
+            e.sa[j] = e.abuf[(size_t)s_global * ad + 6] * e.scale_v[6];
+            e.ra[j] = e.abuf[(size_t)s_global * ad + 7] * e.scale_v[7];
+        }
     }
 }
 // set_velocity.grad (effector.py:270-274)
@@ -1375,6 +1380,10 @@ __global__ void k_eff_set_action_grad(EffP e, int s, int s_global, int n_substep
     for (int j = s * n_substeps; j < (s + 1) * n_substeps; j++) {
         for (int k = 0; k < 3; k++) e.gabuf[(size_t)s_global * ad + k] += e.gv[j * 3 + k] * e.scale_v[k] / nf;
         if (ad > 3) for (int k = 0; k < 3; k++) e.gabuf[(size_t)s_global * ad + k + 3] += e.gw[j * 3 + k] * e.scale_v[k + 3] / nf;
+        if (ad > 6) {
+            e.gabuf[(size_t)s_global * ad + 6] += e.gsa[j] * e.scale_v[6];
+            e.gabuf[(size_t)s_global * ad + 7] += e.gra[j] * e.scale_v[7];
+        }
     }
 }
 // set_action_p_kernel + apply_action_p_kernel (effector.py:223-231, 236-239)
@@ -1403,6 +1412,7 @@ __global__ void k_eff_copy(EffP e, int src, int dst, int grad) {
     float *pos = grad ? e.gpos : e.pos, *quat = grad ? e.gquat : e.quat, *v = grad ? e.gv : e.v, *w = grad ? e.gw : e.w;
     for (int j = 0; j < 3; j++) { pos[dst * 3 + j] = pos[src * 3 + j]; v[dst * 3 + j] = v[src * 3 + j]; w[dst * 3 + j] = w[src * 3 + j]; }
     for (int j = 0; j < 4; j++) quat[dst * 4 + j] = quat[src * 4 + j];
+    if (grad) { e.gsa[dst] = e.gsa[src]; e.gra[dst] = e.gra[src]; } else { e.sa[dst] = e.sa[src]; e.ra[dst] = e.ra[src]; }     // aircon.py:148-163
 }
 
 
@@ -1746,6 +1756,7 @@ struct FeEngine {
     float4 *g_out = nullptr, *gg_in = nullptr;
     bool all_simple_liquid = false;                         // every particle is an inviscid MAT_LIQUID: SVD-free kernels
     std::vector<SdfP> statics_host; std::vector<float*> statics_vox; SdfP* statics_dev = nullptr;   // static SDF colliders
+    struct SmokeState* smoke = nullptr;                     // SmokeField (fe_smoke.h), optional
     bool has_mesh_effector = false; std::vector<float*> mesh_vox;   // Rigid effectors with an SDF mesh (dynamic.py)
     bool has_rigid = false; int n_bodies = 0;               // MAT_RIGID shape-matching bodies (mpm:176-201)
     int* rigid_body = nullptr; RigidBody* bodies_dev = nullptr;   // [Np] body of a MAT_RIGID particle or -1 (by particle id); [n_bodies]
@@ -2106,6 +2117,8 @@ int check_device_errors(FeEngine* h) {
 // =========================================================================================
 // C ABI
 // =========================================================================================
+#include "fe_smoke.h"
+
 extern "C" {
 
 const char* fe_backend(void) { return "hip-gfx950"; }
@@ -2177,6 +2190,7 @@ void fe_destroy(FeEngine* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    smoke_destroy(h);
     for (auto& t : h->tables) { for (void* q : {(void*)t.pid, (void*)t.items, (void*)t.meta, (void*)t.blk_first, (void*)t.active, (void*)t.blk_slot, (void*)t.slot_of_pid}) if (q) (void)hipFree(q); }
     void* ptrs[] = {h->frames, h->grads, h->sort_key, h->sort_rank, h->sort_cnt, h->sort_start, h->sort_src, h->sort_pid, h->slow_dev, h->frame_slow_dev, h->gstore, h->gs_flag, h->slab, h->ts_dev, h->sort_partial, h->effs_dev, h->pinfo, h->pool_idx, h->g_in, h->g_out, h->gg_out, h->gg_in,
                     h->blk_flag, h->blk_list, h->blk_count, h->err_dev, h->stage_r, h->stage_i, h->node_mark, h->counters,
@@ -2185,7 +2199,8 @@ void fe_destroy(FeEngine* h) {
     for (float* v : h->mesh_vox) if (v) (void)hipFree(v);
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& E : h->effs) {
-        void* ep[] = {E.p.pos, E.p.quat, E.p.v, E.p.w, E.p.gpos, E.p.gquat, E.p.gv, E.p.gw, E.p.abuf, E.p.gabuf, E.p.abuf_p, E.p.gabuf_p, E.p.random_vector};
+        void* ep[] = {E.p.pos, E.p.quat, E.p.v, E.p.w, E.p.gpos, E.p.gquat, E.p.gv, E.p.gw, E.p.abuf, E.p.gabuf, E.p.abuf_p, E.p.gabuf_p, E.p.random_vector,
+                      E.p.sa, E.p.ra, E.p.gsa, E.p.gra};
         for (void* p : ep) if (p) (void)hipFree(p);
     }
     for (auto e : h->prof_ev) (void)hipEventDestroy(e);
@@ -2328,6 +2343,7 @@ int fe_copy_grad(FeEngine* h, int src, int dst) {
     return 0;
 }
 int fe_reset_grad(FeEngine* h) {
+    if (smoke_reset_grad_impl(h)) return 1;
     HIPCK(h, hipMemsetAsync(h->grad_ptr[0], 0, sizeof(float) * h->grad_words(), h->stream));
     HIPCK(h, hipMemsetAsync(h->grad_ptr[1], 0, sizeof(float) * h->grad_words(), h->stream));
     h->gtbl[0] = h->gtbl[1] = -1;
@@ -2337,6 +2353,8 @@ int fe_reset_grad(FeEngine* h) {
         HIPCK(h, hipMemsetAsync(E.p.gquat, 0, sizeof(float) * 4 * Fm, h->stream));
         HIPCK(h, hipMemsetAsync(E.p.gv, 0, sizeof(float) * 3 * Fm, h->stream));
         HIPCK(h, hipMemsetAsync(E.p.gw, 0, sizeof(float) * 3 * Fm, h->stream));
+        HIPCK(h, hipMemsetAsync(E.p.gsa, 0, sizeof(float) * Fm, h->stream));
+        HIPCK(h, hipMemsetAsync(E.p.gra, 0, sizeof(float) * Fm, h->stream));
         HIPCK(h, hipMemsetAsync(E.p.gabuf, 0, sizeof(float) * (size_t)h->cfg.max_action_steps * ad, h->stream));
         HIPCK(h, hipMemsetAsync(E.p.gabuf_p, 0, sizeof(float) * ad, h->stream));
     }
@@ -2355,6 +2373,8 @@ int fe_agent_reset_grad_till_frame(FeEngine* h, int f) {
         HIPCK(h, hipMemsetAsync(E.p.gquat, 0, sizeof(float) * 4 * f, h->stream));
         HIPCK(h, hipMemsetAsync(E.p.gv, 0, sizeof(float) * 3 * f, h->stream));
         HIPCK(h, hipMemsetAsync(E.p.gw, 0, sizeof(float) * 3 * f, h->stream));
+        HIPCK(h, hipMemsetAsync(E.p.gsa, 0, sizeof(float) * f, h->stream));
+        HIPCK(h, hipMemsetAsync(E.p.gra, 0, sizeof(float) * f, h->stream));
     }
     return 0;
 }
@@ -2378,13 +2398,14 @@ int fe_get_mat(FeEngine* h, int* mat) {
 int fe_add_effector(FeEngine* h, const FeEffectorDesc* d, const fe_real* random_vector) {
     auto bad = [&](const char* m) { h->err = m; return -1; };
     if (!d || d->struct_size != (int)sizeof(FeEffectorDesc)) return bad("FeEffectorDesc size mismatch");
-    if (!(d->action_dim == 0 || d->action_dim == 3 || d->action_dim == 6)) return bad("action_dim must be 0, 3 or 6");
+    if (!(d->action_dim == 0 || d->action_dim == 3 || d->action_dim == 6 || (d->type == FE_EFF_AIRCON && d->action_dim == 8)))
+        return bad("action_dim must be 0, 3 or 6 (8 for an AirCon)");
     if ((int)h->effs.size() >= FE_MAX_EFF) return bad("too many effectors");
     if (d->type == FE_EFF_INJECTOR && find_injector(h) >= 0) return bad("only one injector per agent (agent_injector.py:17)");
     EffHost E; std::memset(&E.p, 0, sizeof(E.p));
     EffP& p = E.p;
     p.type = d->type; p.action_dim = d->action_dim;
-    for (int i = 0; i < 6; i++) { p.scale_v[i] = d->action_scale_v[i]; p.scale_p[i] = d->action_scale_p[i]; }
+    for (int i = 0; i < 8; i++) { p.scale_v[i] = d->action_scale_v[i]; p.scale_p[i] = d->action_scale_p[i]; }
     p.bnd = to_boundary(d->boundary);
     p.flux = d->flux; p.radius = d->radius;
     for (int i = 0; i < 3; i++) { p.inject_v[i] = d->inject_v[i]; p.inject_p[i] = d->inject_p[i]; }
@@ -2392,6 +2413,7 @@ int fe_add_effector(FeEngine* h, const FeEffectorDesc* d, const fe_real* random_
     const int Fm = h->L + 1, ad = d->action_dim > 0 ? d->action_dim : 1;
     if (dev_alloc(h, &p.pos, 3 * Fm) || dev_alloc(h, &p.quat, 4 * Fm) || dev_alloc(h, &p.v, 3 * Fm) || dev_alloc(h, &p.w, 3 * Fm) ||
         dev_alloc(h, &p.gpos, 3 * Fm) || dev_alloc(h, &p.gquat, 4 * Fm) || dev_alloc(h, &p.gv, 3 * Fm) || dev_alloc(h, &p.gw, 3 * Fm) ||
+        dev_alloc(h, &p.sa, Fm) || dev_alloc(h, &p.ra, Fm) || dev_alloc(h, &p.gsa, Fm) || dev_alloc(h, &p.gra, Fm) ||
         dev_alloc(h, &p.abuf, (size_t)h->cfg.max_action_steps * ad) || dev_alloc(h, &p.gabuf, (size_t)h->cfg.max_action_steps * ad) ||
         dev_alloc(h, &p.abuf_p, ad) || dev_alloc(h, &p.gabuf_p, ad)) return -1;
     if (d->type == FE_EFF_INJECTOR) {
@@ -2441,6 +2463,20 @@ int fe_eff_get_vw(FeEngine* h, int e, int f, fe_real* v3, fe_real* w3) {
     CHECK_EFF(h, e); CHECK_FRAME(h, f);
     HIPCK(h, hipMemcpyAsync(v3, h->effs[e].p.v + f * 3, sizeof(float) * 3, hipMemcpyDeviceToHost, h->stream));
     HIPCK(h, hipMemcpyAsync(w3, h->effs[e].p.w + f * 3, sizeof(float) * 3, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+int fe_eff_get_sr(FeEngine* h, int e, int f, fe_real* s, fe_real* r) {
+    CHECK_EFF(h, e); CHECK_FRAME(h, f);
+    HIPCK(h, hipMemcpyAsync(s, h->effs[e].p.sa + f, sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipMemcpyAsync(r, h->effs[e].p.ra + f, sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    return 0;
+}
+int fe_eff_set_sr(FeEngine* h, int e, int f, fe_real s, fe_real r) {
+    CHECK_EFF(h, e); CHECK_FRAME(h, f);
+    HIPCK(h, hipMemcpyAsync(h->effs[e].p.sa + f, &s, sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCK(h, hipMemcpyAsync(h->effs[e].p.ra + f, &r, sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIPCK(h, hipStreamSynchronize(h->stream));
     return 0;
 }
