@@ -2,8 +2,9 @@
 from .fluid_env import FluidEnv
 from .latteart_env import LatteArtEnv
 from .waterblock_env import WaterBlockEnv
+from .circulation_env import CirculationEnv
 
-REGISTRY = {'LatteArt-v0': LatteArtEnv, 'WaterBlock-v0': WaterBlockEnv}
+REGISTRY = {'LatteArt-v0': LatteArtEnv, 'WaterBlock-v0': WaterBlockEnv, 'Circulation-v0': CirculationEnv}
 
 
 def make(env_name, **kwargs):

@@ -1,3 +1,4 @@
 from .agent import Agent
 from .agent_injector import AgentInjector
 from .agent_rigid import AgentRigid
+from .agent_circulation import AgentCirculation

@@ -1,1 +1,2 @@
 from .mpm_simulator import MPMSimulator
+from .smoke_field import SmokeField

@@ -77,8 +77,6 @@ class MPMSimulator:
             self.boundary = create_boundary()                # mpm:44-45
         self.n_statics = len(statics) if statics is not None else 0
         self.statics = statics
-        if smoke_field is not None:
-            raise NotImplementedError('SmokeField is outside this build (SURVEY 8f-3)')
 
         if self._elib is None:
             self._elib = _capi.load_hip()
@@ -204,6 +202,8 @@ class MPMSimulator:
         is_none_action = action is None
         if not is_none_action:
             self.agent.set_action(s=self.cur_step_local, s_global=self.cur_step_global, n_substeps=self.n_substeps, action=action)
+        if self.smoke_field is not None:                    # smoke simulates at step level, not substep (mpm:744-747)
+            self.smoke_field.step(s=self.cur_step_local, f=self.cur_substep_local)
         self.engine.step(self.cur_substep_local, self.cur_substep_global, self.n_substeps, not is_none_action)
         self.cur_substep_global += self.n_substeps
         assert self.cur_substep_global <= self.max_substeps_global
@@ -215,6 +215,8 @@ class MPMSimulator:
         is_none_action = action is None
         self.cur_substep_global -= self.n_substeps
         self.engine.step_grad(self.cur_substep_local, self.cur_substep_global, self.n_substeps, not is_none_action)
+        if self.smoke_field is not None:                    # mpm:765-767
+            self.smoke_field.step_grad(s=self.cur_step_local, f=self.cur_substep_local)
         if not is_none_action:
             self.agent.set_action_grad(s=self.cur_substep_local // self.n_substeps, s_global=self.cur_substep_global // self.n_substeps,
                                        n_substeps=self.n_substeps, action=action)
@@ -234,6 +236,8 @@ class MPMSimulator:
                     self.readframe(0, st['x'], st['v'], st['C'], st['F'], st['used'])
                     ckpt.update(st)
                 ckpt['actions'] = list(self.actions_buffer)
+            if self.smoke_field is not None:
+                ckpt['smoke_field'] = self.smoke_field.get_ckpt(ckpt_name)            # mpm:794-795
             if self.agent is not None:
                 ckpt['agent'] = self.agent.get_ckpt()
             if self.ckpt_dest == 'disk':
@@ -249,6 +253,8 @@ class MPMSimulator:
         # restart from frame 0 in memory (mpm:844-852)
         if self.has_particles:
             self.copy_frame(self.max_substeps_local, 0)
+        if self.smoke_field is not None:
+            self.smoke_field.copy_frame(self.max_steps_local, 0)                       # mpm:848-849
         if self.agent is not None:
             self.agent.copy_frame(self.max_substeps_local, 0)
 
@@ -259,6 +265,10 @@ class MPMSimulator:
             self.copy_frame(0, L)
             self.copy_grad(0, L)
             self.reset_grad_till_frame(L)
+        if self.smoke_field is not None:                                               # mpm:863-866
+            self.smoke_field.copy_frame(0, self.max_steps_local)
+            self.smoke_field.copy_grad(0, self.max_steps_local)
+            self.smoke_field.reset_grad_till_frame(self.max_steps_local)
         if self.agent is not None:
             self.agent.copy_frame(0, L)
             self.agent.copy_grad(0, L)
@@ -277,6 +287,8 @@ class MPMSimulator:
             assert False
         if self.has_particles:
             self.setframe(0, ckpt['x'], ckpt['v'], ckpt['C'], ckpt['F'], ckpt['used'])
+        if self.smoke_field is not None:
+            self.smoke_field.set_ckpt(ckpt=ckpt['smoke_field'])
         if self.agent is not None:
             self.agent.set_ckpt(ckpt['agent'])
         # forward pass over the chunk to refill frames 1..L (mpm:906-909)
@@ -319,6 +331,8 @@ class MPMSimulator:
             self.readframe(f, state['x'], state['v'], state['C'], state['F'], state['used'])
         if self.agent is not None:
             state['agent'] = self.agent.get_state(f)
+        if self.smoke_field is not None:                    # mpm:628-629
+            state['smoke_field'] = self.smoke_field.get_state(self.cur_step_local)
         return state
 
     def set_state(self, f_global, state):
@@ -327,6 +341,8 @@ class MPMSimulator:
             self.setframe(f, state['x'], state['v'], state['C'], state['F'], state['used'])
         if self.agent is not None:
             self.agent.set_state(f, state['agent'])
+        if self.smoke_field is not None:                    # mpm:643-644
+            self.smoke_field.set_state(f // self.n_substeps, state['smoke_field'])
 
     def get_x(self, f=None):
         f = self.cur_substep_local if f is None else f
@@ -358,6 +374,8 @@ class MPMSimulator:
             self.engine.get_frame(f, x=state['x'], v=state['v'], used=state['used'])
         if self.agent is not None:
             state['agent'] = self.agent.get_state(f)
+        if self.smoke_field is not None:                    # mpm:694-695
+            state['smoke_field'] = self.smoke_field.get_state(self.cur_step_local)
         return state
 
     def get_state_render(self, f):

@@ -1,15 +1,15 @@
 """TaichiEnv -- wires simulator, agent, bodies and loss together (fluidlab/fluidengine/taichi_env.py).
 
 The name is kept so the reference's envs / optimiser import it unchanged; there is no Taichi here
-(no ti.init, taichi_env.py:12): the simulator drives the MI355X HIP engine.  Renderers and the smoke field are
-outside this build (#10-#13)."""
+(no ti.init, taichi_env.py:12): the simulator drives the MI355X HIP engine.  Renderers are outside this build
+(#12-#13)."""
 import numpy as np
 
 from fluidlab_amd.configs.macros import DTYPE_NP
 from fluidlab_amd.fluidengine import agents as _agents
 from fluidlab_amd.fluidengine.bodies import Bodies
 from fluidlab_amd.fluidengine.meshes import Statics
-from fluidlab_amd.fluidengine.simulators import MPMSimulator
+from fluidlab_amd.fluidengine.simulators import MPMSimulator, SmokeField
 from fluidlab_amd.utils.config import CfgNode
 
 
@@ -56,7 +56,7 @@ class TaichiEnv:
         self.particle_bodies.add_body(**kwargs)
 
     def setup_smoke_field(self, **kwargs):
-        raise NotImplementedError('SmokeField is outside this build (SURVEY 8f-3)')
+        self.smoke_field = SmokeField(dim=self.dim, ckpt_dest=self.ckpt_dest, **kwargs)          # taichi_env.py:95-100
 
     def setup_loss(self, loss_cls, **kwargs):
         self.loss = loss_cls(max_loss_steps=self.horizon, **kwargs)
@@ -66,6 +66,8 @@ class TaichiEnv:
         self.n_particles = len(self.particles['x']) if self.particles is not None else 0
         self.has_particles = self.particles is not None
         self.simulator.build(self.agent, self.smoke_field, self.statics, self.particles)
+        if self.smoke_field is not None:
+            self.smoke_field.build(self.simulator, self.agent)                                   # taichi_env.py:125-126
         if self.agent is not None:
             self.agent.build(self.simulator)
         if self.loss is not None:

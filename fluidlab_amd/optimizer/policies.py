@@ -59,6 +59,10 @@ class LatteArtPolicy(TrainablePolicy):
     pass
 
 
+class CirculationPolicy(TrainablePolicy):
+    """policies.py:341-347"""
+
+
 class IceCreamDynamicPolicy(TrainablePolicy):
     """policies.py:196-201"""
 

@@ -92,3 +92,22 @@ def test_agent_rigid_through_python_stack(hiplib, oracle32):
     (xa, ga), (xb, gb) = out
     assert np.abs(xa - xb).max() <= 2e-5
     assert S.cosine(ga, gb) >= 0.9999 and S.rel_l2(ga, gb) <= 2e-2
+
+
+def test_circulation_env_on_the_gpu(hiplib, oracle32):
+    """Circulation-v0 (SmokeField + AirCon + room SDF + CirculationLoss) on the HIP engine vs the oracle: loss and the
+    8-dof action gradient of one Solver pass."""
+    import test_host_env as H
+    out = []
+    for lib in (None, oracle32):
+        env = H._circulation(lib, max_substeps_local=None)
+        cfg = load_config('configs/exp_circulation.yaml').SOLVER
+        pol = env.trainable_policy(cfg.optim, cfg.init_range)
+        pol.actions_v[:] = np.array([0.0, 0.0, 0.0, 0.0, 0.1, 0.0, 0.02, 0.04])
+        pol.actions_p[:] = np.array([0.55, 0.5, 0.27, 0.0, 0.0, 0.0, 0.0, 0.0])
+        info, g = Solver(env, None, cfg).forward_backward(env.taichi_env.get_state()['state'], pol, env.horizon, env.horizon_action)
+        out.append((info['loss'], g, env.taichi_env.smoke_field.get_state(6)['q']))
+    (la, ga, qa), (lb, gb, qb) = out
+    assert abs(la - lb) <= 1e-4 * abs(lb)
+    assert np.abs(qa - qb).max() <= 1e-4
+    assert S.cosine(ga, gb) >= 0.9999 and S.rel_l2(ga, gb) <= 2e-2

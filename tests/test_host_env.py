@@ -231,3 +231,37 @@ def test_agent_rigid_stirs_water(oracle64):
     g = te.agent.get_grad(6)
     assert g.shape == (7, 6) and np.isfinite(g).all()
     assert np.abs(g[:6, 0]).min() > 0 and np.abs(g[:6, 4]).max() > 0          # translation and rotation both matter
+
+
+def _circulation(engine_lib, **kw):
+    det = [[6, 16, 21], [9, 16, 21], [6, 16, 10], [26, 16, 16], [24, 16, 20], [20, 16, 8]]
+    return make('Circulation-v0', seed=0, loss=True, res=32, horizon=6, solver_iters=10, detectors=det, engine_lib=engine_lib, **kw)
+
+
+def test_circulation_env_smoke_field(oracle64):
+    """Circulation-v0 through the whole stack: SmokeField + AirCon + CirculationLoss + room SDF.  The AirCon cools the air
+    it blows at, the loss gradient w.r.t. its 8-dof actions is non-trivial, and backward through 2-step checkpoint chunks
+    (smoke frames copied / reloaded with the MPM state, mpm:794-866) equals the resident trajectory."""
+    grads = {}
+    for mode, kw in [('resident', dict(max_substeps_local=None)), ('chunked', dict(max_substeps_local=20, ckpt_dest='cpu'))]:
+        env = _circulation(oracle64, **kw)
+        te = env.taichi_env
+        sf = te.smoke_field
+        assert (sf.lower_y, sf.higher_y) == (15, 17)
+        cfg = load_config('configs/exp_circulation.yaml').SOLVER
+        solver = Solver(env, None, cfg)
+        pol = env.trainable_policy(cfg.optim, cfg.init_range)
+        assert np.allclose(pol.actions_v[0], [0, 0, 0, 0, 0, 0, 0.02, 0.04])          # init_range of the reference config
+        pol.actions_v[:] = np.array([0.0, 0.0, 0.0, 0.0, 0.1, 0.0, 0.02, 0.04])
+        pol.actions_p[:] = np.array([0.55, 0.5, 0.27, 0.0, 0.0, 0.0, 0.0, 0.0])
+        q0 = sf.get_state(0)['q'].copy()
+        info, g = solver.forward_backward(te.get_state()['state'], pol, env.horizon, env.horizon_action)
+        grads[mode] = (info['loss'], g)
+        if mode == 'resident':
+            q6 = sf.get_state(6)['q']
+            assert q6[:, 16].min() < 0.9 * q0[:, 16].max()                 # the jet cooled part of the slab (low_T = 0)
+            assert (q6[:, :15] == q0[:, :15]).all() and (q6[:, 17:] == q0[:, 17:]).all()
+            assert g.shape == (7, 8) and np.isfinite(g).all()
+            assert np.abs(g[:6, 6]).max() > 0 and np.abs(g[:6, 7]).max() > 0 and np.abs(g[:6, 4]).max() > 0
+    assert abs(grads['chunked'][0] - grads['resident'][0]) < 1e-9 * abs(grads['resident'][0])
+    assert np.abs(grads['chunked'][1] - grads['resident'][1]).max() < 1e-9 * np.abs(grads['resident'][1]).max()
