@@ -171,7 +171,7 @@ def main():
         per_kernel = {}
         for name, (ms, cnt) in prof.items():
             if cnt:
-                bp, bc = KERNEL_BYTES[name]
+                bp, bc = KERNEL_BYTES.get(name, (0, 0))
                 us = 1e3 * ms / cnt
                 b = bp * n_used + bc * nc
                 per_kernel[name] = {'avg_us': round(us, 3), 'launches': cnt, 'alg_bytes': b, 'GBps': round(b / (us * 1e-6) / 1e9, 1)}

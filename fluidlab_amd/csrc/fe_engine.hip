@@ -80,7 +80,6 @@ struct SimP {
     BoundaryP bnd;
 };
 
-#define FE_MAX_EFF 4
 struct EffP {
     int type, action_dim;
     float scale_v[8], scale_p[8];
@@ -94,7 +93,7 @@ struct EffP {
     float* random_vector;                                    // [random_length, flux, 3]
     int has_mesh; SdfP mesh;                                 // Rigid.setup_mesh (rigid.py:19-24): a moving SDF collider
 };
-struct AgentP { int n; int inj; const EffP* e; };       // effector parameter blocks live in device memory (1 KiB as kernarg spilled SGPRs)
+struct AgentP { int n; int inj; const EffP* e; float collide_min_y; };       // effector parameter blocks live in device memory (1 KiB as kernarg spilled SGPRs)
 struct InjectP { int on, act_id, row, flux; };                     // per-substep injection parameters (host-known)
 
 struct PInfo { float mu, lam, mass; int cls, mat; };
@@ -106,10 +105,15 @@ __device__ __forceinline__ PInfo load_info(const float4* pinfo, int pid) {
 }
 
 // blk_flag: 0 untouched, 1 on the dynamic list (slow-path particles), 2 static = on the order's active list already
-__device__ __forceinline__ void mark_block(int b, int* blk_flag, int* blk_list, int* blk_count) {
-    if (blk_flag[b] == 0) {
+// Returns true when the block is NOT on the order's static active list: only then is the per-frame grid store incomplete
+// (static blocks store their totals, slow-path contributions included).
+__device__ __forceinline__ bool mark_block(int b, int* blk_flag, int* blk_list, int* blk_count) {
+    const int fl = blk_flag[b];
+    if (fl == 2) return false;
+    if (fl == 0) {
         if (atomicCAS(&blk_flag[b], 0, 1) == 0) { int i = atomicAdd(blk_count, 1); blk_list[i] = b; }
     }
+    return true;
 }
 
 // -----------------------------------------------------------------------------------------
@@ -134,6 +138,10 @@ __shared__ float  s_tile[4 * TILE_N];      // gathered node values (v_out / d v_
 // ~1.6 T and ds_add_u64 ~2.8 T in this access pattern (profiles/r01_ubench_lds_types.txt); fp64 also makes the
 // in-tile sum insensitive to the order of the atomics.
 __shared__ double s_acc[4 * TILE_N];
+// Effector pose adjoints of the workgroup's particles in contact (agent.collide's adjoint): summed here first -- every
+// contact particle adds to the same 14 numbers per effector, and same-address global atomics serialise.
+#define FE_MAX_EFF 4
+__shared__ float s_pose[FE_MAX_EFF * 14];
 // Keeps the fully unrolled 27-node stencil loops from being software-pipelined into one giant basic
 // block (which drove k_p2g_grad to 512 registers + scratch): nothing is scheduled across the fence.
 #define NODE_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -314,7 +322,6 @@ __device__ __forceinline__ void p2g_prepare(const SimP& S, const FrameV& cur, co
 
 // global path: 108 scattered global atomics + active-block marking
 __device__ __forceinline__ void p2g_scatter_global(const SimP& S, const P2GPrep& q, const GridW& G) {
-    *G.frame_slow = 1;                          // this frame's grid cannot be served from the store in the backward pass
     const Stencil& st = q.st;
 #pragma unroll 1
     for (int ij = 0; ij < 9; ij++) {
@@ -340,7 +347,8 @@ __device__ __forceinline__ void p2g_scatter_global(const SimP& S, const P2GPrep&
     const int bz0 = st.base[2] >> 2, bz1 = (st.base[2] + 2) >> 2;
     for (int bx = bx0; bx <= bx1; bx++)
         for (int by = by0; by <= by1; by++)
-            for (int bz = bz0; bz <= bz1; bz++) mark_block((bx * S.nb + by) * S.nb + bz, G.blk_flag, G.blk_list, G.blk_count);
+            for (int bz = bz0; bz <= bz1; bz++)
+                if (mark_block((bx * S.nb + by) * S.nb + bz, G.blk_flag, G.blk_list, G.blk_count)) *G.frame_slow = 1;   // store incomplete for this frame
 }
 
 // tile path, executed by ALL lanes of the wave: contributions of lanes with `in_tile` are summed over runs of equal
@@ -599,6 +607,7 @@ __device__ __forceinline__ void agent_collide_particle(const SimP& S, const Agen
         const EffP& e = agent.e[ei];
         if (!e.has_mesh) continue;
         const float pos[3] = {x[0] + S.dt * nv[0], x[1] + S.dt * nv[1], x[2] + S.dt * nv[2]};
+        if (!(pos[1] > agent.collide_min_y)) continue;                           // agent_icecreamdynamic.py:39-43
         float out[3];
         t_dynamic_collide<float>(e.mesh, e.pos + f * 3, e.quat + f * 4, e.pos + (f + 1) * 3, e.quat + (f + 1) * 4, pos, nv, S.dt, out);
         nv[0] = out[0]; nv[1] = out[1]; nv[2] = out[2];
@@ -618,9 +627,11 @@ __device__ void agent_collide_particle_grad(const SimP& S, const AgentP& agent, 
             const EffP& e = agent.e[ei];
             vin[ei][0] = nv[0]; vin[ei][1] = nv[1]; vin[ei][2] = nv[2];
             const float pos[3] = {x[0] + S.dt * nv[0], x[1] + S.dt * nv[1], x[2] + S.dt * nv[2]};
-            float out[3];
-            t_dynamic_collide<float>(e.mesh, e.pos + f * 3, e.quat + f * 4, e.pos + (f + 1) * 3, e.quat + (f + 1) * 4, pos, nv, S.dt, out);
-            nv[0] = out[0]; nv[1] = out[1]; nv[2] = out[2];
+            if (pos[1] > agent.collide_min_y) {
+                float out[3];
+                t_dynamic_collide<float>(e.mesh, e.pos + f * 3, e.quat + f * 4, e.pos + (f + 1) * 3, e.quat + (f + 1) * 4, pos, nv, S.dt, out);
+                nv[0] = out[0]; nv[1] = out[1]; nv[2] = out[2];
+            }
         }
     }
 #pragma unroll
@@ -628,6 +639,7 @@ __device__ void agent_collide_particle_grad(const SimP& S, const AgentP& agent, 
         if (!(ei < agent.n && agent.e[ei].has_mesh)) continue;
         const EffP& e = agent.e[ei];
         const float v[3] = {vin[ei][0], vin[ei][1], vin[ei][2]};
+        if (!(x[1] + S.dt * v[1] > agent.collide_min_y)) continue;
         float gin[3] = {0.f, 0.f, 0.f};
         bool hit = true;
 #pragma unroll 1
@@ -650,10 +662,7 @@ __device__ void agent_collide_particle_grad(const SimP& S, const AgentP& agent, 
             const float c = g[0] * out[0].d + g[1] * out[1].d + g[2] * out[2].d;
             if (dir < 3) { gin[0] = dir == 0 ? c : gin[0]; gin[1] = dir == 1 ? c : gin[1]; gin[2] = dir == 2 ? c : gin[2]; }   // (selects: dir is a runtime index)
             else if (dir < 6) { gx[0] += dir == 3 ? c : 0.f; gx[1] += dir == 4 ? c : 0.f; gx[2] += dir == 5 ? c : 0.f; }
-            else if (dir < 9) atomicAdd(&e.gpos[f * 3 + dir - 6], c);
-            else if (dir < 13) atomicAdd(&e.gquat[f * 4 + dir - 9], c);
-            else if (dir < 16) atomicAdd(&e.gpos[(f + 1) * 3 + dir - 13], c);
-            else atomicAdd(&e.gquat[(f + 1) * 4 + dir - 16], c);
+            else atomicAdd(&s_pose[ei * 14 + dir - 6], c);                    // 0-2 pos[f], 3-6 quat[f], 7-9 pos[f+1], 10-13 quat[f+1]
         }
         if (hit) { g[0] = gin[0]; g[1] = gin[1]; g[2] = gin[2]; }
     }
@@ -776,6 +785,15 @@ __global__ __launch_bounds__(WG) void k_g2p(SimP S, float* fr_cur, float* fr_nex
 // every substep_grad overwrites Gc completely.
 // =========================================================================================
 
+// v_out of node (i,j,k) of frame f for the backward pass' global path: the working grid g_out is only valid when grid[f]
+// was recomputed; with a stored frame it comes from the per-frame store (blocks addressed through the order's blk_slot)
+struct VoutSrc { const float4* g_out; const float4* store; const int* blk_slot; };
+__device__ __forceinline__ float4 vout_at(const SimP& S, const VoutSrc& V, int i, int j, int k) {
+    if (!V.store) return V.g_out[cell_addr(i, j, k, S.nb)];
+    const int slot = V.blk_slot[(((i >> 2) * S.nb) + (j >> 2)) * S.nb + (k >> 2)];
+    return slot >= 0 ? V.store[(size_t)slot * 128 + 64 + (((i & 3) << 4) | ((j & 3) << 2) | (k & 3))] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 // advect_kernel.grad + g2p.grad (mpm:443, 538) for one used particle: scatters d/d(v_out), leaves the
 // position adjoint (so far) in Gc.A0.xyz.  TILE: v_out read from / d v_out accumulated into LDS (3+3 planes)
 // TILE=true is executed by ALL lanes of the wave (`live` = this lane holds a used particle whose stencil fits the
@@ -783,7 +801,7 @@ __global__ __launch_bounds__(WG) void k_g2p(SimP S, float* fr_cur, float* fr_nex
 // cg (COLLIDE only): {d/d(gathered velocity) after agent.collide's adjoint [3], extra d/dx[f] from the colliders [3]}
 template <bool TILE, bool COLLIDE = false>
 __device__ __forceinline__ void used_particle_g2p_grad(const SimP& S, const FrameV& Gn, const FrameV& Gc, int s,
-                                                       int lb, const Stencil& st, const float4* __restrict__ g_out, float* gg_out,
+                                                       int lb, const Stencil& st, const VoutSrc& V, float* gg_out,
                                                        bool live, const SegScan& sc, const float* cg = nullptr) {
     PState g;                                   // adjoints of x', v', C'
     if (!TILE || live) load_xvC(Gn, s, g);
@@ -822,7 +840,7 @@ __device__ __forceinline__ void used_particle_g2p_grad(const SimP& S, const Fram
                 }
             } else {
                 const int c = cell_addr(st.base[0] + i, st.base[1] + j, st.base[2] + kk, S.nb);
-                float4 vo = g_out[c];
+                float4 vo = vout_at(S, V, st.base[0] + i, st.base[1] + j, st.base[2] + kk);
                 v0 = vo.x; v1 = vo.y; v2 = vo.z;
                 float* dst = gg_out + c;
                 unsafeAtomicAdd(dst, weight * q[0]);
@@ -846,7 +864,7 @@ __device__ __forceinline__ void used_particle_g2p_grad(const SimP& S, const Fram
 // colliders saw, forms d/d(v[f+1]) = v_bar' + dt x_bar', pulls it back.  cg = {g_v[3], g_x[3]} for used_particle_g2p_grad.
 template <bool TILE>
 __device__ void g2p_collide_grad(const SimP& S, const AgentP& agent, int f, const FrameV& Gn, int s, int lb, const Stencil& st,
-                                 const float x[3], const float4* __restrict__ g_out, float cg[6]) {
+                                 const float x[3], const VoutSrc& V, float cg[6]) {
     float nv[3] = {0.f, 0.f, 0.f};
 #pragma unroll 1
     for (int ij = 0; ij < 9; ij++) {
@@ -860,7 +878,7 @@ __device__ void g2p_collide_grad(const SimP& S, const AgentP& agent, int f, cons
                 const int l = lb + (i * TILE_T + j) * TILE_T + kk;
                 g0 = s_tile[l]; g1 = s_tile[TILE_N + l]; g2 = s_tile[2 * TILE_N + l];
             } else {
-                float4 gv = g_out[cell_addr(st.base[0] + i, st.base[1] + j, st.base[2] + kk, S.nb)];
+                float4 gv = vout_at(S, V, st.base[0] + i, st.base[1] + j, st.base[2] + kk);
                 g0 = gv.x; g1 = gv.y; g2 = gv.z;
             }
             nv[0] += weight * g0; nv[1] += weight * g1; nv[2] += weight * g2;
@@ -875,7 +893,7 @@ __device__ void g2p_collide_grad(const SimP& S, const AgentP& agent, int f, cons
 // one slot on the global path (tail / sort_interval = 0)
 template <bool COLLIDE>
 __device__ __forceinline__ void g2p_grad_slot_global(const SimP& S, const FrameV& cur, const FrameV& Gn, const FrameV& Gc, int s,
-                                                     const float4* __restrict__ g_out, float* gg_out, const AgentP& agent, int f) {
+                                                     const VoutSrc& V, float* gg_out, const AgentP& agent, int f) {
     if (!cur.used[s]) return;
     float4 a0 = cur.A0[s];
     float x[3] = {a0.x, a0.y, a0.z};
@@ -885,8 +903,27 @@ __device__ __forceinline__ void g2p_grad_slot_global(const SimP& S, const FrameV
     SegScan none;
     none.f1 = none.f2 = none.f4 = none.f8 = none.f15 = none.f31 = 0.f; none.tail = true;
     float cg[6];
-    if (COLLIDE) g2p_collide_grad<false>(S, agent, f, Gn, s, 0, st, x, g_out, cg);
-    used_particle_g2p_grad<false, COLLIDE>(S, Gn, Gc, s, 0, st, g_out, gg_out, true, none, cg);
+    if (COLLIDE) g2p_collide_grad<false>(S, agent, f, Gn, s, 0, st, x, V, cg);
+    used_particle_g2p_grad<false, COLLIDE>(S, Gn, Gc, s, 0, st, V, gg_out, true, none, cg);
+}
+
+// workgroup-level flush of s_pose into the effectors' adjoint arrays (call with all threads; contains barriers)
+__device__ __forceinline__ void pose_flush(const AgentP& agent, int f) {
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < FE_MAX_EFF * 14) {
+        const float v = s_pose[t];
+        const int ei = t / 14, k = t % 14;
+        if (v != 0.f && ei < agent.n) {
+            const EffP& e = agent.e[ei];
+            if (k < 3) atomicAdd(&e.gpos[f * 3 + k], v);
+            else if (k < 7) atomicAdd(&e.gquat[f * 4 + k - 3], v);
+            else if (k < 10) atomicAdd(&e.gpos[(f + 1) * 3 + k - 7], v);
+            else atomicAdd(&e.gquat[(f + 1) * 4 + k - 10], v);
+        }
+        s_pose[t] = 0.f;
+    }
+    __syncthreads();
 }
 
 template <bool COLLIDE>
@@ -895,6 +932,8 @@ __global__ __launch_bounds__(WG) void k_g2p_grad(SimP S, float* fr_cur, float* G
                                                  GridStore GS, int f, AgentP agent) {
     const int tid = threadIdx.x;
     const bool stored = GS.cap > 0 && GS.flag[f];
+    if (COLLIDE) { if (tid < FE_MAX_EFF * 14) s_pose[tid] = 0.f; __syncthreads(); }
+    VoutSrc V; V.g_out = g_out; V.store = stored ? GS.data + (size_t)f * GS.cap * 128 : nullptr; V.blk_slot = T.blk_slot;
     FrameV cur = frame_view(fr_cur, S.Np);
     FrameV Gn = frame_view(Gn_, S.Np), Gc = frame_view(Gc_, S.Np);
     const int n_items = T.meta[0], tail_start = T.meta[1];
@@ -921,13 +960,13 @@ __global__ __launch_bounds__(WG) void k_g2p_grad(SimP S, float* fr_cur, float* G
                 const bool live = lb >= 0;
                 if (__any(live)) {                               // wave-uniform: empty waves skip the scan
                     float cg[6];
-                    if (COLLIDE && live) g2p_collide_grad<true>(S, agent, f, Gn, s, lb, st, x, g_out, cg);     // divergent, before the scan
+                    if (COLLIDE && live) g2p_collide_grad<true>(S, agent, f, Gn, s, lb, st, x, V, cg);     // divergent, before the scan
                     const SegScan sc = seg_setup(live ? lb : (0x40000000 | tid));
-                    used_particle_g2p_grad<true, COLLIDE>(S, Gn, Gc, s, live ? lb : 0, st, g_out, gg_out, live, sc, cg);
+                    used_particle_g2p_grad<true, COLLIDE>(S, Gn, Gc, s, live ? lb : 0, st, V, gg_out, live, sc, cg);
                 }
                 if (used && !live) {
                     if (inside) atomicAdd(slow, 1);
-                    g2p_grad_slot_global<COLLIDE>(S, cur, Gn, Gc, s, g_out, gg_out, agent, f);
+                    g2p_grad_slot_global<COLLIDE>(S, cur, Gn, Gc, s, V, gg_out, agent, f);
                 }
             }
             __syncthreads();
@@ -936,9 +975,10 @@ __global__ __launch_bounds__(WG) void k_g2p_grad(SimP S, float* fr_cur, float* G
             __syncthreads();
         } else {
             const int s = tail_start + (w - n_items) * WG + tid;
-            if (s < S.N) g2p_grad_slot_global<COLLIDE>(S, cur, Gn, Gc, s, g_out, gg_out, agent, f);
+            if (s < S.N) g2p_grad_slot_global<COLLIDE>(S, cur, Gn, Gc, s, V, gg_out, agent, f);
         }
     }
+    if (COLLIDE) pose_flush(agent, f);
 }
 
 // grid_op.grad (mpm:539): d/d v_out (slabs of k_g2p_grad + slow-path atomics in gg_out) -> gg_in (d/d v_in, d/d mass);
@@ -1165,7 +1205,7 @@ __global__ __launch_bounds__(WG, MINW) void k_p2g_grad(SimP S, float* fr_cur, fl
 // order was sorted too), so ranks come from an LDS histogram (ds_add_rtn_u32) and only one global atomic per
 // distinct key per workgroup is issued; keys outside the window fall back to a global atomic.
 __global__ __launch_bounds__(256) void k_sort_count(SimP S, float* fr, int* key, int* rank, int* cnt) {
-    __shared__ int hist[SORT_HB];
+    __shared__ int hist[SORT_HB + 1];       // + the sentinel's slot
     __shared__ int kmin;
     const int tid = threadIdx.x;
     const int s = blockIdx.x * blockDim.x + tid;
@@ -1181,18 +1221,23 @@ __global__ __launch_bounds__(256) void k_sort_count(SimP S, float* fr, int* key,
             if (stencil_inside(st, S.n)) kk = cell_addr(st.base[0], st.base[1], st.base[2], S.nb);
         }
     }
+    // The sentinel key (unused / out-of-grid slots -> tail) has its own histogram slot and does not take part in the window's
+    // minimum: freshly injected particles are scattered over the tail, and a tail workgroup whose window starts at one of
+    // their cell keys used to send its other 255 lanes to cnt[ncell] with one same-address global atomic each (215 us per
+    // sort in IceCreamDynamic-v0).
+    const bool is_tail = kk == S.ncell;
     if (tid == 0) kmin = 0x7fffffff;
-    for (int l = tid; l < SORT_HB; l += 256) hist[l] = 0;
+    for (int l = tid; l <= SORT_HB; l += 256) hist[l] = 0;
     __syncthreads();
-    if (valid) atomicMin(&kmin, kk);
+    if (valid && !is_tail) atomicMin(&kmin, kk);
     __syncthreads();
-    const int rel = kk - kmin;
-    const bool local = valid && rel < SORT_HB;
+    const int rel = is_tail ? SORT_HB : kk - kmin;
+    const bool local = valid && rel <= SORT_HB && (is_tail || rel < SORT_HB);
     int r = 0;
     if (local) r = atomicAdd(&hist[rel], 1);
     else if (valid) r = atomicAdd(&cnt[kk], 1);
     __syncthreads();
-    for (int l = tid; l < SORT_HB; l += 256) { int c = hist[l]; if (c > 0) hist[l] = atomicAdd(&cnt[kmin + l], c); }
+    for (int l = tid; l <= SORT_HB; l += 256) { int c = hist[l]; if (c > 0) hist[l] = atomicAdd(&cnt[l == SORT_HB ? S.ncell : kmin + l], c); }
     __syncthreads();
     if (local) r += hist[rel];
     if (valid) { key[s] = kk; rank[s] = r; }
@@ -1713,8 +1758,8 @@ __global__ __launch_bounds__(256) void k_stats_count(int ncells, unsigned char* 
 // =========================================================================================
 // host side
 // =========================================================================================
-enum { KID_P2G = 0, KID_GRID, KID_G2P, KID_P2G_RE, KID_GRID_KEEP, KID_G2P_GRAD, KID_GRID_GRAD, KID_P2G_GRAD, KID_SORT, KID_REORDER_GRAD, KID_COUNT };
-static const char* KNAMES[KID_COUNT] = {"p2g", "grid_op", "g2p", "p2g_recompute", "grid_op_keep", "g2p_grad", "grid_op_grad", "p2g_grad", "sort", "reorder_grad"};
+enum { KID_P2G = 0, KID_GRID, KID_G2P, KID_P2G_RE, KID_GRID_KEEP, KID_G2P_GRAD, KID_GRID_GRAD, KID_P2G_GRAD, KID_SORT, KID_REORDER_GRAD, KID_SORT_COUNT, KID_SORT_SCAN, KID_SORT_ACTIVE, KID_SORT_PERM, KID_COUNT };
+static const char* KNAMES[KID_COUNT] = {"p2g", "grid_op", "g2p", "p2g_recompute", "grid_op_keep", "g2p_grad", "grid_op_grad", "p2g_grad", "sort", "reorder_grad", "sort_count", "sort_scan", "sort_active", "sort_perm"};
 
 struct EffHost {
     EffP p;
@@ -1757,6 +1802,8 @@ struct FeEngine {
     bool all_simple_liquid = false;                         // every particle is an inviscid MAT_LIQUID: SVD-free kernels
     std::vector<SdfP> statics_host; std::vector<float*> statics_vox; SdfP* statics_dev = nullptr;   // static SDF colliders
     struct SmokeState* smoke = nullptr;                     // SmokeField (fe_smoke.h), optional
+    int inject_till = -1; float collide_min_y = -1e30f;    // AgentIceCreamDynamic (agent_icecreamdynamic.py:11,23-43)
+    bool prof_fine = false;
     bool has_mesh_effector = false; std::vector<float*> mesh_vox;   // Rigid effectors with an SDF mesh (dynamic.py)
     bool has_rigid = false; int n_bodies = 0;               // MAT_RIGID shape-matching bodies (mpm:176-201)
     int* rigid_body = nullptr; RigidBody* bodies_dev = nullptr;   // [Np] body of a MAT_RIGID particle or -1 (by particle id); [n_bodies]
@@ -1821,7 +1868,7 @@ BoundaryP to_boundary(const FeBoundary& b) {
 }
 
 AgentP agent_params(FeEngine* h) {
-    AgentP a; a.n = (int)h->effs.size(); a.inj = 0; a.e = h->effs_dev;
+    AgentP a; a.n = (int)h->effs.size(); a.inj = 0; a.e = h->effs_dev; a.collide_min_y = h->collide_min_y;
     for (size_t i = 0; i < h->effs.size(); i++) if (h->effs[i].p.type == FE_EFF_INJECTOR) a.inj = (int)i;
     return a;
 }
@@ -1866,8 +1913,12 @@ int find_injector(FeEngine* h) {
 int make_inject(FeEngine* h, int f, int f_global, int act, bool forward, InjectP& inj) {
     inj.on = 0; inj.act_id = 0; inj.row = 0; inj.flux = 0;
     int ie = find_injector(h);
-    if (!act || ie < 0) return 0;
+    if (ie < 0) return 0;
     EffHost& E = h->effs[ie];
+    if (!act || (h->inject_till >= 0 && f_global >= h->inject_till)) {       // no injection this substep: act_id carries over
+        if (forward) E.act_id[f + 1] = E.act_id[f];
+        return 0;
+    }
     if (E.act_range.empty()) FAIL(h, "injector has no act_range");
     int row = E.p.locally_random ? f : f_global;
     if (row < 0 || row >= E.p.random_length) FAIL(h, "injector random_vector row out of range");
@@ -1929,15 +1980,20 @@ int sort_frame(FeEngine* h, int f) {
         if (h->gtbl[slot] == id_new && reorder_grad(h, slot, 0)) return 1;
     FeEngine::Table& tn = h->tables[id_new];
     const int ncell = h->S.ncell;
-    prof_begin(h, KID_SORT);
+    const bool fine = h->prof_on && h->prof_fine;          // option "prof_fine": time the sort's stages instead of the whole
+    if (!fine) prof_begin(h, KID_SORT);
     use_static_table(h, 0);                          // un-flag the previous order before its lists are rebuilt
+    if (fine) prof_begin(h, KID_SORT_COUNT);
     hipLaunchKernelGGL(k_clear_slots, dim3(64), dim3(256), 0, h->stream, tn.active, tn.meta, tn.blk_slot);
     hipLaunchKernelGGL(k_sort_count, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->sort_key, h->sort_rank, h->sort_cnt);
+    if (fine) { prof_end(h); prof_begin(h, KID_SORT_SCAN); }
     const int scan_wgs = (ncell + 1 + 1023) / 1024;
     hipLaunchKernelGGL(k_scan_partial, dim3(scan_wgs), dim3(256), 0, h->stream, ncell, h->item_max, h->sort_cnt, h->sort_partial);
     hipLaunchKernelGGL(k_scan_final, dim3(scan_wgs), dim3(256), 0, h->stream, ncell, h->item_max, h->sort_cnt, h->sort_partial, h->sort_start, tn.items, tn.meta, tn.blk_first);
+    if (fine) { prof_end(h); prof_begin(h, KID_SORT_ACTIVE); }
     hipLaunchKernelGGL(k_build_active, dim3(256), dim3(256), 0, h->stream, h->nb, tn.items, tn.meta, h->blk_flag, tn.active, tn.blk_slot);
     h->static_table = id_new;
+    if (fine) { prof_end(h); prof_begin(h, KID_SORT_PERM); }
     hipLaunchKernelGGL(k_sort_perm, pgrid(h), dim3(256), 0, h->stream, h->N, h->sort_key, h->sort_rank, h->sort_start,
                        h->tables[id_old].pid, h->sort_src, h->sort_pid, tn.slot_of_pid);
     HIPCK(h, hipMemcpyAsync(tn.pid, h->sort_pid, sizeof(int) * h->Np, hipMemcpyDeviceToDevice, h->stream));
@@ -2235,6 +2291,9 @@ int fe_set_option(FeEngine* h, const char* name, double value) {
         return 0;
     }
     if (!std::strcmp(name, "p2g_grad_waves")) { h->p2g_grad_waves = (int)value; return 0; }
+    if (!std::strcmp(name, "inject_till")) { h->inject_till = (int)value; return 0; }
+    if (!std::strcmp(name, "collide_min_y")) { h->collide_min_y = (float)value; return 0; }
+    if (!std::strcmp(name, "prof_fine")) { h->prof_fine = value != 0; return 0; }
     if (!std::strcmp(name, "xcd_map")) { h->S.xcd = value != 0; return 0; }
     if (!std::strcmp(name, "dbg")) { h->S.dbg = (int)value; return 0; }     // timing experiments: results are wrong
     if (!std::strcmp(name, "threads")) return 0;             // oracle-only tunable

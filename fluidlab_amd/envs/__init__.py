@@ -3,8 +3,10 @@ from .fluid_env import FluidEnv
 from .latteart_env import LatteArtEnv
 from .waterblock_env import WaterBlockEnv
 from .circulation_env import CirculationEnv
+from .icecreamdynamic_env import IceCreamDynamicEnv
 
-REGISTRY = {'LatteArt-v0': LatteArtEnv, 'WaterBlock-v0': WaterBlockEnv, 'Circulation-v0': CirculationEnv}
+REGISTRY = {'LatteArt-v0': LatteArtEnv, 'WaterBlock-v0': WaterBlockEnv, 'Circulation-v0': CirculationEnv,
+            'IceCreamDynamic-v0': IceCreamDynamicEnv}
 
 
 def make(env_name, **kwargs):

@@ -1,0 +1,108 @@
+"""IceCreamDynamic-v0 (fluidlab/envs/icecreamdynamic_env.py): a dispenser (BallInjector) drops plasto-elastic ice cream
+while a controllable cone (Rigid + SDF mesh) moves underneath; the loss matches the ICECREAM particles to a recorded
+swirl.  The scene BASELINE config 5 ("IceCream-v0") refers to.
+
+`quality`, `n_pool`, `horizon`, `inject_till` scale it for tests; defaults are the reference's (64^3, 100k pool particles,
+900 steps, injection until substep 7700).  The cone's collision mesh is an analytic stand-in (fluidengine/meshes.py:
+sdf_cone_tip) because mesh -> SDF conversion is unavailable here.  With max_substeps_local=None the 9,000-substep
+trajectory of the default scene stays resident in HBM (~90 GB) instead of the reference's 40-substep checkpoint window."""
+import os
+
+import numpy as np
+
+from fluidlab_amd.configs.macros import DISPENSER, ICECREAM
+from fluidlab_amd.fluidengine.losses import IceCreamDynamicLoss
+from fluidlab_amd.fluidengine.meshes import sdf_cone_tip
+from fluidlab_amd.fluidengine.taichi_env import TaichiEnv
+from fluidlab_amd.optimizer.policies import ActionsPolicy, IceCreamDynamicPolicy
+from fluidlab_amd.utils.config import CfgNode
+from fluidlab_amd.utils.misc import get_cfg_path, get_tgt_path
+from .fluid_env import FluidEnv
+
+
+class IceCreamDynamicEnv(FluidEnv):
+    def __init__(self, version=0, loss=True, loss_type='diff', seed=None, renderer_type=None, quality=1, n_pool=100000, horizon=900,
+                 inject_till=None, max_substeps_local=40, ckpt_dest='disk', target=None, engine_lib=None, device=0):
+        if seed is not None:
+            self.seed(seed)
+        self.horizon = horizon
+        self.horizon_action = horizon
+        self.target_file = get_tgt_path('IceCreamDynamic-v0.pkl')
+        self._target = target
+        self._n_obs_ptcls_per_body = 2000
+        self._n_pool = n_pool
+        self._inject_till = inject_till
+        self.loss = loss
+        self.loss_type = loss_type
+        self.action_range = np.array([-0.005, 0.005])
+        self.taichi_env = TaichiEnv(dim=3, quality=quality, particle_density=1e6, max_substeps_local=max_substeps_local,
+                                    gravity=(0.0, -10.0, 0.0), horizon=self.horizon, ckpt_dest=ckpt_dest, engine_lib=engine_lib, device=device)
+        self.build_env()
+        self.gym_misc()
+
+    def setup_agent(self):
+        agent_cfg = CfgNode()
+        agent_cfg.merge_from_file(get_cfg_path('agent_icecreamdynamic.yaml'))
+        if self._inject_till is not None:
+            agent_cfg.params.inject_till = self._inject_till
+        agent_cfg.effectors[1]['mesh']['sdf'] = sdf_cone_tip()
+        agent_cfg.effectors[1]['mesh']['sdf_res'] = 64
+        self.taichi_env.setup_agent(agent_cfg)
+        self.agent = self.taichi_env.agent
+
+    def setup_statics(self):
+        self.taichi_env.add_static(file='icecream_dispenser.obj', pos=(-0.32, 0.96, 0.24), euler=(0.0, 0.0, 0.0), scale=(2.5, 2.5, 2.5),
+                                   material=DISPENSER, has_dynamics=False)
+
+    def setup_bodies(self):
+        self.taichi_env.add_body(type='nowhere', n_particles=self._n_pool, material=ICECREAM)
+
+    def setup_boundary(self):
+        self.taichi_env.setup_boundary(type='cube', lower=(0.05, 0.05, 0.05), upper=(0.95, 0.95, 0.95))
+
+    def setup_loss(self):
+        target = self._target if self._target is not None else (self.target_file if os.path.exists(self.target_file) else None)
+        self.taichi_env.setup_loss(loss_cls=IceCreamDynamicLoss, type=self.loss_type, target_file=target, weights={'chamfer': 1.0})
+
+    def demo_policy(self, user_input=False):
+        """icecreamdynamic_env.py:103-166: hold still while the first ice cream falls, then spiral inwards, then slow down.
+        The three phase lengths (168 / rest / 20 of 900) scale with the horizon."""
+        if user_input:
+            raise NotImplementedError
+        H = self.horizon_action
+        comp_actions_p = np.zeros((1, self.agent.action_dim))
+        comp_actions_v = np.zeros((H, self.agent.action_dim))
+        init_center = np.array([0.5, 0.3, 0.5])
+        y_range = 0.0
+        rad_v_lin = 0.0042 * 900 / H
+        init_radius = 0.15
+        theta = np.pi
+        init_p = init_center + np.array([init_radius * np.cos(theta), 0, init_radius * np.sin(theta)])
+        current_p = np.array(init_p)
+        radius_v = 4e-5 * 900 / H
+        horizon_0 = int(round(168 * H / 900))
+        horizon_2 = max(1, int(round(20 * H / 900)))
+        horizon_1 = H - horizon_0 - horizon_2
+        horizon_1_ = horizon_0 + horizon_1
+        r = init_radius
+        for i in range(horizon_0):
+            comp_actions_v[i] = init_p - current_p
+            current_p += comp_actions_v[i]
+        for i in range(horizon_0, horizon_1_):
+            t = i - horizon_0
+            r = init_radius - radius_v * t
+            theta += rad_v_lin / r
+            target_p = np.array([init_center[0] + r * np.cos(theta), init_center[1] - y_range * t / horizon_1, init_center[2] + r * np.sin(theta)])
+            comp_actions_v[i] = target_p - current_p
+            current_p += comp_actions_v[i]
+        for i in range(horizon_1_, H):                                    # cooling down
+            t = i - horizon_1_
+            theta += rad_v_lin / r * (1 - t / horizon_2)
+            target_p = np.array([init_center[0] + r * np.cos(theta), init_center[1] - y_range, init_center[2] + r * np.sin(theta)])
+            comp_actions_v[i] = target_p - current_p
+            current_p += comp_actions_v[i]
+        comp_actions_p[0] = init_p
+        return ActionsPolicy(np.vstack([comp_actions_v, comp_actions_p]))
+
+    def trainable_policy(self, optim_cfg, init_range):
+        return IceCreamDynamicPolicy(optim_cfg, init_range, self.agent.action_dim, self.horizon_action, self.action_range, fix_dim=None)

@@ -2,3 +2,4 @@ from .loss import Loss
 from .shapematching_loss import ShapeMatchingLoss
 from .latteart_loss import LatteArtLoss
 from .circulation_loss import CirculationLoss
+from .icecreamdynamic_loss import IceCreamDynamicLoss

@@ -74,7 +74,7 @@ class ShapeMatchingLoss(Loss):
         if self.temporal_range_type != 'expand':
             return
         loss_improved = self.best_loss - self.total_loss
-        loss_improved_rate = loss_improved / self.best_loss
+        loss_improved_rate = loss_improved / self.best_loss if self.best_loss != 0 else 0.0     # (a loss of exactly 0 only in tests)
         if loss_improved_rate < self.plateau_thresh[0] or loss_improved < self.plateau_thresh[1]:
             self.plateau_count += 1
             print('Plateaued!!!', self.plateau_count)

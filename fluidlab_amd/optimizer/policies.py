@@ -69,7 +69,8 @@ class IceCreamDynamicPolicy(TrainablePolicy):
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self.trainable = np.full(self.comp_actions_shape[0], False)
-        self.trainable[169:-1] = True
+        first = int(round(169 * self.horizon / 900))      # the demo's hold-still phase (168 of 900 steps) is not optimised
+        self.trainable[first:-1] = True
 
 
 class IceCreamStaticPolicy(TrainablePolicy):

@@ -269,6 +269,8 @@ struct FeEngine {
     std::vector<Sdf> statics;        /* statics.py */
     std::vector<Sdf> meshes;         /* Dynamic meshes of Rigid effectors (dynamic.py) */
     bool has_mesh_effector = false;
+    int inject_till = -1;            /* AgentIceCreamDynamic.inject_till (agent_icecreamdynamic.py:11,23-30): no injection from this global substep on */
+    R collide_min_y = (R)-1e30;      /* AgentIceCreamDynamic.collide: only above this height (agent_icecreamdynamic.py:39-43) */
     int loss_steps = 0;
     std::vector<R> tgt;          /* [loss_steps, N, 3] */
     std::vector<R> chamfer, step_loss;
@@ -659,6 +661,7 @@ void agent_collide_particle(FeEngine* h, int f, const R x[3], R nv[3]) {
     for (const Effector& e : h->effs) {
         if (e.mesh < 0) continue;
         R pos[3] = {x[0] + dt * nv[0], x[1] + dt * nv[1], x[2] + dt * nv[2]}, out[3];
+        if (!(pos[1] > h->collide_min_y)) continue;
         t_dynamic_collide<R>(h->meshes[e.mesh], &e.pos[f * 3], &e.quat[f * 4], &e.pos[(f + 1) * 3], &e.quat[(f + 1) * 4], pos, nv, dt, out);
         for (int d = 0; d < 3; d++) nv[d] = out[d];
     }
@@ -673,6 +676,7 @@ void agent_collide_particle_grad(FeEngine* h, int f, const R x[3], const R nv0[3
         if (e.mesh < 0) continue;
         vin.push_back({nv[0], nv[1], nv[2]});
         R pos[3] = {x[0] + dt * nv[0], x[1] + dt * nv[1], x[2] + dt * nv[2]}, out[3];
+        if (!(pos[1] > h->collide_min_y)) continue;
         t_dynamic_collide<R>(h->meshes[e.mesh], &e.pos[f * 3], &e.quat[f * 4], &e.pos[(f + 1) * 3], &e.quat[(f + 1) * 4], pos, nv, dt, out);
         for (int d = 0; d < 3; d++) nv[d] = out[d];
     }
@@ -683,6 +687,7 @@ void agent_collide_particle_grad(FeEngine* h, int f, const R x[3], const R nv0[3
         k--;
         const R* v = vin[k].data();
         const Sdf& s = h->meshes[e.mesh];
+        if (!(x[1] + dt * v[1] > h->collide_min_y)) continue;
         R gin[3] = {0, 0, 0}, gpose[14];
         /* inputs: 0-2 new_v (enters as mat_v and, times dt, in the position), 3-5 x, 6-8 pos[f], 9-12 quat[f],
          *         13-15 pos[f+1], 16-19 quat[f+1] */
@@ -1125,7 +1130,11 @@ int substep(FeEngine* h, int f, int f_global, int act) {
     reset_grid_and_grad(h);
     advect_used(h, f);
     process_unused_particles(h, f);
-    if (act) for (auto& e : h->effs) if (e.d.type == FE_EFF_INJECTOR) { if (injector_act(h, e, f, f_global)) return 1; }
+    const bool inject = act && !(h->inject_till >= 0 && f_global >= h->inject_till);
+    for (auto& e : h->effs) if (e.d.type == FE_EFF_INJECTOR) {
+        if (inject) { if (injector_act(h, e, f, f_global)) return 1; }
+        else e.act_id[f + 1] = e.act_id[f];
+    }
     compute_F_tmp_svd(h, f);
     if (p2g(h, f, true)) return 1;
     if (act) for (auto& e : h->effs) effector_move(e, f);
@@ -1138,7 +1147,6 @@ int substep(FeEngine* h, int f, int f_global, int act) {
 int substep_grad(FeEngine* h, int f, int f_global, int act) {
     /* The reference keeps grid[f] and F_tmp/U/S/V[f] of every frame (mpm:106,117); this
      * restatement keeps one grid and recomputes those forward values of frame f first. */
-    (void)f_global;
     reset_grid_and_grad(h);
     compute_F_tmp_svd(h, f);
     if (p2g(h, f, false)) return 1;
@@ -1149,7 +1157,7 @@ int substep_grad(FeEngine* h, int f, int f_global, int act) {
     grid_op_grad(h);
     if (act) for (int i = (int)h->effs.size() - 1; i >= 0; i--) effector_move_grad(h->effs[i], f);
     p2g_grad(h, f);
-    if (act) for (auto& e : h->effs) if (e.d.type == FE_EFF_INJECTOR) injector_act_grad(h, e, f);
+    if (act && !(h->inject_till >= 0 && f_global >= h->inject_till)) for (auto& e : h->effs) if (e.d.type == FE_EFF_INJECTOR) injector_act_grad(h, e, f);
     process_unused_particles_grad(h, f);
     return 0;
 }
@@ -1514,6 +1522,8 @@ int fe_set_option(FeEngine* h, const char* name, double value) {
 #endif
         h->threads = t; return 0;
     }
+    if (!std::strcmp(name, "inject_till")) { h->inject_till = (int)value; return 0; }
+    if (!std::strcmp(name, "collide_min_y")) { h->collide_min_y = (R)value; return 0; }
     /* HIP-engine tunables are accepted and ignored so the same host code drives both */
     return 0;
 }

@@ -111,3 +111,28 @@ def test_circulation_env_on_the_gpu(hiplib, oracle32):
     assert abs(la - lb) <= 1e-4 * abs(lb)
     assert np.abs(qa - qb).max() <= 1e-4
     assert S.cosine(ga, gb) >= 0.9999 and S.rel_l2(ga, gb) <= 2e-2
+
+
+def test_icecream_dynamic_on_the_gpu(hiplib, oracle32):
+    """IceCreamDynamic-v0 (BallInjector + Rigid cone SDF + plasto-elastic ICECREAM) at a reduced size, HIP vs oracle:
+    recorded target and the action gradient of a drifted policy."""
+    import test_host_env as H
+    res = []
+    for lib in (None, oracle32):
+        env = H._icecream(lib, loss=False, max_substeps_local=None)
+        tgt = Recorder(env).record(write=False)
+        env = H._icecream(lib, target=tgt, max_substeps_local=None)
+        cfg = load_config('configs/exp_icecream_dynamic.yaml').SOLVER
+        pol = env.trainable_policy(cfg.optim, cfg.init_range)
+        demo = env.demo_policy()
+        pol.actions_v[:] = demo.actions_v; pol.actions_p[:] = demo.actions_p
+        pol.actions_v[40:, 0] += 0.0004
+        env.taichi_env.loss.temporal_range[1] = env.horizon
+        info, g = Solver(env, None, cfg).forward_backward(env.taichi_env.get_state()['state'], pol, env.horizon, env.horizon_action)
+        res.append((tgt['x'][-1], tgt['used'][-1], info['loss'], g))
+    (xa, ua, la, ga), (xb, ub, lb, gb) = res
+    assert (ua == ub).all()
+    m = ua > 0
+    assert np.quantile(np.abs(xa[m] - xb[m]).max(1), 0.95) <= 1e-4     # plasto-elastic contact: a few particles sit on branch edges
+    assert abs(la - lb) <= 5e-2 * abs(lb)
+    assert S.cosine(ga, gb) >= 0.99

@@ -265,3 +265,36 @@ def test_circulation_env_smoke_field(oracle64):
             assert np.abs(g[:6, 6]).max() > 0 and np.abs(g[:6, 7]).max() > 0 and np.abs(g[:6, 4]).max() > 0
     assert abs(grads['chunked'][0] - grads['resident'][0]) < 1e-9 * abs(grads['resident'][0])
     assert np.abs(grads['chunked'][1] - grads['resident'][1]).max() < 1e-9 * np.abs(grads['resident'][1]).max()
+
+
+ICE_MINI = dict(quality=0.5, n_pool=3100, horizon=160, inject_till=300)      # 0.32 s: the first ice cream reaches the cone
+
+
+def _icecream(engine_lib, target=None, loss=True, **kw):
+    return make('IceCreamDynamic-v0', seed=0, loss=loss, target=target, engine_lib=engine_lib, **ICE_MINI, **kw)
+
+
+def test_icecream_dynamic_env(oracle32):
+    """IceCreamDynamic-v0 at a reduced size: BallInjector (stops at inject_till) + Rigid cone with an SDF mesh (collides
+    above y = 0.25 only) + plasto-elastic ICECREAM + expanding-range shape-matching loss, record then one Solver pass."""
+    env = _icecream(oracle32, loss=False, max_substeps_local=None)
+    tgt = Recorder(env).record(write=False)
+    used_end = tgt['used'][-1]
+    assert used_end.sum() == 300 * 10                                   # 10 particles per substep until inject_till = 300
+    x_end = tgt['x'][-1][used_end > 0]
+    assert np.isfinite(x_end).all()
+    # ice cream that already came down rests on the cone (top near y = 0.3 + ...) instead of the domain floor at 0.05
+    landed = x_end[x_end[:, 1] < 0.45]
+    assert len(landed) > 200 and landed[:, 1].min() > 0.25
+    env = _icecream(oracle32, target=tgt, max_substeps_local=None)
+    cfg = load_config('configs/exp_icecream_dynamic.yaml').SOLVER
+    pol = env.trainable_policy(cfg.optim, cfg.init_range)
+    demo = env.demo_policy()
+    pol.actions_v[:] = demo.actions_v; pol.actions_p[:] = demo.actions_p
+    env.taichi_env.loss.temporal_range[1] = env.horizon                # evaluate the whole horizon (the curriculum starts at 200)
+    info, g = Solver(env, None, cfg).forward_backward(env.taichi_env.get_state()['state'], pol, env.horizon, env.horizon_action)
+    assert info['loss'] < 1e-6                                          # the demo policy reproduces its own recording
+    pol.actions_v[40:, 0] += 0.0004                                     # drift the cone: the loss wakes up and has a gradient
+    info, g = Solver(env, None, cfg).forward_backward(env.taichi_env.get_state()['state'], pol, env.horizon, env.horizon_action)
+    assert info['loss'] > 1e-4 and g.shape == (161, 3) and np.isfinite(g).all() and np.abs(g[:160]).max() > 0
+    assert pol.trainable[:30].sum() == 0 and pol.trainable[31:-1].all()   # the hold-still prefix of the demo stays frozen
