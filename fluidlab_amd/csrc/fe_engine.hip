@@ -614,9 +614,8 @@ __device__ __forceinline__ void agent_collide_particle(const SimP& S, const Agen
     }
 }
 // Its adjoint.  g = d/d(new_v after the colliders) on entry, d/d(new_v before them) on exit; gx receives the part that
-// flows into x[f]; the effector pose adjoints (pos, quat at f and f+1) are accumulated with atomics.  One Jacobian
-// column per forward-mode pass (inputs: 0-2 new_v, 3-5 x, 6-8 pos[f], 9-12 quat[f], 13-15 pos[f+1], 16-19 quat[f+1]);
-// a particle that is not in contact leaves after the first pass.
+// flows into x[f]; the effector pose adjoints (pos, quat at f and f+1) are accumulated in LDS (s_pose).  One Jacobian
+// column per forward-mode pass; a particle that is not in contact leaves after the first pass.
 __device__ void agent_collide_particle_grad(const SimP& S, const AgentP& agent, int f, const float x[3], const float nv0[3],
                                             float g[3], float gx[3]) {
     float vin[FE_MAX_EFF][3];
@@ -640,31 +639,63 @@ __device__ void agent_collide_particle_grad(const SimP& S, const AgentP& agent, 
         const EffP& e = agent.e[ei];
         const float v[3] = {vin[ei][0], vin[ei][1], vin[ei][2]};
         if (!(x[1] + S.dt * v[1] > agent.collide_min_y)) continue;
-        float gin[3] = {0.f, 0.f, 0.f};
+        // out = cv + vt(rel, n) infl + rel (1 - infl), rel = mv - cv, cv = (R(q1) pm + p1 - pos) / dt: the inputs that enter only
+        // through cv (p1, q1 and the explicit -pos) have the closed-form Jacobian (I - d out/d mv) d cv/d input, so only ten
+        // forward-mode passes are needed -- mv (3), p0 (3: it enters through pm only, like the pm-part of pos), q0 (4).
+        float c[3] = {0.f, 0.f, 0.f}, a[3] = {0.f, 0.f, 0.f}, gq0[4] = {0.f, 0.f, 0.f, 0.f};
         bool hit = true;
 #pragma unroll 1
-        for (int dir = 0; dir < 20 && hit; dir++) {
+        for (int dir = 0; dir < 10 && hit; dir++) {
             Dual p0[3], q0[4], p1[3], q1[4], pos[3], mv[3], out[3];
 #pragma unroll
             for (int d = 0; d < 3; d++) {
-                p0[d] = Dual(e.pos[f * 3 + d], dir == 6 + d ? 1.f : 0.f);
-                p1[d] = Dual(e.pos[(f + 1) * 3 + d], dir == 13 + d ? 1.f : 0.f);
+                p0[d] = Dual(e.pos[f * 3 + d], dir == 3 + d ? 1.f : 0.f);
+                p1[d] = Dual(e.pos[(f + 1) * 3 + d]);
                 mv[d] = Dual(v[d], dir == d ? 1.f : 0.f);
-                pos[d] = Dual(x[d] + S.dt * v[d], dir == d ? S.dt : (dir == 3 + d ? 1.f : 0.f));
+                pos[d] = Dual(x[d] + S.dt * v[d]);
             }
 #pragma unroll
             for (int d = 0; d < 4; d++) {
-                q0[d] = Dual(e.quat[f * 4 + d], dir == 9 + d ? 1.f : 0.f);
-                q1[d] = Dual(e.quat[(f + 1) * 4 + d], dir == 16 + d ? 1.f : 0.f);
+                q0[d] = Dual(e.quat[f * 4 + d], dir == 6 + d ? 1.f : 0.f);
+                q1[d] = Dual(e.quat[(f + 1) * 4 + d]);
             }
             hit = t_dynamic_collide<Dual>(e.mesh, p0, q0, p1, q1, pos, mv, S.dt, out);
             if (!hit) break;
-            const float c = g[0] * out[0].d + g[1] * out[1].d + g[2] * out[2].d;
-            if (dir < 3) { gin[0] = dir == 0 ? c : gin[0]; gin[1] = dir == 1 ? c : gin[1]; gin[2] = dir == 2 ? c : gin[2]; }   // (selects: dir is a runtime index)
-            else if (dir < 6) { gx[0] += dir == 3 ? c : 0.f; gx[1] += dir == 4 ? c : 0.f; gx[2] += dir == 5 ? c : 0.f; }
-            else atomicAdd(&s_pose[ei * 14 + dir - 6], c);                    // 0-2 pos[f], 3-6 quat[f], 7-9 pos[f+1], 10-13 quat[f+1]
+            const float r = g[0] * out[0].d + g[1] * out[1].d + g[2] * out[2].d;
+            c[0] = dir == 0 ? r : c[0]; c[1] = dir == 1 ? r : c[1]; c[2] = dir == 2 ? r : c[2];           // (selects: dir is a runtime index)
+            a[0] = dir == 3 ? r : a[0]; a[1] = dir == 4 ? r : a[1]; a[2] = dir == 5 ? r : a[2];
+            gq0[0] = dir == 6 ? r : gq0[0]; gq0[1] = dir == 7 ? r : gq0[1]; gq0[2] = dir == 8 ? r : gq0[2]; gq0[3] = dir == 9 ? r : gq0[3];
         }
-        if (hit) { g[0] = gin[0]; g[1] = gin[1]; g[2] = gin[2]; }
+        if (!hit) continue;                                             // not in contact: identity, g passes through
+        const float idt = 1.f / S.dt;
+        const float w[3] = {(g[0] - c[0]) * idt, (g[1] - c[1]) * idt, (g[2] - c[2]) * idt};      // (I - J_mv)^T g / dt
+        // pm = R(q0)^-1 (pos - p0), then d(R(q1) pm)/d q1_k by one dual quaternion rotation each
+        float pm[3];
+        {
+            const float qn = 1.f / sqrtf(e.quat[f * 4] * e.quat[f * 4] + e.quat[f * 4 + 1] * e.quat[f * 4 + 1] + e.quat[f * 4 + 2] * e.quat[f * 4 + 2] + e.quat[f * 4 + 3] * e.quat[f * 4 + 3]);
+            const float qi[4] = {e.quat[f * 4] * qn, -e.quat[f * 4 + 1] * qn, -e.quat[f * 4 + 2] * qn, -e.quat[f * 4 + 3] * qn};
+            const float rel0[3] = {x[0] + S.dt * v[0] - e.pos[f * 3], x[1] + S.dt * v[1] - e.pos[f * 3 + 1], x[2] + S.dt * v[2] - e.pos[f * 3 + 2]};
+            t_quat_rotate(rel0, qi, pm);
+        }
+        float gq1[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            Dual q1[4], pmd[3], rot[3];
+            for (int d = 0; d < 4; d++) q1[d] = Dual(e.quat[(f + 1) * 4 + d], d == k ? 1.f : 0.f);
+            for (int d = 0; d < 3; d++) pmd[d] = Dual(pm[d]);
+            t_quat_rotate(pmd, q1, rot);
+            gq1[k] = w[0] * rot[0].d + w[1] * rot[1].d + w[2] * rot[2].d;
+        }
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const float gpos = -a[d] - w[d];                             // d/d pos: the pm part (= -d/d p0) and the explicit -pos/dt of cv
+            gx[d] += gpos;
+            g[d] = c[d] + S.dt * gpos;                                  // new_v enters as mat_v and, times dt, in pos
+            atomicAdd(&s_pose[ei * 14 + d], a[d]);                      // pos[f]
+            atomicAdd(&s_pose[ei * 14 + 7 + d], w[d]);                  // pos[f+1]
+        }
+#pragma unroll
+        for (int d = 0; d < 4; d++) { atomicAdd(&s_pose[ei * 14 + 3 + d], gq0[d]); atomicAdd(&s_pose[ei * 14 + 10 + d], gq1[d]); }
     }
 }
 
