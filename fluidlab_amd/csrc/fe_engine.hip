@@ -707,11 +707,14 @@ __device__ __forceinline__ void used_particle_g2p(const SimP& S, const FrameV& c
     float nv[3] = {0.f, 0.f, 0.f};
     m3 nC = m3_zero();
     const float c4 = 4.f * S.inv_dx;
+    // new_C[a][b] = c4 sum W g[a] (o_b - fx_b) = c4 (M[a][b] - fx_b new_v[a]) with M[a][b] = sum W g[a] o_b; o_0 = i and o_1 = j are
+    // constant over the inner k loop, so the per-node work is the three products W g[a] and two partial sums.
+    m3 M = m3_zero();
 #pragma unroll 1
     for (int ij = 0; ij < 9; ij++) {
         const int i = ij / 3, j = ij - 3 * i;
         const float wij = STW(st, i, 0) * STW(st, j, 1);
-        const float dx0 = (float)i - st.fx[0], dx1 = (float)j - st.fx[1];
+        float T[3] = {0.f, 0.f, 0.f}, Tz[3] = {0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < 3; kk++) {
             const float weight = wij * st.w[kk][2];
@@ -723,16 +726,20 @@ __device__ __forceinline__ void used_particle_g2p(const SimP& S, const FrameV& c
                 float4 gv = g_out[cell_addr(st.base[0] + i, st.base[1] + j, st.base[2] + kk, S.nb)];
                 g0 = gv.x; g1 = gv.y; g2 = gv.z;
             }
-            const float dpos[3] = {dx0, dx1, (float)kk - st.fx[2]};
             const float gw[3] = {weight * g0, weight * g1, weight * g2};
 #pragma unroll
-            for (int a = 0; a < 3; a++) {
-                nv[a] += gw[a];
+            for (int a = 0; a < 3; a++) { T[a] += gw[a]; if (kk > 0) Tz[a] += (float)kk * gw[a]; }
+        }
 #pragma unroll
-                for (int b = 0; b < 3; b++) nC.a[a][b] += c4 * gw[a] * dpos[b];
-            }
+        for (int a = 0; a < 3; a++) {
+            nv[a] += T[a];
+            M.a[a][0] += (float)i * T[a]; M.a[a][1] += (float)j * T[a]; M.a[a][2] += Tz[a];
         }
     }
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) nC.a[a][b] = c4 * (M.a[a][b] - st.fx[b] * nv[a]);
     if (COLLIDE) agent_collide_particle(S, agent, f, x, nv);                    // mpm:418-422
     float xn[3] = {x[0] + S.dt * nv[0], x[1] + S.dt * nv[1], x[2] + S.dt * nv[2]};
     store_xvC(nxt, s, xn, nv, nC);
@@ -844,20 +851,30 @@ __device__ __forceinline__ void used_particle_g2p_grad(const SimP& S, const Fram
     if (COLLIDE && (!TILE || live)) { gv[0] = cg[0]; gv[1] = cg[1]; gv[2] = cg[2]; g.x[0] += cg[3]; g.x[1] += cg[4]; g.x[2] += cg[5]; }
     const float c4 = 4.f * S.inv_dx;
     float gfx[3] = {0.f, 0.f, 0.f};
+    // q(o) = gv + c4 gC (o - fx) is linear in the node offset o: base at o = 0, per-(i,j) part, one fma per node for k.
+    // sum W c4 (v^T gC)_b = c4 (nv^T gC)_b with nv = sum W v_out leaves the loop (VALU-issue-bound kernel).
+    float qb[3], qz[3], nvw[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        qb[a] = gv[a] - c4 * (g.C.a[a][0] * st.fx[0] + g.C.a[a][1] * st.fx[1] + g.C.a[a][2] * st.fx[2]);
+        qz[a] = c4 * g.C.a[a][2];
+    }
 #pragma unroll 1
     for (int ij = 0; ij < 9; ij++) {
         const int i = ij / 3, j = ij - 3 * i;
         const float wi = STW(st, i, 0), wj = STW(st, j, 1);
-        const float dwi = stencil_dw(st, i, 0), dwj = stencil_dw(st, j, 1);
-        const float dx0 = (float)i - st.fx[0], dx1 = (float)j - st.fx[1];
+        const float wiwj = wi * wj, dwiwj = stencil_dw(st, i, 0) * wj, widwj = wi * stencil_dw(st, j, 1);
+        const float lw = livef * wiwj;
+        float qij[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) qij[a] = qb[a] + c4 * (g.C.a[a][0] * (float)i + g.C.a[a][1] * (float)j);
 #pragma unroll
         for (int kk = 0; kk < 3; kk++) {
             const float wk = st.w[kk][2];
-            const float weight = livef * wi * wj * wk;
-            const float dpos[3] = {dx0, dx1, (float)kk - st.fx[2]};
+            const float weight = lw * wk;
             float q[3];
 #pragma unroll
-            for (int a = 0; a < 3; a++) q[a] = gv[a] + c4 * (g.C.a[a][0] * dpos[0] + g.C.a[a][1] * dpos[1] + g.C.a[a][2] * dpos[2]);
+            for (int a = 0; a < 3; a++) q[a] = kk == 0 ? qij[a] : qij[a] + (float)kk * qz[a];
             float v0, v1, v2;
             if (TILE) {
                 const int l = lb + (i * TILE_T + j) * TILE_T + kk;
@@ -879,15 +896,16 @@ __device__ __forceinline__ void used_particle_g2p_grad(const SimP& S, const Fram
                 unsafeAtomicAdd(dst + 2 * S.ncell, weight * q[2]);
             }
             const float sdot = v0 * q[0] + v1 * q[1] + v2 * q[2];
-            // d weight / d fx_d
-            gfx[0] += dwi * wj * wk * sdot;
-            gfx[1] += wi * dwj * wk * sdot;
-            gfx[2] += wi * wj * stencil_dw(st, kk, 2) * sdot;
-            // dpos_b = o_b - fx_b
-#pragma unroll
-            for (int b = 0; b < 3; b++) gfx[b] -= c4 * weight * (v0 * g.C.a[0][b] + v1 * g.C.a[1][b] + v2 * g.C.a[2][b]);
+            const float w3 = wiwj * wk;
+            nvw[0] += w3 * v0; nvw[1] += w3 * v1; nvw[2] += w3 * v2;
+            const float t = wk * sdot;
+            gfx[0] += dwiwj * t;                               // d weight / d fx_d
+            gfx[1] += widwj * t;
+            gfx[2] += wiwj * (stencil_dw(st, kk, 2) * sdot);
         }
     }
+#pragma unroll
+    for (int b = 0; b < 3; b++) gfx[b] -= c4 * (nvw[0] * g.C.a[0][b] + nvw[1] * g.C.a[1][b] + nvw[2] * g.C.a[2][b]);     // dpos_b = o_b - fx_b
     if (!TILE || live) Gc.A0[s] = make_float4(g.x[0] + S.inv_dx * gfx[0], g.x[1] + S.inv_dx * gfx[1], g.x[2] + S.inv_dx * gfx[2], 0.f);
 }
 
@@ -1108,16 +1126,21 @@ __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const Fram
 #pragma unroll
         for (int a = 0; a < 3; a++)
             mv[a] = m * p.v[a] - S.dx * (k.affine.a[a][0] * st.fx[0] + k.affine.a[a][1] * st.fx[1] + k.affine.a[a][2] * st.fx[2]);
+        // The kernel is bound by VALU issue, so the sums are organised to do as little per node as possible:
+        //   GA[a][b] = sum W gin[a] (o_b - fx_b) dx = dx (M[a][b] - fx_b Gv[a]),  M[a][b] = sum W gin[a] o_b, with o_0 = i and
+        //   o_1 = j constant over the inner k loop (per-(i,j) partial sums T, Tz);
+        //   sum W dx (A^T gin)_b = dx (A^T Gv)_b leaves the loop altogether.
+        m3 M = m3_zero();
 #pragma unroll 1
         for (int ij = 0; ij < 9; ij++) {
             const int i = ij / 3, j = ij - 3 * i;
             const float wi = STW(st, i, 0), wj = STW(st, j, 1);
-            const float dwi = stencil_dw(st, i, 0), dwj = stencil_dw(st, j, 1);
+            const float wiwj = wi * wj, dwiwj = stencil_dw(st, i, 0) * wj, widwj = wi * stencil_dw(st, j, 1);
             const float ox = (float)i * S.dx, oy = (float)j * S.dx;
-            const float dp0 = ((float)i - st.fx[0]) * S.dx, dp1 = ((float)j - st.fx[1]) * S.dx;
             float mij[3];
 #pragma unroll
             for (int a = 0; a < 3; a++) mij[a] = mv[a] + k.affine.a[a][0] * ox + k.affine.a[a][1] * oy;
+            float T[3] = {0.f, 0.f, 0.f}, Tz[3] = {0.f, 0.f, 0.f};
 #pragma unroll
             for (int kk = 0; kk < 3; kk++) {
                 float gin[3], gm;
@@ -1129,24 +1152,33 @@ __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const Fram
                     gin[0] = gi.x; gin[1] = gi.y; gin[2] = gi.z; gm = gi.w;
                 }
                 const float wk = st.w[kk][2];
-                const float weight = wi * wj * wk;
-                const float dpos[3] = {dp0, dp1, ((float)kk - st.fx[2]) * S.dx};
+                const float weight = wiwj * wk;
                 const float oz = (float)kk * S.dx;
                 float sdot = gm * m;
 #pragma unroll
                 for (int a = 0; a < 3; a++) {
                     sdot += gin[a] * (mij[a] + k.affine.a[a][2] * oz);
-                    Gv[a] += weight * gin[a];
-#pragma unroll
-                    for (int b = 0; b < 3; b++) GA.a[a][b] += weight * gin[a] * dpos[b];
+                    const float wg = weight * gin[a];
+                    T[a] += wg;
+                    if (kk > 0) Tz[a] += (float)kk * wg;
                 }
-                gfx[0] += dwi * wj * wk * sdot;
-                gfx[1] += wi * dwj * wk * sdot;
-                gfx[2] += wi * wj * stencil_dw(st, kk, 2) * sdot;
+                const float t = wk * sdot;
+                gfx[0] += dwiwj * t;
+                gfx[1] += widwj * t;
+                gfx[2] += wiwj * (stencil_dw(st, kk, 2) * sdot);
+            }
 #pragma unroll
-                for (int b = 0; b < 3; b++) gfx[b] -= S.dx * weight * (gin[0] * k.affine.a[0][b] + gin[1] * k.affine.a[1][b] + gin[2] * k.affine.a[2][b]);
+            for (int a = 0; a < 3; a++) {
+                Gv[a] += T[a];
+                M.a[a][0] += (float)i * T[a]; M.a[a][1] += (float)j * T[a]; M.a[a][2] += Tz[a];
             }
         }
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) GA.a[a][b] = S.dx * (M.a[a][b] - st.fx[b] * Gv[a]);
+#pragma unroll
+        for (int b = 0; b < 3; b++) gfx[b] -= S.dx * (Gv[0] * k.affine.a[0][b] + Gv[1] * k.affine.a[1][b] + Gv[2] * k.affine.a[2][b]);
 #pragma unroll
         for (int d = 0; d < 3; d++) gxs[d] = S.inv_dx * gfx[d];
     }
