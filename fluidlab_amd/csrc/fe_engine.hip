@@ -204,6 +204,21 @@ __device__ __forceinline__ void seg_scan4(const SegScan& sc, float& a, float& b,
     SEG_STEP4("row_bcast:15 row_mask:0xa bank_mask:0xf", sc.f15);
     SEG_STEP4("row_bcast:31 row_mask:0xc bank_mask:0xf", sc.f31);
 }
+// three values (the adjoint scatter of g2p has no mass component)
+#define SEG_STEP3(ctrl, flag) \
+    asm volatile("v_fmac_f32_dpp %0, %0, %3 " ctrl " bound_ctrl:0\n\t" \
+                 "v_fmac_f32_dpp %1, %1, %3 " ctrl " bound_ctrl:0\n\t" \
+                 "v_fmac_f32_dpp %2, %2, %3 " ctrl " bound_ctrl:0\n\t" \
+                 "s_nop 0" : "+v"(a), "+v"(b), "+v"(c) : "v"(flag))      // 2 other VALUs + 1 wait state between write and DPP read
+__device__ __forceinline__ void seg_scan3(const SegScan& sc, float& a, float& b, float& c) {
+    asm volatile("s_nop 1" ::: );
+    SEG_STEP3("row_shr:1 row_mask:0xf bank_mask:0xf", sc.f1);
+    SEG_STEP3("row_shr:2 row_mask:0xf bank_mask:0xf", sc.f2);
+    SEG_STEP3("row_shr:4 row_mask:0xf bank_mask:0xf", sc.f4);
+    SEG_STEP3("row_shr:8 row_mask:0xf bank_mask:0xf", sc.f8);
+    SEG_STEP3("row_bcast:15 row_mask:0xa bank_mask:0xf", sc.f15);
+    SEG_STEP3("row_bcast:31 row_mask:0xc bank_mask:0xf", sc.f31);
+}
 __device__ __forceinline__ float seg_scan(const SegScan& sc, float v) {
     v = fmaf(sc.f1, dpp_mov<0x111, 0xf>(v), v);          // row_shr:1
     v = fmaf(sc.f2, dpp_mov<0x112, 0xf>(v), v);          // row_shr:2
@@ -879,8 +894,8 @@ __device__ __forceinline__ void used_particle_g2p_grad(const SimP& S, const Fram
             if (TILE) {
                 const int l = lb + (i * TILE_T + j) * TILE_T + kk;
                 v0 = s_tile[l]; v1 = s_tile[TILE_N + l]; v2 = s_tile[2 * TILE_N + l];
-                float c0 = weight * q[0], c1 = weight * q[1], c2 = weight * q[2], c3 = 0.f;
-                seg_scan4(sc, c0, c1, c2, c3);
+                float c0 = weight * q[0], c1 = weight * q[1], c2 = weight * q[2];
+                seg_scan3(sc, c0, c1, c2);
                 if (issue) {
                     atomicAdd(&s_acc[l], (double)c0);                         // ds_add_f64
                     atomicAdd(&s_acc[TILE_N + l], (double)c1);
