@@ -180,7 +180,7 @@ def main():
         # HBM traffic of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs)
         traffic = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01p_pmc_traffic.json')))['kernels'][dom]
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01final_pmc_traffic.json')))['kernels'][dom]
             traffic = int(pmc['traffic_bytes'])      # (2*FETCH_SIZE + WRITE_SIZE) KiB: gfx950 FETCH_SIZE correction, see the file's note
         except Exception:
             pass
