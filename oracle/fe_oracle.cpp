@@ -1918,20 +1918,8 @@ int fe_eff_set_mesh(FeEngine* h, int e, const FeSdfDesc* d, const fe_real* voxel
     return 0;
 }
 int fe_add_static(FeEngine* h, const FeSdfDesc* d, const fe_real* voxels) {
-    if (!d || d->struct_size != (int)sizeof(FeSdfDesc) || d->res < 2 || !voxels) { h->err = "add_static: bad descriptor"; return -1; }
     Sdf s;
-    s.res = d->res; s.friction = d->friction; s.softness = d->softness;
-    s.vox.assign(voxels, voxels + (size_t)d->res * d->res * d->res);
-    for (int i = 0; i < 16; i++) s.T[i] = d->T_mesh_to_voxels[i];
-    M3 A;
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) A.m[i][j] = s.T[i * 4 + j];
-    const R det = A.m[0][0] * (A.m[1][1] * A.m[2][2] - A.m[1][2] * A.m[2][1]) - A.m[0][1] * (A.m[1][0] * A.m[2][2] - A.m[1][2] * A.m[2][0]) +
-                  A.m[0][2] * (A.m[1][0] * A.m[2][1] - A.m[1][1] * A.m[2][0]);
-    if (det == 0) { h->err = "add_static: singular T_mesh_to_voxels"; return -1; }
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {       /* inverse = adj / det */
-        const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
-        s.Rinv[j * 3 + i] = (A.m[i1][j1] * A.m[i2][j2] - A.m[i1][j2] * A.m[i2][j1]) / det;
-    }
+    if (make_sdf(h, d, voxels, s)) return -1;
     h->statics.push_back(std::move(s));
     return (int)h->statics.size() - 1;
 }
