@@ -1739,7 +1739,7 @@ __global__ __launch_bounds__(256) void k_loss_fwd(SimP S, float* fr, const int* 
         FrameV cur = frame_view(fr, S.Np);
         if (cur.used[s]) {
             const int pid = pid_of_slot[s];
-            if (load_info(pinfo, pid).mat == matching_mat) {
+            if (matching_mat < 0 || load_info(pinfo, pid).mat == matching_mat) {
                 float4 a0 = cur.A0[s];
                 float d0 = a0.x - tgt[pid * 3], d1 = a0.y - tgt[pid * 3 + 1], d2 = a0.z - tgt[pid * 3 + 2];
                 acc = d0 * d0 + d1 * d1 + d2 * d2;
@@ -1764,7 +1764,7 @@ __global__ __launch_bounds__(256) void k_loss_bwd(SimP S, float* fr, float* G_, 
     FrameV cur = frame_view(fr, S.Np);
     if (!cur.used[s]) return;
     const int pid = pid_of_slot[s];
-    if (load_info(pinfo, pid).mat != matching_mat) return;
+    if (matching_mat >= 0 && load_info(pinfo, pid).mat != matching_mat) return;
     FrameV G = frame_view(G_, S.Np);
     float4 a0 = cur.A0[s];
     float4 g0 = G.A0[s];

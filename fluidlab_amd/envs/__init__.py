@@ -4,9 +4,10 @@ from .latteart_env import LatteArtEnv
 from .waterblock_env import WaterBlockEnv
 from .circulation_env import CirculationEnv
 from .icecreamdynamic_env import IceCreamDynamicEnv
+from .latteartstir_env import LatteArtStirEnv
 
 REGISTRY = {'LatteArt-v0': LatteArtEnv, 'WaterBlock-v0': WaterBlockEnv, 'Circulation-v0': CirculationEnv,
-            'IceCreamDynamic-v0': IceCreamDynamicEnv}
+            'IceCreamDynamic-v0': IceCreamDynamicEnv, 'LatteArtStir-v0': LatteArtStirEnv}
 
 
 def make(env_name, **kwargs):

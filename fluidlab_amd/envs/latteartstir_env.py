@@ -1,0 +1,86 @@
+"""LatteArtStir-v0 (fluidlab/envs/latteartstir_env.py): a layer of viscous milk on viscous coffee, stirred by a Rigid rod.
+
+The reference records its target from an *interactive* demonstration (demo_policy raises without user input,
+latteartstir_env.py:118-121); here a scripted stir -- lower the rod, then draw a circle -- stands in.  The stirrer's collision
+mesh is analytic (fluidengine/meshes.py: sdf_stirrer)."""
+import os
+
+import numpy as np
+
+from fluidlab_amd.configs.macros import COFFEE_VIS, CUP, MILK_VIS
+from fluidlab_amd.fluidengine.losses import LatteArtStirLoss
+from fluidlab_amd.fluidengine.meshes import sdf_stirrer
+from fluidlab_amd.fluidengine.taichi_env import TaichiEnv
+from fluidlab_amd.optimizer.policies import ActionsPolicy, LatteArtStirPolicy
+from fluidlab_amd.utils.config import CfgNode
+from fluidlab_amd.utils.misc import get_cfg_path, get_tgt_path
+from .fluid_env import FluidEnv
+
+
+class LatteArtStirEnv(FluidEnv):
+    def __init__(self, version=0, loss=True, loss_type='diff', seed=None, renderer_type=None, quality=1, particle_density=1e6, horizon=500,
+                 max_substeps_local=50, ckpt_dest='disk', target=None, engine_lib=None, device=0):
+        if seed is not None:
+            self.seed(seed)
+        self.horizon = horizon
+        self.horizon_action = horizon
+        self.target_file = get_tgt_path('LatteArtStir-v0.pkl')
+        self._target = target
+        self._n_obs_ptcls_per_body = 1000
+        self.loss = loss
+        self.loss_type = loss_type
+        self.action_range = np.array([-0.01, 0.01])
+        self.taichi_env = TaichiEnv(dim=3, quality=quality, particle_density=particle_density, max_substeps_local=max_substeps_local,
+                                    gravity=(0.0, -20.0, 0.0), horizon=self.horizon, ckpt_dest=ckpt_dest, engine_lib=engine_lib, device=device)
+        self.build_env()
+        self.gym_misc()
+
+    def setup_agent(self):
+        agent_cfg = CfgNode()
+        agent_cfg.merge_from_file(get_cfg_path('agent_latteartstir.yaml'))
+        agent_cfg.effectors[0]['mesh']['sdf'] = sdf_stirrer()
+        agent_cfg.effectors[0]['mesh']['sdf_res'] = 64
+        self.taichi_env.setup_agent(agent_cfg)
+        self.agent = self.taichi_env.agent
+
+    def setup_statics(self):
+        self.taichi_env.add_static(file='cup.obj', pos=(0.63, 0.42, 0.5), euler=(0.0, 0.0, 0.0), scale=(1.2, 1.2, 1.2), material=CUP,
+                                   has_dynamics=False)
+
+    def setup_bodies(self):
+        self.taichi_env.add_body(type='cylinder', center=(0.5, 0.56, 0.5), height=0.02, radius=0.42, material=MILK_VIS)
+        self.taichi_env.add_body(type='cylinder', center=(0.5, 0.475, 0.5), height=0.15, radius=0.42, material=COFFEE_VIS)
+
+    def setup_boundary(self):
+        self.taichi_env.setup_boundary(type='cylinder', xz_radius=0.42, xz_center=(0.5, 0.5), y_range=(0.4, 0.95))
+
+    def setup_loss(self):
+        target = self._target if self._target is not None else (self.target_file if os.path.exists(self.target_file) else None)
+        self.taichi_env.setup_loss(loss_cls=LatteArtStirLoss, type=self.loss_type, target_file=target, weights={'chamfer': 1.0})
+
+    def demo_policy(self, user_input=False):
+        """scripted stand-in for the reference's interactive demonstration: start above the milk at (0.5, 0.73, 0.5), dip the rod
+        into the liquid during the first fifth of the horizon while moving out (to radius 0.15 at the full horizon), then stir one circle"""
+        if user_input:
+            raise NotImplementedError('interactive demonstrations need the renderer')
+        H = self.horizon_action
+        init_p = np.array([0.5, 0.73, 0.5])
+        cur = init_p.copy()
+        acts = np.zeros((H, self.agent.action_dim))
+        h0 = max(1, H // 5)
+        step = 0.8 * self.action_range[1]                      # stay inside the action range (0.01 per step) for any horizon
+        rad, dip = min(0.15, step * h0), min(0.12, step * h0)
+        rad = min(rad, step * (H - h0) / (2 * np.pi))          # ... also along the circle
+        for i in range(H):
+            if i < h0:
+                t = (i + 1) / h0
+                tgt = init_p + t * np.array([rad, -dip, 0.0])
+            else:
+                th = 2 * np.pi * (i - h0 + 1) / (H - h0)
+                tgt = np.array([0.5 + rad * np.cos(th), init_p[1] - dip, 0.5 + rad * np.sin(th)])
+            acts[i] = tgt - cur
+            cur += acts[i]
+        return ActionsPolicy(np.vstack([acts, init_p[None, :]]))
+
+    def trainable_policy(self, optim_cfg, init_range):
+        return LatteArtStirPolicy(optim_cfg, init_range, self.agent.action_dim, self.horizon_action, self.action_range, fix_dim=[1])

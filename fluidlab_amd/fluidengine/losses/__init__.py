@@ -3,3 +3,4 @@ from .shapematching_loss import ShapeMatchingLoss
 from .latteart_loss import LatteArtLoss
 from .circulation_loss import CirculationLoss
 from .icecreamdynamic_loss import IceCreamDynamicLoss
+from .latteartstir_loss import LatteArtStirLoss

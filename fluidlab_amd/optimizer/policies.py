@@ -59,6 +59,17 @@ class LatteArtPolicy(TrainablePolicy):
     pass
 
 
+class LatteArtStirPolicy(TrainablePolicy):
+    """policies.py:172-187"""
+
+    def optimize(self, grads, loss_info):
+        super().optimize(grads, loss_info)
+        if loss_info['temporal_range'] > 250:
+            self.optim.lr = self.optim.init_lr * 0.2
+        elif loss_info['temporal_range'] > 150:
+            self.optim.lr = self.optim.init_lr * 0.5
+
+
 class CirculationPolicy(TrainablePolicy):
     """policies.py:341-347"""
 

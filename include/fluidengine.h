@@ -215,7 +215,8 @@ int fe_smoke_reset_grad_till_frame(FeEngine* h, int s);              /* :168-171
 int fe_loss_alloc(FeEngine* h, int max_loss_steps);
 int fe_loss_set_target(FeEngine* h, int s, const fe_real* x);                     /* target['x'][s], [N,3] */
 int fe_loss_clear(FeEngine* h);                                                   /* loss.py:55-61 */
-/* chamfer_loss[s] += sum_p [used[f,p] && mat[p]==matching_mat] |x[f,p]-tgt_s[p]|^2 ;
+/* chamfer_loss[s] += sum_p [used[f,p] && mat[p]==matching_mat] |x[f,p]-tgt_s[p]|^2   (matching_mat < 0: every material,
+ * latteartstir_loss.py:62-68);
  * step_loss[s] += chamfer_loss[s] * weight   (shapematching_loss.py:80-88) */
 int fe_loss_step(FeEngine* h, int s, int f, int matching_mat, fe_real weight);
 /* x.grad[f,p] += 2 (x-tgt) * weight * step_loss_grad  (adjoint of the two kernels above) */

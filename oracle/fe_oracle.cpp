@@ -1946,7 +1946,7 @@ int fe_loss_step(FeEngine* h, int s, int f, int matching_mat, fe_real weight) {
     const R* t = &h->tgt[(size_t)s * h->N * 3];
     R acc = 0;
     for (int p = 0; p < h->N; p++) {
-        if (h->Us(f)[p] && h->mat[p] == matching_mat) {                                   /* shapematching_loss.py:83 */
+        if (h->Us(f)[p] && (matching_mat < 0 || h->mat[p] == matching_mat)) {              /* shapematching_loss.py:83; < 0: every material (latteartstir_loss.py:62-68) */
             R d0 = h->X(f)[p * 3] - t[p * 3], d1 = h->X(f)[p * 3 + 1] - t[p * 3 + 1], d2 = h->X(f)[p * 3 + 2] - t[p * 3 + 2];
             acc += d0 * d0 + d1 * d1 + d2 * d2;
         }
@@ -1961,7 +1961,7 @@ int fe_loss_step_grad(FeEngine* h, int s, int f, int matching_mat, fe_real weigh
     const R* t = &h->tgt[(size_t)s * h->N * 3];
     R g = weight * step_loss_grad;
     for (int p = 0; p < h->N; p++) {
-        if (h->Us(f)[p] && h->mat[p] == matching_mat)
+        if (h->Us(f)[p] && (matching_mat < 0 || h->mat[p] == matching_mat))
             for (int d = 0; d < 3; d++) h->GX(f)[p * 3 + d] += 2 * (h->X(f)[p * 3 + d] - t[p * 3 + d]) * g;
     }
     return 0;

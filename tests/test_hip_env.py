@@ -136,3 +136,25 @@ def test_icecream_dynamic_on_the_gpu(hiplib, oracle32):
     assert np.quantile(np.abs(xa[m] - xb[m]).max(1), 0.95) <= 1e-4     # plasto-elastic contact: a few particles sit on branch edges
     assert abs(la - lb) <= 5e-2 * abs(lb)
     assert S.cosine(ga, gb) >= 0.99
+
+
+def test_latteart_stir_on_the_gpu(hiplib, oracle32):
+    """LatteArtStir-v0 (viscous two-liquid bath, Rigid rod, match-all loss) at a reduced size, HIP vs oracle."""
+    import test_host_env as H
+    res = []
+    for lib in (None, oracle32):
+        env = H._stir(lib, loss=False, max_substeps_local=None)
+        tgt = Recorder(env).record(write=False)
+        env = H._stir(lib, target=tgt, max_substeps_local=None)
+        cfg = load_config('configs/exp_latteart_stir.yaml').SOLVER
+        pol = env.trainable_policy(cfg.optim, cfg.init_range)
+        demo = env.demo_policy()
+        pol.actions_v[:] = demo.actions_v; pol.actions_p[:] = demo.actions_p
+        pol.actions_v[8:, 2] += 0.001
+        env.taichi_env.loss.temporal_range[1] = env.horizon
+        info, g = Solver(env, None, cfg).forward_backward(env.taichi_env.get_state()['state'], pol, env.horizon, env.horizon_action)
+        res.append((tgt['x'][-1], info['loss'], info['loss_milk'], g))
+    (xa, la, ma, ga), (xb, lb, mb, gb) = res
+    assert np.quantile(np.abs(xa - xb).max(1), 0.99) <= 1e-4
+    assert abs(la - lb) <= 2e-2 * abs(lb) and abs(ma - mb) <= 2e-2 * abs(mb)
+    assert S.cosine(ga, gb) >= 0.99

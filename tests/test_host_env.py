@@ -298,3 +298,34 @@ def test_icecream_dynamic_env(oracle32):
     info, g = Solver(env, None, cfg).forward_backward(env.taichi_env.get_state()['state'], pol, env.horizon, env.horizon_action)
     assert info['loss'] > 1e-4 and g.shape == (161, 3) and np.isfinite(g).all() and np.abs(g[:160]).max() > 0
     assert pol.trainable[:30].sum() == 0 and pol.trainable[31:-1].all()   # the hold-still prefix of the demo stays frozen
+
+
+STIR_MINI = dict(quality=0.5, particle_density=6e4, horizon=20)
+
+
+def _stir(engine_lib, target=None, loss=True, **kw):
+    return make('LatteArtStir-v0', seed=0, loss=loss, target=target, engine_lib=engine_lib, **STIR_MINI, **kw)
+
+
+def test_latteart_stir_env(oracle32):
+    """LatteArtStir-v0 at a reduced size: viscous milk on viscous coffee (mu > 0 liquids: the SVD path), a Rigid rod with an SDF
+    mesh and softness 100, a loss over every used particle (matching_mat < 0 in the ABI) plus the milk-only figure."""
+    env = _stir(oracle32, loss=False, max_substeps_local=None)
+    x0 = env.taichi_env.simulator.get_x(0).copy()
+    tgt = Recorder(env).record(write=False)
+    mat = tgt['mat']
+    from fluidlab_amd.configs.macros import COFFEE_VIS, MILK_VIS
+    assert set(np.unique(mat)) == {MILK_VIS, COFFEE_VIS}
+    moved = np.linalg.norm(tgt['x'][-1] - x0, axis=1)
+    near = np.hypot(x0[:, 0] - 0.52, x0[:, 2] - 0.5) < 0.06
+    assert moved[near].mean() > 2 * np.median(moved)                     # the rod drags the liquid it passes through
+    env = _stir(oracle32, target=tgt, max_substeps_local=None)
+    cfg = load_config('configs/exp_latteart_stir.yaml').SOLVER
+    pol = env.trainable_policy(cfg.optim, cfg.init_range)
+    demo = env.demo_policy()
+    pol.actions_v[:] = demo.actions_v; pol.actions_p[:] = demo.actions_p
+    pol.actions_v[8:, 2] += 0.001
+    env.taichi_env.loss.temporal_range[1] = env.horizon
+    info, g = Solver(env, None, cfg).forward_backward(env.taichi_env.get_state()['state'], pol, env.horizon, env.horizon_action)
+    assert info['loss'] > info['loss_milk'] > 0                          # all particles vs the milk layer only
+    assert g.shape == (21, 3) and np.isfinite(g).all() and np.abs(g[:20, [0, 2]]).max() > 0
