@@ -5,9 +5,10 @@ from .waterblock_env import WaterBlockEnv
 from .circulation_env import CirculationEnv
 from .icecreamdynamic_env import IceCreamDynamicEnv
 from .latteartstir_env import LatteArtStirEnv
+from .icecreamstatic_env import IceCreamStaticEnv
 
 REGISTRY = {'LatteArt-v0': LatteArtEnv, 'WaterBlock-v0': WaterBlockEnv, 'Circulation-v0': CirculationEnv,
-            'IceCreamDynamic-v0': IceCreamDynamicEnv, 'LatteArtStir-v0': LatteArtStirEnv}
+            'IceCreamDynamic-v0': IceCreamDynamicEnv, 'LatteArtStir-v0': LatteArtStirEnv, 'IceCreamStatic-v0': IceCreamStaticEnv}
 
 
 def make(env_name, **kwargs):

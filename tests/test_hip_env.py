@@ -158,3 +158,26 @@ def test_latteart_stir_on_the_gpu(hiplib, oracle32):
     assert np.quantile(np.abs(xa - xb).max(1), 0.99) <= 1e-4
     assert abs(la - lb) <= 2e-2 * abs(lb) and abs(ma - mb) <= 2e-2 * abs(mb)
     assert S.cosine(ga, gb) >= 0.99
+
+
+def test_icecream_static_on_the_gpu(hiplib, oracle32):
+    """IceCreamStatic-v0 (controllable Injector over a static SDF cone) at a reduced size, HIP vs oracle."""
+    import test_host_env as H
+    res = []
+    for lib in (None, oracle32):
+        env = H._icecream_static(lib, loss=False, max_substeps_local=None)
+        tgt = Recorder(env).record(write=False)
+        env = H._icecream_static(lib, target=tgt, max_substeps_local=None)
+        cfg = load_config('configs/exp_icecream_static.yaml').SOLVER
+        pol = env.trainable_policy(cfg.optim, cfg.init_range)
+        demo = env.demo_policy()
+        pol.actions_v[:] = demo.actions_v; pol.actions_p[:] = demo.actions_p
+        pol.actions_v[5:, 0] += 0.0005
+        env.taichi_env.loss.temporal_range[1] = env.horizon
+        info, g = Solver(env, None, cfg).forward_backward(env.taichi_env.get_state()['state'], pol, env.horizon, env.horizon_action)
+        res.append((tgt['x'][-1], tgt['used'][-1], info['loss'], g))
+    (xa, ua, la, ga), (xb, ub, lb, gb) = res
+    assert (ua == ub).all()
+    m = ua > 0
+    assert np.quantile(np.abs(xa[m] - xb[m]).max(1), 0.95) <= 1e-4
+    assert abs(la - lb) <= 5e-2 * abs(lb) and S.cosine(ga, gb) >= 0.99

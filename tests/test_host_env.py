@@ -329,3 +329,29 @@ def test_latteart_stir_env(oracle32):
     info, g = Solver(env, None, cfg).forward_backward(env.taichi_env.get_state()['state'], pol, env.horizon, env.horizon_action)
     assert info['loss'] > info['loss_milk'] > 0                          # all particles vs the milk layer only
     assert g.shape == (21, 3) and np.isfinite(g).all() and np.abs(g[:20, [0, 2]]).max() > 0
+
+
+ICE_STATIC_MINI = dict(quality=0.5, n_pool=1300, horizon=22, horizon_action=20)
+
+
+def _icecream_static(engine_lib, target=None, loss=True, **kw):
+    return make('IceCreamStatic-v0', seed=0, loss=loss, target=target, engine_lib=engine_lib, **ICE_STATIC_MINI, **kw)
+
+
+def test_icecream_static_env(oracle32):
+    """IceCreamStatic-v0 at a reduced size: a controllable Injector (action gradient through injector.act and move_kernel)
+    above a static SDF cone that grid_op collides with."""
+    env = _icecream_static(oracle32, loss=False, max_substeps_local=None)
+    cone = env.taichi_env.statics[0]
+    assert cone.has_dynamics and cone.sdf([[0.5, 0.2, 0.5]])[0] < 0 < cone.sdf([[0.5, 0.5, 0.5]])[0]
+    tgt = Recorder(env).record(write=False)
+    assert tgt['used'][-1].sum() == 20 * 10 * 6                       # flux 6 per substep while actions last (horizon_action)
+    env = _icecream_static(oracle32, target=tgt, max_substeps_local=None)
+    cfg = load_config('configs/exp_icecream_static.yaml').SOLVER
+    pol = env.trainable_policy(cfg.optim, cfg.init_range)
+    demo = env.demo_policy()
+    pol.actions_v[:] = demo.actions_v; pol.actions_p[:] = demo.actions_p
+    pol.actions_v[5:, 0] += 0.0005
+    env.taichi_env.loss.temporal_range[1] = env.horizon
+    info, g = Solver(env, None, cfg).forward_backward(env.taichi_env.get_state()['state'], pol, env.horizon, env.horizon_action)
+    assert info['loss'] > 0 and g.shape == (21, 3) and np.isfinite(g).all() and np.abs(g).max() > 0
