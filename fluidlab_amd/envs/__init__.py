@@ -6,9 +6,11 @@ from .circulation_env import CirculationEnv
 from .icecreamdynamic_env import IceCreamDynamicEnv
 from .latteartstir_env import LatteArtStirEnv
 from .icecreamstatic_env import IceCreamStaticEnv
+from .gatheringeasy_env import GatheringEasyEnv
 
 REGISTRY = {'LatteArt-v0': LatteArtEnv, 'WaterBlock-v0': WaterBlockEnv, 'Circulation-v0': CirculationEnv,
-            'IceCreamDynamic-v0': IceCreamDynamicEnv, 'LatteArtStir-v0': LatteArtStirEnv, 'IceCreamStatic-v0': IceCreamStaticEnv}
+            'IceCreamDynamic-v0': IceCreamDynamicEnv, 'LatteArtStir-v0': LatteArtStirEnv, 'IceCreamStatic-v0': IceCreamStaticEnv,
+            'GatheringEasy-v0': GatheringEasyEnv}
 
 
 def make(env_name, **kwargs):

@@ -32,6 +32,7 @@ class Agent:
         self.n_effectors = len(self.effectors)
         self.sim = sim
         for effector in self.effectors:
+            effector.sim = sim
             effector.build(sim.engine)
 
     def reset_grad(self):

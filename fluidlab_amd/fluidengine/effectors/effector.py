@@ -12,6 +12,14 @@ from fluidlab_amd.configs.macros import DTYPE_NP
 from fluidlab_amd.utils.misc import eval_str
 
 
+class _Field1:
+    def __init__(self, a):
+        self._a = a
+
+    def to_numpy(self):
+        return self._a
+
+
 class Effector:
     state_dim = 7
     abi_type = _capi.FE_EFF_PLAIN
@@ -53,6 +61,13 @@ class Effector:
     @property
     def init_state(self):
         return np.append(self.init_pos, self.init_rot)
+
+    @property
+    def latest_pos(self):
+        """effector.py:149-151 keeps pos[f] of the last move() in a 1-element field for the renderer; GatheringPolicy reads it
+        (policies.py:240).  Served from the engine: the pose at the simulator's current local substep."""
+        pos = self.engine.eff_get_state(self.index, self.sim.cur_substep_local)[:3]
+        return _Field1(np.asarray(pos, np.float32)[None, :])
 
     # ---- state (effector.py:185-208)
     def get_state(self, f):

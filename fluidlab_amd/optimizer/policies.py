@@ -59,6 +59,47 @@ class LatteArtPolicy(TrainablePolicy):
     pass
 
 
+class GatheringPolicy(TrainablePolicy):
+    """policies.py:218-259: a repeating sweep of 120 steps -- 50 trainable steps pushing, 15 up, 40 back to the start, 15 down."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.trainable = np.full(self.comp_actions_shape[0], False)
+        self.status = np.full(self.comp_actions_shape[0], 0)
+        self.stage_step = [50, 65, 105, 120]
+        for i in range(self.horizon):
+            r = i % self.stage_step[3]
+            if r < self.stage_step[0]:
+                self.trainable[i] = True
+                self.status[i] = 0          # moving
+            elif r < self.stage_step[1]:
+                self.status[i] = 1          # up
+            elif r < self.stage_step[2]:
+                self.status[i] = 2          # moving back
+            else:
+                self.status[i] = 3          # down
+
+    def get_action_v(self, i, agent=None, update=False):
+        if update:
+            if self.status[i] == 1:
+                self.actions_v[i] = np.array([0, 0.008, 0])
+            elif self.status[i] == 2:
+                action = (self.actions_p - agent.rigid.latest_pos.to_numpy()[0]) / (self.stage_step[2] - (i % self.stage_step[3]))
+                action[1] = 0
+                self.actions_v[i] = action
+            elif self.status[i] == 3:
+                self.actions_v[i] = np.array([0, -0.008, 0])
+        return self.actions_v[i]
+
+    def optimize(self, grads, loss_info):
+        for step in [720, 600, 480, 360, 240, 120]:
+            if loss_info['temporal_range'] > step:
+                self.freeze_till = loss_info['temporal_range'] - 120
+                self.trainable[:self.freeze_till] = False
+                break
+        super().optimize(grads, loss_info)
+
+
 class LatteArtStirPolicy(TrainablePolicy):
     """policies.py:172-187"""
 

@@ -355,3 +355,37 @@ def test_icecream_static_env(oracle32):
     env.taichi_env.loss.temporal_range[1] = env.horizon
     info, g = Solver(env, None, cfg).forward_backward(env.taichi_env.get_state()['state'], pol, env.horizon, env.horizon_action)
     assert info['loss'] > 0 and g.shape == (21, 3) and np.isfinite(g).all() and np.abs(g).max() > 0
+
+
+def _gathering(engine_lib, **kw):
+    return make('GatheringEasy-v0', seed=0, loss=True, engine_lib=engine_lib, quality=0.5, particle_density=3e4, horizon=12,
+                max_substeps_local=None, **kw)
+
+
+def test_gathering_easy_env(oracle32):
+    """GatheringEasy-v0 at a reduced size: MAT_RIGID bodies floating in water, pushed by a Rigid plate (soft SDF contact), L1 loss on
+    the bodies' x; the gradient w.r.t. the plate's actions comes back through contact, shape matching and the water."""
+    env = _gathering(oracle32)
+    te = env.taichi_env
+    assert te.simulator.n_bodies == 3
+    cfg = load_config('configs/exp_gathering_easy.yaml').SOLVER
+    pol = env.trainable_policy(cfg.optim, cfg.init_range)
+    assert pol.trainable[:12].all() and pol.status[:12].max() == 0              # the first 50 steps of a sweep are the trainable push
+    pol.actions_v[:, 0] = 0.003
+    pol.actions_p[:] = [0.46, 0.42, 0.5]                                       # start just left of the bodies... inside the plate's boundary box
+    te.loss.temporal_range[1] = env.horizon
+    x0 = te.simulator.get_x(0).copy()
+    info, g = Solver(env, None, cfg).forward_backward(te.get_state()['state'], pol, env.horizon, env.horizon_action)
+    mat = te.simulator.particles_i.mat.to_numpy()
+    from fluidlab_amd.configs.macros import RIGID
+    x1 = te.get_state()['state']['x']
+    assert np.isfinite(x1).all() and info['loss'] > 0
+    assert g.shape == (13, 3) and np.isfinite(g).all()
+    assert np.abs(g[:12, 0]).max() > 0
+    # each body is still rigid
+    bid = np.asarray(te.particles['body_id'])
+    for b in (1, 2):
+        sel = bid == b
+        d0 = np.linalg.norm(x0[sel][:, None] - x0[sel][None], axis=2)
+        d1 = np.linalg.norm(x1[sel][:, None] - x1[sel][None], axis=2)
+        assert np.abs(d1 - d0).max() < 5e-5
