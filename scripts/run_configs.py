@@ -21,6 +21,27 @@ from fluidlab_amd.utils.config import load_config
 out = {}
 which = sys.argv[1:2] or ['3', '5']
 
+if '1' in which:
+    # LatteArt-v0 exactly as the reference ships it (BASELINE configs[0]'s scene): 64^3, 115,480 particles, horizon 330/250,
+    # 50-substep window with *disk* checkpoints (latteart_env.py:31, taichi_env.py:31), 3 Solver iterations
+    t0 = time.time()
+    env = make('LatteArt-v0', seed=0, loss=False, max_substeps_local=50, ckpt_dest='disk')
+    tgt = Recorder(env).record(write=False)
+    t_rec = time.time() - t0
+    n = env.taichi_env.n_particles
+    del env
+    res = {}
+    for mode, kw in (('window50_disk', dict(max_substeps_local=50, ckpt_dest='disk')), ('resident', dict(max_substeps_local=None))):
+        env = make('LatteArt-v0', seed=0, loss=True, target=tgt, **kw)
+        cfg = load_config('configs/exp_latteart.yaml').SOLVER
+        cfg.n_iters = 3
+        infos = []
+        Solver(env, None, cfg).solve(callback=lambda it, info, pol: infos.append(dict(loss=info['loss'], fwd=info['forward_s'], bwd=info['backward_s'])))
+        res[mode] = dict(iters=infos, fwd_substeps_per_s=round(3300 / infos[-1]['fwd'], 1), pairs_per_s=round(3300 / (infos[-1]['fwd'] + infos[-1]['bwd']), 1))
+        del env
+    out['config1_latteart_v0_as_shipped'] = dict(n_particles=int(n), record_s=round(t_rec, 2), **res)
+    print(json.dumps(out['config1_latteart_v0_as_shipped']))
+
 if '3' in which:
     # 128^3 with ~2 particles per cell (the reference scene has 3.8 at 64^3; SURVEY's 0.8/cell goes NaN: J < 0, mpm:359)
     kw = dict(quality=2, particle_density=float(sys.argv[2]) if len(sys.argv) > 2 else 4e6, n_pool=60000)
@@ -87,4 +108,4 @@ if '5' in which:
                                       kernels_us={k: round(1e3 * v[0] / v[1], 1) for k, v in prof.items() if v[1]})
         print(json.dumps(out['config5_' + name]))
         eng.close()
-json.dump(out, open('gpurun_out/configs_3_5.json', 'w'), indent=1)
+json.dump(out, open('gpurun_out/configs_' + '_'.join(which) + '.json', 'w'), indent=1)
