@@ -63,7 +63,7 @@ class FeStats(C.Structure):
 ABI_SYMBOLS = [
     'fe_create', 'fe_destroy', 'fe_last_error', 'fe_backend', 'fe_real_size', 'fe_sync',
     'fe_set_option', 'fe_init_particles', 'fe_substep', 'fe_substep_grad', 'fe_step',
-    'fe_step_grad', 'fe_get_frame', 'fe_set_frame', 'fe_copy_frame', 'fe_copy_grad',
+    'fe_step_grad', 'fe_get_frame', 'fe_set_frame', 'fe_get_frame_dev', 'fe_set_frame_dev', 'fe_copy_frame', 'fe_copy_grad',
     'fe_reset_grad', 'fe_reset_grad_till_frame', 'fe_get_grad', 'fe_add_grad', 'fe_get_mat',
     'fe_add_static', 'fe_eff_set_mesh', 'fe_add_effector', 'fe_eff_set_act_range', 'fe_eff_get_state', 'fe_eff_set_state',
     'fe_eff_get_vw', 'fe_eff_set_vw', 'fe_eff_get_sr', 'fe_eff_set_sr', 'fe_eff_set_action', 'fe_eff_set_action_grad',
@@ -83,6 +83,14 @@ class EngineLib:
         if not os.path.exists(path):
             raise FeEngineError(f'FluidEngine library not found: {path}')
         self.path = path
+        if os.path.basename(path).endswith('_hip.so'):
+            # torch wheels bundle their own libamdhip64; whichever HIP runtime is mapped first serves the whole process,
+            # and torch sees no GPU when /opt/rocm's was mapped first.  The host layer shares device memory with torch
+            # (ckpt_dest='gpu', the action-gradient all-reduce), so let torch map its runtime before the engine binds it.
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         self.lib = C.CDLL(path)
         lib = self.lib
         lib.fe_real_size.restype = C.c_int
@@ -276,6 +284,17 @@ class Engine:
         self._ck(self.lib.fe_get_grad(self.h, int(f), gx.ctypes.data_as(C.c_void_p), gv.ctypes.data_as(C.c_void_p),
                                       gC.ctypes.data_as(C.c_void_p), gF.ctypes.data_as(C.c_void_p)))
         return gx, gv, gC, gF
+
+    # ---- state that stays on the device: torch tensors on the engine's GPU (the reference's readframe/setframe accept them)
+    @staticmethod
+    def _tptr(t):
+        return None if t is None else C.c_void_p(t.data_ptr())
+
+    def get_frame_dev(self, f, x=None, v=None, C_=None, F=None, used=None):
+        self._ck(self.lib.fe_get_frame_dev(self.h, int(f), self._tptr(x), self._tptr(v), self._tptr(C_), self._tptr(F), self._tptr(used)))
+
+    def set_frame_dev(self, f, x=None, v=None, C_=None, F=None, used=None):
+        self._ck(self.lib.fe_set_frame_dev(self.h, int(f), self._tptr(x), self._tptr(v), self._tptr(C_), self._tptr(F), self._tptr(used)))
 
     def add_grad(self, f, gx=None, gv=None, gC=None, gF=None):
         N = self.N

@@ -2457,6 +2457,25 @@ int fe_set_frame(FeEngine* h, int f, const fe_real* x, const fe_real* v, const f
     if (h->gs_cap > 0) HIPCK(h, hipMemsetAsync(h->gs_flag + f, 0, sizeof(int), h->stream));     // the stored grid of this frame is stale now
     return upload_planes(h, h->frame(f), h->pid_of(f), x, v, C, F, used, 0);
 }
+// device-pointer variants: k_unpack / k_pack work straight on the caller's device arrays, nothing crosses PCIe
+int fe_get_frame_dev(FeEngine* h, int f, fe_real* x, fe_real* v, fe_real* C, fe_real* F, int* used) {
+    CHECK_FRAME(h, f);
+    const int mask = (x ? 1 : 0) | (v ? 2 : 0) | (C ? 4 : 0) | (F ? 8 : 0) | (used ? 16 : 0);
+    if (!mask || h->N == 0) return 0;
+    hipLaunchKernelGGL(k_unpack, pgrid(h), dim3(256), 0, h->stream, h->N, (size_t)h->Np, h->frame(f), h->pid_of(f), x, v, C, F, used, mask);
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    return check_device_errors(h);
+}
+int fe_set_frame_dev(FeEngine* h, int f, const fe_real* x, const fe_real* v, const fe_real* C, const fe_real* F, const int* used) {
+    CHECK_FRAME(h, f);
+    h->gs_host_valid = false;
+    if (h->gs_cap > 0) HIPCK(h, hipMemsetAsync(h->gs_flag + f, 0, sizeof(int), h->stream));
+    const int mask = (x ? 1 : 0) | (v ? 2 : 0) | (C ? 4 : 0) | (F ? 8 : 0) | (used ? 16 : 0);
+    if (!mask || h->N == 0) return 0;
+    hipLaunchKernelGGL(k_pack, pgrid(h), dim3(256), 0, h->stream, h->N, (size_t)h->Np, h->frame(f), h->pid_of(f), x, v, C, F, used, mask, 0);
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    return check_async(h);
+}
 int fe_copy_frame(FeEngine* h, int src, int dst) {
     CHECK_FRAME(h, src); CHECK_FRAME(h, dst);
     if (src == dst) return 0;

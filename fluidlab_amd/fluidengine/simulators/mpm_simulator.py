@@ -36,6 +36,10 @@ class _Namespace:
     pass
 
 
+def _is_cuda_tensor(a):
+    return hasattr(a, 'data_ptr') and getattr(a, 'is_cuda', False)
+
+
 class MPMSimulator:
     def __init__(self, dim, quality, gravity, horizon, max_substeps_local, max_substeps_global, ckpt_dest,
                  engine_lib=None, device=0):
@@ -231,6 +235,16 @@ class MPMSimulator:
                 if self.ckpt_dest == 'disk':
                     self.readframe(0, self.x_np, self.v_np, self.C_np, self.F_np, self.used_np)
                     ckpt.update(x=self.x_np, v=self.v_np, C=self.C_np, F=self.F_np, used=self.used_np)
+                elif self.ckpt_dest == 'gpu' and self.engine.elib.backend.startswith('hip'):
+                    # mpm:805-829: the checkpoint stays in HBM as torch tensors on the engine's device
+                    import torch
+                    dev = torch.device('cuda', self._device)
+                    N = self.n_particles
+                    st = dict(x=torch.zeros((N, 3), dtype=torch.float32, device=dev), v=torch.zeros((N, 3), dtype=torch.float32, device=dev),
+                              C=torch.zeros((N, 3, 3), dtype=torch.float32, device=dev), F=torch.zeros((N, 3, 3), dtype=torch.float32, device=dev),
+                              used=torch.zeros((N,), dtype=torch.int32, device=dev))
+                    self.readframe(0, st['x'], st['v'], st['C'], st['F'], st['used'])
+                    ckpt.update(st)
                 else:
                     st = self._frame_arrays()
                     self.readframe(0, st['x'], st['v'], st['C'], st['F'], st['used'])
@@ -303,10 +317,18 @@ class MPMSimulator:
                     F=np.zeros((N, 3, 3), self.dtype), used=np.zeros((N,), np.int32))
 
     def readframe(self, f, x, v, C, F, used):
-        self.engine.get_frame(f, x, v, C, F, used)
+        """mpm:555-564.  Like the reference's, accepts NumPy arrays or torch tensors; tensors living on the engine's GPU are
+        filled in place by the engine without crossing PCIe."""
+        if _is_cuda_tensor(x):
+            self.engine.get_frame_dev(f, x, v, C, F, used)
+        else:
+            self.engine.get_frame(f, x, v, C, F, used)
 
     def setframe(self, f, x, v, C, F, used):
-        self.engine.set_frame(f, x, v, C, F, used)
+        if _is_cuda_tensor(x):
+            self.engine.set_frame_dev(f, x, v, C, F, used)
+        else:
+            self.engine.set_frame(f, x, v, C, F, used)
 
     def set_x(self, f, x):
         self.engine.set_frame(f, x=x)

@@ -123,6 +123,12 @@ int fe_step_grad(FeEngine* h, int f0, int f_global0, int n, int act);
 int fe_get_frame(FeEngine* h, int f, fe_real* x, fe_real* v, fe_real* C, fe_real* F, int* used);
 int fe_set_frame(FeEngine* h, int f, const fe_real* x, const fe_real* v, const fe_real* C,
                  const fe_real* F, const int* used);
+/* The same with DEVICE pointers (memory of the engine's own device): the state never leaves the GPU.  The reference's
+ * readframe/setframe fill torch CUDA tensors in place for ckpt_dest='gpu' (mpm:805-829, 895-897); for the CPU oracle a
+ * "device" pointer is a host pointer. */
+int fe_get_frame_dev(FeEngine* h, int f, fe_real* x, fe_real* v, fe_real* C, fe_real* F, int* used);
+int fe_set_frame_dev(FeEngine* h, int f, const fe_real* x, const fe_real* v, const fe_real* C,
+                     const fe_real* F, const int* used);
 int fe_copy_frame(FeEngine* h, int src, int dst);           /* mpm:588-595 */
 int fe_copy_grad(FeEngine* h, int src, int dst);            /* mpm:597-604 */
 int fe_reset_grad(FeEngine* h);                             /* mpm:203-205 (+ effectors, effector.py:76-82) */

@@ -1599,6 +1599,10 @@ int fe_set_frame(FeEngine* h, int f, const fe_real* x, const fe_real* v, const f
     if (used) std::memcpy(h->Us(f), used, sizeof(int) * N);
     return 0;
 }
+int fe_get_frame_dev(FeEngine* h, int f, fe_real* x, fe_real* v, fe_real* C, fe_real* F, int* used) { return fe_get_frame(h, f, x, v, C, F, used); }
+int fe_set_frame_dev(FeEngine* h, int f, const fe_real* x, const fe_real* v, const fe_real* C, const fe_real* F, const int* used) {
+    return fe_set_frame(h, f, x, v, C, F, used);
+}
 int fe_copy_frame(FeEngine* h, int src, int dst) {
     CHECK_FRAME(h, src); CHECK_FRAME(h, dst);
     return fe_set_frame(h, dst, h->X(src), h->Vv(src), h->Cc(src), h->Ff(src), h->Us(src));

@@ -43,8 +43,13 @@ def test_latteart_env_on_hip_matches_oracle(hiplib, oracle64, monkeypatch):
     assert S.rel_l2(tgt_gpu['x'][-1][tgt['used'][-1] == 1], tgt['x'][-1][tgt['used'][-1] == 1]) <= 1e-5
     tgt32 = dict(tgt, x=[np.asarray(t, np.float32) for t in tgt['x']])
     loss_o, g_o, _ = _fwd_bwd(oracle64, tgt)
-    for kw in (dict(max_substeps_local=None), dict(max_substeps_local=20, ckpt_dest='cpu'), dict(max_substeps_local=40, ckpt_dest='disk')):
+    # 'gpu': chunk checkpoints kept in HBM as torch tensors, filled through fe_get_frame_dev / fe_set_frame_dev
+    for kw in (dict(max_substeps_local=None), dict(max_substeps_local=20, ckpt_dest='cpu'), dict(max_substeps_local=40, ckpt_dest='disk'),
+               dict(max_substeps_local=20, ckpt_dest='gpu')):
         loss_g, g_g, env = _fwd_bwd(hiplib, tgt32, **kw)
+        if kw.get('ckpt_dest') == 'gpu':
+            ck = next(iter(env.taichi_env.simulator.ckpt_ram.values()))
+            assert ck['x'].is_cuda and ck['used'].is_cuda
         assert env.taichi_env.simulator.engine.elib.backend == 'hip-gfx950'
         assert abs(loss_g - loss_o) <= 1e-4 * abs(loss_o), kw
         # measured ~8e-7; a 1e-2 bound once let a 1% error of a stale-grid bug through

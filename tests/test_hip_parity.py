@@ -221,6 +221,36 @@ def test_roundtrip_and_frame_ops(hiplib):
         eng.substep(4, 4, 0)
 
 
+def test_device_pointer_frame_io(hiplib):
+    """fe_get_frame_dev / fe_set_frame_dev (readframe/setframe with ckpt_dest='gpu', mpm:555-587): the state moves between
+    frames and caller-owned HBM arrays bit-exactly, in particle-id order, also after the engine has sorted its own storage."""
+    import torch
+    sc = S.mixed_materials(n_particles=777)
+    eng = S.make_engine(hiplib, sc, max_substeps_local=8)
+    S.run_forward(eng, 5)
+    host = S.get_state(eng, 5)
+    N = sc['N']
+    dev = torch.device('cuda', 0)
+    d = dict(x=torch.full((N, 3), -7.0, device=dev), v=torch.zeros((N, 3), device=dev), C_=torch.zeros((N, 3, 3), device=dev),
+             F=torch.zeros((N, 3, 3), device=dev), used=torch.full((N,), -1, dtype=torch.int32, device=dev))
+    eng.get_frame_dev(5, **d)
+    torch.cuda.synchronize()
+    for k, hk in (('x', 'x'), ('v', 'v'), ('C_', 'C'), ('F', 'F'), ('used', 'used')):
+        assert (d[k].cpu().numpy() == host[hk]).all(), k
+    eng.set_frame_dev(0, **d)
+    st0 = S.get_state(eng, 0)
+    assert all((st0[k] == host[k]).all() for k in host)
+    a = S.run_forward(eng, 3)                    # stepping on from the device-restored frame == stepping on from the host-restored one
+    eng.set_frame(0, host['x'], host['v'], host['C'], host['F'], host['used'])
+    b = S.run_forward(eng, 3)
+    # (the two runs re-sort from different in-cell orders, so sums round differently: tolerance, not bit equality)
+    for k in a:
+        err = np.abs(a[k].astype(np.float64) - b[k]).max()
+        assert err <= 2e-6 * (1.0 + np.abs(b[k]).max()), (k, err)
+    eng.get_frame_dev(3, x=d['x'])               # partial reads leave the other arrays alone
+    assert (d['x'].cpu().numpy() == b['x']).all() and (d['v'].cpu().numpy() == host['v']).all()
+
+
 def test_empty_and_all_unused(hiplib):
     sc = S.water_block(n_grid=8, n_particles=64)
     sc['used'] = np.zeros(64, np.int32)
