@@ -68,7 +68,7 @@ ABI_SYMBOLS = [
     'fe_add_static', 'fe_eff_set_mesh', 'fe_add_effector', 'fe_eff_set_act_range', 'fe_eff_get_state', 'fe_eff_set_state',
     'fe_eff_get_vw', 'fe_eff_set_vw', 'fe_eff_get_sr', 'fe_eff_set_sr', 'fe_eff_set_action', 'fe_eff_set_action_grad',
     'fe_eff_apply_action_p', 'fe_eff_apply_action_p_grad', 'fe_eff_get_action_grad',
-    'fe_agent_copy_frame', 'fe_agent_copy_grad', 'fe_agent_reset_grad_till_frame', 'fe_loss_alloc', 'fe_loss_set_target',
+    'fe_agent_copy_frame', 'fe_agent_copy_grad', 'fe_agent_reset_grad_till_frame', 'fe_agent_set_collector', 'fe_loss_alloc', 'fe_loss_set_target',
     'fe_loss_clear', 'fe_loss_step', 'fe_loss_step_grad', 'fe_loss_get', 'fe_get_stats',
     'fe_smoke_create', 'fe_smoke_step', 'fe_smoke_step_grad', 'fe_smoke_get_frame', 'fe_smoke_set_frame', 'fe_smoke_get_grad',
     'fe_smoke_add_grad', 'fe_smoke_copy_frame', 'fe_smoke_copy_grad', 'fe_smoke_reset_grad', 'fe_smoke_reset_grad_till_frame',
@@ -474,6 +474,10 @@ class Engine:
 
     def agent_reset_grad_till_frame(self, f):
         self._ck(self.lib.fe_agent_reset_grad_till_frame(self.h, int(f)))
+
+    def agent_set_collector(self, boundary=None, mat=-1):
+        """collector_act_kernel (agent_pouring.py:30-41 every material, agent_jetbot.py:33-43 one material)."""
+        self._ck(self.lib.fe_agent_set_collector(self.h, C.byref(boundary) if boundary is not None else None, int(mat)))
 
     # ---- loss
     def loss_alloc(self, max_loss_steps):

@@ -93,7 +93,7 @@ struct EffP {
     float* random_vector;                                    // [random_length, flux, 3]
     int has_mesh; SdfP mesh;                                 // Rigid.setup_mesh (rigid.py:19-24): a moving SDF collider
 };
-struct AgentP { int n; int inj; const EffP* e; float collide_min_y; };       // effector parameter blocks live in device memory (1 KiB as kernarg spilled SGPRs)
+struct AgentP { int n; int inj; const EffP* e; float collide_min_y; const BoundaryP* collector; int collector_mat; };       // effector parameter blocks live in device memory (1 KiB as kernarg spilled SGPRs)
 struct InjectP { int on, act_id, row, flux; };                     // per-substep injection parameters (host-known)
 
 struct PInfo { float mu, lam, mass; int cls, mat; };
@@ -310,6 +310,22 @@ __device__ __forceinline__ void unused_particle_fwd(const SimP& S, const FrameV&
     nxt.used[s] = used_next;
 }
 
+// collector_act_kernel (agent_pouring.py:30-41, agent_jetbot.py:33-43) for one used slot: outside the collector boundary the
+// particle is marked unused in frames f and f+1 and parked at NOWHERE in f+1 (v, C, F carried over, where the reference
+// leaves f+1 stale).  Returns true when the particle was taken; the backward pass then finds used[f] == 0.
+__device__ __forceinline__ bool collector_takes(const FrameV& cur, const FrameV& nxt, int s, int pid, const float4* __restrict__ pinfo, const AgentP& agent) {
+    if (agent.collector_mat >= 0 && load_info(pinfo, pid).mat != agent.collector_mat) return false;
+    PState p;
+    load_xvC(cur, s, p);
+    if (!boundary_is_out(*agent.collector, p.x)) return false;
+    load_F(cur, s, p.F);
+    const float nowhere[3] = {-100.f, -100.f, -100.f};                    // macros.py:216
+    store_xvC(nxt, s, nowhere, p.v, p.C);
+    store_F(nxt, s, p.F);
+    cur.used[s] = 0; nxt.used[s] = 0;
+    return true;
+}
+
 // what a used particle contributes to its 27 nodes (mpm:339-353): momentum at the stencil base + affine increments
 struct P2GPrep { Stencil st; float mv[3]; m3 affine; float m; bool inside; };
 
@@ -431,8 +447,10 @@ __global__ __launch_bounds__(WG) void k_p2g(SimP S, float* fr_cur, float* fr_nex
                 const int i = i0 + tid, s = it.y + i;
                 const bool has = i < it.z;
                 // (`used` is re-read rather than implied by the work list so host edits of a frame cannot desynchronise it)
-                const bool used = has && cur.used[s] != 0;
+                bool used = has && cur.used[s] != 0;
                 const int pid = has ? T.pid_of_slot[s] : 0;
+                bool taken = false;
+                if (WRITE && used && act && agent.collector) { taken = collector_takes(cur, nxt, s, pid, pinfo, agent); used = !taken; }
                 P2GPrep q;
                 q.inside = false;
                 int lb = -1;
@@ -449,7 +467,7 @@ __global__ __launch_bounds__(WG) void k_p2g(SimP S, float* fr_cur, float* fr_nex
                 // the 27-node scan altogether; the branch is wave-uniform, as the DPP scan requires
                 if (__any(in_tile)) p2g_scatter_tile(S, q, in_tile, in_tile ? lb : 0);
                 if (used && q.inside && !in_tile) { atomicAdd(G.slow, 1); p2g_scatter_global(S, q, G); }   // drifted out of the tile
-                if (has && !used && WRITE) unused_particle_fwd(S, cur, nxt, s, pid, pool_idx, agent, inj, f);
+                if (has && !used && !taken && WRITE) unused_particle_fwd(S, cur, nxt, s, pid, pool_idx, agent, inj, f);
             }
             __syncthreads();
             TS(3);
@@ -464,6 +482,7 @@ __global__ __launch_bounds__(WG) void k_p2g(SimP S, float* fr_cur, float* fr_nex
             if (s < S.N) {
                 const int pid = T.pid_of_slot[s];
                 if (cur.used[s]) {
+                    if (WRITE && act && agent.collector && collector_takes(cur, nxt, s, pid, pinfo, agent)) continue;
                     P2GPrep q;
                     p2g_prepare<WRITE, GENERAL>(S, cur, nxt, s, pid, pinfo, G, q);
                     if (q.inside) p2g_scatter_global(S, q, G);
@@ -473,14 +492,119 @@ __global__ __launch_bounds__(WG) void k_p2g(SimP S, float* fr_cur, float* fr_nex
     }
 }
 
+// agent.collide at particle level (mpm:418-422; AgentRigid.collide): every effector that carries a mesh, in order,
+// x_tmp = x + dt * new_v re-formed before each collider.  NODE: the same chain at a grid node (mpm:393-395,
+// Agent.collide_type 'grid' / 'both'), where the position is the node's and does not move with the velocity.
+template <bool NODE>
+__device__ __forceinline__ void agent_collide_particle(const SimP& S, const AgentP& agent, int f, const float x[3], float nv[3]) {
+    const float sdt = NODE ? 0.f : S.dt;
+    for (int ei = 0; ei < agent.n; ei++) {
+        const EffP& e = agent.e[ei];
+        if (!e.has_mesh) continue;
+        const float pos[3] = {x[0] + sdt * nv[0], x[1] + sdt * nv[1], x[2] + sdt * nv[2]};
+        if (!(pos[1] > agent.collide_min_y)) continue;                           // agent_icecreamdynamic.py:39-43
+        float out[3];
+        t_dynamic_collide<float>(e.mesh, e.pos + f * 3, e.quat + f * 4, e.pos + (f + 1) * 3, e.quat + (f + 1) * 4, pos, nv, S.dt, out);
+        nv[0] = out[0]; nv[1] = out[1]; nv[2] = out[2];
+    }
+}
+// Its adjoint.  g = d/d(new_v after the colliders) on entry, d/d(new_v before them) on exit; gx receives the part that
+// flows into x[f]; the effector pose adjoints (pos, quat at f and f+1) are accumulated in LDS (s_pose).  One Jacobian
+// column per forward-mode pass; a particle that is not in contact leaves after the first pass.
+template <bool NODE>
+__device__ void agent_collide_particle_grad(const SimP& S, const AgentP& agent, int f, const float x[3], const float nv0[3],
+                                            float g[3], float gx[3]) {
+    const float sdt = NODE ? 0.f : S.dt;
+    float vin[FE_MAX_EFF][3];
+    float nv[3] = {nv0[0], nv0[1], nv0[2]};
+#pragma unroll
+    for (int ei = 0; ei < FE_MAX_EFF; ei++) {
+        if (ei < agent.n && agent.e[ei].has_mesh) {
+            const EffP& e = agent.e[ei];
+            vin[ei][0] = nv[0]; vin[ei][1] = nv[1]; vin[ei][2] = nv[2];
+            const float pos[3] = {x[0] + sdt * nv[0], x[1] + sdt * nv[1], x[2] + sdt * nv[2]};
+            if (pos[1] > agent.collide_min_y) {
+                float out[3];
+                t_dynamic_collide<float>(e.mesh, e.pos + f * 3, e.quat + f * 4, e.pos + (f + 1) * 3, e.quat + (f + 1) * 4, pos, nv, S.dt, out);
+                nv[0] = out[0]; nv[1] = out[1]; nv[2] = out[2];
+            }
+        }
+    }
+#pragma unroll
+    for (int ei = FE_MAX_EFF - 1; ei >= 0; ei--) {
+        if (!(ei < agent.n && agent.e[ei].has_mesh)) continue;
+        const EffP& e = agent.e[ei];
+        const float v[3] = {vin[ei][0], vin[ei][1], vin[ei][2]};
+        if (!(x[1] + sdt * v[1] > agent.collide_min_y)) continue;
+        // out = cv + vt(rel, n) infl + rel (1 - infl), rel = mv - cv, cv = (R(q1) pm + p1 - pos) / dt: the inputs that enter only
+        // through cv (p1, q1 and the explicit -pos) have the closed-form Jacobian (I - d out/d mv) d cv/d input, so only ten
+        // forward-mode passes are needed -- mv (3), p0 (3: it enters through pm only, like the pm-part of pos), q0 (4).
+        float c[3] = {0.f, 0.f, 0.f}, a[3] = {0.f, 0.f, 0.f}, gq0[4] = {0.f, 0.f, 0.f, 0.f};
+        bool hit = true;
+#pragma unroll 1
+        for (int dir = 0; dir < 10 && hit; dir++) {
+            Dual p0[3], q0[4], p1[3], q1[4], pos[3], mv[3], out[3];
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                p0[d] = Dual(e.pos[f * 3 + d], dir == 3 + d ? 1.f : 0.f);
+                p1[d] = Dual(e.pos[(f + 1) * 3 + d]);
+                mv[d] = Dual(v[d], dir == d ? 1.f : 0.f);
+                pos[d] = Dual(x[d] + sdt * v[d]);
+            }
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                q0[d] = Dual(e.quat[f * 4 + d], dir == 6 + d ? 1.f : 0.f);
+                q1[d] = Dual(e.quat[(f + 1) * 4 + d]);
+            }
+            hit = t_dynamic_collide<Dual>(e.mesh, p0, q0, p1, q1, pos, mv, S.dt, out);
+            if (!hit) break;
+            const float r = g[0] * out[0].d + g[1] * out[1].d + g[2] * out[2].d;
+            c[0] = dir == 0 ? r : c[0]; c[1] = dir == 1 ? r : c[1]; c[2] = dir == 2 ? r : c[2];           // (selects: dir is a runtime index)
+            a[0] = dir == 3 ? r : a[0]; a[1] = dir == 4 ? r : a[1]; a[2] = dir == 5 ? r : a[2];
+            gq0[0] = dir == 6 ? r : gq0[0]; gq0[1] = dir == 7 ? r : gq0[1]; gq0[2] = dir == 8 ? r : gq0[2]; gq0[3] = dir == 9 ? r : gq0[3];
+        }
+        if (!hit) continue;                                             // not in contact: identity, g passes through
+        const float idt = 1.f / S.dt;
+        const float w[3] = {(g[0] - c[0]) * idt, (g[1] - c[1]) * idt, (g[2] - c[2]) * idt};      // (I - J_mv)^T g / dt
+        // pm = R(q0)^-1 (pos - p0), then d(R(q1) pm)/d q1_k by one dual quaternion rotation each
+        float pm[3];
+        {
+            const float qn = 1.f / sqrtf(e.quat[f * 4] * e.quat[f * 4] + e.quat[f * 4 + 1] * e.quat[f * 4 + 1] + e.quat[f * 4 + 2] * e.quat[f * 4 + 2] + e.quat[f * 4 + 3] * e.quat[f * 4 + 3]);
+            const float qi[4] = {e.quat[f * 4] * qn, -e.quat[f * 4 + 1] * qn, -e.quat[f * 4 + 2] * qn, -e.quat[f * 4 + 3] * qn};
+            const float rel0[3] = {x[0] + sdt * v[0] - e.pos[f * 3], x[1] + sdt * v[1] - e.pos[f * 3 + 1], x[2] + sdt * v[2] - e.pos[f * 3 + 2]};
+            t_quat_rotate(rel0, qi, pm);
+        }
+        float gq1[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            Dual q1[4], pmd[3], rot[3];
+            for (int d = 0; d < 4; d++) q1[d] = Dual(e.quat[(f + 1) * 4 + d], d == k ? 1.f : 0.f);
+            for (int d = 0; d < 3; d++) pmd[d] = Dual(pm[d]);
+            t_quat_rotate(pmd, q1, rot);
+            gq1[k] = w[0] * rot[0].d + w[1] * rot[1].d + w[2] * rot[2].d;
+        }
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const float gpos = -a[d] - w[d];                             // d/d pos: the pm part (= -d/d p0) and the explicit -pos/dt of cv
+            if (!NODE) gx[d] += gpos;
+            g[d] = c[d] + sdt * gpos;                                   // new_v enters as mat_v and, times dt, in pos
+            atomicAdd(&s_pose[ei * 14 + d], a[d]);                      // pos[f]
+            atomicAdd(&s_pose[ei * 14 + 7 + d], w[d]);                  // pos[f+1]
+        }
+#pragma unroll
+        for (int d = 0; d < 4; d++) { atomicAdd(&s_pose[ei * 14 + 3 + d], gq0[d]); atomicAdd(&s_pose[ei * 14 + 10 + d], gq1[d]); }
+    }
+}
+
 // velocity of one node after gravity and the domain boundary (mpm:383-398); k[] = boundary multipliers
 #define FE_MAX_STATICS 4
 struct StaticsP { int n; const SdfP* s; };          // the scene's static SDF colliders (statics.py), parameter blocks in device memory
 
 // STATICS=false keeps the collider-free kernels exactly as lean as before (the SDF code costs ~100 VGPRs)
-template <bool STATICS>
+// DYN: the agent's moving colliders act at the nodes too (mpm:393-395); vdyn = the velocity before them (adjoint input)
+template <bool STATICS, bool DYN = false>
 __device__ __forceinline__ void node_velocity(const SimP& S, const StaticsP& ST, const float4 gi, int i, int j, int k, float vo[3], float kmul[3],
-                                              float (*trace)[3] = nullptr) {
+                                              float (*trace)[3] = nullptr, const AgentP* agent = nullptr, int f = 0, float* vdyn = nullptr) {
     float inv = 1.f / gi.w;
     vo[0] = inv * gi.x + S.dt * S.g[0];
     vo[1] = inv * gi.y + S.dt * S.g[1];
@@ -494,6 +618,10 @@ __device__ __forceinline__ void node_velocity(const SimP& S, const StaticsP& ST,
                 static_collide(ST.s[si], xn, vo, nullptr);
             }
         }
+    }
+    if (DYN) {
+        if (vdyn) { vdyn[0] = vo[0]; vdyn[1] = vo[1]; vdyn[2] = vo[2]; }
+        agent_collide_particle<true>(S, *agent, f, xn, vo);
     }
     boundary_v(S.bnd, xn, vo, kmul);
 }
@@ -574,10 +702,10 @@ __device__ __forceinline__ int grid_entry(const TableP& T, const int* __restrict
 // grid_op (mpm:380-398) over the active 4^3 blocks only; one wave per block.  STATICS: the scene has SDF colliders.
 // KEEP=false (forward): also re-zeroes g_in and the dynamic block flag, so no separate reset_grid pass
 // (mpm:219-223) is needed.  KEEP=true (backward recompute): stores the summed (p, m) in g_in for grid_grad.
-template <bool KEEP, bool STATICS>
+template <bool KEEP, bool STATICS, bool DYN>
 __global__ __launch_bounds__(256) void k_grid(SimP S, TableP T, const float4* __restrict__ slab, float* g_in, float4* g_out,
                                               const int* __restrict__ blk_list, const int* __restrict__ blk_count, int* blk_flag,
-                                              GridStore GS, int f, int* frame_slow, StaticsP ST) {
+                                              GridStore GS, int f, int* frame_slow, StaticsP ST, AgentP agent) {
     if (KEEP && GS.cap > 0 && GS.flag[f]) return;        // backward: stored by the forward pass
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n_static = T.meta[2], cnt = n_static + *blk_count;
@@ -598,7 +726,7 @@ __global__ __launch_bounds__(256) void k_grid(SimP S, TableP T, const float4* __
         float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
         if (gi.w > FE_EPS) {
             float vo[3], kmul[3];
-            node_velocity<STATICS>(S, ST, gi, bi * 4 + (lane >> 4), bj * 4 + ((lane >> 2) & 3), bk * 4 + (lane & 3), vo, kmul);
+            node_velocity<STATICS, DYN>(S, ST, gi, bi * 4 + (lane >> 4), bj * 4 + ((lane >> 2) & 3), bk * 4 + (lane & 3), vo, kmul, nullptr, &agent, f);
             out = make_float4(vo[0], vo[1], vo[2], 0.f);
         }
         g_out[c] = out;
@@ -612,105 +740,6 @@ __global__ __launch_bounds__(256) void k_grid(SimP S, TableP T, const float4* __
         } else {
             g_in[c] = gi.x; g_in[S.ncell + c] = gi.y; g_in[2 * S.ncell + c] = gi.z; g_in[3 * S.ncell + c] = gi.w;
         }
-    }
-}
-
-// agent.collide at particle level (mpm:418-422; AgentRigid.collide): every effector that carries a mesh, in order,
-// x_tmp = x + dt * new_v re-formed before each collider.
-__device__ __forceinline__ void agent_collide_particle(const SimP& S, const AgentP& agent, int f, const float x[3], float nv[3]) {
-    for (int ei = 0; ei < agent.n; ei++) {
-        const EffP& e = agent.e[ei];
-        if (!e.has_mesh) continue;
-        const float pos[3] = {x[0] + S.dt * nv[0], x[1] + S.dt * nv[1], x[2] + S.dt * nv[2]};
-        if (!(pos[1] > agent.collide_min_y)) continue;                           // agent_icecreamdynamic.py:39-43
-        float out[3];
-        t_dynamic_collide<float>(e.mesh, e.pos + f * 3, e.quat + f * 4, e.pos + (f + 1) * 3, e.quat + (f + 1) * 4, pos, nv, S.dt, out);
-        nv[0] = out[0]; nv[1] = out[1]; nv[2] = out[2];
-    }
-}
-// Its adjoint.  g = d/d(new_v after the colliders) on entry, d/d(new_v before them) on exit; gx receives the part that
-// flows into x[f]; the effector pose adjoints (pos, quat at f and f+1) are accumulated in LDS (s_pose).  One Jacobian
-// column per forward-mode pass; a particle that is not in contact leaves after the first pass.
-__device__ void agent_collide_particle_grad(const SimP& S, const AgentP& agent, int f, const float x[3], const float nv0[3],
-                                            float g[3], float gx[3]) {
-    float vin[FE_MAX_EFF][3];
-    float nv[3] = {nv0[0], nv0[1], nv0[2]};
-#pragma unroll
-    for (int ei = 0; ei < FE_MAX_EFF; ei++) {
-        if (ei < agent.n && agent.e[ei].has_mesh) {
-            const EffP& e = agent.e[ei];
-            vin[ei][0] = nv[0]; vin[ei][1] = nv[1]; vin[ei][2] = nv[2];
-            const float pos[3] = {x[0] + S.dt * nv[0], x[1] + S.dt * nv[1], x[2] + S.dt * nv[2]};
-            if (pos[1] > agent.collide_min_y) {
-                float out[3];
-                t_dynamic_collide<float>(e.mesh, e.pos + f * 3, e.quat + f * 4, e.pos + (f + 1) * 3, e.quat + (f + 1) * 4, pos, nv, S.dt, out);
-                nv[0] = out[0]; nv[1] = out[1]; nv[2] = out[2];
-            }
-        }
-    }
-#pragma unroll
-    for (int ei = FE_MAX_EFF - 1; ei >= 0; ei--) {
-        if (!(ei < agent.n && agent.e[ei].has_mesh)) continue;
-        const EffP& e = agent.e[ei];
-        const float v[3] = {vin[ei][0], vin[ei][1], vin[ei][2]};
-        if (!(x[1] + S.dt * v[1] > agent.collide_min_y)) continue;
-        // out = cv + vt(rel, n) infl + rel (1 - infl), rel = mv - cv, cv = (R(q1) pm + p1 - pos) / dt: the inputs that enter only
-        // through cv (p1, q1 and the explicit -pos) have the closed-form Jacobian (I - d out/d mv) d cv/d input, so only ten
-        // forward-mode passes are needed -- mv (3), p0 (3: it enters through pm only, like the pm-part of pos), q0 (4).
-        float c[3] = {0.f, 0.f, 0.f}, a[3] = {0.f, 0.f, 0.f}, gq0[4] = {0.f, 0.f, 0.f, 0.f};
-        bool hit = true;
-#pragma unroll 1
-        for (int dir = 0; dir < 10 && hit; dir++) {
-            Dual p0[3], q0[4], p1[3], q1[4], pos[3], mv[3], out[3];
-#pragma unroll
-            for (int d = 0; d < 3; d++) {
-                p0[d] = Dual(e.pos[f * 3 + d], dir == 3 + d ? 1.f : 0.f);
-                p1[d] = Dual(e.pos[(f + 1) * 3 + d]);
-                mv[d] = Dual(v[d], dir == d ? 1.f : 0.f);
-                pos[d] = Dual(x[d] + S.dt * v[d]);
-            }
-#pragma unroll
-            for (int d = 0; d < 4; d++) {
-                q0[d] = Dual(e.quat[f * 4 + d], dir == 6 + d ? 1.f : 0.f);
-                q1[d] = Dual(e.quat[(f + 1) * 4 + d]);
-            }
-            hit = t_dynamic_collide<Dual>(e.mesh, p0, q0, p1, q1, pos, mv, S.dt, out);
-            if (!hit) break;
-            const float r = g[0] * out[0].d + g[1] * out[1].d + g[2] * out[2].d;
-            c[0] = dir == 0 ? r : c[0]; c[1] = dir == 1 ? r : c[1]; c[2] = dir == 2 ? r : c[2];           // (selects: dir is a runtime index)
-            a[0] = dir == 3 ? r : a[0]; a[1] = dir == 4 ? r : a[1]; a[2] = dir == 5 ? r : a[2];
-            gq0[0] = dir == 6 ? r : gq0[0]; gq0[1] = dir == 7 ? r : gq0[1]; gq0[2] = dir == 8 ? r : gq0[2]; gq0[3] = dir == 9 ? r : gq0[3];
-        }
-        if (!hit) continue;                                             // not in contact: identity, g passes through
-        const float idt = 1.f / S.dt;
-        const float w[3] = {(g[0] - c[0]) * idt, (g[1] - c[1]) * idt, (g[2] - c[2]) * idt};      // (I - J_mv)^T g / dt
-        // pm = R(q0)^-1 (pos - p0), then d(R(q1) pm)/d q1_k by one dual quaternion rotation each
-        float pm[3];
-        {
-            const float qn = 1.f / sqrtf(e.quat[f * 4] * e.quat[f * 4] + e.quat[f * 4 + 1] * e.quat[f * 4 + 1] + e.quat[f * 4 + 2] * e.quat[f * 4 + 2] + e.quat[f * 4 + 3] * e.quat[f * 4 + 3]);
-            const float qi[4] = {e.quat[f * 4] * qn, -e.quat[f * 4 + 1] * qn, -e.quat[f * 4 + 2] * qn, -e.quat[f * 4 + 3] * qn};
-            const float rel0[3] = {x[0] + S.dt * v[0] - e.pos[f * 3], x[1] + S.dt * v[1] - e.pos[f * 3 + 1], x[2] + S.dt * v[2] - e.pos[f * 3 + 2]};
-            t_quat_rotate(rel0, qi, pm);
-        }
-        float gq1[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            Dual q1[4], pmd[3], rot[3];
-            for (int d = 0; d < 4; d++) q1[d] = Dual(e.quat[(f + 1) * 4 + d], d == k ? 1.f : 0.f);
-            for (int d = 0; d < 3; d++) pmd[d] = Dual(pm[d]);
-            t_quat_rotate(pmd, q1, rot);
-            gq1[k] = w[0] * rot[0].d + w[1] * rot[1].d + w[2] * rot[2].d;
-        }
-#pragma unroll
-        for (int d = 0; d < 3; d++) {
-            const float gpos = -a[d] - w[d];                             // d/d pos: the pm part (= -d/d p0) and the explicit -pos/dt of cv
-            gx[d] += gpos;
-            g[d] = c[d] + S.dt * gpos;                                  // new_v enters as mat_v and, times dt, in pos
-            atomicAdd(&s_pose[ei * 14 + d], a[d]);                      // pos[f]
-            atomicAdd(&s_pose[ei * 14 + 7 + d], w[d]);                  // pos[f+1]
-        }
-#pragma unroll
-        for (int d = 0; d < 4; d++) { atomicAdd(&s_pose[ei * 14 + 3 + d], gq0[d]); atomicAdd(&s_pose[ei * 14 + 10 + d], gq1[d]); }
     }
 }
 
@@ -755,7 +784,7 @@ __device__ __forceinline__ void used_particle_g2p(const SimP& S, const FrameV& c
     for (int a = 0; a < 3; a++)
 #pragma unroll
         for (int b = 0; b < 3; b++) nC.a[a][b] = c4 * (M.a[a][b] - st.fx[b] * nv[a]);
-    if (COLLIDE) agent_collide_particle(S, agent, f, x, nv);                    // mpm:418-422
+    if (COLLIDE) agent_collide_particle<false>(S, agent, f, x, nv);                    // mpm:418-422
     float xn[3] = {x[0] + S.dt * nv[0], x[1] + S.dt * nv[1], x[2] + S.dt * nv[2]};
     store_xvC(nxt, s, xn, nv, nC);
 }
@@ -951,7 +980,7 @@ __device__ void g2p_collide_grad(const SimP& S, const AgentP& agent, int f, cons
     const float4 a0 = Gn.A0[s], a1 = Gn.A1[s];
     cg[0] = a0.w + S.dt * a0.x; cg[1] = a1.x + S.dt * a0.y; cg[2] = a1.y + S.dt * a0.z;
     cg[3] = cg[4] = cg[5] = 0.f;
-    agent_collide_particle_grad(S, agent, f, x, nv, cg, cg + 3);
+    agent_collide_particle_grad<false>(S, agent, f, x, nv, cg, cg + 3);
 }
 
 // one slot on the global path (tail / sort_interval = 0)
@@ -1047,11 +1076,12 @@ __global__ __launch_bounds__(WG) void k_g2p_grad(SimP S, float* fr_cur, float* G
 
 // grid_op.grad (mpm:539): d/d v_out (slabs of k_g2p_grad + slow-path atomics in gg_out) -> gg_in (d/d v_in, d/d mass);
 // re-zeroes g_in, gg_out and the dynamic flags
-template <bool STATICS>
+template <bool STATICS, bool DYN>
 __global__ __launch_bounds__(256) void k_grid_grad(SimP S, TableP T, const float4* __restrict__ slab, float* g_in, float* gg_out, float4* gg_in,
                                                    const int* __restrict__ blk_list, const int* __restrict__ blk_count, int* blk_flag,
-                                                   GridStore GS, int f, StaticsP ST) {
+                                                   GridStore GS, int f, StaticsP ST, AgentP agent) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (DYN) { if (threadIdx.x < FE_MAX_EFF * 14) s_pose[threadIdx.x] = 0.f; __syncthreads(); }
     const int n_static = T.meta[2], cnt = n_static + *blk_count;
     const bool stored = GS.cap > 0 && GS.flag[f];
     const int per_xcd = ((cnt + 3) / 4 + 7) >> 3;
@@ -1072,9 +1102,14 @@ __global__ __launch_bounds__(256) void k_grid_grad(SimP S, TableP T, const float
             float vo[3], kmul[3];
             float trace[FE_MAX_STATICS][3];
             const int ni = bi * 4 + (lane >> 4), nj = bj * 4 + ((lane >> 2) & 3), nk = bk * 4 + (lane & 3);
-            node_velocity<STATICS>(S, ST, gi, ni, nj, nk, vo, kmul, trace);
+            float vdyn[3];
+            node_velocity<STATICS, DYN>(S, ST, gi, ni, nj, nk, vo, kmul, trace, &agent, f, vdyn);
             float inv = 1.f / gi.w;
             float gcol[3] = {go.x * kmul[0], go.y * kmul[1], go.z * kmul[2]};
+            if (DYN && (gcol[0] != 0.f || gcol[1] != 0.f || gcol[2] != 0.f)) {      // agent.collide's adjoint at the node: pose adjoints -> s_pose
+                const float xn[3] = {(float)ni * S.dx, (float)nj * S.dx, (float)nk * S.dx};
+                agent_collide_particle_grad<true>(S, agent, f, xn, vdyn, gcol, nullptr);
+            }
             if (STATICS) node_statics_grad(S, ST, ni, nj, nk, trace, gcol);
             float g0 = gcol[0], g1 = gcol[1], g2 = gcol[2];
             out.x = g0 * inv; out.y = g1 * inv; out.z = g2 * inv;
@@ -1085,6 +1120,7 @@ __global__ __launch_bounds__(256) void k_grid_grad(SimP S, TableP T, const float
         gg_out[c] = 0.f; gg_out[S.ncell + c] = 0.f; gg_out[2 * S.ncell + c] = 0.f;
         if (lane == 0 && !is_static) blk_flag[b] = 0;
     }
+    if (DYN) pose_flush(agent, f);
 }
 
 // Effector.move_kernel.grad (effector.py:154-155), position chain only
@@ -1231,8 +1267,19 @@ __device__ __forceinline__ void slot_p2g_grad(const SimP& S, const FrameV& cur, 
     if (inj.on) {
         int j = pool_idx[pid] - inj.act_id;
         if (j >= 0 && j < inj.flux) {                      // x[f+1,pid] = offset + pos[f] + R(q) inject_p
-            float* gp = agent.e[agent.inj].gpos + f * 3;
+            const EffP& e = agent.e[agent.inj];
+            float* gp = e.gpos + f * 3;
             atomicAdd(gp + 0, g.x[0]); atomicAdd(gp + 1, g.x[1]); atomicAdd(gp + 2, g.x[2]);
+            // inject_p and inject_v are rotated by quat[f] (injector.py:92-96): one forward-mode pass per quaternion component
+#pragma unroll 1
+            for (int k = 0; k < 4; k++) {
+                Dual q[4], ip[3], iv[3], rp[3], rv[3];
+                for (int d = 0; d < 4; d++) q[d] = Dual(e.quat[f * 4 + d], d == k ? 1.f : 0.f);
+                for (int d = 0; d < 3; d++) { ip[d] = Dual(e.inject_p[d]); iv[d] = Dual(e.inject_v[d]); }
+                t_quat_rotate(ip, q, rp); t_quat_rotate(iv, q, rv);
+                const float c = g.x[0] * rp[0].d + g.x[1] * rp[1].d + g.x[2] * rp[2].d + g.v[0] * rv[0].d + g.v[1] * rv[1].d + g.v[2] * rv[2].d;
+                if (c != 0.f) atomicAdd(&e.gquat[f * 4 + k], c);
+            }
         }
     }
 }
@@ -1880,6 +1927,8 @@ struct FeEngine {
     bool all_simple_liquid = false;                         // every particle is an inviscid MAT_LIQUID: SVD-free kernels
     std::vector<SdfP> statics_host; std::vector<float*> statics_vox; SdfP* statics_dev = nullptr;   // static SDF colliders
     struct SmokeState* smoke = nullptr;                     // SmokeField (fe_smoke.h), optional
+    int collide_type = 1;                                  // Agent.collide_type (agent.py:17-26): 1 particle, 2 grid, 3 both
+    BoundaryP* collector_dev = nullptr; bool has_collector = false; int collector_mat = -1;     // collector_act_kernel (agent_pouring.py:30-41)
     int inject_till = -1; float collide_min_y = -1e30f;    // AgentIceCreamDynamic (agent_icecreamdynamic.py:11,23-43)
     bool prof_fine = false;
     bool has_mesh_effector = false; std::vector<float*> mesh_vox;   // Rigid effectors with an SDF mesh (dynamic.py)
@@ -1947,6 +1996,7 @@ BoundaryP to_boundary(const FeBoundary& b) {
 
 AgentP agent_params(FeEngine* h) {
     AgentP a; a.n = (int)h->effs.size(); a.inj = 0; a.e = h->effs_dev; a.collide_min_y = h->collide_min_y;
+    a.collector = h->has_collector ? h->collector_dev : nullptr; a.collector_mat = h->collector_mat;
     for (size_t i = 0; i < h->effs.size(); i++) if (h->effs[i].p.type == FE_EFF_INJECTOR) a.inj = (int)i;
     return a;
 }
@@ -2099,6 +2149,19 @@ void rigid_forward(FeEngine* h, int f, const TableP& T) {
     hipLaunchKernelGGL(k_rigid_solve, dim3((h->n_bodies + 63) / 64), dim3(64), 0, h->stream, h->bodies_dev, h->n_bodies);
 }
 
+// Agent.collide_type (agent.py:17-26): bit 0 = at the particles (g2p), bit 1 = at the grid nodes (grid_op)
+inline bool grid_collide(FeEngine* h) { return h->has_mesh_effector && (h->collide_type & 2); }
+inline bool particle_collide(FeEngine* h) { return h->has_mesh_effector && (h->collide_type & 1); }
+
+template <bool KEEP>
+void launch_grid(FeEngine* h, const TableP& T, int f, const AgentP& ag) {
+#define LAUNCH_GRID(ST_, DY_) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid<KEEP, ST_, DY_>), ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, h->g_out, \
+                           h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f, h->frame_slow_dev, statics_p(h), ag)
+    if (grid_collide(h)) { if (h->statics_host.empty()) LAUNCH_GRID(false, true); else LAUNCH_GRID(true, true); }
+    else { if (h->statics_host.empty()) LAUNCH_GRID(false, false); else LAUNCH_GRID(true, false); }
+#undef LAUNCH_GRID
+}
+
 int substep_fwd(FeEngine* h, int f, int f_global, int act) {
     h->gs_host_valid = false;
     InjectP inj;
@@ -2117,13 +2180,10 @@ int substep_fwd(FeEngine* h, int f, int f_global, int act) {
                            h->pinfo, h->pool_idx, grid_w(h), ag, inj, act, f, grid_store(h));
     prof_end(h);
     prof_begin(h, KID_GRID);
-    if (h->statics_host.empty())
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid<false, false>), ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, h->g_out, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f, h->frame_slow_dev, statics_p(h));
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid<false, true>), ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, h->g_out, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f, h->frame_slow_dev, statics_p(h));
+    launch_grid<false>(h, T, f, ag);
     prof_end(h);
     prof_begin(h, KID_G2P);
-    if (h->has_mesh_effector)
+    if (particle_collide(h))
         hipLaunchKernelGGL(k_g2p<true>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T, h->g_out, h->blk_count, h->slow_dev, ag, f);
     else
         hipLaunchKernelGGL(k_g2p<false>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T, h->g_out, h->blk_count, h->slow_dev, ag, f);
@@ -2162,10 +2222,7 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act) {
                            h->pinfo, h->pool_idx, grid_w(h), ag, noinj, 0, f, grid_store(h));
     prof_end(h);
     prof_begin(h, KID_GRID_KEEP);
-    if (h->statics_host.empty())
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid<true, false>), ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, h->g_out, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f, h->frame_slow_dev, statics_p(h));
-    else
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid<true, true>), ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, h->g_out, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f, h->frame_slow_dev, statics_p(h));
+    launch_grid<true>(h, T, f, ag);
     prof_end(h);
     }
     if (h->has_rigid) {                                   // advect_grad (mpm:436-447) for the rigid bodies, see k_rigid_final_grad
@@ -2176,16 +2233,16 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act) {
         hipLaunchKernelGGL(k_rigid_final_grad, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), h->grad(f + 1), T.pid_of_slot, h->rigid_body, h->bodies_dev);
     }
     prof_begin(h, KID_G2P_GRAD);
-    if (h->has_mesh_effector)
+    if (particle_collide(h))
         hipLaunchKernelGGL(k_g2p_grad<true>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag);
     else
         hipLaunchKernelGGL(k_g2p_grad<false>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag);
     prof_end(h);
     prof_begin(h, KID_GRID_GRAD);
-    if (h->statics_host.empty())
-        hipLaunchKernelGGL(k_grid_grad<false>, ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, h->gg_out, h->gg_in, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f, statics_p(h));
-    else
-        hipLaunchKernelGGL(k_grid_grad<true>, ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, h->gg_out, h->gg_in, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f, statics_p(h));
+#define LAUNCH_GRID_GRAD(ST_, DY_) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_grad<ST_, DY_>), ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, h->gg_out, \
+                           h->gg_in, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f, statics_p(h), ag)
+    if (grid_collide(h)) { if (h->statics_host.empty()) LAUNCH_GRID_GRAD(false, true); else LAUNCH_GRID_GRAD(true, true); }
+    else { if (h->statics_host.empty()) LAUNCH_GRID_GRAD(false, false); else LAUNCH_GRID_GRAD(true, false); }
     prof_end(h);
     prof_begin(h, KID_P2G_GRAD);
 #define LAUNCH_P2G_GRAD(G, W) hipLaunchKernelGGL((k_p2g_grad<G, W>), wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), \
@@ -2328,7 +2385,7 @@ void fe_destroy(FeEngine* h) {
     for (auto& t : h->tables) { for (void* q : {(void*)t.pid, (void*)t.items, (void*)t.meta, (void*)t.blk_first, (void*)t.active, (void*)t.blk_slot, (void*)t.slot_of_pid}) if (q) (void)hipFree(q); }
     void* ptrs[] = {h->frames, h->grads, h->sort_key, h->sort_rank, h->sort_cnt, h->sort_start, h->sort_src, h->sort_pid, h->slow_dev, h->frame_slow_dev, h->gstore, h->gs_flag, h->slab, h->ts_dev, h->sort_partial, h->effs_dev, h->pinfo, h->pool_idx, h->g_in, h->g_out, h->gg_out, h->gg_in,
                     h->blk_flag, h->blk_list, h->blk_count, h->err_dev, h->stage_r, h->stage_i, h->node_mark, h->counters,
-                    h->tgt, h->chamfer, h->step_loss, h->rigid_body, h->bodies_dev, h->statics_dev};
+                    h->tgt, h->chamfer, h->step_loss, h->rigid_body, h->bodies_dev, h->statics_dev, h->collector_dev};
     for (float* v : h->statics_vox) if (v) (void)hipFree(v);
     for (float* v : h->mesh_vox) if (v) (void)hipFree(v);
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -2371,6 +2428,11 @@ int fe_set_option(FeEngine* h, const char* name, double value) {
     if (!std::strcmp(name, "p2g_grad_waves")) { h->p2g_grad_waves = (int)value; return 0; }
     if (!std::strcmp(name, "inject_till")) { h->inject_till = (int)value; return 0; }
     if (!std::strcmp(name, "collide_min_y")) { h->collide_min_y = (float)value; return 0; }
+    if (!std::strcmp(name, "collide_type")) {
+        const int t = (int)value;
+        if (t < 1 || t > 3) { h->err = "collide_type must be 1 (particle), 2 (grid) or 3 (both)"; return 1; }
+        h->collide_type = t; return 0;
+    }
     if (!std::strcmp(name, "prof_fine")) { h->prof_fine = value != 0; return 0; }
     if (!std::strcmp(name, "xcd_map")) { h->S.xcd = value != 0; return 0; }
     if (!std::strcmp(name, "dbg")) { h->S.dbg = (int)value; return 0; }     // timing experiments: results are wrong
@@ -2519,6 +2581,16 @@ int fe_reset_grad(FeEngine* h) {
 int fe_reset_grad_till_frame(FeEngine* h, int f) {
     CHECK_FRAME(h, f);
     // particle adjoints: every substep_grad overwrites its ring slot, nothing to clear.
+    return 0;
+}
+int fe_agent_set_collector(FeEngine* h, const FeBoundary* b, int mat) {
+    (void)hipSetDevice(h->device);
+    h->has_collector = b != nullptr;
+    h->collector_mat = mat;
+    if (!b) return 0;
+    const BoundaryP p = to_boundary(*b);
+    if (!h->collector_dev && dev_alloc(h, &h->collector_dev, 1)) return 1;
+    if (hipMemcpyOnStream(h, h->collector_dev, &p, sizeof(BoundaryP), hipMemcpyHostToDevice) != hipSuccess) { h->err = "hipMemcpy failed"; return 1; }
     return 0;
 }
 int fe_agent_reset_grad_till_frame(FeEngine* h, int f) {

@@ -342,6 +342,18 @@ FE_HD void boundary_v(const BoundaryP& b, const real x[3], real v[3], real k[3])
     }
 }
 
+// Boundary.is_out (boundaries.py:80-93 cylinder, 127-134 cube)
+FE_HD bool boundary_is_out(const BoundaryP& b, const real x[3]) {
+    if (b.type == 0) {
+        bool out = false;
+#pragma unroll
+        for (int i = 0; i < 3; i++) out = out || x[i] > b.upper[i] || x[i] < b.lower[i];
+        return out;
+    }
+    const real rx = x[0] - b.cx, rz = x[2] - b.cz;
+    return x[1] > b.upper[1] || x[1] < b.lower[1] || sqrt(rx * rx + rz * rz + FE_EPS) > b.radius;
+}
+
 // impose_x (boundaries.py:66-78, 123-126) and its Jacobian under Taichi's min/max adjoint rules
 FE_HD void boundary_x(const BoundaryP& b, const real x[3], real xn[3], real J[3][3]) {
 #pragma unroll

@@ -165,6 +165,12 @@ int fe_eff_get_action_grad(FeEngine* h, int e, int s, int n, fe_real* grad);    
 int fe_agent_copy_frame(FeEngine* h, int src, int dst);                           /* agent.py:117-120 */
 int fe_agent_copy_grad(FeEngine* h, int src, int dst);                            /* agent.py:122-125 */
 int fe_agent_reset_grad_till_frame(FeEngine* h, int f);                            /* agent.py:127-130, effector.py:178-183 */
+/* The collector of AgentPouring / AgentJetBot (collector_act_kernel, agent_pouring.py:30-41, agent_jetbot.py:33-43): in
+ * every acting substep a used particle outside `b` (Boundary.is_out, boundaries.py:80-93 / 127-134) is marked unused in
+ * frames f and f+1 and parked at NOWHERE in f+1.  mat < 0: every material (AgentPouring); else only particles of that
+ * material id (AgentJetBot: WATER).  b == NULL removes the collector.  Where the agent's colliders act -- at the particles,
+ * at the grid nodes (mpm:393-395) or both, Agent.collide_type (agent.py:17-26) -- is fe_set_option("collide_type", 1|2|3). */
+int fe_agent_set_collector(FeEngine* h, const FeBoundary* b, int mat);
 
 /* ---- static SDF colliders: fluidlab/fluidengine/meshes/static.py:25-104, statics.py, mesh.py:57-66,120-127 -------- */
 /* A collider is a signed-distance voxel grid in its own frame plus the affine map world -> voxel coordinates

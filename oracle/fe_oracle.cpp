@@ -270,6 +270,10 @@ struct FeEngine {
     std::vector<Sdf> meshes;         /* Dynamic meshes of Rigid effectors (dynamic.py) */
     bool has_mesh_effector = false;
     int inject_till = -1;            /* AgentIceCreamDynamic.inject_till (agent_icecreamdynamic.py:11,23-30): no injection from this global substep on */
+    int collide_type = 1;            /* Agent.collide_type (agent.py:17-26): 1 'particle', 2 'grid', 3 'both' */
+    bool has_collector = false;      /* AgentPouring / AgentJetBot collector_act_kernel (agent_pouring.py:30-41, agent_jetbot.py:33-43) */
+    FeBoundary collector;            /* particles outside this boundary are taken out of the simulation */
+    int collector_mat = -1;          /* < 0: every material (AgentPouring); else only this one (AgentJetBot: WATER) */
     R collide_min_y = (R)-1e30;      /* AgentIceCreamDynamic.collide: only above this height (agent_icecreamdynamic.py:39-43) */
     int loss_steps = 0;
     std::vector<R> tgt;          /* [loss_steps, N, 3] */
@@ -656,11 +660,12 @@ template <class T> bool t_dynamic_collide(const Sdf& s, const T p0[3], const T q
 
 /* agent.collide at particle level (mpm:419-422; AgentRigid.collide, agent_rigid.py:21-23): every effector that carries
  * a mesh, in order.  x_tmp = x + dt * new_v is re-formed from the current velocity before each collider. */
-void agent_collide_particle(FeEngine* h, int f, const R x[3], R nv[3]) {
+void agent_collide_particle(FeEngine* h, int f, const R x[3], R nv[3], bool at_node = false) {
     const R dt = h->cfg.dt;
+    const R sdt = at_node ? (R)0 : dt;           /* at a grid node (mpm:393-395) the position is the node's, not x + dt v */
     for (const Effector& e : h->effs) {
         if (e.mesh < 0) continue;
-        R pos[3] = {x[0] + dt * nv[0], x[1] + dt * nv[1], x[2] + dt * nv[2]}, out[3];
+        R pos[3] = {x[0] + sdt * nv[0], x[1] + sdt * nv[1], x[2] + sdt * nv[2]}, out[3];
         if (!(pos[1] > h->collide_min_y)) continue;
         t_dynamic_collide<R>(h->meshes[e.mesh], &e.pos[f * 3], &e.quat[f * 4], &e.pos[(f + 1) * 3], &e.quat[(f + 1) * 4], pos, nv, dt, out);
         for (int d = 0; d < 3; d++) nv[d] = out[d];
@@ -668,14 +673,15 @@ void agent_collide_particle(FeEngine* h, int f, const R x[3], R nv[3]) {
 }
 /* its adjoint: g (d/d new_v after the colliders) is pulled back to d/d new_v before them; the x and pose parts are
  * accumulated.  Effector pose adjoints are shared by all particles, hence the critical section. */
-void agent_collide_particle_grad(FeEngine* h, int f, const R x[3], const R nv0[3], R g[3], R gx[3]) {
+void agent_collide_particle_grad(FeEngine* h, int f, const R x[3], const R nv0[3], R g[3], R gx[3], bool at_node = false) {
     const R dt = h->cfg.dt;
+    const R sdt = at_node ? (R)0 : dt;
     std::vector<std::array<R, 3>> vin;
     R nv[3] = {nv0[0], nv0[1], nv0[2]};
     for (const Effector& e : h->effs) {
         if (e.mesh < 0) continue;
         vin.push_back({nv[0], nv[1], nv[2]});
-        R pos[3] = {x[0] + dt * nv[0], x[1] + dt * nv[1], x[2] + dt * nv[2]}, out[3];
+        R pos[3] = {x[0] + sdt * nv[0], x[1] + sdt * nv[1], x[2] + sdt * nv[2]}, out[3];
         if (!(pos[1] > h->collide_min_y)) continue;
         t_dynamic_collide<R>(h->meshes[e.mesh], &e.pos[f * 3], &e.quat[f * 4], &e.pos[(f + 1) * 3], &e.quat[(f + 1) * 4], pos, nv, dt, out);
         for (int d = 0; d < 3; d++) nv[d] = out[d];
@@ -687,7 +693,7 @@ void agent_collide_particle_grad(FeEngine* h, int f, const R x[3], const R nv0[3
         k--;
         const R* v = vin[k].data();
         const Sdf& s = h->meshes[e.mesh];
-        if (!(x[1] + dt * v[1] > h->collide_min_y)) continue;
+        if (!(x[1] + sdt * v[1] > h->collide_min_y)) continue;
         R gin[3] = {0, 0, 0}, gpose[14];
         /* inputs: 0-2 new_v (enters as mat_v and, times dt, in the position), 3-5 x, 6-8 pos[f], 9-12 quat[f],
          *         13-15 pos[f+1], 16-19 quat[f+1] */
@@ -698,7 +704,7 @@ void agent_collide_particle_grad(FeEngine* h, int f, const R x[3], const R nv0[3
                 p0[d] = Dual(e.pos[f * 3 + d], dir == 6 + d ? 1 : 0);
                 p1[d] = Dual(e.pos[(f + 1) * 3 + d], dir == 13 + d ? 1 : 0);
                 mv[d] = Dual(v[d], dir == d ? 1 : 0);
-                pos[d] = Dual(x[d] + dt * v[d], dir == d ? dt : (dir == 3 + d ? 1 : 0));
+                pos[d] = Dual(x[d] + sdt * v[d], dir == d ? sdt : (dir == 3 + d ? 1 : 0));
             }
             for (int d = 0; d < 4; d++) {
                 q0[d] = Dual(e.quat[f * 4 + d], dir == 9 + d ? 1 : 0);
@@ -706,7 +712,7 @@ void agent_collide_particle_grad(FeEngine* h, int f, const R x[3], const R nv0[3
             }
             hit = t_dynamic_collide<Dual>(s, p0, q0, p1, q1, pos, mv, dt, out);
             const R c = g[0] * out[0].d + g[1] * out[1].d + g[2] * out[2].d;
-            if (dir < 3) gin[dir] = c; else if (dir < 6) gx[dir - 3] += c; else gpose[dir - 6] = c;
+            if (dir < 3) gin[dir] = c; else if (dir < 6) { if (gx) gx[dir - 3] += c; } else gpose[dir - 6] = c;
         }
         if (!hit) continue;                       /* identity: g passes through unchanged */
         for (int d = 0; d < 3; d++) g[d] = gin[d];
@@ -749,8 +755,9 @@ void statics_forward(FeEngine* h, const R xn[3], R vo[3], std::vector<R>* trace)
     }
 }
 
-void grid_op(FeEngine* h) {
+void grid_op(FeEngine* h, int f) {
     const int n = h->n;
+    const bool dyn = h->has_mesh_effector && (h->collide_type & 2);
     const size_t n3 = (size_t)n * n * n;
 #pragma omp parallel for num_threads(h->threads) schedule(static)
     for (long long c = 0; c < (long long)n3; c++) {
@@ -763,6 +770,7 @@ void grid_op(FeEngine* h) {
             R xn[3] = {i * h->dx, j * h->dx, k * h->dx};
             R kk[3];
             if (!h->statics.empty()) statics_forward(h, xn, vo, nullptr);                   /* mpm:386-390 */
+            if (dyn) agent_collide_particle(h, f, xn, vo, true);                            /* mpm:393-395 */
             impose_v(h->cfg.boundary, xn, vo, kk);
             for (int a = 0; a < 3; a++) h->g_vout[c * 3 + a] = vo[a];
         }
@@ -789,7 +797,7 @@ int g2p(FeEngine* h, int f) {
                 for (int b = 0; b < 3; b++) nC.m[a][b] += 4 * h->inv_dx * weight * gv[a] * dpos[b];
             }
         }
-        if (h->has_mesh_effector) agent_collide_particle(h, f, &h->X(f)[p * 3], nv);             /* mpm:418-422 */
+        if (h->has_mesh_effector && (h->collide_type & 1)) agent_collide_particle(h, f, &h->X(f)[p * 3], nv);             /* mpm:418-422 */
         for (int a = 0; a < 3; a++) h->Vv(f + 1)[p * 3 + a] = nv[a];
         m_store(&h->Cc(f + 1)[p * 9], nC);
     }
@@ -928,7 +936,7 @@ void g2p_grad(FeEngine* h, int f) {
         M3 gCn = m_load(&h->GC(f + 1)[p * 9]);
         R gfx[3] = {0, 0, 0};
         const R c4 = 4 * h->inv_dx;
-        if (h->has_mesh_effector) {
+        if (h->has_mesh_effector && (h->collide_type & 1)) {
             /* agent.collide's adjoint (mpm:418-422) comes first in reverse order: it needs the gathered velocity again */
             R nv[3] = {0, 0, 0}, gxc[3] = {0, 0, 0};
             for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++) {
@@ -969,8 +977,9 @@ void g2p_grad(FeEngine* h, int f) {
 }
 
 /* grid_op.grad (mpm:539) */
-void grid_op_grad(FeEngine* h) {
+void grid_op_grad(FeEngine* h, int f) {
     const int n = h->n;
+    const bool dyn = h->has_mesh_effector && (h->collide_type & 2);
     const size_t n3 = (size_t)n * n * n;
 #pragma omp parallel for num_threads(h->threads) schedule(static)
     for (long long c = 0; c < (long long)n3; c++) {
@@ -984,9 +993,12 @@ void grid_op_grad(FeEngine* h) {
             R kk[3];
             std::vector<R> trace;
             if (!h->statics.empty()) statics_forward(h, xn, vo, &trace);
+            const R vdyn[3] = {vo[0], vo[1], vo[2]};
+            if (dyn) agent_collide_particle(h, f, xn, vo, true);
             impose_v(h->cfg.boundary, xn, vo, kk);
             R gv[3];
             for (int a = 0; a < 3; a++) gv[a] = h->gg_vout[c * 3 + a] * kk[a];
+            if (dyn && (gv[0] != 0 || gv[1] != 0 || gv[2] != 0)) agent_collide_particle_grad(h, f, xn, vdyn, gv, nullptr, true);
             for (int si = (int)h->statics.size() - 1; si >= 0; si--) {                      /* colliders, in reverse */
                 R vin[3] = {trace[si * 3], trace[si * 3 + 1], trace[si * 3 + 2]};
                 static_collide(h->statics[si], xn, vin, gv);
@@ -1110,6 +1122,16 @@ void injector_act_grad(FeEngine* h, Effector& e, int f) {
         if (idx >= (int)e.act_range.size()) break;
         int pid = e.act_range[idx];
         for (int d = 0; d < 3; d++) e.gpos[f * 3 + d] += h->GX(f + 1)[pid * 3 + d];
+        /* inject_p and inject_v are rotated by quat[f] (injector.py:92-96): one forward-mode pass per quaternion component */
+        for (int k = 0; k < 4; k++) {
+            Dual q[4], ip[3], iv[3], rp[3], rv[3];
+            for (int d = 0; d < 4; d++) q[d] = Dual(e.quat[f * 4 + d], d == k ? 1 : 0);
+            for (int d = 0; d < 3; d++) { ip[d] = Dual((R)e.d.inject_p[d]); iv[d] = Dual((R)e.d.inject_v[d]); }
+            t_quat_rot(ip, q, rp); t_quat_rot(iv, q, rv);
+            R c = 0;
+            for (int d = 0; d < 3; d++) c += h->GX(f + 1)[pid * 3 + d] * rp[d].d + h->GV(f + 1)[pid * 3 + d] * rv[d].d;
+            e.gquat[f * 4 + k] += c;
+        }
     }
 }
 
@@ -1125,6 +1147,36 @@ void process_unused_particles_grad(FeEngine* h, int f) {
     }
 }
 
+/* Boundary.is_out (boundaries.py:80-93 cylinder, 127-134 cube) */
+bool boundary_is_out(const FeBoundary& b, const R x[3]) {
+    if (b.type == FE_BOUNDARY_CYLINDER) {
+        bool out = x[1] > (R)b.upper[1] || x[1] < (R)b.lower[1];
+        const R rx = x[0] - (R)b.xz_center[0], rz = x[2] - (R)b.xz_center[1];
+        if (std::sqrt(rx * rx + rz * rz + EPS) > (R)b.xz_radius) out = true;
+        return out;
+    }
+    for (int d = 0; d < 3; d++) if (x[d] > (R)b.upper[d] || x[d] < (R)b.lower[d]) return true;
+    return false;
+}
+
+/* collector_act_kernel (agent_pouring.py:30-41, agent_jetbot.py:33-43): a used particle outside the collector boundary is
+ * parked at NOWHERE in frame f+1 and marked unused in BOTH frames, so the rest of substep f skips it.  The reference leaves
+ * v, C, F of frame f+1 as they were (stale); here they are the copies process_unused_particles would have made, so that
+ * the state is defined.  Its .grad contributes nothing (x[f+1] is a constant store, `used` carries no gradient); the
+ * backward pass then sees used[f] == 0 and process_unused_particles.grad passes the adjoint straight through. */
+void collector_act(FeEngine* h, int f) {
+    const int N = h->N;
+#pragma omp parallel for num_threads(h->threads) schedule(static)
+    for (int p = 0; p < N; p++) {
+        if (!h->Us(f)[p]) continue;
+        if (h->collector_mat >= 0 && h->mat[p] != h->collector_mat) continue;
+        if (!boundary_is_out(h->collector, &h->X(f)[p * 3])) continue;
+        h->Us(f + 1)[p] = 0; h->Us(f)[p] = 0;
+        for (int d = 0; d < 3; d++) { h->X(f + 1)[p * 3 + d] = (R)-100; h->Vv(f + 1)[p * 3 + d] = h->Vv(f)[p * 3 + d]; }
+        for (int d = 0; d < 9; d++) { h->Cc(f + 1)[p * 9 + d] = h->Cc(f)[p * 9 + d]; h->Ff(f + 1)[p * 9 + d] = h->Ff(f)[p * 9 + d]; }
+    }
+}
+
 int substep(FeEngine* h, int f, int f_global, int act) {
     /* mpm:515-533 */
     reset_grid_and_grad(h);
@@ -1135,10 +1187,11 @@ int substep(FeEngine* h, int f, int f_global, int act) {
         if (inject) { if (injector_act(h, e, f, f_global)) return 1; }
         else e.act_id[f + 1] = e.act_id[f];
     }
+    if (act && h->has_collector) collector_act(h, f);
     compute_F_tmp_svd(h, f);
     if (p2g(h, f, true)) return 1;
     if (act) for (auto& e : h->effs) effector_move(e, f);
-    grid_op(h);
+    grid_op(h, f);
     if (g2p(h, f)) return 1;
     advect(h, f);
     return 0;
@@ -1150,11 +1203,11 @@ int substep_grad(FeEngine* h, int f, int f_global, int act) {
     reset_grid_and_grad(h);
     compute_F_tmp_svd(h, f);
     if (p2g(h, f, false)) return 1;
-    grid_op(h);
+    grid_op(h, f);
     /* mpm:535-552 */
     advect_grad(h, f);
     g2p_grad(h, f);
-    grid_op_grad(h);
+    grid_op_grad(h, f);
     if (act) for (int i = (int)h->effs.size() - 1; i >= 0; i--) effector_move_grad(h->effs[i], f);
     p2g_grad(h, f);
     if (act && !(h->inject_till >= 0 && f_global >= h->inject_till)) for (auto& e : h->effs) if (e.d.type == FE_EFF_INJECTOR) injector_act_grad(h, e, f);
@@ -1524,6 +1577,11 @@ int fe_set_option(FeEngine* h, const char* name, double value) {
     }
     if (!std::strcmp(name, "inject_till")) { h->inject_till = (int)value; return 0; }
     if (!std::strcmp(name, "collide_min_y")) { h->collide_min_y = (R)value; return 0; }
+    if (!std::strcmp(name, "collide_type")) {
+        const int t = (int)value;
+        if (t < 1 || t > 3) { h->err = "collide_type must be 1 (particle), 2 (grid) or 3 (both)"; return 1; }
+        h->collide_type = t; return 0;
+    }
     /* HIP-engine tunables are accepted and ignored so the same host code drives both */
     return 0;
 }
@@ -1626,6 +1684,12 @@ int fe_reset_grad_till_frame(FeEngine* h, int f) {
     size_t N = h->N;
     std::fill(h->gx.begin(), h->gx.begin() + (size_t)f * N * 3, (R)0); std::fill(h->gv.begin(), h->gv.begin() + (size_t)f * N * 3, (R)0);
     std::fill(h->gC.begin(), h->gC.begin() + (size_t)f * N * 9, (R)0); std::fill(h->gF.begin(), h->gF.begin() + (size_t)f * N * 9, (R)0);
+    return 0;
+}
+int fe_agent_set_collector(FeEngine* h, const FeBoundary* b, int mat) {
+    h->has_collector = b != nullptr;
+    if (b) h->collector = *b;
+    h->collector_mat = mat;
     return 0;
 }
 int fe_agent_reset_grad_till_frame(FeEngine* h, int f) {

@@ -137,6 +137,17 @@ def stirrer_mini(n_grid=16, n_particles=1500, seed=11, horizon=4, n_substeps=4, 
     return sc
 
 
+def pouring_mini(**kw):
+    """AgentPouring in small (agent_pouring.py): one Rigid whose collider acts at the particles AND at the grid nodes
+    (collide_type='both'), plus a collector that takes every particle leaving its box; the water drifts towards +z so
+    particles keep crossing the collector's upper z face during the run."""
+    sc = stirrer_mini(shape='sphere', **kw)
+    sc['v'] = sc['v'] + f32([0.0, 0.0, 3.0])
+    sc['collide_type'] = 3
+    sc['collector'] = dict(boundary=dict(type='cube', lower=(0.0, 0.1, 0.0), upper=(1.0, 1.0, 0.58)), mat=-1)
+    return sc
+
+
 def run_rigid(elib, sc, cot, device=0, options=None, actions=None, action_p=None):
     """Forward over the horizon with per-step actions, cotangent `cot` on the final frame, backward, action gradient
     [(horizon + 1), action_dim] -- the Solver's pass (solver.py:23-59) for an AgentRigid scene, through the raw ABI."""
@@ -145,6 +156,10 @@ def run_rigid(elib, sc, cot, device=0, options=None, actions=None, action_p=None
     e = eng.add_effector(type=FE_EFF_PLAIN, action_dim=r['action_dim'], action_scale_v=r['action_scale_v'],
                          action_scale_p=r['action_scale_p'], boundary=elib.make_boundary(**r['boundary']))
     eng.eff_set_mesh(e, r['voxels'], r['T'], friction=r['friction'], softness=r['softness'])
+    if 'collide_type' in sc:                                  # Agent.collide_type (agent.py:17-26): 1 particle, 2 grid, 3 both
+        eng.set_option('collide_type', sc['collide_type'])
+    if 'collector' in sc:                                     # AgentPouring / AgentJetBot collector
+        eng.agent_set_collector(elib.make_boundary(**sc['collector']['boundary']), sc['collector'].get('mat', -1))
     st0 = eng.eff_get_state(e, 0)
     st0[:7] = r['init_state']
     eng.eff_set_state(e, 0, st0)
@@ -156,6 +171,9 @@ def run_rigid(elib, sc, cot, device=0, options=None, actions=None, action_p=None
         eng.step(s * ns, s * ns, ns, 1)
     final = get_state(eng, H * ns)
     eff_state = eng.eff_get_state(e, H * ns)
+    used_hist = None
+    if 'collector' in sc:                                    # used flags of every frame after the forward pass
+        used_hist = np.stack([get_state(eng, f)['used'] for f in range(H * ns + 1)])
     eng.reset_grad()
     eng.add_grad(H * ns, cot['gx'], cot['gv'], cot['gC'], cot['gF'])
     for s in reversed(range(H)):
@@ -166,7 +184,7 @@ def run_rigid(elib, sc, cot, device=0, options=None, actions=None, action_p=None
     gx0 = eng.get_grad(0)[0]
     eng.close()
     loss = float(sum((final[k].astype(np.float64) * cot[g]).sum() for k, g in zip('xvCF', ('gx', 'gv', 'gC', 'gF'))))
-    return dict(final=final, action_grad=grad, eff_state=eff_state, loss=loss, gx0=gx0)
+    return dict(final=final, action_grad=grad, eff_state=eff_state, loss=loss, gx0=gx0, used_hist=used_hist)
 
 
 def latte_mini(n_grid=16, n_coffee=1200, n_pool=200, seed=2, horizon=6, n_substeps=4, flux=2):
@@ -252,6 +270,20 @@ def random_cotangent(N, seed=5):
                 gC=f32(rng.normal(size=(N, 3, 3)) * 1e-4), gF=f32(rng.normal(size=(N, 3, 3)) * 1e-2))
 
 
+def jetbot_mini(**kw):
+    """AgentJetBot's injector in small (agent_transporting.yaml): a 6-dof action turns the nozzle, so the injection point
+    pos + R(quat) inject_p and the jet velocity R(quat) inject_v depend on the quaternion chain (injector.py:92-96)."""
+    sc = latte_mini(**kw)
+    rng = np.random.RandomState(5)
+    H = sc['horizon']
+    inj = sc['injector']
+    inj.update(action_dim=6, action_scale_v=(1.0, 1.0, 1.0, 5.0, 5.0, 5.0), action_scale_p=(1.0,) * 6,
+               inject_v=(-3.0, -1.0, 0.0), inject_p=(-0.07, 0.0, 0.02))
+    sc['action_p'] = f32([0.5, 0.62, 0.5, 0.0, 0.0, 0.0])
+    sc['actions'] = f32(np.concatenate([rng.uniform(-0.01, 0.01, (H, 3)), rng.uniform(-0.02, 0.02, (H, 3))], 1))
+    return sc
+
+
 def run_latte(elib, sc, device=0, options=None):
     """Full mini trajectory optimisation pass through the raw ABI, mirroring Solver.forward_backward
     (optimizer/solver.py:23-59): forward with loss, backward, action gradient."""
@@ -283,7 +315,7 @@ def run_latte(elib, sc, device=0, options=None):
         eng.step_grad(s * ns, s * ns, ns, 1)
         eng.eff_set_action_grad(e, s, s, ns)
     eng.eff_apply_action_p_grad(e)
-    grad = eng.eff_get_action_grad(e, 0, H, 3)
+    grad = eng.eff_get_action_grad(e, 0, H, inj['action_dim'])
     eff_state = eng.eff_get_state(e, H * ns)
     eng.close()
     return dict(step_loss=step_loss, final=final, action_grad=grad, eff_state=eff_state)

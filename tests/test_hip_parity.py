@@ -97,6 +97,53 @@ def test_rigid_effector(hiplib, oracle64, variant, K):
     assert S.cosine(a['gx0'], b['gx0']) >= 0.9999 and S.rel_l2(a['gx0'], b['gx0']) <= 1e-2
 
 
+@pytest.mark.parametrize('where', ['grid', 'both'])
+@pytest.mark.parametrize('K', [0, 10])
+def test_rigid_effector_collides_at_grid_nodes(hiplib, oracle64, where, K):
+    """Agent.collide_type 'grid' / 'both' (agent.py:17-26; AgentPouring uses 'both'): the effector's collider chain inside
+    grid_op (mpm:393-395) and its adjoint into the node velocities and the effector pose."""
+    sc = S.stirrer_mini(shape='sphere', friction=0.5, softness=0.0)
+    sc['collide_type'] = dict(grid=2, both=3)[where]
+    cot = S.random_cotangent(sc['N'])
+    a = S.run_rigid(hiplib, sc, cot, options={'sort_interval': K})
+    b = S.run_rigid(oracle64, sc, {k: v.astype(np.float64) for k, v in cot.items()})
+    p = S.run_rigid(hiplib, dict(sc, collide_type=1), cot, options={'sort_interval': K})
+    assert np.abs(a['final']['v'] - p['final']['v']).max() > 0.05                   # not the particle-only result
+    assert np.abs(a['eff_state'] - b['eff_state']).max() <= 1e-6
+    assert np.abs(a['final']['x'] - b['final']['x']).max() <= 5e-6
+    assert S.rel_l2(a['final']['v'], b['final']['v']) <= 2e-3
+    ga, gb = a['action_grad'], b['action_grad']
+    assert np.isfinite(ga).all()
+    assert S.cosine(ga, gb) >= 0.99999, S.cosine(ga, gb)
+    assert S.rel_l2(ga, gb) <= 2e-3, S.rel_l2(ga, gb)
+    assert S.cosine(a['gx0'], b['gx0']) >= 0.9999 and S.rel_l2(a['gx0'], b['gx0']) <= 1e-2
+
+
+@pytest.mark.parametrize('K', [0, 3])
+def test_collector(hiplib, oracle64, K):
+    """AgentPouring in small: collide_type='both' plus the collector (agent_pouring.py:30-41).  The same particles are taken
+    in the same substeps as in the oracle, they end parked at NOWHERE, and the action gradient agrees."""
+    sc = S.pouring_mini()
+    cot = S.random_cotangent(sc['N'])
+    b = S.run_rigid(oracle64, sc, {k: v.astype(np.float64) for k, v in cot.items()})
+    cot['gx'][b['used_hist'][-1] == 0] = 0.0                 # losses mask unused particles (pouring_loss.py:131-135)
+    b = S.run_rigid(oracle64, sc, {k: v.astype(np.float64) for k, v in cot.items()})
+    a = S.run_rigid(hiplib, sc, cot, options={'sort_interval': K})
+    n_taken = int((b['used_hist'][-1] == 0).sum())
+    assert n_taken > 50 and (b['used_hist'][1] == 0).sum() < n_taken
+    # a particle within fp32 rounding of the collector face may be taken a substep apart; allow a handful
+    assert (a['used_hist'] != b['used_hist']).any(0).sum() <= 2
+    same = (a['used_hist'] == b['used_hist']).all(0)
+    gone = same & (b['used_hist'][-1] == 0)
+    assert (a['final']['x'][gone] == -100.0).all()
+    assert S.rel_l2(a['final']['v'][gone], b['final']['v'][gone]) <= 1e-4       # carried over from the substep they were taken in
+    live = same & (b['used_hist'][-1] == 1)
+    assert np.abs(a['final']['x'][live] - b['final']['x'][live]).max() <= 5e-6
+    ga, gb = a['action_grad'], b['action_grad']
+    assert S.cosine(ga, gb) >= 0.9999, S.cosine(ga, gb)
+    assert S.rel_l2(ga, gb) <= 1e-2, S.rel_l2(ga, gb)
+
+
 @pytest.mark.parametrize('K', [0, 10])
 def test_static_sdf_colliders(hiplib, oracle64, K):
     """grid_op's collide-with-statics (mpm:386-390, static.py:82-103): trilinear SDF, finite-difference normal, contact
@@ -154,6 +201,22 @@ def test_latte_mini_trajectory_gradient(hiplib, oracle64, K):
     assert np.abs(a['eff_state'] - b['eff_state']).max() <= 1e-6
     assert S.cosine(a['action_grad'], b['action_grad']) >= 0.999999
     assert S.rel_l2(a['action_grad'], b['action_grad']) <= 1e-4          # inviscid liquids: measured ~2e-7
+
+
+@pytest.mark.parametrize('K', [0, 3])
+def test_turning_injector(hiplib, oracle64, K):
+    """A 6-dof Injector (AgentJetBot): injection point and jet velocity rotate with quat[f] (injector.py:92-96); the angular
+    action's gradient runs through the quaternion chain."""
+    sc = S.jetbot_mini()
+    a = S.run_latte(hiplib, sc, options={'sort_interval': K})
+    b = S.run_latte(oracle64, sc)
+    assert (a['final']['used'] == b['final']['used']).all()
+    assert S.rel_l2(a['final']['x'], b['final']['x']) <= 1e-5
+    assert np.abs(a['eff_state'] - b['eff_state']).max() <= 1e-6
+    assert np.abs(b['action_grad'][:-1, 3:]).max() > 1e-6
+    assert S.cosine(a['action_grad'], b['action_grad']) >= 0.999999
+    assert S.rel_l2(a['action_grad'], b['action_grad']) <= 1e-4
+    assert S.rel_l2(a['action_grad'][:, 3:], b['action_grad'][:, 3:]) <= 1e-3
 
 
 def test_fast_particles_leave_their_tiles(hiplib, oracle64):
@@ -246,7 +309,7 @@ def test_device_pointer_frame_io(hiplib):
     # (the two runs re-sort from different in-cell orders, so sums round differently: tolerance, not bit equality)
     for k in a:
         err = np.abs(a[k].astype(np.float64) - b[k]).max()
-        assert err <= 2e-6 * (1.0 + np.abs(b[k]).max()), (k, err)
+        assert err <= 2e-5 * (1.0 + np.abs(b[k]).max()), (k, err)
     eng.get_frame_dev(3, x=d['x'])               # partial reads leave the other arrays alone
     assert (d['x'].cpu().numpy() == b['x']).all() and (d['v'].cpu().numpy() == host['v']).all()
 

@@ -205,14 +205,39 @@ def test_action_gradient_vs_finite_differences(oracle64):
         assert abs(fd - g[-1, k]) < 1e-5 * max(abs(fd), 1e-3), (k, fd, g[-1, k])
 
 
-@pytest.mark.parametrize('variant', ['friction', 'soft', 'sticky'])
+def test_turning_injector_gradient_vs_finite_differences(oracle64):
+    """A 6-dof Injector (AgentJetBot, agent_transporting.yaml): the angular action reaches the loss through
+    quat[f] -> R(quat) inject_p / R(quat) inject_v of the particles injected at f (injector.py:92-96)."""
+    sc = S.jetbot_mini(n_grid=8, n_coffee=150, n_pool=40, horizon=3, n_substeps=3)
+    out = S.run_latte(oracle64, sc)
+    g = out['action_grad']
+    assert g.shape == (sc['horizon'] + 1, 6) and np.abs(g[:3, 3:]).max() > 1e-6
+
+    def total(sc_):
+        return float(S.run_latte(oracle64, sc_)['step_loss'].astype(np.float64).sum())
+
+    h = 1e-6
+    for (s, k) in [(0, 3), (0, 5), (1, 4), (1, 0), (2, 5)]:
+        scp = dict(sc, actions=sc['actions'].astype(np.float64).copy()); scp['actions'][s, k] += h
+        scm = dict(sc, actions=sc['actions'].astype(np.float64).copy()); scm['actions'][s, k] -= h
+        fd = (total(scp) - total(scm)) / (2 * h)
+        assert abs(fd - g[s, k]) < 1e-5 * max(abs(fd), 1e-3), (s, k, fd, g[s, k])
+
+
+@pytest.mark.parametrize('variant', ['friction', 'soft', 'sticky', 'friction-grid', 'friction-both'])
 def test_rigid_effector_gradient_vs_finite_differences(oracle64, variant):
     """Dynamic.collide at particle level (dynamic.py:29-122, mpm:418-422) and the 6-dof pose chain (move_kernel's
     quaternion update, effector.py:157-161; set_velocity's w part, 252-260): dL/d(actions) against central differences."""
+    variant, _, where = variant.partition('-')
     kw = dict(friction=dict(friction=0.5, softness=0.0), soft=dict(friction=0.1, softness=60.0), sticky=dict(friction=20.0, softness=0.0))[variant]
     sc = S.stirrer_mini(n_grid=8, n_particles=120, horizon=3, n_substeps=3, **kw)
+    if where:                # the collider chain at the grid nodes too (mpm:393-395, AgentPouring's collide_type='both')
+        sc['collide_type'] = dict(grid=2, both=3)[where]
     cot = {k: v.astype(np.float64) for k, v in S.random_cotangent(sc['N']).items()}
     out = S.run_rigid(oracle64, sc, cot)
+    if where:
+        ref = S.run_rigid(oracle64, dict(sc, collide_type=1), cot)
+        assert np.abs(out['final']['v'] - ref['final']['v']).max() > 1e-2             # the node-level contact changes the flow
     g = out['action_grad']
     assert g.shape == (4, 6) and np.abs(g[:3, :3]).max() > 1e-3 and np.abs(g[:3, 3:]).max() > 1e-5
     # the collider must actually touch the water: same scene without the mesh contact gives another result
@@ -243,6 +268,63 @@ def test_rigid_effector_gradient_vs_finite_differences(oracle64, variant):
             a = sc['action_p'].astype(np.float64).copy(); a[k_] += dh
             return S.run_rigid(oracle64, sc, cot, action_p=a)['loss']
         assert fd_err(run, g[3, k_], (1e-5, 1e-6, 1e-7, 1e-8)) < (5e-2 if variant == 'soft' else 2e-3)      # moves the whole collider: many kinks nearby
+
+
+def test_collector_takes_particles_out(oracle64):
+    """collector_act_kernel (agent_pouring.py:30-41): replayed substep by substep from the frames the engine kept, a
+    particle is taken exactly when it was used and outside the collector box at the start of the substep; from then on it
+    is unused, parked at NOWHERE, and -- as for any unused particle -- the adjoint passes straight through (mpm:551)."""
+    sc = S.pouring_mini(n_grid=8, n_particles=300, horizon=3, n_substeps=3)
+    cot = {k: v.astype(np.float64) for k, v in S.random_cotangent(sc['N']).items()}
+    eng = S.make_engine(oracle64, sc)
+    r = sc['rigid']
+    e = eng.add_effector(type=S.FE_EFF_PLAIN, action_dim=6, action_scale_v=r['action_scale_v'], action_scale_p=r['action_scale_p'],
+                         boundary=oracle64.make_boundary(**r['boundary']))
+    eng.agent_set_collector(oracle64.make_boundary(**sc['collector']['boundary']), -1)
+    lo, up = np.array(sc['collector']['boundary']['lower']), np.array(sc['collector']['boundary']['upper'])
+    taken_total, later = 0, 0
+    for f in range(9):
+        before = S.get_state(eng, f)
+        eng.substep(f, f, 1)
+        cur, nxt = S.get_state(eng, f), S.get_state(eng, f + 1)
+        out = ((before['x'] > up) | (before['x'] < lo)).any(1) & (before['used'] == 1)
+        assert (cur['used'][out] == 0).all() and (nxt['used'][out] == 0).all() and (nxt['x'][out] == -100.0).all()
+        assert (nxt['v'][out] == before['v'][out]).all() and (nxt['F'][out] == before['F'][out]).all()
+        keep = (before['used'] == 1) & ~out
+        assert (cur['used'][keep] == 1).all() and (nxt['used'][keep] == 1).all() and (nxt['x'][keep] > -1).all()
+        gone = before['used'] == 0
+        assert (nxt['used'][gone] == 0).all() and (nxt['x'][gone] == before['x'][gone]).all()
+        taken_total += int(out.sum()); later += int(out.sum()) if f > 0 else 0
+    assert taken_total > 20 and later > 3
+    # a none-action substep does not run agent.act (mpm:318-320)
+    eng2 = S.make_engine(oracle64, sc)
+    eng2.agent_set_collector(oracle64.make_boundary(**sc['collector']['boundary']), -1)
+    eng2.substep(0, 0, 0)
+    assert (S.get_state(eng2, 1)['used'] == 1).all()
+    # material filter (agent_jetbot.py:37): nothing here is of material 99
+    eng3 = S.make_engine(oracle64, sc)
+    eng3.agent_set_collector(oracle64.make_boundary(**sc['collector']['boundary']), 99)
+    eng3.substep(0, 0, 1)
+    assert (S.get_state(eng3, 1)['used'] == 1).all()
+    # adjoint against central differences on the actions (collection events do not move under a 1e-7 nudge).  As in the
+    # reference, process_unused_particles.grad also hands d/dx[f+1] of a taken particle back to x[f] although x[f+1] is the
+    # constant NOWHERE; losses mask unused particles (pouring_loss.py:131-135), so the cotangent does too.
+    out = S.run_rigid(oracle64, sc, cot)
+    assert out['used_hist'][-1].sum() < sc['N'] - 20
+    cot['gx'][out['used_hist'][-1] == 0] = 0.0
+    out = S.run_rigid(oracle64, sc, cot)
+    eng = None
+    rng = np.random.RandomState(1)
+    g = out['action_grad']
+    for _ in range(4):
+        s_, k_ = rng.randint(0, 3), rng.randint(0, 6)
+        best = 1e9
+        for hstep in (1e-5, 1e-6, 1e-7):
+            a1 = sc['actions'].astype(np.float64).copy(); a1[s_, k_] += hstep
+            a0 = sc['actions'].astype(np.float64).copy(); a0[s_, k_] -= hstep
+            fd = (S.run_rigid(oracle64, sc, cot, actions=a1)['loss'] - S.run_rigid(oracle64, sc, cot, actions=a0)['loss']) / (2 * hstep)
+            best = min(best, abs(fd - g[s_, k_]) / max(abs(fd), 1e-3))
+        assert best < 1e-4, best
 
 
 def test_oracle_f32_tracks_f64(oracle32, oracle64):
