@@ -7,10 +7,15 @@ from .icecreamdynamic_env import IceCreamDynamicEnv
 from .latteartstir_env import LatteArtStirEnv
 from .icecreamstatic_env import IceCreamStaticEnv
 from .gatheringeasy_env import GatheringEasyEnv
+from .gatheringo_env import GatheringOEnv
+from .mixing_env import MixingEnv
+from .pouring_env import PouringEnv
+from .transporting_env import TransportingEnv
 
 REGISTRY = {'LatteArt-v0': LatteArtEnv, 'WaterBlock-v0': WaterBlockEnv, 'Circulation-v0': CirculationEnv,
             'IceCreamDynamic-v0': IceCreamDynamicEnv, 'LatteArtStir-v0': LatteArtStirEnv, 'IceCreamStatic-v0': IceCreamStaticEnv,
-            'GatheringEasy-v0': GatheringEasyEnv}
+            'GatheringEasy-v0': GatheringEasyEnv, 'GatheringO-v0': GatheringOEnv, 'Mixing-v0': MixingEnv, 'Pouring-v0': PouringEnv,
+            'Transporting-v0': TransportingEnv}
 
 
 def make(env_name, **kwargs):

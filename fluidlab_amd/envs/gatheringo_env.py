@@ -1,0 +1,69 @@
+"""GatheringO-v0 (fluidlab/envs/gatheringo_env.py): as GatheringEasy, but in an O-shaped tank whose island the water has to
+flow around -- a static SDF collider inside grid_op -- with the goal at (0.88, 0.78) in the xz plane (GatheringOLoss).
+
+Assets absent here are replaced: the ducks (duck.obj mesh bodies) by two rigid boxes at their places, the plate by an analytic
+thin slab, and tank_O.obj by an analytic O: a round pillar in the middle of the tank (mesh frame: a cylinder about y)."""
+import numpy as np
+
+from fluidlab_amd.configs.macros import RIGID, TANK, WATER
+from fluidlab_amd.fluidengine.losses import GatheringOLoss
+from fluidlab_amd.fluidengine.meshes import sdf_box, sdf_cylinder
+from fluidlab_amd.fluidengine.taichi_env import TaichiEnv
+from fluidlab_amd.optimizer.policies import ActionsPolicy, GatheringOPolicy
+from fluidlab_amd.utils.config import CfgNode
+from fluidlab_amd.utils.misc import get_cfg_path
+from .fluid_env import FluidEnv
+
+
+class GatheringOEnv(FluidEnv):
+    def __init__(self, version=0, loss=True, loss_type='diff', seed=None, renderer_type=None, quality=1, particle_density=1e6, horizon=3600,
+                 max_substeps_local=50, ckpt_dest='disk', engine_lib=None, device=0):
+        if seed is not None:
+            self.seed(seed)
+        self.horizon = horizon
+        self.horizon_action = horizon
+        self.target_file = None
+        self._n_obs_ptcls_per_body = 500
+        self.loss = loss
+        self.loss_type = loss_type
+        self.action_range = np.array([-0.003, 0.003])
+        self.taichi_env = TaichiEnv(dim=3, quality=quality, particle_density=particle_density, max_substeps_local=max_substeps_local,
+                                    gravity=(0.0, -20.0, 0.0), horizon=self.horizon, ckpt_dest=ckpt_dest, engine_lib=engine_lib, device=device)
+        self.build_env()
+        self.gym_misc()
+
+    def setup_agent(self):
+        agent_cfg = CfgNode()
+        agent_cfg.merge_from_file(get_cfg_path('agent_gatheringO.yaml'))
+        agent_cfg.effectors[0]['mesh']['sdf'] = sdf_box((0.06, 0.5, 0.5))         # plate.obj stand-in: a thin slab
+        agent_cfg.effectors[0]['mesh']['sdf_res'] = 64
+        self.taichi_env.setup_agent(agent_cfg)
+        self.agent = self.taichi_env.agent
+
+    def setup_statics(self):
+        # tank_O.obj stand-in: the island of the O.  With scale (1.0, 0.92, 0.92) a mesh-frame cylinder of radius 0.2 is a pillar
+        # of radius ~0.19 around (0.5, *, 0.5), leaving a channel ~0.13 wide to the walls at z = 0.18 / 0.82.
+        self.taichi_env.add_static(file='tank_O.obj', pos=(0.5, 0.4, 0.5), euler=(0.0, 0.0, 0.0), scale=(1.0, 0.92, 0.92), material=TANK,
+                                   has_dynamics=True, sdf=sdf_cylinder(radius=0.2, half_height=0.5), sdf_res=64)
+
+    def setup_bodies(self):
+        self.taichi_env.add_body(type='cube', lower=(0.05, 0.3, 0.17), upper=(0.95, 0.45, 0.83), material=WATER)
+        # duck.obj stand-ins (see gatheringeasy_env.py on why boxes with three different edge lengths)
+        self.taichi_env.add_body(type='cube', lower=(0.84, 0.47, 0.42), upper=(0.92, 0.52, 0.48), material=RIGID)
+        self.taichi_env.add_body(type='cube', lower=(0.22, 0.47, 0.74), upper=(0.28, 0.53, 0.82), material=RIGID)
+
+    def setup_boundary(self):
+        self.taichi_env.setup_boundary(type='cube', lower=(0.06, 0.3, 0.18), upper=(0.94, 0.95, 0.82))
+
+    def setup_loss(self):
+        self.taichi_env.setup_loss(loss_cls=GatheringOLoss, type=self.loss_type, matching_mat=RIGID, weights={'dist': 1.0})
+
+    def demo_policy(self):
+        """gatheringo_env.py:118-126: a constant push along +x"""
+        acts = np.zeros((self.horizon_action + 1, self.agent.action_dim))
+        acts[:-1] = np.array([0.003, 0.0, 0.0])
+        acts[-1] = np.array([0.5, 0.45, 0.5])
+        return ActionsPolicy(acts)
+
+    def trainable_policy(self, optim_cfg, init_range):
+        return GatheringOPolicy(optim_cfg, init_range, self.agent.action_dim, self.horizon_action, self.action_range, fix_dim=[1, 2])

@@ -1,0 +1,70 @@
+"""Mixing-v0 (fluidlab/envs/mixing_env.py): a block of viscous milk dropped on viscous coffee in a cup, stirred by a Rigid rod
+in cycles (MixingPolicy); the loss rewards spreading the milk (MixingLoss: minus the pairwise L1 distance of a tenth of the
+milk particles).  The stirrer's collision mesh is analytic (fluidengine/meshes.py: sdf_stirrer); cup.obj is visual only."""
+import numpy as np
+
+from fluidlab_amd.configs.macros import COFFEE_VIS, CUP, MILK_VIS
+from fluidlab_amd.fluidengine.losses import MixingLoss
+from fluidlab_amd.fluidengine.meshes import sdf_stirrer
+from fluidlab_amd.fluidengine.taichi_env import TaichiEnv
+from fluidlab_amd.optimizer.policies import ActionsPolicy, MixingPolicy
+from fluidlab_amd.utils.config import CfgNode
+from fluidlab_amd.utils.misc import get_cfg_path
+from .fluid_env import FluidEnv
+
+
+class MixingEnv(FluidEnv):
+    def __init__(self, version=0, loss=True, loss_type='diff', seed=None, renderer_type=None, quality=1, particle_density=1e6, horizon=2000,
+                 max_substeps_local=50, ckpt_dest='disk', engine_lib=None, device=0):
+        if seed is not None:
+            self.seed(seed)
+        self.horizon = horizon
+        self.horizon_action = horizon
+        self.target_file = None
+        self._n_obs_ptcls_per_body = 1000
+        self.loss = loss
+        self.loss_type = loss_type
+        self.action_range = np.array([-0.007, 0.007])
+        self.taichi_env = TaichiEnv(dim=3, quality=quality, particle_density=particle_density, max_substeps_local=max_substeps_local,
+                                    gravity=(0.0, -20.0, 0.0), horizon=self.horizon, ckpt_dest=ckpt_dest, engine_lib=engine_lib, device=device)
+        self.build_env()
+        self.gym_misc()
+
+    def setup_agent(self):
+        agent_cfg = CfgNode()
+        agent_cfg.merge_from_file(get_cfg_path('agent_mixing.yaml'))
+        agent_cfg.effectors[0]['mesh']['sdf'] = sdf_stirrer()
+        agent_cfg.effectors[0]['mesh']['sdf_res'] = 64
+        self.taichi_env.setup_agent(agent_cfg)
+        self.agent = self.taichi_env.agent
+
+    def setup_statics(self):
+        self.taichi_env.add_static(file='cup.obj', pos=(0.63, 0.42, 0.5), euler=(0.0, 0.0, 0.0), scale=(1.2, 1.2, 1.2), material=CUP,
+                                   has_dynamics=False)
+
+    def setup_bodies(self):
+        self.taichi_env.add_body(type='cube', lower=(0.425, 0.55, 0.425), upper=(0.575, 0.7, 0.575), material=MILK_VIS)
+        self.taichi_env.add_body(type='cylinder', center=(0.5, 0.475, 0.5), height=0.15, radius=0.42, material=COFFEE_VIS)
+
+    def setup_boundary(self):
+        self.taichi_env.setup_boundary(type='cylinder', xz_radius=0.42, xz_center=(0.5, 0.5), y_range=(0.4, 0.95))
+
+    def setup_loss(self):
+        self.taichi_env.setup_loss(loss_cls=MixingLoss, type=self.loss_type, target_file=self.target_file, weights={'dist': 1.0})
+
+    def demo_policy(self, user_input=False):
+        """the reference's demo is a mouse policy (MousePolicy_vxz); scripted here: dip the rod, then sweep back and forth in x"""
+        if user_input:
+            raise NotImplementedError('interactive demonstrations need the renderer')
+        H = self.horizon_action
+        acts = np.zeros((H + 1, self.agent.action_dim))
+        acts[H] = [0.5, 0.73, 0.5]
+        step = 0.8 * self.action_range[1]
+        h0 = max(1, min(H // 5, int(0.15 / step)))
+        acts[:h0, 1] = -step
+        k = np.arange(H - h0)
+        acts[h0:H, 0] = step * np.sign(np.sin(2 * np.pi * (k + 0.5) / max(40, 1)))
+        return ActionsPolicy(acts)
+
+    def trainable_policy(self, optim_cfg, init_range):
+        return MixingPolicy(optim_cfg, init_range, self.agent.action_dim, self.horizon_action, self.action_range, fix_dim=[1])

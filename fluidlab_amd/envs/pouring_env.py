@@ -1,0 +1,72 @@
+"""Pouring-v0 (fluidlab/envs/pouring_env.py): a glass holding a column of milk under a column of water is tilted (6-dof Rigid,
+only the last angular component is trained) so that the water pours out while the milk stays; particles that leave the
+collector box are taken out of the simulation.  The agent collides at the particles and at the grid nodes
+(AgentPouring: collide_type='both').
+
+The glass' collision mesh (glass.obj, absent here) is an analytic open-top cup in the mesh frame.  `quality`,
+`particle_density`, `horizon` scale the scene for tests."""
+import numpy as np
+
+from fluidlab_amd.configs.macros import MILK, WATER
+from fluidlab_amd.fluidengine.losses import PouringLoss
+from fluidlab_amd.fluidengine.meshes import sdf_cup
+from fluidlab_amd.fluidengine.taichi_env import TaichiEnv
+from fluidlab_amd.optimizer.policies import ActionsPolicy, PouringPolicy
+from fluidlab_amd.utils.config import CfgNode
+from fluidlab_amd.utils.misc import get_cfg_path
+from .fluid_env import FluidEnv
+
+
+class PouringEnv(FluidEnv):
+    def __init__(self, version=0, loss=True, loss_type='diff', seed=None, renderer_type=None, quality=1, particle_density=1e6, horizon=1000,
+                 max_substeps_local=20, ckpt_dest='disk', engine_lib=None, device=0):
+        if seed is not None:
+            self.seed(seed)
+        self.horizon = horizon
+        self.horizon_action = horizon
+        self.target_file = None
+        self._n_obs_ptcls_per_body = 500
+        self.loss = loss
+        self.loss_type = loss_type
+        self.action_range = np.array([-0.02, 0.02])
+        self.taichi_env = TaichiEnv(dim=3, quality=quality, particle_density=particle_density, max_substeps_local=max_substeps_local,
+                                    gravity=(0.0, -20.0, 0.0), horizon=self.horizon, ckpt_dest=ckpt_dest, engine_lib=engine_lib, device=device)
+        self.build_env()
+        self.gym_misc()
+
+    def setup_agent(self):
+        agent_cfg = CfgNode()
+        agent_cfg.merge_from_file(get_cfg_path('agent_pouring.yaml'))
+        # glass.obj stand-in: with scale (0.75, 0.65, 0.75) a cup of radius 0.3 / height 1 in the mesh frame is 0.225 wide and
+        # 0.65 tall in the world and holds the two liquid columns (radius 0.18, 0.43 <= y <= 0.83) when centred at (0.6, 0.7, 0.5)
+        agent_cfg.effectors[0]['mesh']['sdf'] = sdf_cup(radius=0.3, half_height=0.5, wall=0.05)
+        agent_cfg.effectors[0]['mesh']['sdf_res'] = 64
+        self.taichi_env.setup_agent(agent_cfg)
+        self.agent = self.taichi_env.agent
+
+    def setup_statics(self):
+        pass
+
+    def setup_bodies(self):
+        self.taichi_env.add_body(type='cylinder', center=(0.6, 0.53, 0.5), height=0.2, radius=0.18, material=MILK)
+        self.taichi_env.add_body(type='cylinder', center=(0.6, 0.73, 0.5), height=0.2, radius=0.18, material=WATER)
+
+    def setup_boundary(self):
+        self.taichi_env.setup_boundary(type='cube', lower=(0.05, 0.05, 0.05), upper=(0.95, 0.95, 0.95))
+
+    def setup_loss(self):
+        self.taichi_env.setup_loss(loss_cls=PouringLoss, type=self.loss_type, weights={'dist': 1.0, 'attraction': 1.0})
+
+    def demo_policy(self, user_input=False):
+        """the reference's demo is a keyboard policy (KeyboardPolicy_wz, v_ang 0.015 per step while a key is held); scripted here:
+        hold for a tenth of the horizon, then tilt about z at the exp config's constant rate"""
+        if user_input:
+            raise NotImplementedError('interactive demonstrations need the renderer')
+        H = self.horizon_action
+        acts = np.zeros((H + 1, self.agent.action_dim))
+        acts[H // 10:H, 5] = 0.00115 * 1000 / H * 10 / 9
+        acts[H] = [0.6, 0.7, 0.5, 0.0, 0.0, 0.0]
+        return ActionsPolicy(acts)
+
+    def trainable_policy(self, optim_cfg, init_range):
+        return PouringPolicy(optim_cfg, init_range, self.agent.action_dim, self.horizon_action, self.action_range, fix_dim=[0, 1, 2, 3, 4])

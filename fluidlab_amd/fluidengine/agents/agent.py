@@ -4,6 +4,9 @@ import numpy as np
 from fluidlab_amd.fluidengine import effectors as _effectors
 
 
+COLLIDE_TYPE_ID = {'particle': 1, 'grid': 2, 'both': 3}        # the engine's "collide_type" option (mpm:393-395, 418-422)
+
+
 class Agent:
     def __init__(self, max_substeps_local, max_substeps_global, max_action_steps_global, ckpt_dest, collide_type='particle'):
         self.max_substeps_local = max_substeps_local
@@ -12,9 +15,6 @@ class Agent:
         self.ckpt_dest = ckpt_dest
         self.collide_type = collide_type
         assert self.collide_type in ['particle', 'grid', 'both']
-        if self.collide_type != 'particle':
-            # no reference config overrides the default (agent.py:17); grid-level agent.collide (mpm:392-395) is not built
-            raise NotImplementedError("collide_type 'grid'/'both' is not supported: agent.collide runs at particle level")
         self.effectors = []
         self.action_dims = [0]
 
@@ -34,6 +34,7 @@ class Agent:
         for effector in self.effectors:
             effector.sim = sim
             effector.build(sim.engine)
+        sim.engine.set_option('collide_type', COLLIDE_TYPE_ID[self.collide_type])
 
     def reset_grad(self):
         pass            # effector adjoints are zeroed by the engine's reset_grad (effector.py:76-82)

@@ -1,0 +1,57 @@
+"""TransportingLoss (fluidlab/fluidengine/losses/transporting_loss.py): drive the RIGID_HEAVY cube towards x = 0.9 (L1 on
+every particle of the cube, :88-91) and, in the 'diff' variant, attract the used WATER particles to it -- 1e-4 times the L1
+distance of every (water, cube) particle pair (:94-99), summed here without forming the pairs (host_loss.pairwise_l1)."""
+import numpy as np
+
+from fluidlab_amd.configs.macros import RIGID_HEAVY, WATER
+from .host_loss import HostLoss, pairwise_l1
+
+
+class TransportingLoss(HostLoss):
+    temporal_range_type = 'all'               # the reference overrides its own 'expand' setting (:33-34)
+
+    def __init__(self, type, **kwargs):
+        super().__init__(**kwargs)
+        assert type in ('diff', 'default')
+        self.type = type
+
+    def build(self, sim):
+        self.dist_weight = self.weights['dist']
+        self._dist = np.zeros((self.max_loss_steps,), np.float64)
+        self._attraction = np.zeros((self.max_loss_steps,), np.float64)
+        super().build(sim)
+        mat = self.particle_mat
+        self.n_particles_water = int((mat == WATER).sum())           # the water pool comes first (transporting_env.py:47-52)
+        self.obj_start = self.n_particles_water
+        self.obj_end = self.obj_start + int((mat == RIGID_HEAVY).sum())
+
+    def clear_loss(self):
+        super().clear_loss()
+        if hasattr(self, '_dist'):
+            self._dist[:] = 0; self._attraction[:] = 0
+
+    def step_value(self, s, f, x, used, want_grad):
+        xd = x.astype(np.float64)
+        obj = xd[self.obj_start:self.obj_end]
+        dist = float(np.abs(obj[:, 0] - 0.9).sum())
+        g = np.zeros_like(xd) if want_grad else None
+        if want_grad:
+            g[self.obj_start:self.obj_end, 0] = np.sign(obj[:, 0] - 0.9) * self.dist_weight
+        attraction = 0.0
+        if self.type == 'diff':
+            w = np.where(used[:self.n_particles_water])[0]
+            attraction, gw, gobj = pairwise_l1(xd[w], obj)
+            attraction *= 1e-4
+            if want_grad:
+                g[w] += gw * 1e-4
+                g[self.obj_start:self.obj_end] += gobj * 1e-4
+        if not want_grad:
+            self._dist[s] += dist; self._attraction[s] += attraction
+        return dist * self.dist_weight + attraction, g
+
+    def final_loss_info(self):
+        return {'dist_loss': float(self._dist.sum()), 'attraction_loss': float(self._attraction.sum())}
+
+    def get_step_loss(self):
+        cur = self.cur_step_loss()
+        return {'reward': 0.05 * (135 - cur), 'loss': cur}                 # :149-156

@@ -137,3 +137,54 @@ class IceCreamStaticPolicy(TrainablePolicy):
         super().optimize(np.clip(grads, -1e5, 1e5), loss_info)
         if loss_info['temporal_range'] > 450:
             self.optim.lr = self.optim.init_lr * 0.1
+
+
+class GatheringOPolicy(GatheringPolicy):
+    """policies.py:262-303: GatheringPolicy's 120-step sweep (50 trainable steps, up, back, down) without the freezing."""
+
+    def optimize(self, grads, loss_info):
+        TrainablePolicy.optimize(self, grads, loss_info)
+
+
+class MixingPolicy(TrainablePolicy):
+    """policies.py:306-338: cycles of 80 steps -- 50 trainable stirring steps, then 30 steps back to the rest pose above the
+    cup; once the loss' temporal range has passed a cycle boundary the cycles more than two back are frozen."""
+    rest_pos = np.array([0.5, 0.73, 0.5])
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.trainable = np.full(self.comp_actions_shape[0], False)
+        self.status = np.full(self.comp_actions_shape[0], 0)
+        self.stage_step = [50, 80]
+        for i in range(self.horizon):
+            if i % self.stage_step[1] < self.stage_step[0]:
+                self.trainable[i] = True
+                self.status[i] = 0          # moving
+            else:
+                self.status[i] = 1          # moving back
+
+    def get_action_v(self, i, agent=None, update=False):
+        if update and self.status[i] == 1:
+            self.actions_v[i] = (self.rest_pos - agent.rigid.latest_pos.to_numpy()[0]) / (self.stage_step[1] - (i % self.stage_step[1]))
+        return self.actions_v[i]
+
+    def optimize(self, grads, loss_info):
+        super().optimize(grads, loss_info)
+        for step in list(range(80, 2000, 80))[::-1]:
+            if loss_info['temporal_range'] > step:
+                self.freeze_till = loss_info['temporal_range'] - 160
+                self.trainable[:max(self.freeze_till, 0)] = False
+                break
+
+
+class PouringPolicy(TrainablePolicy):
+    """policies.py:357-359"""
+
+
+class TransportingPolicy(TrainablePolicy):
+    """policies.py:362-366: the initial pose is not optimised"""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.trainable = np.full(self.comp_actions_shape[0], False)
+        self.trainable[:-1] = True

@@ -206,3 +206,70 @@ def test_gathering_easy_on_the_gpu(hiplib, oracle32):
     assert abs(la - lb) <= 1e-3 * abs(lb)
     # contact + rigid-body SVD adjoint are ill-conditioned in fp32: the oracle's own f32 and f64 builds agree to cos 0.946 here
     assert np.isfinite(ga).all() and S.cosine(ga, gb) >= 0.8
+
+
+def _both(hiplib_unused, oracle32, name, cfg_file, prepare, horizon, **kw):
+    """the same reduced environment through the Solver on the HIP engine and on the oracle"""
+    import test_host_env as H
+    res = []
+    for lib in (None, oracle32):
+        env = H._small(name, lib, horizon=horizon, **kw)
+        if hasattr(env.taichi_env.loss, 'temporal_range'):
+            env.taichi_env.loss.temporal_range[1] = env.horizon
+        info, g, pol = H._solver_pass(env, cfg_file, prepare)
+        fin = H._final_frame(env.taichi_env, horizon)
+        res.append((fin['x'], fin['used'], info['loss'], g))
+    return res
+
+
+def test_pouring_on_the_gpu(hiplib, oracle32):
+    """Pouring-v0 reduced (collide_type='both' + collector + PouringLoss), HIP vs oracle through the Solver."""
+    def prepare(pol):
+        pol.actions_v[:, 5] = 0.02
+    (xa, ua, la, ga), (xb, ub, lb, gb) = _both(hiplib, oracle32, 'Pouring-v0', 'configs/exp_pouring.yaml', prepare, 10)
+    assert (ua == ub).all()
+    assert np.quantile(np.abs(xa - xb).max(1), 0.99) <= 1e-4
+    assert abs(la - lb) <= 1e-3 * abs(lb)
+    assert np.isfinite(ga).all() and S.cosine(ga[:, 5], gb[:, 5]) >= 0.99, S.cosine(ga[:, 5], gb[:, 5])
+
+
+def test_transporting_on_the_gpu(hiplib, oracle32):
+    """Transporting-v0 reduced (turning Injector + WATER collector + RIGID_HEAVY cube, z locked), HIP vs oracle."""
+    def prepare(pol):
+        pol.actions_p[:] = [0.42, 0.5, 0.5, 0.0, 0.0, 0.0]
+        pol.actions_v[:, 5] = 0.002
+    (xa, ua, la, ga), (xb, ub, lb, gb) = _both(hiplib, oracle32, 'Transporting-v0', 'configs/exp_transporting.yaml', prepare, 10,
+                                               n_pool=400, particle_density=2e5)
+    assert (ua == ub).all() and ua[:400].sum() == 400
+    assert np.quantile(np.abs(xa - xb).max(1), 0.99) <= 1e-4
+    assert abs(la - lb) <= 1e-3 * abs(lb)
+    assert np.isfinite(ga).all() and S.cosine(ga[:, [0, 5]], gb[:, [0, 5]]) >= 0.9, S.cosine(ga[:, [0, 5]], gb[:, [0, 5]])
+
+
+def test_mixing_on_the_gpu(hiplib, oracle32):
+    """Mixing-v0 reduced (viscous liquids, Rigid stirrer, pairwise-spread loss), HIP vs oracle."""
+    def prepare(pol):
+        pol.actions_p[:] = [0.5, 0.62, 0.5]
+        pol.actions_v[:, 0] = 0.005
+    (xa, ua, la, ga), (xb, ub, lb, gb) = _both(hiplib, oracle32, 'Mixing-v0', 'configs/exp_mixing.yaml', prepare, 10)
+    assert np.quantile(np.abs(xa - xb).max(1), 0.99) <= 1e-4
+    assert abs(la - lb) <= 1e-3 * abs(lb)
+    assert np.isfinite(ga).all() and S.cosine(ga, gb) >= 0.99, S.cosine(ga, gb)
+
+
+def test_gathering_o_on_the_gpu(hiplib, oracle32):
+    """GatheringO-v0 reduced (static island in grid_op + Rigid plate + rigid bodies), HIP vs oracle."""
+    def prepare(pol):
+        pol.actions_v[:, 0] = 0.003
+    (xa, ua, la, ga), (xb, ub, lb, gb) = _both(hiplib, oracle32, 'GatheringO-v0', 'configs/exp_gatheringO.yaml', prepare, 12)
+    # like the reference, the water block is sampled over the whole tank, island included (gatheringo_env.py:54-59); water
+    # inside the island sits where the SDF normal flips between voxels, and takes different contact branches in two fp32
+    # implementations: compare the water around it
+    away = np.hypot(xb[:, 0] - 0.5, xb[:, 2] - 0.5) > 0.25
+    assert away.sum() > 1500
+    # ... and even there nodes on the island's surface flip between contact and free under rounding: the oracle's own f32 and f64
+    # builds differ by 4.6e-3 at the 99th percentile of this scene (max 1.6e-2, action-gradient cosine 0.977)
+    d = np.abs(xa - xb).max(1)
+    assert np.median(d) <= 5e-6 and np.quantile(d[away], 0.99) <= 2e-3 and d.max() <= 2e-2
+    assert abs(la - lb) <= 1e-3 * abs(lb)
+    assert np.isfinite(ga).all() and S.cosine(ga, gb) >= 0.8, S.cosine(ga, gb)
