@@ -68,7 +68,7 @@ ABI_SYMBOLS = [
     'fe_add_static', 'fe_eff_set_mesh', 'fe_add_effector', 'fe_eff_set_act_range', 'fe_eff_get_state', 'fe_eff_set_state',
     'fe_eff_get_vw', 'fe_eff_set_vw', 'fe_eff_get_sr', 'fe_eff_set_sr', 'fe_eff_set_action', 'fe_eff_set_action_grad',
     'fe_eff_apply_action_p', 'fe_eff_apply_action_p_grad', 'fe_eff_get_action_grad',
-    'fe_agent_copy_frame', 'fe_agent_copy_grad', 'fe_agent_reset_grad_till_frame', 'fe_agent_set_collector', 'fe_loss_alloc', 'fe_loss_set_target',
+    'fe_agent_copy_frame', 'fe_agent_copy_grad', 'fe_agent_reset_grad_till_frame', 'fe_agent_set_collector', 'fe_mesh_sdf', 'fe_loss_alloc', 'fe_loss_set_target',
     'fe_loss_clear', 'fe_loss_step', 'fe_loss_step_grad', 'fe_loss_get', 'fe_get_stats',
     'fe_smoke_create', 'fe_smoke_step', 'fe_smoke_step_grad', 'fe_smoke_get_frame', 'fe_smoke_set_frame', 'fe_smoke_get_grad',
     'fe_smoke_add_grad', 'fe_smoke_copy_frame', 'fe_smoke_copy_grad', 'fe_smoke_reset_grad', 'fe_smoke_reset_grad_till_frame',
@@ -109,6 +109,17 @@ class EngineLib:
         lib.fe_timer_stop_ms.restype = C.c_double
         lib.fe_timer_stop_ms.argtypes = [C.c_void_p]
         lib.fe_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+
+    def mesh_sdf(self, verts, faces, points, device=0):
+        """fe_mesh_sdf: signed distance of points[M,3] to the triangle mesh (verts[nv,3], faces[nf,3]); float32 out."""
+        v = np.ascontiguousarray(verts, np.float32); f = np.ascontiguousarray(faces, np.int32); p = np.ascontiguousarray(points, np.float32)
+        assert v.ndim == 2 and v.shape[1] == 3 and f.ndim == 2 and f.shape[1] == 3 and p.ndim == 2 and p.shape[1] == 3
+        out = np.empty((len(p),), np.float32)
+        rc = self.lib.fe_mesh_sdf(int(device), v.ctypes.data_as(C.c_void_p), len(v), f.ctypes.data_as(C.c_void_p), len(f),
+                                  p.ctypes.data_as(C.c_void_p), C.c_longlong(len(p)), out.ctypes.data_as(C.c_void_p))
+        if rc != 0:
+            raise FeEngineError(self.lib.fe_last_error(None).decode())
+        return out
 
     def missing_symbols(self):
         return [s for s in ABI_SYMBOLS if not hasattr(self.lib, s)]
@@ -176,6 +187,7 @@ class Engine:
         cfg.gravity[:] = [float(g) for g in gravity]
         cfg.boundary = boundary
         cfg.device = int(device)
+        self.device = int(device)
         self.cfg = cfg
         self.N = int(n_particles)
         self.h = self.lib.fe_create(C.byref(cfg))

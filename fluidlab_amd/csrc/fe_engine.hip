@@ -2309,6 +2309,7 @@ int check_device_errors(FeEngine* h) {
 // C ABI
 // =========================================================================================
 #include "fe_smoke.h"
+#include "fe_mesh.h"
 
 extern "C" {
 
@@ -2866,6 +2867,28 @@ int fe_loss_get(FeEngine* h, fe_real* step_loss, int n) {
 }
 
 // ---- measurement
+// utils/mesh.py:63-96 (mesh_to_sdf): exact signed distance of arbitrary points to a triangle mesh, see fe_mesh.h
+int fe_mesh_sdf(int device, const float* verts, int nv, const int* faces, int nf, const float* points, long long n_points, float* sdf) {
+    if (nv <= 0 || nf <= 0 || n_points < 0 || !verts || !faces || (n_points > 0 && (!points || !sdf))) { g_create_err = "fe_mesh_sdf: invalid arguments"; return 1; }
+    for (long long i = 0; i < (long long)nf * 3; i++) if (faces[i] < 0 || faces[i] >= nv) { g_create_err = "fe_mesh_sdf: face index out of range"; return 1; }
+    if (n_points == 0) return 0;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_create_err = "no HIP device visible: the MI355X engine has no CPU fallback"; return 1; }
+    if (device < 0 || device >= ndev || hipSetDevice(device) != hipSuccess) { g_create_err = "HIP device ordinal out of range"; return 1; }
+    float *dv = nullptr, *dp = nullptr, *ds = nullptr; int* df = nullptr;
+    auto done = [&](int rc, const char* msg) { if (msg) g_create_err = msg; (void)hipFree(dv); (void)hipFree(df); (void)hipFree(dp); (void)hipFree(ds); return rc; };
+    if (hipMalloc(&dv, sizeof(float) * 3 * nv) != hipSuccess || hipMalloc(&df, sizeof(int) * 3 * nf) != hipSuccess ||
+        hipMalloc(&dp, sizeof(float) * 3 * n_points) != hipSuccess || hipMalloc(&ds, sizeof(float) * n_points) != hipSuccess)
+        return done(1, "fe_mesh_sdf: hipMalloc failed");
+    if (hipMemcpy(dv, verts, sizeof(float) * 3 * nv, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(df, faces, sizeof(int) * 3 * nf, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(dp, points, sizeof(float) * 3 * n_points, hipMemcpyHostToDevice) != hipSuccess)
+        return done(1, "fe_mesh_sdf: upload failed");
+    hipLaunchKernelGGL(k_mesh_sdf, dim3((unsigned)((n_points + 255) / 256)), dim3(256), 0, 0, dv, df, nf, dp, n_points, ds);
+    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) return done(1, "fe_mesh_sdf: kernel failed");
+    if (hipMemcpy(sdf, ds, sizeof(float) * n_points, hipMemcpyDeviceToHost) != hipSuccess) return done(1, "fe_mesh_sdf: download failed");
+    return done(0, nullptr);
+}
+
 int fe_get_stats(FeEngine* h, int f, FeStats* out) {
     CHECK_FRAME(h, f);
     const int ncell = h->nb * h->nb * h->nb * 64;

@@ -4,6 +4,8 @@ collider with softness, its pose adjoint and an L1 loss on the bodies' particles
 
 The reference's ducks are mesh bodies (trimesh voxelisation, unavailable here): two rigid boxes stand in, at the ducks' places.
 The plate's collision mesh is an analytic thin box.  `quality`, `particle_density`, `horizon` scale the scene for tests."""
+import os
+
 import numpy as np
 
 from fluidlab_amd.configs.macros import RIGID, TANK, WATER
@@ -12,6 +14,7 @@ from fluidlab_amd.fluidengine.meshes import sdf_box
 from fluidlab_amd.fluidengine.taichi_env import TaichiEnv
 from fluidlab_amd.optimizer.policies import GatheringPolicy
 from fluidlab_amd.utils.config import CfgNode
+from fluidlab_amd.utils.mesh import get_raw_mesh_path
 from fluidlab_amd.utils.misc import get_cfg_path
 from .fluid_env import FluidEnv
 
@@ -47,6 +50,12 @@ class GatheringEasyEnv(FluidEnv):
 
     def setup_bodies(self):
         self.taichi_env.add_body(type='cube', lower=(0.05, 0.3, 0.17), upper=(0.95, 0.45, 0.83), material=WATER)
+        if os.path.exists(get_raw_mesh_path('duck.obj')):            # the asset tree has the ducks: the reference's mesh bodies (:61-80)
+            self.taichi_env.add_body(type='mesh', file='duck.obj', pos=(0.22, 0.5, 0.45), scale=(0.10, 0.10, 0.10), euler=(0, -75.0, 0.0),
+                                     color=(1.0, 1.0, 0.3, 1.0), filling='grid', material=RIGID)
+            self.taichi_env.add_body(type='mesh', file='duck.obj', pos=(0.28, 0.5, 0.57), scale=(0.10, 0.10, 0.10), euler=(0, -95.0, 0.0),
+                                     color=(1.0, 0.5, 0.5, 1.0), filling='grid', material=RIGID)
+            return
         # duck.obj stand-ins: boxes with three different edge lengths.  (A ball's covariance H is isotropic, its singular values
         # coincide, and the reference's SVD adjoint 1/clamp(s_j^2 - s_i^2) (mpm:272-292) then amplifies rounding noise: fp32 and fp64
         # runs of the same code disagree in the gradient.)

@@ -3,6 +3,8 @@ flow around -- a static SDF collider inside grid_op -- with the goal at (0.88, 0
 
 Assets absent here are replaced: the ducks (duck.obj mesh bodies) by two rigid boxes at their places, the plate by an analytic
 thin slab, and tank_O.obj by an analytic O: a round pillar in the middle of the tank (mesh frame: a cylinder about y)."""
+import os
+
 import numpy as np
 
 from fluidlab_amd.configs.macros import RIGID, TANK, WATER
@@ -11,6 +13,7 @@ from fluidlab_amd.fluidengine.meshes import sdf_box, sdf_cylinder
 from fluidlab_amd.fluidengine.taichi_env import TaichiEnv
 from fluidlab_amd.optimizer.policies import ActionsPolicy, GatheringOPolicy
 from fluidlab_amd.utils.config import CfgNode
+from fluidlab_amd.utils.mesh import get_raw_mesh_path
 from fluidlab_amd.utils.misc import get_cfg_path
 from .fluid_env import FluidEnv
 
@@ -48,6 +51,12 @@ class GatheringOEnv(FluidEnv):
 
     def setup_bodies(self):
         self.taichi_env.add_body(type='cube', lower=(0.05, 0.3, 0.17), upper=(0.95, 0.45, 0.83), material=WATER)
+        if os.path.exists(get_raw_mesh_path('duck.obj')):            # the asset tree has the ducks: the reference's mesh bodies (:60-79)
+            self.taichi_env.add_body(type='mesh', file='duck.obj', pos=(0.88, 0.5, 0.45), scale=(0.10, 0.10, 0.10), euler=(0, -75.0, 0.0),
+                                     color=(1.0, 1.0, 0.3, 1.0), filling='grid', material=RIGID)
+            self.taichi_env.add_body(type='mesh', file='duck.obj', pos=(0.25, 0.5, 0.78), scale=(0.10, 0.10, 0.10), euler=(0, -95.0, 0.0),
+                                     color=(1.0, 0.5, 0.5, 1.0), filling='grid', material=RIGID)
+            return
         # duck.obj stand-ins (see gatheringeasy_env.py on why boxes with three different edge lengths)
         self.taichi_env.add_body(type='cube', lower=(0.84, 0.47, 0.42), upper=(0.92, 0.52, 0.48), material=RIGID)
         self.taichi_env.add_body(type='cube', lower=(0.22, 0.47, 0.74), upper=(0.28, 0.53, 0.82), material=RIGID)

@@ -2,17 +2,21 @@
 
 Pure host NumPy and part of the input contract: every add_body() re-seeds the global RNG with 0 and
 restores it (bodies.py:27-28,44), so scenes are reproducible and identical to the reference's.
-Mesh bodies need the trimesh voxeliser, which this image lacks (SURVEY 2 #8: out of scope)."""
+Mesh bodies (bodies.py:187-210) reject the samples of a box against the voxelised mesh; the voxelisation is the engine
+library's `fe_mesh_sdf` (fluidlab_amd/utils/mesh.py) in the place of trimesh's."""
 import numpy as np
 from scipy.spatial.transform import Rotation
 
 from fluidlab_amd.configs.macros import COLOR, MAT_NAME, NOWHERE, RHO
+from fluidlab_amd.utils import mesh as mesh_utils
 
 
 class Bodies:
-    def __init__(self, dim, particle_density):
+    def __init__(self, dim, particle_density, elib=None, device=0):
         self.dim = dim
         self.particle_density = particle_density
+        self._elib = elib        # callable returning the engine library (mesh bodies only)
+        self._device = device
         self._parts = []        # one dict per body
 
     def __len__(self):
@@ -72,7 +76,15 @@ class Bodies:
             pts = self._box(center - radius, center + radius, filling)
             return pts[np.linalg.norm(pts - center, axis=1) <= radius], True, kw
         if type == 'mesh':
-            raise NotImplementedError('mesh bodies need trimesh voxelisation, not available here (SURVEY 2 #8)')
+            # add_mesh, bodies.py:187-210: sample the box pos +- scale / 2, keep what falls into filled voxels of the normalised mesh
+            assert filling != 'natural', 'natural filling not supported for body type: mesh.'
+            file, voxelize_res = kw.pop('file'), kw.pop('voxelize_res', 128)
+            pos, scale = np.array(kw.pop('pos', (0.5, 0.5, 0.5))), np.array(kw.pop('scale', (1.0, 1.0, 1.0)))
+            if self._elib is None:
+                raise NotImplementedError('mesh bodies need the engine library for the voxelisation: Bodies(elib=...)')
+            voxels = mesh_utils.load_or_voxelize(file, voxelize_res, self._elib(), self._device)
+            pts = self._box(pos - scale * 0.5, pos + scale * 0.5, filling)
+            return pts[voxels.is_filled((pts - pos) / scale)], True, kw
         raise NotImplementedError(f'Unsupported body type: {type}.')
 
     def add_body(self, type, filling='random', **kwargs):

@@ -17,5 +17,6 @@ class Rigid(Effector):
     def build(self, engine):
         super().build(engine)
         if self.mesh is not None:
+            self.mesh.prepare(engine.elib, engine.device)
             engine.eff_set_mesh(self.index, self.mesh.sdf_voxels_np.astype(engine.dtype), self.mesh.T_mesh_to_voxels_np,
                                 friction=self.mesh.friction, softness=self.mesh.softness)

@@ -1,8 +1,9 @@
 """Static SDF colliders -- fluidlab/fluidengine/meshes/{mesh,static,statics}.py.
 
 The reference turns a triangle mesh into a signed-distance voxel grid with `mesh_to_sdf` + `trimesh` (utils/mesh.py:
-63-87) and caches it as a pickle {'voxels': [res^3], 'T_mesh_to_voxels': 4x4}.  Neither package exists in this image
-and the reference ships no processed .sdf blobs, so a collider's SDF comes from one of:
+63-87) and caches it as a pickle {'voxels': [res^3], 'T_mesh_to_voxels': 4x4}.  Here the conversion is the engine library's
+`fe_mesh_sdf` (fluidlab_amd/utils/mesh.py), used whenever `file` exists in the asset tree ($FLUIDLAB_ASSETS/meshes/raw).  The
+reference's mesh assets are not part of this repository; without them a collider's SDF comes from one of:
   * `sdf=<path>`   a pickle in the reference's format (produced by the reference's tooling elsewhere),
   * `sdf=<dict>`   the same two arrays in memory,
   * `sdf=<callable>` an analytic signed distance f(points[N,3]) -> [N] in the *mesh frame* (the normalised frame the
@@ -11,6 +12,7 @@ and the reference ships no processed .sdf blobs, so a collider's SDF comes from 
 Pose handling follows Mesh.init_transform (mesh.py:97-127): T_mesh_to_voxels @ inverse(T_init), T_init = trans * rot *
 scale with euler given in degrees as (x, y, z) and composed 'zyx'.  Collision itself (sdf_, normal_, collide:
 static.py:25-104) runs inside the engine's grid_op; this class only prepares its inputs."""
+import os
 import pickle as pkl
 
 import numpy as np
@@ -18,6 +20,7 @@ from scipy.spatial.transform import Rotation
 
 from fluidlab_amd.configs import macros
 from fluidlab_amd.configs.macros import FRICTION
+from fluidlab_amd.utils import mesh as mesh_utils
 from fluidlab_amd.utils.misc import eval_str
 
 VOXELS_RADIUS = 0.6          # utils/mesh.py:69
@@ -108,15 +111,35 @@ class Static:
             else eval_str(material)
         self.has_dynamics = has_dynamics
         self.softness = softness
+        self._sdf_arg = sdf
+        self._prepared = False
         if not has_dynamics:
+            self._prepared = True
             return                                             # visual only: Static.collide is the identity (static.py:83)
         self.friction = FRICTION[self.material]                # mesh.py:60
-        if sdf is None:
+        if sdf is not None and not self._asset_present():
+            self.prepare(None)                                 # explicit SDF, no mesh file to prefer: ready now
+
+    def _asset_present(self):
+        return self.raw_file is not None and (os.path.exists(mesh_utils.get_raw_mesh_path(self.raw_file))
+                                              or os.path.exists(mesh_utils.get_processed_sdf_path(self.raw_file, self.sdf_res)))
+
+    def prepare(self, elib, device=0):
+        """Mesh.load_file + init_transform (mesh.py:40-63, 97-127), deferred until an engine library can compute the SDF.  The
+        mesh file wins when the asset tree has it (the reference's behaviour); the `sdf=` argument is the stand-in otherwise."""
+        if self._prepared:
+            return
+        sdf = self._sdf_arg
+        if self._asset_present():
+            if elib is None:
+                return                                          # wait for build(): the distance transform runs in the engine library
+            sdf_data = mesh_utils.load_or_compute_sdf(self.raw_file, self.sdf_res, elib, device)
+        elif sdf is None:
             raise NotImplementedError(
-                f'static {file!r}: mesh -> SDF conversion needs trimesh + mesh_to_sdf, which this image lacks; pass '
-                f'sdf=<pickle path | dict | analytic callable> (fluidlab_amd/fluidengine/meshes.py)')
-        if callable(sdf):
-            sdf_data = sample_sdf(sdf, sdf_res)
+                f'collision mesh {self.raw_file!r} is not in the asset tree ({mesh_utils.get_mesh_dir("raw")}; the reference\'s '
+                f'assets are not part of this repository) and no sdf=<pickle path | dict | analytic callable> stand-in was given')
+        elif callable(sdf):
+            sdf_data = sample_sdf(sdf, self.sdf_res)
         elif isinstance(sdf, dict):
             sdf_data = sdf
         else:
@@ -130,6 +153,7 @@ class Static:
         T_init[:3, :3] = rot @ np.diag(self.scale)
         T_init[:3, 3] = self.pos
         self.T_mesh_to_voxels_np = np.asarray(sdf_data['T_mesh_to_voxels'], np.float64) @ np.linalg.inv(T_init)
+        self._prepared = True
 
     def sdf(self, pos_world):
         """host mirror of Static.sdf (static.py:26-49) for tests and scene building"""

@@ -76,6 +76,12 @@ class MPMSimulator:
         self.boundary = create_boundary(**kwargs)
 
     # ------------------------------------------------------------------ build
+    def engine_library(self):
+        """the library this simulator runs on (loads the HIP library on first use; raises when it is not built)"""
+        if self._elib is None:
+            self._elib = _capi.load_hip()
+        return self._elib
+
     def build(self, agent, smoke_field, statics, particles):
         if self.boundary is None:
             self.boundary = create_boundary()                # mpm:44-45
@@ -115,6 +121,7 @@ class MPMSimulator:
         if statics is not None:
             for st in statics:
                 if st.has_dynamics:
+                    st.prepare(self.engine.elib, self._device)
                     self.engine.add_static(st.sdf_voxels_np.astype(self.dtype), st.T_mesh_to_voxels_np, friction=st.friction,
                                            softness=st.softness)
 

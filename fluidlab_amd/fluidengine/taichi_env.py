@@ -28,7 +28,7 @@ class TaichiEnv:
         self.max_substeps_local = self.simulator.max_substeps_local
         self.agent = None
         self.statics = Statics()
-        self.particle_bodies = Bodies(dim=dim, particle_density=particle_density)
+        self.particle_bodies = Bodies(dim=dim, particle_density=particle_density, elib=self.simulator.engine_library, device=device)
         self.renderer = None
         self.loss = None
         self.smoke_field = None

@@ -236,6 +236,16 @@ int fe_loss_step_grad(FeEngine* h, int s, int f, int matching_mat, fe_real weigh
                       fe_real step_loss_grad);
 int fe_loss_get(FeEngine* h, fe_real* step_loss, int n);                          /* step_loss[0..n) */
 
+/* ---- mesh -> signed distance (utils/mesh.py:63-96; the third-party mesh_to_sdf 0.0.x call) --------------------------
+ * Stateless (no engine handle).  sdf[i] = signed distance from points[i] to the triangle mesh (verts[nv,3] f32,
+ * faces[nf,3] i32): the exact point-triangle distance, negative where the generalized winding number of the mesh around
+ * the point exceeds 1/2 in magnitude (either face orientation).  The reference gets an approximation of the same function from mesh_to_sdf's virtual scans
+ * (scan_count 100*res/64, scan_resolution 400, sign from the 11 nearest scan normals); compute_sdf_data samples it on the
+ * res^3 lattice over [-0.6, 0.6]^3, voxelize_mesh / Voxels.is_filled on particle positions (bodies.py:187-210).
+ * `device`: GPU ordinal for the HIP library, ignored by the oracle.  Always float, whatever fe_real is. */
+int fe_mesh_sdf(int device, const float* verts, int nv, const int* faces, int nf,
+                const float* points, long long n_points, float* sdf);
+
 /* ---- measurement ------------------------------------------------------ */
 typedef struct FeStats {
     long long n_used;          /* used particles in the last processed frame            */

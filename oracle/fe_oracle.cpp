@@ -2041,6 +2041,48 @@ int fe_loss_get(FeEngine* h, fe_real* step_loss, int n) {
 }
 
 /* ---- measurement */
+/* utils/mesh.py:63-96 -- what mesh_to_sdf approximates, restated exactly: distance to the closest point of the closest triangle
+ * (region walk of Ericson, Real-Time Collision Detection 5.1.5), sign from the generalized winding number (sum of the triangles'
+ * solid angles, van Oosterom & Strackee 1983, over 4 pi) > 1/2.  Computed in double whatever R is. */
+static double mesh_tri_dist2(const double a[3], const double b[3], const double c[3]) {
+    double ab[3], ac[3], bc[3];
+    for (int d = 0; d < 3; d++) { ab[d] = b[d] - a[d]; ac[d] = c[d] - a[d]; bc[d] = c[d] - b[d]; }
+    auto dot = [](const double* u, const double* v) { return u[0] * v[0] + u[1] * v[1] + u[2] * v[2]; };
+    const double d1 = -dot(ab, a), d2 = -dot(ac, a), d3 = -dot(ab, b), d4 = -dot(ac, b), d5 = -dot(ab, c), d6 = -dot(ac, c);
+    const double vc = d1 * d4 - d3 * d2, vb = d5 * d2 - d1 * d6, va = d3 * d6 - d5 * d4;
+    double q[3];
+    if (d1 <= 0 && d2 <= 0) { for (int d = 0; d < 3; d++) q[d] = a[d]; }
+    else if (d3 >= 0 && d4 <= d3) { for (int d = 0; d < 3; d++) q[d] = b[d]; }
+    else if (d6 >= 0 && d5 <= d6) { for (int d = 0; d < 3; d++) q[d] = c[d]; }
+    else if (vc <= 0 && d1 >= 0 && d3 <= 0) { const double t = d1 / (d1 - d3); for (int d = 0; d < 3; d++) q[d] = a[d] + t * ab[d]; }
+    else if (vb <= 0 && d2 >= 0 && d6 <= 0) { const double t = d2 / (d2 - d6); for (int d = 0; d < 3; d++) q[d] = a[d] + t * ac[d]; }
+    else if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) { const double t = (d4 - d3) / ((d4 - d3) + (d5 - d6)); for (int d = 0; d < 3; d++) q[d] = b[d] + t * bc[d]; }
+    else { const double den = 1 / (va + vb + vc), v = vb * den, w = vc * den; for (int d = 0; d < 3; d++) q[d] = a[d] + ab[d] * v + ac[d] * w; }
+    return dot(q, q);
+}
+int fe_mesh_sdf(int device, const float* verts, int nv, const int* faces, int nf, const float* points, long long n_points, float* sdf) {
+    (void)device;
+    if (nv <= 0 || nf <= 0 || n_points < 0 || !verts || !faces || (n_points > 0 && (!points || !sdf))) { g_create_err = "fe_mesh_sdf: invalid arguments"; return 1; }
+    for (long long i = 0; i < (long long)nf * 3; i++) if (faces[i] < 0 || faces[i] >= nv) { g_create_err = "fe_mesh_sdf: face index out of range"; return 1; }
+#pragma omp parallel for schedule(static)
+    for (long long i = 0; i < n_points; i++) {
+        double best = 1e300, omega = 0;
+        for (int t = 0; t < nf; t++) {
+            double tri[3][3];
+            for (int k = 0; k < 3; k++) for (int d = 0; d < 3; d++) tri[k][d] = (double)verts[(size_t)faces[(size_t)t * 3 + k] * 3 + d] - (double)points[i * 3 + d];
+            best = std::min(best, mesh_tri_dist2(tri[0], tri[1], tri[2]));
+            const double* a = tri[0]; const double* b = tri[1]; const double* c = tri[2];
+            const double la = std::sqrt(a[0] * a[0] + a[1] * a[1] + a[2] * a[2]), lb = std::sqrt(b[0] * b[0] + b[1] * b[1] + b[2] * b[2]), lc = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+            const double det = a[0] * (b[1] * c[2] - b[2] * c[1]) - a[1] * (b[0] * c[2] - b[2] * c[0]) + a[2] * (b[0] * c[1] - b[1] * c[0]);
+            const double ab = a[0] * b[0] + a[1] * b[1] + a[2] * b[2], bc = b[0] * c[0] + b[1] * c[1] + b[2] * c[2], ca = c[0] * a[0] + c[1] * a[1] + c[2] * a[2];
+            omega += 2 * std::atan2(det, la * lb * lc + ab * lc + bc * la + ca * lb);
+        }
+        const double d = std::sqrt(best);
+        sdf[i] = (float)(std::fabs(omega) > 2 * 3.14159265358979323846 ? -d : d);       /* either face orientation */
+    }
+    return 0;
+}
+
 int fe_get_stats(FeEngine* h, int f, FeStats* out) {
     CHECK_FRAME(h, f);
     const int n = h->n, nb = (n + 3) / 4;

@@ -1,0 +1,177 @@
+"""Mesh inputs of the hot path (fluidlab/utils/mesh.py, meshes/mesh.py, bodies.py:187-210): OBJ -> normalised mesh -> SDF voxels for
+colliders / occupancy for mesh-filled bodies.  The distance transform is `fe_mesh_sdf` of the engine library; on CPU the oracle's
+restatement is checked against analytic distances, on the GPU the HIP kernel against the oracle."""
+import os
+import pickle as pkl
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(__file__))
+import scenarios as S  # noqa: E402
+
+from fluidlab_amd.utils import mesh as M  # noqa: E402
+
+
+def _sdf_box(p, h):
+    q = np.abs(p) - np.asarray(h)
+    return np.linalg.norm(np.maximum(q, 0), axis=1) + np.minimum(q.max(axis=1), 0)
+
+
+@pytest.fixture()
+def assets(tmp_path, monkeypatch):
+    """a throw-away asset tree holding procedural meshes under the reference's file names"""
+    raw = tmp_path / 'meshes' / 'raw'
+    raw.mkdir(parents=True)
+    ball = M.icosphere(3, 0.37)
+    ball.vertices += [3.0, -1.0, 2.0]                           # raw assets are neither centred nor unit-sized
+    M.save_mesh(str(raw / 'duck.obj'), ball)
+    M.save_mesh(str(raw / 'plate.obj'), M.box_mesh((0.12, 1.0, 1.0)))
+    monkeypatch.setenv('FLUIDLAB_ASSETS', str(tmp_path))
+    return tmp_path
+
+
+def test_obj_roundtrip_and_normalisation(tmp_path):
+    path = tmp_path / 'quad.obj'
+    path.write_text('# a quad and a triangle, with texture/normal indices and a relative index\n'
+                    'v 0 0 0\nv 2 0 0\nv 2 4 0\nv 0 4 0\nvt 0 0\nvn 0 0 1\nv 1 2 3\n'
+                    'f 1/1/1 2/1/1 3/1/1 4/1/1\nf 1 2 -1\n')
+    m = M.load_mesh(str(path))
+    assert m.vertices.shape == (5, 3) and m.faces.tolist() == [[0, 1, 2], [0, 2, 3], [0, 1, 4]]
+    n = M.normalize_mesh(m)
+    assert np.allclose(n.vertices.min(0), [-0.25, -0.5, -0.375]) and np.allclose(n.vertices.max(0), [0.25, 0.5, 0.375])     # longest edge -> 1
+    M.save_mesh(str(tmp_path / 'again.obj'), n)
+    again = M.load_mesh(str(tmp_path / 'again.obj'))
+    assert np.allclose(again.vertices, n.vertices) and (again.faces == n.faces).all()
+    with pytest.raises(ValueError):
+        (tmp_path / 'empty.obj').write_text('v 0 0 0\n')
+        M.load_mesh(str(tmp_path / 'empty.obj'))
+
+
+def test_oracle_mesh_sdf_against_analytic_distances(oracle64):
+    rng = np.random.RandomState(0)
+    pts = rng.uniform(-0.6, 0.6, (4000, 3))
+    h = (0.3, 0.2, 0.5)
+    box = M.box_mesh(h)
+    d = oracle64.mesh_sdf(box.vertices, box.faces, pts)
+    assert np.abs(d - _sdf_box(pts, h)).max() < 1e-6             # exact up to float32 I/O
+    flipped = M.TriMesh(box.vertices, box.faces[:, ::-1])        # inward-facing triangles: the same solid
+    assert np.abs(oracle64.mesh_sdf(flipped.vertices, flipped.faces, pts) - d).max() == 0
+    ball = M.icosphere(3, 0.4)
+    d = oracle64.mesh_sdf(ball.vertices, ball.faces, pts)
+    assert np.abs(d - (np.linalg.norm(pts, axis=1) - 0.4)).max() < 2.5e-3          # faceting of 1280 triangles
+    # a mesh with a hole (not watertight): the winding number still separates inside from outside away from the hole
+    open_ball = M.TriMesh(ball.vertices, ball.faces[ball.vertices[ball.faces].mean(1)[:, 1] < 0.36])
+    d2 = oracle64.mesh_sdf(open_ball.vertices, open_ball.faces, np.array([[0, 0, 0], [0, -0.3, 0], [0, -0.6, 0], [0.6, 0, 0]], float))
+    assert (np.sign(d2) == [-1, -1, 1, 1]).all()
+    from fluidlab_amd._capi import FeEngineError
+    with pytest.raises(FeEngineError, match='out of range'):
+        oracle64.mesh_sdf(box.vertices, box.faces + 7, pts[:4])
+
+
+def test_collider_sdf_from_a_mesh_file(oracle64, assets):
+    """Static(file=...) with the asset present: normalise, distance transform on compute_sdf_data's lattice, cache in the reference's
+    pickle layout, reuse the cache; world-space queries agree with the analytic solid in the reference's pose convention."""
+    from fluidlab_amd.fluidengine.meshes import Static
+    from fluidlab_amd.configs.macros import PLATE
+    st = Static(material=PLATE, file='plate.obj', sdf_res=48, pos=(0.5, 0.4, 0.5), euler=(0.0, 90.0, 0.0), scale=(0.2, 0.2, 0.2), has_dynamics=True)
+    assert not st._prepared                                  # nothing is computed before an engine library is at hand
+    st.prepare(oracle64)
+    cache = M.get_processed_sdf_path('plate.obj', 48)
+    assert os.path.exists(cache)
+    data = pkl.load(open(cache, 'rb'))
+    assert set(data) == {'voxels', 'T_mesh_to_voxels'} and data['voxels'].shape == (48, 48, 48)
+    assert np.allclose(data['T_mesh_to_voxels'], M.sdf_lattice(48)[1])
+    # plate.obj: half extents (0.12, 1, 1) -> normalised (0.06, 0.5, 0.5), scaled by 0.2, turned 90 deg about y (thin along world z)
+    rng = np.random.RandomState(1)
+    world = rng.uniform([0.42, 0.32, 0.42], [0.58, 0.48, 0.58], (500, 3))
+    local = (world - [0.5, 0.4, 0.5])[:, [2, 1, 0]] * [-1, 1, 1]         # inverse of the rotation about y by +90 deg
+    ref = _sdf_box(local / 0.2, (0.06, 0.5, 0.5)) * 0.2
+    got = st.sdf(world)
+    near = np.abs(ref) < 0.03
+    # Static.sdf returns the trilinear sample in MESH units (static.py:26-49 samples the voxel values as stored): compare there
+    assert np.abs(got[near] - ref[near] / 0.2).max() < 1.5 * (1.2 / 47)                      # within ~a voxel of the exact distance
+    # second construction reads the cache (poison the raw file to prove it)
+    open(M.get_raw_mesh_path('plate.obj'), 'w').write('garbage')
+    st2 = Static(material=PLATE, file='plate.obj', sdf_res=48, has_dynamics=True)
+    st2.prepare(oracle64)
+    assert (st2.sdf_voxels_np == st.sdf_voxels_np).all()
+
+
+def test_stand_in_is_used_without_the_asset(oracle64, tmp_path, monkeypatch):
+    from fluidlab_amd.fluidengine.meshes import Static, sdf_sphere
+    from fluidlab_amd.configs.macros import PLATE
+    monkeypatch.setenv('FLUIDLAB_ASSETS', str(tmp_path))        # empty tree
+    st = Static(material=PLATE, file='plate.obj', sdf=sdf_sphere(0.3), sdf_res=24, has_dynamics=True)
+    assert st._prepared and st.sdf_voxels_np.shape == (24, 24, 24)
+    with pytest.raises(NotImplementedError, match='asset tree'):
+        Static(material=PLATE, file='plate.obj', has_dynamics=True).prepare(oracle64)
+
+
+def test_mesh_body_sampling(oracle64, assets):
+    """add_body(type='mesh') (bodies.py:187-210): the samples of the box pos +- scale/2 that fall into the voxelised mesh"""
+    from fluidlab_amd.fluidengine.bodies import Bodies
+    from fluidlab_amd.configs.macros import RIGID
+    b = Bodies(dim=3, particle_density=2e6, elib=lambda: oracle64)
+    b.add_body(type='mesh', file='duck.obj', pos=(0.22, 0.5, 0.45), scale=(0.10, 0.10, 0.10), euler=(0, -75.0, 0.0), filling='grid',
+               material=RIGID, voxelize_res=32)
+    x = b.get()['x']
+    # duck.obj here is a ball of radius 0.37 in raw units -> diameter 1 normalised -> radius 0.05 at scale 0.1
+    r = np.linalg.norm(x - [0.22, 0.5, 0.45], axis=1)
+    n_box = round(0.1 * np.cbrt(2e6)) ** 3
+    assert 0.40 * n_box < len(x) < 0.70 * n_box                      # a ball fills pi/6 = 0.52 of its box
+    assert r.max() < 0.05 + 0.1 / 32 * 1.8 and os.path.exists(M.get_voxelized_mesh_path('duck.obj', 32))
+    with pytest.raises(AssertionError, match='natural'):
+        b.add_body(type='mesh', file='duck.obj', filling='natural', material=RIGID)
+
+
+def test_gathering_env_with_mesh_assets(oracle32, assets):
+    """GatheringEasy-v0 with duck.obj / plate.obj in the asset tree: mesh-filled rigid bodies and a mesh-derived plate SDF"""
+    import test_host_env as H
+    env = H._gathering(oracle32)
+    te = env.taichi_env
+    assert te.simulator.n_bodies == 3
+    n = te.particles['bodies']['n_particles']
+    assert n[1] == n[2] and n[1] > 4                                  # two ducks, same mesh, same sampling
+    plate = te.agent.effectors[0].mesh
+    assert os.path.exists(M.get_processed_sdf_path('plate.obj', plate.sdf_res))
+    pol = env.demo_policy() if hasattr(env, 'demo_policy') else None
+    te.apply_agent_action_p(np.array([0.46, 0.42, 0.5]))
+    for i in range(3):
+        te.step(np.array([0.003, 0.0, 0.0]))
+    assert np.isfinite(te.get_state()['state']['x']).all()
+
+
+@pytest.mark.gpu
+def test_hip_mesh_sdf_matches_oracle(hiplib, oracle64):
+    rng = np.random.RandomState(0)
+    ball = M.icosphere(3, 0.4)
+    ball.vertices[:, 0] *= 1.2                                        # an ellipsoid: no symmetry to hide behind
+    pts = np.concatenate([rng.uniform(-0.6, 0.6, (20000, 3)), M.sdf_lattice(20)[0]])
+    a = hiplib.mesh_sdf(ball.vertices, ball.faces, pts)
+    b = oracle64.mesh_sdf(ball.vertices, ball.faces, pts)
+    assert (np.sign(a) == np.sign(b)).mean() > 0.9999                 # (points within rounding of the surface may flip)
+    assert np.abs(np.abs(a) - np.abs(b)).max() <= 2e-6
+    box = M.box_mesh((0.3, 0.2, 0.5))
+    a = hiplib.mesh_sdf(box.vertices, box.faces, pts)
+    assert np.abs(a - _sdf_box(pts, (0.3, 0.2, 0.5))).max() <= 2e-6
+    # ragged sizes: fewer triangles than a tile, a point count that is not a multiple of the workgroup
+    a = hiplib.mesh_sdf(box.vertices, box.faces[:5], pts[:77])
+    b = oracle64.mesh_sdf(box.vertices, box.faces[:5], pts[:77])
+    assert np.abs(np.abs(a) - np.abs(b)).max() <= 2e-6
+
+
+@pytest.mark.gpu
+def test_hip_mesh_sdf_at_the_reference_size(hiplib):
+    """compute_sdf_data's default lattice (sdf_res 128: 2.1M points) against a 20k-triangle mesh"""
+    import time
+    ball = M.icosphere(5, 0.45)                                       # 20480 triangles
+    pts = M.sdf_lattice(128)[0]
+    t0 = time.time()
+    d = hiplib.mesh_sdf(ball.vertices, ball.faces, pts).reshape(128, 128, 128)
+    dt = time.time() - t0
+    ref = (np.linalg.norm(pts, axis=1) - 0.45).reshape(128, 128, 128)
+    assert np.abs(d - ref).max() < 2e-4
+    print(f'fe_mesh_sdf 128^3 x {len(ball.faces)} triangles: {dt:.3f} s wall (upload + kernel + download)')
+    assert dt < 20.0
