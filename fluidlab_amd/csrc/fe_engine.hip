@@ -93,7 +93,8 @@ struct EffP {
     float* random_vector;                                    // [random_length, flux, 3]
     int has_mesh; SdfP mesh;                                 // Rigid.setup_mesh (rigid.py:19-24): a moving SDF collider
 };
-struct AgentP { int n; int inj; const EffP* e; float collide_min_y; const BoundaryP* collector; int collector_mat; };       // effector parameter blocks live in device memory (1 KiB as kernarg spilled SGPRs)
+struct AgentP { int n; int inj; const EffP* e; float collide_min_y; const BoundaryP* collector; int collector_mat;
+                unsigned char* hit; float4* cg; };   // hit[f * Np + slot]: the particle met a collider in g2p of frame f; cg: k_collide_grad -> k_g2p_grad       // effector parameter blocks live in device memory (1 KiB as kernarg spilled SGPRs)
 struct InjectP { int on, act_id, row, flux; };                     // per-substep injection parameters (host-known)
 
 struct PInfo { float mu, lam, mass; int cls, mat; };
@@ -496,17 +497,19 @@ __global__ __launch_bounds__(WG) void k_p2g(SimP S, float* fr_cur, float* fr_nex
 // x_tmp = x + dt * new_v re-formed before each collider.  NODE: the same chain at a grid node (mpm:393-395,
 // Agent.collide_type 'grid' / 'both'), where the position is the node's and does not move with the velocity.
 template <bool NODE>
-__device__ __forceinline__ void agent_collide_particle(const SimP& S, const AgentP& agent, int f, const float x[3], float nv[3]) {
+__device__ __forceinline__ bool agent_collide_particle(const SimP& S, const AgentP& agent, int f, const float x[3], float nv[3]) {
     const float sdt = NODE ? 0.f : S.dt;
+    bool any = false;
     for (int ei = 0; ei < agent.n; ei++) {
         const EffP& e = agent.e[ei];
         if (!e.has_mesh) continue;
         const float pos[3] = {x[0] + sdt * nv[0], x[1] + sdt * nv[1], x[2] + sdt * nv[2]};
         if (!(pos[1] > agent.collide_min_y)) continue;                           // agent_icecreamdynamic.py:39-43
         float out[3];
-        t_dynamic_collide<float>(e.mesh, e.pos + f * 3, e.quat + f * 4, e.pos + (f + 1) * 3, e.quat + (f + 1) * 4, pos, nv, S.dt, out);
+        any |= t_dynamic_collide<float>(e.mesh, e.pos + f * 3, e.quat + f * 4, e.pos + (f + 1) * 3, e.quat + (f + 1) * 4, pos, nv, S.dt, out);
         nv[0] = out[0]; nv[1] = out[1]; nv[2] = out[2];
     }
+    return any;
 }
 // Its adjoint.  g = d/d(new_v after the colliders) on entry, d/d(new_v before them) on exit; gx receives the part that
 // flows into x[f]; the effector pose adjoints (pos, quat at f and f+1) are accumulated in LDS (s_pose).  One Jacobian
@@ -784,7 +787,7 @@ __device__ __forceinline__ void used_particle_g2p(const SimP& S, const FrameV& c
     for (int a = 0; a < 3; a++)
 #pragma unroll
         for (int b = 0; b < 3; b++) nC.a[a][b] = c4 * (M.a[a][b] - st.fx[b] * nv[a]);
-    if (COLLIDE) agent_collide_particle<false>(S, agent, f, x, nv);                    // mpm:418-422
+    if (COLLIDE) agent.hit[(size_t)f * S.Np + s] = agent_collide_particle<false>(S, agent, f, x, nv) ? 1 : 0;      // mpm:418-422; the flag steers the backward pass
     float xn[3] = {x[0] + S.dt * nv[0], x[1] + S.dt * nv[1], x[2] + S.dt * nv[2]};
     store_xvC(nxt, s, xn, nv, nC);
 }
@@ -884,7 +887,7 @@ __device__ __forceinline__ float4 vout_at(const SimP& S, const VoutSrc& V, int i
 template <bool TILE, bool COLLIDE = false>
 __device__ __forceinline__ void used_particle_g2p_grad(const SimP& S, const FrameV& Gn, const FrameV& Gc, int s,
                                                        int lb, const Stencil& st, const VoutSrc& V, float* gg_out,
-                                                       bool live, const SegScan& sc, const float* cg = nullptr) {
+                                                       bool live, const SegScan& sc, const float* cg = nullptr, bool has_cg = false) {
     PState g;                                   // adjoints of x', v', C'
     if (!TILE || live) load_xvC(Gn, s, g);
     else { g.x[0] = g.x[1] = g.x[2] = g.v[0] = g.v[1] = g.v[2] = 0.f; g.C = m3_zero(); }
@@ -892,7 +895,7 @@ __device__ __forceinline__ void used_particle_g2p_grad(const SimP& S, const Fram
     const float livef = (!TILE || live) ? 1.f : 0.f;
     // x' = x + dt v'  =>  v'_bar += dt x'_bar
     float gv[3] = {g.v[0] + S.dt * g.x[0], g.v[1] + S.dt * g.x[1], g.v[2] + S.dt * g.x[2]};
-    if (COLLIDE && (!TILE || live)) { gv[0] = cg[0]; gv[1] = cg[1]; gv[2] = cg[2]; g.x[0] += cg[3]; g.x[1] += cg[4]; g.x[2] += cg[5]; }
+    if (COLLIDE && has_cg) { gv[0] = cg[0]; gv[1] = cg[1]; gv[2] = cg[2]; g.x[0] += cg[3]; g.x[1] += cg[4]; g.x[2] += cg[5]; }
     const float c4 = 4.f * S.inv_dx;
     float gfx[3] = {0.f, 0.f, 0.f};
     // q(o) = gv + c4 gC (o - fx) is linear in the node offset o: base at o = 0, per-(i,j) part, one fma per node for k.
@@ -983,6 +986,14 @@ __device__ void g2p_collide_grad(const SimP& S, const AgentP& agent, int f, cons
     agent_collide_particle_grad<false>(S, agent, f, x, nv, cg, cg + 3);
 }
 
+// what k_collide_grad left for a particle that met a collider in the forward pass
+__device__ __forceinline__ bool load_cg(const SimP& S, const AgentP& agent, int f, int s, float cg[6]) {
+    if (!agent.hit[(size_t)f * S.Np + s]) return false;
+    const float4 a = agent.cg[2 * (size_t)s], b = agent.cg[2 * (size_t)s + 1];
+    cg[0] = a.x; cg[1] = a.y; cg[2] = a.z; cg[3] = a.w; cg[4] = b.x; cg[5] = b.y;
+    return true;
+}
+
 // one slot on the global path (tail / sort_interval = 0)
 template <bool COLLIDE>
 __device__ __forceinline__ void g2p_grad_slot_global(const SimP& S, const FrameV& cur, const FrameV& Gn, const FrameV& Gc, int s,
@@ -996,8 +1007,8 @@ __device__ __forceinline__ void g2p_grad_slot_global(const SimP& S, const FrameV
     SegScan none;
     none.f1 = none.f2 = none.f4 = none.f8 = none.f15 = none.f31 = 0.f; none.tail = true;
     float cg[6];
-    if (COLLIDE) g2p_collide_grad<false>(S, agent, f, Gn, s, 0, st, x, V, cg);
-    used_particle_g2p_grad<false, COLLIDE>(S, Gn, Gc, s, 0, st, V, gg_out, true, none, cg);
+    const bool has_cg = COLLIDE && load_cg(S, agent, f, s, cg);
+    used_particle_g2p_grad<false, COLLIDE>(S, Gn, Gc, s, 0, st, V, gg_out, true, none, cg, has_cg);
 }
 
 // workgroup-level flush of s_pose into the effectors' adjoint arrays (call with all threads; contains barriers)
@@ -1025,7 +1036,6 @@ __global__ __launch_bounds__(WG) void k_g2p_grad(SimP S, float* fr_cur, float* G
                                                  GridStore GS, int f, AgentP agent) {
     const int tid = threadIdx.x;
     const bool stored = GS.cap > 0 && GS.flag[f];
-    if (COLLIDE) { if (tid < FE_MAX_EFF * 14) s_pose[tid] = 0.f; __syncthreads(); }
     VoutSrc V; V.g_out = g_out; V.store = stored ? GS.data + (size_t)f * GS.cap * 128 : nullptr; V.blk_slot = T.blk_slot;
     FrameV cur = frame_view(fr_cur, S.Np);
     FrameV Gn = frame_view(Gn_, S.Np), Gc = frame_view(Gc_, S.Np);
@@ -1053,9 +1063,9 @@ __global__ __launch_bounds__(WG) void k_g2p_grad(SimP S, float* fr_cur, float* G
                 const bool live = lb >= 0;
                 if (__any(live)) {                               // wave-uniform: empty waves skip the scan
                     float cg[6];
-                    if (COLLIDE && live) g2p_collide_grad<true>(S, agent, f, Gn, s, lb, st, x, V, cg);     // divergent, before the scan
+                    const bool has_cg = COLLIDE && live && load_cg(S, agent, f, s, cg);
                     const SegScan sc = seg_setup(live ? lb : (0x40000000 | tid));
-                    used_particle_g2p_grad<true, COLLIDE>(S, Gn, Gc, s, live ? lb : 0, st, V, gg_out, live, sc, cg);
+                    used_particle_g2p_grad<true, COLLIDE>(S, Gn, Gc, s, live ? lb : 0, st, V, gg_out, live, sc, cg, has_cg);
                 }
                 if (used && !live) {
                     if (inside) atomicAdd(slow, 1);
@@ -1071,7 +1081,138 @@ __global__ __launch_bounds__(WG) void k_g2p_grad(SimP S, float* fr_cur, float* G
             if (s < S.N) g2p_grad_slot_global<COLLIDE>(S, cur, Gn, Gc, s, V, gg_out, agent, f);
         }
     }
-    if (COLLIDE) pose_flush(agent, f);
+}
+
+// agent.collide's adjoint (mpm:418-422 in reverse) as a pass of its own, before k_g2p_grad.  Inlined into k_g2p_grad the
+// forward-mode Jacobian passes cost every particle of every scene with a Rigid effector the kernel's occupancy (256 VGPRs +
+// scratch), and run serially in one lane they are ~30k instructions: every wave holding a single contact particle took
+// 50-80 us.  Here only particles flagged by the forward pass do any work, they are compacted into a list, and each gets a
+// row of 16 lanes: lane d < 10 runs Jacobian column d (mv 3, p0 3, q0 4), the 27-node gather of the velocity the colliders
+// saw is split over the row, and the results meet through row shuffles.  The pulled-back velocity adjoint and the position
+// term wait in `agent.cg` for k_g2p_grad; pose adjoints go through s_pose.
+__device__ __forceinline__ float row_sum(float v) {          // sum over the 16 lanes of a row, result in every lane
+    v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
+    return v;
+}
+__device__ void collide_grad_row(const SimP& S, const AgentP& agent, int f, const FrameV& cur, const FrameV& Gn, const VoutSrc& V, int s, int sub) {
+    const int row0 = (threadIdx.x & 63) & ~15;                 // first lane of this row within the wave
+    const float4 a0 = cur.A0[s];
+    const float x[3] = {a0.x, a0.y, a0.z};
+    Stencil st;
+    stencil_make(x, S.inv_dx, st);
+    const float4 g0 = Gn.A0[s], g1 = Gn.A1[s];
+    float g[3] = {g0.w + S.dt * g0.x, g1.x + S.dt * g0.y, g1.y + S.dt * g0.z};       // d/d(v[f+1]) = v_bar' + dt x_bar'
+    float gx[3] = {0.f, 0.f, 0.f};
+    if (stencil_inside(st, S.n)) {                             // (k_g2p_grad passes a particle outside the grid through untouched)
+        float nv[3] = {0.f, 0.f, 0.f};
+        for (int n = sub; n < 27; n += 16) {
+            const int i = n / 9, j = (n / 3) % 3, k = n % 3;
+            const float weight = STW(st, i, 0) * STW(st, j, 1) * STW(st, k, 2);
+            const float4 gv = vout_at(S, V, st.base[0] + i, st.base[1] + j, st.base[2] + k);
+            nv[0] += weight * gv.x; nv[1] += weight * gv.y; nv[2] += weight * gv.z;
+        }
+        nv[0] = row_sum(nv[0]); nv[1] = row_sum(nv[1]); nv[2] = row_sum(nv[2]);
+        // forward through the collider chain (every lane, it is cheap), keeping each collider's input velocity
+        float vin[FE_MAX_EFF][3];
+#pragma unroll
+        for (int ei = 0; ei < FE_MAX_EFF; ei++) {
+            if (ei < agent.n && agent.e[ei].has_mesh) {
+                const EffP& e = agent.e[ei];
+                vin[ei][0] = nv[0]; vin[ei][1] = nv[1]; vin[ei][2] = nv[2];
+                const float pos[3] = {x[0] + S.dt * nv[0], x[1] + S.dt * nv[1], x[2] + S.dt * nv[2]};
+                if (pos[1] > agent.collide_min_y) {
+                    float out[3];
+                    t_dynamic_collide<float>(e.mesh, e.pos + f * 3, e.quat + f * 4, e.pos + (f + 1) * 3, e.quat + (f + 1) * 4, pos, nv, S.dt, out);
+                    nv[0] = out[0]; nv[1] = out[1]; nv[2] = out[2];
+                }
+            }
+        }
+#pragma unroll
+        for (int ei = FE_MAX_EFF - 1; ei >= 0; ei--) {
+            if (!(ei < agent.n && agent.e[ei].has_mesh)) continue;
+            const EffP& e = agent.e[ei];
+            const float v[3] = {vin[ei][0], vin[ei][1], vin[ei][2]};
+            if (!(x[1] + S.dt * v[1] > agent.collide_min_y)) continue;
+            // one Jacobian column per lane; see agent_collide_particle_grad for why ten columns are enough
+            const int dir = sub;
+            Dual p0[3], q0[4], p1[3], q1[4], pos[3], mv[3], out[3];
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                p0[d] = Dual(e.pos[f * 3 + d], dir == 3 + d ? 1.f : 0.f);
+                p1[d] = Dual(e.pos[(f + 1) * 3 + d]);
+                mv[d] = Dual(v[d], dir == d ? 1.f : 0.f);
+                pos[d] = Dual(x[d] + S.dt * v[d]);
+            }
+#pragma unroll
+            for (int d = 0; d < 4; d++) {
+                q0[d] = Dual(e.quat[f * 4 + d], dir == 6 + d ? 1.f : 0.f);
+                q1[d] = Dual(e.quat[(f + 1) * 4 + d]);
+            }
+            const bool hit = t_dynamic_collide<Dual>(e.mesh, p0, q0, p1, q1, pos, mv, S.dt, out);      // same branch in every lane of the row
+            if (!hit) continue;
+            const float r = dir < 10 ? g[0] * out[0].d + g[1] * out[1].d + g[2] * out[2].d : 0.f;
+            float c[3], a[3], gq0[4];
+#pragma unroll
+            for (int d = 0; d < 3; d++) { c[d] = __shfl(r, row0 + d, 64); a[d] = __shfl(r, row0 + 3 + d, 64); }
+#pragma unroll
+            for (int d = 0; d < 4; d++) gq0[d] = __shfl(r, row0 + 6 + d, 64);
+            const float idt = 1.f / S.dt;
+            const float w[3] = {(g[0] - c[0]) * idt, (g[1] - c[1]) * idt, (g[2] - c[2]) * idt};      // (I - J_mv)^T g / dt
+            float pm[3];
+            {
+                const float qn = 1.f / sqrtf(e.quat[f * 4] * e.quat[f * 4] + e.quat[f * 4 + 1] * e.quat[f * 4 + 1] + e.quat[f * 4 + 2] * e.quat[f * 4 + 2] + e.quat[f * 4 + 3] * e.quat[f * 4 + 3]);
+                const float qi[4] = {e.quat[f * 4] * qn, -e.quat[f * 4 + 1] * qn, -e.quat[f * 4 + 2] * qn, -e.quat[f * 4 + 3] * qn};
+                const float rel0[3] = {x[0] + S.dt * v[0] - e.pos[f * 3], x[1] + S.dt * v[1] - e.pos[f * 3 + 1], x[2] + S.dt * v[2] - e.pos[f * 3 + 2]};
+                t_quat_rotate(rel0, qi, pm);
+            }
+            float gq1[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                Dual qd[4], pmd[3], rot[3];
+                for (int d = 0; d < 4; d++) qd[d] = Dual(e.quat[(f + 1) * 4 + d], d == k ? 1.f : 0.f);
+                for (int d = 0; d < 3; d++) pmd[d] = Dual(pm[d]);
+                t_quat_rotate(pmd, qd, rot);
+                gq1[k] = w[0] * rot[0].d + w[1] * rot[1].d + w[2] * rot[2].d;
+            }
+#pragma unroll
+            for (int d = 0; d < 3; d++) {
+                const float gpos = -a[d] - w[d];
+                gx[d] += gpos;
+                g[d] = c[d] + S.dt * gpos;
+                if (sub == 0) { atomicAdd(&s_pose[ei * 14 + d], a[d]); atomicAdd(&s_pose[ei * 14 + 7 + d], w[d]); }
+            }
+            if (sub == 0) {
+#pragma unroll
+                for (int d = 0; d < 4; d++) { atomicAdd(&s_pose[ei * 14 + 3 + d], gq0[d]); atomicAdd(&s_pose[ei * 14 + 10 + d], gq1[d]); }
+            }
+        }
+    }
+    if (sub == 0) {
+        agent.cg[2 * (size_t)s] = make_float4(g[0], g[1], g[2], gx[0]);
+        agent.cg[2 * (size_t)s + 1] = make_float4(gx[1], gx[2], 0.f, 0.f);
+    }
+}
+
+// contact particles sit together in the sorted order, so a slot-indexed launch leaves all the work to a few workgroups: first
+// gather the flagged slots of the frame into one list ...
+__global__ __launch_bounds__(256) void k_collide_list(SimP S, const float* fr_cur, int f, AgentP agent, int* list, int* count) {
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s < S.N && ((const int*)(fr_cur + 24 * (size_t)S.Np))[s] != 0 && agent.hit[(size_t)f * S.Np + s] != 0) list[atomicAdd(count, 1)] = s;
+}
+// ... then one row of 16 lanes per list entry, 16 entries per workgroup (the grid covers the worst case, N entries)
+__global__ __launch_bounds__(256) void k_collide_grad(SimP S, float* fr_cur, float* Gn_, const float4* __restrict__ g_out, TableP T,
+                                                      GridStore GS, int f, AgentP agent, const int* __restrict__ list, const int* __restrict__ count) {
+    const int n = *count, base = blockIdx.x * 16;
+    if (base >= n) return;                                       // (uniform)
+    const int tid = threadIdx.x;
+    if (tid < FE_MAX_EFF * 14) s_pose[tid] = 0.f;
+    __syncthreads();
+    FrameV cur = frame_view(fr_cur, S.Np), Gn = frame_view(Gn_, S.Np);
+    const bool stored = GS.cap > 0 && GS.flag[f];
+    VoutSrc V; V.g_out = g_out; V.store = stored ? GS.data + (size_t)f * GS.cap * 128 : nullptr; V.blk_slot = T.blk_slot;
+    const int idx = base + (tid >> 4);
+    if (idx < n) collide_grad_row(S, agent, f, cur, Gn, V, list[idx], tid & 15);      // whole rows enter or skip together
+    pose_flush(agent, f);
 }
 
 // grid_op.grad (mpm:539): d/d v_out (slabs of k_g2p_grad + slow-path atomics in gg_out) -> gg_in (d/d v_in, d/d mass);
@@ -1927,6 +2068,8 @@ struct FeEngine {
     bool all_simple_liquid = false;                         // every particle is an inviscid MAT_LIQUID: SVD-free kernels
     std::vector<SdfP> statics_host; std::vector<float*> statics_vox; SdfP* statics_dev = nullptr;   // static SDF colliders
     struct SmokeState* smoke = nullptr;                     // SmokeField (fe_smoke.h), optional
+    unsigned char* hit_dev = nullptr; float4* cg_dev = nullptr;      // contact flags per (frame, slot), collide adjoint side buffer
+    int* hit_list = nullptr; int* hit_count = nullptr;                // the flagged slots of the frame being differentiated
     int collide_type = 1;                                  // Agent.collide_type (agent.py:17-26): 1 particle, 2 grid, 3 both
     BoundaryP* collector_dev = nullptr; bool has_collector = false; int collector_mat = -1;     // collector_act_kernel (agent_pouring.py:30-41)
     int inject_till = -1; float collide_min_y = -1e30f;    // AgentIceCreamDynamic (agent_icecreamdynamic.py:11,23-43)
@@ -1997,6 +2140,7 @@ BoundaryP to_boundary(const FeBoundary& b) {
 AgentP agent_params(FeEngine* h) {
     AgentP a; a.n = (int)h->effs.size(); a.inj = 0; a.e = h->effs_dev; a.collide_min_y = h->collide_min_y;
     a.collector = h->has_collector ? h->collector_dev : nullptr; a.collector_mat = h->collector_mat;
+    a.hit = h->hit_dev; a.cg = h->cg_dev;
     for (size_t i = 0; i < h->effs.size(); i++) if (h->effs[i].p.type == FE_EFF_INJECTOR) a.inj = (int)i;
     return a;
 }
@@ -2233,9 +2377,13 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act) {
         hipLaunchKernelGGL(k_rigid_final_grad, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), h->grad(f + 1), T.pid_of_slot, h->rigid_body, h->bodies_dev);
     }
     prof_begin(h, KID_G2P_GRAD);
-    if (particle_collide(h))
+    if (particle_collide(h)) {
+        HIPCK(h, hipMemsetAsync(h->hit_count, 0, sizeof(int), h->stream));
+        hipLaunchKernelGGL(k_collide_list, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), f, ag, h->hit_list, h->hit_count);
+        hipLaunchKernelGGL(k_collide_grad, dim3((h->N + 15) / 16), dim3(256), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->g_out, T, grid_store(h), f, ag,
+                           h->hit_list, h->hit_count);
         hipLaunchKernelGGL(k_g2p_grad<true>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag);
-    else
+    } else
         hipLaunchKernelGGL(k_g2p_grad<false>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag);
     prof_end(h);
     prof_begin(h, KID_GRID_GRAD);
@@ -2386,7 +2534,7 @@ void fe_destroy(FeEngine* h) {
     for (auto& t : h->tables) { for (void* q : {(void*)t.pid, (void*)t.items, (void*)t.meta, (void*)t.blk_first, (void*)t.active, (void*)t.blk_slot, (void*)t.slot_of_pid}) if (q) (void)hipFree(q); }
     void* ptrs[] = {h->frames, h->grads, h->sort_key, h->sort_rank, h->sort_cnt, h->sort_start, h->sort_src, h->sort_pid, h->slow_dev, h->frame_slow_dev, h->gstore, h->gs_flag, h->slab, h->ts_dev, h->sort_partial, h->effs_dev, h->pinfo, h->pool_idx, h->g_in, h->g_out, h->gg_out, h->gg_in,
                     h->blk_flag, h->blk_list, h->blk_count, h->err_dev, h->stage_r, h->stage_i, h->node_mark, h->counters,
-                    h->tgt, h->chamfer, h->step_loss, h->rigid_body, h->bodies_dev, h->statics_dev, h->collector_dev};
+                    h->tgt, h->chamfer, h->step_loss, h->rigid_body, h->bodies_dev, h->statics_dev, h->collector_dev, h->hit_dev, h->cg_dev, h->hit_list, h->hit_count};
     for (float* v : h->statics_vox) if (v) (void)hipFree(v);
     for (float* v : h->mesh_vox) if (v) (void)hipFree(v);
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -2819,6 +2967,10 @@ int fe_eff_set_mesh(FeEngine* h, int e, const FeSdfDesc* d, const fe_real* voxel
     h->effs[e].p.has_mesh = 1; h->effs[e].p.mesh = s;
     HIPCK(h, hipMemcpyOnStream(h, h->effs_dev + e, &h->effs[e].p, sizeof(EffP), hipMemcpyHostToDevice));
     h->has_mesh_effector = true;
+    if (!h->hit_dev) {
+        if (dev_alloc(h, &h->hit_dev, (size_t)(h->L + 1) * h->Np) || dev_alloc(h, &h->cg_dev, 2 * (size_t)h->Np) ||
+            dev_alloc(h, &h->hit_list, (size_t)h->Np) || dev_alloc(h, &h->hit_count, 1)) return 1;
+    }
     return 0;
 }
 

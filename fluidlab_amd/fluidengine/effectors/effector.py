@@ -123,7 +123,3 @@ class Effector:
         if self.action_dim > 0:
             return self.engine.eff_get_action_grad(self.index, s, n, self.action_dim)
         return None
-
-    @property
-    def latest_pos(self):
-        raise NotImplementedError('rendering helper (effector.py:151-152): no renderer in this package')

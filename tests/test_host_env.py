@@ -511,6 +511,22 @@ def test_mixing_env(oracle32):
     assert full.comp_actions_shape == (11, 3)
 
 
+def test_latest_pos_follows_the_effector(oracle32):
+    """Effector.latest_pos (effector.py:149-151), read by the Gathering / Mixing policies to steer back to a rest pose"""
+    env = _small('Mixing-v0', oracle32, horizon=4, loss=False)
+    te = env.taichi_env
+    te.apply_agent_action_p(np.array([0.5, 0.62, 0.5]))
+    assert np.allclose(te.agent.rigid.latest_pos.to_numpy()[0], [0.5, 0.62, 0.5])
+    te.step(np.array([0.005, 0.0, -0.002]))
+    te.step(np.array([0.005, 0.0, -0.002]))
+    assert np.allclose(te.agent.rigid.latest_pos.to_numpy()[0], [0.51, 0.62, 0.496], atol=1e-6)
+    from fluidlab_amd.optimizer.policies import MixingPolicy
+    cfg = load_config('configs/exp_mixing.yaml').SOLVER
+    pol = MixingPolicy(cfg.optim, cfg.init_range, 3, 100, env.action_range, fix_dim=[1])
+    a = pol.get_action_v(50, agent=te.agent, update=True)
+    assert np.allclose(a, (np.array([0.5, 0.73, 0.5]) - [0.51, 0.62, 0.496]) / 30, atol=1e-6)
+
+
 def test_mixing_policy_cycle():
     """MixingPolicy (policies.py:306-338): 50 trainable steps, 30 steps back to the rest pose, per 80-step cycle"""
     from fluidlab_amd.optimizer.policies import MixingPolicy
