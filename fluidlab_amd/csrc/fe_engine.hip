@@ -511,103 +511,17 @@ __device__ __forceinline__ bool agent_collide_particle(const SimP& S, const Agen
     }
     return any;
 }
-// Its adjoint.  g = d/d(new_v after the colliders) on entry, d/d(new_v before them) on exit; gx receives the part that
-// flows into x[f]; the effector pose adjoints (pos, quat at f and f+1) are accumulated in LDS (s_pose).  One Jacobian
-// column per forward-mode pass; a particle that is not in contact leaves after the first pass.
-template <bool NODE>
-__device__ void agent_collide_particle_grad(const SimP& S, const AgentP& agent, int f, const float x[3], const float nv0[3],
-                                            float g[3], float gx[3]) {
-    const float sdt = NODE ? 0.f : S.dt;
-    float vin[FE_MAX_EFF][3];
-    float nv[3] = {nv0[0], nv0[1], nv0[2]};
-#pragma unroll
-    for (int ei = 0; ei < FE_MAX_EFF; ei++) {
-        if (ei < agent.n && agent.e[ei].has_mesh) {
-            const EffP& e = agent.e[ei];
-            vin[ei][0] = nv[0]; vin[ei][1] = nv[1]; vin[ei][2] = nv[2];
-            const float pos[3] = {x[0] + sdt * nv[0], x[1] + sdt * nv[1], x[2] + sdt * nv[2]};
-            if (pos[1] > agent.collide_min_y) {
-                float out[3];
-                t_dynamic_collide<float>(e.mesh, e.pos + f * 3, e.quat + f * 4, e.pos + (f + 1) * 3, e.quat + (f + 1) * 4, pos, nv, S.dt, out);
-                nv[0] = out[0]; nv[1] = out[1]; nv[2] = out[2];
-            }
-        }
-    }
-#pragma unroll
-    for (int ei = FE_MAX_EFF - 1; ei >= 0; ei--) {
-        if (!(ei < agent.n && agent.e[ei].has_mesh)) continue;
-        const EffP& e = agent.e[ei];
-        const float v[3] = {vin[ei][0], vin[ei][1], vin[ei][2]};
-        if (!(x[1] + sdt * v[1] > agent.collide_min_y)) continue;
-        // out = cv + vt(rel, n) infl + rel (1 - infl), rel = mv - cv, cv = (R(q1) pm + p1 - pos) / dt: the inputs that enter only
-        // through cv (p1, q1 and the explicit -pos) have the closed-form Jacobian (I - d out/d mv) d cv/d input, so only ten
-        // forward-mode passes are needed -- mv (3), p0 (3: it enters through pm only, like the pm-part of pos), q0 (4).
-        float c[3] = {0.f, 0.f, 0.f}, a[3] = {0.f, 0.f, 0.f}, gq0[4] = {0.f, 0.f, 0.f, 0.f};
-        bool hit = true;
-#pragma unroll 1
-        for (int dir = 0; dir < 10 && hit; dir++) {
-            Dual p0[3], q0[4], p1[3], q1[4], pos[3], mv[3], out[3];
-#pragma unroll
-            for (int d = 0; d < 3; d++) {
-                p0[d] = Dual(e.pos[f * 3 + d], dir == 3 + d ? 1.f : 0.f);
-                p1[d] = Dual(e.pos[(f + 1) * 3 + d]);
-                mv[d] = Dual(v[d], dir == d ? 1.f : 0.f);
-                pos[d] = Dual(x[d] + sdt * v[d]);
-            }
-#pragma unroll
-            for (int d = 0; d < 4; d++) {
-                q0[d] = Dual(e.quat[f * 4 + d], dir == 6 + d ? 1.f : 0.f);
-                q1[d] = Dual(e.quat[(f + 1) * 4 + d]);
-            }
-            hit = t_dynamic_collide<Dual>(e.mesh, p0, q0, p1, q1, pos, mv, S.dt, out);
-            if (!hit) break;
-            const float r = g[0] * out[0].d + g[1] * out[1].d + g[2] * out[2].d;
-            c[0] = dir == 0 ? r : c[0]; c[1] = dir == 1 ? r : c[1]; c[2] = dir == 2 ? r : c[2];           // (selects: dir is a runtime index)
-            a[0] = dir == 3 ? r : a[0]; a[1] = dir == 4 ? r : a[1]; a[2] = dir == 5 ? r : a[2];
-            gq0[0] = dir == 6 ? r : gq0[0]; gq0[1] = dir == 7 ? r : gq0[1]; gq0[2] = dir == 8 ? r : gq0[2]; gq0[3] = dir == 9 ? r : gq0[3];
-        }
-        if (!hit) continue;                                             // not in contact: identity, g passes through
-        const float idt = 1.f / S.dt;
-        const float w[3] = {(g[0] - c[0]) * idt, (g[1] - c[1]) * idt, (g[2] - c[2]) * idt};      // (I - J_mv)^T g / dt
-        // pm = R(q0)^-1 (pos - p0), then d(R(q1) pm)/d q1_k by one dual quaternion rotation each
-        float pm[3];
-        {
-            const float qn = 1.f / sqrtf(e.quat[f * 4] * e.quat[f * 4] + e.quat[f * 4 + 1] * e.quat[f * 4 + 1] + e.quat[f * 4 + 2] * e.quat[f * 4 + 2] + e.quat[f * 4 + 3] * e.quat[f * 4 + 3]);
-            const float qi[4] = {e.quat[f * 4] * qn, -e.quat[f * 4 + 1] * qn, -e.quat[f * 4 + 2] * qn, -e.quat[f * 4 + 3] * qn};
-            const float rel0[3] = {x[0] + sdt * v[0] - e.pos[f * 3], x[1] + sdt * v[1] - e.pos[f * 3 + 1], x[2] + sdt * v[2] - e.pos[f * 3 + 2]};
-            t_quat_rotate(rel0, qi, pm);
-        }
-        float gq1[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            Dual q1[4], pmd[3], rot[3];
-            for (int d = 0; d < 4; d++) q1[d] = Dual(e.quat[(f + 1) * 4 + d], d == k ? 1.f : 0.f);
-            for (int d = 0; d < 3; d++) pmd[d] = Dual(pm[d]);
-            t_quat_rotate(pmd, q1, rot);
-            gq1[k] = w[0] * rot[0].d + w[1] * rot[1].d + w[2] * rot[2].d;
-        }
-#pragma unroll
-        for (int d = 0; d < 3; d++) {
-            const float gpos = -a[d] - w[d];                             // d/d pos: the pm part (= -d/d p0) and the explicit -pos/dt of cv
-            if (!NODE) gx[d] += gpos;
-            g[d] = c[d] + sdt * gpos;                                   // new_v enters as mat_v and, times dt, in pos
-            atomicAdd(&s_pose[ei * 14 + d], a[d]);                      // pos[f]
-            atomicAdd(&s_pose[ei * 14 + 7 + d], w[d]);                  // pos[f+1]
-        }
-#pragma unroll
-        for (int d = 0; d < 4; d++) { atomicAdd(&s_pose[ei * 14 + 3 + d], gq0[d]); atomicAdd(&s_pose[ei * 14 + 10 + d], gq1[d]); }
-    }
-}
-
 // velocity of one node after gravity and the domain boundary (mpm:383-398); k[] = boundary multipliers
 #define FE_MAX_STATICS 4
+struct NodeWork { int c, ni, nj, nk; float4 gi; float go[3]; float pad; };      // a grid node whose collide adjoint is finished by k_grid_collide_grad
 struct StaticsP { int n; const SdfP* s; };          // the scene's static SDF colliders (statics.py), parameter blocks in device memory
 
 // STATICS=false keeps the collider-free kernels exactly as lean as before (the SDF code costs ~100 VGPRs)
 // DYN: the agent's moving colliders act at the nodes too (mpm:393-395); vdyn = the velocity before them (adjoint input)
 template <bool STATICS, bool DYN = false>
 __device__ __forceinline__ void node_velocity(const SimP& S, const StaticsP& ST, const float4 gi, int i, int j, int k, float vo[3], float kmul[3],
-                                              float (*trace)[3] = nullptr, const AgentP* agent = nullptr, int f = 0, float* vdyn = nullptr) {
+                                              float (*trace)[3] = nullptr, const AgentP* agent = nullptr, int f = 0, float* vdyn = nullptr,
+                                              bool* dyn_hit = nullptr) {
     float inv = 1.f / gi.w;
     vo[0] = inv * gi.x + S.dt * S.g[0];
     vo[1] = inv * gi.y + S.dt * S.g[1];
@@ -624,7 +538,8 @@ __device__ __forceinline__ void node_velocity(const SimP& S, const StaticsP& ST,
     }
     if (DYN) {
         if (vdyn) { vdyn[0] = vo[0]; vdyn[1] = vo[1]; vdyn[2] = vo[2]; }
-        agent_collide_particle<true>(S, *agent, f, xn, vo);
+        const bool hit = agent_collide_particle<true>(S, *agent, f, xn, vo);
+        if (dyn_hit) *dyn_hit = hit;
     }
     boundary_v(S.bnd, xn, vo, kmul);
 }
@@ -956,36 +871,6 @@ __device__ __forceinline__ void used_particle_g2p_grad(const SimP& S, const Fram
     if (!TILE || live) Gc.A0[s] = make_float4(g.x[0] + S.inv_dx * gfx[0], g.x[1] + S.inv_dx * gfx[1], g.x[2] + S.inv_dx * gfx[2], 0.f);
 }
 
-// agent.collide's adjoint for one used particle (first in reverse order, mpm:418-422): re-gathers the velocity the
-// colliders saw, forms d/d(v[f+1]) = v_bar' + dt x_bar', pulls it back.  cg = {g_v[3], g_x[3]} for used_particle_g2p_grad.
-template <bool TILE>
-__device__ void g2p_collide_grad(const SimP& S, const AgentP& agent, int f, const FrameV& Gn, int s, int lb, const Stencil& st,
-                                 const float x[3], const VoutSrc& V, float cg[6]) {
-    float nv[3] = {0.f, 0.f, 0.f};
-#pragma unroll 1
-    for (int ij = 0; ij < 9; ij++) {
-        const int i = ij / 3, j = ij - 3 * i;
-        const float wij = STW(st, i, 0) * STW(st, j, 1);
-#pragma unroll
-        for (int kk = 0; kk < 3; kk++) {
-            const float weight = wij * st.w[kk][2];
-            float g0, g1, g2;
-            if (TILE) {
-                const int l = lb + (i * TILE_T + j) * TILE_T + kk;
-                g0 = s_tile[l]; g1 = s_tile[TILE_N + l]; g2 = s_tile[2 * TILE_N + l];
-            } else {
-                float4 gv = vout_at(S, V, st.base[0] + i, st.base[1] + j, st.base[2] + kk);
-                g0 = gv.x; g1 = gv.y; g2 = gv.z;
-            }
-            nv[0] += weight * g0; nv[1] += weight * g1; nv[2] += weight * g2;
-        }
-    }
-    const float4 a0 = Gn.A0[s], a1 = Gn.A1[s];
-    cg[0] = a0.w + S.dt * a0.x; cg[1] = a1.x + S.dt * a0.y; cg[2] = a1.y + S.dt * a0.z;
-    cg[3] = cg[4] = cg[5] = 0.f;
-    agent_collide_particle_grad<false>(S, agent, f, x, nv, cg, cg + 3);
-}
-
 // what k_collide_grad left for a particle that met a collider in the forward pass
 __device__ __forceinline__ bool load_cg(const SimP& S, const AgentP& agent, int f, int s, float cg[6]) {
     if (!agent.hit[(size_t)f * S.Np + s]) return false;
@@ -1094,8 +979,95 @@ __device__ __forceinline__ float row_sum(float v) {          // sum over the 16 
     v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
     return v;
 }
-__device__ void collide_grad_row(const SimP& S, const AgentP& agent, int f, const FrameV& cur, const FrameV& Gn, const VoutSrc& V, int s, int sub) {
+// The collider chain's adjoint for one position, shared by a row of 16 lanes (lane `sub`): x = the particle position
+// (NODE: the node position, which does not move with the velocity), nv = the velocity the first collider saw, g = d/d(velocity
+// after the chain) on entry and d/d(nv) on exit, gx += the part that flows into x (particles only).
+template <bool NODE>
+__device__ __forceinline__ void collide_chain_grad_row(const SimP& S, const AgentP& agent, int f, const float x[3], const float nv0[3],
+                                                       float g[3], float gx[3], int sub) {
     const int row0 = (threadIdx.x & 63) & ~15;                 // first lane of this row within the wave
+    const float sdt = NODE ? 0.f : S.dt;
+    float nv[3] = {nv0[0], nv0[1], nv0[2]};
+    // forward through the collider chain (every lane, it is cheap), keeping each collider's input velocity
+    float vin[FE_MAX_EFF][3];
+#pragma unroll
+    for (int ei = 0; ei < FE_MAX_EFF; ei++) {
+        if (ei < agent.n && agent.e[ei].has_mesh) {
+            const EffP& e = agent.e[ei];
+            vin[ei][0] = nv[0]; vin[ei][1] = nv[1]; vin[ei][2] = nv[2];
+            const float pos[3] = {x[0] + sdt * nv[0], x[1] + sdt * nv[1], x[2] + sdt * nv[2]};
+            if (pos[1] > agent.collide_min_y) {
+                float out[3];
+                t_dynamic_collide<float>(e.mesh, e.pos + f * 3, e.quat + f * 4, e.pos + (f + 1) * 3, e.quat + (f + 1) * 4, pos, nv, S.dt, out);
+                nv[0] = out[0]; nv[1] = out[1]; nv[2] = out[2];
+            }
+        }
+    }
+#pragma unroll
+    for (int ei = FE_MAX_EFF - 1; ei >= 0; ei--) {
+        if (!(ei < agent.n && agent.e[ei].has_mesh)) continue;
+        const EffP& e = agent.e[ei];
+        const float v[3] = {vin[ei][0], vin[ei][1], vin[ei][2]};
+        if (!(x[1] + sdt * v[1] > agent.collide_min_y)) continue;
+        // One forward-mode Jacobian column per lane.  out = cv + vt(rel, n) infl + rel (1 - infl), rel = mv - cv,
+        // cv = (R(q1) pm + p1 - pos) / dt: the inputs that enter only through cv (p1, q1 and the explicit -pos) have the closed-form
+        // Jacobian (I - d out/d mv) d cv/d input, so ten columns are enough -- mv (3), p0 (3: it enters through pm only, like
+        // the pm-part of pos), q0 (4).
+        const int dir = sub;
+        Dual p0[3], q0[4], p1[3], q1[4], pos[3], mv[3], out[3];
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            p0[d] = Dual(e.pos[f * 3 + d], dir == 3 + d ? 1.f : 0.f);
+            p1[d] = Dual(e.pos[(f + 1) * 3 + d]);
+            mv[d] = Dual(v[d], dir == d ? 1.f : 0.f);
+            pos[d] = Dual(x[d] + sdt * v[d]);
+        }
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            q0[d] = Dual(e.quat[f * 4 + d], dir == 6 + d ? 1.f : 0.f);
+            q1[d] = Dual(e.quat[(f + 1) * 4 + d]);
+        }
+        const bool hit = t_dynamic_collide<Dual>(e.mesh, p0, q0, p1, q1, pos, mv, S.dt, out);      // same branch in every lane of the row
+        if (!hit) continue;
+        const float r = dir < 10 ? g[0] * out[0].d + g[1] * out[1].d + g[2] * out[2].d : 0.f;
+        float c[3], a[3], gq0[4];
+#pragma unroll
+        for (int d = 0; d < 3; d++) { c[d] = __shfl(r, row0 + d, 64); a[d] = __shfl(r, row0 + 3 + d, 64); }
+#pragma unroll
+        for (int d = 0; d < 4; d++) gq0[d] = __shfl(r, row0 + 6 + d, 64);
+        const float idt = 1.f / S.dt;
+        const float w[3] = {(g[0] - c[0]) * idt, (g[1] - c[1]) * idt, (g[2] - c[2]) * idt};      // (I - J_mv)^T g / dt
+        float pm[3];
+        {
+            const float qn = 1.f / sqrtf(e.quat[f * 4] * e.quat[f * 4] + e.quat[f * 4 + 1] * e.quat[f * 4 + 1] + e.quat[f * 4 + 2] * e.quat[f * 4 + 2] + e.quat[f * 4 + 3] * e.quat[f * 4 + 3]);
+            const float qi[4] = {e.quat[f * 4] * qn, -e.quat[f * 4 + 1] * qn, -e.quat[f * 4 + 2] * qn, -e.quat[f * 4 + 3] * qn};
+            const float rel0[3] = {x[0] + sdt * v[0] - e.pos[f * 3], x[1] + sdt * v[1] - e.pos[f * 3 + 1], x[2] + sdt * v[2] - e.pos[f * 3 + 2]};
+            t_quat_rotate(rel0, qi, pm);
+        }
+        float gq1[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            Dual qd[4], pmd[3], rot[3];
+            for (int d = 0; d < 4; d++) qd[d] = Dual(e.quat[(f + 1) * 4 + d], d == k ? 1.f : 0.f);
+            for (int d = 0; d < 3; d++) pmd[d] = Dual(pm[d]);
+            t_quat_rotate(pmd, qd, rot);
+            gq1[k] = w[0] * rot[0].d + w[1] * rot[1].d + w[2] * rot[2].d;
+        }
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const float gpos = -a[d] - w[d];
+            if (!NODE) gx[d] += gpos;
+            g[d] = c[d] + sdt * gpos;
+            if (sub == 0) { atomicAdd(&s_pose[ei * 14 + d], a[d]); atomicAdd(&s_pose[ei * 14 + 7 + d], w[d]); }
+        }
+        if (sub == 0) {
+#pragma unroll
+            for (int d = 0; d < 4; d++) { atomicAdd(&s_pose[ei * 14 + 3 + d], gq0[d]); atomicAdd(&s_pose[ei * 14 + 10 + d], gq1[d]); }
+        }
+    }
+}
+
+__device__ void collide_grad_row(const SimP& S, const AgentP& agent, int f, const FrameV& cur, const FrameV& Gn, const VoutSrc& V, int s, int sub) {
     const float4 a0 = cur.A0[s];
     const float x[3] = {a0.x, a0.y, a0.z};
     Stencil st;
@@ -1112,80 +1084,7 @@ __device__ void collide_grad_row(const SimP& S, const AgentP& agent, int f, cons
             nv[0] += weight * gv.x; nv[1] += weight * gv.y; nv[2] += weight * gv.z;
         }
         nv[0] = row_sum(nv[0]); nv[1] = row_sum(nv[1]); nv[2] = row_sum(nv[2]);
-        // forward through the collider chain (every lane, it is cheap), keeping each collider's input velocity
-        float vin[FE_MAX_EFF][3];
-#pragma unroll
-        for (int ei = 0; ei < FE_MAX_EFF; ei++) {
-            if (ei < agent.n && agent.e[ei].has_mesh) {
-                const EffP& e = agent.e[ei];
-                vin[ei][0] = nv[0]; vin[ei][1] = nv[1]; vin[ei][2] = nv[2];
-                const float pos[3] = {x[0] + S.dt * nv[0], x[1] + S.dt * nv[1], x[2] + S.dt * nv[2]};
-                if (pos[1] > agent.collide_min_y) {
-                    float out[3];
-                    t_dynamic_collide<float>(e.mesh, e.pos + f * 3, e.quat + f * 4, e.pos + (f + 1) * 3, e.quat + (f + 1) * 4, pos, nv, S.dt, out);
-                    nv[0] = out[0]; nv[1] = out[1]; nv[2] = out[2];
-                }
-            }
-        }
-#pragma unroll
-        for (int ei = FE_MAX_EFF - 1; ei >= 0; ei--) {
-            if (!(ei < agent.n && agent.e[ei].has_mesh)) continue;
-            const EffP& e = agent.e[ei];
-            const float v[3] = {vin[ei][0], vin[ei][1], vin[ei][2]};
-            if (!(x[1] + S.dt * v[1] > agent.collide_min_y)) continue;
-            // one Jacobian column per lane; see agent_collide_particle_grad for why ten columns are enough
-            const int dir = sub;
-            Dual p0[3], q0[4], p1[3], q1[4], pos[3], mv[3], out[3];
-#pragma unroll
-            for (int d = 0; d < 3; d++) {
-                p0[d] = Dual(e.pos[f * 3 + d], dir == 3 + d ? 1.f : 0.f);
-                p1[d] = Dual(e.pos[(f + 1) * 3 + d]);
-                mv[d] = Dual(v[d], dir == d ? 1.f : 0.f);
-                pos[d] = Dual(x[d] + S.dt * v[d]);
-            }
-#pragma unroll
-            for (int d = 0; d < 4; d++) {
-                q0[d] = Dual(e.quat[f * 4 + d], dir == 6 + d ? 1.f : 0.f);
-                q1[d] = Dual(e.quat[(f + 1) * 4 + d]);
-            }
-            const bool hit = t_dynamic_collide<Dual>(e.mesh, p0, q0, p1, q1, pos, mv, S.dt, out);      // same branch in every lane of the row
-            if (!hit) continue;
-            const float r = dir < 10 ? g[0] * out[0].d + g[1] * out[1].d + g[2] * out[2].d : 0.f;
-            float c[3], a[3], gq0[4];
-#pragma unroll
-            for (int d = 0; d < 3; d++) { c[d] = __shfl(r, row0 + d, 64); a[d] = __shfl(r, row0 + 3 + d, 64); }
-#pragma unroll
-            for (int d = 0; d < 4; d++) gq0[d] = __shfl(r, row0 + 6 + d, 64);
-            const float idt = 1.f / S.dt;
-            const float w[3] = {(g[0] - c[0]) * idt, (g[1] - c[1]) * idt, (g[2] - c[2]) * idt};      // (I - J_mv)^T g / dt
-            float pm[3];
-            {
-                const float qn = 1.f / sqrtf(e.quat[f * 4] * e.quat[f * 4] + e.quat[f * 4 + 1] * e.quat[f * 4 + 1] + e.quat[f * 4 + 2] * e.quat[f * 4 + 2] + e.quat[f * 4 + 3] * e.quat[f * 4 + 3]);
-                const float qi[4] = {e.quat[f * 4] * qn, -e.quat[f * 4 + 1] * qn, -e.quat[f * 4 + 2] * qn, -e.quat[f * 4 + 3] * qn};
-                const float rel0[3] = {x[0] + S.dt * v[0] - e.pos[f * 3], x[1] + S.dt * v[1] - e.pos[f * 3 + 1], x[2] + S.dt * v[2] - e.pos[f * 3 + 2]};
-                t_quat_rotate(rel0, qi, pm);
-            }
-            float gq1[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                Dual qd[4], pmd[3], rot[3];
-                for (int d = 0; d < 4; d++) qd[d] = Dual(e.quat[(f + 1) * 4 + d], d == k ? 1.f : 0.f);
-                for (int d = 0; d < 3; d++) pmd[d] = Dual(pm[d]);
-                t_quat_rotate(pmd, qd, rot);
-                gq1[k] = w[0] * rot[0].d + w[1] * rot[1].d + w[2] * rot[2].d;
-            }
-#pragma unroll
-            for (int d = 0; d < 3; d++) {
-                const float gpos = -a[d] - w[d];
-                gx[d] += gpos;
-                g[d] = c[d] + S.dt * gpos;
-                if (sub == 0) { atomicAdd(&s_pose[ei * 14 + d], a[d]); atomicAdd(&s_pose[ei * 14 + 7 + d], w[d]); }
-            }
-            if (sub == 0) {
-#pragma unroll
-                for (int d = 0; d < 4; d++) { atomicAdd(&s_pose[ei * 14 + 3 + d], gq0[d]); atomicAdd(&s_pose[ei * 14 + 10 + d], gq1[d]); }
-            }
-        }
+        collide_chain_grad_row<false>(S, agent, f, x, nv, g, gx, sub);
     }
     if (sub == 0) {
         agent.cg[2 * (size_t)s] = make_float4(g[0], g[1], g[2], gx[0]);
@@ -1220,9 +1119,8 @@ __global__ __launch_bounds__(256) void k_collide_grad(SimP S, float* fr_cur, flo
 template <bool STATICS, bool DYN>
 __global__ __launch_bounds__(256) void k_grid_grad(SimP S, TableP T, const float4* __restrict__ slab, float* g_in, float* gg_out, float4* gg_in,
                                                    const int* __restrict__ blk_list, const int* __restrict__ blk_count, int* blk_flag,
-                                                   GridStore GS, int f, StaticsP ST, AgentP agent) {
+                                                   GridStore GS, int f, StaticsP ST, AgentP agent, NodeWork* work, int* work_count) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (DYN) { if (threadIdx.x < FE_MAX_EFF * 14) s_pose[threadIdx.x] = 0.f; __syncthreads(); }
     const int n_static = T.meta[2], cnt = n_static + *blk_count;
     const bool stored = GS.cap > 0 && GS.flag[f];
     const int per_xcd = ((cnt + 3) / 4 + 7) >> 3;
@@ -1243,13 +1141,15 @@ __global__ __launch_bounds__(256) void k_grid_grad(SimP S, TableP T, const float
             float vo[3], kmul[3];
             float trace[FE_MAX_STATICS][3];
             const int ni = bi * 4 + (lane >> 4), nj = bj * 4 + ((lane >> 2) & 3), nk = bk * 4 + (lane & 3);
-            float vdyn[3];
-            node_velocity<STATICS, DYN>(S, ST, gi, ni, nj, nk, vo, kmul, trace, &agent, f, vdyn);
+            bool dyn_hit = false;
+            node_velocity<STATICS, DYN>(S, ST, gi, ni, nj, nk, vo, kmul, trace, &agent, f, nullptr, &dyn_hit);
             float inv = 1.f / gi.w;
             float gcol[3] = {go.x * kmul[0], go.y * kmul[1], go.z * kmul[2]};
-            if (DYN && (gcol[0] != 0.f || gcol[1] != 0.f || gcol[2] != 0.f)) {      // agent.collide's adjoint at the node: pose adjoints -> s_pose
-                const float xn[3] = {(float)ni * S.dx, (float)nj * S.dx, (float)nk * S.dx};
-                agent_collide_particle_grad<true>(S, agent, f, xn, vdyn, gcol, nullptr);
+            if (DYN && dyn_hit && (gcol[0] != 0.f || gcol[1] != 0.f || gcol[2] != 0.f)) {
+                // a node inside one of the agent's colliders with a live adjoint: its chain is finished by k_grid_collide_grad
+                NodeWork w; w.c = c; w.ni = ni; w.nj = nj; w.nk = nk; w.gi = gi; w.go[0] = go.x; w.go[1] = go.y; w.go[2] = go.z; w.pad = 0.f;
+                work[atomicAdd(work_count, 1)] = w;
+                gcol[0] = gcol[1] = gcol[2] = 0.f;                    // (gg_in[c] is overwritten there)
             }
             if (STATICS) node_statics_grad(S, ST, ni, nj, nk, trace, gcol);
             float g0 = gcol[0], g1 = gcol[1], g2 = gcol[2];
@@ -1261,7 +1161,33 @@ __global__ __launch_bounds__(256) void k_grid_grad(SimP S, TableP T, const float
         gg_out[c] = 0.f; gg_out[S.ncell + c] = 0.f; gg_out[2 * S.ncell + c] = 0.f;
         if (lane == 0 && !is_static) blk_flag[b] = 0;
     }
-    if (DYN) pose_flush(agent, f);
+}
+
+// second half of grid_op.grad for the nodes k_grid_grad<.., DYN> set aside: agent.collide's adjoint at the node (mpm:393-395 in
+// reverse), one row of 16 lanes per node like k_collide_grad, then the statics' chain and the division by the mass.
+template <bool STATICS>
+__global__ __launch_bounds__(256) void k_grid_collide_grad(SimP S, float4* gg_in, int f, StaticsP ST, AgentP agent, const NodeWork* __restrict__ work,
+                                                           const int* __restrict__ work_count) {
+    const int n = *work_count, base = blockIdx.x * 16;
+    if (base >= n) return;                                       // (uniform)
+    const int tid = threadIdx.x;
+    if (tid < FE_MAX_EFF * 14) s_pose[tid] = 0.f;
+    __syncthreads();
+    const int idx = base + (tid >> 4), sub = tid & 15;
+    if (idx < n) {
+        const NodeWork w = work[idx];
+        float vo[3], kmul[3], vdyn[3];
+        float trace[FE_MAX_STATICS][3];
+        node_velocity<STATICS, true>(S, ST, w.gi, w.ni, w.nj, w.nk, vo, kmul, trace, &agent, f, vdyn);
+        float gcol[3] = {w.go[0] * kmul[0], w.go[1] * kmul[1], w.go[2] * kmul[2]};
+        const float xn[3] = {(float)w.ni * S.dx, (float)w.nj * S.dx, (float)w.nk * S.dx};
+        collide_chain_grad_row<true>(S, agent, f, xn, vdyn, gcol, nullptr, sub);
+        if (STATICS) node_statics_grad(S, ST, w.ni, w.nj, w.nk, trace, gcol);
+        const float inv = 1.f / w.gi.w;
+        if (sub == 0)
+            gg_in[w.c] = make_float4(gcol[0] * inv, gcol[1] * inv, gcol[2] * inv, -(w.gi.x * gcol[0] + w.gi.y * gcol[1] + w.gi.z * gcol[2]) * inv * inv);
+    }
+    pose_flush(agent, f);
 }
 
 // Effector.move_kernel.grad (effector.py:154-155), position chain only
@@ -2070,6 +1996,7 @@ struct FeEngine {
     struct SmokeState* smoke = nullptr;                     // SmokeField (fe_smoke.h), optional
     unsigned char* hit_dev = nullptr; float4* cg_dev = nullptr;      // contact flags per (frame, slot), collide adjoint side buffer
     int* hit_list = nullptr; int* hit_count = nullptr;                // the flagged slots of the frame being differentiated
+    NodeWork* node_work = nullptr; int* node_work_count = nullptr;    // grid nodes inside an agent collider (collide_type grid / both)
     int collide_type = 1;                                  // Agent.collide_type (agent.py:17-26): 1 particle, 2 grid, 3 both
     BoundaryP* collector_dev = nullptr; bool has_collector = false; int collector_mat = -1;     // collector_act_kernel (agent_pouring.py:30-41)
     int inject_till = -1; float collide_min_y = -1e30f;    // AgentIceCreamDynamic (agent_icecreamdynamic.py:11,23-43)
@@ -2388,9 +2315,15 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act) {
     prof_end(h);
     prof_begin(h, KID_GRID_GRAD);
 #define LAUNCH_GRID_GRAD(ST_, DY_) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_grad<ST_, DY_>), ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, h->gg_out, \
-                           h->gg_in, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f, statics_p(h), ag)
-    if (grid_collide(h)) { if (h->statics_host.empty()) LAUNCH_GRID_GRAD(false, true); else LAUNCH_GRID_GRAD(true, true); }
-    else { if (h->statics_host.empty()) LAUNCH_GRID_GRAD(false, false); else LAUNCH_GRID_GRAD(true, false); }
+                           h->gg_in, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f, statics_p(h), ag, h->node_work, h->node_work_count)
+    if (grid_collide(h)) {
+        if (!h->node_work && (dev_alloc(h, &h->node_work, (size_t)h->S.ncell, false) || dev_alloc(h, &h->node_work_count, 1))) return 1;
+        HIPCK(h, hipMemsetAsync(h->node_work_count, 0, sizeof(int), h->stream));
+        if (h->statics_host.empty()) LAUNCH_GRID_GRAD(false, true); else LAUNCH_GRID_GRAD(true, true);
+        const dim3 wg((unsigned)((h->S.ncell + 15) / 16) < 65535u * 16u ? (unsigned)((h->S.ncell + 15) / 16) : 65535u * 16u);
+        if (h->statics_host.empty()) hipLaunchKernelGGL(k_grid_collide_grad<false>, wg, dim3(256), 0, h->stream, h->S, h->gg_in, f, statics_p(h), ag, h->node_work, h->node_work_count);
+        else hipLaunchKernelGGL(k_grid_collide_grad<true>, wg, dim3(256), 0, h->stream, h->S, h->gg_in, f, statics_p(h), ag, h->node_work, h->node_work_count);
+    } else { if (h->statics_host.empty()) LAUNCH_GRID_GRAD(false, false); else LAUNCH_GRID_GRAD(true, false); }
     prof_end(h);
     prof_begin(h, KID_P2G_GRAD);
 #define LAUNCH_P2G_GRAD(G, W) hipLaunchKernelGGL((k_p2g_grad<G, W>), wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), \
@@ -2534,7 +2467,7 @@ void fe_destroy(FeEngine* h) {
     for (auto& t : h->tables) { for (void* q : {(void*)t.pid, (void*)t.items, (void*)t.meta, (void*)t.blk_first, (void*)t.active, (void*)t.blk_slot, (void*)t.slot_of_pid}) if (q) (void)hipFree(q); }
     void* ptrs[] = {h->frames, h->grads, h->sort_key, h->sort_rank, h->sort_cnt, h->sort_start, h->sort_src, h->sort_pid, h->slow_dev, h->frame_slow_dev, h->gstore, h->gs_flag, h->slab, h->ts_dev, h->sort_partial, h->effs_dev, h->pinfo, h->pool_idx, h->g_in, h->g_out, h->gg_out, h->gg_in,
                     h->blk_flag, h->blk_list, h->blk_count, h->err_dev, h->stage_r, h->stage_i, h->node_mark, h->counters,
-                    h->tgt, h->chamfer, h->step_loss, h->rigid_body, h->bodies_dev, h->statics_dev, h->collector_dev, h->hit_dev, h->cg_dev, h->hit_list, h->hit_count};
+                    h->tgt, h->chamfer, h->step_loss, h->rigid_body, h->bodies_dev, h->statics_dev, h->collector_dev, h->hit_dev, h->cg_dev, h->hit_list, h->hit_count, h->node_work, h->node_work_count};
     for (float* v : h->statics_vox) if (v) (void)hipFree(v);
     for (float* v : h->mesh_vox) if (v) (void)hipFree(v);
     for (void* p : ptrs) if (p) (void)hipFree(p);
