@@ -94,7 +94,7 @@ struct EffP {
     int has_mesh; SdfP mesh;                                 // Rigid.setup_mesh (rigid.py:19-24): a moving SDF collider
 };
 struct AgentP { int n; int inj; const EffP* e; float collide_min_y; const BoundaryP* collector; int collector_mat;
-                unsigned char* hit; float4* cg; };   // hit[f * Np + slot]: the particle met a collider in g2p of frame f; cg: k_collide_grad -> k_g2p_grad       // effector parameter blocks live in device memory (1 KiB as kernarg spilled SGPRs)
+                unsigned char* hit; };   // hit[f * Np + slot]: the particle met a collider in g2p of frame f (steers k_collide_grad)       // effector parameter blocks live in device memory (1 KiB as kernarg spilled SGPRs)
 struct InjectP { int on, act_id, row, flux; };                     // per-substep injection parameters (host-known)
 
 struct PInfo { float mu, lam, mass; int cls, mat; };
@@ -798,11 +798,11 @@ __device__ __forceinline__ float4 vout_at(const SimP& S, const VoutSrc& V, int i
 // position adjoint (so far) in Gc.A0.xyz.  TILE: v_out read from / d v_out accumulated into LDS (3+3 planes)
 // TILE=true is executed by ALL lanes of the wave (`live` = this lane holds a used particle whose stencil fits the
 // tile); the d v_out contributions are summed over runs of equal stencil base before the LDS atomics (seg_scan).
-// cg (COLLIDE only): {d/d(gathered velocity) after agent.collide's adjoint [3], extra d/dx[f] from the colliders [3]}
-template <bool TILE, bool COLLIDE = false>
+// (agent.collide's adjoint has already been folded into Gn's x/v adjoints by k_collide_grad)
+template <bool TILE>
 __device__ __forceinline__ void used_particle_g2p_grad(const SimP& S, const FrameV& Gn, const FrameV& Gc, int s,
                                                        int lb, const Stencil& st, const VoutSrc& V, float* gg_out,
-                                                       bool live, const SegScan& sc, const float* cg = nullptr, bool has_cg = false) {
+                                                       bool live, const SegScan& sc) {
     PState g;                                   // adjoints of x', v', C'
     if (!TILE || live) load_xvC(Gn, s, g);
     else { g.x[0] = g.x[1] = g.x[2] = g.v[0] = g.v[1] = g.v[2] = 0.f; g.C = m3_zero(); }
@@ -810,7 +810,6 @@ __device__ __forceinline__ void used_particle_g2p_grad(const SimP& S, const Fram
     const float livef = (!TILE || live) ? 1.f : 0.f;
     // x' = x + dt v'  =>  v'_bar += dt x'_bar
     float gv[3] = {g.v[0] + S.dt * g.x[0], g.v[1] + S.dt * g.x[1], g.v[2] + S.dt * g.x[2]};
-    if (COLLIDE && has_cg) { gv[0] = cg[0]; gv[1] = cg[1]; gv[2] = cg[2]; g.x[0] += cg[3]; g.x[1] += cg[4]; g.x[2] += cg[5]; }
     const float c4 = 4.f * S.inv_dx;
     float gfx[3] = {0.f, 0.f, 0.f};
     // q(o) = gv + c4 gC (o - fx) is linear in the node offset o: base at o = 0, per-(i,j) part, one fma per node for k.
@@ -871,16 +870,7 @@ __device__ __forceinline__ void used_particle_g2p_grad(const SimP& S, const Fram
     if (!TILE || live) Gc.A0[s] = make_float4(g.x[0] + S.inv_dx * gfx[0], g.x[1] + S.inv_dx * gfx[1], g.x[2] + S.inv_dx * gfx[2], 0.f);
 }
 
-// what k_collide_grad left for a particle that met a collider in the forward pass
-__device__ __forceinline__ bool load_cg(const SimP& S, const AgentP& agent, int f, int s, float cg[6]) {
-    if (!agent.hit[(size_t)f * S.Np + s]) return false;
-    const float4 a = agent.cg[2 * (size_t)s], b = agent.cg[2 * (size_t)s + 1];
-    cg[0] = a.x; cg[1] = a.y; cg[2] = a.z; cg[3] = a.w; cg[4] = b.x; cg[5] = b.y;
-    return true;
-}
-
 // one slot on the global path (tail / sort_interval = 0)
-template <bool COLLIDE>
 __device__ __forceinline__ void g2p_grad_slot_global(const SimP& S, const FrameV& cur, const FrameV& Gn, const FrameV& Gc, int s,
                                                      const VoutSrc& V, float* gg_out, const AgentP& agent, int f) {
     if (!cur.used[s]) return;
@@ -891,9 +881,7 @@ __device__ __forceinline__ void g2p_grad_slot_global(const SimP& S, const FrameV
     if (!stencil_inside(st, S.n)) { float4 gx = Gn.A0[s]; Gc.A0[s] = make_float4(gx.x, gx.y, gx.z, 0.f); return; }
     SegScan none;
     none.f1 = none.f2 = none.f4 = none.f8 = none.f15 = none.f31 = 0.f; none.tail = true;
-    float cg[6];
-    const bool has_cg = COLLIDE && load_cg(S, agent, f, s, cg);
-    used_particle_g2p_grad<false, COLLIDE>(S, Gn, Gc, s, 0, st, V, gg_out, true, none, cg, has_cg);
+    used_particle_g2p_grad<false>(S, Gn, Gc, s, 0, st, V, gg_out, true, none);
 }
 
 // workgroup-level flush of s_pose into the effectors' adjoint arrays (call with all threads; contains barriers)
@@ -915,7 +903,6 @@ __device__ __forceinline__ void pose_flush(const AgentP& agent, int f) {
     __syncthreads();
 }
 
-template <bool COLLIDE>
 __global__ __launch_bounds__(WG) void k_g2p_grad(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T,
                                                  const float4* __restrict__ g_out, float* gg_out, float4* slab, int* slow,
                                                  GridStore GS, int f, AgentP agent) {
@@ -947,14 +934,12 @@ __global__ __launch_bounds__(WG) void k_g2p_grad(SimP S, float* fr_cur, float* G
                 const int lb = inside ? tile_base(to, st) : -1;
                 const bool live = lb >= 0;
                 if (__any(live)) {                               // wave-uniform: empty waves skip the scan
-                    float cg[6];
-                    const bool has_cg = COLLIDE && live && load_cg(S, agent, f, s, cg);
                     const SegScan sc = seg_setup(live ? lb : (0x40000000 | tid));
-                    used_particle_g2p_grad<true, COLLIDE>(S, Gn, Gc, s, live ? lb : 0, st, V, gg_out, live, sc, cg, has_cg);
+                    used_particle_g2p_grad<true>(S, Gn, Gc, s, live ? lb : 0, st, V, gg_out, live, sc);
                 }
                 if (used && !live) {
                     if (inside) atomicAdd(slow, 1);
-                    g2p_grad_slot_global<COLLIDE>(S, cur, Gn, Gc, s, V, gg_out, agent, f);
+                    g2p_grad_slot_global(S, cur, Gn, Gc, s, V, gg_out, agent, f);
                 }
             }
             __syncthreads();
@@ -963,7 +948,7 @@ __global__ __launch_bounds__(WG) void k_g2p_grad(SimP S, float* fr_cur, float* G
             __syncthreads();
         } else {
             const int s = tail_start + (w - n_items) * WG + tid;
-            if (s < S.N) g2p_grad_slot_global<COLLIDE>(S, cur, Gn, Gc, s, V, gg_out, agent, f);
+            if (s < S.N) g2p_grad_slot_global(S, cur, Gn, Gc, s, V, gg_out, agent, f);
         }
     }
 }
@@ -974,7 +959,7 @@ __global__ __launch_bounds__(WG) void k_g2p_grad(SimP S, float* fr_cur, float* G
 // 50-80 us.  Here only particles flagged by the forward pass do any work, they are compacted into a list, and each gets a
 // row of 16 lanes: lane d < 10 runs Jacobian column d (mv 3, p0 3, q0 4), the 27-node gather of the velocity the colliders
 // saw is split over the row, and the results meet through row shuffles.  The pulled-back velocity adjoint and the position
-// term wait in `agent.cg` for k_g2p_grad; pose adjoints go through s_pose.
+// term are folded into the frame-(f+1) adjoints k_g2p_grad starts from; pose adjoints go through s_pose.
 __device__ __forceinline__ float row_sum(float v) {          // sum over the 16 lanes of a row, result in every lane
     v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 1, 64);
     return v;
@@ -1086,9 +1071,12 @@ __device__ void collide_grad_row(const SimP& S, const AgentP& agent, int f, cons
         nv[0] = row_sum(nv[0]); nv[1] = row_sum(nv[1]); nv[2] = row_sum(nv[2]);
         collide_chain_grad_row<false>(S, agent, f, x, nv, g, gx, sub);
     }
+    // Fold the result into the adjoints k_g2p_grad reads: it forms d/d(gathered velocity) = v_bar' + dt x_bar' and starts d/dx[f]
+    // from x_bar', so x_bar' += gx and v_bar' = g - dt x_bar' make it continue from behind the colliders, unchanged itself.
     if (sub == 0) {
-        agent.cg[2 * (size_t)s] = make_float4(g[0], g[1], g[2], gx[0]);
-        agent.cg[2 * (size_t)s + 1] = make_float4(gx[1], gx[2], 0.f, 0.f);
+        const float nx[3] = {g0.x + gx[0], g0.y + gx[1], g0.z + gx[2]};
+        Gn.A0[s] = make_float4(nx[0], nx[1], nx[2], g[0] - S.dt * nx[0]);
+        Gn.A1[s] = make_float4(g[1] - S.dt * nx[1], g[2] - S.dt * nx[2], g1.z, g1.w);
     }
 }
 
@@ -1994,7 +1982,7 @@ struct FeEngine {
     bool all_simple_liquid = false;                         // every particle is an inviscid MAT_LIQUID: SVD-free kernels
     std::vector<SdfP> statics_host; std::vector<float*> statics_vox; SdfP* statics_dev = nullptr;   // static SDF colliders
     struct SmokeState* smoke = nullptr;                     // SmokeField (fe_smoke.h), optional
-    unsigned char* hit_dev = nullptr; float4* cg_dev = nullptr;      // contact flags per (frame, slot), collide adjoint side buffer
+    unsigned char* hit_dev = nullptr;                                 // contact flags per (frame, slot)
     int* hit_list = nullptr; int* hit_count = nullptr;                // the flagged slots of the frame being differentiated
     NodeWork* node_work = nullptr; int* node_work_count = nullptr;    // grid nodes inside an agent collider (collide_type grid / both)
     int collide_type = 1;                                  // Agent.collide_type (agent.py:17-26): 1 particle, 2 grid, 3 both
@@ -2067,7 +2055,7 @@ BoundaryP to_boundary(const FeBoundary& b) {
 AgentP agent_params(FeEngine* h) {
     AgentP a; a.n = (int)h->effs.size(); a.inj = 0; a.e = h->effs_dev; a.collide_min_y = h->collide_min_y;
     a.collector = h->has_collector ? h->collector_dev : nullptr; a.collector_mat = h->collector_mat;
-    a.hit = h->hit_dev; a.cg = h->cg_dev;
+    a.hit = h->hit_dev;
     for (size_t i = 0; i < h->effs.size(); i++) if (h->effs[i].p.type == FE_EFF_INJECTOR) a.inj = (int)i;
     return a;
 }
@@ -2309,9 +2297,8 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act) {
         hipLaunchKernelGGL(k_collide_list, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), f, ag, h->hit_list, h->hit_count);
         hipLaunchKernelGGL(k_collide_grad, dim3((h->N + 15) / 16), dim3(256), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->g_out, T, grid_store(h), f, ag,
                            h->hit_list, h->hit_count);
-        hipLaunchKernelGGL(k_g2p_grad<true>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag);
-    } else
-        hipLaunchKernelGGL(k_g2p_grad<false>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag);
+    }
+    hipLaunchKernelGGL(k_g2p_grad, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag);
     prof_end(h);
     prof_begin(h, KID_GRID_GRAD);
 #define LAUNCH_GRID_GRAD(ST_, DY_) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_grad<ST_, DY_>), ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, h->gg_out, \
@@ -2467,7 +2454,7 @@ void fe_destroy(FeEngine* h) {
     for (auto& t : h->tables) { for (void* q : {(void*)t.pid, (void*)t.items, (void*)t.meta, (void*)t.blk_first, (void*)t.active, (void*)t.blk_slot, (void*)t.slot_of_pid}) if (q) (void)hipFree(q); }
     void* ptrs[] = {h->frames, h->grads, h->sort_key, h->sort_rank, h->sort_cnt, h->sort_start, h->sort_src, h->sort_pid, h->slow_dev, h->frame_slow_dev, h->gstore, h->gs_flag, h->slab, h->ts_dev, h->sort_partial, h->effs_dev, h->pinfo, h->pool_idx, h->g_in, h->g_out, h->gg_out, h->gg_in,
                     h->blk_flag, h->blk_list, h->blk_count, h->err_dev, h->stage_r, h->stage_i, h->node_mark, h->counters,
-                    h->tgt, h->chamfer, h->step_loss, h->rigid_body, h->bodies_dev, h->statics_dev, h->collector_dev, h->hit_dev, h->cg_dev, h->hit_list, h->hit_count, h->node_work, h->node_work_count};
+                    h->tgt, h->chamfer, h->step_loss, h->rigid_body, h->bodies_dev, h->statics_dev, h->collector_dev, h->hit_dev, h->hit_list, h->hit_count, h->node_work, h->node_work_count};
     for (float* v : h->statics_vox) if (v) (void)hipFree(v);
     for (float* v : h->mesh_vox) if (v) (void)hipFree(v);
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -2901,7 +2888,7 @@ int fe_eff_set_mesh(FeEngine* h, int e, const FeSdfDesc* d, const fe_real* voxel
     HIPCK(h, hipMemcpyOnStream(h, h->effs_dev + e, &h->effs[e].p, sizeof(EffP), hipMemcpyHostToDevice));
     h->has_mesh_effector = true;
     if (!h->hit_dev) {
-        if (dev_alloc(h, &h->hit_dev, (size_t)(h->L + 1) * h->Np) || dev_alloc(h, &h->cg_dev, 2 * (size_t)h->Np) ||
+        if (dev_alloc(h, &h->hit_dev, (size_t)(h->L + 1) * h->Np) ||
             dev_alloc(h, &h->hit_list, (size_t)h->Np) || dev_alloc(h, &h->hit_count, 1)) return 1;
     }
     return 0;
