@@ -68,7 +68,7 @@ ABI_SYMBOLS = [
     'fe_add_static', 'fe_eff_set_mesh', 'fe_add_effector', 'fe_eff_set_act_range', 'fe_eff_get_state', 'fe_eff_set_state',
     'fe_eff_get_vw', 'fe_eff_set_vw', 'fe_eff_get_sr', 'fe_eff_set_sr', 'fe_eff_set_action', 'fe_eff_set_action_grad',
     'fe_eff_apply_action_p', 'fe_eff_apply_action_p_grad', 'fe_eff_get_action_grad',
-    'fe_agent_copy_frame', 'fe_agent_copy_grad', 'fe_agent_reset_grad_till_frame', 'fe_agent_set_collector', 'fe_mesh_sdf', 'fe_loss_alloc', 'fe_loss_set_target',
+    'fe_agent_copy_frame', 'fe_agent_copy_grad', 'fe_agent_reset_grad_till_frame', 'fe_agent_set_collector', 'fe_mesh_sdf', 'fe_add_grad_dev', 'fe_loss_alloc', 'fe_loss_set_target',
     'fe_loss_clear', 'fe_loss_step', 'fe_loss_step_grad', 'fe_loss_get', 'fe_get_stats',
     'fe_smoke_create', 'fe_smoke_step', 'fe_smoke_step_grad', 'fe_smoke_get_frame', 'fe_smoke_set_frame', 'fe_smoke_get_grad',
     'fe_smoke_add_grad', 'fe_smoke_copy_frame', 'fe_smoke_copy_grad', 'fe_smoke_reset_grad', 'fe_smoke_reset_grad_till_frame',
@@ -307,6 +307,10 @@ class Engine:
 
     def set_frame_dev(self, f, x=None, v=None, C_=None, F=None, used=None):
         self._ck(self.lib.fe_set_frame_dev(self.h, int(f), self._tptr(x), self._tptr(v), self._tptr(C_), self._tptr(F), self._tptr(used)))
+
+    def add_grad_dev(self, f, gx=None, gv=None, gC=None, gF=None):
+        """fe_add_grad_dev: torch tensors on the engine's GPU, already complete (synchronise the producing stream first)"""
+        self._ck(self.lib.fe_add_grad_dev(self.h, int(f), self._tptr(gx), self._tptr(gv), self._tptr(gC), self._tptr(gF)))
 
     def add_grad(self, f, gx=None, gv=None, gC=None, gF=None):
         N = self.N

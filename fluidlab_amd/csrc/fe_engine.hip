@@ -2685,6 +2685,16 @@ int fe_add_grad(FeEngine* h, int f, const fe_real* gx, const fe_real* gv, const 
     if (grad_order_for_frame(h, f)) return 1;
     return upload_planes(h, h->grad(f), h->pid_of(f), gx, gv, gC, gF, nullptr, 1);
 }
+// device-pointer variant (a loss evaluated on the GPU hands its adjoint over without crossing PCIe)
+int fe_add_grad_dev(FeEngine* h, int f, const fe_real* gx, const fe_real* gv, const fe_real* gC, const fe_real* gF) {
+    CHECK_FRAME(h, f);
+    if (grad_order_for_frame(h, f)) return 1;
+    const int mask = (gx ? 1 : 0) | (gv ? 2 : 0) | (gC ? 4 : 0) | (gF ? 8 : 0);
+    if (!mask || h->N == 0) return 0;
+    hipLaunchKernelGGL(k_pack, pgrid(h), dim3(256), 0, h->stream, h->N, (size_t)h->Np, h->grad(f), h->pid_of(f), gx, gv, gC, gF, (const int*)nullptr, mask, 1);
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    return check_async(h);
+}
 int fe_get_mat(FeEngine* h, int* mat) {
     if ((int)h->mat_host.size() != h->N) FAIL(h, "particles not initialised");
     std::memcpy(mat, h->mat_host.data(), sizeof(int) * h->N);

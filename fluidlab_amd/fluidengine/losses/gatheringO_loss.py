@@ -1,7 +1,5 @@
 """GatheringOLoss (fluidlab/fluidengine/losses/gatheringO_loss.py): squared distance, in the xz plane, of every used particle
 of the matching material to the goal (0.88, 0.78) (:75-79)."""
-import numpy as np
-
 from .host_loss import HostLoss
 
 
@@ -26,15 +24,15 @@ class GatheringOLoss(HostLoss):
         super().build(sim)
 
     def step_value(self, s, f, x, used, want_grad):
+        xp = self.xp
         m = used & (self.particle_mat == self.matching_mat)
-        xd = x.astype(np.float64)
-        dx, dz = xd[m, 0] - self.goal[0], xd[m, 2] - self.goal[1]
+        dx, dz = x[m, 0] - self.goal[0], x[m, 2] - self.goal[1]
         g = None
         if want_grad:
-            g = np.zeros_like(xd)
+            g = xp.zeros_like(x)
             g[m, 0] = 2 * dx * self.dist_weight
             g[m, 2] = 2 * dz * self.dist_weight
-        return float((dx * dx + dz * dz).sum()) * self.dist_weight, g
+        return xp.to_float((dx * dx + dz * dz).sum()) * self.dist_weight, g
 
     def get_step_loss(self):
         cur = self.cur_step_loss()

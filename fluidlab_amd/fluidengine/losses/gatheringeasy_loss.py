@@ -1,7 +1,6 @@
 """GatheringEasyLoss (fluidlab/fluidengine/losses/gatheringeasy_loss.py): sum over the matching material's used particles of
-|x_0 - 0.8| -- push the floating bodies towards x = 0.8 (gatheringeasy_loss.py:75-79).  The reduction is an N-wide pass per
-step over data the engine owns; it runs on the host (HostLoss: one frame download per step, one adjoint upload per backward
-step)."""
+|x_0 - 0.8| -- push the floating bodies towards x = 0.8 (gatheringeasy_loss.py:75-79).  A HostLoss: evaluated next to the
+frames (torch on the GPU for the HIP engine, numpy against the oracle)."""
 import numpy as np
 
 from .host_loss import HostLoss
@@ -28,12 +27,14 @@ class GatheringEasyLoss(HostLoss):
         super().build(sim)
 
     def step_value(self, s, f, x, used, want_grad):
+        xp = self.xp
         m = used & (self.particle_mat == self.matching_mat)
+        d = x[m, 0] - self.goal_x
         g = None
         if want_grad:
-            g = np.zeros((self.n_particles, 3), np.float64)
-            g[m, 0] = np.sign(x[m, 0] - self.goal_x) * self.dist_weight
-        return float(np.abs(x[m, 0].astype(np.float64) - self.goal_x).sum()) * self.dist_weight, g
+            g = xp.zeros_like(x)
+            g[m, 0] = xp.sign(d) * self.dist_weight
+        return xp.to_float(xp.abs(d).sum()) * self.dist_weight, g
 
     def final_loss_info(self):
         return {'reward': float(np.sum((150 - self._step_loss) * 0.01))}

@@ -1,7 +1,5 @@
 """MixingLoss (fluidlab/fluidengine/losses/mixing_loss.py): spread the milk -- minus 1e-4 times the L1 distance over all
 ordered pairs of the first tenth of the MILK_VIS particles (:47, 72-75; no `used` test), summed without forming the pairs."""
-import numpy as np
-
 from fluidlab_amd.configs.macros import MILK_VIS
 from .host_loss import HostLoss, pairwise_l1
 
@@ -19,14 +17,13 @@ class MixingLoss(HostLoss):
     def build(self, sim):
         self.dist_weight = self.weights['dist']
         super().build(sim)
-        self.n_particles_milk = int((self.particle_mat == MILK_VIS).sum() * 0.1)
+        self.n_particles_milk = int(self.xp.count(self.particle_mat == MILK_VIS) * 0.1)
 
     def step_value(self, s, f, x, used, want_grad):
-        a = x[:self.n_particles_milk].astype(np.float64)
-        total, ga, _ = pairwise_l1(a)
+        total, ga, _ = pairwise_l1(x[:self.n_particles_milk], xp=self.xp)
         g = None
         if want_grad:
-            g = np.zeros((self.n_particles, 3), np.float64)
+            g = self.xp.zeros_like(x)
             g[:self.n_particles_milk] = -1e-4 * self.dist_weight * ga
         return -1e-4 * total * self.dist_weight, g
 

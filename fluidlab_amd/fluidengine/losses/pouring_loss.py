@@ -1,8 +1,6 @@
 """PouringLoss (fluidlab/fluidengine/losses/pouring_loss.py): keep the MILK where it started (L1 to the initial positions,
 :131-135), pull the WATER towards the floor y = 0.05 ('default' only: dist_scale 0.2, :30-33) and, in the 'diff' variant, on
 the last step attract the 100 WATER particles nearest to the lowest one towards it (:101-118, 137-146)."""
-import numpy as np
-
 from fluidlab_amd.configs.macros import MILK, WATER
 from .host_loss import HostLoss
 
@@ -24,36 +22,35 @@ class PouringLoss(HostLoss):
 
     def _attraction(self, x, used, want_grad):
         """find_best_particle + compute_attraction_loss_kernel + scale_attraction_loss_kernel (:101-146)"""
+        xp = self.xp
         water = used & (self.particle_mat == WATER)
-        if not water.any():
+        if xp.count(water) == 0:
             return 0.0, None
-        xd = x.astype(np.float64)
-        loss = np.abs(xd[:, 1] - 0.05); loss[~water] = 1000
-        best = int(np.argmin(loss))
-        dist = np.linalg.norm(xd - xd[best], axis=1); dist[~water] = 1000
-        score = np.argsort(np.argsort(dist))
-        near = water & (score < 100)
-        scale = float((xd[water, 1] > 0.55).sum()) / 12500
-        value = float(np.abs(xd[near] - xd[best]).sum()) * 5000 * scale
+        loss = xp.abs(x[:, 1] - 0.05); loss[~water] = 1000
+        best = x[xp.argmin(loss)] + 0.0                         # best_particle_pos is a constant copy (:108)
+        dist = xp.norm_rows(x - best); dist[~water] = 1000
+        near = water & (xp.rank(dist) < 100)
+        scale = float(xp.count(water & (x[:, 1] > 0.55))) / 12500
+        value = xp.to_float(xp.abs(x[near] - best).sum()) * 5000 * scale
         if not want_grad:
             return value, None
-        g = np.zeros_like(xd)
-        g[near] = np.sign(xd[near] - xd[best]) * 5000 * scale          # best_particle_pos is a constant copy (:108)
+        g = xp.zeros_like(x)
+        g[near] = xp.sign(x[near] - best) * 5000 * scale
         return value, g
 
     def step_value(self, s, f, x, used, want_grad):
+        xp = self.xp
         if s == 0 and not want_grad:
-            self.init_particle_pos = x.astype(np.float64).copy()                  # get_init_particles, :97-99
-        xd = x.astype(np.float64)
+            self.init_particle_pos = x + 0.0                     # get_init_particles, :97-99
         water = used & (self.particle_mat == WATER)
         milk = used & (self.particle_mat == MILK)
-        value = float(np.abs(xd[water, 1] - 0.05).sum()) * self.dist_scale + float(np.abs(xd[milk] - self.init_particle_pos[milk]).sum())
-        value *= self.dist_weight
+        dw, dm = x[water, 1] - 0.05, x[milk] - self.init_particle_pos[milk]
+        value = (xp.to_float(xp.abs(dw).sum()) * self.dist_scale + xp.to_float(xp.abs(dm).sum())) * self.dist_weight
         g = None
         if want_grad:
-            g = np.zeros_like(xd)
-            g[water, 1] = np.sign(xd[water, 1] - 0.05) * self.dist_scale * self.dist_weight
-            g[milk] = np.sign(xd[milk] - self.init_particle_pos[milk]) * self.dist_weight
+            g = xp.zeros_like(x)
+            g[water, 1] = xp.sign(dw) * self.dist_scale * self.dist_weight
+            g[milk] = xp.sign(dm) * self.dist_weight
         if self.type == 'diff' and s == self.max_loss_steps - 1:
             av, ag = self._attraction(x, used, want_grad)
             value += av

@@ -21,9 +21,9 @@ class TransportingLoss(HostLoss):
         self._attraction = np.zeros((self.max_loss_steps,), np.float64)
         super().build(sim)
         mat = self.particle_mat
-        self.n_particles_water = int((mat == WATER).sum())           # the water pool comes first (transporting_env.py:47-52)
+        self.n_particles_water = self.xp.count(mat == WATER)         # the water pool comes first (transporting_env.py:47-52)
         self.obj_start = self.n_particles_water
-        self.obj_end = self.obj_start + int((mat == RIGID_HEAVY).sum())
+        self.obj_end = self.obj_start + self.xp.count(mat == RIGID_HEAVY)
 
     def clear_loss(self):
         super().clear_loss()
@@ -31,16 +31,16 @@ class TransportingLoss(HostLoss):
             self._dist[:] = 0; self._attraction[:] = 0
 
     def step_value(self, s, f, x, used, want_grad):
-        xd = x.astype(np.float64)
-        obj = xd[self.obj_start:self.obj_end]
-        dist = float(np.abs(obj[:, 0] - 0.9).sum())
-        g = np.zeros_like(xd) if want_grad else None
+        xp = self.xp
+        obj = x[self.obj_start:self.obj_end]
+        dist = xp.to_float(xp.abs(obj[:, 0] - 0.9).sum())
+        g = xp.zeros_like(x) if want_grad else None
         if want_grad:
-            g[self.obj_start:self.obj_end, 0] = np.sign(obj[:, 0] - 0.9) * self.dist_weight
+            g[self.obj_start:self.obj_end, 0] = xp.sign(obj[:, 0] - 0.9) * self.dist_weight
         attraction = 0.0
         if self.type == 'diff':
-            w = np.where(used[:self.n_particles_water])[0]
-            attraction, gw, gobj = pairwise_l1(xd[w], obj)
+            w = xp.where(used[:self.n_particles_water])
+            attraction, gw, gobj = pairwise_l1(x[w], obj, xp=xp)
             attraction *= 1e-4
             if want_grad:
                 g[w] += gw * 1e-4

@@ -137,6 +137,9 @@ int fe_reset_grad_till_frame(FeEngine* h, int f);           /* mpm:606-609 */
 int fe_get_grad(FeEngine* h, int f, fe_real* gx, fe_real* gv, fe_real* gC, fe_real* gF);
 int fe_add_grad(FeEngine* h, int f, const fe_real* gx, const fe_real* gv, const fe_real* gC,
                 const fe_real* gF);
+/* the same with DEVICE pointers (the reference's loss kernels write particles.grad on the device: loss.py, *_loss.py) */
+int fe_add_grad_dev(FeEngine* h, int f, const fe_real* gx, const fe_real* gv, const fe_real* gC,
+                    const fe_real* gF);
 /* particles_i.mat, used by Recorder (recorder.py:59) */
 int fe_get_mat(FeEngine* h, int* mat);
 

@@ -1719,6 +1719,7 @@ int fe_add_grad(FeEngine* h, int f, const fe_real* gx, const fe_real* gv, const 
     if (gF) for (size_t i = 0; i < N * 9; i++) h->GF(f)[i] += gF[i];
     return 0;
 }
+int fe_add_grad_dev(FeEngine* h, int f, const fe_real* gx, const fe_real* gv, const fe_real* gC, const fe_real* gF) { return fe_add_grad(h, f, gx, gv, gC, gF); }   /* host == device here */
 int fe_get_mat(FeEngine* h, int* mat) { std::memcpy(mat, h->mat.data(), sizeof(int) * h->N); return 0; }
 
 /* ---- effectors */
