@@ -1643,135 +1643,43 @@ __global__ void k_eff_copy(EffP e, int src, int dst, int grad) {
 
 // =========================================================================================
 // MAT_RIGID shape matching (advect / advect_grad, mpm:428-505).  Bodies are few and their particles a small part of
-// the scene, so this is a handful of N-wide launches that only exist when a rigid body does: per-body moments are
-// reduced in fp64 (wave butterfly when the wave's rigid lanes belong to one body, plain atomics otherwise), one
-// thread per body does the 3x3 SVD.  The reference accumulates in fp32 with atomics (mpm:456-478).
+// the scene: one workgroup per body walks the body's particle list, per-body moments are reduced in fp64 through LDS, one
+// thread does the 3x3 SVD.  The reference accumulates in fp32 with atomics (mpm:456-478).
 // =========================================================================================
 struct RigidBody {
-    double acc[30];      // forward  [0..2] COM_t0  [3..5] COM_t1  [6..14] H        (mpm:181-189)
-                         // backward [15..23] R.grad  [24..26] COM_t0.grad  [27..29] COM_t1.grad
     float c0[3], c1[3], R[9], U[9], sig[3], V[9], gH[9];
     float inv_n;         // 1 / bodies_i.n_particles (all particles of the body, used or not: mpm:201)
     int rigid;           // bodies_i.mat_cls == MAT_RIGID
 };
 
+// Sum val[0..K) over the workgroup (256 threads) into out[0..K) (LDS); every thread may read out[] after the call.
 template <int K>
-__device__ __forceinline__ void rigid_accumulate(RigidBody* B, int b, int off, const double (&val)[K]) {
-    const unsigned long long m = __ballot(b >= 0);
-    if (m == 0) return;                                          // wave-uniform
-    const int b0 = __shfl(b, __ffsll((long long)m) - 1, 64);
-    if (__ballot(b >= 0 && b != b0) == 0) {
+__device__ __forceinline__ void block_sum(const double (&val)[K], double* out, double* part /* [4][K] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
-        for (int k = 0; k < K; k++) {
-            double v = b >= 0 ? val[k] : 0.0;
+    for (int k = 0; k < K; k++) {
+        double v = val[k];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-            if ((threadIdx.x & 63) == 0) atomicAdd(&B[b0].acc[off + k], v);
-        }
-    } else if (b >= 0) {
-#pragma unroll
-        for (int k = 0; k < K; k++) atomicAdd(&B[b].acc[off + k], val[k]);
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) part[wave * K + k] = v;
     }
+    __syncthreads();
+    if (threadIdx.x < K) out[threadIdx.x] = part[threadIdx.x] + part[K + threadIdx.x] + part[2 * K + threadIdx.x] + part[3 * K + threadIdx.x];
+    __syncthreads();
 }
 
-struct RigidLane { int b; float x[3], y[3]; };
-// x = x[f], y = x[f] + dt v[f+1] of a used MAT_RIGID particle (b = -1 otherwise)
-__device__ __forceinline__ RigidLane rigid_lane(const SimP& S, const FrameV& cur, const FrameV& nxt, const int* pid_of_slot,
-                                                const int* rigid_body, int s) {
-    RigidLane l; l.b = -1;
-    if (s < S.N && cur.used[s]) l.b = rigid_body[pid_of_slot[s]];
-    if (l.b >= 0) {
-        float4 a0 = cur.A0[s], n0 = nxt.A0[s], n1 = nxt.A1[s];
+struct RigidLane { int s; float x[3], y[3]; };
+// x = x[f], y = x[f] + dt v[f+1] of the i-th particle of a body's list if it is in use (s = -1 otherwise)
+__device__ __forceinline__ RigidLane rigid_lane(const SimP& S, const FrameV& cur, const FrameV& nxt, const int* __restrict__ slot_of_pid,
+                                                const int* __restrict__ pids, int i, int hi) {
+    RigidLane l; l.s = -1;
+    if (i < hi) { const int s = slot_of_pid[pids[i]]; if (cur.used[s]) l.s = s; }
+    if (l.s >= 0) {
+        const float4 a0 = cur.A0[l.s], n0 = nxt.A0[l.s], n1 = nxt.A1[l.s];
         l.x[0] = a0.x; l.x[1] = a0.y; l.x[2] = a0.z;
         l.y[0] = a0.x + S.dt * n0.w; l.y[1] = a0.y + S.dt * n1.x; l.y[2] = a0.z + S.dt * n1.y;
     }
     return l;
-}
-
-__global__ __launch_bounds__(256) void k_rigid_clear(RigidBody* B, int n_bodies) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_bodies * 30) B[i / 30].acc[i % 30] = 0.0;                                  // reset_bodies_and_grad, mpm:449-454
-}
-
-// PASS 0: compute_COM (mpm:456-462); PASS 1: compute_H (mpm:464-478)
-template <int PASS>
-__global__ __launch_bounds__(256) void k_rigid_moments(SimP S, float* fr_f, float* fr_n, const int* __restrict__ pid_of_slot,
-                                                       const int* __restrict__ rigid_body, RigidBody* B) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    const RigidLane l = rigid_lane(S, frame_view(fr_f, S.Np), frame_view(fr_n, S.Np), pid_of_slot, rigid_body, s);
-    if (PASS == 0) {
-        double val[6] = {0, 0, 0, 0, 0, 0};
-        if (l.b >= 0) { const double w = B[l.b].inv_n; for (int d = 0; d < 3; d++) { val[d] = l.x[d] * w; val[3 + d] = l.y[d] * w; } }
-        rigid_accumulate(B, l.b, 0, val);
-    } else {
-        double val[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        if (l.b >= 0) {
-            const RigidBody& bd = B[l.b];
-            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) val[i * 3 + j] = ((double)l.x[i] - bd.acc[i]) * ((double)l.y[j] - bd.acc[3 + j]);
-        }
-        rigid_accumulate(B, l.b, 6, val);
-    }
-}
-
-// compute_H_svd + compute_R (mpm:480-483, 491-495): one thread per body
-__global__ void k_rigid_solve(RigidBody* B, int n_bodies) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_bodies || !B[i].rigid) return;
-    RigidBody& b = B[i];
-    m3 H, U, V; float sig[3];
-    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) H.a[r][c] = (float)b.acc[6 + r * 3 + c];
-    svd3(H, U, sig, V);
-    const m3 R = m3_mul_nt(V, U);
-    for (int d = 0; d < 3; d++) { b.c0[d] = (float)b.acc[d]; b.c1[d] = (float)b.acc[3 + d]; b.sig[d] = sig[d]; }
-    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { b.R[r * 3 + c] = R.a[r][c]; b.U[r * 3 + c] = U.a[r][c]; b.V[r * 3 + c] = V.a[r][c]; }
-}
-
-// advect_kernel, rigid branch (mpm:500-502): x[f+1] = R (x[f] - COM_t0) + COM_t1 (k_g2p wrote the non-rigid x + dt v)
-__global__ __launch_bounds__(256) void k_rigid_advect(SimP S, float* fr_f, float* fr_n, const int* __restrict__ pid_of_slot,
-                                                      const int* __restrict__ rigid_body, const RigidBody* B) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    FrameV nxt = frame_view(fr_n, S.Np);
-    const RigidLane l = rigid_lane(S, frame_view(fr_f, S.Np), nxt, pid_of_slot, rigid_body, s);
-    if (l.b < 0) return;
-    const RigidBody& b = B[l.b];
-    float o[3];
-    for (int i = 0; i < 3; i++) { o[i] = b.c1[i]; for (int j = 0; j < 3; j++) o[i] += b.R[i * 3 + j] * (l.x[j] - b.c0[j]); }
-    float4 n0 = nxt.A0[s];
-    n0.x = o[0]; n0.y = o[1]; n0.z = o[2];
-    nxt.A0[s] = n0;
-}
-
-// advect_kernel.grad, rigid branch: R.grad += g (x - COM_t0)^T, COM_t0.grad -= R^T g, COM_t1.grad += g
-__global__ __launch_bounds__(256) void k_rigid_advect_grad(SimP S, float* fr_f, float* fr_n, float* G1_, const int* __restrict__ pid_of_slot,
-                                                           const int* __restrict__ rigid_body, RigidBody* B) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    const RigidLane l = rigid_lane(S, frame_view(fr_f, S.Np), frame_view(fr_n, S.Np), pid_of_slot, rigid_body, s);
-    double val[15];
-    for (int k = 0; k < 15; k++) val[k] = 0.0;
-    if (l.b >= 0) {
-        const RigidBody& b = B[l.b];
-        const float4 g0 = frame_view(G1_, S.Np).A0[s];
-        const float g[3] = {g0.x, g0.y, g0.z};
-        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) val[i * 3 + j] = (double)g[i] * (double)(l.x[j] - b.c0[j]);
-        for (int j = 0; j < 3; j++) {
-            float rtg = 0; for (int i = 0; i < 3; i++) rtg += b.R[i * 3 + j] * g[i];
-            val[9 + j] = -(double)rtg; val[12 + j] = g[j];
-        }
-    }
-    rigid_accumulate(B, l.b, 15, val);
-}
-
-// compute_R.grad (R = V U^T) and compute_H_svd_grad (mpm:485-489)
-__global__ void k_rigid_solve_grad(RigidBody* B, int n_bodies) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_bodies || !B[i].rigid) return;
-    RigidBody& b = B[i];
-    m3 gR, U, V;
-    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { gR.a[r][c] = (float)b.acc[15 + r * 3 + c]; U.a[r][c] = b.U[r * 3 + c]; V.a[r][c] = b.V[r * 3 + c]; }
-    const m3 gV = m3_mul(gR, U), gU = m3_mul_tn(gR, V);
-    const float gS[3] = {0.f, 0.f, 0.f};
-    const m3 gH = backward_svd(gU, gS, gV, U, b.sig, V);
-    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) b.gH[r * 3 + c] = gH.a[r][c];
 }
 
 __device__ __forceinline__ void rigid_H_adjoint(const RigidBody& b, const RigidLane& l, float ga[3], float gb[3]) {
@@ -1783,45 +1691,122 @@ __device__ __forceinline__ void rigid_H_adjoint(const RigidBody& b, const RigidL
     }
 }
 
-// compute_H.grad, the part that flows into the COM adjoints
-__global__ __launch_bounds__(256) void k_rigid_H_grad(SimP S, float* fr_f, float* fr_n, const int* __restrict__ pid_of_slot,
-                                                      const int* __restrict__ rigid_body, RigidBody* B) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    const RigidLane l = rigid_lane(S, frame_view(fr_f, S.Np), frame_view(fr_n, S.Np), pid_of_slot, rigid_body, s);
-    double val[6] = {0, 0, 0, 0, 0, 0};
-    if (l.b >= 0) {
-        float ga[3], gb[3];
-        rigid_H_adjoint(B[l.b], l, ga, gb);
-        for (int d = 0; d < 3; d++) { val[d] = -(double)ga[d]; val[3 + d] = -(double)gb[d]; }
-    }
-    rigid_accumulate(B, l.b, 24, val);
-}
-
-// Particle side of advect_kernel.grad + compute_H.grad + compute_COM.grad.  With
+// One workgroup per body does the whole chain for its particles (a per-body list of particle ids, fixed at init; slots through
+// the order's slot_of_pid): reset_bodies + compute_COM + compute_H (mpm:449-478) reduced in fp64 through LDS, compute_H_svd +
+// compute_R on one thread (mpm:480-495), then the rigid branch of advect_kernel (mpm:500-502).  It used to be five N-wide
+// launches per substep (and four more in the backward pass) that touched every particle to find the few hundred rigid ones.
+// BACKWARD: the forward values are rebuilt, then advect_kernel.grad -> compute_R.grad / compute_H_svd_grad (mpm:485-489) ->
+// compute_H.grad -> compute_COM.grad, rewriting the incoming adjoint so that k_g2p_grad's generic advect adjoint finishes it:
 //   X = R^T g + H.grad b + H.grad^T a + (COM_t0.grad + COM_t1.grad)/n   (what x.grad[f] receives)
 //   W = H.grad^T a + COM_t1.grad/n                                       (what v.grad[f+1] receives, times dt)
-// the incoming adjoint is rewritten as x.grad[f+1] := X, v.grad[f+1] += dt (W - X), so that the generic
-// advect adjoint in k_g2p_grad (x.grad[f] += x.grad[f+1]; v.grad[f+1] += dt x.grad[f+1]) yields exactly X and dt W.
-__global__ __launch_bounds__(256) void k_rigid_final_grad(SimP S, float* fr_f, float* fr_n, float* G1_, const int* __restrict__ pid_of_slot,
-                                                          const int* __restrict__ rigid_body, const RigidBody* B) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    const RigidLane l = rigid_lane(S, frame_view(fr_f, S.Np), frame_view(fr_n, S.Np), pid_of_slot, rigid_body, s);
-    if (l.b < 0) return;
-    const RigidBody& b = B[l.b];
-    FrameV G1 = frame_view(G1_, S.Np);
-    float4 g0 = G1.A0[s], g1 = G1.A1[s];
-    const float g[3] = {g0.x, g0.y, g0.z};
-    float ga[3], gb[3], X[3], W[3];
-    rigid_H_adjoint(b, l, ga, gb);
-    for (int j = 0; j < 3; j++) {
-        float rtg = 0; for (int i = 0; i < 3; i++) rtg += b.R[i * 3 + j] * g[i];
-        const float gc0 = (float)b.acc[24 + j], gc1 = (float)b.acc[27 + j];
-        X[j] = rtg + ga[j] + gb[j] + (gc0 + gc1) * b.inv_n;
-        W[j] = gb[j] + gc1 * b.inv_n;
+//   x.grad[f+1] := X, v.grad[f+1] += dt (W - X)   =>   x.grad[f] += x.grad[f+1]; v.grad[f+1] += dt x.grad[f+1] yields X and dt W.
+template <bool BACKWARD>
+__global__ __launch_bounds__(256) void k_rigid_body(SimP S, float* fr_f, float* fr_n, float* G1_, const int* __restrict__ slot_of_pid,
+                                                    const int* __restrict__ body_start, const int* __restrict__ body_pids, RigidBody* B) {
+    __shared__ RigidBody sb;
+    __shared__ double s_out[15], s_part[4 * 15];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (!B[b].rigid) return;                                   // (uniform)
+    const int lo = body_start[b], hi = body_start[b + 1];
+    const int n_iter = (hi - lo + 255) / 256;
+    FrameV cur = frame_view(fr_f, S.Np), nxt = frame_view(fr_n, S.Np);
+    const double inv_n = B[b].inv_n;
+    {   // compute_COM
+        double val[6] = {0, 0, 0, 0, 0, 0};
+        for (int it = 0; it < n_iter; it++) {
+            const RigidLane l = rigid_lane(S, cur, nxt, slot_of_pid, body_pids, lo + it * 256 + tid, hi);
+            if (l.s >= 0) for (int d = 0; d < 3; d++) { val[d] += l.x[d] * inv_n; val[3 + d] += l.y[d] * inv_n; }
+        }
+        block_sum<6>(val, s_out, s_part);
     }
-    g0.x = X[0]; g0.y = X[1]; g0.z = X[2];
-    g0.w += S.dt * (W[0] - X[0]); g1.x += S.dt * (W[1] - X[1]); g1.y += S.dt * (W[2] - X[2]);
-    G1.A0[s] = g0; G1.A1[s] = g1;
+    const double com[6] = {s_out[0], s_out[1], s_out[2], s_out[3], s_out[4], s_out[5]};
+    __syncthreads();
+    {   // compute_H
+        double val[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int it = 0; it < n_iter; it++) {
+            const RigidLane l = rigid_lane(S, cur, nxt, slot_of_pid, body_pids, lo + it * 256 + tid, hi);
+            if (l.s >= 0) for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) val[i * 3 + j] += ((double)l.x[i] - com[i]) * ((double)l.y[j] - com[3 + j]);
+        }
+        block_sum<9>(val, s_out, s_part);
+    }
+    if (tid == 0) {                                            // compute_H_svd + compute_R
+        m3 H, U, V; float sig[3];
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) H.a[r][c] = (float)s_out[r * 3 + c];
+        svd3(H, U, sig, V);
+        const m3 R = m3_mul_nt(V, U);
+        for (int d = 0; d < 3; d++) { sb.c0[d] = (float)com[d]; sb.c1[d] = (float)com[3 + d]; sb.sig[d] = sig[d]; }
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { sb.R[r * 3 + c] = R.a[r][c]; sb.U[r * 3 + c] = U.a[r][c]; sb.V[r * 3 + c] = V.a[r][c]; }
+        sb.inv_n = (float)inv_n;
+    }
+    __syncthreads();
+    if (!BACKWARD) {                                           // advect_kernel, rigid branch: x[f+1] = R (x[f] - COM_t0) + COM_t1
+        for (int it = 0; it < n_iter; it++) {
+            const RigidLane l = rigid_lane(S, cur, nxt, slot_of_pid, body_pids, lo + it * 256 + tid, hi);
+            if (l.s < 0) continue;
+            float o[3];
+            for (int i = 0; i < 3; i++) { o[i] = sb.c1[i]; for (int j = 0; j < 3; j++) o[i] += sb.R[i * 3 + j] * (l.x[j] - sb.c0[j]); }
+            float4 n0 = nxt.A0[l.s];
+            n0.x = o[0]; n0.y = o[1]; n0.z = o[2];
+            nxt.A0[l.s] = n0;
+        }
+        return;
+    }
+    FrameV G1 = frame_view(G1_, S.Np);
+    {   // advect_kernel.grad, rigid branch: R.grad += g (x - COM_t0)^T, COM_t0.grad -= R^T g, COM_t1.grad += g
+        double val[15];
+        for (int k = 0; k < 15; k++) val[k] = 0.0;
+        for (int it = 0; it < n_iter; it++) {
+            const RigidLane l = rigid_lane(S, cur, nxt, slot_of_pid, body_pids, lo + it * 256 + tid, hi);
+            if (l.s < 0) continue;
+            const float4 g0 = G1.A0[l.s];
+            const float g[3] = {g0.x, g0.y, g0.z};
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) val[i * 3 + j] += (double)g[i] * (double)(l.x[j] - sb.c0[j]);
+            for (int j = 0; j < 3; j++) {
+                float rtg = 0; for (int i = 0; i < 3; i++) rtg += sb.R[i * 3 + j] * g[i];
+                val[9 + j] -= (double)rtg; val[12 + j] += g[j];
+            }
+        }
+        block_sum<15>(val, s_out, s_part);
+    }
+    const double gcom_a[6] = {s_out[9], s_out[10], s_out[11], s_out[12], s_out[13], s_out[14]};
+    if (tid == 0) {                                            // compute_R.grad (R = V U^T) and compute_H_svd_grad
+        m3 gR, U, V;
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { gR.a[r][c] = (float)s_out[r * 3 + c]; U.a[r][c] = sb.U[r * 3 + c]; V.a[r][c] = sb.V[r * 3 + c]; }
+        const m3 gV = m3_mul(gR, U), gU = m3_mul_tn(gR, V);
+        const float gS[3] = {0.f, 0.f, 0.f};
+        const m3 gH = backward_svd(gU, gS, gV, U, sb.sig, V);
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) sb.gH[r * 3 + c] = gH.a[r][c];
+    }
+    __syncthreads();
+    {   // compute_H.grad, the part that flows into the COM adjoints
+        double val[6] = {0, 0, 0, 0, 0, 0};
+        for (int it = 0; it < n_iter; it++) {
+            const RigidLane l = rigid_lane(S, cur, nxt, slot_of_pid, body_pids, lo + it * 256 + tid, hi);
+            if (l.s < 0) continue;
+            float ga[3], gb[3];
+            rigid_H_adjoint(sb, l, ga, gb);
+            for (int d = 0; d < 3; d++) { val[d] -= (double)ga[d]; val[3 + d] -= (double)gb[d]; }
+        }
+        block_sum<6>(val, s_out, s_part);
+    }
+    float gc0[3], gc1[3];
+    for (int j = 0; j < 3; j++) { gc0[j] = (float)(gcom_a[j] + s_out[j]); gc1[j] = (float)(gcom_a[3 + j] + s_out[3 + j]); }
+    for (int it = 0; it < n_iter; it++) {                      // particle side
+        const RigidLane l = rigid_lane(S, cur, nxt, slot_of_pid, body_pids, lo + it * 256 + tid, hi);
+        if (l.s < 0) continue;
+        float4 g0 = G1.A0[l.s], g1 = G1.A1[l.s];
+        const float g[3] = {g0.x, g0.y, g0.z};
+        float ga[3], gb[3], X[3], W[3];
+        rigid_H_adjoint(sb, l, ga, gb);
+        for (int j = 0; j < 3; j++) {
+            float rtg = 0; for (int i = 0; i < 3; i++) rtg += sb.R[i * 3 + j] * g[i];
+            X[j] = rtg + ga[j] + gb[j] + (gc0[j] + gc1[j]) * sb.inv_n;
+            W[j] = gb[j] + gc1[j] * sb.inv_n;
+        }
+        g0.x = X[0]; g0.y = X[1]; g0.z = X[2];
+        g0.w += S.dt * (W[0] - X[0]); g1.x += S.dt * (W[1] - X[1]); g1.y += S.dt * (W[2] - X[2]);
+        G1.A0[l.s] = g0; G1.A1[l.s] = g1;
+    }
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -1991,7 +1976,8 @@ struct FeEngine {
     bool prof_fine = false;
     bool has_mesh_effector = false; std::vector<float*> mesh_vox;   // Rigid effectors with an SDF mesh (dynamic.py)
     bool has_rigid = false; int n_bodies = 0;               // MAT_RIGID shape-matching bodies (mpm:176-201)
-    int* rigid_body = nullptr; RigidBody* bodies_dev = nullptr;   // [Np] body of a MAT_RIGID particle or -1 (by particle id); [n_bodies]
+    RigidBody* bodies_dev = nullptr;                        // [n_bodies]
+    int* body_start = nullptr; int* body_pids = nullptr;    // [n_bodies + 1], [n rigid]: the MAT_RIGID particle ids of each body
     int *blk_flag = nullptr, *blk_list = nullptr, *blk_count = nullptr, *err_dev = nullptr;
     float* stage_r = nullptr; int* stage_i = nullptr;       // 24 N floats, N ints
     unsigned char* node_mark = nullptr; unsigned long long* counters = nullptr;
@@ -2200,14 +2186,6 @@ GridW grid_w(FeEngine* h) {
     return g;
 }
 
-// MAT_RIGID: forward moments + rotation of every rigid body for substep f (shared by advect and advect_grad, mpm:428-441)
-void rigid_forward(FeEngine* h, int f, const TableP& T) {
-    hipLaunchKernelGGL(k_rigid_clear, dim3((h->n_bodies * 30 + 255) / 256), dim3(256), 0, h->stream, h->bodies_dev, h->n_bodies);
-    hipLaunchKernelGGL(k_rigid_moments<0>, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T.pid_of_slot, h->rigid_body, h->bodies_dev);
-    hipLaunchKernelGGL(k_rigid_moments<1>, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T.pid_of_slot, h->rigid_body, h->bodies_dev);
-    hipLaunchKernelGGL(k_rigid_solve, dim3((h->n_bodies + 63) / 64), dim3(64), 0, h->stream, h->bodies_dev, h->n_bodies);
-}
-
 // Agent.collide_type (agent.py:17-26): bit 0 = at the particles (g2p), bit 1 = at the grid nodes (grid_op)
 inline bool grid_collide(FeEngine* h) { return h->has_mesh_effector && (h->collide_type & 2); }
 inline bool particle_collide(FeEngine* h) { return h->has_mesh_effector && (h->collide_type & 1); }
@@ -2248,8 +2226,8 @@ int substep_fwd(FeEngine* h, int f, int f_global, int act) {
         hipLaunchKernelGGL(k_g2p<false>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T, h->g_out, h->blk_count, h->slow_dev, ag, f);
     prof_end(h);
     if (h->has_rigid) {
-        rigid_forward(h, f, T);
-        hipLaunchKernelGGL(k_rigid_advect, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T.pid_of_slot, h->rigid_body, h->bodies_dev);
+        hipLaunchKernelGGL(k_rigid_body<false>, dim3(h->n_bodies), dim3(256), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), (float*)nullptr,
+                           h->tables[h->tbl_of_frame[f]].slot_of_pid, h->body_start, h->body_pids, h->bodies_dev);
     }
     return 0;
 }
@@ -2284,12 +2262,9 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act) {
     launch_grid<true>(h, T, f, ag);
     prof_end(h);
     }
-    if (h->has_rigid) {                                   // advect_grad (mpm:436-447) for the rigid bodies, see k_rigid_final_grad
-        rigid_forward(h, f, T);
-        hipLaunchKernelGGL(k_rigid_advect_grad, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), h->grad(f + 1), T.pid_of_slot, h->rigid_body, h->bodies_dev);
-        hipLaunchKernelGGL(k_rigid_solve_grad, dim3((h->n_bodies + 63) / 64), dim3(64), 0, h->stream, h->bodies_dev, h->n_bodies);
-        hipLaunchKernelGGL(k_rigid_H_grad, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T.pid_of_slot, h->rigid_body, h->bodies_dev);
-        hipLaunchKernelGGL(k_rigid_final_grad, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), h->grad(f + 1), T.pid_of_slot, h->rigid_body, h->bodies_dev);
+    if (h->has_rigid) {                                   // advect_grad (mpm:436-447) for the rigid bodies, see k_rigid_body
+        hipLaunchKernelGGL(k_rigid_body<true>, dim3(h->n_bodies), dim3(256), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), h->grad(f + 1),
+                           h->tables[t].slot_of_pid, h->body_start, h->body_pids, h->bodies_dev);
     }
     prof_begin(h, KID_G2P_GRAD);
     if (particle_collide(h)) {
@@ -2454,7 +2429,7 @@ void fe_destroy(FeEngine* h) {
     for (auto& t : h->tables) { for (void* q : {(void*)t.pid, (void*)t.items, (void*)t.meta, (void*)t.blk_first, (void*)t.active, (void*)t.blk_slot, (void*)t.slot_of_pid}) if (q) (void)hipFree(q); }
     void* ptrs[] = {h->frames, h->grads, h->sort_key, h->sort_rank, h->sort_cnt, h->sort_start, h->sort_src, h->sort_pid, h->slow_dev, h->frame_slow_dev, h->gstore, h->gs_flag, h->slab, h->ts_dev, h->sort_partial, h->effs_dev, h->pinfo, h->pool_idx, h->g_in, h->g_out, h->gg_out, h->gg_in,
                     h->blk_flag, h->blk_list, h->blk_count, h->err_dev, h->stage_r, h->stage_i, h->node_mark, h->counters,
-                    h->tgt, h->chamfer, h->step_loss, h->rigid_body, h->bodies_dev, h->statics_dev, h->collector_dev, h->hit_dev, h->hit_list, h->hit_count, h->node_work, h->node_work_count};
+                    h->tgt, h->chamfer, h->step_loss, h->body_start, h->body_pids, h->bodies_dev, h->statics_dev, h->collector_dev, h->hit_dev, h->hit_list, h->hit_count, h->node_work, h->node_work_count};
     for (float* v : h->statics_vox) if (v) (void)hipFree(v);
     for (float* v : h->mesh_vox) if (v) (void)hipFree(v);
     for (void* p : ptrs) if (p) (void)hipFree(p);
@@ -2533,21 +2508,28 @@ int fe_init_particles(FeEngine* h, const fe_real* x, const int* used, const int*
         if (b + 1 > h->n_bodies) h->n_bodies = b + 1;
         if (mat_cls[i] == FE_MAT_RIGID) h->has_rigid = true;
     }
-    if (h->bodies_dev) { (void)hipFree(h->bodies_dev); h->bodies_dev = nullptr; }
+    for (void* q : {(void*)h->bodies_dev, (void*)h->body_start, (void*)h->body_pids}) if (q) (void)hipFree(q);
+    h->bodies_dev = nullptr; h->body_start = nullptr; h->body_pids = nullptr;
     if (h->has_rigid) {
         std::vector<RigidBody> bodies(h->n_bodies);
-        std::vector<int> cnt(h->n_bodies, 0), rb(h->Np, -1);
+        std::vector<int> cnt(h->n_bodies, 0);
+        std::vector<std::vector<int>> members(h->n_bodies);
         std::memset(bodies.data(), 0, sizeof(RigidBody) * bodies.size());
         for (int i = 0; i < N; i++) {
             const int b = body_id ? body_id[i] : 0;
             if (cnt[b]++ == 0) bodies[b].rigid = mat_cls[i] == FE_MAT_RIGID;       // mat_cls[body_id == b][0], mpm:201
-            if (mat_cls[i] == FE_MAT_RIGID) rb[i] = b;
+            if (mat_cls[i] == FE_MAT_RIGID) members[b].push_back(i);
         }
-        for (int b = 0; b < h->n_bodies; b++) bodies[b].inv_n = cnt[b] ? 1.f / (float)cnt[b] : 0.f;
-        if (!h->rigid_body && dev_alloc(h, &h->rigid_body, h->Np)) return 1;
-        if (dev_alloc(h, &h->bodies_dev, h->n_bodies)) return 1;
-        HIPCK(h, hipMemcpyAsync(h->rigid_body, rb.data(), sizeof(int) * h->Np, hipMemcpyHostToDevice, h->stream));
+        std::vector<int> start(h->n_bodies + 1, 0), pids;
+        for (int b = 0; b < h->n_bodies; b++) {
+            bodies[b].inv_n = cnt[b] ? 1.f / (float)cnt[b] : 0.f;
+            pids.insert(pids.end(), members[b].begin(), members[b].end());
+            start[b + 1] = (int)pids.size();
+        }
+        if (dev_alloc(h, &h->bodies_dev, h->n_bodies) || dev_alloc(h, &h->body_start, h->n_bodies + 1) || dev_alloc(h, &h->body_pids, pids.size())) return 1;
         HIPCK(h, hipMemcpyAsync(h->bodies_dev, bodies.data(), sizeof(RigidBody) * h->n_bodies, hipMemcpyHostToDevice, h->stream));
+        HIPCK(h, hipMemcpyAsync(h->body_start, start.data(), sizeof(int) * start.size(), hipMemcpyHostToDevice, h->stream));
+        HIPCK(h, hipMemcpyAsync(h->body_pids, pids.data(), sizeof(int) * pids.size(), hipMemcpyHostToDevice, h->stream));
         HIPCK(h, hipStreamSynchronize(h->stream));
     }
     HIPCK(h, hipMemcpyAsync(h->pinfo, info.data(), sizeof(float4) * h->Np, hipMemcpyHostToDevice, h->stream));
