@@ -1970,6 +1970,7 @@ struct FeEngine {
     unsigned char* hit_dev = nullptr;                                 // contact flags per (frame, slot)
     int* hit_list = nullptr; int* hit_count = nullptr;                // the flagged slots of the frame being differentiated
     NodeWork* node_work = nullptr; int* node_work_count = nullptr;    // grid nodes inside an agent collider (collide_type grid / both)
+    int wgrid_cap = 2048;                                  // workgroups of the work-list kernels (option "wgrid_cap")
     int collide_type = 1;                                  // Agent.collide_type (agent.py:17-26): 1 particle, 2 grid, 3 both
     BoundaryP* collector_dev = nullptr; bool has_collector = false; int collector_mat = -1;     // collector_act_kernel (agent_pouring.py:30-41)
     int inject_till = -1; float collide_min_y = -1e30f;    // AgentIceCreamDynamic (agent_icecreamdynamic.py:11,23-43)
@@ -2048,7 +2049,8 @@ AgentP agent_params(FeEngine* h) {
 
 inline dim3 pgrid(FeEngine* h) { return dim3((h->N + 255) / 256); }
 // work-list kernels loop over (items + tail chunks); the count lives on the device, so launch a bounded grid
-inline dim3 wgrid(FeEngine* h) { int g = (h->N + 63) / 64 + 8; return dim3(g < 2048 ? g : 2048); }
+// ("wgrid_cap": upper bound; the lower bound keeps sparse scenes -- few particles per item -- from serialising their items)
+inline dim3 wgrid(FeEngine* h) { int g = (h->N + 63) / 64 + 8; if (g < 512) g = 512; return dim3(g < h->wgrid_cap ? g : h->wgrid_cap); }
 inline dim3 ggrid(FeEngine* h) { int blocks = h->nb * h->nb * h->nb; int g = (blocks + 3) / 4; return dim3(g < 1024 ? g : 1024); }
 
 void prof_drain(FeEngine* h);
@@ -2479,6 +2481,7 @@ int fe_set_option(FeEngine* h, const char* name, double value) {
     }
     if (!std::strcmp(name, "prof_fine")) { h->prof_fine = value != 0; return 0; }
     if (!std::strcmp(name, "xcd_map")) { h->S.xcd = value != 0; return 0; }
+    if (!std::strcmp(name, "wgrid_cap")) { if (value < 64) { h->err = "wgrid_cap must be >= 64"; return 1; } h->wgrid_cap = (int)value; return 0; }
     if (!std::strcmp(name, "dbg")) { h->S.dbg = (int)value; return 0; }     // timing experiments: results are wrong
     if (!std::strcmp(name, "threads")) return 0;             // oracle-only tunable
     FAIL(h, std::string("unknown option: ") + name);
