@@ -736,11 +736,14 @@ __device__ __forceinline__ void load_tile4(const TileO& to, const SimP& S, const
     }
 }
 
+// (u, a0): the slot's `used` flag and first state plane, loaded by the caller -- in the item path before the tile load and
+// its barrier, so that the particle loads do not queue up behind them (a substep kernel at this size is one workgroup's chain of
+// dependent HBM round trips: table -> item -> tile -> barrier -> particle -> ...)
 template <bool COLLIDE>
 __device__ __forceinline__ void slot_g2p(const SimP& S, const FrameV& cur, const FrameV& nxt, int s, bool use_tile,
-                                         const TileO& to, const float4* __restrict__ g_out, int* slow, const AgentP& agent, int f) {
-    if (!cur.used[s]) return;
-    float4 a0 = cur.A0[s];
+                                         const TileO& to, const float4* __restrict__ g_out, int* slow, const AgentP& agent, int f,
+                                         int u, const float4 a0) {
+    if (!u) return;
     float x[3] = {a0.x, a0.y, a0.z};
     Stencil st;
     stencil_make(x, S.inv_dx, st);
@@ -767,14 +770,20 @@ __global__ __launch_bounds__(WG) void k_g2p(SimP S, float* fr_cur, float* fr_nex
         if (w < n_items) {
             const int4 it = T.items[w];
             const TileO to = tile_origin(it.x, S.nb);
+            const int s0 = it.y + (tid < it.z ? tid : 0);       // items hold <= item_max <= WG particles: one pass
+            int u = cur.used[s0];
+            float4 a0 = cur.A0[s0];
             load_tile3(to, S, g_out, tid);
             __syncthreads();
-            for (int i = tid; i < it.z; i += WG) slot_g2p<COLLIDE>(S, cur, nxt, it.y + i, true, to, g_out, slow, agent, f);
+            for (int i = tid; i < it.z; i += WG) {
+                if (i != tid) { u = cur.used[it.y + i]; a0 = cur.A0[it.y + i]; }
+                slot_g2p<COLLIDE>(S, cur, nxt, it.y + i, true, to, g_out, slow, agent, f, u, a0);
+            }
             __syncthreads();
         } else {
             const int s = tail_start + (w - n_items) * WG + tid;
             TileO none = {0, 0, 0};
-            if (s < S.N) slot_g2p<COLLIDE>(S, cur, nxt, s, false, none, g_out, slow, agent, f);
+            if (s < S.N) slot_g2p<COLLIDE>(S, cur, nxt, s, false, none, g_out, slow, agent, f, cur.used[s], cur.A0[s]);
         }
     }
 }
@@ -920,14 +929,19 @@ __global__ __launch_bounds__(WG) void k_g2p_grad(SimP S, float* fr_cur, float* G
         if (w < n_items) {
             const int4 it = T.items[w];
             const TileO to = tile_origin(it.x, S.nb);
+            // the particle loads go out ahead of the tile load and its barrier (see slot_g2p); items hold <= WG particles
+            const int s0 = it.y + (tid < it.z ? tid : 0);
+            int u0 = cur.used[s0];
+            float4 a00 = cur.A0[s0];
             if (stored) load_tile3_store(to, S, T, GS.data + (size_t)f * GS.cap * 128, tid); else load_tile3(to, S, g_out, tid);
             for (int l = tid; l < 3 * TILE_N; l += WG) s_acc[l] = 0.0;
             __syncthreads();
             for (int i0 = 0; i0 < it.z; i0 += WG) {              // uniform trip count: the DPP scan needs every lane
                 const int i = i0 + tid, s = it.y + i;
-                const bool used = i < it.z && cur.used[s] != 0;
+                if (i0 > 0 && i < it.z) { u0 = cur.used[s]; a00 = cur.A0[s]; }
+                const bool used = i < it.z && u0 != 0;
                 float x[3] = {0.f, 0.f, 0.f};
-                if (used) { float4 a0 = cur.A0[s]; x[0] = a0.x; x[1] = a0.y; x[2] = a0.z; }
+                if (used) { x[0] = a00.x; x[1] = a00.y; x[2] = a00.z; }
                 Stencil st;
                 stencil_make(x, S.inv_dx, st);
                 const bool inside = used && stencil_inside(st, S.n);
