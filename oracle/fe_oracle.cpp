@@ -11,8 +11,13 @@
  * line by line (citations as `mpm:NNN`); the adjoints, which the reference obtains
  * from Taichi's source-transform autodiff, are hand-derived here and validated
  * against central finite differences of this file's own forward (tests/).
+ * Also restated: boundaries.py, effector.py / injector.py / aircon.py / rigid.py,
+ * meshes/static.py + dynamic.py (SDF colliders), the agents' collector kernels,
+ * smoke_field.py and shapematching_loss.py.
  * Third-party arithmetic not in /root/reference: taichi==1.1.0 `ti.svd` (McAdams
- * et al. 3x3 SVD; contract restated in svd3() below).
+ * et al. 3x3 SVD; contract restated in svd3() below) and mesh_to_sdf 0.0.x (the
+ * signed distance it approximates by virtual scans is computed exactly in
+ * fe_mesh_sdf() below: point-triangle distance + generalized winding number).
  *
  * Build: see oracle/Makefile (-DFE_REAL=float -> libfe_oracle_f32.so, double -> _f64).
  */
