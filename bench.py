@@ -93,6 +93,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-replica-probe', action='store_true')
     ap.add_argument('--opt', action='append', default=[], help='engine option name=value (tuning sweeps)')
     args = ap.parse_args()
 
@@ -146,7 +147,7 @@ def main():
         wall = float(t.item())
 
     # ---- untimed extras (rank 0 reports)
-    fwd_rate = prof = stats = None
+    fwd_rate = prof = stats = two = None
     if rank == 0:
         barrier_local = lambda: (eng.sync(), torch.cuda.synchronize())
         barrier_local()
@@ -161,6 +162,21 @@ def main():
         prof = eng.profile_read()
         eng.profile_enable(False)
         stats = eng.get_stats(CHUNK // 2)
+        # How much of the chip one 200k-particle scene leaves idle: a second, independent replica of the same scene on the same
+        # GPU (its own engine and HIP stream), both driven from this thread.  Reported beside `value`, never part of it.
+        two = None
+        if world == 1 and not args.no_replica_probe:
+            eng2, _ = build_engine(elib, local_rank)
+            for e in (eng, eng2):
+                one_step(e, CHUNK)
+            eng2.sync(); barrier_local()
+            n2 = max(3, args.steps // 3)
+            t2 = time.perf_counter()
+            for _ in range(n2):
+                one_step(eng, CHUNK); one_step(eng2, CHUNK)
+            eng2.sync(); barrier_local()
+            two = 2 * n2 * CHUNK / (time.perf_counter() - t2)
+            eng2.close()
     if dist is not None:
         dist.barrier()
 
@@ -199,6 +215,8 @@ def main():
             'pair_roofline': {'alg_bytes_per_pair': b_pair, 'achieved_GBps': round(b_pair * value / world / 1e9, 1),
                               'frac': round(b_pair * value / world / 1e9 / HBM_PEAK_GBS, 4)},
             'forward_only_substeps_per_s': round(fwd_rate, 1),
+            'two_replicas_one_gpu': None if two is None else {'value': round(two, 1), 'unit': 'substep_pairs/s (both scenes)', 'ratio_to_value': round(two / value, 3),
+                                                              'note': 'two independent engines/streams on this GPU; not part of `value`'},
             'hip_event_ms_per_step_rank0': round(ev_ms / args.steps, 3),
             'kernels': per_kernel,
         }

@@ -5,7 +5,7 @@ OUT=gpurun_out/$TAG; mkdir -p $OUT
 for cfg in "$@"; do
   args=""; for o in $cfg; do args="$args --opt $o"; done
   echo "== $cfg"
-  timeout 300 python bench.py --steps 6 --warmup 2 --no-cpu-baseline $args 2>/dev/null | tail -1 | python -c "
+  timeout 300 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-replica-probe $args 2>/dev/null | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
 k=d['kernels']
