@@ -175,3 +175,67 @@ def test_hip_mesh_sdf_at_the_reference_size(hiplib):
     assert np.abs(d - ref).max() < 2e-4
     print(f'fe_mesh_sdf 128^3 x {len(ball.faces)} triangles: {dt:.3f} s wall (upload + kernel + download)')
     assert dt < 20.0
+
+
+REF_DUCK_VOX = '/root/reference/fluidlab/assets/meshes/voxelized/duck-128.vox'
+REF_DUCK_OBJ = '/root/reference/fluidlab/assets/meshes/raw/duck.obj'
+
+
+@pytest.mark.skipif(not (os.path.exists(REF_DUCK_VOX) and os.path.exists(REF_DUCK_OBJ)), reason='needs the reference checkout (build container only)')
+def test_voxelisation_against_reference_grid(oracle64):
+    """The one output of its mesh tooling the reference ships: the trimesh voxel grid of duck.obj at pitch 1/128, pickled
+    (bodies.py:190-199).  Its arrays are read straight from the pickle stream (a bool [79, 81, 129] occupancy and the 4x4
+    index -> mesh-frame transform; unpickling would need trimesh) and compared with this package's voxelisation of the same .obj."""
+    import pickletools
+    from fluidlab_amd.utils.mesh import FILL_REACH
+    blobs = [arg for op, arg, pos in pickletools.genops(open(REF_DUCK_VOX, 'rb').read()) if op.name in ('BINBYTES', 'SHORT_BINBYTES') and len(arg) > 100]
+    occ = np.frombuffer(blobs[0], dtype=np.bool_).reshape(79, 81, 129)
+    T = np.frombuffer(blobs[1], dtype='<f8').reshape(4, 4)
+    pitch = T[0, 0]
+    assert pitch == 1.0 / 128 and np.allclose(T[:3, :3], np.eye(3) * pitch)
+    assert np.allclose(T[:3, 3] / pitch, np.round(T[:3, 3] / pitch))           # voxel centres at integer multiples of the pitch
+    mesh = M.normalize_mesh(M.load_mesh(REF_DUCK_OBJ))
+    assert len(mesh.faces) == 31872
+    # the occupied voxels span the normalised mesh's bounding box
+    filled = np.argwhere(occ) @ T[:3, :3].T + T[:3, 3]
+    assert np.abs(filled.min(0) - mesh.vertices.min(0)).max() <= pitch and np.abs(filled.max(0) - mesh.vertices.max(0)).max() <= pitch
+    rng = np.random.RandomState(0)
+    idx = np.stack(np.unravel_index(rng.choice(occ.size, 12000, replace=False), occ.shape), 1)
+    pts = idx @ T[:3, :3].T + T[:3, 3]
+    d = oracle64.mesh_sdf(mesh.vertices, mesh.faces, pts)
+    ref = occ[idx[:, 0], idx[:, 1], idx[:, 2]]
+    mine = d <= FILL_REACH * pitch
+    assert (mine == ref).mean() >= 0.995
+    off = np.abs(d[mine != ref]) / pitch
+    assert off.min() >= 0.45 and off.max() <= 0.87        # only voxels the surface grazes: centre between half and sqrt(3)/2 pitches away
+    # and through the same lookup the body sampler uses
+    from fluidlab_amd.utils.mesh import FilledVoxels
+    n = 2 * (128 // 2 + 1) + 1
+    full = np.zeros((n, n, n), bool)
+    lo = np.round(T[:3, 3] / pitch).astype(int) + n // 2
+    full[lo[0]:lo[0] + 79, lo[1]:lo[1] + 81, lo[2]:lo[2] + 129] = occ
+    vox = FilledVoxels(full, 128)
+    q = rng.uniform(-0.5, 0.5, (5000, 3))
+    near = np.round(q / pitch).astype(int) - np.round(T[:3, 3] / pitch).astype(int)
+    inb = ((near >= 0) & (near < occ.shape)).all(1)
+    expect = np.zeros(len(q), bool)
+    expect[inb] = occ[near[inb, 0], near[inb, 1], near[inb, 2]]
+    assert (vox.is_filled(q) == expect).all()
+
+
+REF_MESHES = '/root/reference/fluidlab/assets/meshes/'
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_MESHES + 'processed'), reason='needs the reference checkout (build container only)')
+@pytest.mark.parametrize('raw,vis,processed', [('plate.obj', 'plate.obj', 'plate-plate.obj'), ('cup.obj', 'cup.obj', 'cup-cup.obj'),
+                                               ('stirrer.obj', 'stirrer.obj', 'stirrer-stirrer.obj'), ('glass.obj', 'glass_vis.obj', 'glass-glass_vis.obj'),
+                                               ('room.obj', 'room.obj', 'room-room.obj'), ('board.obj', 'board.obj', 'board-board.obj')])
+def test_normalised_meshes_against_reference_outputs(raw, vis, processed):
+    """assets/meshes/processed/*.obj are what the reference's Mesh.process_mesh wrote (mesh.py:72-82: normalize_mesh(raw_vis, raw),
+    exported by trimesh, which also merges duplicate vertices).  load_mesh + normalize_mesh here give the same vertex set."""
+    from scipy.spatial import cKDTree
+    mine = M.normalize_mesh(M.load_mesh(REF_MESHES + 'raw/' + vis), M.load_mesh(REF_MESHES + 'raw/' + raw))
+    ref = M.load_mesh(REF_MESHES + 'processed/' + processed)
+    assert cKDTree(mine.vertices).query(ref.vertices)[0].max() < 2e-8          # the export keeps 8 decimals
+    assert cKDTree(ref.vertices).query(mine.vertices)[0].max() < 2e-8
+    assert len(ref.vertices) <= len(mine.vertices)
