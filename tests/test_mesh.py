@@ -239,3 +239,31 @@ def test_normalised_meshes_against_reference_outputs(raw, vis, processed):
     assert cKDTree(mine.vertices).query(ref.vertices)[0].max() < 2e-8          # the export keeps 8 decimals
     assert cKDTree(ref.vertices).query(mine.vertices)[0].max() < 2e-8
     assert len(ref.vertices) <= len(mine.vertices)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_MESHES + 'raw'), reason='needs the reference checkout (build container only)')
+def test_envs_build_from_the_reference_mesh_tree(oracle32, tmp_path, monkeypatch):
+    """With FLUIDLAB_ASSETS pointing at the reference's meshes/raw (read-only, linked into a scratch tree so the caches have a
+    place), every env whose meshes are there uses them: colliders through fe_mesh_sdf, the Gathering ducks as mesh-filled
+    bodies.  Resolutions are cut so the CPU oracle finishes in seconds."""
+    (tmp_path / 'meshes').mkdir()
+    os.symlink(REF_MESHES + 'raw', tmp_path / 'meshes' / 'raw')
+    monkeypatch.setenv('FLUIDLAB_ASSETS', str(tmp_path))
+    sdf, vox = M.load_or_compute_sdf, M.load_or_voxelize
+    monkeypatch.setattr(M, 'load_or_compute_sdf', lambda file, res, elib, device=0: sdf(file, 16, elib, device))
+    monkeypatch.setattr(M, 'load_or_voxelize', lambda file, res, elib, device=0: vox(file, 16, elib, device))
+    from fluidlab_amd.envs import make
+    used = {}
+    for name in ('GatheringEasy-v0', 'GatheringO-v0', 'Mixing-v0', 'Pouring-v0', 'LatteArtStir-v0'):
+        env = make(name, seed=0, loss=False, engine_lib=oracle32, quality=0.5, particle_density=2e4, horizon=4, max_substeps_local=None)
+        te = env.taichi_env
+        for _ in range(2):
+            te.step(np.zeros(te.agent.action_dim))
+        assert np.isfinite(te.get_state()['state']['x']).all(), name
+        mesh = te.agent.effectors[0].mesh
+        used[name] = mesh.raw_file
+        assert mesh.sdf_voxels_np.shape == (16, 16, 16), name              # from the .obj, not the 64^3 analytic stand-in
+    assert used == {'GatheringEasy-v0': 'plate.obj', 'GatheringO-v0': 'plate.obj', 'Mixing-v0': 'stirrer.obj', 'Pouring-v0': 'glass.obj',
+                    'LatteArtStir-v0': 'stirrer.obj'}
+    cached = sorted(os.listdir(tmp_path / 'meshes' / 'processed'))
+    assert cached == ['glass-16.sdf', 'plate-16.sdf', 'stirrer-16.sdf'] and os.listdir(tmp_path / 'meshes' / 'voxelized') == ['duck-16.vox']
