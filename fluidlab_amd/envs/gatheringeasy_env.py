@@ -39,7 +39,9 @@ class GatheringEasyEnv(FluidEnv):
     def setup_agent(self):
         agent_cfg = CfgNode()
         agent_cfg.merge_from_file(get_cfg_path('agent_gatheringeasy.yaml'))
-        agent_cfg.effectors[0]['mesh']['sdf'] = sdf_box((0.06, 0.5, 0.5))         # plate.obj stand-in: a thin slab
+        # plate.obj stand-in: the real mesh, normalised, has half extents (0.333, 0.5, 0.083) -- thin along its z, which the yaml's
+        # euler (0, 90, 0) turns into the world x the plate pushes along
+        agent_cfg.effectors[0]['mesh']['sdf'] = sdf_box((0.333, 0.5, 0.083))
         agent_cfg.effectors[0]['mesh']['sdf_res'] = 64
         self.taichi_env.setup_agent(agent_cfg)
         self.agent = self.taichi_env.agent

@@ -34,7 +34,7 @@ class MixingEnv(FluidEnv):
         agent_cfg = CfgNode()
         agent_cfg.merge_from_file(get_cfg_path('agent_mixing.yaml'))
         agent_cfg.effectors[0]['mesh']['sdf'] = sdf_stirrer()
-        agent_cfg.effectors[0]['mesh']['sdf_res'] = 64
+        agent_cfg.effectors[0]['mesh']['sdf_res'] = 128          # the rod is ~4 voxels thick at the reference's resolution
         self.taichi_env.setup_agent(agent_cfg)
         self.agent = self.taichi_env.agent
 

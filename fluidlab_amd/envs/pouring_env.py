@@ -37,9 +37,10 @@ class PouringEnv(FluidEnv):
     def setup_agent(self):
         agent_cfg = CfgNode()
         agent_cfg.merge_from_file(get_cfg_path('agent_pouring.yaml'))
-        # glass.obj stand-in: with scale (0.75, 0.65, 0.75) a cup of radius 0.3 / height 1 in the mesh frame is 0.225 wide and
-        # 0.65 tall in the world and holds the two liquid columns (radius 0.18, 0.43 <= y <= 0.83) when centred at (0.6, 0.7, 0.5)
-        agent_cfg.effectors[0]['mesh']['sdf'] = sdf_cup(radius=0.3, half_height=0.5, wall=0.05)
+        # glass.obj stand-in.  The real mesh, normalised, is 1 tall, slightly tapered (outer radius 0.34 -> 0.40, wall 0.08, bottom
+        # 0.07 thick: measured with fe_mesh_sdf on the reference's asset); with scale (0.75, 0.65, 0.75) its cavity (radius >= 0.2 in the
+        # world) holds the two liquid columns (radius 0.18, 0.43 <= y <= 0.83) when centred at (0.6, 0.7, 0.5)
+        agent_cfg.effectors[0]['mesh']['sdf'] = sdf_cup(radius=0.37, half_height=0.5, wall=0.08)
         agent_cfg.effectors[0]['mesh']['sdf_res'] = 64
         self.taichi_env.setup_agent(agent_cfg)
         self.agent = self.taichi_env.agent

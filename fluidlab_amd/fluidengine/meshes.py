@@ -87,8 +87,9 @@ def sdf_cone_tip(r_bottom=0.10, r_top=0.28, z_bottom=-0.25, z_top=0.10, dent=0.0
     return fn
 
 
-def sdf_stirrer(r=0.09, half_height=0.5):
-    """stand-in for the reference's stirrer.obj: a vertical rod (axis y) with a rounded tip, in the mesh frame"""
+def sdf_stirrer(r=0.035, half_height=0.5):
+    """stand-in for the reference's stirrer.obj: a vertical rod (axis y) in the mesh frame.  The real mesh, normalised, is 1 tall
+    and 0.031-0.04 in radius (measured with fe_mesh_sdf on the reference's asset)."""
     def fn(p):
         d = np.stack([np.hypot(p[:, 0], p[:, 2]) - r, np.abs(p[:, 1]) - half_height], axis=1)
         return np.minimum(d.max(axis=1), 0) + np.linalg.norm(np.maximum(d, 0), axis=1)
