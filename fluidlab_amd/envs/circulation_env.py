@@ -16,19 +16,30 @@ from fluidlab_amd.utils.misc import get_cfg_path
 from .fluid_env import FluidEnv
 
 
-def sdf_room(half=0.33, wall=0.03):
-    """mesh frame (about [-0.5, 0.5]^3): solid everywhere except the room's interior; two partition walls along z with a
-    doorway each"""
-    def box(p, c, h):
-        q = np.abs(p - np.asarray(c)) - np.asarray(h)
+ROOM_SCALE = np.array([1.4, 3.0, 1.4])          # circulation_env.py's add_static(room.obj, scale=...), about (0.5, 0.5, 0.5)
+
+
+def sdf_room():
+    """Stand-in for room.obj, after the floor plan of the reference's mesh (mapped with fe_mesh_sdf on the asset): the free space
+    is x in [0.05, 0.95], z in [0.22, 0.80] over the whole height, split into four rooms -- a wall at x = 0.38 with doorways at
+    z in [0.29, 0.38] and [0.59, 0.71], a wall at z = 0.49 between the two rooms on its low-x side, and a wall at x = 0.68 with a
+    doorway at z in [0.41, 0.56].  Written in world coordinates, returned in the mesh frame the SDF lattice samples (distances
+    divided by the xz scale; only sign and direction matter to the colliders)."""
+    def box(w, lo, hi):
+        c, h = (np.asarray(lo) + np.asarray(hi)) / 2, (np.asarray(hi) - np.asarray(lo)) / 2
+        q = np.abs(w - c) - h
         return np.linalg.norm(np.maximum(q, 0), axis=1) + np.minimum(q.max(axis=1), 0)
 
+    walls = [((0.36, -1, 0.22), (0.40, 2, 0.29)), ((0.36, -1, 0.38), (0.40, 2, 0.59)), ((0.36, -1, 0.71), (0.40, 2, 0.80)),
+             ((0.05, -1, 0.47), (0.38, 2, 0.51)),
+             ((0.66, -1, 0.22), (0.70, 2, 0.41)), ((0.66, -1, 0.56), (0.70, 2, 0.80))]
+
     def fn(p):
-        interior = box(p, (0, 0, 0), (half - wall, half, half - wall))             # negative inside the room
-        solid = -interior                                                            # walls: outside the interior
-        part1 = box(p, (-0.12, 0, -0.18), (wall / 2, half, 0.22))                    # partition with a gap towards +z
-        part2 = box(p, (0.14, 0, 0.2), (wall / 2, half, 0.2))                        # partition with a gap towards -z
-        return np.minimum(solid, np.minimum(part1, part2))
+        w = p * ROOM_SCALE + 0.5
+        d = -box(w, (0.05, -1, 0.22), (0.95, 2, 0.80))              # solid outside the free space
+        for lo, hi in walls:
+            d = np.minimum(d, box(w, lo, hi))
+        return d / ROOM_SCALE[0]
     return fn
 
 
