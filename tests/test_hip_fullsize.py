@@ -15,8 +15,23 @@ pytestmark = pytest.mark.gpu
 N_GRID, N = 128, 200000
 
 
-def _scene(**kw):
-    return S.water_block(n_grid=N_GRID, n_particles=N, seed=0, **kw)
+def _scene(n_grid=N_GRID, n=N, **kw):
+    return S.water_block(n_grid=n_grid, n_particles=n, seed=0, **kw)
+
+
+def test_largest_config_conserves_momentum(hiplib):
+    """BASELINE configs' largest case (256^3 grid, 1M particles): uniform motion preserved, momentum of a stirred block conserved"""
+    n = 1000000
+    sc = _scene(256, n, gravity=(0.0, 0.0, 0.0))
+    rng = np.random.RandomState(4)
+    sc['v'] = S.f32(rng.normal(0, 0.3, (n, 3)) + [0.2, 0.1, -0.1])
+    eng = S.make_engine(hiplib, sc, max_substeps_local=8)
+    p0 = sc['v'].astype(np.float64).sum(0)
+    st = S.run_forward(eng, 6)
+    assert (st['used'] == 1).all() and np.isfinite(st['x']).all()
+    assert np.abs(st['v'].astype(np.float64).sum(0) - p0).max() <= 2e-6 * np.abs(sc['v']).astype(np.float64).sum()
+    assert eng.get_stats(5)['n_used'] == n
+    eng.close()
 
 
 def test_uniform_motion_is_preserved(hiplib):
