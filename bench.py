@@ -94,6 +94,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-replica-probe', action='store_true')
+    ap.add_argument('--dist-backend', default='nccl', help="'gloo' + --one-device: exercise the N>1 control flow on a 1-GPU box")
+    ap.add_argument('--one-device', action='store_true', help='testing only: every rank uses GPU 0')
     ap.add_argument('--opt', action='append', default=[], help='engine option name=value (tuning sweeps)')
     args = ap.parse_args()
 
@@ -102,11 +104,16 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     dist = None
+    if args.one_device:
+        local_rank = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if args.dist_backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(args.dist_backend)
     else:
         torch.cuda.set_device(local_rank)
 
@@ -116,7 +123,8 @@ def main():
     for o in args.opt:
         k, v = o.split('=')
         eng.set_option(k, float(v))
-    action_grad = torch.zeros((251, 3), device='cuda')    # LatteArt-sized action gradient
+    coll_dev = 'cuda' if args.dist_backend == 'nccl' else 'cpu'
+    action_grad = torch.zeros((251, 3), device=coll_dev)  # LatteArt-sized action gradient
 
     def barrier():
         eng.sync()
@@ -142,7 +150,7 @@ def main():
     barrier()
     wall = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([wall], device='cuda', dtype=torch.float64)
+        t = torch.tensor([wall], device=coll_dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         wall = float(t.item())
 
