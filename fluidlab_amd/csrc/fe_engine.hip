@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -2384,6 +2385,7 @@ FeEngine* fe_create(const FeConfig* cfg) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_create_err = "no HIP device visible: the MI355X engine has no CPU fallback"; return nullptr; }
     if (cfg->device < 0 || cfg->device >= ndev) { g_create_err = "HIP device ordinal out of range"; return nullptr; }
     FeEngine* h = new FeEngine();
+    if (const char* e = std::getenv("FE_SORT_INTERVAL")) h->sort_interval = std::atoi(e);     // tuning experiments (the option of the same name wins)
     h->cfg = *cfg; h->N = cfg->n_particles; h->L = cfg->max_substeps_local; h->n = cfg->n_grid; h->nb = cfg->n_grid / 4;
     h->Np = ((h->N + 63) / 64) * 64; if (h->Np == 0) h->Np = 64;
     h->device = cfg->device;
