@@ -45,3 +45,20 @@ def test_hip_engine_fails_loudly_without_gpu():
     lib = _capi.load_hip()
     with pytest.raises(_capi.FeEngineError, match='no HIP device|no CPU fallback'):
         S.make_engine(lib, S.water_block(n_grid=8, n_particles=8))
+
+
+def test_bench_byte_accounting_matches_the_survey():
+    """bench.py credits each kernel its algorithmic bytes; they have to add up to SURVEY 8d's per-unit figures:
+    forward 216 N + 72 Nc, backward 308 N + 132 Nc, pair 524 N + 204 Nc."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location('bench', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    kb = bench.KERNEL_BYTES
+    fwd = [kb[k] for k in bench.FWD_KERNELS]
+    bwd = [kb[k] for k in ('p2g_recompute', 'grid_op_keep', 'g2p_grad', 'grid_op_grad', 'p2g_grad')]
+    assert (sum(p for p, _ in fwd), sum(c for _, c in fwd)) == (216, 72)
+    assert (sum(p for p, _ in bwd), sum(c for _, c in bwd)) == (308, 132)
+    assert kb['sort'] == (0, 0) and kb['reorder_grad'] == (0, 0)            # layout overhead is never credited
+    assert bench.HBM_PEAK_GBS == 8000.0 and bench.N_GRID == 128 and bench.N_PARTICLES == 200000
