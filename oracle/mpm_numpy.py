@@ -99,8 +99,54 @@ def static_collide(static, xn, v):
     return out
 
 
-def substep(x, v, C, F, used, mu, lam, mass, mat_cls, n_grid, dt, p_vol, gravity, bnd, body_id=None, statics=()):
-    """One forward substep (mpm:515-533, no agent).  Returns x', v', C', F'."""
+def _quat_rot(v, q):
+    """geom.py:86-90 transform_by_quat (rows of v by one quaternion wxyz)"""
+    qv = np.asarray(q[1:], np.float64)
+    uv = np.cross(qv, v)
+    uuv = np.cross(qv, uv)
+    return v + 2 * (q[0] * uv + uuv)
+
+
+def dynamic_collide(dyn, pos, v, dt):
+    """Dynamic.collide (dynamic.py:90-122) for positions pos [M,3] and material velocities v [M,3].  dyn: voxels, T (mesh ->
+    voxels), friction, softness, and the carrier's pose at f and f+1 (pos0, quat0, pos1, quat1)."""
+    vox, T = np.asarray(dyn['voxels'], np.float64), np.asarray(dyn['T'], np.float64)
+    q0 = np.asarray(dyn['quat0'], np.float64)
+    qi = np.array([q0[0], -q0[1], -q0[2], -q0[3]]) / np.linalg.norm(q0)                  # inv_quat(...).normalized(), geom.py:30-32
+    pm = _quat_rot(pos - np.asarray(dyn['pos0'], np.float64), qi)                       # dynamic.py:33
+    pv = pm @ T[:3, :3].T + T[:3, 3]
+    sd = _sdf_sample(vox, pv)
+    infl = np.minimum(np.exp(-sd * dyn['softness']), 1.0)
+    hit = (sd <= 0) | ((dyn['softness'] > 0) & (infl > 0.1))
+    out = v.copy()
+    if not hit.any():
+        return out
+    pm_h, pv_h, vh, infl_h = pm[hit], pv[hit], v[hit], infl[hit]
+    cv = (_quat_rot(pm_h, np.asarray(dyn['quat1'], np.float64)) + np.asarray(dyn['pos1'], np.float64) - pos[hit]) / dt     # collider_v, :84-88
+    if dyn['friction'] > 10.0:
+        out[hit] = cv
+        return out
+    rel = vh - cv
+    g = np.zeros_like(pv_h)
+    for d in range(3):
+        e = np.zeros(3); e[d] = 1e-2
+        g[:, d] = (_sdf_sample(vox, pv_h + e) - _sdf_sample(vox, pv_h - e)) / 2e-2
+    g /= np.sqrt((g ** 2).sum(1) + EPS)[:, None]
+    n = _quat_rot(g @ np.linalg.inv(T[:3, :3]).T, q0)
+    n /= np.sqrt((n ** 2).sum(1) + EPS)[:, None]
+    nc = (rel * n).sum(1)
+    vt = rel - np.minimum(nc, 0)[:, None] * n
+    vtn = np.linalg.norm(vt, axis=1)
+    flag = (nc < 0) & (vtn > EPS)
+    scale = np.where(flag, np.maximum(0, vtn + nc * dyn['friction']) / np.where(vtn > 0, vtn, 1.0), 1.0)
+    out[hit] = cv + (vt * scale[:, None]) * infl_h[:, None] + rel * (1 - infl_h)[:, None]
+    return out
+
+
+def substep(x, v, C, F, used, mu, lam, mass, mat_cls, n_grid, dt, p_vol, gravity, bnd, body_id=None, statics=(), dynamic=None,
+            collide_type=1):
+    """One forward substep (mpm:515-533).  `dynamic`: a moving SDF collider (see dynamic_collide) applied at the particles
+    (collide_type & 1, mpm:418-422) and/or at the grid nodes (collide_type & 2, mpm:393-395).  Returns x', v', C', F'."""
     n = n_grid
     dx, inv_dx = 1.0 / n, float(n)
     act = used.astype(bool)
@@ -142,6 +188,8 @@ def substep(x, v, C, F, used, mu, lam, mass, mat_cls, n_grid, dt, p_vol, gravity
     xn = np.stack([ii, jj, kk], 1) * dx
     for st in statics:                                                  # mpm:386-390
         vo = static_collide(st, xn, vo)
+    if dynamic is not None and (collide_type & 2):                      # mpm:393-395
+        vo = dynamic_collide(dynamic, xn, vo, dt)
     v_out[occ] = boundary_v(bnd, xn, vo)
     # g2p (mpm:400-426)
     nv = np.zeros_like(vs)
@@ -156,6 +204,8 @@ def substep(x, v, C, F, used, mu, lam, mass, mat_cls, n_grid, dt, p_vol, gravity
                 gv = v_out[idx[:, 0], idx[:, 1], idx[:, 2]]
                 nv += wt[:, None] * gv
                 nC += 4 * inv_dx * wt[:, None, None] * gv[:, :, None] * dpos[:, None, :]
+    if dynamic is not None and (collide_type & 1):                      # mpm:418-422
+        nv = dynamic_collide(dynamic, xs + dt * nv, nv, dt)
     x2, v2, C2, F2 = x.copy(), v.copy(), C.copy(), F.copy()
     xn2 = xs + dt * nv                                                  # mpm:505
     if body_id is not None and (cls == MAT_RIGID).any():

@@ -87,6 +87,47 @@ def test_static_colliders_match_numpy(oracle64):
     assert np.abs(got['v'] - got_free['v']).max() > 0.05           # the colliders changed the flow
 
 
+@pytest.mark.parametrize('variant', ['friction', 'soft', 'sticky', 'friction-grid', 'friction-both'])
+def test_dynamic_collider_matches_numpy(oracle64, variant):
+    """A Rigid effector's moving SDF collider (dynamic.py:29-122): the C++ restatement against the independent numpy one, substep
+    by substep with the effector poses the engine produced -- contact at the particles (mpm:418-422), at the grid nodes
+    (mpm:393-395) or both, with friction, softness and the sticky (friction > 10) branch."""
+    variant, _, where = variant.partition('-')
+    kw = dict(friction=dict(friction=0.5, softness=0.0), soft=dict(friction=0.1, softness=60.0), sticky=dict(friction=20.0, softness=0.0))[variant]
+    sc = S.stirrer_mini(shape='sphere', **kw)
+    ct = dict(grid=2, both=3).get(where, 1)
+    eng = S.make_engine(oracle64, sc)
+    r = sc['rigid']
+    e = eng.add_effector(type=S.FE_EFF_PLAIN, action_dim=6, action_scale_v=r['action_scale_v'], action_scale_p=r['action_scale_p'],
+                         boundary=oracle64.make_boundary(**r['boundary']))
+    eng.eff_set_mesh(e, r['voxels'], r['T'], friction=r['friction'], softness=r['softness'])
+    eng.set_option('collide_type', ct)
+    st0 = eng.eff_get_state(e, 0); st0[:7] = r['init_state']; eng.eff_set_state(e, 0, st0)
+    eng.eff_apply_action_p(e, sc['action_p'])
+    ns = sc['n_substeps']
+    props = np.array([S.MATERIALS[int(m)] for m in sc['mat']])
+    n = sc['n_grid']
+    st = S.get_state(eng, 0)
+    x, v, C, F = (st[k].astype(np.float64) for k in 'xvCF')
+    touched = 0
+    for s_ in range(2):
+        eng.eff_set_action(e, s_, s_, ns, sc['actions'][s_])
+        eng.step(s_ * ns, s_ * ns, ns, 1)
+        for f in range(s_ * ns, (s_ + 1) * ns):
+            p0, p1 = eng.eff_get_state(e, f), eng.eff_get_state(e, f + 1)
+            dyn = dict(voxels=r['voxels'], T=r['T'], friction=r['friction'], softness=r['softness'],
+                       pos0=p0[:3], quat0=p0[3:7], pos1=p1[:3], quat1=p1[3:7])
+            free = mpm_numpy.substep(x, v, C, F, sc['used'], props[:, 0], props[:, 1], (0.5 / n) ** 2 * props[:, 2], props[:, 3].astype(int), n,
+                                     sc['dt'], (0.5 / n) ** 2, sc['gravity'], sc['boundary'])[1]
+            x, v, C, F, _ = mpm_numpy.substep(x, v, C, F, sc['used'], props[:, 0], props[:, 1], (0.5 / n) ** 2 * props[:, 2], props[:, 3].astype(int), n,
+                                              sc['dt'], (0.5 / n) ** 2, sc['gravity'], sc['boundary'], dynamic=dyn, collide_type=ct)
+            touched += int((np.abs(v - free).max(1) > 1e-9).sum())
+    got = S.get_state(eng, 2 * ns)
+    for k, ref in zip('xvCF', (x, v, C, F)):
+        assert np.abs(got[k] - ref).max() < 1e-9 * max(1.0, np.abs(ref).max()), k
+    assert touched > 50                                         # the collider did act on particles
+
+
 def test_cylinder_boundary_matches_numpy(oracle64):
     sc = S.latte_mini()
     sc = dict(sc, used=np.where(sc['used'] == 1, 1, 0).astype(np.int32))
