@@ -99,6 +99,32 @@ def static_collide(static, xn, v):
     return out
 
 
+def impose_x(bnd, x):
+    """Boundary.impose_x (boundaries.py:66-78 cylinder, 123-126 cube) for one position"""
+    x = np.asarray(x, np.float64)
+    if bnd.get('type', 'cube') == 'cube':
+        return np.maximum(np.minimum(x, np.asarray(bnd['upper'], np.float64)), np.asarray(bnd['lower'], np.float64))
+    lo, hi = np.array([0.0, bnd['y_range'][0], 0.0]), np.array([1.0, bnd['y_range'][1], 1.0])
+    xn = np.maximum(np.minimum(x, hi), lo)
+    c = np.asarray(bnd['xz_center'], np.float64)
+    r = np.array([x[0], x[2]]) - c
+    rn = np.sqrt((r ** 2).sum() + EPS)
+    if rn > bnd['xz_radius']:
+        nxz = r / rn * bnd['xz_radius'] + c
+        xn = np.array([nxz[0], xn[1], nxz[1]])
+    return xn
+
+
+def effector_move(bnd, pos, quat, v, w):
+    """Effector.move_kernel (effector.py:157-161): pos' = impose_x(pos + v); quat' = qmul(w2quat(w), quat) (geom.py:8-28)"""
+    wn = np.sqrt((np.asarray(w, np.float64) ** 2).sum() + EPS)
+    a = np.concatenate([[np.cos(wn / 2)], np.asarray(w, np.float64) / wn * np.sin(wn / 2)])
+    t = np.outer(np.asarray(quat, np.float64), a)                    # terms = r.outer_product(q) with q = a, r = quat
+    o = np.array([t[0, 0] - t[1, 1] - t[2, 2] - t[3, 3], t[0, 1] + t[1, 0] - t[2, 3] + t[3, 2],
+                  t[0, 2] + t[1, 3] + t[2, 0] - t[3, 1], t[0, 3] - t[1, 2] + t[2, 1] + t[3, 0]])
+    return impose_x(bnd, np.asarray(pos, np.float64) + np.asarray(v, np.float64)), o / np.sqrt((o ** 2).sum())
+
+
 def _quat_rot(v, q):
     """geom.py:86-90 transform_by_quat (rows of v by one quaternion wxyz)"""
     qv = np.asarray(q[1:], np.float64)

@@ -128,6 +128,49 @@ def test_dynamic_collider_matches_numpy(oracle64, variant):
     assert touched > 50                                         # the collider did act on particles
 
 
+def test_effector_and_injector_chain_matches_numpy(oracle64):
+    """The action path of a 6-dof Injector (AgentJetBot): apply_action_p (effector.py:223-225), set_velocity (252-260),
+    move_kernel with the quaternion update (157-161) and Injector.act (injector.py:80-105), checked on what the engine kept --
+    effector states of every frame and the freshly injected particles -- against the numpy restatement."""
+    sc = S.jetbot_mini(n_grid=8, n_coffee=150, n_pool=60, horizon=3, n_substeps=3)
+    inj = sc['injector']
+    eng = S.make_engine(oracle64, sc)
+    e = eng.add_effector(type=S.FE_EFF_INJECTOR, action_dim=6, action_scale_v=inj['action_scale_v'], action_scale_p=inj['action_scale_p'],
+                         boundary=oracle64.make_boundary(**inj['boundary']), flux=inj['flux'], radius=inj['radius'], inject_v=inj['inject_v'],
+                         inject_p=inj['inject_p'], locally_random=inj['locally_random'], random_vector=inj['random_vector'])
+    pool = np.where(sc['used'] == 0)[0].astype(np.int32)
+    eng.eff_set_act_range(e, pool)
+    st0 = eng.eff_get_state(e, 0); st0[:7] = [0.5, 0.5, 0.5, 1.0, 0.0, 0.0, 0.0]; eng.eff_set_state(e, 0, st0)
+    eng.eff_apply_action_p(e, sc['action_p'])
+    ns, H = sc['n_substeps'], sc['horizon']
+    pos = mpm_numpy.impose_x(inj['boundary'], np.asarray(sc['action_p'][:3], np.float64) * np.asarray(inj['action_scale_p'][:3]))
+    quat = np.array([1.0, 0.0, 0.0, 0.0])
+    assert np.abs(eng.eff_get_state(e, 0)[:3] - pos).max() < 1e-12
+    n_inj = 0
+    for s_ in range(H):
+        a = sc['actions'][s_].astype(np.float64)
+        eng.eff_set_action(e, s_, s_, ns, a)
+        eng.step(s_ * ns, s_ * ns, ns, 1)
+        vv = a[:3] * np.asarray(inj['action_scale_v'][:3]) / ns
+        ww = a[3:] * np.asarray(inj['action_scale_v'][3:]) / ns
+        for f in range(s_ * ns, (s_ + 1) * ns):
+            # Injector.act at frame f: flux pool particles appear in frame f+1 around pos[f] + R(quat[f]) inject_p
+            nxt = S.get_state(eng, f + 1)
+            ids = pool[n_inj:n_inj + inj['flux']]
+            rv = inj['random_vector'][f].astype(np.float64)               # locally_random: row f
+            ip = mpm_numpy._quat_rot(np.asarray(inj['inject_p'], np.float64)[None], quat)[0]
+            iv = mpm_numpy._quat_rot(np.asarray(inj['inject_v'], np.float64)[None], quat)[0]
+            assert (nxt['used'][ids] == 1).all() and (nxt['used'][pool[n_inj + inj['flux']:]] == 0).all()
+            newest = nxt['x'][ids]                                        # (older particles have moved on; the newest are where they were put)
+            assert np.abs(newest - ((rv * 2 - 1) * inj['radius'] + pos + ip)).max() < 1e-12, f
+            assert np.abs(nxt['v'][ids] - iv).max() < 1e-12
+            n_inj += inj['flux']
+            pos, quat = mpm_numpy.effector_move(inj['boundary'], pos, quat, vv, ww)
+            got = eng.eff_get_state(e, f + 1)
+            assert np.abs(got[:3] - pos).max() < 1e-12 and np.abs(got[3:7] - quat).max() < 1e-12, f
+    assert np.abs(quat - [1, 0, 0, 0]).max() > 1e-3                       # the nozzle did turn
+
+
 def test_cylinder_boundary_matches_numpy(oracle64):
     sc = S.latte_mini()
     sc = dict(sc, used=np.where(sc['used'] == 1, 1, 0).astype(np.int32))
