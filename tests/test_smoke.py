@@ -158,3 +158,38 @@ def test_smoke_hip_matches_oracle(hiplib, oracle64, iters):
     assert S.rel_l2(a['gv0'], b['gv0']) <= 1e-4 and S.rel_l2(a['gq0'], b['gq0']) <= 1e-4
     assert S.cosine(a['action_grad'], b['action_grad']) >= 0.999999
     assert S.rel_l2(a['action_grad'], b['action_grad']) <= 1e-3, S.rel_l2(a['action_grad'], b['action_grad'])
+
+
+def test_smoke_step_matches_numpy_restatement(oracle64):
+    """SmokeField.step (smoke_field.py:95-360) in the C++ oracle against the independent numpy restatement (oracle/smoke_numpy.py):
+    free space with a static obstacle, RK3 back-trace + trilerp, the AirCon impulse, wall-mirrored divergence, Jacobi sweeps and
+    the gradient subtraction, over three steps with a moving, turning AirCon."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle'))
+    import smoke_numpy
+    eng, e = make_smoke_engine(oracle64, solver_iters=9)
+    g = np.linspace(0, 1, 16)
+    X, Y, Z = np.meshgrid(g, g, g, indexing='ij')
+    qb = np.abs(np.stack([X - 0.62, Y - 0.45, Z - 0.4], -1)) - [0.1, 0.3, 0.12]
+    vox = S.f32(np.linalg.norm(np.maximum(qb, 0), axis=-1) + np.minimum(qb.max(-1), 0)).astype(np.float64)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'oracle'))
+    import mpm_numpy
+    solid = lambda pts: mpm_numpy._sdf_sample(vox, pts * 15.0) <= 0          # Static.is_collide (static.py:107-113) with T = 15 I
+    free = smoke_numpy.free_space(RES, 3, 8, solid)
+    assert 0 < (~free[:, 4:8]).sum() < free[:, 4:8].size                     # the obstacle takes cells out of the slab
+    f0 = eng.smoke_get_frame(0, ('v', 'q', 'p'))
+    v, q, p = (f0[k].astype(np.float64) for k in ('v', 'q', 'p'))
+    acts = _actions()
+    for s in range(3):
+        eng.eff_set_action(e, s, s, 2, acts[s])
+        eng.smoke_step(s, 2 * s)
+        st = eng.eff_get_state(e, 2 * s)
+        sa, ra = eng.eff_get_sr(e, 2 * s)
+        air = dict(pos=st[:3], quat=st[3:7], inject_v=(-0.3, 0.1, 1.0), s=sa, r=ra)
+        v_tmp, div, v, q, p = smoke_numpy.step(v, q, p, free, 0.03, 9, air)
+        got0 = eng.smoke_get_frame(s, ('v_tmp', 'div'))
+        got1 = eng.smoke_get_frame(s + 1, ('v', 'q', 'p'))
+        for name, ref, got in (('v_tmp', v_tmp, got0['v_tmp']), ('div', div, got0['div']), ('v', v, got1['v']), ('q', q, got1['q']), ('p', p, got1['p'])):
+            assert np.abs(got - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max()), (s, name, np.abs(got - ref).max())
+        eng.step(2 * s, 2 * s, 2, 1)                                          # the AirCon moves and turns during the step's substeps
+    assert np.abs(v).max() > 0.1
+    eng.close()
