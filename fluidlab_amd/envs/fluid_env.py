@@ -33,37 +33,27 @@ class FluidEnv:
     def seed(self, seed):
         misc_utils.set_random_seed(seed)
 
+    #: the scene-description hooks a task env overrides, in the order the scene is assembled (fluid_env.py:35-49)
+    SETUP_ORDER = ('setup_agent', 'setup_statics', 'setup_bodies', 'setup_smoke_field', 'setup_boundary')
+
     def build_env(self):
-        """fluid_env.py:35-49"""
-        self.setup_agent()
-        self.setup_statics()
-        self.setup_bodies()
-        self.setup_smoke_field()
-        self.setup_boundary()
+        for hook in self.SETUP_ORDER:
+            getattr(self, hook)()
         if self.loss:
             self.setup_loss()
         self.taichi_env.build()
-        self._init_state = self.taichi_env.get_state()
+        self._init_state = self.taichi_env.get_state()           # reset() returns here
         print(f'===>  {type(self).__name__} built successfully.')
 
-    def setup_agent(self):
-        pass
+    def _nothing(self):
+        """default of every optional hook"""
 
-    def setup_statics(self):
-        pass
+    setup_agent = setup_statics = setup_smoke_field = setup_boundary = setup_loss = _nothing
 
     def setup_bodies(self):
+        """the base class' demo scene: a water cube and a water ball"""
         self.taichi_env.add_body(type='cube', lower=(0.2, 0.2, 0.2), upper=(0.4, 0.4, 0.4), material=WATER)
         self.taichi_env.add_body(type='ball', center=(0.6, 0.3, 0.6), radius=0.1, material=WATER)
-
-    def setup_smoke_field(self):
-        pass
-
-    def setup_boundary(self):
-        pass
-
-    def setup_loss(self):
-        pass
 
     def gym_misc(self):
         if self.loss_type == 'default':

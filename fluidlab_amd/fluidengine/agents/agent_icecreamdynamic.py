@@ -1,10 +1,14 @@
 """AgentIceCreamDynamic -- a fixed BallInjector dispensing ice cream and one controllable Rigid cone
-(fluidlab/fluidengine/agents/agent_icecreamdynamic.py).  The action drives the cone only; injection stops at
-`inject_till` global substeps; the cone only collides above y = 0.25 (agent_icecreamdynamic.py:23-43)."""
+(interface of fluidlab/fluidengine/agents/agent_icecreamdynamic.py).  The action drives the cone only; injection stops at
+`inject_till` global substeps; the cone only collides above y = 0.25 (agent_icecreamdynamic.py:23-43) -- both gates live in
+the engine (options `inject_till`, `collide_min_y`)."""
 import numpy as np
 
 from fluidlab_amd.fluidengine.effectors import Injector, Rigid
 from .agent import Agent
+
+COLLIDE_ABOVE_Y = 0.25           # agent_icecreamdynamic.py:41
+POS_RANGE = (0.05, 0.95)         # apply_action_p clips the start position to the domain interior
 
 
 class AgentIceCreamDynamic(Agent):
@@ -14,38 +18,33 @@ class AgentIceCreamDynamic(Agent):
 
     def build(self, sim):
         super().build(sim)
-        assert self.n_effectors == 2
-        assert isinstance(self.effectors[0], Injector)
-        self.injector = self.effectors[0]
-        assert isinstance(self.effectors[1], Rigid)
-        self.rigid = self.effectors[1]
-        self.injector.set_act_range(self.sim.particles_ng.used.to_numpy()[0])
-        sim.engine.set_option('inject_till', self.inject_till)          # act()/act_grad() gates, :23-30
-        sim.engine.set_option('collide_min_y', 0.25)                    # collide(), :39-43
+        injector, rigid = self.effectors if self.n_effectors == 2 else (None, None)
+        assert isinstance(injector, Injector) and isinstance(rigid, Rigid), 'expects [BallInjector, Rigid]'
+        self.injector, self.rigid = injector, rigid
+        injector.set_act_range(self.sim.particles_ng.used.to_numpy()[0])
+        for option, value in (('inject_till', self.inject_till), ('collide_min_y', COLLIDE_ABOVE_Y)):
+            sim.engine.set_option(option, value)
 
-    @property
-    def action_dim(self):
-        return self.rigid.action_dim
+    # the injector has no action: the agent's action vector is the cone's
+    action_dim = property(lambda self: self.rigid.action_dim)
+    state_dim = property(lambda self: self.rigid.state_dim)
 
-    @property
-    def state_dim(self):
-        return self.rigid.state_dim
+    def _cone_action(self, action):
+        a = np.asarray(action).reshape(-1).clip(-1, 1)
+        assert len(a) == self.rigid.action_dim
+        return a
 
     def set_action(self, s, s_global, n_substeps, action):
-        action = np.asarray(action).reshape(-1).clip(-1, 1)
-        assert len(action) == self.rigid.action_dim
-        self.rigid.set_action(s, s_global, n_substeps, action)
+        self.rigid.set_action(s, s_global, n_substeps, self._cone_action(action))
 
     def set_action_grad(self, s, s_global, n_substeps, action):
-        action = np.asarray(action).reshape(-1).clip(-1, 1)
-        assert len(action) == self.rigid.action_dim
-        self.rigid.set_action_grad(s, s_global, n_substeps, action)
+        self.rigid.set_action_grad(s, s_global, n_substeps, self._cone_action(action))
 
     def apply_action_p(self, action_p):
-        self.rigid.apply_action_p(np.asarray(action_p).reshape(-1).clip(0.05, 0.95))
+        self.rigid.apply_action_p(np.asarray(action_p).reshape(-1).clip(*POS_RANGE))
 
     def apply_action_p_grad(self, action_p):
-        self.rigid.apply_action_p_grad(np.asarray(action_p).reshape(-1).clip(0.05, 0.95))
+        self.rigid.apply_action_p_grad(np.asarray(action_p).reshape(-1).clip(*POS_RANGE))
 
     def get_grad(self, n):
         return self.rigid.get_action_grad(0, n)
