@@ -1097,9 +1097,9 @@ __device__ void collide_grad_row(const SimP& S, const AgentP& agent, int f, cons
 
 // contact particles sit together in the sorted order, so a slot-indexed launch leaves all the work to a few workgroups: first
 // gather the flagged slots of the frame into one list ...
-__global__ __launch_bounds__(256) void k_collide_list(SimP S, const float* fr_cur, int f, AgentP agent, int* list, int* count) {
+__global__ __launch_bounds__(256) void k_collide_list(SimP S, float* fr_cur, int f, AgentP agent, int* list, int* count) {
     const int s = blockIdx.x * 256 + threadIdx.x;
-    if (s < S.N && ((const int*)(fr_cur + 24 * (size_t)S.Np))[s] != 0 && agent.hit[(size_t)f * S.Np + s] != 0) list[atomicAdd(count, 1)] = s;
+    if (s < S.N && frame_view(fr_cur, S.Np).used[s] != 0 && agent.hit[(size_t)f * S.Np + s] != 0) list[atomicAdd(count, 1)] = s;
 }
 // ... then one row of 16 lanes per list entry, 16 entries per workgroup (the grid covers the worst case, N entries)
 __global__ __launch_bounds__(256) void k_collide_grad(SimP S, float* fr_cur, float* Gn_, const float4* __restrict__ g_out, TableP T,
