@@ -7,6 +7,7 @@
 // per-kernel roofline accounting.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1104,16 +1105,18 @@ __global__ __launch_bounds__(256) void k_collide_list(SimP S, float* fr_cur, int
 // ... then one row of 16 lanes per list entry, 16 entries per workgroup (the grid covers the worst case, N entries)
 __global__ __launch_bounds__(256) void k_collide_grad(SimP S, float* fr_cur, float* Gn_, const float4* __restrict__ g_out, TableP T,
                                                       GridStore GS, int f, AgentP agent, const int* __restrict__ list, const int* __restrict__ count) {
-    const int n = *count, base = blockIdx.x * 16;
-    if (base >= n) return;                                       // (uniform)
+    const int n = *count;
+    if ((int)blockIdx.x * 16 >= n) return;                       // (uniform) the grid is sized for the worst case, the list is short
     const int tid = threadIdx.x;
     if (tid < FE_MAX_EFF * 14) s_pose[tid] = 0.f;
     __syncthreads();
     FrameV cur = frame_view(fr_cur, S.Np), Gn = frame_view(Gn_, S.Np);
     const bool stored = GS.cap > 0 && GS.flag[f];
     VoutSrc V; V.g_out = g_out; V.store = stored ? GS.data + (size_t)f * GS.cap * 128 : nullptr; V.blk_slot = T.blk_slot;
-    const int idx = base + (tid >> 4);
-    if (idx < n) collide_grad_row(S, agent, f, cur, Gn, V, list[idx], tid & 15);      // whole rows enter or skip together
+    for (int base = blockIdx.x * 16; base < n; base += gridDim.x * 16) {
+        const int idx = base + (tid >> 4);
+        if (idx < n) collide_grad_row(S, agent, f, cur, Gn, V, list[idx], tid & 15);      // whole rows enter or skip together
+    }
     pose_flush(agent, f);
 }
 
@@ -1171,12 +1174,14 @@ __global__ __launch_bounds__(256) void k_grid_grad(SimP S, TableP T, const float
 template <bool STATICS>
 __global__ __launch_bounds__(256) void k_grid_collide_grad(SimP S, float4* gg_in, int f, StaticsP ST, AgentP agent, const NodeWork* __restrict__ work,
                                                            const int* __restrict__ work_count) {
-    const int n = *work_count, base = blockIdx.x * 16;
-    if (base >= n) return;                                       // (uniform)
+    const int n = *work_count;
+    if ((int)blockIdx.x * 16 >= n) return;                       // (uniform)
     const int tid = threadIdx.x;
     if (tid < FE_MAX_EFF * 14) s_pose[tid] = 0.f;
     __syncthreads();
-    const int idx = base + (tid >> 4), sub = tid & 15;
+    const int sub = tid & 15;
+    for (int base = blockIdx.x * 16; base < n; base += gridDim.x * 16) {
+    const int idx = base + (tid >> 4);
     if (idx < n) {
         const NodeWork w = work[idx];
         float vo[3], kmul[3], vdyn[3];
@@ -1189,6 +1194,7 @@ __global__ __launch_bounds__(256) void k_grid_collide_grad(SimP S, float4* gg_in
         const float inv = 1.f / w.gi.w;
         if (sub == 0)
             gg_in[w.c] = make_float4(gcol[0] * inv, gcol[1] * inv, gcol[2] * inv, -(w.gi.x * gcol[0] + w.gi.y * gcol[1] + w.gi.z * gcol[2]) * inv * inv);
+    }
     }
     pose_flush(agent, f);
 }
@@ -2287,7 +2293,7 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act) {
     if (particle_collide(h)) {
         HIPCK(h, hipMemsetAsync(h->hit_count, 0, sizeof(int), h->stream));
         hipLaunchKernelGGL(k_collide_list, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), f, ag, h->hit_list, h->hit_count);
-        hipLaunchKernelGGL(k_collide_grad, dim3((h->N + 15) / 16), dim3(256), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->g_out, T, grid_store(h), f, ag,
+        hipLaunchKernelGGL(k_collide_grad, dim3(std::min((h->N + 15) / 16, 2048)), dim3(256), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->g_out, T, grid_store(h), f, ag,
                            h->hit_list, h->hit_count);
     }
     hipLaunchKernelGGL(k_g2p_grad, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag);
@@ -2299,7 +2305,7 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act) {
         if (!h->node_work && (dev_alloc(h, &h->node_work, (size_t)h->S.ncell, false) || dev_alloc(h, &h->node_work_count, 1))) return 1;
         HIPCK(h, hipMemsetAsync(h->node_work_count, 0, sizeof(int), h->stream));
         if (h->statics_host.empty()) LAUNCH_GRID_GRAD(false, true); else LAUNCH_GRID_GRAD(true, true);
-        const dim3 wg((unsigned)((h->S.ncell + 15) / 16) < 65535u * 16u ? (unsigned)((h->S.ncell + 15) / 16) : 65535u * 16u);
+        const dim3 wg((unsigned)std::min((h->S.ncell + 15) / 16, 1024));
         if (h->statics_host.empty()) hipLaunchKernelGGL(k_grid_collide_grad<false>, wg, dim3(256), 0, h->stream, h->S, h->gg_in, f, statics_p(h), ag, h->node_work, h->node_work_count);
         else hipLaunchKernelGGL(k_grid_collide_grad<true>, wg, dim3(256), 0, h->stream, h->S, h->gg_in, f, statics_p(h), ag, h->node_work, h->node_work_count);
     } else { if (h->statics_host.empty()) LAUNCH_GRID_GRAD(false, false); else LAUNCH_GRID_GRAD(true, false); }
