@@ -1,20 +1,26 @@
 #!/usr/bin/env python
-"""bench.py -- MPM substep pairs/s (forward + backward) on the BASELINE workload.
-
-Workload (SURVEY 8d C2 = BASELINE.json configs[1] inputs, run forward AND backward as the metric
-asks): single-material water block, 128^3 grid, 200,000 particles, x ~ U([0.30,0.53]^3) seed 0,
-g=(0,-10,0), CubeBoundary [0.05,0.95]^3.  One "step" = CHUNK forward substeps from frame 0
-followed by CHUNK backward substeps (adjoint seeded by the squared-distance loss on the last
-frame); all inputs are resident in HBM before the timed region, nothing crosses PCIe inside it.
+"""bench.py -- MPM substep pairs/s (one forward + one backward substep) on the BASELINE workloads.
 
   python bench.py [--gpus N --steps K --warmup W]
-N>1: launched by torch.distributed.run, one env replica per GPU (weak scaling), plus the path's
-one real exchange: an RCCL all-reduce of the (horizon_action+1) x action_dim action gradient per
-optimisation pass.
+
+N = 1 (BASELINE configs[1] inputs, the configuration the metric is quoted on): single-material water block,
+  128^3 grid, 200,000 particles, x ~ U([0.30,0.53]^3) seed 0, g=(0,-10,0), CubeBoundary [0.05,0.95]^3, run forward AND backward.
+  The block EVOLVES: one "step" = CHUNK forward substeps continuing from where the previous step ended (frame CHUNK is
+  copied to frame 0: a rolling window) followed by CHUNK backward substeps (adjoint seeded by a squared-distance loss on
+  the window's last frame).  The block falls, hits the floor and spreads while it is timed, so particles change cells and
+  tiles, the order is re-sorted every K substeps and the active node set drifts (`n_slow_path`, `nc_*` in the line).
+  All inputs are resident in HBM before the timed region; nothing crosses PCIe inside it.
+
+N > 1 (BASELINE configs[3]): one LatteArt-v0 replica per GPU at 128^3 (the config-3 scene, injector
+  randomness seeded by the rank), one process per GPU.  One "step" = one optimisation pass of fluidlab's Solver: 3300
+  forward substeps with the loss, 3300 backward substeps, `agent.get_grad(horizon_action)`, ONE RCCL all-reduce of that
+  (251 x 3) action gradient through EnvParallel.all_reduce_mean, the identical fp64 Adam step on every rank.  No other
+  collective: weak scaling.  `python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run.
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -22,10 +28,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
-N_GRID, N_PARTICLES, CHUNK = 128, 200_000, 50
+N_GRID, N_PARTICLES, CHUNK = 128, 200_000, 100
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')      # rocprofv3 --pmc passes of this round's kernels
 
 # algorithmic bytes per launch (DESIGN.md "Roofline accounting"; N = used particles, Nc = touched nodes).
 # They sum to SURVEY 8d's B_fwd = 216 N + 72 Nc and B_bwd = 308 N + 132 Nc.
@@ -34,12 +40,15 @@ KERNEL_BYTES = {
     'p2g_recompute': (116, 16), 'grid_op_keep': (0, 28), 'g2p_grad': (60, 24), 'grid_op_grad': (0, 48), 'p2g_grad': (132, 16),
     'sort': (0, 0), 'reorder_grad': (0, 0),          # overhead of the cell-sorted layout: no algorithmic bytes credited
 }
-FWD_KERNELS = ('p2g', 'grid_op', 'g2p')
+METRIC = 'MPM substeps/sec (fwd+bwd), 128^3 grid / 200k particles'
 
 
-def build_engine(elib, device, n_grid=N_GRID, n_particles=N_PARTICLES, L=CHUNK):
-    import scenarios as S
-    sc = S.water_block(n_grid=n_grid, n_particles=n_particles, seed=0)
+# ------------------------------------------------------------------------------------------------------------------
+# N = 1: the evolving water block
+# ------------------------------------------------------------------------------------------------------------------
+def build_block(elib, device, n_grid=N_GRID, n_particles=N_PARTICLES, L=CHUNK, mat=None, seed=0):
+    from fluidlab_amd import scenes as S
+    sc = S.water_block(n_grid=n_grid, n_particles=n_particles, seed=seed, **({} if mat is None else {'mat': mat}))
     eng = S.make_engine(elib, sc, max_substeps_local=L, device=device)
     eng.loss_alloc(1)
     rng = np.random.RandomState(1)
@@ -47,29 +56,41 @@ def build_engine(elib, device, n_grid=N_GRID, n_particles=N_PARTICLES, L=CHUNK):
     return eng, sc
 
 
-def one_step(eng, chunk, backward=True):
+def window_step(eng, chunk, mat=0, backward=True, roll=True):
+    """CHUNK forward substeps from frame 0, CHUNK backward substeps, then the window rolls on (frame chunk -> frame 0)."""
     eng.step(0, 0, chunk, 0)
     if backward:
         eng.reset_grad()
-        eng.loss_step_grad(0, chunk, 0, 1.0, 1.0)        # mat 0 = WATER
+        eng.loss_step_grad(0, chunk, mat, 1.0, 1.0)
         eng.step_grad(0, 0, chunk, 0)
+    if roll:
+        eng.copy_frame(chunk, 0)
+
+
+def kernel_table(prof, n_used, nc):
+    out = {}
+    for name, (ms, cnt) in prof.items():
+        if cnt:
+            bp, bc = KERNEL_BYTES.get(name, (0, 0))
+            us = 1e3 * ms / cnt
+            b = bp * n_used + bc * nc
+            out[name] = {'avg_us': round(us, 3), 'launches': cnt, 'alg_bytes': b, 'GBps': round(b / (us * 1e-6) / 1e9, 1)}
+    return out
 
 
 def cpu_baseline(budget_s=12.0):
-    """The oracle (fp32 build, OpenMP over all host cores) on the same 128^3 / 200k workload:
-    a bounded number of forward+backward substep pairs.  Reported, never the target."""
+    """The oracle (fp32 build, OpenMP over the host cores) on the same 128^3 / 200k workload: a bounded number of
+    forward+backward substep pairs.  Reported, never the target."""
     from fluidlab_amd import _capi
-    path = os.path.join(ROOT, 'oracle', '_build', 'libfe_oracle_f32.so')
-    elib = _capi.EngineLib(path)
+    elib = _capi.EngineLib(os.path.join(ROOT, 'oracle', '_build', 'libfe_oracle_f32.so'))
     L = 3
-    eng, _ = build_engine(elib, 0, L=L)
+    eng, _ = build_block(elib, 0, L=L)
     ncpu = os.cpu_count() or 1
-    one_step(eng, 1)                                      # warm (page faults)
-    # the scatter uses float atomics: more threads is not always faster.  Use the best of a few counts.
-    best = None
+    window_step(eng, 1)                                      # warm (page faults)
+    best = None                                              # float atomics in the scatter: more threads is not always faster
     for c in sorted({ncpu, max(1, ncpu // 2), max(1, ncpu // 4), min(ncpu, 16)}, reverse=True):
         eng.set_option('threads', c)
-        t = time.perf_counter(); one_step(eng, 1); t = time.perf_counter() - t
+        t = time.perf_counter(); window_step(eng, 1); t = time.perf_counter() - t
         if best is None or t < best[0]:
             best = (t, c)
     cores = best[1]
@@ -77,163 +98,288 @@ def cpu_baseline(budget_s=12.0):
     t0 = time.perf_counter()
     pairs = 0
     while True:
-        one_step(eng, L)
+        window_step(eng, L)
         pairs += L
         if time.perf_counter() - t0 > budget_s or pairs >= 90:
             break
     dt = time.perf_counter() - t0
     eng.close()
     return {'value': pairs / dt, 'unit': 'substep_pairs/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{pairs} fwd+bwd substep pairs of the same 128^3/200k water block, oracle fp32 + OpenMP ({cores} of {ncpu} hardware threads, fastest of a short sweep), {dt:.1f}s'}
+            'sample': f'{pairs} fwd+bwd substep pairs of the same 128^3/200k water block (evolving window), oracle fp32 + OpenMP '
+                      f'({cores} of {ncpu} hardware threads, fastest of a short sweep), {dt:.1f}s'}
+
+
+def extra_block(elib, device, name, n_grid, n, mat, L, reps):
+    """A bounded side measurement (config 5's sizes): pairs/s and pair_roofline of an at-rest block, never part of `value`."""
+    from fluidlab_amd import scenes as S
+    rng = np.random.RandomState(0)
+    side = (n / 8.0) ** (1 / 3) / n_grid                    # ~8 particles per cell
+    sc = S.water_block(n_grid=n_grid, n_particles=n, seed=0, mat=mat)
+    sc['x'] = S.f32(rng.uniform(0.3, 0.3 + side, (n, 3)))
+    eng = S.make_engine(elib, sc, max_substeps_local=L, device=device)
+    eng.loss_alloc(1); eng.loss_set_target(0, sc['x'])
+    window_step(eng, L, mat=mat, roll=False); eng.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        window_step(eng, L, mat=mat, roll=False)
+    eng.sync()
+    dt = (time.perf_counter() - t0) / reps
+    eng.profile_enable(True); window_step(eng, L, mat=mat, roll=False); prof = eng.profile_read(); eng.profile_enable(False)
+    st = eng.get_stats(L // 2)
+    b_pair = 524 * st['n_used'] + 204 * st['n_cells_touched']
+    out = {'workload': name, 'pairs_per_s': round(L / dt, 1), 'n_used': int(st['n_used']), 'n_cells_touched': int(st['n_cells_touched']),
+           'pair_roofline': {'alg_bytes_per_pair': b_pair, 'frac': round(b_pair * L / dt / 1e9 / HBM_PEAK_GBS, 4)},
+           'kernels_us': {k: round(1e3 * v[0] / v[1], 1) for k, v in prof.items() if v[1]}}
+    eng.close()
+    return out
+
+
+def run_single(args):
+    import torch
+    torch.cuda.set_device(0)
+    from fluidlab_amd import _capi
+    elib = _capi.load_hip()                               # no fallback: raises without the HIP library
+    eng, sc = build_block(elib, 0)
+    for o in args.opt:
+        k, v = o.split('=')
+        eng.set_option(k, float(v))
+
+    def barrier():
+        eng.sync()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        window_step(eng, CHUNK)
+    barrier()
+    st0 = eng.get_stats(0)                                # (also clears the slow-path counter)
+    barrier()
+    t0 = time.perf_counter()
+    eng.timer_start()
+    for _ in range(args.steps):
+        window_step(eng, CHUNK)
+    ev_ms = eng.timer_stop_ms()
+    barrier()
+    wall = time.perf_counter() - t0
+    st1 = eng.get_stats(0)
+    pairs = args.steps * CHUNK
+    value = pairs / wall
+
+    # ---- untimed extras
+    t1 = time.perf_counter()
+    nf = max(2, args.steps // 4)
+    for _ in range(nf):
+        window_step(eng, CHUNK, backward=False)
+    barrier()
+    fwd_rate = nf * CHUNK / (time.perf_counter() - t1)
+    eng.profile_enable(True)
+    for _ in range(2):
+        window_step(eng, CHUNK)
+    prof = eng.profile_read()
+    eng.profile_enable(False)
+    st2 = eng.get_stats(CHUNK // 2)
+    n_used, nc = st2['n_used'], st2['n_cells_touched']
+    per_kernel = kernel_table(prof, n_used, nc)
+    # dominant kernel = largest share of the measured time among the kernels that carry algorithmic bytes
+    dom = max((k for k in per_kernel if per_kernel[k]['alg_bytes'] > 0), key=lambda k: prof[k][0])
+    traffic = None
+    try:                                                  # HBM traffic of that kernel from this round's committed PMC passes
+        traffic = int(json.load(open(PMC_TRAFFIC))['kernels'][dom]['traffic_bytes'])
+    except Exception:
+        pass
+    b_pair = 524 * n_used + 204 * nc
+    sorts = prof.get('sort', (0, 0))[1]
+    out = {
+        'metric': METRIC, 'value': round(value, 1), 'unit': 'substep_pairs/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(1e3 * wall / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'water block 128^3 grid, 200k particles (BASELINE configs[1] inputs), fwd+bwd, evolving (rolling window)',
+                   'substeps_per_step': CHUNK, 'timed_pairs': pairs, 'timed_s': round(wall, 3), 'n_used': n_used,
+                   'nc_start': int(st0['n_cells_touched']), 'nc_end': int(st1['n_cells_touched']), 'n_cells_touched': nc,
+                   'n_slow_path': int(st1['n_slow_path']), 'sorts_per_pair': round(sorts / max(1, 2 * CHUNK), 3),
+                   'parallelism': '1 env, 1 GPU'},
+        'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': per_kernel[dom]['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': round(per_kernel[dom]['GBps'] / HBM_PEAK_GBS, 4), 'traffic': traffic,
+                     'alg_bytes_per_launch': per_kernel[dom]['alg_bytes'], 'avg_launch_us': per_kernel[dom]['avg_us']},
+        'pair_roofline': {'alg_bytes_per_pair': b_pair, 'achieved_GBps': round(b_pair * value / 1e9, 1),
+                          'frac': round(b_pair * value / 1e9 / HBM_PEAK_GBS, 4)},
+        'forward_only_substeps_per_s': round(fwd_rate, 1),
+        'hip_event_ms_per_step': round(ev_ms / args.steps, 3),
+        'kernels': per_kernel,
+    }
+    eng.close()
+    if not args.no_extras:
+        extra = {}
+        # round 1's headline for continuity: the same block restarted from rest every step (nothing moves, the sort is always fresh)
+        e2, _ = build_block(elib, 0, L=50)
+        for _ in range(3):
+            window_step(e2, 50, roll=False)
+        e2.sync(); t2 = time.perf_counter()
+        for _ in range(20):
+            window_step(e2, 50, roll=False)
+        e2.sync()
+        extra['restart_from_rest_pairs_per_s'] = round(20 * 50 / (time.perf_counter() - t2), 1)
+        e2.close()
+        from fluidlab_amd import scenes as S
+        extra['config5_water_256_1M'] = extra_block(elib, 0, 'water block 256^3, 1M particles, fwd+bwd', 256, 1_000_000, S.WATER, 40, 3)
+        extra['config5_icecream_256_1M'] = extra_block(elib, 0, 'ICECREAM (plasto-elastic, SVD) block 256^3, 1M particles, fwd+bwd, 10 substeps', 256, 1_000_000, S.ICECREAM, 10, 3)
+        out['extra'] = extra
+    if not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline()
+    print(json.dumps(out))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# N > 1: LatteArt replicas, one per GPU, action-gradient all-reduce
+# ------------------------------------------------------------------------------------------------------------------
+C4_SCENES = {
+    # BASELINE config 3's scene (DESIGN.md section 6): 128^3, ~2 particles per cell, 60k milk pool -> 281,883 particles
+    'config3': dict(quality=2, particle_density=4e6, n_pool=60000),
+    # the reference's own LatteArt-v0 (64^3, 115,480 particles): tests only
+    'as_shipped': dict(),
+}
+
+
+def run_replicas(args, rank, local_rank, world):
+    import contextlib
+    import io
+    import torch
+    from fluidlab_amd import _capi
+    from fluidlab_amd.envs import make
+    from fluidlab_amd.optimizer.distributed import EnvParallel
+    from fluidlab_amd.optimizer.recorder import Recorder
+    from fluidlab_amd.optimizer.solver import Solver
+    from fluidlab_amd.utils.config import load_config
+    dev = 0 if args.one_device else local_rank
+    torch.cuda.set_device(dev)
+    par = EnvParallel(backend=args.dist_backend, device=dev)          # init_process_group('nccl' = RCCL), one rank per GPU
+    assert par.world_size == world and par.dist is not None and par.dist.get_world_size() == world
+    elib = _capi.load_hip()
+    kw = dict(C4_SCENES[args.c4_scene], engine_lib=elib, device=dev)
+    quiet = lambda: contextlib.redirect_stdout(io.StringIO())        # the env / solver layers print progress lines
+    with quiet():
+        # the target pattern every replica pours towards: the demo policy's recording (seed 0 on every rank)
+        tgt = Recorder(make('LatteArt-v0', seed=0, loss=False, **kw)).record(write=False)
+        env = make('LatteArt-v0', seed=1000 + rank, loss=True, target=tgt, **kw)      # injector randomness differs per rank
+    cfg = load_config('configs/exp_latteart.yaml').SOLVER
+    # 128^3 sits at the stability edge of the reference's fixed dt (DESIGN.md section 6): the Adam step is kept small so that W + K
+    # passes stay in the stable regime.  Gradient, collective and update are the real ones.
+    cfg.optim.lr = cfg.optim.lr * args.c4_lr_scale
+    np.random.seed(0)                                                 # identical initial policy on every rank
+    solver = Solver(env, None, cfg, parallel=par)
+    policy = env.trainable_policy(cfg.optim, cfg.init_range)
+    init = env.taichi_env.get_state()
+    eng = env.taichi_env.simulator.engine
+    sub = env.horizon * env.taichi_env.simulator.n_substeps           # substep pairs per pass
+    t_comp, t_coll, losses, skipped = [], [], [], [0]
+
+    def one_pass():
+        a = time.perf_counter()
+        with quiet():
+            info, g_local = solver.forward_backward(init['state'], policy, env.horizon, env.horizon_action)   # agent.get_grad inside
+        b = time.perf_counter()
+        g_mean, (loss_mean,) = par.all_reduce_mean(g_local, [info['loss']])      # the path's one exchange
+        c = time.perf_counter()
+        if np.isfinite(g_mean).all():
+            policy.optimize(g_mean, info)
+        else:
+            skipped[0] += 1
+        t_comp.append(b - a); t_coll.append(c - b); losses.append(float(loss_mean))
+
+    def barrier():
+        eng.sync(); torch.cuda.synchronize()
+        par.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_pass()
+    del t_comp[:], t_coll[:]
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_pass()
+    barrier()
+    wall = time.perf_counter() - t0
+    dist = par.dist
+    cdev = 'cuda' if args.dist_backend == 'nccl' else 'cpu'
+    t = torch.tensor([wall], dtype=torch.float64, device=cdev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall_max = float(t.item())
+    mine = torch.tensor([sub * args.steps / max(sum(t_comp), 1e-9), 1e6 * float(np.median(t_coll)), float(skipped[0])], dtype=torch.float64, device=cdev)
+    allr = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    # latency of the collective itself on a warm communicator (the per-pass figure above also waits for the slowest rank)
+    probe = torch.zeros((env.horizon_action + 1) * 3 + 1, dtype=torch.float32, device=cdev)
+    for _ in range(5):
+        dist.all_reduce(probe)
+    torch.cuda.synchronize(); par.barrier()
+    p0 = time.perf_counter()
+    for _ in range(50):
+        dist.all_reduce(probe)
+    torch.cuda.synchronize()
+    ar_us = 1e6 * (time.perf_counter() - p0) / 50
+    st = eng.get_stats(sub - 1)
+    if rank == 0:
+        per_rank = [float(a[0]) for a in allr]
+        value = world * sub * args.steps / wall_max
+        b_pair = 524 * st['n_used'] + 204 * st['n_cells_touched']
+        out = {
+            'metric': METRIC, 'value': round(value, 1), 'unit': 'substep_pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(1e3 * wall_max / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'{world} LatteArt-v0 replicas ({args.c4_scene}: {"128^3" if args.c4_scene == "config3" else "64^3"} grid, {eng.N} particles each), '
+                                   'one per GPU: one step = one Solver pass (forward with loss, backward, action-gradient all-reduce, Adam)',
+                       'substep_pairs_per_step_per_rank': sub, 'rccl_world_size': dist.get_world_size(), 'dist_backend': args.dist_backend,
+                       'action_grad_shape': [env.horizon_action + 1, 3], 'lr_scale': args.c4_lr_scale,
+                       'parallelism': f'{world} env replicas, one per GPU, 1 all-reduce of the action gradient per pass'},
+            'per_rank_pairs_per_s_compute_only': [round(v, 1) for v in per_rank],
+            'weak_scaling_efficiency_vs_rank_compute': round(value / sum(per_rank), 4),
+            'allreduce_us': {'warm_latency': round(ar_us, 1), 'per_pass_median_incl_wait': [round(float(a[1]), 1) for a in allr]},
+            'passes_skipped_nonfinite_grad': int(sum(float(a[2]) for a in allr)),
+            'loss_mean_over_envs': [round(v, 3) for v in losses[-args.steps:]],
+            'pair_roofline': {'alg_bytes_per_pair': b_pair, 'frac_per_gpu': round(b_pair * value / world / 1e9 / HBM_PEAK_GBS, 4)},
+            'note': 'N=1 prints the water-block line (the configuration the metric is quoted on); the single-replica rate of THIS scene is per_rank_pairs_per_s_compute_only',
+        }
+        print(json.dumps(out))
+    par.barrier()
+    eng.close()
+    par.close()
+
+
+def free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close()
+    return p
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=None)
+    ap.add_argument('--warmup', type=int, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-replica-probe', action='store_true')
-    ap.add_argument('--dist-backend', default='nccl', help="'gloo' + --one-device: exercise the N>1 control flow on a 1-GPU box")
-    ap.add_argument('--one-device', action='store_true', help='testing only: every rank uses GPU 0')
-    ap.add_argument('--opt', action='append', default=[], help='engine option name=value (tuning sweeps)')
+    ap.add_argument('--no-extras', action='store_true')
+    ap.add_argument('--dist-backend', default='nccl', help="'gloo' + --one-device: exercise the N>1 path on a 1-GPU box (tests)")
+    ap.add_argument('--one-device', action='store_true', help='tests only: every rank uses GPU 0')
+    ap.add_argument('--c4-scene', default='config3', choices=sorted(C4_SCENES))
+    ap.add_argument('--c4-lr-scale', type=float, default=0.1)
+    ap.add_argument('--opt', action='append', default=[], help='engine option name=value (tuning sweeps, N=1)')
     args = ap.parse_args()
-
-    import torch
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    dist = None
-    if args.one_device:
-        local_rank = 0
-    if world > 1:
-        import torch.distributed as dist
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N`: start the N ranks ourselves, exactly as the driver would
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+               '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        torch.cuda.set_device(local_rank)
-        if args.dist_backend == 'nccl':
-            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
-        else:
-            dist.init_process_group(args.dist_backend)
+        os.execvp(cmd[0], cmd)
+    if args.gpus != world:
+        sys.exit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} (or without a launcher)')
+    if world == 1:
+        args.steps = 100 if args.steps is None else args.steps            # 10,000 substep pairs: about a second of timed region
+        args.warmup = 5 if args.warmup is None else args.warmup
+        run_single(args)
     else:
-        torch.cuda.set_device(local_rank)
-
-    from fluidlab_amd import _capi
-    elib = _capi.load_hip()                               # no fallback: raises without the HIP library
-    eng, sc = build_engine(elib, local_rank)
-    for o in args.opt:
-        k, v = o.split('=')
-        eng.set_option(k, float(v))
-    coll_dev = 'cuda' if args.dist_backend == 'nccl' else 'cpu'
-    action_grad = torch.zeros((251, 3), device=coll_dev)  # LatteArt-sized action gradient
-
-    def barrier():
-        eng.sync()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    def step():
-        one_step(eng, CHUNK)
-        if dist is not None:
-            eng.sync()
-            dist.all_reduce(action_grad)
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    eng.timer_start()
-    for _ in range(args.steps):
-        step()
-    ev_ms = eng.timer_stop_ms()
-    barrier()
-    wall = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([wall], device=coll_dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
-
-    # ---- untimed extras (rank 0 reports)
-    fwd_rate = prof = stats = two = None
-    if rank == 0:
-        barrier_local = lambda: (eng.sync(), torch.cuda.synchronize())
-        barrier_local()
-        t1 = time.perf_counter()
-        for _ in range(max(2, args.steps // 2)):
-            one_step(eng, CHUNK, backward=False)
-        barrier_local()
-        fwd_rate = max(2, args.steps // 2) * CHUNK / (time.perf_counter() - t1)
-        eng.profile_enable(True)
-        for _ in range(2):
-            one_step(eng, CHUNK)
-        prof = eng.profile_read()
-        eng.profile_enable(False)
-        stats = eng.get_stats(CHUNK // 2)
-        # How much of the chip one 200k-particle scene leaves idle: a second, independent replica of the same scene on the same
-        # GPU (its own engine and HIP stream), both driven from this thread.  Reported beside `value`, never part of it.
-        two = None
-        if world == 1 and not args.no_replica_probe:
-            eng2, _ = build_engine(elib, local_rank)
-            for e in (eng, eng2):
-                one_step(e, CHUNK)
-            eng2.sync(); barrier_local()
-            n2 = max(3, args.steps // 3)
-            t2 = time.perf_counter()
-            for _ in range(n2):
-                one_step(eng, CHUNK); one_step(eng2, CHUNK)
-            eng2.sync(); barrier_local()
-            two = 2 * n2 * CHUNK / (time.perf_counter() - t2)
-            eng2.close()
-    if dist is not None:
-        dist.barrier()
-
-    if rank == 0:
-        pairs = args.steps * CHUNK * world
-        value = pairs / wall
-        n_used, nc = stats['n_used'], stats['n_cells_touched']
-        per_kernel = {}
-        for name, (ms, cnt) in prof.items():
-            if cnt:
-                bp, bc = KERNEL_BYTES.get(name, (0, 0))
-                us = 1e3 * ms / cnt
-                b = bp * n_used + bc * nc
-                per_kernel[name] = {'avg_us': round(us, 3), 'launches': cnt, 'alg_bytes': b, 'GBps': round(b / (us * 1e-6) / 1e9, 1)}
-        # dominant kernel = largest share of the measured time among the kernels that carry algorithmic bytes
-        dom = max((k for k in per_kernel if per_kernel[k]['alg_bytes'] > 0), key=lambda k: prof[k][0])
-        # HBM traffic of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs)
-        traffic = None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01final_pmc_traffic.json')))['kernels'][dom]
-            traffic = int(pmc['traffic_bytes'])      # (2*FETCH_SIZE + WRITE_SIZE) KiB: gfx950 FETCH_SIZE correction, see the file's note
-        except Exception:
-            pass
-        b_pair = 524 * n_used + 204 * nc
-        out = {
-            'metric': 'MPM substeps/sec (fwd+bwd), 128^3 grid / 200k particles', 'value': round(value, 1),
-            'unit': 'substep_pairs/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': round(1e3 * wall / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': 'water block 128^3 grid, 200k particles (BASELINE configs[1] inputs), fwd+bwd',
-                       'substeps_per_step': CHUNK, 'n_used': n_used, 'n_cells_touched': nc,
-                       'parallelism': f'{world} env replica(s), one per GPU' + (', all-reduce of 251x3 action grad per step' if world > 1 else '')},
-            'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': per_kernel[dom]['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': round(per_kernel[dom]['GBps'] / HBM_PEAK_GBS, 4), 'traffic': traffic,
-                         'alg_bytes_per_launch': per_kernel[dom]['alg_bytes'], 'avg_launch_us': per_kernel[dom]['avg_us']},
-            'pair_roofline': {'alg_bytes_per_pair': b_pair, 'achieved_GBps': round(b_pair * value / world / 1e9, 1),
-                              'frac': round(b_pair * value / world / 1e9 / HBM_PEAK_GBS, 4)},
-            'forward_only_substeps_per_s': round(fwd_rate, 1),
-            'two_replicas_one_gpu': None if two is None else {'value': round(two, 1), 'unit': 'substep_pairs/s (both scenes)', 'ratio_to_value': round(two / value, 3),
-                                                              'note': 'two independent engines/streams on this GPU; not part of `value`'},
-            'hip_event_ms_per_step_rank0': round(ev_ms / args.steps, 3),
-            'kernels': per_kernel,
-        }
-        if not args.no_cpu_baseline and world == 1:
-            out['cpu_baseline'] = cpu_baseline()
-        print(json.dumps(out))
-    eng.close()
-    if dist is not None:
-        dist.destroy_process_group()
+        args.steps = 3 if args.steps is None else args.steps
+        args.warmup = 1 if args.warmup is None else args.warmup
+        run_replicas(args, int(os.environ.get('RANK', '0')), int(os.environ.get('LOCAL_RANK', '0')), world)
 
 
 if __name__ == '__main__':

@@ -30,15 +30,27 @@ static_assert(sizeof(fe_real) == 4, "the HIP engine is fp32 (macros.py:207-211)"
 #define FR_WORDS 25          // 24 state words + used
 #define GR_WORDS 24
 
-struct FrameV {
-    float4 *A0, *A1, *A2; float *a3, *a4, *a5; float4 *B0, *B1; float *b2; int* used;
+// A plane is addressed as (uniform 64-bit frame base) + (32-bit byte offset: uniform plane offset + slot * element size), so a
+// lane's address is one VGPR next to an SGPR pair (global_load ... v_off, s[base:base+1]) and cheap to form again.  With ten 64-bit
+// pointers per frame view the compiler kept ~25 precomputed 64-bit lane addresses alive across the stencil loops (k_p2g and
+// k_p2g_grad spilled them to scratch).  A frame is 100 B per slot, so 32 bits cover 40M particles (checked in fe_create).
+template <typename T>
+struct Plane {
+    char* base; unsigned off;
+    __host__ __device__ __forceinline__ T& operator[](int s) const { return *(T*)(base + (size_t)(off + (unsigned)s * (unsigned)sizeof(T))); }
+    __host__ __device__ __forceinline__ T* ptr() const { return (T*)(base + (size_t)off); }
 };
-__host__ __device__ inline FrameV frame_view(float* base, size_t Np) {
+struct FrameV {
+    Plane<float4> A0, A1, A2; Plane<float> a3, a4, a5; Plane<float4> B0, B1; Plane<float> b2; Plane<int> used;
+};
+__host__ __device__ inline FrameV frame_view(float* base_, size_t Np_) {
     FrameV v;
-    v.A0 = (float4*)base; v.A1 = (float4*)(base + 4 * Np); v.A2 = (float4*)(base + 8 * Np);
-    v.a3 = base + 12 * Np; v.a4 = base + 13 * Np; v.a5 = base + 14 * Np;
-    v.B0 = (float4*)(base + 15 * Np); v.B1 = (float4*)(base + 19 * Np); v.b2 = base + 23 * Np;
-    v.used = (int*)(base + 24 * Np);
+    char* base = (char*)base_;
+    const unsigned Np = (unsigned)Np_;
+    v.A0 = {base, 0u}; v.A1 = {base, 16u * Np}; v.A2 = {base, 32u * Np};
+    v.a3 = {base, 48u * Np}; v.a4 = {base, 52u * Np}; v.a5 = {base, 56u * Np};
+    v.B0 = {base, 60u * Np}; v.B1 = {base, 76u * Np}; v.b2 = {base, 92u * Np};
+    v.used = {base, 96u * Np};
     return v;
 }
 
@@ -72,11 +84,23 @@ __device__ __forceinline__ int cell_addr(int i, int j, int k, int nb) {
     return (((((i >> 2) * nb) + (j >> 2)) * nb + (k >> 2)) << 6) | ((i & 3) << 4) | ((j & 3) << 2) | (k & 3);
 }
 
+// Profiling builds only (-DFE_TIMELINE -> libfluidengine_hip_tl.so, scripts/timeline.py): thread 0 of every workgroup stamps
+// s_memrealtime (100 MHz) at the phase boundaries of the six substep kernels.  Not compiled into the product library.
+#ifdef FE_TIMELINE
+#define TL_WGS 2048
+#define TL(S_, k) do { if (threadIdx.x == 0 && blockIdx.x < TL_WGS) { (S_).tl[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+        if ((k) == 0) (S_).tl[TL_WGS * 8 + blockIdx.x] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) | __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); } } while (0)
+#else
+#define TL(S_, k) do { } while (0)
+#endif
+
 struct SimP {
+#ifdef FE_TIMELINE
+    unsigned long long* tl;
+#endif
     int N, Np, n, nb;
     int ncell;                               // nb^3 * 64: plane stride of the SoA accumulator grids
     int xcd;                                 // option "xcd_map": consecutive work items on the same XCD (shared L2)
-    int dbg;                                 // timing experiments only (option "dbg"): 1 no LDS atomics, 2 no flush, 4 no stores
     float dx, inv_dx, dt, stress_scale;     // stress_scale = -dt * p_vol * 4 * inv_dx^2 (mpm:343)
     float g[3];
     BoundaryP bnd;
@@ -100,8 +124,8 @@ struct AgentP { int n; int inj; const EffP* e; float collide_min_y; const Bounda
 struct InjectP { int on, act_id, row, flux; };                     // per-substep injection parameters (host-known)
 
 struct PInfo { float mu, lam, mass; int cls, mat; };
-__device__ __forceinline__ PInfo load_info(const float4* pinfo, int pid) {
-    float4 t = pinfo[pid];
+__device__ __forceinline__ PInfo load_info(const float4* info, int i) {
+    float4 t = info[i];
     PInfo r; r.mu = t.x; r.lam = t.y; r.mass = t.z;
     int bits = __float_as_int(t.w); r.cls = bits & 0xffff; r.mat = (bits >> 16) & 0xffff;
     return r;
@@ -126,7 +150,7 @@ __device__ __forceinline__ bool mark_block(int b, int* blk_flag, int* blk_list, 
 // occupied block (split at ITEM_MAX particles) = a contiguous slot range.  One workgroup
 // processes one item with the block's stencil footprint staged in LDS as an 8^3-node tile
 // (block + 2 halo nodes + 1 node of drift margin on each side), so the 27-node APIC scatter /
-// gather runs on ds_add_f32 / ds_read instead of global atomics / L2 gathers.  Slots behind the
+// gather runs on LDS (ds_add_f64 / ds_read) instead of global atomics / L2 gathers.  Slots behind the
 // last item ("tail": unused pool particles, particles injected since the last sort) and
 // particles that drifted out of their tile take the global path, which is always correct.
 // -----------------------------------------------------------------------------------------
@@ -158,82 +182,9 @@ __device__ __forceinline__ float sel3(int i, float a, float b, float c) { return
 __device__ __forceinline__ int xcd_item(int wg, int per, int on) { return on ? (wg & 7) * per + (wg >> 3) : wg; }
 #define STW(st, i, d) sel3((i), (st).w[0][d], (st).w[1][d], (st).w[2][d])
 
-// -----------------------------------------------------------------------------------------
-// Wavefront aggregation of scatter contributions.  After the cell-level sort, lanes holding particles of one
-// cell are adjacent and write the same 27 nodes.  A segmented inclusive scan over the 64 lanes (DPP row_shr
-// 1/2/4/8 + row_bcast15/31: pure VALU, no LDS traffic) sums each run of equal keys; only the last lane of a run
-// issues the LDS atomic.  Measured motivation (profiles/r01e): ~30 us of a 44 us P2G launch were ds_add_f64.
-// Correct for ANY lane order: only *adjacent* equal keys are merged.
-// -----------------------------------------------------------------------------------------
-struct SegScan { float f1, f2, f4, f8, f15, f31; bool tail; };
-
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_mov(float v) {      // lanes without a source get 0
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
-}
-// must be executed by all 64 lanes of the wave
-__device__ __forceinline__ SegScan seg_setup(int key) {
-    const int lane = threadIdx.x & 63;
-    const int prev = __shfl_up(key, 1, 64);
-    const bool is_head = lane == 0 || key != prev;
-    const unsigned long long mask = __ballot(is_head);
-    const unsigned long long lower = mask & ((2ull << lane) - 1ull);       // run heads at or before this lane
-    const int head = 63 - __clzll((long long)lower);
-    const int dist = lane - head, row = lane >> 4;
-    SegScan sc;
-    sc.f1 = dist >= 1 ? 1.f : 0.f; sc.f2 = dist >= 2 ? 1.f : 0.f; sc.f4 = dist >= 4 ? 1.f : 0.f; sc.f8 = dist >= 8 ? 1.f : 0.f;
-    sc.f15 = ((row & 1) && head <= row * 16 - 1) ? 1.f : 0.f;             // run reaches back into the previous row
-    sc.f31 = (row >= 2 && head <= 31) ? 1.f : 0.f;                         // ... into the first half of the wave
-    sc.tail = lane == 63 || ((mask >> (lane + 1)) & 1ull);                 // last lane of its run
-    return sc;
-}
-// Four independent values at once, one v_fmac_f32_dpp per step and value (the compiler's own lowering of seg_scan
-// is v_mov_b32_dpp + v_fma_f32).  A DPP read of a VGPR written by the previous VALU needs 2 wait states, which
-// inline asm has to provide itself: the 4 chains are independent, so three other VALU instructions always sit between
-// the write of a value in one step and its DPP read in the next; only the entry needs an s_nop.
-// (Cutting runs at 8-lane groups to halve the scan was measured slower: the extra ds_add_f64 lane-ops cost more than
-// the 36 v_fmac_dpp saved per 3 nodes -- p2g 21.0 -> 25.3 us.)
-#define SEG_STEP4(ctrl, flag) \
-    asm volatile("v_fmac_f32_dpp %0, %0, %4 " ctrl " bound_ctrl:0\n\t" \
-                 "v_fmac_f32_dpp %1, %1, %4 " ctrl " bound_ctrl:0\n\t" \
-                 "v_fmac_f32_dpp %2, %2, %4 " ctrl " bound_ctrl:0\n\t" \
-                 "v_fmac_f32_dpp %3, %3, %4 " ctrl " bound_ctrl:0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(flag))
-__device__ __forceinline__ void seg_scan4(const SegScan& sc, float& a, float& b, float& c, float& d) {
-    asm volatile("s_nop 1" ::: );                        // the inputs were just produced by VALU
-    SEG_STEP4("row_shr:1 row_mask:0xf bank_mask:0xf", sc.f1);
-    SEG_STEP4("row_shr:2 row_mask:0xf bank_mask:0xf", sc.f2);
-    SEG_STEP4("row_shr:4 row_mask:0xf bank_mask:0xf", sc.f4);
-    SEG_STEP4("row_shr:8 row_mask:0xf bank_mask:0xf", sc.f8);
-    SEG_STEP4("row_bcast:15 row_mask:0xa bank_mask:0xf", sc.f15);
-    SEG_STEP4("row_bcast:31 row_mask:0xc bank_mask:0xf", sc.f31);
-}
-// three values (the adjoint scatter of g2p has no mass component)
-#define SEG_STEP3(ctrl, flag) \
-    asm volatile("v_fmac_f32_dpp %0, %0, %3 " ctrl " bound_ctrl:0\n\t" \
-                 "v_fmac_f32_dpp %1, %1, %3 " ctrl " bound_ctrl:0\n\t" \
-                 "v_fmac_f32_dpp %2, %2, %3 " ctrl " bound_ctrl:0\n\t" \
-                 "s_nop 0" : "+v"(a), "+v"(b), "+v"(c) : "v"(flag))      // 2 other VALUs + 1 wait state between write and DPP read
-__device__ __forceinline__ void seg_scan3(const SegScan& sc, float& a, float& b, float& c) {
-    asm volatile("s_nop 1" ::: );
-    SEG_STEP3("row_shr:1 row_mask:0xf bank_mask:0xf", sc.f1);
-    SEG_STEP3("row_shr:2 row_mask:0xf bank_mask:0xf", sc.f2);
-    SEG_STEP3("row_shr:4 row_mask:0xf bank_mask:0xf", sc.f4);
-    SEG_STEP3("row_shr:8 row_mask:0xf bank_mask:0xf", sc.f8);
-    SEG_STEP3("row_bcast:15 row_mask:0xa bank_mask:0xf", sc.f15);
-    SEG_STEP3("row_bcast:31 row_mask:0xc bank_mask:0xf", sc.f31);
-}
-__device__ __forceinline__ float seg_scan(const SegScan& sc, float v) {
-    v = fmaf(sc.f1, dpp_mov<0x111, 0xf>(v), v);          // row_shr:1
-    v = fmaf(sc.f2, dpp_mov<0x112, 0xf>(v), v);          // row_shr:2
-    v = fmaf(sc.f4, dpp_mov<0x114, 0xf>(v), v);          // row_shr:4
-    v = fmaf(sc.f8, dpp_mov<0x118, 0xf>(v), v);          // row_shr:8
-    v = fmaf(sc.f15, dpp_mov<0x142, 0xa>(v), v);         // row_bcast:15 -> rows 1,3
-    v = fmaf(sc.f31, dpp_mov<0x143, 0xc>(v), v);         // row_bcast:31 -> rows 2,3
-    return v;
-}
-
 struct TableP {
     const int*  pid_of_slot;   // [Np]
+    const float4* info;        // [Np] material record of the particle in each slot (pinfo in slot order: a coalesced load, not pinfo[pid])
     const int4* items;         // (block, start, count, 0), sorted by block
     const int*  meta;          // meta[0] = n_items, meta[1] = tail_start, meta[2] = n_active
     const int2* blk_first;     // [nblk] (first item, item count) of a block
@@ -279,7 +230,7 @@ __device__ void effector_move(const EffP& e, int f) {
 struct GridStore { float4* data; int* flag; int cap; };      // data: [(L+1) * cap * 128] float4, 64 (p,m) then 64 v_out per block
 
 struct GridW {            // everything a scattering particle needs of the global grid
-    float* g_in; float4* slab; int ncell; unsigned long long* ts; int* frame_slow; int* blk_flag; int* blk_list; int* blk_count; int* err; int* slow;
+    float* g_in; float4* slab; int ncell; int* frame_slow; int* blk_flag; int* blk_list; int* blk_count; int* err; int* slow;
 };
 
 // advect_used + process_unused_particles (mpm:304-316) + Injector.act (injector.py:80-105) for one unused slot
@@ -316,8 +267,8 @@ __device__ __forceinline__ void unused_particle_fwd(const SimP& S, const FrameV&
 // collector_act_kernel (agent_pouring.py:30-41, agent_jetbot.py:33-43) for one used slot: outside the collector boundary the
 // particle is marked unused in frames f and f+1 and parked at NOWHERE in f+1 (v, C, F carried over, where the reference
 // leaves f+1 stale).  Returns true when the particle was taken; the backward pass then finds used[f] == 0.
-__device__ __forceinline__ bool collector_takes(const FrameV& cur, const FrameV& nxt, int s, int pid, const float4* __restrict__ pinfo, const AgentP& agent) {
-    if (agent.collector_mat >= 0 && load_info(pinfo, pid).mat != agent.collector_mat) return false;
+__device__ __forceinline__ bool collector_takes(const FrameV& cur, const FrameV& nxt, int s, const float4* __restrict__ info, const AgentP& agent) {
+    if (agent.collector_mat >= 0 && load_info(info, s).mat != agent.collector_mat) return false;
     PState p;
     load_xvC(cur, s, p);
     if (!boundary_is_out(*agent.collector, p.x)) return false;
@@ -333,16 +284,23 @@ __device__ __forceinline__ bool collector_takes(const FrameV& cur, const FrameV&
 struct P2GPrep { Stencil st; float mv[3]; m3 affine; float m; bool inside; };
 
 // compute_F_tmp + svd + stress + F update for one used particle (mpm:254-264, 331-344, 355-378)
+struct P2GRaw { PState p; PInfo info; };
+__device__ __forceinline__ void p2g_load(const FrameV& cur, int s, const float4* __restrict__ info_, P2GRaw& r) {
+    load_xvC(cur, s, r.p);
+    load_F(cur, s, r.p.F);
+    r.info = load_info(info_, s);
+}
 template <bool WRITE, bool GENERAL>
-__device__ __forceinline__ void p2g_prepare(const SimP& S, const FrameV& cur, const FrameV& nxt, int s, int pid,
-                                            const float4* __restrict__ pinfo, const GridW& G, P2GPrep& q) {
-    PState p;
-    load_xvC(cur, s, p);
-    load_F(cur, s, p.F);
-    PInfo info = load_info(pinfo, pid);
+__device__ __forceinline__ void p2g_compute(const SimP& S, const FrameV& nxt, int s, const P2GRaw& r, const GridW& G, P2GPrep& q) {
+    const PState& p = r.p;
+    const PInfo& info = r.info;
     Constitutive k;
     constitutive_eval_t<GENERAL>(p.C, p.F, S.dt, info.mu, info.lam, info.mass, info.cls, S.stress_scale, k);
-    if (WRITE && !(S.dbg & 4)) { store_F(nxt, s, k.Fnew); nxt.used[s] = 1; }
+    if (WRITE) {
+        int sw = s;
+        asm volatile("" : "+v"(sw));             // form the store addresses here, not ahead of the constitutive model (they were spilled)
+        store_F(nxt, sw, k.Fnew); nxt.used[sw] = 1;
+    }
     stencil_make(p.x, S.inv_dx, q.st);
     q.inside = stencil_inside(q.st, S.n);
     if (!q.inside) atomicAdd(G.err, 1);
@@ -352,6 +310,13 @@ __device__ __forceinline__ void p2g_prepare(const SimP& S, const FrameV& cur, co
 #pragma unroll
     for (int a = 0; a < 3; a++)
         q.mv[a] = q.m * p.v[a] - S.dx * (k.affine.a[a][0] * q.st.fx[0] + k.affine.a[a][1] * q.st.fx[1] + k.affine.a[a][2] * q.st.fx[2]);
+}
+template <bool WRITE, bool GENERAL>
+__device__ __forceinline__ void p2g_prepare(const SimP& S, const FrameV& cur, const FrameV& nxt, int s,
+                                            const float4* __restrict__ info_, const GridW& G, P2GPrep& q) {
+    P2GRaw r;
+    p2g_load(cur, s, info_, r);
+    p2g_compute<WRITE, GENERAL>(S, nxt, s, r, G, q);
 }
 
 // global path: 108 scattered global atomics + active-block marking
@@ -385,43 +350,121 @@ __device__ __forceinline__ void p2g_scatter_global(const SimP& S, const P2GPrep&
                 if (mark_block((bx * S.nb + by) * S.nb + bz, G.blk_flag, G.blk_list, G.blk_count)) *G.frame_slow = 1;   // store incomplete for this frame
 }
 
-// tile path, executed by ALL lanes of the wave: contributions of lanes with `in_tile` are summed over runs of equal
-// stencil base (seg_scan) and the last lane of each run adds the total into the fp64 LDS accumulators
-__device__ __forceinline__ void p2g_scatter_tile(const SimP& S, const P2GPrep& q, bool in_tile, int lb) {
-    const SegScan sc = seg_setup(in_tile ? lb : (0x40000000 | (int)threadIdx.x));
-    const bool issue = sc.tail && in_tile && !(S.dbg & 1);
-    const float live = in_tile ? 1.f : 0.f;
+// -----------------------------------------------------------------------------------------
+// Transposed scatter (P2G and the d v_out scatter of g2p's adjoint).  After the cell-level sort the lanes of a wave hold
+// runs ("segments") of particles with the same stencil base, i.e. the same 27 nodes.  Round 1 summed each run with a DPP
+// segmented scan executed by every lane for every node (27 nodes x 4 values x 6 v_fmac_dpp per particle) and let the run's
+// last lane issue the LDS atomics.  Here the reduction is transposed instead:
+//   phase A (one lane per particle)  the particle's contribution record -- 9 stencil weights + what its node values are linear
+//            in -- goes to LDS (s_pay, SoA planes), and each wave lists its segments (s_seg);
+//   phase B (one lane per (segment, x-offset i) = a 3 x 3 slab of the segment's 27 nodes)  walks the segment's records, accumulating
+//            the slab's 9 x 4 (9 x 3) sums in registers: ~75 VALU per (particle, slab) instead of ~450, no cross-lane traffic;
+//   phase C  the slab's sums go into the fp64 LDS tile with ds_add_f64.
+// Segments never cross a wave, their order and the order inside them is the slot order: the sums are bit-reproducible up to the
+// order of the fp64 atomics, which fp32 results do not see.  Correct for ANY slot order (an unsorted frame just has runs of 1).
+// -----------------------------------------------------------------------------------------
+#define PAY_MAX 22
+__shared__ float s_pay[PAY_MAX * WG];        // [plane][tid within the pass]
+__shared__ int   s_seg[WG];                  // per wave 64 entries: start (8 bits) | length (8 bits) | tile-local base index (16 bits)
+__shared__ int   s_nseg[4];
+// planes 0..8: w[i][d] at d * 3 + i
+__device__ __forceinline__ void pay_weights(const Stencil& st, int t) {
+#pragma unroll
+    for (int d = 0; d < 3; d++)
+#pragma unroll
+        for (int i = 0; i < 3; i++) s_pay[(d * 3 + i) * WG + t] = st.w[i][d];
+}
+// must be executed by all 64 lanes of the wave; `lb` < 0: this lane takes no part
+__device__ __forceinline__ void seg_list(int lb, int t) {
+    int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    // (lane-derived masks and LDS addresses are cheap to form: laundering the lane id keeps LICM from hoisting them out of the
+    // item loop, where they lived in VGPRs for the whole kernel and were spilled)
+    asm volatile("" : "+v"(lane));
+    const int key = lb >= 0 ? lb : (0x40000000 | lane);
+    const int prev = __shfl_up(key, 1, 64);
+    const bool is_head = lane == 0 || key != prev;
+    const unsigned long long heads = __ballot(is_head), valid = __ballot(is_head && lb >= 0);
+    if (is_head && lb >= 0) {
+        const int idx = __popcll(valid & ((1ull << lane) - 1ull));
+        const unsigned long long after = lane == 63 ? 0ull : (heads >> (lane + 1));
+        const int len = after ? __ffsll((long long)after) : 64 - lane;        // distance to the next run head
+        s_seg[wave * 64 + idx] = t | (len << 8) | (lb << 16);
+    }
+    if (lane == 0) s_nseg[wave] = __popcll(valid);
+}
+struct SegUnit { int start, len, lb, sub; };
+// unit u of the pass -> (segment, sub-unit) with PER sub-units per segment; false when u is past the last unit
+template <int PER>
+__device__ __forceinline__ bool seg_unit(int u, SegUnit& q) {
+    const int n0 = s_nseg[0], n1 = s_nseg[1], n2 = s_nseg[2], n3 = s_nseg[3];
+    int l = u / PER;
+    q.sub = u - PER * l;
+    if (l >= n0 + n1 + n2 + n3) return false;
+    int w = 0;
+    if (l >= n0) { l -= n0; w = 1; if (l >= n1) { l -= n1; w = 2; if (l >= n2) { l -= n2; w = 3; } } }
+    const int e = s_seg[w * 64 + l];
+    q.start = e & 255; q.len = (e >> 8) & 255; q.lb = e >> 16;
+    return true;
+}
+
+// phase A of P2G for one in-tile particle.  P2G's records are 22-float structs (88 B) laid out for 8-byte reads:
+//   [wz0 wz1 | wz2 m | mv0 mv1 | mv2 A00 | A01 A02 | A10 A11 | A12 A20 | A21 A22 | wx0 wx1 | wx2 wy0 | wy1 wy2]
+#define PREC 22
+__device__ __forceinline__ void p2g_pay(const P2GPrep& q, int t) {
+    asm volatile("" : "+v"(t));
+    float2* r = (float2*)(s_pay + PREC * t);
     const Stencil& st = q.st;
-#pragma unroll 1
-    for (int ij = 0; ij < 9; ij++) {
-        const int i = ij / 3, j = ij - 3 * i;
-        const float wij = live * STW(st, i, 0) * STW(st, j, 1);
+    r[0] = make_float2(st.w[0][2], st.w[1][2]); r[1] = make_float2(st.w[2][2], q.m);
+    r[2] = make_float2(q.mv[0], q.mv[1]); r[3] = make_float2(q.mv[2], q.affine.a[0][0]);
+    r[4] = make_float2(q.affine.a[0][1], q.affine.a[0][2]); r[5] = make_float2(q.affine.a[1][0], q.affine.a[1][1]);
+    r[6] = make_float2(q.affine.a[1][2], q.affine.a[2][0]); r[7] = make_float2(q.affine.a[2][1], q.affine.a[2][2]);
+    r[8] = make_float2(st.w[0][0], st.w[1][0]); r[9] = make_float2(st.w[2][0], st.w[0][1]); r[10] = make_float2(st.w[1][1], st.w[2][1]);
+}
+// phases B + C of P2G (all threads of the workgroup, after a barrier): one lane per (segment, i, j) column of 3 nodes.  Nine
+// lanes per segment read every record nine times (same address: a broadcast, but still an LDS cycle each), which is what this phase
+// is bound by -- hence the struct layout: 8 ds_read_b64 + 2 ds_read_b32 per record and lane.  (Three lanes per segment with 3 x 3
+// nodes each, as in g2p's adjoint, need 36 accumulators: this kernel then spills in its per-particle phase.)
+__device__ __forceinline__ void p2g_columns(const SimP& S) {
+    for (int u = threadIdx.x; ; u += WG) {
+        SegUnit q;
+        if (!seg_unit<9>(u, q)) break;
+        const int i = q.sub / 3, j = q.sub - 3 * i;
         const float ox = (float)i * S.dx, oy = (float)j * S.dx;
-        float mij[3];
+        float acc[3][4];
 #pragma unroll
-        for (int a = 0; a < 3; a++) mij[a] = q.mv[a] + q.affine.a[a][0] * ox + q.affine.a[a][1] * oy;
+        for (int kk = 0; kk < 3; kk++)
 #pragma unroll
-        for (int kk = 0; kk < 3; kk++) {
-            const float weight = wij * st.w[kk][2];
-            const float oz = (float)kk * S.dx;
-            const int l = lb + (i * TILE_T + j) * TILE_T + kk;
-            float c[4];
+            for (int a = 0; a < 4; a++) acc[kk][a] = 0.f;
+        for (int t = q.start; t < q.start + q.len; t++) {
+            const float* rec = s_pay + PREC * t;
+            const float2* r = (const float2*)rec;
+            const float2 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5], r6 = r[6], r7 = r[7];
+            const float wij = rec[16 + i] * rec[19 + j];
+            const float wz[3] = {r0.x, r0.y, r1.x};
+            const float m = r1.y;
+            const float mij[3] = {r2.x + r3.y * ox + r4.x * oy, r2.y + r5.x * ox + r5.y * oy, r3.x + r6.y * ox + r7.x * oy};
+            const float az[3] = {r4.y * S.dx, r6.x * S.dx, r7.y * S.dx};
 #pragma unroll
-            for (int a = 0; a < 3; a++) c[a] = weight * (mij[a] + q.affine.a[a][2] * oz);
-            c[3] = weight * q.m;
-            seg_scan4(sc, c[0], c[1], c[2], c[3]);
-            if (issue) {
+            for (int kk = 0; kk < 3; kk++) {
+                const float weight = wij * wz[kk];
 #pragma unroll
-                for (int a = 0; a < 4; a++) atomicAdd(&s_acc[a * TILE_N + l], (double)c[a]);            // ds_add_f64
+                for (int a = 0; a < 3; a++) acc[kk][a] += weight * (kk == 0 ? mij[a] : mij[a] + az[a] * (float)kk);
+                acc[kk][3] += weight * m;
             }
         }
+        const int l = q.lb + (i * TILE_T + j) * TILE_T;
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++)
+#pragma unroll
+            for (int a = 0; a < 4; a++) atomicAdd(&s_acc[a * TILE_N + l + kk], (double)acc[kk][a]);            // ds_add_f64
     }
 }
 
 // p2g (mpm:331-378) fused with compute_F_tmp + svd, advect_used + process_unused_particles, Injector.act and,
 // on one thread, Effector.move_kernel.  WRITE=false is the backward pass' recompute of grid[f]: scatter only.
 template <bool WRITE, bool GENERAL>
-__global__ __launch_bounds__(WG) void k_p2g(SimP S, float* fr_cur, float* fr_next, TableP T, const float4* __restrict__ pinfo,
+__global__ __launch_bounds__(WG, GENERAL ? 2 : 4) void k_p2g(SimP S, float* fr_cur, float* fr_next, TableP T,
                                             const int* __restrict__ pool_idx, GridW G, AgentP agent, InjectP inj, int act, int f,
                                             GridStore GS) {
     if (!WRITE && GS.cap > 0 && GS.flag[f]) return;      // backward: grid[f] was stored by the forward pass
@@ -431,8 +474,7 @@ __global__ __launch_bounds__(WG) void k_p2g(SimP S, float* fr_cur, float* fr_nex
     }
     FrameV cur = frame_view(fr_cur, S.Np);
     FrameV nxt = frame_view(fr_next, S.Np);
-#define TS(k) do { if ((S.dbg & 8) && tid == 0 && blockIdx.x < 4096) G.ts[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-    TS(0);
+    TL(S, 0);
     const int n_items = T.meta[0], tail_start = T.meta[1];
     const int n_tail = (S.N - tail_start + WG - 1) / WG;
     const int n_work = n_items + n_tail, per_xcd = (n_work + 7) >> 3;
@@ -442,54 +484,64 @@ __global__ __launch_bounds__(WG) void k_p2g(SimP S, float* fr_cur, float* fr_nex
         if (w < n_items) {
             const int4 it = T.items[w];
             const TileO to = tile_origin(it.x, S.nb);
-            TS(1);
+            TL(S, 1);
             for (int l = tid; l < 4 * TILE_N; l += WG) s_acc[l] = 0.0;
-            __syncthreads();
-            TS(2);
-            for (int i0 = 0; i0 < it.z; i0 += WG) {              // uniform trip count: the DPP scan needs every lane
-                const int i = i0 + tid, s = it.y + i;
+            for (int i0 = 0; i0 < it.z; i0 += WG) {              // uniform trip count: the segment list needs every lane
+                const int i = i0 + tid;
                 const bool has = i < it.z;
-                // (`used` is re-read rather than implied by the work list so host edits of a frame cannot desynchronise it)
-                bool used = has && cur.used[s] != 0;
-                const int pid = has ? T.pid_of_slot[s] : 0;
+                const int s = it.y + (has ? i : 0);                // (a lane without a slot looks at the item's first one)
+                // (`used` is re-read rather than implied by the work list so host edits of a frame cannot desynchronise it.)  The
+                // particle's state is requested together with the flag, not after it: one memory round trip instead of two.
+                const int u = cur.used[s];
+                P2GRaw raw;
+                p2g_load(cur, s, T.info, raw);
+                bool used = has && u != 0;
                 bool taken = false;
-                if (WRITE && used && act && agent.collector) { taken = collector_takes(cur, nxt, s, pid, pinfo, agent); used = !taken; }
+                if (WRITE && used && act && agent.collector) { taken = collector_takes(cur, nxt, s, T.info, agent); used = !taken; }
                 P2GPrep q;
                 q.inside = false;
                 int lb = -1;
                 if (used) {
-                    p2g_prepare<WRITE, GENERAL>(S, cur, nxt, s, pid, pinfo, G, q);
+                    p2g_compute<WRITE, GENERAL>(S, nxt, s, raw, G, q);
                     if (q.inside) lb = tile_base(to, q.st);
-                } else {
-                    q.m = 0.f; q.affine = m3_zero(); q.mv[0] = q.mv[1] = q.mv[2] = 0.f;
-                    float zero[3] = {0.f, 0.f, 0.f};
-                    stencil_make(zero, S.inv_dx, q.st);
                 }
-                const bool in_tile = lb >= 0;
-                // a wave without any particle (items hold <= item_max particles, the workgroup always has 4 waves) skips
-                // the 27-node scan altogether; the branch is wave-uniform, as the DPP scan requires
-                if (__any(in_tile)) p2g_scatter_tile(S, q, in_tile, in_tile ? lb : 0);
-                if (used && q.inside && !in_tile) { atomicAdd(G.slow, 1); p2g_scatter_global(S, q, G); }   // drifted out of the tile
-                if (has && !used && !taken && WRITE) unused_particle_fwd(S, cur, nxt, s, pid, pool_idx, agent, inj, f);
+                TL(S, 2);
+                if (lb >= 0) p2g_pay(q, tid);
+                seg_list(lb, tid);
+                const bool drifted = used && q.inside && lb < 0;            // out of the tile: global path, after the fast path
+                const bool idle = has && !used && !taken && WRITE;          // an unused slot inside an item (host edits, the collector)
+                __syncthreads();
+                TL(S, 3);
+                p2g_columns(S);
+                TL(S, 4);
+                __syncthreads();
+                TL(S, 5);
+                // Rare, and kept out of the region above on purpose: inlined between the record write and the barrier, the 27-node
+                // global scatter set the register budget of the whole kernel (spills in the fast path).  The particle is prepared
+                // again (F' is already stored).
+                if (idle) unused_particle_fwd(S, cur, nxt, s, T.pid_of_slot[s], pool_idx, agent, inj, f);
+                if (drifted) {
+                    atomicAdd(G.slow, 1);
+                    P2GPrep q2;
+                    p2g_prepare<false, GENERAL>(S, cur, nxt, s, T.info, G, q2);
+                    p2g_scatter_global(S, q2, G);
+                }
             }
-            __syncthreads();
-            TS(3);
             // hand the tile over: plain coalesced float4 stores into this item's slab.  No atomics, no waiting:
             // k_grid sums, per node, the slabs of the (at most 8) blocks whose tiles reach it, in a fixed order.
             for (int l = tid; l < TILE_N; l += WG)
                 G.slab[(size_t)w * TILE_N + l] = make_float4((float)s_acc[l], (float)s_acc[TILE_N + l], (float)s_acc[2 * TILE_N + l], (float)s_acc[3 * TILE_N + l]);
             __syncthreads();
-            TS(4);
+            TL(S, 6);
         } else {
             const int s = tail_start + (w - n_items) * WG + tid;
             if (s < S.N) {
-                const int pid = T.pid_of_slot[s];
                 if (cur.used[s]) {
-                    if (WRITE && act && agent.collector && collector_takes(cur, nxt, s, pid, pinfo, agent)) continue;
+                    if (WRITE && act && agent.collector && collector_takes(cur, nxt, s, T.info, agent)) continue;
                     P2GPrep q;
-                    p2g_prepare<WRITE, GENERAL>(S, cur, nxt, s, pid, pinfo, G, q);
+                    p2g_prepare<WRITE, GENERAL>(S, cur, nxt, s, T.info, G, q);
                     if (q.inside) p2g_scatter_global(S, q, G);
-                } else if (WRITE) unused_particle_fwd(S, cur, nxt, s, pid, pool_idx, agent, inj, f);
+                } else if (WRITE) unused_particle_fwd(S, cur, nxt, s, T.pid_of_slot[s], pool_idx, agent, inj, f);
             }
         }
     }
@@ -628,6 +680,7 @@ __global__ __launch_bounds__(256) void k_grid(SimP S, TableP T, const float4* __
                                               GridStore GS, int f, int* frame_slow, StaticsP ST, AgentP agent) {
     if (KEEP && GS.cap > 0 && GS.flag[f]) return;        // backward: stored by the forward pass
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    TL(S, 0);
     const int n_static = T.meta[2], cnt = n_static + *blk_count;
     if (!KEEP && blockIdx.x == 0 && threadIdx.x == 0) {
         if (GS.cap > 0) GS.flag[f] = (n_static <= GS.cap && *frame_slow == 0) ? 1 : 0;
@@ -641,9 +694,11 @@ __global__ __launch_bounds__(256) void k_grid(SimP S, TableP T, const float4* __
         const int b = grid_entry(T, blk_list, e, n_static, is_static);
         const int c = (b << 6) | lane;
         const int bi = b / (S.nb * S.nb), bj = (b / S.nb) % S.nb, bk = b % S.nb;
+        TL(S, 1);
         float4 gi = make_float4(g_in[c], g_in[S.ncell + c], g_in[2 * S.ncell + c], g_in[3 * S.ncell + c]);     // slow-path atomics
         if (is_static) { const float4 t = gather_slabs(S, T, slab, bi, bj, bk, lane); gi.x += t.x; gi.y += t.y; gi.z += t.z; gi.w += t.w; }
         float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (gi.w > FE_EPS) TL(S, 2);
         if (gi.w > FE_EPS) {
             float vo[3], kmul[3];
             node_velocity<STATICS, DYN>(S, ST, gi, bi * 4 + (lane >> 4), bj * 4 + ((lane >> 2) & 3), bk * 4 + (lane & 3), vo, kmul, nullptr, &agent, f);
@@ -660,6 +715,7 @@ __global__ __launch_bounds__(256) void k_grid(SimP S, TableP T, const float4* __
         } else {
             g_in[c] = gi.x; g_in[S.ncell + c] = gi.y; g_in[2 * S.ncell + c] = gi.z; g_in[3 * S.ncell + c] = gi.w;
         }
+        TL(S, 3);
     }
 }
 
@@ -717,18 +773,6 @@ __device__ __forceinline__ void load_tile3(const TileO& to, const SimP& S, const
         s_tile[l] = v.x; s_tile[TILE_N + l] = v.y; s_tile[2 * TILE_N + l] = v.z;
     }
 }
-// same, reading v_out of frame f from the grid store (blocks addressed through the order's blk_slot)
-__device__ __forceinline__ void load_tile3_store(const TileO& to, const SimP& S, const TableP& T, const float4* __restrict__ st, int tid) {
-    for (int l = tid; l < TILE_N; l += WG) {
-        int i, j, k;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tile_node(to, l, S.n, i, j, k)) {
-            const int slot = T.blk_slot[(((i >> 2) * S.nb) + (j >> 2)) * S.nb + (k >> 2)];
-            if (slot >= 0) v = st[(size_t)slot * 128 + 64 + (((i & 3) << 4) | ((j & 3) << 2) | (k & 3))];
-        }
-        s_tile[l] = v.x; s_tile[TILE_N + l] = v.y; s_tile[2 * TILE_N + l] = v.z;
-    }
-}
 __device__ __forceinline__ void load_tile4(const TileO& to, const SimP& S, const float4* __restrict__ src, int tid) {
     for (int l = tid; l < TILE_N; l += WG) {
         int i, j, k;
@@ -763,6 +807,7 @@ __global__ __launch_bounds__(WG) void k_g2p(SimP S, float* fr_cur, float* fr_nex
     if (blockIdx.x == 0 && tid == 0) *blk_count = 0;          // grid_op was the last reader of the active list
     FrameV cur = frame_view(fr_cur, S.Np);
     FrameV nxt = frame_view(fr_next, S.Np);
+    TL(S, 0);
     const int n_items = T.meta[0], tail_start = T.meta[1];
     const int n_tail = (S.N - tail_start + WG - 1) / WG;
     const int n_work = n_items + n_tail, per_xcd = (n_work + 7) >> 3;
@@ -773,15 +818,19 @@ __global__ __launch_bounds__(WG) void k_g2p(SimP S, float* fr_cur, float* fr_nex
             const int4 it = T.items[w];
             const TileO to = tile_origin(it.x, S.nb);
             const int s0 = it.y + (tid < it.z ? tid : 0);       // items hold <= item_max <= WG particles: one pass
+            TL(S, 1);
             int u = cur.used[s0];
             float4 a0 = cur.A0[s0];
             load_tile3(to, S, g_out, tid);
             __syncthreads();
+            TL(S, 2);
             for (int i = tid; i < it.z; i += WG) {
                 if (i != tid) { u = cur.used[it.y + i]; a0 = cur.A0[it.y + i]; }
                 slot_g2p<COLLIDE>(S, cur, nxt, it.y + i, true, to, g_out, slow, agent, f, u, a0);
             }
+            TL(S, 3);
             __syncthreads();
+            TL(S, 4);
         } else {
             const int s = tail_start + (w - n_items) * WG + tid;
             TileO none = {0, 0, 0};
@@ -805,20 +854,16 @@ __device__ __forceinline__ float4 vout_at(const SimP& S, const VoutSrc& V, int i
     return slot >= 0 ? V.store[(size_t)slot * 128 + 64 + (((i & 3) << 4) | ((j & 3) << 2) | (k & 3))] : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-// advect_kernel.grad + g2p.grad (mpm:443, 538) for one used particle: scatters d/d(v_out), leaves the
-// position adjoint (so far) in Gc.A0.xyz.  TILE: v_out read from / d v_out accumulated into LDS (3+3 planes)
-// TILE=true is executed by ALL lanes of the wave (`live` = this lane holds a used particle whose stencil fits the
-// tile); the d v_out contributions are summed over runs of equal stencil base before the LDS atomics (seg_scan).
+// advect_kernel.grad + g2p.grad (mpm:443, 538) for one used particle: leaves the position adjoint (so far) in Gc.A0.xyz and
+// scatters d/d(v_out).  TILE: v_out is read from the LDS tile G2_TILE and the scatter is deferred to g2p_grad_columns -- this lane
+// only writes its record (planes 9..11 q at the stencil base, 12..20 c4 * gC) into slot t of s_pay.  !TILE: global atomics.
 // (agent.collide's adjoint has already been folded into Gn's x/v adjoints by k_collide_grad)
+#define G2_TILE ((float*)s_acc)          // k_g2p_grad keeps its v_out tile where the fp64 accumulators go afterwards
 template <bool TILE>
 __device__ __forceinline__ void used_particle_g2p_grad(const SimP& S, const FrameV& Gn, const FrameV& Gc, int s,
-                                                       int lb, const Stencil& st, const VoutSrc& V, float* gg_out,
-                                                       bool live, const SegScan& sc) {
+                                                       int lb, const Stencil& st, const VoutSrc& V, float* gg_out, int t) {
     PState g;                                   // adjoints of x', v', C'
-    if (!TILE || live) load_xvC(Gn, s, g);
-    else { g.x[0] = g.x[1] = g.x[2] = g.v[0] = g.v[1] = g.v[2] = 0.f; g.C = m3_zero(); }
-    const bool issue = TILE && sc.tail && live;
-    const float livef = (!TILE || live) ? 1.f : 0.f;
+    load_xvC(Gn, s, g);
     // x' = x + dt v'  =>  v'_bar += dt x'_bar
     float gv[3] = {g.v[0] + S.dt * g.x[0], g.v[1] + S.dt * g.x[1], g.v[2] + S.dt * g.x[2]};
     const float c4 = 4.f * S.inv_dx;
@@ -831,34 +876,34 @@ __device__ __forceinline__ void used_particle_g2p_grad(const SimP& S, const Fram
         qb[a] = gv[a] - c4 * (g.C.a[a][0] * st.fx[0] + g.C.a[a][1] * st.fx[1] + g.C.a[a][2] * st.fx[2]);
         qz[a] = c4 * g.C.a[a][2];
     }
+    if (TILE) {
+        pay_weights(st, t);
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            s_pay[(9 + a) * WG + t] = qb[a];
+            s_pay[(12 + a * 3) * WG + t] = c4 * g.C.a[a][0]; s_pay[(13 + a * 3) * WG + t] = c4 * g.C.a[a][1]; s_pay[(14 + a * 3) * WG + t] = qz[a];
+        }
+    }
 #pragma unroll 1
     for (int ij = 0; ij < 9; ij++) {
         const int i = ij / 3, j = ij - 3 * i;
         const float wi = STW(st, i, 0), wj = STW(st, j, 1);
         const float wiwj = wi * wj, dwiwj = stencil_dw(st, i, 0) * wj, widwj = wi * stencil_dw(st, j, 1);
-        const float lw = livef * wiwj;
         float qij[3];
 #pragma unroll
         for (int a = 0; a < 3; a++) qij[a] = qb[a] + c4 * (g.C.a[a][0] * (float)i + g.C.a[a][1] * (float)j);
 #pragma unroll
         for (int kk = 0; kk < 3; kk++) {
             const float wk = st.w[kk][2];
-            const float weight = lw * wk;
             float q[3];
 #pragma unroll
             for (int a = 0; a < 3; a++) q[a] = kk == 0 ? qij[a] : qij[a] + (float)kk * qz[a];
             float v0, v1, v2;
             if (TILE) {
                 const int l = lb + (i * TILE_T + j) * TILE_T + kk;
-                v0 = s_tile[l]; v1 = s_tile[TILE_N + l]; v2 = s_tile[2 * TILE_N + l];
-                float c0 = weight * q[0], c1 = weight * q[1], c2 = weight * q[2];
-                seg_scan3(sc, c0, c1, c2);
-                if (issue) {
-                    atomicAdd(&s_acc[l], (double)c0);                         // ds_add_f64
-                    atomicAdd(&s_acc[TILE_N + l], (double)c1);
-                    atomicAdd(&s_acc[2 * TILE_N + l], (double)c2);
-                }
+                v0 = G2_TILE[l]; v1 = G2_TILE[TILE_N + l]; v2 = G2_TILE[2 * TILE_N + l];
             } else {
+                const float weight = wiwj * wk;
                 const int c = cell_addr(st.base[0] + i, st.base[1] + j, st.base[2] + kk, S.nb);
                 float4 vo = vout_at(S, V, st.base[0] + i, st.base[1] + j, st.base[2] + kk);
                 v0 = vo.x; v1 = vo.y; v2 = vo.z;
@@ -870,15 +915,65 @@ __device__ __forceinline__ void used_particle_g2p_grad(const SimP& S, const Fram
             const float sdot = v0 * q[0] + v1 * q[1] + v2 * q[2];
             const float w3 = wiwj * wk;
             nvw[0] += w3 * v0; nvw[1] += w3 * v1; nvw[2] += w3 * v2;
-            const float t = wk * sdot;
-            gfx[0] += dwiwj * t;                               // d weight / d fx_d
-            gfx[1] += widwj * t;
+            const float tt = wk * sdot;
+            gfx[0] += dwiwj * tt;                              // d weight / d fx_d
+            gfx[1] += widwj * tt;
             gfx[2] += wiwj * (stencil_dw(st, kk, 2) * sdot);
         }
     }
 #pragma unroll
     for (int b = 0; b < 3; b++) gfx[b] -= c4 * (nvw[0] * g.C.a[0][b] + nvw[1] * g.C.a[1][b] + nvw[2] * g.C.a[2][b]);     // dpos_b = o_b - fx_b
-    if (!TILE || live) Gc.A0[s] = make_float4(g.x[0] + S.inv_dx * gfx[0], g.x[1] + S.inv_dx * gfx[1], g.x[2] + S.inv_dx * gfx[2], 0.f);
+    Gc.A0[s] = make_float4(g.x[0] + S.inv_dx * gfx[0], g.x[1] + S.inv_dx * gfx[1], g.x[2] + S.inv_dx * gfx[2], 0.f);
+}
+// phases B + C of the d v_out scatter (see the transposed scatter above): 3 x 3 nodes x 3 components per (segment, i)
+__device__ __forceinline__ void g2p_grad_columns() {
+    for (int u = threadIdx.x; ; u += WG) {
+        SegUnit q;
+        if (!seg_unit<3>(u, q)) break;
+        const float fi = (float)q.sub;
+        float acc[3][3][3];
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int kk = 0; kk < 3; kk++)
+#pragma unroll
+                for (int a = 0; a < 3; a++) acc[j][kk][a] = 0.f;
+        for (int t = q.start; t < q.start + q.len; t++) {
+            const float wi = s_pay[q.sub * WG + t];
+            float wz[3], qi[3], qy[3], qz[3];
+#pragma unroll
+            for (int kk = 0; kk < 3; kk++) wz[kk] = s_pay[(6 + kk) * WG + t];
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                qi[a] = s_pay[(9 + a) * WG + t] + s_pay[(12 + a * 3) * WG + t] * fi;
+                qy[a] = s_pay[(13 + a * 3) * WG + t];
+                qz[a] = s_pay[(14 + a * 3) * WG + t];
+            }
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const float wij = wi * s_pay[(3 + j) * WG + t];
+                float qij[3];
+#pragma unroll
+                for (int a = 0; a < 3; a++) qij[a] = j == 0 ? qi[a] : qi[a] + qy[a] * (float)j;
+#pragma unroll
+                for (int kk = 0; kk < 3; kk++) {
+                    const float weight = wij * wz[kk];
+#pragma unroll
+                    for (int a = 0; a < 3; a++) acc[j][kk][a] += weight * (kk == 0 ? qij[a] : qij[a] + (float)kk * qz[a]);
+                }
+            }
+        }
+        const int l = q.lb + q.sub * TILE_T * TILE_T;
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+#pragma unroll
+            for (int kk = 0; kk < 3; kk++)
+            {
+#pragma unroll
+                for (int a = 0; a < 3; a++) atomicAdd(&s_acc[a * TILE_N + l + j * TILE_T + kk], (double)acc[j][kk][a]);            // ds_add_f64
+                NODE_FENCE();
+            }
+    }
 }
 
 // one slot on the global path (tail / sort_interval = 0)
@@ -890,9 +985,7 @@ __device__ __forceinline__ void g2p_grad_slot_global(const SimP& S, const FrameV
     Stencil st;
     stencil_make(x, S.inv_dx, st);
     if (!stencil_inside(st, S.n)) { float4 gx = Gn.A0[s]; Gc.A0[s] = make_float4(gx.x, gx.y, gx.z, 0.f); return; }
-    SegScan none;
-    none.f1 = none.f2 = none.f4 = none.f8 = none.f15 = none.f31 = 0.f; none.tail = true;
-    used_particle_g2p_grad<false>(S, Gn, Gc, s, 0, st, V, gg_out, true, none);
+    used_particle_g2p_grad<false>(S, Gn, Gc, s, 0, st, V, gg_out, 0);
 }
 
 // workgroup-level flush of s_pose into the effectors' adjoint arrays (call with all threads; contains barriers)
@@ -914,7 +1007,23 @@ __device__ __forceinline__ void pose_flush(const AgentP& agent, int f) {
     __syncthreads();
 }
 
-__global__ __launch_bounds__(WG) void k_g2p_grad(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T,
+// v_out of the item's tile into G2_TILE (3 planes), from the working grid or from the forward pass' store
+__device__ __forceinline__ void g2p_grad_load_tile(const TileO& to, const SimP& S, const TableP& T, const float4* __restrict__ g_out,
+                                                   const float4* __restrict__ st, int tid) {
+    for (int l = tid; l < TILE_N; l += WG) {
+        int i, j, k;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tile_node(to, l, S.n, i, j, k)) {
+            if (st) {
+                const int slot = T.blk_slot[(((i >> 2) * S.nb) + (j >> 2)) * S.nb + (k >> 2)];
+                if (slot >= 0) v = st[(size_t)slot * 128 + 64 + (((i & 3) << 4) | ((j & 3) << 2) | (k & 3))];
+            } else v = g_out[cell_addr(i, j, k, S.nb)];
+        }
+        G2_TILE[l] = v.x; G2_TILE[TILE_N + l] = v.y; G2_TILE[2 * TILE_N + l] = v.z;
+    }
+}
+
+__global__ __launch_bounds__(WG, 4) void k_g2p_grad(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T,
                                                  const float4* __restrict__ g_out, float* gg_out, float4* slab, int* slow,
                                                  GridStore GS, int f, AgentP agent) {
     const int tid = threadIdx.x;
@@ -922,6 +1031,7 @@ __global__ __launch_bounds__(WG) void k_g2p_grad(SimP S, float* fr_cur, float* G
     VoutSrc V; V.g_out = g_out; V.store = stored ? GS.data + (size_t)f * GS.cap * 128 : nullptr; V.blk_slot = T.blk_slot;
     FrameV cur = frame_view(fr_cur, S.Np);
     FrameV Gn = frame_view(Gn_, S.Np), Gc = frame_view(Gc_, S.Np);
+    TL(S, 0);
     const int n_items = T.meta[0], tail_start = T.meta[1];
     const int n_tail = (S.N - tail_start + WG - 1) / WG;
     const int n_work = n_items + n_tail, per_xcd = (n_work + 7) >> 3;
@@ -931,14 +1041,19 @@ __global__ __launch_bounds__(WG) void k_g2p_grad(SimP S, float* fr_cur, float* G
         if (w < n_items) {
             const int4 it = T.items[w];
             const TileO to = tile_origin(it.x, S.nb);
-            // the particle loads go out ahead of the tile load and its barrier (see slot_g2p); items hold <= WG particles
+            TL(S, 1);
+            // the particle loads go out ahead of the tile load and its barrier (see slot_g2p)
             const int s0 = it.y + (tid < it.z ? tid : 0);
             int u0 = cur.used[s0];
             float4 a00 = cur.A0[s0];
-            if (stored) load_tile3_store(to, S, T, GS.data + (size_t)f * GS.cap * 128, tid); else load_tile3(to, S, g_out, tid);
-            for (int l = tid; l < 3 * TILE_N; l += WG) s_acc[l] = 0.0;
+            // The v_out tile and the fp64 accumulators share LDS (they are never live together): gather + records first, then
+            // the tile is zeroed into accumulators.  Items of more than WG particles (item_max > 256) accumulate pass by pass in
+            // the global grid instead of re-loading the tile: rare, and only a question of speed.
+            g2p_grad_load_tile(to, S, T, g_out, V.store, tid);
             __syncthreads();
-            for (int i0 = 0; i0 < it.z; i0 += WG) {              // uniform trip count: the DPP scan needs every lane
+            TL(S, 2);
+            const bool one_pass = it.z <= WG;
+            for (int i0 = 0; i0 < it.z; i0 += WG) {              // uniform trip count: the segment list needs every lane
                 const int i = i0 + tid, s = it.y + i;
                 if (i0 > 0 && i < it.z) { u0 = cur.used[s]; a00 = cur.A0[s]; }
                 const bool used = i < it.z && u0 != 0;
@@ -947,21 +1062,27 @@ __global__ __launch_bounds__(WG) void k_g2p_grad(SimP S, float* fr_cur, float* G
                 Stencil st;
                 stencil_make(x, S.inv_dx, st);
                 const bool inside = used && stencil_inside(st, S.n);
-                const int lb = inside ? tile_base(to, st) : -1;
-                const bool live = lb >= 0;
-                if (__any(live)) {                               // wave-uniform: empty waves skip the scan
-                    const SegScan sc = seg_setup(live ? lb : (0x40000000 | tid));
-                    used_particle_g2p_grad<true>(S, Gn, Gc, s, live ? lb : 0, st, V, gg_out, live, sc);
-                }
-                if (used && !live) {
+                const int lb = (inside && one_pass) ? tile_base(to, st) : -1;
+                if (lb >= 0) used_particle_g2p_grad<true>(S, Gn, Gc, s, lb, st, V, gg_out, tid);
+                seg_list(lb, tid);
+                if (used && lb < 0) {
                     if (inside) atomicAdd(slow, 1);
                     g2p_grad_slot_global(S, cur, Gn, Gc, s, V, gg_out, agent, f);
                 }
             }
+            TL(S, 3);
+            __syncthreads();                                     // every lane is done with the v_out tile
+            for (int l = tid; l < 3 * TILE_N; l += WG) s_acc[l] = 0.0;
             __syncthreads();
+            TL(S, 4);
+            if (one_pass) g2p_grad_columns();
+            TL(S, 5);
+            __syncthreads();
+            TL(S, 6);
             for (int l = tid; l < TILE_N; l += WG)
                 slab[(size_t)w * TILE_N + l] = make_float4((float)s_acc[l], (float)s_acc[TILE_N + l], (float)s_acc[2 * TILE_N + l], 0.f);
             __syncthreads();
+            TL(S, 7);
         } else {
             const int s = tail_start + (w - n_items) * WG + tid;
             if (s < S.N) g2p_grad_slot_global(S, cur, Gn, Gc, s, V, gg_out, agent, f);
@@ -1225,28 +1346,51 @@ __device__ void effector_move_grad(const EffP& e, int f) {
 }
 
 // p2g.grad + svd_grad + compute_F_tmp.grad (mpm:544-546) for one used particle; TILE: (d v_in, d mass) in LDS (4 planes)
+// What the constitutive adjoint needs again after the 27-node loop -- C, F and, in the SVD build, U, V, sigma, J -- waits in LDS
+// (s_stash, one column per thread) instead of in registers: round 1 re-read C and F from the frame (72 B per particle of extra
+// HBM traffic) and re-ran the constitutive model, and the SVD build kept everything live (256 + 32 VGPRs, one wave per SIMD).
+#define STASH_GENERAL 40
+#define STASH_LIQUID 18
+template <bool GENERAL> struct Stash { static __device__ __forceinline__ float* at(); };
+__shared__ float s_stash_g[STASH_GENERAL * WG];
+__shared__ float s_stash_l[STASH_LIQUID * WG];
+template <> __device__ __forceinline__ float* Stash<true>::at() { return s_stash_g; }
+template <> __device__ __forceinline__ float* Stash<false>::at() { return s_stash_l; }
 template <bool TILE, bool GENERAL>
 __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const FrameV& cur, const FrameV& Gn, const FrameV& Gc, int s,
-                                                       int pid, const float4* __restrict__ pinfo, const TileO& to,
+                                                       const float4* __restrict__ info_, const TileO& to,
                                                        const float4* __restrict__ gg_in, int* slow) {
     PState p;
     load_xvC(cur, s, p);
     load_F(cur, s, p.F);
-    PInfo info = load_info(pinfo, pid);
+    PInfo info = load_info(info_, s);
     Constitutive k;
     constitutive_eval_t<GENERAL>(p.C, p.F, S.dt, info.mu, info.lam, info.mass, info.cls, S.stress_scale, k);
+    Stencil st;
+    stencil_make(p.x, S.inv_dx, st);
+    const bool inside = stencil_inside(st, S.n);
+    const int lb = (TILE && inside) ? tile_base(to, st) : -1;
+    if (TILE && inside && lb < 0) {            // drifted out of the tile: redo on the global path
+        atomicAdd(slow, 1);
+        used_particle_p2g_grad<false, GENERAL>(S, cur, Gn, Gc, s, info_, to, gg_in, slow);
+        return;
+    }
+    float* stash = Stash<GENERAL>::at();
+    int col = threadIdx.x;
+    {
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) {
+                stash[(a * 3 + b) * WG + col] = p.C.a[a][b]; stash[(9 + a * 3 + b) * WG + col] = p.F.a[a][b];
+                if (GENERAL) { stash[(18 + a * 3 + b) * WG + col] = k.U.a[a][b]; stash[(27 + a * 3 + b) * WG + col] = k.V.a[a][b]; }
+            }
+        if (GENERAL) { stash[36 * WG + col] = k.sig[0]; stash[37 * WG + col] = k.sig[1]; stash[38 * WG + col] = k.sig[2]; stash[39 * WG + col] = k.J; }
+    }
     float Gv[3] = {0.f, 0.f, 0.f};
     m3 GA = m3_zero();
     float gxs[3] = {0.f, 0.f, 0.f};             // inv_dx * d/d fx from the stencil
-    Stencil st;
-    stencil_make(p.x, S.inv_dx, st);
-    if (stencil_inside(st, S.n)) {
-        const int lb = TILE ? tile_base(to, st) : -1;
-        if (TILE && lb < 0) {                   // drifted out of the tile: redo on the global path
-            atomicAdd(slow, 1);
-            used_particle_p2g_grad<false, GENERAL>(S, cur, Gn, Gc, s, pid, pinfo, to, gg_in, slow);
-            return;
-        }
+    if (inside) {
         const float m = info.mass;
         float gfx[3] = {0.f, 0.f, 0.f};
         float mv[3];
@@ -1309,16 +1453,26 @@ __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const Fram
 #pragma unroll
         for (int d = 0; d < 3; d++) gxs[d] = S.inv_dx * gfx[d];
     }
-    if (!GENERAL) {
-        // Register diet for the SVD-free build: C and F (18 VGPRs) are not kept alive across the 27-node loop but
-        // re-read (L2-hot) behind a pointer the optimiser cannot see through; F_tmp and J are recomputed.
-        FrameV again = cur;
-        asm volatile("" : "+v"(again.A1), "+v"(again.A2), "+v"(again.a3), "+v"(again.a4), "+v"(again.a5), "+v"(again.B0), "+v"(again.B1), "+v"(again.b2));
-        float4 a1 = again.A1[s], a2 = again.A2[s];
-        p.C.a[0][0] = a1.z; p.C.a[0][1] = a1.w; p.C.a[0][2] = a2.x; p.C.a[1][0] = a2.y; p.C.a[1][1] = a2.z; p.C.a[1][2] = a2.w;
-        p.C.a[2][0] = again.a3[s]; p.C.a[2][1] = again.a4[s]; p.C.a[2][2] = again.a5[s];
-        load_F(again, s, p.F);
-        constitutive_eval_t<GENERAL>(p.C, p.F, S.dt, info.mu, info.lam, info.mass, info.cls, S.stress_scale, k);
+    // (the slot index is laundered too: otherwise the ~25 64-bit addresses of the loads and stores below are formed before the
+    // loop and live -- or spill -- across it)
+    asm volatile("" : "+v"(s));
+    {
+        // back from the stash, behind an index the optimiser cannot see through (it would otherwise forward the stored values,
+        // i.e. keep them in registers across the loop)
+        asm volatile("" : "+v"(col));
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) {
+                p.C.a[a][b] = stash[(a * 3 + b) * WG + col]; p.F.a[a][b] = stash[(9 + a * 3 + b) * WG + col];
+                if (GENERAL) { k.U.a[a][b] = stash[(18 + a * 3 + b) * WG + col]; k.V.a[a][b] = stash[(27 + a * 3 + b) * WG + col]; }
+            }
+        if (GENERAL) { k.sig[0] = stash[36 * WG + col]; k.sig[1] = stash[37 * WG + col]; k.sig[2] = stash[38 * WG + col]; k.J = stash[39 * WG + col]; }
+        // F_tmp = (I + dt C) F again (27 fma) rather than 9 more stash planes; J of the SVD-free build likewise
+        m3 IdtC = m3_scale(p.C, S.dt);
+        IdtC.a[0][0] += 1.f; IdtC.a[1][1] += 1.f; IdtC.a[2][2] += 1.f;
+        k.Ft = m3_mul(IdtC, p.F);
+        if (!GENERAL) k.J = m3_det(k.Ft);
     }
     m3 Fg; load_F(Gn, s, Fg);
     float4 gc0 = Gc.A0[s];                      // position adjoint so far (k_g2p_grad)
@@ -1332,16 +1486,15 @@ __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const Fram
 
 template <bool TILE, bool GENERAL>
 __device__ __forceinline__ void slot_p2g_grad(const SimP& S, const FrameV& cur, const FrameV& Gn, const FrameV& Gc, int s, const TableP& T,
-                                              const float4* __restrict__ pinfo, const int* __restrict__ pool_idx,
+                                              const int* __restrict__ pool_idx,
                                               const TileO& to, const float4* __restrict__ gg_in, int* slow, const AgentP& agent,
                                               const InjectP& inj, int f) {
-    const int pid = T.pid_of_slot[s];
-    if (cur.used[s]) { used_particle_p2g_grad<TILE, GENERAL>(S, cur, Gn, Gc, s, pid, pinfo, to, gg_in, slow); return; }
+    if (cur.used[s]) { used_particle_p2g_grad<TILE, GENERAL>(S, cur, Gn, Gc, s, T.info, to, gg_in, slow); return; }
     // the copy f -> f+1 of an unused particle passes its adjoint straight through (mpm:551)
     PState g; load_xvC(Gn, s, g); load_F(Gn, s, g.F);
     store_xvC(Gc, s, g.x, g.v, g.C); store_F(Gc, s, g.F);
     if (inj.on) {
-        int j = pool_idx[pid] - inj.act_id;
+        int j = pool_idx[T.pid_of_slot[s]] - inj.act_id;
         if (j >= 0 && j < inj.flux) {                      // x[f+1,pid] = offset + pos[f] + R(q) inject_p
             const EffP& e = agent.e[agent.inj];
             float* gp = e.gpos + f * 3;
@@ -1364,7 +1517,7 @@ __device__ __forceinline__ void slot_p2g_grad(const SimP& S, const FrameV& cur, 
 // + Effector.move_kernel.grad on one thread
 template <bool GENERAL, int MINW>
 __global__ __launch_bounds__(WG, MINW) void k_p2g_grad(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T,
-                                                 const float4* __restrict__ pinfo, const int* __restrict__ pool_idx,
+                                                 const int* __restrict__ pool_idx,
                                                  const float4* __restrict__ gg_in, int* blk_count, int* slow, AgentP agent,
                                                  InjectP inj, int act, int f) {
     const int tid = threadIdx.x;
@@ -1374,6 +1527,7 @@ __global__ __launch_bounds__(WG, MINW) void k_p2g_grad(SimP S, float* fr_cur, fl
     }
     FrameV cur = frame_view(fr_cur, S.Np);
     FrameV Gn = frame_view(Gn_, S.Np), Gc = frame_view(Gc_, S.Np);
+    TL(S, 0);
     const int n_items = T.meta[0], tail_start = T.meta[1];
     const int n_tail = (S.N - tail_start + WG - 1) / WG;
     const int n_work = n_items + n_tail, per_xcd = (n_work + 7) >> 3;
@@ -1383,14 +1537,18 @@ __global__ __launch_bounds__(WG, MINW) void k_p2g_grad(SimP S, float* fr_cur, fl
         if (w < n_items) {
             const int4 it = T.items[w];
             const TileO to = tile_origin(it.x, S.nb);
+            TL(S, 1);
             load_tile4(to, S, gg_in, tid);
             __syncthreads();
-            for (int i = tid; i < it.z; i += WG) slot_p2g_grad<true, GENERAL>(S, cur, Gn, Gc, it.y + i, T, pinfo, pool_idx, to, gg_in, slow, agent, inj, f);
+            TL(S, 2);
+            for (int i = tid; i < it.z; i += WG) slot_p2g_grad<true, GENERAL>(S, cur, Gn, Gc, it.y + i, T, pool_idx, to, gg_in, slow, agent, inj, f);
+            TL(S, 3);
             __syncthreads();
+            TL(S, 4);
         } else {
             const int s = tail_start + (w - n_items) * WG + tid;
             TileO none = {0, 0, 0};
-            if (s < S.N) slot_p2g_grad<false, GENERAL>(S, cur, Gn, Gc, s, T, pinfo, pool_idx, none, gg_in, slow, agent, inj, f);
+            if (s < S.N) slot_p2g_grad<false, GENERAL>(S, cur, Gn, Gc, s, T, pool_idx, none, gg_in, slow, agent, inj, f);
         }
     }
 }
@@ -1554,13 +1712,15 @@ __global__ __launch_bounds__(256) void k_set_static(const int* __restrict__ acti
 }
 
 __global__ __launch_bounds__(256) void k_sort_perm(int N, const int* __restrict__ key, const int* __restrict__ rank,
-                                                   const int* __restrict__ start, const int* __restrict__ pid_old, int* src, int* pid_new, int* slot_of_pid) {
+                                                   const int* __restrict__ start, const int* __restrict__ pid_old, int* src, int* pid_new, int* slot_of_pid,
+                                                   const float4* __restrict__ pinfo, float4* info_new) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= N) return;
     const int d = start[key[s]] + rank[s];
     const int pid = pid_old[s];
     src[d] = s;
     pid_new[d] = pid;
+    info_new[d] = pinfo[pid];                                  // the order's slot-indexed material record (TableP::info)
     slot_of_pid[pid] = d;
 }
 
@@ -1964,7 +2124,7 @@ struct FeEngine {
     float* grads = nullptr;                                 // 3 x (GR_WORDS*Np + Np) floats: ring of two + 1 spare
     float* grad_ptr[3] = {nullptr, nullptr, nullptr};
     // particle orders ("tables"): id 0 = identity; id 1+f = order produced by the sort at frame f
-    struct Table { int* pid = nullptr; int4* items = nullptr; int* meta = nullptr; int2* blk_first = nullptr; int* active = nullptr; int* blk_slot = nullptr; int* slot_of_pid = nullptr; };
+    struct Table { int* pid = nullptr; float4* info = nullptr; int4* items = nullptr; int* meta = nullptr; int2* blk_first = nullptr; int* active = nullptr; int* blk_slot = nullptr; int* slot_of_pid = nullptr; };
     int static_table = -1;                                  // order whose active list is currently flagged 2 in blk_flag
     std::vector<int> gs_host; bool gs_host_valid = false;   // host copy of gs_flag, refreshed once per backward sweep
     float4* gstore = nullptr; int* gs_flag = nullptr; int gs_cap = 0;     // forward grid store (see GridStore)
@@ -1979,7 +2139,6 @@ struct FeEngine {
     int *sort_key = nullptr, *sort_rank = nullptr, *sort_cnt = nullptr, *sort_start = nullptr, *sort_src = nullptr, *sort_pid = nullptr;
     int* slow_dev = nullptr;
     int* frame_slow_dev = nullptr;                          // set by a slow-path scatter of the current forward substep
-    unsigned long long* ts_dev = nullptr;                   // dbg&8: per-workgroup phase timestamps of k_p2g (8 x 4096)
     int2* sort_partial = nullptr;
     float4* pinfo = nullptr; int* pool_idx = nullptr;
     std::vector<int> mat_host;
@@ -2013,12 +2172,15 @@ struct FeEngine {
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev; std::vector<int> prof_kid; size_t prof_used = 0;
     double prof_ms[KID_COUNT] = {0}; long long prof_n[KID_COUNT] = {0};
+#ifdef FE_TIMELINE
+    unsigned long long* tl_dev = nullptr;                   // [KID_COUNT][TL_WGS][8] phase stamps of the last launch of each kernel
+#endif
 
     float* frame(int f) { return frame_ptr[f]; }
     float*& spare_frame() { return frame_ptr[L + 1]; }
     float* grad(int f) { return grad_ptr[f & 1]; }
     size_t grad_words() const { return (size_t)GR_WORDS * Np + Np; }
-    TableP tableP(int id) const { TableP t; t.pid_of_slot = tables[id].pid; t.items = tables[id].items; t.meta = tables[id].meta; t.blk_first = tables[id].blk_first; t.active = tables[id].active; t.blk_slot = tables[id].blk_slot; return t; }
+    TableP tableP(int id) const { TableP t; t.pid_of_slot = tables[id].pid; t.info = tables[id].info; t.items = tables[id].items; t.meta = tables[id].meta; t.blk_first = tables[id].blk_first; t.active = tables[id].active; t.blk_slot = tables[id].blk_slot; return t; }
     const int* pid_of(int f) const { return tables[tbl_of_frame[f]].pid; }
 };
 
@@ -2030,6 +2192,9 @@ static std::string g_create_err;
 static hipError_t hipMemcpyOnStream(FeEngine* h, void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
 
 #define FAIL(h, msg) do { (h)->err = (msg); return 1; } while (0)
+// every ABI entry runs on its engine's device, whatever the calling thread's current device is (two engines on two GPUs in
+// one process; a caller that switched devices after fe_create)
+#define FE_ENTRY(h) do { if ((h) != nullptr) (void)hipSetDevice((h)->device); } while (0)
 #define HIPCK(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (h)->err = std::string(#call) + ": " + hipGetErrorString(e_); return 1; } } while (0)
 #define CHECK_FRAME(h, f) do { if ((f) < 0 || (f) > (h)->L) FAIL(h, "frame index out of range"); } while (0)
 #define CHECK_EFF(h, e) do { if ((e) < 0 || (e) >= (int)(h)->effs.size()) FAIL(h, "effector index out of range"); } while (0)
@@ -2076,6 +2241,11 @@ inline dim3 ggrid(FeEngine* h) { int blocks = h->nb * h->nb * h->nb; int g = (bl
 
 void prof_drain(FeEngine* h);
 void prof_begin(FeEngine* h, int kid) {
+#ifdef FE_TIMELINE
+    if (!h->tl_dev) { (void)hipMalloc((void**)&h->tl_dev, sizeof(unsigned long long) * KID_COUNT * TL_WGS * 9); }
+    h->S.tl = h->tl_dev + (size_t)kid * TL_WGS * 9;
+    (void)hipMemsetAsync(h->S.tl, 0, sizeof(unsigned long long) * TL_WGS * 9, h->stream);
+#endif
     if (!h->prof_on) return;
     if (h->prof_used >= 8192) prof_drain(h);
     if (h->prof_used + 2 > h->prof_ev.size()) {
@@ -2133,6 +2303,8 @@ int ensure_table(FeEngine* h, int id) {
     FeEngine::Table& t = h->tables[id];
     if (t.pid) return 0;
     const size_t nblk = (size_t)h->nb * h->nb * h->nb;
+    if (id == 0) t.info = h->pinfo;                            // identity order: slot == particle id
+    else if (dev_alloc(h, &t.info, h->Np)) return 1;
     if (dev_alloc(h, &t.pid, h->Np) || dev_alloc(h, &t.items, h->items_cap) || dev_alloc(h, &t.meta, 4) ||
         dev_alloc(h, &t.blk_first, nblk) || dev_alloc(h, &t.active, nblk) || dev_alloc(h, &t.blk_slot, nblk) || dev_alloc(h, &t.slot_of_pid, h->Np)) return 1;
     HIPCK(h, hipMemsetAsync(t.blk_slot, 0xff, sizeof(int) * nblk, h->stream));
@@ -2191,7 +2363,7 @@ int sort_frame(FeEngine* h, int f) {
     h->static_table = id_new;
     if (fine) { prof_end(h); prof_begin(h, KID_SORT_PERM); }
     hipLaunchKernelGGL(k_sort_perm, pgrid(h), dim3(256), 0, h->stream, h->N, h->sort_key, h->sort_rank, h->sort_start,
-                       h->tables[id_old].pid, h->sort_src, h->sort_pid, tn.slot_of_pid);
+                       h->tables[id_old].pid, h->sort_src, h->sort_pid, tn.slot_of_pid, h->pinfo, tn.info);
     HIPCK(h, hipMemcpyAsync(tn.pid, h->sort_pid, sizeof(int) * h->Np, hipMemcpyDeviceToDevice, h->stream));
     hipLaunchKernelGGL(k_perm_gather<true>, pgrid(h), dim3(256), 0, h->stream, h->N, (size_t)h->Np, h->spare_frame(), h->frame(f), h->sort_src);
     prof_end(h);
@@ -2205,7 +2377,7 @@ StaticsP statics_p(FeEngine* h) { StaticsP p; p.n = (int)h->statics_host.size();
 GridStore grid_store(FeEngine* h) { GridStore g; g.data = h->gstore; g.flag = h->gs_flag; g.cap = h->gs_cap; return g; }
 
 GridW grid_w(FeEngine* h) {
-    GridW g; g.g_in = h->g_in; g.slab = h->slab; g.ncell = h->S.ncell; g.ts = h->ts_dev; g.frame_slow = h->frame_slow_dev; g.blk_flag = h->blk_flag; g.blk_list = h->blk_list; g.blk_count = h->blk_count; g.err = h->err_dev; g.slow = h->slow_dev;
+    GridW g; g.g_in = h->g_in; g.slab = h->slab; g.ncell = h->S.ncell; g.frame_slow = h->frame_slow_dev; g.blk_flag = h->blk_flag; g.blk_list = h->blk_list; g.blk_count = h->blk_count; g.err = h->err_dev; g.slow = h->slow_dev;
     return g;
 }
 
@@ -2234,10 +2406,10 @@ int substep_fwd(FeEngine* h, int f, int f_global, int act) {
     prof_begin(h, KID_P2G);
     if (h->all_simple_liquid)
         hipLaunchKernelGGL((k_p2g<true, false>), wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T,
-                           h->pinfo, h->pool_idx, grid_w(h), ag, inj, act, f, grid_store(h));
+                           h->pool_idx, grid_w(h), ag, inj, act, f, grid_store(h));
     else
         hipLaunchKernelGGL((k_p2g<true, true>), wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T,
-                           h->pinfo, h->pool_idx, grid_w(h), ag, inj, act, f, grid_store(h));
+                           h->pool_idx, grid_w(h), ag, inj, act, f, grid_store(h));
     prof_end(h);
     prof_begin(h, KID_GRID);
     launch_grid<false>(h, T, f, ag);
@@ -2276,10 +2448,10 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act) {
     prof_begin(h, KID_P2G_RE);
     if (h->all_simple_liquid)
         hipLaunchKernelGGL((k_p2g<false, false>), wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T,
-                           h->pinfo, h->pool_idx, grid_w(h), ag, noinj, 0, f, grid_store(h));
+                           h->pool_idx, grid_w(h), ag, noinj, 0, f, grid_store(h));
     else
         hipLaunchKernelGGL((k_p2g<false, true>), wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T,
-                           h->pinfo, h->pool_idx, grid_w(h), ag, noinj, 0, f, grid_store(h));
+                           h->pool_idx, grid_w(h), ag, noinj, 0, f, grid_store(h));
     prof_end(h);
     prof_begin(h, KID_GRID_KEEP);
     launch_grid<true>(h, T, f, ag);
@@ -2312,7 +2484,7 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act) {
     prof_end(h);
     prof_begin(h, KID_P2G_GRAD);
 #define LAUNCH_P2G_GRAD(G, W) hipLaunchKernelGGL((k_p2g_grad<G, W>), wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), \
-                           h->grad(f), T, h->pinfo, h->pool_idx, h->gg_in, h->blk_count, h->slow_dev, ag, inj, act, f)
+                           h->grad(f), T, h->pool_idx, h->gg_in, h->blk_count, h->slow_dev, ag, inj, act, f)
     if (h->all_simple_liquid) {
         if (h->p2g_grad_waves >= 4) LAUNCH_P2G_GRAD(false, 4);
         else if (h->p2g_grad_waves == 3) LAUNCH_P2G_GRAD(false, 3);
@@ -2384,6 +2556,7 @@ int fe_real_size(void) { return 4; }
 
 FeEngine* fe_create(const FeConfig* cfg) {
     if (!cfg || cfg->struct_size != (int)sizeof(FeConfig)) { g_create_err = "FeConfig size mismatch"; return nullptr; }
+    if (cfg->n_particles > 40000000) { g_create_err = "n_particles > 40M: a frame no longer fits 32-bit plane offsets"; return nullptr; }
     if (cfg->n_grid < 4 || cfg->n_grid % 4 != 0 || cfg->n_particles < 0 || cfg->max_substeps_local < 1 || cfg->n_substeps < 1) {
         g_create_err = "invalid FeConfig (n_grid must be a multiple of 4)"; return nullptr;
     }
@@ -2399,7 +2572,7 @@ FeEngine* fe_create(const FeConfig* cfg) {
     if (hipSetDevice(h->device) != hipSuccess) return fail("hipSetDevice failed");
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
     SimP& S = h->S;
-    S.dbg = 0; S.xcd = 1;
+    S.xcd = 1;
     S.N = h->N; S.Np = h->Np; S.n = h->n; S.nb = h->nb; S.ncell = h->nb * h->nb * h->nb * 64;
     S.dx = 1.0f / (float)h->n; S.inv_dx = (float)h->n; S.dt = cfg->dt;
     S.stress_scale = -cfg->dt * cfg->p_vol * 4.f * S.inv_dx * S.inv_dx;
@@ -2418,18 +2591,20 @@ FeEngine* fe_create(const FeConfig* cfg) {
         h->items_cap = (nblk < (size_t)h->Np ? nblk : (size_t)h->Np) + (size_t)h->Np / 64 + 2;      // item_max >= 64
         if (dev_alloc(h, &h->sort_key, h->Np) || dev_alloc(h, &h->sort_rank, h->Np) || dev_alloc(h, &h->sort_cnt, ncell + 1) ||
             dev_alloc(h, &h->sort_start, ncell + 1) || dev_alloc(h, &h->sort_src, h->Np) || dev_alloc(h, &h->sort_pid, h->Np) ||
-            dev_alloc(h, &h->slow_dev, 1) || dev_alloc(h, &h->frame_slow_dev, 1) || dev_alloc(h, &h->slab, h->items_cap * TILE_N, false) || dev_alloc(h, &h->ts_dev, 8 * 4096) || dev_alloc(h, &h->sort_partial, (ncell + 1 + 1023) / 1024 + 1)) return fail("");
+            dev_alloc(h, &h->slow_dev, 1) || dev_alloc(h, &h->frame_slow_dev, 1) || dev_alloc(h, &h->slab, h->items_cap * TILE_N, false) || dev_alloc(h, &h->sort_partial, (ncell + 1 + 1023) / 1024 + 1)) return fail("");
     }
     if (dev_alloc(h, &h->effs_dev, FE_MAX_EFF)) return fail("");
     {   // forward grid store: cap blocks per frame, 2 KiB each; bounded to 64 GiB
         const size_t nblk = (size_t)h->nb * h->nb * h->nb;
-        size_t cap = nblk < 4096 ? nblk : 4096;
+        // (round 1 clamped this to 4096 blocks: a block of water that has spread into a thin layer over the floor of a 128^3 box
+        // has more active blocks than that, every frame lost its store and the backward pass recomputed P2G + grid_op throughout)
+        size_t cap = nblk;
         while (cap > 0 && (size_t)(h->L + 1) * cap * 2048 > ((size_t)64 << 30)) cap /= 2;
         h->gs_cap = (int)cap;
         if (cap > 0 && (dev_alloc(h, &h->gstore, (size_t)(h->L + 1) * cap * 128, false) || dev_alloc(h, &h->gs_flag, h->L + 1))) return fail("");
     }
-    if (ensure_table(h, 0)) return fail("");                 // identity order: no items, everything is "tail"
     if (dev_alloc(h, &h->pinfo, h->Np) || dev_alloc(h, &h->pool_idx, h->Np)) return fail("");
+    if (ensure_table(h, 0)) return fail("");                 // identity order: no items, everything is "tail"; its `info` is pinfo itself
     if (dev_alloc(h, &h->g_in, 4 * ncell) || dev_alloc(h, &h->g_out, ncell) || dev_alloc(h, &h->gg_out, 3 * ncell) || dev_alloc(h, &h->gg_in, ncell)) return fail("");
     if (dev_alloc(h, &h->blk_flag, ncell / 64) || dev_alloc(h, &h->blk_list, ncell / 64) || dev_alloc(h, &h->blk_count, 1) || dev_alloc(h, &h->err_dev, 1)) return fail("");
     if (dev_alloc(h, &h->stage_r, (size_t)24 * h->Np) || dev_alloc(h, &h->stage_i, h->Np)) return fail("");
@@ -2450,8 +2625,9 @@ void fe_destroy(FeEngine* h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     smoke_destroy(h);
-    for (auto& t : h->tables) { for (void* q : {(void*)t.pid, (void*)t.items, (void*)t.meta, (void*)t.blk_first, (void*)t.active, (void*)t.blk_slot, (void*)t.slot_of_pid}) if (q) (void)hipFree(q); }
-    void* ptrs[] = {h->frames, h->grads, h->sort_key, h->sort_rank, h->sort_cnt, h->sort_start, h->sort_src, h->sort_pid, h->slow_dev, h->frame_slow_dev, h->gstore, h->gs_flag, h->slab, h->ts_dev, h->sort_partial, h->effs_dev, h->pinfo, h->pool_idx, h->g_in, h->g_out, h->gg_out, h->gg_in,
+    for (auto& t : h->tables) { if (t.info && t.info != h->pinfo) (void)hipFree(t.info);
+        for (void* q : {(void*)t.pid, (void*)t.items, (void*)t.meta, (void*)t.blk_first, (void*)t.active, (void*)t.blk_slot, (void*)t.slot_of_pid}) if (q) (void)hipFree(q); }
+    void* ptrs[] = {h->frames, h->grads, h->sort_key, h->sort_rank, h->sort_cnt, h->sort_start, h->sort_src, h->sort_pid, h->slow_dev, h->frame_slow_dev, h->gstore, h->gs_flag, h->slab, h->sort_partial, h->effs_dev, h->pinfo, h->pool_idx, h->g_in, h->g_out, h->gg_out, h->gg_in,
                     h->blk_flag, h->blk_list, h->blk_count, h->err_dev, h->stage_r, h->stage_i, h->node_mark, h->counters,
                     h->tgt, h->chamfer, h->step_loss, h->body_start, h->body_pids, h->bodies_dev, h->statics_dev, h->collector_dev, h->hit_dev, h->hit_list, h->hit_count, h->node_work, h->node_work_count};
     for (float* v : h->statics_vox) if (v) (void)hipFree(v);
@@ -2472,12 +2648,14 @@ void fe_destroy(FeEngine* h) {
 const char* fe_last_error(FeEngine* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
 int fe_sync(FeEngine* h) {
+    FE_ENTRY(h);
     HIPCK(h, hipStreamSynchronize(h->stream));
     if (check_async(h)) return 1;
     return check_device_errors(h);
 }
 
 int fe_set_option(FeEngine* h, const char* name, double value) {
+    FE_ENTRY(h);
     if (!std::strcmp(name, "sort_interval")) {
         if (value < 0) FAIL(h, "sort_interval must be >= 0");
         h->sort_interval = (int)value;
@@ -2504,13 +2682,13 @@ int fe_set_option(FeEngine* h, const char* name, double value) {
     if (!std::strcmp(name, "prof_fine")) { h->prof_fine = value != 0; return 0; }
     if (!std::strcmp(name, "xcd_map")) { h->S.xcd = value != 0; return 0; }
     if (!std::strcmp(name, "wgrid_cap")) { if (value < 64) { h->err = "wgrid_cap must be >= 64"; return 1; } h->wgrid_cap = (int)value; return 0; }
-    if (!std::strcmp(name, "dbg")) { h->S.dbg = (int)value; return 0; }     // timing experiments: results are wrong
     if (!std::strcmp(name, "threads")) return 0;             // oracle-only tunable
     FAIL(h, std::string("unknown option: ") + name);
 }
 
 int fe_init_particles(FeEngine* h, const fe_real* x, const int* used, const int* mat, const int* mat_cls,
                       const fe_real* mu, const fe_real* lam, const fe_real* rho, const int* body_id) {
+    FE_ENTRY(h);
     const int N = h->N;
     std::vector<float4> info(h->Np, make_float4(0, 0, 0, 0));
     std::vector<float> C0((size_t)9 * N, 0.f), F0((size_t)9 * N, 0.f), v0((size_t)3 * N, 0.f);
@@ -2564,32 +2742,38 @@ int fe_init_particles(FeEngine* h, const fe_real* x, const int* used, const int*
 }
 
 int fe_substep(FeEngine* h, int f, int f_global, int act) {
+    FE_ENTRY(h);
     if (f < 0 || f >= h->L) FAIL(h, "substep frame out of range");
     if (substep_fwd(h, f, f_global, act)) return 1;
     return check_async(h);
 }
 int fe_substep_grad(FeEngine* h, int f, int f_global, int act) {
+    FE_ENTRY(h);
     if (f < 0 || f >= h->L) FAIL(h, "substep frame out of range");
     if (substep_bwd(h, f, f_global, act)) return 1;
     return check_async(h);
 }
 int fe_step(FeEngine* h, int f0, int f_global0, int n, int act) {
+    FE_ENTRY(h);
     if (f0 < 0 || f0 + n > h->L) FAIL(h, "step frames out of range");
     for (int i = 0; i < n; i++) if (substep_fwd(h, f0 + i, f_global0 + i, act)) return 1;
     return check_async(h);
 }
 int fe_step_grad(FeEngine* h, int f0, int f_global0, int n, int act) {
+    FE_ENTRY(h);
     if (f0 < 0 || f0 + n > h->L) FAIL(h, "step frames out of range");
     for (int i = n - 1; i >= 0; i--) if (substep_bwd(h, f0 + i, f_global0 + i, act)) return 1;
     return check_async(h);
 }
 
 int fe_get_frame(FeEngine* h, int f, fe_real* x, fe_real* v, fe_real* C, fe_real* F, int* used) {
+    FE_ENTRY(h);
     CHECK_FRAME(h, f);
     if (download_planes(h, h->frame(f), h->pid_of(f), x, v, C, F, used)) return 1;
     return check_device_errors(h);
 }
 int fe_set_frame(FeEngine* h, int f, const fe_real* x, const fe_real* v, const fe_real* C, const fe_real* F, const int* used) {
+    FE_ENTRY(h);
     CHECK_FRAME(h, f);
     h->gs_host_valid = false;
     if (h->gs_cap > 0) HIPCK(h, hipMemsetAsync(h->gs_flag + f, 0, sizeof(int), h->stream));     // the stored grid of this frame is stale now
@@ -2597,6 +2781,7 @@ int fe_set_frame(FeEngine* h, int f, const fe_real* x, const fe_real* v, const f
 }
 // device-pointer variants: k_unpack / k_pack work straight on the caller's device arrays, nothing crosses PCIe
 int fe_get_frame_dev(FeEngine* h, int f, fe_real* x, fe_real* v, fe_real* C, fe_real* F, int* used) {
+    FE_ENTRY(h);
     CHECK_FRAME(h, f);
     const int mask = (x ? 1 : 0) | (v ? 2 : 0) | (C ? 4 : 0) | (F ? 8 : 0) | (used ? 16 : 0);
     if (!mask || h->N == 0) return 0;
@@ -2605,6 +2790,7 @@ int fe_get_frame_dev(FeEngine* h, int f, fe_real* x, fe_real* v, fe_real* C, fe_
     return check_device_errors(h);
 }
 int fe_set_frame_dev(FeEngine* h, int f, const fe_real* x, const fe_real* v, const fe_real* C, const fe_real* F, const int* used) {
+    FE_ENTRY(h);
     CHECK_FRAME(h, f);
     h->gs_host_valid = false;
     if (h->gs_cap > 0) HIPCK(h, hipMemsetAsync(h->gs_flag + f, 0, sizeof(int), h->stream));
@@ -2615,6 +2801,7 @@ int fe_set_frame_dev(FeEngine* h, int f, const fe_real* x, const fe_real* v, con
     return check_async(h);
 }
 int fe_copy_frame(FeEngine* h, int src, int dst) {
+    FE_ENTRY(h);
     CHECK_FRAME(h, src); CHECK_FRAME(h, dst);
     if (src == dst) return 0;
     HIPCK(h, hipMemcpyAsync(h->frame(dst), h->frame(src), sizeof(float) * h->frame_stride, hipMemcpyDeviceToDevice, h->stream));
@@ -2624,6 +2811,7 @@ int fe_copy_frame(FeEngine* h, int src, int dst) {
     return 0;
 }
 int fe_copy_grad(FeEngine* h, int src, int dst) {
+    FE_ENTRY(h);
     CHECK_FRAME(h, src); CHECK_FRAME(h, dst);
     // adjoint frames are a ring of two (slot = f & 1); the `used` copy of mpm:604 is a frame copy
     if ((src & 1) != (dst & 1)) {
@@ -2632,11 +2820,12 @@ int fe_copy_grad(FeEngine* h, int src, int dst) {
     }
     if (src != dst) {
         FrameV s = frame_view(h->frame(src), h->Np), d = frame_view(h->frame(dst), h->Np);
-        HIPCK(h, hipMemcpyAsync(d.used, s.used, sizeof(int) * h->Np, hipMemcpyDeviceToDevice, h->stream));
+        HIPCK(h, hipMemcpyAsync(d.used.ptr(), s.used.ptr(), sizeof(int) * h->Np, hipMemcpyDeviceToDevice, h->stream));
     }
     return 0;
 }
 int fe_reset_grad(FeEngine* h) {
+    FE_ENTRY(h);
     if (smoke_reset_grad_impl(h)) return 1;
     HIPCK(h, hipMemsetAsync(h->grad_ptr[0], 0, sizeof(float) * h->grad_words(), h->stream));
     HIPCK(h, hipMemsetAsync(h->grad_ptr[1], 0, sizeof(float) * h->grad_words(), h->stream));
@@ -2655,11 +2844,13 @@ int fe_reset_grad(FeEngine* h) {
     return 0;
 }
 int fe_reset_grad_till_frame(FeEngine* h, int f) {
+    FE_ENTRY(h);
     CHECK_FRAME(h, f);
     // particle adjoints: every substep_grad overwrites its ring slot, nothing to clear.
     return 0;
 }
 int fe_agent_set_collector(FeEngine* h, const FeBoundary* b, int mat) {
+    FE_ENTRY(h);
     (void)hipSetDevice(h->device);
     h->has_collector = b != nullptr;
     h->collector_mat = mat;
@@ -2670,6 +2861,7 @@ int fe_agent_set_collector(FeEngine* h, const FeBoundary* b, int mat) {
     return 0;
 }
 int fe_agent_reset_grad_till_frame(FeEngine* h, int f) {
+    FE_ENTRY(h);
     CHECK_FRAME(h, f);
     for (auto& E : h->effs) {
         if (f == 0) break;
@@ -2683,17 +2875,20 @@ int fe_agent_reset_grad_till_frame(FeEngine* h, int f) {
     return 0;
 }
 int fe_get_grad(FeEngine* h, int f, fe_real* gx, fe_real* gv, fe_real* gC, fe_real* gF) {
+    FE_ENTRY(h);
     CHECK_FRAME(h, f);
     const int t = h->gtbl[f & 1] < 0 ? 0 : h->gtbl[f & 1];
     return download_planes(h, h->grad(f), h->tables[t].pid, gx, gv, gC, gF, nullptr);
 }
 int fe_add_grad(FeEngine* h, int f, const fe_real* gx, const fe_real* gv, const fe_real* gC, const fe_real* gF) {
+    FE_ENTRY(h);
     CHECK_FRAME(h, f);
     if (grad_order_for_frame(h, f)) return 1;
     return upload_planes(h, h->grad(f), h->pid_of(f), gx, gv, gC, gF, nullptr, 1);
 }
 // device-pointer variant (a loss evaluated on the GPU hands its adjoint over without crossing PCIe)
 int fe_add_grad_dev(FeEngine* h, int f, const fe_real* gx, const fe_real* gv, const fe_real* gC, const fe_real* gF) {
+    FE_ENTRY(h);
     CHECK_FRAME(h, f);
     if (grad_order_for_frame(h, f)) return 1;
     const int mask = (gx ? 1 : 0) | (gv ? 2 : 0) | (gC ? 4 : 0) | (gF ? 8 : 0);
@@ -2703,6 +2898,7 @@ int fe_add_grad_dev(FeEngine* h, int f, const fe_real* gx, const fe_real* gv, co
     return check_async(h);
 }
 int fe_get_mat(FeEngine* h, int* mat) {
+    FE_ENTRY(h);
     if ((int)h->mat_host.size() != h->N) FAIL(h, "particles not initialised");
     std::memcpy(mat, h->mat_host.data(), sizeof(int) * h->N);
     return 0;
@@ -2710,6 +2906,7 @@ int fe_get_mat(FeEngine* h, int* mat) {
 
 // ---- effectors
 int fe_add_effector(FeEngine* h, const FeEffectorDesc* d, const fe_real* random_vector) {
+    FE_ENTRY(h);
     auto bad = [&](const char* m) { h->err = m; return -1; };
     if (!d || d->struct_size != (int)sizeof(FeEffectorDesc)) return bad("FeEffectorDesc size mismatch");
     if (!(d->action_dim == 0 || d->action_dim == 3 || d->action_dim == 6 || (d->type == FE_EFF_AIRCON && d->action_dim == 8)))
@@ -2742,6 +2939,7 @@ int fe_add_effector(FeEngine* h, const FeEffectorDesc* d, const fe_real* random_
     return (int)h->effs.size() - 1;
 }
 int fe_eff_set_act_range(FeEngine* h, int e, const int* act_range, int n) {
+    FE_ENTRY(h);
     CHECK_EFF(h, e);
     EffHost& E = h->effs[e];
     E.act_range.assign(act_range, act_range + n);
@@ -2756,6 +2954,7 @@ int fe_eff_set_act_range(FeEngine* h, int e, const int* act_range, int n) {
     return 0;
 }
 int fe_eff_get_state(FeEngine* h, int e, int f, fe_real* s) {
+    FE_ENTRY(h);
     CHECK_EFF(h, e); CHECK_FRAME(h, f);
     EffHost& E = h->effs[e];
     HIPCK(h, hipMemcpyAsync(s, E.p.pos + f * 3, sizeof(float) * 3, hipMemcpyDeviceToHost, h->stream));
@@ -2765,6 +2964,7 @@ int fe_eff_get_state(FeEngine* h, int e, int f, fe_real* s) {
     return 0;
 }
 int fe_eff_set_state(FeEngine* h, int e, int f, const fe_real* s) {
+    FE_ENTRY(h);
     CHECK_EFF(h, e); CHECK_FRAME(h, f);
     EffHost& E = h->effs[e];
     HIPCK(h, hipMemcpyAsync(E.p.pos + f * 3, s, sizeof(float) * 3, hipMemcpyHostToDevice, h->stream));
@@ -2774,6 +2974,7 @@ int fe_eff_set_state(FeEngine* h, int e, int f, const fe_real* s) {
     return 0;
 }
 int fe_eff_get_vw(FeEngine* h, int e, int f, fe_real* v3, fe_real* w3) {
+    FE_ENTRY(h);
     CHECK_EFF(h, e); CHECK_FRAME(h, f);
     HIPCK(h, hipMemcpyAsync(v3, h->effs[e].p.v + f * 3, sizeof(float) * 3, hipMemcpyDeviceToHost, h->stream));
     HIPCK(h, hipMemcpyAsync(w3, h->effs[e].p.w + f * 3, sizeof(float) * 3, hipMemcpyDeviceToHost, h->stream));
@@ -2781,6 +2982,7 @@ int fe_eff_get_vw(FeEngine* h, int e, int f, fe_real* v3, fe_real* w3) {
     return 0;
 }
 int fe_eff_get_sr(FeEngine* h, int e, int f, fe_real* s, fe_real* r) {
+    FE_ENTRY(h);
     CHECK_EFF(h, e); CHECK_FRAME(h, f);
     HIPCK(h, hipMemcpyAsync(s, h->effs[e].p.sa + f, sizeof(float), hipMemcpyDeviceToHost, h->stream));
     HIPCK(h, hipMemcpyAsync(r, h->effs[e].p.ra + f, sizeof(float), hipMemcpyDeviceToHost, h->stream));
@@ -2788,6 +2990,7 @@ int fe_eff_get_sr(FeEngine* h, int e, int f, fe_real* s, fe_real* r) {
     return 0;
 }
 int fe_eff_set_sr(FeEngine* h, int e, int f, fe_real s, fe_real r) {
+    FE_ENTRY(h);
     CHECK_EFF(h, e); CHECK_FRAME(h, f);
     HIPCK(h, hipMemcpyAsync(h->effs[e].p.sa + f, &s, sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIPCK(h, hipMemcpyAsync(h->effs[e].p.ra + f, &r, sizeof(float), hipMemcpyHostToDevice, h->stream));
@@ -2795,6 +2998,7 @@ int fe_eff_set_sr(FeEngine* h, int e, int f, fe_real s, fe_real r) {
     return 0;
 }
 int fe_eff_set_vw(FeEngine* h, int e, int f, const fe_real* v3, const fe_real* w3) {
+    FE_ENTRY(h);
     CHECK_EFF(h, e); CHECK_FRAME(h, f);
     HIPCK(h, hipMemcpyAsync(h->effs[e].p.v + f * 3, v3, sizeof(float) * 3, hipMemcpyHostToDevice, h->stream));
     HIPCK(h, hipMemcpyAsync(h->effs[e].p.w + f * 3, w3, sizeof(float) * 3, hipMemcpyHostToDevice, h->stream));
@@ -2802,6 +3006,7 @@ int fe_eff_set_vw(FeEngine* h, int e, int f, const fe_real* v3, const fe_real* w
     return 0;
 }
 int fe_eff_set_action(FeEngine* h, int e, int s, int s_global, int n_substeps, const fe_real* action) {
+    FE_ENTRY(h);
     CHECK_EFF(h, e);
     EffP& p = h->effs[e].p;
     if (p.action_dim == 0) return 0;
@@ -2813,6 +3018,7 @@ int fe_eff_set_action(FeEngine* h, int e, int s, int s_global, int n_substeps, c
     return check_async(h);
 }
 int fe_eff_set_action_grad(FeEngine* h, int e, int s, int s_global, int n_substeps) {
+    FE_ENTRY(h);
     CHECK_EFF(h, e);
     EffP& p = h->effs[e].p;
     if (p.action_dim == 0) return 0;
@@ -2822,6 +3028,7 @@ int fe_eff_set_action_grad(FeEngine* h, int e, int s, int s_global, int n_subste
     return check_async(h);
 }
 int fe_eff_apply_action_p(FeEngine* h, int e, const fe_real* action_p) {
+    FE_ENTRY(h);
     CHECK_EFF(h, e);
     EffP& p = h->effs[e].p;
     if (p.action_dim == 0) return 0;
@@ -2831,6 +3038,7 @@ int fe_eff_apply_action_p(FeEngine* h, int e, const fe_real* action_p) {
     return check_async(h);
 }
 int fe_eff_apply_action_p_grad(FeEngine* h, int e) {
+    FE_ENTRY(h);
     CHECK_EFF(h, e);
     EffP& p = h->effs[e].p;
     if (p.action_dim == 0) return 0;
@@ -2838,6 +3046,7 @@ int fe_eff_apply_action_p_grad(FeEngine* h, int e) {
     return check_async(h);
 }
 int fe_eff_get_action_grad(FeEngine* h, int e, int s, int n, fe_real* grad) {
+    FE_ENTRY(h);
     CHECK_EFF(h, e);
     EffP& p = h->effs[e].p;
     const int ad = p.action_dim;
@@ -2849,6 +3058,7 @@ int fe_eff_get_action_grad(FeEngine* h, int e, int s, int n, fe_real* grad) {
     return 0;
 }
 int fe_agent_copy_frame(FeEngine* h, int src, int dst) {
+    FE_ENTRY(h);
     CHECK_FRAME(h, src); CHECK_FRAME(h, dst);
     for (auto& E : h->effs) {
         hipLaunchKernelGGL(k_eff_copy, dim3(1), dim3(64), 0, h->stream, E.p, src, dst, 0);
@@ -2857,6 +3067,7 @@ int fe_agent_copy_frame(FeEngine* h, int src, int dst) {
     return check_async(h);
 }
 int fe_agent_copy_grad(FeEngine* h, int src, int dst) {
+    FE_ENTRY(h);
     CHECK_FRAME(h, src); CHECK_FRAME(h, dst);
     for (auto& E : h->effs) hipLaunchKernelGGL(k_eff_copy, dim3(1), dim3(64), 0, h->stream, E.p, src, dst, 1);
     return check_async(h);
@@ -2886,6 +3097,7 @@ static int build_sdf(FeEngine* h, const FeSdfDesc* d, const fe_real* voxels, Sdf
     return 0;
 }
 int fe_add_static(FeEngine* h, const FeSdfDesc* d, const fe_real* voxels) {
+    FE_ENTRY(h);
     if ((int)h->statics_host.size() >= FE_MAX_STATICS) { h->err = "add_static: too many static colliders"; return -1; }
     SdfP s; float* vox = nullptr;
     if (build_sdf(h, d, voxels, s, &vox)) return -1;
@@ -2897,6 +3109,7 @@ int fe_add_static(FeEngine* h, const FeSdfDesc* d, const fe_real* voxels) {
     return (int)h->statics_host.size() - 1;
 }
 int fe_eff_set_mesh(FeEngine* h, int e, const FeSdfDesc* d, const fe_real* voxels) {
+    FE_ENTRY(h);
     if (e < 0 || e >= (int)h->effs.size()) FAIL(h, "effector index out of range");
     SdfP s; float* vox = nullptr;
     if (build_sdf(h, d, voxels, s, &vox)) return 1;
@@ -2913,6 +3126,7 @@ int fe_eff_set_mesh(FeEngine* h, int e, const FeSdfDesc* d, const fe_real* voxel
 
 // ---- loss
 int fe_loss_alloc(FeEngine* h, int max_loss_steps) {
+    FE_ENTRY(h);
     if (max_loss_steps <= 0) FAIL(h, "max_loss_steps must be positive");
     if (h->tgt) { (void)hipFree(h->tgt); (void)hipFree(h->chamfer); (void)hipFree(h->step_loss); h->tgt = h->chamfer = h->step_loss = nullptr; }
     h->loss_steps = max_loss_steps;
@@ -2921,18 +3135,21 @@ int fe_loss_alloc(FeEngine* h, int max_loss_steps) {
     return 0;
 }
 int fe_loss_set_target(FeEngine* h, int s, const fe_real* x) {
+    FE_ENTRY(h);
     if (s < 0 || s >= h->loss_steps) FAIL(h, "loss step out of range");
     HIPCK(h, hipMemcpyAsync(h->tgt + (size_t)s * h->N * 3, x, sizeof(float) * 3 * h->N, hipMemcpyHostToDevice, h->stream));
     HIPCK(h, hipStreamSynchronize(h->stream));
     return 0;
 }
 int fe_loss_clear(FeEngine* h) {
+    FE_ENTRY(h);
     if (!h->loss_steps) return 0;
     HIPCK(h, hipMemsetAsync(h->chamfer, 0, sizeof(float) * h->loss_steps, h->stream));
     HIPCK(h, hipMemsetAsync(h->step_loss, 0, sizeof(float) * h->loss_steps, h->stream));
     return 0;
 }
 int fe_loss_step(FeEngine* h, int s, int f, int matching_mat, fe_real weight) {
+    FE_ENTRY(h);
     if (s < 0 || s >= h->loss_steps) FAIL(h, "loss step out of range");
     CHECK_FRAME(h, f);
     hipLaunchKernelGGL(k_loss_fwd, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->pid_of(f), h->pinfo,
@@ -2941,6 +3158,7 @@ int fe_loss_step(FeEngine* h, int s, int f, int matching_mat, fe_real weight) {
     return check_async(h);
 }
 int fe_loss_step_grad(FeEngine* h, int s, int f, int matching_mat, fe_real weight, fe_real step_loss_grad) {
+    FE_ENTRY(h);
     if (s < 0 || s >= h->loss_steps) FAIL(h, "loss step out of range");
     CHECK_FRAME(h, f);
     if (grad_order_for_frame(h, f)) return 1;
@@ -2949,6 +3167,7 @@ int fe_loss_step_grad(FeEngine* h, int s, int f, int matching_mat, fe_real weigh
     return check_async(h);
 }
 int fe_loss_get(FeEngine* h, fe_real* step_loss, int n) {
+    FE_ENTRY(h);
     if (n > h->loss_steps) FAIL(h, "loss_get: n too large");
     HIPCK(h, hipMemcpyAsync(step_loss, h->step_loss, sizeof(float) * n, hipMemcpyDeviceToHost, h->stream));
     HIPCK(h, hipStreamSynchronize(h->stream));
@@ -2979,6 +3198,7 @@ int fe_mesh_sdf(int device, const float* verts, int nv, const int* faces, int nf
 }
 
 int fe_get_stats(FeEngine* h, int f, FeStats* out) {
+    FE_ENTRY(h);
     CHECK_FRAME(h, f);
     const int ncell = h->nb * h->nb * h->nb * 64;
     HIPCK(h, hipMemsetAsync(h->counters, 0, sizeof(unsigned long long) * 4, h->stream));
@@ -2994,27 +3214,33 @@ int fe_get_stats(FeEngine* h, int f, FeStats* out) {
     out->n_slow_path = slow; out->bytes_state = (long long)h->bytes;
     return check_async(h);
 }
-// debug only (not part of include/fluidengine.h): phase timestamps written by k_p2g when option dbg & 8
-int fe_debug_timestamps(FeEngine* h, unsigned long long* out, int n) {
-    if (n > 8 * 4096) n = 8 * 4096;
-    HIPCK(h, hipMemcpyAsync(out, h->ts_dev, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost, h->stream));
+#ifdef FE_TIMELINE
+// profiling builds only (not part of include/fluidengine.h): the stamps of the last launch of kernel `kid` (order of KNAMES)
+int fe_timeline_read(FeEngine* h, int kid, unsigned long long* out) {
+    FE_ENTRY(h);
+    if (kid < 0 || kid >= KID_COUNT || !h->tl_dev) FAIL(h, "no timeline");
+    HIPCK(h, hipMemcpyAsync(out, h->tl_dev + (size_t)kid * TL_WGS * 9, sizeof(unsigned long long) * TL_WGS * 9, hipMemcpyDeviceToHost, h->stream));
     HIPCK(h, hipStreamSynchronize(h->stream));
     return 0;
 }
-int fe_timer_start(FeEngine* h) { HIPCK(h, hipEventRecord(h->ev_t0, h->stream)); return 0; }
+#endif
+int fe_timer_start(FeEngine* h) { FE_ENTRY(h); HIPCK(h, hipEventRecord(h->ev_t0, h->stream)); return 0; }
 double fe_timer_stop_ms(FeEngine* h) {
+    FE_ENTRY(h);
     if (hipEventRecord(h->ev_t1, h->stream) != hipSuccess || hipEventSynchronize(h->ev_t1) != hipSuccess) { h->err = "timer stop failed"; return -1.0; }
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, h->ev_t0, h->ev_t1) != hipSuccess) { h->err = "hipEventElapsedTime failed"; return -1.0; }
     return (double)ms;
 }
 int fe_profile_enable(FeEngine* h, int on) {
+    FE_ENTRY(h);
     prof_drain(h);
     h->prof_on = on != 0;
     if (on) for (int i = 0; i < KID_COUNT; i++) { h->prof_ms[i] = 0; h->prof_n[i] = 0; }
     return 0;
 }
 int fe_profile_read(FeEngine* h, char* buf, int buf_len, double* ms_total, long long* launches, int cap) {
+    FE_ENTRY(h);
     prof_drain(h);
     std::string names;
     for (int i = 0; i < KID_COUNT; i++) { if (i) names += "\n"; names += KNAMES[i]; }

@@ -438,6 +438,7 @@ __global__ void k_smoke_init_q(SmokeP P, float high_T) {
 }
 
 int fe_smoke_create(FeEngine* h, const FeSmokeConfig* c) {
+    FE_ENTRY(h);
     if (hipSetDevice(h->device) != hipSuccess) FAIL(h, "hipSetDevice failed");
     if (!c || c->struct_size != (int)sizeof(FeSmokeConfig)) FAIL(h, "FeSmokeConfig size mismatch");
     if (c->res < 4 || c->q_dim < 1 || c->q_dim > 3 || c->max_steps_local < 1 || c->solver_iters < 0) FAIL(h, "bad smoke configuration (q_dim 1..3)");
@@ -461,6 +462,7 @@ int fe_smoke_create(FeEngine* h, const FeSmokeConfig* c) {
 }
 
 int fe_smoke_step(FeEngine* h, int s, int f) {
+    FE_ENTRY(h);
     CHECK_SMOKE(h, s); CHECK_FRAME(h, f);
     SmokeP& P = h->smoke->P;
     if (s >= P.S) FAIL(h, "smoke step frame out of range");
@@ -487,6 +489,7 @@ int fe_smoke_step(FeEngine* h, int s, int f) {
 }
 
 int fe_smoke_step_grad(FeEngine* h, int s, int f) {
+    FE_ENTRY(h);
     CHECK_SMOKE(h, s); CHECK_FRAME(h, f);
     SmokeP& P = h->smoke->P;
     if (s >= P.S) FAIL(h, "smoke step frame out of range");
@@ -523,6 +526,7 @@ static int smoke_io(FeEngine* h, int s, float* base, int comps, void* host, bool
     return 0;
 }
 int fe_smoke_get_frame(FeEngine* h, int s, fe_real* v, fe_real* v_tmp, fe_real* div, fe_real* p, fe_real* q) {
+    FE_ENTRY(h);
     CHECK_SMOKE(h, s);
     SmokeP& P = h->smoke->P;
     if (smoke_io(h, s, P.v, 3, v, true) || smoke_io(h, s, P.vt, 3, v_tmp, true) || smoke_io(h, s, P.dv, 1, div, true) ||
@@ -531,6 +535,7 @@ int fe_smoke_get_frame(FeEngine* h, int s, fe_real* v, fe_real* v_tmp, fe_real* 
     return 0;
 }
 int fe_smoke_set_frame(FeEngine* h, int s, const fe_real* v, const fe_real* v_tmp, const fe_real* div, const fe_real* p, const fe_real* q) {
+    FE_ENTRY(h);
     CHECK_SMOKE(h, s);
     SmokeP& P = h->smoke->P;
     if (smoke_io(h, s, P.v, 3, (void*)v, false) || smoke_io(h, s, P.vt, 3, (void*)v_tmp, false) || smoke_io(h, s, P.dv, 1, (void*)div, false) ||
@@ -539,6 +544,7 @@ int fe_smoke_set_frame(FeEngine* h, int s, const fe_real* v, const fe_real* v_tm
     return 0;
 }
 int fe_smoke_get_grad(FeEngine* h, int s, fe_real* gv, fe_real* gq) {
+    FE_ENTRY(h);
     CHECK_SMOKE(h, s);
     SmokeP& P = h->smoke->P;
     if (smoke_io(h, s, P.gv, 3, gv, true) || smoke_io(h, s, P.gq, P.qd, gq, true)) return 1;
@@ -550,6 +556,7 @@ __global__ void k_smoke_axpy(float* dst, const float* src, size_t n) {
     if (t < n) dst[t] += src[t];
 }
 int fe_smoke_add_grad(FeEngine* h, int s, const fe_real* gv, const fe_real* gq) {
+    FE_ENTRY(h);
     CHECK_SMOKE(h, s);
     SmokeP& P = h->smoke->P;
     // staged through the scratch v_tmp / q adjoint-free buffers is not possible (all live): use a temporary allocation
@@ -577,10 +584,11 @@ static int smoke_copy(FeEngine* h, int src, int dst, bool grad) {
                                 hipMemcpyDeviceToDevice, h->stream));
     return 0;
 }
-int fe_smoke_copy_frame(FeEngine* h, int src, int dst) { CHECK_SMOKE(h, src); CHECK_SMOKE(h, dst); return src == dst ? 0 : smoke_copy(h, src, dst, false); }
-int fe_smoke_copy_grad(FeEngine* h, int src, int dst) { CHECK_SMOKE(h, src); CHECK_SMOKE(h, dst); return src == dst ? 0 : smoke_copy(h, src, dst, true); }
-int fe_smoke_reset_grad(FeEngine* h) { if (!h->smoke) FAIL(h, "no smoke field"); return smoke_reset_grad_impl(h); }
+int fe_smoke_copy_frame(FeEngine* h, int src, int dst) { FE_ENTRY(h); CHECK_SMOKE(h, src); CHECK_SMOKE(h, dst); return src == dst ? 0 : smoke_copy(h, src, dst, false); }
+int fe_smoke_copy_grad(FeEngine* h, int src, int dst) { FE_ENTRY(h); CHECK_SMOKE(h, src); CHECK_SMOKE(h, dst); return src == dst ? 0 : smoke_copy(h, src, dst, true); }
+int fe_smoke_reset_grad(FeEngine* h) { FE_ENTRY(h); if (!h->smoke) FAIL(h, "no smoke field"); return smoke_reset_grad_impl(h); }
 int fe_smoke_reset_grad_till_frame(FeEngine* h, int s) {
+    FE_ENTRY(h);
     CHECK_SMOKE(h, s);
     SmokeP& P = h->smoke->P;
     const size_t F = (size_t)s * P.n3;
