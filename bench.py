@@ -258,7 +258,10 @@ def run_replicas(args, rank, local_rank, world):
     quiet = lambda: contextlib.redirect_stdout(io.StringIO())        # the env / solver layers print progress lines
     with quiet():
         # the target pattern every replica pours towards: the demo policy's recording (seed 0 on every rank)
-        tgt = Recorder(make('LatteArt-v0', seed=0, loss=False, **kw)).record(write=False)
+        rec = make('LatteArt-v0', seed=0, loss=False, **kw)
+        tgt = Recorder(rec).record(write=False)
+        rec.taichi_env.simulator.engine.close()                      # its resident trajectory is tens of GB: free it before the replica is built
+        del rec
         env = make('LatteArt-v0', seed=1000 + rank, loss=True, target=tgt, **kw)      # injector randomness differs per rank
     cfg = load_config('configs/exp_latteart.yaml').SOLVER
     # 128^3 sits at the stability edge of the reference's fixed dt: the Adam step is kept small so that W + K

@@ -302,14 +302,27 @@ class Engine:
     def _tptr(t):
         return None if t is None else C.c_void_p(t.data_ptr())
 
+    def _torch_fence(self, *tensors):
+        """The engine's stream is non-blocking: nothing orders it with torch's streams.  Before the engine reads or overwrites a
+        torch tensor, whatever torch has queued on it -- the fill of a fresh allocation, an earlier read of a staging tensor --
+        has to be finished (the engine calls themselves return after the engine's stream has drained)."""
+        for t in tensors:
+            if t is not None:
+                import torch
+                torch.cuda.current_stream(t.device).synchronize()
+                return
+
     def get_frame_dev(self, f, x=None, v=None, C_=None, F=None, used=None):
+        self._torch_fence(x, v, C_, F, used)
         self._ck(self.lib.fe_get_frame_dev(self.h, int(f), self._tptr(x), self._tptr(v), self._tptr(C_), self._tptr(F), self._tptr(used)))
 
     def set_frame_dev(self, f, x=None, v=None, C_=None, F=None, used=None):
+        self._torch_fence(x, v, C_, F, used)
         self._ck(self.lib.fe_set_frame_dev(self.h, int(f), self._tptr(x), self._tptr(v), self._tptr(C_), self._tptr(F), self._tptr(used)))
 
     def add_grad_dev(self, f, gx=None, gv=None, gC=None, gF=None):
-        """fe_add_grad_dev: torch tensors on the engine's GPU, already complete (synchronise the producing stream first)"""
+        """fe_add_grad_dev: torch tensors on the engine's GPU (the producing torch stream is synchronised here)"""
+        self._torch_fence(gx, gv, gC, gF)
         self._ck(self.lib.fe_add_grad_dev(self.h, int(f), self._tptr(gx), self._tptr(gv), self._tptr(gC), self._tptr(gF)))
 
     def add_grad(self, f, gx=None, gv=None, gC=None, gF=None):

@@ -182,6 +182,80 @@ __device__ __forceinline__ float sel3(int i, float a, float b, float c) { return
 __device__ __forceinline__ int xcd_item(int wg, int per, int on) { return on ? (wg & 7) * per + (wg >> 3) : wg; }
 #define STW(st, i, d) sel3((i), (st).w[0][d], (st).w[1][d], (st).w[2][d])
 
+// -----------------------------------------------------------------------------------------
+// Wavefront aggregation of scatter contributions.  After the cell-level sort, lanes holding particles of one
+// cell are adjacent and write the same 27 nodes.  A segmented inclusive scan over the 64 lanes (DPP row_shr
+// 1/2/4/8 + row_bcast15/31: pure VALU, no LDS traffic) sums each run of equal keys; only the last lane of a run
+// issues the LDS atomic.  Measured motivation (profiles/r01e): ~30 us of a 44 us P2G launch were ds_add_f64.
+// Correct for ANY lane order: only *adjacent* equal keys are merged.
+// -----------------------------------------------------------------------------------------
+struct SegScan { float f1, f2, f4, f8, f15, f31; bool tail; };
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov(float v) {      // lanes without a source get 0
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+// must be executed by all 64 lanes of the wave
+__device__ __forceinline__ SegScan seg_setup(int key) {
+    const int lane = threadIdx.x & 63;
+    const int prev = __shfl_up(key, 1, 64);
+    const bool is_head = lane == 0 || key != prev;
+    const unsigned long long mask = __ballot(is_head);
+    const unsigned long long lower = mask & ((2ull << lane) - 1ull);       // run heads at or before this lane
+    const int head = 63 - __clzll((long long)lower);
+    const int dist = lane - head, row = lane >> 4;
+    SegScan sc;
+    sc.f1 = dist >= 1 ? 1.f : 0.f; sc.f2 = dist >= 2 ? 1.f : 0.f; sc.f4 = dist >= 4 ? 1.f : 0.f; sc.f8 = dist >= 8 ? 1.f : 0.f;
+    sc.f15 = ((row & 1) && head <= row * 16 - 1) ? 1.f : 0.f;             // run reaches back into the previous row
+    sc.f31 = (row >= 2 && head <= 31) ? 1.f : 0.f;                         // ... into the first half of the wave
+    sc.tail = lane == 63 || ((mask >> (lane + 1)) & 1ull);                 // last lane of its run
+    return sc;
+}
+// Four independent values at once, one v_fmac_f32_dpp per step and value (the compiler's own lowering of seg_scan
+// is v_mov_b32_dpp + v_fma_f32).  A DPP read of a VGPR written by the previous VALU needs 2 wait states, which
+// inline asm has to provide itself: the 4 chains are independent, so three other VALU instructions always sit between
+// the write of a value in one step and its DPP read in the next; only the entry needs an s_nop.
+// (Cutting runs at 8-lane groups to halve the scan was measured slower: the extra ds_add_f64 lane-ops cost more than
+// the 36 v_fmac_dpp saved per 3 nodes -- p2g 21.0 -> 25.3 us.)
+#define SEG_STEP4(ctrl, flag) \
+    asm volatile("v_fmac_f32_dpp %0, %0, %4 " ctrl " bound_ctrl:0\n\t" \
+                 "v_fmac_f32_dpp %1, %1, %4 " ctrl " bound_ctrl:0\n\t" \
+                 "v_fmac_f32_dpp %2, %2, %4 " ctrl " bound_ctrl:0\n\t" \
+                 "v_fmac_f32_dpp %3, %3, %4 " ctrl " bound_ctrl:0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(flag))
+__device__ __forceinline__ void seg_scan4(const SegScan& sc, float& a, float& b, float& c, float& d) {
+    asm volatile("s_nop 1" ::: );                        // the inputs were just produced by VALU
+    SEG_STEP4("row_shr:1 row_mask:0xf bank_mask:0xf", sc.f1);
+    SEG_STEP4("row_shr:2 row_mask:0xf bank_mask:0xf", sc.f2);
+    SEG_STEP4("row_shr:4 row_mask:0xf bank_mask:0xf", sc.f4);
+    SEG_STEP4("row_shr:8 row_mask:0xf bank_mask:0xf", sc.f8);
+    SEG_STEP4("row_bcast:15 row_mask:0xa bank_mask:0xf", sc.f15);
+    SEG_STEP4("row_bcast:31 row_mask:0xc bank_mask:0xf", sc.f31);
+}
+// three values (the adjoint scatter of g2p has no mass component)
+#define SEG_STEP3(ctrl, flag) \
+    asm volatile("v_fmac_f32_dpp %0, %0, %3 " ctrl " bound_ctrl:0\n\t" \
+                 "v_fmac_f32_dpp %1, %1, %3 " ctrl " bound_ctrl:0\n\t" \
+                 "v_fmac_f32_dpp %2, %2, %3 " ctrl " bound_ctrl:0\n\t" \
+                 "s_nop 0" : "+v"(a), "+v"(b), "+v"(c) : "v"(flag))      // 2 other VALUs + 1 wait state between write and DPP read
+__device__ __forceinline__ void seg_scan3(const SegScan& sc, float& a, float& b, float& c) {
+    asm volatile("s_nop 1" ::: );
+    SEG_STEP3("row_shr:1 row_mask:0xf bank_mask:0xf", sc.f1);
+    SEG_STEP3("row_shr:2 row_mask:0xf bank_mask:0xf", sc.f2);
+    SEG_STEP3("row_shr:4 row_mask:0xf bank_mask:0xf", sc.f4);
+    SEG_STEP3("row_shr:8 row_mask:0xf bank_mask:0xf", sc.f8);
+    SEG_STEP3("row_bcast:15 row_mask:0xa bank_mask:0xf", sc.f15);
+    SEG_STEP3("row_bcast:31 row_mask:0xc bank_mask:0xf", sc.f31);
+}
+__device__ __forceinline__ float seg_scan(const SegScan& sc, float v) {
+    v = fmaf(sc.f1, dpp_mov<0x111, 0xf>(v), v);          // row_shr:1
+    v = fmaf(sc.f2, dpp_mov<0x112, 0xf>(v), v);          // row_shr:2
+    v = fmaf(sc.f4, dpp_mov<0x114, 0xf>(v), v);          // row_shr:4
+    v = fmaf(sc.f8, dpp_mov<0x118, 0xf>(v), v);          // row_shr:8
+    v = fmaf(sc.f15, dpp_mov<0x142, 0xa>(v), v);         // row_bcast:15 -> rows 1,3
+    v = fmaf(sc.f31, dpp_mov<0x143, 0xc>(v), v);         // row_bcast:31 -> rows 2,3
+    return v;
+}
+
 struct TableP {
     const int*  pid_of_slot;   // [Np]
     const float4* info;        // [Np] material record of the particle in each slot (pinfo in slot order: a coalesced load, not pinfo[pid])
@@ -296,11 +370,7 @@ __device__ __forceinline__ void p2g_compute(const SimP& S, const FrameV& nxt, in
     const PInfo& info = r.info;
     Constitutive k;
     constitutive_eval_t<GENERAL>(p.C, p.F, S.dt, info.mu, info.lam, info.mass, info.cls, S.stress_scale, k);
-    if (WRITE) {
-        int sw = s;
-        asm volatile("" : "+v"(sw));             // form the store addresses here, not ahead of the constitutive model (they were spilled)
-        store_F(nxt, sw, k.Fnew); nxt.used[sw] = 1;
-    }
+    if (WRITE) { store_F(nxt, s, k.Fnew); nxt.used[s] = 1; }
     stencil_make(p.x, S.inv_dx, q.st);
     q.inside = stencil_inside(q.st, S.n);
     if (!q.inside) atomicAdd(G.err, 1);
@@ -350,114 +420,36 @@ __device__ __forceinline__ void p2g_scatter_global(const SimP& S, const P2GPrep&
                 if (mark_block((bx * S.nb + by) * S.nb + bz, G.blk_flag, G.blk_list, G.blk_count)) *G.frame_slow = 1;   // store incomplete for this frame
 }
 
-// -----------------------------------------------------------------------------------------
-// Transposed scatter (P2G and the d v_out scatter of g2p's adjoint).  After the cell-level sort the lanes of a wave hold
-// runs ("segments") of particles with the same stencil base, i.e. the same 27 nodes.  Round 1 summed each run with a DPP
-// segmented scan executed by every lane for every node (27 nodes x 4 values x 6 v_fmac_dpp per particle) and let the run's
-// last lane issue the LDS atomics.  Here the reduction is transposed instead:
-//   phase A (one lane per particle)  the particle's contribution record -- 9 stencil weights + what its node values are linear
-//            in -- goes to LDS (s_pay, SoA planes), and each wave lists its segments (s_seg);
-//   phase B (one lane per (segment, x-offset i) = a 3 x 3 slab of the segment's 27 nodes)  walks the segment's records, accumulating
-//            the slab's 9 x 4 (9 x 3) sums in registers: ~75 VALU per (particle, slab) instead of ~450, no cross-lane traffic;
-//   phase C  the slab's sums go into the fp64 LDS tile with ds_add_f64.
-// Segments never cross a wave, their order and the order inside them is the slot order: the sums are bit-reproducible up to the
-// order of the fp64 atomics, which fp32 results do not see.  Correct for ANY slot order (an unsorted frame just has runs of 1).
-// -----------------------------------------------------------------------------------------
-#define PAY_MAX 22
-__shared__ float s_pay[PAY_MAX * WG];        // [plane][tid within the pass]
-__shared__ int   s_seg[WG];                  // per wave 64 entries: start (8 bits) | length (8 bits) | tile-local base index (16 bits)
-__shared__ int   s_nseg[4];
-// planes 0..8: w[i][d] at d * 3 + i
-__device__ __forceinline__ void pay_weights(const Stencil& st, int t) {
-#pragma unroll
-    for (int d = 0; d < 3; d++)
-#pragma unroll
-        for (int i = 0; i < 3; i++) s_pay[(d * 3 + i) * WG + t] = st.w[i][d];
-}
-// must be executed by all 64 lanes of the wave; `lb` < 0: this lane takes no part
-__device__ __forceinline__ void seg_list(int lb, int t) {
-    int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    // (lane-derived masks and LDS addresses are cheap to form: laundering the lane id keeps LICM from hoisting them out of the
-    // item loop, where they lived in VGPRs for the whole kernel and were spilled)
-    asm volatile("" : "+v"(lane));
-    const int key = lb >= 0 ? lb : (0x40000000 | lane);
-    const int prev = __shfl_up(key, 1, 64);
-    const bool is_head = lane == 0 || key != prev;
-    const unsigned long long heads = __ballot(is_head), valid = __ballot(is_head && lb >= 0);
-    if (is_head && lb >= 0) {
-        const int idx = __popcll(valid & ((1ull << lane) - 1ull));
-        const unsigned long long after = lane == 63 ? 0ull : (heads >> (lane + 1));
-        const int len = after ? __ffsll((long long)after) : 64 - lane;        // distance to the next run head
-        s_seg[wave * 64 + idx] = t | (len << 8) | (lb << 16);
-    }
-    if (lane == 0) s_nseg[wave] = __popcll(valid);
-}
-struct SegUnit { int start, len, lb, sub; };
-// unit u of the pass -> (segment, sub-unit) with PER sub-units per segment; false when u is past the last unit
-template <int PER>
-__device__ __forceinline__ bool seg_unit(int u, SegUnit& q) {
-    const int n0 = s_nseg[0], n1 = s_nseg[1], n2 = s_nseg[2], n3 = s_nseg[3];
-    int l = u / PER;
-    q.sub = u - PER * l;
-    if (l >= n0 + n1 + n2 + n3) return false;
-    int w = 0;
-    if (l >= n0) { l -= n0; w = 1; if (l >= n1) { l -= n1; w = 2; if (l >= n2) { l -= n2; w = 3; } } }
-    const int e = s_seg[w * 64 + l];
-    q.start = e & 255; q.len = (e >> 8) & 255; q.lb = e >> 16;
-    return true;
-}
-
-// phase A of P2G for one in-tile particle.  P2G's records are 22-float structs (88 B) laid out for 8-byte reads:
-//   [wz0 wz1 | wz2 m | mv0 mv1 | mv2 A00 | A01 A02 | A10 A11 | A12 A20 | A21 A22 | wx0 wx1 | wx2 wy0 | wy1 wy2]
-#define PREC 22
-__device__ __forceinline__ void p2g_pay(const P2GPrep& q, int t) {
-    asm volatile("" : "+v"(t));
-    float2* r = (float2*)(s_pay + PREC * t);
+// tile path, executed by ALL lanes of the wave: contributions of lanes with `in_tile` are summed over runs of equal
+// stencil base (seg_scan) and the last lane of each run adds the total into the fp64 LDS accumulators
+__device__ __forceinline__ void p2g_scatter_tile(const SimP& S, const P2GPrep& q, bool in_tile, int lb) {
+    const SegScan sc = seg_setup(in_tile ? lb : (0x40000000 | (int)threadIdx.x));
+    const bool issue = sc.tail && in_tile;
+    const float live = in_tile ? 1.f : 0.f;
     const Stencil& st = q.st;
-    r[0] = make_float2(st.w[0][2], st.w[1][2]); r[1] = make_float2(st.w[2][2], q.m);
-    r[2] = make_float2(q.mv[0], q.mv[1]); r[3] = make_float2(q.mv[2], q.affine.a[0][0]);
-    r[4] = make_float2(q.affine.a[0][1], q.affine.a[0][2]); r[5] = make_float2(q.affine.a[1][0], q.affine.a[1][1]);
-    r[6] = make_float2(q.affine.a[1][2], q.affine.a[2][0]); r[7] = make_float2(q.affine.a[2][1], q.affine.a[2][2]);
-    r[8] = make_float2(st.w[0][0], st.w[1][0]); r[9] = make_float2(st.w[2][0], st.w[0][1]); r[10] = make_float2(st.w[1][1], st.w[2][1]);
-}
-// phases B + C of P2G (all threads of the workgroup, after a barrier): one lane per (segment, i, j) column of 3 nodes.  Nine
-// lanes per segment read every record nine times (same address: a broadcast, but still an LDS cycle each), which is what this phase
-// is bound by -- hence the struct layout: 8 ds_read_b64 + 2 ds_read_b32 per record and lane.  (Three lanes per segment with 3 x 3
-// nodes each, as in g2p's adjoint, need 36 accumulators: this kernel then spills in its per-particle phase.)
-__device__ __forceinline__ void p2g_columns(const SimP& S) {
-    for (int u = threadIdx.x; ; u += WG) {
-        SegUnit q;
-        if (!seg_unit<9>(u, q)) break;
-        const int i = q.sub / 3, j = q.sub - 3 * i;
+#pragma unroll 1
+    for (int ij = 0; ij < 9; ij++) {
+        const int i = ij / 3, j = ij - 3 * i;
+        const float wij = live * STW(st, i, 0) * STW(st, j, 1);
         const float ox = (float)i * S.dx, oy = (float)j * S.dx;
-        float acc[3][4];
+        float mij[3];
 #pragma unroll
-        for (int kk = 0; kk < 3; kk++)
+        for (int a = 0; a < 3; a++) mij[a] = q.mv[a] + q.affine.a[a][0] * ox + q.affine.a[a][1] * oy;
 #pragma unroll
-            for (int a = 0; a < 4; a++) acc[kk][a] = 0.f;
-        for (int t = q.start; t < q.start + q.len; t++) {
-            const float* rec = s_pay + PREC * t;
-            const float2* r = (const float2*)rec;
-            const float2 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3], r4 = r[4], r5 = r[5], r6 = r[6], r7 = r[7];
-            const float wij = rec[16 + i] * rec[19 + j];
-            const float wz[3] = {r0.x, r0.y, r1.x};
-            const float m = r1.y;
-            const float mij[3] = {r2.x + r3.y * ox + r4.x * oy, r2.y + r5.x * ox + r5.y * oy, r3.x + r6.y * ox + r7.x * oy};
-            const float az[3] = {r4.y * S.dx, r6.x * S.dx, r7.y * S.dx};
+        for (int kk = 0; kk < 3; kk++) {
+            const float weight = wij * st.w[kk][2];
+            const float oz = (float)kk * S.dx;
+            const int l = lb + (i * TILE_T + j) * TILE_T + kk;
+            float c[4];
 #pragma unroll
-            for (int kk = 0; kk < 3; kk++) {
-                const float weight = wij * wz[kk];
+            for (int a = 0; a < 3; a++) c[a] = weight * (mij[a] + q.affine.a[a][2] * oz);
+            c[3] = weight * q.m;
+            seg_scan4(sc, c[0], c[1], c[2], c[3]);
+            if (issue) {
 #pragma unroll
-                for (int a = 0; a < 3; a++) acc[kk][a] += weight * (kk == 0 ? mij[a] : mij[a] + az[a] * (float)kk);
-                acc[kk][3] += weight * m;
+                for (int a = 0; a < 4; a++) atomicAdd(&s_acc[a * TILE_N + l], (double)c[a]);            // ds_add_f64
             }
         }
-        const int l = q.lb + (i * TILE_T + j) * TILE_T;
-#pragma unroll
-        for (int kk = 0; kk < 3; kk++)
-#pragma unroll
-            for (int a = 0; a < 4; a++) atomicAdd(&s_acc[a * TILE_N + l + kk], (double)acc[kk][a]);            // ds_add_f64
     }
 }
 
@@ -486,47 +478,36 @@ __global__ __launch_bounds__(WG, GENERAL ? 2 : 4) void k_p2g(SimP S, float* fr_c
             const TileO to = tile_origin(it.x, S.nb);
             TL(S, 1);
             for (int l = tid; l < 4 * TILE_N; l += WG) s_acc[l] = 0.0;
-            for (int i0 = 0; i0 < it.z; i0 += WG) {              // uniform trip count: the segment list needs every lane
-                const int i = i0 + tid;
+            __syncthreads();
+            for (int i0 = 0; i0 < it.z; i0 += WG) {              // uniform trip count: the DPP scan needs every lane
+                const int i = i0 + tid, s = it.y + i;
                 const bool has = i < it.z;
-                const int s = it.y + (has ? i : 0);                // (a lane without a slot looks at the item's first one)
-                // (`used` is re-read rather than implied by the work list so host edits of a frame cannot desynchronise it.)  The
-                // particle's state is requested together with the flag, not after it: one memory round trip instead of two.
-                const int u = cur.used[s];
-                P2GRaw raw;
-                p2g_load(cur, s, T.info, raw);
-                bool used = has && u != 0;
+                // (`used` is re-read rather than implied by the work list so host edits of a frame cannot desynchronise it)
+                bool used = has && cur.used[s] != 0;
                 bool taken = false;
                 if (WRITE && used && act && agent.collector) { taken = collector_takes(cur, nxt, s, T.info, agent); used = !taken; }
                 P2GPrep q;
                 q.inside = false;
                 int lb = -1;
                 if (used) {
-                    p2g_compute<WRITE, GENERAL>(S, nxt, s, raw, G, q);
+                    p2g_prepare<WRITE, GENERAL>(S, cur, nxt, s, T.info, G, q);
                     if (q.inside) lb = tile_base(to, q.st);
+                } else {
+                    q.m = 0.f; q.affine = m3_zero(); q.mv[0] = q.mv[1] = q.mv[2] = 0.f;
+                    float zero[3] = {0.f, 0.f, 0.f};
+                    stencil_make(zero, S.inv_dx, q.st);
                 }
                 TL(S, 2);
-                if (lb >= 0) p2g_pay(q, tid);
-                seg_list(lb, tid);
-                const bool drifted = used && q.inside && lb < 0;            // out of the tile: global path, after the fast path
-                const bool idle = has && !used && !taken && WRITE;          // an unused slot inside an item (host edits, the collector)
-                __syncthreads();
-                TL(S, 3);
-                p2g_columns(S);
-                TL(S, 4);
-                __syncthreads();
-                TL(S, 5);
-                // Rare, and kept out of the region above on purpose: inlined between the record write and the barrier, the 27-node
-                // global scatter set the register budget of the whole kernel (spills in the fast path).  The particle is prepared
-                // again (F' is already stored).
-                if (idle) unused_particle_fwd(S, cur, nxt, s, T.pid_of_slot[s], pool_idx, agent, inj, f);
-                if (drifted) {
-                    atomicAdd(G.slow, 1);
-                    P2GPrep q2;
-                    p2g_prepare<false, GENERAL>(S, cur, nxt, s, T.info, G, q2);
-                    p2g_scatter_global(S, q2, G);
-                }
+                const bool in_tile = lb >= 0;
+                // a wave without any particle (items hold <= item_max particles, the workgroup always has 4 waves) skips
+                // the 27-node scan altogether; the branch is wave-uniform, as the DPP scan requires
+                if (__any(in_tile)) p2g_scatter_tile(S, q, in_tile, in_tile ? lb : 0);
+                if (used && q.inside && !in_tile) { atomicAdd(G.slow, 1); p2g_scatter_global(S, q, G); }   // drifted out of the tile
+                if (has && !used && !taken && WRITE) unused_particle_fwd(S, cur, nxt, s, T.pid_of_slot[s], pool_idx, agent, inj, f);
             }
+            TL(S, 4);
+            __syncthreads();
+            TL(S, 5);
             // hand the tile over: plain coalesced float4 stores into this item's slab.  No atomics, no waiting:
             // k_grid sums, per node, the slabs of the (at most 8) blocks whose tiles reach it, in a fixed order.
             for (int l = tid; l < TILE_N; l += WG)
@@ -854,16 +835,20 @@ __device__ __forceinline__ float4 vout_at(const SimP& S, const VoutSrc& V, int i
     return slot >= 0 ? V.store[(size_t)slot * 128 + 64 + (((i & 3) << 4) | ((j & 3) << 2) | (k & 3))] : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-// advect_kernel.grad + g2p.grad (mpm:443, 538) for one used particle: leaves the position adjoint (so far) in Gc.A0.xyz and
-// scatters d/d(v_out).  TILE: v_out is read from the LDS tile G2_TILE and the scatter is deferred to g2p_grad_columns -- this lane
-// only writes its record (planes 9..11 q at the stencil base, 12..20 c4 * gC) into slot t of s_pay.  !TILE: global atomics.
+// advect_kernel.grad + g2p.grad (mpm:443, 538) for one used particle: scatters d/d(v_out), leaves the
+// position adjoint (so far) in Gc.A0.xyz.  TILE: v_out read from / d v_out accumulated into LDS (3+3 planes)
+// TILE=true is executed by ALL lanes of the wave (`live` = this lane holds a used particle whose stencil fits the
+// tile); the d v_out contributions are summed over runs of equal stencil base before the LDS atomics (seg_scan).
 // (agent.collide's adjoint has already been folded into Gn's x/v adjoints by k_collide_grad)
-#define G2_TILE ((float*)s_acc)          // k_g2p_grad keeps its v_out tile where the fp64 accumulators go afterwards
 template <bool TILE>
 __device__ __forceinline__ void used_particle_g2p_grad(const SimP& S, const FrameV& Gn, const FrameV& Gc, int s,
-                                                       int lb, const Stencil& st, const VoutSrc& V, float* gg_out, int t) {
+                                                       int lb, const Stencil& st, const VoutSrc& V, float* gg_out,
+                                                       bool live, const SegScan& sc) {
     PState g;                                   // adjoints of x', v', C'
-    load_xvC(Gn, s, g);
+    if (!TILE || live) load_xvC(Gn, s, g);
+    else { g.x[0] = g.x[1] = g.x[2] = g.v[0] = g.v[1] = g.v[2] = 0.f; g.C = m3_zero(); }
+    const bool issue = TILE && sc.tail && live;
+    const float livef = (!TILE || live) ? 1.f : 0.f;
     // x' = x + dt v'  =>  v'_bar += dt x'_bar
     float gv[3] = {g.v[0] + S.dt * g.x[0], g.v[1] + S.dt * g.x[1], g.v[2] + S.dt * g.x[2]};
     const float c4 = 4.f * S.inv_dx;
@@ -876,34 +861,34 @@ __device__ __forceinline__ void used_particle_g2p_grad(const SimP& S, const Fram
         qb[a] = gv[a] - c4 * (g.C.a[a][0] * st.fx[0] + g.C.a[a][1] * st.fx[1] + g.C.a[a][2] * st.fx[2]);
         qz[a] = c4 * g.C.a[a][2];
     }
-    if (TILE) {
-        pay_weights(st, t);
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-            s_pay[(9 + a) * WG + t] = qb[a];
-            s_pay[(12 + a * 3) * WG + t] = c4 * g.C.a[a][0]; s_pay[(13 + a * 3) * WG + t] = c4 * g.C.a[a][1]; s_pay[(14 + a * 3) * WG + t] = qz[a];
-        }
-    }
 #pragma unroll 1
     for (int ij = 0; ij < 9; ij++) {
         const int i = ij / 3, j = ij - 3 * i;
         const float wi = STW(st, i, 0), wj = STW(st, j, 1);
         const float wiwj = wi * wj, dwiwj = stencil_dw(st, i, 0) * wj, widwj = wi * stencil_dw(st, j, 1);
+        const float lw = livef * wiwj;
         float qij[3];
 #pragma unroll
         for (int a = 0; a < 3; a++) qij[a] = qb[a] + c4 * (g.C.a[a][0] * (float)i + g.C.a[a][1] * (float)j);
 #pragma unroll
         for (int kk = 0; kk < 3; kk++) {
             const float wk = st.w[kk][2];
+            const float weight = lw * wk;
             float q[3];
 #pragma unroll
             for (int a = 0; a < 3; a++) q[a] = kk == 0 ? qij[a] : qij[a] + (float)kk * qz[a];
             float v0, v1, v2;
             if (TILE) {
                 const int l = lb + (i * TILE_T + j) * TILE_T + kk;
-                v0 = G2_TILE[l]; v1 = G2_TILE[TILE_N + l]; v2 = G2_TILE[2 * TILE_N + l];
+                v0 = s_tile[l]; v1 = s_tile[TILE_N + l]; v2 = s_tile[2 * TILE_N + l];
+                float c0 = weight * q[0], c1 = weight * q[1], c2 = weight * q[2];
+                seg_scan3(sc, c0, c1, c2);
+                if (issue) {
+                    atomicAdd(&s_acc[l], (double)c0);                         // ds_add_f64
+                    atomicAdd(&s_acc[TILE_N + l], (double)c1);
+                    atomicAdd(&s_acc[2 * TILE_N + l], (double)c2);
+                }
             } else {
-                const float weight = wiwj * wk;
                 const int c = cell_addr(st.base[0] + i, st.base[1] + j, st.base[2] + kk, S.nb);
                 float4 vo = vout_at(S, V, st.base[0] + i, st.base[1] + j, st.base[2] + kk);
                 v0 = vo.x; v1 = vo.y; v2 = vo.z;
@@ -915,65 +900,15 @@ __device__ __forceinline__ void used_particle_g2p_grad(const SimP& S, const Fram
             const float sdot = v0 * q[0] + v1 * q[1] + v2 * q[2];
             const float w3 = wiwj * wk;
             nvw[0] += w3 * v0; nvw[1] += w3 * v1; nvw[2] += w3 * v2;
-            const float tt = wk * sdot;
-            gfx[0] += dwiwj * tt;                              // d weight / d fx_d
-            gfx[1] += widwj * tt;
+            const float t = wk * sdot;
+            gfx[0] += dwiwj * t;                               // d weight / d fx_d
+            gfx[1] += widwj * t;
             gfx[2] += wiwj * (stencil_dw(st, kk, 2) * sdot);
         }
     }
 #pragma unroll
     for (int b = 0; b < 3; b++) gfx[b] -= c4 * (nvw[0] * g.C.a[0][b] + nvw[1] * g.C.a[1][b] + nvw[2] * g.C.a[2][b]);     // dpos_b = o_b - fx_b
-    Gc.A0[s] = make_float4(g.x[0] + S.inv_dx * gfx[0], g.x[1] + S.inv_dx * gfx[1], g.x[2] + S.inv_dx * gfx[2], 0.f);
-}
-// phases B + C of the d v_out scatter (see the transposed scatter above): 3 x 3 nodes x 3 components per (segment, i)
-__device__ __forceinline__ void g2p_grad_columns() {
-    for (int u = threadIdx.x; ; u += WG) {
-        SegUnit q;
-        if (!seg_unit<3>(u, q)) break;
-        const float fi = (float)q.sub;
-        float acc[3][3][3];
-#pragma unroll
-        for (int j = 0; j < 3; j++)
-#pragma unroll
-            for (int kk = 0; kk < 3; kk++)
-#pragma unroll
-                for (int a = 0; a < 3; a++) acc[j][kk][a] = 0.f;
-        for (int t = q.start; t < q.start + q.len; t++) {
-            const float wi = s_pay[q.sub * WG + t];
-            float wz[3], qi[3], qy[3], qz[3];
-#pragma unroll
-            for (int kk = 0; kk < 3; kk++) wz[kk] = s_pay[(6 + kk) * WG + t];
-#pragma unroll
-            for (int a = 0; a < 3; a++) {
-                qi[a] = s_pay[(9 + a) * WG + t] + s_pay[(12 + a * 3) * WG + t] * fi;
-                qy[a] = s_pay[(13 + a * 3) * WG + t];
-                qz[a] = s_pay[(14 + a * 3) * WG + t];
-            }
-#pragma unroll
-            for (int j = 0; j < 3; j++) {
-                const float wij = wi * s_pay[(3 + j) * WG + t];
-                float qij[3];
-#pragma unroll
-                for (int a = 0; a < 3; a++) qij[a] = j == 0 ? qi[a] : qi[a] + qy[a] * (float)j;
-#pragma unroll
-                for (int kk = 0; kk < 3; kk++) {
-                    const float weight = wij * wz[kk];
-#pragma unroll
-                    for (int a = 0; a < 3; a++) acc[j][kk][a] += weight * (kk == 0 ? qij[a] : qij[a] + (float)kk * qz[a]);
-                }
-            }
-        }
-        const int l = q.lb + q.sub * TILE_T * TILE_T;
-#pragma unroll
-        for (int j = 0; j < 3; j++)
-#pragma unroll
-            for (int kk = 0; kk < 3; kk++)
-            {
-#pragma unroll
-                for (int a = 0; a < 3; a++) atomicAdd(&s_acc[a * TILE_N + l + j * TILE_T + kk], (double)acc[j][kk][a]);            // ds_add_f64
-                NODE_FENCE();
-            }
-    }
+    if (!TILE || live) Gc.A0[s] = make_float4(g.x[0] + S.inv_dx * gfx[0], g.x[1] + S.inv_dx * gfx[1], g.x[2] + S.inv_dx * gfx[2], 0.f);
 }
 
 // one slot on the global path (tail / sort_interval = 0)
@@ -985,7 +920,9 @@ __device__ __forceinline__ void g2p_grad_slot_global(const SimP& S, const FrameV
     Stencil st;
     stencil_make(x, S.inv_dx, st);
     if (!stencil_inside(st, S.n)) { float4 gx = Gn.A0[s]; Gc.A0[s] = make_float4(gx.x, gx.y, gx.z, 0.f); return; }
-    used_particle_g2p_grad<false>(S, Gn, Gc, s, 0, st, V, gg_out, 0);
+    SegScan none;
+    none.f1 = none.f2 = none.f4 = none.f8 = none.f15 = none.f31 = 0.f; none.tail = true;
+    used_particle_g2p_grad<false>(S, Gn, Gc, s, 0, st, V, gg_out, true, none);
 }
 
 // workgroup-level flush of s_pose into the effectors' adjoint arrays (call with all threads; contains barriers)
@@ -1007,23 +944,19 @@ __device__ __forceinline__ void pose_flush(const AgentP& agent, int f) {
     __syncthreads();
 }
 
-// v_out of the item's tile into G2_TILE (3 planes), from the working grid or from the forward pass' store
-__device__ __forceinline__ void g2p_grad_load_tile(const TileO& to, const SimP& S, const TableP& T, const float4* __restrict__ g_out,
-                                                   const float4* __restrict__ st, int tid) {
+// same, reading v_out of frame f from the grid store (blocks addressed through the order's blk_slot)
+__device__ __forceinline__ void load_tile3_store(const TileO& to, const SimP& S, const TableP& T, const float4* __restrict__ st, int tid) {
     for (int l = tid; l < TILE_N; l += WG) {
         int i, j, k;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (tile_node(to, l, S.n, i, j, k)) {
-            if (st) {
-                const int slot = T.blk_slot[(((i >> 2) * S.nb) + (j >> 2)) * S.nb + (k >> 2)];
-                if (slot >= 0) v = st[(size_t)slot * 128 + 64 + (((i & 3) << 4) | ((j & 3) << 2) | (k & 3))];
-            } else v = g_out[cell_addr(i, j, k, S.nb)];
+            const int slot = T.blk_slot[(((i >> 2) * S.nb) + (j >> 2)) * S.nb + (k >> 2)];
+            if (slot >= 0) v = st[(size_t)slot * 128 + 64 + (((i & 3) << 4) | ((j & 3) << 2) | (k & 3))];
         }
-        G2_TILE[l] = v.x; G2_TILE[TILE_N + l] = v.y; G2_TILE[2 * TILE_N + l] = v.z;
+        s_tile[l] = v.x; s_tile[TILE_N + l] = v.y; s_tile[2 * TILE_N + l] = v.z;
     }
 }
-
-__global__ __launch_bounds__(WG, 4) void k_g2p_grad(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T,
+__global__ __launch_bounds__(WG) void k_g2p_grad(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T,
                                                  const float4* __restrict__ g_out, float* gg_out, float4* slab, int* slow,
                                                  GridStore GS, int f, AgentP agent) {
     const int tid = threadIdx.x;
@@ -1041,19 +974,15 @@ __global__ __launch_bounds__(WG, 4) void k_g2p_grad(SimP S, float* fr_cur, float
         if (w < n_items) {
             const int4 it = T.items[w];
             const TileO to = tile_origin(it.x, S.nb);
-            TL(S, 1);
-            // the particle loads go out ahead of the tile load and its barrier (see slot_g2p)
+            // the particle loads go out ahead of the tile load and its barrier (see slot_g2p); items hold <= WG particles
             const int s0 = it.y + (tid < it.z ? tid : 0);
             int u0 = cur.used[s0];
             float4 a00 = cur.A0[s0];
-            // The v_out tile and the fp64 accumulators share LDS (they are never live together): gather + records first, then
-            // the tile is zeroed into accumulators.  Items of more than WG particles (item_max > 256) accumulate pass by pass in
-            // the global grid instead of re-loading the tile: rare, and only a question of speed.
-            g2p_grad_load_tile(to, S, T, g_out, V.store, tid);
+            if (stored) load_tile3_store(to, S, T, GS.data + (size_t)f * GS.cap * 128, tid); else load_tile3(to, S, g_out, tid);
+            for (int l = tid; l < 3 * TILE_N; l += WG) s_acc[l] = 0.0;
             __syncthreads();
             TL(S, 2);
-            const bool one_pass = it.z <= WG;
-            for (int i0 = 0; i0 < it.z; i0 += WG) {              // uniform trip count: the segment list needs every lane
+            for (int i0 = 0; i0 < it.z; i0 += WG) {              // uniform trip count: the DPP scan needs every lane
                 const int i = i0 + tid, s = it.y + i;
                 if (i0 > 0 && i < it.z) { u0 = cur.used[s]; a00 = cur.A0[s]; }
                 const bool used = i < it.z && u0 != 0;
@@ -1062,20 +991,17 @@ __global__ __launch_bounds__(WG, 4) void k_g2p_grad(SimP S, float* fr_cur, float
                 Stencil st;
                 stencil_make(x, S.inv_dx, st);
                 const bool inside = used && stencil_inside(st, S.n);
-                const int lb = (inside && one_pass) ? tile_base(to, st) : -1;
-                if (lb >= 0) used_particle_g2p_grad<true>(S, Gn, Gc, s, lb, st, V, gg_out, tid);
-                seg_list(lb, tid);
-                if (used && lb < 0) {
+                const int lb = inside ? tile_base(to, st) : -1;
+                const bool live = lb >= 0;
+                if (__any(live)) {                               // wave-uniform: empty waves skip the scan
+                    const SegScan sc = seg_setup(live ? lb : (0x40000000 | tid));
+                    used_particle_g2p_grad<true>(S, Gn, Gc, s, live ? lb : 0, st, V, gg_out, live, sc);
+                }
+                if (used && !live) {
                     if (inside) atomicAdd(slow, 1);
                     g2p_grad_slot_global(S, cur, Gn, Gc, s, V, gg_out, agent, f);
                 }
             }
-            TL(S, 3);
-            __syncthreads();                                     // every lane is done with the v_out tile
-            for (int l = tid; l < 3 * TILE_N; l += WG) s_acc[l] = 0.0;
-            __syncthreads();
-            TL(S, 4);
-            if (one_pass) g2p_grad_columns();
             TL(S, 5);
             __syncthreads();
             TL(S, 6);
@@ -1349,8 +1275,8 @@ __device__ void effector_move_grad(const EffP& e, int f) {
 // What the constitutive adjoint needs again after the 27-node loop -- C, F and, in the SVD build, U, V, sigma, J -- waits in LDS
 // (s_stash, one column per thread) instead of in registers: round 1 re-read C and F from the frame (72 B per particle of extra
 // HBM traffic) and re-ran the constitutive model, and the SVD build kept everything live (256 + 32 VGPRs, one wave per SIMD).
-#define STASH_GENERAL 40
-#define STASH_LIQUID 18
+#define STASH_GENERAL 52
+#define STASH_LIQUID 30
 template <bool GENERAL> struct Stash { static __device__ __forceinline__ float* at(); };
 __shared__ float s_stash_g[STASH_GENERAL * WG];
 __shared__ float s_stash_l[STASH_LIQUID * WG];
@@ -1364,6 +1290,10 @@ __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const Fram
     load_xvC(cur, s, p);
     load_F(cur, s, p.F);
     PInfo info = load_info(info_, s);
+    // what is only needed behind the 27-node loop is requested now as well (one memory round trip for the whole particle) and
+    // waits in the stash: d/d F[f+1] and the position adjoint k_g2p_grad left in Gc
+    m3 Fg; load_F(Gn, s, Fg);
+    const float4 gc0 = Gc.A0[s];
     Constitutive k;
     constitutive_eval_t<GENERAL>(p.C, p.F, S.dt, info.mu, info.lam, info.mass, info.cls, S.stress_scale, k);
     Stencil st;
@@ -1386,6 +1316,12 @@ __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const Fram
                 if (GENERAL) { stash[(18 + a * 3 + b) * WG + col] = k.U.a[a][b]; stash[(27 + a * 3 + b) * WG + col] = k.V.a[a][b]; }
             }
         if (GENERAL) { stash[36 * WG + col] = k.sig[0]; stash[37 * WG + col] = k.sig[1]; stash[38 * WG + col] = k.sig[2]; stash[39 * WG + col] = k.J; }
+        const int o = GENERAL ? 40 : 18;
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) stash[(o + a * 3 + b) * WG + col] = Fg.a[a][b];
+        stash[(o + 9) * WG + col] = gc0.x; stash[(o + 10) * WG + col] = gc0.y; stash[(o + 11) * WG + col] = gc0.z;
     }
     float Gv[3] = {0.f, 0.f, 0.f};
     m3 GA = m3_zero();
@@ -1474,12 +1410,20 @@ __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const Fram
         k.Ft = m3_mul(IdtC, p.F);
         if (!GENERAL) k.J = m3_det(k.Ft);
     }
-    m3 Fg; load_F(Gn, s, Fg);
-    float4 gc0 = Gc.A0[s];                      // position adjoint so far (k_g2p_grad)
-    float gx[3] = {gc0.x + gxs[0], gc0.y + gxs[1], gc0.z + gxs[2]};
+    m3 Fg2;
+    float gx[3];
+    {
+        const int o = GENERAL ? 40 : 18;
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) Fg2.a[a][b] = stash[(o + a * 3 + b) * WG + col];
+#pragma unroll
+        for (int d = 0; d < 3; d++) gx[d] = stash[(o + 9 + d) * WG + col] + gxs[d];      // position adjoint so far (k_g2p_grad) + this kernel's part
+    }
     float gvv[3] = {info.mass * Gv[0], info.mass * Gv[1], info.mass * Gv[2]};
     m3 gC, gF;
-    constitutive_grad_t<GENERAL>(p.C, p.F, S.dt, info.mu, info.lam, info.mass, info.cls, S.stress_scale, k, GA, Fg, gC, gF);
+    constitutive_grad_t<GENERAL>(p.C, p.F, S.dt, info.mu, info.lam, info.mass, info.cls, S.stress_scale, k, GA, Fg2, gC, gF);
     store_xvC(Gc, s, gx, gvv, gC);
     store_F(Gc, s, gF);
 }
@@ -1563,7 +1507,7 @@ __global__ __launch_bounds__(WG, MINW) void k_p2g_grad(SimP S, float* fr_cur, fl
 // histogram + rank.  Keys of one workgroup's 256 slots are nearly always within a narrow range (the previous
 // order was sorted too), so ranks come from an LDS histogram (ds_add_rtn_u32) and only one global atomic per
 // distinct key per workgroup is issued; keys outside the window fall back to a global atomic.
-__global__ __launch_bounds__(256) void k_sort_count(SimP S, float* fr, int* key, int* rank, int* cnt) {
+__global__ __launch_bounds__(256) void k_sort_count(SimP S, float* fr, int* key, int* rank, int* cnt, int* bflag) {
     __shared__ int hist[SORT_HB + 1];       // + the sentinel's slot
     __shared__ int kmin;
     const int tid = threadIdx.x;
@@ -1594,9 +1538,13 @@ __global__ __launch_bounds__(256) void k_sort_count(SimP S, float* fr, int* key,
     const bool local = valid && rel <= SORT_HB && (is_tail || rel < SORT_HB);
     int r = 0;
     if (local) r = atomicAdd(&hist[rel], 1);
-    else if (valid) r = atomicAdd(&cnt[kk], 1);
+    else if (valid) { r = atomicAdd(&cnt[kk], 1); bflag[kk >> 6] = 1; }
     __syncthreads();
-    for (int l = tid; l <= SORT_HB; l += 256) { int c = hist[l]; if (c > 0) hist[l] = atomicAdd(&cnt[l == SORT_HB ? S.ncell : kmin + l], c); }
+    // bflag[b] = 1: block b (index nblk: the tail sentinel) has particles -- the scan kernels only touch the cells of such blocks
+    for (int l = tid; l <= SORT_HB; l += 256) {
+        int c = hist[l];
+        if (c > 0) { const int cell = l == SORT_HB ? S.ncell : kmin + l; hist[l] = atomicAdd(&cnt[cell], c); bflag[cell >> 6] = 1; }
+    }
     __syncthreads();
     if (local) r += hist[rel];
     if (valid) { key[s] = kk; rank[s] = r; }
@@ -1620,14 +1568,16 @@ __device__ __forceinline__ int wg_scan_excl(int v, int* sh, int tid, int& total)
     return off + incl - v;
 }
 
-// per-thread sum of its 4 histogram entries, and (threads 0..15) the particle count of block wg*16+t
-__device__ __forceinline__ int scan_load(int ncell, const int* cnt, int tid, int c[4], int* sh_sum, int& blk_cnt) {
+// per-thread sum of its 4 histogram entries, and (threads 0..15) the particle count of block wg*16+t.  The histogram has n^3 + 1
+// entries, nearly all of them empty: only the cells of blocks flagged by k_sort_count are read (and, in k_scan_final, written).
+__device__ __forceinline__ int scan_load(int ncell, const int* cnt, const int* bflag, int tid, int c[4], int* sh_sum, int& blk_cnt, bool& live) {
     const int b0 = blockIdx.x * 1024 + tid * 4;
+    live = b0 <= ncell && bflag[b0 >> 6] != 0;
     int sp = 0, sb = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
         const int b = b0 + q;
-        c[q] = b <= ncell ? cnt[b] : 0;
+        c[q] = (live && b <= ncell) ? cnt[b] : 0;
         sp += c[q];
         if (b < ncell) sb += c[q];
     }
@@ -1639,12 +1589,13 @@ __device__ __forceinline__ int scan_load(int ncell, const int* cnt, int tid, int
     return sp;
 }
 
-__global__ __launch_bounds__(256) void k_scan_partial(int ncell, int ITEM_MAX, const int* __restrict__ cnt, int2* partial) {
+__global__ __launch_bounds__(256) void k_scan_partial(int ncell, int ITEM_MAX, const int* __restrict__ cnt, const int* __restrict__ bflag, int2* partial) {
     __shared__ int sh[4];
     __shared__ int sh_sum[256];
     const int tid = threadIdx.x;
     int c[4], blk_cnt;
-    const int sp = scan_load(ncell, cnt, tid, c, sh_sum, blk_cnt);
+    bool live;
+    const int sp = scan_load(ncell, cnt, bflag, tid, c, sh_sum, blk_cnt, live);
     const int si = tid < 16 ? (blk_cnt + ITEM_MAX - 1) / ITEM_MAX : 0;
     int tp, ti;
     wg_scan_excl(sp, sh, tid, tp);
@@ -1652,7 +1603,7 @@ __global__ __launch_bounds__(256) void k_scan_partial(int ncell, int ITEM_MAX, c
     if (tid == 0) partial[blockIdx.x] = make_int2(tp, ti);
 }
 
-__global__ __launch_bounds__(256) void k_scan_final(int ncell, int ITEM_MAX, int* cnt, const int2* __restrict__ partial, int* start, int4* items, int* meta, int2* blk_first) {
+__global__ __launch_bounds__(256) void k_scan_final(int ncell, int ITEM_MAX, int* cnt, int* bflag, const int2* __restrict__ partial, int* start, int4* items, int* meta, int2* blk_first) {
     __shared__ int sh[4];
     __shared__ int sh_sum[256];
     __shared__ int sh_bp[256];
@@ -1663,7 +1614,8 @@ __global__ __launch_bounds__(256) void k_scan_final(int ncell, int ITEM_MAX, int
     wg_scan_excl(pp, sh, tid, base_p);
     wg_scan_excl(pi, sh, tid, base_i);
     int c[4], blk_cnt;
-    const int sp = scan_load(ncell, cnt, tid, c, sh_sum, blk_cnt);
+    bool live;
+    const int sp = scan_load(ncell, cnt, bflag, tid, c, sh_sum, blk_cnt, live);
     const int si = tid < 16 ? (blk_cnt + ITEM_MAX - 1) / ITEM_MAX : 0;
     int toti;
     int bp = base_p + wg_scan_excl(sp, sh, tid, dummy);
@@ -1680,11 +1632,14 @@ __global__ __launch_bounds__(256) void k_scan_final(int ncell, int ITEM_MAX, int
     for (int q = 0; q < 4; q++) {
         const int b = b0 + q;
         if (b > ncell) break;
-        start[b] = bp;
         if (b == ncell) meta[1] = bp;                         // first tail slot
-        bp += c[q];
-        cnt[b] = 0;                                           // ready for the next sort
+        if (live) {
+            start[b] = bp;
+            bp += c[q];
+            cnt[b] = 0;                                       // ready for the next sort
+        }
     }
+    if (live && (tid & 15) == 0) bflag[b0 >> 6] = 0;         // (this workgroup was the flag's only reader in this launch)
     if (blockIdx.x == gridDim.x - 1 && tid == 0) { meta[0] = base_i + toti; meta[2] = 0; }
 }
 
@@ -1711,17 +1666,25 @@ __global__ __launch_bounds__(256) void k_set_static(const int* __restrict__ acti
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) blk_flag[active[i]] = value;
 }
 
-__global__ __launch_bounds__(256) void k_sort_perm(int N, const int* __restrict__ key, const int* __restrict__ rank,
-                                                   const int* __restrict__ start, const int* __restrict__ pid_old, int* src, int* pid_new, int* slot_of_pid,
-                                                   const float4* __restrict__ pinfo, float4* info_new) {
+// The permutation itself, one pass: slot s of the old order goes to d = start[key] + rank -- its particle id, material record and
+// all 25 planes.  Reads are coalesced, writes land near s (the old order was sorted too: particles move less than a cell between
+// sorts), so the write combining of the L2 sees them almost in order.  (Round 1: index kernel, copy of the id table, gather kernel.)
+__global__ __launch_bounds__(256) void k_sort_apply(int N, size_t Np, const int* __restrict__ key, const int* __restrict__ rank,
+                                                    const int* __restrict__ start, const int* __restrict__ pid_old, int* pid_new, int* slot_of_pid,
+                                                    const float4* __restrict__ pinfo, float4* info_new, float* dst_, float* src_) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= N) return;
     const int d = start[key[s]] + rank[s];
     const int pid = pid_old[s];
-    src[d] = s;
+    FrameV q = frame_view(src_, Np), o = frame_view(dst_, Np);
+    const float4 a0 = q.A0[s], a1 = q.A1[s], a2 = q.A2[s], b0 = q.B0[s], b1 = q.B1[s];
+    const float a3 = q.a3[s], a4 = q.a4[s], a5 = q.a5[s], b2 = q.b2[s];
+    const int u = q.used[s];
     pid_new[d] = pid;
     info_new[d] = pinfo[pid];                                  // the order's slot-indexed material record (TableP::info)
     slot_of_pid[pid] = d;
+    o.A0[d] = a0; o.A1[d] = a1; o.A2[d] = a2; o.a3[d] = a3; o.a4[d] = a4; o.a5[d] = a5;
+    o.B0[d] = b0; o.B1[d] = b1; o.b2[d] = b2; o.used[d] = u;
 }
 
 // dst[s] = src[idx[s]] over all 24 planes (+ used when WITH_USED): coalesced writes, gathered 16-byte reads
@@ -2136,7 +2099,7 @@ struct FeEngine {
     int item_max = 256;                                     // particles per work item (<= ITEM_MAX_CAP)
     int sort_interval = 10;                                 // K: re-sort every K substeps (0 = never: global path only)
     size_t items_cap = 0;
-    int *sort_key = nullptr, *sort_rank = nullptr, *sort_cnt = nullptr, *sort_start = nullptr, *sort_src = nullptr, *sort_pid = nullptr;
+    int *sort_key = nullptr, *sort_rank = nullptr, *sort_cnt = nullptr, *sort_start = nullptr, *sort_pid = nullptr, *sort_bflag = nullptr;
     int* slow_dev = nullptr;
     int* frame_slow_dev = nullptr;                          // set by a slow-path scatter of the current forward substep
     int2* sort_partial = nullptr;
@@ -2353,19 +2316,20 @@ int sort_frame(FeEngine* h, int f) {
     use_static_table(h, 0);                          // un-flag the previous order before its lists are rebuilt
     if (fine) prof_begin(h, KID_SORT_COUNT);
     hipLaunchKernelGGL(k_clear_slots, dim3(64), dim3(256), 0, h->stream, tn.active, tn.meta, tn.blk_slot);
-    hipLaunchKernelGGL(k_sort_count, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->sort_key, h->sort_rank, h->sort_cnt);
+    hipLaunchKernelGGL(k_sort_count, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->sort_key, h->sort_rank, h->sort_cnt, h->sort_bflag);
     if (fine) { prof_end(h); prof_begin(h, KID_SORT_SCAN); }
     const int scan_wgs = (ncell + 1 + 1023) / 1024;
-    hipLaunchKernelGGL(k_scan_partial, dim3(scan_wgs), dim3(256), 0, h->stream, ncell, h->item_max, h->sort_cnt, h->sort_partial);
-    hipLaunchKernelGGL(k_scan_final, dim3(scan_wgs), dim3(256), 0, h->stream, ncell, h->item_max, h->sort_cnt, h->sort_partial, h->sort_start, tn.items, tn.meta, tn.blk_first);
+    hipLaunchKernelGGL(k_scan_partial, dim3(scan_wgs), dim3(256), 0, h->stream, ncell, h->item_max, h->sort_cnt, h->sort_bflag, h->sort_partial);
+    hipLaunchKernelGGL(k_scan_final, dim3(scan_wgs), dim3(256), 0, h->stream, ncell, h->item_max, h->sort_cnt, h->sort_bflag, h->sort_partial, h->sort_start, tn.items, tn.meta, tn.blk_first);
     if (fine) { prof_end(h); prof_begin(h, KID_SORT_ACTIVE); }
     hipLaunchKernelGGL(k_build_active, dim3(256), dim3(256), 0, h->stream, h->nb, tn.items, tn.meta, h->blk_flag, tn.active, tn.blk_slot);
     h->static_table = id_new;
     if (fine) { prof_end(h); prof_begin(h, KID_SORT_PERM); }
-    hipLaunchKernelGGL(k_sort_perm, pgrid(h), dim3(256), 0, h->stream, h->N, h->sort_key, h->sort_rank, h->sort_start,
-                       h->tables[id_old].pid, h->sort_src, h->sort_pid, tn.slot_of_pid, h->pinfo, tn.info);
-    HIPCK(h, hipMemcpyAsync(tn.pid, h->sort_pid, sizeof(int) * h->Np, hipMemcpyDeviceToDevice, h->stream));
-    hipLaunchKernelGGL(k_perm_gather<true>, pgrid(h), dim3(256), 0, h->stream, h->N, (size_t)h->Np, h->spare_frame(), h->frame(f), h->sort_src);
+    // re-sorting a frame that is already in this table's order reads the id table it rewrites: stage it
+    int* pid_dst = id_old == id_new ? h->sort_pid : tn.pid;
+    hipLaunchKernelGGL(k_sort_apply, pgrid(h), dim3(256), 0, h->stream, h->N, (size_t)h->Np, h->sort_key, h->sort_rank, h->sort_start,
+                       h->tables[id_old].pid, pid_dst, tn.slot_of_pid, h->pinfo, tn.info, h->spare_frame(), h->frame(f));
+    if (id_old == id_new) HIPCK(h, hipMemcpyAsync(tn.pid, h->sort_pid, sizeof(int) * h->Np, hipMemcpyDeviceToDevice, h->stream));
     prof_end(h);
     std::swap(h->frame_ptr[f], h->spare_frame());
     h->tbl_of_frame[f] = id_new;
@@ -2590,7 +2554,7 @@ FeEngine* fe_create(const FeConfig* cfg) {
         const size_t nblk = (size_t)h->nb * h->nb * h->nb;
         h->items_cap = (nblk < (size_t)h->Np ? nblk : (size_t)h->Np) + (size_t)h->Np / 64 + 2;      // item_max >= 64
         if (dev_alloc(h, &h->sort_key, h->Np) || dev_alloc(h, &h->sort_rank, h->Np) || dev_alloc(h, &h->sort_cnt, ncell + 1) ||
-            dev_alloc(h, &h->sort_start, ncell + 1) || dev_alloc(h, &h->sort_src, h->Np) || dev_alloc(h, &h->sort_pid, h->Np) ||
+            dev_alloc(h, &h->sort_start, ncell + 1) || dev_alloc(h, &h->sort_bflag, ncell / 64 + 2) || dev_alloc(h, &h->sort_pid, h->Np) ||
             dev_alloc(h, &h->slow_dev, 1) || dev_alloc(h, &h->frame_slow_dev, 1) || dev_alloc(h, &h->slab, h->items_cap * TILE_N, false) || dev_alloc(h, &h->sort_partial, (ncell + 1 + 1023) / 1024 + 1)) return fail("");
     }
     if (dev_alloc(h, &h->effs_dev, FE_MAX_EFF)) return fail("");
@@ -2627,7 +2591,7 @@ void fe_destroy(FeEngine* h) {
     smoke_destroy(h);
     for (auto& t : h->tables) { if (t.info && t.info != h->pinfo) (void)hipFree(t.info);
         for (void* q : {(void*)t.pid, (void*)t.items, (void*)t.meta, (void*)t.blk_first, (void*)t.active, (void*)t.blk_slot, (void*)t.slot_of_pid}) if (q) (void)hipFree(q); }
-    void* ptrs[] = {h->frames, h->grads, h->sort_key, h->sort_rank, h->sort_cnt, h->sort_start, h->sort_src, h->sort_pid, h->slow_dev, h->frame_slow_dev, h->gstore, h->gs_flag, h->slab, h->sort_partial, h->effs_dev, h->pinfo, h->pool_idx, h->g_in, h->g_out, h->gg_out, h->gg_in,
+    void* ptrs[] = {h->frames, h->grads, h->sort_key, h->sort_rank, h->sort_cnt, h->sort_start, h->sort_bflag, h->sort_pid, h->slow_dev, h->frame_slow_dev, h->gstore, h->gs_flag, h->slab, h->sort_partial, h->effs_dev, h->pinfo, h->pool_idx, h->g_in, h->g_out, h->gg_out, h->gg_in,
                     h->blk_flag, h->blk_list, h->blk_count, h->err_dev, h->stage_r, h->stage_i, h->node_mark, h->counters,
                     h->tgt, h->chamfer, h->step_loss, h->body_start, h->body_pids, h->bodies_dev, h->statics_dev, h->collector_dev, h->hit_dev, h->hit_list, h->hit_count, h->node_work, h->node_work_count};
     for (float* v : h->statics_vox) if (v) (void)hipFree(v);

@@ -64,9 +64,15 @@ class Effector:
 
     @property
     def latest_pos(self):
-        """effector.py:149-151 keeps pos[f] of the last move() in a 1-element field for the renderer; GatheringPolicy reads it
-        (policies.py:240).  Served from the engine: the pose at the simulator's current local substep."""
-        pos = self.engine.eff_get_state(self.index, self.sim.cur_substep_local)[:3]
+        """effector.py:146-152: `move(f)` stores pos[f] -- the pose at the START of the last substep that moved the effector -- in a
+        1-element field for the renderer; the Gathering / Mixing policies steer by it (policies.py:240, 327).  Served from the
+        engine: the simulator remembers the local frame of the last move (None before the first one: the current pose, which is
+        what the field holds after apply_action_p in this package).  A frame that old survives until the window has gone round
+        once more; policies read the value right after the step that moved."""
+        f = getattr(self.sim, 'last_move_f', None)
+        if f is None:
+            f = self.sim.cur_substep_local
+        pos = self.engine.eff_get_state(self.index, f)[:3]
         return _Field1(np.asarray(pos, np.float32)[None, :])
 
     # ---- state (effector.py:185-208)

@@ -161,10 +161,12 @@ class MPMSimulator:
     def enable_grad(self):
         self.grad_enabled = True
         self.cur_substep_global = 0
+        self.last_move_f = None
 
     def disable_grad(self):
         self.grad_enabled = False
         self.cur_substep_global = 0
+        self.last_move_f = None
 
     # ------------------------------------------------------------------ time indexing, mpm:225-252
     def f_global_to_f_local(self, f_global):
@@ -216,6 +218,8 @@ class MPMSimulator:
         if self.smoke_field is not None:                    # smoke simulates at step level, not substep (mpm:744-747)
             self.smoke_field.step(s=self.cur_step_local, f=self.cur_substep_local)
         self.engine.step(self.cur_substep_local, self.cur_substep_global, self.n_substeps, not is_none_action)
+        if not is_none_action:
+            self.last_move_f = self.cur_substep_local + self.n_substeps - 1        # Effector.latest_pos (effector.py:146-152)
         self.cur_substep_global += self.n_substeps
         assert self.cur_substep_global <= self.max_substeps_global
 
@@ -247,9 +251,10 @@ class MPMSimulator:
                     import torch
                     dev = torch.device('cuda', self._device)
                     N = self.n_particles
-                    st = dict(x=torch.zeros((N, 3), dtype=torch.float32, device=dev), v=torch.zeros((N, 3), dtype=torch.float32, device=dev),
-                              C=torch.zeros((N, 3, 3), dtype=torch.float32, device=dev), F=torch.zeros((N, 3, 3), dtype=torch.float32, device=dev),
-                              used=torch.zeros((N,), dtype=torch.int32, device=dev))
+                    # (empty, not zeros: the engine fills every element, and get_frame_dev fences torch's stream before it does)
+                    st = dict(x=torch.empty((N, 3), dtype=torch.float32, device=dev), v=torch.empty((N, 3), dtype=torch.float32, device=dev),
+                              C=torch.empty((N, 3, 3), dtype=torch.float32, device=dev), F=torch.empty((N, 3, 3), dtype=torch.float32, device=dev),
+                              used=torch.empty((N,), dtype=torch.int32, device=dev))
                     self.readframe(0, st['x'], st['v'], st['C'], st['F'], st['used'])
                     ckpt.update(st)
                 else:

@@ -1,7 +1,7 @@
 """In-kernel phase timeline of the six substep kernels on the benchmark scene (profiling build only).
 
   hipcc ... -DFE_TIMELINE -o fluidlab_amd/csrc/libfluidengine_tl_hip.so   (scripts/build_tl.sh)
-  python scripts/timeline.py [n_grid n_particles]
+  python scripts/timeline.py [n_grid n_particles [windows]]      windows: roll the block on by that many 24-substep windows first
 
 Thread 0 of every workgroup stamps s_memrealtime (100 MHz) at the phase boundaries (TL(S, k) in fe_engine.hip).  Printed per
 kernel: for each stamp k, the median / 90th percentile / max over workgroups of (stamp - earliest stamp 0 of the launch), in us.
@@ -36,12 +36,17 @@ def main():
     eng = make_engine(elib, sc, max_substeps_local=L, device=0)
     eng.loss_alloc(1)
     eng.loss_set_target(0, sc['x'])
+    for _ in range(int(sys.argv[3]) if len(sys.argv) > 3 else 0):         # let the block fall / splash first
+        eng.step(0, 0, L, 0)
+        eng.copy_frame(L, 0)
     for _ in range(2):
         eng.step(0, 0, L, 0)
         eng.reset_grad()
         eng.loss_step_grad(0, L, 0, 1.0, 1.0)
         eng.step_grad(0, 0, L, 0)
     eng.sync()
+    st = eng.get_stats(L // 2)
+    print('state:', {k: int(v) for k, v in st.items() if k != 'bytes_state'})
     buf = np.zeros((2048 * 9,), np.uint64)
     raw = {}
     for kid, name in enumerate(KNAMES):

@@ -1,0 +1,40 @@
+"""bench.py's launch contract: `--gpus N` without a launcher starts N ranks itself; a launcher / flag mismatch is an error; on the
+GPU box two ranks run the real N > 1 path (LatteArt replicas, action-gradient all-reduce) sharing the one device over gloo."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    env.update(MASTER_ADDR='127.0.0.1', **kw)
+    return env
+
+
+def test_bench_rejects_a_world_size_that_contradicts_gpus():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '3'], env=_env(WORLD_SIZE='1'), capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and '--gpus 3 but WORLD_SIZE=1' in r.stderr
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_spawns_two_ranks_and_all_reduces_the_action_gradient():
+    """`python bench.py --gpus 2 ...` exactly as the driver would call it (no launcher around it): two ranks, one LatteArt-v0 replica
+    each with its own injector randomness, Solver passes with the action-gradient all-reduce.  The box has one GPU: both ranks use
+    it and the collective runs over gloo (the only test-only switches); the scene is the reference's own 64^3 LatteArt."""
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+           '--dist-backend', 'gloo', '--one-device', '--c4-scene', 'as_shipped']
+    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith('{')][-1]
+    out = json.loads(line)
+    assert out['n_gpus'] == 2 and out['config']['rccl_world_size'] == 2 and out['steps'] == 2 and out['scaling'] == 'weak'
+    assert out['value'] > 0 and len(out['per_rank_pairs_per_s_compute_only']) == 2
+    assert out['passes_skipped_nonfinite_grad'] == 0 and len(out['loss_mean_over_envs']) == 2
+    assert all(v == v and v > 0 for v in out['loss_mean_over_envs'])
+    assert out['config']['substep_pairs_per_step_per_rank'] == 3300 and out['config']['action_grad_shape'] == [251, 3]
+    assert 0.2 < out['weak_scaling_efficiency_vs_rank_compute'] <= 1.05

@@ -60,13 +60,14 @@ def test_substep_adjoint(hiplib, oracle64, scene, K):
     if scene == 'water':
         sc = S.water_block(n_grid=16, n_particles=2000)
         sc['v'] = S.f32(np.random.RandomState(9).normal(0, 0.5, (2000, 3)))
-        tol_l2 = 1e-4
+        tol_l2 = 4e-6           # measured 1.1e-6 (gC)
     else:
         sc = S.mixed_materials()
-        tol_l2 = 1e-2
+        tol_l2 = 2e-3           # measured 5.4e-4 (gF: SVD / plastic-clamp adjoint in fp32); 1e-2 in round 1
     cot = S.random_cotangent(sc['N'])
     _, ga = S.run_forward_backward(S.make_engine(hiplib, sc, options={'sort_interval': K}), 6, cot)
     _, gb = S.run_forward_backward(S.make_engine(oracle64, sc), 6, {k: v.astype(np.float64) for k, v in cot.items()})
+    print(f'MEASURED substep_adjoint[{scene}, K={K}]: ' + ' '.join(f'{k} relL2 {S.rel_l2(ga[k], gb[k]):.2e}' for k in ('gx', 'gv', 'gC', 'gF')))
     for k in ('gx', 'gv', 'gC', 'gF'):
         assert np.isfinite(ga[k]).all(), k
         assert S.cosine(ga[k], gb[k]) >= 0.999, (k, S.cosine(ga[k], gb[k]))

@@ -519,12 +519,32 @@ def test_latest_pos_follows_the_effector(oracle32):
     assert np.allclose(te.agent.rigid.latest_pos.to_numpy()[0], [0.5, 0.62, 0.5])
     te.step(np.array([0.005, 0.0, -0.002]))
     te.step(np.array([0.005, 0.0, -0.002]))
-    assert np.allclose(te.agent.rigid.latest_pos.to_numpy()[0], [0.51, 0.62, 0.496], atol=1e-6)
+    # the reference's field holds pos[f] at the START of the last move (effector.py:146-152): one substep short of the current pose
+    ns = te.simulator.n_substeps
+    last = np.array([0.5, 0.62, 0.5]) + (2 - 1.0 / ns) * np.array([0.005, 0.0, -0.002])
+    assert np.allclose(te.agent.rigid.latest_pos.to_numpy()[0], last, atol=1e-6)
     from fluidlab_amd.optimizer.policies import MixingPolicy
     cfg = load_config('configs/exp_mixing.yaml').SOLVER
     pol = MixingPolicy(cfg.optim, cfg.init_range, 3, 100, env.action_range, fix_dim=[1])
     a = pol.get_action_v(50, agent=te.agent, update=True)
-    assert np.allclose(a, (np.array([0.5, 0.73, 0.5]) - [0.51, 0.62, 0.496]) / 30, atol=1e-6)
+    assert np.allclose(a, (np.array([0.5, 0.73, 0.5]) - last) / 30, atol=1e-6)
+
+
+def test_latteart_stir_policy_freezes_progressively():
+    """LatteArtStirPolicy.optimize (policies.py:172-194): the learning rate drops and the early actions are frozen as the loss'
+    temporal range grows; only `trainable` is touched, not `freeze_till`."""
+    from fluidlab_amd.optimizer.policies import LatteArtStirPolicy
+    cfg = load_config('configs/exp_latteart_stir.yaml').SOLVER
+    pol = LatteArtStirPolicy(cfg.optim, cfg.init_range, 3, 500, np.array([-0.007, 0.007]), fix_dim=[1])
+    g = np.ones(pol.comp_actions_shape)
+    before = pol.comp_actions.copy()
+    pol.optimize(g, {'temporal_range': 90})
+    assert pol.trainable.all() and pol.optim.lr == pol.optim.init_lr
+    for tr, frozen, lr in ((120, 0, 1.0), (160, 50, 0.5), (210, 100, 0.5), (260, 150, 0.2), (420, 300, 0.2)):
+        pol.optimize(g, {'temporal_range': tr})
+        assert not pol.trainable[:frozen].any() and pol.trainable[max(frozen, 300 if tr > 400 else frozen):].all(), tr
+        assert np.isclose(pol.optim.lr, pol.optim.init_lr * lr) and pol.freeze_till == 0
+    assert not np.array_equal(pol.comp_actions[300:], before[300:])           # (frozen rows still coast on Adam's momentum, as in the reference)
 
 
 def test_mixing_policy_cycle():
