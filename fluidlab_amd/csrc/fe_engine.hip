@@ -156,15 +156,24 @@ __device__ __forceinline__ bool mark_block(int b, int* blk_flag, int* blk_list, 
 // -----------------------------------------------------------------------------------------
 #define TILE_T 8
 #define TILE_N 512
-#define ITEM_MAX_CAP 512      // upper bound of the runtime `item_max` option (particles per work item)
+#define ITEM_MAX_CAP 128      // upper bound (and default) of the runtime `item_max` option: an item is one pass of one half workgroup
 #define WG 256
-// The LDS tile of the workgroup's current item (SoA planes of TILE_N floats).  File scope, so every
-// access is a known-LDS ds_* instruction (a `float*` parameter that may also be null degrades to flat_*).
-__shared__ float  s_tile[4 * TILE_N];      // gathered node values (v_out / d v_in,d m)
+#define HALF 128
+// Work items and workgroups.  An item holds <= 128 particles of one block; a workgroup (4 waves) takes TWO consecutive items, one
+// per pair of waves.  When both belong to the same block (the usual case in a dense region: a block of ~400 particles is 4 items,
+// and blocks with several items are padded to an even number) the two halves share one LDS tile and hand over one slab -- exactly
+// what a 256-particle item did in round 1.  When they belong to different blocks (blocks with few particles: a splash, a thin
+// layer, an injected jet) each half has its own tile.  Round 1 gave every block its own workgroup: a block that has spread into
+// 1,600 sparsely filled blocks needed two rounds of the chip's 1,024 resident workgroups per kernel (scripts/timeline.py).
+// The LDS tiles (SoA planes of TILE_N floats, two tiles per workgroup).  File scope, so every access is a known-LDS ds_*
+// instruction (a `float*` parameter that may also be null degrades to flat_*).
+__shared__ float  s_tile[2 * 4 * TILE_N];   // gathered node values (v_out / d v_in,d m): k_g2p (3 planes), k_p2g_grad (4)
 // Scatter accumulators are fp64: measured on MI355X ds_add_f32 sustains ~0.2 T lane-ops/s chip-wide, ds_add_f64
 // ~1.6 T and ds_add_u64 ~2.8 T in this access pattern (profiles/r01_ubench_lds_types.txt); fp64 also makes the
 // in-tile sum insensitive to the order of the atomics.
-__shared__ double s_acc[4 * TILE_N];
+__shared__ double s_acc[2 * 4 * TILE_N];    // k_p2g
+__shared__ float  s_tile3[2 * 3 * TILE_N];  // k_g2p_grad: v_out ...
+__shared__ double s_acc3[2 * 3 * TILE_N];   // ... and d v_out (3 planes each: 36 KB per workgroup, four workgroups per CU)
 // Effector pose adjoints of the workgroup's particles in contact (agent.collide's adjoint): summed here first -- every
 // contact particle adds to the same 14 numbers per effector, and same-address global atomics serialise.
 #define FE_MAX_EFF 4
@@ -259,8 +268,10 @@ __device__ __forceinline__ float seg_scan(const SegScan& sc, float v) {
 struct TableP {
     const int*  pid_of_slot;   // [Np]
     const float4* info;        // [Np] material record of the particle in each slot (pinfo in slot order: a coalesced load, not pinfo[pid])
-    const int4* items;         // (block, start, count, 0), sorted by block
-    const int*  meta;          // meta[0] = n_items, meta[1] = tail_start, meta[2] = n_active
+    const int4* items;         // (block, start, count <= 128, 0), sorted by block
+    const int2* pairs;         // workgroups of blocks with several items: (item, its partner in the same block or -1)
+    const int*  singles;       // the items of blocks with a single item (paired up two by two by the kernels)
+    const int*  meta;          // meta[0] = n_items, [1] = tail_start, [2] = n_active, [3] = n pairs, [4] = n singles
     const int2* blk_first;     // [nblk] (first item, item count) of a block
     const int*  active;        // blocks within one block of an occupied block: every block a tile can reach
     const int*  blk_slot;      // [nblk] index of a block in `active`, or -1
@@ -279,6 +290,35 @@ __device__ __forceinline__ int tile_base(const TileO& t, const Stencil& st) {
 __device__ __forceinline__ bool tile_node(const TileO& t, int l, int n, int& i, int& j, int& k) {
     i = t.ox + (l >> 6); j = t.oy + ((l >> 3) & 7); k = t.oz + (l & 7);
     return (unsigned)i < (unsigned)n && (unsigned)j < (unsigned)n && (unsigned)k < (unsigned)n;
+}
+
+// What one half of a workgroup works on (see "Work items and workgroups" above).  Uniform per wave.
+struct PairCtx {
+    int4 it;         // (block, first slot, count <= 128, 0) of this half's item; count 0 when the half is idle
+    int  ti;         // LDS tile of this half: 0, or 1 when the two items belong to different blocks
+    int  slab;       // slab the tile is handed over in (the item's index; a shared tile goes to the first item's)
+    int  nth, t0;    // the threads that load / zero / store this tile: all 256 from t0 = tid when shared, else this half's 128
+    bool live;       // this half's threads take part in tile loads and stores
+};
+// number of workgroup-level work units of the item path
+__device__ __forceinline__ int n_pair_work(const TableP& T) { return T.meta[3] + ((T.meta[4] + 1) >> 1); }
+__device__ __forceinline__ PairCtx pair_ctx(const TableP& T, int w) {
+    const int tid = threadIdx.x, half = __builtin_amdgcn_readfirstlane(tid >> 7);
+    const int nM = T.meta[3], nS = T.meta[4];
+    int ia, ib;
+    bool same;
+    if (w < nM) { const int2 p = T.pairs[w]; ia = p.x; ib = p.y; same = true; }
+    else { const int q = 2 * (w - nM); ia = T.singles[q]; ib = q + 1 < nS ? T.singles[q + 1] : -1; same = false; }
+    const int ih = half ? ib : ia;
+    PairCtx c;
+    c.live = same || ih >= 0;
+    c.it = T.items[ih >= 0 ? ih : ia];
+    if (ih < 0) c.it.z = 0;                                  // no second item: the half idles (through the same barriers)
+    c.ti = (half && !same) ? 1 : 0;
+    c.slab = same ? ia : (ih >= 0 ? ih : ia);
+    c.nth = same ? WG : HALF;
+    c.t0 = same ? tid : (tid & (HALF - 1));
+    return c;
 }
 
 // =========================================================================================
@@ -422,7 +462,7 @@ __device__ __forceinline__ void p2g_scatter_global(const SimP& S, const P2GPrep&
 
 // tile path, executed by ALL lanes of the wave: contributions of lanes with `in_tile` are summed over runs of equal
 // stencil base (seg_scan) and the last lane of each run adds the total into the fp64 LDS accumulators
-__device__ __forceinline__ void p2g_scatter_tile(const SimP& S, const P2GPrep& q, bool in_tile, int lb) {
+__device__ __forceinline__ void p2g_scatter_tile(const SimP& S, const P2GPrep& q, bool in_tile, int lb, int aofs) {
     const SegScan sc = seg_setup(in_tile ? lb : (0x40000000 | (int)threadIdx.x));
     const bool issue = sc.tail && in_tile;
     const float live = in_tile ? 1.f : 0.f;
@@ -447,7 +487,7 @@ __device__ __forceinline__ void p2g_scatter_tile(const SimP& S, const P2GPrep& q
             seg_scan4(sc, c[0], c[1], c[2], c[3]);
             if (issue) {
 #pragma unroll
-                for (int a = 0; a < 4; a++) atomicAdd(&s_acc[a * TILE_N + l], (double)c[a]);            // ds_add_f64
+                for (int a = 0; a < 4; a++) atomicAdd(&s_acc[aofs + a * TILE_N + l], (double)c[a]);            // ds_add_f64
             }
         }
     }
@@ -468,19 +508,22 @@ __global__ __launch_bounds__(WG, GENERAL ? 2 : 4) void k_p2g(SimP S, float* fr_c
     FrameV nxt = frame_view(fr_next, S.Np);
     TL(S, 0);
     const int n_items = T.meta[0], tail_start = T.meta[1];
+    const int n_pairs = n_pair_work(T);
     const int n_tail = (S.N - tail_start + WG - 1) / WG;
-    const int n_work = n_items + n_tail, per_xcd = (n_work + 7) >> 3;
+    const int n_work = n_pairs + n_tail, per_xcd = (n_work + 7) >> 3;
     for (int wg = blockIdx.x; wg < per_xcd * 8; wg += gridDim.x) {
         const int w = xcd_item(wg, per_xcd, S.xcd);
         if (w >= n_work) continue;
-        if (w < n_items) {
-            const int4 it = T.items[w];
+        if (w < n_pairs) {
+            const PairCtx pc = pair_ctx(T, w);
+            const int4 it = pc.it;
             const TileO to = tile_origin(it.x, S.nb);
+            const int aofs = pc.ti * 4 * TILE_N;
             TL(S, 1);
-            for (int l = tid; l < 4 * TILE_N; l += WG) s_acc[l] = 0.0;
+            if (pc.live) for (int l = pc.t0; l < 4 * TILE_N; l += pc.nth) s_acc[aofs + l] = 0.0;
             __syncthreads();
-            for (int i0 = 0; i0 < it.z; i0 += WG) {              // uniform trip count: the DPP scan needs every lane
-                const int i = i0 + tid, s = it.y + i;
+            {                                                    // one pass: an item is <= 128 particles, one per lane of the half
+                const int i = tid & (HALF - 1), s = it.y + i;
                 const bool has = i < it.z;
                 // (`used` is re-read rather than implied by the work list so host edits of a frame cannot desynchronise it)
                 bool used = has && cur.used[s] != 0;
@@ -499,23 +542,22 @@ __global__ __launch_bounds__(WG, GENERAL ? 2 : 4) void k_p2g(SimP S, float* fr_c
                 }
                 TL(S, 2);
                 const bool in_tile = lb >= 0;
-                // a wave without any particle (items hold <= item_max particles, the workgroup always has 4 waves) skips
-                // the 27-node scan altogether; the branch is wave-uniform, as the DPP scan requires
-                if (__any(in_tile)) p2g_scatter_tile(S, q, in_tile, in_tile ? lb : 0);
+                // a wave without any particle skips the 27-node scan altogether; the branch is wave-uniform, as the DPP scan requires
+                if (__any(in_tile)) p2g_scatter_tile(S, q, in_tile, in_tile ? lb : 0, aofs);
                 if (used && q.inside && !in_tile) { atomicAdd(G.slow, 1); p2g_scatter_global(S, q, G); }   // drifted out of the tile
                 if (has && !used && !taken && WRITE) unused_particle_fwd(S, cur, nxt, s, T.pid_of_slot[s], pool_idx, agent, inj, f);
             }
             TL(S, 4);
             __syncthreads();
             TL(S, 5);
-            // hand the tile over: plain coalesced float4 stores into this item's slab.  No atomics, no waiting:
+            // hand the tile over: plain coalesced float4 stores into the item's slab.  No atomics, no waiting:
             // k_grid sums, per node, the slabs of the (at most 8) blocks whose tiles reach it, in a fixed order.
-            for (int l = tid; l < TILE_N; l += WG)
-                G.slab[(size_t)w * TILE_N + l] = make_float4((float)s_acc[l], (float)s_acc[TILE_N + l], (float)s_acc[2 * TILE_N + l], (float)s_acc[3 * TILE_N + l]);
+            if (pc.live) for (int l = pc.t0; l < TILE_N; l += pc.nth)
+                G.slab[(size_t)pc.slab * TILE_N + l] = make_float4((float)s_acc[aofs + l], (float)s_acc[aofs + TILE_N + l], (float)s_acc[aofs + 2 * TILE_N + l], (float)s_acc[aofs + 3 * TILE_N + l]);
             __syncthreads();
             TL(S, 6);
         } else {
-            const int s = tail_start + (w - n_items) * WG + tid;
+            const int s = tail_start + (w - n_pairs) * WG + tid;
             if (s < S.N) {
                 if (cur.used[s]) {
                     if (WRITE && act && agent.collector && collector_takes(cur, nxt, s, T.info, agent)) continue;
@@ -604,11 +646,12 @@ __device__ __forceinline__ float4 gather_slabs(const SimP& S, const TableP& T, c
             mine = T.blk_first[(i2 * S.nb + j2) * S.nb + k2];
     }
     const int o[3] = {lane >> 4, (lane >> 2) & 3, lane & 3};
-    // The first two items of each of the 8 source blocks are loaded unconditionally-shaped (16 independent loads in
-    // flight, zero when absent): summing inside a `for k < count` loop made every load wait for the previous one, eight
-    // dependent L2/MALL round trips per node.  Blocks split into more than two items (> 2 * item_max particles) finish
-    // in the loop below.  The summation order stays fixed (source c ascending, item k ascending): deterministic.
-    int first[8], count[8], tidx[8];
+    // Which items of a block own a slab: the items of a block pair up from its first one, and a pair shares the first one's slab:
+    // the slabs of a block whose items are [first, first + count) are first, first + 2, ...  The first two of each of the 8 source
+    // blocks are loaded unconditionally-shaped (16 independent loads in flight, zero when absent): summing inside a loop made
+    // every load wait for the previous one, eight dependent L2/MALL round trips per node.  Blocks with more than two slabs
+    // (> 512 particles) finish in the loop below.  The summation order stays fixed (source c ascending, slab ascending).
+    int first[8], end[8], second[8], tidx[8];
     float4 v0[8], v1[8];
 #pragma unroll
     for (int c = 0; c < 8; c++) {
@@ -621,15 +664,16 @@ __device__ __forceinline__ float4 gather_slabs(const SimP& S, const TableP& T, c
             nbr = nbr * 3 + delta + 1;
             ti_all = ti_all * TILE_T + ti;
         }
-        first[c] = __shfl(mine.x, nbr, 64); count[c] = __shfl(mine.y, nbr, 64); tidx[c] = ti_all;
+        first[c] = __shfl(mine.x, nbr, 64); end[c] = first[c] + __shfl(mine.y, nbr, 64); tidx[c] = ti_all;
+        second[c] = first[c] + 2;
     }
     // (the loads are unconditional from a clamped, always valid slab index and masked afterwards: a conditional float4
     // load into an array element ended up in scratch)
 #pragma unroll
     for (int c = 0; c < 8; c++) {
-        const bool h0 = count[c] > 0, h1 = count[c] > 1;
+        const bool h0 = end[c] > first[c], h1 = second[c] < end[c];
         const float4 a = slab[(size_t)(h0 ? first[c] : 0) * TILE_N + tidx[c]];
-        const float4 b = slab[(size_t)(h1 ? first[c] + 1 : 0) * TILE_N + tidx[c]];
+        const float4 b = slab[(size_t)(h1 ? second[c] : 0) * TILE_N + tidx[c]];
         v0[c] = make_float4(h0 ? a.x : 0.f, h0 ? a.y : 0.f, h0 ? a.z : 0.f, h0 ? a.w : 0.f);
         v1[c] = make_float4(h1 ? b.x : 0.f, h1 ? b.y : 0.f, h1 ? b.z : 0.f, h1 ? b.w : 0.f);
     }
@@ -638,8 +682,8 @@ __device__ __forceinline__ float4 gather_slabs(const SimP& S, const TableP& T, c
     for (int c = 0; c < 8; c++) {
         acc.x += v0[c].x; acc.y += v0[c].y; acc.z += v0[c].z; acc.w += v0[c].w;
         acc.x += v1[c].x; acc.y += v1[c].y; acc.z += v1[c].z; acc.w += v1[c].w;
-        for (int k = 2; k < count[c]; k++) {
-            const float4 v = slab[(size_t)(first[c] + k) * TILE_N + tidx[c]];
+        for (int k = second[c] + 2; k < end[c]; k += 2) {
+            const float4 v = slab[(size_t)k * TILE_N + tidx[c]];
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
     }
@@ -704,7 +748,7 @@ __global__ __launch_bounds__(256) void k_grid(SimP S, TableP T, const float4* __
 template <bool TILE, bool COLLIDE>
 __device__ __forceinline__ void used_particle_g2p(const SimP& S, const FrameV& cur, const FrameV& nxt, int s,
                                                   int lb, const Stencil& st, const float x[3],
-                                                  const float4* __restrict__ g_out, const AgentP& agent, int f) {
+                                                  const float4* __restrict__ g_out, const AgentP& agent, int f, int tofs = 0) {
     float nv[3] = {0.f, 0.f, 0.f};
     m3 nC = m3_zero();
     const float c4 = 4.f * S.inv_dx;
@@ -721,7 +765,7 @@ __device__ __forceinline__ void used_particle_g2p(const SimP& S, const FrameV& c
             const float weight = wij * st.w[kk][2];
             float g0, g1, g2;
             if (TILE) {
-                const int l = lb + (i * TILE_T + j) * TILE_T + kk;
+                const int l = tofs + lb + (i * TILE_T + j) * TILE_T + kk;
                 g0 = s_tile[l]; g1 = s_tile[TILE_N + l]; g2 = s_tile[2 * TILE_N + l];
             } else {
                 float4 gv = g_out[cell_addr(st.base[0] + i, st.base[1] + j, st.base[2] + kk, S.nb)];
@@ -746,20 +790,24 @@ __device__ __forceinline__ void used_particle_g2p(const SimP& S, const FrameV& c
     store_xvC(nxt, s, xn, nv, nC);
 }
 
-__device__ __forceinline__ void load_tile3(const TileO& to, const SimP& S, const float4* __restrict__ src, int tid) {
-    for (int l = tid; l < TILE_N; l += WG) {
+__device__ __forceinline__ void load_tile3(const TileO& to, const SimP& S, const float4* __restrict__ src, const PairCtx& pc) {
+    if (!pc.live) return;
+    const int tofs = pc.ti * 4 * TILE_N;
+    for (int l = pc.t0; l < TILE_N; l += pc.nth) {
         int i, j, k;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (tile_node(to, l, S.n, i, j, k)) v = src[cell_addr(i, j, k, S.nb)];
-        s_tile[l] = v.x; s_tile[TILE_N + l] = v.y; s_tile[2 * TILE_N + l] = v.z;
+        s_tile[tofs + l] = v.x; s_tile[tofs + TILE_N + l] = v.y; s_tile[tofs + 2 * TILE_N + l] = v.z;
     }
 }
-__device__ __forceinline__ void load_tile4(const TileO& to, const SimP& S, const float4* __restrict__ src, int tid) {
-    for (int l = tid; l < TILE_N; l += WG) {
+__device__ __forceinline__ void load_tile4(const TileO& to, const SimP& S, const float4* __restrict__ src, const PairCtx& pc) {
+    if (!pc.live) return;
+    const int tofs = pc.ti * 4 * TILE_N;
+    for (int l = pc.t0; l < TILE_N; l += pc.nth) {
         int i, j, k;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (tile_node(to, l, S.n, i, j, k)) v = src[cell_addr(i, j, k, S.nb)];
-        s_tile[l] = v.x; s_tile[TILE_N + l] = v.y; s_tile[2 * TILE_N + l] = v.z; s_tile[3 * TILE_N + l] = v.w;
+        s_tile[tofs + l] = v.x; s_tile[tofs + TILE_N + l] = v.y; s_tile[tofs + 2 * TILE_N + l] = v.z; s_tile[tofs + 3 * TILE_N + l] = v.w;
     }
 }
 
@@ -769,14 +817,14 @@ __device__ __forceinline__ void load_tile4(const TileO& to, const SimP& S, const
 template <bool COLLIDE>
 __device__ __forceinline__ void slot_g2p(const SimP& S, const FrameV& cur, const FrameV& nxt, int s, bool use_tile,
                                          const TileO& to, const float4* __restrict__ g_out, int* slow, const AgentP& agent, int f,
-                                         int u, const float4 a0) {
+                                         int u, const float4 a0, int tofs = 0) {
     if (!u) return;
     float x[3] = {a0.x, a0.y, a0.z};
     Stencil st;
     stencil_make(x, S.inv_dx, st);
     if (!stencil_inside(st, S.n)) return;                   // already counted in err by p2g
     const int lb = use_tile ? tile_base(to, st) : -1;
-    if (lb >= 0) used_particle_g2p<true, COLLIDE>(S, cur, nxt, s, lb, st, x, g_out, agent, f);
+    if (lb >= 0) used_particle_g2p<true, COLLIDE>(S, cur, nxt, s, lb, st, x, g_out, agent, f, tofs);
     else { if (use_tile) atomicAdd(slow, 1); used_particle_g2p<false, COLLIDE>(S, cur, nxt, s, 0, st, x, g_out, agent, f); }
 }
 
@@ -790,30 +838,30 @@ __global__ __launch_bounds__(WG) void k_g2p(SimP S, float* fr_cur, float* fr_nex
     FrameV nxt = frame_view(fr_next, S.Np);
     TL(S, 0);
     const int n_items = T.meta[0], tail_start = T.meta[1];
+    const int n_pairs = n_pair_work(T);
     const int n_tail = (S.N - tail_start + WG - 1) / WG;
-    const int n_work = n_items + n_tail, per_xcd = (n_work + 7) >> 3;
+    const int n_work = n_pairs + n_tail, per_xcd = (n_work + 7) >> 3;
     for (int wg = blockIdx.x; wg < per_xcd * 8; wg += gridDim.x) {
         const int w = xcd_item(wg, per_xcd, S.xcd);
         if (w >= n_work) continue;
-        if (w < n_items) {
-            const int4 it = T.items[w];
+        if (w < n_pairs) {
+            const PairCtx pc = pair_ctx(T, w);
+            const int4 it = pc.it;
             const TileO to = tile_origin(it.x, S.nb);
-            const int s0 = it.y + (tid < it.z ? tid : 0);       // items hold <= item_max <= WG particles: one pass
+            const int i = tid & (HALF - 1);
+            const int s0 = it.y + (i < it.z ? i : 0);
             TL(S, 1);
-            int u = cur.used[s0];
-            float4 a0 = cur.A0[s0];
-            load_tile3(to, S, g_out, tid);
+            const int u = cur.used[s0];
+            const float4 a0 = cur.A0[s0];
+            load_tile3(to, S, g_out, pc);
             __syncthreads();
             TL(S, 2);
-            for (int i = tid; i < it.z; i += WG) {
-                if (i != tid) { u = cur.used[it.y + i]; a0 = cur.A0[it.y + i]; }
-                slot_g2p<COLLIDE>(S, cur, nxt, it.y + i, true, to, g_out, slow, agent, f, u, a0);
-            }
+            if (i < it.z) slot_g2p<COLLIDE>(S, cur, nxt, s0, true, to, g_out, slow, agent, f, u, a0, pc.ti * 4 * TILE_N);
             TL(S, 3);
             __syncthreads();
             TL(S, 4);
         } else {
-            const int s = tail_start + (w - n_items) * WG + tid;
+            const int s = tail_start + (w - n_pairs) * WG + tid;
             TileO none = {0, 0, 0};
             if (s < S.N) slot_g2p<COLLIDE>(S, cur, nxt, s, false, none, g_out, slow, agent, f, cur.used[s], cur.A0[s]);
         }
@@ -843,7 +891,7 @@ __device__ __forceinline__ float4 vout_at(const SimP& S, const VoutSrc& V, int i
 template <bool TILE>
 __device__ __forceinline__ void used_particle_g2p_grad(const SimP& S, const FrameV& Gn, const FrameV& Gc, int s,
                                                        int lb, const Stencil& st, const VoutSrc& V, float* gg_out,
-                                                       bool live, const SegScan& sc) {
+                                                       bool live, const SegScan& sc, int tofs = 0) {
     PState g;                                   // adjoints of x', v', C'
     if (!TILE || live) load_xvC(Gn, s, g);
     else { g.x[0] = g.x[1] = g.x[2] = g.v[0] = g.v[1] = g.v[2] = 0.f; g.C = m3_zero(); }
@@ -879,14 +927,14 @@ __device__ __forceinline__ void used_particle_g2p_grad(const SimP& S, const Fram
             for (int a = 0; a < 3; a++) q[a] = kk == 0 ? qij[a] : qij[a] + (float)kk * qz[a];
             float v0, v1, v2;
             if (TILE) {
-                const int l = lb + (i * TILE_T + j) * TILE_T + kk;
-                v0 = s_tile[l]; v1 = s_tile[TILE_N + l]; v2 = s_tile[2 * TILE_N + l];
+                const int l = tofs + lb + (i * TILE_T + j) * TILE_T + kk;
+                v0 = s_tile3[l]; v1 = s_tile3[TILE_N + l]; v2 = s_tile3[2 * TILE_N + l];
                 float c0 = weight * q[0], c1 = weight * q[1], c2 = weight * q[2];
                 seg_scan3(sc, c0, c1, c2);
                 if (issue) {
-                    atomicAdd(&s_acc[l], (double)c0);                         // ds_add_f64
-                    atomicAdd(&s_acc[TILE_N + l], (double)c1);
-                    atomicAdd(&s_acc[2 * TILE_N + l], (double)c2);
+                    atomicAdd(&s_acc3[l], (double)c0);                        // ds_add_f64
+                    atomicAdd(&s_acc3[TILE_N + l], (double)c1);
+                    atomicAdd(&s_acc3[2 * TILE_N + l], (double)c2);
                 }
             } else {
                 const int c = cell_addr(st.base[0] + i, st.base[1] + j, st.base[2] + kk, S.nb);
@@ -944,19 +992,26 @@ __device__ __forceinline__ void pose_flush(const AgentP& agent, int f) {
     __syncthreads();
 }
 
-// same, reading v_out of frame f from the grid store (blocks addressed through the order's blk_slot)
-__device__ __forceinline__ void load_tile3_store(const TileO& to, const SimP& S, const TableP& T, const float4* __restrict__ st, int tid) {
-    for (int l = tid; l < TILE_N; l += WG) {
+// v_out of this half's tile into s_tile3 (3 planes), from the working grid or from the forward pass' store (blocks addressed
+// through the order's blk_slot)
+__device__ __forceinline__ void g2p_grad_load_tile(const TileO& to, const SimP& S, const TableP& T, const float4* __restrict__ g_out,
+                                                   const float4* __restrict__ st, const PairCtx& pc) {
+    if (!pc.live) return;
+    const int tofs = pc.ti * 3 * TILE_N;
+    for (int l = pc.t0; l < TILE_N; l += pc.nth) {
         int i, j, k;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (tile_node(to, l, S.n, i, j, k)) {
-            const int slot = T.blk_slot[(((i >> 2) * S.nb) + (j >> 2)) * S.nb + (k >> 2)];
-            if (slot >= 0) v = st[(size_t)slot * 128 + 64 + (((i & 3) << 4) | ((j & 3) << 2) | (k & 3))];
+            if (st) {
+                const int slot = T.blk_slot[(((i >> 2) * S.nb) + (j >> 2)) * S.nb + (k >> 2)];
+                if (slot >= 0) v = st[(size_t)slot * 128 + 64 + (((i & 3) << 4) | ((j & 3) << 2) | (k & 3))];
+            } else v = g_out[cell_addr(i, j, k, S.nb)];
         }
-        s_tile[l] = v.x; s_tile[TILE_N + l] = v.y; s_tile[2 * TILE_N + l] = v.z;
+        s_tile3[tofs + l] = v.x; s_tile3[tofs + TILE_N + l] = v.y; s_tile3[tofs + 2 * TILE_N + l] = v.z;
     }
 }
-__global__ __launch_bounds__(WG) void k_g2p_grad(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T,
+
+__global__ __launch_bounds__(WG, 4) void k_g2p_grad(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T,
                                                  const float4* __restrict__ g_out, float* gg_out, float4* slab, int* slow,
                                                  GridStore GS, int f, AgentP agent) {
     const int tid = threadIdx.x;
@@ -966,25 +1021,27 @@ __global__ __launch_bounds__(WG) void k_g2p_grad(SimP S, float* fr_cur, float* G
     FrameV Gn = frame_view(Gn_, S.Np), Gc = frame_view(Gc_, S.Np);
     TL(S, 0);
     const int n_items = T.meta[0], tail_start = T.meta[1];
+    const int n_pairs = n_pair_work(T);
     const int n_tail = (S.N - tail_start + WG - 1) / WG;
-    const int n_work = n_items + n_tail, per_xcd = (n_work + 7) >> 3;
+    const int n_work = n_pairs + n_tail, per_xcd = (n_work + 7) >> 3;
     for (int wg = blockIdx.x; wg < per_xcd * 8; wg += gridDim.x) {
         const int w = xcd_item(wg, per_xcd, S.xcd);
         if (w >= n_work) continue;
-        if (w < n_items) {
-            const int4 it = T.items[w];
+        if (w < n_pairs) {
+            const PairCtx pc = pair_ctx(T, w);
+            const int4 it = pc.it;
             const TileO to = tile_origin(it.x, S.nb);
-            // the particle loads go out ahead of the tile load and its barrier (see slot_g2p); items hold <= WG particles
-            const int s0 = it.y + (tid < it.z ? tid : 0);
-            int u0 = cur.used[s0];
-            float4 a00 = cur.A0[s0];
-            if (stored) load_tile3_store(to, S, T, GS.data + (size_t)f * GS.cap * 128, tid); else load_tile3(to, S, g_out, tid);
-            for (int l = tid; l < 3 * TILE_N; l += WG) s_acc[l] = 0.0;
+            const int tofs = pc.ti * 3 * TILE_N;
+            // the particle loads go out ahead of the tile load and its barrier (see slot_g2p); an item is one pass of its half
+            const int i = tid & (HALF - 1);
+            const int s = it.y + (i < it.z ? i : 0);
+            const int u0 = cur.used[s];
+            const float4 a00 = cur.A0[s];
+            g2p_grad_load_tile(to, S, T, g_out, V.store, pc);
+            if (pc.live) for (int l = pc.t0; l < 3 * TILE_N; l += pc.nth) s_acc3[tofs + l] = 0.0;
             __syncthreads();
             TL(S, 2);
-            for (int i0 = 0; i0 < it.z; i0 += WG) {              // uniform trip count: the DPP scan needs every lane
-                const int i = i0 + tid, s = it.y + i;
-                if (i0 > 0 && i < it.z) { u0 = cur.used[s]; a00 = cur.A0[s]; }
+            {
                 const bool used = i < it.z && u0 != 0;
                 float x[3] = {0.f, 0.f, 0.f};
                 if (used) { x[0] = a00.x; x[1] = a00.y; x[2] = a00.z; }
@@ -995,7 +1052,7 @@ __global__ __launch_bounds__(WG) void k_g2p_grad(SimP S, float* fr_cur, float* G
                 const bool live = lb >= 0;
                 if (__any(live)) {                               // wave-uniform: empty waves skip the scan
                     const SegScan sc = seg_setup(live ? lb : (0x40000000 | tid));
-                    used_particle_g2p_grad<true>(S, Gn, Gc, s, live ? lb : 0, st, V, gg_out, live, sc);
+                    used_particle_g2p_grad<true>(S, Gn, Gc, s, live ? lb : 0, st, V, gg_out, live, sc, tofs);
                 }
                 if (used && !live) {
                     if (inside) atomicAdd(slow, 1);
@@ -1005,12 +1062,12 @@ __global__ __launch_bounds__(WG) void k_g2p_grad(SimP S, float* fr_cur, float* G
             TL(S, 5);
             __syncthreads();
             TL(S, 6);
-            for (int l = tid; l < TILE_N; l += WG)
-                slab[(size_t)w * TILE_N + l] = make_float4((float)s_acc[l], (float)s_acc[TILE_N + l], (float)s_acc[2 * TILE_N + l], 0.f);
+            if (pc.live) for (int l = pc.t0; l < TILE_N; l += pc.nth)
+                slab[(size_t)pc.slab * TILE_N + l] = make_float4((float)s_acc3[tofs + l], (float)s_acc3[tofs + TILE_N + l], (float)s_acc3[tofs + 2 * TILE_N + l], 0.f);
             __syncthreads();
             TL(S, 7);
         } else {
-            const int s = tail_start + (w - n_items) * WG + tid;
+            const int s = tail_start + (w - n_pairs) * WG + tid;
             if (s < S.N) g2p_grad_slot_global(S, cur, Gn, Gc, s, V, gg_out, agent, f);
         }
     }
@@ -1275,8 +1332,8 @@ __device__ void effector_move_grad(const EffP& e, int f) {
 // What the constitutive adjoint needs again after the 27-node loop -- C, F and, in the SVD build, U, V, sigma, J -- waits in LDS
 // (s_stash, one column per thread) instead of in registers: round 1 re-read C and F from the frame (72 B per particle of extra
 // HBM traffic) and re-ran the constitutive model, and the SVD build kept everything live (256 + 32 VGPRs, one wave per SIMD).
-#define STASH_GENERAL 52
-#define STASH_LIQUID 30
+#define STASH_GENERAL 40
+#define STASH_LIQUID 18
 template <bool GENERAL> struct Stash { static __device__ __forceinline__ float* at(); };
 __shared__ float s_stash_g[STASH_GENERAL * WG];
 __shared__ float s_stash_l[STASH_LIQUID * WG];
@@ -1285,15 +1342,11 @@ template <> __device__ __forceinline__ float* Stash<false>::at() { return s_stas
 template <bool TILE, bool GENERAL>
 __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const FrameV& cur, const FrameV& Gn, const FrameV& Gc, int s,
                                                        const float4* __restrict__ info_, const TileO& to,
-                                                       const float4* __restrict__ gg_in, int* slow) {
+                                                       const float4* __restrict__ gg_in, int* slow, int tofs = 0) {
     PState p;
     load_xvC(cur, s, p);
     load_F(cur, s, p.F);
     PInfo info = load_info(info_, s);
-    // what is only needed behind the 27-node loop is requested now as well (one memory round trip for the whole particle) and
-    // waits in the stash: d/d F[f+1] and the position adjoint k_g2p_grad left in Gc
-    m3 Fg; load_F(Gn, s, Fg);
-    const float4 gc0 = Gc.A0[s];
     Constitutive k;
     constitutive_eval_t<GENERAL>(p.C, p.F, S.dt, info.mu, info.lam, info.mass, info.cls, S.stress_scale, k);
     Stencil st;
@@ -1316,12 +1369,6 @@ __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const Fram
                 if (GENERAL) { stash[(18 + a * 3 + b) * WG + col] = k.U.a[a][b]; stash[(27 + a * 3 + b) * WG + col] = k.V.a[a][b]; }
             }
         if (GENERAL) { stash[36 * WG + col] = k.sig[0]; stash[37 * WG + col] = k.sig[1]; stash[38 * WG + col] = k.sig[2]; stash[39 * WG + col] = k.J; }
-        const int o = GENERAL ? 40 : 18;
-#pragma unroll
-        for (int a = 0; a < 3; a++)
-#pragma unroll
-            for (int b = 0; b < 3; b++) stash[(o + a * 3 + b) * WG + col] = Fg.a[a][b];
-        stash[(o + 9) * WG + col] = gc0.x; stash[(o + 10) * WG + col] = gc0.y; stash[(o + 11) * WG + col] = gc0.z;
     }
     float Gv[3] = {0.f, 0.f, 0.f};
     m3 GA = m3_zero();
@@ -1352,7 +1399,7 @@ __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const Fram
             for (int kk = 0; kk < 3; kk++) {
                 float gin[3], gm;
                 if (TILE) {
-                    const int l = lb + (i * TILE_T + j) * TILE_T + kk;
+                    const int l = tofs + lb + (i * TILE_T + j) * TILE_T + kk;
                     gin[0] = s_tile[l]; gin[1] = s_tile[TILE_N + l]; gin[2] = s_tile[2 * TILE_N + l]; gm = s_tile[3 * TILE_N + l];
                 } else {
                     float4 gi = gg_in[cell_addr(st.base[0] + i, st.base[1] + j, st.base[2] + kk, S.nb)];
@@ -1410,17 +1457,9 @@ __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const Fram
         k.Ft = m3_mul(IdtC, p.F);
         if (!GENERAL) k.J = m3_det(k.Ft);
     }
-    m3 Fg2;
-    float gx[3];
-    {
-        const int o = GENERAL ? 40 : 18;
-#pragma unroll
-        for (int a = 0; a < 3; a++)
-#pragma unroll
-            for (int b = 0; b < 3; b++) Fg2.a[a][b] = stash[(o + a * 3 + b) * WG + col];
-#pragma unroll
-        for (int d = 0; d < 3; d++) gx[d] = stash[(o + 9 + d) * WG + col] + gxs[d];      // position adjoint so far (k_g2p_grad) + this kernel's part
-    }
+    m3 Fg2; load_F(Gn, s, Fg2);
+    const float4 gc0 = Gc.A0[s];                // position adjoint so far (k_g2p_grad)
+    float gx[3] = {gc0.x + gxs[0], gc0.y + gxs[1], gc0.z + gxs[2]};
     float gvv[3] = {info.mass * Gv[0], info.mass * Gv[1], info.mass * Gv[2]};
     m3 gC, gF;
     constitutive_grad_t<GENERAL>(p.C, p.F, S.dt, info.mu, info.lam, info.mass, info.cls, S.stress_scale, k, GA, Fg2, gC, gF);
@@ -1432,8 +1471,8 @@ template <bool TILE, bool GENERAL>
 __device__ __forceinline__ void slot_p2g_grad(const SimP& S, const FrameV& cur, const FrameV& Gn, const FrameV& Gc, int s, const TableP& T,
                                               const int* __restrict__ pool_idx,
                                               const TileO& to, const float4* __restrict__ gg_in, int* slow, const AgentP& agent,
-                                              const InjectP& inj, int f) {
-    if (cur.used[s]) { used_particle_p2g_grad<TILE, GENERAL>(S, cur, Gn, Gc, s, T.info, to, gg_in, slow); return; }
+                                              const InjectP& inj, int f, int tofs = 0) {
+    if (cur.used[s]) { used_particle_p2g_grad<TILE, GENERAL>(S, cur, Gn, Gc, s, T.info, to, gg_in, slow, tofs); return; }
     // the copy f -> f+1 of an unused particle passes its adjoint straight through (mpm:551)
     PState g; load_xvC(Gn, s, g); load_F(Gn, s, g.F);
     store_xvC(Gc, s, g.x, g.v, g.C); store_F(Gc, s, g.F);
@@ -1473,24 +1512,27 @@ __global__ __launch_bounds__(WG, MINW) void k_p2g_grad(SimP S, float* fr_cur, fl
     FrameV Gn = frame_view(Gn_, S.Np), Gc = frame_view(Gc_, S.Np);
     TL(S, 0);
     const int n_items = T.meta[0], tail_start = T.meta[1];
+    const int n_pairs = n_pair_work(T);
     const int n_tail = (S.N - tail_start + WG - 1) / WG;
-    const int n_work = n_items + n_tail, per_xcd = (n_work + 7) >> 3;
+    const int n_work = n_pairs + n_tail, per_xcd = (n_work + 7) >> 3;
     for (int wg = blockIdx.x; wg < per_xcd * 8; wg += gridDim.x) {
         const int w = xcd_item(wg, per_xcd, S.xcd);
         if (w >= n_work) continue;
-        if (w < n_items) {
-            const int4 it = T.items[w];
+        if (w < n_pairs) {
+            const PairCtx pc = pair_ctx(T, w);
+            const int4 it = pc.it;
             const TileO to = tile_origin(it.x, S.nb);
             TL(S, 1);
-            load_tile4(to, S, gg_in, tid);
+            load_tile4(to, S, gg_in, pc);
             __syncthreads();
             TL(S, 2);
-            for (int i = tid; i < it.z; i += WG) slot_p2g_grad<true, GENERAL>(S, cur, Gn, Gc, it.y + i, T, pool_idx, to, gg_in, slow, agent, inj, f);
+            const int i = tid & (HALF - 1);
+            if (i < it.z) slot_p2g_grad<true, GENERAL>(S, cur, Gn, Gc, it.y + i, T, pool_idx, to, gg_in, slow, agent, inj, f, pc.ti * 4 * TILE_N);
             TL(S, 3);
             __syncthreads();
             TL(S, 4);
         } else {
-            const int s = tail_start + (w - n_items) * WG + tid;
+            const int s = tail_start + (w - n_pairs) * WG + tid;
             TileO none = {0, 0, 0};
             if (s < S.N) slot_p2g_grad<false, GENERAL>(S, cur, Gn, Gc, s, T, pool_idx, none, gg_in, slow, agent, inj, f);
         }
@@ -1589,42 +1631,58 @@ __device__ __forceinline__ int scan_load(int ncell, const int* cnt, const int* b
     return sp;
 }
 
-__global__ __launch_bounds__(256) void k_scan_partial(int ncell, int ITEM_MAX, const int* __restrict__ cnt, const int* __restrict__ bflag, int2* partial) {
+// Work items and workgroup pairs of a block with n particles: ceil(n / ITEM_MAX) items.  A block with several items pairs them up
+// among themselves (pair list M: items 2j and 2j + 1 of the block share one LDS tile and one slab -- the last one of an odd count
+// stays alone); blocks with a single item are listed in S and paired with the next such block by the kernels (two tiles).
+__device__ __forceinline__ int3 block_work(int n, int ITEM_MAX) {
+    const int k = (n + ITEM_MAX - 1) / ITEM_MAX;
+    return make_int3(k, k > 1 ? (k + 1) >> 1 : 0, k == 1 ? 1 : 0);          // items, M pairs, singles
+}
+__global__ __launch_bounds__(256) void k_scan_partial(int ncell, int ITEM_MAX, const int* __restrict__ cnt, const int* __restrict__ bflag, int4* partial) {
     __shared__ int sh[4];
     __shared__ int sh_sum[256];
     const int tid = threadIdx.x;
     int c[4], blk_cnt;
     bool live;
     const int sp = scan_load(ncell, cnt, bflag, tid, c, sh_sum, blk_cnt, live);
-    const int si = tid < 16 ? (blk_cnt + ITEM_MAX - 1) / ITEM_MAX : 0;
-    int tp, ti;
+    const int3 bw = tid < 16 ? block_work(blk_cnt, ITEM_MAX) : make_int3(0, 0, 0);
+    int tp, ti, tm, ts;
     wg_scan_excl(sp, sh, tid, tp);
-    wg_scan_excl(si, sh, tid, ti);
-    if (tid == 0) partial[blockIdx.x] = make_int2(tp, ti);
+    wg_scan_excl(bw.x, sh, tid, ti);
+    wg_scan_excl(bw.y, sh, tid, tm);
+    wg_scan_excl(bw.z, sh, tid, ts);
+    if (tid == 0) partial[blockIdx.x] = make_int4(tp, ti, tm, ts);
 }
 
-__global__ __launch_bounds__(256) void k_scan_final(int ncell, int ITEM_MAX, int* cnt, int* bflag, const int2* __restrict__ partial, int* start, int4* items, int* meta, int2* blk_first) {
+__global__ __launch_bounds__(256) void k_scan_final(int ncell, int ITEM_MAX, int* cnt, int* bflag, const int4* __restrict__ partial, int* start, int4* items, int* meta,
+                                                    int2* blk_first, int2* pairs, int* singles) {
     __shared__ int sh[4];
     __shared__ int sh_sum[256];
     __shared__ int sh_bp[256];
     const int tid = threadIdx.x;
-    int pp = 0, pi = 0;                                       // sums of the partials before this workgroup
-    for (int w = tid; w < (int)blockIdx.x; w += 256) { int2 t = partial[w]; pp += t.x; pi += t.y; }
-    int base_p, base_i, dummy;
+    int pp = 0, pi = 0, pm = 0, ps = 0;                       // sums of the partials before this workgroup
+    for (int w = tid; w < (int)blockIdx.x; w += 256) { int4 t = partial[w]; pp += t.x; pi += t.y; pm += t.z; ps += t.w; }
+    int base_p, base_i, base_m, base_s, dummy;
     wg_scan_excl(pp, sh, tid, base_p);
     wg_scan_excl(pi, sh, tid, base_i);
+    wg_scan_excl(pm, sh, tid, base_m);
+    wg_scan_excl(ps, sh, tid, base_s);
     int c[4], blk_cnt;
     bool live;
     const int sp = scan_load(ncell, cnt, bflag, tid, c, sh_sum, blk_cnt, live);
-    const int si = tid < 16 ? (blk_cnt + ITEM_MAX - 1) / ITEM_MAX : 0;
-    int toti;
+    const int3 bw = tid < 16 ? block_work(blk_cnt, ITEM_MAX) : make_int3(0, 0, 0);
+    int toti, totm, tots;
     int bp = base_p + wg_scan_excl(sp, sh, tid, dummy);
-    int bi = base_i + wg_scan_excl(si, sh, tid, toti);
+    int bi = base_i + wg_scan_excl(bw.x, sh, tid, toti);
+    int bm = base_m + wg_scan_excl(bw.y, sh, tid, totm);
+    const int bs = base_s + wg_scan_excl(bw.z, sh, tid, tots);
     sh_bp[tid] = bp;
     __syncthreads();
     if (tid < 16 && blockIdx.x * 16 + tid < ncell / 64) {     // the items of block wg*16+tid: slots [bstart, bstart+blk_cnt)
         const int blk = blockIdx.x * 16 + tid, bstart = sh_bp[tid * 16];
-        blk_first[blk] = make_int2(bi, (blk_cnt + ITEM_MAX - 1) / ITEM_MAX);
+        blk_first[blk] = make_int2(bi, bw.x);
+        if (bw.z) singles[bs] = bi;
+        for (int j = 0; j < bw.y; j++) pairs[bm + j] = make_int2(bi + 2 * j, 2 * j + 1 < bw.x ? bi + 2 * j + 1 : -1);
         for (int o = 0; o < blk_cnt; o += ITEM_MAX) items[bi++] = make_int4(blk, bstart + o, min(ITEM_MAX, blk_cnt - o), 0);
     }
     const int b0 = blockIdx.x * 1024 + tid * 4;
@@ -1640,7 +1698,7 @@ __global__ __launch_bounds__(256) void k_scan_final(int ncell, int ITEM_MAX, int
         }
     }
     if (live && (tid & 15) == 0) bflag[b0 >> 6] = 0;         // (this workgroup was the flag's only reader in this launch)
-    if (blockIdx.x == gridDim.x - 1 && tid == 0) { meta[0] = base_i + toti; meta[2] = 0; }
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) { meta[0] = base_i + toti; meta[2] = 0; meta[3] = base_m + totm; meta[4] = base_s + tots; }
 }
 
 // the order's static active list: every block within one block of an occupied block (= every block some tile reaches)
@@ -2087,7 +2145,7 @@ struct FeEngine {
     float* grads = nullptr;                                 // 3 x (GR_WORDS*Np + Np) floats: ring of two + 1 spare
     float* grad_ptr[3] = {nullptr, nullptr, nullptr};
     // particle orders ("tables"): id 0 = identity; id 1+f = order produced by the sort at frame f
-    struct Table { int* pid = nullptr; float4* info = nullptr; int4* items = nullptr; int* meta = nullptr; int2* blk_first = nullptr; int* active = nullptr; int* blk_slot = nullptr; int* slot_of_pid = nullptr; };
+    struct Table { int* pid = nullptr; float4* info = nullptr; int2* pairs = nullptr; int* singles = nullptr; int4* items = nullptr; int* meta = nullptr; int2* blk_first = nullptr; int* active = nullptr; int* blk_slot = nullptr; int* slot_of_pid = nullptr; };
     int static_table = -1;                                  // order whose active list is currently flagged 2 in blk_flag
     std::vector<int> gs_host; bool gs_host_valid = false;   // host copy of gs_flag, refreshed once per backward sweep
     float4* gstore = nullptr; int* gs_flag = nullptr; int gs_cap = 0;     // forward grid store (see GridStore)
@@ -2096,13 +2154,13 @@ struct FeEngine {
     std::vector<int> tbl_of_frame;                          // [L+1]
     int gtbl[2] = {-1, -1};                                 // order of each adjoint ring slot; -1 = all zero
     int p2g_grad_waves = 4;                                 // occupancy target of the SVD-free p2g_grad build (tuning)
-    int item_max = 256;                                     // particles per work item (<= ITEM_MAX_CAP)
+    int item_max = ITEM_MAX_CAP;                            // particles per work item (<= ITEM_MAX_CAP = one half workgroup)
     int sort_interval = 10;                                 // K: re-sort every K substeps (0 = never: global path only)
     size_t items_cap = 0;
     int *sort_key = nullptr, *sort_rank = nullptr, *sort_cnt = nullptr, *sort_start = nullptr, *sort_pid = nullptr, *sort_bflag = nullptr;
     int* slow_dev = nullptr;
     int* frame_slow_dev = nullptr;                          // set by a slow-path scatter of the current forward substep
-    int2* sort_partial = nullptr;
+    int4* sort_partial = nullptr;
     float4* pinfo = nullptr; int* pool_idx = nullptr;
     std::vector<int> mat_host;
     float *g_in = nullptr, *gg_out = nullptr;              // SoA accumulator planes (4 and 3 x ncell floats)
@@ -2143,7 +2201,7 @@ struct FeEngine {
     float*& spare_frame() { return frame_ptr[L + 1]; }
     float* grad(int f) { return grad_ptr[f & 1]; }
     size_t grad_words() const { return (size_t)GR_WORDS * Np + Np; }
-    TableP tableP(int id) const { TableP t; t.pid_of_slot = tables[id].pid; t.info = tables[id].info; t.items = tables[id].items; t.meta = tables[id].meta; t.blk_first = tables[id].blk_first; t.active = tables[id].active; t.blk_slot = tables[id].blk_slot; return t; }
+    TableP tableP(int id) const { TableP t; t.pid_of_slot = tables[id].pid; t.info = tables[id].info; t.pairs = tables[id].pairs; t.singles = tables[id].singles; t.items = tables[id].items; t.meta = tables[id].meta; t.blk_first = tables[id].blk_first; t.active = tables[id].active; t.blk_slot = tables[id].blk_slot; return t; }
     const int* pid_of(int f) const { return tables[tbl_of_frame[f]].pid; }
 };
 
@@ -2268,7 +2326,8 @@ int ensure_table(FeEngine* h, int id) {
     const size_t nblk = (size_t)h->nb * h->nb * h->nb;
     if (id == 0) t.info = h->pinfo;                            // identity order: slot == particle id
     else if (dev_alloc(h, &t.info, h->Np)) return 1;
-    if (dev_alloc(h, &t.pid, h->Np) || dev_alloc(h, &t.items, h->items_cap) || dev_alloc(h, &t.meta, 4) ||
+    if (dev_alloc(h, &t.pairs, h->items_cap / 2 + 2) || dev_alloc(h, &t.singles, h->items_cap)) return 1;
+    if (dev_alloc(h, &t.pid, h->Np) || dev_alloc(h, &t.items, h->items_cap) || dev_alloc(h, &t.meta, 8) ||
         dev_alloc(h, &t.blk_first, nblk) || dev_alloc(h, &t.active, nblk) || dev_alloc(h, &t.blk_slot, nblk) || dev_alloc(h, &t.slot_of_pid, h->Np)) return 1;
     HIPCK(h, hipMemsetAsync(t.blk_slot, 0xff, sizeof(int) * nblk, h->stream));
     return 0;
@@ -2320,7 +2379,7 @@ int sort_frame(FeEngine* h, int f) {
     if (fine) { prof_end(h); prof_begin(h, KID_SORT_SCAN); }
     const int scan_wgs = (ncell + 1 + 1023) / 1024;
     hipLaunchKernelGGL(k_scan_partial, dim3(scan_wgs), dim3(256), 0, h->stream, ncell, h->item_max, h->sort_cnt, h->sort_bflag, h->sort_partial);
-    hipLaunchKernelGGL(k_scan_final, dim3(scan_wgs), dim3(256), 0, h->stream, ncell, h->item_max, h->sort_cnt, h->sort_bflag, h->sort_partial, h->sort_start, tn.items, tn.meta, tn.blk_first);
+    hipLaunchKernelGGL(k_scan_final, dim3(scan_wgs), dim3(256), 0, h->stream, ncell, h->item_max, h->sort_cnt, h->sort_bflag, h->sort_partial, h->sort_start, tn.items, tn.meta, tn.blk_first, tn.pairs, tn.singles);
     if (fine) { prof_end(h); prof_begin(h, KID_SORT_ACTIVE); }
     hipLaunchKernelGGL(k_build_active, dim3(256), dim3(256), 0, h->stream, h->nb, tn.items, tn.meta, h->blk_flag, tn.active, tn.blk_slot);
     h->static_table = id_new;
@@ -2590,7 +2649,7 @@ void fe_destroy(FeEngine* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     smoke_destroy(h);
     for (auto& t : h->tables) { if (t.info && t.info != h->pinfo) (void)hipFree(t.info);
-        for (void* q : {(void*)t.pid, (void*)t.items, (void*)t.meta, (void*)t.blk_first, (void*)t.active, (void*)t.blk_slot, (void*)t.slot_of_pid}) if (q) (void)hipFree(q); }
+        for (void* q : {(void*)t.pairs, (void*)t.singles, (void*)t.pid, (void*)t.items, (void*)t.meta, (void*)t.blk_first, (void*)t.active, (void*)t.blk_slot, (void*)t.slot_of_pid}) if (q) (void)hipFree(q); }
     void* ptrs[] = {h->frames, h->grads, h->sort_key, h->sort_rank, h->sort_cnt, h->sort_start, h->sort_bflag, h->sort_pid, h->slow_dev, h->frame_slow_dev, h->gstore, h->gs_flag, h->slab, h->sort_partial, h->effs_dev, h->pinfo, h->pool_idx, h->g_in, h->g_out, h->gg_out, h->gg_in,
                     h->blk_flag, h->blk_list, h->blk_count, h->err_dev, h->stage_r, h->stage_i, h->node_mark, h->counters,
                     h->tgt, h->chamfer, h->step_loss, h->body_start, h->body_pids, h->bodies_dev, h->statics_dev, h->collector_dev, h->hit_dev, h->hit_list, h->hit_count, h->node_work, h->node_work_count};
@@ -2626,7 +2685,7 @@ int fe_set_option(FeEngine* h, const char* name, double value) {
         return 0;
     }
     if (!std::strcmp(name, "item_max")) {
-        if (value < 64 || value > ITEM_MAX_CAP) FAIL(h, "item_max must be in [64, 512]");
+        if (value < 64 || value > ITEM_MAX_CAP) FAIL(h, "item_max must be in [64, 128]");
         h->item_max = (int)value;
         return 0;
     }
