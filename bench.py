@@ -40,6 +40,7 @@ KERNEL_BYTES = {
     'p2g_recompute': (116, 16), 'grid_op_keep': (0, 28), 'g2p_grad': (60, 24), 'grid_op_grad': (0, 48), 'p2g_grad': (132, 16),
     'sort': (0, 0), 'reorder_grad': (0, 0),          # overhead of the cell-sorted layout: no algorithmic bytes credited
 }
+FWD_KERNELS = ('p2g', 'grid_op', 'g2p')
 METRIC = 'MPM substeps/sec (fwd+bwd), 128^3 grid / 200k particles'
 
 
@@ -219,6 +220,38 @@ def run_single(args):
         e2.sync()
         extra['restart_from_rest_pairs_per_s'] = round(20 * 50 / (time.perf_counter() - t2), 1)
         e2.close()
+        # B environments stepped in lockstep through shared launches (fe_step_batch): the same evolving block with B different
+        # particle sets; aggregate substep pairs/s of the B scenes against ONE scene on the same schedule (same warm-up, same number
+        # of windows: the same part of the fall).  Never part of `value`.
+        def batched_rate(B, nb):
+            engs = [build_block(elib, 0, seed=sd)[0] for sd in range(B)]
+            E = type(engs[0])
+
+            def batch_window():
+                E.step_batch(engs, 0, 0, CHUNK, 0)
+                for e in engs:
+                    e.reset_grad(); e.loss_step_grad(0, CHUNK, 0, 1.0, 1.0)
+                E.step_grad_batch(engs, 0, 0, CHUNK, 0)
+                for e in engs:
+                    e.copy_frame(CHUNK, 0)
+            for _ in range(args.warmup):
+                batch_window()
+            for e in engs:
+                e.sync()
+            t3 = time.perf_counter()
+            for _ in range(nb):
+                batch_window()
+            for e in engs:
+                e.sync()
+            rate = B * nb * CHUNK / (time.perf_counter() - t3)
+            for e in engs:
+                e.close()
+            return rate
+        nb = max(4, args.steps // 4)
+        r1, r4 = batched_rate(1, nb), batched_rate(4, nb)
+        extra['batched_envs'] = {'n_envs': 4, 'pairs_per_s_all_envs': round(r4, 1), 'pairs_per_s_one_env_same_schedule': round(r1, 1),
+                                 'ratio': round(r4 / r1, 3), 'timed_pairs_per_env': nb * CHUNK,
+                                 'note': 'fe_step_batch: one launch per phase for all envs (gridDim.y = n_envs)'}
         from fluidlab_amd import scenes as S
         extra['config5_water_256_1M'] = extra_block(elib, 0, 'water block 256^3, 1M particles, fwd+bwd', 256, 1_000_000, S.WATER, 40, 3)
         extra['config5_icecream_256_1M'] = extra_block(elib, 0, 'ICECREAM (plasto-elastic, SVD) block 256^3, 1M particles, fwd+bwd, 10 substeps', 256, 1_000_000, S.ICECREAM, 10, 3)

@@ -63,7 +63,7 @@ class FeStats(C.Structure):
 ABI_SYMBOLS = [
     'fe_create', 'fe_destroy', 'fe_last_error', 'fe_backend', 'fe_real_size', 'fe_sync',
     'fe_set_option', 'fe_init_particles', 'fe_substep', 'fe_substep_grad', 'fe_step',
-    'fe_step_grad', 'fe_get_frame', 'fe_set_frame', 'fe_get_frame_dev', 'fe_set_frame_dev', 'fe_copy_frame', 'fe_copy_grad',
+    'fe_step_grad', 'fe_step_batch', 'fe_step_grad_batch', 'fe_get_frame', 'fe_set_frame', 'fe_get_frame_dev', 'fe_set_frame_dev', 'fe_copy_frame', 'fe_copy_grad',
     'fe_reset_grad', 'fe_reset_grad_till_frame', 'fe_get_grad', 'fe_add_grad', 'fe_get_mat',
     'fe_add_static', 'fe_eff_set_mesh', 'fe_add_effector', 'fe_eff_set_act_range', 'fe_eff_get_state', 'fe_eff_set_state',
     'fe_eff_get_vw', 'fe_eff_set_vw', 'fe_eff_get_sr', 'fe_eff_set_sr', 'fe_eff_set_action', 'fe_eff_set_action_grad',
@@ -276,6 +276,22 @@ class Engine:
         k0, px = self._r(x, (N, 3)); k1, pv = self._r(v, (N, 3)); k2, pC = self._r(C_, (N, 3, 3))
         k3, pF = self._r(F, (N, 3, 3)); k4, pu = self._i(used, (N,))
         self._ck(self.lib.fe_set_frame(self.h, int(f), px, pv, pC, pF, pu))
+
+    @staticmethod
+    def _handles(engines):
+        arr = (C.c_void_p * len(engines))(*[e.h for e in engines])
+        return arr
+
+    @staticmethod
+    def step_batch(engines, f0, f_global0, n, act):
+        """fe_step_batch: the same n substeps for every engine of the list (lockstep environments, one launch per phase)"""
+        e0 = engines[0]
+        e0._ck(e0.lib.fe_step_batch(Engine._handles(engines), len(engines), int(f0), int(f_global0), int(n), int(bool(act))))
+
+    @staticmethod
+    def step_grad_batch(engines, f0, f_global0, n, act):
+        e0 = engines[0]
+        e0._ck(e0.lib.fe_step_grad_batch(Engine._handles(engines), len(engines), int(f0), int(f_global0), int(n), int(bool(act))))
 
     def copy_frame(self, src, dst):
         self._ck(self.lib.fe_copy_frame(self.h, int(src), int(dst)))

@@ -321,6 +321,15 @@ __device__ __forceinline__ PairCtx pair_ctx(const TableP& T, int w) {
     return c;
 }
 
+// -----------------------------------------------------------------------------------------
+// Batched environments: B engines of one process (same device, same kernel variants) step together -- one launch per phase with
+// gridDim.y = B instead of B launches.  A 200k-particle scene is one round of the chip's resident workgroups and each of its
+// launches spends a good part of its time ramping up and draining; B scenes in one launch fill those gaps (fe_step_batch).
+// Every substep kernel is a __device__ body with two entry points: k_x(args) and k_x_b(Batch<args>) picking its env by blockIdx.y.
+// -----------------------------------------------------------------------------------------
+#define FE_MAX_BATCH 8
+template <typename A> struct Batch { A a[FE_MAX_BATCH]; };
+
 // =========================================================================================
 // forward kernels
 // =========================================================================================
@@ -496,7 +505,7 @@ __device__ __forceinline__ void p2g_scatter_tile(const SimP& S, const P2GPrep& q
 // p2g (mpm:331-378) fused with compute_F_tmp + svd, advect_used + process_unused_particles, Injector.act and,
 // on one thread, Effector.move_kernel.  WRITE=false is the backward pass' recompute of grid[f]: scatter only.
 template <bool WRITE, bool GENERAL>
-__global__ __launch_bounds__(WG, GENERAL ? 2 : 4) void k_p2g(SimP S, float* fr_cur, float* fr_next, TableP T,
+__device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, TableP T,
                                             const int* __restrict__ pool_idx, GridW G, AgentP agent, InjectP inj, int act, int f,
                                             GridStore GS) {
     if (!WRITE && GS.cap > 0 && GS.flag[f]) return;      // backward: grid[f] was stored by the forward pass
@@ -569,6 +578,12 @@ __global__ __launch_bounds__(WG, GENERAL ? 2 : 4) void k_p2g(SimP S, float* fr_c
         }
     }
 }
+struct P2GArgs { SimP S; float* fr_cur; float* fr_next; TableP T; const int* pool_idx; GridW G; AgentP agent; InjectP inj; int act; int f; GridStore GS; };
+template <bool WRITE, bool GENERAL>
+__global__ __launch_bounds__(WG, GENERAL ? 2 : 4) void k_p2g(SimP S, float* fr_cur, float* fr_next, TableP T, const int* pool_idx, GridW G, AgentP agent, InjectP inj, int act, int f, GridStore GS) { p2g_body<WRITE, GENERAL>(S, fr_cur, fr_next, T, pool_idx, G, agent, inj, act, f, GS); }
+template <bool WRITE, bool GENERAL>
+__global__ __launch_bounds__(WG, GENERAL ? 2 : 4) void k_p2g_b(Batch<P2GArgs> B) { const P2GArgs& A = B.a[blockIdx.y]; p2g_body<WRITE, GENERAL>(A.S, A.fr_cur, A.fr_next, A.T, A.pool_idx, A.G, A.agent, A.inj, A.act, A.f, A.GS); }
+
 
 // agent.collide at particle level (mpm:418-422; AgentRigid.collide): every effector that carries a mesh, in order,
 // x_tmp = x + dt * new_v re-formed before each collider.  NODE: the same chain at a grid node (mpm:393-395,
@@ -700,7 +715,7 @@ __device__ __forceinline__ int grid_entry(const TableP& T, const int* __restrict
 // KEEP=false (forward): also re-zeroes g_in and the dynamic block flag, so no separate reset_grid pass
 // (mpm:219-223) is needed.  KEEP=true (backward recompute): stores the summed (p, m) in g_in for grid_grad.
 template <bool KEEP, bool STATICS, bool DYN>
-__global__ __launch_bounds__(256) void k_grid(SimP S, TableP T, const float4* __restrict__ slab, float* g_in, float4* g_out,
+__device__ __forceinline__ void grid_body(SimP S, TableP T, const float4* __restrict__ slab, float* g_in, float4* g_out,
                                               const int* __restrict__ blk_list, const int* __restrict__ blk_count, int* blk_flag,
                                               GridStore GS, int f, int* frame_slow, StaticsP ST, AgentP agent) {
     if (KEEP && GS.cap > 0 && GS.flag[f]) return;        // backward: stored by the forward pass
@@ -743,6 +758,12 @@ __global__ __launch_bounds__(256) void k_grid(SimP S, TableP T, const float4* __
         TL(S, 3);
     }
 }
+struct GridArgs { SimP S; TableP T; const float4* slab; float* g_in; float4* g_out; const int* blk_list; const int* blk_count; int* blk_flag; GridStore GS; int f; int* frame_slow; StaticsP ST; AgentP agent; };
+template <bool KEEP, bool STATICS, bool DYN>
+__global__ __launch_bounds__(256) void k_grid(SimP S, TableP T, const float4* slab, float* g_in, float4* g_out, const int* blk_list, const int* blk_count, int* blk_flag, GridStore GS, int f, int* frame_slow, StaticsP ST, AgentP agent) { grid_body<KEEP, STATICS, DYN>(S, T, slab, g_in, g_out, blk_list, blk_count, blk_flag, GS, f, frame_slow, ST, agent); }
+template <bool KEEP, bool STATICS, bool DYN>
+__global__ __launch_bounds__(256) void k_grid_b(Batch<GridArgs> B) { const GridArgs& A = B.a[blockIdx.y]; grid_body<KEEP, STATICS, DYN>(A.S, A.T, A.slab, A.g_in, A.g_out, A.blk_list, A.blk_count, A.blk_flag, A.GS, A.f, A.frame_slow, A.ST, A.agent); }
+
 
 // g2p (mpm:400-426) + advect_kernel (mpm:497-505) for one used particle; TILE: v_out staged in LDS (3 planes)
 template <bool TILE, bool COLLIDE>
@@ -830,7 +851,7 @@ __device__ __forceinline__ void slot_g2p(const SimP& S, const FrameV& cur, const
 
 // COLLIDE: some effector carries a mesh (Rigid): agent.collide runs on the gathered velocity
 template <bool COLLIDE>
-__global__ __launch_bounds__(WG) void k_g2p(SimP S, float* fr_cur, float* fr_next, TableP T, const float4* __restrict__ g_out,
+__device__ __forceinline__ void g2p_body(SimP S, float* fr_cur, float* fr_next, TableP T, const float4* __restrict__ g_out,
                                             int* blk_count, int* slow, AgentP agent, int f) {
     const int tid = threadIdx.x;
     if (blockIdx.x == 0 && tid == 0) *blk_count = 0;          // grid_op was the last reader of the active list
@@ -867,6 +888,12 @@ __global__ __launch_bounds__(WG) void k_g2p(SimP S, float* fr_cur, float* fr_nex
         }
     }
 }
+struct G2PArgs { SimP S; float* fr_cur; float* fr_next; TableP T; const float4* g_out; int* blk_count; int* slow; AgentP agent; int f; };
+template <bool COLLIDE>
+__global__ __launch_bounds__(WG) void k_g2p(SimP S, float* fr_cur, float* fr_next, TableP T, const float4* g_out, int* blk_count, int* slow, AgentP agent, int f) { g2p_body<COLLIDE>(S, fr_cur, fr_next, T, g_out, blk_count, slow, agent, f); }
+template <bool COLLIDE>
+__global__ __launch_bounds__(WG) void k_g2p_b(Batch<G2PArgs> B) { const G2PArgs& A = B.a[blockIdx.y]; g2p_body<COLLIDE>(A.S, A.fr_cur, A.fr_next, A.T, A.g_out, A.blk_count, A.slow, A.agent, A.f); }
+
 
 // =========================================================================================
 // adjoint kernels (hand-derived; closed forms in SURVEY.md Appendix A, validated by the oracle's
@@ -1011,7 +1038,7 @@ __device__ __forceinline__ void g2p_grad_load_tile(const TileO& to, const SimP& 
     }
 }
 
-__global__ __launch_bounds__(WG, 4) void k_g2p_grad(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T,
+__device__ __forceinline__ void g2p_grad_body(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T,
                                                  const float4* __restrict__ g_out, float* gg_out, float4* slab, int* slow,
                                                  GridStore GS, int f, AgentP agent) {
     const int tid = threadIdx.x;
@@ -1072,6 +1099,12 @@ __global__ __launch_bounds__(WG, 4) void k_g2p_grad(SimP S, float* fr_cur, float
         }
     }
 }
+struct G2PGradArgs { SimP S; float* fr_cur; float* Gn_; float* Gc_; TableP T; const float4* g_out; float* gg_out; float4* slab; int* slow; GridStore GS; int f; AgentP agent; };
+
+__global__ __launch_bounds__(WG, 4) void k_g2p_grad(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T, const float4* g_out, float* gg_out, float4* slab, int* slow, GridStore GS, int f, AgentP agent) { g2p_grad_body(S, fr_cur, Gn_, Gc_, T, g_out, gg_out, slab, slow, GS, f, agent); }
+
+__global__ __launch_bounds__(WG, 4) void k_g2p_grad_b(Batch<G2PGradArgs> B) { const G2PGradArgs& A = B.a[blockIdx.y]; g2p_grad_body(A.S, A.fr_cur, A.Gn_, A.Gc_, A.T, A.g_out, A.gg_out, A.slab, A.slow, A.GS, A.f, A.agent); }
+
 
 // agent.collide's adjoint (mpm:418-422 in reverse) as a pass of its own, before k_g2p_grad.  Inlined into k_g2p_grad the
 // forward-mode Jacobian passes cost every particle of every scene with a Rigid effector the kernel's occupancy (256 VGPRs +
@@ -1227,7 +1260,7 @@ __global__ __launch_bounds__(256) void k_collide_grad(SimP S, float* fr_cur, flo
 // grid_op.grad (mpm:539): d/d v_out (slabs of k_g2p_grad + slow-path atomics in gg_out) -> gg_in (d/d v_in, d/d mass);
 // re-zeroes g_in, gg_out and the dynamic flags
 template <bool STATICS, bool DYN>
-__global__ __launch_bounds__(256) void k_grid_grad(SimP S, TableP T, const float4* __restrict__ slab, float* g_in, float* gg_out, float4* gg_in,
+__device__ __forceinline__ void grid_grad_body(SimP S, TableP T, const float4* __restrict__ slab, float* g_in, float* gg_out, float4* gg_in,
                                                    const int* __restrict__ blk_list, const int* __restrict__ blk_count, int* blk_flag,
                                                    GridStore GS, int f, StaticsP ST, AgentP agent, NodeWork* work, int* work_count) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1272,6 +1305,12 @@ __global__ __launch_bounds__(256) void k_grid_grad(SimP S, TableP T, const float
         if (lane == 0 && !is_static) blk_flag[b] = 0;
     }
 }
+struct GridGradArgs { SimP S; TableP T; const float4* slab; float* g_in; float* gg_out; float4* gg_in; const int* blk_list; const int* blk_count; int* blk_flag; GridStore GS; int f; StaticsP ST; AgentP agent; NodeWork* work; int* work_count; };
+template <bool STATICS, bool DYN>
+__global__ __launch_bounds__(256) void k_grid_grad(SimP S, TableP T, const float4* slab, float* g_in, float* gg_out, float4* gg_in, const int* blk_list, const int* blk_count, int* blk_flag, GridStore GS, int f, StaticsP ST, AgentP agent, NodeWork* work, int* work_count) { grid_grad_body<STATICS, DYN>(S, T, slab, g_in, gg_out, gg_in, blk_list, blk_count, blk_flag, GS, f, ST, agent, work, work_count); }
+template <bool STATICS, bool DYN>
+__global__ __launch_bounds__(256) void k_grid_grad_b(Batch<GridGradArgs> B) { const GridGradArgs& A = B.a[blockIdx.y]; grid_grad_body<STATICS, DYN>(A.S, A.T, A.slab, A.g_in, A.gg_out, A.gg_in, A.blk_list, A.blk_count, A.blk_flag, A.GS, A.f, A.ST, A.agent, A.work, A.work_count); }
+
 
 // second half of grid_op.grad for the nodes k_grid_grad<.., DYN> set aside: agent.collide's adjoint at the node (mpm:393-395 in
 // reverse), one row of 16 lanes per node like k_collide_grad, then the statics' chain and the division by the mass.
@@ -1499,7 +1538,7 @@ __device__ __forceinline__ void slot_p2g_grad(const SimP& S, const FrameV& cur, 
 // p2g.grad + svd_grad + compute_F_tmp.grad + AgentInjector.act_kernel.grad + process_unused_particles.grad (mpm:551)
 // + Effector.move_kernel.grad on one thread
 template <bool GENERAL, int MINW>
-__global__ __launch_bounds__(WG, MINW) void k_p2g_grad(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T,
+__device__ __forceinline__ void p2g_grad_body(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T,
                                                  const int* __restrict__ pool_idx,
                                                  const float4* __restrict__ gg_in, int* blk_count, int* slow, AgentP agent,
                                                  InjectP inj, int act, int f) {
@@ -1538,6 +1577,12 @@ __global__ __launch_bounds__(WG, MINW) void k_p2g_grad(SimP S, float* fr_cur, fl
         }
     }
 }
+struct P2GGradArgs { SimP S; float* fr_cur; float* Gn_; float* Gc_; TableP T; const int* pool_idx; const float4* gg_in; int* blk_count; int* slow; AgentP agent; InjectP inj; int act; int f; };
+template <bool GENERAL, int MINW>
+__global__ __launch_bounds__(WG, MINW) void k_p2g_grad(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T, const int* pool_idx, const float4* gg_in, int* blk_count, int* slow, AgentP agent, InjectP inj, int act, int f) { p2g_grad_body<GENERAL, MINW>(S, fr_cur, Gn_, Gc_, T, pool_idx, gg_in, blk_count, slow, agent, inj, act, f); }
+template <bool GENERAL, int MINW>
+__global__ __launch_bounds__(WG, MINW) void k_p2g_grad_b(Batch<P2GGradArgs> B) { const P2GGradArgs& A = B.a[blockIdx.y]; p2g_grad_body<GENERAL, MINW>(A.S, A.fr_cur, A.Gn_, A.Gc_, A.T, A.pool_idx, A.gg_in, A.blk_count, A.slow, A.agent, A.inj, A.act, A.f); }
+
 
 // =========================================================================================
 // block sort (counting sort by 4^3 block of the stencil base)
@@ -2188,7 +2233,7 @@ struct FeEngine {
     int loss_steps = 0; float *tgt = nullptr, *chamfer = nullptr, *step_loss = nullptr;
     size_t bytes = 0;
     std::string err;
-    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr;
+    hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_batch = nullptr;
     // per-kernel profiling
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev; std::vector<int> prof_kid; size_t prof_used = 0;
@@ -2518,6 +2563,122 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act) {
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// batched environments (fe_step_batch / fe_step_grad_batch): see "Batched environments" above the kernels
+// ---------------------------------------------------------------------------------------------------------------
+// The launches of a batch need one variant of every kernel and one grid geometry: liquid-only or not alike, no SDF colliders, no
+// mesh effectors, no MAT_RIGID bodies (those scenes step one engine at a time: fe_step_batch falls back to a loop).
+bool batchable(FeEngine** hs, int B) {
+    if (B < 2 || B > FE_MAX_BATCH) return false;
+    for (int i = 0; i < B; i++) {
+        FeEngine* h = hs[i];
+        if (h->device != hs[0]->device || h->n != hs[0]->n || h->L != hs[0]->L || h->all_simple_liquid != hs[0]->all_simple_liquid ||
+            h->sort_interval != hs[0]->sort_interval || !h->statics_host.empty() || h->has_mesh_effector || h->has_rigid || h->prof_fine ||
+            (h->gs_cap > 0) != (hs[0]->gs_cap > 0)) return false;
+        for (int j = 0; j < i; j++) if (hs[j] == h) return false;
+    }
+    return true;
+}
+inline dim3 wgrid_b(FeEngine** hs, int B) { unsigned g = 0; for (int i = 0; i < B; i++) g = std::max(g, wgrid(hs[i]).x); return dim3(g, B); }
+
+int substep_fwd_batch(FeEngine** hs, int B, int f, int f_global, int act) {
+    FeEngine* h0 = hs[0];
+    Batch<P2GArgs> bp; Batch<GridArgs> bg; Batch<G2PArgs> bq;
+    for (int i = 0; i < B; i++) {
+        FeEngine* h = hs[i];
+        h->gs_host_valid = false;
+        InjectP inj;
+        if (make_inject(h, f, f_global, act, true, inj)) return 1;
+        if (h->sort_interval > 0 && f % h->sort_interval == 0 && sort_frame(h, f)) return 1;
+        h->tbl_of_frame[f + 1] = h->tbl_of_frame[f];
+        use_static_table(h, h->tbl_of_frame[f]);
+        const TableP T = h->tableP(h->tbl_of_frame[f]);
+        const AgentP ag = agent_params(h);
+        bp.a[i] = P2GArgs{h->S, h->frame(f), h->frame(f + 1), T, h->pool_idx, grid_w(h), ag, inj, act, f, grid_store(h)};
+        bg.a[i] = GridArgs{h->S, T, h->slab, h->g_in, h->g_out, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f, h->frame_slow_dev, statics_p(h), ag};
+        bq.a[i] = G2PArgs{h->S, h->frame(f), h->frame(f + 1), T, h->g_out, h->blk_count, h->slow_dev, ag, f};
+    }
+    prof_begin(h0, KID_P2G);
+    if (h0->all_simple_liquid) hipLaunchKernelGGL((k_p2g_b<true, false>), wgrid_b(hs, B), dim3(WG), 0, h0->stream, bp);
+    else hipLaunchKernelGGL((k_p2g_b<true, true>), wgrid_b(hs, B), dim3(WG), 0, h0->stream, bp);
+    prof_end(h0);
+    prof_begin(h0, KID_GRID);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_b<false, false, false>), dim3(ggrid(h0).x, B), dim3(256), 0, h0->stream, bg);
+    prof_end(h0);
+    prof_begin(h0, KID_G2P);
+    hipLaunchKernelGGL(k_g2p_b<false>, wgrid_b(hs, B), dim3(WG), 0, h0->stream, bq);
+    prof_end(h0);
+    return 0;
+}
+
+int substep_bwd_batch(FeEngine** hs, int B, int f, int f_global, int act) {
+    FeEngine* h0 = hs[0];
+    Batch<P2GArgs> bp; Batch<GridArgs> bg; Batch<G2PGradArgs> bq; Batch<GridGradArgs> bgg; Batch<P2GGradArgs> bpg;
+    const InjectP noinj = {0, 0, 0, 0};
+    bool all_stored = true;
+    for (int i = 0; i < B; i++) {
+        FeEngine* h = hs[i];
+        InjectP inj;
+        if (make_inject(h, f, f_global, act, false, inj)) return 1;
+        const int t = h->tbl_of_frame[f];
+        if (reorder_grad(h, (f + 1) & 1, t)) return 1;
+        use_static_table(h, t);
+        const TableP T = h->tableP(t);
+        const AgentP ag = agent_params(h);
+        if (h->gs_cap > 0 && !h->gs_host_valid) {
+            h->gs_host.resize(h->L + 1);
+            HIPCK(h, hipMemcpyAsync(h->gs_host.data(), h->gs_flag, sizeof(int) * (h->L + 1), hipMemcpyDeviceToHost, h->stream));
+            HIPCK(h, hipStreamSynchronize(h->stream));
+            h->gs_host_valid = true;
+        }
+        all_stored = all_stored && h->gs_cap > 0 && h->gs_host[f] != 0;
+        bp.a[i] = P2GArgs{h->S, h->frame(f), h->frame(f + 1), T, h->pool_idx, grid_w(h), ag, noinj, 0, f, grid_store(h)};
+        bg.a[i] = GridArgs{h->S, T, h->slab, h->g_in, h->g_out, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f, h->frame_slow_dev, statics_p(h), ag};
+        bq.a[i] = G2PGradArgs{h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag};
+        bgg.a[i] = GridGradArgs{h->S, T, h->slab, h->g_in, h->gg_out, h->gg_in, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f, statics_p(h), ag, h->node_work, h->node_work_count};
+        bpg.a[i] = P2GGradArgs{h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->pool_idx, h->gg_in, h->blk_count, h->slow_dev, ag, inj, act, f};
+        h->gtbl[f & 1] = t;
+    }
+    if (!all_stored) {                                    // (the kernels of an env whose frame is stored return at once)
+        prof_begin(h0, KID_P2G_RE);
+        if (h0->all_simple_liquid) hipLaunchKernelGGL((k_p2g_b<false, false>), wgrid_b(hs, B), dim3(WG), 0, h0->stream, bp);
+        else hipLaunchKernelGGL((k_p2g_b<false, true>), wgrid_b(hs, B), dim3(WG), 0, h0->stream, bp);
+        prof_end(h0);
+        prof_begin(h0, KID_GRID_KEEP);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_b<true, false, false>), dim3(ggrid(h0).x, B), dim3(256), 0, h0->stream, bg);
+        prof_end(h0);
+    }
+    prof_begin(h0, KID_G2P_GRAD);
+    hipLaunchKernelGGL(k_g2p_grad_b, wgrid_b(hs, B), dim3(WG), 0, h0->stream, bq);
+    prof_end(h0);
+    prof_begin(h0, KID_GRID_GRAD);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_grad_b<false, false>), dim3(ggrid(h0).x, B), dim3(256), 0, h0->stream, bgg);
+    prof_end(h0);
+    prof_begin(h0, KID_P2G_GRAD);
+    if (h0->all_simple_liquid) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_p2g_grad_b<false, 4>), wgrid_b(hs, B), dim3(WG), 0, h0->stream, bpg);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_p2g_grad_b<true, 1>), wgrid_b(hs, B), dim3(WG), 0, h0->stream, bpg);
+    prof_end(h0);
+    return 0;
+}
+
+// All engines of a batch work on the leader's stream for the duration of the call: it first waits for whatever the others have
+// queued on their own streams, and they wait for it afterwards.
+struct BatchStreams {
+    FeEngine** hs; int B; std::vector<hipStream_t> own;
+    BatchStreams(FeEngine** hs_, int B_) : hs(hs_), B(B_), own(B_) {
+        for (int i = 0; i < B; i++) own[i] = hs[i]->stream;
+        for (int i = 1; i < B; i++) {
+            (void)hipEventRecord(hs[i]->ev_batch, own[i]);
+            (void)hipStreamWaitEvent(own[0], hs[i]->ev_batch, 0);
+            hs[i]->stream = own[0];
+        }
+    }
+    ~BatchStreams() {
+        (void)hipEventRecord(hs[0]->ev_batch, own[0]);
+        for (int i = 1; i < B; i++) { hs[i]->stream = own[i]; (void)hipStreamWaitEvent(own[i], hs[0]->ev_batch, 0); }
+    }
+};
+
 int check_async(FeEngine* h) {
     HIPCK(h, hipGetLastError());
     return 0;
@@ -2638,7 +2799,8 @@ FeEngine* fe_create(const FeConfig* cfg) {
         if (hipMemcpyOnStream(h, h->tables[0].pid, id.data(), sizeof(int) * h->Np, hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy failed");
         if (hipMemcpyOnStream(h, h->tables[0].slot_of_pid, id.data(), sizeof(int) * h->Np, hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy failed");
     }
-    if (hipEventCreate(&h->ev_t0) != hipSuccess || hipEventCreate(&h->ev_t1) != hipSuccess) return fail("hipEventCreate failed");
+    if (hipEventCreate(&h->ev_t0) != hipSuccess || hipEventCreate(&h->ev_t1) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_batch, hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate failed");
     if (hipStreamSynchronize(h->stream) != hipSuccess) return fail("device initialisation failed");
     return h;
 }
@@ -2664,6 +2826,7 @@ void fe_destroy(FeEngine* h) {
     for (auto e : h->prof_ev) (void)hipEventDestroy(e);
     if (h->ev_t0) (void)hipEventDestroy(h->ev_t0);
     if (h->ev_t1) (void)hipEventDestroy(h->ev_t1);
+    if (h->ev_batch) (void)hipEventDestroy(h->ev_batch);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -2786,6 +2949,32 @@ int fe_step_grad(FeEngine* h, int f0, int f_global0, int n, int act) {
     FE_ENTRY(h);
     if (f0 < 0 || f0 + n > h->L) FAIL(h, "step frames out of range");
     for (int i = n - 1; i >= 0; i--) if (substep_bwd(h, f0 + i, f_global0 + i, act)) return 1;
+    return check_async(h);
+}
+int fe_step_batch(FeEngine** hs, int n_env, int f0, int f_global0, int n, int act) {
+    if (!hs || n_env < 1) return 1;
+    FeEngine* h = hs[0];
+    FE_ENTRY(h);
+    if (!batchable(hs, n_env)) {                              // scenes that cannot share launches: one engine after the other
+        for (int e = 0; e < n_env; e++) if (fe_step(hs[e], f0, f_global0, n, act)) { h->err = hs[e]->err; return 1; }
+        return 0;
+    }
+    if (f0 < 0 || f0 + n > h->L) FAIL(h, "step frames out of range");
+    BatchStreams bs(hs, n_env);
+    for (int i = 0; i < n; i++) if (substep_fwd_batch(hs, n_env, f0 + i, f_global0 + i, act)) { for (int e = 1; e < n_env; e++) if (!hs[e]->err.empty()) h->err = hs[e]->err; return 1; }
+    return check_async(h);
+}
+int fe_step_grad_batch(FeEngine** hs, int n_env, int f0, int f_global0, int n, int act) {
+    if (!hs || n_env < 1) return 1;
+    FeEngine* h = hs[0];
+    FE_ENTRY(h);
+    if (!batchable(hs, n_env)) {
+        for (int e = 0; e < n_env; e++) if (fe_step_grad(hs[e], f0, f_global0, n, act)) { h->err = hs[e]->err; return 1; }
+        return 0;
+    }
+    if (f0 < 0 || f0 + n > h->L) FAIL(h, "step frames out of range");
+    BatchStreams bs(hs, n_env);
+    for (int i = n - 1; i >= 0; i--) if (substep_bwd_batch(hs, n_env, f0 + i, f_global0 + i, act)) { for (int e = 1; e < n_env; e++) if (!hs[e]->err.empty()) h->err = hs[e]->err; return 1; }
     return check_async(h);
 }
 

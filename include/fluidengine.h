@@ -117,6 +117,12 @@ int fe_substep_grad(FeEngine* h, int f, int f_global, int act);
  * fe_step walks f0, f0+1, ...; fe_step_grad walks f0+n-1 down to f0. */
 int fe_step(FeEngine* h, int f0, int f_global0, int n, int act);
 int fe_step_grad(FeEngine* h, int f0, int f_global0, int n, int act);
+/* Batched environments (BASELINE's "batched envs"; the reference steps one env per process, fluidlab/optimizer/solver.py:23-59):
+ * the same n substeps for n_env engines of this process in lockstep -- same frame indices, same `act`.  Engines on one device
+ * whose scenes use the same kernel variants (no SDF colliders / mesh effectors / MAT_RIGID bodies) share ONE launch per phase
+ * (gridDim.y = n_env); any other set of engines is stepped one after the other.  Results are those of the individual calls. */
+int fe_step_batch(FeEngine** hs, int n_env, int f0, int f_global0, int n, int act);
+int fe_step_grad_batch(FeEngine** hs, int n_env, int f0, int f_global0, int n, int act);
 
 /* ---- state I/O: mpm:555-609, 646-719 ---------------------------------- */
 /* NULL pointers are skipped.  x,v [N,3]; C,F [N,3,3]; used [N] i32. */

@@ -1641,6 +1641,14 @@ int fe_step_grad(FeEngine* h, int f0, int f_global0, int n, int act) {
     for (int i = n - 1; i >= 0; i--) if (fe_substep_grad(h, f0 + i, f_global0 + i, act)) return 1;
     return 0;
 }
+int fe_step_batch(FeEngine** hs, int n_env, int f0, int f_global0, int n, int act) {      /* include/fluidengine.h: lockstep envs, one after the other here */
+    for (int e = 0; e < n_env; e++) if (fe_step(hs[e], f0, f_global0, n, act)) return 1;
+    return 0;
+}
+int fe_step_grad_batch(FeEngine** hs, int n_env, int f0, int f_global0, int n, int act) {
+    for (int e = 0; e < n_env; e++) if (fe_step_grad(hs[e], f0, f_global0, n, act)) return 1;
+    return 0;
+}
 
 int fe_get_frame(FeEngine* h, int f, fe_real* x, fe_real* v, fe_real* C, fe_real* F, int* used) {
     CHECK_FRAME(h, f);

@@ -3,7 +3,7 @@
 TAG=$1; PMC=$2; shift; shift
 OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
-(cd /tmp && timeout 600 rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d $OUT/pmc -o pmc -- python $OLDPWD/bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $OUT/pmc.log 2>&1)
+(cd /tmp && timeout 600 rocprofv3 --pmc $PMC --kernel-trace --output-format csv -d $OUT/pmc -o pmc -- python $OLDPWD/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras "$@" > $OUT/pmc.log 2>&1)
 f=$(find $OUT/pmc -name "*counter_collection.csv" | head -1)
 python - "$f" <<'PY' | tee $OUT/pmc_summary.txt
 import csv, sys, collections

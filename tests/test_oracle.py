@@ -428,3 +428,25 @@ def test_errors_are_reported_not_fatal(oracle64):
         eng.substep(0, 0, 0)
     with pytest.raises(FeEngineError, match='out of range'):
         eng.substep(4, 4, 0)
+
+
+def test_batch_entry_points_step_every_engine(oracle64):
+    """fe_step_batch / fe_step_grad_batch on the oracle: the engines of the list are stepped in lockstep (one after the other here)"""
+    scenes = [S.water_block(n_grid=16, n_particles=600, seed=sd) for sd in (0, 1)]
+    L = 6
+    solo = []
+    for sc in scenes:
+        eng = S.make_engine(oracle64, sc, max_substeps_local=L)
+        eng.step(0, 0, L, 0)
+        solo.append(S.get_state(eng, L)['x'])
+        eng.close()
+    engs = [S.make_engine(oracle64, sc, max_substeps_local=L) for sc in scenes]
+    type(engs[0]).step_batch(engs, 0, 0, L, 0)
+    cot = S.random_cotangent(600)
+    for e in engs:
+        e.reset_grad(); e.add_grad(L, cot['gx'], cot['gv'], cot['gC'], cot['gF'])
+    type(engs[0]).step_grad_batch(engs, 0, 0, L, 0)
+    for e, x0 in zip(engs, solo):
+        assert np.array_equal(S.get_state(e, L)['x'], x0)
+        assert np.abs(e.get_grad(0)[0]).max() > 0
+        e.close()
