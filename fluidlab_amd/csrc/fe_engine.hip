@@ -193,39 +193,35 @@ __device__ __forceinline__ int xcd_item(int wg, int per, int on) { return on ? (
 
 // -----------------------------------------------------------------------------------------
 // Wavefront aggregation of scatter contributions.  After the cell-level sort, lanes holding particles of one
-// cell are adjacent and write the same 27 nodes.  A segmented inclusive scan over the 64 lanes (DPP row_shr
-// 1/2/4/8 + row_bcast15/31: pure VALU, no LDS traffic) sums each run of equal keys; only the last lane of a run
-// issues the LDS atomic.  Measured motivation (profiles/r01e): ~30 us of a 44 us P2G launch were ds_add_f64.
+// cell are adjacent and write the same 27 nodes.  A segmented inclusive scan over each 16-lane DPP row (row_shr
+// 1/2/4/8: pure VALU, no LDS traffic) sums each run of equal keys; only the last lane of a run issues the LDS
+// atomic.  Measured motivation (profiles/r01e): ~30 us of a 44 us P2G launch were ds_add_f64.
 // Correct for ANY lane order: only *adjacent* equal keys are merged.
+// Runs are cut at the row boundaries: carrying them across with row_bcast:15 / :31 costs two more DPP steps per
+// value and saves at most 3 atomics per wave and node -- measured (round 2, A/B on the same box): evolving block
+// 5,786 -> 5,824 pairs/s, 1M-particle block 3,167 -> 3,246, p2g 74.2 -> 71.6 us, g2p_grad 70.4 -> 67.1 us.
+// (Cutting at 8-lane groups as well was measured slower in round 1: p2g 21.0 -> 25.3 us.)
 // -----------------------------------------------------------------------------------------
-struct SegScan { float f1, f2, f4, f8, f15, f31; bool tail; };
+struct SegScan { float f1, f2, f4, f8; bool tail; };
 
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float dpp_mov(float v) {      // lanes without a source get 0
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
-}
 // must be executed by all 64 lanes of the wave
 __device__ __forceinline__ SegScan seg_setup(int key) {
     const int lane = threadIdx.x & 63;
     const int prev = __shfl_up(key, 1, 64);
-    const bool is_head = lane == 0 || key != prev;
+    const bool is_head = (lane & 15) == 0 || key != prev;
     const unsigned long long mask = __ballot(is_head);
     const unsigned long long lower = mask & ((2ull << lane) - 1ull);       // run heads at or before this lane
     const int head = 63 - __clzll((long long)lower);
-    const int dist = lane - head, row = lane >> 4;
+    const int dist = lane - head;
     SegScan sc;
     sc.f1 = dist >= 1 ? 1.f : 0.f; sc.f2 = dist >= 2 ? 1.f : 0.f; sc.f4 = dist >= 4 ? 1.f : 0.f; sc.f8 = dist >= 8 ? 1.f : 0.f;
-    sc.f15 = ((row & 1) && head <= row * 16 - 1) ? 1.f : 0.f;             // run reaches back into the previous row
-    sc.f31 = (row >= 2 && head <= 31) ? 1.f : 0.f;                         // ... into the first half of the wave
     sc.tail = lane == 63 || ((mask >> (lane + 1)) & 1ull);                 // last lane of its run
     return sc;
 }
-// Four independent values at once, one v_fmac_f32_dpp per step and value (the compiler's own lowering of seg_scan
-// is v_mov_b32_dpp + v_fma_f32).  A DPP read of a VGPR written by the previous VALU needs 2 wait states, which
+// Four independent values at once, one v_fmac_f32_dpp per step and value (the compiler's own lowering is
+// v_mov_b32_dpp + v_fma_f32).  A DPP read of a VGPR written by the previous VALU needs 2 wait states, which
 // inline asm has to provide itself: the 4 chains are independent, so three other VALU instructions always sit between
 // the write of a value in one step and its DPP read in the next; only the entry needs an s_nop.
-// (Cutting runs at 8-lane groups to halve the scan was measured slower: the extra ds_add_f64 lane-ops cost more than
-// the 36 v_fmac_dpp saved per 3 nodes -- p2g 21.0 -> 25.3 us.)
 #define SEG_STEP4(ctrl, flag) \
     asm volatile("v_fmac_f32_dpp %0, %0, %4 " ctrl " bound_ctrl:0\n\t" \
                  "v_fmac_f32_dpp %1, %1, %4 " ctrl " bound_ctrl:0\n\t" \
@@ -237,8 +233,6 @@ __device__ __forceinline__ void seg_scan4(const SegScan& sc, float& a, float& b,
     SEG_STEP4("row_shr:2 row_mask:0xf bank_mask:0xf", sc.f2);
     SEG_STEP4("row_shr:4 row_mask:0xf bank_mask:0xf", sc.f4);
     SEG_STEP4("row_shr:8 row_mask:0xf bank_mask:0xf", sc.f8);
-    SEG_STEP4("row_bcast:15 row_mask:0xa bank_mask:0xf", sc.f15);
-    SEG_STEP4("row_bcast:31 row_mask:0xc bank_mask:0xf", sc.f31);
 }
 // three values (the adjoint scatter of g2p has no mass component)
 #define SEG_STEP3(ctrl, flag) \
@@ -252,17 +246,6 @@ __device__ __forceinline__ void seg_scan3(const SegScan& sc, float& a, float& b,
     SEG_STEP3("row_shr:2 row_mask:0xf bank_mask:0xf", sc.f2);
     SEG_STEP3("row_shr:4 row_mask:0xf bank_mask:0xf", sc.f4);
     SEG_STEP3("row_shr:8 row_mask:0xf bank_mask:0xf", sc.f8);
-    SEG_STEP3("row_bcast:15 row_mask:0xa bank_mask:0xf", sc.f15);
-    SEG_STEP3("row_bcast:31 row_mask:0xc bank_mask:0xf", sc.f31);
-}
-__device__ __forceinline__ float seg_scan(const SegScan& sc, float v) {
-    v = fmaf(sc.f1, dpp_mov<0x111, 0xf>(v), v);          // row_shr:1
-    v = fmaf(sc.f2, dpp_mov<0x112, 0xf>(v), v);          // row_shr:2
-    v = fmaf(sc.f4, dpp_mov<0x114, 0xf>(v), v);          // row_shr:4
-    v = fmaf(sc.f8, dpp_mov<0x118, 0xf>(v), v);          // row_shr:8
-    v = fmaf(sc.f15, dpp_mov<0x142, 0xa>(v), v);         // row_bcast:15 -> rows 1,3
-    v = fmaf(sc.f31, dpp_mov<0x143, 0xc>(v), v);         // row_bcast:31 -> rows 2,3
-    return v;
 }
 
 struct TableP {
@@ -996,7 +979,7 @@ __device__ __forceinline__ void g2p_grad_slot_global(const SimP& S, const FrameV
     stencil_make(x, S.inv_dx, st);
     if (!stencil_inside(st, S.n)) { float4 gx = Gn.A0[s]; Gc.A0[s] = make_float4(gx.x, gx.y, gx.z, 0.f); return; }
     SegScan none;
-    none.f1 = none.f2 = none.f4 = none.f8 = none.f15 = none.f31 = 0.f; none.tail = true;
+    none.f1 = none.f2 = none.f4 = none.f8 = 0.f; none.tail = true;
     used_particle_g2p_grad<false>(S, Gn, Gc, s, 0, st, V, gg_out, true, none);
 }
 

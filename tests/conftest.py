@@ -40,5 +40,8 @@ def oracle32():
 @pytest.fixture(scope='session')
 def hiplib():
     """The product library; only usable on a GPU box."""
-    from fluidlab_amd._capi import load_hip
-    return load_hip()
+    from fluidlab_amd import _capi
+    alt = os.environ.get('FE_TEST_HIP_LIB')          # A/B builds of the engine (scripts/ab_bench.py): tests only, never the product path
+    if alt:
+        _capi.HIP_LIB_PATH = os.path.abspath(alt)
+    return _capi.load_hip()
