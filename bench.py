@@ -284,7 +284,7 @@ def run_replicas(args, rank, local_rank, world):
     from fluidlab_amd.utils.config import load_config
     dev = 0 if args.one_device else local_rank
     torch.cuda.set_device(dev)
-    par = EnvParallel(backend=args.dist_backend, device=dev)          # init_process_group('nccl' = RCCL), one rank per GPU
+    par = EnvParallel(backend=args.dist_backend, device=dev, always=True)       # init_process_group('nccl' = RCCL), one rank per GPU
     assert par.world_size == world and par.dist is not None and par.dist.get_world_size() == world
     elib = _capi.load_hip()
     kw = dict(C4_SCENES[args.c4_scene], engine_lib=elib, device=dev)
@@ -395,6 +395,7 @@ def main():
     ap.add_argument('--no-extras', action='store_true')
     ap.add_argument('--dist-backend', default='nccl', help="'gloo' + --one-device: exercise the N>1 path on a 1-GPU box (tests)")
     ap.add_argument('--one-device', action='store_true', help='tests only: every rank uses GPU 0')
+    ap.add_argument('--replicas', action='store_true', help='run the N > 1 workload (LatteArt replicas + all-reduce) even with one rank')
     ap.add_argument('--c4-scene', default='config3', choices=sorted(C4_SCENES))
     ap.add_argument('--c4-lr-scale', type=float, default=0.1)
     ap.add_argument('--opt', action='append', default=[], help='engine option name=value (tuning sweeps, N=1)')
@@ -408,7 +409,7 @@ def main():
         os.execvp(cmd[0], cmd)
     if args.gpus != world:
         sys.exit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} (or without a launcher)')
-    if world == 1:
+    if world == 1 and not args.replicas:
         args.steps = 100 if args.steps is None else args.steps            # 10,000 substep pairs: about a second of timed region
         args.warmup = 5 if args.warmup is None else args.warmup
         run_single(args)

@@ -69,7 +69,7 @@ ABI_SYMBOLS = [
     'fe_eff_get_vw', 'fe_eff_set_vw', 'fe_eff_get_sr', 'fe_eff_set_sr', 'fe_eff_set_action', 'fe_eff_set_action_grad',
     'fe_eff_apply_action_p', 'fe_eff_apply_action_p_grad', 'fe_eff_get_action_grad',
     'fe_agent_copy_frame', 'fe_agent_copy_grad', 'fe_agent_reset_grad_till_frame', 'fe_agent_set_collector', 'fe_mesh_sdf', 'fe_add_grad_dev', 'fe_loss_alloc', 'fe_loss_set_target',
-    'fe_loss_clear', 'fe_loss_step', 'fe_loss_step_grad', 'fe_loss_get', 'fe_get_stats',
+    'fe_loss_clear', 'fe_loss_step', 'fe_loss_step_grad', 'fe_loss_get', 'fe_get_stats', 'fe_get_work_stats',
     'fe_smoke_create', 'fe_smoke_step', 'fe_smoke_step_grad', 'fe_smoke_get_frame', 'fe_smoke_set_frame', 'fe_smoke_get_grad',
     'fe_smoke_add_grad', 'fe_smoke_copy_frame', 'fe_smoke_copy_grad', 'fe_smoke_reset_grad', 'fe_smoke_reset_grad_till_frame',
     'fe_timer_start', 'fe_timer_stop_ms', 'fe_profile_enable', 'fe_profile_read',
@@ -552,6 +552,15 @@ class Engine:
         st = FeStats()
         self._ck(self.lib.fe_get_stats(self.h, int(f), C.byref(st)))
         return {k: getattr(st, k) for k, _ in FeStats._fields_}
+
+    def get_work_stats(self, f):
+        out = (C.c_longlong * 16)()
+        self._ck(self.lib.fe_get_work_stats(self.h, int(f), out))
+        keys = ('n_items', 'tail_start', 'n_active_blocks', 'n_multi_item_workgroups', 'n_single_item_blocks')
+        d = {k: int(out[i]) for i, k in enumerate(keys)}
+        d['items_by_size'] = {k: int(out[5 + i]) for i, k in enumerate(('1', '2-4', '5-8', '9-16', '17-32', '33-64', '65-128'))}
+        d['n_occupied_blocks'] = int(out[12])
+        return d
 
     def timer_start(self):
         self._ck(self.lib.fe_timer_start(self.h))

@@ -3409,6 +3409,30 @@ int fe_get_stats(FeEngine* h, int f, FeStats* out) {
     out->n_slow_path = slow; out->bytes_state = (long long)h->bytes;
     return check_async(h);
 }
+int fe_get_work_stats(FeEngine* h, int f, long long out[16]) {
+    FE_ENTRY(h);
+    CHECK_FRAME(h, f);
+    for (int i = 0; i < 16; i++) out[i] = 0;
+    const int t = h->tbl_of_frame[f];
+    if (t < 0 || t >= (int)h->tables.size() || !h->tables[t].meta) return 0;
+    int meta[8];
+    HIPCK(h, hipMemcpyAsync(meta, h->tables[t].meta, sizeof(meta), hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    for (int i = 0; i < 5; i++) out[i] = meta[i];
+    std::vector<int4> items((size_t)std::max(meta[0], 0));
+    if (!items.empty()) {
+        HIPCK(h, hipMemcpyAsync(items.data(), h->tables[t].items, sizeof(int4) * items.size(), hipMemcpyDeviceToHost, h->stream));
+        HIPCK(h, hipStreamSynchronize(h->stream));
+    }
+    int last_block = -1;
+    for (const int4& it : items) {
+        const int c = it.z;
+        const int b = c <= 1 ? 0 : c <= 4 ? 1 : c <= 8 ? 2 : c <= 16 ? 3 : c <= 32 ? 4 : c <= 64 ? 5 : 6;
+        out[5 + b]++;
+        if (it.x != last_block) { out[12]++; last_block = it.x; }
+    }
+    return check_async(h);
+}
 #ifdef FE_TIMELINE
 // profiling builds only (not part of include/fluidengine.h): the stamps of the last launch of kernel `kid` (order of KNAMES)
 int fe_timeline_read(FeEngine* h, int kid, unsigned long long* out) {

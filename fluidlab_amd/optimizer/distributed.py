@@ -11,16 +11,22 @@ import numpy as np
 
 
 class EnvParallel:
-    def __init__(self, backend=None, device=None):
+    def __init__(self, backend=None, device=None, always=False):
         self.world_size = int(os.environ.get('WORLD_SIZE', '1'))
         self.rank = int(os.environ.get('RANK', '0'))
         self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
         self.dist = None
         self.device = device
-        if self.world_size > 1:
+        if self.world_size > 1 or always:             # always: a process group even for one rank (bench.py --replicas)
             import torch
             import torch.distributed as dist
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            if 'MASTER_PORT' not in os.environ:       # one rank without a launcher
+                import socket
+                with socket.socket() as sk:
+                    sk.bind(('127.0.0.1', 0))
+                    os.environ['MASTER_PORT'] = str(sk.getsockname()[1])
+                os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
             if backend is None:
                 backend = 'nccl' if torch.cuda.is_available() else 'gloo'
             self.backend = backend

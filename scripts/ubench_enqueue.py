@@ -1,16 +1,16 @@
-"""How long does the host take to enqueue a chunk of substeps, against how long the GPU takes to run it?"""
+"""How long does the host take to enqueue a window of substeps, against how long the GPU takes to run it?  (evolving block of bench.py)"""
 import sys, time
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import bench
 from fluidlab_amd._capi import load_hip
-eng, sc = bench.build_engine(load_hip(), 0)
-for _ in range(3): bench.one_step(eng, bench.CHUNK)
+eng, sc = bench.build_block(load_hip(), 0)
+for _ in range(3): bench.window_step(eng, bench.CHUNK)
 eng.sync()
 for back in (False, True):
     te = tg = 0.0
     for _ in range(10):
         eng.sync(); t0 = time.perf_counter()
-        bench.one_step(eng, bench.CHUNK, backward=back)
+        bench.window_step(eng, bench.CHUNK, backward=back)
         t1 = time.perf_counter(); eng.sync(); t2 = time.perf_counter()
         te += t1 - t0; tg += t2 - t0
     n = 10 * bench.CHUNK

@@ -38,3 +38,15 @@ def test_bench_gpus_2_spawns_two_ranks_and_all_reduces_the_action_gradient():
     assert all(v == v and v > 0 for v in out['loss_mean_over_envs'])
     assert out['config']['substep_pairs_per_step_per_rank'] == 3300 and out['config']['action_grad_shape'] == [251, 3]
     assert 0.2 < out['weak_scaling_efficiency_vs_rank_compute'] <= 1.05
+
+
+@pytest.mark.gpu
+def test_bench_replica_path_over_rccl_with_one_rank():
+    """The N > 1 workload on the real collective backend: one rank, `nccl` (= RCCL) process group bound to the device, the action
+    gradient and the timing reductions as device tensors.  What the one-GPU box can show of the path the driver runs on eight."""
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--replicas', '--steps', '1', '--warmup', '1', '--c4-scene', 'as_shipped']
+    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert out['config']['dist_backend'] == 'nccl' and out['config']['rccl_world_size'] == 1 and out['n_gpus'] == 1
+    assert out['value'] > 0 and out['passes_skipped_nonfinite_grad'] == 0 and out['allreduce_us']['warm_latency'] > 0
