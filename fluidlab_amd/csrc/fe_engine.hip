@@ -333,7 +333,50 @@ __device__ void effector_move(const EffP& e, int f) {
 
 // Per-frame store of the forward grid (summed (p, m) and v_out of every static active block), so that the backward
 // pass can skip the recompute of P2G + grid_op when the frame had no slow-path particle (gs_flag[f] == 1).
-struct GridStore { float4* data; int* flag; int cap; };      // data: [(L+1) * cap * 128] float4, 64 (p,m) then 64 v_out per block
+struct GridStore { float4* data; int* flag; int cap;         // data: [(L+1) * cap * 128] float4, 64 (p,m) then 64 v_out per block
+    // Which entries of the order's active list got anything this substep.  The list holds every block a tile may reach (27 per
+    // occupied block); what the particles actually reach is 40-60 % of it (water flying apart: 9.6k of 23.4k blocks), and the
+    // grid kernels are rounds of a dependent chain per entry.  The scatter kernel marks the entries it deposits into -- every
+    // particle ORs the (at most 8) tile regions of its stencil into its wave's set, one lane per region sets touched[entry] (a
+    // plain byte store; the entry numbers of the item's 27 neighbours are fetched with the item) -- and slow-path atomics set
+    // dirty[entry]: only those blocks have anything in their g_in / gg_out planes to read and re-zero.  A mark is the launch's
+    // stamp (1..255, cyclic; nothing is ever cleared: a stale mark that aliases after 255 launches costs one block of zeros).
+    // k_grid gives every workgroup a range of entries, works on the marked ones, and records them -- live[f][e] beside the stored
+    // grid, cur[e] for the recompute path -- for k_grid_grad: a node without mass has v_out = 0 and passes no adjoint on
+    // (mpm:383), and no particle reads such a node.
+    unsigned char* touched; unsigned char* dirty; unsigned char* live; unsigned char* cur; unsigned char stamp; };
+// tile regions (= neighbour blocks, bit (di+1)*9 + (dj+1)*3 + dk+1) under the 3^3 stencil whose base has tile index lb.
+// Tile index 0 = node 4B-1 (block B-1), 1..4 = block B, 5..7 = block B+1; a base index is 0..5.
+__device__ __forceinline__ int stencil_regions(int lb) {
+    const int lut = 0x26c93;                                    // per base index the 3-bit set {region(t), .., region(t+2)}: 3,2,2,6,6,4
+    const int ax = (lut >> (3 * (lb >> 6))) & 7, ay = (lut >> (3 * ((lb >> 3) & 7))) & 7, az = (lut >> (3 * (lb & 7))) & 7;
+    const int myz = ((ay & 1) ? az : 0) | ((ay & 2) ? az << 3 : 0) | ((ay & 4) ? az << 6 : 0);
+    return ((ax & 1) ? myz : 0) | ((ax & 2) ? myz << 9 : 0) | ((ax & 4) ? myz << 18 : 0);
+}
+// lane n < 27: the active-list entry of neighbour block n of `block` (-1 outside the grid / not on the list)
+__device__ __forceinline__ int neighbour_entry(const int* __restrict__ blk_slot, int nb, int block) {
+    const int lane = threadIdx.x & 63;
+    int e = -1;
+    if (lane < 27) {
+        const int i2 = block / (nb * nb) + lane / 9 - 1, j2 = (block / nb) % nb + (lane / 3) % 3 - 1, k2 = block % nb + lane % 3 - 1;
+        if ((unsigned)i2 < (unsigned)nb && (unsigned)j2 < (unsigned)nb && (unsigned)k2 < (unsigned)nb) e = blk_slot[(i2 * nb + j2) * nb + k2];
+    }
+    return e;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_or(int x) { return x | __builtin_amdgcn_update_dpp(0, x, CTRL, ROW_MASK, 0xf, true); }
+// all lanes of the wave: the union of the lanes' region sets, then one lane per region marks its entry
+__device__ __forceinline__ void touch_regions(int mask, int entry, const GridStore& GS) {
+    mask = dpp_or<0x111, 0xf>(mask); mask = dpp_or<0x112, 0xf>(mask); mask = dpp_or<0x114, 0xf>(mask); mask = dpp_or<0x118, 0xf>(mask);   // row_shr 1 2 4 8
+    mask = dpp_or<0x142, 0xa>(mask); mask = dpp_or<0x143, 0xc>(mask);                                   // row_bcast 15, 31: lane 63 holds the union
+    mask = __builtin_amdgcn_readlane(mask, 63);
+    if (entry >= 0 && ((mask >> (threadIdx.x & 63)) & 1)) GS.touched[entry] = GS.stamp;
+}
+// a slow-path particle deposited into block b with global atomics
+__device__ __forceinline__ void mark_dirty(const GridStore& GS, const int* __restrict__ blk_slot, int b) {
+    const int e = blk_slot[b];
+    if (e >= 0) GS.dirty[e] = GS.stamp;
+}
 
 struct GridW {            // everything a scattering particle needs of the global grid
     float* g_in; float4* slab; int ncell; int* frame_slow; int* blk_flag; int* blk_list; int* blk_count; int* err; int* slow;
@@ -422,7 +465,7 @@ __device__ __forceinline__ void p2g_prepare(const SimP& S, const FrameV& cur, co
 }
 
 // global path: 108 scattered global atomics + active-block marking
-__device__ __forceinline__ void p2g_scatter_global(const SimP& S, const P2GPrep& q, const GridW& G) {
+__device__ __forceinline__ void p2g_scatter_global(const SimP& S, const P2GPrep& q, const GridW& G, const GridStore& GS, const int* __restrict__ blk_slot) {
     const Stencil& st = q.st;
 #pragma unroll 1
     for (int ij = 0; ij < 9; ij++) {
@@ -448,8 +491,11 @@ __device__ __forceinline__ void p2g_scatter_global(const SimP& S, const P2GPrep&
     const int bz0 = st.base[2] >> 2, bz1 = (st.base[2] + 2) >> 2;
     for (int bx = bx0; bx <= bx1; bx++)
         for (int by = by0; by <= by1; by++)
-            for (int bz = bz0; bz <= bz1; bz++)
-                if (mark_block((bx * S.nb + by) * S.nb + bz, G.blk_flag, G.blk_list, G.blk_count)) *G.frame_slow = 1;   // store incomplete for this frame
+            for (int bz = bz0; bz <= bz1; bz++) {
+                const int b = (bx * S.nb + by) * S.nb + bz;
+                if (mark_block(b, G.blk_flag, G.blk_list, G.blk_count)) *G.frame_slow = 1;   // store incomplete for this frame
+                else mark_dirty(GS, blk_slot, b);                                              // a block of the active list
+            }
 }
 
 // tile path, executed by ALL lanes of the wave: contributions of lanes with `in_tile` are summed over runs of equal
@@ -512,6 +558,7 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
             const TileO to = tile_origin(it.x, S.nb);
             const int aofs = pc.ti * 4 * TILE_N;
             TL(S, 1);
+            const int nbr_entry = neighbour_entry(T.blk_slot, S.nb, it.x);      // (in flight together with the particle loads)
             if (pc.live) for (int l = pc.t0; l < 4 * TILE_N; l += pc.nth) s_acc[aofs + l] = 0.0;
             __syncthreads();
             {                                                    // one pass: an item is <= 128 particles, one per lane of the half
@@ -535,8 +582,11 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
                 TL(S, 2);
                 const bool in_tile = lb >= 0;
                 // a wave without any particle skips the 27-node scan altogether; the branch is wave-uniform, as the DPP scan requires
-                if (__any(in_tile)) p2g_scatter_tile(S, q, in_tile, in_tile ? lb : 0, aofs);
-                if (used && q.inside && !in_tile) { atomicAdd(G.slow, 1); p2g_scatter_global(S, q, G); }   // drifted out of the tile
+                if (__any(in_tile)) {
+                    touch_regions(in_tile ? stencil_regions(lb) : 0, nbr_entry, GS);
+                    p2g_scatter_tile(S, q, in_tile, in_tile ? lb : 0, aofs);
+                }
+                if (used && q.inside && !in_tile) { atomicAdd(G.slow, 1); p2g_scatter_global(S, q, G, GS, T.blk_slot); }   // drifted out of the tile
                 if (has && !used && !taken && WRITE) unused_particle_fwd(S, cur, nxt, s, T.pid_of_slot[s], pool_idx, agent, inj, f);
             }
             TL(S, 4);
@@ -555,7 +605,7 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
                     if (WRITE && act && agent.collector && collector_takes(cur, nxt, s, T.info, agent)) continue;
                     P2GPrep q;
                     p2g_prepare<WRITE, GENERAL>(S, cur, nxt, s, T.info, G, q);
-                    if (q.inside) p2g_scatter_global(S, q, G);
+                    if (q.inside) p2g_scatter_global(S, q, G, GS, T.blk_slot);
                 } else if (WRITE) unused_particle_fwd(S, cur, nxt, s, T.pid_of_slot[s], pool_idx, agent, inj, f);
             }
         }
@@ -688,13 +738,26 @@ __device__ __forceinline__ float4 gather_slabs(const SimP& S, const TableP& T, c
     return acc;
 }
 
-// entries of the grid kernels: first the order's static active list, then the dynamic list of slow-path blocks
-__device__ __forceinline__ int grid_entry(const TableP& T, const int* __restrict__ blk_list, int e, int n_static, bool& is_static) {
-    is_static = e < n_static;
-    return is_static ? T.active[e] : blk_list[e - n_static];
+// The grid kernels' share of the active list: every workgroup owns a contiguous range of entries (4 while the list is shorter
+// than the launch has waves), the ranges dealt to the XCDs like the work items (xcd_item).  A workgroup reads the marks of its
+// range 32 entries at a time and its four waves share out the marked ones.
+struct EntryRange { int e0, e1; };
+__device__ __forceinline__ EntryRange entry_range(const SimP& S, int n_static) {
+    const int G = gridDim.x >= 8 ? (int)(gridDim.x & ~7u) : (int)gridDim.x;       // workgroups that take ranges
+    int R = (n_static + G - 1) / G;                                               // entries per workgroup, a multiple of 4
+    R = (R + 3) & ~3;
+    const int n_wg = R > 0 ? (n_static + R - 1) / R : 0;                          // workgroups with work: <= G
+    const int per_xcd = (n_wg + 7) >> 3;                                          // 8 * per_xcd <= G when G is a multiple of 8
+    int wg = blockIdx.x;
+    if (gridDim.x >= 8) wg = (int)blockIdx.x < 8 * per_xcd ? xcd_item(blockIdx.x, per_xcd, S.xcd) : n_wg;
+    EntryRange r;
+    r.e0 = wg * R < n_static ? wg * R : n_static;
+    r.e1 = r.e0 + R < n_static ? r.e0 + R : n_static;
+    return r;
 }
 
-// grid_op (mpm:380-398) over the active 4^3 blocks only; one wave per block.  STATICS: the scene has SDF colliders.
+// grid_op (mpm:380-398) over the 4^3 blocks the scatter reached (GridStore: the marked entries of the order's active list, then
+// the dynamic list of slow-path blocks outside it); one wave per block.  STATICS: the scene has SDF colliders.
 // KEEP=false (forward): also re-zeroes g_in and the dynamic block flag, so no separate reset_grid pass
 // (mpm:219-223) is needed.  KEEP=true (backward recompute): stores the summed (p, m) in g_in for grid_grad.
 template <bool KEEP, bool STATICS, bool DYN>
@@ -704,22 +767,19 @@ __device__ __forceinline__ void grid_body(SimP S, TableP T, const float4* __rest
     if (KEEP && GS.cap > 0 && GS.flag[f]) return;        // backward: stored by the forward pass
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     TL(S, 0);
-    const int n_static = T.meta[2], cnt = n_static + *blk_count;
+    const int n_static = T.meta[2], n_dyn = *blk_count;
     if (!KEEP && blockIdx.x == 0 && threadIdx.x == 0) {
         if (GS.cap > 0) GS.flag[f] = (n_static <= GS.cap && *frame_slow == 0) ? 1 : 0;
         *frame_slow = 0;
     }
-    const int per_xcd = ((cnt + 3) / 4 + 7) >> 3;
-    for (int wg = blockIdx.x; wg < per_xcd * 8; wg += gridDim.x) {
-        const int e = xcd_item(wg, per_xcd, S.xcd) * 4 + wave;
-        if (e >= cnt) continue;
-        bool is_static;
-        const int b = grid_entry(T, blk_list, e, n_static, is_static);
+    // one block: is_static = an entry of the active list (slab gather, store slot e); dirty = its g_in planes hold slow-path atomics
+    auto one_block = [&](int e, int b, bool is_static, bool touched, bool dirty) {
         const int c = (b << 6) | lane;
         const int bi = b / (S.nb * S.nb), bj = (b / S.nb) % S.nb, bk = b % S.nb;
         TL(S, 1);
-        float4 gi = make_float4(g_in[c], g_in[S.ncell + c], g_in[2 * S.ncell + c], g_in[3 * S.ncell + c]);     // slow-path atomics
-        if (is_static) { const float4 t = gather_slabs(S, T, slab, bi, bj, bk, lane); gi.x += t.x; gi.y += t.y; gi.z += t.z; gi.w += t.w; }
+        float4 gi = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (dirty) gi = make_float4(g_in[c], g_in[S.ncell + c], g_in[2 * S.ncell + c], g_in[3 * S.ncell + c]);
+        if (touched) { const float4 t = gather_slabs(S, T, slab, bi, bj, bk, lane); gi.x += t.x; gi.y += t.y; gi.z += t.z; gi.w += t.w; }
         float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
         if (gi.w > FE_EPS) TL(S, 2);
         if (gi.w > FE_EPS) {
@@ -733,13 +793,33 @@ __device__ __forceinline__ void grid_body(SimP S, TableP T, const float4* __rest
                 float4* dst = GS.data + ((size_t)f * GS.cap + e) * 128;
                 dst[lane] = gi; dst[64 + lane] = out;
             }
-            g_in[c] = 0.f; g_in[S.ncell + c] = 0.f; g_in[2 * S.ncell + c] = 0.f; g_in[3 * S.ncell + c] = 0.f;
+            if (dirty) { g_in[c] = 0.f; g_in[S.ncell + c] = 0.f; g_in[2 * S.ncell + c] = 0.f; g_in[3 * S.ncell + c] = 0.f; }
             if (lane == 0 && !is_static) blk_flag[b] = 0;
         } else {
             g_in[c] = gi.x; g_in[S.ncell + c] = gi.y; g_in[2 * S.ncell + c] = gi.z; g_in[3 * S.ncell + c] = gi.w;
         }
         TL(S, 3);
+    };
+    const EntryRange r = entry_range(S, n_static);
+    for (int base = r.e0; base < r.e1; base += 32) {       // block numbers and marks of 32 entries: one load each
+        const int e = base + (lane & 31);
+        const bool in = e < r.e1;
+        const int blkv = (lane < 32 && in) ? T.active[e] : 0;
+        const unsigned char mk = in ? (lane < 32 ? GS.touched[e] : GS.dirty[e]) : 0;
+        const unsigned long long bal = __ballot(mk == GS.stamp);
+        const unsigned tm = (unsigned)bal, dm = (unsigned)(bal >> 32);
+        if (wave == 0 && lane < 32 && in) {                  // this launch's entries, recorded for k_grid_grad
+            if (KEEP) GS.cur[e] = ((tm | dm) >> lane) & 1;
+            else if (e < GS.cap) GS.live[(size_t)f * GS.cap + e] = ((tm | dm) >> lane) & 1;
+        }
+        unsigned todo = tm | dm;                             // (entries without a mark: nothing arrived, and no particle reads those nodes)
+        for (int rank = 0; todo; rank++) {
+            const int i = __builtin_ctz(todo);
+            todo &= todo - 1;
+            if ((rank & 3) == wave) one_block(base + i, __builtin_amdgcn_readlane(blkv, i), true, (tm >> i) & 1, (dm >> i) & 1);
+        }
     }
+    for (int d = blockIdx.x * 4 + wave; d < n_dyn; d += gridDim.x * 4) one_block(-1, blk_list[d], false, false, true);
 }
 struct GridArgs { SimP S; TableP T; const float4* slab; float* g_in; float4* g_out; const int* blk_list; const int* blk_count; int* blk_flag; GridStore GS; int f; int* frame_slow; StaticsP ST; AgentP agent; };
 template <bool KEEP, bool STATICS, bool DYN>
@@ -971,7 +1051,7 @@ __device__ __forceinline__ void used_particle_g2p_grad(const SimP& S, const Fram
 
 // one slot on the global path (tail / sort_interval = 0)
 __device__ __forceinline__ void g2p_grad_slot_global(const SimP& S, const FrameV& cur, const FrameV& Gn, const FrameV& Gc, int s,
-                                                     const VoutSrc& V, float* gg_out, const AgentP& agent, int f) {
+                                                     const VoutSrc& V, float* gg_out, const AgentP& agent, int f, const GridStore& GS) {
     if (!cur.used[s]) return;
     float4 a0 = cur.A0[s];
     float x[3] = {a0.x, a0.y, a0.z};
@@ -981,6 +1061,9 @@ __device__ __forceinline__ void g2p_grad_slot_global(const SimP& S, const FrameV
     SegScan none;
     none.f1 = none.f2 = none.f4 = none.f8 = 0.f; none.tail = true;
     used_particle_g2p_grad<false>(S, Gn, Gc, s, 0, st, V, gg_out, true, none);
+    for (int bx = st.base[0] >> 2; bx <= (st.base[0] + 2) >> 2; bx++)              // the (up to 8) blocks whose gg_out planes now hold atomics
+        for (int by = st.base[1] >> 2; by <= (st.base[1] + 2) >> 2; by++)
+            for (int bz = st.base[2] >> 2; bz <= (st.base[2] + 2) >> 2; bz++) mark_dirty(GS, V.blk_slot, (bx * S.nb + by) * S.nb + bz);
 }
 
 // workgroup-level flush of s_pose into the effectors' adjoint arrays (call with all threads; contains barriers)
@@ -1066,7 +1149,7 @@ __device__ __forceinline__ void g2p_grad_body(SimP S, float* fr_cur, float* Gn_,
                 }
                 if (used && !live) {
                     if (inside) atomicAdd(slow, 1);
-                    g2p_grad_slot_global(S, cur, Gn, Gc, s, V, gg_out, agent, f);
+                    g2p_grad_slot_global(S, cur, Gn, Gc, s, V, gg_out, agent, f, GS);
                 }
             }
             TL(S, 5);
@@ -1078,7 +1161,7 @@ __device__ __forceinline__ void g2p_grad_body(SimP S, float* fr_cur, float* Gn_,
             TL(S, 7);
         } else {
             const int s = tail_start + (w - n_pairs) * WG + tid;
-            if (s < S.N) g2p_grad_slot_global(S, cur, Gn, Gc, s, V, gg_out, agent, f);
+            if (s < S.N) g2p_grad_slot_global(S, cur, Gn, Gc, s, V, gg_out, agent, f, GS);
         }
     }
 }
@@ -1247,20 +1330,16 @@ __device__ __forceinline__ void grid_grad_body(SimP S, TableP T, const float4* _
                                                    const int* __restrict__ blk_list, const int* __restrict__ blk_count, int* blk_flag,
                                                    GridStore GS, int f, StaticsP ST, AgentP agent, NodeWork* work, int* work_count) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int n_static = T.meta[2], cnt = n_static + *blk_count;
     const bool stored = GS.cap > 0 && GS.flag[f];
-    const int per_xcd = ((cnt + 3) / 4 + 7) >> 3;
-    for (int wg = blockIdx.x; wg < per_xcd * 8; wg += gridDim.x) {
-        const int e = xcd_item(wg, per_xcd, S.xcd) * 4 + wave;
-        if (e >= cnt) continue;
-        bool is_static;
-        const int b = grid_entry(T, blk_list, e, n_static, is_static);
+    const int n_static = T.meta[2], n_dyn = *blk_count;
+    auto one_block = [&](int e, int b, bool is_static, bool dirty) {
         const int c = (b << 6) | lane;
         const int bi = b / (S.nb * S.nb), bj = (b / S.nb) % S.nb, bk = b % S.nb;
         // total (p, m): from the forward pass' store, or kept in g_in by k_grid<true>
         const float4 gi = stored ? GS.data[((size_t)f * GS.cap + e) * 128 + lane]
                                  : make_float4(g_in[c], g_in[S.ncell + c], g_in[2 * S.ncell + c], g_in[3 * S.ncell + c]);
-        float4 go = make_float4(gg_out[c], gg_out[S.ncell + c], gg_out[2 * S.ncell + c], 0.f);
+        float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (dirty) go = make_float4(gg_out[c], gg_out[S.ncell + c], gg_out[2 * S.ncell + c], 0.f);
         if (is_static) { const float4 t = gather_slabs(S, T, slab, bi, bj, bk, lane); go.x += t.x; go.y += t.y; go.z += t.z; }
         float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
         if (gi.w > FE_EPS) {
@@ -1283,10 +1362,28 @@ __device__ __forceinline__ void grid_grad_body(SimP S, TableP T, const float4* _
             out.w = -(gi.x * g0 + gi.y * g1 + gi.z * g2) * inv * inv;
         }
         gg_in[c] = out;
-        g_in[c] = 0.f; g_in[S.ncell + c] = 0.f; g_in[2 * S.ncell + c] = 0.f; g_in[3 * S.ncell + c] = 0.f;
-        gg_out[c] = 0.f; gg_out[S.ncell + c] = 0.f; gg_out[2 * S.ncell + c] = 0.f;
+        if (!stored) { g_in[c] = 0.f; g_in[S.ncell + c] = 0.f; g_in[2 * S.ncell + c] = 0.f; g_in[3 * S.ncell + c] = 0.f; }      // k_grid<true> kept the totals there
+        if (dirty) { gg_out[c] = 0.f; gg_out[S.ncell + c] = 0.f; gg_out[2 * S.ncell + c] = 0.f; }
         if (lane == 0 && !is_static) blk_flag[b] = 0;
+    };
+    // the entries k_grid worked on in this frame (GridStore): the others have no mass, pass nothing on, and are read by no particle
+    const unsigned char* __restrict__ live = stored ? GS.live + (size_t)f * GS.cap : GS.cur;
+    const EntryRange r = entry_range(S, n_static);
+    for (int base = r.e0; base < r.e1; base += 32) {
+        const int e = base + (lane & 31);
+        const bool in = e < r.e1;
+        const int blkv = (lane < 32 && in) ? T.active[e] : 0;
+        const unsigned char mk = in ? (lane < 32 ? live[e] : GS.dirty[e]) : 0;
+        const unsigned long long bal = __ballot(lane < 32 ? mk != 0 : mk == GS.stamp);
+        const unsigned lm = (unsigned)bal, dm = (unsigned)(bal >> 32);
+        unsigned todo = lm;
+        for (int rank = 0; todo; rank++) {
+            const int i = __builtin_ctz(todo);
+            todo &= todo - 1;
+            if ((rank & 3) == wave) one_block(base + i, __builtin_amdgcn_readlane(blkv, i), true, (dm >> i) & 1);
+        }
     }
+    for (int d = blockIdx.x * 4 + wave; d < n_dyn; d += gridDim.x * 4) one_block(0, blk_list[d], false, true);
 }
 struct GridGradArgs { SimP S; TableP T; const float4* slab; float* g_in; float* gg_out; float4* gg_in; const int* blk_list; const int* blk_count; int* blk_flag; GridStore GS; int f; StaticsP ST; AgentP agent; NodeWork* work; int* work_count; };
 template <bool STATICS, bool DYN>
@@ -2177,6 +2274,8 @@ struct FeEngine {
     int static_table = -1;                                  // order whose active list is currently flagged 2 in blk_flag
     std::vector<int> gs_host; bool gs_host_valid = false;   // host copy of gs_flag, refreshed once per backward sweep
     float4* gstore = nullptr; int* gs_flag = nullptr; int gs_cap = 0;     // forward grid store (see GridStore)
+    unsigned char *ent_touched = nullptr, *ent_dirty = nullptr; unsigned stamp = 0;    // [nblk] marks of the scatter kernels per active-list entry (see GridStore)
+    unsigned char *gs_live = nullptr, *cur_live = nullptr;                // k_grid's record of the entries it worked on: [(L+1) * cap] beside the store, [nblk] current
     float4* slab = nullptr;                                 // one 512-node float4 tile per work item (scatter hand-over)
     std::vector<Table> tables;
     std::vector<int> tbl_of_frame;                          // [L+1]
@@ -2425,7 +2524,11 @@ int sort_frame(FeEngine* h, int f) {
 
 StaticsP statics_p(FeEngine* h) { StaticsP p; p.n = (int)h->statics_host.size(); p.s = h->statics_dev; return p; }
 
-GridStore grid_store(FeEngine* h) { GridStore g; g.data = h->gstore; g.flag = h->gs_flag; g.cap = h->gs_cap; return g; }
+GridStore grid_store(FeEngine* h) {
+    GridStore g; g.data = h->gstore; g.flag = h->gs_flag; g.cap = h->gs_cap;
+    g.touched = h->ent_touched; g.dirty = h->ent_dirty; g.live = h->gs_live; g.cur = h->cur_live; g.stamp = (unsigned char)(1 + h->stamp % 255);
+    return g;
+}
 
 GridW grid_w(FeEngine* h) {
     GridW g; g.g_in = h->g_in; g.slab = h->slab; g.ncell = h->S.ncell; g.frame_slow = h->frame_slow_dev; g.blk_flag = h->blk_flag; g.blk_list = h->blk_list; g.blk_count = h->blk_count; g.err = h->err_dev; g.slow = h->slow_dev;
@@ -2447,6 +2550,7 @@ void launch_grid(FeEngine* h, const TableP& T, int f, const AgentP& ag) {
 
 int substep_fwd(FeEngine* h, int f, int f_global, int act) {
     h->gs_host_valid = false;
+    h->stamp++;                                           // p2g marks, grid_op reads (GridStore)
     InjectP inj;
     if (make_inject(h, f, f_global, act, true, inj)) return 1;
     if (h->sort_interval > 0 && f % h->sort_interval == 0 && sort_frame(h, f)) return 1;
@@ -2496,6 +2600,7 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act) {
     }
     const bool stored = h->gs_cap > 0 && h->gs_host[f] != 0;
     if (!stored) {
+    h->stamp++;                                           // marks of the recompute (p2g -> grid_op)
     prof_begin(h, KID_P2G_RE);
     if (h->all_simple_liquid)
         hipLaunchKernelGGL((k_p2g<false, false>), wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T,
@@ -2508,6 +2613,7 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act) {
     launch_grid<true>(h, T, f, ag);
     prof_end(h);
     }
+    h->stamp++;                                           // marks of the adjoint scatter (g2p.grad -> grid_op.grad)
     if (h->has_rigid) {                                   // advect_grad (mpm:436-447) for the rigid bodies, see k_rigid_body
         hipLaunchKernelGGL(k_rigid_body<true>, dim3(h->n_bodies), dim3(256), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), h->grad(f + 1),
                            h->tables[t].slot_of_pid, h->body_start, h->body_pids, h->bodies_dev);
@@ -2570,6 +2676,7 @@ int substep_fwd_batch(FeEngine** hs, int B, int f, int f_global, int act) {
     for (int i = 0; i < B; i++) {
         FeEngine* h = hs[i];
         h->gs_host_valid = false;
+        h->stamp++;
         InjectP inj;
         if (make_inject(h, f, f_global, act, true, inj)) return 1;
         if (h->sort_interval > 0 && f % h->sort_interval == 0 && sort_frame(h, f)) return 1;
@@ -2615,8 +2722,10 @@ int substep_bwd_batch(FeEngine** hs, int B, int f, int f_global, int act) {
             h->gs_host_valid = true;
         }
         all_stored = all_stored && h->gs_cap > 0 && h->gs_host[f] != 0;
+        h->stamp++;                                       // recompute marks, then the adjoint scatter's (as in substep_bwd)
         bp.a[i] = P2GArgs{h->S, h->frame(f), h->frame(f + 1), T, h->pool_idx, grid_w(h), ag, noinj, 0, f, grid_store(h)};
         bg.a[i] = GridArgs{h->S, T, h->slab, h->g_in, h->g_out, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f, h->frame_slow_dev, statics_p(h), ag};
+        h->stamp++;
         bq.a[i] = G2PGradArgs{h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag};
         bgg.a[i] = GridGradArgs{h->S, T, h->slab, h->g_in, h->gg_out, h->gg_in, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f, statics_p(h), ag, h->node_work, h->node_work_count};
         bpg.a[i] = P2GGradArgs{h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->pool_idx, h->gg_in, h->blk_count, h->slow_dev, ag, inj, act, f};
@@ -2768,7 +2877,9 @@ FeEngine* fe_create(const FeConfig* cfg) {
         size_t cap = nblk;
         while (cap > 0 && (size_t)(h->L + 1) * cap * 2048 > ((size_t)64 << 30)) cap /= 2;
         h->gs_cap = (int)cap;
-        if (cap > 0 && (dev_alloc(h, &h->gstore, (size_t)(h->L + 1) * cap * 128, false) || dev_alloc(h, &h->gs_flag, h->L + 1))) return fail("");
+        if (cap > 0 && (dev_alloc(h, &h->gstore, (size_t)(h->L + 1) * cap * 128, false) || dev_alloc(h, &h->gs_flag, h->L + 1) ||
+                        dev_alloc(h, &h->gs_live, (size_t)(h->L + 1) * cap))) return fail("");
+        if (dev_alloc(h, &h->ent_touched, nblk) || dev_alloc(h, &h->ent_dirty, nblk) || dev_alloc(h, &h->cur_live, nblk)) return fail("");
     }
     if (dev_alloc(h, &h->pinfo, h->Np) || dev_alloc(h, &h->pool_idx, h->Np)) return fail("");
     if (ensure_table(h, 0)) return fail("");                 // identity order: no items, everything is "tail"; its `info` is pinfo itself
@@ -2795,7 +2906,7 @@ void fe_destroy(FeEngine* h) {
     smoke_destroy(h);
     for (auto& t : h->tables) { if (t.info && t.info != h->pinfo) (void)hipFree(t.info);
         for (void* q : {(void*)t.pairs, (void*)t.singles, (void*)t.pid, (void*)t.items, (void*)t.meta, (void*)t.blk_first, (void*)t.active, (void*)t.blk_slot, (void*)t.slot_of_pid}) if (q) (void)hipFree(q); }
-    void* ptrs[] = {h->frames, h->grads, h->sort_key, h->sort_rank, h->sort_cnt, h->sort_start, h->sort_bflag, h->sort_pid, h->slow_dev, h->frame_slow_dev, h->gstore, h->gs_flag, h->slab, h->sort_partial, h->effs_dev, h->pinfo, h->pool_idx, h->g_in, h->g_out, h->gg_out, h->gg_in,
+    void* ptrs[] = {h->frames, h->grads, h->sort_key, h->sort_rank, h->sort_cnt, h->sort_start, h->sort_bflag, h->sort_pid, h->slow_dev, h->frame_slow_dev, h->gstore, h->gs_flag, h->gs_live, h->ent_touched, h->ent_dirty, h->cur_live, h->slab, h->sort_partial, h->effs_dev, h->pinfo, h->pool_idx, h->g_in, h->g_out, h->gg_out, h->gg_in,
                     h->blk_flag, h->blk_list, h->blk_count, h->err_dev, h->stage_r, h->stage_i, h->node_mark, h->counters,
                     h->tgt, h->chamfer, h->step_loss, h->body_start, h->body_pids, h->bodies_dev, h->statics_dev, h->collector_dev, h->hit_dev, h->hit_list, h->hit_count, h->node_work, h->node_work_count};
     for (float* v : h->statics_vox) if (v) (void)hipFree(v);
