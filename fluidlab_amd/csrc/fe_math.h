@@ -108,10 +108,18 @@ FE_HD m3 m3_cof(const m3& x) { m3 r;
 // 3x3 SVD, contract of taichi 1.1.0 ti.svd (call site mpm:264): F = U diag(sig) V^T with
 // U, V proper rotations, |sig| descending, a negative determinant carried by sig[2].
 // One-sided (Hestenes) Jacobi on the columns of F: works on F itself, not F^T F, so fp32
-// keeps full relative accuracy for the near-identity F of fluids.  Fixed 5 sweeps, no
-// data-dependent loop exit => no wave divergence.
+// keeps full relative accuracy for the near-identity F of fluids.  At most 5 sweeps; the loop
+// ends early only when a whole sweep rotated nothing in ANY lane of the wave (a wave-uniform
+// exit: no divergence).  Such a sweep leaves A and V bit-for-bit unchanged, so every later
+// sweep would do the same: the result is that of the fixed 5 sweeps.  (F within 0.3 % of a
+// rotation -- the plastic clamp of ICECREAM -- is done after two sweeps; the third finds that out.)
 // ---------------------------------------------------------------------------------------
-FE_HD void svd3_rot(m3& A, m3& V, const int p, const int q) {
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FE_WAVE_ANY(x) (__any(x) != 0)
+#else
+#define FE_WAVE_ANY(x) (x)
+#endif
+FE_HD bool svd3_rot(m3& A, m3& V, const int p, const int q) {
     real alpha = A.a[0][p] * A.a[0][p] + A.a[1][p] * A.a[1][p] + A.a[2][p] * A.a[2][p];
     real beta  = A.a[0][q] * A.a[0][q] + A.a[1][q] * A.a[1][q] + A.a[2][q] * A.a[2][q];
     real gamma = A.a[0][p] * A.a[0][q] + A.a[1][p] * A.a[1][q] + A.a[2][p] * A.a[2][q];
@@ -132,6 +140,7 @@ FE_HD void svd3_rot(m3& A, m3& V, const int p, const int q) {
         real vp = V.a[i][p], vq = V.a[i][q];
         V.a[i][p] = c * vp - s * vq; V.a[i][q] = s * vp + c * vq;
     }
+    return live;
 }
 
 FE_HD void m3_swap_cols(m3& A, int p, int q) {
@@ -144,9 +153,10 @@ FE_HD void svd3(const m3& F, m3& U, real sig[3], m3& V) {
     V = m3_ident();
 #pragma unroll 1
     for (int sweep = 0; sweep < (sizeof(real) == 4 ? 5 : 12); sweep++) {
-        svd3_rot(A, V, 0, 1);
-        svd3_rot(A, V, 0, 2);
-        svd3_rot(A, V, 1, 2);
+        bool moved = svd3_rot(A, V, 0, 1);
+        moved |= svd3_rot(A, V, 0, 2);
+        moved |= svd3_rot(A, V, 1, 2);
+        if (!FE_WAVE_ANY(moved)) break;
     }
 #pragma unroll
     for (int j = 0; j < 3; j++) sig[j] = sqrt(A.a[0][j] * A.a[0][j] + A.a[1][j] * A.a[1][j] + A.a[2][j] * A.a[2][j]);
