@@ -613,9 +613,9 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
 }
 struct P2GArgs { SimP S; float* fr_cur; float* fr_next; TableP T; const int* pool_idx; GridW G; AgentP agent; InjectP inj; int act; int f; GridStore GS; };
 template <bool WRITE, bool GENERAL>
-__global__ __launch_bounds__(WG, GENERAL ? 2 : 4) void k_p2g(SimP S, float* fr_cur, float* fr_next, TableP T, const int* pool_idx, GridW G, AgentP agent, InjectP inj, int act, int f, GridStore GS) { p2g_body<WRITE, GENERAL>(S, fr_cur, fr_next, T, pool_idx, G, agent, inj, act, f, GS); }
+__global__ __launch_bounds__(WG, GENERAL ? 3 : 4) void k_p2g(SimP S, float* fr_cur, float* fr_next, TableP T, const int* pool_idx, GridW G, AgentP agent, InjectP inj, int act, int f, GridStore GS) { p2g_body<WRITE, GENERAL>(S, fr_cur, fr_next, T, pool_idx, G, agent, inj, act, f, GS); }
 template <bool WRITE, bool GENERAL>
-__global__ __launch_bounds__(WG, GENERAL ? 2 : 4) void k_p2g_b(Batch<P2GArgs> B) { const P2GArgs& A = B.a[blockIdx.y]; p2g_body<WRITE, GENERAL>(A.S, A.fr_cur, A.fr_next, A.T, A.pool_idx, A.G, A.agent, A.inj, A.act, A.f, A.GS); }
+__global__ __launch_bounds__(WG, GENERAL ? 3 : 4) void k_p2g_b(Batch<P2GArgs> B) { const P2GArgs& A = B.a[blockIdx.y]; p2g_body<WRITE, GENERAL>(A.S, A.fr_cur, A.fr_next, A.T, A.pool_idx, A.G, A.agent, A.inj, A.act, A.f, A.GS); }
 
 
 // agent.collide at particle level (mpm:418-422; AgentRigid.collide): every effector that carries a mesh, in order,

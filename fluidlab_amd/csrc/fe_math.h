@@ -126,6 +126,7 @@ FE_HD bool svd3_rot(m3& A, m3& V, const int p, const int q) {
     // skip when the columns are already orthogonal to fp32 precision (also avoids 0/0)
     const real tol2 = sizeof(real) == 4 ? R_(1e-15) : R_(1e-31);   // (fp64 only in the host tests)
     bool live = gamma * gamma > tol2 * alpha * beta && fabs(gamma) > R_(1e-30);
+    if (!FE_WAVE_ANY(live)) return false;                          // (the identity rotation in every lane: skipped as a whole)
     real g = live ? gamma : R_(1.0);
     real zeta = (beta - alpha) / (R_(2.0) * g);
     real t = copysign(R_(1.0), zeta) / (fabs(zeta) + sqrt(R_(1.0) + zeta * zeta));
