@@ -254,7 +254,10 @@ struct TableP {
     const int4* items;         // (block, start, count <= 128, 0), sorted by block
     const int2* pairs;         // workgroups of blocks with several items: (item, its partner in the same block or -1)
     const int*  singles;       // the items of blocks with a single item (paired up two by two by the kernels)
-    const int*  meta;          // meta[0] = n_items, [1] = tail_start, [2] = n_active, [3] = n pairs, [4] = n singles
+    const int*  meta;          // meta[0] = n_items, [1] = tail_start, [2] = n_active, [3] = n pairs, [4] = n singles, [5] = n unit slots
+    const struct Unit* units;  // what workgroup w of the particle kernels works on: ready-made descriptors, XCD order (see Unit)
+    int units_cap;
+    const int2* nbr;           // [n_active * 27] (first item, item count) of the 27 neighbours of each active-list entry's block
     const int2* blk_first;     // [nblk] (first item, item count) of a block
     const int*  active;        // blocks within one block of an occupied block: every block a tile can reach
     const int*  blk_slot;      // [nblk] index of a block in `active`, or -1
@@ -283,25 +286,40 @@ struct PairCtx {
     int  nth, t0;    // the threads that load / zero / store this tile: all 256 from t0 = tid when shared, else this half's 128
     bool live;       // this half's threads take part in tile loads and stores
 };
-// number of workgroup-level work units of the item path
-__device__ __forceinline__ int n_pair_work(const TableP& T) { return T.meta[3] + ((T.meta[4] + 1) >> 1); }
-__device__ __forceinline__ PairCtx pair_ctx(const TableP& T, int w) {
+// The work of one workgroup of the particle kernels, as the sort leaves it (k_build_active): two item descriptors ready to use.
+// The kernels used to walk meta -> pairs[w] / singles[q] -> items[i] before they could ask for their particles: three dependent
+// round trips ahead of the first useful load in kernels that are one round of such chains.  Now workgroup w reads units[w] together
+// with meta.  The list is stored in XCD order (slot w holds work unit xcd_item(w): every XCD a contiguous eighth of the items).
+//   a = (block, first slot, count, item index | same << 30), b likewise with b.w = -1 when there is no second item;
+//   same: both items belong to one block and share tile and slab;  a.z == -1: a tail unit (slots from a.y);  a.z == -2: nothing
+struct Unit { int4 a, b; };
+__device__ __forceinline__ PairCtx pair_ctx(const Unit& u) {
     const int tid = threadIdx.x, half = __builtin_amdgcn_readfirstlane(tid >> 7);
-    const int nM = T.meta[3], nS = T.meta[4];
-    int ia, ib;
-    bool same;
-    if (w < nM) { const int2 p = T.pairs[w]; ia = p.x; ib = p.y; same = true; }
-    else { const int q = 2 * (w - nM); ia = T.singles[q]; ib = q + 1 < nS ? T.singles[q + 1] : -1; same = false; }
+    const bool same = (u.a.w >> 30) & 1;
+    const int ia = u.a.w & 0x3fffffff, ib = u.b.w;
     const int ih = half ? ib : ia;
     PairCtx c;
     c.live = same || ih >= 0;
-    c.it = T.items[ih >= 0 ? ih : ia];
+    c.it = (half && ib >= 0) ? u.b : u.a;
+    c.it.w = 0;
     if (ih < 0) c.it.z = 0;                                  // no second item: the half idles (through the same barriers)
     c.ti = (half && !same) ? 1 : 0;
     c.slab = same ? ia : (ih >= 0 ? ih : ia);
     c.nth = same ? WG : HALF;
     c.t0 = same ? tid : (tid & (HALF - 1));
     return c;
+}
+// slot w of the unit list (read ahead of meta for the first one: the list is padded to units_cap)
+__device__ __forceinline__ Unit unit_load(const TableP& T, int w) {
+    Unit u;
+    if (w < T.units_cap) u = T.units[w];
+    else { u.a = make_int4(0, 0, -2, 0); u.b = make_int4(0, 0, 0, -1); }
+    // (wave-uniform: into scalar registers, the particle kernels have no vector registers to spare)
+    u.a.x = __builtin_amdgcn_readfirstlane(u.a.x); u.a.y = __builtin_amdgcn_readfirstlane(u.a.y);
+    u.a.z = __builtin_amdgcn_readfirstlane(u.a.z); u.a.w = __builtin_amdgcn_readfirstlane(u.a.w);
+    u.b.x = __builtin_amdgcn_readfirstlane(u.b.x); u.b.y = __builtin_amdgcn_readfirstlane(u.b.y);
+    u.b.z = __builtin_amdgcn_readfirstlane(u.b.z); u.b.w = __builtin_amdgcn_readfirstlane(u.b.w);
+    return u;
 }
 
 // -----------------------------------------------------------------------------------------
@@ -545,15 +563,13 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
     FrameV cur = frame_view(fr_cur, S.Np);
     FrameV nxt = frame_view(fr_next, S.Np);
     TL(S, 0);
-    const int n_items = T.meta[0], tail_start = T.meta[1];
-    const int n_pairs = n_pair_work(T);
-    const int n_tail = (S.N - tail_start + WG - 1) / WG;
-    const int n_work = n_pairs + n_tail, per_xcd = (n_work + 7) >> 3;
-    for (int wg = blockIdx.x; wg < per_xcd * 8; wg += gridDim.x) {
-        const int w = xcd_item(wg, per_xcd, S.xcd);
-        if (w >= n_work) continue;
-        if (w < n_pairs) {
-            const PairCtx pc = pair_ctx(T, w);
+    Unit un = unit_load(T, blockIdx.x);                       // this workgroup's first unit, asked for together with meta
+    const int n_slots = T.meta[5];
+    for (int wg = blockIdx.x; wg < n_slots; wg += gridDim.x) {
+        if (wg != (int)blockIdx.x) un = unit_load(T, wg);
+        if (un.a.z == -2) continue;
+        if (un.a.z >= 0) {
+            const PairCtx pc = pair_ctx(un);
             const int4 it = pc.it;
             const TileO to = tile_origin(it.x, S.nb);
             const int aofs = pc.ti * 4 * TILE_N;
@@ -599,7 +615,7 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
             __syncthreads();
             TL(S, 6);
         } else {
-            const int s = tail_start + (w - n_pairs) * WG + tid;
+            const int s = un.a.y + tid;
             if (s < S.N) {
                 if (cur.used[s]) {
                     if (WRITE && act && agent.collector && collector_takes(cur, nxt, s, T.info, agent)) continue;
@@ -686,13 +702,8 @@ __device__ __forceinline__ void node_statics_grad(const SimP& S, const StaticsP&
 // (deterministic sums).  `slab` holds one 512-node float4 tile per item.  The item ranges of the 27 neighbour
 // blocks are fetched once per wave (lane n < 27 loads neighbour n) and handed out by cross-lane reads, so a
 // lane's critical path is two dependent memory round trips: range -> slab values.
-__device__ __forceinline__ float4 gather_slabs(const SimP& S, const TableP& T, const float4* __restrict__ slab, int bi, int bj, int bk, int lane) {
-    int2 mine = make_int2(0, 0);
-    if (lane < 27) {
-        const int i2 = bi + lane / 9 - 1, j2 = bj + (lane / 3) % 3 - 1, k2 = bk + lane % 3 - 1;
-        if ((unsigned)i2 < (unsigned)S.nb && (unsigned)j2 < (unsigned)S.nb && (unsigned)k2 < (unsigned)S.nb)
-            mine = T.blk_first[(i2 * S.nb + j2) * S.nb + k2];
-    }
+__device__ __forceinline__ float4 gather_slabs(const SimP& S, const TableP& T, const float4* __restrict__ slab, int e, int lane) {
+    const int2 mine = lane < 27 ? T.nbr[e * 27 + lane] : make_int2(0, 0);       // (laid out by k_build_units: no detour over the block number)
     const int o[3] = {lane >> 4, (lane >> 2) & 3, lane & 3};
     // Which items of a block own a slab: the items of a block pair up from its first one, and a pair shares the first one's slab:
     // the slabs of a block whose items are [first, first + count) are first, first + 2, ...  The first two of each of the 8 source
@@ -779,7 +790,7 @@ __device__ __forceinline__ void grid_body(SimP S, TableP T, const float4* __rest
         TL(S, 1);
         float4 gi = make_float4(0.f, 0.f, 0.f, 0.f);
         if (dirty) gi = make_float4(g_in[c], g_in[S.ncell + c], g_in[2 * S.ncell + c], g_in[3 * S.ncell + c]);
-        if (touched) { const float4 t = gather_slabs(S, T, slab, bi, bj, bk, lane); gi.x += t.x; gi.y += t.y; gi.z += t.z; gi.w += t.w; }
+        if (touched) { const float4 t = gather_slabs(S, T, slab, e, lane); gi.x += t.x; gi.y += t.y; gi.z += t.z; gi.w += t.w; }
         float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
         if (gi.w > FE_EPS) TL(S, 2);
         if (gi.w > FE_EPS) {
@@ -921,15 +932,13 @@ __device__ __forceinline__ void g2p_body(SimP S, float* fr_cur, float* fr_next, 
     FrameV cur = frame_view(fr_cur, S.Np);
     FrameV nxt = frame_view(fr_next, S.Np);
     TL(S, 0);
-    const int n_items = T.meta[0], tail_start = T.meta[1];
-    const int n_pairs = n_pair_work(T);
-    const int n_tail = (S.N - tail_start + WG - 1) / WG;
-    const int n_work = n_pairs + n_tail, per_xcd = (n_work + 7) >> 3;
-    for (int wg = blockIdx.x; wg < per_xcd * 8; wg += gridDim.x) {
-        const int w = xcd_item(wg, per_xcd, S.xcd);
-        if (w >= n_work) continue;
-        if (w < n_pairs) {
-            const PairCtx pc = pair_ctx(T, w);
+    Unit un = unit_load(T, blockIdx.x);                       // this workgroup's first unit, asked for together with meta
+    const int n_slots = T.meta[5];
+    for (int wg = blockIdx.x; wg < n_slots; wg += gridDim.x) {
+        if (wg != (int)blockIdx.x) un = unit_load(T, wg);
+        if (un.a.z == -2) continue;
+        if (un.a.z >= 0) {
+            const PairCtx pc = pair_ctx(un);
             const int4 it = pc.it;
             const TileO to = tile_origin(it.x, S.nb);
             const int i = tid & (HALF - 1);
@@ -945,7 +954,7 @@ __device__ __forceinline__ void g2p_body(SimP S, float* fr_cur, float* fr_next, 
             __syncthreads();
             TL(S, 4);
         } else {
-            const int s = tail_start + (w - n_pairs) * WG + tid;
+            const int s = un.a.y + tid;
             TileO none = {0, 0, 0};
             if (s < S.N) slot_g2p<COLLIDE>(S, cur, nxt, s, false, none, g_out, slow, agent, f, cur.used[s], cur.A0[s]);
         }
@@ -1113,15 +1122,13 @@ __device__ __forceinline__ void g2p_grad_body(SimP S, float* fr_cur, float* Gn_,
     FrameV cur = frame_view(fr_cur, S.Np);
     FrameV Gn = frame_view(Gn_, S.Np), Gc = frame_view(Gc_, S.Np);
     TL(S, 0);
-    const int n_items = T.meta[0], tail_start = T.meta[1];
-    const int n_pairs = n_pair_work(T);
-    const int n_tail = (S.N - tail_start + WG - 1) / WG;
-    const int n_work = n_pairs + n_tail, per_xcd = (n_work + 7) >> 3;
-    for (int wg = blockIdx.x; wg < per_xcd * 8; wg += gridDim.x) {
-        const int w = xcd_item(wg, per_xcd, S.xcd);
-        if (w >= n_work) continue;
-        if (w < n_pairs) {
-            const PairCtx pc = pair_ctx(T, w);
+    Unit un = unit_load(T, blockIdx.x);                       // this workgroup's first unit, asked for together with meta
+    const int n_slots = T.meta[5];
+    for (int wg = blockIdx.x; wg < n_slots; wg += gridDim.x) {
+        if (wg != (int)blockIdx.x) un = unit_load(T, wg);
+        if (un.a.z == -2) continue;
+        if (un.a.z >= 0) {
+            const PairCtx pc = pair_ctx(un);
             const int4 it = pc.it;
             const TileO to = tile_origin(it.x, S.nb);
             const int tofs = pc.ti * 3 * TILE_N;
@@ -1160,7 +1167,7 @@ __device__ __forceinline__ void g2p_grad_body(SimP S, float* fr_cur, float* Gn_,
             __syncthreads();
             TL(S, 7);
         } else {
-            const int s = tail_start + (w - n_pairs) * WG + tid;
+            const int s = un.a.y + tid;
             if (s < S.N) g2p_grad_slot_global(S, cur, Gn, Gc, s, V, gg_out, agent, f, GS);
         }
     }
@@ -1340,7 +1347,7 @@ __device__ __forceinline__ void grid_grad_body(SimP S, TableP T, const float4* _
                                  : make_float4(g_in[c], g_in[S.ncell + c], g_in[2 * S.ncell + c], g_in[3 * S.ncell + c]);
         float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
         if (dirty) go = make_float4(gg_out[c], gg_out[S.ncell + c], gg_out[2 * S.ncell + c], 0.f);
-        if (is_static) { const float4 t = gather_slabs(S, T, slab, bi, bj, bk, lane); go.x += t.x; go.y += t.y; go.z += t.z; }
+        if (is_static) { const float4 t = gather_slabs(S, T, slab, e, lane); go.x += t.x; go.y += t.y; go.z += t.z; }
         float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
         if (gi.w > FE_EPS) {
             float vo[3], kmul[3];
@@ -1630,15 +1637,13 @@ __device__ __forceinline__ void p2g_grad_body(SimP S, float* fr_cur, float* Gn_,
     FrameV cur = frame_view(fr_cur, S.Np);
     FrameV Gn = frame_view(Gn_, S.Np), Gc = frame_view(Gc_, S.Np);
     TL(S, 0);
-    const int n_items = T.meta[0], tail_start = T.meta[1];
-    const int n_pairs = n_pair_work(T);
-    const int n_tail = (S.N - tail_start + WG - 1) / WG;
-    const int n_work = n_pairs + n_tail, per_xcd = (n_work + 7) >> 3;
-    for (int wg = blockIdx.x; wg < per_xcd * 8; wg += gridDim.x) {
-        const int w = xcd_item(wg, per_xcd, S.xcd);
-        if (w >= n_work) continue;
-        if (w < n_pairs) {
-            const PairCtx pc = pair_ctx(T, w);
+    Unit un = unit_load(T, blockIdx.x);                       // this workgroup's first unit, asked for together with meta
+    const int n_slots = T.meta[5];
+    for (int wg = blockIdx.x; wg < n_slots; wg += gridDim.x) {
+        if (wg != (int)blockIdx.x) un = unit_load(T, wg);
+        if (un.a.z == -2) continue;
+        if (un.a.z >= 0) {
+            const PairCtx pc = pair_ctx(un);
             const int4 it = pc.it;
             const TileO to = tile_origin(it.x, S.nb);
             TL(S, 1);
@@ -1651,7 +1656,7 @@ __device__ __forceinline__ void p2g_grad_body(SimP S, float* fr_cur, float* Gn_,
             __syncthreads();
             TL(S, 4);
         } else {
-            const int s = tail_start + (w - n_pairs) * WG + tid;
+            const int s = un.a.y + tid;
             TileO none = {0, 0, 0};
             if (s < S.N) slot_p2g_grad<false, GENERAL>(S, cur, Gn, Gc, s, T, pool_idx, none, gg_in, slow, agent, inj, f);
         }
@@ -1838,6 +1843,38 @@ __global__ __launch_bounds__(256) void k_build_active(int nb, const int4* __rest
         if ((unsigned)i2 >= (unsigned)nb || (unsigned)j2 >= (unsigned)nb || (unsigned)k2 >= (unsigned)nb) continue;
         const int n2 = (i2 * nb + j2) * nb + k2;
         if (atomicCAS(&blk_flag[n2], 0, 2) == 0) { const int e = atomicAdd(&meta[2], 1); active[e] = n2; blk_slot[n2] = e; }
+    }
+}
+// What the substep kernels would otherwise look up through chains of dependent loads, laid out once per sort: the unit list of
+// the particle kernels (struct Unit) and, per active-list entry, the item ranges of its block's 27 neighbours (gather_slabs).
+__global__ __launch_bounds__(256) void k_build_units(int nb, int N, int xcd_on, const int4* __restrict__ items, const int2* __restrict__ pairs,
+                                                     const int* __restrict__ singles, const int2* __restrict__ blk_first, const int* __restrict__ active,
+                                                     int* meta, Unit* units, int units_cap, int2* nbr) {
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+    const int tail_start = meta[1], nM = meta[3], nS = meta[4], n_active = meta[2];
+    const int n_pairs = nM + ((nS + 1) >> 1), n_tail = (N - tail_start + WG - 1) / WG;
+    const int n_work = n_pairs + n_tail, per_xcd = (n_work + 7) >> 3;
+    const int n_slots = per_xcd * 8 < units_cap ? per_xcd * 8 : units_cap;      // (units_cap covers the worst case)
+    if (gtid == 0) meta[5] = n_slots;
+    for (int w = gtid; w < n_slots; w += nth) {
+        const int u = xcd_item(w, per_xcd, xcd_on);
+        Unit un;
+        un.a = make_int4(0, 0, -2, 0); un.b = make_int4(0, 0, 0, -1);
+        if (u < n_pairs) {
+            int ia, ib, same;
+            if (u < nM) { const int2 pr = pairs[u]; ia = pr.x; ib = pr.y; same = 1; }
+            else { const int q = 2 * (u - nM); ia = singles[q]; ib = q + 1 < nS ? singles[q + 1] : -1; same = 0; }
+            un.a = items[ia]; un.a.w = ia | (same << 30);
+            if (ib >= 0) { un.b = items[ib]; un.b.w = ib; }
+        } else if (u < n_work) un.a = make_int4(0, tail_start + (u - n_pairs) * WG, -1, 0);
+        units[w] = un;
+    }
+    for (int t = gtid; t < n_active * 27; t += nth) {
+        const int e = t / 27, n = t - e * 27, b = active[e];
+        const int i2 = b / (nb * nb) + n / 9 - 1, j2 = (b / nb) % nb + (n / 3) % 3 - 1, k2 = b % nb + n % 3 - 1;
+        int2 v = make_int2(0, 0);
+        if ((unsigned)i2 < (unsigned)nb && (unsigned)j2 < (unsigned)nb && (unsigned)k2 < (unsigned)nb) v = blk_first[(i2 * nb + j2) * nb + k2];
+        nbr[t] = v;
     }
 }
 __global__ __launch_bounds__(256) void k_clear_slots(const int* __restrict__ active, const int* __restrict__ meta, int* blk_slot) {
@@ -2270,7 +2307,7 @@ struct FeEngine {
     float* grads = nullptr;                                 // 3 x (GR_WORDS*Np + Np) floats: ring of two + 1 spare
     float* grad_ptr[3] = {nullptr, nullptr, nullptr};
     // particle orders ("tables"): id 0 = identity; id 1+f = order produced by the sort at frame f
-    struct Table { int* pid = nullptr; float4* info = nullptr; int2* pairs = nullptr; int* singles = nullptr; int4* items = nullptr; int* meta = nullptr; int2* blk_first = nullptr; int* active = nullptr; int* blk_slot = nullptr; int* slot_of_pid = nullptr; };
+    struct Table { int* pid = nullptr; float4* info = nullptr; int2* pairs = nullptr; int* singles = nullptr; int4* items = nullptr; int* meta = nullptr; int2* blk_first = nullptr; int* active = nullptr; int* blk_slot = nullptr; int* slot_of_pid = nullptr; Unit* units = nullptr; int2* nbr = nullptr; };
     int static_table = -1;                                  // order whose active list is currently flagged 2 in blk_flag
     std::vector<int> gs_host; bool gs_host_valid = false;   // host copy of gs_flag, refreshed once per backward sweep
     float4* gstore = nullptr; int* gs_flag = nullptr; int gs_cap = 0;     // forward grid store (see GridStore)
@@ -2283,7 +2320,7 @@ struct FeEngine {
     int p2g_grad_waves = 4;                                 // occupancy target of the SVD-free p2g_grad build (tuning)
     int item_max = ITEM_MAX_CAP;                            // particles per work item (<= ITEM_MAX_CAP = one half workgroup)
     int sort_interval = 10;                                 // K: re-sort every K substeps (0 = never: global path only)
-    size_t items_cap = 0;
+    size_t items_cap = 0, units_cap = 0;
     int *sort_key = nullptr, *sort_rank = nullptr, *sort_cnt = nullptr, *sort_start = nullptr, *sort_pid = nullptr, *sort_bflag = nullptr;
     int* slow_dev = nullptr;
     int* frame_slow_dev = nullptr;                          // set by a slow-path scatter of the current forward substep
@@ -2328,7 +2365,7 @@ struct FeEngine {
     float*& spare_frame() { return frame_ptr[L + 1]; }
     float* grad(int f) { return grad_ptr[f & 1]; }
     size_t grad_words() const { return (size_t)GR_WORDS * Np + Np; }
-    TableP tableP(int id) const { TableP t; t.pid_of_slot = tables[id].pid; t.info = tables[id].info; t.pairs = tables[id].pairs; t.singles = tables[id].singles; t.items = tables[id].items; t.meta = tables[id].meta; t.blk_first = tables[id].blk_first; t.active = tables[id].active; t.blk_slot = tables[id].blk_slot; return t; }
+    TableP tableP(int id) const { TableP t; t.pid_of_slot = tables[id].pid; t.info = tables[id].info; t.pairs = tables[id].pairs; t.singles = tables[id].singles; t.items = tables[id].items; t.meta = tables[id].meta; t.blk_first = tables[id].blk_first; t.active = tables[id].active; t.blk_slot = tables[id].blk_slot; t.units = tables[id].units; t.units_cap = (int)units_cap; t.nbr = tables[id].nbr; return t; }
     const int* pid_of(int f) const { return tables[tbl_of_frame[f]].pid; }
 };
 
@@ -2446,6 +2483,10 @@ int make_inject(FeEngine* h, int f, int f_global, int act, bool forward, InjectP
 
 int check_async(FeEngine* h);
 
+void build_units(FeEngine* h, FeEngine::Table& t) {
+    hipLaunchKernelGGL(k_build_units, dim3(256), dim3(256), 0, h->stream, h->nb, h->N, h->S.xcd, t.items, t.pairs, t.singles, t.blk_first, t.active, t.meta,
+                       t.units, (int)h->units_cap, t.nbr);
+}
 int ensure_table(FeEngine* h, int id) {
     if ((int)h->tables.size() <= id) h->tables.resize(id + 1);
     FeEngine::Table& t = h->tables[id];
@@ -2455,8 +2496,10 @@ int ensure_table(FeEngine* h, int id) {
     else if (dev_alloc(h, &t.info, h->Np)) return 1;
     if (dev_alloc(h, &t.pairs, h->items_cap / 2 + 2) || dev_alloc(h, &t.singles, h->items_cap)) return 1;
     if (dev_alloc(h, &t.pid, h->Np) || dev_alloc(h, &t.items, h->items_cap) || dev_alloc(h, &t.meta, 8) ||
-        dev_alloc(h, &t.blk_first, nblk) || dev_alloc(h, &t.active, nblk) || dev_alloc(h, &t.blk_slot, nblk) || dev_alloc(h, &t.slot_of_pid, h->Np)) return 1;
+        dev_alloc(h, &t.blk_first, nblk) || dev_alloc(h, &t.active, nblk) || dev_alloc(h, &t.blk_slot, nblk) || dev_alloc(h, &t.slot_of_pid, h->Np) ||
+        dev_alloc(h, &t.units, h->units_cap, false) || dev_alloc(h, &t.nbr, nblk * 27, false)) return 1;
     HIPCK(h, hipMemsetAsync(t.blk_slot, 0xff, sizeof(int) * nblk, h->stream));
+    if (id == 0) build_units(h, t);                            // the identity order: no items, every slot on the tail
     return 0;
 }
 
@@ -2509,6 +2552,7 @@ int sort_frame(FeEngine* h, int f) {
     hipLaunchKernelGGL(k_scan_final, dim3(scan_wgs), dim3(256), 0, h->stream, ncell, h->item_max, h->sort_cnt, h->sort_bflag, h->sort_partial, h->sort_start, tn.items, tn.meta, tn.blk_first, tn.pairs, tn.singles);
     if (fine) { prof_end(h); prof_begin(h, KID_SORT_ACTIVE); }
     hipLaunchKernelGGL(k_build_active, dim3(256), dim3(256), 0, h->stream, h->nb, tn.items, tn.meta, h->blk_flag, tn.active, tn.blk_slot);
+    build_units(h, tn);
     h->static_table = id_new;
     if (fine) { prof_end(h); prof_begin(h, KID_SORT_PERM); }
     // re-sorting a frame that is already in this table's order reads the id table it rewrites: stage it
@@ -2865,6 +2909,7 @@ FeEngine* fe_create(const FeConfig* cfg) {
     {
         const size_t nblk = (size_t)h->nb * h->nb * h->nb;
         h->items_cap = (nblk < (size_t)h->Np ? nblk : (size_t)h->Np) + (size_t)h->Np / 64 + 2;      // item_max >= 64
+        h->units_cap = h->items_cap + (size_t)h->Np / WG + 16;                                      // work units: items (at worst one each) + tail workgroups, rounded up to 8
         if (dev_alloc(h, &h->sort_key, h->Np) || dev_alloc(h, &h->sort_rank, h->Np) || dev_alloc(h, &h->sort_cnt, ncell + 1) ||
             dev_alloc(h, &h->sort_start, ncell + 1) || dev_alloc(h, &h->sort_bflag, ncell / 64 + 2) || dev_alloc(h, &h->sort_pid, h->Np) ||
             dev_alloc(h, &h->slow_dev, 1) || dev_alloc(h, &h->frame_slow_dev, 1) || dev_alloc(h, &h->slab, h->items_cap * TILE_N, false) || dev_alloc(h, &h->sort_partial, (ncell + 1 + 1023) / 1024 + 1)) return fail("");
@@ -2905,7 +2950,7 @@ void fe_destroy(FeEngine* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     smoke_destroy(h);
     for (auto& t : h->tables) { if (t.info && t.info != h->pinfo) (void)hipFree(t.info);
-        for (void* q : {(void*)t.pairs, (void*)t.singles, (void*)t.pid, (void*)t.items, (void*)t.meta, (void*)t.blk_first, (void*)t.active, (void*)t.blk_slot, (void*)t.slot_of_pid}) if (q) (void)hipFree(q); }
+        for (void* q : {(void*)t.pairs, (void*)t.singles, (void*)t.pid, (void*)t.items, (void*)t.meta, (void*)t.blk_first, (void*)t.active, (void*)t.blk_slot, (void*)t.slot_of_pid, (void*)t.units, (void*)t.nbr}) if (q) (void)hipFree(q); }
     void* ptrs[] = {h->frames, h->grads, h->sort_key, h->sort_rank, h->sort_cnt, h->sort_start, h->sort_bflag, h->sort_pid, h->slow_dev, h->frame_slow_dev, h->gstore, h->gs_flag, h->gs_live, h->ent_touched, h->ent_dirty, h->cur_live, h->slab, h->sort_partial, h->effs_dev, h->pinfo, h->pool_idx, h->g_in, h->g_out, h->gg_out, h->gg_in,
                     h->blk_flag, h->blk_list, h->blk_count, h->err_dev, h->stage_r, h->stage_i, h->node_mark, h->counters,
                     h->tgt, h->chamfer, h->step_loss, h->body_start, h->body_pids, h->bodies_dev, h->statics_dev, h->collector_dev, h->hit_dev, h->hit_list, h->hit_count, h->node_work, h->node_work_count};

@@ -1,6 +1,6 @@
 OUT=gpurun_out/r02r; mkdir -p $OUT; export TMPDIR=/tmp
 timeout 1000 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > $OUT/pytest_gpu.txt
-timeout 600 python bench.py --no-cpu-baseline > $OUT/bench.json 2> $OUT/bench.err
+timeout 600 python bench.py --no-cpu-baseline --steps 100 > $OUT/bench.json 2> $OUT/bench.err
 timeout 300 python scripts/evolve_probe.py 104 16 > $OUT/evolve.txt 2>&1
 tail -5 $OUT/pytest_gpu.txt; python - <<'PY'
 import json
@@ -9,3 +9,4 @@ print('value', b['value'], 'rest', b['extra']['restart_from_rest_pairs_per_s'], 
 print({k: v['avg_us'] for k, v in b['kernels'].items()})
 PY
 cut -c1-420 $OUT/evolve.txt
+timeout 300 python scripts/latteart_probe.py config3 40 2>&1 | tail -1 | cut -c1-200
