@@ -238,6 +238,33 @@ def test_fast_particles_leave_their_tiles(hiplib, oracle64):
     assert g.get_stats(20)['n_slow_path'] > 0
 
 
+@pytest.mark.parametrize('grid_store', [1, 0])
+def test_scattered_droplets_and_untouched_blocks(hiplib, oracle64, grid_store):
+    """Water that has come apart: droplets all over the box (most blocks of the active list get nothing, most items hold one or two
+    particles) plus a dense clump, some of it fast enough to leave its tiles between two sorts (slow-path deposits into blocks of the
+    active list: the dirty marks).  The grid kernels work on the marked entries only -- forward, backward from the stored grid
+    (grid_store 1) and backward from the recompute (grid_store 0) must match the oracle, and so must the work list the stats report."""
+    rng = np.random.RandomState(3)
+    n_drop, n_clump = 1500, 2500
+    sc = S.water_block(n_grid=64, n_particles=n_drop + n_clump, lo=0.40, hi=0.52)
+    sc['x'][:n_drop] = S.f32(rng.uniform(0.08, 0.92, (n_drop, 3)))
+    sc['v'] = S.f32(rng.normal(0, 1.0, (n_drop + n_clump, 3)))
+    sc['v'][n_drop:] = S.f32(rng.normal(0, 0.2, (n_clump, 3)) + [12.0, -9.0, 4.0])       # the clump drifts 1.5 cells between two sorts
+    g = S.make_engine(hiplib, sc, options={'sort_interval': 20, 'grid_store': grid_store})
+    o = S.make_engine(oracle64, sc)
+    cot = S.random_cotangent(sc['N'])
+    sa, ga = S.run_forward_backward(g, 30, cot)
+    sb, gb = S.run_forward_backward(o, 30, {k: v.astype(np.float64) for k, v in cot.items()})
+    assert (sa['used'] == sb['used']).all()
+    assert S.rel_l2(sa['x'], sb['x']) <= 1e-5 and S.rel_l2(sa['v'], sb['v']) <= 1e-3 and S.rel_l2(sa['C'], sb['C']) <= 1e-3
+    for k in ('gx', 'gv', 'gC', 'gF'):
+        assert S.cosine(ga[k], gb[k]) >= 0.999 and S.rel_l2(ga[k], gb[k]) <= 1e-2, k
+    assert g.get_stats(30)['n_slow_path'] > 0
+    ws = g.get_work_stats(21)
+    assert ws['items_by_size']['1'] + ws['items_by_size']['2-4'] > 800 and ws['n_active_blocks'] > 2 * ws['n_occupied_blocks']
+    assert ws['n_items'] == sum(ws['items_by_size'].values()) and ws['n_multi_item_workgroups'] + ws['n_single_item_blocks'] >= ws['n_occupied_blocks']
+
+
 def test_forward_is_independent_of_sort_interval(hiplib):
     sc = S.water_block(n_grid=32, n_particles=6000)
     ref = S.run_forward(S.make_engine(hiplib, sc, options={'sort_interval': 0}), 25)
