@@ -1742,6 +1742,10 @@ __device__ __forceinline__ int wg_scan_excl(int v, int* sh, int tid, int& total)
 
 // per-thread sum of its 4 histogram entries, and (threads 0..15) the particle count of block wg*16+t.  The histogram has n^3 + 1
 // entries, nearly all of them empty: only the cells of blocks flagged by k_sort_count are read (and, in k_scan_final, written).
+__device__ __forceinline__ int scan_live(int ncell, const int* bflag, int tid) {
+    const int b0 = blockIdx.x * 1024 + tid * 4;
+    return b0 <= ncell && bflag[b0 >> 6] != 0;
+}
 __device__ __forceinline__ int scan_load(int ncell, const int* cnt, const int* bflag, int tid, int c[4], int* sh_sum, int& blk_cnt, bool& live) {
     const int b0 = blockIdx.x * 1024 + tid * 4;
     live = b0 <= ncell && bflag[b0 >> 6] != 0;
@@ -1772,6 +1776,8 @@ __global__ __launch_bounds__(256) void k_scan_partial(int ncell, int ITEM_MAX, c
     __shared__ int sh[4];
     __shared__ int sh_sum[256];
     const int tid = threadIdx.x;
+    // a workgroup none of whose 16 blocks is occupied (at 256^3: 16,000 of 16,400) has nothing to add
+    if (!__syncthreads_or(scan_live(ncell, bflag, tid))) { if (tid == 0) partial[blockIdx.x] = make_int4(0, 0, 0, 0); return; }
     int c[4], blk_cnt;
     bool live;
     const int sp = scan_load(ncell, cnt, bflag, tid, c, sh_sum, blk_cnt, live);
@@ -1790,6 +1796,12 @@ __global__ __launch_bounds__(256) void k_scan_final(int ncell, int ITEM_MAX, int
     __shared__ int sh_sum[256];
     __shared__ int sh_bp[256];
     const int tid = threadIdx.x;
+    // Nothing occupied here (and not the workgroup that writes the totals): only the block table has to say so.  Without this
+    // exit every one of the 16,400 workgroups of a 256^3 grid summed the partials of all those before it (110 us per sort).
+    if (!__syncthreads_or(scan_live(ncell, bflag, tid)) && blockIdx.x != gridDim.x - 1) {
+        if (tid < 16 && blockIdx.x * 16 + tid < ncell / 64) blk_first[blockIdx.x * 16 + tid] = make_int2(0, 0);
+        return;
+    }
     int pp = 0, pi = 0, pm = 0, ps = 0;                       // sums of the partials before this workgroup
     for (int w = tid; w < (int)blockIdx.x; w += 256) { int4 t = partial[w]; pp += t.x; pi += t.y; pm += t.z; ps += t.w; }
     int base_p, base_i, base_m, base_s, dummy;
