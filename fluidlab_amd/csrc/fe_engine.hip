@@ -251,14 +251,12 @@ __device__ __forceinline__ void seg_scan3(const SegScan& sc, float& a, float& b,
 struct TableP {
     const int*  pid_of_slot;   // [Np]
     const float4* info;        // [Np] material record of the particle in each slot (pinfo in slot order: a coalesced load, not pinfo[pid])
-    const int4* items;         // (block, start, count <= 128, 0), sorted by block
-    const int2* pairs;         // workgroups of blocks with several items: (item, its partner in the same block or -1)
-    const int*  singles;       // the items of blocks with a single item (paired up two by two by the kernels)
+    // (the sort's item list -- (block, start, count <= 128), sorted by block --, its pair list for blocks with several items and
+    //  its list of single-item blocks stay on the host side of the table: the kernels read what k_build_units made of them)
     const int*  meta;          // meta[0] = n_items, [1] = tail_start, [2] = n_active, [3] = n pairs, [4] = n singles, [5] = n unit slots
     const struct Unit* units;  // what workgroup w of the particle kernels works on: ready-made descriptors, XCD order (see Unit)
     int units_cap;
     const int2* nbr;           // [n_active * 27] (first item, item count) of the 27 neighbours of each active-list entry's block
-    const int2* blk_first;     // [nblk] (first item, item count) of a block
     const int*  active;        // blocks within one block of an occupied block: every block a tile can reach
     const int*  blk_slot;      // [nblk] index of a block in `active`, or -1
 };
@@ -2377,7 +2375,7 @@ struct FeEngine {
     float*& spare_frame() { return frame_ptr[L + 1]; }
     float* grad(int f) { return grad_ptr[f & 1]; }
     size_t grad_words() const { return (size_t)GR_WORDS * Np + Np; }
-    TableP tableP(int id) const { TableP t; t.pid_of_slot = tables[id].pid; t.info = tables[id].info; t.pairs = tables[id].pairs; t.singles = tables[id].singles; t.items = tables[id].items; t.meta = tables[id].meta; t.blk_first = tables[id].blk_first; t.active = tables[id].active; t.blk_slot = tables[id].blk_slot; t.units = tables[id].units; t.units_cap = (int)units_cap; t.nbr = tables[id].nbr; return t; }
+    TableP tableP(int id) const { TableP t; t.pid_of_slot = tables[id].pid; t.info = tables[id].info; t.meta = tables[id].meta; t.active = tables[id].active; t.blk_slot = tables[id].blk_slot; t.units = tables[id].units; t.units_cap = (int)units_cap; t.nbr = tables[id].nbr; return t; }
     const int* pid_of(int f) const { return tables[tbl_of_frame[f]].pid; }
 };
 
