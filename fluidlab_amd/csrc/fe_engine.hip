@@ -2363,6 +2363,7 @@ struct FeEngine {
     size_t bytes = 0;
     std::string err;
     hipEvent_t ev_t0 = nullptr, ev_t1 = nullptr, ev_batch = nullptr;
+    hipStream_t own_stream = nullptr;                       // the engine's stream; `stream` is the leader's while a batch call runs
     // per-kernel profiling
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev; std::vector<int> prof_kid; size_t prof_used = 0;
@@ -2724,9 +2725,29 @@ bool batchable(FeEngine** hs, int B) {
 }
 inline dim3 wgrid_b(FeEngine** hs, int B) { unsigned g = 0; for (int i = 0; i < B; i++) g = std::max(g, wgrid(hs[i]).x); return dim3(g, B); }
 
+// Inside a batch call every engine enqueues on the leader's stream.  The per-engine stretches of a substep -- the sort's nine
+// small launches, the adjoint reorder -- are independent of each other: they fork onto the engines' own streams, where the
+// launches of different engines overlap, and join the leader's stream again before the next shared launch.
+void batch_fork(FeEngine** hs, int B) {
+    (void)hipEventRecord(hs[0]->ev_batch, hs[0]->own_stream);
+    for (int i = 1; i < B; i++) { (void)hipStreamWaitEvent(hs[i]->own_stream, hs[0]->ev_batch, 0); hs[i]->stream = hs[i]->own_stream; }
+}
+void batch_join(FeEngine** hs, int B) {
+    for (int i = 1; i < B; i++) {
+        (void)hipEventRecord(hs[i]->ev_batch, hs[i]->own_stream);
+        (void)hipStreamWaitEvent(hs[0]->own_stream, hs[i]->ev_batch, 0);
+        hs[i]->stream = hs[0]->own_stream;
+    }
+}
+
 int substep_fwd_batch(FeEngine** hs, int B, int f, int f_global, int act) {
     FeEngine* h0 = hs[0];
     Batch<P2GArgs> bp; Batch<GridArgs> bg; Batch<G2PArgs> bq;
+    const bool sorting = h0->sort_interval > 0 && f % h0->sort_interval == 0;     // (batchable: the same interval in every engine)
+    if (sorting) batch_fork(hs, B);
+    struct Join { FeEngine** hs; int B; bool on; ~Join() { if (on) batch_join(hs, B); } };
+    {
+    Join join{hs, B, sorting};
     for (int i = 0; i < B; i++) {
         FeEngine* h = hs[i];
         h->gs_host_valid = false;
@@ -2741,6 +2762,7 @@ int substep_fwd_batch(FeEngine** hs, int B, int f, int f_global, int act) {
         bp.a[i] = P2GArgs{h->S, h->frame(f), h->frame(f + 1), T, h->pool_idx, grid_w(h), ag, inj, act, f, grid_store(h)};
         bg.a[i] = GridArgs{h->S, T, h->slab, h->g_in, h->g_out, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f, h->frame_slow_dev, statics_p(h), ag};
         bq.a[i] = G2PArgs{h->S, h->frame(f), h->frame(f + 1), T, h->g_out, h->blk_count, h->slow_dev, ag, f};
+    }
     }
     prof_begin(h0, KID_P2G);
     if (h0->all_simple_liquid) hipLaunchKernelGGL((k_p2g_b<true, false>), wgrid_b(hs, B), dim3(WG), 0, h0->stream, bp);
@@ -2760,6 +2782,12 @@ int substep_bwd_batch(FeEngine** hs, int B, int f, int f_global, int act) {
     Batch<P2GArgs> bp; Batch<GridArgs> bg; Batch<G2PGradArgs> bq; Batch<GridGradArgs> bgg; Batch<P2GGradArgs> bpg;
     const InjectP noinj = {0, 0, 0, 0};
     bool all_stored = true;
+    bool reordering = false;                               // some engine's adjoint crosses a sort here
+    for (int i = 0; i < B; i++) { const int from = hs[i]->gtbl[(f + 1) & 1]; reordering = reordering || (from >= 0 && from != hs[i]->tbl_of_frame[f]); }
+    if (reordering) batch_fork(hs, B);
+    struct Join { FeEngine** hs; int B; bool on; ~Join() { if (on) batch_join(hs, B); } };
+    {
+    Join join{hs, B, reordering};
     for (int i = 0; i < B; i++) {
         FeEngine* h = hs[i];
         InjectP inj;
@@ -2784,6 +2812,7 @@ int substep_bwd_batch(FeEngine** hs, int B, int f, int f_global, int act) {
         bgg.a[i] = GridGradArgs{h->S, T, h->slab, h->g_in, h->gg_out, h->gg_in, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f, statics_p(h), ag, h->node_work, h->node_work_count};
         bpg.a[i] = P2GGradArgs{h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->pool_idx, h->gg_in, h->blk_count, h->slow_dev, ag, inj, act, f};
         h->gtbl[f & 1] = t;
+    }
     }
     if (!all_stored) {                                    // (the kernels of an env whose frame is stored return at once)
         prof_begin(h0, KID_P2G_RE);
@@ -2810,18 +2839,17 @@ int substep_bwd_batch(FeEngine** hs, int B, int f, int f_global, int act) {
 // All engines of a batch work on the leader's stream for the duration of the call: it first waits for whatever the others have
 // queued on their own streams, and they wait for it afterwards.
 struct BatchStreams {
-    FeEngine** hs; int B; std::vector<hipStream_t> own;
-    BatchStreams(FeEngine** hs_, int B_) : hs(hs_), B(B_), own(B_) {
-        for (int i = 0; i < B; i++) own[i] = hs[i]->stream;
+    FeEngine** hs; int B;
+    BatchStreams(FeEngine** hs_, int B_) : hs(hs_), B(B_) {
         for (int i = 1; i < B; i++) {
-            (void)hipEventRecord(hs[i]->ev_batch, own[i]);
-            (void)hipStreamWaitEvent(own[0], hs[i]->ev_batch, 0);
-            hs[i]->stream = own[0];
+            (void)hipEventRecord(hs[i]->ev_batch, hs[i]->own_stream);
+            (void)hipStreamWaitEvent(hs[0]->own_stream, hs[i]->ev_batch, 0);
+            hs[i]->stream = hs[0]->own_stream;
         }
     }
     ~BatchStreams() {
-        (void)hipEventRecord(hs[0]->ev_batch, own[0]);
-        for (int i = 1; i < B; i++) { hs[i]->stream = own[i]; (void)hipStreamWaitEvent(own[i], hs[0]->ev_batch, 0); }
+        (void)hipEventRecord(hs[0]->ev_batch, hs[0]->own_stream);
+        for (int i = 1; i < B; i++) { hs[i]->stream = hs[i]->own_stream; (void)hipStreamWaitEvent(hs[i]->own_stream, hs[0]->ev_batch, 0); }
     }
 };
 
@@ -2901,6 +2929,7 @@ FeEngine* fe_create(const FeConfig* cfg) {
     auto fail = [&](const std::string& m) { g_create_err = m.empty() ? h->err : m; fe_destroy(h); return (FeEngine*)nullptr; };
     if (hipSetDevice(h->device) != hipSuccess) return fail("hipSetDevice failed");
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
+    h->own_stream = h->stream;
     SimP& S = h->S;
     S.xcd = 1;
     S.N = h->N; S.Np = h->Np; S.n = h->n; S.nb = h->nb; S.ncell = h->nb * h->nb * h->nb * 64;
@@ -2976,7 +3005,7 @@ void fe_destroy(FeEngine* h) {
     if (h->ev_t0) (void)hipEventDestroy(h->ev_t0);
     if (h->ev_t1) (void)hipEventDestroy(h->ev_t1);
     if (h->ev_batch) (void)hipEventDestroy(h->ev_batch);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
 }
 
