@@ -1,0 +1,78 @@
+"""Seeded random scenes through the C ABI, HIP engine against the fp64 oracle, forward and backward.
+
+Every case draws its own grid size, particle count (down to a handful, never a multiple of the wave size on purpose), material mix,
+cluster layout (dense clumps, droplets, particles hugging the domain walls), velocities (slow, or fast enough to leave tiles between
+two sorts), sort interval, work-item size and grid-store mode.  What the hand-written scenes of test_hip_parity.py pin one by one, these
+cases cross: the work list with one-particle items next to full ones, tiles at the edge of the grid, marked and unmarked blocks of
+the active list, slow-path deposits, the recompute path of the backward pass."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(__file__))
+import scenarios as S  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def random_scene(seed):
+    rng = np.random.RandomState(1000 + seed)
+    n_grid = int(rng.choice([16, 32, 64]))
+    N = int(rng.choice([3, 17, 130, 700, 2500, 6001]))
+    # the 3^3 stencil has to stay on the grid (x < (n - 1.5) / n): the walls move in with the cell size, as in the hand-written scenes
+    wall = (0.2, 0.8) if n_grid == 16 else (0.05, 0.95)
+    lo, hi = wall[0] + 0.03, wall[1] - 0.03
+    parts = []
+    left = N
+    while left > 0:                                                # clumps of random size and tightness, then droplets
+        k = int(min(left, max(1, rng.randint(1, max(2, N // 2)))))
+        c = rng.uniform(lo + 0.1, hi - 0.1, 3)
+        r = rng.choice([0.5 / n_grid, 2.0 / n_grid, 0.08, 0.3])
+        parts.append(np.clip(c + rng.uniform(-r, r, (k, 3)), lo, hi))
+        left -= k
+    x = np.concatenate(parts)
+    fast = rng.rand() < 0.4
+    if fast:                                                       # a fast scene keeps clear of the walls (up to 0.05 of travel)
+        x = 0.5 + (x - 0.5) * 0.5
+    elif rng.rand() < 0.5:                                         # a sheet against a wall: tiles at the edge of the grid
+        m = rng.rand(N) < 0.3
+        x[m, rng.randint(3)] = rng.choice([lo + 1e-3, hi - 1e-3])
+    liquid_only = rng.rand() < 0.5
+    pool = [S.WATER, S.MILK] if liquid_only else [S.WATER, S.MILK_VIS, S.ELASTIC, S.ICECREAM]
+    mat = np.array(pool, np.int32)[rng.randint(0, len(pool), N)]
+    drift = rng.normal(0, 1.0, 3)
+    v = rng.normal(0, 0.5, (N, 3)) + (11.0 * drift / np.linalg.norm(drift) if fast else 0.0)
+    sc = dict(n_grid=n_grid, N=N, dt=2e-4, gravity=(0.0, -10.0, 0.0), n_substeps=10,
+              boundary=dict(type='cube', lower=(wall[0],) * 3, upper=(wall[1],) * 3),
+              x=S.f32(x), used=(rng.rand(N) > 0.05).astype(np.int32), mat=mat, v=S.f32(v),
+              C=S.f32(rng.normal(0, 1.0, (N, 3, 3))),
+              F=S.f32(np.eye(3)[None] + rng.normal(0, 1.0, (N, 3, 3)) * np.where((mat == S.ICECREAM)[:, None, None], 0.002, 0.02)))
+    opts = {'sort_interval': int(rng.choice([0, 1, 4, 10])), 'grid_store': int(rng.rand() < 0.7),
+            'item_max': int(rng.choice([64, 96, 128]))}
+    n_sub = int(rng.choice([5, 12, 21]))
+    return sc, opts, n_sub, liquid_only
+
+
+@pytest.mark.parametrize('seed', range(24))
+def test_random_scene_matches_the_oracle(hiplib, oracle64, seed):
+    sc, opts, n_sub, liquid_only = random_scene(seed)
+    g = S.make_engine(hiplib, sc, options=opts)
+    o = S.make_engine(oracle64, sc)
+    cot = S.random_cotangent(sc['N'], seed=seed)
+    sa, ga = S.run_forward_backward(g, n_sub, cot)
+    sb, gb = S.run_forward_backward(o, n_sub, {k: v.astype(np.float64) for k, v in cot.items()})
+    assert (sa['used'] == sb['used']).all()
+    m = sb['used'] > 0
+    if not m.any():
+        return
+    assert np.isfinite(sa['x']).all() and np.abs(sa['x'][m] - sb['x'][m]).max() <= 5e-6
+    assert S.rel_l2(sa['v'][m], sb['v'][m]) <= 2e-3 and S.rel_l2(sa['F'][m], sb['F'][m]) <= 1e-4
+    # the adjoint through SVD / plastic clamp materials is conditioned by 1 / (s_i^2 - s_j^2): the liquid-only cases carry the tight bound
+    tol_cos, tol_rel = (0.99999, 3e-3) if liquid_only else (0.999, 3e-2)
+    for k in ('gx', 'gv', 'gC', 'gF'):
+        if np.abs(gb[k]).max() > 0:
+            assert S.cosine(ga[k], gb[k]) >= tol_cos and S.rel_l2(ga[k], gb[k]) <= tol_rel, (k, S.cosine(ga[k], gb[k]), S.rel_l2(ga[k], gb[k]))
+    ws = g.get_work_stats(n_sub - 1)
+    assert ws['n_items'] == sum(ws['items_by_size'].values())
