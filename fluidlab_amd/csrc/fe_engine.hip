@@ -1456,7 +1456,7 @@ __device__ void effector_move_grad(const EffP& e, int f) {
 // What the constitutive adjoint needs again after the 27-node loop -- C, F and, in the SVD build, U, V, sigma, J -- waits in LDS
 // (s_stash, one column per thread) instead of in registers: round 1 re-read C and F from the frame (72 B per particle of extra
 // HBM traffic) and re-ran the constitutive model, and the SVD build kept everything live (256 + 32 VGPRs, one wave per SIMD).
-#define STASH_GENERAL 40
+#define STASH_GENERAL 36     // C, F, U, V; the singular values and J stay in registers: 36 KB + 16 KB of tile = three workgroups per CU
 #define STASH_LIQUID 18
 template <bool GENERAL> struct Stash { static __device__ __forceinline__ float* at(); };
 __shared__ float s_stash_g[STASH_GENERAL * WG];
@@ -1492,7 +1492,6 @@ __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const Fram
                 stash[(a * 3 + b) * WG + col] = p.C.a[a][b]; stash[(9 + a * 3 + b) * WG + col] = p.F.a[a][b];
                 if (GENERAL) { stash[(18 + a * 3 + b) * WG + col] = k.U.a[a][b]; stash[(27 + a * 3 + b) * WG + col] = k.V.a[a][b]; }
             }
-        if (GENERAL) { stash[36 * WG + col] = k.sig[0]; stash[37 * WG + col] = k.sig[1]; stash[38 * WG + col] = k.sig[2]; stash[39 * WG + col] = k.J; }
     }
     float Gv[3] = {0.f, 0.f, 0.f};
     m3 GA = m3_zero();
@@ -1574,7 +1573,6 @@ __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const Fram
                 p.C.a[a][b] = stash[(a * 3 + b) * WG + col]; p.F.a[a][b] = stash[(9 + a * 3 + b) * WG + col];
                 if (GENERAL) { k.U.a[a][b] = stash[(18 + a * 3 + b) * WG + col]; k.V.a[a][b] = stash[(27 + a * 3 + b) * WG + col]; }
             }
-        if (GENERAL) { k.sig[0] = stash[36 * WG + col]; k.sig[1] = stash[37 * WG + col]; k.sig[2] = stash[38 * WG + col]; k.J = stash[39 * WG + col]; }
         // F_tmp = (I + dt C) F again (27 fma) rather than 9 more stash planes; J of the SVD-free build likewise
         m3 IdtC = m3_scale(p.C, S.dt);
         IdtC.a[0][0] += 1.f; IdtC.a[1][1] += 1.f; IdtC.a[2][2] += 1.f;
