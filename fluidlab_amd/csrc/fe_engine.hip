@@ -521,7 +521,7 @@ __device__ __forceinline__ void p2g_scatter_tile(const SimP& S, const P2GPrep& q
     const bool issue = sc.tail && in_tile;
     const float live = in_tile ? 1.f : 0.f;
     const Stencil& st = q.st;
-#pragma unroll 1
+#pragma unroll
     for (int ij = 0; ij < 9; ij++) {
         const int i = ij / 3, j = ij - 3 * i;
         const float wij = live * STW(st, i, 0) * STW(st, j, 1);
@@ -848,7 +848,7 @@ __device__ __forceinline__ void used_particle_g2p(const SimP& S, const FrameV& c
     // new_C[a][b] = c4 sum W g[a] (o_b - fx_b) = c4 (M[a][b] - fx_b new_v[a]) with M[a][b] = sum W g[a] o_b; o_0 = i and o_1 = j are
     // constant over the inner k loop, so the per-node work is the three products W g[a] and two partial sums.
     m3 M = m3_zero();
-#pragma unroll 1
+#pragma unroll
     for (int ij = 0; ij < 9; ij++) {
         const int i = ij / 3, j = ij - 3 * i;
         const float wij = STW(st, i, 0) * STW(st, j, 1);
@@ -1508,7 +1508,7 @@ __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const Fram
         //   o_1 = j constant over the inner k loop (per-(i,j) partial sums T, Tz);
         //   sum W dx (A^T gin)_b = dx (A^T Gv)_b leaves the loop altogether.
         m3 M = m3_zero();
-#pragma unroll 1
+#pragma unroll
         for (int ij = 0; ij < 9; ij++) {
             const int i = ij / 3, j = ij - 3 * i;
             const float wi = STW(st, i, 0), wj = STW(st, j, 1);
