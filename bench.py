@@ -30,8 +30,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 N_GRID, N_PARTICLES, CHUNK = 128, 200_000, 100
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')      # rocprofv3 --pmc passes of this round's kernels
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0          # measured float4 copy on this part: `frac_of_measured_copy`
+# rocprofv3 --pmc passes of THIS command line (`--steps 20 --warmup 5`), sliced by window (scripts/phase_profile.py): the traffic of
+# the roofline kernel is read for the same windows it is timed in, or not at all
+PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')
+# fixed substep windows of the evolving block, comparable across --steps and across rounds (window w = substeps [100 w, 100 w + 100))
+PHASES = {'falling': (5, 11), 'splash': (26, 34), 'layer': (80, 90)}
 
 # algorithmic bytes per launch (DESIGN.md "Roofline accounting"; N = used particles, Nc = touched nodes).
 # They sum to SURVEY 8d's B_fwd = 216 N + 72 Nc and B_bwd = 308 N + 132 Nc.
@@ -79,6 +84,62 @@ def kernel_table(prof, n_used, nc):
     return out
 
 
+def probe_pass(elib, n_windows, timed, profiled):
+    """The same evolving block once more on a fresh engine, untimed: the touched-node count Nc at every window boundary (the
+    physics is deterministic, so this IS the timed run's Nc history), and per window either its wall time or -- for the windows in
+    `profiled` -- the HIP-event time of every kernel.  Feeds pair_roofline (Nc integrated over the timed windows), roofline (the
+    dominant kernel over the timed windows, bytes from those windows' Nc) and extra.phase_rates."""
+    eng, _ = build_block(elib, 0)
+    rec = []
+    for w in range(n_windows):
+        st = eng.get_stats(0)                                 # frame 0 = the state at substep 100 w (syncs; clears the slow counter)
+        r = {'w': w, 'nc0': int(st['n_cells_touched']), 'n_used': int(st['n_used'])}
+        if w in profiled:
+            eng.profile_enable(True)
+            window_step(eng, CHUNK)
+            r['prof'] = eng.profile_read()
+            eng.profile_enable(False)
+        else:
+            eng.sync(); t0 = time.perf_counter()
+            window_step(eng, CHUNK)
+            eng.sync(); r['dt'] = time.perf_counter() - t0
+        rec.append(r)
+    st = eng.get_stats(0)
+    eng.close()
+    for i, r in enumerate(rec):
+        r['nc1'] = rec[i + 1]['nc0'] if i + 1 < len(rec) else int(st['n_cells_touched'])
+        r['nc'] = 0.5 * (r['nc0'] + r['nc1'])
+    return rec
+
+
+def fold_windows(rec, lo, hi):
+    """Windows [lo, hi) of a probe pass -> pairs/s of the plain-timed ones, per-kernel event times and algorithmic bytes of the
+    profiled ones (bytes of a launch = its window's mean Nc), mean Nc."""
+    ws = [r for r in rec if lo <= r['w'] < hi]
+    if not ws:
+        return None
+    plain = [r for r in ws if 'dt' in r]
+    ms, cnt, byt = {}, {}, {}
+    for r in ws:
+        for name, (m, c) in r.get('prof', {}).items():
+            if c:
+                bp, bc = KERNEL_BYTES.get(name, (0, 0))
+                ms[name] = ms.get(name, 0.0) + m; cnt[name] = cnt.get(name, 0) + c
+                byt[name] = byt.get(name, 0.0) + c * (bp * r['n_used'] + bc * r['nc'])
+    kern = {k: {'avg_us': round(1e3 * ms[k] / cnt[k], 3), 'launches': cnt[k], 'alg_bytes': int(byt[k] / cnt[k]),
+                'GBps': round(byt[k] / (ms[k] * 1e-3) / 1e9, 1)} for k in ms}
+    nc = float(np.mean([r['nc'] for r in ws]))
+    n_used = ws[0]['n_used']
+    out = {'substeps': [lo * CHUNK, hi * CHUNK], 'nc_mean': int(nc), 'nc_min': int(min(min(r['nc0'], r['nc1']) for r in ws)),
+           'nc_max': int(max(max(r['nc0'], r['nc1']) for r in ws)), 'kernels': kern}
+    if plain:
+        rate = len(plain) * CHUNK / sum(r['dt'] for r in plain)
+        b_pair = 524 * n_used + 204 * nc
+        out['pairs_per_s'] = round(rate, 1)
+        out['pair_roofline_frac'] = round(b_pair * rate / 1e9 / HBM_PEAK_GBS, 4)
+    return out
+
+
 def cpu_baseline(budget_s=12.0):
     """The oracle (fp32 build, OpenMP over the host cores) on the same 128^3 / 200k workload: a bounded number of
     forward+backward substep pairs.  Reported, never the target."""
@@ -107,7 +168,8 @@ def cpu_baseline(budget_s=12.0):
     eng.close()
     return {'value': pairs / dt, 'unit': 'substep_pairs/s', 'cores': cores, 'kind': 'port',
             'sample': f'{pairs} fwd+bwd substep pairs of the same 128^3/200k water block (evolving window), oracle fp32 + OpenMP '
-                      f'({cores} of {ncpu} hardware threads, fastest of a short sweep), {dt:.1f}s'}
+                      f'({cores} of {ncpu} hardware threads, fastest of a short sweep), {dt:.1f}s',
+            'scatter': 'particle-parallel loops, `#pragma omp atomic` fp32 adds into the shared grid (P2G and the adjoint scatter of G2P)'}
 
 
 def extra_block(elib, device, name, n_grid, n, mat, L, reps):
@@ -165,51 +227,63 @@ def run_single(args):
     pairs = args.steps * CHUNK
     value = pairs / wall
 
-    # ---- untimed extras
+    # ---- untimed: forward-only rate on the same engine, then the probe pass (Nc history, per-kernel event times, phase windows)
     t1 = time.perf_counter()
     nf = max(2, args.steps // 4)
     for _ in range(nf):
         window_step(eng, CHUNK, backward=False)
     barrier()
     fwd_rate = nf * CHUNK / (time.perf_counter() - t1)
-    eng.profile_enable(True)
-    for _ in range(2):
-        window_step(eng, CHUNK)
-    prof = eng.profile_read()
-    eng.profile_enable(False)
-    st2 = eng.get_stats(CHUNK // 2)
-    n_used, nc = st2['n_used'], st2['n_cells_touched']
-    per_kernel = kernel_table(prof, n_used, nc)
-    # dominant kernel = largest share of the measured time among the kernels that carry algorithmic bytes
-    dom = max((k for k in per_kernel if per_kernel[k]['alg_bytes'] > 0), key=lambda k: prof[k][0])
-    traffic = None
-    try:                                                  # HBM traffic of that kernel from this round's committed PMC passes
-        traffic = int(json.load(open(PMC_TRAFFIC))['kernels'][dom]['traffic_bytes'])
-    except Exception:
-        pass
-    b_pair = 524 * n_used + 204 * nc
-    sorts = prof.get('sort', (0, 0))[1]
+    n_used = int(st1['n_used'])
+    eng.close()
+    w0, w1 = args.warmup, args.warmup + args.steps                     # the timed windows
     out = {
         'metric': METRIC, 'value': round(value, 1), 'unit': 'substep_pairs/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(1e3 * wall / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'water block 128^3 grid, 200k particles (BASELINE configs[1] inputs), fwd+bwd, evolving (rolling window)',
-                   'substeps_per_step': CHUNK, 'timed_pairs': pairs, 'timed_s': round(wall, 3), 'n_used': n_used,
-                   'nc_start': int(st0['n_cells_touched']), 'nc_end': int(st1['n_cells_touched']), 'n_cells_touched': nc,
-                   'n_slow_path': int(st1['n_slow_path']), 'sorts_per_pair': round(sorts / max(1, 2 * CHUNK), 3),
-                   'parallelism': '1 env, 1 GPU'},
-        'roofline': {'bound': 'hbm', 'kernel': dom, 'achieved': per_kernel[dom]['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': round(per_kernel[dom]['GBps'] / HBM_PEAK_GBS, 4), 'traffic': traffic,
-                     'alg_bytes_per_launch': per_kernel[dom]['alg_bytes'], 'avg_launch_us': per_kernel[dom]['avg_us']},
-        'pair_roofline': {'alg_bytes_per_pair': b_pair, 'achieved_GBps': round(b_pair * value / 1e9, 1),
-                          'frac': round(b_pair * value / 1e9 / HBM_PEAK_GBS, 4)},
+                   'substeps_per_step': CHUNK, 'timed_pairs': pairs, 'timed_s': round(wall, 3), 'timed_substeps': [w0 * CHUNK, w1 * CHUNK],
+                   'n_used': n_used, 'nc_start': int(st0['n_cells_touched']), 'nc_end': int(st1['n_cells_touched']),
+                   'n_slow_path': int(st1['n_slow_path']), 'parallelism': '1 env, 1 GPU'},
+        'roofline': None, 'pair_roofline': None,
         'forward_only_substeps_per_s': round(fwd_rate, 1),
         'hip_event_ms_per_step': round(ev_ms / args.steps, 3),
-        'kernels': per_kernel,
     }
-    eng.close()
+    rec = None
+    if not args.no_probe:
+        n_probe = w1 if args.no_extras else max(w1, max(b for _, b in PHASES.values()))
+        # every second timed window is profiled with HIP events on the engine's stream (all of them when there is only one);
+        # the others are wall-timed; outside the timed range likewise within the phase windows
+        profiled = {w for w in range(n_probe) if (w - w0) % 2 == 1 or args.steps == 1}
+        rec = probe_pass(elib, n_probe, range(w0, w1), profiled)
+        tw = fold_windows(rec, w0, w1)
+        kern = tw['kernels']
+        dom = max((k for k in kern if kern[k]['alg_bytes'] > 0), key=lambda k: kern[k]['avg_us'] * kern[k]['launches'])
+        traffic = None
+        try:                                              # PMC passes of this very command line, same windows (else: no claim)
+            pj = json.load(open(PMC_TRAFFIC))
+            if pj['steps'] == args.steps and pj['warmup'] == args.warmup:
+                traffic = int(pj['timed_region']['kernels'][dom]['traffic_bytes'])
+        except Exception:
+            pass
+        b_pair = 524 * n_used + 204 * tw['nc_mean']
+        sorts = kern.get('sort', {}).get('launches', 0)
+        fwd_launches = max(1, kern.get('p2g', {}).get('launches', 1))
+        out['config'].update({'nc_mean_timed': tw['nc_mean'], 'nc_min_timed': tw['nc_min'], 'nc_max_timed': tw['nc_max'],
+                              'sorts_per_pair': round(sorts / fwd_launches, 3)})
+        out['roofline'] = {'bound': 'hbm', 'kernel': dom, 'achieved': kern[dom]['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                           'frac': round(kern[dom]['GBps'] / HBM_PEAK_GBS, 4), 'frac_of_measured_copy': round(kern[dom]['GBps'] / HBM_COPY_GBS, 4),
+                           'traffic': traffic, 'alg_bytes_per_launch': kern[dom]['alg_bytes'], 'avg_launch_us': kern[dom]['avg_us'],
+                           'windows': f'HIP events over every second timed window (substeps {w0 * CHUNK}..{w1 * CHUNK}) of an untimed replay; bytes from those windows\' Nc'}
+        out['pair_roofline'] = {'alg_bytes_per_pair': int(b_pair), 'achieved_GBps': round(b_pair * value / 1e9, 1),
+                                'frac': round(b_pair * value / 1e9 / HBM_PEAK_GBS, 4),
+                                'frac_of_measured_copy': round(b_pair * value / 1e9 / HBM_COPY_GBS, 4),
+                                'nc': 'mean over the timed windows (probe replay), not a post-region sample'}
+        out['kernels'] = kern
     if not args.no_extras:
         extra = {}
+        if rec is not None:
+            extra['phase_rates'] = {name: fold_windows(rec, a, b) for name, (a, b) in PHASES.items() if b <= len(rec)}
         # round 1's headline for continuity: the same block restarted from rest every step (nothing moves, the sort is always fresh)
         e2, _ = build_block(elib, 0, L=50)
         for _ in range(3):
@@ -283,6 +357,10 @@ def run_replicas(args, rank, local_rank, world):
     from fluidlab_amd.optimizer.solver import Solver
     from fluidlab_amd.utils.config import load_config
     dev = 0 if args.one_device else local_rank
+    # every rank on its own cores: the host enqueues ~90 us of launches per 160 us substep pair, i.e. needs most of a core, and
+    # the ranks of a node would otherwise migrate over each other's
+    local_world = int(os.environ.get('LOCAL_WORLD_SIZE', world))
+    cores = pin_to_cores(local_rank, local_world)
     torch.cuda.set_device(dev)
     par = EnvParallel(backend=args.dist_backend, device=dev, always=True)       # init_process_group('nccl' = RCCL), one rank per GPU
     assert par.world_size == world and par.dist is not None and par.dist.get_world_size() == world
@@ -326,6 +404,17 @@ def run_replicas(args, rank, local_rank, world):
         par.barrier()
         torch.cuda.synchronize()
 
+    # the N = 1 figure of THIS scene, measured in this run: rank 0 alone (the others wait at the barrier), one warm and one timed
+    # forward+backward pass, no collective, no update -- the denominator of `scaling_efficiency`
+    barrier()
+    n1_rate = 0.0
+    if rank == 0:
+        for k in range(2):
+            eng.sync(); a = time.perf_counter()
+            with quiet():
+                solver.forward_backward(init['state'], policy, env.horizon, env.horizon_action)
+            eng.sync(); n1_rate = sub / (time.perf_counter() - a)
+    barrier()
     for _ in range(args.warmup):
         one_pass()
     del t_comp[:], t_coll[:]
@@ -340,7 +429,13 @@ def run_replicas(args, rank, local_rank, world):
     t = torch.tensor([wall], dtype=torch.float64, device=cdev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall_max = float(t.item())
-    mine = torch.tensor([sub * args.steps / max(sum(t_comp), 1e-9), 1e6 * float(np.median(t_coll)), float(skipped[0])], dtype=torch.float64, device=cdev)
+    rss_gb = host_rss_gb()
+    hbm_gb = eng.get_stats(sub - 1)['bytes_state'] / 2**30
+    import hashlib
+    dig = hashlib.sha256(np.ascontiguousarray(policy.comp_actions, dtype=np.float64).tobytes()).digest()      # the policy after the last Adam step
+    h_lo, h_hi = float(int.from_bytes(dig[:4], 'little')), float(int.from_bytes(dig[4:8], 'little'))
+    mine = torch.tensor([sub * args.steps / max(sum(t_comp), 1e-9), 1e6 * float(np.median(t_coll)), float(skipped[0]), rss_gb, hbm_gb, float(len(cores)), h_lo, h_hi],
+                        dtype=torch.float64, device=cdev)
     allr = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(allr, mine)
     # latency of the collective itself on a warm communicator (the per-pass figure above also waits for the slowest rank)
@@ -367,18 +462,44 @@ def run_replicas(args, rank, local_rank, world):
                        'substep_pairs_per_step_per_rank': sub, 'rccl_world_size': dist.get_world_size(), 'dist_backend': args.dist_backend,
                        'action_grad_shape': [env.horizon_action + 1, 3], 'lr_scale': args.c4_lr_scale,
                        'parallelism': f'{world} env replicas, one per GPU, 1 all-reduce of the action gradient per pass'},
+            'n1_same_scene_pairs_per_s': round(n1_rate, 1),
+            'scaling_efficiency': round(value / (world * n1_rate), 4) if n1_rate > 0 else None,
             'per_rank_pairs_per_s_compute_only': [round(v, 1) for v in per_rank],
             'weak_scaling_efficiency_vs_rank_compute': round(value / sum(per_rank), 4),
+            'host': {'rss_gb_per_rank': [round(float(a[3]), 2) for a in allr], 'cores_per_rank': [int(a[5]) for a in allr],
+                     'hbm_state_gb_per_rank': [round(float(a[4]), 1) for a in allr], 'cpus_visible': os.cpu_count()},
             'allreduce_us': {'warm_latency': round(ar_us, 1), 'per_pass_median_incl_wait': [round(float(a[1]), 1) for a in allr]},
             'passes_skipped_nonfinite_grad': int(sum(float(a[2]) for a in allr)),
+            'actions_identical_across_ranks': all(float(a[6]) == float(allr[0][6]) and float(a[7]) == float(allr[0][7]) for a in allr),
             'loss_mean_over_envs': [round(v, 3) for v in losses[-args.steps:]],
             'pair_roofline': {'alg_bytes_per_pair': b_pair, 'frac_per_gpu': round(b_pair * value / world / 1e9 / HBM_PEAK_GBS, 4)},
-            'note': 'N=1 prints the water-block line (the configuration the metric is quoted on); the single-replica rate of THIS scene is per_rank_pairs_per_s_compute_only',
+            'note': 'N=1 prints the water-block line (the configuration the metric is quoted on): its `value` is a different workload. The '
+                    'N=1 rate of THIS scene is n1_same_scene_pairs_per_s (rank 0 alone, same run); scaling_efficiency = value / (n_gpus x that)',
         }
         print(json.dumps(out))
     par.barrier()
     eng.close()
     par.close()
+
+
+def pin_to_cores(local_rank, local_world):
+    """Give this rank an equal, contiguous share of the cores the process may run on."""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+        per = max(1, len(cpus) // max(1, local_world))
+        mine = cpus[local_rank * per:(local_rank + 1) * per] or cpus
+        os.sched_setaffinity(0, mine)
+        return mine
+    except (AttributeError, OSError):
+        return []
+
+
+def host_rss_gb():
+    try:
+        import psutil
+        return psutil.Process().memory_info().rss / 2**30
+    except Exception:
+        return 0.0
 
 
 def free_port():
@@ -393,6 +514,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=None)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true')
+    ap.add_argument('--no-probe', action='store_true', help='skip the untimed probe replay (profiler runs: the trace then holds one trajectory)')
     ap.add_argument('--dist-backend', default='nccl', help="'gloo' + --one-device: exercise the N>1 path on a 1-GPU box (tests)")
     ap.add_argument('--one-device', action='store_true', help='tests only: every rank uses GPU 0')
     ap.add_argument('--replicas', action='store_true', help='run the N > 1 workload (LatteArt replicas + all-reduce) even with one rank')

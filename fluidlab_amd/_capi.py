@@ -320,13 +320,15 @@ class Engine:
 
     def _torch_fence(self, *tensors):
         """The engine's stream is non-blocking: nothing orders it with torch's streams.  Before the engine reads or overwrites a
-        torch tensor, whatever torch has queued on it -- the fill of a fresh allocation, an earlier read of a staging tensor --
-        has to be finished (the engine calls themselves return after the engine's stream has drained)."""
+        torch tensor, whatever torch has queued on it -- the fill of a fresh allocation, an earlier read of a staging tensor,
+        a producer on a side stream -- has to be finished: every stream of the tensors' devices is drained (the engine calls
+        themselves return after the engine's stream has drained)."""
+        done = set()
         for t in tensors:
-            if t is not None:
+            if t is not None and t.device not in done:
                 import torch
-                torch.cuda.current_stream(t.device).synchronize()
-                return
+                torch.cuda.synchronize(t.device)
+                done.add(t.device)
 
     def get_frame_dev(self, f, x=None, v=None, C_=None, F=None, used=None):
         self._torch_fence(x, v, C_, F, used)
@@ -337,7 +339,7 @@ class Engine:
         self._ck(self.lib.fe_set_frame_dev(self.h, int(f), self._tptr(x), self._tptr(v), self._tptr(C_), self._tptr(F), self._tptr(used)))
 
     def add_grad_dev(self, f, gx=None, gv=None, gC=None, gF=None):
-        """fe_add_grad_dev: torch tensors on the engine's GPU (the producing torch stream is synchronised here)"""
+        """fe_add_grad_dev: torch tensors on the engine's GPU (their device is synchronised here, whichever stream produced them)"""
         self._torch_fence(gx, gv, gC, gF)
         self._ck(self.lib.fe_add_grad_dev(self.h, int(f), self._tptr(gx), self._tptr(gv), self._tptr(gC), self._tptr(gF)))
 

@@ -40,11 +40,33 @@ struct Plane {
     __host__ __device__ __forceinline__ T& operator[](int s) const { return *(T*)(base + (size_t)(off + (unsigned)s * (unsigned)sizeof(T))); }
     __host__ __device__ __forceinline__ T* ptr() const { return (T*)(base + (size_t)off); }
 };
+// Write-through (sc1) stores, option "write_through".  A kernel boundary costs its ~1.8 us plus (dirty bytes left in the per-XCD
+// L2s) / ~6 TB/s (MI355X_MICROARCH.md, `boundary`): the substep kernels leave 11-19 MB each.  Bulk outputs that no later part of the
+// same kernel reads -- the new particle state, the adjoint frame, the slabs -- can go through to memory while the kernel is still
+// computing.  A buffer store through a descriptor over the plane's base, with the plane offset + slot as the 32-bit offset.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wt_rsrc(void* base) { return __builtin_amdgcn_make_buffer_rsrc(base, 0, -1, 0x00020000); }
+__device__ __forceinline__ void wt_store16(void* base, unsigned byte_off, float4 v) {
+    const u32x4 u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(u, wt_rsrc(base), (int)byte_off, 0, 16);              // aux 16 = sc1
+}
+__device__ __forceinline__ void wt_store4(void* base, unsigned byte_off, unsigned v) { __builtin_amdgcn_raw_buffer_store_b32(v, wt_rsrc(base), (int)byte_off, 0, 16); }
 struct FrameV {
     Plane<float4> A0, A1, A2; Plane<float> a3, a4, a5; Plane<float4> B0, B1; Plane<float> b2; Plane<int> used;
+    int wt;                                  // stores into this frame go through to memory (kernels that produce a whole frame)
 };
-__host__ __device__ inline FrameV frame_view(float* base_, size_t Np_) {
+__device__ __forceinline__ void pstore(const FrameV& fr, const Plane<float4>& p, int s, float4 v) {
+    if (fr.wt) wt_store16(p.base, p.off + (unsigned)s * 16u, v); else p[s] = v;
+}
+__device__ __forceinline__ void pstore(const FrameV& fr, const Plane<float>& p, int s, float v) {
+    if (fr.wt) wt_store4(p.base, p.off + (unsigned)s * 4u, __float_as_uint(v)); else p[s] = v;
+}
+__device__ __forceinline__ void pstore(const FrameV& fr, const Plane<int>& p, int s, int v) {
+    if (fr.wt) wt_store4(p.base, p.off + (unsigned)s * 4u, (unsigned)v); else p[s] = v;
+}
+__host__ __device__ inline FrameV frame_view(float* base_, size_t Np_, int wt = 0) {
     FrameV v;
+    v.wt = wt;
     char* base = (char*)base_;
     const unsigned Np = (unsigned)Np_;
     v.A0 = {base, 0u}; v.A1 = {base, 16u * Np}; v.A2 = {base, 32u * Np};
@@ -68,15 +90,31 @@ __device__ __forceinline__ void load_F(const FrameV& fr, int s, m3& F) {
     F.a[1][1] = b1.x; F.a[1][2] = b1.y; F.a[2][0] = b1.z; F.a[2][1] = b1.w; F.a[2][2] = fr.b2[s];
 }
 __device__ __forceinline__ void store_xvC(const FrameV& fr, int s, const float x[3], const float v[3], const m3& C) {
-    fr.A0[s] = make_float4(x[0], x[1], x[2], v[0]);
-    fr.A1[s] = make_float4(v[1], v[2], C.a[0][0], C.a[0][1]);
-    fr.A2[s] = make_float4(C.a[0][2], C.a[1][0], C.a[1][1], C.a[1][2]);
-    fr.a3[s] = C.a[2][0]; fr.a4[s] = C.a[2][1]; fr.a5[s] = C.a[2][2];
+    const float4 a0 = make_float4(x[0], x[1], x[2], v[0]), a1 = make_float4(v[1], v[2], C.a[0][0], C.a[0][1]), a2 = make_float4(C.a[0][2], C.a[1][0], C.a[1][1], C.a[1][2]);
+    if (fr.wt) {                                             // (one uniform branch around the whole group of stores)
+        const unsigned o16 = (unsigned)s * 16u, o4 = (unsigned)s * 4u;
+        wt_store16(fr.A0.base, fr.A0.off + o16, a0); wt_store16(fr.A0.base, fr.A1.off + o16, a1); wt_store16(fr.A0.base, fr.A2.off + o16, a2);
+        wt_store4(fr.A0.base, fr.a3.off + o4, __float_as_uint(C.a[2][0])); wt_store4(fr.A0.base, fr.a4.off + o4, __float_as_uint(C.a[2][1]));
+        wt_store4(fr.A0.base, fr.a5.off + o4, __float_as_uint(C.a[2][2]));
+    } else {
+        fr.A0[s] = a0; fr.A1[s] = a1; fr.A2[s] = a2;
+        fr.a3[s] = C.a[2][0]; fr.a4[s] = C.a[2][1]; fr.a5[s] = C.a[2][2];
+    }
 }
 __device__ __forceinline__ void store_F(const FrameV& fr, int s, const m3& F) {
-    fr.B0[s] = make_float4(F.a[0][0], F.a[0][1], F.a[0][2], F.a[1][0]);
-    fr.B1[s] = make_float4(F.a[1][1], F.a[1][2], F.a[2][0], F.a[2][1]);
-    fr.b2[s] = F.a[2][2];
+    const float4 b0 = make_float4(F.a[0][0], F.a[0][1], F.a[0][2], F.a[1][0]), b1 = make_float4(F.a[1][1], F.a[1][2], F.a[2][0], F.a[2][1]);
+    if (fr.wt) {
+        wt_store16(fr.A0.base, fr.B0.off + (unsigned)s * 16u, b0); wt_store16(fr.A0.base, fr.B1.off + (unsigned)s * 16u, b1);
+        wt_store4(fr.A0.base, fr.b2.off + (unsigned)s * 4u, __float_as_uint(F.a[2][2]));
+    } else { fr.B0[s] = b0; fr.B1[s] = b1; fr.b2[s] = F.a[2][2]; }
+}
+// F and the `used` flag together (p2g: one branch for the whole group)
+__device__ __forceinline__ void store_F_used(const FrameV& fr, int s, const m3& F, int used) {
+    const float4 b0 = make_float4(F.a[0][0], F.a[0][1], F.a[0][2], F.a[1][0]), b1 = make_float4(F.a[1][1], F.a[1][2], F.a[2][0], F.a[2][1]);
+    if (fr.wt) {
+        wt_store16(fr.A0.base, fr.B0.off + (unsigned)s * 16u, b0); wt_store16(fr.A0.base, fr.B1.off + (unsigned)s * 16u, b1);
+        wt_store4(fr.A0.base, fr.b2.off + (unsigned)s * 4u, __float_as_uint(F.a[2][2])); wt_store4(fr.A0.base, fr.used.off + (unsigned)s * 4u, (unsigned)used);
+    } else { fr.B0[s] = b0; fr.B1[s] = b1; fr.b2[s] = F.a[2][2]; fr.used[s] = used; }
 }
 
 // grid: float4 per node, nodes grouped in 4x4x4 blocks of 64 contiguous float4 (1 KiB)
@@ -101,6 +139,7 @@ struct SimP {
     int N, Np, n, nb;
     int ncell;                               // nb^3 * 64: plane stride of the SoA accumulator grids
     int xcd;                                 // option "xcd_map": consecutive work items on the same XCD (shared L2)
+    int wt;                                  // option "write_through": bulk outputs as sc1 stores (see wt_store16)
     float dx, inv_dx, dt, stress_scale;     // stress_scale = -dt * p_vol * 4 * inv_dx^2 (mpm:343)
     float g[3];
     BoundaryP bnd;
@@ -394,6 +433,12 @@ __device__ __forceinline__ void mark_dirty(const GridStore& GS, const int* __res
     if (e >= 0) GS.dirty[e] = GS.stamp;
 }
 
+// one node of a slab (the slab index is wave-uniform: the descriptor of the write-through form is built over the slab itself)
+__device__ __forceinline__ void slab_store(float4* slab, int item, int l, float4 v, int wt) {
+    float4* base = slab + (size_t)item * TILE_N;
+    if (wt) wt_store16(base, (unsigned)l * 16u, v); else base[l] = v;
+}
+
 struct GridW {            // everything a scattering particle needs of the global grid
     float* g_in; float4* slab; int ncell; int* frame_slow; int* blk_flag; int* blk_list; int* blk_count; int* err; int* slow;
 };
@@ -426,7 +471,7 @@ __device__ __forceinline__ void unused_particle_fwd(const SimP& S, const FrameV&
     }
     store_xvC(nxt, s, p.x, p.v, p.C);
     store_F(nxt, s, p.F);
-    nxt.used[s] = used_next;
+    pstore(nxt, nxt.used, s, used_next);
 }
 
 // collector_act_kernel (agent_pouring.py:30-41, agent_jetbot.py:33-43) for one used slot: outside the collector boundary the
@@ -461,7 +506,7 @@ __device__ __forceinline__ void p2g_compute(const SimP& S, const FrameV& nxt, in
     const PInfo& info = r.info;
     Constitutive k;
     constitutive_eval_t<GENERAL>(p.C, p.F, S.dt, info.mu, info.lam, info.mass, info.cls, S.stress_scale, k);
-    if (WRITE) { store_F(nxt, s, k.Fnew); nxt.used[s] = 1; }
+    if (WRITE) store_F_used(nxt, s, k.Fnew, 1);
     stencil_make(p.x, S.inv_dx, q.st);
     q.inside = stencil_inside(q.st, S.n);
     if (!q.inside) atomicAdd(G.err, 1);
@@ -559,7 +604,7 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
         for (int i = 0; i < agent.n; i++) effector_move(agent.e[i], f);
     }
     FrameV cur = frame_view(fr_cur, S.Np);
-    FrameV nxt = frame_view(fr_next, S.Np);
+    FrameV nxt = frame_view(fr_next, S.Np, S.wt);
     TL(S, 0);
     Unit un = unit_load(T, blockIdx.x);                       // this workgroup's first unit, asked for together with meta
     const int n_slots = T.meta[5];
@@ -609,7 +654,7 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
             // hand the tile over: plain coalesced float4 stores into the item's slab.  No atomics, no waiting:
             // k_grid sums, per node, the slabs of the (at most 8) blocks whose tiles reach it, in a fixed order.
             if (pc.live) for (int l = pc.t0; l < TILE_N; l += pc.nth)
-                G.slab[(size_t)pc.slab * TILE_N + l] = make_float4((float)s_acc[aofs + l], (float)s_acc[aofs + TILE_N + l], (float)s_acc[aofs + 2 * TILE_N + l], (float)s_acc[aofs + 3 * TILE_N + l]);
+                slab_store(G.slab, pc.slab, l, make_float4((float)s_acc[aofs + l], (float)s_acc[aofs + TILE_N + l], (float)s_acc[aofs + 2 * TILE_N + l], (float)s_acc[aofs + 3 * TILE_N + l]), S.wt);
             __syncthreads();
             TL(S, 6);
         } else {
@@ -928,7 +973,7 @@ __device__ __forceinline__ void g2p_body(SimP S, float* fr_cur, float* fr_next, 
     const int tid = threadIdx.x;
     if (blockIdx.x == 0 && tid == 0) *blk_count = 0;          // grid_op was the last reader of the active list
     FrameV cur = frame_view(fr_cur, S.Np);
-    FrameV nxt = frame_view(fr_next, S.Np);
+    FrameV nxt = frame_view(fr_next, S.Np, S.wt);
     TL(S, 0);
     Unit un = unit_load(T, blockIdx.x);                       // this workgroup's first unit, asked for together with meta
     const int n_slots = T.meta[5];
@@ -1053,7 +1098,7 @@ __device__ __forceinline__ void used_particle_g2p_grad(const SimP& S, const Fram
     }
 #pragma unroll
     for (int b = 0; b < 3; b++) gfx[b] -= c4 * (nvw[0] * g.C.a[0][b] + nvw[1] * g.C.a[1][b] + nvw[2] * g.C.a[2][b]);     // dpos_b = o_b - fx_b
-    if (!TILE || live) Gc.A0[s] = make_float4(g.x[0] + S.inv_dx * gfx[0], g.x[1] + S.inv_dx * gfx[1], g.x[2] + S.inv_dx * gfx[2], 0.f);
+    if (!TILE || live) pstore(Gc, Gc.A0, s, make_float4(g.x[0] + S.inv_dx * gfx[0], g.x[1] + S.inv_dx * gfx[1], g.x[2] + S.inv_dx * gfx[2], 0.f));
 }
 
 // one slot on the global path (tail / sort_interval = 0)
@@ -1118,7 +1163,7 @@ __device__ __forceinline__ void g2p_grad_body(SimP S, float* fr_cur, float* Gn_,
     const bool stored = GS.cap > 0 && GS.flag[f];
     VoutSrc V; V.g_out = g_out; V.store = stored ? GS.data + (size_t)f * GS.cap * 128 : nullptr; V.blk_slot = T.blk_slot;
     FrameV cur = frame_view(fr_cur, S.Np);
-    FrameV Gn = frame_view(Gn_, S.Np), Gc = frame_view(Gc_, S.Np);
+    FrameV Gn = frame_view(Gn_, S.Np), Gc = frame_view(Gc_, S.Np, S.wt);
     TL(S, 0);
     Unit un = unit_load(T, blockIdx.x);                       // this workgroup's first unit, asked for together with meta
     const int n_slots = T.meta[5];
@@ -1161,7 +1206,7 @@ __device__ __forceinline__ void g2p_grad_body(SimP S, float* fr_cur, float* Gn_,
             __syncthreads();
             TL(S, 6);
             if (pc.live) for (int l = pc.t0; l < TILE_N; l += pc.nth)
-                slab[(size_t)pc.slab * TILE_N + l] = make_float4((float)s_acc3[tofs + l], (float)s_acc3[tofs + TILE_N + l], (float)s_acc3[tofs + 2 * TILE_N + l], 0.f);
+                slab_store(slab, pc.slab, l, make_float4((float)s_acc3[tofs + l], (float)s_acc3[tofs + TILE_N + l], (float)s_acc3[tofs + 2 * TILE_N + l], 0.f), S.wt);
             __syncthreads();
             TL(S, 7);
         } else {
@@ -1175,6 +1220,178 @@ struct G2PGradArgs { SimP S; float* fr_cur; float* Gn_; float* Gc_; TableP T; co
 __global__ __launch_bounds__(WG, 4) void k_g2p_grad(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T, const float4* g_out, float* gg_out, float4* slab, int* slow, GridStore GS, int f, AgentP agent) { g2p_grad_body(S, fr_cur, Gn_, Gc_, T, g_out, gg_out, slab, slow, GS, f, agent); }
 
 __global__ __launch_bounds__(WG, 4) void k_g2p_grad_b(Batch<G2PGradArgs> B) { const G2PGradArgs& A = B.a[blockIdx.y]; g2p_grad_body(A.S, A.fr_cur, A.Gn_, A.Gc_, A.T, A.g_out, A.gg_out, A.slab, A.slow, A.GS, A.f, A.agent); }
+
+
+// -----------------------------------------------------------------------------------------
+// k_g2p_grad2 (option "g2p_grad_v", default): the same adjoint with the 27-node loop split in two, each half unrolled completely.
+// Round 2's kernel gathers (v_out -> the position adjoint) and scatters (three scanned values -> d v_out) in ONE loop; unrolled it
+// needs 650 B of scratch per lane, so it stayed a rolled 9 x 3 loop with register selects of the weights -- 7.8 us of the
+// workgroup's 11.7 at C2, where k_g2p's gather takes 1.5 and k_p2g's four-value scatter 4.9.  Here the gather pass runs first (tile
+// reads, nine partial sums, nothing scanned; the position adjoint is stored as soon as it is done), then the scatter pass (no tile
+// reads: w q recomputed from 12 coefficients, three scanned values per node).  Between the passes only the coefficients of
+// q(o) = qb + o_x qx + o_y qy + o_z qz and the nine weights are live.
+// The tile of v_out comes through the 27 neighbour entries of the item's block, fetched by 27 lanes together with the particle
+// state (k_p2g's neighbour_entry): round 2 looked every tile node's block up in blk_slot first (two dependent hops per node).
+// -----------------------------------------------------------------------------------------
+__device__ __forceinline__ int tile_region(int t) { return (t + 3) >> 2; }        // tile index 0 -> block B-1, 1..4 -> B, 5..7 -> B+1
+__device__ __forceinline__ void g2p_grad_load_tile2(const TileO& to, const SimP& S, const float4* __restrict__ g_out,
+                                                    const float4* __restrict__ st, int nbr_entry, const PairCtx& pc) {
+    if (!pc.live) return;                                    // (whole waves: the shuffles below see all 64 lanes)
+    const int tofs = pc.ti * 3 * TILE_N;
+    for (int l = pc.t0; l < TILE_N; l += pc.nth) {
+        const int tx = l >> 6, ty = (l >> 3) & 7, tz = l & 7;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (st) {
+            const int e = __shfl(nbr_entry, tile_region(tx) * 9 + tile_region(ty) * 3 + tile_region(tz), 64);
+            if (e >= 0) v = st[(size_t)e * 128 + 64 + ((((tx + 3) & 3) << 4) | (((ty + 3) & 3) << 2) | ((tz + 3) & 3))];
+        } else {
+            int i, j, k;
+            if (tile_node(to, l, S.n, i, j, k)) v = g_out[cell_addr(i, j, k, S.nb)];
+        }
+        s_tile3[tofs + l] = v.x; s_tile3[tofs + TILE_N + l] = v.y; s_tile3[tofs + 2 * TILE_N + l] = v.z;
+    }
+}
+
+// executed by ALL lanes of the wave (`live` = this lane holds a used particle whose stencil fits the tile)
+template <int MINW>
+__device__ __forceinline__ void g2p_grad_particle2(const SimP& S, const FrameV& Gn, const FrameV& Gc, int s, int lb, const Stencil& st,
+                                                   bool live, int tofs) {
+    PState g;                                   // adjoints of x', v', C'
+    if (live) load_xvC(Gn, s, g);
+    else { g.x[0] = g.x[1] = g.x[2] = g.v[0] = g.v[1] = g.v[2] = 0.f; g.C = m3_zero(); }
+    const float c4 = 4.f * S.inv_dx;
+    // q(o) = gv + c4 gC (o - fx), gv = v'_bar + dt x'_bar  (x' = x + dt v')
+    float qb[3], qx[3], qy[3], qz[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        qx[a] = c4 * g.C.a[a][0]; qy[a] = c4 * g.C.a[a][1]; qz[a] = c4 * g.C.a[a][2];
+        qb[a] = (g.v[a] + S.dt * g.x[a]) - (qx[a] * st.fx[0] + qy[a] * st.fx[1] + qz[a] * st.fx[2]);
+    }
+    const int l0 = tofs + lb;
+    {   // ---- pass 1: gather.  gfx_d = sum_o dW/df_d (v_o . q_o),  nvw = sum_o W v_o
+        const float dwz[3] = {stencil_dw(st, 0, 2), stencil_dw(st, 1, 2), stencil_dw(st, 2, 2)};      // (the x and y ones are one VALU each: made where used)
+        float gfx[3] = {0.f, 0.f, 0.f}, nvw[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ij = 0; ij < 9; ij++) {
+            const int i = ij / 3, j = ij - 3 * i;
+            float qij[3];
+#pragma unroll
+            for (int a = 0; a < 3; a++) qij[a] = qb[a] + (float)i * qx[a] + (float)j * qy[a];
+            float T = 0.f, Tz = 0.f, P[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 3; kk++) {
+                const int l = l0 + (i * TILE_T + j) * TILE_T + kk;
+                const float v0 = s_tile3[l], v1 = s_tile3[TILE_N + l], v2 = s_tile3[2 * TILE_N + l];
+                const float sdot = v0 * (qij[0] + (float)kk * qz[0]) + v1 * (qij[1] + (float)kk * qz[1]) + v2 * (qij[2] + (float)kk * qz[2]);
+                const float wk = st.w[kk][2];
+                T += wk * sdot; Tz += dwz[kk] * sdot;
+                P[0] += wk * v0; P[1] += wk * v1; P[2] += wk * v2;
+            }
+            const float wiwj = st.w[i][0] * st.w[j][1];
+            gfx[0] += (stencil_dw(st, i, 0) * st.w[j][1]) * T;
+            gfx[1] += (st.w[i][0] * stencil_dw(st, j, 1)) * T;
+            gfx[2] += wiwj * Tz;
+#pragma unroll
+            for (int a = 0; a < 3; a++) nvw[a] += wiwj * P[a];
+            // the running sums are pinned here: otherwise the (pure) arithmetic sinks towards its use behind the loop while the 81 tile
+            // reads stay where they are, and every tile value is live at once (650 B of scratch per lane)
+            asm volatile("" : "+v"(gfx[0]), "+v"(gfx[1]), "+v"(gfx[2]), "+v"(nvw[0]), "+v"(nvw[1]), "+v"(nvw[2]));
+        }
+        // sum_o W c4 (v_o^T gC)_b = (nvw^T c4 gC)_b enters with dpos_b = o_b - fx_b
+        gfx[0] -= nvw[0] * qx[0] + nvw[1] * qx[1] + nvw[2] * qx[2];
+        gfx[1] -= nvw[0] * qy[0] + nvw[1] * qy[1] + nvw[2] * qy[2];
+        gfx[2] -= nvw[0] * qz[0] + nvw[1] * qz[1] + nvw[2] * qz[2];
+        if (live) pstore(Gc, Gc.A0, s, make_float4(g.x[0] + S.inv_dx * gfx[0], g.x[1] + S.inv_dx * gfx[1], g.x[2] + S.inv_dx * gfx[2], 0.f));
+    }
+    NODE_FENCE();
+    // ---- pass 2: scatter d v_out(o) += W(o) q(o), summed over runs of equal stencil base before the LDS atomics
+    const SegScan sc = seg_setup(live ? lb : (0x40000000 | (int)threadIdx.x));       // (only now: five registers less across pass 1)
+    const bool issue = sc.tail && live;
+    const float livef = live ? 1.f : 0.f;
+    const int la = l0;
+#pragma unroll
+    for (int ij = 0; ij < 9; ij++) {
+        const int i = ij / 3, j = ij - 3 * i;
+        const float lw = livef * (st.w[i][0] * st.w[j][1]);
+        float qij[3];
+#pragma unroll
+        for (int a = 0; a < 3; a++) qij[a] = qb[a] + (float)i * qx[a] + (float)j * qy[a];
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) {
+            const float weight = lw * st.w[kk][2];
+            float c0 = weight * (qij[0] + (float)kk * qz[0]), c1 = weight * (qij[1] + (float)kk * qz[1]), c2 = weight * (qij[2] + (float)kk * qz[2]);
+            seg_scan3(sc, c0, c1, c2);
+            if (issue) {
+                const int l = la + (i * TILE_T + j) * TILE_T + kk;
+                atomicAdd(&s_acc3[l], (double)c0);                        // ds_add_f64
+                atomicAdd(&s_acc3[TILE_N + l], (double)c1);
+                atomicAdd(&s_acc3[2 * TILE_N + l], (double)c2);
+            }
+        }
+    }
+}
+
+template <int MINW>
+__device__ __forceinline__ void g2p_grad2_body(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T,
+                                                  const float4* __restrict__ g_out, float* gg_out, float4* slab, int* slow,
+                                                  GridStore GS, int f, AgentP agent) {
+    const int tid = threadIdx.x;
+    const bool stored = GS.cap > 0 && GS.flag[f];
+    VoutSrc V; V.g_out = g_out; V.store = stored ? GS.data + (size_t)f * GS.cap * 128 : nullptr; V.blk_slot = T.blk_slot;
+    FrameV cur = frame_view(fr_cur, S.Np);
+    FrameV Gn = frame_view(Gn_, S.Np), Gc = frame_view(Gc_, S.Np, S.wt);
+    TL(S, 0);
+    Unit un = unit_load(T, blockIdx.x);                       // this workgroup's first unit, asked for together with meta
+    const int n_slots = T.meta[5];
+    for (int wg = blockIdx.x; wg < n_slots; wg += gridDim.x) {
+        if (wg != (int)blockIdx.x) un = unit_load(T, wg);
+        if (un.a.z == -2) continue;
+        if (un.a.z >= 0) {
+            const PairCtx pc = pair_ctx(un);
+            const int4 it = pc.it;
+            const TileO to = tile_origin(it.x, S.nb);
+            const int tofs = pc.ti * 3 * TILE_N;
+            const int i = tid & (HALF - 1);
+            const int s = it.y + (i < it.z ? i : 0);
+            const int nbr_entry = V.store ? neighbour_entry(T.blk_slot, S.nb, it.x) : -1;       // (with the particle loads: one hop)
+            const int u0 = cur.used[s];
+            const float4 a00 = cur.A0[s];
+            g2p_grad_load_tile2(to, S, g_out, V.store, nbr_entry, pc);
+            if (pc.live) for (int l = pc.t0; l < 3 * TILE_N; l += pc.nth) s_acc3[tofs + l] = 0.0;
+            __syncthreads();
+            TL(S, 2);
+            {
+                const bool used = i < it.z && u0 != 0;
+                float x[3] = {0.f, 0.f, 0.f};
+                if (used) { x[0] = a00.x; x[1] = a00.y; x[2] = a00.z; }
+                Stencil st;
+                stencil_make(x, S.inv_dx, st);
+                const bool inside = used && stencil_inside(st, S.n);
+                const int lb = inside ? tile_base(to, st) : -1;
+                const bool live = lb >= 0;
+                if (__any(live)) g2p_grad_particle2<MINW>(S, Gn, Gc, s, live ? lb : 0, st, live, tofs);     // wave-uniform: empty waves skip the loops
+                if (used && !live) {
+                    if (inside) atomicAdd(slow, 1);
+                    g2p_grad_slot_global(S, cur, Gn, Gc, s, V, gg_out, agent, f, GS);
+                }
+            }
+            TL(S, 5);
+            __syncthreads();
+            TL(S, 6);
+            if (pc.live) for (int l = pc.t0; l < TILE_N; l += pc.nth)
+                slab_store(slab, pc.slab, l, make_float4((float)s_acc3[tofs + l], (float)s_acc3[tofs + TILE_N + l], (float)s_acc3[tofs + 2 * TILE_N + l], 0.f), S.wt);
+            __syncthreads();
+            TL(S, 7);
+        } else {
+            const int s = un.a.y + tid;
+            if (s < S.N) g2p_grad_slot_global(S, cur, Gn, Gc, s, V, gg_out, agent, f, GS);
+        }
+    }
+}
+template <int MINW>
+__global__ __launch_bounds__(WG, MINW) void k_g2p_grad2(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T, const float4* g_out, float* gg_out, float4* slab, int* slow, GridStore GS, int f, AgentP agent) { g2p_grad2_body<MINW>(S, fr_cur, Gn_, Gc_, T, g_out, gg_out, slab, slow, GS, f, agent); }
+template <int MINW>
+__global__ __launch_bounds__(WG, MINW) void k_g2p_grad2_b(Batch<G2PGradArgs> B) { const G2PGradArgs& A = B.a[blockIdx.y]; g2p_grad2_body<MINW>(A.S, A.fr_cur, A.Gn_, A.Gc_, A.T, A.g_out, A.gg_out, A.slab, A.slow, A.GS, A.f, A.agent); }
 
 
 // agent.collide's adjoint (mpm:418-422 in reverse) as a pass of its own, before k_g2p_grad.  Inlined into k_g2p_grad the
@@ -1631,7 +1848,7 @@ __device__ __forceinline__ void p2g_grad_body(SimP S, float* fr_cur, float* Gn_,
         if (act) for (int i = agent.n - 1; i >= 0; i--) effector_move_grad(agent.e[i], f);
     }
     FrameV cur = frame_view(fr_cur, S.Np);
-    FrameV Gn = frame_view(Gn_, S.Np), Gc = frame_view(Gc_, S.Np);
+    FrameV Gn = frame_view(Gn_, S.Np), Gc = frame_view(Gc_, S.Np, S.wt);
     TL(S, 0);
     Unit un = unit_load(T, blockIdx.x);                       // this workgroup's first unit, asked for together with meta
     const int n_slots = T.meta[5];
@@ -2326,6 +2543,7 @@ struct FeEngine {
     std::vector<int> tbl_of_frame;                          // [L+1]
     int gtbl[2] = {-1, -1};                                 // order of each adjoint ring slot; -1 = all zero
     int p2g_grad_waves = 4;                                 // occupancy target of the SVD-free p2g_grad build (tuning)
+    int g2p_grad_v = 2;                                     // 2 / 3: split, fully unrolled loops (k_g2p_grad2 at 3 / 4 waves per SIMD); 1: round 2's fused rolled loop
     int item_max = ITEM_MAX_CAP;                            // particles per work item (<= ITEM_MAX_CAP = one half workgroup)
     int sort_interval = 10;                                 // K: re-sort every K substeps (0 = never: global path only)
     size_t items_cap = 0, units_cap = 0;
@@ -2503,7 +2721,8 @@ int ensure_table(FeEngine* h, int id) {
     const size_t nblk = (size_t)h->nb * h->nb * h->nb;
     if (id == 0) t.info = h->pinfo;                            // identity order: slot == particle id
     else if (dev_alloc(h, &t.info, h->Np)) return 1;
-    if (dev_alloc(h, &t.pairs, h->items_cap / 2 + 2) || dev_alloc(h, &t.singles, h->items_cap)) return 1;
+    // (pairs: a block with k > 1 items makes ceil(k / 2) pairs -- two from three -- so the bound is the item count, not half of it)
+    if (dev_alloc(h, &t.pairs, h->items_cap) || dev_alloc(h, &t.singles, h->items_cap)) return 1;
     if (dev_alloc(h, &t.pid, h->Np) || dev_alloc(h, &t.items, h->items_cap) || dev_alloc(h, &t.meta, 8) ||
         dev_alloc(h, &t.blk_first, nblk) || dev_alloc(h, &t.active, nblk) || dev_alloc(h, &t.blk_slot, nblk) || dev_alloc(h, &t.slot_of_pid, h->Np) ||
         dev_alloc(h, &t.units, h->units_cap, false) || dev_alloc(h, &t.nbr, nblk * 27, false)) return 1;
@@ -2678,7 +2897,9 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act) {
         hipLaunchKernelGGL(k_collide_grad, dim3(std::min((h->N + 15) / 16, 2048)), dim3(256), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->g_out, T, grid_store(h), f, ag,
                            h->hit_list, h->hit_count);
     }
-    hipLaunchKernelGGL(k_g2p_grad, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag);
+    if (h->g2p_grad_v == 2) hipLaunchKernelGGL(k_g2p_grad2<3>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag);
+    else if (h->g2p_grad_v == 3) hipLaunchKernelGGL(k_g2p_grad2<4>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag);
+    else hipLaunchKernelGGL(k_g2p_grad, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag);
     prof_end(h);
     prof_begin(h, KID_GRID_GRAD);
 #define LAUNCH_GRID_GRAD(ST_, DY_) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_grad<ST_, DY_>), ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, h->gg_out, \
@@ -2712,10 +2933,11 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act) {
 // mesh effectors, no MAT_RIGID bodies (those scenes step one engine at a time: fe_step_batch falls back to a loop).
 bool batchable(FeEngine** hs, int B) {
     if (B < 2 || B > FE_MAX_BATCH) return false;
+    for (int i = 0; i < B; i++) if (!hs[i]) return false;
     for (int i = 0; i < B; i++) {
         FeEngine* h = hs[i];
         if (h->device != hs[0]->device || h->n != hs[0]->n || h->L != hs[0]->L || h->all_simple_liquid != hs[0]->all_simple_liquid ||
-            h->sort_interval != hs[0]->sort_interval || !h->statics_host.empty() || h->has_mesh_effector || h->has_rigid || h->prof_fine ||
+            h->sort_interval != hs[0]->sort_interval || h->p2g_grad_waves != hs[0]->p2g_grad_waves || h->g2p_grad_v != hs[0]->g2p_grad_v || h->S.wt != hs[0]->S.wt || !h->statics_host.empty() || h->has_mesh_effector || h->has_rigid || h->prof_fine ||
             (h->gs_cap > 0) != (hs[0]->gs_cap > 0)) return false;
         for (int j = 0; j < i; j++) if (hs[j] == h) return false;
     }
@@ -2822,14 +3044,19 @@ int substep_bwd_batch(FeEngine** hs, int B, int f, int f_global, int act) {
         prof_end(h0);
     }
     prof_begin(h0, KID_G2P_GRAD);
-    hipLaunchKernelGGL(k_g2p_grad_b, wgrid_b(hs, B), dim3(WG), 0, h0->stream, bq);
+    if (h0->g2p_grad_v == 2) hipLaunchKernelGGL(k_g2p_grad2_b<3>, wgrid_b(hs, B), dim3(WG), 0, h0->stream, bq);
+    else if (h0->g2p_grad_v == 3) hipLaunchKernelGGL(k_g2p_grad2_b<4>, wgrid_b(hs, B), dim3(WG), 0, h0->stream, bq);
+    else hipLaunchKernelGGL(k_g2p_grad_b, wgrid_b(hs, B), dim3(WG), 0, h0->stream, bq);
     prof_end(h0);
     prof_begin(h0, KID_GRID_GRAD);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_grad_b<false, false>), dim3(ggrid(h0).x, B), dim3(256), 0, h0->stream, bgg);
     prof_end(h0);
     prof_begin(h0, KID_P2G_GRAD);
-    if (h0->all_simple_liquid) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_p2g_grad_b<false, 4>), wgrid_b(hs, B), dim3(WG), 0, h0->stream, bpg);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_p2g_grad_b<true, 1>), wgrid_b(hs, B), dim3(WG), 0, h0->stream, bpg);
+    if (h0->all_simple_liquid) {                          // (batchable: the same p2g_grad_waves in every engine)
+        if (h0->p2g_grad_waves >= 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_p2g_grad_b<false, 4>), wgrid_b(hs, B), dim3(WG), 0, h0->stream, bpg);
+        else if (h0->p2g_grad_waves == 3) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_p2g_grad_b<false, 3>), wgrid_b(hs, B), dim3(WG), 0, h0->stream, bpg);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_p2g_grad_b<false, 2>), wgrid_b(hs, B), dim3(WG), 0, h0->stream, bpg);
+    } else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_p2g_grad_b<true, 1>), wgrid_b(hs, B), dim3(WG), 0, h0->stream, bpg);
     prof_end(h0);
     return 0;
 }
@@ -2930,6 +3157,7 @@ FeEngine* fe_create(const FeConfig* cfg) {
     h->own_stream = h->stream;
     SimP& S = h->S;
     S.xcd = 1;
+    S.wt = 0;
     S.N = h->N; S.Np = h->Np; S.n = h->n; S.nb = h->nb; S.ncell = h->nb * h->nb * h->nb * 64;
     S.dx = 1.0f / (float)h->n; S.inv_dx = (float)h->n; S.dt = cfg->dt;
     S.stress_scale = -cfg->dt * cfg->p_vol * 4.f * S.inv_dx * S.inv_dx;
@@ -3034,6 +3262,7 @@ int fe_set_option(FeEngine* h, const char* name, double value) {
         return 0;
     }
     if (!std::strcmp(name, "p2g_grad_waves")) { h->p2g_grad_waves = (int)value; return 0; }
+    if (!std::strcmp(name, "g2p_grad_v")) { h->g2p_grad_v = (int)value; return 0; }
     if (!std::strcmp(name, "inject_till")) { h->inject_till = (int)value; return 0; }
     if (!std::strcmp(name, "collide_min_y")) { h->collide_min_y = (float)value; return 0; }
     if (!std::strcmp(name, "collide_type")) {
@@ -3043,6 +3272,7 @@ int fe_set_option(FeEngine* h, const char* name, double value) {
     }
     if (!std::strcmp(name, "prof_fine")) { h->prof_fine = value != 0; return 0; }
     if (!std::strcmp(name, "xcd_map")) { h->S.xcd = value != 0; return 0; }
+    if (!std::strcmp(name, "write_through")) { h->S.wt = value != 0; return 0; }
     if (!std::strcmp(name, "wgrid_cap")) { if (value < 64) { h->err = "wgrid_cap must be >= 64"; return 1; } h->wgrid_cap = (int)value; return 0; }
     if (!std::strcmp(name, "threads")) return 0;             // oracle-only tunable
     FAIL(h, std::string("unknown option: ") + name);
@@ -3129,6 +3359,7 @@ int fe_step_grad(FeEngine* h, int f0, int f_global0, int n, int act) {
 }
 int fe_step_batch(FeEngine** hs, int n_env, int f0, int f_global0, int n, int act) {
     if (!hs || n_env < 1) return 1;
+    for (int e = 0; e < n_env; e++) if (!hs[e]) return 1;
     FeEngine* h = hs[0];
     FE_ENTRY(h);
     if (!batchable(hs, n_env)) {                              // scenes that cannot share launches: one engine after the other
@@ -3142,6 +3373,7 @@ int fe_step_batch(FeEngine** hs, int n_env, int f0, int f_global0, int n, int ac
 }
 int fe_step_grad_batch(FeEngine** hs, int n_env, int f0, int f_global0, int n, int act) {
     if (!hs || n_env < 1) return 1;
+    for (int e = 0; e < n_env; e++) if (!hs[e]) return 1;
     FeEngine* h = hs[0];
     FE_ENTRY(h);
     if (!batchable(hs, n_env)) {

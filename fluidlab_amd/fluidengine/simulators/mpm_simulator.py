@@ -371,6 +371,7 @@ class MPMSimulator:
 
     def set_state(self, f_global, state):
         f = self.f_global_to_f_local(f_global)
+        self.last_move_f = None                              # a restored state starts a new episode: no move has happened in it yet
         if self.has_particles:
             self.setframe(f, state['x'], state['v'], state['C'], state['F'], state['used'])
         if self.agent is not None:

@@ -38,6 +38,9 @@ def test_bench_gpus_2_spawns_two_ranks_and_all_reduces_the_action_gradient():
     assert all(v == v and v > 0 for v in out['loss_mean_over_envs'])
     assert out['config']['substep_pairs_per_step_per_rank'] == 3300 and out['config']['action_grad_shape'] == [251, 3]
     assert 0.2 < out['weak_scaling_efficiency_vs_rank_compute'] <= 1.05
+    assert out['actions_identical_across_ranks'] is True                      # same averaged gradient, same fp64 Adam step on both ranks
+    assert out['n1_same_scene_pairs_per_s'] > 0 and 0.1 < out['scaling_efficiency'] <= 1.1      # (two ranks share one GPU here)
+    assert len(out['host']['rss_gb_per_rank']) == 2 and all(c >= 1 for c in out['host']['cores_per_rank'])
 
 
 @pytest.mark.gpu
@@ -50,3 +53,21 @@ def test_bench_replica_path_over_rccl_with_one_rank():
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
     assert out['config']['dist_backend'] == 'nccl' and out['config']['rccl_world_size'] == 1 and out['n_gpus'] == 1
     assert out['value'] > 0 and out['passes_skipped_nonfinite_grad'] == 0 and out['allreduce_us']['warm_latency'] > 0
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_over_rccl_when_the_box_has_two_gpus():
+    """The first box with two GPUs exercises the path the driver runs on eight: `python bench.py --gpus 2` with the default `nccl`
+    (= RCCL) backend, one rank per GPU, LatteArt replicas, the action-gradient all-reduce -- and every rank must end up with the same
+    policy (the averaged gradient and the fp64 Adam step are identical by construction)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip('needs two GPUs (the 1-GPU box runs the gloo variant above and the one-rank RCCL group below)')
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1', '--c4-scene', 'as_shipped']
+    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert out['config']['dist_backend'] == 'nccl' and out['config']['rccl_world_size'] == 2 and out['n_gpus'] == 2
+    assert out['value'] > 0 and out['passes_skipped_nonfinite_grad'] == 0
+    assert out['actions_identical_across_ranks'] is True
+    assert out['n1_same_scene_pairs_per_s'] > 0 and 0.2 < out['scaling_efficiency'] <= 1.1

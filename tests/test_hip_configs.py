@@ -56,6 +56,47 @@ def test_config3_latteart_128_matches_the_fp32_oracle(hiplib, oracle32):
     assert a[-1][1].sum() > a[0][1].sum()                         # milk was injected in between
 
 
+def test_config3_latteart_128_backward_matches_the_fp32_oracle(hiplib, oracle32):
+    """Config 3 at size, forward AND backward: one 50-substep chunk (5 steps of the demo pour's first actions) of LatteArt at 128^3,
+    281,883 particles, through fluidlab's Solver.forward_backward (solver.py:23-59) on the HIP engine and on the fp32 oracle:
+    loss, the (5+1) x 3 action gradient `agent.get_grad` and the position adjoint of frame 0."""
+    from fluidlab_amd.envs import make
+    from fluidlab_amd.optimizer.policies import ActionsPolicy
+    from fluidlab_amd.optimizer.solver import Solver
+    H = 5
+    kw = dict(quality=2, particle_density=4e6, n_pool=60000, horizon=H, horizon_action=H, max_substeps_local=50, ckpt_dest='cpu', loss=True)
+
+    def run(lib):
+        env = make('LatteArt-v0', seed=0, engine_lib=lib, **kw)
+        te = env.taichi_env
+        n = te.simulator.n_particles
+        rng = np.random.RandomState(3)
+        # a synthetic pattern for the milk to match (the loss only looks at used MILK particles): a blob above the cup centre
+        tgt = (np.array([0.5, 0.62, 0.5]) + rng.normal(0, 0.03, (H, n, 3))).astype(np.float32)
+        te.loss.set_target({'x': tgt})
+        env.horizon_action = 250                              # the scripted sine pour of the full scene: its first H actions
+        table = env.demo_policy()
+        env.horizon_action = H
+        pol = ActionsPolicy(np.vstack([table.actions_v[:H], table.actions_p[None, :]]))
+        pol.freeze_till = 0
+        init = te.get_state()
+        info, grad = Solver(env, None, None).forward_backward(init['state'], pol, H, H)
+        gx = te.simulator.engine.get_grad(0)[0]
+        used0 = init['state']['used'].copy()
+        te.simulator.engine.close()
+        return info['loss'], np.asarray(grad, np.float64), gx.astype(np.float64), used0, n
+
+    la, ga, xa, ua, n = run(hiplib)
+    lb, gb, xb, ub, _ = run(oracle32)
+    assert n > 250000 and ga.shape == (H + 1, 3) and np.isfinite(ga).all() and np.isfinite(xa).all()
+    assert np.array_equal(ua, ub)
+    print('MEASURED config3 fwd+bwd: loss', la, lb, 'action-grad cos', S.cosine(ga, gb), 'relL2', S.rel_l2(ga, gb),
+          'x_bar[0] cos', S.cosine(xa, xb), 'relL2', S.rel_l2(xa, xb))
+    assert abs(la - lb) <= 1e-4 * abs(lb)
+    assert np.abs(gb).max() > 0 and S.cosine(ga, gb) >= 0.9999 and S.rel_l2(ga, gb) <= 1e-3
+    assert np.abs(xb).max() > 0 and S.cosine(xa, xb) >= 0.9999 and S.rel_l2(xa, xb) <= 1e-3
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # config 5
 # ------------------------------------------------------------------------------------------------------------------

@@ -265,6 +265,22 @@ def test_scattered_droplets_and_untouched_blocks(hiplib, oracle64, grid_store):
     assert ws['n_items'] == sum(ws['items_by_size'].values()) and ws['n_multi_item_workgroups'] + ws['n_single_item_blocks'] >= ws['n_occupied_blocks']
 
 
+def test_dense_scene_with_small_items(hiplib, oracle64):
+    """item_max = 64 on a box filled with water: every block holds 3-4 items, i.e. two pairs -- more pairs than half the items
+    (the order's pair list used to be sized items / 2 and overflowed here).  Forward and backward against the oracle."""
+    sc = S.water_block(n_grid=32, n_particles=77000, lo=0.06, hi=0.94, seed=4)
+    opts = {'item_max': 64, 'sort_interval': 2}
+    g = S.make_engine(hiplib, sc, options=opts)
+    o = S.make_engine(oracle64, sc)
+    cot = S.random_cotangent(sc['N'], seed=8)
+    (a, ga), (b, gb) = S.run_forward_backward(g, 4, cot), S.run_forward_backward(o, 4, cot)
+    ws = g.get_work_stats(0)
+    assert ws['n_multi_item_workgroups'] > ws['n_items'] // 2 - 40 and ws['n_items'] > 1200, ws
+    assert np.abs(a['x'] - b['x']).max() <= 5e-6 and (a['used'] == b['used']).all()
+    for k in ('gx', 'gv', 'gC', 'gF'):
+        assert S.cosine(ga[k], gb[k]) >= 0.99999 and S.rel_l2(ga[k], gb[k]) <= 3e-3, k
+
+
 def test_forward_is_independent_of_sort_interval(hiplib):
     sc = S.water_block(n_grid=32, n_particles=6000)
     ref = S.run_forward(S.make_engine(hiplib, sc, options={'sort_interval': 0}), 25)
