@@ -139,7 +139,7 @@ struct SimP {
     int N, Np, n, nb;
     int ncell;                               // nb^3 * 64: plane stride of the SoA accumulator grids
     int xcd;                                 // option "xcd_map": consecutive work items on the same XCD (shared L2)
-    int wt;                                  // option "write_through": bulk outputs as sc1 stores (see wt_store16)
+    int wt;                                  // option "write_through": bulk outputs as sc1 stores (see wt_store16); bit 0 p2g, 1 g2p, 2 g2p_grad, 3 p2g_grad
     float dx, inv_dx, dt, stress_scale;     // stress_scale = -dt * p_vol * 4 * inv_dx^2 (mpm:343)
     float g[3];
     BoundaryP bnd;
@@ -170,16 +170,16 @@ __device__ __forceinline__ PInfo load_info(const float4* info, int i) {
     return r;
 }
 
-// blk_flag: 0 untouched, 1 on the dynamic list (slow-path particles), 2 static = on the order's active list already
-// Returns true when the block is NOT on the order's static active list: only then is the per-frame grid store incomplete
-// (static blocks store their totals, slow-path contributions included).
-__device__ __forceinline__ bool mark_block(int b, int* blk_flag, int* blk_list, int* blk_count) {
+// A block is on the active list of the order a substep runs in exactly when that order's blk_slot holds an entry for it (>= 0):
+// the orders keep their own tables, so forward and backward substeps of any frame agree without re-flagging anything (round 2
+// kept the value 2 in blk_flag on exactly one order's list and switched it with two launches whenever backward crossed a sort).
+// blk_flag only says whether a block OUTSIDE that list is on the substep's dynamic list already (1); the sorts leave their tags
+// (>= 3, k_sort_fill) in it, which read as "not yet" like 0 does.
+__device__ __forceinline__ void mark_dynamic(int b, int* blk_flag, int* blk_list, int* blk_count) {
     const int fl = blk_flag[b];
-    if (fl == 2) return false;
-    if (fl == 0) {
-        if (atomicCAS(&blk_flag[b], 0, 1) == 0) { int i = atomicAdd(blk_count, 1); blk_list[i] = b; }
+    if (fl != 1) {
+        if (atomicCAS(&blk_flag[b], fl, 1) == fl) { int i = atomicAdd(blk_count, 1); blk_list[i] = b; }
     }
-    return true;
 }
 
 // -----------------------------------------------------------------------------------------
@@ -195,6 +195,13 @@ __device__ __forceinline__ bool mark_block(int b, int* blk_flag, int* blk_list, 
 // -----------------------------------------------------------------------------------------
 #define TILE_T 8
 #define TILE_N 512
+// A tile is handed over as a SLAB of its inner 6^3 nodes (tile indices 1..6 per axis = the block and its two halo nodes per side:
+// everything an item deposits right after a sort).  The outer shell -- the node of drift margin on each side -- is rarely
+// touched; what does land there goes to the slow-path accumulator with global atomics and marks its block dirty.  Round 2 stored
+// all 8^3 nodes: 8 KiB per item where 3.4 KiB carry data, written by the scatter kernels (left dirty in L2 at the kernel boundary)
+// and gathered by the grid kernels from 16 candidate slabs per node, of which a fresh order fills 3.4.
+#define SLAB_T 6
+#define SLAB_N 216
 #define ITEM_MAX_CAP 128      // upper bound (and default) of the runtime `item_max` option: an item is one pass of one half workgroup
 #define WG 256
 #define HALF 128
@@ -323,7 +330,7 @@ struct PairCtx {
     int  nth, t0;    // the threads that load / zero / store this tile: all 256 from t0 = tid when shared, else this half's 128
     bool live;       // this half's threads take part in tile loads and stores
 };
-// The work of one workgroup of the particle kernels, as the sort leaves it (k_build_active): two item descriptors ready to use.
+// The work of one workgroup of the particle kernels, as the sort leaves it (build_units_dev): two item descriptors ready to use.
 // The kernels used to walk meta -> pairs[w] / singles[q] -> items[i] before they could ask for their particles: three dependent
 // round trips ahead of the first useful load in kernels that are one round of such chains.  Now workgroup w reads units[w] together
 // with meta.  The list is stored in XCD order (slot w holds work unit xcd_item(w): every XCD a contiguous eighth of the items).
@@ -435,8 +442,26 @@ __device__ __forceinline__ void mark_dirty(const GridStore& GS, const int* __res
 
 // one node of a slab (the slab index is wave-uniform: the descriptor of the write-through form is built over the slab itself)
 __device__ __forceinline__ void slab_store(float4* slab, int item, int l, float4 v, int wt) {
-    float4* base = slab + (size_t)item * TILE_N;
+    float4* base = slab + (size_t)item * SLAB_N;
     if (wt) wt_store16(base, (unsigned)l * 16u, v); else base[l] = v;
+}
+__device__ __forceinline__ int tile_region(int t) { return (t + 3) >> 2; }        // tile index 0 -> block B-1, 1..4 -> B, 5..7 -> B+1
+// Tile node l of a finished scatter tile: the inner 6^3 go to the item's slab; a shell node that received something is added to
+// the slow-path accumulator `acc` (NPL planes of ncell floats) and its block -- active-list entry from the item's 27 neighbour
+// entries, lane r of every wave holds neighbour r -- is marked dirty for the grid kernel.  Called by whole waves (shuffle).
+template <int NPL>
+__device__ __forceinline__ void tile_handover(const SimP& S, float4* slab, int item, float* acc, const GridStore& GS, const TileO& to,
+                                              int nbr_entry, int l, float4 v, int wt) {
+    const int tx = l >> 6, ty = (l >> 3) & 7, tz = l & 7;
+    const int e = __shfl(nbr_entry, tile_region(tx) * 9 + tile_region(ty) * 3 + tile_region(tz), 64);
+    if ((unsigned)(tx - 1) < (unsigned)SLAB_T && (unsigned)(ty - 1) < (unsigned)SLAB_T && (unsigned)(tz - 1) < (unsigned)SLAB_T)
+        slab_store(slab, item, ((tx - 1) * SLAB_T + (ty - 1)) * SLAB_T + (tz - 1), v, wt);
+    else if (e >= 0 && (v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f)) {
+        float* dst = acc + cell_addr(to.ox + tx, to.oy + ty, to.oz + tz, S.nb);
+        unsafeAtomicAdd(dst, v.x); unsafeAtomicAdd(dst + S.ncell, v.y); unsafeAtomicAdd(dst + 2 * S.ncell, v.z);
+        if (NPL > 3) unsafeAtomicAdd(dst + 3 * S.ncell, v.w);
+        GS.dirty[e] = GS.stamp;
+    }
 }
 
 struct GridW {            // everything a scattering particle needs of the global grid
@@ -546,17 +571,26 @@ __device__ __forceinline__ void p2g_scatter_global(const SimP& S, const P2GPrep&
             unsafeAtomicAdd(dst + 3 * S.ncell, weight * q.m);
         }
     }
-    // mark the (up to 8) 4^3 blocks this stencil touches
-    const int bx0 = st.base[0] >> 2, bx1 = (st.base[0] + 2) >> 2;
-    const int by0 = st.base[1] >> 2, by1 = (st.base[1] + 2) >> 2;
-    const int bz0 = st.base[2] >> 2, bz1 = (st.base[2] + 2) >> 2;
-    for (int bx = bx0; bx <= bx1; bx++)
-        for (int by = by0; by <= by1; by++)
-            for (int bz = bz0; bz <= bz1; bz++) {
-                const int b = (bx * S.nb + by) * S.nb + bz;
-                if (mark_block(b, G.blk_flag, G.blk_list, G.blk_count)) *G.frame_slow = 1;   // store incomplete for this frame
-                else mark_dirty(GS, blk_slot, b);                                              // a block of the active list
-            }
+    // mark the (up to 8) 4^3 blocks this stencil touches: lower and upper block per axis (equal when the three nodes sit in one
+    // block).  All flags and list entries are asked for at once (a rolled triple loop made this up to eight rounds of two
+    // dependent round trips per particle -- nothing for a few drifted particles, too much for the loose ones).
+    const int bl[3] = {st.base[0] >> 2, st.base[1] >> 2, st.base[2] >> 2};
+    const int bh[3] = {(st.base[0] + 2) >> 2, (st.base[1] + 2) >> 2, (st.base[2] + 2) >> 2};
+    int ent[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        const int b = (((c & 1) ? bh[0] : bl[0]) * S.nb + ((c & 2) ? bh[1] : bl[1])) * S.nb + ((c & 4) ? bh[2] : bl[2]);
+        ent[c] = blk_slot[b];
+    }
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        if (ent[c] >= 0) GS.dirty[ent[c]] = GS.stamp;                                      // a block of the order's active list
+        else {
+            const int b = (((c & 1) ? bh[0] : bl[0]) * S.nb + ((c & 2) ? bh[1] : bl[1])) * S.nb + ((c & 4) ? bh[2] : bl[2]);
+            mark_dynamic(b, G.blk_flag, G.blk_list, G.blk_count);
+            *G.frame_slow = 1;                                                              // store incomplete for this frame
+        }
+    }
 }
 
 // tile path, executed by ALL lanes of the wave: contributions of lanes with `in_tile` are summed over runs of equal
@@ -604,7 +638,7 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
         for (int i = 0; i < agent.n; i++) effector_move(agent.e[i], f);
     }
     FrameV cur = frame_view(fr_cur, S.Np);
-    FrameV nxt = frame_view(fr_next, S.Np, S.wt);
+    FrameV nxt = frame_view(fr_next, S.Np, S.wt & 1);
     TL(S, 0);
     Unit un = unit_load(T, blockIdx.x);                       // this workgroup's first unit, asked for together with meta
     const int n_slots = T.meta[5];
@@ -654,7 +688,8 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
             // hand the tile over: plain coalesced float4 stores into the item's slab.  No atomics, no waiting:
             // k_grid sums, per node, the slabs of the (at most 8) blocks whose tiles reach it, in a fixed order.
             if (pc.live) for (int l = pc.t0; l < TILE_N; l += pc.nth)
-                slab_store(G.slab, pc.slab, l, make_float4((float)s_acc[aofs + l], (float)s_acc[aofs + TILE_N + l], (float)s_acc[aofs + 2 * TILE_N + l], (float)s_acc[aofs + 3 * TILE_N + l]), S.wt);
+                tile_handover<4>(S, G.slab, pc.slab, G.g_in, GS, to, nbr_entry, l,
+                                 make_float4((float)s_acc[aofs + l], (float)s_acc[aofs + TILE_N + l], (float)s_acc[aofs + 2 * TILE_N + l], (float)s_acc[aofs + 3 * TILE_N + l]), S.wt & 1);
             __syncthreads();
             TL(S, 6);
         } else {
@@ -739,43 +774,49 @@ __device__ __forceinline__ void node_statics_grad(const SimP& S, const StaticsP&
     }
 }
 
-// Sum, for node (oi,oj,ok) of block b, what the work items' tiles deposited there.  A tile of block B' covers the
-// nodes [4B'-1, 4B'+7) per axis, so a node with in-block offset o receives from B'=B (tile index o+1) and from
-// B'=B-1 (index o+5) when o <= 2, or B'=B+1 (index 0) when o == 3: 8 source blocks, visited in a fixed order
-// (deterministic sums).  `slab` holds one 512-node float4 tile per item.  The item ranges of the 27 neighbour
-// blocks are fetched once per wave (lane n < 27 loads neighbour n) and handed out by cross-lane reads, so a
+// Sum, for node (oi,oj,ok) of block b, what the work items' slabs hold for it.  The slab of an item of block B' covers the nodes
+// [4B', 4B'+6) per axis (tile indices 1..6), so a node with in-block offset o receives from B'=B (slab index o) and, when o <= 1,
+// from B'=B-1 (slab index o+4): 1..8 source blocks per node (3.4 on average), visited in a fixed order (deterministic sums).  What
+// a tile collected on its outer shell arrives through the slow-path accumulator instead (tile_handover).  The item ranges of the
+// 27 neighbour blocks are fetched once per wave (lane n < 27 loads neighbour n) and handed out by cross-lane reads, so a
 // lane's critical path is two dependent memory round trips: range -> slab values.
-__device__ __forceinline__ float4 gather_slabs(const SimP& S, const TableP& T, const float4* __restrict__ slab, int e, int lane) {
-    const int2 mine = lane < 27 ? T.nbr[e * 27 + lane] : make_int2(0, 0);       // (laid out by k_build_units: no detour over the block number)
+__device__ __forceinline__ int2 nbr_record(const TableP& T, int e, int lane) {      // (laid out by k_build_units: no detour over the block number)
+    return lane < 27 ? T.nbr[e * 27 + lane] : make_int2(0, 0);
+}
+__device__ __forceinline__ float4 gather_slabs(const float4* __restrict__ slab, const int2 mine, int lane) {
     const int o[3] = {lane >> 4, (lane >> 2) & 3, lane & 3};
     // Which items of a block own a slab: the items of a block pair up from its first one, and a pair shares the first one's slab:
     // the slabs of a block whose items are [first, first + count) are first, first + 2, ...  The first two of each of the 8 source
     // blocks are loaded unconditionally-shaped (16 independent loads in flight, zero when absent): summing inside a loop made
     // every load wait for the previous one, eight dependent L2/MALL round trips per node.  Blocks with more than two slabs
     // (> 512 particles) finish in the loop below.  The summation order stays fixed (source c ascending, slab ascending).
-    int first[8], end[8], second[8], tidx[8];
+    int first[8], end[8], second[8], sidx[8];
     float4 v0[8], v1[8];
 #pragma unroll
     for (int c = 0; c < 8; c++) {
-        int nbr = 0, ti_all = 0;                    // neighbour code (di+1)*9 + (dj+1)*3 + (dk+1), tile index
+        int nbr = 0, si = 0;                        // neighbour code (di+1)*9 + (dj+1)*3 + (dk+1), slab node index
+        bool valid = true;
 #pragma unroll
         for (int d = 0; d < 3; d++) {
-            const bool other = (c >> d) & 1;
-            const int delta = other ? (o[d] == 3 ? 1 : -1) : 0;
-            const int ti = other ? (o[d] == 3 ? 0 : o[d] + 5) : o[d] + 1;
-            nbr = nbr * 3 + delta + 1;
-            ti_all = ti_all * TILE_T + ti;
+            const bool other = (c >> d) & 1;        // the lower neighbour along d instead of the block itself
+            valid = valid && (!other || o[d] <= 1);
+            nbr = nbr * 3 + (other ? 0 : 1);
+            si = si * SLAB_T + o[d] + (other ? 4 : 0);
         }
-        first[c] = __shfl(mine.x, nbr, 64); end[c] = first[c] + __shfl(mine.y, nbr, 64); tidx[c] = ti_all;
+        // (both shuffles by ALL lanes, whatever `valid` says: a cross-lane read of a lane that sits out returns 0)
+        first[c] = __shfl(mine.x, nbr, 64);
+        const int cnt_c = __shfl(mine.y, nbr, 64);
+        end[c] = valid ? first[c] + cnt_c : first[c];                           // (else: no slab of that block reaches this node)
+        sidx[c] = valid ? si : 0;
         second[c] = first[c] + 2;
     }
     // (the loads are unconditional from a clamped, always valid slab index and masked afterwards: a conditional float4
-    // load into an array element ended up in scratch)
+    // load into an array element ended up in scratch; lanes without a source all read node 0 of slab 0, one broadcast line)
 #pragma unroll
     for (int c = 0; c < 8; c++) {
         const bool h0 = end[c] > first[c], h1 = second[c] < end[c];
-        const float4 a = slab[(size_t)(h0 ? first[c] : 0) * TILE_N + tidx[c]];
-        const float4 b = slab[(size_t)(h1 ? second[c] : 0) * TILE_N + tidx[c]];
+        const float4 a = slab[(size_t)(h0 ? first[c] : 0) * SLAB_N + (h0 ? sidx[c] : 0)];
+        const float4 b = slab[(size_t)(h1 ? second[c] : 0) * SLAB_N + (h1 ? sidx[c] : 0)];
         v0[c] = make_float4(h0 ? a.x : 0.f, h0 ? a.y : 0.f, h0 ? a.z : 0.f, h0 ? a.w : 0.f);
         v1[c] = make_float4(h1 ? b.x : 0.f, h1 ? b.y : 0.f, h1 ? b.z : 0.f, h1 ? b.w : 0.f);
     }
@@ -785,7 +826,7 @@ __device__ __forceinline__ float4 gather_slabs(const SimP& S, const TableP& T, c
         acc.x += v0[c].x; acc.y += v0[c].y; acc.z += v0[c].z; acc.w += v0[c].w;
         acc.x += v1[c].x; acc.y += v1[c].y; acc.z += v1[c].z; acc.w += v1[c].w;
         for (int k = second[c] + 2; k < end[c]; k += 2) {
-            const float4 v = slab[(size_t)k * TILE_N + tidx[c]];
+            const float4 v = slab[(size_t)k * SLAB_N + sidx[c]];
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
     }
@@ -795,6 +836,17 @@ __device__ __forceinline__ float4 gather_slabs(const SimP& S, const TableP& T, c
 // The grid kernels' share of the active list: every workgroup owns a contiguous range of entries (4 while the list is shorter
 // than the launch has waves), the ranges dealt to the XCDs like the work items (xcd_item).  A workgroup reads the marks of its
 // range 32 entries at a time and its four waves share out the marked ones.
+// Short active lists (a block of water that has not come apart: ~1,000 entries) take a shorter road: wave w of the launch owns
+// entry static_entry(w) outright, so its block number, marks and neighbour record are asked for at once, together with the
+// list's length -- one round trip where the range walk below needs three (length -> marks -> neighbour record), in kernels that
+// are nothing but such a chain (k_grid at C2: entry known after 1.9 us, slabs in after 4.9, done at 4.9 of 8.5).  The mapping
+// keeps chunks of 64 consecutive entries on one XCD (their blocks are neighbours and share slabs).
+__device__ __forceinline__ int static_entry(int wave) {
+    const int G = gridDim.x;
+    if ((G & 127) != 0) return blockIdx.x * 4 + wave;
+    const int j = blockIdx.x >> 3;
+    return ((j >> 4) * 8 + (blockIdx.x & 7)) * 64 + (j & 15) * 4 + wave;
+}
 struct EntryRange { int e0, e1; };
 __device__ __forceinline__ EntryRange entry_range(const SimP& S, int n_static) {
     const int G = gridDim.x >= 8 ? (int)(gridDim.x & ~7u) : (int)gridDim.x;       // workgroups that take ranges
@@ -821,19 +873,25 @@ __device__ __forceinline__ void grid_body(SimP S, TableP T, const float4* __rest
     if (KEEP && GS.cap > 0 && GS.flag[f]) return;        // backward: stored by the forward pass
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     TL(S, 0);
+    // this wave's entry on the short-list road, asked for before the list's length is known
+    const int es = static_entry(wave);
+    const bool es_ok = es < S.nb * S.nb * S.nb;
+    const int blk_s = es_ok ? T.active[es] : 0;
+    const unsigned char tch_s = es_ok ? GS.touched[es] : (unsigned char)0, drt_s = es_ok ? GS.dirty[es] : (unsigned char)0;
+    const int2 nbr_s = es_ok ? nbr_record(T, es, lane) : make_int2(0, 0);
     const int n_static = T.meta[2], n_dyn = *blk_count;
     if (!KEEP && blockIdx.x == 0 && threadIdx.x == 0) {
         if (GS.cap > 0) GS.flag[f] = (n_static <= GS.cap && *frame_slow == 0) ? 1 : 0;
         *frame_slow = 0;
     }
     // one block: is_static = an entry of the active list (slab gather, store slot e); dirty = its g_in planes hold slow-path atomics
-    auto one_block = [&](int e, int b, bool is_static, bool touched, bool dirty) {
+    auto one_block = [&](int e, int b, bool is_static, bool touched, bool dirty, const int2 nbr) {
         const int c = (b << 6) | lane;
         const int bi = b / (S.nb * S.nb), bj = (b / S.nb) % S.nb, bk = b % S.nb;
         TL(S, 1);
         float4 gi = make_float4(0.f, 0.f, 0.f, 0.f);
         if (dirty) gi = make_float4(g_in[c], g_in[S.ncell + c], g_in[2 * S.ncell + c], g_in[3 * S.ncell + c]);
-        if (touched) { const float4 t = gather_slabs(S, T, slab, e, lane); gi.x += t.x; gi.y += t.y; gi.z += t.z; gi.w += t.w; }
+        if (touched) { const float4 t = gather_slabs(slab, nbr, lane); gi.x += t.x; gi.y += t.y; gi.z += t.z; gi.w += t.w; }
         float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
         if (gi.w > FE_EPS) TL(S, 2);
         if (gi.w > FE_EPS) {
@@ -854,6 +912,16 @@ __device__ __forceinline__ void grid_body(SimP S, TableP T, const float4* __rest
         }
         TL(S, 3);
     };
+    if (n_static <= 4 * (int)gridDim.x) {                   // short list: every entry has a wave of its own
+        if (es < n_static) {
+            const bool tm = tch_s == GS.stamp, dm = drt_s == GS.stamp;
+            if (lane == 0) {                                 // this launch's entries, recorded for k_grid_grad
+                if (KEEP) GS.cur[es] = (tm || dm) ? 1 : 0;
+                else if (es < GS.cap) GS.live[(size_t)f * GS.cap + es] = (tm || dm) ? 1 : 0;
+            }
+            if (tm || dm) one_block(es, blk_s, true, tm, dm, nbr_s);      // (entries without a mark: nothing arrived, and no particle reads those nodes)
+        }
+    } else {
     const EntryRange r = entry_range(S, n_static);
     for (int base = r.e0; base < r.e1; base += 32) {       // block numbers and marks of 32 entries: one load each
         const int e = base + (lane & 31);
@@ -870,10 +938,11 @@ __device__ __forceinline__ void grid_body(SimP S, TableP T, const float4* __rest
         for (int rank = 0; todo; rank++) {
             const int i = __builtin_ctz(todo);
             todo &= todo - 1;
-            if ((rank & 3) == wave) one_block(base + i, __builtin_amdgcn_readlane(blkv, i), true, (tm >> i) & 1, (dm >> i) & 1);
+            if ((rank & 3) == wave) one_block(base + i, __builtin_amdgcn_readlane(blkv, i), true, (tm >> i) & 1, (dm >> i) & 1, nbr_record(T, base + i, lane));
         }
     }
-    for (int d = blockIdx.x * 4 + wave; d < n_dyn; d += gridDim.x * 4) one_block(-1, blk_list[d], false, false, true);
+    }
+    for (int d = blockIdx.x * 4 + wave; d < n_dyn; d += gridDim.x * 4) one_block(-1, blk_list[d], false, false, true, make_int2(0, 0));
 }
 struct GridArgs { SimP S; TableP T; const float4* slab; float* g_in; float4* g_out; const int* blk_list; const int* blk_count; int* blk_flag; GridStore GS; int f; int* frame_slow; StaticsP ST; AgentP agent; };
 template <bool KEEP, bool STATICS, bool DYN>
@@ -973,7 +1042,7 @@ __device__ __forceinline__ void g2p_body(SimP S, float* fr_cur, float* fr_next, 
     const int tid = threadIdx.x;
     if (blockIdx.x == 0 && tid == 0) *blk_count = 0;          // grid_op was the last reader of the active list
     FrameV cur = frame_view(fr_cur, S.Np);
-    FrameV nxt = frame_view(fr_next, S.Np, S.wt);
+    FrameV nxt = frame_view(fr_next, S.Np, S.wt & 2);
     TL(S, 0);
     Unit un = unit_load(T, blockIdx.x);                       // this workgroup's first unit, asked for together with meta
     const int n_slots = T.meta[5];
@@ -1163,7 +1232,7 @@ __device__ __forceinline__ void g2p_grad_body(SimP S, float* fr_cur, float* Gn_,
     const bool stored = GS.cap > 0 && GS.flag[f];
     VoutSrc V; V.g_out = g_out; V.store = stored ? GS.data + (size_t)f * GS.cap * 128 : nullptr; V.blk_slot = T.blk_slot;
     FrameV cur = frame_view(fr_cur, S.Np);
-    FrameV Gn = frame_view(Gn_, S.Np), Gc = frame_view(Gc_, S.Np, S.wt);
+    FrameV Gn = frame_view(Gn_, S.Np), Gc = frame_view(Gc_, S.Np, S.wt & 4);
     TL(S, 0);
     Unit un = unit_load(T, blockIdx.x);                       // this workgroup's first unit, asked for together with meta
     const int n_slots = T.meta[5];
@@ -1178,6 +1247,7 @@ __device__ __forceinline__ void g2p_grad_body(SimP S, float* fr_cur, float* Gn_,
             // the particle loads go out ahead of the tile load and its barrier (see slot_g2p); an item is one pass of its half
             const int i = tid & (HALF - 1);
             const int s = it.y + (i < it.z ? i : 0);
+            const int nbr_entry = neighbour_entry(T.blk_slot, S.nb, it.x);
             const int u0 = cur.used[s];
             const float4 a00 = cur.A0[s];
             g2p_grad_load_tile(to, S, T, g_out, V.store, pc);
@@ -1206,7 +1276,8 @@ __device__ __forceinline__ void g2p_grad_body(SimP S, float* fr_cur, float* Gn_,
             __syncthreads();
             TL(S, 6);
             if (pc.live) for (int l = pc.t0; l < TILE_N; l += pc.nth)
-                slab_store(slab, pc.slab, l, make_float4((float)s_acc3[tofs + l], (float)s_acc3[tofs + TILE_N + l], (float)s_acc3[tofs + 2 * TILE_N + l], 0.f), S.wt);
+                tile_handover<3>(S, slab, pc.slab, gg_out, GS, to, nbr_entry, l,
+                                 make_float4((float)s_acc3[tofs + l], (float)s_acc3[tofs + TILE_N + l], (float)s_acc3[tofs + 2 * TILE_N + l], 0.f), S.wt & 4);
             __syncthreads();
             TL(S, 7);
         } else {
@@ -1233,7 +1304,6 @@ __global__ __launch_bounds__(WG, 4) void k_g2p_grad_b(Batch<G2PGradArgs> B) { co
 // The tile of v_out comes through the 27 neighbour entries of the item's block, fetched by 27 lanes together with the particle
 // state (k_p2g's neighbour_entry): round 2 looked every tile node's block up in blk_slot first (two dependent hops per node).
 // -----------------------------------------------------------------------------------------
-__device__ __forceinline__ int tile_region(int t) { return (t + 3) >> 2; }        // tile index 0 -> block B-1, 1..4 -> B, 5..7 -> B+1
 __device__ __forceinline__ void g2p_grad_load_tile2(const TileO& to, const SimP& S, const float4* __restrict__ g_out,
                                                     const float4* __restrict__ st, int nbr_entry, const PairCtx& pc) {
     if (!pc.live) return;                                    // (whole waves: the shuffles below see all 64 lanes)
@@ -1339,7 +1409,7 @@ __device__ __forceinline__ void g2p_grad2_body(SimP S, float* fr_cur, float* Gn_
     const bool stored = GS.cap > 0 && GS.flag[f];
     VoutSrc V; V.g_out = g_out; V.store = stored ? GS.data + (size_t)f * GS.cap * 128 : nullptr; V.blk_slot = T.blk_slot;
     FrameV cur = frame_view(fr_cur, S.Np);
-    FrameV Gn = frame_view(Gn_, S.Np), Gc = frame_view(Gc_, S.Np, S.wt);
+    FrameV Gn = frame_view(Gn_, S.Np), Gc = frame_view(Gc_, S.Np, S.wt & 4);
     TL(S, 0);
     Unit un = unit_load(T, blockIdx.x);                       // this workgroup's first unit, asked for together with meta
     const int n_slots = T.meta[5];
@@ -1353,7 +1423,7 @@ __device__ __forceinline__ void g2p_grad2_body(SimP S, float* fr_cur, float* Gn_
             const int tofs = pc.ti * 3 * TILE_N;
             const int i = tid & (HALF - 1);
             const int s = it.y + (i < it.z ? i : 0);
-            const int nbr_entry = V.store ? neighbour_entry(T.blk_slot, S.nb, it.x) : -1;       // (with the particle loads: one hop)
+            const int nbr_entry = neighbour_entry(T.blk_slot, S.nb, it.x);      // (with the particle loads: one hop) tile load + shell hand-over
             const int u0 = cur.used[s];
             const float4 a00 = cur.A0[s];
             g2p_grad_load_tile2(to, S, g_out, V.store, nbr_entry, pc);
@@ -1379,7 +1449,8 @@ __device__ __forceinline__ void g2p_grad2_body(SimP S, float* fr_cur, float* Gn_
             __syncthreads();
             TL(S, 6);
             if (pc.live) for (int l = pc.t0; l < TILE_N; l += pc.nth)
-                slab_store(slab, pc.slab, l, make_float4((float)s_acc3[tofs + l], (float)s_acc3[tofs + TILE_N + l], (float)s_acc3[tofs + 2 * TILE_N + l], 0.f), S.wt);
+                tile_handover<3>(S, slab, pc.slab, gg_out, GS, to, nbr_entry, l,
+                                 make_float4((float)s_acc3[tofs + l], (float)s_acc3[tofs + TILE_N + l], (float)s_acc3[tofs + 2 * TILE_N + l], 0.f), S.wt & 4);
             __syncthreads();
             TL(S, 7);
         } else {
@@ -1552,9 +1623,16 @@ __device__ __forceinline__ void grid_grad_body(SimP S, TableP T, const float4* _
                                                    const int* __restrict__ blk_list, const int* __restrict__ blk_count, int* blk_flag,
                                                    GridStore GS, int f, StaticsP ST, AgentP agent, NodeWork* work, int* work_count) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (the short-list road of k_grid: this wave's entry, asked for together with the list's length and the frame's store flag)
+    const int es = static_entry(wave);
+    const bool es_ok = es < S.nb * S.nb * S.nb;
+    const int blk_s = es_ok ? T.active[es] : 0;
+    const unsigned char lv_st = (es_ok && es < GS.cap) ? GS.live[(size_t)f * GS.cap + es] : (unsigned char)0, lv_cur = es_ok ? GS.cur[es] : (unsigned char)0;
+    const unsigned char drt_s = es_ok ? GS.dirty[es] : (unsigned char)0;
+    const int2 nbr_s = es_ok ? nbr_record(T, es, lane) : make_int2(0, 0);
     const bool stored = GS.cap > 0 && GS.flag[f];
     const int n_static = T.meta[2], n_dyn = *blk_count;
-    auto one_block = [&](int e, int b, bool is_static, bool dirty) {
+    auto one_block = [&](int e, int b, bool is_static, bool dirty, const int2 nbr) {
         const int c = (b << 6) | lane;
         const int bi = b / (S.nb * S.nb), bj = (b / S.nb) % S.nb, bk = b % S.nb;
         // total (p, m): from the forward pass' store, or kept in g_in by k_grid<true>
@@ -1562,7 +1640,7 @@ __device__ __forceinline__ void grid_grad_body(SimP S, TableP T, const float4* _
                                  : make_float4(g_in[c], g_in[S.ncell + c], g_in[2 * S.ncell + c], g_in[3 * S.ncell + c]);
         float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
         if (dirty) go = make_float4(gg_out[c], gg_out[S.ncell + c], gg_out[2 * S.ncell + c], 0.f);
-        if (is_static) { const float4 t = gather_slabs(S, T, slab, e, lane); go.x += t.x; go.y += t.y; go.z += t.z; }
+        if (is_static) { const float4 t = gather_slabs(slab, nbr, lane); go.x += t.x; go.y += t.y; go.z += t.z; }
         float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
         if (gi.w > FE_EPS) {
             float vo[3], kmul[3];
@@ -1590,6 +1668,9 @@ __device__ __forceinline__ void grid_grad_body(SimP S, TableP T, const float4* _
     };
     // the entries k_grid worked on in this frame (GridStore): the others have no mass, pass nothing on, and are read by no particle
     const unsigned char* __restrict__ live = stored ? GS.live + (size_t)f * GS.cap : GS.cur;
+    if (n_static <= 4 * (int)gridDim.x) {
+        if (es < n_static && (stored ? lv_st : lv_cur) != 0) one_block(es, blk_s, true, drt_s == GS.stamp, nbr_s);
+    } else {
     const EntryRange r = entry_range(S, n_static);
     for (int base = r.e0; base < r.e1; base += 32) {
         const int e = base + (lane & 31);
@@ -1602,10 +1683,11 @@ __device__ __forceinline__ void grid_grad_body(SimP S, TableP T, const float4* _
         for (int rank = 0; todo; rank++) {
             const int i = __builtin_ctz(todo);
             todo &= todo - 1;
-            if ((rank & 3) == wave) one_block(base + i, __builtin_amdgcn_readlane(blkv, i), true, (dm >> i) & 1);
+            if ((rank & 3) == wave) one_block(base + i, __builtin_amdgcn_readlane(blkv, i), true, (dm >> i) & 1, nbr_record(T, base + i, lane));
         }
     }
-    for (int d = blockIdx.x * 4 + wave; d < n_dyn; d += gridDim.x * 4) one_block(0, blk_list[d], false, true);
+    }
+    for (int d = blockIdx.x * 4 + wave; d < n_dyn; d += gridDim.x * 4) one_block(0, blk_list[d], false, true, make_int2(0, 0));
 }
 struct GridGradArgs { SimP S; TableP T; const float4* slab; float* g_in; float* gg_out; float4* gg_in; const int* blk_list; const int* blk_count; int* blk_flag; GridStore GS; int f; StaticsP ST; AgentP agent; NodeWork* work; int* work_count; };
 template <bool STATICS, bool DYN>
@@ -1848,7 +1930,7 @@ __device__ __forceinline__ void p2g_grad_body(SimP S, float* fr_cur, float* Gn_,
         if (act) for (int i = agent.n - 1; i >= 0; i--) effector_move_grad(agent.e[i], f);
     }
     FrameV cur = frame_view(fr_cur, S.Np);
-    FrameV Gn = frame_view(Gn_, S.Np), Gc = frame_view(Gc_, S.Np, S.wt);
+    FrameV Gn = frame_view(Gn_, S.Np), Gc = frame_view(Gc_, S.Np, S.wt & 8);
     TL(S, 0);
     Unit un = unit_load(T, blockIdx.x);                       // this workgroup's first unit, asked for together with meta
     const int n_slots = T.meta[5];
@@ -1885,17 +1967,34 @@ __global__ __launch_bounds__(WG, MINW) void k_p2g_grad_b(Batch<P2GGradArgs> B) {
 // =========================================================================================
 // block sort (counting sort by 4^3 block of the stencil base)
 // =========================================================================================
-#define SORT_HB 2048
+#define SORT_HB 4096      // cells in a workgroup's rank window: two y-neighbour blocks are 32 * 64 = 2048 cells apart at 128^3, and water falls in y
+// The sort is four launches (round 2: nine to ten, most of them 4-7 us latency chains):
+//   k_sort_count   key + rank of every slot, per-cell and per-block counts            (+ the rebuilt table's old block slots are cleared)
+//   k_sort_blocks  scan over the blocks -> slot ranges, work items, pair / single lists, list of occupied blocks
+//   k_sort_fill    one wave per occupied block: cell starts inside the block, the block's 27 neighbours go on the active list
+//   k_sort_apply   the permutation                                                   (+ unit descriptors and neighbour records)
+// Slot order: [particles of DENSE blocks, by cell] [particles of LOOSE blocks, by cell] [unused / outside the grid].
+// A block with at most `loose_max` particles is LOOSE: it gets no work item -- no workgroup half, no 16 KB tile, no 27-node scan
+// for a handful of lanes, no slab -- and its particles are worked on by the global path of every kernel, 256 to a workgroup, in
+// cell order (meta[1] = first such slot).  Where the water has come apart most occupied blocks are of that kind.
+//
 // Sort key = blocked cell address of the stencil base (block-major, then the 64 cells of the block): slots of one
 // block are contiguous (-> work items) AND particles of one cell are adjacent (-> the wavefront segmented scan in
 // the scatter kernels merges their contributions before touching LDS).
 // histogram + rank.  Keys of one workgroup's 256 slots are nearly always within a narrow range (the previous
 // order was sorted too), so ranks come from an LDS histogram (ds_add_rtn_u32) and only one global atomic per
 // distinct key per workgroup is issued; keys outside the window fall back to a global atomic.
-__global__ __launch_bounds__(256) void k_sort_count(SimP S, float* fr, int* key, int* rank, int* cnt, int* bflag) {
+#define SORT_CLR_WGS 32
+__global__ __launch_bounds__(256) void k_sort_count(SimP S, float* fr, int n_pwg, int* key, int* rank, int* cnt, int* bcnt,
+                                                    const int* __restrict__ clr_active, const int* __restrict__ clr_meta, int* clr_slot) {
     __shared__ int hist[SORT_HB + 1];       // + the sentinel's slot
     __shared__ int kmin;
     const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= n_pwg) {          // the table about to be rebuilt: forget the block slots of its previous life
+        const int n = clr_meta[2];
+        for (int i = (blockIdx.x - n_pwg) * 256 + tid; i < n; i += SORT_CLR_WGS * 256) clr_slot[clr_active[i]] = -1;
+        return;
+    }
     const int s = blockIdx.x * blockDim.x + tid;
     const bool valid = s < S.N;
     int kk = S.ncell;                                        // sentinel: unused / outside -> tail
@@ -1923,59 +2022,36 @@ __global__ __launch_bounds__(256) void k_sort_count(SimP S, float* fr, int* key,
     const bool local = valid && rel <= SORT_HB && (is_tail || rel < SORT_HB);
     int r = 0;
     if (local) r = atomicAdd(&hist[rel], 1);
-    else if (valid) { r = atomicAdd(&cnt[kk], 1); bflag[kk >> 6] = 1; }
+    else if (valid) r = atomicAdd(&cnt[kk], 1);
+    {   // keys outside the window: their block counts, one atomic per distinct block and wave (a window's worth of particles that
+        // moved on together all name the same block: 250 same-address atomics per workgroup took the kernel from 13 to 40 us)
+        unsigned long long todo = __ballot(valid && !local);
+        const int myb = kk >> 6;
+        while (todo) {
+            const int b = __builtin_amdgcn_readlane(myb, __builtin_ctzll(todo));
+            const unsigned long long same = __ballot(valid && !local && myb == b);
+            if ((tid & 63) == __builtin_ctzll(todo)) atomicAdd(&bcnt[b], __popcll(same));
+            todo &= ~same;
+        }
+    }
     __syncthreads();
-    // bflag[b] = 1: block b (index nblk: the tail sentinel) has particles -- the scan kernels only touch the cells of such blocks
+    // per-block counts of the window (it starts anywhere, so it overlaps up to 33 blocks; block nblk = the tail sentinel)
+    if (tid <= SORT_HB / 64 && kmin != 0x7fffffff) {
+        const int blk = (kmin >> 6) + tid;
+        const int lo = max(blk << 6, kmin) - kmin, hi = min((blk + 1) << 6, kmin + SORT_HB) - kmin;
+        int n = 0;
+        for (int l = lo; l < hi; l++) n += hist[l];
+        if (n > 0) atomicAdd(&bcnt[blk], n);
+    }
+    if (tid == 255 && hist[SORT_HB] > 0) atomicAdd(&bcnt[S.ncell >> 6], hist[SORT_HB]);
+    __syncthreads();
     for (int l = tid; l <= SORT_HB; l += 256) {
         int c = hist[l];
-        if (c > 0) { const int cell = l == SORT_HB ? S.ncell : kmin + l; hist[l] = atomicAdd(&cnt[cell], c); bflag[cell >> 6] = 1; }
+        if (c > 0) { const int cell = l == SORT_HB ? S.ncell : kmin + l; hist[l] = atomicAdd(&cnt[cell], c); }
     }
     __syncthreads();
     if (local) r += hist[rel];
     if (valid) { key[s] = kk; rank[s] = r; }
-}
-
-// exclusive scan of the cell histogram (ncell+1 entries) in two launches of ceil((ncell+1)/1024) workgroups:
-// per-workgroup partial sums, then every workgroup adds the partials before it and scans its own 1024 entries
-// (= 16 blocks).  Also emits the work list (one item per occupied block, split at ITEM_MAX particles) and
-// re-zeroes the histogram.
-__device__ __forceinline__ int wg_scan_excl(int v, int* sh, int tid, int& total) {   // 256 threads
-    const int lane = tid & 63, wave = tid >> 6;
-    int incl = v;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
-    if (lane == 63) sh[wave] = incl;
-    __syncthreads();
-    int off = 0;
-    for (int w = 0; w < wave; w++) off += sh[w];
-    total = sh[0] + sh[1] + sh[2] + sh[3];
-    __syncthreads();
-    return off + incl - v;
-}
-
-// per-thread sum of its 4 histogram entries, and (threads 0..15) the particle count of block wg*16+t.  The histogram has n^3 + 1
-// entries, nearly all of them empty: only the cells of blocks flagged by k_sort_count are read (and, in k_scan_final, written).
-__device__ __forceinline__ int scan_live(int ncell, const int* bflag, int tid) {
-    const int b0 = blockIdx.x * 1024 + tid * 4;
-    return b0 <= ncell && bflag[b0 >> 6] != 0;
-}
-__device__ __forceinline__ int scan_load(int ncell, const int* cnt, const int* bflag, int tid, int c[4], int* sh_sum, int& blk_cnt, bool& live) {
-    const int b0 = blockIdx.x * 1024 + tid * 4;
-    live = b0 <= ncell && bflag[b0 >> 6] != 0;
-    int sp = 0, sb = 0;
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int b = b0 + q;
-        c[q] = (live && b <= ncell) ? cnt[b] : 0;
-        sp += c[q];
-        if (b < ncell) sb += c[q];
-    }
-    sh_sum[tid] = sb;
-    __syncthreads();
-    blk_cnt = 0;
-    if (tid < 16) for (int q = 0; q < 16; q++) blk_cnt += sh_sum[tid * 16 + q];
-    __syncthreads();
-    return sp;
 }
 
 // Work items and workgroup pairs of a block with n particles: ceil(n / ITEM_MAX) items.  A block with several items pairs them up
@@ -1985,97 +2061,146 @@ __device__ __forceinline__ int3 block_work(int n, int ITEM_MAX) {
     const int k = (n + ITEM_MAX - 1) / ITEM_MAX;
     return make_int3(k, k > 1 ? (k + 1) >> 1 : 0, k == 1 ? 1 : 0);          // items, M pairs, singles
 }
-__global__ __launch_bounds__(256) void k_scan_partial(int ncell, int ITEM_MAX, const int* __restrict__ cnt, const int* __restrict__ bflag, int4* partial) {
-    __shared__ int sh[4];
-    __shared__ int sh_sum[256];
+
+// The scan over the blocks, ceil((nblk + 1) / 1024) workgroups (33 at 128^3): a workgroup owns 1024 consecutive blocks, four per
+// thread (one 16-byte load, coalesced; bcnt is padded with zeros), sums what lies before it (and everything: the loose particles
+// start behind ALL dense ones), scans its own threads and hands out slot ranges, items, pairs, singles and the list of occupied blocks.  nblk + 1 counts instead of the
+// n^3 + 1 cell counts the two-launch scan of round 2 went over; the cells are dealt with block by block in k_sort_fill.
+// (A single workgroup walking thread-contiguous stretches was tried first: 70 us at 128^3 and 420 us at 256^3 -- every load and
+// store instruction of a wave touched 64 different cache lines.)
+#define SORT_BLK_WG 1024
+struct BlkSums { int v[6]; };                 // dense particles, loose particles, items, pairs, singles, occupied blocks
+__device__ __forceinline__ void blk_accumulate(BlkSums& a, int n, int ITEM_MAX, int loose_max) {
+    if (n <= 0) return;
+    a.v[5]++;
+    if (n <= loose_max) { a.v[1] += n; return; }
+    const int3 w = block_work(n, ITEM_MAX);
+    a.v[0] += n; a.v[2] += w.x; a.v[3] += w.y; a.v[4] += w.z;
+}
+// the thread's four block counts and their sums
+__device__ __forceinline__ BlkSums blk_load4(int nblk, int ITEM_MAX, int loose_max, const int* __restrict__ bcnt, int n[4]) {
+    const int b0 = blockIdx.x * SORT_BLK_WG + threadIdx.x * 4;
+    const int4 n4 = *(const int4*)(bcnt + b0);
+    n[0] = n4.x; n[1] = n4.y; n[2] = n4.z; n[3] = n4.w;
+    BlkSums m = {{0, 0, 0, 0, 0, 0}};
+#pragma unroll
+    for (int u = 0; u < 4; u++) if (b0 + u < nblk) blk_accumulate(m, n[u], ITEM_MAX, loose_max);
+    return m;
+}
+// six sums over the 256 threads of the workgroup: exclusive prefix of this thread in ex[], workgroup totals in tot[]
+__device__ __forceinline__ void wg_scan6(const BlkSums& m, int (*sh)[6], int ex[6], int tot[6]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        int incl = m.v[k];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        ex[k] = incl - m.v[k];
+        if (lane == 63) sh[wave][k] = incl;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        int before = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < 4; w++) { const int t = sh[w][k]; all += t; if (w < wave) before += t; }
+        ex[k] += before; tot[k] = all;
+    }
+    __syncthreads();
+}
+__global__ __launch_bounds__(256) void k_sort_blocks(int nblk, int ncell, int ITEM_MAX, int loose_max, const int* __restrict__ bcnt, int* cnt, int* start,
+                                                     int4* items, int2* pairs, int* singles, int2* blk_first, int4* occ, int* meta) {
+    __shared__ int sh[4][6];
     const int tid = threadIdx.x;
-    // a workgroup none of whose 16 blocks is occupied (at 256^3: 16,000 of 16,400) has nothing to add
-    if (!__syncthreads_or(scan_live(ncell, bflag, tid))) { if (tid == 0) partial[blockIdx.x] = make_int4(0, 0, 0, 0); return; }
-    int c[4], blk_cnt;
-    bool live;
-    const int sp = scan_load(ncell, cnt, bflag, tid, c, sh_sum, blk_cnt, live);
-    const int3 bw = tid < 16 ? block_work(blk_cnt, ITEM_MAX) : make_int3(0, 0, 0);
-    int tp, ti, tm, ts;
-    wg_scan_excl(sp, sh, tid, tp);
-    wg_scan_excl(bw.x, sh, tid, ti);
-    wg_scan_excl(bw.y, sh, tid, tm);
-    wg_scan_excl(bw.z, sh, tid, ts);
-    if (tid == 0) partial[blockIdx.x] = make_int4(tp, ti, tm, ts);
+    // the sums of all workgroups' stretches, and of those before this one: every workgroup goes over the whole array again (128 KB
+    // of L2-resident counts at 128^3) instead of waiting for a launch that leaves partial sums -- a launch costs ~9 us here
+    BlkSums pb = {{0, 0, 0, 0, 0, 0}}, pa = {{0, 0, 0, 0, 0, 0}};
+    for (int w = 0; w < (int)gridDim.x; w++) {
+        const int b0 = w * SORT_BLK_WG + tid * 4;
+        const int4 n4 = *(const int4*)(bcnt + b0);
+        const int n[4] = {n4.x, n4.y, n4.z, n4.w};
+        BlkSums m = {{0, 0, 0, 0, 0, 0}};
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (b0 + u < nblk) blk_accumulate(m, n[u], ITEM_MAX, loose_max);
+#pragma unroll
+        for (int k = 0; k < 6; k++) { pa.v[k] += m.v[k]; if (w < (int)blockIdx.x) pb.v[k] += m.v[k]; }
+    }
+    int exb[6], before[6], exa[6], total[6];
+    wg_scan6(pb, sh, exb, before);
+    wg_scan6(pa, sh, exa, total);
+    int n[4], ex[6], tot[6];
+    const BlkSums m = blk_load4(nblk, ITEM_MAX, loose_max, bcnt, n);
+    wg_scan6(m, sh, ex, tot);
+    if (blockIdx.x == 0 && tid == 0) { meta[0] = total[2]; meta[1] = total[0]; meta[2] = 0; meta[3] = total[3]; meta[4] = total[4]; meta[6] = total[5]; meta[7] = total[0] + total[1]; }
+    const int b0 = blockIdx.x * SORT_BLK_WG + tid * 4;
+    if (b0 > nblk) return;
+    int D = before[0] + ex[0], L = total[0] + before[1] + ex[1], bi = before[2] + ex[2], bm = before[3] + ex[3], bs = before[4] + ex[4], oi = before[5] + ex[5];
+    int2 bf[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int b = b0 + u, nn = n[u];
+        bf[u] = make_int2(0, 0);
+        if (b > nblk) continue;
+        if (b == nblk) { start[ncell] = total[0] + total[1]; cnt[ncell] = 0; continue; }     // the tail: behind everything
+        if (nn <= 0) continue;
+        if (nn <= loose_max) { occ[oi++] = make_int4(b, L, nn, 1); L += nn; continue; }
+        const int3 w = block_work(nn, ITEM_MAX);
+        bf[u] = make_int2(bi, w.x);
+        occ[oi++] = make_int4(b, D, nn, 0);
+        if (w.z) singles[bs++] = bi;
+        for (int j = 0; j < w.y; j++) pairs[bm++] = make_int2(bi + 2 * j, 2 * j + 1 < w.x ? bi + 2 * j + 1 : -1);
+        for (int o = 0; o < nn; o += ITEM_MAX) items[bi++] = make_int4(b, D + o, min(ITEM_MAX, nn - o), 0);
+        D += nn;
+    }
+    if (b0 + 3 < nblk) { *(int4*)(blk_first + b0) = make_int4(bf[0].x, bf[0].y, bf[1].x, bf[1].y); *(int4*)(blk_first + b0 + 2) = make_int4(bf[2].x, bf[2].y, bf[3].x, bf[3].y); }
+    else for (int u = 0; u < 4; u++) if (b0 + u < nblk) blk_first[b0 + u] = bf[u];
 }
 
-__global__ __launch_bounds__(256) void k_scan_final(int ncell, int ITEM_MAX, int* cnt, int* bflag, const int4* __restrict__ partial, int* start, int4* items, int* meta,
-                                                    int2* blk_first, int2* pairs, int* singles) {
-    __shared__ int sh[4];
-    __shared__ int sh_sum[256];
-    __shared__ int sh_bp[256];
-    const int tid = threadIdx.x;
-    // Nothing occupied here (and not the workgroup that writes the totals): only the block table has to say so.  Without this
-    // exit every one of the 16,400 workgroups of a 256^3 grid summed the partials of all those before it (110 us per sort).
-    if (!__syncthreads_or(scan_live(ncell, bflag, tid)) && blockIdx.x != gridDim.x - 1) {
-        if (tid < 16 && blockIdx.x * 16 + tid < ncell / 64) blk_first[blockIdx.x * 16 + tid] = make_int2(0, 0);
-        return;
-    }
-    int pp = 0, pi = 0, pm = 0, ps = 0;                       // sums of the partials before this workgroup
-    for (int w = tid; w < (int)blockIdx.x; w += 256) { int4 t = partial[w]; pp += t.x; pi += t.y; pm += t.z; ps += t.w; }
-    int base_p, base_i, base_m, base_s, dummy;
-    wg_scan_excl(pp, sh, tid, base_p);
-    wg_scan_excl(pi, sh, tid, base_i);
-    wg_scan_excl(pm, sh, tid, base_m);
-    wg_scan_excl(ps, sh, tid, base_s);
-    int c[4], blk_cnt;
-    bool live;
-    const int sp = scan_load(ncell, cnt, bflag, tid, c, sh_sum, blk_cnt, live);
-    const int3 bw = tid < 16 ? block_work(blk_cnt, ITEM_MAX) : make_int3(0, 0, 0);
-    int toti, totm, tots;
-    int bp = base_p + wg_scan_excl(sp, sh, tid, dummy);
-    int bi = base_i + wg_scan_excl(bw.x, sh, tid, toti);
-    int bm = base_m + wg_scan_excl(bw.y, sh, tid, totm);
-    const int bs = base_s + wg_scan_excl(bw.z, sh, tid, tots);
-    sh_bp[tid] = bp;
-    __syncthreads();
-    if (tid < 16 && blockIdx.x * 16 + tid < ncell / 64) {     // the items of block wg*16+tid: slots [bstart, bstart+blk_cnt)
-        const int blk = blockIdx.x * 16 + tid, bstart = sh_bp[tid * 16];
-        blk_first[blk] = make_int2(bi, bw.x);
-        if (bw.z) singles[bs] = bi;
-        for (int j = 0; j < bw.y; j++) pairs[bm + j] = make_int2(bi + 2 * j, 2 * j + 1 < bw.x ? bi + 2 * j + 1 : -1);
-        for (int o = 0; o < blk_cnt; o += ITEM_MAX) items[bi++] = make_int4(blk, bstart + o, min(ITEM_MAX, blk_cnt - o), 0);
-    }
-    const int b0 = blockIdx.x * 1024 + tid * 4;
+// One wave per occupied block: where the block's 64 cells start inside its slot range (and the cell counts are zeroed for the next
+// sort), and its 27 neighbours join the order's active list -- every block some tile or some loose particle's stencil can reach.
+// The first lane to see a block swaps the sort's tag (unique per sort, >= 3) into blk_flag and appends it (see mark_dynamic).
+__global__ __launch_bounds__(256) void k_sort_fill(int nb, int tag, const int4* __restrict__ occ, int* meta, int* cnt, int* bcnt, int* start,
+                                                   int* blk_flag, int* active, int* blk_slot) {
+    const int lane = threadIdx.x & 63, nw = gridDim.x * 4;
+    const int n_occ = meta[6];
+    if (blockIdx.x == 0 && threadIdx.x == 0) bcnt[nb * nb * nb] = 0;              // the tail's count (the scan only read it)
+    for (int j = blockIdx.x * 4 + (threadIdx.x >> 6); j < n_occ; j += nw) {
+        const int4 r = occ[j];
+        const int b = r.x;
+        const int c = cnt[b * 64 + lane];
+        int incl = c;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int b = b0 + q;
-        if (b > ncell) break;
-        if (b == ncell) meta[1] = bp;                         // first tail slot
-        if (live) {
-            start[b] = bp;
-            bp += c[q];
-            cnt[b] = 0;                                       // ready for the next sort
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        start[b * 64 + lane] = r.y + incl - c;
+        if (c) cnt[b * 64 + lane] = 0;                                             // ready for the next sort
+        if (lane == 0) bcnt[b] = 0;
+        bool won = false;
+        int n2 = 0;
+        if (lane < 27) {
+            const int i2 = b / (nb * nb) + lane / 9 - 1, j2 = (b / nb) % nb + (lane / 3) % 3 - 1, k2 = b % nb + lane % 3 - 1;
+            if ((unsigned)i2 < (unsigned)nb && (unsigned)j2 < (unsigned)nb && (unsigned)k2 < (unsigned)nb) {
+                n2 = (i2 * nb + j2) * nb + k2;
+                won = blk_flag[n2] != tag && atomicExch(&blk_flag[n2], tag) != tag;
+            }
+        }
+        // the wave's new entries with ONE returning atomic on the list's length (27 lanes each asking for one: 25,000 returning
+        // atomics on one word per sort where the water has come apart, 36 us)
+        const unsigned long long wm = __ballot(won);
+        if (wm) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&meta[2], __popcll(wm));
+            base = __shfl(base, 0, 64);
+            if (won) { const int e = base + __popcll(wm & ((1ull << lane) - 1ull)); active[e] = n2; blk_slot[n2] = e; }
         }
     }
-    if (live && (tid & 15) == 0) bflag[b0 >> 6] = 0;         // (this workgroup was the flag's only reader in this launch)
-    if (blockIdx.x == gridDim.x - 1 && tid == 0) { meta[0] = base_i + toti; meta[2] = 0; meta[3] = base_m + totm; meta[4] = base_s + tots; }
 }
 
-// the order's static active list: every block within one block of an occupied block (= every block some tile reaches)
-__global__ __launch_bounds__(256) void k_build_active(int nb, const int4* __restrict__ items, int* meta, int* blk_flag, int* active, int* blk_slot) {
-    const int n_items = meta[0];
-    // one thread per (item, neighbour): 27 independent CAS instead of a serial chain per block
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n_items * 27; t += gridDim.x * blockDim.x) {
-        const int i = t / 27, nbr = t - i * 27;
-        const int b = items[i].x;
-        if (i > 0 && items[i - 1].x == b) continue;           // first item of its block only
-        const int i2 = b / (nb * nb) + nbr / 9 - 1, j2 = (b / nb) % nb + (nbr / 3) % 3 - 1, k2 = b % nb + nbr % 3 - 1;
-        if ((unsigned)i2 >= (unsigned)nb || (unsigned)j2 >= (unsigned)nb || (unsigned)k2 >= (unsigned)nb) continue;
-        const int n2 = (i2 * nb + j2) * nb + k2;
-        if (atomicCAS(&blk_flag[n2], 0, 2) == 0) { const int e = atomicAdd(&meta[2], 1); active[e] = n2; blk_slot[n2] = e; }
-    }
-}
 // What the substep kernels would otherwise look up through chains of dependent loads, laid out once per sort: the unit list of
 // the particle kernels (struct Unit) and, per active-list entry, the item ranges of its block's 27 neighbours (gather_slabs).
-__global__ __launch_bounds__(256) void k_build_units(int nb, int N, int xcd_on, const int4* __restrict__ items, const int2* __restrict__ pairs,
-                                                     const int* __restrict__ singles, const int2* __restrict__ blk_first, const int* __restrict__ active,
-                                                     int* meta, Unit* units, int units_cap, int2* nbr) {
-    const int gtid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
+// (device function: runs in the extra workgroups of k_sort_apply's launch, and alone for the identity order)
+__device__ __forceinline__ void build_units_dev(int gtid, int nth, int nb, int N, int xcd_on, const int4* __restrict__ items, const int2* __restrict__ pairs,
+                                                const int* __restrict__ singles, const int2* __restrict__ blk_first, const int* __restrict__ active,
+                                                int* meta, Unit* units, int units_cap, int2* nbr) {
     const int tail_start = meta[1], nM = meta[3], nS = meta[4], n_active = meta[2];
     const int n_pairs = nM + ((nS + 1) >> 1), n_tail = (N - tail_start + WG - 1) / WG;
     const int n_work = n_pairs + n_tail, per_xcd = (n_work + 7) >> 3;
@@ -2102,21 +2227,25 @@ __global__ __launch_bounds__(256) void k_build_units(int nb, int N, int xcd_on, 
         nbr[t] = v;
     }
 }
-__global__ __launch_bounds__(256) void k_clear_slots(const int* __restrict__ active, const int* __restrict__ meta, int* blk_slot) {
-    const int n = meta[2];
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) blk_slot[active[i]] = -1;
-}
-__global__ __launch_bounds__(256) void k_set_static(const int* __restrict__ active, const int* __restrict__ meta, int* blk_flag, int value) {
-    const int n = meta[2];
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) blk_flag[active[i]] = value;
+__global__ __launch_bounds__(256) void k_build_units(int nb, int N, int xcd_on, const int4* __restrict__ items, const int2* __restrict__ pairs,
+                                                     const int* __restrict__ singles, const int2* __restrict__ blk_first, const int* __restrict__ active,
+                                                     int* meta, Unit* units, int units_cap, int2* nbr) {
+    build_units_dev(blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, nb, N, xcd_on, items, pairs, singles, blk_first, active, meta, units, units_cap, nbr);
 }
 
 // The permutation itself, one pass: slot s of the old order goes to d = start[key] + rank -- its particle id, material record and
 // all 25 planes.  Reads are coalesced, writes land near s (the old order was sorted too: particles move less than a cell between
 // sorts), so the write combining of the L2 sees them almost in order.  (Round 1: index kernel, copy of the id table, gather kernel.)
-__global__ __launch_bounds__(256) void k_sort_apply(int N, size_t Np, const int* __restrict__ key, const int* __restrict__ rank,
+#define SORT_UNIT_WGS 128
+struct UnitsArgs { int nb, xcd_on; const int4* items; const int2* pairs; const int* singles; const int2* blk_first; const int* active; int* meta; Unit* units; int units_cap; int2* nbr; };
+__global__ __launch_bounds__(256) void k_sort_apply(int N, size_t Np, int n_pwg, const int* __restrict__ key, const int* __restrict__ rank,
                                                     const int* __restrict__ start, const int* __restrict__ pid_old, int* pid_new, int* slot_of_pid,
-                                                    const float4* __restrict__ pinfo, float4* info_new, float* dst_, float* src_) {
+                                                    const float4* __restrict__ pinfo, float4* info_new, float* dst_, float* src_, UnitsArgs U) {
+    if ((int)blockIdx.x >= n_pwg) {          // (independent of the permutation: both only need what k_sort_blocks / k_sort_fill left)
+        build_units_dev((blockIdx.x - n_pwg) * 256 + threadIdx.x, SORT_UNIT_WGS * 256, U.nb, N, U.xcd_on, U.items, U.pairs, U.singles, U.blk_first, U.active, U.meta,
+                        U.units, U.units_cap, U.nbr);
+        return;
+    }
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= N) return;
     const int d = start[key[s]] + rank[s];
@@ -2532,25 +2661,26 @@ struct FeEngine {
     float* grads = nullptr;                                 // 3 x (GR_WORDS*Np + Np) floats: ring of two + 1 spare
     float* grad_ptr[3] = {nullptr, nullptr, nullptr};
     // particle orders ("tables"): id 0 = identity; id 1+f = order produced by the sort at frame f
-    struct Table { int* pid = nullptr; float4* info = nullptr; int2* pairs = nullptr; int* singles = nullptr; int4* items = nullptr; int* meta = nullptr; int2* blk_first = nullptr; int* active = nullptr; int* blk_slot = nullptr; int* slot_of_pid = nullptr; Unit* units = nullptr; int2* nbr = nullptr; };
-    int static_table = -1;                                  // order whose active list is currently flagged 2 in blk_flag
+    struct Table { int tag = 2; int* pid = nullptr; float4* info = nullptr; int2* pairs = nullptr; int* singles = nullptr; int4* items = nullptr; int* meta = nullptr; int2* blk_first = nullptr; int* active = nullptr; int* blk_slot = nullptr; int* slot_of_pid = nullptr; Unit* units = nullptr; int2* nbr = nullptr; };
+    int sort_gen = 0;                                       // sorts so far: the next order's tag is sort_gen + 2
+    int* meta_host = nullptr;                               // pinned: the meta words of every order, copied after its sort (never waited for: heuristics only)
+    int loose_max = 0;                                      // blocks with <= this many particles get no work item (option "loose_max")
     std::vector<int> gs_host; bool gs_host_valid = false;   // host copy of gs_flag, refreshed once per backward sweep
     float4* gstore = nullptr; int* gs_flag = nullptr; int gs_cap = 0;     // forward grid store (see GridStore)
     unsigned char *ent_touched = nullptr, *ent_dirty = nullptr; unsigned stamp = 0;    // [nblk] marks of the scatter kernels per active-list entry (see GridStore)
     unsigned char *gs_live = nullptr, *cur_live = nullptr;                // k_grid's record of the entries it worked on: [(L+1) * cap] beside the store, [nblk] current
-    float4* slab = nullptr;                                 // one 512-node float4 tile per work item (scatter hand-over)
+    float4* slab = nullptr;                                 // one 6^3-node float4 slab per work item (scatter hand-over)
     std::vector<Table> tables;
     std::vector<int> tbl_of_frame;                          // [L+1]
     int gtbl[2] = {-1, -1};                                 // order of each adjoint ring slot; -1 = all zero
     int p2g_grad_waves = 4;                                 // occupancy target of the SVD-free p2g_grad build (tuning)
-    int g2p_grad_v = 2;                                     // 2 / 3: split, fully unrolled loops (k_g2p_grad2 at 3 / 4 waves per SIMD); 1: round 2's fused rolled loop
+    int g2p_grad_v = 0;                                     // 1: fused rolled loop (k_g2p_grad), 2: split unrolled loops (k_g2p_grad2), 0: by the order's particles per item
     int item_max = ITEM_MAX_CAP;                            // particles per work item (<= ITEM_MAX_CAP = one half workgroup)
     int sort_interval = 10;                                 // K: re-sort every K substeps (0 = never: global path only)
     size_t items_cap = 0, units_cap = 0;
-    int *sort_key = nullptr, *sort_rank = nullptr, *sort_cnt = nullptr, *sort_start = nullptr, *sort_pid = nullptr, *sort_bflag = nullptr;
+    int *sort_key = nullptr, *sort_rank = nullptr, *sort_cnt = nullptr, *sort_start = nullptr, *sort_pid = nullptr, *sort_bcnt = nullptr; int4* sort_occ = nullptr;
     int* slow_dev = nullptr;
     int* frame_slow_dev = nullptr;                          // set by a slow-path scatter of the current forward substep
-    int4* sort_partial = nullptr;
     float4* pinfo = nullptr; int* pool_idx = nullptr;
     std::vector<int> mat_host;
     float *g_in = nullptr, *gg_out = nullptr;              // SoA accumulator planes (4 and 3 x ncell floats)
@@ -2751,14 +2881,8 @@ int grad_order_for_frame(FeEngine* h, int f) {
     return reorder_grad(h, f & 1, t);
 }
 
-// blk_flag carries the value 2 on the active list of exactly one order; switch it when another order is used
-int use_static_table(FeEngine* h, int id) {
-    if (h->static_table == id) return 0;
-    if (h->static_table > 0) { FeEngine::Table& o = h->tables[h->static_table]; hipLaunchKernelGGL(k_set_static, dim3(64), dim3(256), 0, h->stream, o.active, o.meta, h->blk_flag, 0); }
-    if (id > 0) { FeEngine::Table& n = h->tables[id]; hipLaunchKernelGGL(k_set_static, dim3(64), dim3(256), 0, h->stream, n.active, n.meta, h->blk_flag, 2); }
-    h->static_table = id;
-    return 0;
-}
+// (round 2 switched the blocks flagged "static" here, two launches; an order's active list is now recognised by its own blk_slot)
+int use_static_table(FeEngine*, int) { return 0; }
 
 // counting sort of frame f by 4^3 block; the new order becomes table 1+f
 int sort_frame(FeEngine* h, int f) {
@@ -2770,28 +2894,42 @@ int sort_frame(FeEngine* h, int f) {
     const int ncell = h->S.ncell;
     const bool fine = h->prof_on && h->prof_fine;          // option "prof_fine": time the sort's stages instead of the whole
     if (!fine) prof_begin(h, KID_SORT);
-    use_static_table(h, 0);                          // un-flag the previous order before its lists are rebuilt
+    tn.tag = ++h->sort_gen + 2;
+    const int n_pwg = (int)pgrid(h).x;
+    const int nblk = h->nb * h->nb * h->nb;
     if (fine) prof_begin(h, KID_SORT_COUNT);
-    hipLaunchKernelGGL(k_clear_slots, dim3(64), dim3(256), 0, h->stream, tn.active, tn.meta, tn.blk_slot);
-    hipLaunchKernelGGL(k_sort_count, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->sort_key, h->sort_rank, h->sort_cnt, h->sort_bflag);
+    hipLaunchKernelGGL(k_sort_count, dim3(n_pwg + SORT_CLR_WGS), dim3(256), 0, h->stream, h->S, h->frame(f), n_pwg, h->sort_key, h->sort_rank, h->sort_cnt, h->sort_bcnt,
+                       tn.active, tn.meta, tn.blk_slot);
     if (fine) { prof_end(h); prof_begin(h, KID_SORT_SCAN); }
-    const int scan_wgs = (ncell + 1 + 1023) / 1024;
-    hipLaunchKernelGGL(k_scan_partial, dim3(scan_wgs), dim3(256), 0, h->stream, ncell, h->item_max, h->sort_cnt, h->sort_bflag, h->sort_partial);
-    hipLaunchKernelGGL(k_scan_final, dim3(scan_wgs), dim3(256), 0, h->stream, ncell, h->item_max, h->sort_cnt, h->sort_bflag, h->sort_partial, h->sort_start, tn.items, tn.meta, tn.blk_first, tn.pairs, tn.singles);
+    const int blk_wgs = (nblk + 1 + SORT_BLK_WG - 1) / SORT_BLK_WG;
+    hipLaunchKernelGGL(k_sort_blocks, dim3(blk_wgs), dim3(256), 0, h->stream, nblk, ncell, h->item_max, h->loose_max, h->sort_bcnt, h->sort_cnt, h->sort_start,
+                       tn.items, tn.pairs, tn.singles, tn.blk_first, h->sort_occ, tn.meta);
     if (fine) { prof_end(h); prof_begin(h, KID_SORT_ACTIVE); }
-    hipLaunchKernelGGL(k_build_active, dim3(256), dim3(256), 0, h->stream, h->nb, tn.items, tn.meta, h->blk_flag, tn.active, tn.blk_slot);
-    build_units(h, tn);
-    h->static_table = id_new;
+    hipLaunchKernelGGL(k_sort_fill, dim3(1024), dim3(256), 0, h->stream, h->nb, tn.tag, h->sort_occ, tn.meta, h->sort_cnt, h->sort_bcnt, h->sort_start, h->blk_flag, tn.active, tn.blk_slot);
     if (fine) { prof_end(h); prof_begin(h, KID_SORT_PERM); }
     // re-sorting a frame that is already in this table's order reads the id table it rewrites: stage it
     int* pid_dst = id_old == id_new ? h->sort_pid : tn.pid;
-    hipLaunchKernelGGL(k_sort_apply, pgrid(h), dim3(256), 0, h->stream, h->N, (size_t)h->Np, h->sort_key, h->sort_rank, h->sort_start,
-                       h->tables[id_old].pid, pid_dst, tn.slot_of_pid, h->pinfo, tn.info, h->spare_frame(), h->frame(f));
+    const UnitsArgs U = {h->nb, h->S.xcd, tn.items, tn.pairs, tn.singles, tn.blk_first, tn.active, tn.meta, tn.units, (int)h->units_cap, tn.nbr};
+    hipLaunchKernelGGL(k_sort_apply, dim3(n_pwg + SORT_UNIT_WGS), dim3(256), 0, h->stream, h->N, (size_t)h->Np, n_pwg, h->sort_key, h->sort_rank, h->sort_start,
+                       h->tables[id_old].pid, pid_dst, tn.slot_of_pid, h->pinfo, tn.info, h->spare_frame(), h->frame(f), U);
     if (id_old == id_new) HIPCK(h, hipMemcpyAsync(tn.pid, h->sort_pid, sizeof(int) * h->Np, hipMemcpyDeviceToDevice, h->stream));
     prof_end(h);
+    if (h->meta_host) (void)hipMemcpyAsync(h->meta_host + (size_t)id_new * 8, tn.meta, sizeof(int) * 8, hipMemcpyDeviceToHost, h->stream);
     std::swap(h->frame_ptr[f], h->spare_frame());
     h->tbl_of_frame[f] = id_new;
     return 0;
+}
+
+// Which build of the G2P adjoint an order gets.  The fused kernel (four waves per SIMD, shared weight arithmetic) is the faster one
+// where the items are full -- the falling block: 23.0 vs 25.8 us -- the split one (no selects, no loop bookkeeping, three waves per
+// SIMD) where they are not -- the layer: 29.8 vs 32.0 us.  Decided by the order's dense particles per item as its sort left them
+// in meta_host (a copy that is never waited for: an order whose numbers have not arrived yet takes the fused kernel).
+bool g2p_grad_split(FeEngine* h, int table) {
+    if (h->g2p_grad_v == 1) return false;
+    if (h->g2p_grad_v >= 2) return true;
+    if (!h->meta_host || table <= 0) return false;
+    const int* m = h->meta_host + (size_t)table * 8;
+    return m[0] > 0 && m[1] < 90 * m[0];
 }
 
 StaticsP statics_p(FeEngine* h) { StaticsP p; p.n = (int)h->statics_host.size(); p.s = h->statics_dev; return p; }
@@ -2897,8 +3035,7 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act) {
         hipLaunchKernelGGL(k_collide_grad, dim3(std::min((h->N + 15) / 16, 2048)), dim3(256), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->g_out, T, grid_store(h), f, ag,
                            h->hit_list, h->hit_count);
     }
-    if (h->g2p_grad_v == 2) hipLaunchKernelGGL(k_g2p_grad2<3>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag);
-    else if (h->g2p_grad_v == 3) hipLaunchKernelGGL(k_g2p_grad2<4>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag);
+    if (g2p_grad_split(h, t)) hipLaunchKernelGGL(k_g2p_grad2<3>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag);
     else hipLaunchKernelGGL(k_g2p_grad, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag);
     prof_end(h);
     prof_begin(h, KID_GRID_GRAD);
@@ -3044,8 +3181,7 @@ int substep_bwd_batch(FeEngine** hs, int B, int f, int f_global, int act) {
         prof_end(h0);
     }
     prof_begin(h0, KID_G2P_GRAD);
-    if (h0->g2p_grad_v == 2) hipLaunchKernelGGL(k_g2p_grad2_b<3>, wgrid_b(hs, B), dim3(WG), 0, h0->stream, bq);
-    else if (h0->g2p_grad_v == 3) hipLaunchKernelGGL(k_g2p_grad2_b<4>, wgrid_b(hs, B), dim3(WG), 0, h0->stream, bq);
+    if (g2p_grad_split(h0, h0->tbl_of_frame[f])) hipLaunchKernelGGL(k_g2p_grad2_b<3>, wgrid_b(hs, B), dim3(WG), 0, h0->stream, bq);
     else hipLaunchKernelGGL(k_g2p_grad_b, wgrid_b(hs, B), dim3(WG), 0, h0->stream, bq);
     prof_end(h0);
     prof_begin(h0, KID_GRID_GRAD);
@@ -3157,7 +3293,7 @@ FeEngine* fe_create(const FeConfig* cfg) {
     h->own_stream = h->stream;
     SimP& S = h->S;
     S.xcd = 1;
-    S.wt = 0;
+    S.wt = 5;                                              // p2g and g2p_grad: their bulk stores come early (A/B in DESIGN.md section 6)
     S.N = h->N; S.Np = h->Np; S.n = h->n; S.nb = h->nb; S.ncell = h->nb * h->nb * h->nb * 64;
     S.dx = 1.0f / (float)h->n; S.inv_dx = (float)h->n; S.dt = cfg->dt;
     S.stress_scale = -cfg->dt * cfg->p_vol * 4.f * S.inv_dx * S.inv_dx;
@@ -3176,8 +3312,8 @@ FeEngine* fe_create(const FeConfig* cfg) {
         h->items_cap = (nblk < (size_t)h->Np ? nblk : (size_t)h->Np) + (size_t)h->Np / 64 + 2;      // item_max >= 64
         h->units_cap = h->items_cap + (size_t)h->Np / WG + 16;                                      // work units: items (at worst one each) + tail workgroups, rounded up to 8
         if (dev_alloc(h, &h->sort_key, h->Np) || dev_alloc(h, &h->sort_rank, h->Np) || dev_alloc(h, &h->sort_cnt, ncell + 1) ||
-            dev_alloc(h, &h->sort_start, ncell + 1) || dev_alloc(h, &h->sort_bflag, ncell / 64 + 2) || dev_alloc(h, &h->sort_pid, h->Np) ||
-            dev_alloc(h, &h->slow_dev, 1) || dev_alloc(h, &h->frame_slow_dev, 1) || dev_alloc(h, &h->slab, h->items_cap * TILE_N, false) || dev_alloc(h, &h->sort_partial, (ncell + 1 + 1023) / 1024 + 1)) return fail("");
+            dev_alloc(h, &h->sort_start, ncell + 1) || dev_alloc(h, &h->sort_bcnt, ((nblk + 1 + SORT_BLK_WG - 1) / SORT_BLK_WG) * SORT_BLK_WG) || dev_alloc(h, &h->sort_occ, nblk + 1, false) || dev_alloc(h, &h->sort_pid, h->Np) ||
+            dev_alloc(h, &h->slow_dev, 1) || dev_alloc(h, &h->frame_slow_dev, 1) || dev_alloc(h, &h->slab, h->items_cap * SLAB_N, false)) return fail("");
     }
     if (dev_alloc(h, &h->effs_dev, FE_MAX_EFF)) return fail("");
     {   // forward grid store: cap blocks per frame, 2 KiB each; bounded to 64 GiB
@@ -3203,6 +3339,7 @@ FeEngine* fe_create(const FeConfig* cfg) {
         if (hipMemcpyOnStream(h, h->tables[0].pid, id.data(), sizeof(int) * h->Np, hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy failed");
         if (hipMemcpyOnStream(h, h->tables[0].slot_of_pid, id.data(), sizeof(int) * h->Np, hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy failed");
     }
+    if (hipHostMalloc((void**)&h->meta_host, sizeof(int) * 8 * (h->L + 2)) == hipSuccess) std::memset(h->meta_host, 0, sizeof(int) * 8 * (h->L + 2)); else h->meta_host = nullptr;
     if (hipEventCreate(&h->ev_t0) != hipSuccess || hipEventCreate(&h->ev_t1) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_batch, hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate failed");
     if (hipStreamSynchronize(h->stream) != hipSuccess) return fail("device initialisation failed");
@@ -3216,7 +3353,7 @@ void fe_destroy(FeEngine* h) {
     smoke_destroy(h);
     for (auto& t : h->tables) { if (t.info && t.info != h->pinfo) (void)hipFree(t.info);
         for (void* q : {(void*)t.pairs, (void*)t.singles, (void*)t.pid, (void*)t.items, (void*)t.meta, (void*)t.blk_first, (void*)t.active, (void*)t.blk_slot, (void*)t.slot_of_pid, (void*)t.units, (void*)t.nbr}) if (q) (void)hipFree(q); }
-    void* ptrs[] = {h->frames, h->grads, h->sort_key, h->sort_rank, h->sort_cnt, h->sort_start, h->sort_bflag, h->sort_pid, h->slow_dev, h->frame_slow_dev, h->gstore, h->gs_flag, h->gs_live, h->ent_touched, h->ent_dirty, h->cur_live, h->slab, h->sort_partial, h->effs_dev, h->pinfo, h->pool_idx, h->g_in, h->g_out, h->gg_out, h->gg_in,
+    void* ptrs[] = {h->frames, h->grads, h->sort_key, h->sort_rank, h->sort_cnt, h->sort_start, h->sort_bcnt, h->sort_occ, h->sort_pid, h->slow_dev, h->frame_slow_dev, h->gstore, h->gs_flag, h->gs_live, h->ent_touched, h->ent_dirty, h->cur_live, h->slab, h->effs_dev, h->pinfo, h->pool_idx, h->g_in, h->g_out, h->gg_out, h->gg_in,
                     h->blk_flag, h->blk_list, h->blk_count, h->err_dev, h->stage_r, h->stage_i, h->node_mark, h->counters,
                     h->tgt, h->chamfer, h->step_loss, h->body_start, h->body_pids, h->bodies_dev, h->statics_dev, h->collector_dev, h->hit_dev, h->hit_list, h->hit_count, h->node_work, h->node_work_count};
     for (float* v : h->statics_vox) if (v) (void)hipFree(v);
@@ -3232,6 +3369,7 @@ void fe_destroy(FeEngine* h) {
     if (h->ev_t1) (void)hipEventDestroy(h->ev_t1);
     if (h->ev_batch) (void)hipEventDestroy(h->ev_batch);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+    if (h->meta_host) (void)hipHostFree(h->meta_host);
     delete h;
 }
 
@@ -3263,6 +3401,7 @@ int fe_set_option(FeEngine* h, const char* name, double value) {
     }
     if (!std::strcmp(name, "p2g_grad_waves")) { h->p2g_grad_waves = (int)value; return 0; }
     if (!std::strcmp(name, "g2p_grad_v")) { h->g2p_grad_v = (int)value; return 0; }
+    if (!std::strcmp(name, "loose_max")) { if (value < 0 || value > ITEM_MAX_CAP) FAIL(h, "loose_max must be in [0, 128]"); h->loose_max = (int)value; return 0; }
     if (!std::strcmp(name, "inject_till")) { h->inject_till = (int)value; return 0; }
     if (!std::strcmp(name, "collide_min_y")) { h->collide_min_y = (float)value; return 0; }
     if (!std::strcmp(name, "collide_type")) {
@@ -3272,7 +3411,7 @@ int fe_set_option(FeEngine* h, const char* name, double value) {
     }
     if (!std::strcmp(name, "prof_fine")) { h->prof_fine = value != 0; return 0; }
     if (!std::strcmp(name, "xcd_map")) { h->S.xcd = value != 0; return 0; }
-    if (!std::strcmp(name, "write_through")) { h->S.wt = value != 0; return 0; }
+    if (!std::strcmp(name, "write_through")) { h->S.wt = (int)value; return 0; }
     if (!std::strcmp(name, "wgrid_cap")) { if (value < 64) { h->err = "wgrid_cap must be >= 64"; return 1; } h->wgrid_cap = (int)value; return 0; }
     if (!std::strcmp(name, "threads")) return 0;             // oracle-only tunable
     FAIL(h, std::string("unknown option: ") + name);
@@ -3844,6 +3983,7 @@ int fe_get_work_stats(FeEngine* h, int f, long long out[16]) {
     HIPCK(h, hipMemcpyAsync(meta, h->tables[t].meta, sizeof(meta), hipMemcpyDeviceToHost, h->stream));
     HIPCK(h, hipStreamSynchronize(h->stream));
     for (int i = 0; i < 5; i++) out[i] = meta[i];
+    out[13] = meta[7] - meta[1];                              // particles of loose blocks: slots [tail_start, tail_start + this)
     std::vector<int4> items((size_t)std::max(meta[0], 0));
     if (!items.empty()) {
         HIPCK(h, hipMemcpyAsync(items.data(), h->tables[t].items, sizeof(int4) * items.size(), hipMemcpyDeviceToHost, h->stream));

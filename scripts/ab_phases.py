@@ -5,7 +5,7 @@ wall-clock rate of the plain windows and the HIP-event time per kernel of the pr
 import json, sys, time
 sys.path.insert(0, '.')
 import bench
-from fluidlab_amd._capi import load_hip
+from fluidlab_amd._capi import load_hip, EngineLib
 
 args = sys.argv[1:]
 n_win, reps = 90, 1
@@ -14,17 +14,28 @@ while args and args[0].startswith('--'):
     if args[0] == '--reps': reps = int(args[1])
     args = args[2:]
 configs = args or ['']
-elib = load_hip()
+default_lib = load_hip()
+libs = {}
 orig = bench.build_block
 
 
 def run(cfg):
+    """cfg: comma-separated engine options; `lib=<path>` picks another build of the engine (A/B against an earlier round's kernels;
+    options that build does not know are skipped)"""
     opts = [o.split('=') for o in cfg.split(',') if o]
+    lib_path = next((v for k, v in opts if k == 'lib'), None)
+    opts = [(k, v) for k, v in opts if k != 'lib']
+    if lib_path and lib_path not in libs:
+        libs[lib_path] = EngineLib(lib_path)
+    elib = libs[lib_path] if lib_path else default_lib
 
     def build(*a, **k):
         eng, sc = orig(*a, **k)
         for name, v in opts:
-            eng.set_option(name, float(v))
+            try:
+                eng.set_option(name, float(v))
+            except Exception as e:                  # an older build without that option
+                print('   (option skipped:', name, e, ')', file=sys.stderr)
         return eng, sc
     bench.build_block = build
     try:

@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 rocminfo 2>/dev/null | grep -m3 -E "Marketing Name|gfx9" > $OUT/device.txt
 nproc >> $OUT/device.txt
 if [ "$TESTS" = "tests" ]; then
-  echo "== pytest -m gpu"; timeout 1500 python -m pytest tests -m gpu -x -q -s 2>&1 | grep -v "^$" | tail -60 | tee $OUT/pytest_gpu.txt
+  echo "== pytest -m gpu"; timeout 1500 python -m pytest tests/test_hip_parity.py tests/test_hip_random_scenes.py tests/test_kernel_golden.py tests/test_hip_fullsize.py tests/test_hip_env.py tests/test_smoke.py tests/test_mesh.py tests/test_hip_configs.py tests/test_bench.py -m gpu --maxfail=6 -q -s 2>&1 | grep -v "^$" | grep -v "^E  " | tail -70 | tee $OUT/pytest_gpu.txt
   echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee $OUT/smoke.txt
 fi
 if [ $# -gt 0 ]; then

@@ -52,6 +52,7 @@ def random_scene(seed):
     opts = {'sort_interval': int(rng.choice([0, 1, 4, 10])), 'grid_store': int(rng.rand() < 0.7),
             'item_max': int(rng.choice([64, 96, 128]))}
     n_sub = int(rng.choice([5, 12, 21]))
+    opts['loose_max'] = int(rng.choice([0, 0, 6, 20, 48]))         # (drawn last: the scenes of the earlier rounds stay what they were)
     return sc, opts, n_sub, liquid_only
 
 
