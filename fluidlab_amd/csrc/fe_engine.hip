@@ -173,8 +173,7 @@ __device__ __forceinline__ PInfo load_info(const float4* info, int i) {
 // A block is on the active list of the order a substep runs in exactly when that order's blk_slot holds an entry for it (>= 0):
 // the orders keep their own tables, so forward and backward substeps of any frame agree without re-flagging anything (round 2
 // kept the value 2 in blk_flag on exactly one order's list and switched it with two launches whenever backward crossed a sort).
-// blk_flag only says whether a block OUTSIDE that list is on the substep's dynamic list already (1); the sorts leave their tags
-// (>= 3, k_sort_fill) in it, which read as "not yet" like 0 does.
+// blk_flag only says whether a block OUTSIDE that list is on the substep's dynamic list already (1).
 __device__ __forceinline__ void mark_dynamic(int b, int* blk_flag, int* blk_list, int* blk_count) {
     const int fl = blk_flag[b];
     if (fl != 1) {
@@ -266,32 +265,28 @@ __device__ __forceinline__ SegScan seg_setup(int key) {
 }
 // Four independent values at once, one v_fmac_f32_dpp per step and value (the compiler's own lowering is
 // v_mov_b32_dpp + v_fma_f32).  A DPP read of a VGPR written by the previous VALU needs 2 wait states, which
-// inline asm has to provide itself: the 4 chains are independent, so three other VALU instructions always sit between
-// the write of a value in one step and its DPP read in the next; only the entry needs an s_nop.
-#define SEG_STEP4(ctrl, flag) \
-    asm volatile("v_fmac_f32_dpp %0, %0, %4 " ctrl " bound_ctrl:0\n\t" \
-                 "v_fmac_f32_dpp %1, %1, %4 " ctrl " bound_ctrl:0\n\t" \
-                 "v_fmac_f32_dpp %2, %2, %4 " ctrl " bound_ctrl:0\n\t" \
-                 "v_fmac_f32_dpp %3, %3, %4 " ctrl " bound_ctrl:0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(flag))
+// inline asm has to provide itself.
+// All four steps of the four chains in ONE asm statement: between separate statements the compiler pads a wait state of its own
+// (three s_nop per node and scan, 81 issue slots per particle).  Inside, a value written in one step is read by DPP four
+// instructions later (the three other chains sit in between): no wait states needed.
+#define SEG_ROW(r, ctrl, flag) "v_fmac_f32_dpp " r ", " r ", " flag " " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"
 __device__ __forceinline__ void seg_scan4(const SegScan& sc, float& a, float& b, float& c, float& d) {
-    asm volatile("s_nop 1" ::: );                        // the inputs were just produced by VALU
-    SEG_STEP4("row_shr:1 row_mask:0xf bank_mask:0xf", sc.f1);
-    SEG_STEP4("row_shr:2 row_mask:0xf bank_mask:0xf", sc.f2);
-    SEG_STEP4("row_shr:4 row_mask:0xf bank_mask:0xf", sc.f4);
-    SEG_STEP4("row_shr:8 row_mask:0xf bank_mask:0xf", sc.f8);
+    asm volatile("s_nop 1\n\t"                           // the inputs were just produced by VALU
+                 SEG_ROW("%0", "row_shr:1", "%4") SEG_ROW("%1", "row_shr:1", "%4") SEG_ROW("%2", "row_shr:1", "%4") SEG_ROW("%3", "row_shr:1", "%4")
+                 SEG_ROW("%0", "row_shr:2", "%5") SEG_ROW("%1", "row_shr:2", "%5") SEG_ROW("%2", "row_shr:2", "%5") SEG_ROW("%3", "row_shr:2", "%5")
+                 SEG_ROW("%0", "row_shr:4", "%6") SEG_ROW("%1", "row_shr:4", "%6") SEG_ROW("%2", "row_shr:4", "%6") SEG_ROW("%3", "row_shr:4", "%6")
+                 SEG_ROW("%0", "row_shr:8", "%7") SEG_ROW("%1", "row_shr:8", "%7") SEG_ROW("%2", "row_shr:8", "%7") SEG_ROW("%3", "row_shr:8", "%7")
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(sc.f1), "v"(sc.f2), "v"(sc.f4), "v"(sc.f8));
 }
-// three values (the adjoint scatter of g2p has no mass component)
-#define SEG_STEP3(ctrl, flag) \
-    asm volatile("v_fmac_f32_dpp %0, %0, %3 " ctrl " bound_ctrl:0\n\t" \
-                 "v_fmac_f32_dpp %1, %1, %3 " ctrl " bound_ctrl:0\n\t" \
-                 "v_fmac_f32_dpp %2, %2, %3 " ctrl " bound_ctrl:0\n\t" \
-                 "s_nop 0" : "+v"(a), "+v"(b), "+v"(c) : "v"(flag))      // 2 other VALUs + 1 wait state between write and DPP read
+// three values (the adjoint scatter of g2p has no mass component): two other VALUs between a write and its DPP read, so one
+// wait state per step
 __device__ __forceinline__ void seg_scan3(const SegScan& sc, float& a, float& b, float& c) {
-    asm volatile("s_nop 1" ::: );
-    SEG_STEP3("row_shr:1 row_mask:0xf bank_mask:0xf", sc.f1);
-    SEG_STEP3("row_shr:2 row_mask:0xf bank_mask:0xf", sc.f2);
-    SEG_STEP3("row_shr:4 row_mask:0xf bank_mask:0xf", sc.f4);
-    SEG_STEP3("row_shr:8 row_mask:0xf bank_mask:0xf", sc.f8);
+    asm volatile("s_nop 1\n\t"
+                 SEG_ROW("%0", "row_shr:1", "%3") SEG_ROW("%1", "row_shr:1", "%3") SEG_ROW("%2", "row_shr:1", "%3") "s_nop 0\n\t"
+                 SEG_ROW("%0", "row_shr:2", "%4") SEG_ROW("%1", "row_shr:2", "%4") SEG_ROW("%2", "row_shr:2", "%4") "s_nop 0\n\t"
+                 SEG_ROW("%0", "row_shr:4", "%5") SEG_ROW("%1", "row_shr:4", "%5") SEG_ROW("%2", "row_shr:4", "%5") "s_nop 0\n\t"
+                 SEG_ROW("%0", "row_shr:8", "%6") SEG_ROW("%1", "row_shr:8", "%6") SEG_ROW("%2", "row_shr:8", "%6")
+                 : "+v"(a), "+v"(b), "+v"(c) : "v"(sc.f1), "v"(sc.f2), "v"(sc.f4), "v"(sc.f8));
 }
 
 struct TableP {
@@ -790,7 +785,7 @@ __device__ __forceinline__ float4 gather_slabs(const float4* __restrict__ slab, 
     // blocks are loaded unconditionally-shaped (16 independent loads in flight, zero when absent): summing inside a loop made
     // every load wait for the previous one, eight dependent L2/MALL round trips per node.  Blocks with more than two slabs
     // (> 512 particles) finish in the loop below.  The summation order stays fixed (source c ascending, slab ascending).
-    int first[8], end[8], second[8], sidx[8];
+    int a0[8], n[8];                                // node's element in the source block's first slab; that block's item count (0: none reaches this node)
     float4 v0[8], v1[8];
 #pragma unroll
     for (int c = 0; c < 8; c++) {
@@ -804,19 +799,17 @@ __device__ __forceinline__ float4 gather_slabs(const float4* __restrict__ slab, 
             si = si * SLAB_T + o[d] + (other ? 4 : 0);
         }
         // (both shuffles by ALL lanes, whatever `valid` says: a cross-lane read of a lane that sits out returns 0)
-        first[c] = __shfl(mine.x, nbr, 64);
-        const int cnt_c = __shfl(mine.y, nbr, 64);
-        end[c] = valid ? first[c] + cnt_c : first[c];                           // (else: no slab of that block reaches this node)
-        sidx[c] = valid ? si : 0;
-        second[c] = first[c] + 2;
+        const int f = __shfl(mine.x, nbr, 64), k = __shfl(mine.y, nbr, 64);
+        n[c] = valid ? k : 0;
+        a0[c] = valid ? f * SLAB_N + si : 0;
     }
-    // (the loads are unconditional from a clamped, always valid slab index and masked afterwards: a conditional float4
+    // (the loads are unconditional from a clamped, always valid index and masked afterwards: a conditional float4
     // load into an array element ended up in scratch; lanes without a source all read node 0 of slab 0, one broadcast line)
 #pragma unroll
     for (int c = 0; c < 8; c++) {
-        const bool h0 = end[c] > first[c], h1 = second[c] < end[c];
-        const float4 a = slab[(size_t)(h0 ? first[c] : 0) * SLAB_N + (h0 ? sidx[c] : 0)];
-        const float4 b = slab[(size_t)(h1 ? second[c] : 0) * SLAB_N + (h1 ? sidx[c] : 0)];
+        const bool h0 = n[c] > 0, h1 = n[c] > 2;
+        const float4 a = slab[h0 ? a0[c] : 0];
+        const float4 b = slab[h1 ? a0[c] + 2 * SLAB_N : 0];
         v0[c] = make_float4(h0 ? a.x : 0.f, h0 ? a.y : 0.f, h0 ? a.z : 0.f, h0 ? a.w : 0.f);
         v1[c] = make_float4(h1 ? b.x : 0.f, h1 ? b.y : 0.f, h1 ? b.z : 0.f, h1 ? b.w : 0.f);
     }
@@ -825,17 +818,14 @@ __device__ __forceinline__ float4 gather_slabs(const float4* __restrict__ slab, 
     for (int c = 0; c < 8; c++) {
         acc.x += v0[c].x; acc.y += v0[c].y; acc.z += v0[c].z; acc.w += v0[c].w;
         acc.x += v1[c].x; acc.y += v1[c].y; acc.z += v1[c].z; acc.w += v1[c].w;
-        for (int k = second[c] + 2; k < end[c]; k += 2) {
-            const float4 v = slab[(size_t)k * SLAB_N + sidx[c]];
+        for (int k = 4; k < n[c]; k += 2) {
+            const float4 v = slab[a0[c] + k * SLAB_N];
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
     }
     return acc;
 }
 
-// The grid kernels' share of the active list: every workgroup owns a contiguous range of entries (4 while the list is shorter
-// than the launch has waves), the ranges dealt to the XCDs like the work items (xcd_item).  A workgroup reads the marks of its
-// range 32 entries at a time and its four waves share out the marked ones.
 // Short active lists (a block of water that has not come apart: ~1,000 entries) take a shorter road: wave w of the launch owns
 // entry static_entry(w) outright, so its block number, marks and neighbour record are asked for at once, together with the
 // list's length -- one round trip where the range walk below needs three (length -> marks -> neighbour record), in kernels that
@@ -847,21 +837,6 @@ __device__ __forceinline__ int static_entry(int wave) {
     const int j = blockIdx.x >> 3;
     return ((j >> 4) * 8 + (blockIdx.x & 7)) * 64 + (j & 15) * 4 + wave;
 }
-struct EntryRange { int e0, e1; };
-__device__ __forceinline__ EntryRange entry_range(const SimP& S, int n_static) {
-    const int G = gridDim.x >= 8 ? (int)(gridDim.x & ~7u) : (int)gridDim.x;       // workgroups that take ranges
-    int R = (n_static + G - 1) / G;                                               // entries per workgroup, a multiple of 4
-    R = (R + 3) & ~3;
-    const int n_wg = R > 0 ? (n_static + R - 1) / R : 0;                          // workgroups with work: <= G
-    const int per_xcd = (n_wg + 7) >> 3;                                          // 8 * per_xcd <= G when G is a multiple of 8
-    int wg = blockIdx.x;
-    if (gridDim.x >= 8) wg = (int)blockIdx.x < 8 * per_xcd ? xcd_item(blockIdx.x, per_xcd, S.xcd) : n_wg;
-    EntryRange r;
-    r.e0 = wg * R < n_static ? wg * R : n_static;
-    r.e1 = r.e0 + R < n_static ? r.e0 + R : n_static;
-    return r;
-}
-
 // grid_op (mpm:380-398) over the 4^3 blocks the scatter reached (GridStore: the marked entries of the order's active list, then
 // the dynamic list of slow-path blocks outside it); one wave per block.  STATICS: the scene has SDF colliders.
 // KEEP=false (forward): also re-zeroes g_in and the dynamic block flag, so no separate reset_grid pass
@@ -871,7 +846,7 @@ __device__ __forceinline__ void grid_body(SimP S, TableP T, const float4* __rest
                                               const int* __restrict__ blk_list, const int* __restrict__ blk_count, int* blk_flag,
                                               GridStore GS, int f, int* frame_slow, StaticsP ST, AgentP agent) {
     if (KEEP && GS.cap > 0 && GS.flag[f]) return;        // backward: stored by the forward pass
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     TL(S, 0);
     // this wave's entry on the short-list road, asked for before the list's length is known
     const int es = static_entry(wave);
@@ -922,33 +897,48 @@ __device__ __forceinline__ void grid_body(SimP S, TableP T, const float4* __rest
             if (tm || dm) one_block(es, blk_s, true, tm, dm, nbr_s);      // (entries without a mark: nothing arrived, and no particle reads those nodes)
         }
     } else {
-    const EntryRange r = entry_range(S, n_static);
-    for (int base = r.e0; base < r.e1; base += 32) {       // block numbers and marks of 32 entries: one load each
-        const int e = base + (lane & 31);
-        const bool in = e < r.e1;
-        const int blkv = (lane < 32 && in) ? T.active[e] : 0;
-        const unsigned char mk = in ? (lane < 32 ? GS.touched[e] : GS.dirty[e]) : 0;
-        const unsigned long long bal = __ballot(mk == GS.stamp);
-        const unsigned tm = (unsigned)bal, dm = (unsigned)(bal >> 32);
-        if (wave == 0 && lane < 32 && in) {                  // this launch's entries, recorded for k_grid_grad
-            if (KEEP) GS.cur[e] = ((tm | dm) >> lane) & 1;
-            else if (e < GS.cap) GS.live[(size_t)f * GS.cap + e] = ((tm | dm) >> lane) & 1;
+        // Longer lists: wave w takes the entries w, w + W, w + 2 W, ... (W = the launch's waves), eight at a time.  The marks of the
+        // eight come in one round trip; the marked ones are then worked on one after the other, the next one's block number and
+        // neighbour record on their way meanwhile.  Marked entries come in clusters (the list is in block order: water in one corner
+        // of the box): dealt out in contiguous ranges -- round 2 -- some workgroups had all of their 28 entries to work on and
+        // most had none (the splash: 25 us for 10,000 blocks); strided, every wave gets its share of every cluster.
+        const int W = 4 * (int)gridDim.x;
+        for (int e0 = es; e0 < n_static; e0 += 8 * W) {
+            unsigned tm = 0, dm = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int e = e0 + k * W;
+                const bool ok = e < n_static;
+                const unsigned char t = ok ? GS.touched[e] : (unsigned char)0, d = ok ? GS.dirty[e] : (unsigned char)0;
+                tm |= (t == GS.stamp ? 1u : 0u) << k; dm |= (d == GS.stamp ? 1u : 0u) << k;
+            }
+            tm = __builtin_amdgcn_readfirstlane(tm); dm = __builtin_amdgcn_readfirstlane(dm);
+            if (lane < 8 && e0 + lane * W < n_static) {       // this launch's entries, recorded for k_grid_grad
+                const int e = e0 + lane * W;
+                if (KEEP) GS.cur[e] = ((tm | dm) >> lane) & 1;
+                else if (e < GS.cap) GS.live[(size_t)f * GS.cap + e] = ((tm | dm) >> lane) & 1;
+            }
+            unsigned todo = tm | dm;                          // (entries without a mark: nothing arrived, and no particle reads those nodes)
+            int k = todo ? __builtin_ctz(todo) : -1;
+            int blk = k >= 0 ? T.active[e0 + k * W] : 0;
+            int2 nbr = k >= 0 ? nbr_record(T, e0 + k * W, lane) : make_int2(0, 0);
+            while (k >= 0) {
+                todo &= todo - 1;
+                const int k_next = todo ? __builtin_ctz(todo) : -1;
+                const int blk_next = k_next >= 0 ? T.active[e0 + k_next * W] : 0;
+                const int2 nbr_next = k_next >= 0 ? nbr_record(T, e0 + k_next * W, lane) : make_int2(0, 0);
+                one_block(e0 + k * W, blk, true, (tm >> k) & 1, (dm >> k) & 1, nbr);
+                k = k_next; blk = blk_next; nbr = nbr_next;
+            }
         }
-        unsigned todo = tm | dm;                             // (entries without a mark: nothing arrived, and no particle reads those nodes)
-        for (int rank = 0; todo; rank++) {
-            const int i = __builtin_ctz(todo);
-            todo &= todo - 1;
-            if ((rank & 3) == wave) one_block(base + i, __builtin_amdgcn_readlane(blkv, i), true, (tm >> i) & 1, (dm >> i) & 1, nbr_record(T, base + i, lane));
-        }
-    }
     }
     for (int d = blockIdx.x * 4 + wave; d < n_dyn; d += gridDim.x * 4) one_block(-1, blk_list[d], false, false, true, make_int2(0, 0));
 }
 struct GridArgs { SimP S; TableP T; const float4* slab; float* g_in; float4* g_out; const int* blk_list; const int* blk_count; int* blk_flag; GridStore GS; int f; int* frame_slow; StaticsP ST; AgentP agent; };
 template <bool KEEP, bool STATICS, bool DYN>
-__global__ __launch_bounds__(256) void k_grid(SimP S, TableP T, const float4* slab, float* g_in, float4* g_out, const int* blk_list, const int* blk_count, int* blk_flag, GridStore GS, int f, int* frame_slow, StaticsP ST, AgentP agent) { grid_body<KEEP, STATICS, DYN>(S, T, slab, g_in, g_out, blk_list, blk_count, blk_flag, GS, f, frame_slow, ST, agent); }
+__global__ __launch_bounds__(256, (STATICS || DYN) ? 2 : 4) void k_grid(SimP S, TableP T, const float4* slab, float* g_in, float4* g_out, const int* blk_list, const int* blk_count, int* blk_flag, GridStore GS, int f, int* frame_slow, StaticsP ST, AgentP agent) { grid_body<KEEP, STATICS, DYN>(S, T, slab, g_in, g_out, blk_list, blk_count, blk_flag, GS, f, frame_slow, ST, agent); }
 template <bool KEEP, bool STATICS, bool DYN>
-__global__ __launch_bounds__(256) void k_grid_b(Batch<GridArgs> B) { const GridArgs& A = B.a[blockIdx.y]; grid_body<KEEP, STATICS, DYN>(A.S, A.T, A.slab, A.g_in, A.g_out, A.blk_list, A.blk_count, A.blk_flag, A.GS, A.f, A.frame_slow, A.ST, A.agent); }
+__global__ __launch_bounds__(256, (STATICS || DYN) ? 2 : 4) void k_grid_b(Batch<GridArgs> B) { const GridArgs& A = B.a[blockIdx.y]; grid_body<KEEP, STATICS, DYN>(A.S, A.T, A.slab, A.g_in, A.g_out, A.blk_list, A.blk_count, A.blk_flag, A.GS, A.f, A.frame_slow, A.ST, A.agent); }
 
 
 // g2p (mpm:400-426) + advect_kernel (mpm:497-505) for one used particle; TILE: v_out staged in LDS (3 planes)
@@ -1622,7 +1612,7 @@ template <bool STATICS, bool DYN>
 __device__ __forceinline__ void grid_grad_body(SimP S, TableP T, const float4* __restrict__ slab, float* g_in, float* gg_out, float4* gg_in,
                                                    const int* __restrict__ blk_list, const int* __restrict__ blk_count, int* blk_flag,
                                                    GridStore GS, int f, StaticsP ST, AgentP agent, NodeWork* work, int* work_count) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // (the short-list road of k_grid: this wave's entry, asked for together with the list's length and the frame's store flag)
     const int es = static_entry(wave);
     const bool es_ok = es < S.nb * S.nb * S.nb;
@@ -1670,30 +1660,39 @@ __device__ __forceinline__ void grid_grad_body(SimP S, TableP T, const float4* _
     const unsigned char* __restrict__ live = stored ? GS.live + (size_t)f * GS.cap : GS.cur;
     if (n_static <= 4 * (int)gridDim.x) {
         if (es < n_static && (stored ? lv_st : lv_cur) != 0) one_block(es, blk_s, true, drt_s == GS.stamp, nbr_s);
-    } else {
-    const EntryRange r = entry_range(S, n_static);
-    for (int base = r.e0; base < r.e1; base += 32) {
-        const int e = base + (lane & 31);
-        const bool in = e < r.e1;
-        const int blkv = (lane < 32 && in) ? T.active[e] : 0;
-        const unsigned char mk = in ? (lane < 32 ? live[e] : GS.dirty[e]) : 0;
-        const unsigned long long bal = __ballot(lane < 32 ? mk != 0 : mk == GS.stamp);
-        const unsigned lm = (unsigned)bal, dm = (unsigned)(bal >> 32);
-        unsigned todo = lm;
-        for (int rank = 0; todo; rank++) {
-            const int i = __builtin_ctz(todo);
-            todo &= todo - 1;
-            if ((rank & 3) == wave) one_block(base + i, __builtin_amdgcn_readlane(blkv, i), true, (dm >> i) & 1, nbr_record(T, base + i, lane));
+    } else {                                                  // (the strided walk of k_grid's longer lists)
+        const int W = 4 * (int)gridDim.x;
+        for (int e0 = es; e0 < n_static; e0 += 8 * W) {
+            unsigned lm = 0, dm = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int e = e0 + k * W;
+                const bool ok = e < n_static;
+                const unsigned char l = ok ? live[e] : (unsigned char)0, d = ok ? GS.dirty[e] : (unsigned char)0;
+                lm |= (l != 0 ? 1u : 0u) << k; dm |= (d == GS.stamp ? 1u : 0u) << k;
+            }
+            lm = __builtin_amdgcn_readfirstlane(lm); dm = __builtin_amdgcn_readfirstlane(dm);
+            unsigned todo = lm;
+            int k = todo ? __builtin_ctz(todo) : -1;
+            int blk = k >= 0 ? T.active[e0 + k * W] : 0;
+            int2 nbr = k >= 0 ? nbr_record(T, e0 + k * W, lane) : make_int2(0, 0);
+            while (k >= 0) {
+                todo &= todo - 1;
+                const int k_next = todo ? __builtin_ctz(todo) : -1;
+                const int blk_next = k_next >= 0 ? T.active[e0 + k_next * W] : 0;
+                const int2 nbr_next = k_next >= 0 ? nbr_record(T, e0 + k_next * W, lane) : make_int2(0, 0);
+                one_block(e0 + k * W, blk, true, (dm >> k) & 1, nbr);
+                k = k_next; blk = blk_next; nbr = nbr_next;
+            }
         }
-    }
     }
     for (int d = blockIdx.x * 4 + wave; d < n_dyn; d += gridDim.x * 4) one_block(0, blk_list[d], false, true, make_int2(0, 0));
 }
 struct GridGradArgs { SimP S; TableP T; const float4* slab; float* g_in; float* gg_out; float4* gg_in; const int* blk_list; const int* blk_count; int* blk_flag; GridStore GS; int f; StaticsP ST; AgentP agent; NodeWork* work; int* work_count; };
 template <bool STATICS, bool DYN>
-__global__ __launch_bounds__(256) void k_grid_grad(SimP S, TableP T, const float4* slab, float* g_in, float* gg_out, float4* gg_in, const int* blk_list, const int* blk_count, int* blk_flag, GridStore GS, int f, StaticsP ST, AgentP agent, NodeWork* work, int* work_count) { grid_grad_body<STATICS, DYN>(S, T, slab, g_in, gg_out, gg_in, blk_list, blk_count, blk_flag, GS, f, ST, agent, work, work_count); }
+__global__ __launch_bounds__(256, (STATICS || DYN) ? 2 : 4) void k_grid_grad(SimP S, TableP T, const float4* slab, float* g_in, float* gg_out, float4* gg_in, const int* blk_list, const int* blk_count, int* blk_flag, GridStore GS, int f, StaticsP ST, AgentP agent, NodeWork* work, int* work_count) { grid_grad_body<STATICS, DYN>(S, T, slab, g_in, gg_out, gg_in, blk_list, blk_count, blk_flag, GS, f, ST, agent, work, work_count); }
 template <bool STATICS, bool DYN>
-__global__ __launch_bounds__(256) void k_grid_grad_b(Batch<GridGradArgs> B) { const GridGradArgs& A = B.a[blockIdx.y]; grid_grad_body<STATICS, DYN>(A.S, A.T, A.slab, A.g_in, A.gg_out, A.gg_in, A.blk_list, A.blk_count, A.blk_flag, A.GS, A.f, A.ST, A.agent, A.work, A.work_count); }
+__global__ __launch_bounds__(256, (STATICS || DYN) ? 2 : 4) void k_grid_grad_b(Batch<GridGradArgs> B) { const GridGradArgs& A = B.a[blockIdx.y]; grid_grad_body<STATICS, DYN>(A.S, A.T, A.slab, A.g_in, A.gg_out, A.gg_in, A.blk_list, A.blk_count, A.blk_flag, A.GS, A.f, A.ST, A.agent, A.work, A.work_count); }
 
 
 // second half of grid_op.grad for the nodes k_grid_grad<.., DYN> set aside: agent.collide's adjoint at the node (mpm:393-395 in
@@ -1968,9 +1967,9 @@ __global__ __launch_bounds__(WG, MINW) void k_p2g_grad_b(Batch<P2GGradArgs> B) {
 // block sort (counting sort by 4^3 block of the stencil base)
 // =========================================================================================
 #define SORT_HB 4096      // cells in a workgroup's rank window: two y-neighbour blocks are 32 * 64 = 2048 cells apart at 128^3, and water falls in y
-// The sort is four launches (round 2: nine to ten, most of them 4-7 us latency chains):
+// The sort is five launches (round 2: nine to ten, most of them 4-7 us latency chains):
 //   k_sort_count   key + rank of every slot, per-cell and per-block counts            (+ the rebuilt table's old block slots are cleared)
-//   k_sort_blocks  scan over the blocks -> slot ranges, work items, pair / single lists, list of occupied blocks
+//   k_sort_blk_partial / k_sort_blk_final  scan over the blocks -> slot ranges, work items, pair / single lists, list of occupied blocks
 //   k_sort_fill    one wave per occupied block: cell starts inside the block, the block's 27 neighbours go on the active list
 //   k_sort_apply   the permutation                                                   (+ unit descriptors and neighbour records)
 // Slot order: [particles of DENSE blocks, by cell] [particles of LOOSE blocks, by cell] [unused / outside the grid].
@@ -2062,9 +2061,10 @@ __device__ __forceinline__ int3 block_work(int n, int ITEM_MAX) {
     return make_int3(k, k > 1 ? (k + 1) >> 1 : 0, k == 1 ? 1 : 0);          // items, M pairs, singles
 }
 
-// The scan over the blocks, ceil((nblk + 1) / 1024) workgroups (33 at 128^3): a workgroup owns 1024 consecutive blocks, four per
-// thread (one 16-byte load, coalesced; bcnt is padded with zeros), sums what lies before it (and everything: the loose particles
-// start behind ALL dense ones), scans its own threads and hands out slot ranges, items, pairs, singles and the list of occupied blocks.  nblk + 1 counts instead of the
+// The scan over the blocks, two launches of ceil((nblk + 1) / 1024) workgroups (33 at 128^3): a workgroup owns 1024 consecutive
+// blocks, four per thread (one 16-byte load, coalesced; bcnt is padded with zeros); k_sort_blk_partial leaves the workgroup's six
+// sums, k_sort_blk_final adds up the partials before it (and all of them: the loose particles start behind ALL dense ones), scans
+// its own threads and hands out slot ranges, items, pairs, singles and the list of occupied blocks.  nblk + 1 counts instead of the
 // n^3 + 1 cell counts the two-launch scan of round 2 went over; the cells are dealt with block by block in k_sort_fill.
 // (A single workgroup walking thread-contiguous stretches was tried first: 70 us at 128^3 and 420 us at 256^3 -- every load and
 // store instruction of a wave touched 64 different cache lines.)
@@ -2089,7 +2089,7 @@ __device__ __forceinline__ BlkSums blk_load4(int nblk, int ITEM_MAX, int loose_m
 }
 // six sums over the 256 threads of the workgroup: exclusive prefix of this thread in ex[], workgroup totals in tot[]
 __device__ __forceinline__ void wg_scan6(const BlkSums& m, int (*sh)[6], int ex[6], int tot[6]) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #pragma unroll
     for (int k = 0; k < 6; k++) {
         int incl = m.v[k];
@@ -2108,22 +2108,24 @@ __device__ __forceinline__ void wg_scan6(const BlkSums& m, int (*sh)[6], int ex[
     }
     __syncthreads();
 }
-__global__ __launch_bounds__(256) void k_sort_blocks(int nblk, int ncell, int ITEM_MAX, int loose_max, const int* __restrict__ bcnt, int* cnt, int* start,
-                                                     int4* items, int2* pairs, int* singles, int2* blk_first, int4* occ, int* meta) {
+__global__ __launch_bounds__(256) void k_sort_blk_partial(int nblk, int ITEM_MAX, int loose_max, const int* __restrict__ bcnt, int* partial) {
+    __shared__ int sh[4][6];
+    int n[4], ex[6], tot[6];
+    const BlkSums m = blk_load4(nblk, ITEM_MAX, loose_max, bcnt, n);
+    wg_scan6(m, sh, ex, tot);
+    if (threadIdx.x < 6) partial[blockIdx.x * 8 + threadIdx.x] = tot[threadIdx.x];
+}
+// (one launch in which every workgroup goes over the whole array again instead of reading partial sums was tried: the six sums need
+// a division per block, 35 us for the launch against 18 for these two)
+__global__ __launch_bounds__(256) void k_sort_blk_final(int nblk, int ncell, int ITEM_MAX, int loose_max, const int* __restrict__ bcnt, int* cnt, int* start,
+                                                        const int* __restrict__ partial, int4* items, int2* pairs, int* singles, int2* blk_first, int4* occ, int* meta) {
     __shared__ int sh[4][6];
     const int tid = threadIdx.x;
-    // the sums of all workgroups' stretches, and of those before this one: every workgroup goes over the whole array again (128 KB
-    // of L2-resident counts at 128^3) instead of waiting for a launch that leaves partial sums -- a launch costs ~9 us here
+    // the partials of the workgroups before this one, and of all of them
     BlkSums pb = {{0, 0, 0, 0, 0, 0}}, pa = {{0, 0, 0, 0, 0, 0}};
-    for (int w = 0; w < (int)gridDim.x; w++) {
-        const int b0 = w * SORT_BLK_WG + tid * 4;
-        const int4 n4 = *(const int4*)(bcnt + b0);
-        const int n[4] = {n4.x, n4.y, n4.z, n4.w};
-        BlkSums m = {{0, 0, 0, 0, 0, 0}};
+    for (int w = tid; w < (int)gridDim.x; w += 256) {
 #pragma unroll
-        for (int u = 0; u < 4; u++) if (b0 + u < nblk) blk_accumulate(m, n[u], ITEM_MAX, loose_max);
-#pragma unroll
-        for (int k = 0; k < 6; k++) { pa.v[k] += m.v[k]; if (w < (int)blockIdx.x) pb.v[k] += m.v[k]; }
+        for (int k = 0; k < 6; k++) { const int t = partial[w * 8 + k]; pa.v[k] += t; if (w < (int)blockIdx.x) pb.v[k] += t; }
     }
     int exb[6], before[6], exa[6], total[6];
     wg_scan6(pb, sh, exb, before);
@@ -2156,42 +2158,52 @@ __global__ __launch_bounds__(256) void k_sort_blocks(int nblk, int ncell, int IT
     else for (int u = 0; u < 4; u++) if (b0 + u < nblk) blk_first[b0 + u] = bf[u];
 }
 
-// One wave per occupied block: where the block's 64 cells start inside its slot range (and the cell counts are zeroed for the next
-// sort), and its 27 neighbours join the order's active list -- every block some tile or some loose particle's stencil can reach.
-// The first lane to see a block swaps the sort's tag (unique per sort, >= 3) into blk_flag and appends it (see mark_dynamic).
-__global__ __launch_bounds__(256) void k_sort_fill(int nb, int tag, const int4* __restrict__ occ, int* meta, int* cnt, int* bcnt, int* start,
-                                                   int* blk_flag, int* active, int* blk_slot) {
-    const int lane = threadIdx.x & 63, nw = gridDim.x * 4;
-    const int n_occ = meta[6];
-    if (blockIdx.x == 0 && threadIdx.x == 0) bcnt[nb * nb * nb] = 0;              // the tail's count (the scan only read it)
-    for (int j = blockIdx.x * 4 + (threadIdx.x >> 6); j < n_occ; j += nw) {
-        const int4 r = occ[j];
-        const int b = r.x;
-        const int c = cnt[b * 64 + lane];
-        int incl = c;
+// Two jobs in one launch.  Workgroups [0, SORT_FILL_WGS): one wave per occupied block -- where the block's 64 cells start inside its
+// slot range (the cell counts are zeroed for the next sort).  The workgroups behind them: one thread per block of the grid -- is any
+// of its 27 neighbours occupied?  Then it joins the order's active list: every block some tile or some loose particle's stencil can
+// reach.  (Round 2 and the first form of this kernel pushed instead: each occupied block swapped a flag into its 27 neighbours'
+// words; where the water has come apart that is 200,000 returning atomics on 25,000 words, 27 deep each -- 36 us.  Asking costs 27
+// cached loads per block and one atomic per wave, and the list comes out in block order.)
+#define SORT_FILL_WGS 512
+__global__ __launch_bounds__(256) void k_sort_fill(int nb, const int4* __restrict__ occ, int* meta, int* cnt, const int* __restrict__ bcnt, int* start,
+                                                   int* active, int* blk_slot) {
+    const int lane = threadIdx.x & 63;
+    if ((int)blockIdx.x < SORT_FILL_WGS) {
+        const int n_occ = meta[6];
+        for (int j = blockIdx.x * 4 + (threadIdx.x >> 6); j < n_occ; j += SORT_FILL_WGS * 4) {
+            const int4 r = occ[j];
+            const int b = r.x;
+            const int c = cnt[b * 64 + lane];
+            int incl = c;
 #pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
-        start[b * 64 + lane] = r.y + incl - c;
-        if (c) cnt[b * 64 + lane] = 0;                                             // ready for the next sort
-        if (lane == 0) bcnt[b] = 0;
-        bool won = false;
-        int n2 = 0;
-        if (lane < 27) {
-            const int i2 = b / (nb * nb) + lane / 9 - 1, j2 = (b / nb) % nb + (lane / 3) % 3 - 1, k2 = b % nb + lane % 3 - 1;
-            if ((unsigned)i2 < (unsigned)nb && (unsigned)j2 < (unsigned)nb && (unsigned)k2 < (unsigned)nb) {
-                n2 = (i2 * nb + j2) * nb + k2;
-                won = blk_flag[n2] != tag && atomicExch(&blk_flag[n2], tag) != tag;
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+            start[b * 64 + lane] = r.y + incl - c;
+            if (c) cnt[b * 64 + lane] = 0;                                         // ready for the next sort
+        }
+        return;
+    }
+    const int nblk = nb * nb * nb;
+    const int b = (blockIdx.x - SORT_FILL_WGS) * 256 + threadIdx.x;
+    bool on = false;
+    if (b < nblk) {
+        const int bi = b / (nb * nb), bj = (b / nb) % nb, bk = b % nb;
+#pragma unroll
+        for (int di = -1; di <= 1; di++)
+#pragma unroll
+            for (int dj = -1; dj <= 1; dj++) {
+                const int i2 = bi + di, j2 = bj + dj;
+                if ((unsigned)i2 < (unsigned)nb && (unsigned)j2 < (unsigned)nb) {
+                    const int row = (i2 * nb + j2) * nb;
+                    on = on || bcnt[row + bk] > 0 || (bk > 0 && bcnt[row + bk - 1] > 0) || (bk + 1 < nb && bcnt[row + bk + 1] > 0);
+                }
             }
-        }
-        // the wave's new entries with ONE returning atomic on the list's length (27 lanes each asking for one: 25,000 returning
-        // atomics on one word per sort where the water has come apart, 36 us)
-        const unsigned long long wm = __ballot(won);
-        if (wm) {
-            int base = 0;
-            if (lane == 0) base = atomicAdd(&meta[2], __popcll(wm));
-            base = __shfl(base, 0, 64);
-            if (won) { const int e = base + __popcll(wm & ((1ull << lane) - 1ull)); active[e] = n2; blk_slot[n2] = e; }
-        }
+    }
+    const unsigned long long wm = __ballot(on);
+    if (wm) {                                                  // the wave's entries with ONE returning atomic on the list's length
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&meta[2], __popcll(wm));
+        base = __shfl(base, 0, 64);
+        if (on) { const int e = base + __popcll(wm & ((1ull << lane) - 1ull)); active[e] = b; blk_slot[b] = e; }
     }
 }
 
@@ -2237,11 +2249,12 @@ __global__ __launch_bounds__(256) void k_build_units(int nb, int N, int xcd_on, 
 // all 25 planes.  Reads are coalesced, writes land near s (the old order was sorted too: particles move less than a cell between
 // sorts), so the write combining of the L2 sees them almost in order.  (Round 1: index kernel, copy of the id table, gather kernel.)
 #define SORT_UNIT_WGS 128
-struct UnitsArgs { int nb, xcd_on; const int4* items; const int2* pairs; const int* singles; const int2* blk_first; const int* active; int* meta; Unit* units; int units_cap; int2* nbr; };
+struct UnitsArgs { int* bcnt; int nb, xcd_on; const int4* items; const int2* pairs; const int* singles; const int2* blk_first; const int* active; int* meta; Unit* units; int units_cap; int2* nbr; };
 __global__ __launch_bounds__(256) void k_sort_apply(int N, size_t Np, int n_pwg, const int* __restrict__ key, const int* __restrict__ rank,
                                                     const int* __restrict__ start, const int* __restrict__ pid_old, int* pid_new, int* slot_of_pid,
                                                     const float4* __restrict__ pinfo, float4* info_new, float* dst_, float* src_, UnitsArgs U) {
-    if ((int)blockIdx.x >= n_pwg) {          // (independent of the permutation: both only need what k_sort_blocks / k_sort_fill left)
+    if ((int)blockIdx.x >= n_pwg) {          // (independent of the permutation: both only need what the scan and k_sort_fill left)
+        for (int i = (blockIdx.x - n_pwg) * 256 + threadIdx.x; i <= U.nb * U.nb * U.nb; i += SORT_UNIT_WGS * 256) U.bcnt[i] = 0;      // block counts: ready for the next sort
         build_units_dev((blockIdx.x - n_pwg) * 256 + threadIdx.x, SORT_UNIT_WGS * 256, U.nb, N, U.xcd_on, U.items, U.pairs, U.singles, U.blk_first, U.active, U.meta,
                         U.units, U.units_cap, U.nbr);
         return;
@@ -2373,7 +2386,7 @@ struct RigidBody {
 // Sum val[0..K) over the workgroup (256 threads) into out[0..K) (LDS); every thread may read out[] after the call.
 template <int K>
 __device__ __forceinline__ void block_sum(const double (&val)[K], double* out, double* part /* [4][K] */) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #pragma unroll
     for (int k = 0; k < K; k++) {
         double v = val[k];
@@ -2661,8 +2674,7 @@ struct FeEngine {
     float* grads = nullptr;                                 // 3 x (GR_WORDS*Np + Np) floats: ring of two + 1 spare
     float* grad_ptr[3] = {nullptr, nullptr, nullptr};
     // particle orders ("tables"): id 0 = identity; id 1+f = order produced by the sort at frame f
-    struct Table { int tag = 2; int* pid = nullptr; float4* info = nullptr; int2* pairs = nullptr; int* singles = nullptr; int4* items = nullptr; int* meta = nullptr; int2* blk_first = nullptr; int* active = nullptr; int* blk_slot = nullptr; int* slot_of_pid = nullptr; Unit* units = nullptr; int2* nbr = nullptr; };
-    int sort_gen = 0;                                       // sorts so far: the next order's tag is sort_gen + 2
+    struct Table { int* pid = nullptr; float4* info = nullptr; int2* pairs = nullptr; int* singles = nullptr; int4* items = nullptr; int* meta = nullptr; int2* blk_first = nullptr; int* active = nullptr; int* blk_slot = nullptr; int* slot_of_pid = nullptr; Unit* units = nullptr; int2* nbr = nullptr; };
     int* meta_host = nullptr;                               // pinned: the meta words of every order, copied after its sort (never waited for: heuristics only)
     int loose_max = 0;                                      // blocks with <= this many particles get no work item (option "loose_max")
     std::vector<int> gs_host; bool gs_host_valid = false;   // host copy of gs_flag, refreshed once per backward sweep
@@ -2678,7 +2690,7 @@ struct FeEngine {
     int item_max = ITEM_MAX_CAP;                            // particles per work item (<= ITEM_MAX_CAP = one half workgroup)
     int sort_interval = 10;                                 // K: re-sort every K substeps (0 = never: global path only)
     size_t items_cap = 0, units_cap = 0;
-    int *sort_key = nullptr, *sort_rank = nullptr, *sort_cnt = nullptr, *sort_start = nullptr, *sort_pid = nullptr, *sort_bcnt = nullptr; int4* sort_occ = nullptr;
+    int *sort_key = nullptr, *sort_rank = nullptr, *sort_cnt = nullptr, *sort_start = nullptr, *sort_pid = nullptr, *sort_bcnt = nullptr, *sort_partial = nullptr; int4* sort_occ = nullptr;
     int* slow_dev = nullptr;
     int* frame_slow_dev = nullptr;                          // set by a slow-path scatter of the current forward substep
     float4* pinfo = nullptr; int* pool_idx = nullptr;
@@ -2894,7 +2906,6 @@ int sort_frame(FeEngine* h, int f) {
     const int ncell = h->S.ncell;
     const bool fine = h->prof_on && h->prof_fine;          // option "prof_fine": time the sort's stages instead of the whole
     if (!fine) prof_begin(h, KID_SORT);
-    tn.tag = ++h->sort_gen + 2;
     const int n_pwg = (int)pgrid(h).x;
     const int nblk = h->nb * h->nb * h->nb;
     if (fine) prof_begin(h, KID_SORT_COUNT);
@@ -2902,14 +2913,15 @@ int sort_frame(FeEngine* h, int f) {
                        tn.active, tn.meta, tn.blk_slot);
     if (fine) { prof_end(h); prof_begin(h, KID_SORT_SCAN); }
     const int blk_wgs = (nblk + 1 + SORT_BLK_WG - 1) / SORT_BLK_WG;
-    hipLaunchKernelGGL(k_sort_blocks, dim3(blk_wgs), dim3(256), 0, h->stream, nblk, ncell, h->item_max, h->loose_max, h->sort_bcnt, h->sort_cnt, h->sort_start,
+    hipLaunchKernelGGL(k_sort_blk_partial, dim3(blk_wgs), dim3(256), 0, h->stream, nblk, h->item_max, h->loose_max, h->sort_bcnt, h->sort_partial);
+    hipLaunchKernelGGL(k_sort_blk_final, dim3(blk_wgs), dim3(256), 0, h->stream, nblk, ncell, h->item_max, h->loose_max, h->sort_bcnt, h->sort_cnt, h->sort_start, h->sort_partial,
                        tn.items, tn.pairs, tn.singles, tn.blk_first, h->sort_occ, tn.meta);
     if (fine) { prof_end(h); prof_begin(h, KID_SORT_ACTIVE); }
-    hipLaunchKernelGGL(k_sort_fill, dim3(1024), dim3(256), 0, h->stream, h->nb, tn.tag, h->sort_occ, tn.meta, h->sort_cnt, h->sort_bcnt, h->sort_start, h->blk_flag, tn.active, tn.blk_slot);
+    hipLaunchKernelGGL(k_sort_fill, dim3(SORT_FILL_WGS + (nblk + 255) / 256), dim3(256), 0, h->stream, h->nb, h->sort_occ, tn.meta, h->sort_cnt, h->sort_bcnt, h->sort_start, tn.active, tn.blk_slot);
     if (fine) { prof_end(h); prof_begin(h, KID_SORT_PERM); }
     // re-sorting a frame that is already in this table's order reads the id table it rewrites: stage it
     int* pid_dst = id_old == id_new ? h->sort_pid : tn.pid;
-    const UnitsArgs U = {h->nb, h->S.xcd, tn.items, tn.pairs, tn.singles, tn.blk_first, tn.active, tn.meta, tn.units, (int)h->units_cap, tn.nbr};
+    const UnitsArgs U = {h->sort_bcnt, h->nb, h->S.xcd, tn.items, tn.pairs, tn.singles, tn.blk_first, tn.active, tn.meta, tn.units, (int)h->units_cap, tn.nbr};
     hipLaunchKernelGGL(k_sort_apply, dim3(n_pwg + SORT_UNIT_WGS), dim3(256), 0, h->stream, h->N, (size_t)h->Np, n_pwg, h->sort_key, h->sort_rank, h->sort_start,
                        h->tables[id_old].pid, pid_dst, tn.slot_of_pid, h->pinfo, tn.info, h->spare_frame(), h->frame(f), U);
     if (id_old == id_new) HIPCK(h, hipMemcpyAsync(tn.pid, h->sort_pid, sizeof(int) * h->Np, hipMemcpyDeviceToDevice, h->stream));
@@ -3312,7 +3324,7 @@ FeEngine* fe_create(const FeConfig* cfg) {
         h->items_cap = (nblk < (size_t)h->Np ? nblk : (size_t)h->Np) + (size_t)h->Np / 64 + 2;      // item_max >= 64
         h->units_cap = h->items_cap + (size_t)h->Np / WG + 16;                                      // work units: items (at worst one each) + tail workgroups, rounded up to 8
         if (dev_alloc(h, &h->sort_key, h->Np) || dev_alloc(h, &h->sort_rank, h->Np) || dev_alloc(h, &h->sort_cnt, ncell + 1) ||
-            dev_alloc(h, &h->sort_start, ncell + 1) || dev_alloc(h, &h->sort_bcnt, ((nblk + 1 + SORT_BLK_WG - 1) / SORT_BLK_WG) * SORT_BLK_WG) || dev_alloc(h, &h->sort_occ, nblk + 1, false) || dev_alloc(h, &h->sort_pid, h->Np) ||
+            dev_alloc(h, &h->sort_start, ncell + 1) || dev_alloc(h, &h->sort_bcnt, ((nblk + 1 + SORT_BLK_WG - 1) / SORT_BLK_WG) * SORT_BLK_WG) || dev_alloc(h, &h->sort_partial, ((nblk + 1 + SORT_BLK_WG - 1) / SORT_BLK_WG) * 8) || dev_alloc(h, &h->sort_occ, nblk + 1, false) || dev_alloc(h, &h->sort_pid, h->Np) ||
             dev_alloc(h, &h->slow_dev, 1) || dev_alloc(h, &h->frame_slow_dev, 1) || dev_alloc(h, &h->slab, h->items_cap * SLAB_N, false)) return fail("");
     }
     if (dev_alloc(h, &h->effs_dev, FE_MAX_EFF)) return fail("");
@@ -3353,7 +3365,7 @@ void fe_destroy(FeEngine* h) {
     smoke_destroy(h);
     for (auto& t : h->tables) { if (t.info && t.info != h->pinfo) (void)hipFree(t.info);
         for (void* q : {(void*)t.pairs, (void*)t.singles, (void*)t.pid, (void*)t.items, (void*)t.meta, (void*)t.blk_first, (void*)t.active, (void*)t.blk_slot, (void*)t.slot_of_pid, (void*)t.units, (void*)t.nbr}) if (q) (void)hipFree(q); }
-    void* ptrs[] = {h->frames, h->grads, h->sort_key, h->sort_rank, h->sort_cnt, h->sort_start, h->sort_bcnt, h->sort_occ, h->sort_pid, h->slow_dev, h->frame_slow_dev, h->gstore, h->gs_flag, h->gs_live, h->ent_touched, h->ent_dirty, h->cur_live, h->slab, h->effs_dev, h->pinfo, h->pool_idx, h->g_in, h->g_out, h->gg_out, h->gg_in,
+    void* ptrs[] = {h->frames, h->grads, h->sort_key, h->sort_rank, h->sort_cnt, h->sort_start, h->sort_bcnt, h->sort_partial, h->sort_occ, h->sort_pid, h->slow_dev, h->frame_slow_dev, h->gstore, h->gs_flag, h->gs_live, h->ent_touched, h->ent_dirty, h->cur_live, h->slab, h->effs_dev, h->pinfo, h->pool_idx, h->g_in, h->g_out, h->gg_out, h->gg_in,
                     h->blk_flag, h->blk_list, h->blk_count, h->err_dev, h->stage_r, h->stage_i, h->node_mark, h->counters,
                     h->tgt, h->chamfer, h->step_loss, h->body_start, h->body_pids, h->bodies_dev, h->statics_dev, h->collector_dev, h->hit_dev, h->hit_list, h->hit_count, h->node_work, h->node_work_count};
     for (float* v : h->statics_vox) if (v) (void)hipFree(v);

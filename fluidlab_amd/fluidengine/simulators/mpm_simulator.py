@@ -212,27 +212,41 @@ class MPMSimulator:
 
     def step_(self, action=None):
         """mpm:735-753: one ABI crossing for the n_substeps loop."""
-        is_none_action = action is None
-        if not is_none_action:
+        self.step_begin(action)
+        self.engine.step(*self.step_args(action))
+        self.step_end(action)
+
+    # step_ in three pieces, so that B simulators can share the middle one (fe_step_batch: optimizer/batch.py)
+    def step_args(self, action):
+        return self.cur_substep_local, self.cur_substep_global, self.n_substeps, action is not None
+
+    def step_begin(self, action):
+        if action is not None:
             self.agent.set_action(s=self.cur_step_local, s_global=self.cur_step_global, n_substeps=self.n_substeps, action=action)
         if self.smoke_field is not None:                    # smoke simulates at step level, not substep (mpm:744-747)
             self.smoke_field.step(s=self.cur_step_local, f=self.cur_substep_local)
-        self.engine.step(self.cur_substep_local, self.cur_substep_global, self.n_substeps, not is_none_action)
-        if not is_none_action:
+
+    def step_end(self, action):
+        if action is not None:
             self.last_move_f = self.cur_substep_local + self.n_substeps - 1        # Effector.latest_pos (effector.py:146-152)
         self.cur_substep_global += self.n_substeps
         assert self.cur_substep_global <= self.max_substeps_global
 
     def step_grad(self, action=None):
         """mpm:755-775"""
+        self.step_grad_begin()
+        self.engine.step_grad(*self.step_args(action))
+        self.step_grad_end(action)
+
+    def step_grad_begin(self):
         if self.cur_substep_local == 0:
             self.memory_from_cache()
-        is_none_action = action is None
         self.cur_substep_global -= self.n_substeps
-        self.engine.step_grad(self.cur_substep_local, self.cur_substep_global, self.n_substeps, not is_none_action)
+
+    def step_grad_end(self, action):
         if self.smoke_field is not None:                    # mpm:765-767
             self.smoke_field.step_grad(s=self.cur_step_local, f=self.cur_substep_local)
-        if not is_none_action:
+        if action is not None:
             self.agent.set_action_grad(s=self.cur_substep_local // self.n_substeps, s_global=self.cur_substep_global // self.n_substeps,
                                        n_substeps=self.n_substeps, action=action)
 
