@@ -233,7 +233,15 @@ __device__ __forceinline__ float sel3(int i, float a, float b, float c) { return
 // Workgroups are dealt round-robin to the 8 XCDs (workgroup id % 8), each with its own L2.  Work items are sorted by
 // block, and neighbouring blocks share tile halos and slabs, so workgroup `wg` takes item (wg % 8) * per + wg / 8:
 // every XCD gets one contiguous eighth of the list.  A bijection on [0, 8 * per); ids >= n_work are skipped.
-__device__ __forceinline__ int xcd_item(int wg, int per, int on) { return on ? (wg & 7) * per + (wg >> 3) : wg; }
+// `mode` (option "xcd_map"): 0 = none (unit = slot: consecutive units on consecutive XCDs), 1 = contiguous eighths, k >= 2 = blocked-
+// cyclic: runs of k consecutive units per XCD, the runs dealt round-robin.  Contiguous eighths keep the most neighbours together but
+// hand whole regions -- the dense core of a splash, all the two-item pairs at the head of the list -- to single XCDs.
+__device__ __forceinline__ int xcd_item(int wg, int per, int mode) {
+    if (mode == 0) return wg;
+    const int x = wg & 7, j = wg >> 3;
+    if (mode == 1) return x * per + j;
+    return ((j / mode) * 8 + x) * mode + j % mode;
+}
 #define STW(st, i, d) sel3((i), (st).w[0][d], (st).w[1][d], (st).w[2][d])
 
 // -----------------------------------------------------------------------------------------
@@ -2215,7 +2223,8 @@ __device__ __forceinline__ void build_units_dev(int gtid, int nth, int nb, int N
                                                 int* meta, Unit* units, int units_cap, int2* nbr) {
     const int tail_start = meta[1], nM = meta[3], nS = meta[4], n_active = meta[2];
     const int n_pairs = nM + ((nS + 1) >> 1), n_tail = (N - tail_start + WG - 1) / WG;
-    const int n_work = n_pairs + n_tail, per_xcd = (n_work + 7) >> 3;
+    const int n_work = n_pairs + n_tail;
+    const int per_xcd = xcd_on >= 2 ? (((n_work + xcd_on - 1) / xcd_on + 7) >> 3) * xcd_on : (n_work + 7) >> 3;      // slots per XCD
     const int n_slots = per_xcd * 8 < units_cap ? per_xcd * 8 : units_cap;      // (units_cap covers the worst case)
     if (gtid == 0) meta[5] = n_slots;
     for (int w = gtid; w < n_slots; w += nth) {
@@ -3304,7 +3313,7 @@ FeEngine* fe_create(const FeConfig* cfg) {
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
     h->own_stream = h->stream;
     SimP& S = h->S;
-    S.xcd = 1;
+    S.xcd = 16;                                            // blocked-cyclic unit mapping (A/B in DESIGN.md section 6)
     S.wt = 5;                                              // p2g and g2p_grad: their bulk stores come early (A/B in DESIGN.md section 6)
     S.N = h->N; S.Np = h->Np; S.n = h->n; S.nb = h->nb; S.ncell = h->nb * h->nb * h->nb * 64;
     S.dx = 1.0f / (float)h->n; S.inv_dx = (float)h->n; S.dt = cfg->dt;
@@ -3322,7 +3331,7 @@ FeEngine* fe_create(const FeConfig* cfg) {
     {
         const size_t nblk = (size_t)h->nb * h->nb * h->nb;
         h->items_cap = (nblk < (size_t)h->Np ? nblk : (size_t)h->Np) + (size_t)h->Np / 64 + 2;      // item_max >= 64
-        h->units_cap = h->items_cap + (size_t)h->Np / WG + 16;                                      // work units: items (at worst one each) + tail workgroups, rounded up to 8
+        h->units_cap = h->items_cap + (size_t)h->Np / WG + 16 + 1024;                                      // work units: items (at worst one each) + tail workgroups, rounded up to 8
         if (dev_alloc(h, &h->sort_key, h->Np) || dev_alloc(h, &h->sort_rank, h->Np) || dev_alloc(h, &h->sort_cnt, ncell + 1) ||
             dev_alloc(h, &h->sort_start, ncell + 1) || dev_alloc(h, &h->sort_bcnt, ((nblk + 1 + SORT_BLK_WG - 1) / SORT_BLK_WG) * SORT_BLK_WG) || dev_alloc(h, &h->sort_partial, ((nblk + 1 + SORT_BLK_WG - 1) / SORT_BLK_WG) * 8) || dev_alloc(h, &h->sort_occ, nblk + 1, false) || dev_alloc(h, &h->sort_pid, h->Np) ||
             dev_alloc(h, &h->slow_dev, 1) || dev_alloc(h, &h->frame_slow_dev, 1) || dev_alloc(h, &h->slab, h->items_cap * SLAB_N, false)) return fail("");
@@ -3422,7 +3431,7 @@ int fe_set_option(FeEngine* h, const char* name, double value) {
         h->collide_type = t; return 0;
     }
     if (!std::strcmp(name, "prof_fine")) { h->prof_fine = value != 0; return 0; }
-    if (!std::strcmp(name, "xcd_map")) { h->S.xcd = value != 0; return 0; }
+    if (!std::strcmp(name, "xcd_map")) { if (value < 0) FAIL(h, "xcd_map must be >= 0"); h->S.xcd = (int)value; return 0; }
     if (!std::strcmp(name, "write_through")) { h->S.wt = (int)value; return 0; }
     if (!std::strcmp(name, "wgrid_cap")) { if (value < 64) { h->err = "wgrid_cap must be >= 64"; return 1; } h->wgrid_cap = (int)value; return 0; }
     if (!std::strcmp(name, "threads")) return 0;             // oracle-only tunable
