@@ -373,7 +373,9 @@ def run_replicas(args, rank, local_rank, world):
         tgt = Recorder(rec).record(write=False)
         rec.taichi_env.simulator.engine.close()                      # its resident trajectory is tens of GB: free it before the replica is built
         del rec
-        env = make('LatteArt-v0', seed=1000 + rank, loss=True, target=tgt, **kw)      # injector randomness differs per rank
+        B = max(1, args.envs_per_gpu)
+        envs = [make('LatteArt-v0', seed=1000 + rank * B + i, loss=True, target=tgt, **kw) for i in range(B)]      # injector randomness differs per replica
+        env = envs[0]
     cfg = load_config('configs/exp_latteart.yaml').SOLVER
     # 128^3 sits at the stability edge of the reference's fixed dt: the Adam step is kept small so that W + K
     # passes stay in the stable regime.  Gradient, collective and update are the real ones.
@@ -383,13 +385,24 @@ def run_replicas(args, rank, local_rank, world):
     policy = env.trainable_policy(cfg.optim, cfg.init_range)
     init = env.taichi_env.get_state()
     eng = env.taichi_env.simulator.engine
-    sub = env.horizon * env.taichi_env.simulator.n_substeps           # substep pairs per pass
+    n_frames = env.horizon * env.taichi_env.simulator.n_substeps      # substeps of one replica's trajectory
+    sub = B * n_frames                                                # substep pairs per pass and rank (all B replicas)
+    batch = None
+    if B > 1:                                                         # the rank's replicas share every launch (optimizer/batch.py)
+        from fluidlab_amd.optimizer.batch import EnvBatch
+        batch = EnvBatch(envs)
+        inits = [e.taichi_env.get_state()['state'] for e in envs]
     t_comp, t_coll, losses, skipped = [], [], [], [0]
 
     def one_pass():
         a = time.perf_counter()
         with quiet():
-            info, g_local = solver.forward_backward(init['state'], policy, env.horizon, env.horizon_action)   # agent.get_grad inside
+            if batch is None:
+                info, g_local = solver.forward_backward(init['state'], policy, env.horizon, env.horizon_action)   # agent.get_grad inside
+            else:                                                     # the mean over the rank's replicas; the all-reduce then averages the ranks
+                res = batch.forward_backward(inits, [policy] * B, env.horizon, env.horizon_action)
+                info = dict(res[0][0]); info['loss'] = float(np.mean([r[0]['loss'] for r in res]))
+                g_local = np.mean([r[1] for r in res], axis=0)
         b = time.perf_counter()
         g_mean, (loss_mean,) = par.all_reduce_mean(g_local, [info['loss']])      # the path's one exchange
         c = time.perf_counter()
@@ -412,8 +425,8 @@ def run_replicas(args, rank, local_rank, world):
         for k in range(2):
             eng.sync(); a = time.perf_counter()
             with quiet():
-                solver.forward_backward(init['state'], policy, env.horizon, env.horizon_action)
-            eng.sync(); n1_rate = sub / (time.perf_counter() - a)
+                solver.forward_backward(init['state'], policy, env.horizon, env.horizon_action)      # ONE replica, as `--gpus 1 --replicas` would run it
+            eng.sync(); n1_rate = sub / B / (time.perf_counter() - a)
     barrier()
     for _ in range(args.warmup):
         one_pass()
@@ -430,7 +443,7 @@ def run_replicas(args, rank, local_rank, world):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall_max = float(t.item())
     rss_gb = host_rss_gb()
-    hbm_gb = eng.get_stats(sub - 1)['bytes_state'] / 2**30
+    hbm_gb = sum(e.taichi_env.simulator.engine.get_stats(n_frames - 1)['bytes_state'] for e in envs) / 2**30
     import hashlib
     dig = hashlib.sha256(np.ascontiguousarray(policy.comp_actions, dtype=np.float64).tobytes()).digest()      # the policy after the last Adam step
     h_lo, h_hi = float(int.from_bytes(dig[:4], 'little')), float(int.from_bytes(dig[4:8], 'little'))
@@ -448,7 +461,7 @@ def run_replicas(args, rank, local_rank, world):
         dist.all_reduce(probe)
     torch.cuda.synchronize()
     ar_us = 1e6 * (time.perf_counter() - p0) / 50
-    st = eng.get_stats(sub - 1)
+    st = eng.get_stats(n_frames - 1)
     if rank == 0:
         per_rank = [float(a[0]) for a in allr]
         value = world * sub * args.steps / wall_max
@@ -461,7 +474,8 @@ def run_replicas(args, rank, local_rank, world):
                                    'one per GPU: one step = one Solver pass (forward with loss, backward, action-gradient all-reduce, Adam)',
                        'substep_pairs_per_step_per_rank': sub, 'rccl_world_size': dist.get_world_size(), 'dist_backend': args.dist_backend,
                        'action_grad_shape': [env.horizon_action + 1, 3], 'lr_scale': args.c4_lr_scale,
-                       'parallelism': f'{world} env replicas, one per GPU, 1 all-reduce of the action gradient per pass'},
+                       'envs_per_gpu': B,
+                       'parallelism': f'{world * B} env replicas, {B} per GPU' + (' sharing launches (fe_step_batch)' if B > 1 else '') + ', 1 all-reduce of the action gradient per pass'},
             'n1_same_scene_pairs_per_s': round(n1_rate, 1),
             'scaling_efficiency': round(value / (world * n1_rate), 4) if n1_rate > 0 else None,
             'per_rank_pairs_per_s_compute_only': [round(v, 1) for v in per_rank],
@@ -478,7 +492,8 @@ def run_replicas(args, rank, local_rank, world):
         }
         print(json.dumps(out))
     par.barrier()
-    eng.close()
+    for e in envs:
+        e.taichi_env.simulator.engine.close()
     par.close()
 
 
@@ -520,6 +535,7 @@ def main():
     ap.add_argument('--replicas', action='store_true', help='run the N > 1 workload (LatteArt replicas + all-reduce) even with one rank')
     ap.add_argument('--c4-scene', default='config3', choices=sorted(C4_SCENES))
     ap.add_argument('--c4-lr-scale', type=float, default=0.1)
+    ap.add_argument('--envs-per-gpu', type=int, default=1, help='N > 1 workload: B replicas per rank stepped in lockstep through fe_step_batch (they have to fit the HBM: the config-3 scene keeps ~150 GB per replica resident)')
     ap.add_argument('--opt', action='append', default=[], help='engine option name=value (tuning sweeps, N=1)')
     args = ap.parse_args()
     world = int(os.environ.get('WORLD_SIZE', '1'))

@@ -71,3 +71,16 @@ def test_bench_gpus_2_over_rccl_when_the_box_has_two_gpus():
     assert out['value'] > 0 and out['passes_skipped_nonfinite_grad'] == 0
     assert out['actions_identical_across_ranks'] is True
     assert out['n1_same_scene_pairs_per_s'] > 0 and 0.2 < out['scaling_efficiency'] <= 1.1
+
+
+@pytest.mark.gpu
+def test_bench_replicas_with_two_envs_per_gpu():
+    """`--envs-per-gpu 2`: the rank's two replicas step in lockstep through fe_step_batch (optimizer/batch.py), their gradients are
+    averaged before the rank's all-reduce.  One rank over RCCL, the reference's own 64^3 scene (two of them fit the HBM resident)."""
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--replicas', '--envs-per-gpu', '2', '--steps', '1', '--warmup', '1', '--c4-scene', 'as_shipped']
+    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert out['config']['envs_per_gpu'] == 2 and out['config']['substep_pairs_per_step_per_rank'] == 6600
+    assert out['value'] > 0 and out['passes_skipped_nonfinite_grad'] == 0 and out['loss_mean_over_envs'][0] > 0
+    assert out['scaling_efficiency'] >= 0.9        # two replicas per launch are no slower per replica than one alone (measured ~1.2)

@@ -317,3 +317,15 @@ def test_gathering_o_on_the_gpu(hiplib, oracle32, oracle64):
     assert abs(la - lb) <= 1e-6 * abs(lb)                                    # measured 2.6e-8
     assert S.cosine(ga, gb) >= 0.97                                          # measured 0.9899
     _grad_no_worse_than_fp32_oracle('gathering_o', ga, gb, gc, 0.02)
+
+
+def test_env_batch_on_the_gpu(hiplib):
+    """The same on the HIP engine, where the batch really shares launches (gridDim.y = 2): each replica within fp32 atomics noise of
+    the run it makes alone."""
+    import test_host_env as H
+    env = H.make('LatteArt-v0', seed=0, loss=False, engine_lib=hiplib, **H.MINI)
+    tgt = Recorder(env).record(write=False)
+    single, batch = H._batch_vs_single(hiplib, tgt)
+    for (ia, ga), (ib, gb) in zip(single, batch):
+        assert abs(ia['loss'] - ib['loss']) <= 1e-5 * abs(ia['loss'])
+        assert S.cosine(ga, gb) >= 0.999999 and S.rel_l2(ga, gb) <= 1e-4

@@ -43,6 +43,35 @@ def test_record_then_optimise(oracle32, mini_target):
     assert losses[0] > losses[1] > losses[2] > 0
 
 
+def _batch_vs_single(lib, mini_target, seeds=(3, 4)):
+    """EnvBatch.forward_backward over two replicas (own injector noise) against Solver.forward_backward on each of them alone."""
+    from fluidlab_amd.optimizer.batch import EnvBatch
+
+    def build(seed):
+        env = make('LatteArt-v0', seed=seed, loss=True, target=mini_target, engine_lib=lib, **MINI)
+        np.random.seed(0)                                         # the same initial policy for every replica
+        pol = env.trainable_policy(_cfg().optim, _cfg().init_range)
+        pol.actions_v[:] = np.random.RandomState(4).uniform(-0.004, 0.004, pol.actions_v.shape)
+        return env, pol
+
+    single = []
+    for sd in seeds:
+        env, pol = build(sd)
+        single.append(Solver(env, None, _cfg()).forward_backward(env.taichi_env.get_state()['state'], pol, env.horizon, env.horizon_action))
+    envs, pols = zip(*[build(sd) for sd in seeds])
+    batch = EnvBatch(envs).forward_backward([e.taichi_env.get_state()['state'] for e in envs], pols, envs[0].horizon, envs[0].horizon_action)
+    return single, batch
+
+
+def test_env_batch_equals_environments_stepped_alone(oracle64, mini_target):
+    """optimizer/batch.py: B environments through ONE engine call per step (fe_step_batch) give each environment exactly what it gets
+    alone -- loss, action gradient -- and the replicas differ (their injector noise does)."""
+    single, batch = _batch_vs_single(oracle64, mini_target)
+    for (ia, ga), (ib, gb) in zip(single, batch):
+        assert ia['loss'] == ib['loss'] and np.array_equal(ga, gb)
+    assert single[0][0]['loss'] != single[1][0]['loss'] and np.abs(batch[0][1]).max() > 0
+
+
 def test_chunked_checkpointing_equals_resident_trajectory(oracle64, mini_target, tmp_path, monkeypatch):
     """mpm:777-912: backward through 20-substep chunks (checkpoint + re-forward) must give the gradient of the
     whole-trajectory-resident mode."""
