@@ -13,7 +13,10 @@ import collections
 import csv
 import json
 import math
+import os
 import sys
+
+OUT = os.environ.get('PROFILE_OUT', 'profiles')          # (on the GPU box: a directory under gpurun_out/, copied into profiles/ afterwards)
 
 CHUNK = 100
 BENCH_NAME = [('k_p2g_grad', 'p2g_grad'), ('k_g2p_grad', 'g2p_grad'), ('k_grid_grad', 'grid_op_grad'), ('k_p2g<true', 'p2g'), ('k_p2g<false', 'p2g_recompute'),
@@ -69,7 +72,7 @@ def stats(tag, path, steps, warmup):
             if a <= w < b:
                 dur[r['Kernel_Name']].append(int(r['End_Timestamp']) - int(r['Start_Timestamp']))
         total = sum(sum(v) for v in dur.values()) or 1
-        out = f'profiles/{tag}_kernel_stats_{ph}.csv'
+        out = f'{OUT}/{tag}_kernel_stats_{ph}.csv'
         with open(out, 'w', newline='') as f:
             wr = csv.writer(f, quoting=csv.QUOTE_NONNUMERIC)
             wr.writerow(['Name', 'Calls', 'TotalDurationNs', 'AverageNs', 'Percentage', 'MinNs', 'MaxNs', 'StdDev'])
@@ -117,7 +120,7 @@ def pmc(tag, steps, warmup, paths):
                 e['traffic_bytes'] = int((2 * e['FETCH_SIZE_KB'] + e['WRITE_SIZE_KB']) * 1024)
             d['kernels'][bn] = e
         out[ph] = d
-    json.dump(out, open(f'profiles/{tag}_pmc_traffic.json', 'w'), indent=1)
+    json.dump(out, open(f'{OUT}/{tag}_pmc_traffic.json', 'w'), indent=1)
     print(json.dumps({ph: {k: v.get('traffic_bytes') for k, v in out[ph]['kernels'].items()} for ph in per}, indent=1))
 
 
