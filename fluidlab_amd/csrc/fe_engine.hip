@@ -1204,25 +1204,7 @@ __device__ __forceinline__ void pose_flush(const AgentP& agent, int f) {
     __syncthreads();
 }
 
-// v_out of this half's tile into s_tile3 (3 planes), from the working grid or from the forward pass' store (blocks addressed
-// through the order's blk_slot)
-__device__ __forceinline__ void g2p_grad_load_tile(const TileO& to, const SimP& S, const TableP& T, const float4* __restrict__ g_out,
-                                                   const float4* __restrict__ st, const PairCtx& pc) {
-    if (!pc.live) return;
-    const int tofs = pc.ti * 3 * TILE_N;
-    for (int l = pc.t0; l < TILE_N; l += pc.nth) {
-        int i, j, k;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tile_node(to, l, S.n, i, j, k)) {
-            if (st) {
-                const int slot = T.blk_slot[(((i >> 2) * S.nb) + (j >> 2)) * S.nb + (k >> 2)];
-                if (slot >= 0) v = st[(size_t)slot * 128 + 64 + (((i & 3) << 4) | ((j & 3) << 2) | (k & 3))];
-            } else v = g_out[cell_addr(i, j, k, S.nb)];
-        }
-        s_tile3[tofs + l] = v.x; s_tile3[tofs + TILE_N + l] = v.y; s_tile3[tofs + 2 * TILE_N + l] = v.z;
-    }
-}
-
+__device__ __forceinline__ void g2p_grad_load_tile2(const TileO& to, const SimP& S, const float4* __restrict__ g_out, const float4* __restrict__ st, int nbr_entry, const PairCtx& pc);
 __device__ __forceinline__ void g2p_grad_body(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T,
                                                  const float4* __restrict__ g_out, float* gg_out, float4* slab, int* slow,
                                                  GridStore GS, int f, AgentP agent) {
@@ -1248,7 +1230,7 @@ __device__ __forceinline__ void g2p_grad_body(SimP S, float* fr_cur, float* Gn_,
             const int nbr_entry = neighbour_entry(T.blk_slot, S.nb, it.x);
             const int u0 = cur.used[s];
             const float4 a00 = cur.A0[s];
-            g2p_grad_load_tile(to, S, T, g_out, V.store, pc);
+            g2p_grad_load_tile2(to, S, g_out, V.store, nbr_entry, pc);        // (through the 27 neighbour entries: one hop)
             if (pc.live) for (int l = pc.t0; l < 3 * TILE_N; l += pc.nth) s_acc3[tofs + l] = 0.0;
             __syncthreads();
             TL(S, 2);
@@ -2135,11 +2117,11 @@ __global__ __launch_bounds__(256) void k_sort_blk_final(int nblk, int ncell, int
 #pragma unroll
         for (int k = 0; k < 6; k++) { const int t = partial[w * 8 + k]; pa.v[k] += t; if (w < (int)blockIdx.x) pb.v[k] += t; }
     }
+    int n[4], ex[6], tot[6];
+    const BlkSums m = blk_load4(nblk, ITEM_MAX, loose_max, bcnt, n);
     int exb[6], before[6], exa[6], total[6];
     wg_scan6(pb, sh, exb, before);
     wg_scan6(pa, sh, exa, total);
-    int n[4], ex[6], tot[6];
-    const BlkSums m = blk_load4(nblk, ITEM_MAX, loose_max, bcnt, n);
     wg_scan6(m, sh, ex, tot);
     if (blockIdx.x == 0 && tid == 0) { meta[0] = total[2]; meta[1] = total[0]; meta[2] = 0; meta[3] = total[3]; meta[4] = total[4]; meta[6] = total[5]; meta[7] = total[0] + total[1]; }
     const int b0 = blockIdx.x * SORT_BLK_WG + tid * 4;
@@ -2258,11 +2240,13 @@ __global__ __launch_bounds__(256) void k_build_units(int nb, int N, int xcd_on, 
 // all 25 planes.  Reads are coalesced, writes land near s (the old order was sorted too: particles move less than a cell between
 // sorts), so the write combining of the L2 sees them almost in order.  (Round 1: index kernel, copy of the id table, gather kernel.)
 #define SORT_UNIT_WGS 128
-struct UnitsArgs { int* bcnt; int nb, xcd_on; const int4* items; const int2* pairs; const int* singles; const int2* blk_first; const int* active; int* meta; Unit* units; int units_cap; int2* nbr; };
+struct UnitsArgs { int* bcnt; int* meta_host; int nb, xcd_on; const int4* items; const int2* pairs; const int* singles; const int2* blk_first; const int* active; int* meta; Unit* units; int units_cap; int2* nbr; };
 __global__ __launch_bounds__(256) void k_sort_apply(int N, size_t Np, int n_pwg, const int* __restrict__ key, const int* __restrict__ rank,
                                                     const int* __restrict__ start, const int* __restrict__ pid_old, int* pid_new, int* slot_of_pid,
                                                     const float4* __restrict__ pinfo, float4* info_new, float* dst_, float* src_, UnitsArgs U) {
     if ((int)blockIdx.x >= n_pwg) {          // (independent of the permutation: both only need what the scan and k_sort_fill left)
+        // the order's item and dense-particle counts for the host's heuristics (g2p_grad_split): plain stores into mapped host memory
+        if ((int)blockIdx.x == n_pwg && threadIdx.x < 2 && U.meta_host) U.meta_host[threadIdx.x] = U.meta[threadIdx.x];
         for (int i = (blockIdx.x - n_pwg) * 256 + threadIdx.x; i <= U.nb * U.nb * U.nb; i += SORT_UNIT_WGS * 256) U.bcnt[i] = 0;      // block counts: ready for the next sort
         build_units_dev((blockIdx.x - n_pwg) * 256 + threadIdx.x, SORT_UNIT_WGS * 256, U.nb, N, U.xcd_on, U.items, U.pairs, U.singles, U.blk_first, U.active, U.meta,
                         U.units, U.units_cap, U.nbr);
@@ -2684,7 +2668,7 @@ struct FeEngine {
     float* grad_ptr[3] = {nullptr, nullptr, nullptr};
     // particle orders ("tables"): id 0 = identity; id 1+f = order produced by the sort at frame f
     struct Table { int* pid = nullptr; float4* info = nullptr; int2* pairs = nullptr; int* singles = nullptr; int4* items = nullptr; int* meta = nullptr; int2* blk_first = nullptr; int* active = nullptr; int* blk_slot = nullptr; int* slot_of_pid = nullptr; Unit* units = nullptr; int2* nbr = nullptr; };
-    int* meta_host = nullptr;                               // pinned: the meta words of every order, copied after its sort (never waited for: heuristics only)
+    int* meta_host = nullptr; int* meta_host_dev = nullptr; // mapped pinned memory: (items, dense particles) of every order, written by its sort (never waited for: heuristics only)
     int loose_max = 0;                                      // blocks with <= this many particles get no work item (option "loose_max")
     std::vector<int> gs_host; bool gs_host_valid = false;   // host copy of gs_flag, refreshed once per backward sweep
     float4* gstore = nullptr; int* gs_flag = nullptr; int gs_cap = 0;     // forward grid store (see GridStore)
@@ -2930,12 +2914,11 @@ int sort_frame(FeEngine* h, int f) {
     if (fine) { prof_end(h); prof_begin(h, KID_SORT_PERM); }
     // re-sorting a frame that is already in this table's order reads the id table it rewrites: stage it
     int* pid_dst = id_old == id_new ? h->sort_pid : tn.pid;
-    const UnitsArgs U = {h->sort_bcnt, h->nb, h->S.xcd, tn.items, tn.pairs, tn.singles, tn.blk_first, tn.active, tn.meta, tn.units, (int)h->units_cap, tn.nbr};
+    const UnitsArgs U = {h->sort_bcnt, h->meta_host_dev ? h->meta_host_dev + (size_t)id_new * 8 : nullptr, h->nb, h->S.xcd, tn.items, tn.pairs, tn.singles, tn.blk_first, tn.active, tn.meta, tn.units, (int)h->units_cap, tn.nbr};
     hipLaunchKernelGGL(k_sort_apply, dim3(n_pwg + SORT_UNIT_WGS), dim3(256), 0, h->stream, h->N, (size_t)h->Np, n_pwg, h->sort_key, h->sort_rank, h->sort_start,
                        h->tables[id_old].pid, pid_dst, tn.slot_of_pid, h->pinfo, tn.info, h->spare_frame(), h->frame(f), U);
     if (id_old == id_new) HIPCK(h, hipMemcpyAsync(tn.pid, h->sort_pid, sizeof(int) * h->Np, hipMemcpyDeviceToDevice, h->stream));
     prof_end(h);
-    if (h->meta_host) (void)hipMemcpyAsync(h->meta_host + (size_t)id_new * 8, tn.meta, sizeof(int) * 8, hipMemcpyDeviceToHost, h->stream);
     std::swap(h->frame_ptr[f], h->spare_frame());
     h->tbl_of_frame[f] = id_new;
     return 0;
@@ -3360,7 +3343,9 @@ FeEngine* fe_create(const FeConfig* cfg) {
         if (hipMemcpyOnStream(h, h->tables[0].pid, id.data(), sizeof(int) * h->Np, hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy failed");
         if (hipMemcpyOnStream(h, h->tables[0].slot_of_pid, id.data(), sizeof(int) * h->Np, hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy failed");
     }
-    if (hipHostMalloc((void**)&h->meta_host, sizeof(int) * 8 * (h->L + 2)) == hipSuccess) std::memset(h->meta_host, 0, sizeof(int) * 8 * (h->L + 2)); else h->meta_host = nullptr;
+    if (hipHostMalloc((void**)&h->meta_host, sizeof(int) * 8 * (h->L + 2), hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer((void**)&h->meta_host_dev, h->meta_host, 0) == hipSuccess)
+        std::memset(h->meta_host, 0, sizeof(int) * 8 * (h->L + 2));
+    else { if (h->meta_host) (void)hipHostFree(h->meta_host); h->meta_host = nullptr; h->meta_host_dev = nullptr; }
     if (hipEventCreate(&h->ev_t0) != hipSuccess || hipEventCreate(&h->ev_t1) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_batch, hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate failed");
     if (hipStreamSynchronize(h->stream) != hipSuccess) return fail("device initialisation failed");
