@@ -1280,7 +1280,7 @@ __global__ __launch_bounds__(WG, 4) void k_g2p_grad_b(Batch<G2PGradArgs> B) { co
 
 
 // -----------------------------------------------------------------------------------------
-// k_g2p_grad2 (option "g2p_grad_v", default): the same adjoint with the 27-node loop split in two, each half unrolled completely.
+// k_g2p_grad2 (option "g2p_grad_v", default): the same adjoint with the 27-node loop split in two passes.
 // Round 2's kernel gathers (v_out -> the position adjoint) and scatters (three scanned values -> d v_out) in ONE loop; unrolled it
 // needs 650 B of scratch per lane, so it stayed a rolled 9 x 3 loop with register selects of the weights -- 7.8 us of the
 // workgroup's 11.7 at C2, where k_g2p's gather takes 1.5 and k_p2g's four-value scatter 4.9.  Here the gather pass runs first (tile
@@ -1324,34 +1324,39 @@ __device__ __forceinline__ void g2p_grad_particle2(const SimP& S, const FrameV& 
         qb[a] = (g.v[a] + S.dt * g.x[a]) - (qx[a] * st.fx[0] + qy[a] * st.fx[1] + qz[a] * st.fx[2]);
     }
     const int l0 = tofs + lb;
+    // MINW = 4: the x offset of the stencil stays a rolled loop of three (nine nodes unrolled inside it, the x weights by register
+    // select): the completely unrolled passes need 166 registers, this form fits the 128 of four waves per SIMD
     {   // ---- pass 1: gather.  gfx_d = sum_o dW/df_d (v_o . q_o),  nvw = sum_o W v_o
         const float dwz[3] = {stencil_dw(st, 0, 2), stencil_dw(st, 1, 2), stencil_dw(st, 2, 2)};      // (the x and y ones are one VALU each: made where used)
         float gfx[3] = {0.f, 0.f, 0.f}, nvw[3] = {0.f, 0.f, 0.f};
+#pragma unroll(MINW >= 4 ? 1 : 3)
+        for (int i = 0; i < 3; i++) {
+            const float wi = MINW >= 4 ? STW(st, i, 0) : st.w[i][0], dwi = stencil_dw(st, i, 0);
 #pragma unroll
-        for (int ij = 0; ij < 9; ij++) {
-            const int i = ij / 3, j = ij - 3 * i;
-            float qij[3];
+            for (int j = 0; j < 3; j++) {
+                float qij[3];
 #pragma unroll
-            for (int a = 0; a < 3; a++) qij[a] = qb[a] + (float)i * qx[a] + (float)j * qy[a];
-            float T = 0.f, Tz = 0.f, P[3] = {0.f, 0.f, 0.f};
+                for (int a = 0; a < 3; a++) qij[a] = qb[a] + (float)i * qx[a] + (float)j * qy[a];
+                float T = 0.f, Tz = 0.f, P[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kk = 0; kk < 3; kk++) {
-                const int l = l0 + (i * TILE_T + j) * TILE_T + kk;
-                const float v0 = s_tile3[l], v1 = s_tile3[TILE_N + l], v2 = s_tile3[2 * TILE_N + l];
-                const float sdot = v0 * (qij[0] + (float)kk * qz[0]) + v1 * (qij[1] + (float)kk * qz[1]) + v2 * (qij[2] + (float)kk * qz[2]);
-                const float wk = st.w[kk][2];
-                T += wk * sdot; Tz += dwz[kk] * sdot;
-                P[0] += wk * v0; P[1] += wk * v1; P[2] += wk * v2;
+                for (int kk = 0; kk < 3; kk++) {
+                    const int l = l0 + (i * TILE_T + j) * TILE_T + kk;
+                    const float v0 = s_tile3[l], v1 = s_tile3[TILE_N + l], v2 = s_tile3[2 * TILE_N + l];
+                    const float sdot = v0 * (qij[0] + (float)kk * qz[0]) + v1 * (qij[1] + (float)kk * qz[1]) + v2 * (qij[2] + (float)kk * qz[2]);
+                    const float wk = st.w[kk][2];
+                    T += wk * sdot; Tz += dwz[kk] * sdot;
+                    P[0] += wk * v0; P[1] += wk * v1; P[2] += wk * v2;
+                }
+                const float wiwj = wi * st.w[j][1];
+                gfx[0] += (dwi * st.w[j][1]) * T;
+                gfx[1] += (wi * stencil_dw(st, j, 1)) * T;
+                gfx[2] += wiwj * Tz;
+#pragma unroll
+                for (int a = 0; a < 3; a++) nvw[a] += wiwj * P[a];
+                // the running sums are pinned here: otherwise the (pure) arithmetic sinks towards its use behind the loop while the 81 tile
+                // reads stay where they are, and every tile value is live at once (650 B of scratch per lane)
+                asm volatile("" : "+v"(gfx[0]), "+v"(gfx[1]), "+v"(gfx[2]), "+v"(nvw[0]), "+v"(nvw[1]), "+v"(nvw[2]));
             }
-            const float wiwj = st.w[i][0] * st.w[j][1];
-            gfx[0] += (stencil_dw(st, i, 0) * st.w[j][1]) * T;
-            gfx[1] += (st.w[i][0] * stencil_dw(st, j, 1)) * T;
-            gfx[2] += wiwj * Tz;
-#pragma unroll
-            for (int a = 0; a < 3; a++) nvw[a] += wiwj * P[a];
-            // the running sums are pinned here: otherwise the (pure) arithmetic sinks towards its use behind the loop while the 81 tile
-            // reads stay where they are, and every tile value is live at once (650 B of scratch per lane)
-            asm volatile("" : "+v"(gfx[0]), "+v"(gfx[1]), "+v"(gfx[2]), "+v"(nvw[0]), "+v"(nvw[1]), "+v"(nvw[2]));
         }
         // sum_o W c4 (v_o^T gC)_b = (nvw^T c4 gC)_b enters with dpos_b = o_b - fx_b
         gfx[0] -= nvw[0] * qx[0] + nvw[1] * qx[1] + nvw[2] * qx[2];
@@ -1364,29 +1369,30 @@ __device__ __forceinline__ void g2p_grad_particle2(const SimP& S, const FrameV& 
     const SegScan sc = seg_setup(live ? lb : (0x40000000 | (int)threadIdx.x));       // (only now: five registers less across pass 1)
     const bool issue = sc.tail && live;
     const float livef = live ? 1.f : 0.f;
-    const int la = l0;
+#pragma unroll(MINW >= 4 ? 1 : 3)
+    for (int i = 0; i < 3; i++) {
+        const float lwi = livef * (MINW >= 4 ? STW(st, i, 0) : st.w[i][0]);
 #pragma unroll
-    for (int ij = 0; ij < 9; ij++) {
-        const int i = ij / 3, j = ij - 3 * i;
-        const float lw = livef * (st.w[i][0] * st.w[j][1]);
-        float qij[3];
+        for (int j = 0; j < 3; j++) {
+            const float lw = lwi * st.w[j][1];
+            float qij[3];
 #pragma unroll
-        for (int a = 0; a < 3; a++) qij[a] = qb[a] + (float)i * qx[a] + (float)j * qy[a];
+            for (int a = 0; a < 3; a++) qij[a] = qb[a] + (float)i * qx[a] + (float)j * qy[a];
 #pragma unroll
-        for (int kk = 0; kk < 3; kk++) {
-            const float weight = lw * st.w[kk][2];
-            float c0 = weight * (qij[0] + (float)kk * qz[0]), c1 = weight * (qij[1] + (float)kk * qz[1]), c2 = weight * (qij[2] + (float)kk * qz[2]);
-            seg_scan3(sc, c0, c1, c2);
-            if (issue) {
-                const int l = la + (i * TILE_T + j) * TILE_T + kk;
-                atomicAdd(&s_acc3[l], (double)c0);                        // ds_add_f64
-                atomicAdd(&s_acc3[TILE_N + l], (double)c1);
-                atomicAdd(&s_acc3[2 * TILE_N + l], (double)c2);
+            for (int kk = 0; kk < 3; kk++) {
+                const float weight = lw * st.w[kk][2];
+                float c0 = weight * (qij[0] + (float)kk * qz[0]), c1 = weight * (qij[1] + (float)kk * qz[1]), c2 = weight * (qij[2] + (float)kk * qz[2]);
+                seg_scan3(sc, c0, c1, c2);
+                if (issue) {
+                    const int l = l0 + (i * TILE_T + j) * TILE_T + kk;
+                    atomicAdd(&s_acc3[l], (double)c0);                        // ds_add_f64
+                    atomicAdd(&s_acc3[TILE_N + l], (double)c1);
+                    atomicAdd(&s_acc3[2 * TILE_N + l], (double)c2);
+                }
             }
         }
     }
 }
-
 template <int MINW>
 __device__ __forceinline__ void g2p_grad2_body(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T,
                                                   const float4* __restrict__ g_out, float* gg_out, float4* slab, int* slow,
@@ -2251,13 +2257,11 @@ __global__ __launch_bounds__(256) void k_build_units(int nb, int N, int xcd_on, 
 // all 25 planes.  Reads are coalesced, writes land near s (the old order was sorted too: particles move less than a cell between
 // sorts), so the write combining of the L2 sees them almost in order.  (Round 1: index kernel, copy of the id table, gather kernel.)
 #define SORT_UNIT_WGS 128
-struct UnitsArgs { int* bcnt; int* meta_host; int nb, xcd_on; const int4* items; const int2* pairs; const int* singles; const int2* blk_first; const int* active; int* meta; Unit* units; int units_cap; int2* nbr; };
+struct UnitsArgs { int* bcnt; int nb, xcd_on; const int4* items; const int2* pairs; const int* singles; const int2* blk_first; const int* active; int* meta; Unit* units; int units_cap; int2* nbr; };
 __global__ __launch_bounds__(256) void k_sort_apply(int N, size_t Np, int n_pwg, const int* __restrict__ key, const int* __restrict__ rank,
                                                     const int* __restrict__ start, const int* __restrict__ pid_old, int* pid_new, int* slot_of_pid,
                                                     const float4* __restrict__ pinfo, float4* info_new, float* dst_, float* src_, UnitsArgs U) {
     if ((int)blockIdx.x >= n_pwg) {          // (independent of the permutation: both only need what the scan and k_sort_fill left)
-        // the order's item and dense-particle counts for the host's heuristics (g2p_grad_split): plain stores into mapped host memory
-        if ((int)blockIdx.x == n_pwg && threadIdx.x < 2 && U.meta_host) U.meta_host[threadIdx.x] = U.meta[threadIdx.x];
         for (int i = (blockIdx.x - n_pwg) * 256 + threadIdx.x; i <= U.nb * U.nb * U.nb; i += SORT_UNIT_WGS * 256) U.bcnt[i] = 0;      // block counts: ready for the next sort
         build_units_dev((blockIdx.x - n_pwg) * 256 + threadIdx.x, SORT_UNIT_WGS * 256, U.nb, N, U.xcd_on, U.items, U.pairs, U.singles, U.blk_first, U.active, U.meta,
                         U.units, U.units_cap, U.nbr);
@@ -2679,7 +2683,6 @@ struct FeEngine {
     float* grad_ptr[3] = {nullptr, nullptr, nullptr};
     // particle orders ("tables"): id 0 = identity; id 1+f = order produced by the sort at frame f
     struct Table { int* pid = nullptr; float4* info = nullptr; int2* pairs = nullptr; int* singles = nullptr; int4* items = nullptr; int* meta = nullptr; int2* blk_first = nullptr; int* active = nullptr; int* blk_slot = nullptr; int* slot_of_pid = nullptr; Unit* units = nullptr; int2* nbr = nullptr; };
-    int* meta_host = nullptr; int* meta_host_dev = nullptr; // mapped pinned memory: (items, dense particles) of every order, written by its sort (never waited for: heuristics only)
     int loose_max = 0;                                      // blocks with <= this many particles get no work item (option "loose_max")
     std::vector<int> gs_host; bool gs_host_valid = false;   // host copy of gs_flag, refreshed once per backward sweep
     float4* gstore = nullptr; int* gs_flag = nullptr; int gs_cap = 0;     // forward grid store (see GridStore)
@@ -2690,7 +2693,7 @@ struct FeEngine {
     std::vector<int> tbl_of_frame;                          // [L+1]
     int gtbl[2] = {-1, -1};                                 // order of each adjoint ring slot; -1 = all zero
     int p2g_grad_waves = 4;                                 // occupancy target of the SVD-free p2g_grad build (tuning)
-    int g2p_grad_v = 0;                                     // 1: fused rolled loop (k_g2p_grad), 2: split unrolled loops (k_g2p_grad2), 0: by the order's particles per item
+    int g2p_grad_v = 3;                                     // build of the G2P adjoint: 3 = split passes, x offset rolled (k_g2p_grad2<4>, default); 2 = split, unrolled completely (<3>); 1 = fused rolled loop (k_g2p_grad)
     int item_max = ITEM_MAX_CAP;                            // particles per work item (<= ITEM_MAX_CAP = one half workgroup)
     int sort_interval = 10;                                 // K: re-sort every K substeps (0 = never: global path only)
     size_t items_cap = 0, units_cap = 0;
@@ -2925,7 +2928,7 @@ int sort_frame(FeEngine* h, int f) {
     if (fine) { prof_end(h); prof_begin(h, KID_SORT_PERM); }
     // re-sorting a frame that is already in this table's order reads the id table it rewrites: stage it
     int* pid_dst = id_old == id_new ? h->sort_pid : tn.pid;
-    const UnitsArgs U = {h->sort_bcnt, h->meta_host_dev ? h->meta_host_dev + (size_t)id_new * 8 : nullptr, h->nb, h->S.xcd, tn.items, tn.pairs, tn.singles, tn.blk_first, tn.active, tn.meta, tn.units, (int)h->units_cap, tn.nbr};
+    const UnitsArgs U = {h->sort_bcnt, h->nb, h->S.xcd, tn.items, tn.pairs, tn.singles, tn.blk_first, tn.active, tn.meta, tn.units, (int)h->units_cap, tn.nbr};
     hipLaunchKernelGGL(k_sort_apply, dim3(n_pwg + SORT_UNIT_WGS), dim3(256), 0, h->stream, h->N, (size_t)h->Np, n_pwg, h->sort_key, h->sort_rank, h->sort_start,
                        h->tables[id_old].pid, pid_dst, tn.slot_of_pid, h->pinfo, tn.info, h->spare_frame(), h->frame(f), U);
     if (id_old == id_new) HIPCK(h, hipMemcpyAsync(tn.pid, h->sort_pid, sizeof(int) * h->Np, hipMemcpyDeviceToDevice, h->stream));
@@ -2933,18 +2936,6 @@ int sort_frame(FeEngine* h, int f) {
     std::swap(h->frame_ptr[f], h->spare_frame());
     h->tbl_of_frame[f] = id_new;
     return 0;
-}
-
-// Which build of the G2P adjoint an order gets.  The fused kernel (four waves per SIMD, shared weight arithmetic) is the faster one
-// where the items are full -- the falling block: 23.0 vs 25.8 us -- the split one (no selects, no loop bookkeeping, three waves per
-// SIMD) where they are not -- the layer: 29.8 vs 32.0 us.  Decided by the order's dense particles per item as its sort left them
-// in meta_host (a copy that is never waited for: an order whose numbers have not arrived yet takes the fused kernel).
-bool g2p_grad_split(FeEngine* h, int table) {
-    if (h->g2p_grad_v == 1) return false;
-    if (h->g2p_grad_v >= 2) return true;
-    if (!h->meta_host || table <= 0) return false;
-    const int* m = h->meta_host + (size_t)table * 8;
-    return m[0] > 0 && m[1] < 90 * m[0];
 }
 
 StaticsP statics_p(FeEngine* h) { StaticsP p; p.n = (int)h->statics_host.size(); p.s = h->statics_dev; return p; }
@@ -3050,7 +3041,8 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act) {
         hipLaunchKernelGGL(k_collide_grad, dim3(std::min((h->N + 15) / 16, 2048)), dim3(256), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->g_out, T, grid_store(h), f, ag,
                            h->hit_list, h->hit_count);
     }
-    if (g2p_grad_split(h, t)) hipLaunchKernelGGL(k_g2p_grad2<3>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag);
+    if (h->g2p_grad_v == 2) hipLaunchKernelGGL(k_g2p_grad2<3>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag);
+    else if (h->g2p_grad_v != 1) hipLaunchKernelGGL(k_g2p_grad2<4>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag);
     else hipLaunchKernelGGL(k_g2p_grad, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag);
     prof_end(h);
     prof_begin(h, KID_GRID_GRAD);
@@ -3196,7 +3188,8 @@ int substep_bwd_batch(FeEngine** hs, int B, int f, int f_global, int act) {
         prof_end(h0);
     }
     prof_begin(h0, KID_G2P_GRAD);
-    if (g2p_grad_split(h0, h0->tbl_of_frame[f])) hipLaunchKernelGGL(k_g2p_grad2_b<3>, wgrid_b(hs, B), dim3(WG), 0, h0->stream, bq);
+    if (h0->g2p_grad_v == 2) hipLaunchKernelGGL(k_g2p_grad2_b<3>, wgrid_b(hs, B), dim3(WG), 0, h0->stream, bq);
+    else if (h0->g2p_grad_v != 1) hipLaunchKernelGGL(k_g2p_grad2_b<4>, wgrid_b(hs, B), dim3(WG), 0, h0->stream, bq);
     else hipLaunchKernelGGL(k_g2p_grad_b, wgrid_b(hs, B), dim3(WG), 0, h0->stream, bq);
     prof_end(h0);
     prof_begin(h0, KID_GRID_GRAD);
@@ -3299,6 +3292,7 @@ FeEngine* fe_create(const FeConfig* cfg) {
     if (cfg->device < 0 || cfg->device >= ndev) { g_create_err = "HIP device ordinal out of range"; return nullptr; }
     FeEngine* h = new FeEngine();
     if (const char* e = std::getenv("FE_SORT_INTERVAL")) h->sort_interval = std::atoi(e);     // tuning experiments (the option of the same name wins)
+    if (const char* e = std::getenv("FE_G2P_GRAD_V")) h->g2p_grad_v = std::atoi(e);           // (the parity suite is run once per build of the G2P adjoint)
     h->cfg = *cfg; h->N = cfg->n_particles; h->L = cfg->max_substeps_local; h->n = cfg->n_grid; h->nb = cfg->n_grid / 4;
     h->Np = ((h->N + 63) / 64) * 64; if (h->Np == 0) h->Np = 64;
     h->device = cfg->device;
@@ -3354,9 +3348,6 @@ FeEngine* fe_create(const FeConfig* cfg) {
         if (hipMemcpyOnStream(h, h->tables[0].pid, id.data(), sizeof(int) * h->Np, hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy failed");
         if (hipMemcpyOnStream(h, h->tables[0].slot_of_pid, id.data(), sizeof(int) * h->Np, hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy failed");
     }
-    if (hipHostMalloc((void**)&h->meta_host, sizeof(int) * 8 * (h->L + 2), hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer((void**)&h->meta_host_dev, h->meta_host, 0) == hipSuccess)
-        std::memset(h->meta_host, 0, sizeof(int) * 8 * (h->L + 2));
-    else { if (h->meta_host) (void)hipHostFree(h->meta_host); h->meta_host = nullptr; h->meta_host_dev = nullptr; }
     if (hipEventCreate(&h->ev_t0) != hipSuccess || hipEventCreate(&h->ev_t1) != hipSuccess ||
         hipEventCreateWithFlags(&h->ev_batch, hipEventDisableTiming) != hipSuccess) return fail("hipEventCreate failed");
     if (hipStreamSynchronize(h->stream) != hipSuccess) return fail("device initialisation failed");
@@ -3386,7 +3377,6 @@ void fe_destroy(FeEngine* h) {
     if (h->ev_t1) (void)hipEventDestroy(h->ev_t1);
     if (h->ev_batch) (void)hipEventDestroy(h->ev_batch);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
-    if (h->meta_host) (void)hipHostFree(h->meta_host);
     delete h;
 }
 
