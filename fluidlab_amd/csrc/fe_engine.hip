@@ -1324,12 +1324,13 @@ __device__ __forceinline__ void g2p_grad_particle2(const SimP& S, const FrameV& 
         qb[a] = (g.v[a] + S.dt * g.x[a]) - (qx[a] * st.fx[0] + qy[a] * st.fx[1] + qz[a] * st.fx[2]);
     }
     const int l0 = tofs + lb;
+    constexpr int UNR_X = MINW >= 4 ? 1 : 3;
     // MINW = 4: the x offset of the stencil stays a rolled loop of three (nine nodes unrolled inside it, the x weights by register
     // select): the completely unrolled passes need 166 registers, this form fits the 128 of four waves per SIMD
     {   // ---- pass 1: gather.  gfx_d = sum_o dW/df_d (v_o . q_o),  nvw = sum_o W v_o
         const float dwz[3] = {stencil_dw(st, 0, 2), stencil_dw(st, 1, 2), stencil_dw(st, 2, 2)};      // (the x and y ones are one VALU each: made where used)
         float gfx[3] = {0.f, 0.f, 0.f}, nvw[3] = {0.f, 0.f, 0.f};
-#pragma unroll(MINW >= 4 ? 1 : 3)
+#pragma unroll UNR_X
         for (int i = 0; i < 3; i++) {
             const float wi = MINW >= 4 ? STW(st, i, 0) : st.w[i][0], dwi = stencil_dw(st, i, 0);
 #pragma unroll
@@ -1369,7 +1370,7 @@ __device__ __forceinline__ void g2p_grad_particle2(const SimP& S, const FrameV& 
     const SegScan sc = seg_setup(live ? lb : (0x40000000 | (int)threadIdx.x));       // (only now: five registers less across pass 1)
     const bool issue = sc.tail && live;
     const float livef = live ? 1.f : 0.f;
-#pragma unroll(MINW >= 4 ? 1 : 3)
+#pragma unroll UNR_X
     for (int i = 0; i < 3; i++) {
         const float lwi = livef * (MINW >= 4 ? STW(st, i, 0) : st.w[i][0]);
 #pragma unroll
