@@ -212,7 +212,8 @@ __device__ __forceinline__ void mark_dynamic(int b, int* blk_flag, int* blk_list
 // 1,600 sparsely filled blocks needed two rounds of the chip's 1,024 resident workgroups per kernel (scripts/timeline.py).
 // The LDS tiles (SoA planes of TILE_N floats, two tiles per workgroup).  File scope, so every access is a known-LDS ds_*
 // instruction (a `float*` parameter that may also be null degrades to flat_*).
-__shared__ float  s_tile[2 * 4 * TILE_N];   // gathered node values (v_out / d v_in,d m): k_g2p (3 planes), k_p2g_grad (4)
+__shared__ float  s_tile[2 * 4 * TILE_N];   // gathered node values (d v_in, d m): k_p2g_grad (4 planes)
+__shared__ float  s_gtile[2 * 3 * TILE_N];  // gathered v_out: k_g2p (3 planes)
 // Scatter accumulators are fp64: measured on MI355X ds_add_f32 sustains ~0.2 T lane-ops/s chip-wide, ds_add_f64
 // ~1.6 T and ds_add_u64 ~2.8 T in this access pattern (profiles/r01_ubench_lds_types.txt); fp64 also makes the
 // in-tile sum insensitive to the order of the atomics.
@@ -303,7 +304,8 @@ struct TableP {
     // (the sort's item list -- (block, start, count <= 128), sorted by block --, its pair list for blocks with several items and
     //  its list of single-item blocks stay on the host side of the table: the kernels read what k_build_units made of them)
     const int*  meta;          // meta[0] = n_items, [1] = tail_start, [2] = n_active, [3] = n pairs, [4] = n singles, [5] = n unit slots
-    const struct Unit* units;  // what workgroup w of the particle kernels works on: ready-made descriptors, XCD order (see Unit)
+    const struct UnitRec* units;  // what workgroup w of the scatter kernels works on: ready-made descriptors, XCD order (see Unit); meta[5] slots
+    const struct UnitRec* units_p;// the same work as pair units only, for the gather kernels (build_units_dev); meta[9] slots
     int units_cap;
     const int2* nbr;           // [n_active * 27] (first item, item count) of the 27 neighbours of each active-list entry's block
     const int*  active;        // blocks within one block of an occupied block: every block a tile can reach
@@ -325,25 +327,35 @@ __device__ __forceinline__ bool tile_node(const TileO& t, int l, int n, int& i, 
     return (unsigned)i < (unsigned)n && (unsigned)j < (unsigned)n && (unsigned)k < (unsigned)n;
 }
 
-// What one half of a workgroup works on (see "Work items and workgroups" above).  Uniform per wave.
+// What one half of a workgroup (a pair unit) or one wave of it (a quad unit) works on.  Uniform per wave.
 struct PairCtx {
-    int4 it;         // (block, first slot, count <= 128, 0) of this half's item; count 0 when the half is idle
-    int  ti;         // LDS tile of this half: 0, or 1 when the two items belong to different blocks
+    int4 it;         // (block, first slot, count <= 128, 0) of this half's / wave's item; count 0 when it idles
+    int  ti;         // LDS tile: 0, or 1 when the two items of a pair belong to different blocks; the wave's number in a quad
     int  slab;       // slab the tile is handed over in (the item's index; a shared tile goes to the first item's)
-    int  nth, t0;    // the threads that load / zero / store this tile: all 256 from t0 = tid when shared, else this half's 128
-    bool live;       // this half's threads take part in tile loads and stores
+    int  nth, t0;    // the threads that load / zero / store this tile: all 256 from t0 = tid when shared, this half's 128, a quad's wave
+    int  i;          // this thread's particle within the item
+    bool live;       // this half's / wave's threads take part in tile loads and stores
+    bool quad;
 };
-// The work of one workgroup of the particle kernels, as the sort leaves it (build_units_dev): two item descriptors ready to use.
+// The work of one workgroup of the particle kernels, as the sort leaves it (build_units_dev): item descriptors ready to use.
 // The kernels used to walk meta -> pairs[w] / singles[q] -> items[i] before they could ask for their particles: three dependent
 // round trips ahead of the first useful load in kernels that are one round of such chains.  Now workgroup w reads units[w] together
 // with meta.  The list is stored in XCD order (slot w holds work unit xcd_item(w): every XCD a contiguous eighth of the items).
-//   a = (block, first slot, count, item index | same << 30), b likewise with b.w = -1 when there is no second item;
-//   same: both items belong to one block and share tile and slab;  a.z == -1: a tail unit (slots from a.y);  a.z == -2: nothing
-struct Unit { int4 a, b; };
+//   PAIR: a = (block, first slot, count, item index | same << 30), b likewise with b.w = -1 when there is no second item;
+//         same: both items belong to one block and share tile and slab
+//   QUAD (a.w has QUAD_BIT): a, b, c, d = four items of at most QUAD_MAX particles, each the only item of its block -- one WAVE per
+//         item, four tiles per workgroup.  Where the water has come apart most items are of that kind, and a pair unit keeps two
+//         waves and a 16 KB fp64 tile waiting on each of them: the particle kernels there are rounds of resident workgroups (measured,
+//         profiles/r03_ab_lds_pad_occupancy.txt: splash time = a + b / workgroups per CU with b / 4 = 13-21 us per kernel).
+//   a.z == -1: a tail unit (slots from a.y);  a.z == -2: nothing
+#define QUAD_BIT (1 << 29)
+#define QUAD_MAX 64
+struct UnitRec { int4 a, b, c, d; };         // in memory
+struct Unit { int4 a, b, q; };               // as a wave holds it: q = the descriptor of this wave's number (its own item in a quad)
 __device__ __forceinline__ PairCtx pair_ctx(const Unit& u) {
     const int tid = threadIdx.x, half = __builtin_amdgcn_readfirstlane(tid >> 7);
     const bool same = (u.a.w >> 30) & 1;
-    const int ia = u.a.w & 0x3fffffff, ib = u.b.w;
+    const int ia = u.a.w & 0x1fffffff, ib = u.b.w;
     const int ih = half ? ib : ia;
     PairCtx c;
     c.live = same || ih >= 0;
@@ -354,18 +366,55 @@ __device__ __forceinline__ PairCtx pair_ctx(const Unit& u) {
     c.slab = same ? ia : (ih >= 0 ? ih : ia);
     c.nth = same ? WG : HALF;
     c.t0 = same ? tid : (tid & (HALF - 1));
+    c.i = tid & (HALF - 1);
+    c.quad = false;
     return c;
 }
+// (one function, field by field: a ternary over two struct-returning calls puts both structs on the stack)
+__device__ __forceinline__ PairCtx unit_ctx(const Unit& u) {
+    const int tid = threadIdx.x;
+    const bool quad = (u.a.w & QUAD_BIT) != 0;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), half = wave >> 1;
+    const bool same = (u.a.w >> 30) & 1;
+    const int ia = u.a.w & 0x1fffffff;
+    // the descriptor this wave works on: its own in a quad, its half's in a pair (the first one's when there is no second)
+    // (fields copied out first: a conditional between struct members is a conditional between ADDRESSES to the front end, which keeps
+    //  the whole unit on the stack)
+    const int ax = u.a.x, ay = u.a.y, az = u.a.z, bx = u.b.x, by = u.b.y, bz = u.b.z, bw = u.b.w, qx = u.q.x, qy = u.q.y, qz = u.q.z, qw = u.q.w;
+    const bool second = half && bw >= 0;
+    const int mx = quad ? qx : (second ? bx : ax);
+    const int my = quad ? qy : (second ? by : ay);
+    const int mz = quad ? qz : (second ? bz : az);
+    const int ih = quad ? (wave == 0 ? ia : qw) : (half ? bw : ia);          // this wave's / half's item, -1: none
+    PairCtx c;
+    c.quad = quad;
+    c.live = (same && !quad) || ih >= 0;
+    c.it = make_int4(mx, my, ih >= 0 ? mz : 0, 0);           // no item: the half / wave idles (through the same barriers)
+    c.ti = quad ? wave : ((half && !same) ? 1 : 0);
+    c.slab = quad ? (ih >= 0 ? ih : 0) : (same ? ia : (ih >= 0 ? ih : ia));
+    c.nth = quad ? 64 : (same ? WG : HALF);
+    c.t0 = quad ? (tid & 63) : (same ? tid : (tid & (HALF - 1)));
+    c.i = quad ? (tid & 63) : (tid & (HALF - 1));
+    return c;
+}
+// Between the phases of a unit: a pair's tiles are shared by waves (workgroup barrier); a quad's wave owns its tile, its LDS operations
+// complete in order, and only the compiler has to be kept from moving accesses across (the tile is read and written as floats
+// and as words).  Uniform per workgroup.
+__device__ __forceinline__ void unit_sync(bool quad) {
+    if (quad) asm volatile("" ::: "memory");
+    else __syncthreads();
+}
 // slot w of the unit list (read ahead of meta for the first one: the list is padded to units_cap)
+template <bool GATHER = false>
 __device__ __forceinline__ Unit unit_load(const TableP& T, int w) {
-    Unit u;
-    if (w < T.units_cap) u = T.units[w];
-    else { u.a = make_int4(0, 0, -2, 0); u.b = make_int4(0, 0, 0, -1); }
+    const int4* p = (const int4*)((GATHER ? T.units_p : T.units) + (w < T.units_cap ? w : T.units_cap - 1));
+    int4 a = p[0], b = p[1], q = p[__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)];
+    if (w >= T.units_cap) a.z = -2;
     // (wave-uniform: into scalar registers, the particle kernels have no vector registers to spare)
-    u.a.x = __builtin_amdgcn_readfirstlane(u.a.x); u.a.y = __builtin_amdgcn_readfirstlane(u.a.y);
-    u.a.z = __builtin_amdgcn_readfirstlane(u.a.z); u.a.w = __builtin_amdgcn_readfirstlane(u.a.w);
-    u.b.x = __builtin_amdgcn_readfirstlane(u.b.x); u.b.y = __builtin_amdgcn_readfirstlane(u.b.y);
-    u.b.z = __builtin_amdgcn_readfirstlane(u.b.z); u.b.w = __builtin_amdgcn_readfirstlane(u.b.w);
+#define UNIT_SCALAR(q) make_int4(__builtin_amdgcn_readfirstlane(q.x), __builtin_amdgcn_readfirstlane(q.y), __builtin_amdgcn_readfirstlane(q.z), __builtin_amdgcn_readfirstlane(q.w))
+    Unit u;
+    u.a = UNIT_SCALAR(a); u.b = UNIT_SCALAR(b); u.q = UNIT_SCALAR(q);
+#undef UNIT_SCALAR
     return u;
 }
 
@@ -596,8 +645,30 @@ __device__ __forceinline__ void p2g_scatter_global(const SimP& S, const P2GPrep&
     }
 }
 
+// Fixed-point accumulators of a quad unit's tiles.  Four fp64 tiles (16 KB each) do not fit beside each other at four workgroups per
+// CU, and ds_add_f32 is no alternative on this chip (0.2 T lane-ops/s against 5.9 T for ds_add_u32, profiles/r01_ubench_lds_types.txt).
+// A quad's tile belongs to ONE wave holding <= 64 particles: the wave takes the largest contribution any of its lanes can make
+// (M, a bound), scales by the power of two that puts M at 2^24 -- so that 64 of them stay below 2^30 --, runs the same fp32 segmented
+// scan on the scaled values and adds the run totals, rounded to nearest, with ds_add_u32.  The quantum is 2^-24 M, an fp32 ulp of the
+// largest contribution (what fp32 atomics into the node would lose, and independent of the order of the adds); the hand-over converts
+// back with the exact inverse.  Momentum / adjoint planes and the mass plane have scales of their own.
+__device__ __forceinline__ float wave_max(float x) {           // all 64 lanes; x >= 0
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) x = fmaxf(x, __shfl_xor(x, o, 64));
+    return x;
+}
+struct FixScale { float s, inv; };
+__device__ __forceinline__ FixScale fix_scale(float M) {       // M wave-uniform, >= 0
+    int e = ((__builtin_amdgcn_readfirstlane(__float_as_int(M)) >> 23) & 0xff) - 126;          // M < 2^e (scalar registers from here on)
+    e = e < -100 ? -100 : e;
+    FixScale f; f.s = __int_as_float((127 + 24 - e) << 23); f.inv = __int_as_float((127 - 24 + e) << 23);
+    return f;
+}
+
 // tile path, executed by ALL lanes of the wave: contributions of lanes with `in_tile` are summed over runs of equal
-// stencil base (seg_scan) and the last lane of each run adds the total into the fp64 LDS accumulators
+// stencil base (seg_scan) and the last lane of each run adds the total into the LDS accumulators: fp64, or -- QUAD, `q` scaled by
+// the caller -- fixed point
+template <bool QUAD>
 __device__ __forceinline__ void p2g_scatter_tile(const SimP& S, const P2GPrep& q, bool in_tile, int lb, int aofs) {
     const SegScan sc = seg_setup(in_tile ? lb : (0x40000000 | (int)threadIdx.x));
     const bool issue = sc.tail && in_tile;
@@ -623,7 +694,10 @@ __device__ __forceinline__ void p2g_scatter_tile(const SimP& S, const P2GPrep& q
             seg_scan4(sc, c[0], c[1], c[2], c[3]);
             if (issue) {
 #pragma unroll
-                for (int a = 0; a < 4; a++) atomicAdd(&s_acc[aofs + a * TILE_N + l], (double)c[a]);            // ds_add_f64
+                for (int a = 0; a < 4; a++) {
+                    if (QUAD) atomicAdd((int*)s_acc + aofs + a * TILE_N + l, (int)rintf(c[a]));                // ds_add_u32
+                    else atomicAdd(&s_acc[aofs + a * TILE_N + l], (double)c[a]);                               // ds_add_f64
+                }
             }
         }
     }
@@ -649,16 +723,18 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
         if (wg != (int)blockIdx.x) un = unit_load(T, wg);
         if (un.a.z == -2) continue;
         if (un.a.z >= 0) {
-            const PairCtx pc = pair_ctx(un);
+            const PairCtx pc = unit_ctx(un);
             const int4 it = pc.it;
             const TileO to = tile_origin(it.x, S.nb);
-            const int aofs = pc.ti * 4 * TILE_N;
+            const int aofs = pc.ti * 4 * TILE_N;                 // (doubles of a pair's tile, words of a quad's)
             TL(S, 1);
             const int nbr_entry = neighbour_entry(T.blk_slot, S.nb, it.x);      // (in flight together with the particle loads)
-            if (pc.live) for (int l = pc.t0; l < 4 * TILE_N; l += pc.nth) s_acc[aofs + l] = 0.0;
-            __syncthreads();
+            if (pc.quad) { if (pc.live) for (int l = pc.t0; l < 4 * TILE_N; l += pc.nth) ((int*)s_acc)[aofs + l] = 0; }
+            else if (pc.live) for (int l = pc.t0; l < 4 * TILE_N; l += pc.nth) s_acc[aofs + l] = 0.0;
+            unit_sync(pc.quad);
+            FixScale fs_p = {1.f, 1.f}, fs_m = {1.f, 1.f};
             {                                                    // one pass: an item is <= 128 particles, one per lane of the half
-                const int i = tid & (HALF - 1), s = it.y + i;
+                const int i = pc.i, s = it.y + i;
                 const bool has = i < it.z;
                 // (`used` is re-read rather than implied by the work list so host edits of a frame cannot desynchronise it)
                 // The state is asked for together with the flag (a slot of an item is valid memory either way): one round trip
@@ -686,20 +762,36 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
                 // a wave without any particle skips the 27-node scan altogether; the branch is wave-uniform, as the DPP scan requires
                 if (__any(in_tile)) {
                     touch_regions(in_tile ? stencil_regions(lb) : 0, nbr_entry, GS);
-                    p2g_scatter_tile(S, q, in_tile, in_tile ? lb : 0, aofs);
+                    if (pc.quad) {
+                        float bp = 0.f;
+#pragma unroll
+                        for (int a = 0; a < 3; a++) bp = fmaxf(bp, fabsf(q.mv[a]) + 2.f * S.dx * (fabsf(q.affine.a[a][0]) + fabsf(q.affine.a[a][1]) + fabsf(q.affine.a[a][2])));
+                        fs_p = fix_scale(wave_max(in_tile ? bp : 0.f));
+                        fs_m = fix_scale(wave_max(in_tile ? q.m : 0.f));
+                        const float sp = in_tile ? fs_p.s : 1.f;          // (in place -- the registers are all taken --, and only where the tile path uses it)
+                        q.m *= in_tile ? fs_m.s : 1.f;
+#pragma unroll
+                        for (int a = 0; a < 3; a++) { q.mv[a] *= sp; q.affine.a[a][0] *= sp; q.affine.a[a][1] *= sp; q.affine.a[a][2] *= sp; }
+                        p2g_scatter_tile<true>(S, q, in_tile, in_tile ? lb : 0, aofs);
+                    } else p2g_scatter_tile<false>(S, q, in_tile, in_tile ? lb : 0, aofs);
                 }
                 if (used && q.inside && !in_tile) { atomicAdd(G.slow, 1); p2g_scatter_global(S, q, G, GS, T.blk_slot); }   // drifted out of the tile
                 if (has && !used && !taken && WRITE) unused_particle_fwd(S, cur, nxt, s, T.pid_of_slot[s], pool_idx, agent, inj, f);
             }
             TL(S, 4);
-            __syncthreads();
+            unit_sync(pc.quad);
             TL(S, 5);
             // hand the tile over: plain coalesced float4 stores into the item's slab.  No atomics, no waiting:
             // k_grid sums, per node, the slabs of the (at most 8) blocks whose tiles reach it, in a fixed order.
-            if (pc.live) for (int l = pc.t0; l < TILE_N; l += pc.nth)
+            if (pc.quad) {
+                const int* acc = (const int*)s_acc + aofs;
+                if (pc.live) for (int l = pc.t0; l < TILE_N; l += pc.nth)
+                    tile_handover<4>(S, G.slab, pc.slab, G.g_in, GS, to, nbr_entry, l,
+                                     make_float4((float)acc[l] * fs_p.inv, (float)acc[TILE_N + l] * fs_p.inv, (float)acc[2 * TILE_N + l] * fs_p.inv, (float)acc[3 * TILE_N + l] * fs_m.inv), S.wt & 1);
+            } else if (pc.live) for (int l = pc.t0; l < TILE_N; l += pc.nth)
                 tile_handover<4>(S, G.slab, pc.slab, G.g_in, GS, to, nbr_entry, l,
                                  make_float4((float)s_acc[aofs + l], (float)s_acc[aofs + TILE_N + l], (float)s_acc[aofs + 2 * TILE_N + l], (float)s_acc[aofs + 3 * TILE_N + l]), S.wt & 1);
-            __syncthreads();
+            unit_sync(pc.quad);
             TL(S, 6);
         } else {
             const int s = un.a.y + tid;
@@ -977,7 +1069,7 @@ __device__ __forceinline__ void used_particle_g2p(const SimP& S, const FrameV& c
             float g0, g1, g2;
             if (TILE) {
                 const int l = tofs + lb + (i * TILE_T + j) * TILE_T + kk;
-                g0 = s_tile[l]; g1 = s_tile[TILE_N + l]; g2 = s_tile[2 * TILE_N + l];
+                g0 = s_gtile[l]; g1 = s_gtile[TILE_N + l]; g2 = s_gtile[2 * TILE_N + l];
             } else {
                 float4 gv = g_out[cell_addr(st.base[0] + i, st.base[1] + j, st.base[2] + kk, S.nb)];
                 g0 = gv.x; g1 = gv.y; g2 = gv.z;
@@ -1003,12 +1095,12 @@ __device__ __forceinline__ void used_particle_g2p(const SimP& S, const FrameV& c
 
 __device__ __forceinline__ void load_tile3(const TileO& to, const SimP& S, const float4* __restrict__ src, const PairCtx& pc) {
     if (!pc.live) return;
-    const int tofs = pc.ti * 4 * TILE_N;
+    const int tofs = pc.ti * 3 * TILE_N;
     for (int l = pc.t0; l < TILE_N; l += pc.nth) {
         int i, j, k;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (tile_node(to, l, S.n, i, j, k)) v = src[cell_addr(i, j, k, S.nb)];
-        s_tile[tofs + l] = v.x; s_tile[tofs + TILE_N + l] = v.y; s_tile[tofs + 2 * TILE_N + l] = v.z;
+        s_gtile[tofs + l] = v.x; s_gtile[tofs + TILE_N + l] = v.y; s_gtile[tofs + 2 * TILE_N + l] = v.z;
     }
 }
 __device__ __forceinline__ void load_tile4(const TileO& to, const SimP& S, const float4* __restrict__ src, const PairCtx& pc) {
@@ -1048,16 +1140,16 @@ __device__ __forceinline__ void g2p_body(SimP S, float* fr_cur, float* fr_next, 
     FrameV cur = frame_view(fr_cur, S.Np);
     FrameV nxt = frame_view(fr_next, S.Np, S.wt & 2);
     TL(S, 0);
-    Unit un = unit_load(T, blockIdx.x);                       // this workgroup's first unit, asked for together with meta
-    const int n_slots = T.meta[5];
+    Unit un = unit_load<true>(T, blockIdx.x);                       // this workgroup's first unit, asked for together with meta
+    const int n_slots = T.meta[9];
     for (int wg = blockIdx.x; wg < n_slots; wg += gridDim.x) {
-        if (wg != (int)blockIdx.x) un = unit_load(T, wg);
+        if (wg != (int)blockIdx.x) un = unit_load<true>(T, wg);
         if (un.a.z == -2) continue;
         if (un.a.z >= 0) {
-            const PairCtx pc = pair_ctx(un);
+            const PairCtx pc = pair_ctx(un);                     // (the gather kernels walk the pairs-only list)
             const int4 it = pc.it;
             const TileO to = tile_origin(it.x, S.nb);
-            const int i = tid & (HALF - 1);
+            const int i = pc.i;
             const int s0 = it.y + (i < it.z ? i : 0);
             TL(S, 1);
             const int u = cur.used[s0];
@@ -1065,7 +1157,7 @@ __device__ __forceinline__ void g2p_body(SimP S, float* fr_cur, float* fr_next, 
             load_tile3(to, S, g_out, pc);
             __syncthreads();
             TL(S, 2);
-            if (i < it.z) slot_g2p<COLLIDE>(S, cur, nxt, s0, true, to, g_out, slow, agent, f, u, a0, pc.ti * 4 * TILE_N);
+            if (i < it.z) slot_g2p<COLLIDE>(S, cur, nxt, s0, true, to, g_out, slow, agent, f, u, a0, pc.ti * 3 * TILE_N);
             TL(S, 3);
             __syncthreads();
             TL(S, 4);
@@ -1210,7 +1302,7 @@ __device__ __forceinline__ void pose_flush(const AgentP& agent, int f) {
     __syncthreads();
 }
 
-__device__ __forceinline__ void g2p_grad_load_tile2(const TileO& to, const SimP& S, const float4* __restrict__ g_out, const float4* __restrict__ st, int nbr_entry, const PairCtx& pc);
+__device__ __forceinline__ void g2p_grad_load_tile2(const TileO& to, const SimP& S, const float4* __restrict__ g_out, const float4* __restrict__ st, int nbr_entry, const PairCtx& pc, float* gt);
 __device__ __forceinline__ void g2p_grad_body(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T,
                                                  const float4* __restrict__ g_out, float* gg_out, float4* slab, int* slow,
                                                  GridStore GS, int f, AgentP agent) {
@@ -1220,10 +1312,10 @@ __device__ __forceinline__ void g2p_grad_body(SimP S, float* fr_cur, float* Gn_,
     FrameV cur = frame_view(fr_cur, S.Np);
     FrameV Gn = frame_view(Gn_, S.Np), Gc = frame_view(Gc_, S.Np, S.wt & 4);
     TL(S, 0);
-    Unit un = unit_load(T, blockIdx.x);                       // this workgroup's first unit, asked for together with meta
-    const int n_slots = T.meta[5];
+    Unit un = unit_load<true>(T, blockIdx.x);                       // this workgroup's first unit, asked for together with meta
+    const int n_slots = T.meta[9];
     for (int wg = blockIdx.x; wg < n_slots; wg += gridDim.x) {
-        if (wg != (int)blockIdx.x) un = unit_load(T, wg);
+        if (wg != (int)blockIdx.x) un = unit_load<true>(T, wg);
         if (un.a.z == -2) continue;
         if (un.a.z >= 0) {
             const PairCtx pc = pair_ctx(un);
@@ -1236,7 +1328,7 @@ __device__ __forceinline__ void g2p_grad_body(SimP S, float* fr_cur, float* Gn_,
             const int nbr_entry = neighbour_entry(T.blk_slot, S.nb, it.x);
             const int u0 = cur.used[s];
             const float4 a00 = cur.A0[s];
-            g2p_grad_load_tile2(to, S, g_out, V.store, nbr_entry, pc);        // (through the 27 neighbour entries: one hop)
+            g2p_grad_load_tile2(to, S, g_out, V.store, nbr_entry, pc, s_tile3 + tofs);        // (through the 27 neighbour entries: one hop)
             if (pc.live) for (int l = pc.t0; l < 3 * TILE_N; l += pc.nth) s_acc3[tofs + l] = 0.0;
             __syncthreads();
             TL(S, 2);
@@ -1291,9 +1383,8 @@ __global__ __launch_bounds__(WG, 4) void k_g2p_grad_b(Batch<G2PGradArgs> B) { co
 // state (k_p2g's neighbour_entry): round 2 looked every tile node's block up in blk_slot first (two dependent hops per node).
 // -----------------------------------------------------------------------------------------
 __device__ __forceinline__ void g2p_grad_load_tile2(const TileO& to, const SimP& S, const float4* __restrict__ g_out,
-                                                    const float4* __restrict__ st, int nbr_entry, const PairCtx& pc) {
+                                                    const float4* __restrict__ st, int nbr_entry, const PairCtx& pc, float* gt) {
     if (!pc.live) return;                                    // (whole waves: the shuffles below see all 64 lanes)
-    const int tofs = pc.ti * 3 * TILE_N;
     for (int l = pc.t0; l < TILE_N; l += pc.nth) {
         const int tx = l >> 6, ty = (l >> 3) & 7, tz = l & 7;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1304,14 +1395,16 @@ __device__ __forceinline__ void g2p_grad_load_tile2(const TileO& to, const SimP&
             int i, j, k;
             if (tile_node(to, l, S.n, i, j, k)) v = g_out[cell_addr(i, j, k, S.nb)];
         }
-        s_tile3[tofs + l] = v.x; s_tile3[tofs + TILE_N + l] = v.y; s_tile3[tofs + 2 * TILE_N + l] = v.z;
+        gt[l] = v.x; gt[TILE_N + l] = v.y; gt[2 * TILE_N + l] = v.z;
     }
 }
 
 // executed by ALL lanes of the wave (`live` = this lane holds a used particle whose stencil fits the tile)
-template <int MINW>
-__device__ __forceinline__ void g2p_grad_particle2(const SimP& S, const FrameV& Gn, const FrameV& Gc, int s, int lb, const Stencil& st,
-                                                   bool live, int tofs) {
+// QUAD: the wave's own tile -- v_out in `gt`, which the fixed-point accumulators (words, see fix_scale) take over between the passes;
+// returns the factor that turns them back into floats.
+template <int MINW, bool QUAD>
+__device__ __forceinline__ float g2p_grad_particle2(const SimP& S, const FrameV& Gn, const FrameV& Gc, int s, int lb, const Stencil& st,
+                                                    bool live, int tofs, const float* gt) {
     PState g;                                   // adjoints of x', v', C'
     if (live) load_xvC(Gn, s, g);
     else { g.x[0] = g.x[1] = g.x[2] = g.v[0] = g.v[1] = g.v[2] = 0.f; g.C = m3_zero(); }
@@ -1324,6 +1417,7 @@ __device__ __forceinline__ void g2p_grad_particle2(const SimP& S, const FrameV& 
         qb[a] = (g.v[a] + S.dt * g.x[a]) - (qx[a] * st.fx[0] + qy[a] * st.fx[1] + qz[a] * st.fx[2]);
     }
     const int l0 = tofs + lb;
+    gt += lb;
     constexpr int UNR_X = MINW >= 4 ? 1 : 3;
     // MINW = 4: the x offset of the stencil stays a rolled loop of three (nine nodes unrolled inside it, the x weights by register
     // select): the completely unrolled passes need 166 registers, this form fits the 128 of four waves per SIMD
@@ -1341,8 +1435,8 @@ __device__ __forceinline__ void g2p_grad_particle2(const SimP& S, const FrameV& 
                 float T = 0.f, Tz = 0.f, P[3] = {0.f, 0.f, 0.f};
 #pragma unroll
                 for (int kk = 0; kk < 3; kk++) {
-                    const int l = l0 + (i * TILE_T + j) * TILE_T + kk;
-                    const float v0 = s_tile3[l], v1 = s_tile3[TILE_N + l], v2 = s_tile3[2 * TILE_N + l];
+                    const int l = (i * TILE_T + j) * TILE_T + kk;
+                    const float v0 = gt[l], v1 = gt[TILE_N + l], v2 = gt[2 * TILE_N + l];
                     const float sdot = v0 * (qij[0] + (float)kk * qz[0]) + v1 * (qij[1] + (float)kk * qz[1]) + v2 * (qij[2] + (float)kk * qz[2]);
                     const float wk = st.w[kk][2];
                     T += wk * sdot; Tz += dwz[kk] * sdot;
@@ -1366,6 +1460,22 @@ __device__ __forceinline__ void g2p_grad_particle2(const SimP& S, const FrameV& 
         if (live) pstore(Gc, Gc.A0, s, make_float4(g.x[0] + S.inv_dx * gfx[0], g.x[1] + S.inv_dx * gfx[1], g.x[2] + S.inv_dx * gfx[2], 0.f));
     }
     NODE_FENCE();
+    float inv = 1.f;
+    if (QUAD) {
+        // the tile changes hands: every read of v_out is done (the wave's LDS operations complete in order), the words are zeroed and
+        // the coefficients of q scaled for the fixed-point sums
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        int* acc = (int*)s_acc3 + tofs;
+        for (int l = threadIdx.x & 63; l < 3 * TILE_N / 4; l += 64) ((int4*)acc)[l] = make_int4(0, 0, 0, 0);
+        asm volatile("" ::: "memory");
+        float b = 0.f;
+#pragma unroll
+        for (int a = 0; a < 3; a++) b = fmaxf(b, fabsf(qb[a]) + 2.f * (fabsf(qx[a]) + fabsf(qy[a]) + fabsf(qz[a])));
+        const FixScale fs = fix_scale(wave_max(live ? b : 0.f));
+        inv = fs.inv;
+#pragma unroll
+        for (int a = 0; a < 3; a++) { qb[a] *= fs.s; qx[a] *= fs.s; qy[a] *= fs.s; qz[a] *= fs.s; }
+    }
     // ---- pass 2: scatter d v_out(o) += W(o) q(o), summed over runs of equal stencil base before the LDS atomics
     const SegScan sc = seg_setup(live ? lb : (0x40000000 | (int)threadIdx.x));       // (only now: five registers less across pass 1)
     const bool issue = sc.tail && live;
@@ -1386,13 +1496,21 @@ __device__ __forceinline__ void g2p_grad_particle2(const SimP& S, const FrameV& 
                 seg_scan3(sc, c0, c1, c2);
                 if (issue) {
                     const int l = l0 + (i * TILE_T + j) * TILE_T + kk;
-                    atomicAdd(&s_acc3[l], (double)c0);                        // ds_add_f64
-                    atomicAdd(&s_acc3[TILE_N + l], (double)c1);
-                    atomicAdd(&s_acc3[2 * TILE_N + l], (double)c2);
+                    if (QUAD) {
+                        int* acc = (int*)s_acc3;
+                        atomicAdd(acc + l, (int)rintf(c0));                   // ds_add_u32
+                        atomicAdd(acc + TILE_N + l, (int)rintf(c1));
+                        atomicAdd(acc + 2 * TILE_N + l, (int)rintf(c2));
+                    } else {
+                        atomicAdd(&s_acc3[l], (double)c0);                    // ds_add_f64
+                        atomicAdd(&s_acc3[TILE_N + l], (double)c1);
+                        atomicAdd(&s_acc3[2 * TILE_N + l], (double)c2);
+                    }
                 }
             }
         }
     }
+    return inv;
 }
 template <int MINW>
 __device__ __forceinline__ void g2p_grad2_body(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T,
@@ -1410,19 +1528,22 @@ __device__ __forceinline__ void g2p_grad2_body(SimP S, float* fr_cur, float* Gn_
         if (wg != (int)blockIdx.x) un = unit_load(T, wg);
         if (un.a.z == -2) continue;
         if (un.a.z >= 0) {
-            const PairCtx pc = pair_ctx(un);
+            const PairCtx pc = unit_ctx(un);
             const int4 it = pc.it;
             const TileO to = tile_origin(it.x, S.nb);
-            const int tofs = pc.ti * 3 * TILE_N;
-            const int i = tid & (HALF - 1);
+            const int tofs = pc.ti * 3 * TILE_N;                 // (floats / doubles of a pair's tiles, words of a quad's one)
+            const int i = pc.i;
             const int s = it.y + (i < it.z ? i : 0);
             const int nbr_entry = neighbour_entry(T.blk_slot, S.nb, it.x);      // (with the particle loads: one hop) tile load + shell hand-over
             const int u0 = cur.used[s];
             const float4 a00 = cur.A0[s];
-            g2p_grad_load_tile2(to, S, g_out, V.store, nbr_entry, pc);
-            if (pc.live) for (int l = pc.t0; l < 3 * TILE_N; l += pc.nth) s_acc3[tofs + l] = 0.0;
-            __syncthreads();
+            // a quad's wave keeps v_out where its accumulators will be (g2p_grad_particle2): four tiles of each do not fit side by side
+            float* gt = pc.quad ? (float*)s_acc3 + tofs : s_tile3 + tofs;
+            g2p_grad_load_tile2(to, S, g_out, V.store, nbr_entry, pc, gt);
+            if (!pc.quad && pc.live) for (int l = pc.t0; l < 3 * TILE_N; l += pc.nth) s_acc3[tofs + l] = 0.0;
+            unit_sync(pc.quad);
             TL(S, 2);
+            float inv = 1.f;
             {
                 const bool used = i < it.z && u0 != 0;
                 float x[3] = {0.f, 0.f, 0.f};
@@ -1432,19 +1553,30 @@ __device__ __forceinline__ void g2p_grad2_body(SimP S, float* fr_cur, float* Gn_
                 const bool inside = used && stencil_inside(st, S.n);
                 const int lb = inside ? tile_base(to, st) : -1;
                 const bool live = lb >= 0;
-                if (__any(live)) g2p_grad_particle2<MINW>(S, Gn, Gc, s, live ? lb : 0, st, live, tofs);     // wave-uniform: empty waves skip the loops
+                if (__any(live)) {                               // wave-uniform: empty waves skip the loops
+                    if (pc.quad) inv = g2p_grad_particle2<MINW, true>(S, Gn, Gc, s, live ? lb : 0, st, live, tofs, gt);
+                    else g2p_grad_particle2<MINW, false>(S, Gn, Gc, s, live ? lb : 0, st, live, tofs, gt);
+                } else if (pc.quad && pc.live) {                 // nothing scattered: the hand-over must not see v_out as sums
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    for (int l = pc.t0; l < 3 * TILE_N; l += pc.nth) ((int*)s_acc3)[tofs + l] = 0;
+                }
                 if (used && !live) {
                     if (inside) atomicAdd(slow, 1);
                     g2p_grad_slot_global(S, cur, Gn, Gc, s, V, gg_out, agent, f, GS);
                 }
             }
             TL(S, 5);
-            __syncthreads();
+            unit_sync(pc.quad);
             TL(S, 6);
-            if (pc.live) for (int l = pc.t0; l < TILE_N; l += pc.nth)
+            if (pc.quad) {
+                const int* acc = (const int*)s_acc3 + tofs;
+                if (pc.live) for (int l = pc.t0; l < TILE_N; l += pc.nth)
+                    tile_handover<3>(S, slab, pc.slab, gg_out, GS, to, nbr_entry, l,
+                                     make_float4((float)acc[l] * inv, (float)acc[TILE_N + l] * inv, (float)acc[2 * TILE_N + l] * inv, 0.f), S.wt & 4);
+            } else if (pc.live) for (int l = pc.t0; l < TILE_N; l += pc.nth)
                 tile_handover<3>(S, slab, pc.slab, gg_out, GS, to, nbr_entry, l,
                                  make_float4((float)s_acc3[tofs + l], (float)s_acc3[tofs + TILE_N + l], (float)s_acc3[tofs + 2 * TILE_N + l], 0.f), S.wt & 4);
-            __syncthreads();
+            unit_sync(pc.quad);
             TL(S, 7);
         } else {
             const int s = un.a.y + tid;
@@ -1935,13 +2067,13 @@ __device__ __forceinline__ void p2g_grad_body(SimP S, float* fr_cur, float* Gn_,
     FrameV cur = frame_view(fr_cur, S.Np);
     FrameV Gn = frame_view(Gn_, S.Np), Gc = frame_view(Gc_, S.Np, S.wt & 8);
     TL(S, 0);
-    Unit un = unit_load(T, blockIdx.x);                       // this workgroup's first unit, asked for together with meta
-    const int n_slots = T.meta[5];
+    Unit un = unit_load<true>(T, blockIdx.x);                       // this workgroup's first unit, asked for together with meta
+    const int n_slots = T.meta[9];
     for (int wg = blockIdx.x; wg < n_slots; wg += gridDim.x) {
-        if (wg != (int)blockIdx.x) un = unit_load(T, wg);
+        if (wg != (int)blockIdx.x) un = unit_load<true>(T, wg);
         if (un.a.z == -2) continue;
         if (un.a.z >= 0) {
-            const PairCtx pc = pair_ctx(un);
+            const PairCtx pc = pair_ctx(un);                     // (the gather kernels walk the pairs-only list: four 4-plane tiles beside the stash would cost a resident workgroup)
             const int4 it = pc.it;
             const TileO to = tile_origin(it.x, S.nb);
             TL(S, 1);
@@ -1950,7 +2082,7 @@ __device__ __forceinline__ void p2g_grad_body(SimP S, float* fr_cur, float* Gn_,
             TL(S, 2);
             // (asking for the particle's state ahead of the tile load and its barrier -- the PRE form of slot_p2g_grad -- was measured:
             // falling 15.8 -> 16.4 us, layer 20.5 -> 21.1, splash 30.0 -> 29.7; the same move pays in k_p2g, where nothing precedes it)
-            const int i = tid & (HALF - 1);
+            const int i = pc.i;
             P2GRaw no_pre;
             if (i < it.z) slot_p2g_grad<true, GENERAL, false>(S, cur, Gn, Gc, it.y + i, T, pool_idx, to, gg_in, slow, agent, inj, f, pc.ti * 4 * TILE_N, 0, no_pre);
             TL(S, 3);
@@ -2077,29 +2209,31 @@ __device__ __forceinline__ int3 block_work(int n, int ITEM_MAX) {
 // (A single workgroup walking thread-contiguous stretches was tried first: 70 us at 128^3 and 420 us at 256^3 -- every load and
 // store instruction of a wave touched 64 different cache lines.)
 #define SORT_BLK_WG 1024
-struct BlkSums { int v[6]; };                 // dense particles, loose particles, items, pairs, singles, occupied blocks
-__device__ __forceinline__ void blk_accumulate(BlkSums& a, int n, int ITEM_MAX, int loose_max) {
+#define NSUM 7
+struct BlkSums { int v[NSUM]; };              // dense particles, loose particles, items, pairs, singles, occupied blocks, small singles (quads)
+__device__ __forceinline__ void blk_accumulate(BlkSums& a, int n, int ITEM_MAX, int loose_max, int quad_max) {
     if (n <= 0) return;
     a.v[5]++;
     if (n <= loose_max) { a.v[1] += n; return; }
     const int3 w = block_work(n, ITEM_MAX);
-    a.v[0] += n; a.v[2] += w.x; a.v[3] += w.y; a.v[4] += w.z;
+    a.v[0] += n; a.v[2] += w.x; a.v[3] += w.y;
+    if (w.z) { if (n <= quad_max) a.v[6]++; else a.v[4]++; }
 }
 // the thread's four block counts and their sums
-__device__ __forceinline__ BlkSums blk_load4(int nblk, int ITEM_MAX, int loose_max, const int* __restrict__ bcnt, int n[4]) {
+__device__ __forceinline__ BlkSums blk_load4(int nblk, int ITEM_MAX, int loose_max, int quad_max, const int* __restrict__ bcnt, int n[4]) {
     const int b0 = blockIdx.x * SORT_BLK_WG + threadIdx.x * 4;
     const int4 n4 = *(const int4*)(bcnt + b0);
     n[0] = n4.x; n[1] = n4.y; n[2] = n4.z; n[3] = n4.w;
-    BlkSums m = {{0, 0, 0, 0, 0, 0}};
+    BlkSums m = {{0, 0, 0, 0, 0, 0, 0}};
 #pragma unroll
-    for (int u = 0; u < 4; u++) if (b0 + u < nblk) blk_accumulate(m, n[u], ITEM_MAX, loose_max);
+    for (int u = 0; u < 4; u++) if (b0 + u < nblk) blk_accumulate(m, n[u], ITEM_MAX, loose_max, quad_max);
     return m;
 }
-// six sums over the 256 threads of the workgroup: exclusive prefix of this thread in ex[], workgroup totals in tot[]
-__device__ __forceinline__ void wg_scan6(const BlkSums& m, int (*sh)[6], int ex[6], int tot[6]) {
+// NSUM sums over the 256 threads of the workgroup: exclusive prefix of this thread in ex[], workgroup totals in tot[]
+__device__ __forceinline__ void wg_scan6(const BlkSums& m, int (*sh)[NSUM], int ex[NSUM], int tot[NSUM]) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #pragma unroll
-    for (int k = 0; k < 6; k++) {
+    for (int k = 0; k < NSUM; k++) {
         int incl = m.v[k];
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
@@ -2108,7 +2242,7 @@ __device__ __forceinline__ void wg_scan6(const BlkSums& m, int (*sh)[6], int ex[
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 6; k++) {
+    for (int k = 0; k < NSUM; k++) {
         int before = 0, all = 0;
 #pragma unroll
         for (int w = 0; w < 4; w++) { const int t = sh[w][k]; all += t; if (w < wave) before += t; }
@@ -2116,35 +2250,36 @@ __device__ __forceinline__ void wg_scan6(const BlkSums& m, int (*sh)[6], int ex[
     }
     __syncthreads();
 }
-__global__ __launch_bounds__(256) void k_sort_blk_partial(int nblk, int ITEM_MAX, int loose_max, const int* __restrict__ bcnt, int* partial) {
-    __shared__ int sh[4][6];
-    int n[4], ex[6], tot[6];
-    const BlkSums m = blk_load4(nblk, ITEM_MAX, loose_max, bcnt, n);
+__global__ __launch_bounds__(256) void k_sort_blk_partial(int nblk, int ITEM_MAX, int loose_max, int quad_max, const int* __restrict__ bcnt, int* partial) {
+    __shared__ int sh[4][NSUM];
+    int n[4], ex[NSUM], tot[NSUM];
+    const BlkSums m = blk_load4(nblk, ITEM_MAX, loose_max, quad_max, bcnt, n);
     wg_scan6(m, sh, ex, tot);
-    if (threadIdx.x < 6) partial[blockIdx.x * 8 + threadIdx.x] = tot[threadIdx.x];
+    if (threadIdx.x < NSUM) partial[blockIdx.x * 8 + threadIdx.x] = tot[threadIdx.x];
 }
 // (one launch in which every workgroup goes over the whole array again instead of reading partial sums was tried: the six sums need
 // a division per block, 35 us for the launch against 18 for these two)
-__global__ __launch_bounds__(256) void k_sort_blk_final(int nblk, int ncell, int ITEM_MAX, int loose_max, const int* __restrict__ bcnt, int* cnt, int* start,
+__global__ __launch_bounds__(256) void k_sort_blk_final(int nblk, int ncell, int ITEM_MAX, int loose_max, int quad_max, const int* __restrict__ bcnt, int* cnt, int* start,
                                                         const int* __restrict__ partial, int4* items, int2* pairs, int* singles, int2* blk_first, int4* occ, int* meta) {
-    __shared__ int sh[4][6];
+    __shared__ int sh[4][NSUM];
     const int tid = threadIdx.x;
     // the partials of the workgroups before this one, and of all of them
-    BlkSums pb = {{0, 0, 0, 0, 0, 0}}, pa = {{0, 0, 0, 0, 0, 0}};
+    BlkSums pb = {{0, 0, 0, 0, 0, 0, 0}}, pa = {{0, 0, 0, 0, 0, 0, 0}};
     for (int w = tid; w < (int)gridDim.x; w += 256) {
 #pragma unroll
-        for (int k = 0; k < 6; k++) { const int t = partial[w * 8 + k]; pa.v[k] += t; if (w < (int)blockIdx.x) pb.v[k] += t; }
+        for (int k = 0; k < NSUM; k++) { const int t = partial[w * 8 + k]; pa.v[k] += t; if (w < (int)blockIdx.x) pb.v[k] += t; }
     }
-    int n[4], ex[6], tot[6];
-    const BlkSums m = blk_load4(nblk, ITEM_MAX, loose_max, bcnt, n);
-    int exb[6], before[6], exa[6], total[6];
+    int n[4], ex[NSUM], tot[NSUM];
+    const BlkSums m = blk_load4(nblk, ITEM_MAX, loose_max, quad_max, bcnt, n);
+    int exb[NSUM], before[NSUM], exa[NSUM], total[NSUM];
     wg_scan6(pb, sh, exb, before);
     wg_scan6(pa, sh, exa, total);
     wg_scan6(m, sh, ex, tot);
-    if (blockIdx.x == 0 && tid == 0) { meta[0] = total[2]; meta[1] = total[0]; meta[2] = 0; meta[3] = total[3]; meta[4] = total[4]; meta[6] = total[5]; meta[7] = total[0] + total[1]; }
+    if (blockIdx.x == 0 && tid == 0) { meta[0] = total[2]; meta[1] = total[0]; meta[2] = 0; meta[3] = total[3]; meta[4] = total[4]; meta[6] = total[5]; meta[7] = total[0] + total[1]; meta[8] = total[6]; }
     const int b0 = blockIdx.x * SORT_BLK_WG + tid * 4;
     if (b0 > nblk) return;
     int D = before[0] + ex[0], L = total[0] + before[1] + ex[1], bi = before[2] + ex[2], bm = before[3] + ex[3], bs = before[4] + ex[4], oi = before[5] + ex[5];
+    int bq = total[4] + before[6] + ex[6];                     // the small singles (-> quad units) sit behind the others in `singles`
     int2 bf[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
@@ -2157,7 +2292,7 @@ __global__ __launch_bounds__(256) void k_sort_blk_final(int nblk, int ncell, int
         const int3 w = block_work(nn, ITEM_MAX);
         bf[u] = make_int2(bi, w.x);
         occ[oi++] = make_int4(b, D, nn, 0);
-        if (w.z) singles[bs++] = bi;
+        if (w.z) { if (nn <= quad_max) singles[bq++] = bi; else singles[bs++] = bi; }
         for (int j = 0; j < w.y; j++) pairs[bm++] = make_int2(bi + 2 * j, 2 * j + 1 < w.x ? bi + 2 * j + 1 : -1);
         for (int o = 0; o < nn; o += ITEM_MAX) items[bi++] = make_int4(b, D + o, min(ITEM_MAX, nn - o), 0);
         D += nn;
@@ -2218,28 +2353,45 @@ __global__ __launch_bounds__(256) void k_sort_fill(int nb, const int4* __restric
 // What the substep kernels would otherwise look up through chains of dependent loads, laid out once per sort: the unit list of
 // the particle kernels (struct Unit) and, per active-list entry, the item ranges of its block's 27 neighbours (gather_slabs).
 // (device function: runs in the extra workgroups of k_sort_apply's launch, and alone for the identity order)
-__device__ __forceinline__ void build_units_dev(int gtid, int nth, int nb, int N, int xcd_on, const int4* __restrict__ items, const int2* __restrict__ pairs,
-                                                const int* __restrict__ singles, const int2* __restrict__ blk_first, const int* __restrict__ active,
-                                                int* meta, Unit* units, int units_cap, int2* nbr) {
-    const int tail_start = meta[1], nM = meta[3], nS = meta[4], n_active = meta[2];
-    const int n_pairs = nM + ((nS + 1) >> 1), n_tail = (N - tail_start + WG - 1) / WG;
-    const int n_work = n_pairs + n_tail;
+// One unit list: nS single-item blocks taken two to a pair unit, the nQ behind them in `singles` four to a quad unit.
+__device__ __forceinline__ void build_unit_list(int gtid, int nth, int N, int xcd_on, const int4* __restrict__ items, const int2* __restrict__ pairs,
+                                                const int* __restrict__ singles, int tail_start, int nM, int nS, int nQ, int* n_slots_out, UnitRec* units, int units_cap) {
+    const int n_pairs = nM + ((nS + 1) >> 1), n_quads = (nQ + 3) >> 2, n_tail = (N - tail_start + WG - 1) / WG;
+    const int n_work = n_pairs + n_quads + n_tail;
     const int per_xcd = xcd_on >= 2 ? (((n_work + xcd_on - 1) / xcd_on + 7) >> 3) * xcd_on : (n_work + 7) >> 3;      // slots per XCD
     const int n_slots = per_xcd * 8 < units_cap ? per_xcd * 8 : units_cap;      // (units_cap covers the worst case)
-    if (gtid == 0) meta[5] = n_slots;
+    if (gtid == 0) *n_slots_out = n_slots;
     for (int w = gtid; w < n_slots; w += nth) {
         const int u = xcd_item(w, per_xcd, xcd_on);
-        Unit un;
-        un.a = make_int4(0, 0, -2, 0); un.b = make_int4(0, 0, 0, -1);
+        UnitRec un;
+        un.a = make_int4(0, 0, -2, 0); un.b = un.c = un.d = make_int4(0, 0, 0, -1);
         if (u < n_pairs) {
             int ia, ib, same;
             if (u < nM) { const int2 pr = pairs[u]; ia = pr.x; ib = pr.y; same = 1; }
             else { const int q = 2 * (u - nM); ia = singles[q]; ib = q + 1 < nS ? singles[q + 1] : -1; same = 0; }
             un.a = items[ia]; un.a.w = ia | (same << 30);
             if (ib >= 0) { un.b = items[ib]; un.b.w = ib; }
-        } else if (u < n_work) un.a = make_int4(0, tail_start + (u - n_pairs) * WG, -1, 0);
+        } else if (u < n_pairs + n_quads) {
+            const int q = nS + 4 * (u - n_pairs), nq = min(4, nS + nQ - q);
+            int4* dst[4] = {&un.a, &un.b, &un.c, &un.d};
+            for (int k = 0; k < nq; k++) { const int ii = singles[q + k]; *dst[k] = items[ii]; dst[k]->w = ii; }
+            un.a.w |= QUAD_BIT;
+        } else if (u < n_work) un.a = make_int4(0, tail_start + (u - n_pairs - n_quads) * WG, -1, 0);
         units[w] = un;
     }
+}
+// Two lists.  `units` is what the SCATTER kernels (k_p2g, k_g2p_grad2) walk: with quad units when pairing everything would need more
+// than `quad_min_units` workgroups -- several rounds of the chip's resident ones, which is when halving their number pays (splash:
+// p2g 43 -> 35 us, g2p_grad 45 -> 37); in a single round a quad's longer chain (one wave zeroes and hands over a whole tile) is the
+// launch's critical path instead (falling: +0.3 ... +0.5 us), so there the list is pairs only.  `units_p` is always pairs only, for
+// the GATHER kernels (k_g2p, k_p2g_grad), which quads never helped (k_p2g_grad has no room for four 4-plane tiles beside its stash).
+__device__ __forceinline__ void build_units_dev(int gtid, int nth, int nb, int N, int xcd_on, int quad_min_units, const int4* __restrict__ items, const int2* __restrict__ pairs,
+                                                const int* __restrict__ singles, const int2* __restrict__ blk_first, const int* __restrict__ active,
+                                                int* meta, UnitRec* units, UnitRec* units_p, int units_cap, int2* nbr) {
+    const int tail_start = meta[1], nM = meta[3], nS = meta[4], nQ = meta[8], n_active = meta[2];
+    const bool quads = nM + ((nS + nQ + 1) >> 1) > quad_min_units;
+    build_unit_list(gtid, nth, N, xcd_on, items, pairs, singles, tail_start, nM, quads ? nS : nS + nQ, quads ? nQ : 0, meta + 5, units, units_cap);
+    build_unit_list(gtid, nth, N, xcd_on, items, pairs, singles, tail_start, nM, nS + nQ, 0, meta + 9, units_p, units_cap);
     for (int t = gtid; t < n_active * 27; t += nth) {
         const int e = t / 27, n = t - e * 27, b = active[e];
         const int i2 = b / (nb * nb) + n / 9 - 1, j2 = (b / nb) % nb + (n / 3) % 3 - 1, k2 = b % nb + n % 3 - 1;
@@ -2250,22 +2402,22 @@ __device__ __forceinline__ void build_units_dev(int gtid, int nth, int nb, int N
 }
 __global__ __launch_bounds__(256) void k_build_units(int nb, int N, int xcd_on, const int4* __restrict__ items, const int2* __restrict__ pairs,
                                                      const int* __restrict__ singles, const int2* __restrict__ blk_first, const int* __restrict__ active,
-                                                     int* meta, Unit* units, int units_cap, int2* nbr) {
-    build_units_dev(blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, nb, N, xcd_on, items, pairs, singles, blk_first, active, meta, units, units_cap, nbr);
+                                                     int* meta, UnitRec* units, UnitRec* units_p, int units_cap, int2* nbr) {
+    build_units_dev(blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, nb, N, xcd_on, 0x7fffffff, items, pairs, singles, blk_first, active, meta, units, units_p, units_cap, nbr);
 }
 
 // The permutation itself, one pass: slot s of the old order goes to d = start[key] + rank -- its particle id, material record and
 // all 25 planes.  Reads are coalesced, writes land near s (the old order was sorted too: particles move less than a cell between
 // sorts), so the write combining of the L2 sees them almost in order.  (Round 1: index kernel, copy of the id table, gather kernel.)
 #define SORT_UNIT_WGS 128
-struct UnitsArgs { int* bcnt; int nb, xcd_on; const int4* items; const int2* pairs; const int* singles; const int2* blk_first; const int* active; int* meta; Unit* units; int units_cap; int2* nbr; };
+struct UnitsArgs { int* bcnt; int nb, xcd_on, quad_min_units; const int4* items; const int2* pairs; const int* singles; const int2* blk_first; const int* active; int* meta; UnitRec* units; UnitRec* units_p; int units_cap; int2* nbr; };
 __global__ __launch_bounds__(256) void k_sort_apply(int N, size_t Np, int n_pwg, const int* __restrict__ key, const int* __restrict__ rank,
                                                     const int* __restrict__ start, const int* __restrict__ pid_old, int* pid_new, int* slot_of_pid,
                                                     const float4* __restrict__ pinfo, float4* info_new, float* dst_, float* src_, UnitsArgs U) {
     if ((int)blockIdx.x >= n_pwg) {          // (independent of the permutation: both only need what the scan and k_sort_fill left)
         for (int i = (blockIdx.x - n_pwg) * 256 + threadIdx.x; i <= U.nb * U.nb * U.nb; i += SORT_UNIT_WGS * 256) U.bcnt[i] = 0;      // block counts: ready for the next sort
-        build_units_dev((blockIdx.x - n_pwg) * 256 + threadIdx.x, SORT_UNIT_WGS * 256, U.nb, N, U.xcd_on, U.items, U.pairs, U.singles, U.blk_first, U.active, U.meta,
-                        U.units, U.units_cap, U.nbr);
+        build_units_dev((blockIdx.x - n_pwg) * 256 + threadIdx.x, SORT_UNIT_WGS * 256, U.nb, N, U.xcd_on, U.quad_min_units, U.items, U.pairs, U.singles, U.blk_first, U.active, U.meta,
+                        U.units, U.units_p, U.units_cap, U.nbr);
         return;
     }
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2683,7 +2835,7 @@ struct FeEngine {
     float* grads = nullptr;                                 // 3 x (GR_WORDS*Np + Np) floats: ring of two + 1 spare
     float* grad_ptr[3] = {nullptr, nullptr, nullptr};
     // particle orders ("tables"): id 0 = identity; id 1+f = order produced by the sort at frame f
-    struct Table { int* pid = nullptr; float4* info = nullptr; int2* pairs = nullptr; int* singles = nullptr; int4* items = nullptr; int* meta = nullptr; int2* blk_first = nullptr; int* active = nullptr; int* blk_slot = nullptr; int* slot_of_pid = nullptr; Unit* units = nullptr; int2* nbr = nullptr; };
+    struct Table { int* pid = nullptr; float4* info = nullptr; int2* pairs = nullptr; int* singles = nullptr; int4* items = nullptr; int* meta = nullptr; int2* blk_first = nullptr; int* active = nullptr; int* blk_slot = nullptr; int* slot_of_pid = nullptr; UnitRec* units = nullptr; UnitRec* units_p = nullptr; int2* nbr = nullptr; };
     int loose_max = 0;                                      // blocks with <= this many particles get no work item (option "loose_max")
     std::vector<int> gs_host; bool gs_host_valid = false;   // host copy of gs_flag, refreshed once per backward sweep
     float4* gstore = nullptr; int* gs_flag = nullptr; int gs_cap = 0;     // forward grid store (see GridStore)
@@ -2694,6 +2846,8 @@ struct FeEngine {
     std::vector<int> tbl_of_frame;                          // [L+1]
     int gtbl[2] = {-1, -1};                                 // order of each adjoint ring slot; -1 = all zero
     int p2g_grad_waves = 4;                                 // occupancy target of the SVD-free p2g_grad build (tuning)
+    int quad_min_units = 2048;                              // option "quad_min_units": quad units only when pairs alone would be more workgroups than this (build_units_dev)
+    int quad = QUAD_MAX;                                    // option "quad_max": single-item blocks of at most this many particles go four to a workgroup (0: never)
     int g2p_grad_v = 3;                                     // build of the G2P adjoint: 3 = split passes, x offset rolled (k_g2p_grad2<4>, default); 2 = split, unrolled completely (<3>); 1 = fused rolled loop (k_g2p_grad)
     int item_max = ITEM_MAX_CAP;                            // particles per work item (<= ITEM_MAX_CAP = one half workgroup)
     int sort_interval = 10;                                 // K: re-sort every K substeps (0 = never: global path only)
@@ -2742,7 +2896,7 @@ struct FeEngine {
     float*& spare_frame() { return frame_ptr[L + 1]; }
     float* grad(int f) { return grad_ptr[f & 1]; }
     size_t grad_words() const { return (size_t)GR_WORDS * Np + Np; }
-    TableP tableP(int id) const { TableP t; t.pid_of_slot = tables[id].pid; t.info = tables[id].info; t.meta = tables[id].meta; t.active = tables[id].active; t.blk_slot = tables[id].blk_slot; t.units = tables[id].units; t.units_cap = (int)units_cap; t.nbr = tables[id].nbr; return t; }
+    TableP tableP(int id) const { TableP t; t.pid_of_slot = tables[id].pid; t.info = tables[id].info; t.meta = tables[id].meta; t.active = tables[id].active; t.blk_slot = tables[id].blk_slot; t.units = tables[id].units; t.units_p = tables[id].units_p; t.units_cap = (int)units_cap; t.nbr = tables[id].nbr; return t; }
     const int* pid_of(int f) const { return tables[tbl_of_frame[f]].pid; }
 };
 
@@ -2862,7 +3016,7 @@ int check_async(FeEngine* h);
 
 void build_units(FeEngine* h, FeEngine::Table& t) {
     hipLaunchKernelGGL(k_build_units, dim3(256), dim3(256), 0, h->stream, h->nb, h->N, h->S.xcd, t.items, t.pairs, t.singles, t.blk_first, t.active, t.meta,
-                       t.units, (int)h->units_cap, t.nbr);
+                       t.units, t.units_p, (int)h->units_cap, t.nbr);
 }
 int ensure_table(FeEngine* h, int id) {
     if ((int)h->tables.size() <= id) h->tables.resize(id + 1);
@@ -2873,9 +3027,9 @@ int ensure_table(FeEngine* h, int id) {
     else if (dev_alloc(h, &t.info, h->Np)) return 1;
     // (pairs: a block with k > 1 items makes ceil(k / 2) pairs -- two from three -- so the bound is the item count, not half of it)
     if (dev_alloc(h, &t.pairs, h->items_cap) || dev_alloc(h, &t.singles, h->items_cap)) return 1;
-    if (dev_alloc(h, &t.pid, h->Np) || dev_alloc(h, &t.items, h->items_cap) || dev_alloc(h, &t.meta, 8) ||
+    if (dev_alloc(h, &t.pid, h->Np) || dev_alloc(h, &t.items, h->items_cap) || dev_alloc(h, &t.meta, 16) ||
         dev_alloc(h, &t.blk_first, nblk) || dev_alloc(h, &t.active, nblk) || dev_alloc(h, &t.blk_slot, nblk) || dev_alloc(h, &t.slot_of_pid, h->Np) ||
-        dev_alloc(h, &t.units, h->units_cap, false) || dev_alloc(h, &t.nbr, nblk * 27, false)) return 1;
+        dev_alloc(h, &t.units, h->units_cap, false) || dev_alloc(h, &t.units_p, h->units_cap, false) || dev_alloc(h, &t.nbr, nblk * 27, false)) return 1;
     HIPCK(h, hipMemsetAsync(t.blk_slot, 0xff, sizeof(int) * nblk, h->stream));
     if (id == 0) build_units(h, t);                            // the identity order: no items, every slot on the tail
     return 0;
@@ -2904,6 +3058,7 @@ int grad_order_for_frame(FeEngine* h, int f) {
 // (round 2 switched the blocks flagged "static" here, two launches; an order's active list is now recognised by its own blk_slot)
 int use_static_table(FeEngine*, int) { return 0; }
 
+inline int quad_max(FeEngine* h) { return h->quad; }
 // counting sort of frame f by 4^3 block; the new order becomes table 1+f
 int sort_frame(FeEngine* h, int f) {
     const int id_new = 1 + f, id_old = h->tbl_of_frame[f];
@@ -2921,15 +3076,15 @@ int sort_frame(FeEngine* h, int f) {
                        tn.active, tn.meta, tn.blk_slot);
     if (fine) { prof_end(h); prof_begin(h, KID_SORT_SCAN); }
     const int blk_wgs = (nblk + 1 + SORT_BLK_WG - 1) / SORT_BLK_WG;
-    hipLaunchKernelGGL(k_sort_blk_partial, dim3(blk_wgs), dim3(256), 0, h->stream, nblk, h->item_max, h->loose_max, h->sort_bcnt, h->sort_partial);
-    hipLaunchKernelGGL(k_sort_blk_final, dim3(blk_wgs), dim3(256), 0, h->stream, nblk, ncell, h->item_max, h->loose_max, h->sort_bcnt, h->sort_cnt, h->sort_start, h->sort_partial,
+    hipLaunchKernelGGL(k_sort_blk_partial, dim3(blk_wgs), dim3(256), 0, h->stream, nblk, h->item_max, h->loose_max, quad_max(h), h->sort_bcnt, h->sort_partial);
+    hipLaunchKernelGGL(k_sort_blk_final, dim3(blk_wgs), dim3(256), 0, h->stream, nblk, ncell, h->item_max, h->loose_max, quad_max(h), h->sort_bcnt, h->sort_cnt, h->sort_start, h->sort_partial,
                        tn.items, tn.pairs, tn.singles, tn.blk_first, h->sort_occ, tn.meta);
     if (fine) { prof_end(h); prof_begin(h, KID_SORT_ACTIVE); }
     hipLaunchKernelGGL(k_sort_fill, dim3(SORT_FILL_WGS + (nblk + 255) / 256), dim3(256), 0, h->stream, h->nb, h->sort_occ, tn.meta, h->sort_cnt, h->sort_bcnt, h->sort_start, tn.active, tn.blk_slot);
     if (fine) { prof_end(h); prof_begin(h, KID_SORT_PERM); }
     // re-sorting a frame that is already in this table's order reads the id table it rewrites: stage it
     int* pid_dst = id_old == id_new ? h->sort_pid : tn.pid;
-    const UnitsArgs U = {h->sort_bcnt, h->nb, h->S.xcd, tn.items, tn.pairs, tn.singles, tn.blk_first, tn.active, tn.meta, tn.units, (int)h->units_cap, tn.nbr};
+    const UnitsArgs U = {h->sort_bcnt, h->nb, h->S.xcd, h->quad_min_units, tn.items, tn.pairs, tn.singles, tn.blk_first, tn.active, tn.meta, tn.units, tn.units_p, (int)h->units_cap, tn.nbr};
     hipLaunchKernelGGL(k_sort_apply, dim3(n_pwg + SORT_UNIT_WGS), dim3(256), 0, h->stream, h->N, (size_t)h->Np, n_pwg, h->sort_key, h->sort_rank, h->sort_start,
                        h->tables[id_old].pid, pid_dst, tn.slot_of_pid, h->pinfo, tn.info, h->spare_frame(), h->frame(f), U);
     if (id_old == id_new) HIPCK(h, hipMemcpyAsync(tn.pid, h->sort_pid, sizeof(int) * h->Np, hipMemcpyDeviceToDevice, h->stream));
@@ -3361,7 +3516,7 @@ void fe_destroy(FeEngine* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     smoke_destroy(h);
     for (auto& t : h->tables) { if (t.info && t.info != h->pinfo) (void)hipFree(t.info);
-        for (void* q : {(void*)t.pairs, (void*)t.singles, (void*)t.pid, (void*)t.items, (void*)t.meta, (void*)t.blk_first, (void*)t.active, (void*)t.blk_slot, (void*)t.slot_of_pid, (void*)t.units, (void*)t.nbr}) if (q) (void)hipFree(q); }
+        for (void* q : {(void*)t.pairs, (void*)t.singles, (void*)t.pid, (void*)t.items, (void*)t.meta, (void*)t.blk_first, (void*)t.active, (void*)t.blk_slot, (void*)t.slot_of_pid, (void*)t.units, (void*)t.units_p, (void*)t.nbr}) if (q) (void)hipFree(q); }
     void* ptrs[] = {h->frames, h->grads, h->sort_key, h->sort_rank, h->sort_cnt, h->sort_start, h->sort_bcnt, h->sort_partial, h->sort_occ, h->sort_pid, h->slow_dev, h->frame_slow_dev, h->gstore, h->gs_flag, h->gs_live, h->ent_touched, h->ent_dirty, h->cur_live, h->slab, h->effs_dev, h->pinfo, h->pool_idx, h->g_in, h->g_out, h->gg_out, h->gg_in,
                     h->blk_flag, h->blk_list, h->blk_count, h->err_dev, h->stage_r, h->stage_i, h->node_mark, h->counters,
                     h->tgt, h->chamfer, h->step_loss, h->body_start, h->body_pids, h->bodies_dev, h->statics_dev, h->collector_dev, h->hit_dev, h->hit_list, h->hit_count, h->node_work, h->node_work_count};
@@ -3420,6 +3575,8 @@ int fe_set_option(FeEngine* h, const char* name, double value) {
     if (!std::strcmp(name, "prof_fine")) { h->prof_fine = value != 0; return 0; }
     if (!std::strcmp(name, "xcd_map")) { if (value < 0) FAIL(h, "xcd_map must be >= 0"); h->S.xcd = (int)value; return 0; }
     if (!std::strcmp(name, "write_through")) { h->S.wt = (int)value; return 0; }
+    if (!std::strcmp(name, "quad_min_units")) { h->quad_min_units = (int)value; return 0; }
+    if (!std::strcmp(name, "quad_max")) { if (value < 0 || value > QUAD_MAX) FAIL(h, "quad_max must be in [0, 64]"); h->quad = (int)value; return 0; }
     if (!std::strcmp(name, "wgrid_cap")) { if (value < 64) { h->err = "wgrid_cap must be >= 64"; return 1; } h->wgrid_cap = (int)value; return 0; }
     if (!std::strcmp(name, "threads")) return 0;             // oracle-only tunable
     FAIL(h, std::string("unknown option: ") + name);
@@ -3987,10 +4144,11 @@ int fe_get_work_stats(FeEngine* h, int f, long long out[16]) {
     for (int i = 0; i < 16; i++) out[i] = 0;
     const int t = h->tbl_of_frame[f];
     if (t < 0 || t >= (int)h->tables.size() || !h->tables[t].meta) return 0;
-    int meta[8];
+    int meta[16];
     HIPCK(h, hipMemcpyAsync(meta, h->tables[t].meta, sizeof(meta), hipMemcpyDeviceToHost, h->stream));
     HIPCK(h, hipStreamSynchronize(h->stream));
     for (int i = 0; i < 5; i++) out[i] = meta[i];
+    out[4] += meta[8]; out[14] = meta[8];                     // single-item blocks: the small ones (four to a quad unit) are counted apart
     out[13] = meta[7] - meta[1];                              // particles of loose blocks: slots [tail_start, tail_start + this)
     std::vector<int4> items((size_t)std::max(meta[0], 0));
     if (!items.empty()) {
