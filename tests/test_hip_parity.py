@@ -238,21 +238,23 @@ def test_fast_particles_leave_their_tiles(hiplib, oracle64):
     assert g.get_stats(20)['n_slow_path'] > 0
 
 
-@pytest.mark.parametrize('loose_max', [0, 12])
+@pytest.mark.parametrize('loose_max,quads', [(0, 0), (0, 1), (12, 0), (12, 1)])
 @pytest.mark.parametrize('grid_store', [1, 0])
-def test_scattered_droplets_and_untouched_blocks(hiplib, oracle64, grid_store, loose_max):
+def test_scattered_droplets_and_untouched_blocks(hiplib, oracle64, grid_store, loose_max, quads):
     """Water that has come apart: droplets all over the box (most blocks of the active list get nothing, most items hold one or two
     particles) plus a dense clump, some of it fast enough to leave its tiles between two sorts (slow-path deposits into blocks of the
     active list: the dirty marks).  The grid kernels work on the marked entries only -- forward, backward from the stored grid
     (grid_store 1) and backward from the recompute (grid_store 0) must match the oracle, and so must the work list the stats report.
-    loose_max 12: blocks with up to 12 particles get no work item, their particles are worked on in cell order by the global path."""
+    loose_max 12: blocks with up to 12 particles get no work item, their particles are worked on in cell order by the global path.
+    quads 1: the single-item blocks of at most 64 particles go four to a workgroup, one wave and one fixed-point LDS tile each (the
+    scatter kernels' quad units; by default only orders with more than 2048 workgroups of pairs get them)."""
     rng = np.random.RandomState(3)
     n_drop, n_clump = 1500, 2500
     sc = S.water_block(n_grid=64, n_particles=n_drop + n_clump, lo=0.40, hi=0.52)
     sc['x'][:n_drop] = S.f32(rng.uniform(0.08, 0.92, (n_drop, 3)))
     sc['v'] = S.f32(rng.normal(0, 1.0, (n_drop + n_clump, 3)))
     sc['v'][n_drop:] = S.f32(rng.normal(0, 0.2, (n_clump, 3)) + [12.0, -9.0, 4.0])       # the clump drifts 1.5 cells between two sorts
-    g = S.make_engine(hiplib, sc, options={'sort_interval': 20, 'grid_store': grid_store, 'loose_max': loose_max})
+    g = S.make_engine(hiplib, sc, options={'sort_interval': 20, 'grid_store': grid_store, 'loose_max': loose_max, 'quad_min_units': 0 if quads else 1 << 30})
     o = S.make_engine(oracle64, sc)
     cot = S.random_cotangent(sc['N'])
     sa, ga = S.run_forward_backward(g, 30, cot)
@@ -266,9 +268,38 @@ def test_scattered_droplets_and_untouched_blocks(hiplib, oracle64, grid_store, l
     assert ws['n_items'] == sum(ws['items_by_size'].values()) and ws['n_multi_item_workgroups'] + ws['n_single_item_blocks'] >= ws['n_occupied_blocks']
     if loose_max == 0:
         assert ws['items_by_size']['1'] + ws['items_by_size']['2-4'] > 800 and ws['n_active_blocks'] > 2 * ws['n_occupied_blocks']
+        assert ws['n_quad_items'] > 800                          # (classified either way; `quads` decides whether the unit list uses them)
     else:                                                      # the droplets' blocks are loose: no item holds 12 particles or fewer
         assert ws['items_by_size']['1'] + ws['items_by_size']['2-4'] + ws['items_by_size']['5-8'] == 0 and ws['n_loose_particles'] > 1000
         assert ws['tail_start'] + ws['n_loose_particles'] == sc['N']
+
+
+def test_quad_units_agree_with_pair_units(hiplib):
+    """The same spray stepped with quad units (fixed-point LDS accumulators, quantum 2^-24 of a wave's largest contribution) and with
+    pair units (fp64 accumulators): states and adjoints agree to fp32 rounding.  Velocities span five orders of magnitude inside
+    single items, which is what a shared fixed-point scale has to survive."""
+    rng = np.random.RandomState(11)
+    N = 6000
+    sc = S.water_block(n_grid=64, n_particles=N, lo=0.3, hi=0.7)
+    sc['x'] = S.f32(rng.uniform(0.1, 0.9, (N, 3)))
+    sc['x'][:3000] = S.f32(0.5 + rng.normal(0, 0.045, (3000, 3)))         # a cloud dense enough for items of 10-60 particles
+    sc['v'] = S.f32(rng.normal(0, 1.0, (N, 3)) * 10.0 ** rng.uniform(-4, 0.5, (N, 1)))
+    cot = S.random_cotangent(N, seed=5)
+    out = {}
+    for quads in (0, 1):
+        g = S.make_engine(hiplib, sc, options={'sort_interval': 5, 'quad_min_units': 0 if quads else 1 << 30})
+        out[quads] = S.run_forward_backward(g, 12, cot)
+        ws = g.get_work_stats(0)
+        assert ws['n_quad_items'] > 1000 and ws['items_by_size']['9-16'] + ws['items_by_size']['17-32'] + ws['items_by_size']['33-64'] > 30, ws
+    (a, ga), (b, gb) = out[0], out[1]
+    assert (a['used'] == b['used']).all()
+    print('MEASURED quad vs pair units: x', np.abs(a['x'] - b['x']).max(), 'v', S.rel_l2(a['v'], b['v']), 'C', S.rel_l2(a['C'], b['C']),
+          {k: S.rel_l2(ga[k], gb[k]) for k in ga})
+    # measured: x one ulp (1.2e-7), v 2.7e-6, C 1.8e-5, gx 9.1e-5, gv 2.0e-5, gC 1.5e-5, gF 1.8e-5 (twelve substeps; the fast particles'
+    # shell and slow-path deposits are fp32 global atomics in both runs, i.e. two pair-unit runs differ at this level too)
+    assert np.abs(a['x'] - b['x']).max() <= 2.5e-7 and S.rel_l2(a['v'], b['v']) <= 1e-5 and S.rel_l2(a['C'], b['C']) <= 6e-5
+    for k in ('gx', 'gv', 'gC', 'gF'):
+        assert S.rel_l2(ga[k], gb[k]) <= 3e-4, (k, S.rel_l2(ga[k], gb[k]))
 
 
 def test_dense_scene_with_small_items(hiplib, oracle64):

@@ -2,7 +2,7 @@
 
 Every case draws its own grid size, particle count (down to a handful, never a multiple of the wave size on purpose), material mix,
 cluster layout (dense clumps, droplets, particles hugging the domain walls), velocities (slow, or fast enough to leave tiles between
-two sorts), sort interval, work-item size and grid-store mode.  What the hand-written scenes of test_hip_parity.py pin one by one, these
+two sorts), sort interval, work-item size, grid-store mode, loose blocks and quad units.  What the hand-written scenes of test_hip_parity.py pin one by one, these
 cases cross: the work list with one-particle items next to full ones, tiles at the edge of the grid, marked and unmarked blocks of
 the active list, slow-path deposits, the recompute path of the backward pass."""
 import os
@@ -53,6 +53,8 @@ def random_scene(seed):
             'item_max': int(rng.choice([64, 96, 128]))}
     n_sub = int(rng.choice([5, 12, 21]))
     opts['loose_max'] = int(rng.choice([0, 0, 6, 20, 48]))         # (drawn last: the scenes of the earlier rounds stay what they were)
+    opts['quad_min_units'] = int(rng.choice([0, 0, 2048]))         # quad units whenever blocks are small enough / only on big orders (the default)
+    opts['quad_max'] = int(rng.choice([64, 64, 20]))
     return sc, opts, n_sub, liquid_only
 
 
