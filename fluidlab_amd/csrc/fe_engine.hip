@@ -260,7 +260,8 @@ struct SegScan { float f1, f2, f4, f8; bool tail; };
 
 // must be executed by all 64 lanes of the wave
 __device__ __forceinline__ SegScan seg_setup(int key) {
-    const int lane = threadIdx.x & 63;
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));          // (opaque: what is derived from it below must not become a loop invariant held -- spilled -- across the kernel)
     const int prev = __shfl_up(key, 1, 64);
     const bool is_head = (lane & 15) == 0 || key != prev;
     const unsigned long long mask = __ballot(is_head);
@@ -469,7 +470,8 @@ __device__ __forceinline__ int stencil_regions(int lb) {
 }
 // lane n < 27: the active-list entry of neighbour block n of `block` (-1 outside the grid / not on the list)
 __device__ __forceinline__ int neighbour_entry(const int* __restrict__ blk_slot, int nb, int block) {
-    const int lane = threadIdx.x & 63;
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));          // (opaque: otherwise the three offsets below are hoisted out of the unit loop and live -- spilled -- across the whole kernel)
     int e = -1;
     if (lane < 27) {
         const int i2 = block / (nb * nb) + lane / 9 - 1, j2 = (block / nb) % nb + (lane / 3) % 3 - 1, k2 = block % nb + lane % 3 - 1;
@@ -504,6 +506,7 @@ __device__ __forceinline__ int tile_region(int t) { return (t + 3) >> 2; }      
 template <int NPL>
 __device__ __forceinline__ void tile_handover(const SimP& S, float4* slab, int item, float* acc, const GridStore& GS, const TileO& to,
                                               int nbr_entry, int l, float4 v, int wt) {
+    asm volatile("" : "+v"(l));             // (opaque, as in neighbour_entry: tz and its region are loop invariants otherwise)
     const int tx = l >> 6, ty = (l >> 3) & 7, tz = l & 7;
     const int e = __shfl(nbr_entry, tile_region(tx) * 9 + tile_region(ty) * 3 + tile_region(tz), 64);
     if ((unsigned)(tx - 1) < (unsigned)SLAB_T && (unsigned)(ty - 1) < (unsigned)SLAB_T && (unsigned)(tz - 1) < (unsigned)SLAB_T)
