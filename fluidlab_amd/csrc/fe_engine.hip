@@ -2214,13 +2214,19 @@ __device__ __forceinline__ int3 block_work(int n, int ITEM_MAX) {
 #define SORT_BLK_WG 1024
 #define NSUM 7
 struct BlkSums { int v[NSUM]; };              // dense particles, loose particles, items, pairs, singles, occupied blocks, small singles (quads)
+// (straight-line selects: with early returns the sums lived in memory -- scratch, then LDS when a seventh one was added -- and the scan
+//  stage took 29 us instead of 18)
 __device__ __forceinline__ void blk_accumulate(BlkSums& a, int n, int ITEM_MAX, int loose_max, int quad_max) {
-    if (n <= 0) return;
-    a.v[5]++;
-    if (n <= loose_max) { a.v[1] += n; return; }
-    const int3 w = block_work(n, ITEM_MAX);
-    a.v[0] += n; a.v[2] += w.x; a.v[3] += w.y;
-    if (w.z) { if (n <= quad_max) a.v[6]++; else a.v[4]++; }
+    const bool occ = n > 0, loose = occ && n <= loose_max, dense = occ && !loose;
+    const int3 w = block_work(n > 0 ? n : 1, ITEM_MAX);
+    const bool small = dense && w.z && n <= quad_max;
+    a.v[5] += occ ? 1 : 0;
+    a.v[1] += loose ? n : 0;
+    a.v[0] += dense ? n : 0;
+    a.v[2] += dense ? w.x : 0;
+    a.v[3] += dense ? w.y : 0;
+    a.v[4] += (dense && w.z && !small) ? 1 : 0;
+    a.v[6] += small ? 1 : 0;
 }
 // the thread's four block counts and their sums
 __device__ __forceinline__ BlkSums blk_load4(int nblk, int ITEM_MAX, int loose_max, int quad_max, const int* __restrict__ bcnt, int n[4]) {
@@ -2258,7 +2264,8 @@ __global__ __launch_bounds__(256) void k_sort_blk_partial(int nblk, int ITEM_MAX
     int n[4], ex[NSUM], tot[NSUM];
     const BlkSums m = blk_load4(nblk, ITEM_MAX, loose_max, quad_max, bcnt, n);
     wg_scan6(m, sh, ex, tot);
-    if (threadIdx.x < NSUM) partial[blockIdx.x * 8 + threadIdx.x] = tot[threadIdx.x];
+#pragma unroll
+    for (int k = 0; k < NSUM; k++) if ((int)threadIdx.x == k) partial[blockIdx.x * 8 + k] = tot[k];      // (static indices: tot[threadIdx.x] sends the sums through memory)
 }
 // (one launch in which every workgroup goes over the whole array again instead of reading partial sums was tried: the six sums need
 // a division per block, 35 us for the launch against 18 for these two)
@@ -2376,9 +2383,10 @@ __device__ __forceinline__ void build_unit_list(int gtid, int nth, int N, int xc
             if (ib >= 0) { un.b = items[ib]; un.b.w = ib; }
         } else if (u < n_pairs + n_quads) {
             const int q = nS + 4 * (u - n_pairs), nq = min(4, nS + nQ - q);
-            int4* dst[4] = {&un.a, &un.b, &un.c, &un.d};
-            for (int k = 0; k < nq; k++) { const int ii = singles[q + k]; *dst[k] = items[ii]; dst[k]->w = ii; }
-            un.a.w |= QUAD_BIT;
+            { const int ii = singles[q]; un.a = items[ii]; un.a.w = ii | QUAD_BIT; }
+            if (nq > 1) { const int ii = singles[q + 1]; un.b = items[ii]; un.b.w = ii; }
+            if (nq > 2) { const int ii = singles[q + 2]; un.c = items[ii]; un.c.w = ii; }
+            if (nq > 3) { const int ii = singles[q + 3]; un.d = items[ii]; un.d.w = ii; }
         } else if (u < n_work) un.a = make_int4(0, tail_start + (u - n_pairs - n_quads) * WG, -1, 0);
         units[w] = un;
     }
