@@ -35,6 +35,7 @@ HBM_COPY_GBS = 6290.0          # measured float4 copy on this part (DESIGN.md se
 # rocprofv3 --pmc passes of THIS command line (`--steps 20 --warmup 5`), sliced by window (scripts/phase_profile.py): the traffic of
 # the roofline kernel is read for the same windows it is timed in, or not at all
 PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')
+ROCPROF_TIMED = os.path.join(ROOT, 'profiles', 'r03_kernel_stats_timed_region.csv')
 # fixed substep windows of the evolving block, comparable across --steps and across rounds (window w = substeps [100 w, 100 w + 100))
 PHASES = {'falling': (5, 11), 'splash': (26, 34), 'layer': (80, 90)}
 
@@ -259,11 +260,19 @@ def run_single(args):
         tw = fold_windows(rec, w0, w1)
         kern = tw['kernels']
         dom = max((k for k in kern if kern[k]['alg_bytes'] > 0), key=lambda k: kern[k]['avg_us'] * kern[k]['launches'])
-        traffic = None
+        traffic, rocprof_us = None, None
         try:                                              # PMC passes of this very command line, same windows (else: no claim)
             pj = json.load(open(PMC_TRAFFIC))
             if pj['steps'] == args.steps and pj['warmup'] == args.warmup:
                 traffic = int(pj['timed_region']['kernels'][dom]['traffic_bytes'])
+                # the committed rocprofv3 --kernel-trace of the same command, same windows (scripts/gpu_profile.sh wrote both files)
+                import csv
+                pre = {'p2g': 'k_p2g<true', 'g2p': 'k_g2p<', 'g2p_grad': 'k_g2p_grad', 'p2g_grad': 'k_p2g_grad', 'grid_op': 'k_grid<', 'grid_op_grad': 'k_grid_grad'}[dom]
+                tot = cnt = 0
+                for r in csv.DictReader(open(ROCPROF_TIMED)):
+                    if r['Name'].replace('void ', '').startswith(pre):
+                        tot += float(r['TotalDurationNs']); cnt += int(r['Calls'])
+                rocprof_us = round(1e-3 * tot / cnt, 3) if cnt else None
         except Exception:
             pass
         b_pair = 524 * n_used + 204 * tw['nc_mean']
@@ -274,6 +283,10 @@ def run_single(args):
         out['roofline'] = {'bound': 'hbm', 'kernel': dom, 'achieved': kern[dom]['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                            'frac': round(kern[dom]['GBps'] / HBM_PEAK_GBS, 4), 'frac_of_measured_copy': round(kern[dom]['GBps'] / HBM_COPY_GBS, 4),
                            'traffic': traffic, 'alg_bytes_per_launch': kern[dom]['alg_bytes'], 'avg_launch_us': kern[dom]['avg_us'],
+                           # (an event bracket serialises the launches around it: the profiled windows run ~13 % slower than the timed ones, so
+                           #  `frac` is the conservative figure; the kernel's own begin-to-end time in the committed trace is given beside it)
+                           'rocprof_avg_launch_us': rocprof_us,
+                           'frac_rocprof': round(kern[dom]['alg_bytes'] / (rocprof_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if rocprof_us else None,
                            'windows': f'HIP events over every second timed window (substeps {w0 * CHUNK}..{w1 * CHUNK}) of an untimed replay; bytes from those windows\' Nc'}
         out['pair_roofline'] = {'alg_bytes_per_pair': int(b_pair), 'achieved_GBps': round(b_pair * value / 1e9, 1),
                                 'frac': round(b_pair * value / 1e9 / HBM_PEAK_GBS, 4),
