@@ -3459,6 +3459,7 @@ FeEngine* fe_create(const FeConfig* cfg) {
     if (cfg->device < 0 || cfg->device >= ndev) { g_create_err = "HIP device ordinal out of range"; return nullptr; }
     FeEngine* h = new FeEngine();
     if (const char* e = std::getenv("FE_SORT_INTERVAL")) h->sort_interval = std::atoi(e);     // tuning experiments (the option of the same name wins)
+    if (const char* e = std::getenv("FE_QUAD_MIN_UNITS")) h->quad_min_units = std::atoi(e);   // (task-level A/B of the quad units: scripts/run_envs.py)
     if (const char* e = std::getenv("FE_G2P_GRAD_V")) h->g2p_grad_v = std::atoi(e);           // (the parity suite is run once per build of the G2P adjoint)
     h->cfg = *cfg; h->N = cfg->n_particles; h->L = cfg->max_substeps_local; h->n = cfg->n_grid; h->nb = cfg->n_grid / 4;
     h->Np = ((h->N + 63) / 64) * 64; if (h->Np == 0) h->Np = 64;
