@@ -259,7 +259,10 @@ def run_single(args):
         rec = probe_pass(elib, n_probe, range(w0, w1), profiled)
         tw = fold_windows(rec, w0, w1)
         kern = tw['kernels']
-        dom = max((k for k in kern if kern[k]['alg_bytes'] > 0), key=lambda k: kern[k]['avg_us'] * kern[k]['launches'])
+        # the kernel with the largest share of the profiled time; p2g and g2p_grad tie to within a per cent on this workload and would swap
+        # places from run to run: among those within 2 % of the largest share, the one furthest below the roofline is reported
+        share = {k: kern[k]['avg_us'] * kern[k]['launches'] for k in kern if kern[k]['alg_bytes'] > 0}
+        dom = min((k for k in share if share[k] >= 0.98 * max(share.values())), key=lambda k: kern[k]['GBps'])
         traffic, rocprof_us = None, None
         try:                                              # PMC passes of this very command line, same windows (else: no claim)
             pj = json.load(open(PMC_TRAFFIC))
