@@ -732,7 +732,7 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
             const int aofs = pc.ti * 4 * TILE_N;                 // (doubles of a pair's tile, words of a quad's)
             TL(S, 1);
             const int nbr_entry = neighbour_entry(T.blk_slot, S.nb, it.x);      // (in flight together with the particle loads)
-            if (pc.quad) { if (pc.live) for (int l = pc.t0; l < 4 * TILE_N; l += pc.nth) ((int*)s_acc)[aofs + l] = 0; }
+            if (pc.quad) { if (pc.live) for (int l = pc.t0; l < TILE_N; l += 64) ((int4*)((int*)s_acc + aofs))[l] = make_int4(0, 0, 0, 0); }      // (16 bytes per lane and store)
             else if (pc.live) for (int l = pc.t0; l < 4 * TILE_N; l += pc.nth) s_acc[aofs + l] = 0.0;
             unit_sync(pc.quad);
             FixScale fs_p = {1.f, 1.f}, fs_m = {1.f, 1.f};
@@ -788,9 +788,19 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
             // k_grid sums, per node, the slabs of the (at most 8) blocks whose tiles reach it, in a fixed order.
             if (pc.quad) {
                 const int* acc = (const int*)s_acc + aofs;
-                if (pc.live) for (int l = pc.t0; l < TILE_N; l += pc.nth)
-                    tile_handover<4>(S, G.slab, pc.slab, G.g_in, GS, to, nbr_entry, l,
-                                     make_float4((float)acc[l] * fs_p.inv, (float)acc[TILE_N + l] * fs_p.inv, (float)acc[2 * TILE_N + l] * fs_p.inv, (float)acc[3 * TILE_N + l] * fs_m.inv), S.wt & 1);
+                if (pc.live) {                                   // one wave, eight nodes per lane: all the tile reads first, then the stores
+#pragma unroll 1
+                    for (int k0 = 0; k0 < TILE_N / 64; k0 += 4) {         // (four at a time: eight spill)
+                        float4 v[4];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int l = pc.t0 + 64 * (k0 + k);
+                            v[k] = make_float4((float)acc[l] * fs_p.inv, (float)acc[TILE_N + l] * fs_p.inv, (float)acc[2 * TILE_N + l] * fs_p.inv, (float)acc[3 * TILE_N + l] * fs_m.inv);
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; k++) tile_handover<4>(S, G.slab, pc.slab, G.g_in, GS, to, nbr_entry, pc.t0 + 64 * (k0 + k), v[k], S.wt & 1);
+                    }
+                }
             } else if (pc.live) for (int l = pc.t0; l < TILE_N; l += pc.nth)
                 tile_handover<4>(S, G.slab, pc.slab, G.g_in, GS, to, nbr_entry, l,
                                  make_float4((float)s_acc[aofs + l], (float)s_acc[aofs + TILE_N + l], (float)s_acc[aofs + 2 * TILE_N + l], (float)s_acc[aofs + 3 * TILE_N + l]), S.wt & 1);
@@ -1573,9 +1583,16 @@ __device__ __forceinline__ void g2p_grad2_body(SimP S, float* fr_cur, float* Gn_
             TL(S, 6);
             if (pc.quad) {
                 const int* acc = (const int*)s_acc3 + tofs;
-                if (pc.live) for (int l = pc.t0; l < TILE_N; l += pc.nth)
-                    tile_handover<3>(S, slab, pc.slab, gg_out, GS, to, nbr_entry, l,
-                                     make_float4((float)acc[l] * inv, (float)acc[TILE_N + l] * inv, (float)acc[2 * TILE_N + l] * inv, 0.f), S.wt & 4);
+                if (pc.live) {                                   // (as in k_p2g: the reads of the wave's eight nodes per lane first)
+                    float4 v[TILE_N / 64];
+#pragma unroll
+                    for (int k = 0; k < TILE_N / 64; k++) {
+                        const int l = pc.t0 + 64 * k;
+                        v[k] = make_float4((float)acc[l] * inv, (float)acc[TILE_N + l] * inv, (float)acc[2 * TILE_N + l] * inv, 0.f);
+                    }
+#pragma unroll
+                    for (int k = 0; k < TILE_N / 64; k++) tile_handover<3>(S, slab, pc.slab, gg_out, GS, to, nbr_entry, pc.t0 + 64 * k, v[k], S.wt & 4);
+                }
             } else if (pc.live) for (int l = pc.t0; l < TILE_N; l += pc.nth)
                 tile_handover<3>(S, slab, pc.slab, gg_out, GS, to, nbr_entry, l,
                                  make_float4((float)s_acc3[tofs + l], (float)s_acc3[tofs + TILE_N + l], (float)s_acc3[tofs + 2 * TILE_N + l], 0.f), S.wt & 4);
