@@ -563,7 +563,8 @@ class Engine:
         d['items_by_size'] = {k: int(out[5 + i]) for i, k in enumerate(('1', '2-4', '5-8', '9-16', '17-32', '33-64', '65-128'))}
         d['n_occupied_blocks'] = int(out[12])
         d['n_loose_particles'] = int(out[13])            # particles of blocks without a work item (engine option loose_max)
-        d['n_quad_items'] = int(out[14])                 # single-item blocks of <= quad_max particles: four to a workgroup, one wave each
+        d['n_quad_items'] = int(out[14])                 # single-item blocks of <= quad_max particles: four to a workgroup, one wave each ...
+        d['n_quad_units'] = int(out[15])                 # ... when the order's unit list holds quad units at all (engine option quad_min_units): how many
         return d
 
     def timer_start(self):

@@ -351,6 +351,9 @@ struct PairCtx {
 //   a.z == -1: a tail unit (slots from a.y);  a.z == -2: nothing
 #define QUAD_BIT (1 << 29)
 #define QUAD_MAX 64
+#ifndef QH
+#define QH 2
+#endif
 struct UnitRec { int4 a, b, c, d; };         // in memory
 struct Unit { int4 a, b, q; };               // as a wave holds it: q = the descriptor of this wave's number (its own item in a quad)
 __device__ __forceinline__ PairCtx pair_ctx(const Unit& u) {
@@ -404,6 +407,15 @@ __device__ __forceinline__ PairCtx unit_ctx(const Unit& u) {
 __device__ __forceinline__ void unit_sync(bool quad) {
     if (quad) asm volatile("" ::: "memory");
     else __syncthreads();
+}
+// A quad unit ends without a workgroup barrier (its waves own their tiles), so a wave that is done with its quad may enter the
+// workgroup's next unit while the others still scatter into or hand over theirs -- harmless when that unit is a quad again (the
+// same wave-owned tiles) or a tail unit (no LDS), a race when it is a PAIR unit, whose tiles are shared by waves and overlap the
+// quads' bytes.  With the default blocked-cyclic unit mapping a workgroup's unit numbers only grow (pairs, then quads, then
+// tails), but `xcd_map` 0 / 1 and odd grid sizes interleave them.  Uniform per workgroup: every wave walks the same units.
+__device__ __forceinline__ void unit_enter(bool quad, bool& prev_quad) {
+    if (prev_quad && !quad) __syncthreads();
+    prev_quad = quad;
 }
 // slot w of the unit list (read ahead of meta for the first one: the list is padded to units_cap)
 template <bool GATHER = false>
@@ -655,6 +667,9 @@ __device__ __forceinline__ void p2g_scatter_global(const SimP& S, const P2GPrep&
 // scan on the scaled values and adds the run totals, rounded to nearest, with ds_add_u32.  The quantum is 2^-24 M, an fp32 ulp of the
 // largest contribution (what fp32 atomics into the node would lose, and independent of the order of the adds); the hand-over converts
 // back with the exact inverse.  Momentum / adjoint planes and the mass plane have scales of their own.
+// fix_nonfinite: fmaxf ignores a NaN and (int)rintf(NaN) is 0, so a particle state that has blown up would vanish from the sums of a
+// quad unit while the fp64 tiles of a pair unit -- and the reference's atomics, mpm:346-353 -- carry it to the grid.  A wave that sees
+// a non-finite bound therefore hands its whole tile over as NaN: the divergence stays visible in losses and gradients.
 __device__ __forceinline__ float wave_max(float x) {           // all 64 lanes; x >= 0
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) x = fmaxf(x, __shfl_xor(x, o, 64));
@@ -722,11 +737,13 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
     TL(S, 0);
     Unit un = unit_load(T, blockIdx.x);                       // this workgroup's first unit, asked for together with meta
     const int n_slots = T.meta[5];
+    bool prev_quad = false;                                   // (unit_enter)
     for (int wg = blockIdx.x; wg < n_slots; wg += gridDim.x) {
         if (wg != (int)blockIdx.x) un = unit_load(T, wg);
         if (un.a.z == -2) continue;
         if (un.a.z >= 0) {
             const PairCtx pc = unit_ctx(un);
+            unit_enter(pc.quad, prev_quad);
             const int4 it = pc.it;
             const TileO to = tile_origin(it.x, S.nb);
             const int aofs = pc.ti * 4 * TILE_N;                 // (doubles of a pair's tile, words of a quad's)
@@ -771,6 +788,7 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
                         for (int a = 0; a < 3; a++) bp = fmaxf(bp, fabsf(q.mv[a]) + 2.f * S.dx * (fabsf(q.affine.a[a][0]) + fabsf(q.affine.a[a][1]) + fabsf(q.affine.a[a][2])));
                         fs_p = fix_scale(wave_max(in_tile ? bp : 0.f));
                         fs_m = fix_scale(wave_max(in_tile ? q.m : 0.f));
+                        if (__any(in_tile && !(bp <= 3.4e38f))) fs_p.inv = __int_as_float(0x7fc00000);   // a NaN / Inf state: fmaxf and the int conversion would swallow it -- the tile is handed over as NaN (fix_nonfinite)
                         const float sp = in_tile ? fs_p.s : 1.f;          // (in place -- the registers are all taken --, and only where the tile path uses it)
                         q.m *= in_tile ? fs_m.s : 1.f;
 #pragma unroll
@@ -790,15 +808,15 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
                 const int* acc = (const int*)s_acc + aofs;
                 if (pc.live) {                                   // one wave, eight nodes per lane: all the tile reads first, then the stores
 #pragma unroll 1
-                    for (int k0 = 0; k0 < TILE_N / 64; k0 += 4) {         // (four at a time: eight spill)
-                        float4 v[4];
+                    for (int k0 = 0; k0 < TILE_N / 64; k0 += QH) {
+                        float4 v[QH];
 #pragma unroll
-                        for (int k = 0; k < 4; k++) {
+                        for (int k = 0; k < QH; k++) {
                             const int l = pc.t0 + 64 * (k0 + k);
                             v[k] = make_float4((float)acc[l] * fs_p.inv, (float)acc[TILE_N + l] * fs_p.inv, (float)acc[2 * TILE_N + l] * fs_p.inv, (float)acc[3 * TILE_N + l] * fs_m.inv);
                         }
 #pragma unroll
-                        for (int k = 0; k < 4; k++) tile_handover<4>(S, G.slab, pc.slab, G.g_in, GS, to, nbr_entry, pc.t0 + 64 * (k0 + k), v[k], S.wt & 1);
+                        for (int k = 0; k < QH; k++) tile_handover<4>(S, G.slab, pc.slab, G.g_in, GS, to, nbr_entry, pc.t0 + 64 * (k0 + k), v[k], S.wt & 1);
                     }
                 }
             } else if (pc.live) for (int l = pc.t0; l < TILE_N; l += pc.nth)
@@ -1485,7 +1503,7 @@ __device__ __forceinline__ float g2p_grad_particle2(const SimP& S, const FrameV&
 #pragma unroll
         for (int a = 0; a < 3; a++) b = fmaxf(b, fabsf(qb[a]) + 2.f * (fabsf(qx[a]) + fabsf(qy[a]) + fabsf(qz[a])));
         const FixScale fs = fix_scale(wave_max(live ? b : 0.f));
-        inv = fs.inv;
+        inv = __any(live && !(b <= 3.4e38f)) ? __int_as_float(0x7fc00000) : fs.inv;       // (fix_nonfinite: a blown-up adjoint stays NaN on the grid, as in the fp64 tiles)
 #pragma unroll
         for (int a = 0; a < 3; a++) { qb[a] *= fs.s; qx[a] *= fs.s; qy[a] *= fs.s; qz[a] *= fs.s; }
     }
@@ -1537,11 +1555,13 @@ __device__ __forceinline__ void g2p_grad2_body(SimP S, float* fr_cur, float* Gn_
     TL(S, 0);
     Unit un = unit_load(T, blockIdx.x);                       // this workgroup's first unit, asked for together with meta
     const int n_slots = T.meta[5];
+    bool prev_quad = false;                                   // (unit_enter)
     for (int wg = blockIdx.x; wg < n_slots; wg += gridDim.x) {
         if (wg != (int)blockIdx.x) un = unit_load(T, wg);
         if (un.a.z == -2) continue;
         if (un.a.z >= 0) {
             const PairCtx pc = unit_ctx(un);
+            unit_enter(pc.quad, prev_quad);
             const int4 it = pc.it;
             const TileO to = tile_origin(it.x, S.nb);
             const int tofs = pc.ti * 3 * TILE_N;                 // (floats / doubles of a pair's tiles, words of a quad's one)
@@ -2418,6 +2438,7 @@ __device__ __forceinline__ void build_units_dev(int gtid, int nth, int nb, int N
                                                 int* meta, UnitRec* units, UnitRec* units_p, int units_cap, int2* nbr) {
     const int tail_start = meta[1], nM = meta[3], nS = meta[4], nQ = meta[8], n_active = meta[2];
     const bool quads = nM + ((nS + nQ + 1) >> 1) > quad_min_units;
+    if (gtid == 0) meta[10] = quads ? (nQ + 3) >> 2 : 0;         // (fe_get_work_stats: the quad units of this order's scatter list)
     build_unit_list(gtid, nth, N, xcd_on, items, pairs, singles, tail_start, nM, quads ? nS : nS + nQ, quads ? nQ : 0, meta + 5, units, units_cap);
     build_unit_list(gtid, nth, N, xcd_on, items, pairs, singles, tail_start, nM, nS + nQ, 0, meta + 9, units_p, units_cap);
     for (int t = gtid; t < n_active * 27; t += nth) {
@@ -3602,7 +3623,8 @@ int fe_set_option(FeEngine* h, const char* name, double value) {
         h->collide_type = t; return 0;
     }
     if (!std::strcmp(name, "prof_fine")) { h->prof_fine = value != 0; return 0; }
-    if (!std::strcmp(name, "xcd_map")) { if (value < 0) FAIL(h, "xcd_map must be >= 0"); h->S.xcd = (int)value; return 0; }
+    // (run length k rounds the unit list up to a multiple of 8 k slots; units_cap has ~1,040 slots of slack: k <= 64 always fits)
+    if (!std::strcmp(name, "xcd_map")) { if (value < 0 || value > 64) FAIL(h, "xcd_map must be 0 (none), 1 (contiguous eighths) or a run length 2..64"); h->S.xcd = (int)value; return 0; }
     if (!std::strcmp(name, "write_through")) { h->S.wt = (int)value; return 0; }
     if (!std::strcmp(name, "quad_min_units")) { h->quad_min_units = (int)value; return 0; }
     if (!std::strcmp(name, "quad_max")) { if (value < 0 || value > QUAD_MAX) FAIL(h, "quad_max must be in [0, 64]"); h->quad = (int)value; return 0; }
@@ -4177,7 +4199,7 @@ int fe_get_work_stats(FeEngine* h, int f, long long out[16]) {
     HIPCK(h, hipMemcpyAsync(meta, h->tables[t].meta, sizeof(meta), hipMemcpyDeviceToHost, h->stream));
     HIPCK(h, hipStreamSynchronize(h->stream));
     for (int i = 0; i < 5; i++) out[i] = meta[i];
-    out[4] += meta[8]; out[14] = meta[8];                     // single-item blocks: the small ones (four to a quad unit) are counted apart
+    out[4] += meta[8]; out[14] = meta[8]; out[15] = meta[10];                     // single-item blocks: the small ones (four to a quad unit) are counted apart
     out[13] = meta[7] - meta[1];                              // particles of loose blocks: slots [tail_start, tail_start + this)
     std::vector<int4> items((size_t)std::max(meta[0], 0));
     if (!items.empty()) {

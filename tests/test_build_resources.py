@@ -1,0 +1,42 @@
+"""The shipped gfx950 code object must not spill in the kernels a substep pair launches (k_p2g<true,false> had got 20 B
+of scratch per lane back between two commits without anybody noticing).  Reads the AMDGPU metadata notes of the code object inside
+the built libfluidengine_hip.so (scripts/kres.py --lib): no GPU, no recompilation."""
+import importlib.util
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# the launches of one forward + one backward substep with the default options, liquid-only and general (SVD) scenes, and their
+# batched entry points (fe_step_batch)
+NO_SCRATCH = [
+    'k_p2g<true, false>', 'k_grid<false, false, false>', 'k_g2p<false>', 'k_g2p_grad2<4>', 'k_grid_grad<false, false>', 'k_p2g_grad<false, 4>',
+    'k_p2g<true, true>', 'k_p2g_grad<true, 1>', 'k_p2g<false, false>', 'k_p2g<false, true>', 'k_grid<true, false, false>',
+    'k_p2g_b<true, false>', 'k_grid_b<false, false, false>', 'k_g2p_b<false>', 'k_g2p_grad2_b<4>', 'k_grid_grad_b<false, false>', 'k_p2g_grad_b<false, 4>',
+    'k_sort_count', 'k_sort_blk_partial', 'k_sort_blk_final', 'k_sort_fill', 'k_sort_apply', 'k_perm_reorder',
+]
+# occupancy the launch bounds promise: VGPRs per lane at most 512 / waves per SIMD
+MAX_VGPR = {'k_p2g<true, false>': 128, 'k_g2p<false>': 128, 'k_g2p_grad2<4>': 128, 'k_p2g_grad<false, 4>': 128, 'k_grid<false, false, false>': 128,
+            'k_grid_grad<false, false>': 128, 'k_p2g<true, true>': 168, 'k_p2g_grad<true, 1>': 168}
+
+
+@pytest.fixture(scope='module')
+def resources():
+    import __graft_entry__ as g
+    g.build()                                                 # (up to date unless the sources changed)
+    spec = importlib.util.spec_from_file_location('kres', os.path.join(ROOT, 'scripts', 'kres.py'))
+    kres = importlib.util.module_from_spec(spec); spec.loader.exec_module(kres)
+    return kres.kernel_resources()
+
+
+def test_substep_kernels_do_not_spill(resources):
+    missing = [k for k in NO_SCRATCH if k not in resources]
+    assert not missing, f'kernels not found in the code object: {missing} (have: {sorted(resources)[:8]} ...)'
+    bad = {k: resources[k] for k in NO_SCRATCH if resources[k]['scratch'] != 0 or resources[k]['vgpr_spills'] != 0}
+    assert not bad, f'scratch / VGPR spills in substep kernels: {bad}'
+
+
+def test_substep_kernels_keep_their_occupancy(resources):
+    over = {k: resources[k]['vgpr'] for k, cap in MAX_VGPR.items() if resources[k]['vgpr'] > cap}
+    assert not over, f'more registers than the occupancy target allows: {over}'

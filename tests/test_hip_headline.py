@@ -1,0 +1,152 @@
+"""Oracle parity at the headline size and in the states bench.py times ("what's missing" 3).
+
+config 2 -- the benchmark's own scene (bench.build_block: water block, 128^3 grid, 200,000 particles, the benchmark's loss):
+  * from rest: 50 forward substeps + the loss + 50 backward substeps on the HIP engine and on the fp64 oracle (mpm:515-552);
+  * in the timed state: the HIP engine runs the scene into the splash (substep 2,600: the water has come apart, the unit list
+    holds quad units by the DEFAULT `quad_min_units` -- nothing forced), that frame seeds a fresh HIP engine and the oracle, and
+    both run 10 forward + 10 backward substeps from it.
+config 3 -- LatteArt at 128^3 with the milk flowing: both engines restart from the HIP state after 100 steps of the demo pour
+  (2,000 milk particles in the coffee) and run one 50-substep chunk through fluidlab's Solver.forward_backward (solver.py:23-59).
+
+Tolerances: the ones of test_hip_parity.py (fp32 engine against the fp64 oracle), bounds set to ~3x what was measured
+(`pytest -s` prints the MEASURED lines; profiles/r04_pytest_gpu_measured.txt).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(__file__))
+import scenarios as S  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+ORACLE_THREADS = 16       # the oracle's particle loops are OpenMP-parallel (fp64 atomics: order noise ~1e-16)
+
+
+def _bench_pass(lib, chunk, frame0=None, threads=None):
+    """bench.window_step on bench.build_block's scene, with the states read back: `chunk` forward substeps from frame 0 (optionally
+    re-seeded with `frame0`), the benchmark's loss on the last frame, `chunk` backward substeps."""
+    import bench
+    eng, sc = bench.build_block(lib, 0, L=chunk)
+    if threads:
+        eng.set_option('threads', threads)
+    if frame0 is not None:
+        eng.set_frame(0, x=frame0['x'], v=frame0['v'], C_=frame0['C'], F=frame0['F'], used=frame0['used'])
+    eng.step(0, 0, chunk, 0)
+    fin = S.get_state(eng, chunk)
+    eng.reset_grad()
+    eng.loss_step_grad(0, chunk, 0, 1.0, 1.0)
+    eng.step_grad(0, 0, chunk, 0)
+    g = dict(zip(('gx', 'gv', 'gC', 'gF'), eng.get_grad(0)))
+    work = eng.get_work_stats(0) if lib.backend.startswith('hip') else None
+    stats = eng.get_stats(chunk)
+    eng.close()
+    return fin, g, work, stats
+
+
+def _compare(tag, a, ga, b, gb, tol):
+    """State of the last frame: max |difference| <= abs + rel * max |oracle| per field (C of a block in free fall is rounding noise
+    around zero: a relative L2 norm means nothing there); adjoints of frame 0: cosine and relative L2."""
+    m = {k: (float(np.abs(a[k].astype(np.float64) - b[k]).max()), float(np.abs(b[k]).max()), S.rel_l2(a[k], b[k])) for k in 'xvCF'}
+    mg = {k: (S.cosine(ga[k], gb[k]), S.rel_l2(ga[k], gb[k])) for k in ('gx', 'gv', 'gC', 'gF')}
+    print(f'MEASURED {tag}: ' + ' '.join(f'{k} max|d| {v[0]:.2e} (|{k}|max {v[1]:.2e}) relL2 {v[2]:.2e}' for k, v in m.items()) + ' | '
+          + ' '.join(f'{k} cos 1-{1 - v[0]:.1e} relL2 {v[1]:.2e}' for k, v in mg.items()))
+    assert (a['used'] == b['used']).all()
+    for k in 'xvCF':
+        assert np.isfinite(a[k]).all(), k
+        ab, rl = tol[k]
+        assert m[k][0] <= ab + rl * m[k][1], (k, m[k])
+    assert m['x'][2] <= tol['x_l2'], m['x']
+    for k in ('gx', 'gv', 'gC', 'gF'):
+        assert np.isfinite(ga[k]).all() and np.abs(gb[k]).max() > 0, k
+        assert mg[k][0] >= tol['g_cos'] and mg[k][1] <= tol['g_l2'], (k, mg[k])
+
+
+def test_config2_water_block_128_matches_the_oracle(hiplib, oracle64):
+    """The benchmark scene from rest, 50 forward substeps + bench's loss + 50 backward substeps (mpm:515-552), HIP against the
+    fp64 oracle: x, v, C, F of frame 50 and all four adjoints of frame 0."""
+    a, ga, work, st = _bench_pass(hiplib, 50)
+    b, gb, _, _ = _bench_pass(oracle64, 50, threads=ORACLE_THREADS)
+    assert st['n_used'] == 200000 and work['n_items'] > 1000
+    _compare('config2 from rest, 50+50', a, ga, b, gb,
+             dict(x=(1e-6, 0), x_l2=1e-6, v=(1e-4, 1e-4), C=(2e-4, 1e-3), F=(1e-5, 0), g_cos=0.99999, g_l2=1e-3))
+
+
+def test_config2_splash_state_with_quad_units_matches_the_oracle(hiplib, oracle64):
+    """Parity in the state that decides the benchmark's `value`: the scene is run on the HIP engine to substep 2,600 (the splash:
+    > 2,048 pair units, so the sort lays out quad units by the default options), that frame seeds a fresh HIP engine and the fp64
+    oracle, 10 forward + 10 backward substeps on each.  `n_quad_units > 0` proves the quad path (fixed-point tiles) is what ran."""
+    import bench
+    eng, _ = bench.build_block(hiplib, 0, L=100)
+    for _ in range(26):
+        bench.window_step(eng, 100, backward=False)
+    frame = S.get_state(eng, 0)
+    eng.close()
+    assert (frame['used'] == 1).all() and np.isfinite(frame['x']).all()
+    a, ga, work, st = _bench_pass(hiplib, 10, frame0=frame)
+    b, gb, _, _ = _bench_pass(oracle64, 10, frame0=frame, threads=ORACLE_THREADS)
+    print('MEASURED splash work list:', work, 'touched nodes', st['n_cells_touched'])
+    assert work['n_quad_units'] > 0 and work['n_quad_items'] > 4000, work
+    assert st['n_cells_touched'] > 150000
+    _compare('config2 splash (quad units), 10+10', a, ga, b, gb,
+             dict(x=(2e-6, 0), x_l2=1e-6, v=(1e-4, 1e-4), C=(1e-3, 1e-3), F=(1e-5, 0), g_cos=0.99999, g_l2=3e-3))
+
+
+def test_config3_latteart_128_backward_with_milk_flowing(hiplib, oracle32):
+    """Config 3's backward where the two fluids interact: the demo pour runs 100 steps (1,000 substeps, 2,000 milk particles
+    injected into the coffee) on the HIP engine, both engines restart from that state (particles, nozzle pose, injector act_id)
+    and run ONE 50-substep chunk through Solver.forward_backward (solver.py:23-59): loss, action gradient, position adjoint."""
+    from fluidlab_amd.envs import make
+    from fluidlab_amd.optimizer.policies import ActionsPolicy
+    from fluidlab_amd.optimizer.solver import Solver
+    H, T0 = 5, 100
+    base = dict(quality=2, particle_density=4e6, n_pool=60000, max_substeps_local=50, ckpt_dest='cpu')
+
+    env = make('LatteArt-v0', seed=0, engine_lib=hiplib, loss=False, **base)
+    te = env.taichi_env
+    table = env.demo_policy()
+    te.apply_agent_action_p(table.get_actions_p())
+    for i in range(T0):
+        te.step(table.get_action_v(i))
+    state = te.get_state()['state']
+    milk = te.simulator.engine.get_mat() == S.MILK
+    te.simulator.engine.close()
+    pos = np.asarray(state['agent'][0][:3], np.float64)        # the nozzle where the pour left it: the chunk starts there
+    acts = np.asarray(table.actions_v[T0:T0 + H], np.float64)
+
+    def run(lib):
+        env = make('LatteArt-v0', seed=0, engine_lib=lib, loss=True, horizon=H, horizon_action=H, **base)
+        te = env.taichi_env
+        n = te.simulator.n_particles
+        if not lib.backend.startswith('hip'):
+            te.simulator.engine.set_option('threads', ORACLE_THREADS)
+        rng = np.random.RandomState(3)
+        tgt = (np.array([0.5, 0.62, 0.5]) + rng.normal(0, 0.03, (H, n, 3))).astype(np.float32)
+        te.loss.set_target({'x': tgt})
+        scale_p = np.asarray(te.agent.effectors[0].action_scale_p, np.float64)[:3]
+        pol = ActionsPolicy(np.vstack([acts, (pos / scale_p)[None, :]]))
+        pol.freeze_till = 0
+        info, grad = Solver(env, None, None).forward_backward(state, pol, H, H)
+        gx = te.simulator.engine.get_grad(0)[0]
+        fin = S.get_state(te.simulator.engine, 10 * H)           # (the chunk's last frame is still in the window after the reverse sweep)
+        te.simulator.engine.close()
+        return info['loss'], np.asarray(grad, np.float64), gx.astype(np.float64), fin, n
+
+    la, ga, xa, fa, n = run(hiplib)
+    lb, gb, xb, fb, _ = run(oracle32)
+    used0, used1 = state['used'] > 0, fa['used'] > 0
+    milk0 = int((used0 & milk).sum())
+    print('MEASURED config3 chunk with milk flowing: milk particles at the start', milk0, 'injected in the chunk', int(used1.sum() - used0.sum()),
+          'loss', la, lb, 'action-grad cos', S.cosine(ga, gb), 'relL2', S.rel_l2(ga, gb), 'x_bar[0] cos', S.cosine(xa, xb), 'relL2', S.rel_l2(xa, xb),
+          'x relL2', S.rel_l2(fa['x'][used1], fb['x'][used1]))
+    assert n > 250000 and milk0 >= 1900 and used1.sum() - used0.sum() == 2 * 10 * H
+    assert np.array_equal(fa['used'], fb['used'])
+    assert S.rel_l2(fa['x'][used1], fb['x'][used1]) <= 1e-5
+    assert np.isfinite(ga).all() and np.isfinite(xa).all() and ga.shape == (H + 1, 3)
+    assert abs(la - lb) <= 1e-4 * abs(lb)
+    assert np.abs(gb).max() > 0 and S.cosine(ga, gb) >= 0.9999 and S.rel_l2(ga, gb) <= 1e-3
+    assert np.abs(xb).max() > 0 and S.cosine(xa, xb) >= 0.9999 and S.rel_l2(xa, xb) <= 1e-3
+    # the adjoint reaches the milk that was already in the cup: the interaction the config is named for
+    assert np.abs(xb[used0 & milk]).max() > 0 and np.abs(xb[used0 & ~milk]).max() > 0
