@@ -37,7 +37,7 @@ HBM_COPY_GBS = 6290.0          # measured float4 copy on this part (DESIGN.md se
 PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')
 ROCPROF_TIMED = os.path.join(ROOT, 'profiles', 'r03_kernel_stats_timed_region.csv')
 # fixed substep windows of the evolving block, comparable across --steps and across rounds (window w = substeps [100 w, 100 w + 100))
-PHASES = {'falling': (5, 11), 'splash': (26, 34), 'layer': (80, 90)}
+PHASES = {'falling': (5, 11), 'impact': (11, 18), 'splash': (26, 34), 'layer': (80, 90)}
 
 # algorithmic bytes per launch (DESIGN.md "Roofline accounting"; N = used particles, Nc = touched nodes).
 # They sum to SURVEY 8d's B_fwd = 216 N + 72 Nc and B_bwd = 308 N + 132 Nc.

@@ -556,7 +556,7 @@ class Engine:
         return {k: getattr(st, k) for k, _ in FeStats._fields_}
 
     def get_work_stats(self, f):
-        out = (C.c_longlong * 16)()
+        out = (C.c_longlong * 24)()
         self._ck(self.lib.fe_get_work_stats(self.h, int(f), out))
         keys = ('n_items', 'tail_start', 'n_active_blocks', 'n_multi_item_workgroups', 'n_single_item_blocks')
         d = {k: int(out[i]) for i, k in enumerate(keys)}
@@ -565,6 +565,9 @@ class Engine:
         d['n_loose_particles'] = int(out[13])            # particles of blocks without a work item (engine option loose_max)
         d['n_quad_items'] = int(out[14])                 # single-item blocks of <= quad_max particles: four to a workgroup, one wave each ...
         d['n_quad_units'] = int(out[15])                 # ... when the order's unit list holds quad units at all (engine option quad_min_units): how many
+        d['n_scatter_units'], d['n_gather_units'] = int(out[16]), int(out[17])     # work units of the two unit lists: the workgroups of a scatter / gather launch that have something to do
+        d['packed'] = bool(out[18])                      # the scatter list has no idle halves (engine options pack_units, quad_fit)
+        d['n_leftover_items'] = int(out[19]) + int(out[20])
         return d
 
     def timer_start(self):

@@ -45,6 +45,7 @@ struct Plane {
 // same kernel reads -- the new particle state, the adjoint frame, the slabs -- can go through to memory while the kernel is still
 // computing.  A buffer store through a descriptor over the plane's base, with the plane offset + slot as the 32-bit offset.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x3 __attribute__((ext_vector_type(3)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t wt_rsrc(void* base) { return __builtin_amdgcn_make_buffer_rsrc(base, 0, -1, 0x00020000); }
 __device__ __forceinline__ void wt_store16(void* base, unsigned byte_off, float4 v) {
     const u32x4 u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
@@ -139,6 +140,7 @@ struct SimP {
     int N, Np, n, nb;
     int ncell;                               // nb^3 * 64: plane stride of the SoA accumulator grids
     int xcd;                                 // option "xcd_map": consecutive work items on the same XCD (shared L2)
+    int wsort;                               // option "wave_sort": the scatter kernels regroup their lanes by stencil base before the scan (wave_sort_dest)
     int wt;                                  // option "write_through": bulk outputs as sc1 stores (see wt_store16); bit 0 p2g, 1 g2p, 2 g2p_grad, 3 p2g_grad
     float dx, inv_dx, dt, stress_scale;     // stress_scale = -dt * p_vol * 4 * inv_dx^2 (mpm:343)
     float g[3];
@@ -298,6 +300,33 @@ __device__ __forceinline__ void seg_scan3(const SegScan& sc, float& a, float& b,
                  SEG_ROW("%0", "row_shr:8", "%6") SEG_ROW("%1", "row_shr:8", "%6") SEG_ROW("%2", "row_shr:8", "%6")
                  : "+v"(a), "+v"(b), "+v"(c) : "v"(sc.f1), "v"(sc.f2), "v"(sc.f4), "v"(sc.f8));
 }
+
+// -----------------------------------------------------------------------------------------
+// Lanes regrouped by stencil base inside the wave (option "wave_sort", round 4).
+// The scan merges ADJACENT lanes with equal keys, and adjacent they are right after a sort.  Then the particles move: a few substeps
+// later a cell's particles sit in the wave as  a a b a b b a b  -- host-side count on the benchmark block (scripts/run_stats.py, runs
+// = LDS atomics per node and value): 40.6k runs on a fresh order, 111k five substeps later, 129k after nine, where the block hits the
+// floor; 38k / 85k / 108k while it falls.  ds_add_f64 goes at ~2.6 lane-operations per clock and CU, and with every second lane a
+// run of its own the scatter kernels are bound by it: k_p2g 32.5 us with a sort every 10 substeps, 22.3 us with one every substep
+// (k_g2p_grad 33.5 / 23.4; on the falling block 23.4 / 19.7) -- but a sort is 60 us.  Regrouping the 64 lanes of the wave by their
+// CURRENT key before the scan brings the runs back to 60k / 64k (48k / 51k falling) for ~250 instructions per wave: the rank of
+// every lane among the wave's (key, lane) pairs from 64 cross-lane reads, then one ds_permute per value the scatter loop consumes.
+// A wave whose keys are still in order (a fresh sort, an item of one cell) skips all of it.
+// -----------------------------------------------------------------------------------------
+__device__ __forceinline__ bool wave_needs_sort(int key) {       // all 64 lanes; wave-uniform result
+    const int prev = __shfl_up(key, 1, 64);
+    return __any((threadIdx.x & 63) != 0 && prev > key);
+}
+// byte address (for ds_permute) of the lane this lane's values go to: its rank among the wave's (key, lane) pairs.  0 <= key < 2^20.
+__device__ __forceinline__ int wave_sort_dest(int key) {
+    const unsigned kl = ((unsigned)key << 6) | (threadIdx.x & 63);
+    int rank = 0;
+#pragma unroll
+    for (int j = 0; j < 64; j++) rank += ((unsigned)__builtin_amdgcn_readlane((int)kl, j) < kl) ? 1 : 0;
+    return rank << 2;
+}
+__device__ __forceinline__ void wave_send(int dest, float& v) { v = __int_as_float(__builtin_amdgcn_ds_permute(dest, __float_as_int(v))); }
+__device__ __forceinline__ void wave_send(int dest, int& v) { v = __builtin_amdgcn_ds_permute(dest, v); }
 
 struct TableP {
     const int*  pid_of_slot;   // [Np]
@@ -460,7 +489,10 @@ __device__ void effector_move(const EffP& e, int f) {
 
 // Per-frame store of the forward grid (summed (p, m) and v_out of every static active block), so that the backward
 // pass can skip the recompute of P2G + grid_op when the frame had no slow-path particle (gs_flag[f] == 1).
-struct GridStore { float4* data; int* flag; int cap;         // data: [(L+1) * cap * 128] float4, 64 (p,m) then 64 v_out per block
+// A block's record in the store: 64 float4 (p, m), then its 64 v_out PACKED at 12 bytes per node (round 3: float4 with w unused --
+// a quarter of what k_grid writes there and of what the adjoint's tile load reads back): GS_BLK float4 units = 1,792 bytes.
+#define GS_BLK 112
+struct GridStore { float4* data; int* flag; int cap;         // data: [(L+1) * cap * GS_BLK] float4
     // Which entries of the order's active list got anything this substep.  The list holds every block a tile may reach (27 per
     // occupied block); what the particles actually reach is 40-60 % of it (water flying apart: 9.6k of 23.4k blocks), and the
     // grid kernels are rounds of a dependent chain per entry.  The scatter kernel marks the entries it deposits into -- every
@@ -506,10 +538,19 @@ __device__ __forceinline__ void mark_dirty(const GridStore& GS, const int* __res
     if (e >= 0) GS.dirty[e] = GS.stamp;
 }
 
-// one node of a slab (the slab index is wave-uniform: the descriptor of the write-through form is built over the slab itself)
+// one node of a slab (the slab index is wave-uniform: the descriptor of the write-through form is built over the slab itself).
+// NPL = 4: (p, m) of k_p2g, one float4 per node.  NPL = 3: the adjoint d v_out of k_g2p_grad, PACKED at 12 bytes per node (2.6 KB per
+// slab instead of 3.4: round 3 stored a float4 whose w was padding, a quarter of what the kernel hands over and k_grid_grad gathers).
+// Both kinds live in the same buffer at the same slab stride (they are never alive at the same time).
+template <int NPL>
 __device__ __forceinline__ void slab_store(float4* slab, int item, int l, float4 v, int wt) {
     float4* base = slab + (size_t)item * SLAB_N;
-    if (wt) wt_store16(base, (unsigned)l * 16u, v); else base[l] = v;
+    if (NPL == 4) { if (wt) wt_store16(base, (unsigned)l * 16u, v); else base[l] = v; }
+    else {
+        const u32x3 u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z)};
+        if (wt) __builtin_amdgcn_raw_buffer_store_b96(u, wt_rsrc(base), l * 12, 0, 16);               // aux 16 = sc1
+        else __builtin_amdgcn_raw_buffer_store_b96(u, wt_rsrc(base), l * 12, 0, 0);
+    }
 }
 __device__ __forceinline__ int tile_region(int t) { return (t + 3) >> 2; }        // tile index 0 -> block B-1, 1..4 -> B, 5..7 -> B+1
 // Tile node l of a finished scatter tile: the inner 6^3 go to the item's slab; a shell node that received something is added to
@@ -522,7 +563,7 @@ __device__ __forceinline__ void tile_handover(const SimP& S, float4* slab, int i
     const int tx = l >> 6, ty = (l >> 3) & 7, tz = l & 7;
     const int e = __shfl(nbr_entry, tile_region(tx) * 9 + tile_region(ty) * 3 + tile_region(tz), 64);
     if ((unsigned)(tx - 1) < (unsigned)SLAB_T && (unsigned)(ty - 1) < (unsigned)SLAB_T && (unsigned)(tz - 1) < (unsigned)SLAB_T)
-        slab_store(slab, item, ((tx - 1) * SLAB_T + (ty - 1)) * SLAB_T + (tz - 1), v, wt);
+        slab_store<NPL>(slab, item, ((tx - 1) * SLAB_T + (ty - 1)) * SLAB_T + (tz - 1), v, wt);
     else if (e >= 0 && (v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f)) {
         float* dst = acc + cell_addr(to.ox + tx, to.oy + ty, to.oz + tz, S.nb);
         unsafeAtomicAdd(dst, v.x); unsafeAtomicAdd(dst + S.ncell, v.y); unsafeAtomicAdd(dst + 2 * S.ncell, v.z);
@@ -667,13 +708,26 @@ __device__ __forceinline__ void p2g_scatter_global(const SimP& S, const P2GPrep&
 // scan on the scaled values and adds the run totals, rounded to nearest, with ds_add_u32.  The quantum is 2^-24 M, an fp32 ulp of the
 // largest contribution (what fp32 atomics into the node would lose, and independent of the order of the adds); the hand-over converts
 // back with the exact inverse.  Momentum / adjoint planes and the mass plane have scales of their own.
-// fix_nonfinite: fmaxf ignores a NaN and (int)rintf(NaN) is 0, so a particle state that has blown up would vanish from the sums of a
+// fix_nonfinite: fmaxf ignores a NaN and fix_round(NaN) is 0, so a particle state that has blown up would vanish from the sums of a
 // quad unit while the fp64 tiles of a pair unit -- and the reference's atomics, mpm:346-353 -- carry it to the grid.  A wave that sees
 // a non-finite bound therefore hands its whole tile over as NaN: the divergence stays visible in losses and gradients.
 __device__ __forceinline__ float wave_max(float x) {           // all 64 lanes; x >= 0
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) x = fmaxf(x, __shfl_xor(x, o, 64));
     return x;
+}
+// round to nearest into the fixed-point word.  FIX_RPI: v_cvt_rpi_i32_f32 = floor(x + 0.5) in ONE instruction where rintf + the
+// conversion are two (108 / 81 of them per lane in the scatter loops of a quad unit); ties go up instead of to even, which is as
+// good a rounding for a sum of ~64 terms.
+#ifndef FIX_RPI
+#define FIX_RPI 0
+#endif
+__device__ __forceinline__ int fix_round(float c) {
+#if FIX_RPI
+    int r; asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(c)); return r;
+#else
+    return (int)rintf(c);
+#endif
 }
 struct FixScale { float s, inv; };
 __device__ __forceinline__ FixScale fix_scale(float M) {       // M wave-uniform, >= 0
@@ -687,7 +741,22 @@ __device__ __forceinline__ FixScale fix_scale(float M) {       // M wave-uniform
 // stencil base (seg_scan) and the last lane of each run adds the total into the LDS accumulators: fp64, or -- QUAD, `q` scaled by
 // the caller -- fixed point
 template <bool QUAD>
-__device__ __forceinline__ void p2g_scatter_tile(const SimP& S, const P2GPrep& q, bool in_tile, int lb, int aofs) {
+__device__ __forceinline__ void p2g_scatter_tile(const SimP& S, P2GPrep& q, bool in_tile, int lb, int aofs) {
+    if (S.wsort) {
+        int key = in_tile ? lb : 0x3ff;                        // (lanes without a tile particle go to the end: they add nothing)
+        if (wave_needs_sort(key)) {
+            const int dest = wave_sort_dest(key);
+            wave_send(dest, key);
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                wave_send(dest, q.mv[a]);
+#pragma unroll
+                for (int b = 0; b < 3; b++) { wave_send(dest, q.affine.a[a][b]); wave_send(dest, q.st.w[a][b]); }
+            }
+            wave_send(dest, q.m);
+            in_tile = key != 0x3ff; lb = in_tile ? key : 0;
+        }
+    }
     const SegScan sc = seg_setup(in_tile ? lb : (0x40000000 | (int)threadIdx.x));
     const bool issue = sc.tail && in_tile;
     const float live = in_tile ? 1.f : 0.f;
@@ -713,7 +782,7 @@ __device__ __forceinline__ void p2g_scatter_tile(const SimP& S, const P2GPrep& q
             if (issue) {
 #pragma unroll
                 for (int a = 0; a < 4; a++) {
-                    if (QUAD) atomicAdd((int*)s_acc + aofs + a * TILE_N + l, (int)rintf(c[a]));                // ds_add_u32
+                    if (QUAD) atomicAdd((int*)s_acc + aofs + a * TILE_N + l, fix_round(c[a]));                // ds_add_u32
                     else atomicAdd(&s_acc[aofs + a * TILE_N + l], (double)c[a]);                               // ds_add_f64
                 }
             }
@@ -779,6 +848,7 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
                 }
                 TL(S, 2);
                 const bool in_tile = lb >= 0;
+                if (used && q.inside && !in_tile) { atomicAdd(G.slow, 1); p2g_scatter_global(S, q, G, GS, T.blk_slot); }   // drifted out of the tile (ahead of the tile path, which may pass q on to another lane: wave_sort)
                 // a wave without any particle skips the 27-node scan altogether; the branch is wave-uniform, as the DPP scan requires
                 if (__any(in_tile)) {
                     touch_regions(in_tile ? stencil_regions(lb) : 0, nbr_entry, GS);
@@ -796,7 +866,6 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
                         p2g_scatter_tile<true>(S, q, in_tile, in_tile ? lb : 0, aofs);
                     } else p2g_scatter_tile<false>(S, q, in_tile, in_tile ? lb : 0, aofs);
                 }
-                if (used && q.inside && !in_tile) { atomicAdd(G.slow, 1); p2g_scatter_global(S, q, G, GS, T.blk_slot); }   // drifted out of the tile
                 if (has && !used && !taken && WRITE) unused_particle_fwd(S, cur, nxt, s, T.pid_of_slot[s], pool_idx, agent, inj, f);
             }
             TL(S, 4);
@@ -915,6 +984,7 @@ __device__ __forceinline__ void node_statics_grad(const SimP& S, const StaticsP&
 __device__ __forceinline__ int2 nbr_record(const TableP& T, int e, int lane) {      // (laid out by k_build_units: no detour over the block number)
     return lane < 27 ? T.nbr[e * 27 + lane] : make_int2(0, 0);
 }
+template <int NPL>
 __device__ __forceinline__ float4 gather_slabs(const float4* __restrict__ slab, const int2 mine, int lane) {
     const int o[3] = {lane >> 4, (lane >> 2) & 3, lane & 3};
     // Which items of a block own a slab: the items of a block pair up from its first one, and a pair shares the first one's slab:
@@ -938,15 +1008,22 @@ __device__ __forceinline__ float4 gather_slabs(const float4* __restrict__ slab, 
         // (both shuffles by ALL lanes, whatever `valid` says: a cross-lane read of a lane that sits out returns 0)
         const int f = __shfl(mine.x, nbr, 64), k = __shfl(mine.y, nbr, 64);
         n[c] = valid ? k : 0;
-        a0[c] = valid ? f * SLAB_N + si : 0;
+        a0[c] = valid ? (NPL == 4 ? f * SLAB_N + si : f * (SLAB_N * 16) + si * 12) : 0;      // (element index / byte offset of a packed node)
     }
     // (the loads are unconditional from a clamped, always valid index and masked afterwards: a conditional float4
     // load into an array element ended up in scratch; lanes without a source all read node 0 of slab 0, one broadcast line)
+    const __amdgpu_buffer_rsrc_t rs = wt_rsrc((void*)slab);
+    auto ld = [&](int at) -> float4 {
+        if (NPL == 4) return slab[at];
+        const u32x3 u = __builtin_amdgcn_raw_buffer_load_b96(rs, at, 0, 0);
+        return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), 0.f);
+    };
+    constexpr int STRIDE = NPL == 4 ? SLAB_N : SLAB_N * 16;       // from one slab to the next, in the units of a0
 #pragma unroll
     for (int c = 0; c < 8; c++) {
         const bool h0 = n[c] > 0, h1 = n[c] > 2;
-        const float4 a = slab[h0 ? a0[c] : 0];
-        const float4 b = slab[h1 ? a0[c] + 2 * SLAB_N : 0];
+        const float4 a = ld(h0 ? a0[c] : 0);
+        const float4 b = ld(h1 ? a0[c] + 2 * STRIDE : 0);
         v0[c] = make_float4(h0 ? a.x : 0.f, h0 ? a.y : 0.f, h0 ? a.z : 0.f, h0 ? a.w : 0.f);
         v1[c] = make_float4(h1 ? b.x : 0.f, h1 ? b.y : 0.f, h1 ? b.z : 0.f, h1 ? b.w : 0.f);
     }
@@ -956,7 +1033,7 @@ __device__ __forceinline__ float4 gather_slabs(const float4* __restrict__ slab, 
         acc.x += v0[c].x; acc.y += v0[c].y; acc.z += v0[c].z; acc.w += v0[c].w;
         acc.x += v1[c].x; acc.y += v1[c].y; acc.z += v1[c].z; acc.w += v1[c].w;
         for (int k = 4; k < n[c]; k += 2) {
-            const float4 v = slab[a0[c] + k * SLAB_N];
+            const float4 v = ld(a0[c] + k * STRIDE);
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         }
     }
@@ -1003,7 +1080,7 @@ __device__ __forceinline__ void grid_body(SimP S, TableP T, const float4* __rest
         TL(S, 1);
         float4 gi = make_float4(0.f, 0.f, 0.f, 0.f);
         if (dirty) gi = make_float4(g_in[c], g_in[S.ncell + c], g_in[2 * S.ncell + c], g_in[3 * S.ncell + c]);
-        if (touched) { const float4 t = gather_slabs(slab, nbr, lane); gi.x += t.x; gi.y += t.y; gi.z += t.z; gi.w += t.w; }
+        if (touched) { const float4 t = gather_slabs<4>(slab, nbr, lane); gi.x += t.x; gi.y += t.y; gi.z += t.z; gi.w += t.w; }
         float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
         if (gi.w > FE_EPS) TL(S, 2);
         if (gi.w > FE_EPS) {
@@ -1014,8 +1091,10 @@ __device__ __forceinline__ void grid_body(SimP S, TableP T, const float4* __rest
         g_out[c] = out;
         if (!KEEP) {
             if (is_static && e < GS.cap) {
-                float4* dst = GS.data + ((size_t)f * GS.cap + e) * 128;
-                dst[lane] = gi; dst[64 + lane] = out;
+                float4* dst = GS.data + ((size_t)f * GS.cap + e) * GS_BLK;
+                dst[lane] = gi;
+                const u32x3 u = {__float_as_uint(out.x), __float_as_uint(out.y), __float_as_uint(out.z)};
+                __builtin_amdgcn_raw_buffer_store_b96(u, wt_rsrc(dst), 1024 + lane * 12, 0, 0);
             }
             if (dirty) { g_in[c] = 0.f; g_in[S.ncell + c] = 0.f; g_in[2 * S.ncell + c] = 0.f; g_in[3 * S.ncell + c] = 0.f; }
             if (lane == 0 && !is_static) blk_flag[b] = 0;
@@ -1215,10 +1294,15 @@ __global__ __launch_bounds__(WG) void k_g2p_b(Batch<G2PArgs> B) { const G2PArgs&
 // v_out of node (i,j,k) of frame f for the backward pass' global path: the working grid g_out is only valid when grid[f]
 // was recomputed; with a stored frame it comes from the per-frame store (blocks addressed through the order's blk_slot)
 struct VoutSrc { const float4* g_out; const float4* store; const int* blk_slot; };
+// v_out of node `node` of the block in slot `slot` of a frame's store (`st` = the frame's first record; uniform)
+__device__ __forceinline__ float4 store_vout(const float4* __restrict__ st, int slot, int node) {
+    const u32x3 u = __builtin_amdgcn_raw_buffer_load_b96(wt_rsrc((void*)st), slot * (GS_BLK * 16) + 1024 + node * 12, 0, 0);
+    return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), 0.f);
+}
 __device__ __forceinline__ float4 vout_at(const SimP& S, const VoutSrc& V, int i, int j, int k) {
     if (!V.store) return V.g_out[cell_addr(i, j, k, S.nb)];
     const int slot = V.blk_slot[(((i >> 2) * S.nb) + (j >> 2)) * S.nb + (k >> 2)];
-    return slot >= 0 ? V.store[(size_t)slot * 128 + 64 + (((i & 3) << 4) | ((j & 3) << 2) | (k & 3))] : make_float4(0.f, 0.f, 0.f, 0.f);
+    return slot >= 0 ? store_vout(V.store, slot, ((i & 3) << 4) | ((j & 3) << 2) | (k & 3)) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 // advect_kernel.grad + g2p.grad (mpm:443, 538) for one used particle: scatters d/d(v_out), leaves the
@@ -1339,7 +1423,7 @@ __device__ __forceinline__ void g2p_grad_body(SimP S, float* fr_cur, float* Gn_,
                                                  GridStore GS, int f, AgentP agent) {
     const int tid = threadIdx.x;
     const bool stored = GS.cap > 0 && GS.flag[f];
-    VoutSrc V; V.g_out = g_out; V.store = stored ? GS.data + (size_t)f * GS.cap * 128 : nullptr; V.blk_slot = T.blk_slot;
+    VoutSrc V; V.g_out = g_out; V.store = stored ? GS.data + (size_t)f * GS.cap * GS_BLK : nullptr; V.blk_slot = T.blk_slot;
     FrameV cur = frame_view(fr_cur, S.Np);
     FrameV Gn = frame_view(Gn_, S.Np), Gc = frame_view(Gc_, S.Np, S.wt & 4);
     TL(S, 0);
@@ -1421,7 +1505,7 @@ __device__ __forceinline__ void g2p_grad_load_tile2(const TileO& to, const SimP&
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (st) {
             const int e = __shfl(nbr_entry, tile_region(tx) * 9 + tile_region(ty) * 3 + tile_region(tz), 64);
-            if (e >= 0) v = st[(size_t)e * 128 + 64 + ((((tx + 3) & 3) << 4) | (((ty + 3) & 3) << 2) | ((tz + 3) & 3))];
+            if (e >= 0) v = store_vout(st, e, (((tx + 3) & 3) << 4) | (((ty + 3) & 3) << 2) | ((tz + 3) & 3));
         } else {
             int i, j, k;
             if (tile_node(to, l, S.n, i, j, k)) v = g_out[cell_addr(i, j, k, S.nb)];
@@ -1435,7 +1519,7 @@ __device__ __forceinline__ void g2p_grad_load_tile2(const TileO& to, const SimP&
 // returns the factor that turns them back into floats.
 template <int MINW, bool QUAD>
 __device__ __forceinline__ float g2p_grad_particle2(const SimP& S, const FrameV& Gn, const FrameV& Gc, int s, int lb, const Stencil& st,
-                                                    bool live, int tofs, const float* gt) {
+                                                    bool live, int tofs, const float* gt) {      // (lb, live: this lane's particle; from pass 2 on the particle it scatters for)
     PState g;                                   // adjoints of x', v', C'
     if (live) load_xvC(Gn, s, g);
     else { g.x[0] = g.x[1] = g.x[2] = g.v[0] = g.v[1] = g.v[2] = 0.f; g.C = m3_zero(); }
@@ -1508,30 +1592,46 @@ __device__ __forceinline__ float g2p_grad_particle2(const SimP& S, const FrameV&
         for (int a = 0; a < 3; a++) { qb[a] *= fs.s; qx[a] *= fs.s; qy[a] *= fs.s; qz[a] *= fs.s; }
     }
     // ---- pass 2: scatter d v_out(o) += W(o) q(o), summed over runs of equal stencil base before the LDS atomics
+    Stencil sw = st;                                         // (the weights of the particle this lane scatters for: another lane's after wave_sort)
+    int l0s = l0;
+    if (S.wsort) {
+        int key = live ? lb : 0x3ff;
+        if (wave_needs_sort(key)) {
+            const int dest = wave_sort_dest(key);
+            wave_send(dest, key);
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                wave_send(dest, qb[a]); wave_send(dest, qx[a]); wave_send(dest, qy[a]); wave_send(dest, qz[a]);
+#pragma unroll
+                for (int b = 0; b < 3; b++) wave_send(dest, sw.w[a][b]);
+            }
+            live = key != 0x3ff; lb = live ? key : 0; l0s = tofs + lb;
+        }
+    }
     const SegScan sc = seg_setup(live ? lb : (0x40000000 | (int)threadIdx.x));       // (only now: five registers less across pass 1)
     const bool issue = sc.tail && live;
     const float livef = live ? 1.f : 0.f;
 #pragma unroll UNR_X
     for (int i = 0; i < 3; i++) {
-        const float lwi = livef * (MINW >= 4 ? STW(st, i, 0) : st.w[i][0]);
+        const float lwi = livef * (MINW >= 4 ? STW(sw, i, 0) : sw.w[i][0]);
 #pragma unroll
         for (int j = 0; j < 3; j++) {
-            const float lw = lwi * st.w[j][1];
+            const float lw = lwi * sw.w[j][1];
             float qij[3];
 #pragma unroll
             for (int a = 0; a < 3; a++) qij[a] = qb[a] + (float)i * qx[a] + (float)j * qy[a];
 #pragma unroll
             for (int kk = 0; kk < 3; kk++) {
-                const float weight = lw * st.w[kk][2];
+                const float weight = lw * sw.w[kk][2];
                 float c0 = weight * (qij[0] + (float)kk * qz[0]), c1 = weight * (qij[1] + (float)kk * qz[1]), c2 = weight * (qij[2] + (float)kk * qz[2]);
                 seg_scan3(sc, c0, c1, c2);
                 if (issue) {
-                    const int l = l0 + (i * TILE_T + j) * TILE_T + kk;
+                    const int l = l0s + (i * TILE_T + j) * TILE_T + kk;
                     if (QUAD) {
                         int* acc = (int*)s_acc3;
-                        atomicAdd(acc + l, (int)rintf(c0));                   // ds_add_u32
-                        atomicAdd(acc + TILE_N + l, (int)rintf(c1));
-                        atomicAdd(acc + 2 * TILE_N + l, (int)rintf(c2));
+                        atomicAdd(acc + l, fix_round(c0));                   // ds_add_u32
+                        atomicAdd(acc + TILE_N + l, fix_round(c1));
+                        atomicAdd(acc + 2 * TILE_N + l, fix_round(c2));
                     } else {
                         atomicAdd(&s_acc3[l], (double)c0);                    // ds_add_f64
                         atomicAdd(&s_acc3[TILE_N + l], (double)c1);
@@ -1549,7 +1649,7 @@ __device__ __forceinline__ void g2p_grad2_body(SimP S, float* fr_cur, float* Gn_
                                                   GridStore GS, int f, AgentP agent) {
     const int tid = threadIdx.x;
     const bool stored = GS.cap > 0 && GS.flag[f];
-    VoutSrc V; V.g_out = g_out; V.store = stored ? GS.data + (size_t)f * GS.cap * 128 : nullptr; V.blk_slot = T.blk_slot;
+    VoutSrc V; V.g_out = g_out; V.store = stored ? GS.data + (size_t)f * GS.cap * GS_BLK : nullptr; V.blk_slot = T.blk_slot;
     FrameV cur = frame_view(fr_cur, S.Np);
     FrameV Gn = frame_view(Gn_, S.Np), Gc = frame_view(Gc_, S.Np, S.wt & 4);
     TL(S, 0);
@@ -1773,7 +1873,7 @@ __global__ __launch_bounds__(256) void k_collide_grad(SimP S, float* fr_cur, flo
     __syncthreads();
     FrameV cur = frame_view(fr_cur, S.Np), Gn = frame_view(Gn_, S.Np);
     const bool stored = GS.cap > 0 && GS.flag[f];
-    VoutSrc V; V.g_out = g_out; V.store = stored ? GS.data + (size_t)f * GS.cap * 128 : nullptr; V.blk_slot = T.blk_slot;
+    VoutSrc V; V.g_out = g_out; V.store = stored ? GS.data + (size_t)f * GS.cap * GS_BLK : nullptr; V.blk_slot = T.blk_slot;
     for (int base = blockIdx.x * 16; base < n; base += gridDim.x * 16) {
         const int idx = base + (tid >> 4);
         if (idx < n) collide_grad_row(S, agent, f, cur, Gn, V, list[idx], tid & 15);      // whole rows enter or skip together
@@ -1801,11 +1901,11 @@ __device__ __forceinline__ void grid_grad_body(SimP S, TableP T, const float4* _
         const int c = (b << 6) | lane;
         const int bi = b / (S.nb * S.nb), bj = (b / S.nb) % S.nb, bk = b % S.nb;
         // total (p, m): from the forward pass' store, or kept in g_in by k_grid<true>
-        const float4 gi = stored ? GS.data[((size_t)f * GS.cap + e) * 128 + lane]
+        const float4 gi = stored ? GS.data[((size_t)f * GS.cap + e) * GS_BLK + lane]
                                  : make_float4(g_in[c], g_in[S.ncell + c], g_in[2 * S.ncell + c], g_in[3 * S.ncell + c]);
         float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
         if (dirty) go = make_float4(gg_out[c], gg_out[S.ncell + c], gg_out[2 * S.ncell + c], 0.f);
-        if (is_static) { const float4 t = gather_slabs(slab, nbr, lane); go.x += t.x; go.y += t.y; go.z += t.z; }
+        if (is_static) { const float4 t = gather_slabs<3>(slab, nbr, lane); go.x += t.x; go.y += t.y; go.z += t.z; }
         float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
         if (gi.w > FE_EPS) {
             float vo[3], kmul[3];
@@ -2146,6 +2246,9 @@ __global__ __launch_bounds__(WG, MINW) void k_p2g_grad_b(Batch<P2GGradArgs> B) {
 // =========================================================================================
 // block sort (counting sort by 4^3 block of the stencil base)
 // =========================================================================================
+#ifndef SORT_YFAST
+#define SORT_YFAST 0
+#endif
 #define SORT_HB 4096      // cells in a workgroup's rank window: two y-neighbour blocks are 32 * 64 = 2048 cells apart at 128^3, and water falls in y
 // The sort is five launches (round 2: nine to ten, most of them 4-7 us latency chains):
 //   k_sort_count   key + rank of every slot, per-cell and per-block counts            (+ the rebuilt table's old block slots are cleared)
@@ -2184,7 +2287,14 @@ __global__ __launch_bounds__(256) void k_sort_count(SimP S, float* fr, int n_pwg
             float x[3] = {a0.x, a0.y, a0.z};
             Stencil st;
             stencil_make(x, S.inv_dx, st);
-            if (stencil_inside(st, S.n)) kk = cell_addr(st.base[0], st.base[1], st.base[2], S.nb);
+            if (stencil_inside(st, S.n)) {
+                kk = cell_addr(st.base[0], st.base[1], st.base[2], S.nb);
+#if SORT_YFAST
+                // the 64 cells of a block in y-fastest order (the grid's own layout is z-fastest): gravity is along y in every scene, and a
+                // particle that falls into the next cell then sits next to that cell's lanes, in the same wave (wave_sort_dest)
+                kk = (kk & ~63) | ((st.base[0] & 3) << 4) | ((st.base[2] & 3) << 2) | (st.base[1] & 3);
+#endif
+            }
         }
     }
     // The sentinel key (unused / out-of-grid slots -> tail) has its own histogram slot and does not take part in the window's
@@ -2233,44 +2343,55 @@ __global__ __launch_bounds__(256) void k_sort_count(SimP S, float* fr, int n_pwg
     if (valid) { key[s] = kk; rank[s] = r; }
 }
 
-// Work items and workgroup pairs of a block with n particles: ceil(n / ITEM_MAX) items.  A block with several items pairs them up
-// among themselves (pair list M: items 2j and 2j + 1 of the block share one LDS tile and one slab -- the last one of an odd count
-// stays alone); blocks with a single item are listed in S and paired with the next such block by the kernels (two tiles).
-__device__ __forceinline__ int3 block_work(int n, int ITEM_MAX) {
-    const int k = (n + ITEM_MAX - 1) / ITEM_MAX;
-    return make_int3(k, k > 1 ? (k + 1) >> 1 : 0, k == 1 ? 1 : 0);          // items, M pairs, singles
+// Work items of a block with n particles: k = ceil(n / ITEM_MAX) items, all full but the last.  The items of a block with several
+// items pair up among themselves (pair list: items 2j and 2j + 1 share one LDS tile and one slab); the last one of an odd count is
+// the block's LEFTOVER.  A block with one item is a (true) SINGLE.  Leftovers and singles are listed in four classes -- big / small
+// (at most quad_max particles: one wave is enough) -- because the unit lists combine them in two ways (build_unit_list).
+struct BlkWork { int k, full, single, left, last; };
+__device__ __forceinline__ BlkWork block_work(int n, int ITEM_MAX) {
+    BlkWork w;
+    w.k = (n + ITEM_MAX - 1) / ITEM_MAX;
+    w.full = w.k > 1 ? w.k >> 1 : 0;
+    w.single = w.k == 1 ? 1 : 0;
+    w.left = (w.k > 1 && (w.k & 1)) ? 1 : 0;
+    w.last = n - (w.k - 1) * ITEM_MAX;                          // particles of the last item
+    return w;
 }
 
 // The scan over the blocks, two launches of ceil((nblk + 1) / 1024) workgroups (33 at 128^3): a workgroup owns 1024 consecutive
-// blocks, four per thread (one 16-byte load, coalesced; bcnt is padded with zeros); k_sort_blk_partial leaves the workgroup's six
+// blocks, four per thread (one 16-byte load, coalesced; bcnt is padded with zeros); k_sort_blk_partial leaves the workgroup's
 // sums, k_sort_blk_final adds up the partials before it (and all of them: the loose particles start behind ALL dense ones), scans
 // its own threads and hands out slot ranges, items, pairs, singles and the list of occupied blocks.  nblk + 1 counts instead of the
 // n^3 + 1 cell counts the two-launch scan of round 2 went over; the cells are dealt with block by block in k_sort_fill.
 // (A single workgroup walking thread-contiguous stretches was tried first: 70 us at 128^3 and 420 us at 256^3 -- every load and
 // store instruction of a wave touched 64 different cache lines.)
 #define SORT_BLK_WG 1024
-#define NSUM 7
-struct BlkSums { int v[NSUM]; };              // dense particles, loose particles, items, pairs, singles, occupied blocks, small singles (quads)
+#define NSUM 9
+#define PART_STRIDE 16
+// dense particles, loose particles, items, full pairs, big singles, occupied blocks, small singles, big leftovers, small leftovers
+struct BlkSums { int v[NSUM]; };
 // (straight-line selects: with early returns the sums lived in memory -- scratch, then LDS when a seventh one was added -- and the scan
 //  stage took 29 us instead of 18)
 __device__ __forceinline__ void blk_accumulate(BlkSums& a, int n, int ITEM_MAX, int loose_max, int quad_max) {
     const bool occ = n > 0, loose = occ && n <= loose_max, dense = occ && !loose;
-    const int3 w = block_work(n > 0 ? n : 1, ITEM_MAX);
-    const bool small = dense && w.z && n <= quad_max;
+    const BlkWork w = block_work(n > 0 ? n : 1, ITEM_MAX);
+    const bool small = w.last <= quad_max;
     a.v[5] += occ ? 1 : 0;
     a.v[1] += loose ? n : 0;
     a.v[0] += dense ? n : 0;
-    a.v[2] += dense ? w.x : 0;
-    a.v[3] += dense ? w.y : 0;
-    a.v[4] += (dense && w.z && !small) ? 1 : 0;
-    a.v[6] += small ? 1 : 0;
+    a.v[2] += dense ? w.k : 0;
+    a.v[3] += dense ? w.full : 0;
+    a.v[4] += (dense && w.single && !small) ? 1 : 0;
+    a.v[6] += (dense && w.single && small) ? 1 : 0;
+    a.v[7] += (dense && w.left && !small) ? 1 : 0;
+    a.v[8] += (dense && w.left && small) ? 1 : 0;
 }
 // the thread's four block counts and their sums
 __device__ __forceinline__ BlkSums blk_load4(int nblk, int ITEM_MAX, int loose_max, int quad_max, const int* __restrict__ bcnt, int n[4]) {
     const int b0 = blockIdx.x * SORT_BLK_WG + threadIdx.x * 4;
     const int4 n4 = *(const int4*)(bcnt + b0);
     n[0] = n4.x; n[1] = n4.y; n[2] = n4.z; n[3] = n4.w;
-    BlkSums m = {{0, 0, 0, 0, 0, 0, 0}};
+    BlkSums m = {{0, 0, 0, 0, 0, 0, 0, 0, 0}};
 #pragma unroll
     for (int u = 0; u < 4; u++) if (b0 + u < nblk) blk_accumulate(m, n[u], ITEM_MAX, loose_max, quad_max);
     return m;
@@ -2302,7 +2423,7 @@ __global__ __launch_bounds__(256) void k_sort_blk_partial(int nblk, int ITEM_MAX
     const BlkSums m = blk_load4(nblk, ITEM_MAX, loose_max, quad_max, bcnt, n);
     wg_scan6(m, sh, ex, tot);
 #pragma unroll
-    for (int k = 0; k < NSUM; k++) if ((int)threadIdx.x == k) partial[blockIdx.x * 8 + k] = tot[k];      // (static indices: tot[threadIdx.x] sends the sums through memory)
+    for (int k = 0; k < NSUM; k++) if ((int)threadIdx.x == k) partial[blockIdx.x * PART_STRIDE + k] = tot[k];      // (static indices: tot[threadIdx.x] sends the sums through memory)
 }
 // (one launch in which every workgroup goes over the whole array again instead of reading partial sums was tried: the six sums need
 // a division per block, 35 us for the launch against 18 for these two)
@@ -2311,10 +2432,10 @@ __global__ __launch_bounds__(256) void k_sort_blk_final(int nblk, int ncell, int
     __shared__ int sh[4][NSUM];
     const int tid = threadIdx.x;
     // the partials of the workgroups before this one, and of all of them
-    BlkSums pb = {{0, 0, 0, 0, 0, 0, 0}}, pa = {{0, 0, 0, 0, 0, 0, 0}};
+    BlkSums pb = {{0, 0, 0, 0, 0, 0, 0, 0, 0}}, pa = {{0, 0, 0, 0, 0, 0, 0, 0, 0}};
     for (int w = tid; w < (int)gridDim.x; w += 256) {
 #pragma unroll
-        for (int k = 0; k < NSUM; k++) { const int t = partial[w * 8 + k]; pa.v[k] += t; if (w < (int)blockIdx.x) pb.v[k] += t; }
+        for (int k = 0; k < NSUM; k++) { const int t = partial[w * PART_STRIDE + k]; pa.v[k] += t; if (w < (int)blockIdx.x) pb.v[k] += t; }
     }
     int n[4], ex[NSUM], tot[NSUM];
     const BlkSums m = blk_load4(nblk, ITEM_MAX, loose_max, quad_max, bcnt, n);
@@ -2322,11 +2443,16 @@ __global__ __launch_bounds__(256) void k_sort_blk_final(int nblk, int ncell, int
     wg_scan6(pb, sh, exb, before);
     wg_scan6(pa, sh, exa, total);
     wg_scan6(m, sh, ex, tot);
-    if (blockIdx.x == 0 && tid == 0) { meta[0] = total[2]; meta[1] = total[0]; meta[2] = 0; meta[3] = total[3]; meta[4] = total[4]; meta[6] = total[5]; meta[7] = total[0] + total[1]; meta[8] = total[6]; }
+    // meta: [0] items, [1] first slot behind the dense blocks, [2] active blocks (k_sort_fill), [3] full pairs, [4] big singles, [5] / [9] slots
+    // of the two unit lists, [6] occupied blocks, [7] first slot of the tail, [8] small singles, [10] quad units, [11] big / [12] small leftovers, [13] scatter list packed, [14] / [15] work units of the two lists
+    if (blockIdx.x == 0 && tid == 0) { meta[0] = total[2]; meta[1] = total[0]; meta[2] = 0; meta[3] = total[3]; meta[4] = total[4]; meta[6] = total[5]; meta[7] = total[0] + total[1]; meta[8] = total[6];
+                                       meta[11] = total[7]; meta[12] = total[8]; }
     const int b0 = blockIdx.x * SORT_BLK_WG + tid * 4;
     if (b0 > nblk) return;
-    int D = before[0] + ex[0], L = total[0] + before[1] + ex[1], bi = before[2] + ex[2], bm = before[3] + ex[3], bs = before[4] + ex[4], oi = before[5] + ex[5];
-    int bq = total[4] + before[6] + ex[6];                     // the small singles (-> quad units) sit behind the others in `singles`
+    int D = before[0] + ex[0], L = total[0] + before[1] + ex[1], bi = before[2] + ex[2], bm = before[3] + ex[3], oi = before[5] + ex[5];
+    // `singles` = [big singles][big leftovers][small leftovers][small singles]: the big ones, the small ones and the leftovers are each
+    // one stretch of it, the true singles two (build_unit_list)
+    int p_tb = before[4] + ex[4], p_lb = total[4] + before[7] + ex[7], p_ls = total[4] + total[7] + before[8] + ex[8], p_ts = total[4] + total[7] + total[8] + before[6] + ex[6];
     int2 bf[4];
 #pragma unroll
     for (int u = 0; u < 4; u++) {
@@ -2336,11 +2462,13 @@ __global__ __launch_bounds__(256) void k_sort_blk_final(int nblk, int ncell, int
         if (b == nblk) { start[ncell] = total[0] + total[1]; cnt[ncell] = 0; continue; }     // the tail: behind everything
         if (nn <= 0) continue;
         if (nn <= loose_max) { occ[oi++] = make_int4(b, L, nn, 1); L += nn; continue; }
-        const int3 w = block_work(nn, ITEM_MAX);
-        bf[u] = make_int2(bi, w.x);
+        const BlkWork w = block_work(nn, ITEM_MAX);
+        bf[u] = make_int2(bi, w.k);
         occ[oi++] = make_int4(b, D, nn, 0);
-        if (w.z) { if (nn <= quad_max) singles[bq++] = bi; else singles[bs++] = bi; }
-        for (int j = 0; j < w.y; j++) pairs[bm++] = make_int2(bi + 2 * j, 2 * j + 1 < w.x ? bi + 2 * j + 1 : -1);
+        const bool small = w.last <= quad_max;
+        if (w.single) { if (small) singles[p_ts++] = bi; else singles[p_tb++] = bi; }
+        if (w.left) { if (small) singles[p_ls++] = bi + w.k - 1; else singles[p_lb++] = bi + w.k - 1; }
+        for (int j = 0; j < w.full; j++) pairs[bm++] = make_int2(bi + 2 * j, bi + 2 * j + 1);
         for (int o = 0; o < nn; o += ITEM_MAX) items[bi++] = make_int4(b, D + o, min(ITEM_MAX, nn - o), 0);
         D += nn;
     }
@@ -2400,26 +2528,44 @@ __global__ __launch_bounds__(256) void k_sort_fill(int nb, const int4* __restric
 // What the substep kernels would otherwise look up through chains of dependent loads, laid out once per sort: the unit list of
 // the particle kernels (struct Unit) and, per active-list entry, the item ranges of its block's 27 neighbours (gather_slabs).
 // (device function: runs in the extra workgroups of k_sort_apply's launch, and alone for the identity order)
-// One unit list: nS single-item blocks taken two to a pair unit, the nQ behind them in `singles` four to a quad unit.
+// One unit list out of the sort's lists: nF full pairs (two items of one block, shared tile) and `singles` = [tB big singles][lB big
+// leftovers][lS small leftovers][tS small singles] (item indices), in one of two layouts:
+//   pack = false   [full pairs] [every leftover alone in its workgroup, the other half idle] [true singles two to a workgroup]
+//                  [the last x small singles four to a QUAD unit] [tail units]                  -- round 3's list
+//   pack = true    [full pairs] [big ones -- singles and leftovers alike -- then the small ones not in quads, two to a workgroup]
+//                  [the last x small ones (leftovers included) four to a QUAD unit] [tail units]
+// Packing takes the idle halves out: a leftover has a tile and a slab of its own either way (gather_slabs: the slabs of a block are
+// its items first, first + 2, ... -- the leftover of an odd count is one of them).
+struct UnitLists { int nF, tB, lB, lS, tS; };
+__device__ __forceinline__ int unit_count(const UnitLists& u, bool pack, int x, int n_tail) {
+    const int nsing = u.tB + u.lB + u.lS + u.tS;
+    return u.nF + (pack ? (nsing - x + 1) >> 1 : u.lB + u.lS + ((u.tB + u.tS - x + 1) >> 1)) + ((x + 3) >> 2) + n_tail;
+}
 __device__ __forceinline__ void build_unit_list(int gtid, int nth, int N, int xcd_on, const int4* __restrict__ items, const int2* __restrict__ pairs,
-                                                const int* __restrict__ singles, int tail_start, int nM, int nS, int nQ, int* n_slots_out, UnitRec* units, int units_cap) {
-    const int n_pairs = nM + ((nS + 1) >> 1), n_quads = (nQ + 3) >> 2, n_tail = (N - tail_start + WG - 1) / WG;
+                                                const int* __restrict__ singles, int tail_start, const UnitLists L, bool pack, int x, int* n_slots_out, int* n_work_out, UnitRec* units, int units_cap) {
+    const int nsing = L.tB + L.lB + L.lS + L.tS, n_left = L.lB + L.lS;
+    const int n_alone = pack ? 0 : n_left;                                   // leftovers with a workgroup of their own
+    const int n_two = pack ? nsing - x : L.tB + L.tS - x;                    // list entries taken two to a workgroup
+    const int n_pairs = L.nF + n_alone + ((n_two + 1) >> 1), n_quads = (x + 3) >> 2, n_tail = (N - tail_start + WG - 1) / WG;
     const int n_work = n_pairs + n_quads + n_tail;
     const int per_xcd = xcd_on >= 2 ? (((n_work + xcd_on - 1) / xcd_on + 7) >> 3) * xcd_on : (n_work + 7) >> 3;      // slots per XCD
     const int n_slots = per_xcd * 8 < units_cap ? per_xcd * 8 : units_cap;      // (units_cap covers the worst case)
-    if (gtid == 0) *n_slots_out = n_slots;
+    if (gtid == 0) { *n_slots_out = n_slots; *n_work_out = n_work; }
+    // entry j of the stretch taken two at a time: all of `singles` when packing, else the true singles (big, then small)
+    auto two = [&](int j) { return singles[pack ? j : (j < L.tB ? j : j + n_left)]; };
     for (int w = gtid; w < n_slots; w += nth) {
         const int u = xcd_item(w, per_xcd, xcd_on);
         UnitRec un;
         un.a = make_int4(0, 0, -2, 0); un.b = un.c = un.d = make_int4(0, 0, 0, -1);
         if (u < n_pairs) {
             int ia, ib, same;
-            if (u < nM) { const int2 pr = pairs[u]; ia = pr.x; ib = pr.y; same = 1; }
-            else { const int q = 2 * (u - nM); ia = singles[q]; ib = q + 1 < nS ? singles[q + 1] : -1; same = 0; }
+            if (u < L.nF) { const int2 pr = pairs[u]; ia = pr.x; ib = pr.y; same = 1; }
+            else if (u < L.nF + n_alone) { ia = singles[L.tB + (u - L.nF)]; ib = -1; same = 1; }
+            else { const int q = 2 * (u - L.nF - n_alone); ia = two(q); ib = q + 1 < n_two ? two(q + 1) : -1; same = 0; }
             un.a = items[ia]; un.a.w = ia | (same << 30);
             if (ib >= 0) { un.b = items[ib]; un.b.w = ib; }
         } else if (u < n_pairs + n_quads) {
-            const int q = nS + 4 * (u - n_pairs), nq = min(4, nS + nQ - q);
+            const int q = nsing - x + 4 * (u - n_pairs), nq = min(4, nsing - q);      // (the last x entries of `singles`: small ones)
             { const int ii = singles[q]; un.a = items[ii]; un.a.w = ii | QUAD_BIT; }
             if (nq > 1) { const int ii = singles[q + 1]; un.b = items[ii]; un.b.w = ii; }
             if (nq > 2) { const int ii = singles[q + 2]; un.c = items[ii]; un.c.w = ii; }
@@ -2428,19 +2574,34 @@ __device__ __forceinline__ void build_unit_list(int gtid, int nth, int N, int xc
         units[w] = un;
     }
 }
-// Two lists.  `units` is what the SCATTER kernels (k_p2g, k_g2p_grad2) walk: with quad units when pairing everything would need more
-// than `quad_min_units` workgroups -- several rounds of the chip's resident ones, which is when halving their number pays (splash:
-// p2g 43 -> 35 us, g2p_grad 45 -> 37); in a single round a quad's longer chain (one wave zeroes and hands over a whole tile) is the
-// launch's critical path instead (falling: +0.3 ... +0.5 us), so there the list is pairs only.  `units_p` is always pairs only, for
-// the GATHER kernels (k_g2p, k_p2g_grad), which quads never helped (k_p2g_grad has no room for four 4-plane tiles beside its stash).
-__device__ __forceinline__ void build_units_dev(int gtid, int nth, int nb, int N, int xcd_on, int quad_min_units, const int4* __restrict__ items, const int2* __restrict__ pairs,
+// Two lists.  `units_p` is round 3's pairs-only list, for the GATHER kernels (k_g2p, k_p2g_grad): quads never helped them (k_p2g_grad
+// has no room for four 4-plane tiles beside its stash) and a second tile to load per workgroup costs them more than an idle half.
+// `units` is what the SCATTER kernels (k_p2g, k_g2p_grad2) walk.  Their launches are ONE round of the chip's resident workgroups
+// (`quad_fit` = 4 per CU) while the block falls -- a latency chain, in which a quad's longer chain (one wave zeroes and hands over a
+// whole tile) costs +0.3 ... 0.5 us: pairs only.  Where the water has come apart they are several rounds -- throughput, and halving
+// the workgroups pays (splash: p2g 43 -> 35 us, g2p_grad 45 -> 37): every small single in a quad (`quad_min_units`).  In between --
+// the block hitting the floor, 1,030 ... 2,000 pair units -- round 3 left the list as pairs: the few hundred workgroups beyond the
+// first 1,024 started when the first ones retired and the scatter kernels took two chains instead of one (31.8 / 32.3 us against
+// 20.9 / 19.0 on the falling block).  There the list is now PACKED (no idle halves) and takes as many quads as it needs to fit one
+// round again, if that is enough.
+__device__ __forceinline__ void build_units_dev(int gtid, int nth, int nb, int N, int xcd_on, int quad_min_units, int quad_fit, int pack_units, const int4* __restrict__ items, const int2* __restrict__ pairs,
                                                 const int* __restrict__ singles, const int2* __restrict__ blk_first, const int* __restrict__ active,
                                                 int* meta, UnitRec* units, UnitRec* units_p, int units_cap, int2* nbr) {
-    const int tail_start = meta[1], nM = meta[3], nS = meta[4], nQ = meta[8], n_active = meta[2];
-    const bool quads = nM + ((nS + nQ + 1) >> 1) > quad_min_units;
-    if (gtid == 0) meta[10] = quads ? (nQ + 3) >> 2 : 0;         // (fe_get_work_stats: the quad units of this order's scatter list)
-    build_unit_list(gtid, nth, N, xcd_on, items, pairs, singles, tail_start, nM, quads ? nS : nS + nQ, quads ? nQ : 0, meta + 5, units, units_cap);
-    build_unit_list(gtid, nth, N, xcd_on, items, pairs, singles, tail_start, nM, nS + nQ, 0, meta + 9, units_p, units_cap);
+    const int tail_start = meta[1], n_active = meta[2];
+    const UnitLists L = {meta[3], meta[4], meta[11], meta[12], meta[8]};
+    const int n_tail = (N - tail_start + WG - 1) / WG;
+    const int U0 = unit_count(L, false, 0, n_tail);
+    bool pack = false; int x = 0;
+    if (U0 > quad_fit && quad_fit > 0) {
+        const int U1 = unit_count(L, true, 0, n_tail), small = L.lS + L.tS;
+        const int need = U1 > quad_fit ? 4 * (U1 - quad_fit) + 4 : 0;       // four small ones as a quad instead of two pairs: one workgroup less
+        if (pack_units > 0 && need <= small) { pack = true; x = need; }      // back in one round
+        else if (U0 > quad_min_units) { pack = pack_units > 1; x = pack ? small : L.tS; }
+        else pack = pack_units > 1;
+    } else if (U0 > quad_min_units) x = L.tS;
+    if (gtid == 0) { meta[10] = (x + 3) >> 2; meta[13] = pack ? 1 : 0; }       // (fe_get_work_stats)
+    build_unit_list(gtid, nth, N, xcd_on, items, pairs, singles, tail_start, L, pack, x, meta + 5, meta + 14, units, units_cap);
+    build_unit_list(gtid, nth, N, xcd_on, items, pairs, singles, tail_start, L, false, 0, meta + 9, meta + 15, units_p, units_cap);
     for (int t = gtid; t < n_active * 27; t += nth) {
         const int e = t / 27, n = t - e * 27, b = active[e];
         const int i2 = b / (nb * nb) + n / 9 - 1, j2 = (b / nb) % nb + (n / 3) % 3 - 1, k2 = b % nb + n % 3 - 1;
@@ -2452,20 +2613,20 @@ __device__ __forceinline__ void build_units_dev(int gtid, int nth, int nb, int N
 __global__ __launch_bounds__(256) void k_build_units(int nb, int N, int xcd_on, const int4* __restrict__ items, const int2* __restrict__ pairs,
                                                      const int* __restrict__ singles, const int2* __restrict__ blk_first, const int* __restrict__ active,
                                                      int* meta, UnitRec* units, UnitRec* units_p, int units_cap, int2* nbr) {
-    build_units_dev(blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, nb, N, xcd_on, 0x7fffffff, items, pairs, singles, blk_first, active, meta, units, units_p, units_cap, nbr);
+    build_units_dev(blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, nb, N, xcd_on, 0x7fffffff, 0, 0, items, pairs, singles, blk_first, active, meta, units, units_p, units_cap, nbr);
 }
 
 // The permutation itself, one pass: slot s of the old order goes to d = start[key] + rank -- its particle id, material record and
 // all 25 planes.  Reads are coalesced, writes land near s (the old order was sorted too: particles move less than a cell between
 // sorts), so the write combining of the L2 sees them almost in order.  (Round 1: index kernel, copy of the id table, gather kernel.)
 #define SORT_UNIT_WGS 128
-struct UnitsArgs { int* bcnt; int nb, xcd_on, quad_min_units; const int4* items; const int2* pairs; const int* singles; const int2* blk_first; const int* active; int* meta; UnitRec* units; UnitRec* units_p; int units_cap; int2* nbr; };
+struct UnitsArgs { int* bcnt; int nb, xcd_on, quad_min_units, quad_fit, pack_units; const int4* items; const int2* pairs; const int* singles; const int2* blk_first; const int* active; int* meta; UnitRec* units; UnitRec* units_p; int units_cap; int2* nbr; };
 __global__ __launch_bounds__(256) void k_sort_apply(int N, size_t Np, int n_pwg, const int* __restrict__ key, const int* __restrict__ rank,
                                                     const int* __restrict__ start, const int* __restrict__ pid_old, int* pid_new, int* slot_of_pid,
                                                     const float4* __restrict__ pinfo, float4* info_new, float* dst_, float* src_, UnitsArgs U) {
     if ((int)blockIdx.x >= n_pwg) {          // (independent of the permutation: both only need what the scan and k_sort_fill left)
         for (int i = (blockIdx.x - n_pwg) * 256 + threadIdx.x; i <= U.nb * U.nb * U.nb; i += SORT_UNIT_WGS * 256) U.bcnt[i] = 0;      // block counts: ready for the next sort
-        build_units_dev((blockIdx.x - n_pwg) * 256 + threadIdx.x, SORT_UNIT_WGS * 256, U.nb, N, U.xcd_on, U.quad_min_units, U.items, U.pairs, U.singles, U.blk_first, U.active, U.meta,
+        build_units_dev((blockIdx.x - n_pwg) * 256 + threadIdx.x, SORT_UNIT_WGS * 256, U.nb, N, U.xcd_on, U.quad_min_units, U.quad_fit, U.pack_units, U.items, U.pairs, U.singles, U.blk_first, U.active, U.meta,
                         U.units, U.units_p, U.units_cap, U.nbr);
         return;
     }
@@ -2895,6 +3056,8 @@ struct FeEngine {
     std::vector<int> tbl_of_frame;                          // [L+1]
     int gtbl[2] = {-1, -1};                                 // order of each adjoint ring slot; -1 = all zero
     int p2g_grad_waves = 4;                                 // occupancy target of the SVD-free p2g_grad build (tuning)
+    int pack_units = 1;                                     // option "pack_units": 0 never, 1 pack the scatter list (no idle halves) when that brings it back into one round, 2 whenever it is more than one round
+    int quad_fit = 1024;                                    // option "quad_fit": the workgroups of one resident round (set from the device in fe_create: 4 per CU); 0 = round 3's rule
     int quad_min_units = 2048;                              // option "quad_min_units": quad units only when pairs alone would be more workgroups than this (build_units_dev)
     int quad = QUAD_MAX;                                    // option "quad_max": single-item blocks of at most this many particles go four to a workgroup (0: never)
     int g2p_grad_v = 3;                                     // build of the G2P adjoint: 3 = split passes, x offset rolled (k_g2p_grad2<4>, default); 2 = split, unrolled completely (<3>); 1 = fused rolled loop (k_g2p_grad)
@@ -3133,7 +3296,7 @@ int sort_frame(FeEngine* h, int f) {
     if (fine) { prof_end(h); prof_begin(h, KID_SORT_PERM); }
     // re-sorting a frame that is already in this table's order reads the id table it rewrites: stage it
     int* pid_dst = id_old == id_new ? h->sort_pid : tn.pid;
-    const UnitsArgs U = {h->sort_bcnt, h->nb, h->S.xcd, h->quad_min_units, tn.items, tn.pairs, tn.singles, tn.blk_first, tn.active, tn.meta, tn.units, tn.units_p, (int)h->units_cap, tn.nbr};
+    const UnitsArgs U = {h->sort_bcnt, h->nb, h->S.xcd, h->quad_min_units, h->quad_fit, h->pack_units, tn.items, tn.pairs, tn.singles, tn.blk_first, tn.active, tn.meta, tn.units, tn.units_p, (int)h->units_cap, tn.nbr};
     hipLaunchKernelGGL(k_sort_apply, dim3(n_pwg + SORT_UNIT_WGS), dim3(256), 0, h->stream, h->N, (size_t)h->Np, n_pwg, h->sort_key, h->sort_rank, h->sort_start,
                        h->tables[id_old].pid, pid_dst, tn.slot_of_pid, h->pinfo, tn.info, h->spare_frame(), h->frame(f), U);
     if (id_old == id_new) HIPCK(h, hipMemcpyAsync(tn.pid, h->sort_pid, sizeof(int) * h->Np, hipMemcpyDeviceToDevice, h->stream));
@@ -3505,9 +3668,11 @@ FeEngine* fe_create(const FeConfig* cfg) {
     auto fail = [&](const std::string& m) { g_create_err = m.empty() ? h->err : m; fe_destroy(h); return (FeEngine*)nullptr; };
     if (hipSetDevice(h->device) != hipSuccess) return fail("hipSetDevice failed");
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
+    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) h->quad_fit = 4 * cus; }   // one round of resident workgroups (128 VGPRs: 4 per CU)
     h->own_stream = h->stream;
     SimP& S = h->S;
     S.xcd = 16;                                            // blocked-cyclic unit mapping (A/B in DESIGN.md section 6)
+    S.wsort = 1;                                           // lanes regrouped by stencil base before the scan (A/B in DESIGN.md section 6)
     S.wt = 5;                                              // p2g and g2p_grad: their bulk stores come early (A/B in DESIGN.md section 6)
     S.N = h->N; S.Np = h->Np; S.n = h->n; S.nb = h->nb; S.ncell = h->nb * h->nb * h->nb * 64;
     S.dx = 1.0f / (float)h->n; S.inv_dx = (float)h->n; S.dt = cfg->dt;
@@ -3527,18 +3692,18 @@ FeEngine* fe_create(const FeConfig* cfg) {
         h->items_cap = (nblk < (size_t)h->Np ? nblk : (size_t)h->Np) + (size_t)h->Np / 64 + 2;      // item_max >= 64
         h->units_cap = h->items_cap + (size_t)h->Np / WG + 16 + 1024;                                      // work units: items (at worst one each) + tail workgroups, rounded up to 8
         if (dev_alloc(h, &h->sort_key, h->Np) || dev_alloc(h, &h->sort_rank, h->Np) || dev_alloc(h, &h->sort_cnt, ncell + 1) ||
-            dev_alloc(h, &h->sort_start, ncell + 1) || dev_alloc(h, &h->sort_bcnt, ((nblk + 1 + SORT_BLK_WG - 1) / SORT_BLK_WG) * SORT_BLK_WG) || dev_alloc(h, &h->sort_partial, ((nblk + 1 + SORT_BLK_WG - 1) / SORT_BLK_WG) * 8) || dev_alloc(h, &h->sort_occ, nblk + 1, false) || dev_alloc(h, &h->sort_pid, h->Np) ||
+            dev_alloc(h, &h->sort_start, ncell + 1) || dev_alloc(h, &h->sort_bcnt, ((nblk + 1 + SORT_BLK_WG - 1) / SORT_BLK_WG) * SORT_BLK_WG) || dev_alloc(h, &h->sort_partial, ((nblk + 1 + SORT_BLK_WG - 1) / SORT_BLK_WG) * PART_STRIDE) || dev_alloc(h, &h->sort_occ, nblk + 1, false) || dev_alloc(h, &h->sort_pid, h->Np) ||
             dev_alloc(h, &h->slow_dev, 1) || dev_alloc(h, &h->frame_slow_dev, 1) || dev_alloc(h, &h->slab, h->items_cap * SLAB_N, false)) return fail("");
     }
     if (dev_alloc(h, &h->effs_dev, FE_MAX_EFF)) return fail("");
-    {   // forward grid store: cap blocks per frame, 2 KiB each; bounded to 64 GiB
+    {   // forward grid store: cap blocks per frame, 1,792 bytes each (GS_BLK); bounded to 64 GiB
         const size_t nblk = (size_t)h->nb * h->nb * h->nb;
         // (round 1 clamped this to 4096 blocks: a block of water that has spread into a thin layer over the floor of a 128^3 box
         // has more active blocks than that, every frame lost its store and the backward pass recomputed P2G + grid_op throughout)
         size_t cap = nblk;
-        while (cap > 0 && (size_t)(h->L + 1) * cap * 2048 > ((size_t)64 << 30)) cap /= 2;
+        while (cap > 0 && (size_t)(h->L + 1) * cap * (GS_BLK * 16) > ((size_t)64 << 30)) cap /= 2;
         h->gs_cap = (int)cap;
-        if (cap > 0 && (dev_alloc(h, &h->gstore, (size_t)(h->L + 1) * cap * 128, false) || dev_alloc(h, &h->gs_flag, h->L + 1) ||
+        if (cap > 0 && (dev_alloc(h, &h->gstore, (size_t)(h->L + 1) * cap * GS_BLK, false) || dev_alloc(h, &h->gs_flag, h->L + 1) ||
                         dev_alloc(h, &h->gs_live, (size_t)(h->L + 1) * cap))) return fail("");
         if (dev_alloc(h, &h->ent_touched, nblk) || dev_alloc(h, &h->ent_dirty, nblk) || dev_alloc(h, &h->cur_live, nblk)) return fail("");
     }
@@ -3626,7 +3791,10 @@ int fe_set_option(FeEngine* h, const char* name, double value) {
     // (run length k rounds the unit list up to a multiple of 8 k slots; units_cap has ~1,040 slots of slack: k <= 64 always fits)
     if (!std::strcmp(name, "xcd_map")) { if (value < 0 || value > 64) FAIL(h, "xcd_map must be 0 (none), 1 (contiguous eighths) or a run length 2..64"); h->S.xcd = (int)value; return 0; }
     if (!std::strcmp(name, "write_through")) { h->S.wt = (int)value; return 0; }
+    if (!std::strcmp(name, "wave_sort")) { h->S.wsort = value != 0; return 0; }
     if (!std::strcmp(name, "quad_min_units")) { h->quad_min_units = (int)value; return 0; }
+    if (!std::strcmp(name, "pack_units")) { if (value < 0 || value > 2) FAIL(h, "pack_units must be 0, 1 or 2"); h->pack_units = (int)value; return 0; }
+    if (!std::strcmp(name, "quad_fit")) { if (value < 0) FAIL(h, "quad_fit must be >= 0"); h->quad_fit = (int)value; return 0; }
     if (!std::strcmp(name, "quad_max")) { if (value < 0 || value > QUAD_MAX) FAIL(h, "quad_max must be in [0, 64]"); h->quad = (int)value; return 0; }
     if (!std::strcmp(name, "wgrid_cap")) { if (value < 64) { h->err = "wgrid_cap must be >= 64"; return 1; } h->wgrid_cap = (int)value; return 0; }
     if (!std::strcmp(name, "threads")) return 0;             // oracle-only tunable
@@ -4189,18 +4357,20 @@ int fe_get_stats(FeEngine* h, int f, FeStats* out) {
     out->n_slow_path = slow; out->bytes_state = (long long)h->bytes;
     return check_async(h);
 }
-int fe_get_work_stats(FeEngine* h, int f, long long out[16]) {
+int fe_get_work_stats(FeEngine* h, int f, long long out[24]) {
     FE_ENTRY(h);
     CHECK_FRAME(h, f);
-    for (int i = 0; i < 16; i++) out[i] = 0;
+    for (int i = 0; i < 24; i++) out[i] = 0;
     const int t = h->tbl_of_frame[f];
     if (t < 0 || t >= (int)h->tables.size() || !h->tables[t].meta) return 0;
     int meta[16];
     HIPCK(h, hipMemcpyAsync(meta, h->tables[t].meta, sizeof(meta), hipMemcpyDeviceToHost, h->stream));
     HIPCK(h, hipStreamSynchronize(h->stream));
     for (int i = 0; i < 5; i++) out[i] = meta[i];
+    out[3] += meta[11] + meta[12];                            // full pairs + the leftovers of odd item counts: the workgroups multi-item blocks get in the pairs-only list
     out[4] += meta[8]; out[14] = meta[8]; out[15] = meta[10];                     // single-item blocks: the small ones (four to a quad unit) are counted apart
     out[13] = meta[7] - meta[1];                              // particles of loose blocks: slots [tail_start, tail_start + this)
+    out[16] = meta[14]; out[17] = meta[15]; out[18] = meta[13]; out[19] = meta[11]; out[20] = meta[12];
     std::vector<int4> items((size_t)std::max(meta[0], 0));
     if (!items.empty()) {
         HIPCK(h, hipMemcpyAsync(items.data(), h->tables[t].items, sizeof(int4) * items.size(), hipMemcpyDeviceToHost, h->stream));

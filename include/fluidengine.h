@@ -268,8 +268,9 @@ int fe_get_stats(FeEngine* h, int f, FeStats* out);
  * out[0] work items, [1] first item of the global-atomics tail, [2] active blocks, [3] workgroups of blocks with several items,
  * [4] single-item blocks, [5..11] items holding 1, 2-4, 5-8, 9-16, 17-32, 33-64, 65-128 particles, [12] occupied blocks,
  * [13] particles of blocks without a work item (option loose_max), [14] single-item blocks small enough for a quad unit (option quad_max),
- * [15] quad units in the order's scatter list (0 while pairs alone stay within option quad_min_units). */
-int fe_get_work_stats(FeEngine* h, int f, long long out[16]);
+ * [15] quad units in the order's scatter list, [16] / [17] work units (workgroups with something to do) of the scatter / gather unit list, [18] the scatter list is
+ * packed (no idle halves: options pack_units, quad_fit), [19] / [20] big / small leftover items of odd item counts, [21..23] reserved. */
+int fe_get_work_stats(FeEngine* h, int f, long long out[24]);
 /* HIP-event stopwatch on the engine's stream */
 int    fe_timer_start(FeEngine* h);
 double fe_timer_stop_ms(FeEngine* h);               /* records, waits, returns elapsed ms (<0 on error) */

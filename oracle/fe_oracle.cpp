@@ -2097,7 +2097,7 @@ int fe_mesh_sdf(int device, const float* verts, int nv, const int* faces, int nf
     return 0;
 }
 
-int fe_get_work_stats(FeEngine*, int, long long out[16]) { for (int i = 0; i < 16; i++) out[i] = 0; return 0; }   // no work lists here
+int fe_get_work_stats(FeEngine*, int, long long out[24]) { for (int i = 0; i < 24; i++) out[i] = 0; return 0; }   // no work lists here
 int fe_get_stats(FeEngine* h, int f, FeStats* out) {
     CHECK_FRAME(h, f);
     const int n = h->n, nb = (n + 3) / 4;

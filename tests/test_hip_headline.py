@@ -25,13 +25,15 @@ pytestmark = pytest.mark.gpu
 ORACLE_THREADS = 16       # the oracle's particle loops are OpenMP-parallel (fp64 atomics: order noise ~1e-16)
 
 
-def _bench_pass(lib, chunk, frame0=None, threads=None):
+def _bench_pass(lib, chunk, frame0=None, threads=None, options=None):
     """bench.window_step on bench.build_block's scene, with the states read back: `chunk` forward substeps from frame 0 (optionally
     re-seeded with `frame0`), the benchmark's loss on the last frame, `chunk` backward substeps."""
     import bench
     eng, sc = bench.build_block(lib, 0, L=chunk)
     if threads:
         eng.set_option('threads', threads)
+    for k, v in (options or {}).items():
+        eng.set_option(k, v)
     if frame0 is not None:
         eng.set_frame(0, x=frame0['x'], v=frame0['v'], C_=frame0['C'], F=frame0['F'], used=frame0['used'])
     eng.step(0, 0, chunk, 0)
@@ -74,7 +76,7 @@ def test_config2_water_block_128_matches_the_oracle(hiplib, oracle64):
              dict(x=(1e-6, 0), x_l2=1e-6, v=(1e-4, 1e-4), C=(2e-4, 1e-3), F=(1e-5, 0), g_cos=0.99999, g_l2=1e-3))
 
 
-def test_config2_splash_state_with_quad_units_matches_the_oracle(hiplib, oracle64):
+def test_config2_splash_state_with_quad_units_matches_the_oracle(hiplib, oracle64, oracle32):
     """Parity in the state that decides the benchmark's `value`: the scene is run on the HIP engine to substep 2,600 (the splash:
     > 2,048 pair units, so the sort lays out quad units by the default options), that frame seeds a fresh HIP engine and the fp64
     oracle, 10 forward + 10 backward substeps on each.  `n_quad_units > 0` proves the quad path (fixed-point tiles) is what ran."""
@@ -88,10 +90,20 @@ def test_config2_splash_state_with_quad_units_matches_the_oracle(hiplib, oracle6
     a, ga, work, st = _bench_pass(hiplib, 10, frame0=frame)
     b, gb, _, _ = _bench_pass(oracle64, 10, frame0=frame, threads=ORACLE_THREADS)
     print('MEASURED splash work list:', work, 'touched nodes', st['n_cells_touched'])
-    assert work['n_quad_units'] > 0 and work['n_quad_items'] > 4000, work
+    assert work['n_quad_units'] > 500 and work['n_quad_items'] > 3000, work
     assert st['n_cells_touched'] > 150000
+    # What fp32 costs in this state (|C| up to 1e3, velocities of 4 m/s, ten substeps of a chaotic splash forward and back): the
+    # oracle's own fp32 build and the HIP engine with pair units only (fp64 LDS sums) against the same fp64 run.  The bounds below are
+    # ~3x the HIP engine's measured distance; the quad units' fixed-point sums must not be further off than 2x the pair units'.
+    c, gc, _, _ = _bench_pass(oracle32, 10, frame0=frame, threads=ORACLE_THREADS)
+    d, gd, wd, _ = _bench_pass(hiplib, 10, frame0=frame, options={'quad_min_units': 1 << 30, 'pack_units': 0})
+    assert wd['n_quad_units'] == 0
+    err = {name: {k: S.rel_l2(g[k], gb[k]) for k in ('gx', 'gv', 'gC', 'gF')} for name, g in (('hip', ga), ('hip pairs only', gd), ('oracle fp32', gc))}
+    print('MEASURED splash adjoints relL2 vs fp64 oracle:', {n: {k: f'{v:.2e}' for k, v in e.items()} for n, e in err.items()})
+    for k in ('gx', 'gv', 'gC', 'gF'):
+        assert err['hip'][k] <= 2.0 * max(err['hip pairs only'][k], err['oracle fp32'][k]) + 1e-6, (k, err)
     _compare('config2 splash (quad units), 10+10', a, ga, b, gb,
-             dict(x=(2e-6, 0), x_l2=1e-6, v=(1e-4, 1e-4), C=(1e-3, 1e-3), F=(1e-5, 0), g_cos=0.99999, g_l2=3e-3))
+             dict(x=(2e-6, 0), x_l2=1e-6, v=(1e-4, 1e-4), C=(1e-3, 1e-3), F=(1e-5, 0), g_cos=0.9999, g_l2=3e-2))
 
 
 def test_config3_latteart_128_backward_with_milk_flowing(hiplib, oracle32):

@@ -450,3 +450,45 @@ def test_batched_envs_match_individual_runs(hiplib):
         for a, b in zip(g, g0):
             assert S.rel_l2(a, b) <= 1e-4
         eng.close()
+
+
+@pytest.mark.parametrize('pack_units,quad_fit', [(1, 40), (1, 90), (2, 4), (0, 40)])
+def test_packed_unit_list_matches_the_oracle(hiplib, oracle64, pack_units, quad_fit):
+    """Round 4's scatter list: the leftover item of a block with an odd number of items no longer sits alone in a workgroup -- it
+    pairs with another block's item or goes into a quad unit with its own fixed-point tile -- and exactly as many small items go
+    four to a workgroup as it takes to fit `quad_fit` workgroups (one resident round on the chip; small here).  A dense block (three
+    to five items per 4^3 block, odd counts among them) in a cloud of droplets (single-item blocks of every size), forward and
+    backward against the fp64 oracle; (1, 90) fits with a few quads, (1, 40) cannot fit and stays pairs, (2, 4) packs regardless."""
+    rng = np.random.RandomState(21)
+    core = []                                                                      # 27 blocks of 140 ... 600 particles: two to five items each
+    for bi in range(3):
+        for bj in range(3):
+            for bk in range(3):
+                lo = (4 * np.array([3 + bi, 3 + bj, 3 + bk]) + 0.5) / 32
+                core.append(lo + rng.uniform(0.02, 0.98, (int(rng.randint(140, 600)), 3)) * (4 / 32))
+    core = np.concatenate(core)
+    n_drop = 1400
+    drops = np.concatenate([c + rng.uniform(-r, r, (k, 3)) for c, r, k in
+                            zip(rng.uniform(0.15, 0.85, (70, 3)), rng.choice([0.01, 0.02, 0.04], 70), [n_drop // 70] * 70)])
+    x = S.f32(np.clip(np.concatenate([core, drops]), 0.08, 0.92))
+    N = len(x)
+    sc = dict(S.water_block(n_grid=32, n_particles=N, seed=3), x=x, v=S.f32(rng.normal(0, 0.4, (N, 3))))
+    opts = {'sort_interval': 4, 'pack_units': pack_units, 'quad_fit': quad_fit, 'item_max': 128}
+    g = S.make_engine(hiplib, sc, options=opts)
+    o = S.make_engine(oracle64, sc)
+    cot = S.random_cotangent(N, seed=4)
+    sa, ga = S.run_forward_backward(g, 9, cot)
+    sb, gb = S.run_forward_backward(o, 9, {k: v.astype(np.float64) for k, v in cot.items()})
+    ws = g.get_work_stats(8)
+    print('MEASURED packed unit list', (pack_units, quad_fit), {k: ws[k] for k in ('n_items', 'n_multi_item_workgroups', 'n_leftover_items', 'n_single_item_blocks', 'n_quad_items', 'n_quad_units', 'n_scatter_units', 'n_gather_units', 'packed')})
+    assert ws['n_leftover_items'] >= 8 and ws['n_quad_items'] > 30
+    if pack_units == 0:
+        assert not ws['packed'] and ws['n_quad_units'] == 0 and ws['n_scatter_units'] == ws['n_gather_units']
+    elif (pack_units, quad_fit) == (1, 90):
+        assert ws['packed'] and 0 < ws['n_quad_units'] and ws['n_scatter_units'] <= 90 < ws['n_gather_units']
+    elif pack_units == 2:
+        assert ws['packed'] and ws['n_scatter_units'] < ws['n_gather_units']
+    assert np.abs(sa['x'] - sb['x']).max() <= 2e-6
+    assert S.rel_l2(sa['v'], sb['v']) <= 1e-4
+    for k in ('gx', 'gv', 'gC', 'gF'):
+        assert S.cosine(ga[k], gb[k]) >= 0.99999 and S.rel_l2(ga[k], gb[k]) <= 1e-3, (k, S.rel_l2(ga[k], gb[k]))

@@ -55,6 +55,10 @@ def random_scene(seed):
     opts['loose_max'] = int(rng.choice([0, 0, 6, 20, 48]))         # (drawn last: the scenes of the earlier rounds stay what they were)
     opts['quad_min_units'] = int(rng.choice([0, 0, 2048]))         # quad units whenever blocks are small enough / only on big orders (the default)
     opts['quad_max'] = int(rng.choice([64, 64, 20]))
+    # round 4: the scatter list packed (no idle halves) with as many quads as bring it into `quad_fit` workgroups -- one round of the
+    # chip's resident ones (1,024; small here so that scenes of a few dozen items take that road) -- or whenever it is more than that
+    opts['quad_fit'] = int(rng.choice([1024, 2, 8, 40]))
+    opts['pack_units'] = int(rng.choice([0, 1, 2]))
     return sc, opts, n_sub, liquid_only
 
 
@@ -80,3 +84,4 @@ def test_random_scene_matches_the_oracle(hiplib, oracle64, seed):
             assert S.cosine(ga[k], gb[k]) >= tol_cos and S.rel_l2(ga[k], gb[k]) <= tol_rel, (k, S.cosine(ga[k], gb[k]), S.rel_l2(ga[k], gb[k]))
     ws = g.get_work_stats(n_sub - 1)
     assert ws['n_items'] == sum(ws['items_by_size'].values())
+    assert ws['n_scatter_units'] <= ws['n_gather_units'] or not ws['packed']      # packing never needs more workgroups than the pairs-only list
