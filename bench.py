@@ -34,8 +34,10 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0          # measured float4 copy on this part: `frac_of_measured_copy`
 # rocprofv3 --pmc passes of THIS command line (`--steps 20 --warmup 5`), sliced by window (scripts/phase_profile.py): the traffic of
 # the roofline kernel is read for the same windows it is timed in, or not at all
-PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r03_pmc_traffic.json')
-ROCPROF_TIMED = os.path.join(ROOT, 'profiles', 'r03_kernel_stats_timed_region.csv')
+# (the files also record the engine's source hash and the device they were taken on: numbers of another build or another GPU are not printed)
+PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r04_pmc_traffic.json')
+ROCPROF_TIMED = os.path.join(ROOT, 'profiles', 'r04_kernel_stats_timed_region.csv')
+SRC_HASH_FILE = os.path.join(ROOT, 'fluidlab_amd', 'csrc', 'libfluidengine_hip.so.srchash')
 # fixed substep windows of the evolving block, comparable across --steps and across rounds (window w = substeps [100 w, 100 w + 100))
 PHASES = {'falling': (5, 11), 'impact': (11, 18), 'splash': (26, 34), 'layer': (80, 90)}
 
@@ -141,19 +143,29 @@ def fold_windows(rec, lo, hi):
     return out
 
 
+def source_hash():
+    try:
+        return open(SRC_HASH_FILE).read().strip()
+    except OSError:
+        return None
+
+
 def cpu_baseline(budget_s=12.0):
-    """The oracle (fp32 build, OpenMP over the host cores) on the same 128^3 / 200k workload: a bounded number of
-    forward+backward substep pairs.  Reported, never the target."""
+    """The oracle (fp32 build, OpenMP over the host cores) on the same 128^3 / 200k workload: a bounded number of forward+backward
+    substep pairs.  Its particle scatters (P2G, the adjoint scatter of G2P) run colour by colour over 4^3-cell blocks with plain adds
+    (oracle option `scatter`): with `#pragma omp atomic` they got slower beyond ~16 threads.  Reported, never the target."""
     from fluidlab_amd import _capi
     elib = _capi.EngineLib(os.path.join(ROOT, 'oracle', '_build', 'libfe_oracle_f32.so'))
     L = 3
     eng, _ = build_block(elib, 0, L=L)
-    ncpu = os.cpu_count() or 1
+    eng.set_option('scatter', 1)
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
     window_step(eng, 1)                                      # warm (page faults)
-    best = None                                              # float atomics in the scatter: more threads is not always faster
-    for c in sorted({ncpu, max(1, ncpu // 2), max(1, ncpu // 4), min(ncpu, 16)}, reverse=True):
+    best, sweep = None, {}
+    for c in sorted({ncpu, max(1, ncpu // 2), max(1, ncpu // 4), min(ncpu, 32), min(ncpu, 16)}, reverse=True):
         eng.set_option('threads', c)
         t = time.perf_counter(); window_step(eng, 1); t = time.perf_counter() - t
+        sweep[c] = round(1.0 / t, 2)
         if best is None or t < best[0]:
             best = (t, c)
     cores = best[1]
@@ -163,18 +175,19 @@ def cpu_baseline(budget_s=12.0):
     while True:
         window_step(eng, L)
         pairs += L
-        if time.perf_counter() - t0 > budget_s or pairs >= 90:
+        if time.perf_counter() - t0 > budget_s or pairs >= 150:
             break
     dt = time.perf_counter() - t0
     eng.close()
-    return {'value': pairs / dt, 'unit': 'substep_pairs/s', 'cores': cores, 'kind': 'port',
+    return {'value': pairs / dt, 'unit': 'substep_pairs/s', 'cores': cores, 'kind': 'port', 'threads_sweep_pairs_per_s': sweep,
             'sample': f'{pairs} fwd+bwd substep pairs of the same 128^3/200k water block (evolving window), oracle fp32 + OpenMP '
                       f'({cores} of {ncpu} hardware threads, fastest of a short sweep), {dt:.1f}s',
-            'scatter': 'particle-parallel loops, `#pragma omp atomic` fp32 adds into the shared grid (P2G and the adjoint scatter of G2P)'}
+            'scatter': 'coloured: particles bucketed by 4^3-cell block, eight colours one after the other, the blocks of a colour in parallel '
+                       'with plain adds (no atomics); dense n^3 grid loops as in the reference'}
 
 
 def extra_block(elib, device, name, n_grid, n, mat, L, reps):
-    """A bounded side measurement (config 5's sizes): pairs/s and pair_roofline of an at-rest block, never part of `value`."""
+    """A bounded side measurement: pairs/s, per-kernel event times and pair_roofline of an at-rest block, never part of `value`."""
     from fluidlab_amd import scenes as S
     rng = np.random.RandomState(0)
     side = (n / 8.0) ** (1 / 3) / n_grid                    # ~8 particles per cell
@@ -193,6 +206,7 @@ def extra_block(elib, device, name, n_grid, n, mat, L, reps):
     b_pair = 524 * st['n_used'] + 204 * st['n_cells_touched']
     out = {'workload': name, 'pairs_per_s': round(L / dt, 1), 'n_used': int(st['n_used']), 'n_cells_touched': int(st['n_cells_touched']),
            'pair_roofline': {'alg_bytes_per_pair': b_pair, 'frac': round(b_pair * L / dt / 1e9 / HBM_PEAK_GBS, 4)},
+           'kernels': kernel_table(prof, int(st['n_used']), int(st['n_cells_touched'])),
            'kernels_us': {k: round(1e3 * v[0] / v[1], 1) for k, v in prof.items() if v[1]}}
     eng.close()
     return out
@@ -236,6 +250,7 @@ def run_single(args):
     barrier()
     fwd_rate = nf * CHUNK / (time.perf_counter() - t1)
     n_used = int(st1['n_used'])
+    options = eng.get_options()                              # as the engine holds them: defaults, --opt, FE_* environment variables alike
     eng.close()
     w0, w1 = args.warmup, args.warmup + args.steps                     # the timed windows
     out = {
@@ -245,7 +260,9 @@ def run_single(args):
         'config': {'workload': 'water block 128^3 grid, 200k particles (BASELINE configs[1] inputs), fwd+bwd, evolving (rolling window)',
                    'substeps_per_step': CHUNK, 'timed_pairs': pairs, 'timed_s': round(wall, 3), 'timed_substeps': [w0 * CHUNK, w1 * CHUNK],
                    'n_used': n_used, 'nc_start': int(st0['n_cells_touched']), 'nc_end': int(st1['n_cells_touched']),
-                   'n_slow_path': int(st1['n_slow_path']), 'parallelism': '1 env, 1 GPU'},
+                   'n_slow_path': int(st1['n_slow_path']), 'parallelism': '1 env, 1 GPU',
+                   'engine_options': options, 'engine_env': {k: v for k, v in os.environ.items() if k.startswith('FE_')},
+                   'engine_source_hash': source_hash()},
         'roofline': None, 'pair_roofline': None,
         'forward_only_substeps_per_s': round(fwd_rate, 1),
         'hip_event_ms_per_step': round(ev_ms / args.steps, 3),
@@ -264,9 +281,10 @@ def run_single(args):
         share = {k: kern[k]['avg_us'] * kern[k]['launches'] for k in kern if kern[k]['alg_bytes'] > 0}
         dom = min((k for k in share if share[k] >= 0.98 * max(share.values())), key=lambda k: kern[k]['GBps'])
         traffic, rocprof_us = None, None
-        try:                                              # PMC passes of this very command line, same windows (else: no claim)
+        try:                                              # PMC passes of this very command line, same windows, same build, same GPU (else: no claim)
             pj = json.load(open(PMC_TRAFFIC))
-            if pj['steps'] == args.steps and pj['warmup'] == args.warmup:
+            same_build = pj.get('source_hash') == source_hash() and pj.get('device') == torch.cuda.get_device_name(0)
+            if pj['steps'] == args.steps and pj['warmup'] == args.warmup and same_build:
                 traffic = int(pj['timed_region']['kernels'][dom]['traffic_bytes'])
                 # the committed rocprofv3 --kernel-trace of the same command, same windows (scripts/gpu_profile.sh wrote both files)
                 import csv
@@ -343,6 +361,23 @@ def run_single(args):
                                  'ratio': round(r4 / r1, 3), 'timed_pairs_per_env': nb * CHUNK,
                                  'note': 'fe_step_batch: one launch per phase for all envs (gridDim.y = n_envs)'}
         from fluidlab_amd import scenes as S
+        # the default run's figure (10,000 pairs: the block falls, splashes and settles into a layer) beside `value`, whatever --steps was
+        if args.steps == 100 and args.warmup == 5:
+            extra['value_full_run'] = {'pairs_per_s': out['value'], 'timed_substeps': [500, 10500], 'note': 'this run'}
+        else:
+            e3, _ = build_block(elib, 0)
+            for _ in range(5):
+                window_step(e3, CHUNK)
+            e3.sync(); t3 = time.perf_counter()
+            for _ in range(100):
+                window_step(e3, CHUNK)
+            e3.sync()
+            extra['value_full_run'] = {'pairs_per_s': round(100 * CHUNK / (time.perf_counter() - t3), 1), 'timed_substeps': [500, 10500],
+                                       'note': 'the default `python bench.py` workload (100 steps after 5), run untimed beside the line\'s own timed region'}
+            e3.close()
+        # the metric's size through the GENERAL kernels (svd3, backward_svd, multi-material stress: compiled out for inviscid liquids)
+        extra['general_128_200k'] = extra_block(elib, 0, 'ICECREAM (plasto-elastic, SVD) block 128^3, 200k particles, fwd+bwd, 10 substeps from rest',
+                                                N_GRID, N_PARTICLES, S.ICECREAM, 10, 5)
         extra['config5_water_256_1M'] = extra_block(elib, 0, 'water block 256^3, 1M particles, fwd+bwd', 256, 1_000_000, S.WATER, 40, 3)
         extra['config5_icecream_256_1M'] = extra_block(elib, 0, 'ICECREAM (plasto-elastic, SVD) block 256^3, 1M particles, fwd+bwd, 10 substeps', 256, 1_000_000, S.ICECREAM, 10, 3)
         out['extra'] = extra
@@ -382,6 +417,8 @@ def run_replicas(args, rank, local_rank, world):
     assert par.world_size == world and par.dist is not None and par.dist.get_world_size() == world
     elib = _capi.load_hip()
     kw = dict(C4_SCENES[args.c4_scene], engine_lib=elib, device=dev)
+    if args.c4_window > 0:                                             # the reference's memory model: a window of substeps, checkpoints in host memory, the chunk's forward re-run in backward (mpm:856-912)
+        kw.update(max_substeps_local=args.c4_window, ckpt_dest='cpu')
     quiet = lambda: contextlib.redirect_stdout(io.StringIO())        # the env / solver layers print progress lines
     with quiet():
         # the target pattern every replica pours towards: the demo policy's recording (seed 0 on every rank)
@@ -489,7 +526,7 @@ def run_replicas(args, rank, local_rank, world):
             'config': {'workload': f'{world} LatteArt-v0 replicas ({args.c4_scene}: {"128^3" if args.c4_scene == "config3" else "64^3"} grid, {eng.N} particles each), '
                                    'one per GPU: one step = one Solver pass (forward with loss, backward, action-gradient all-reduce, Adam)',
                        'substep_pairs_per_step_per_rank': sub, 'rccl_world_size': dist.get_world_size(), 'dist_backend': args.dist_backend,
-                       'action_grad_shape': [env.horizon_action + 1, 3], 'lr_scale': args.c4_lr_scale,
+                       'action_grad_shape': [env.horizon_action + 1, 3], 'lr_scale': args.c4_lr_scale, 'window_substeps': args.c4_window or n_frames,
                        'envs_per_gpu': B,
                        'parallelism': f'{world * B} env replicas, {B} per GPU' + (' sharing launches (fe_step_batch)' if B > 1 else '') + ', 1 all-reduce of the action gradient per pass'},
             'n1_same_scene_pairs_per_s': round(n1_rate, 1),
@@ -513,12 +550,17 @@ def run_replicas(args, rank, local_rank, world):
     par.close()
 
 
+def core_share(local_rank, local_world, cpus):
+    """Rank `local_rank`'s equal, contiguous share of the cores `cpus` (fewer cores than ranks: everybody gets them all)."""
+    cpus = sorted(cpus)
+    per = len(cpus) // max(1, local_world)
+    return cpus[local_rank * per:(local_rank + 1) * per] if per >= 1 else cpus
+
+
 def pin_to_cores(local_rank, local_world):
     """Give this rank an equal, contiguous share of the cores the process may run on."""
     try:
-        cpus = sorted(os.sched_getaffinity(0))
-        per = max(1, len(cpus) // max(1, local_world))
-        mine = cpus[local_rank * per:(local_rank + 1) * per] or cpus
+        mine = core_share(local_rank, local_world, os.sched_getaffinity(0))
         os.sched_setaffinity(0, mine)
         return mine
     except (AttributeError, OSError):
@@ -551,6 +593,7 @@ def main():
     ap.add_argument('--replicas', action='store_true', help='run the N > 1 workload (LatteArt replicas + all-reduce) even with one rank')
     ap.add_argument('--c4-scene', default='config3', choices=sorted(C4_SCENES))
     ap.add_argument('--c4-lr-scale', type=float, default=0.1)
+    ap.add_argument('--c4-window', type=int, default=0, help='N > 1 workload: max_substeps_local (0 = the whole trajectory resident); tests use 50 so that eight ranks fit one device')
     ap.add_argument('--envs-per-gpu', type=int, default=1, help='N > 1 workload: B replicas per rank stepped in lockstep through fe_step_batch (they have to fit the HBM: the config-3 scene keeps ~150 GB per replica resident)')
     ap.add_argument('--opt', action='append', default=[], help='engine option name=value (tuning sweeps, N=1)')
     args = ap.parse_args()

@@ -62,7 +62,7 @@ class FeStats(C.Structure):
 # every symbol include/fluidengine.h declares (tests assert the libraries export all of them)
 ABI_SYMBOLS = [
     'fe_create', 'fe_destroy', 'fe_last_error', 'fe_backend', 'fe_real_size', 'fe_sync',
-    'fe_set_option', 'fe_init_particles', 'fe_substep', 'fe_substep_grad', 'fe_step',
+    'fe_set_option', 'fe_get_option', 'fe_init_particles', 'fe_substep', 'fe_substep_grad', 'fe_step',
     'fe_step_grad', 'fe_step_batch', 'fe_step_grad_batch', 'fe_get_frame', 'fe_set_frame', 'fe_get_frame_dev', 'fe_set_frame_dev', 'fe_copy_frame', 'fe_copy_grad',
     'fe_reset_grad', 'fe_reset_grad_till_frame', 'fe_get_grad', 'fe_add_grad', 'fe_get_mat',
     'fe_add_static', 'fe_eff_set_mesh', 'fe_add_effector', 'fe_eff_set_act_range', 'fe_eff_get_state', 'fe_eff_set_state',
@@ -109,6 +109,7 @@ class EngineLib:
         lib.fe_timer_stop_ms.restype = C.c_double
         lib.fe_timer_stop_ms.argtypes = [C.c_void_p]
         lib.fe_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
+        lib.fe_get_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]
 
     def mesh_sdf(self, verts, faces, points, device=0):
         """fe_mesh_sdf: signed distance of points[M,3] to the triangle mesh (verts[nv,3], faces[nf,3]); float32 out."""
@@ -239,6 +240,18 @@ class Engine:
 
     def set_option(self, name, value):
         self._ck(self.lib.fe_set_option(self.h, name.encode(), float(value)))
+
+    OPTION_NAMES = ('sort_interval', 'item_max', 'grid_store', 'p2g_grad_waves', 'g2p_grad_v', 'loose_max', 'xcd_map', 'write_through',
+                    'wave_sort', 'quad_min_units', 'quad_max', 'quad_fit', 'pack_units', 'wgrid_cap', 'collide_type')
+
+    def get_option(self, name):
+        v = C.c_double(0.0)
+        self._ck(self.lib.fe_get_option(self.h, name.encode(), C.byref(v)))
+        return v.value
+
+    def get_options(self):
+        """every tunable as the engine holds it now: defaults, fe_set_option calls and FE_* environment variables alike"""
+        return {n: self.get_option(n) for n in self.OPTION_NAMES}
 
     def init_particles(self, x, used, mat, mat_cls, mu, lam, rho, body_id):
         N = self.N

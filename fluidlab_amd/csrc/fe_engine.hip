@@ -562,7 +562,10 @@ __device__ __forceinline__ void tile_handover(const SimP& S, float4* slab, int i
     asm volatile("" : "+v"(l));             // (opaque, as in neighbour_entry: tz and its region are loop invariants otherwise)
     const int tx = l >> 6, ty = (l >> 3) & 7, tz = l & 7;
     const int e = __shfl(nbr_entry, tile_region(tx) * 9 + tile_region(ty) * 3 + tile_region(tz), 64);
-    if ((unsigned)(tx - 1) < (unsigned)SLAB_T && (unsigned)(ty - 1) < (unsigned)SLAB_T && (unsigned)(tz - 1) < (unsigned)SLAB_T)
+    // (one condition, not three short-circuited ones: those became nested branches across which the pieces of the slab index were kept
+    //  alive as 64-bit values -- and, in k_g2p_grad2, spilled)
+    const bool inner = ((unsigned)(tx - 1) < (unsigned)SLAB_T) & ((unsigned)(ty - 1) < (unsigned)SLAB_T) & ((unsigned)(tz - 1) < (unsigned)SLAB_T);
+    if (inner)
         slab_store<NPL>(slab, item, ((tx - 1) * SLAB_T + (ty - 1)) * SLAB_T + (tz - 1), v, wt);
     else if (e >= 0 && (v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f)) {
         float* dst = acc + cell_addr(to.ox + tx, to.oy + ty, to.oz + tz, S.nb);
@@ -1398,6 +1401,71 @@ __device__ __forceinline__ void g2p_grad_slot_global(const SimP& S, const FrameV
             for (int bz = st.base[2] >> 2; bz <= (st.base[2] + 2) >> 2; bz++) mark_dirty(GS, V.blk_slot, (bx * S.nb + by) * S.nb + bz);
 }
 
+// A particle that has left its tile since the sort, worked on by the WHOLE wave: lane n < 27 takes node n of its stencil (uniform
+// inputs: the slot `s` and the position `x`).  The per-lane road above walks the 27 nodes in a rolled loop, and every v_out comes
+// through two dependent loads (block table, then the store): nine rounds of two round trips, ~15 us during which the lane's wave --
+// and with it its workgroup's tile hand-over -- waits.  The block hitting the floor has ~60 such particles per substep, enough to
+// make their workgroups the launch's tail: k_g2p_grad 28.7 us where a fresh order takes 23.4 (k_p2g's slow path is fire-and-forget
+// atomics and costs it 1.4 us).  Here the 27 fetches are in flight together and the sums meet through cross-lane adds.
+__device__ __forceinline__ void g2p_grad_drifted(const SimP& S, const FrameV& Gn, const FrameV& Gc, int s, const float x[3],
+                                                 const VoutSrc& V, float* gg_out, const GridStore& GS) {
+    const int lane = threadIdx.x & 63;
+    Stencil st;
+    stencil_make(x, S.inv_dx, st);
+    PState g;
+    load_xvC(Gn, s, g);                                       // (one address for all lanes)
+    const float c4 = 4.f * S.inv_dx;
+    float qb[3], qx[3], qy[3], qz[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        qx[a] = c4 * g.C.a[a][0]; qy[a] = c4 * g.C.a[a][1]; qz[a] = c4 * g.C.a[a][2];
+        qb[a] = (g.v[a] + S.dt * g.x[a]) - (qx[a] * st.fx[0] + qy[a] * st.fx[1] + qz[a] * st.fx[2]);
+    }
+    const bool node = lane < 27;
+    const int n = node ? lane : 0, i = n / 9, j = (n / 3) % 3, k = n % 3;
+    const float wi = STW(st, i, 0), wj = STW(st, j, 1), wk = STW(st, k, 2);
+    const float dwi = stencil_dw(st, i, 0), dwj = stencil_dw(st, j, 1), dwk = stencil_dw(st, k, 2);
+    const float4 vo = vout_at(S, V, st.base[0] + i, st.base[1] + j, st.base[2] + k);
+    float q[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) q[a] = qb[a] + (float)i * qx[a] + (float)j * qy[a] + (float)k * qz[a];
+    const float W = node ? wi * wj * wk : 0.f;
+    if (node) {
+        float* dst = gg_out + cell_addr(st.base[0] + i, st.base[1] + j, st.base[2] + k, S.nb);
+        unsafeAtomicAdd(dst, W * q[0]); unsafeAtomicAdd(dst + S.ncell, W * q[1]); unsafeAtomicAdd(dst + 2 * S.ncell, W * q[2]);
+    }
+    const float sdot = node ? vo.x * q[0] + vo.y * q[1] + vo.z * q[2] : 0.f;
+    float r[6] = {dwi * wj * wk * sdot, wi * dwj * wk * sdot, wi * wj * dwk * sdot, W * vo.x, W * vo.y, W * vo.z};
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1)
+#pragma unroll
+        for (int c = 0; c < 6; c++) r[c] += __shfl_xor(r[c], o, 64);
+    // sum_o W c4 (v_o^T gC)_b enters with dpos_b = o_b - fx_b (g2p_grad_particle2)
+    const float gfx[3] = {r[0] - (r[3] * qx[0] + r[4] * qx[1] + r[5] * qx[2]), r[1] - (r[3] * qy[0] + r[4] * qy[1] + r[5] * qy[2]),
+                          r[2] - (r[3] * qz[0] + r[4] * qz[1] + r[5] * qz[2])};
+    if (lane == 0) pstore(Gc, Gc.A0, s, make_float4(g.x[0] + S.inv_dx * gfx[0], g.x[1] + S.inv_dx * gfx[1], g.x[2] + S.inv_dx * gfx[2], 0.f));
+    if (lane < 8) {                                           // the (up to 8) blocks whose gg_out planes now hold atomics
+        const int b0 = (lane & 1) ? (st.base[0] + 2) >> 2 : st.base[0] >> 2, b1 = (lane & 2) ? (st.base[1] + 2) >> 2 : st.base[1] >> 2,
+                  b2 = (lane & 4) ? (st.base[2] + 2) >> 2 : st.base[2] >> 2;
+        mark_dirty(GS, V.blk_slot, (b0 * S.nb + b1) * S.nb + b2);
+    }
+}
+// the lanes of a tile unit's wave whose particles drifted out of the tile (`drifted`: used, stencil on the grid, not on the tile;
+// `outside`: used, stencil off the grid -- passed through untouched, as the per-lane road does); a00 = the lane's (x, .) plane, s its slot
+__device__ __forceinline__ void g2p_grad_wave_slow(const SimP& S, const FrameV& Gn, const FrameV& Gc, int s, const float4 a00, bool drifted, bool outside,
+                                                   const VoutSrc& V, float* gg_out, int* slow, const GridStore& GS) {
+    if (outside) { const float4 gx = Gn.A0[s]; Gc.A0[s] = make_float4(gx.x, gx.y, gx.z, 0.f); }
+    unsigned long long todo = __ballot(drifted);
+    if (todo && (threadIdx.x & 63) == 0) atomicAdd(slow, __popcll(todo));
+    while (todo) {
+        const int L = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        const float x[3] = {__int_as_float(__builtin_amdgcn_readlane(__float_as_int(a00.x), L)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a00.y), L)),
+                            __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a00.z), L))};
+        g2p_grad_drifted(S, Gn, Gc, __builtin_amdgcn_readlane(s, L), x, V, gg_out, GS);
+    }
+}
+
 // workgroup-level flush of s_pose into the effectors' adjoint arrays (call with all threads; contains barriers)
 __device__ __forceinline__ void pose_flush(const AgentP& agent, int f) {
     __syncthreads();
@@ -1693,10 +1761,7 @@ __device__ __forceinline__ void g2p_grad2_body(SimP S, float* fr_cur, float* Gn_
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     for (int l = pc.t0; l < 3 * TILE_N; l += pc.nth) ((int*)s_acc3)[tofs + l] = 0;
                 }
-                if (used && !live) {
-                    if (inside) atomicAdd(slow, 1);
-                    g2p_grad_slot_global(S, cur, Gn, Gc, s, V, gg_out, agent, f, GS);
-                }
+                g2p_grad_wave_slow(S, Gn, Gc, s, a00, inside && !live, used && !inside, V, gg_out, slow, GS);      // (whole waves: wave-uniform loop)
             }
             TL(S, 5);
             unit_sync(pc.quad);
@@ -3798,6 +3863,20 @@ int fe_set_option(FeEngine* h, const char* name, double value) {
     if (!std::strcmp(name, "quad_max")) { if (value < 0 || value > QUAD_MAX) FAIL(h, "quad_max must be in [0, 64]"); h->quad = (int)value; return 0; }
     if (!std::strcmp(name, "wgrid_cap")) { if (value < 64) { h->err = "wgrid_cap must be >= 64"; return 1; } h->wgrid_cap = (int)value; return 0; }
     if (!std::strcmp(name, "threads")) return 0;             // oracle-only tunable
+    FAIL(h, std::string("unknown option: ") + name);
+}
+
+int fe_get_option(FeEngine* h, const char* name, double* value) {
+    FE_ENTRY(h);
+    if (!value) FAIL(h, "fe_get_option: null output");
+    const struct { const char* n; double v; } tab[] = {
+        {"sort_interval", (double)h->sort_interval}, {"item_max", (double)h->item_max}, {"grid_store", h->gs_cap > 0 ? 1.0 : 0.0},
+        {"p2g_grad_waves", (double)h->p2g_grad_waves}, {"g2p_grad_v", (double)h->g2p_grad_v}, {"loose_max", (double)h->loose_max},
+        {"inject_till", (double)h->inject_till}, {"collide_min_y", (double)h->collide_min_y}, {"collide_type", (double)h->collide_type},
+        {"prof_fine", h->prof_fine ? 1.0 : 0.0}, {"xcd_map", (double)h->S.xcd}, {"write_through", (double)h->S.wt}, {"wave_sort", (double)h->S.wsort},
+        {"quad_min_units", (double)h->quad_min_units}, {"quad_max", (double)h->quad}, {"quad_fit", (double)h->quad_fit}, {"pack_units", (double)h->pack_units},
+        {"wgrid_cap", (double)h->wgrid_cap}, {"threads", 0.0}};
+    for (const auto& t : tab) if (!std::strcmp(name, t.n)) { *value = t.v; return 0; }
     FAIL(h, std::string("unknown option: ") + name);
 }
 

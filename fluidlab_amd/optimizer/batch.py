@@ -57,8 +57,15 @@ class EnvBatch:
 
     def forward_backward(self, sim_states, policies, horizon, horizon_action):
         """Solver.forward_backward (solver.py:23-59) for the whole batch: [(loss_info, dLoss/d comp_actions)] per environment.
-        `policies`: one per environment (they may be the same object: replicas of one policy)."""
+        `policies`: one per environment (the same object for replicas of a plain actions table; staged policies need one object each)."""
         tes = self.tes
+        # A staged policy (StagePlan with a RETURN stage) writes its scripted actions into its own table from the environment it is asked
+        # for: shared between replicas that diverge (injector noise), every replica would read back the LAST one's action in the reverse
+        # sweep.  Replicas of a plain actions table may share the object; staged ones need a copy each.
+        for a in range(len(policies)):
+            for b in range(a):
+                assert policies[a] is not policies[b] or getattr(policies[a], 'plan', None) is None, \
+                    'EnvBatch.forward_backward: environments must not share a staged policy object (copy it per environment)'
         for te, st in zip(tes, sim_states):
             te.set_state(st, grad_enabled=True)
         t1 = time()

@@ -101,6 +101,9 @@ const char* fe_backend(void);                          /* "hip-gfx950", "oracle-
 int         fe_real_size(void);                        /* sizeof(fe_real)                      */
 int         fe_sync(FeEngine* h);                      /* wait for the engine's stream         */
 int         fe_set_option(FeEngine* h, const char* name, double value);  /* tunables, see DESIGN.md */
+/* The value an option has right now, wherever it came from (default, fe_set_option, an FE_* environment variable read at fe_create):
+ * bench.py echoes the effective options into its line.  Returns 1 for a name the library does not know. */
+int         fe_get_option(FeEngine* h, const char* name, double* value);
 
 /* ---- particles: init_particles_kernel, mpm:136-175 -------------------- */
 /* x[N,3]; used/mat/mat_cls/body_id[N] i32; mu/lam/rho[N].  mass = p_vol*rho.

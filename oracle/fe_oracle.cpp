@@ -22,6 +22,7 @@
  * Build: see oracle/Makefile (-DFE_REAL=float -> libfe_oracle_f32.so, double -> _f64).
  */
 #include <algorithm>
+#include <atomic>
 #include <array>
 #include <chrono>
 #include <cmath>
@@ -285,6 +286,7 @@ struct FeEngine {
     std::vector<R> chamfer, step_loss;
     std::string err;
     int threads = 1;
+    int scatter_coloured = 0;      /* option "scatter": 1 = the particle scatters go colour by colour without atomics (scatter_loop) */
     bool initialized = false;
     std::chrono::steady_clock::time_point t0;
     bool prof_on = false;
@@ -422,15 +424,67 @@ inline void p2g_local(FeEngine* h, int f, int p, P2GLocal& l) {
 }
 
 /* mpm:331-378 */
-int p2g(FeEngine* h, int f, bool write_F) {
-    const int N = h->N, n = h->n;
-    int bad = 0;
-    const bool par = h->threads > 1;
-#pragma omp parallel for num_threads(h->threads) schedule(static) reduction(+:bad)
+
+/* Scatter without atomics (option "scatter" = 1; bench.py's CPU baseline): the used particles are bucketed by the 4x4x4-cell block of
+ * their stencil base; a block's particles write nodes [4B, 4B + 5] per axis, so blocks whose indices have the same parity along every
+ * axis never touch the same node -- eight colours, one after the other, the blocks of a colour in parallel with plain adds.  With
+ * `#pragma omp atomic` (the default, which the parity tests use) more than ~16 threads made the scatter loops SLOWER. */
+struct ColourLists { std::vector<int> pid; std::vector<int> blk_start; std::vector<int> blocks[8]; };
+static void build_colour_lists(FeEngine* h, int f, ColourLists& L) {
+    const int N = h->N, n = h->n, nb = (n + 3) / 4;
+    std::vector<int> key(N, -1), cnt((size_t)nb * nb * nb + 1, 0);
     for (int p = 0; p < N; p++) {
         if (!h->Us(f)[p]) continue;
         Stencil s; make_stencil(&h->X(f)[p * 3], h->inv_dx, s);
-        if (!stencil_in_grid(s, n)) { bad++; continue; }
+        if (!stencil_in_grid(s, n)) continue;
+        key[p] = ((s.base[0] >> 2) * nb + (s.base[1] >> 2)) * nb + (s.base[2] >> 2);
+        cnt[key[p] + 1]++;
+    }
+    for (size_t b = 0; b + 1 < cnt.size(); b++) cnt[b + 1] += cnt[b];
+    L.blk_start = cnt;
+    L.pid.assign(cnt.back(), 0);
+    std::vector<int> fill(cnt.begin(), cnt.end() - 1);
+    for (int p = 0; p < N; p++) if (key[p] >= 0) L.pid[fill[key[p]]++] = p;
+    for (int c = 0; c < 8; c++) L.blocks[c].clear();
+    for (int b = 0; b + 1 < (int)cnt.size(); b++) {
+        if (cnt[b + 1] == cnt[b]) continue;
+        const int bi = b / (nb * nb), bj = (b / nb) % nb, bk = b % nb;
+        L.blocks[(bi & 1) * 4 + (bj & 1) * 2 + (bk & 1)].push_back(b);
+    }
+}
+/* run one(p, atomic) over every particle: in particle order with atomics, or colour by colour without */
+template <typename F>
+static void scatter_loop(FeEngine* h, int f, F&& one) {
+    const int N = h->N;
+    if (h->scatter_coloured && h->threads > 1) {
+        ColourLists L; build_colour_lists(h, f, L);
+        for (int c = 0; c < 8; c++) {
+            const std::vector<int>& bl = L.blocks[c];
+#pragma omp parallel for num_threads(h->threads) schedule(dynamic, 4)
+            for (long long i = 0; i < (long long)bl.size(); i++)
+                for (int q = L.blk_start[bl[i]]; q < L.blk_start[bl[i] + 1]; q++) one(L.pid[q], false);
+        }
+        /* particles without a bucket (unused / stencil off the grid) take the plain road: they scatter nothing */
+#pragma omp parallel for num_threads(h->threads) schedule(static)
+        for (int p = 0; p < N; p++) {
+            bool skip = false;
+            if (h->Us(f)[p]) { Stencil s; make_stencil(&h->X(f)[p * 3], h->inv_dx, s); skip = stencil_in_grid(s, h->n); }
+            if (!skip) one(p, false);
+        }
+    } else {
+        const bool par = h->threads > 1;
+#pragma omp parallel for num_threads(h->threads) schedule(static)
+        for (int p = 0; p < N; p++) one(p, par);
+    }
+}
+
+int p2g(FeEngine* h, int f, bool write_F) {
+    const int n = h->n;
+    std::atomic<int> bad{0};
+    scatter_loop(h, f, [&](int p, bool par) {
+        if (!h->Us(f)[p]) return;
+        Stencil s; make_stencil(&h->X(f)[p * 3], h->inv_dx, s);
+        if (!stencil_in_grid(s, n)) { bad++; return; }
         P2GLocal l; p2g_local(h, f, p, l);
         const R m = h->mass[p];
         const R* vp = &h->Vv(f)[p * 3];
@@ -450,7 +504,7 @@ int p2g(FeEngine* h, int f, bool write_F) {
                 h->g_mass[c] += weight * m;                                                  /* mpm:353 */
             } else h->g_mass[c] += weight * m;
         }
-        if (!write_F) continue;
+        if (!write_F) return;
         /* mpm:355-378 */
         M3 Fn = m_zero();
         int cls = h->mat_cls[p];
@@ -465,7 +519,7 @@ int p2g(FeEngine* h, int f, bool write_F) {
             Fn = m_mul(m_mul(l.U, Sn), m_T(l.V));
         }
         m_store(&h->Ff(f + 1)[p * 9], Fn);
-    }
+    });
     if (bad) { h->err = "particle stencil left the grid (p2g)"; return 1; }
     return 0;
 }
@@ -930,13 +984,11 @@ void advect_grad(FeEngine* h, int f) {
 
 /* g2p.grad (mpm:538) */
 void g2p_grad(FeEngine* h, int f) {
-    const int N = h->N, n = h->n;
-    const bool par = h->threads > 1;
-#pragma omp parallel for num_threads(h->threads) schedule(static)
-    for (int p = 0; p < N; p++) {
-        if (!h->Us(f)[p]) continue;
+    const int n = h->n;
+    scatter_loop(h, f, [&](int p, bool par) {
+        if (!h->Us(f)[p]) return;
         Stencil s; make_stencil(&h->X(f)[p * 3], h->inv_dx, s);
-        if (!stencil_in_grid(s, n)) continue;
+        if (!stencil_in_grid(s, n)) return;
         R gvn[3] = {h->GV(f + 1)[p * 3], h->GV(f + 1)[p * 3 + 1], h->GV(f + 1)[p * 3 + 2]};
         M3 gCn = m_load(&h->GC(f + 1)[p * 9]);
         R gfx[3] = {0, 0, 0};
@@ -978,7 +1030,7 @@ void g2p_grad(FeEngine* h, int f) {
             for (int b = 0; b < 3; b++) gfx[b] -= c4 * weight * (gv[0] * gCn.m[0][b] + gv[1] * gCn.m[1][b] + gv[2] * gCn.m[2][b]);
         }
         for (int d = 0; d < 3; d++) h->GX(f)[p * 3 + d] += h->inv_dx * gfx[d];
-    }
+    });
 }
 
 /* grid_op.grad (mpm:539) */
@@ -1570,6 +1622,16 @@ void fe_destroy(FeEngine* h) { if (h) delete h->smoke; delete h; }
 const char* fe_last_error(FeEngine* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 int fe_sync(FeEngine*) { return 0; }
 
+int fe_get_option(FeEngine* h, const char* name, double* value) {      // (the oracle has four options of its own; the HIP engine's tunables read as 0)
+    if (!value) { h->err = "fe_get_option: null output"; return 1; }
+    if (!std::strcmp(name, "threads")) { *value = h->threads; return 0; }
+    if (!std::strcmp(name, "scatter")) { *value = h->scatter_coloured; return 0; }
+    if (!std::strcmp(name, "inject_till")) { *value = h->inject_till; return 0; }
+    if (!std::strcmp(name, "collide_min_y")) { *value = (double)h->collide_min_y; return 0; }
+    if (!std::strcmp(name, "collide_type")) { *value = h->collide_type; return 0; }
+    *value = 0.0;
+    return 0;
+}
 int fe_set_option(FeEngine* h, const char* name, double value) {
     if (!std::strcmp(name, "threads")) {
         int t = (int)value;
@@ -1580,6 +1642,7 @@ int fe_set_option(FeEngine* h, const char* name, double value) {
 #endif
         h->threads = t; return 0;
     }
+    if (!std::strcmp(name, "scatter")) { h->scatter_coloured = value != 0; return 0; }
     if (!std::strcmp(name, "inject_till")) { h->inject_till = (int)value; return 0; }
     if (!std::strcmp(name, "collide_min_y")) { h->collide_min_y = (R)value; return 0; }
     if (!std::strcmp(name, "collide_type")) {

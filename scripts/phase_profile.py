@@ -25,6 +25,22 @@ SORT_KERNELS = ('k_sort', 'k_scan', 'k_build', 'k_clear_slots', 'k_set_static', 
 FIXED = {'falling': (5, 11), 'impact': (11, 18), 'splash': (18, 45), 'layer': (45, 10**9)}
 
 
+def _source_hash():
+    """the engine build these numbers belong to (bench.py prints them only beside the same build on the same GPU)"""
+    try:
+        return open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'fluidlab_amd', 'csrc', 'libfluidengine_hip.so.srchash')).read().strip()
+    except OSError:
+        return None
+
+
+def _device_name():
+    try:
+        import torch
+        return torch.cuda.get_device_name(0)
+    except Exception:
+        return None
+
+
 def clean(name):
     return name.replace('void ', '').strip()
 
@@ -108,7 +124,7 @@ def pmc(tag, steps, warmup, paths):
     out = {'note': 'rocprofv3 --pmc per-launch averages of `bench.py --steps %d --warmup %d --no-probe --no-extras --no-cpu-baseline`, one pass per counter '
                    'group, --kernel-trace only, launches assigned to windows of 100 substeps (scripts/phase_profile.py).  traffic_bytes = 2 x FETCH_SIZE + '
                    'WRITE_SIZE (KB -> bytes): the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md for 16 B/lane reads; traffic_raw_bytes is the plain sum.' % (steps, warmup),
-           'steps': steps, 'warmup': warmup}
+           'steps': steps, 'warmup': warmup, 'source_hash': _source_hash(), 'device': _device_name()}
     for ph, kern in per.items():
         a, b = phases_of(steps, warmup, w_max)[ph]
         d = {'substeps': [a * CHUNK, b * CHUNK], 'kernels': {}}

@@ -84,3 +84,21 @@ def test_bench_replicas_with_two_envs_per_gpu():
     assert out['config']['envs_per_gpu'] == 2 and out['config']['substep_pairs_per_step_per_rank'] == 6600
     assert out['value'] > 0 and out['passes_skipped_nonfinite_grad'] == 0 and out['loss_mean_over_envs'][0] > 0
     assert out['scaling_efficiency'] >= 0.9        # two replicas per launch are no slower per replica than one alone (measured ~1.2)
+
+
+@pytest.mark.gpu
+def test_bench_gpus_8_as_the_driver_launches_it_on_one_device():
+    """Eight ranks -- the driver's node -- before the driver runs them: `python bench.py --gpus 8` spawns its eight ranks, every rank a
+    LatteArt-v0 replica with its own injector noise, one all-reduce of the (251 x 3) action gradient per Solver pass.  The box has one
+    GPU: all ranks share it, the collective runs over gloo, and the trajectory is kept as a 50-substep window with host checkpoints
+    (`--c4-window`, the reference's memory model) so that eight replicas fit.  All eight policies must come out bit-identical."""
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '1', '--warmup', '1',
+           '--dist-backend', 'gloo', '--one-device', '--c4-scene', 'as_shipped', '--c4-window', '50']
+    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=2400, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+    assert out['n_gpus'] == 8 and out['config']['rccl_world_size'] == 8 and out['config']['window_substeps'] == 50
+    assert out['value'] > 0 and len(out['per_rank_pairs_per_s_compute_only']) == 8 and out['passes_skipped_nonfinite_grad'] == 0
+    assert out['actions_identical_across_ranks'] is True
+    cores = out['host']['cores_per_rank']
+    assert len(cores) == 8 and all(c >= 1 for c in cores) and sum(cores) <= out['host']['cpus_visible']

@@ -1,11 +1,12 @@
-"""Env-level data parallelism on CPU: world_size 2, gloo.  Each rank owns one environment
-replica with its own injector randomness; the action gradients are all-reduced once per optimisation pass and
-the replicated Adam state must stay bit-identical."""
+"""Env-level data parallelism on CPU: world_size 2 and 8 (the driver's node: one rank per GPU), gloo.  Each rank
+owns one environment replica with its own injector randomness; the action gradients are all-reduced once per optimisation pass
+and the replicated Adam state must stay bit-identical on every rank."""
 import os
 import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -41,20 +42,38 @@ par.close()
 '''
 
 
-def test_two_rank_gloo_action_gradient_allreduce(tmp_path):
+@pytest.mark.parametrize('world', [2, 8])
+def test_gloo_action_gradient_allreduce(tmp_path, world):
     script = tmp_path / 'worker.py'
     script.write_text(WORKER % dict(root=ROOT, out=str(tmp_path)))
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='2')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
-           '--master-port', '29517', str(script)]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='2' if world == 2 else '1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
+           '--master-port', str(29517 + world), str(script)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     import pickle
-    logs = [pickle.load(open(tmp_path / f'rank{k}.pkl', 'rb')) for k in range(2)]
+    logs = [pickle.load(open(tmp_path / f'rank{k}.pkl', 'rb')) for k in range(world)]
     for it in range(2):
-        a, b = logs[0][it], logs[1][it]
-        assert not np.array_equal(a['g_local'], b['g_local'])                 # replicas really differ
-        mean = 0.5 * (a['g_local'].astype(np.float32) + b['g_local'].astype(np.float32))
-        assert np.allclose(a['g_mean'], mean, rtol=1e-6, atol=1e-12)
-        assert np.array_equal(a['g_mean'], b['g_mean'])                       # identical on every rank ...
-        assert np.array_equal(a['actions'], b['actions'])                     # ... so the policies stay bit-identical
+        rows = [lg[it] for lg in logs]
+        for k in range(1, world):
+            assert not np.array_equal(rows[0]['g_local'], rows[k]['g_local'])      # replicas really differ (per-rank injector noise)
+        mean = np.mean([r_['g_local'].astype(np.float32) for r_ in rows], axis=0)
+        assert np.allclose(rows[0]['g_mean'], mean, rtol=2e-6, atol=1e-12)
+        for k in range(1, world):
+            assert np.array_equal(rows[0]['g_mean'], rows[k]['g_mean'])            # identical on every rank ...
+            assert np.array_equal(rows[0]['actions'], rows[k]['actions'])          # ... so the policies stay bit-identical
+
+
+def test_pin_to_cores_gives_every_rank_of_a_node_its_own_cores():
+    """bench.py pins each rank to an equal, contiguous share of the cores (the host enqueues most of a core's worth of launches per
+    rank): eight ranks of one node get eight disjoint, non-empty sets that cover what the process may run on."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for cpus in (list(range(256)), list(range(8)), [3, 5, 9, 11, 12, 13, 20, 21, 22, 40], list(range(5))):
+        sets = [bench.core_share(r, 8, cpus) for r in range(8)]
+        assert all(len(s_) >= 1 for s_ in sets)
+        if len(cpus) >= 8:
+            flat = [c for s_ in sets for c in s_]
+            assert len(flat) == len(set(flat)) and set(flat) <= set(cpus)            # disjoint
+            assert max(len(s_) for s_ in sets) - min(len(s_) for s_ in sets) <= 0   # equal shares
+    assert bench.core_share(0, 1, [0, 1, 2, 3]) == [0, 1, 2, 3]
