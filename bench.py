@@ -496,7 +496,8 @@ def run_replicas(args, rank, local_rank, world):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     wall_max = float(t.item())
     rss_gb = host_rss_gb()
-    hbm_gb = sum(e.taichi_env.simulator.engine.get_stats(n_frames - 1)['bytes_state'] for e in envs) / 2**30
+    f_stats = min(n_frames, args.c4_window or n_frames) - 1        # a frame the engine holds (the window's last one when the trajectory is chunked)
+    hbm_gb = sum(e.taichi_env.simulator.engine.get_stats(f_stats)['bytes_state'] for e in envs) / 2**30
     import hashlib
     dig = hashlib.sha256(np.ascontiguousarray(policy.comp_actions, dtype=np.float64).tobytes()).digest()      # the policy after the last Adam step
     h_lo, h_hi = float(int.from_bytes(dig[:4], 'little')), float(int.from_bytes(dig[4:8], 'little'))
@@ -514,7 +515,7 @@ def run_replicas(args, rank, local_rank, world):
         dist.all_reduce(probe)
     torch.cuda.synchronize()
     ar_us = 1e6 * (time.perf_counter() - p0) / 50
-    st = eng.get_stats(n_frames - 1)
+    st = eng.get_stats(f_stats)
     if rank == 0:
         per_rank = [float(a[0]) for a in allr]
         value = world * sub * args.steps / wall_max

@@ -143,6 +143,7 @@ struct SimP {
     int wsort;                               // option "wave_sort": the scatter kernels regroup their lanes by stencil base before the scan (wave_sort_dest)
     int wt;                                  // option "write_through": bulk outputs as sc1 stores (see wt_store16); bit 0 p2g, 1 g2p, 2 g2p_grad, 3 p2g_grad
     float dx, inv_dx, dt, stress_scale;     // stress_scale = -dt * p_vol * 4 * inv_dx^2 (mpm:343)
+    int uni; float uinfo[4];                 // every particle has the same material record (mu, lam, mass, class | material): it travels here instead of 16 bytes per particle and kernel
     float g[3];
     BoundaryP bnd;
 };
@@ -165,11 +166,17 @@ struct AgentP { int n; int inj; const EffP* e; float collide_min_y; const Bounda
 struct InjectP { int on, act_id, row, flux; };                     // per-substep injection parameters (host-known)
 
 struct PInfo { float mu, lam, mass; int cls, mat; };
-__device__ __forceinline__ PInfo load_info(const float4* info, int i) {
-    float4 t = info[i];
+__device__ __forceinline__ PInfo unpack_info(const float4 t) {
     PInfo r; r.mu = t.x; r.lam = t.y; r.mass = t.z;
     int bits = __float_as_int(t.w); r.cls = bits & 0xffff; r.mat = (bits >> 16) & 0xffff;
     return r;
+}
+__device__ __forceinline__ PInfo load_info(const float4* info, int i) { return unpack_info(info[i]); }
+// the record of slot i of an order -- or the scene's one record (uniform branch): a single-material scene reads 16 bytes per particle less
+// in k_p2g and k_p2g_grad, and its sorts move 16 bytes per particle less
+__device__ __forceinline__ PInfo load_info(const SimP& S, const float4* info, int i) {
+    if (S.uni) return unpack_info(make_float4(S.uinfo[0], S.uinfo[1], S.uinfo[2], S.uinfo[3]));
+    return unpack_info(info[i]);
 }
 
 // A block is on the active list of the order a substep runs in exactly when that order's blk_slot holds an entry for it (>= 0):
@@ -309,21 +316,41 @@ __device__ __forceinline__ void seg_scan3(const SegScan& sc, float& a, float& b,
 // floor; 38k / 85k / 108k while it falls.  ds_add_f64 goes at ~2.6 lane-operations per clock and CU, and with every second lane a
 // run of its own the scatter kernels are bound by it: k_p2g 32.5 us with a sort every 10 substeps, 22.3 us with one every substep
 // (k_g2p_grad 33.5 / 23.4; on the falling block 23.4 / 19.7) -- but a sort is 60 us.  Regrouping the 64 lanes of the wave by their
-// CURRENT key before the scan brings the runs back to 60k / 64k (48k / 51k falling) for ~250 instructions per wave: the rank of
-// every lane among the wave's (key, lane) pairs from 64 cross-lane reads, then one ds_permute per value the scatter loop consumes.
+// CURRENT key before the scan brings the runs back to 60k / 64k (48k / 51k falling) for ~150 instructions per wave: the rank of
+// every lane among the wave's (key, lane) pairs (wave_sort_dest), then one ds_permute per value the scatter loop consumes.
 // A wave whose keys are still in order (a fresh sort, an item of one cell) skips all of it.
 // -----------------------------------------------------------------------------------------
 __device__ __forceinline__ bool wave_needs_sort(int key) {       // all 64 lanes; wave-uniform result
     const int prev = __shfl_up(key, 1, 64);
     return __any((threadIdx.x & 63) != 0 && prev > key);
 }
-// byte address (for ds_permute) of the lane this lane's values go to: its rank among the wave's (key, lane) pairs.  0 <= key < 2^20.
+// byte address (for ds_permute) of the lane this lane's values go to: its rank among the wave's (key, lane) pairs.  0 <= key < 1024.
+// Bit-serial, most significant bit first: every lane keeps the set of lanes whose keys equal its own so far (`eq`, a 64-bit mask) and
+// counts those that fell below it: a ballot per bit, two and-nots, two population counts -- ~12 instructions for each of the 10 bits,
+// where comparing against all 64 lanes one cross-lane read at a time took ~220 (and an SGPR hazard stall after each read).
+#ifndef WSORT_BITS
+#define WSORT_BITS 1
+#endif
 __device__ __forceinline__ int wave_sort_dest(int key) {
+#if WSORT_BITS
+    unsigned eq_lo = ~0u, eq_hi = ~0u;                         // (two halves: the 64-bit form kept a lane mask alive -- in scratch -- across the kernel)
+    int lt = 0;
+#pragma unroll
+    for (int b = 9; b >= 0; b--) {
+        const bool mine = (key >> b) & 1;
+        const unsigned long long m = __ballot(mine);
+        const unsigned z_lo = eq_lo & ~(unsigned)m, z_hi = eq_hi & ~(unsigned)(m >> 32);     // equal so far, with a 0 in this bit
+        lt += mine ? __popc(z_lo) + __popc(z_hi) : 0;          // ... smaller than a key with a 1 there
+        eq_lo = mine ? eq_lo ^ z_lo : z_lo; eq_hi = mine ? eq_hi ^ z_hi : z_hi;
+    }
+    return (lt + (int)__builtin_amdgcn_mbcnt_hi(eq_hi, __builtin_amdgcn_mbcnt_lo(eq_lo, 0u))) << 2;      // equal keys keep their lane order
+#else
     const unsigned kl = ((unsigned)key << 6) | (threadIdx.x & 63);
     int rank = 0;
 #pragma unroll
     for (int j = 0; j < 64; j++) rank += ((unsigned)__builtin_amdgcn_readlane((int)kl, j) < kl) ? 1 : 0;
     return rank << 2;
+#endif
 }
 __device__ __forceinline__ void wave_send(int dest, float& v) { v = __int_as_float(__builtin_amdgcn_ds_permute(dest, __float_as_int(v))); }
 __device__ __forceinline__ void wave_send(int dest, int& v) { v = __builtin_amdgcn_ds_permute(dest, v); }
@@ -613,8 +640,8 @@ __device__ __forceinline__ void unused_particle_fwd(const SimP& S, const FrameV&
 // collector_act_kernel (agent_pouring.py:30-41, agent_jetbot.py:33-43) for one used slot: outside the collector boundary the
 // particle is marked unused in frames f and f+1 and parked at NOWHERE in f+1 (v, C, F carried over, where the reference
 // leaves f+1 stale).  Returns true when the particle was taken; the backward pass then finds used[f] == 0.
-__device__ __forceinline__ bool collector_takes(const FrameV& cur, const FrameV& nxt, int s, const float4* __restrict__ info, const AgentP& agent) {
-    if (agent.collector_mat >= 0 && load_info(info, s).mat != agent.collector_mat) return false;
+__device__ __forceinline__ bool collector_takes(const SimP& S, const FrameV& cur, const FrameV& nxt, int s, const float4* __restrict__ info, const AgentP& agent) {
+    if (agent.collector_mat >= 0 && load_info(S, info, s).mat != agent.collector_mat) return false;
     PState p;
     load_xvC(cur, s, p);
     if (!boundary_is_out(*agent.collector, p.x)) return false;
@@ -631,10 +658,10 @@ struct P2GPrep { Stencil st; float mv[3]; m3 affine; float m; bool inside; };
 
 // compute_F_tmp + svd + stress + F update for one used particle (mpm:254-264, 331-344, 355-378)
 struct P2GRaw { PState p; PInfo info; };
-__device__ __forceinline__ void p2g_load(const FrameV& cur, int s, const float4* __restrict__ info_, P2GRaw& r) {
+__device__ __forceinline__ void p2g_load(const SimP& S, const FrameV& cur, int s, const float4* __restrict__ info_, P2GRaw& r) {
     load_xvC(cur, s, r.p);
     load_F(cur, s, r.p.F);
-    r.info = load_info(info_, s);
+    r.info = load_info(S, info_, s);
 }
 template <bool WRITE, bool GENERAL>
 __device__ __forceinline__ void p2g_compute(const SimP& S, const FrameV& nxt, int s, const P2GRaw& r, const GridW& G, P2GPrep& q) {
@@ -657,7 +684,7 @@ template <bool WRITE, bool GENERAL>
 __device__ __forceinline__ void p2g_prepare(const SimP& S, const FrameV& cur, const FrameV& nxt, int s,
                                             const float4* __restrict__ info_, const GridW& G, P2GPrep& q) {
     P2GRaw r;
-    p2g_load(cur, s, info_, r);
+    p2g_load(S, cur, s, info_, r);
     p2g_compute<WRITE, GENERAL>(S, nxt, s, r, G, q);
 }
 
@@ -834,10 +861,10 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
                 const int s_ld = has ? s : it.y;
                 const int uflag = cur.used[s_ld];
                 P2GRaw raw;
-                p2g_load(cur, s_ld, T.info, raw);
+                p2g_load(S, cur, s_ld, T.info, raw);
                 bool used = has && uflag != 0;
                 bool taken = false;
-                if (WRITE && used && act && agent.collector) { taken = collector_takes(cur, nxt, s, T.info, agent); used = !taken; }
+                if (WRITE && used && act && agent.collector) { taken = collector_takes(S, cur, nxt, s, T.info, agent); used = !taken; }
                 P2GPrep q;
                 q.inside = false;
                 int lb = -1;
@@ -900,7 +927,7 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
             const int s = un.a.y + tid;
             if (s < S.N) {
                 if (cur.used[s]) {
-                    if (WRITE && act && agent.collector && collector_takes(cur, nxt, s, T.info, agent)) continue;
+                    if (WRITE && act && agent.collector && collector_takes(S, cur, nxt, s, T.info, agent)) continue;
                     P2GPrep q;
                     p2g_prepare<WRITE, GENERAL>(S, cur, nxt, s, T.info, G, q);
                     if (q.inside) p2g_scatter_global(S, q, G, GS, T.blk_slot);
@@ -2108,7 +2135,7 @@ __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const Fram
     PState p;
     PInfo info;
     if (PRE) { p = pre.p; info = pre.info; }                  // (asked for ahead of the tile load and its barrier: p2g_grad_body)
-    else { load_xvC(cur, s, p); load_F(cur, s, p.F); info = load_info(info_, s); }
+    else { load_xvC(cur, s, p); load_F(cur, s, p.F); info = load_info(S, info_, s); }
     Constitutive k;
     constitutive_eval_t<GENERAL>(p.C, p.F, S.dt, info.mu, info.lam, info.mass, info.cls, S.stress_scale, k);
     Stencil st;
@@ -2688,7 +2715,7 @@ __global__ __launch_bounds__(256) void k_build_units(int nb, int N, int xcd_on, 
 struct UnitsArgs { int* bcnt; int nb, xcd_on, quad_min_units, quad_fit, pack_units; const int4* items; const int2* pairs; const int* singles; const int2* blk_first; const int* active; int* meta; UnitRec* units; UnitRec* units_p; int units_cap; int2* nbr; };
 __global__ __launch_bounds__(256) void k_sort_apply(int N, size_t Np, int n_pwg, const int* __restrict__ key, const int* __restrict__ rank,
                                                     const int* __restrict__ start, const int* __restrict__ pid_old, int* pid_new, int* slot_of_pid,
-                                                    const float4* __restrict__ pinfo, float4* info_new, float* dst_, float* src_, UnitsArgs U) {
+                                                    const float4* __restrict__ pinfo, float4* info_new, float* dst_, float* src_, UnitsArgs U, int uni) {
     if ((int)blockIdx.x >= n_pwg) {          // (independent of the permutation: both only need what the scan and k_sort_fill left)
         for (int i = (blockIdx.x - n_pwg) * 256 + threadIdx.x; i <= U.nb * U.nb * U.nb; i += SORT_UNIT_WGS * 256) U.bcnt[i] = 0;      // block counts: ready for the next sort
         build_units_dev((blockIdx.x - n_pwg) * 256 + threadIdx.x, SORT_UNIT_WGS * 256, U.nb, N, U.xcd_on, U.quad_min_units, U.quad_fit, U.pack_units, U.items, U.pairs, U.singles, U.blk_first, U.active, U.meta,
@@ -2704,7 +2731,7 @@ __global__ __launch_bounds__(256) void k_sort_apply(int N, size_t Np, int n_pwg,
     const float a3 = q.a3[s], a4 = q.a4[s], a5 = q.a5[s], b2 = q.b2[s];
     const int u = q.used[s];
     pid_new[d] = pid;
-    info_new[d] = pinfo[pid];                                  // the order's slot-indexed material record (TableP::info)
+    if (!uni) info_new[d] = pinfo[pid];                        // the order's slot-indexed material record (TableP::info); nobody reads it in a single-material scene
     slot_of_pid[pid] = d;
     o.A0[d] = a0; o.A1[d] = a1; o.A2[d] = a2; o.a3[d] = a3; o.a4[d] = a4; o.a5[d] = a5;
     o.B0[d] = b0; o.B1[d] = b1; o.b2[d] = b2; o.used[d] = u;
@@ -3121,9 +3148,9 @@ struct FeEngine {
     std::vector<int> tbl_of_frame;                          // [L+1]
     int gtbl[2] = {-1, -1};                                 // order of each adjoint ring slot; -1 = all zero
     int p2g_grad_waves = 4;                                 // occupancy target of the SVD-free p2g_grad build (tuning)
-    int pack_units = 1;                                     // option "pack_units": 0 never, 1 pack the scatter list (no idle halves) when that brings it back into one round, 2 whenever it is more than one round
+    int pack_units = 2;                                     // option "pack_units": 0 never, 1 pack the scatter list (no idle halves) when that brings it back into one round, 2 whenever it is more than one round
     int quad_fit = 1024;                                    // option "quad_fit": the workgroups of one resident round (set from the device in fe_create: 4 per CU); 0 = round 3's rule
-    int quad_min_units = 2048;                              // option "quad_min_units": quad units only when pairs alone would be more workgroups than this (build_units_dev)
+    int quad_min_units = 1400;                              // option "quad_min_units": quad units only when pairs alone would be more workgroups than this (build_units_dev)
     int quad = QUAD_MAX;                                    // option "quad_max": single-item blocks of at most this many particles go four to a workgroup (0: never)
     int g2p_grad_v = 3;                                     // build of the G2P adjoint: 3 = split passes, x offset rolled (k_g2p_grad2<4>, default); 2 = split, unrolled completely (<3>); 1 = fused rolled loop (k_g2p_grad)
     int item_max = ITEM_MAX_CAP;                            // particles per work item (<= ITEM_MAX_CAP = one half workgroup)
@@ -3363,7 +3390,7 @@ int sort_frame(FeEngine* h, int f) {
     int* pid_dst = id_old == id_new ? h->sort_pid : tn.pid;
     const UnitsArgs U = {h->sort_bcnt, h->nb, h->S.xcd, h->quad_min_units, h->quad_fit, h->pack_units, tn.items, tn.pairs, tn.singles, tn.blk_first, tn.active, tn.meta, tn.units, tn.units_p, (int)h->units_cap, tn.nbr};
     hipLaunchKernelGGL(k_sort_apply, dim3(n_pwg + SORT_UNIT_WGS), dim3(256), 0, h->stream, h->N, (size_t)h->Np, n_pwg, h->sort_key, h->sort_rank, h->sort_start,
-                       h->tables[id_old].pid, pid_dst, tn.slot_of_pid, h->pinfo, tn.info, h->spare_frame(), h->frame(f), U);
+                       h->tables[id_old].pid, pid_dst, tn.slot_of_pid, h->pinfo, tn.info, h->spare_frame(), h->frame(f), U, h->S.uni);
     if (id_old == id_new) HIPCK(h, hipMemcpyAsync(tn.pid, h->sort_pid, sizeof(int) * h->Np, hipMemcpyDeviceToDevice, h->stream));
     prof_end(h);
     std::swap(h->frame_ptr[f], h->spare_frame());
@@ -3737,6 +3764,7 @@ FeEngine* fe_create(const FeConfig* cfg) {
     h->own_stream = h->stream;
     SimP& S = h->S;
     S.xcd = 16;                                            // blocked-cyclic unit mapping (A/B in DESIGN.md section 6)
+    S.uni = 0;
     S.wsort = 1;                                           // lanes regrouped by stencil base before the scan (A/B in DESIGN.md section 6)
     S.wt = 5;                                              // p2g and g2p_grad: their bulk stores come early (A/B in DESIGN.md section 6)
     S.N = h->N; S.Np = h->Np; S.n = h->n; S.nb = h->nb; S.ncell = h->nb * h->nb * h->nb * 64;
@@ -3897,6 +3925,12 @@ int fe_init_particles(FeEngine* h, const fe_real* x, const int* used, const int*
         F0[(size_t)i * 9] = F0[(size_t)i * 9 + 4] = F0[(size_t)i * 9 + 8] = 1.f;
     }
     h->all_simple_liquid = simple;
+    {   // one material record for every particle?  (collector scenes pick particles by material through the per-slot record: they keep it)
+        bool uni = N > 0;
+        for (int i = 1; i < N && uni; i++) uni = std::memcmp(&info[i], &info[0], sizeof(float4)) == 0;
+        h->S.uni = uni ? 1 : 0;
+        if (uni) { h->S.uinfo[0] = info[0].x; h->S.uinfo[1] = info[0].y; h->S.uinfo[2] = info[0].z; h->S.uinfo[3] = info[0].w; }
+    }
     // init_bodies, mpm:176-201
     h->has_rigid = false; h->n_bodies = 0;
     for (int i = 0; i < N; i++) {

@@ -46,7 +46,7 @@ def run(cfg):
     finally:
         bench.build_block = orig
     out = {'config': cfg or '(defaults)', 'wall_s': round(wall, 2)}
-    for name, (a, b) in list(bench.PHASES.items()) + [('timed', (5, 25)), ('all', (5, n_win))]:
+    for name, (a, b) in list(bench.PHASES.items()) + [('esplash', (18, 25)), ('timed', (5, 25)), ('all', (5, n_win))]:
         if b <= n_win or name == 'all':
             f = bench.fold_windows(rec, a, min(b, n_win))
             out[name] = {'pairs_per_s': f.get('pairs_per_s'), 'us_per_pair': round(1e6 / f['pairs_per_s'], 1) if f.get('pairs_per_s') else None, 'nc': f['nc_mean'],

@@ -2,7 +2,7 @@
 import json, sys
 rows = [json.loads(l) for l in open(sys.argv[1]) if l.startswith('{')]
 ks = ['p2g', 'grid_op', 'g2p', 'g2p_grad', 'grid_op_grad', 'p2g_grad', 'sort', 'reorder_grad', 'sort_count', 'sort_scan', 'sort_active', 'sort_perm']
-for ph in ('falling', 'impact', 'timed', 'splash', 'layer', 'all'):
+for ph in ('falling', 'impact', 'esplash', 'timed', 'splash', 'layer', 'all'):
     print('==', ph)
     for r in rows:
         d = r.get(ph)

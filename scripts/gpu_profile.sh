@@ -1,7 +1,7 @@
 #!/bin/bash
 # The round's profile evidence, on the GPU box: rocprofv3 kernel trace + PMC passes of the DRIVER'S command line, sliced into the
 # phases of the evolving block (scripts/phase_profile.py).  usage: scripts/gpu_profile.sh <tag> [steps warmup]
-TAG=${1:-r03}; STEPS=${2:-20}; WARM=${3:-5}
+TAG=${1:-r04}; STEPS=${2:-20}; WARM=${3:-5}
 OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT/profiles
 export TMPDIR=/tmp PROFILE_OUT=$OUT/profiles
 CMD="python $PWD/bench.py --gpus 1 --steps $STEPS --warmup $WARM --no-probe --no-extras --no-cpu-baseline"

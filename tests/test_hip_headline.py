@@ -78,7 +78,7 @@ def test_config2_water_block_128_matches_the_oracle(hiplib, oracle64):
 
 def test_config2_splash_state_with_quad_units_matches_the_oracle(hiplib, oracle64, oracle32):
     """Parity in the state that decides the benchmark's `value`: the scene is run on the HIP engine to substep 2,600 (the splash:
-    > 2,048 pair units, so the sort lays out quad units by the default options), that frame seeds a fresh HIP engine and the fp64
+    more pair units than `quad_min_units`, so the sort lays out quad units by the default options), that frame seeds a fresh HIP engine and the fp64
     oracle, 10 forward + 10 backward substeps on each.  `n_quad_units > 0` proves the quad path (fixed-point tiles) is what ran."""
     import bench
     eng, _ = bench.build_block(hiplib, 0, L=100)

@@ -247,7 +247,7 @@ def test_scattered_droplets_and_untouched_blocks(hiplib, oracle64, grid_store, l
     (grid_store 1) and backward from the recompute (grid_store 0) must match the oracle, and so must the work list the stats report.
     loose_max 12: blocks with up to 12 particles get no work item, their particles are worked on in cell order by the global path.
     quads 1: the single-item blocks of at most 64 particles go four to a workgroup, one wave and one fixed-point LDS tile each (the
-    scatter kernels' quad units; by default only orders with more than 2048 workgroups of pairs get them)."""
+    scatter kernels' quad units; by default only orders with more than `quad_min_units` (1,400) workgroups of pairs get them)."""
     rng = np.random.RandomState(3)
     n_drop, n_clump = 1500, 2500
     sc = S.water_block(n_grid=64, n_particles=n_drop + n_clump, lo=0.40, hi=0.52)

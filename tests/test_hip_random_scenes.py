@@ -53,7 +53,7 @@ def random_scene(seed):
             'item_max': int(rng.choice([64, 96, 128]))}
     n_sub = int(rng.choice([5, 12, 21]))
     opts['loose_max'] = int(rng.choice([0, 0, 6, 20, 48]))         # (drawn last: the scenes of the earlier rounds stay what they were)
-    opts['quad_min_units'] = int(rng.choice([0, 0, 2048]))         # quad units whenever blocks are small enough / only on big orders (the default)
+    opts['quad_min_units'] = int(rng.choice([0, 0, 2048]))         # quad units whenever blocks are small enough / only on big orders
     opts['quad_max'] = int(rng.choice([64, 64, 20]))
     # round 4: the scatter list packed (no idle halves) with as many quads as bring it into `quad_fit` workgroups -- one round of the
     # chip's resident ones (1,024; small here so that scenes of a few dozen items take that road) -- or whenever it is more than that
