@@ -1,6 +1,6 @@
 #!/bin/bash
 # End-of-round evidence besides the profiles: the bench lines the driver will reproduce, the replica path.  usage: scripts/gpu_final.sh <tag>
-TAG=${1:-r03f}; OUT=gpurun_out/$TAG; mkdir -p $OUT
+TAG=${1:-r04f}; OUT=gpurun_out/$TAG; mkdir -p $OUT
 export TMPDIR=/tmp
 rocminfo 2>/dev/null | grep -m3 -E "Marketing Name|gfx9" > $OUT/device.txt; nproc >> $OUT/device.txt; grep -m1 "model name" /proc/cpuinfo >> $OUT/device.txt
 echo "== bench (driver flags)"; timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 2>&1 | grep '^{' | tail -1 > $OUT/bench_driver.json; cut -c1-300 $OUT/bench_driver.json
