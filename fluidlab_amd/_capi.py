@@ -109,7 +109,8 @@ class EngineLib:
         lib.fe_timer_stop_ms.restype = C.c_double
         lib.fe_timer_stop_ms.argtypes = [C.c_void_p]
         lib.fe_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_double]
-        lib.fe_get_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]
+        if hasattr(lib, 'fe_get_option'):                 # (A/B builds of earlier rounds, scripts/ab_phases.py `lib=`, do not have it)
+            lib.fe_get_option.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]
 
     def mesh_sdf(self, verts, faces, points, device=0):
         """fe_mesh_sdf: signed distance of points[M,3] to the triangle mesh (verts[nv,3], faces[nf,3]); float32 out."""
@@ -242,7 +243,7 @@ class Engine:
         self._ck(self.lib.fe_set_option(self.h, name.encode(), float(value)))
 
     OPTION_NAMES = ('sort_interval', 'item_max', 'grid_store', 'p2g_grad_waves', 'g2p_grad_v', 'loose_max', 'xcd_map', 'write_through',
-                    'wave_sort', 'quad_min_units', 'quad_max', 'quad_fit', 'pack_units', 'wgrid_cap', 'collide_type')
+                    'wave_sort', 'quad_min_units', 'quad_max', 'quad_fit', 'pack_units', 'wgrid_cap', 'ggrid_cap', 'collide_type')
 
     def get_option(self, name):
         v = C.c_double(0.0)

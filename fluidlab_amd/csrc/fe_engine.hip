@@ -3169,6 +3169,7 @@ struct FeEngine {
     unsigned char* hit_dev = nullptr;                                 // contact flags per (frame, slot)
     int* hit_list = nullptr; int* hit_count = nullptr;                // the flagged slots of the frame being differentiated
     NodeWork* node_work = nullptr; int* node_work_count = nullptr;    // grid nodes inside an agent collider (collide_type grid / both)
+    int ggrid_cap = 1024;                                  // workgroups of the grid kernels: one round of the chip's resident ones (option "ggrid_cap")
     int wgrid_cap = 2048;                                  // workgroups of the work-list kernels (option "wgrid_cap")
     int collide_type = 1;                                  // Agent.collide_type (agent.py:17-26): 1 particle, 2 grid, 3 both
     BoundaryP* collector_dev = nullptr; bool has_collector = false; int collector_mat = -1;     // collector_act_kernel (agent_pouring.py:30-41)
@@ -3257,7 +3258,7 @@ inline dim3 pgrid(FeEngine* h) { return dim3((h->N + 255) / 256); }
 // work-list kernels loop over (items + tail chunks); the count lives on the device, so launch a bounded grid
 // ("wgrid_cap": upper bound; the lower bound keeps sparse scenes -- few particles per item -- from serialising their items)
 inline dim3 wgrid(FeEngine* h) { int g = (h->N + 63) / 64 + 8; if (g < 512) g = 512; return dim3(g < h->wgrid_cap ? g : h->wgrid_cap); }
-inline dim3 ggrid(FeEngine* h) { int blocks = h->nb * h->nb * h->nb; int g = (blocks + 3) / 4; return dim3(g < 1024 ? g : 1024); }
+inline dim3 ggrid(FeEngine* h) { int blocks = h->nb * h->nb * h->nb; int g = (blocks + 3) / 4; return dim3(g < h->ggrid_cap ? g : h->ggrid_cap); }      // (option "ggrid_cap": tests shrink it so that small scenes take the long-list road of the grid kernels)
 
 void prof_drain(FeEngine* h);
 void prof_begin(FeEngine* h, int kid) {
@@ -3889,6 +3890,7 @@ int fe_set_option(FeEngine* h, const char* name, double value) {
     if (!std::strcmp(name, "pack_units")) { if (value < 0 || value > 2) FAIL(h, "pack_units must be 0, 1 or 2"); h->pack_units = (int)value; return 0; }
     if (!std::strcmp(name, "quad_fit")) { if (value < 0) FAIL(h, "quad_fit must be >= 0"); h->quad_fit = (int)value; return 0; }
     if (!std::strcmp(name, "quad_max")) { if (value < 0 || value > QUAD_MAX) FAIL(h, "quad_max must be in [0, 64]"); h->quad = (int)value; return 0; }
+    if (!std::strcmp(name, "ggrid_cap")) { if (value < 1) FAIL(h, "ggrid_cap must be >= 1"); h->ggrid_cap = (int)value; return 0; }
     if (!std::strcmp(name, "wgrid_cap")) { if (value < 64) { h->err = "wgrid_cap must be >= 64"; return 1; } h->wgrid_cap = (int)value; return 0; }
     if (!std::strcmp(name, "threads")) return 0;             // oracle-only tunable
     FAIL(h, std::string("unknown option: ") + name);
@@ -3903,7 +3905,7 @@ int fe_get_option(FeEngine* h, const char* name, double* value) {
         {"inject_till", (double)h->inject_till}, {"collide_min_y", (double)h->collide_min_y}, {"collide_type", (double)h->collide_type},
         {"prof_fine", h->prof_fine ? 1.0 : 0.0}, {"xcd_map", (double)h->S.xcd}, {"write_through", (double)h->S.wt}, {"wave_sort", (double)h->S.wsort},
         {"quad_min_units", (double)h->quad_min_units}, {"quad_max", (double)h->quad}, {"quad_fit", (double)h->quad_fit}, {"pack_units", (double)h->pack_units},
-        {"wgrid_cap", (double)h->wgrid_cap}, {"threads", 0.0}};
+        {"wgrid_cap", (double)h->wgrid_cap}, {"ggrid_cap", (double)h->ggrid_cap}, {"threads", 0.0}};
     for (const auto& t : tab) if (!std::strcmp(name, t.n)) { *value = t.v; return 0; }
     FAIL(h, std::string("unknown option: ") + name);
 }

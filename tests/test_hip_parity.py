@@ -492,3 +492,28 @@ def test_packed_unit_list_matches_the_oracle(hiplib, oracle64, pack_units, quad_
     assert S.rel_l2(sa['v'], sb['v']) <= 1e-4
     for k in ('gx', 'gv', 'gC', 'gF'):
         assert S.cosine(ga[k], gb[k]) >= 0.99999 and S.rel_l2(ga[k], gb[k]) <= 1e-3, (k, S.rel_l2(ga[k], gb[k]))
+
+
+@pytest.mark.parametrize('ggrid_cap', [1, 2, 5])
+@pytest.mark.parametrize('grid_store', [0, 1])
+def test_grid_kernels_long_list_road(hiplib, oracle64, ggrid_cap, grid_store):
+    """`k_grid` / `k_grid_grad` on a list longer than four times their workgroups (option `ggrid_cap` shrinks the launch; by default only a
+    spread-out scene at 128^3 gets there): candidates eight at a time per wave, several rounds of them, the marked ones shared out among
+    the workgroup's four waves; droplets all over the box so that most entries of the list are unmarked, a few fast ones for dirty
+    blocks; backward from the stored grid and from the recompute."""
+    rng = np.random.RandomState(31)
+    N = 1800
+    c = rng.uniform(0.25, 0.75, (60, 3))
+    x = S.f32(np.clip(np.repeat(c, N // 60, 0) + rng.uniform(-0.02, 0.02, (N, 3)), 0.22, 0.78))
+    sc = dict(S.water_block(n_grid=32, n_particles=N, seed=5), x=x, v=S.f32(rng.normal(0, 0.5, (N, 3))))
+    sc['v'][::37] *= 25.0                                                         # a few particles leave their tiles between sorts
+    g = S.make_engine(hiplib, sc, options={'sort_interval': 6, 'ggrid_cap': ggrid_cap, 'grid_store': grid_store})
+    o = S.make_engine(oracle64, sc)
+    cot = S.random_cotangent(N, seed=6)
+    sa, ga = S.run_forward_backward(g, 9, cot)
+    sb, gb = S.run_forward_backward(o, 9, {k: v.astype(np.float64) for k, v in cot.items()})
+    ws = g.get_work_stats(8)
+    assert ws['n_active_blocks'] > 8 * 4 * ggrid_cap                              # several rounds of eight candidates per wave
+    assert np.abs(sa['x'] - sb['x']).max() <= 2e-6 and S.rel_l2(sa['v'], sb['v']) <= 1e-4
+    for k in ('gx', 'gv', 'gC', 'gF'):
+        assert S.cosine(ga[k], gb[k]) >= 0.99999 and S.rel_l2(ga[k], gb[k]) <= 1e-3, (k, S.rel_l2(ga[k], gb[k]))

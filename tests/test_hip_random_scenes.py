@@ -59,6 +59,9 @@ def random_scene(seed):
     # chip's resident ones (1,024; small here so that scenes of a few dozen items take that road) -- or whenever it is more than that
     opts['quad_fit'] = int(rng.choice([1024, 2, 8, 40]))
     opts['pack_units'] = int(rng.choice([0, 1, 2]))
+    # the grid kernels' long-list road (more active blocks than 4 x their workgroups: at the default 1,024 workgroups only spread-out scenes
+    # at 128^3 and up take it): a workgroup's four waves share out the marked blocks among them through LDS
+    opts['ggrid_cap'] = int(rng.choice([1024, 1, 3, 16]))
     return sc, opts, n_sub, liquid_only
 
 
