@@ -2128,10 +2128,12 @@ __shared__ float s_stash_g[STASH_GENERAL * WG];
 __shared__ float s_stash_l[STASH_LIQUID * WG];
 template <> __device__ __forceinline__ float* Stash<true>::at() { return s_stash_g; }
 template <> __device__ __forceinline__ float* Stash<false>::at() { return s_stash_l; }
-template <bool TILE, bool GENERAL, bool PRE = false>
+// NOSTASH (a quad unit's wave, whose tile `tl` lies where the pair units keep their stash): C and F are read from the frame again behind
+// the loop -- 72 bytes per particle that the wave's own loads left in the L2 a few microseconds earlier
+template <bool TILE, bool GENERAL, bool PRE = false, bool NOSTASH = false>
 __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const FrameV& cur, const FrameV& Gn, const FrameV& Gc, int s,
                                                        const float4* __restrict__ info_, const TileO& to,
-                                                       const float4* __restrict__ gg_in, int* slow, int tofs, const P2GRaw& pre) {
+                                                       const float4* __restrict__ gg_in, int* slow, int tofs, const P2GRaw& pre, const float* tl = nullptr) {
     PState p;
     PInfo info;
     if (PRE) { p = pre.p; info = pre.info; }                  // (asked for ahead of the tile load and its barrier: p2g_grad_body)
@@ -2149,7 +2151,7 @@ __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const Fram
     }
     float* stash = Stash<GENERAL>::at();
     int col = threadIdx.x;
-    {
+    if (!NOSTASH) {
 #pragma unroll
         for (int a = 0; a < 3; a++)
 #pragma unroll
@@ -2186,7 +2188,10 @@ __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const Fram
 #pragma unroll
             for (int kk = 0; kk < 3; kk++) {
                 float gin[3], gm;
-                if (TILE) {
+                if (TILE && NOSTASH) {
+                    const int l = lb + (i * TILE_T + j) * TILE_T + kk;
+                    gin[0] = tl[l]; gin[1] = tl[TILE_N + l]; gin[2] = tl[2 * TILE_N + l]; gm = tl[3 * TILE_N + l];
+                } else if (TILE) {
                     const int l = tofs + lb + (i * TILE_T + j) * TILE_T + kk;
                     gin[0] = s_tile[l]; gin[1] = s_tile[TILE_N + l]; gin[2] = s_tile[2 * TILE_N + l]; gm = s_tile[3 * TILE_N + l];
                 } else {
@@ -2231,6 +2236,8 @@ __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const Fram
         // back from the stash, behind an index the optimiser cannot see through (it would otherwise forward the stored values,
         // i.e. keep them in registers across the loop)
         asm volatile("" : "+v"(col));
+        if (NOSTASH) { PState q2; load_xvC(cur, s, q2); p.C = q2.C; load_F(cur, s, p.F); }
+        else {
 #pragma unroll
         for (int a = 0; a < 3; a++)
 #pragma unroll
@@ -2238,6 +2245,7 @@ __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const Fram
                 p.C.a[a][b] = stash[(a * 3 + b) * WG + col]; p.F.a[a][b] = stash[(9 + a * 3 + b) * WG + col];
                 if (GENERAL) { k.U.a[a][b] = stash[(18 + a * 3 + b) * WG + col]; k.V.a[a][b] = stash[(27 + a * 3 + b) * WG + col]; }
             }
+        }
         // F_tmp = (I + dt C) F again (27 fma) rather than 9 more stash planes; J of the SVD-free build likewise
         m3 IdtC = m3_scale(p.C, S.dt);
         IdtC.a[0][0] += 1.f; IdtC.a[1][1] += 1.f; IdtC.a[2][2] += 1.f;
@@ -2254,13 +2262,13 @@ __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const Fram
     store_F(Gc, s, gF);
 }
 
-template <bool TILE, bool GENERAL, bool PRE = false>
+template <bool TILE, bool GENERAL, bool PRE = false, bool NOSTASH = false>
 __device__ __forceinline__ void slot_p2g_grad(const SimP& S, const FrameV& cur, const FrameV& Gn, const FrameV& Gc, int s, const TableP& T,
                                               const int* __restrict__ pool_idx,
                                               const TileO& to, const float4* __restrict__ gg_in, int* slow, const AgentP& agent,
-                                              const InjectP& inj, int f, int tofs, int used, const P2GRaw& pre) {
+                                              const InjectP& inj, int f, int tofs, int used, const P2GRaw& pre, const float* tl = nullptr) {
     if (!PRE) used = cur.used[s];
-    if (used) { used_particle_p2g_grad<TILE, GENERAL, PRE>(S, cur, Gn, Gc, s, T.info, to, gg_in, slow, tofs, pre); return; }
+    if (used) { used_particle_p2g_grad<TILE, GENERAL, PRE, NOSTASH>(S, cur, Gn, Gc, s, T.info, to, gg_in, slow, tofs, pre, tl); return; }
     // the copy f -> f+1 of an unused particle passes its adjoint straight through (mpm:551)
     PState g; load_xvC(Gn, s, g); load_F(Gn, s, g.F);
     store_xvC(Gc, s, g.x, g.v, g.C); store_F(Gc, s, g.F);
@@ -2299,13 +2307,40 @@ __device__ __forceinline__ void p2g_grad_body(SimP S, float* fr_cur, float* Gn_,
     FrameV cur = frame_view(fr_cur, S.Np);
     FrameV Gn = frame_view(Gn_, S.Np), Gc = frame_view(Gc_, S.Np, S.wt & 8);
     TL(S, 0);
-    Unit un = unit_load<true>(T, blockIdx.x);                       // this workgroup's first unit, asked for together with meta
-    const int n_slots = T.meta[9];
+    // The SVD-free build walks the scatter kernels' list, quad units included (round 4): a quad's wave has its own 8 KB tile -- the first two
+    // in s_tile, the other two where the pair units keep their stash, whose part C and F are read from the frame again instead (NOSTASH) --,
+    // so that where the water has come apart the launch is two rounds of workgroups instead of three or four.  The SVD build keeps the
+    // pairs-only list (its stash holds U and V as well: 36 KB).
+    constexpr bool QLIST = !GENERAL;
+    Unit un = unit_load<!QLIST>(T, blockIdx.x);                     // this workgroup's first unit, asked for together with meta
+    const int n_slots = T.meta[QLIST ? 5 : 9];
+    bool prev_quad = false;                                   // (unit_enter)
     for (int wg = blockIdx.x; wg < n_slots; wg += gridDim.x) {
-        if (wg != (int)blockIdx.x) un = unit_load<true>(T, wg);
+        if (wg != (int)blockIdx.x) un = unit_load<!QLIST>(T, wg);
         if (un.a.z == -2) continue;
+        if (QLIST && un.a.z >= 0 && (un.a.w & QUAD_BIT)) {
+            const PairCtx pc = unit_ctx(un);
+            unit_enter(true, prev_quad);
+            const int4 it = pc.it;
+            const TileO to = tile_origin(it.x, S.nb);
+            float* tl = pc.ti < 2 ? s_tile + pc.ti * 4 * TILE_N : s_stash_l + (pc.ti - 2) * 4 * TILE_N;
+            if (pc.live) {
+                for (int l = pc.t0; l < TILE_N; l += 64) {
+                    int i, j, k;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (tile_node(to, l, S.n, i, j, k)) v = gg_in[cell_addr(i, j, k, S.nb)];
+                    tl[l] = v.x; tl[TILE_N + l] = v.y; tl[2 * TILE_N + l] = v.z; tl[3 * TILE_N + l] = v.w;
+                }
+            }
+            unit_sync(true);
+            P2GRaw no_pre;
+            if (pc.i < it.z) slot_p2g_grad<true, GENERAL, false, true>(S, cur, Gn, Gc, it.y + pc.i, T, pool_idx, to, gg_in, slow, agent, inj, f, 0, 0, no_pre, tl);
+            unit_sync(true);
+            continue;
+        }
         if (un.a.z >= 0) {
-            const PairCtx pc = pair_ctx(un);                     // (the gather kernels walk the pairs-only list: four 4-plane tiles beside the stash would cost a resident workgroup)
+            const PairCtx pc = QLIST ? unit_ctx(un) : pair_ctx(un);       // (a pair unit either way)
+            if (QLIST) unit_enter(false, prev_quad);
             const int4 it = pc.it;
             const TileO to = tile_origin(it.x, S.nb);
             TL(S, 1);
