@@ -3205,6 +3205,7 @@ struct FeEngine {
     int* hit_list = nullptr; int* hit_count = nullptr;                // the flagged slots of the frame being differentiated
     NodeWork* node_work = nullptr; int* node_work_count = nullptr;    // grid nodes inside an agent collider (collide_type grid / both)
     int ggrid_cap = 1024;                                  // workgroups of the grid kernels: one round of the chip's resident ones (option "ggrid_cap")
+    int wgrid_cap_g2p = 2048;                              // the same for k_g2p (option "wgrid_cap_g2p")
     int wgrid_cap = 2048;                                  // workgroups of the work-list kernels (option "wgrid_cap")
     int collide_type = 1;                                  // Agent.collide_type (agent.py:17-26): 1 particle, 2 grid, 3 both
     BoundaryP* collector_dev = nullptr; bool has_collector = false; int collector_mat = -1;     // collector_act_kernel (agent_pouring.py:30-41)
@@ -3293,6 +3294,8 @@ inline dim3 pgrid(FeEngine* h) { return dim3((h->N + 255) / 256); }
 // work-list kernels loop over (items + tail chunks); the count lives on the device, so launch a bounded grid
 // ("wgrid_cap": upper bound; the lower bound keeps sparse scenes -- few particles per item -- from serialising their items)
 inline dim3 wgrid(FeEngine* h) { int g = (h->N + 63) / 64 + 8; if (g < 512) g = 512; return dim3(g < h->wgrid_cap ? g : h->wgrid_cap); }
+// k_g2p keeps six workgroups per CU resident (80 registers, 12 KB of LDS) where the other particle kernels keep four: its own bound ("wgrid_cap_g2p")
+inline dim3 wgrid_g2p(FeEngine* h) { int g = (h->N + 63) / 64 + 8; if (g < 512) g = 512; return dim3(g < h->wgrid_cap_g2p ? g : h->wgrid_cap_g2p); }
 inline dim3 ggrid(FeEngine* h) { int blocks = h->nb * h->nb * h->nb; int g = (blocks + 3) / 4; return dim3(g < h->ggrid_cap ? g : h->ggrid_cap); }      // (option "ggrid_cap": tests shrink it so that small scenes take the long-list road of the grid kernels)
 
 void prof_drain(FeEngine* h);
@@ -3483,9 +3486,9 @@ int substep_fwd(FeEngine* h, int f, int f_global, int act) {
     prof_end(h);
     prof_begin(h, KID_G2P);
     if (particle_collide(h))
-        hipLaunchKernelGGL(k_g2p<true>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T, h->g_out, h->blk_count, h->slow_dev, ag, f);
+        hipLaunchKernelGGL(k_g2p<true>, wgrid_g2p(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T, h->g_out, h->blk_count, h->slow_dev, ag, f);
     else
-        hipLaunchKernelGGL(k_g2p<false>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T, h->g_out, h->blk_count, h->slow_dev, ag, f);
+        hipLaunchKernelGGL(k_g2p<false>, wgrid_g2p(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T, h->g_out, h->blk_count, h->slow_dev, ag, f);
     prof_end(h);
     if (h->has_rigid) {
         hipLaunchKernelGGL(k_rigid_body<false>, dim3(h->n_bodies), dim3(256), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), (float*)nullptr,
@@ -3796,7 +3799,12 @@ FeEngine* fe_create(const FeConfig* cfg) {
     auto fail = [&](const std::string& m) { g_create_err = m.empty() ? h->err : m; fe_destroy(h); return (FeEngine*)nullptr; };
     if (hipSetDevice(h->device) != hipSuccess) return fail("hipSetDevice failed");
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
-    { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) h->quad_fit = 4 * cus; }   // one round of resident workgroups (128 VGPRs: 4 per CU)
+    {   // one round of resident workgroups: 4 per CU for the kernels at 128 registers, 6 for k_g2p.  The work-list launches are no larger than that
+        // (round 4: a launch of 2,048 started a second round of workgroups where the first ones could have looped on: early splash -2.4 %, the
+        // layer -2 %, the whole run -1.9 % in time; `profiles/r04_ab_wgrid_caps.txt`)
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) { h->quad_fit = 4 * cus; h->wgrid_cap = 4 * cus; h->wgrid_cap_g2p = 6 * cus; }
+    }
     h->own_stream = h->stream;
     SimP& S = h->S;
     S.xcd = 16;                                            // blocked-cyclic unit mapping (A/B in DESIGN.md section 6)
@@ -3926,6 +3934,7 @@ int fe_set_option(FeEngine* h, const char* name, double value) {
     if (!std::strcmp(name, "quad_fit")) { if (value < 0) FAIL(h, "quad_fit must be >= 0"); h->quad_fit = (int)value; return 0; }
     if (!std::strcmp(name, "quad_max")) { if (value < 0 || value > QUAD_MAX) FAIL(h, "quad_max must be in [0, 64]"); h->quad = (int)value; return 0; }
     if (!std::strcmp(name, "ggrid_cap")) { if (value < 1) FAIL(h, "ggrid_cap must be >= 1"); h->ggrid_cap = (int)value; return 0; }
+    if (!std::strcmp(name, "wgrid_cap_g2p")) { if (value < 64) FAIL(h, "wgrid_cap_g2p must be >= 64"); h->wgrid_cap_g2p = (int)value; return 0; }
     if (!std::strcmp(name, "wgrid_cap")) { if (value < 64) { h->err = "wgrid_cap must be >= 64"; return 1; } h->wgrid_cap = (int)value; return 0; }
     if (!std::strcmp(name, "threads")) return 0;             // oracle-only tunable
     FAIL(h, std::string("unknown option: ") + name);
@@ -3940,7 +3949,7 @@ int fe_get_option(FeEngine* h, const char* name, double* value) {
         {"inject_till", (double)h->inject_till}, {"collide_min_y", (double)h->collide_min_y}, {"collide_type", (double)h->collide_type},
         {"prof_fine", h->prof_fine ? 1.0 : 0.0}, {"xcd_map", (double)h->S.xcd}, {"write_through", (double)h->S.wt}, {"wave_sort", (double)h->S.wsort},
         {"quad_min_units", (double)h->quad_min_units}, {"quad_max", (double)h->quad}, {"quad_fit", (double)h->quad_fit}, {"pack_units", (double)h->pack_units},
-        {"wgrid_cap", (double)h->wgrid_cap}, {"ggrid_cap", (double)h->ggrid_cap}, {"threads", 0.0}};
+        {"wgrid_cap", (double)h->wgrid_cap}, {"wgrid_cap_g2p", (double)h->wgrid_cap_g2p}, {"ggrid_cap", (double)h->ggrid_cap}, {"threads", 0.0}};
     for (const auto& t : tab) if (!std::strcmp(name, t.n)) { *value = t.v; return 0; }
     FAIL(h, std::string("unknown option: ") + name);
 }
