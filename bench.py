@@ -429,6 +429,10 @@ def run_replicas(args, rank, local_rank, world):
         B = max(1, args.envs_per_gpu)
         envs = [make('LatteArt-v0', seed=1000 + rank * B + i, loss=True, target=tgt, **kw) for i in range(B)]      # injector randomness differs per replica
         env = envs[0]
+    for e in envs:                                                    # --opt name=value: engine options of every replica (tuning sweeps)
+        for o in args.opt:
+            k, v = o.split('=')
+            e.taichi_env.simulator.engine.set_option(k, float(v))
     cfg = load_config('configs/exp_latteart.yaml').SOLVER
     # 128^3 sits at the stability edge of the reference's fixed dt: the Adam step is kept small so that W + K
     # passes stay in the stable regime.  Gradient, collective and update are the real ones.
@@ -528,7 +532,7 @@ def run_replicas(args, rank, local_rank, world):
                                    'one per GPU: one step = one Solver pass (forward with loss, backward, action-gradient all-reduce, Adam)',
                        'substep_pairs_per_step_per_rank': sub, 'rccl_world_size': dist.get_world_size(), 'dist_backend': args.dist_backend,
                        'action_grad_shape': [env.horizon_action + 1, 3], 'lr_scale': args.c4_lr_scale, 'window_substeps': args.c4_window or n_frames,
-                       'envs_per_gpu': B,
+                       'envs_per_gpu': B, 'engine_options': eng.get_options(), 'engine_env': {k: v for k, v in os.environ.items() if k.startswith('FE_')},
                        'parallelism': f'{world * B} env replicas, {B} per GPU' + (' sharing launches (fe_step_batch)' if B > 1 else '') + ', 1 all-reduce of the action gradient per pass'},
             'n1_same_scene_pairs_per_s': round(n1_rate, 1),
             'scaling_efficiency': round(value / (world * n1_rate), 4) if n1_rate > 0 else None,
@@ -596,7 +600,7 @@ def main():
     ap.add_argument('--c4-lr-scale', type=float, default=0.1)
     ap.add_argument('--c4-window', type=int, default=0, help='N > 1 workload: max_substeps_local (0 = the whole trajectory resident); tests use 50 so that eight ranks fit one device')
     ap.add_argument('--envs-per-gpu', type=int, default=1, help='N > 1 workload: B replicas per rank stepped in lockstep through fe_step_batch (they have to fit the HBM: the config-3 scene keeps ~150 GB per replica resident)')
-    ap.add_argument('--opt', action='append', default=[], help='engine option name=value (tuning sweeps, N=1)')
+    ap.add_argument('--opt', action='append', default=[], help='engine option name=value (tuning sweeps)')
     args = ap.parse_args()
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:

@@ -3205,6 +3205,7 @@ struct FeEngine {
     int* hit_list = nullptr; int* hit_count = nullptr;                // the flagged slots of the frame being differentiated
     NodeWork* node_work = nullptr; int* node_work_count = nullptr;    // grid nodes inside an agent collider (collide_type grid / both)
     int ggrid_cap = 1024;                                  // workgroups of the grid kernels: one round of the chip's resident ones (option "ggrid_cap")
+    int wgrid_cap_pgg = 2048;                              // ... and for k_p2g_grad (option "wgrid_cap_pgg")
     int wgrid_cap_g2p = 2048;                              // the same for k_g2p (option "wgrid_cap_g2p")
     int wgrid_cap = 2048;                                  // workgroups of the work-list kernels (option "wgrid_cap")
     int collide_type = 1;                                  // Agent.collide_type (agent.py:17-26): 1 particle, 2 grid, 3 both
@@ -3296,6 +3297,7 @@ inline dim3 pgrid(FeEngine* h) { return dim3((h->N + 255) / 256); }
 inline dim3 wgrid(FeEngine* h) { int g = (h->N + 63) / 64 + 8; if (g < 512) g = 512; return dim3(g < h->wgrid_cap ? g : h->wgrid_cap); }
 // k_g2p keeps six workgroups per CU resident (80 registers, 12 KB of LDS) where the other particle kernels keep four: its own bound ("wgrid_cap_g2p")
 inline dim3 wgrid_g2p(FeEngine* h) { int g = (h->N + 63) / 64 + 8; if (g < 512) g = 512; return dim3(g < h->wgrid_cap_g2p ? g : h->wgrid_cap_g2p); }
+inline dim3 wgrid_pgg(FeEngine* h) { int g = (h->N + 63) / 64 + 8; if (g < 512) g = 512; return dim3(g < h->wgrid_cap_pgg ? g : h->wgrid_cap_pgg); }      // k_p2g_grad ("wgrid_cap_pgg")
 inline dim3 ggrid(FeEngine* h) { int blocks = h->nb * h->nb * h->nb; int g = (blocks + 3) / 4; return dim3(g < h->ggrid_cap ? g : h->ggrid_cap); }      // (option "ggrid_cap": tests shrink it so that small scenes take the long-list road of the grid kernels)
 
 void prof_drain(FeEngine* h);
@@ -3557,7 +3559,7 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act) {
     } else { if (h->statics_host.empty()) LAUNCH_GRID_GRAD(false, false); else LAUNCH_GRID_GRAD(true, false); }
     prof_end(h);
     prof_begin(h, KID_P2G_GRAD);
-#define LAUNCH_P2G_GRAD(G, W) hipLaunchKernelGGL((k_p2g_grad<G, W>), wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), \
+#define LAUNCH_P2G_GRAD(G, W) hipLaunchKernelGGL((k_p2g_grad<G, W>), wgrid_pgg(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), \
                            h->grad(f), T, h->pool_idx, h->gg_in, h->blk_count, h->slow_dev, ag, inj, act, f)
     if (h->all_simple_liquid) {
         if (h->p2g_grad_waves >= 4) LAUNCH_P2G_GRAD(false, 4);
@@ -3799,13 +3801,14 @@ FeEngine* fe_create(const FeConfig* cfg) {
     auto fail = [&](const std::string& m) { g_create_err = m.empty() ? h->err : m; fe_destroy(h); return (FeEngine*)nullptr; };
     if (hipSetDevice(h->device) != hipSuccess) return fail("hipSetDevice failed");
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return fail("hipStreamCreate failed");
-    {   // one round of resident workgroups: 4 per CU for the kernels at 128 registers, 6 for k_g2p.  The work-list launches are no larger than that
-        // (round 4: a launch of 2,048 started a second round of workgroups where the first ones could have looped on: early splash -2.4 %, the
-        // layer -2 %, the whole run -1.9 % in time; `profiles/r04_ab_wgrid_caps.txt`)
+    {   // One round of resident workgroups: 4 per CU for the kernels at 128 registers, 6 for k_g2p.  The scatter kernels' and k_g2p's work-list
+        // launches are no larger than that (round 4: a launch of 2,048 started a second round of workgroups where the first ones could have
+        // looped on: early splash -2.4 %, the layer -2 %, the whole run -1.9 % in time; `profiles/r04_ab_wgrid_caps.txt`).  k_p2g_grad keeps the
+        // larger launch: its extra workgroups fill whatever slot frees first, which is worth 3.7 % on LatteArt at 128^3 (1,995 units of
+        // full 128-particle items: 8,216 -> 8,520 pairs/s) and costs the water block 0.2 ... 0.4 % (`r04_ab_wgrid_caps_latteart.txt`).
         int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) { h->quad_fit = 4 * cus; h->wgrid_cap = 4 * cus; h->wgrid_cap_g2p = 6 * cus; }
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) { h->quad_fit = 4 * cus; h->wgrid_cap = 4 * cus; h->wgrid_cap_pgg = 8 * cus; h->wgrid_cap_g2p = 6 * cus; }
     }
-    h->own_stream = h->stream;
     SimP& S = h->S;
     S.xcd = 16;                                            // blocked-cyclic unit mapping (A/B in DESIGN.md section 6)
     S.uni = 0;
@@ -3934,6 +3937,7 @@ int fe_set_option(FeEngine* h, const char* name, double value) {
     if (!std::strcmp(name, "quad_fit")) { if (value < 0) FAIL(h, "quad_fit must be >= 0"); h->quad_fit = (int)value; return 0; }
     if (!std::strcmp(name, "quad_max")) { if (value < 0 || value > QUAD_MAX) FAIL(h, "quad_max must be in [0, 64]"); h->quad = (int)value; return 0; }
     if (!std::strcmp(name, "ggrid_cap")) { if (value < 1) FAIL(h, "ggrid_cap must be >= 1"); h->ggrid_cap = (int)value; return 0; }
+    if (!std::strcmp(name, "wgrid_cap_pgg")) { if (value < 64) FAIL(h, "wgrid_cap_pgg must be >= 64"); h->wgrid_cap_pgg = (int)value; return 0; }
     if (!std::strcmp(name, "wgrid_cap_g2p")) { if (value < 64) FAIL(h, "wgrid_cap_g2p must be >= 64"); h->wgrid_cap_g2p = (int)value; return 0; }
     if (!std::strcmp(name, "wgrid_cap")) { if (value < 64) { h->err = "wgrid_cap must be >= 64"; return 1; } h->wgrid_cap = (int)value; return 0; }
     if (!std::strcmp(name, "threads")) return 0;             // oracle-only tunable
@@ -3949,7 +3953,7 @@ int fe_get_option(FeEngine* h, const char* name, double* value) {
         {"inject_till", (double)h->inject_till}, {"collide_min_y", (double)h->collide_min_y}, {"collide_type", (double)h->collide_type},
         {"prof_fine", h->prof_fine ? 1.0 : 0.0}, {"xcd_map", (double)h->S.xcd}, {"write_through", (double)h->S.wt}, {"wave_sort", (double)h->S.wsort},
         {"quad_min_units", (double)h->quad_min_units}, {"quad_max", (double)h->quad}, {"quad_fit", (double)h->quad_fit}, {"pack_units", (double)h->pack_units},
-        {"wgrid_cap", (double)h->wgrid_cap}, {"wgrid_cap_g2p", (double)h->wgrid_cap_g2p}, {"ggrid_cap", (double)h->ggrid_cap}, {"threads", 0.0}};
+        {"wgrid_cap", (double)h->wgrid_cap}, {"wgrid_cap_g2p", (double)h->wgrid_cap_g2p}, {"wgrid_cap_pgg", (double)h->wgrid_cap_pgg}, {"ggrid_cap", (double)h->ggrid_cap}, {"threads", 0.0}};
     for (const auto& t : tab) if (!std::strcmp(name, t.n)) { *value = t.v; return 0; }
     FAIL(h, std::string("unknown option: ") + name);
 }
