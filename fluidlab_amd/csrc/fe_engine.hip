@@ -3809,6 +3809,7 @@ FeEngine* fe_create(const FeConfig* cfg) {
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) { h->quad_fit = 4 * cus; h->wgrid_cap = 4 * cus; h->wgrid_cap_pgg = 8 * cus; h->wgrid_cap_g2p = 6 * cus; }
     }
+    h->own_stream = h->stream;
     SimP& S = h->S;
     S.xcd = 16;                                            // blocked-cyclic unit mapping (A/B in DESIGN.md section 6)
     S.uni = 0;
