@@ -2121,6 +2121,13 @@ __device__ void effector_move_grad(const EffP& e, int f) {
 // What the constitutive adjoint needs again after the 27-node loop -- C, F and, in the SVD build, U, V, sigma, J -- waits in LDS
 // (s_stash, one column per thread) instead of in registers: round 1 re-read C and F from the frame (72 B per particle of extra
 // HBM traffic) and re-ran the constitutive model, and the SVD build kept everything live (256 + 32 VGPRs, one wave per SIMD).
+// Where k_p2g_grad leaves the adjoint of frame f.  Normally slot s of Gc.  When the next substep of the same fe_step_grad call works in
+// another particle order (a sort lies between frames f - 1 and f), the kernel writes the third adjoint buffer in THAT order instead --
+// slot to_slot[pid_of_slot[s]] -- and the separate reorder pass (k_perm_reorder: 12.7 us, once per sort interval) is not launched.
+struct GradDst {
+    FrameV G; const int* __restrict__ to_slot; const int* __restrict__ pid_of_slot;
+    __device__ __forceinline__ int slot(int s) const { return to_slot ? to_slot[pid_of_slot[s]] : s; }
+};
 #define STASH_GENERAL 36     // C, F, U, V; the singular values and J stay in registers: 36 KB + 16 KB of tile = three workgroups per CU
 #define STASH_LIQUID 18
 template <bool GENERAL> struct Stash { static __device__ __forceinline__ float* at(); };
@@ -2133,7 +2140,7 @@ template <> __device__ __forceinline__ float* Stash<false>::at() { return s_stas
 template <bool TILE, bool GENERAL, bool PRE = false, bool NOSTASH = false>
 __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const FrameV& cur, const FrameV& Gn, const FrameV& Gc, int s,
                                                        const float4* __restrict__ info_, const TileO& to,
-                                                       const float4* __restrict__ gg_in, int* slow, int tofs, const P2GRaw& pre, const float* tl = nullptr) {
+                                                       const float4* __restrict__ gg_in, int* slow, int tofs, const P2GRaw& pre, const GradDst& D, const float* tl = nullptr) {
     PState p;
     PInfo info;
     if (PRE) { p = pre.p; info = pre.info; }                  // (asked for ahead of the tile load and its barrier: p2g_grad_body)
@@ -2146,7 +2153,7 @@ __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const Fram
     const int lb = (TILE && inside) ? tile_base(to, st) : -1;
     if (TILE && inside && lb < 0) {            // drifted out of the tile: redo on the global path
         atomicAdd(slow, 1);
-        used_particle_p2g_grad<false, GENERAL, false>(S, cur, Gn, Gc, s, info_, to, gg_in, slow, 0, pre);
+        used_particle_p2g_grad<false, GENERAL, false>(S, cur, Gn, Gc, s, info_, to, gg_in, slow, 0, pre, D);
         return;
     }
     float* stash = Stash<GENERAL>::at();
@@ -2232,6 +2239,7 @@ __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const Fram
     // (the slot index is laundered too: otherwise the ~25 64-bit addresses of the loads and stores below are formed before the
     // loop and live -- or spill -- across it)
     asm volatile("" : "+v"(s));
+    const int sd = D.slot(s);                   // where this particle's adjoint goes (asked for here: two dependent loads behind the constitutive adjoint)
     {
         // back from the stash, behind an index the optimiser cannot see through (it would otherwise forward the stored values,
         // i.e. keep them in registers across the loop)
@@ -2258,20 +2266,21 @@ __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const Fram
     float gvv[3] = {info.mass * Gv[0], info.mass * Gv[1], info.mass * Gv[2]};
     m3 gC, gF;
     constitutive_grad_t<GENERAL>(p.C, p.F, S.dt, info.mu, info.lam, info.mass, info.cls, S.stress_scale, k, GA, Fg2, gC, gF);
-    store_xvC(Gc, s, gx, gvv, gC);
-    store_F(Gc, s, gF);
+    store_xvC(D.G, sd, gx, gvv, gC);
+    store_F(D.G, sd, gF);
 }
 
 template <bool TILE, bool GENERAL, bool PRE = false, bool NOSTASH = false>
 __device__ __forceinline__ void slot_p2g_grad(const SimP& S, const FrameV& cur, const FrameV& Gn, const FrameV& Gc, int s, const TableP& T,
                                               const int* __restrict__ pool_idx,
                                               const TileO& to, const float4* __restrict__ gg_in, int* slow, const AgentP& agent,
-                                              const InjectP& inj, int f, int tofs, int used, const P2GRaw& pre, const float* tl = nullptr) {
+                                              const InjectP& inj, int f, int tofs, int used, const P2GRaw& pre, const GradDst& D, const float* tl = nullptr) {
     if (!PRE) used = cur.used[s];
-    if (used) { used_particle_p2g_grad<TILE, GENERAL, PRE, NOSTASH>(S, cur, Gn, Gc, s, T.info, to, gg_in, slow, tofs, pre, tl); return; }
+    if (used) { used_particle_p2g_grad<TILE, GENERAL, PRE, NOSTASH>(S, cur, Gn, Gc, s, T.info, to, gg_in, slow, tofs, pre, D, tl); return; }
     // the copy f -> f+1 of an unused particle passes its adjoint straight through (mpm:551)
     PState g; load_xvC(Gn, s, g); load_F(Gn, s, g.F);
-    store_xvC(Gc, s, g.x, g.v, g.C); store_F(Gc, s, g.F);
+    const int sd = D.slot(s);
+    store_xvC(D.G, sd, g.x, g.v, g.C); store_F(D.G, sd, g.F);
     if (inj.on) {
         int j = pool_idx[T.pid_of_slot[s]] - inj.act_id;
         if (j >= 0 && j < inj.flux) {                      // x[f+1,pid] = offset + pos[f] + R(q) inject_p
@@ -2298,7 +2307,7 @@ template <bool GENERAL, int MINW>
 __device__ __forceinline__ void p2g_grad_body(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T,
                                                  const int* __restrict__ pool_idx,
                                                  const float4* __restrict__ gg_in, int* blk_count, int* slow, AgentP agent,
-                                                 InjectP inj, int act, int f) {
+                                                 InjectP inj, int act, int f, float* Gd_, const int* __restrict__ to_slot) {
     const int tid = threadIdx.x;
     if (blockIdx.x == 0 && tid == 0) {
         *blk_count = 0;
@@ -2306,6 +2315,7 @@ __device__ __forceinline__ void p2g_grad_body(SimP S, float* fr_cur, float* Gn_,
     }
     FrameV cur = frame_view(fr_cur, S.Np);
     FrameV Gn = frame_view(Gn_, S.Np), Gc = frame_view(Gc_, S.Np, S.wt & 8);
+    const GradDst D = {frame_view(Gd_, S.Np, S.wt & 8), to_slot, T.pid_of_slot};
     TL(S, 0);
     // The SVD-free build walks the scatter kernels' list, quad units included (round 4): a quad's wave has its own 8 KB tile -- the first two
     // in s_tile, the other two where the pair units keep their stash, whose part C and F are read from the frame again instead (NOSTASH) --,
@@ -2334,7 +2344,7 @@ __device__ __forceinline__ void p2g_grad_body(SimP S, float* fr_cur, float* Gn_,
             }
             unit_sync(true);
             P2GRaw no_pre;
-            if (pc.i < it.z) slot_p2g_grad<true, GENERAL, false, true>(S, cur, Gn, Gc, it.y + pc.i, T, pool_idx, to, gg_in, slow, agent, inj, f, 0, 0, no_pre, tl);
+            if (pc.i < it.z) slot_p2g_grad<true, GENERAL, false, true>(S, cur, Gn, Gc, it.y + pc.i, T, pool_idx, to, gg_in, slow, agent, inj, f, 0, 0, no_pre, D, tl);
             unit_sync(true);
             continue;
         }
@@ -2351,7 +2361,7 @@ __device__ __forceinline__ void p2g_grad_body(SimP S, float* fr_cur, float* Gn_,
             // falling 15.8 -> 16.4 us, layer 20.5 -> 21.1, splash 30.0 -> 29.7; the same move pays in k_p2g, where nothing precedes it)
             const int i = pc.i;
             P2GRaw no_pre;
-            if (i < it.z) slot_p2g_grad<true, GENERAL, false>(S, cur, Gn, Gc, it.y + i, T, pool_idx, to, gg_in, slow, agent, inj, f, pc.ti * 4 * TILE_N, 0, no_pre);
+            if (i < it.z) slot_p2g_grad<true, GENERAL, false>(S, cur, Gn, Gc, it.y + i, T, pool_idx, to, gg_in, slow, agent, inj, f, pc.ti * 4 * TILE_N, 0, no_pre, D);
             TL(S, 3);
             __syncthreads();
             TL(S, 4);
@@ -2359,15 +2369,15 @@ __device__ __forceinline__ void p2g_grad_body(SimP S, float* fr_cur, float* Gn_,
             const int s = un.a.y + tid;
             TileO none = {0, 0, 0};
             P2GRaw none_pre;
-            if (s < S.N) slot_p2g_grad<false, GENERAL, false>(S, cur, Gn, Gc, s, T, pool_idx, none, gg_in, slow, agent, inj, f, 0, 0, none_pre);
+            if (s < S.N) slot_p2g_grad<false, GENERAL, false>(S, cur, Gn, Gc, s, T, pool_idx, none, gg_in, slow, agent, inj, f, 0, 0, none_pre, D);
         }
     }
 }
-struct P2GGradArgs { SimP S; float* fr_cur; float* Gn_; float* Gc_; TableP T; const int* pool_idx; const float4* gg_in; int* blk_count; int* slow; AgentP agent; InjectP inj; int act; int f; };
+struct P2GGradArgs { SimP S; float* fr_cur; float* Gn_; float* Gc_; TableP T; const int* pool_idx; const float4* gg_in; int* blk_count; int* slow; AgentP agent; InjectP inj; int act; int f; float* Gd_; const int* to_slot; };
 template <bool GENERAL, int MINW>
-__global__ __launch_bounds__(WG, MINW) void k_p2g_grad(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T, const int* pool_idx, const float4* gg_in, int* blk_count, int* slow, AgentP agent, InjectP inj, int act, int f) { p2g_grad_body<GENERAL, MINW>(S, fr_cur, Gn_, Gc_, T, pool_idx, gg_in, blk_count, slow, agent, inj, act, f); }
+__global__ __launch_bounds__(WG, MINW) void k_p2g_grad(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T, const int* pool_idx, const float4* gg_in, int* blk_count, int* slow, AgentP agent, InjectP inj, int act, int f, float* Gd_, const int* to_slot) { p2g_grad_body<GENERAL, MINW>(S, fr_cur, Gn_, Gc_, T, pool_idx, gg_in, blk_count, slow, agent, inj, act, f, Gd_, to_slot); }
 template <bool GENERAL, int MINW>
-__global__ __launch_bounds__(WG, MINW) void k_p2g_grad_b(Batch<P2GGradArgs> B) { const P2GGradArgs& A = B.a[blockIdx.y]; p2g_grad_body<GENERAL, MINW>(A.S, A.fr_cur, A.Gn_, A.Gc_, A.T, A.pool_idx, A.gg_in, A.blk_count, A.slow, A.agent, A.inj, A.act, A.f); }
+__global__ __launch_bounds__(WG, MINW) void k_p2g_grad_b(Batch<P2GGradArgs> B) { const P2GGradArgs& A = B.a[blockIdx.y]; p2g_grad_body<GENERAL, MINW>(A.S, A.fr_cur, A.Gn_, A.Gc_, A.T, A.pool_idx, A.gg_in, A.blk_count, A.slow, A.agent, A.inj, A.act, A.f, A.Gd_, A.to_slot); }
 
 
 // =========================================================================================
@@ -2377,11 +2387,11 @@ __global__ __launch_bounds__(WG, MINW) void k_p2g_grad_b(Batch<P2GGradArgs> B) {
 #define SORT_YFAST 0
 #endif
 #define SORT_HB 4096      // cells in a workgroup's rank window: two y-neighbour blocks are 32 * 64 = 2048 cells apart at 128^3, and water falls in y
-// The sort is five launches (round 2: nine to ten, most of them 4-7 us latency chains):
-//   k_sort_count   key + rank of every slot, per-cell and per-block counts            (+ the rebuilt table's old block slots are cleared)
-//   k_sort_blk_partial / k_sort_blk_final  scan over the blocks -> slot ranges, work items, pair / single lists, list of occupied blocks
-//   k_sort_fill    one wave per occupied block: cell starts inside the block, the block's 27 neighbours go on the active list
-//   k_sort_apply   the permutation                                                   (+ unit descriptors and neighbour records)
+// The sort is four launches (round 2: nine to ten, most of them 4-7 us latency chains; round 3: five):
+//   k_sort_count        key + rank of every slot, per-cell and per-block counts       (+ the rebuilt table's old block slots are cleared)
+//   k_sort_blk_partial  partial sums of the scan over the blocks                      (+ cell starts inside every occupied block, the active list)
+//   k_sort_blk_final    the scan -> first slot of every block, work items, pair / single lists
+//   k_sort_apply        the permutation                                               (+ unit descriptors and neighbour records)
 // Slot order: [particles of DENSE blocks, by cell] [particles of LOOSE blocks, by cell] [unused / outside the grid].
 // A block with at most `loose_max` particles is LOOSE: it gets no work item -- no workgroup half, no 16 KB tile, no 27-node scan
 // for a handful of lanes, no slab -- and its particles are worked on by the global path of every kernel, 256 to a workgroup, in
@@ -2395,10 +2405,11 @@ __global__ __launch_bounds__(WG, MINW) void k_p2g_grad_b(Batch<P2GGradArgs> B) {
 // distinct key per workgroup is issued; keys outside the window fall back to a global atomic.
 #define SORT_CLR_WGS 32
 __global__ __launch_bounds__(256) void k_sort_count(SimP S, float* fr, int n_pwg, int* key, int* rank, int* cnt, int* bcnt,
-                                                    const int* __restrict__ clr_active, const int* __restrict__ clr_meta, int* clr_slot) {
+                                                    const int* __restrict__ clr_active, const int* __restrict__ clr_meta, int* clr_slot, int* nact) {
     __shared__ int hist[SORT_HB + 1];       // + the sentinel's slot
     __shared__ int kmin;
     const int tid = threadIdx.x;
+    if (blockIdx.x == 0 && tid == 0) *nact = 0;              // length of the new order's active list (k_sort_blk_partial's launch counts it)
     if ((int)blockIdx.x >= n_pwg) {          // the table about to be rebuilt: forget the block slots of its previous life
         const int n = clr_meta[2];
         for (int i = (blockIdx.x - n_pwg) * 256 + tid; i < n; i += SORT_CLR_WGS * 256) clr_slot[clr_active[i]] = -1;
@@ -2451,13 +2462,18 @@ __global__ __launch_bounds__(256) void k_sort_count(SimP S, float* fr, int n_pwg
         }
     }
     __syncthreads();
-    // per-block counts of the window (it starts anywhere, so it overlaps up to 33 blocks; block nblk = the tail sentinel)
-    if (tid <= SORT_HB / 64 && kmin != 0x7fffffff) {
-        const int blk = (kmin >> 6) + tid;
-        const int lo = max(blk << 6, kmin) - kmin, hi = min((blk + 1) << 6, kmin + SORT_HB) - kmin;
-        int n = 0;
-        for (int l = lo; l < hi; l++) n += hist[l];
-        if (n > 0) atomicAdd(&bcnt[blk], n);
+    // per-block counts of the window (it starts anywhere, so it overlaps up to 65 blocks; block nblk = the tail sentinel): 16 cells per
+    // thread, the four threads of a block add up across lanes (65 threads walking 64 cells each were a 64-deep LDS chain)
+    if (kmin != 0x7fffffff) {
+        const int k0 = kmin, base = k0 & ~63;
+        for (int t = tid; t < (SORT_HB + 64) / 16; t += 256) {
+            const int c0 = base + t * 16;
+            int n = 0;
+#pragma unroll
+            for (int u = 0; u < 16; u++) { const int l = c0 + u - k0; if (l >= 0 && l < SORT_HB) n += hist[l]; }
+            n += __shfl_xor(n, 1, 64); n += __shfl_xor(n, 2, 64);
+            if ((t & 3) == 0 && n > 0) atomicAdd(&bcnt[c0 >> 6], n);
+        }
     }
     if (tid == 255 && hist[SORT_HB] > 0) atomicAdd(&bcnt[S.ncell >> 6], hist[SORT_HB]);
     __syncthreads();
@@ -2544,8 +2560,75 @@ __device__ __forceinline__ void wg_scan6(const BlkSums& m, int (*sh)[NSUM], int 
     }
     __syncthreads();
 }
-__global__ __launch_bounds__(256) void k_sort_blk_partial(int nblk, int ITEM_MAX, int loose_max, int quad_max, const int* __restrict__ bcnt, int* partial) {
+// Three jobs in one launch, all of which need the block counts and nothing else:
+//   workgroups [0, blk_wgs)            the partial sums of the block scan;
+//   the next scan_wgs                  where a block's 64 cells start INSIDE the block (exclusive scan of its cell counts; the counts
+//                                      are zeroed for the next sort): a wave takes 16 blocks, four at a time -- a lane owns four
+//                                      consecutive cells (one 16-byte load) and the 16 lanes of a DPP row one block, so a row-wide
+//                                      scan is a block's scan.  k_sort_apply adds the block's first slot (blk_base, k_sort_blk_final).
+//                                      (Round 3 did this behind the scan, one wave per OCCUPIED block and one dependent round trip
+//                                      per block: 8.1 us of its own launch, k_sort_fill.)
+//   the rest                           one thread per block of the grid -- is any of its 27 neighbours occupied?  Then it joins the
+//                                      order's active list: every block some tile or some loose particle's stencil can reach (asking
+//                                      costs 27 cached loads per block and one atomic per wave, and the list comes out nearly in block
+//                                      order; round 2 pushed instead -- 200,000 returning atomics on 25,000 words, 36 us).
+__global__ __launch_bounds__(256) void k_sort_blk_partial(int nblk, int nb, int ITEM_MAX, int loose_max, int quad_max, const int* __restrict__ bcnt, int* partial,
+                                                          int blk_wgs, int scan_wgs, int* cnt, int* start, int* nact, int* active, int* blk_slot) {
     __shared__ int sh[4][NSUM];
+    const int lane = threadIdx.x & 63;
+    if ((int)blockIdx.x >= blk_wgs + scan_wgs) {
+        const int b = (blockIdx.x - blk_wgs - scan_wgs) * 256 + threadIdx.x;
+        bool on = false;
+        if (b < nblk) {
+            const int bi = b / (nb * nb), bj = (b / nb) % nb, bk = b % nb;
+#pragma unroll
+            for (int di = -1; di <= 1; di++)
+#pragma unroll
+                for (int dj = -1; dj <= 1; dj++) {
+                    const int i2 = bi + di, j2 = bj + dj;
+                    if ((unsigned)i2 < (unsigned)nb && (unsigned)j2 < (unsigned)nb) {
+                        const int row = (i2 * nb + j2) * nb;
+                        on = on || bcnt[row + bk] > 0 || (bk > 0 && bcnt[row + bk - 1] > 0) || (bk + 1 < nb && bcnt[row + bk + 1] > 0);
+                    }
+                }
+        }
+        const unsigned long long wm = __ballot(on);
+        if (wm) {                                                  // the wave's entries with ONE returning atomic on the list's length
+            int base = 0;
+            if (lane == 0) base = atomicAdd(nact, __popcll(wm));
+            base = __shfl(base, 0, 64);
+            if (on) { const int e = base + __popcll(wm & ((1ull << lane) - 1ull)); active[e] = b; blk_slot[b] = e; }
+        }
+        return;
+    }
+    if ((int)blockIdx.x >= blk_wgs) {
+        const int g = (blockIdx.x - blk_wgs) * 4 + (threadIdx.x >> 6);         // this wave's 16 blocks: [16 g, 16 g + 16)
+        const int bl = g * 16 + (lane & 15);
+        const unsigned occ = (unsigned)__ballot(lane < 16 && bl < nblk && bcnt[bl] > 0);
+        if (!occ) return;
+        int4 c[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {                                          // the loads of all four groups before the first scan
+            const int b = g * 16 + i * 4 + (lane >> 4);
+            c[i] = make_int4(0, 0, 0, 0);
+            if (((occ >> (4 * i)) & 15u) && b < nblk) c[i] = *(const int4*)(cnt + (size_t)b * 64 + (lane & 15) * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (!((occ >> (4 * i)) & 15u)) continue;
+            const int b = g * 16 + i * 4 + (lane >> 4);
+            const int s0 = c[i].x, s1 = s0 + c[i].y, s2 = s1 + c[i].z, s3 = s2 + c[i].w;
+            int incl = s3;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { const int t = __shfl_up(incl, o, 16); if ((lane & 15) >= o) incl += t; }
+            const int ex = incl - s3;
+            if (b < nblk && ((occ >> (4 * i + (lane >> 4))) & 1u)) {
+                *(int4*)(start + (size_t)b * 64 + (lane & 15) * 4) = make_int4(ex, ex + s0, ex + s1, ex + s2);
+                if (s3) *(int4*)(cnt + (size_t)b * 64 + (lane & 15) * 4) = make_int4(0, 0, 0, 0);      // ready for the next sort
+            }
+        }
+        return;
+    }
     int n[4], ex[NSUM], tot[NSUM];
     const BlkSums m = blk_load4(nblk, ITEM_MAX, loose_max, quad_max, bcnt, n);
     wg_scan6(m, sh, ex, tot);
@@ -2555,7 +2638,7 @@ __global__ __launch_bounds__(256) void k_sort_blk_partial(int nblk, int ITEM_MAX
 // (one launch in which every workgroup goes over the whole array again instead of reading partial sums was tried: the six sums need
 // a division per block, 35 us for the launch against 18 for these two)
 __global__ __launch_bounds__(256) void k_sort_blk_final(int nblk, int ncell, int ITEM_MAX, int loose_max, int quad_max, const int* __restrict__ bcnt, int* cnt, int* start,
-                                                        const int* __restrict__ partial, int4* items, int2* pairs, int* singles, int2* blk_first, int4* occ, int* meta) {
+                                                        const int* __restrict__ partial, int4* items, int2* pairs, int* singles, int2* blk_first, int* blk_base, const int* __restrict__ nact, int* meta) {
     __shared__ int sh[4][NSUM];
     const int tid = threadIdx.x;
     // the partials of the workgroups before this one, and of all of them
@@ -2572,26 +2655,27 @@ __global__ __launch_bounds__(256) void k_sort_blk_final(int nblk, int ncell, int
     wg_scan6(m, sh, ex, tot);
     // meta: [0] items, [1] first slot behind the dense blocks, [2] active blocks (k_sort_fill), [3] full pairs, [4] big singles, [5] / [9] slots
     // of the two unit lists, [6] occupied blocks, [7] first slot of the tail, [8] small singles, [10] quad units, [11] big / [12] small leftovers, [13] scatter list packed, [14] / [15] work units of the two lists
-    if (blockIdx.x == 0 && tid == 0) { meta[0] = total[2]; meta[1] = total[0]; meta[2] = 0; meta[3] = total[3]; meta[4] = total[4]; meta[6] = total[5]; meta[7] = total[0] + total[1]; meta[8] = total[6];
+    if (blockIdx.x == 0 && tid == 0) { meta[0] = total[2]; meta[1] = total[0]; meta[2] = *nact; meta[3] = total[3]; meta[4] = total[4]; meta[6] = total[5]; meta[7] = total[0] + total[1]; meta[8] = total[6];
                                        meta[11] = total[7]; meta[12] = total[8]; }
     const int b0 = blockIdx.x * SORT_BLK_WG + tid * 4;
     if (b0 > nblk) return;
-    int D = before[0] + ex[0], L = total[0] + before[1] + ex[1], bi = before[2] + ex[2], bm = before[3] + ex[3], oi = before[5] + ex[5];
+    int D = before[0] + ex[0], L = total[0] + before[1] + ex[1], bi = before[2] + ex[2], bm = before[3] + ex[3];
     // `singles` = [big singles][big leftovers][small leftovers][small singles]: the big ones, the small ones and the leftovers are each
     // one stretch of it, the true singles two (build_unit_list)
     int p_tb = before[4] + ex[4], p_lb = total[4] + before[7] + ex[7], p_ls = total[4] + total[7] + before[8] + ex[8], p_ts = total[4] + total[7] + total[8] + before[6] + ex[6];
     int2 bf[4];
+    int base[4] = {0, 0, 0, 0};                                 // first slot of the block's particles (its cells follow in order: k_sort_blk_partial's launch)
 #pragma unroll
     for (int u = 0; u < 4; u++) {
         const int b = b0 + u, nn = n[u];
         bf[u] = make_int2(0, 0);
         if (b > nblk) continue;
-        if (b == nblk) { start[ncell] = total[0] + total[1]; cnt[ncell] = 0; continue; }     // the tail: behind everything
+        if (b == nblk) { base[u] = total[0] + total[1]; start[ncell] = 0; cnt[ncell] = 0; continue; }     // the tail: behind everything
         if (nn <= 0) continue;
-        if (nn <= loose_max) { occ[oi++] = make_int4(b, L, nn, 1); L += nn; continue; }
+        if (nn <= loose_max) { base[u] = L; L += nn; continue; }
         const BlkWork w = block_work(nn, ITEM_MAX);
         bf[u] = make_int2(bi, w.k);
-        occ[oi++] = make_int4(b, D, nn, 0);
+        base[u] = D;
         const bool small = w.last <= quad_max;
         if (w.single) { if (small) singles[p_ts++] = bi; else singles[p_tb++] = bi; }
         if (w.left) { if (small) singles[p_ls++] = bi + w.k - 1; else singles[p_lb++] = bi + w.k - 1; }
@@ -2599,57 +2683,9 @@ __global__ __launch_bounds__(256) void k_sort_blk_final(int nblk, int ncell, int
         for (int o = 0; o < nn; o += ITEM_MAX) items[bi++] = make_int4(b, D + o, min(ITEM_MAX, nn - o), 0);
         D += nn;
     }
+    *(int4*)(blk_base + b0) = make_int4(base[0], base[1], base[2], base[3]);        // (padded like bcnt)
     if (b0 + 3 < nblk) { *(int4*)(blk_first + b0) = make_int4(bf[0].x, bf[0].y, bf[1].x, bf[1].y); *(int4*)(blk_first + b0 + 2) = make_int4(bf[2].x, bf[2].y, bf[3].x, bf[3].y); }
     else for (int u = 0; u < 4; u++) if (b0 + u < nblk) blk_first[b0 + u] = bf[u];
-}
-
-// Two jobs in one launch.  Workgroups [0, SORT_FILL_WGS): one wave per occupied block -- where the block's 64 cells start inside its
-// slot range (the cell counts are zeroed for the next sort).  The workgroups behind them: one thread per block of the grid -- is any
-// of its 27 neighbours occupied?  Then it joins the order's active list: every block some tile or some loose particle's stencil can
-// reach.  (Round 2 and the first form of this kernel pushed instead: each occupied block swapped a flag into its 27 neighbours'
-// words; where the water has come apart that is 200,000 returning atomics on 25,000 words, 27 deep each -- 36 us.  Asking costs 27
-// cached loads per block and one atomic per wave, and the list comes out in block order.)
-#define SORT_FILL_WGS 512
-__global__ __launch_bounds__(256) void k_sort_fill(int nb, const int4* __restrict__ occ, int* meta, int* cnt, const int* __restrict__ bcnt, int* start,
-                                                   int* active, int* blk_slot) {
-    const int lane = threadIdx.x & 63;
-    if ((int)blockIdx.x < SORT_FILL_WGS) {
-        const int n_occ = meta[6];
-        for (int j = blockIdx.x * 4 + (threadIdx.x >> 6); j < n_occ; j += SORT_FILL_WGS * 4) {
-            const int4 r = occ[j];
-            const int b = r.x;
-            const int c = cnt[b * 64 + lane];
-            int incl = c;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
-            start[b * 64 + lane] = r.y + incl - c;
-            if (c) cnt[b * 64 + lane] = 0;                                         // ready for the next sort
-        }
-        return;
-    }
-    const int nblk = nb * nb * nb;
-    const int b = (blockIdx.x - SORT_FILL_WGS) * 256 + threadIdx.x;
-    bool on = false;
-    if (b < nblk) {
-        const int bi = b / (nb * nb), bj = (b / nb) % nb, bk = b % nb;
-#pragma unroll
-        for (int di = -1; di <= 1; di++)
-#pragma unroll
-            for (int dj = -1; dj <= 1; dj++) {
-                const int i2 = bi + di, j2 = bj + dj;
-                if ((unsigned)i2 < (unsigned)nb && (unsigned)j2 < (unsigned)nb) {
-                    const int row = (i2 * nb + j2) * nb;
-                    on = on || bcnt[row + bk] > 0 || (bk > 0 && bcnt[row + bk - 1] > 0) || (bk + 1 < nb && bcnt[row + bk + 1] > 0);
-                }
-            }
-    }
-    const unsigned long long wm = __ballot(on);
-    if (wm) {                                                  // the wave's entries with ONE returning atomic on the list's length
-        int base = 0;
-        if (lane == 0) base = atomicAdd(&meta[2], __popcll(wm));
-        base = __shfl(base, 0, 64);
-        if (on) { const int e = base + __popcll(wm & ((1ull << lane) - 1ull)); active[e] = b; blk_slot[b] = e; }
-    }
 }
 
 // What the substep kernels would otherwise look up through chains of dependent loads, laid out once per sort: the unit list of
@@ -2749,9 +2785,9 @@ __global__ __launch_bounds__(256) void k_build_units(int nb, int N, int xcd_on, 
 #define SORT_UNIT_WGS 128
 struct UnitsArgs { int* bcnt; int nb, xcd_on, quad_min_units, quad_fit, pack_units; const int4* items; const int2* pairs; const int* singles; const int2* blk_first; const int* active; int* meta; UnitRec* units; UnitRec* units_p; int units_cap; int2* nbr; };
 __global__ __launch_bounds__(256) void k_sort_apply(int N, size_t Np, int n_pwg, const int* __restrict__ key, const int* __restrict__ rank,
-                                                    const int* __restrict__ start, const int* __restrict__ pid_old, int* pid_new, int* slot_of_pid,
+                                                    const int* __restrict__ start, const int* __restrict__ blk_base, const int* __restrict__ pid_old, int* pid_new, int* slot_of_pid,
                                                     const float4* __restrict__ pinfo, float4* info_new, float* dst_, float* src_, UnitsArgs U, int uni) {
-    if ((int)blockIdx.x >= n_pwg) {          // (independent of the permutation: both only need what the scan and k_sort_fill left)
+    if ((int)blockIdx.x >= n_pwg) {          // (independent of the permutation: both only need what the block scan's two launches left)
         for (int i = (blockIdx.x - n_pwg) * 256 + threadIdx.x; i <= U.nb * U.nb * U.nb; i += SORT_UNIT_WGS * 256) U.bcnt[i] = 0;      // block counts: ready for the next sort
         build_units_dev((blockIdx.x - n_pwg) * 256 + threadIdx.x, SORT_UNIT_WGS * 256, U.nb, N, U.xcd_on, U.quad_min_units, U.quad_fit, U.pack_units, U.items, U.pairs, U.singles, U.blk_first, U.active, U.meta,
                         U.units, U.units_p, U.units_cap, U.nbr);
@@ -2759,7 +2795,8 @@ __global__ __launch_bounds__(256) void k_sort_apply(int N, size_t Np, int n_pwg,
     }
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= N) return;
-    const int d = start[key[s]] + rank[s];
+    const int kk = key[s];
+    const int d = blk_base[kk >> 6] + start[kk] + rank[s];     // the block's first slot + the cell's start inside the block + the rank inside the cell
     const int pid = pid_old[s];
     FrameV q = frame_view(src_, Np), o = frame_view(dst_, Np);
     const float4 a0 = q.A0[s], a1 = q.A1[s], a2 = q.A2[s], b0 = q.B0[s], b1 = q.B1[s];
@@ -3191,7 +3228,7 @@ struct FeEngine {
     int item_max = ITEM_MAX_CAP;                            // particles per work item (<= ITEM_MAX_CAP = one half workgroup)
     int sort_interval = 10;                                 // K: re-sort every K substeps (0 = never: global path only)
     size_t items_cap = 0, units_cap = 0;
-    int *sort_key = nullptr, *sort_rank = nullptr, *sort_cnt = nullptr, *sort_start = nullptr, *sort_pid = nullptr, *sort_bcnt = nullptr, *sort_partial = nullptr; int4* sort_occ = nullptr;
+    int *sort_key = nullptr, *sort_rank = nullptr, *sort_cnt = nullptr, *sort_start = nullptr, *sort_pid = nullptr, *sort_bcnt = nullptr, *sort_partial = nullptr, *sort_base = nullptr, *sort_nact = nullptr;
     int* slow_dev = nullptr;
     int* frame_slow_dev = nullptr;                          // set by a slow-path scatter of the current forward substep
     float4* pinfo = nullptr; int* pool_idx = nullptr;
@@ -3205,6 +3242,7 @@ struct FeEngine {
     int* hit_list = nullptr; int* hit_count = nullptr;                // the flagged slots of the frame being differentiated
     NodeWork* node_work = nullptr; int* node_work_count = nullptr;    // grid nodes inside an agent collider (collide_type grid / both)
     int ggrid_cap = 1024;                                  // workgroups of the grid kernels: one round of the chip's resident ones (option "ggrid_cap")
+    bool fold_reorder = true;                               // option "fold_reorder": k_p2g_grad writes across a sort boundary in the next substep's order (substep_bwd)
     int wgrid_cap_pgg = 2048;                              // ... and for k_p2g_grad (option "wgrid_cap_pgg")
     int wgrid_cap_g2p = 2048;                              // the same for k_g2p (option "wgrid_cap_g2p")
     int wgrid_cap = 2048;                                  // workgroups of the work-list kernels (option "wgrid_cap")
@@ -3418,19 +3456,18 @@ int sort_frame(FeEngine* h, int f) {
     const int nblk = h->nb * h->nb * h->nb;
     if (fine) prof_begin(h, KID_SORT_COUNT);
     hipLaunchKernelGGL(k_sort_count, dim3(n_pwg + SORT_CLR_WGS), dim3(256), 0, h->stream, h->S, h->frame(f), n_pwg, h->sort_key, h->sort_rank, h->sort_cnt, h->sort_bcnt,
-                       tn.active, tn.meta, tn.blk_slot);
+                       tn.active, tn.meta, tn.blk_slot, h->sort_nact);
     if (fine) { prof_end(h); prof_begin(h, KID_SORT_SCAN); }
-    const int blk_wgs = (nblk + 1 + SORT_BLK_WG - 1) / SORT_BLK_WG;
-    hipLaunchKernelGGL(k_sort_blk_partial, dim3(blk_wgs), dim3(256), 0, h->stream, nblk, h->item_max, h->loose_max, quad_max(h), h->sort_bcnt, h->sort_partial);
+    const int blk_wgs = (nblk + 1 + SORT_BLK_WG - 1) / SORT_BLK_WG, scan_wgs = (nblk + 63) / 64, act_wgs = (nblk + 255) / 256;
+    hipLaunchKernelGGL(k_sort_blk_partial, dim3(blk_wgs + scan_wgs + act_wgs), dim3(256), 0, h->stream, nblk, h->nb, h->item_max, h->loose_max, quad_max(h), h->sort_bcnt, h->sort_partial,
+                       blk_wgs, scan_wgs, h->sort_cnt, h->sort_start, h->sort_nact, tn.active, tn.blk_slot);
     hipLaunchKernelGGL(k_sort_blk_final, dim3(blk_wgs), dim3(256), 0, h->stream, nblk, ncell, h->item_max, h->loose_max, quad_max(h), h->sort_bcnt, h->sort_cnt, h->sort_start, h->sort_partial,
-                       tn.items, tn.pairs, tn.singles, tn.blk_first, h->sort_occ, tn.meta);
-    if (fine) { prof_end(h); prof_begin(h, KID_SORT_ACTIVE); }
-    hipLaunchKernelGGL(k_sort_fill, dim3(SORT_FILL_WGS + (nblk + 255) / 256), dim3(256), 0, h->stream, h->nb, h->sort_occ, tn.meta, h->sort_cnt, h->sort_bcnt, h->sort_start, tn.active, tn.blk_slot);
+                       tn.items, tn.pairs, tn.singles, tn.blk_first, h->sort_base, h->sort_nact, tn.meta);
     if (fine) { prof_end(h); prof_begin(h, KID_SORT_PERM); }
     // re-sorting a frame that is already in this table's order reads the id table it rewrites: stage it
     int* pid_dst = id_old == id_new ? h->sort_pid : tn.pid;
     const UnitsArgs U = {h->sort_bcnt, h->nb, h->S.xcd, h->quad_min_units, h->quad_fit, h->pack_units, tn.items, tn.pairs, tn.singles, tn.blk_first, tn.active, tn.meta, tn.units, tn.units_p, (int)h->units_cap, tn.nbr};
-    hipLaunchKernelGGL(k_sort_apply, dim3(n_pwg + SORT_UNIT_WGS), dim3(256), 0, h->stream, h->N, (size_t)h->Np, n_pwg, h->sort_key, h->sort_rank, h->sort_start,
+    hipLaunchKernelGGL(k_sort_apply, dim3(n_pwg + SORT_UNIT_WGS), dim3(256), 0, h->stream, h->N, (size_t)h->Np, n_pwg, h->sort_key, h->sort_rank, h->sort_start, h->sort_base,
                        h->tables[id_old].pid, pid_dst, tn.slot_of_pid, h->pinfo, tn.info, h->spare_frame(), h->frame(f), U, h->S.uni);
     if (id_old == id_new) HIPCK(h, hipMemcpyAsync(tn.pid, h->sort_pid, sizeof(int) * h->Np, hipMemcpyDeviceToDevice, h->stream));
     prof_end(h);
@@ -3499,7 +3536,9 @@ int substep_fwd(FeEngine* h, int f, int f_global, int act) {
     return 0;
 }
 
-int substep_bwd(FeEngine* h, int f, int f_global, int act) {
+// `next_f` >= 0: the caller goes on with substep next_f of the same sweep (fe_step_grad) -- when that one works in another particle order,
+// k_p2g_grad leaves the adjoint of frame f in that order right away (GradDst) instead of a reorder pass at the head of the next substep.
+int substep_bwd(FeEngine* h, int f, int f_global, int act, int next_f = -1) {
     InjectP inj;
     if (make_inject(h, f, f_global, act, false, inj)) return 1;
     // grad[f+1] arrives in the order frame f+1 is stored in; substep f works in frame f's order
@@ -3559,15 +3598,20 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act) {
     } else { if (h->statics_host.empty()) LAUNCH_GRID_GRAD(false, false); else LAUNCH_GRID_GRAD(true, false); }
     prof_end(h);
     prof_begin(h, KID_P2G_GRAD);
+    const int t_next = (h->fold_reorder && next_f >= 0) ? h->tbl_of_frame[next_f] : t;
+    const bool fold = t_next != t && t_next >= 0;
+    float* g_dst = fold ? h->grad_ptr[2] : h->grad(f);
+    const int* to_slot = fold ? h->tables[t_next].slot_of_pid : nullptr;
 #define LAUNCH_P2G_GRAD(G, W) hipLaunchKernelGGL((k_p2g_grad<G, W>), wgrid_pgg(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), \
-                           h->grad(f), T, h->pool_idx, h->gg_in, h->blk_count, h->slow_dev, ag, inj, act, f)
+                           h->grad(f), T, h->pool_idx, h->gg_in, h->blk_count, h->slow_dev, ag, inj, act, f, g_dst, to_slot)
     if (h->all_simple_liquid) {
         if (h->p2g_grad_waves >= 4) LAUNCH_P2G_GRAD(false, 4);
         else if (h->p2g_grad_waves == 3) LAUNCH_P2G_GRAD(false, 3);
         else LAUNCH_P2G_GRAD(false, 2);
     } else LAUNCH_P2G_GRAD(true, 1);
     prof_end(h);
-    h->gtbl[f & 1] = t;
+    if (fold) std::swap(h->grad_ptr[2], h->grad_ptr[f & 1]);
+    h->gtbl[f & 1] = fold ? t_next : t;
     return 0;
 }
 
@@ -3675,7 +3719,7 @@ int substep_bwd_batch(FeEngine** hs, int B, int f, int f_global, int act) {
         h->stamp++;
         bq.a[i] = G2PGradArgs{h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag};
         bgg.a[i] = GridGradArgs{h->S, T, h->slab, h->g_in, h->gg_out, h->gg_in, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f, statics_p(h), ag, h->node_work, h->node_work_count};
-        bpg.a[i] = P2GGradArgs{h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->pool_idx, h->gg_in, h->blk_count, h->slow_dev, ag, inj, act, f};
+        bpg.a[i] = P2GGradArgs{h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->pool_idx, h->gg_in, h->blk_count, h->slow_dev, ag, inj, act, f, h->grad(f), nullptr};
         h->gtbl[f & 1] = t;
     }
     }
@@ -3833,7 +3877,7 @@ FeEngine* fe_create(const FeConfig* cfg) {
         h->items_cap = (nblk < (size_t)h->Np ? nblk : (size_t)h->Np) + (size_t)h->Np / 64 + 2;      // item_max >= 64
         h->units_cap = h->items_cap + (size_t)h->Np / WG + 16 + 1024;                                      // work units: items (at worst one each) + tail workgroups, rounded up to 8
         if (dev_alloc(h, &h->sort_key, h->Np) || dev_alloc(h, &h->sort_rank, h->Np) || dev_alloc(h, &h->sort_cnt, ncell + 1) ||
-            dev_alloc(h, &h->sort_start, ncell + 1) || dev_alloc(h, &h->sort_bcnt, ((nblk + 1 + SORT_BLK_WG - 1) / SORT_BLK_WG) * SORT_BLK_WG) || dev_alloc(h, &h->sort_partial, ((nblk + 1 + SORT_BLK_WG - 1) / SORT_BLK_WG) * PART_STRIDE) || dev_alloc(h, &h->sort_occ, nblk + 1, false) || dev_alloc(h, &h->sort_pid, h->Np) ||
+            dev_alloc(h, &h->sort_start, ncell + 1) || dev_alloc(h, &h->sort_bcnt, ((nblk + 1 + SORT_BLK_WG - 1) / SORT_BLK_WG) * SORT_BLK_WG) || dev_alloc(h, &h->sort_partial, ((nblk + 1 + SORT_BLK_WG - 1) / SORT_BLK_WG) * PART_STRIDE) || dev_alloc(h, &h->sort_base, ((nblk + 1 + SORT_BLK_WG - 1) / SORT_BLK_WG) * SORT_BLK_WG) || dev_alloc(h, &h->sort_nact, 1) || dev_alloc(h, &h->sort_pid, h->Np) ||
             dev_alloc(h, &h->slow_dev, 1) || dev_alloc(h, &h->frame_slow_dev, 1) || dev_alloc(h, &h->slab, h->items_cap * SLAB_N, false)) return fail("");
     }
     if (dev_alloc(h, &h->effs_dev, FE_MAX_EFF)) return fail("");
@@ -3873,7 +3917,7 @@ void fe_destroy(FeEngine* h) {
     smoke_destroy(h);
     for (auto& t : h->tables) { if (t.info && t.info != h->pinfo) (void)hipFree(t.info);
         for (void* q : {(void*)t.pairs, (void*)t.singles, (void*)t.pid, (void*)t.items, (void*)t.meta, (void*)t.blk_first, (void*)t.active, (void*)t.blk_slot, (void*)t.slot_of_pid, (void*)t.units, (void*)t.units_p, (void*)t.nbr}) if (q) (void)hipFree(q); }
-    void* ptrs[] = {h->frames, h->grads, h->sort_key, h->sort_rank, h->sort_cnt, h->sort_start, h->sort_bcnt, h->sort_partial, h->sort_occ, h->sort_pid, h->slow_dev, h->frame_slow_dev, h->gstore, h->gs_flag, h->gs_live, h->ent_touched, h->ent_dirty, h->cur_live, h->slab, h->effs_dev, h->pinfo, h->pool_idx, h->g_in, h->g_out, h->gg_out, h->gg_in,
+    void* ptrs[] = {h->frames, h->grads, h->sort_key, h->sort_rank, h->sort_cnt, h->sort_start, h->sort_bcnt, h->sort_partial, h->sort_base, h->sort_nact, h->sort_pid, h->slow_dev, h->frame_slow_dev, h->gstore, h->gs_flag, h->gs_live, h->ent_touched, h->ent_dirty, h->cur_live, h->slab, h->effs_dev, h->pinfo, h->pool_idx, h->g_in, h->g_out, h->gg_out, h->gg_in,
                     h->blk_flag, h->blk_list, h->blk_count, h->err_dev, h->stage_r, h->stage_i, h->node_mark, h->counters,
                     h->tgt, h->chamfer, h->step_loss, h->body_start, h->body_pids, h->bodies_dev, h->statics_dev, h->collector_dev, h->hit_dev, h->hit_list, h->hit_count, h->node_work, h->node_work_count};
     for (float* v : h->statics_vox) if (v) (void)hipFree(v);
@@ -3933,6 +3977,7 @@ int fe_set_option(FeEngine* h, const char* name, double value) {
     if (!std::strcmp(name, "xcd_map")) { if (value < 0 || value > 64) FAIL(h, "xcd_map must be 0 (none), 1 (contiguous eighths) or a run length 2..64"); h->S.xcd = (int)value; return 0; }
     if (!std::strcmp(name, "write_through")) { h->S.wt = (int)value; return 0; }
     if (!std::strcmp(name, "wave_sort")) { h->S.wsort = value != 0; return 0; }
+    if (!std::strcmp(name, "fold_reorder")) { h->fold_reorder = value != 0; return 0; }
     if (!std::strcmp(name, "quad_min_units")) { h->quad_min_units = (int)value; return 0; }
     if (!std::strcmp(name, "pack_units")) { if (value < 0 || value > 2) FAIL(h, "pack_units must be 0, 1 or 2"); h->pack_units = (int)value; return 0; }
     if (!std::strcmp(name, "quad_fit")) { if (value < 0) FAIL(h, "quad_fit must be >= 0"); h->quad_fit = (int)value; return 0; }
@@ -3952,7 +3997,7 @@ int fe_get_option(FeEngine* h, const char* name, double* value) {
         {"sort_interval", (double)h->sort_interval}, {"item_max", (double)h->item_max}, {"grid_store", h->gs_cap > 0 ? 1.0 : 0.0},
         {"p2g_grad_waves", (double)h->p2g_grad_waves}, {"g2p_grad_v", (double)h->g2p_grad_v}, {"loose_max", (double)h->loose_max},
         {"inject_till", (double)h->inject_till}, {"collide_min_y", (double)h->collide_min_y}, {"collide_type", (double)h->collide_type},
-        {"prof_fine", h->prof_fine ? 1.0 : 0.0}, {"xcd_map", (double)h->S.xcd}, {"write_through", (double)h->S.wt}, {"wave_sort", (double)h->S.wsort},
+        {"prof_fine", h->prof_fine ? 1.0 : 0.0}, {"xcd_map", (double)h->S.xcd}, {"write_through", (double)h->S.wt}, {"wave_sort", (double)h->S.wsort}, {"fold_reorder", h->fold_reorder ? 1.0 : 0.0},
         {"quad_min_units", (double)h->quad_min_units}, {"quad_max", (double)h->quad}, {"quad_fit", (double)h->quad_fit}, {"pack_units", (double)h->pack_units},
         {"wgrid_cap", (double)h->wgrid_cap}, {"wgrid_cap_g2p", (double)h->wgrid_cap_g2p}, {"wgrid_cap_pgg", (double)h->wgrid_cap_pgg}, {"ggrid_cap", (double)h->ggrid_cap}, {"threads", 0.0}};
     for (const auto& t : tab) if (!std::strcmp(name, t.n)) { *value = t.v; return 0; }
@@ -4041,7 +4086,7 @@ int fe_step(FeEngine* h, int f0, int f_global0, int n, int act) {
 int fe_step_grad(FeEngine* h, int f0, int f_global0, int n, int act) {
     FE_ENTRY(h);
     if (f0 < 0 || f0 + n > h->L) FAIL(h, "step frames out of range");
-    for (int i = n - 1; i >= 0; i--) if (substep_bwd(h, f0 + i, f_global0 + i, act)) return 1;
+    for (int i = n - 1; i >= 0; i--) if (substep_bwd(h, f0 + i, f_global0 + i, act, i > 0 ? f0 + i - 1 : -1)) return 1;
     return check_async(h);
 }
 int fe_step_batch(FeEngine** hs, int n_env, int f0, int f_global0, int n, int act) {

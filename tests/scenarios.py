@@ -202,14 +202,19 @@ def run_forward(eng, n_sub, f0=0):
     return get_state(eng, f0 + n_sub)
 
 
-def run_forward_backward(eng, n_sub, cot):
+def run_forward_backward(eng, n_sub, cot, ranged=False):
     """Forward n_sub substeps from frame 0, seed the cotangent `cot` (dict gx,gv,gC,gF) on the
-    last frame, backward to frame 0.  Returns (final state, grads at frame 0)."""
+    last frame, backward to frame 0.  Returns (final state, grads at frame 0).
+    ranged: the reverse sweep as ONE fe_step_grad call (the HIP engine then writes the adjoint across a sort boundary in the next
+    substep's order straight away, option `fold_reorder`) instead of one fe_substep_grad call per substep."""
     st = run_forward(eng, n_sub)
     eng.reset_grad()
     eng.add_grad(n_sub, cot['gx'], cot['gv'], cot['gC'], cot['gF'])
-    for f in reversed(range(n_sub)):
-        eng.substep_grad(f, f, 0)
+    if ranged:
+        eng.step_grad(0, 0, n_sub, 0)
+    else:
+        for f in reversed(range(n_sub)):
+            eng.substep_grad(f, f, 0)
     gx, gv, gC, gF = eng.get_grad(0)
     return st, dict(gx=gx, gv=gv, gC=gC, gF=gF)
 

@@ -14,7 +14,7 @@ NO_SCRATCH = [
     'k_p2g<true, false>', 'k_grid<false, false, false>', 'k_g2p<false>', 'k_g2p_grad2<4>', 'k_grid_grad<false, false>', 'k_p2g_grad<false, 4>',
     'k_p2g<true, true>', 'k_p2g_grad<true, 1>', 'k_p2g<false, false>', 'k_p2g<false, true>', 'k_grid<true, false, false>',
     'k_p2g_b<true, false>', 'k_grid_b<false, false, false>', 'k_g2p_b<false>', 'k_g2p_grad2_b<4>', 'k_grid_grad_b<false, false>', 'k_p2g_grad_b<false, 4>',
-    'k_sort_count', 'k_sort_blk_partial', 'k_sort_blk_final', 'k_sort_fill', 'k_sort_apply', 'k_perm_reorder',
+    'k_sort_count', 'k_sort_blk_partial', 'k_sort_blk_final', 'k_sort_apply', 'k_perm_reorder',
 ]
 # occupancy the launch bounds promise: VGPRs per lane at most 512 / waves per SIMD
 MAX_VGPR = {'k_p2g<true, false>': 128, 'k_g2p<false>': 128, 'k_g2p_grad2<4>': 128, 'k_p2g_grad<false, 4>': 128, 'k_grid<false, false, false>': 128,

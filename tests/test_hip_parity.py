@@ -517,3 +517,39 @@ def test_grid_kernels_long_list_road(hiplib, oracle64, ggrid_cap, grid_store):
     assert np.abs(sa['x'] - sb['x']).max() <= 2e-6 and S.rel_l2(sa['v'], sb['v']) <= 1e-4
     for k in ('gx', 'gv', 'gC', 'gF'):
         assert S.cosine(ga[k], gb[k]) >= 0.99999 and S.rel_l2(ga[k], gb[k]) <= 1e-3, (k, S.rel_l2(ga[k], gb[k]))
+
+
+@pytest.mark.parametrize('liquid_only', [True, False])
+def test_adjoint_crosses_sort_boundaries_inside_p2g_grad(hiplib, oracle64, liquid_only):
+    """`fold_reorder` (round 4): inside one fe_step_grad call the adjoint of a frame that a sort follows is written by k_p2g_grad in the
+    order of the NEXT substep (slot_of_pid of that order, through the third adjoint buffer) and the reorder pass is skipped.  The same
+    reverse sweep three ways -- one call per substep (nothing folded), one ranged call with the option off, one with it on -- must agree
+    to rounding (the arithmetic per particle is the same; only where the result lands differs), and with the fp64 oracle.  Unused
+    slots (their adjoint passes straight through, mpm:551), a sort every 3 substeps, particles fast enough to change blocks."""
+    rng = np.random.RandomState(17)
+    N = 6000
+    x = S.f32(np.clip(np.repeat(rng.uniform(0.3, 0.7, (40, 3)), N // 40, 0) + rng.uniform(-0.05, 0.05, (N, 3)), 0.1, 0.9))
+    sc = dict(S.water_block(n_grid=32, n_particles=N, seed=9), x=x, v=S.f32(rng.normal(0, 3.0, (N, 3))),
+              used=(rng.rand(N) > 0.1).astype(np.int32))
+    sc['v'][::7] *= 8.0
+    if not liquid_only:
+        sc['mat'] = np.array([S.WATER, S.ELASTIC, S.ICECREAM], np.int32)[rng.randint(0, 3, N)]
+        sc['F'] = S.f32(np.eye(3)[None] + rng.normal(0, 1.0, (N, 3, 3)) * np.where((sc['mat'] == S.ICECREAM)[:, None, None], 0.002, 0.02))
+    cot = S.random_cotangent(N, seed=8)
+    n_sub = 11
+    runs = {}
+    for name, opts, ranged in (('per substep', {}, False), ('ranged, off', {'fold_reorder': 0}, True), ('ranged, on', {'fold_reorder': 1}, True)):
+        g = S.make_engine(hiplib, sc, options=dict(opts, sort_interval=3))
+        runs[name] = S.run_forward_backward(g, n_sub, cot, ranged=ranged)
+        if name == 'ranged, on':
+            assert g.get_option('fold_reorder') == 1.0
+        g.close()
+    o = S.make_engine(oracle64, sc)
+    sb, gb = S.run_forward_backward(o, n_sub, {k: v.astype(np.float64) for k, v in cot.items()})
+    ref = runs['per substep'][1]
+    for name in ('ranged, off', 'ranged, on'):
+        for k in ('gx', 'gv', 'gC', 'gF'):
+            assert S.rel_l2(runs[name][1][k], ref[k]) <= 2e-5, (name, k, S.rel_l2(runs[name][1][k], ref[k]))      # (the fast particles' slow path adds with global fp32 atomics: order noise, measured 1.5e-6 through the SVD adjoint)
+    tol_cos, tol_rel = (0.99999, 3e-3) if liquid_only else (0.999, 8e-2)
+    for k in ('gx', 'gv', 'gC', 'gF'):
+        assert S.cosine(runs['ranged, on'][1][k], gb[k]) >= tol_cos and S.rel_l2(runs['ranged, on'][1][k], gb[k]) <= tol_rel, k

@@ -71,7 +71,8 @@ def test_random_scene_matches_the_oracle(hiplib, oracle64, seed):
     g = S.make_engine(hiplib, sc, options=opts)
     o = S.make_engine(oracle64, sc)
     cot = S.random_cotangent(sc['N'], seed=seed)
-    sa, ga = S.run_forward_backward(g, n_sub, cot)
+    # (odd seeds: the reverse sweep as one fe_step_grad call -- adjoints cross the sort boundaries inside k_p2g_grad, `fold_reorder`)
+    sa, ga = S.run_forward_backward(g, n_sub, cot, ranged=seed % 2 == 1)
     sb, gb = S.run_forward_backward(o, n_sub, {k: v.astype(np.float64) for k, v in cot.items()})
     assert (sa['used'] == sb['used']).all()
     m = sb['used'] > 0
