@@ -494,6 +494,13 @@ __device__ __forceinline__ Unit unit_load(const TableP& T, int w) {
 // Every substep kernel is a __device__ body with two entry points: k_x(args) and k_x_b(Batch<args>) picking its env by blockIdx.y.
 // -----------------------------------------------------------------------------------------
 #define FE_MAX_BATCH 8
+// The six substep kernels start at multiples of FE_KALIGN_BYTES in the code object: where a kernel sat relative to the instruction
+// cache's lines and sets used to move with every edit of an UNRELATED kernel in front of it (k_grid: 12.2 <-> 12.6 us from a change
+// in the sort), which made A/B numbers of small changes unreadable.
+#ifndef FE_KALIGN_BYTES
+#define FE_KALIGN_BYTES 1024
+#endif
+#define FE_KALIGN __attribute__((aligned(FE_KALIGN_BYTES)))
 template <typename A> struct Batch { A a[FE_MAX_BATCH]; };
 
 // =========================================================================================
@@ -938,9 +945,9 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
 }
 struct P2GArgs { SimP S; float* fr_cur; float* fr_next; TableP T; const int* pool_idx; GridW G; AgentP agent; InjectP inj; int act; int f; GridStore GS; };
 template <bool WRITE, bool GENERAL>
-__global__ __launch_bounds__(WG, GENERAL ? 3 : 4) void k_p2g(SimP S, float* fr_cur, float* fr_next, TableP T, const int* pool_idx, GridW G, AgentP agent, InjectP inj, int act, int f, GridStore GS) { p2g_body<WRITE, GENERAL>(S, fr_cur, fr_next, T, pool_idx, G, agent, inj, act, f, GS); }
+__global__ FE_KALIGN __launch_bounds__(WG, GENERAL ? 3 : 4) void k_p2g(SimP S, float* fr_cur, float* fr_next, TableP T, const int* pool_idx, GridW G, AgentP agent, InjectP inj, int act, int f, GridStore GS) { p2g_body<WRITE, GENERAL>(S, fr_cur, fr_next, T, pool_idx, G, agent, inj, act, f, GS); }
 template <bool WRITE, bool GENERAL>
-__global__ __launch_bounds__(WG, GENERAL ? 3 : 4) void k_p2g_b(Batch<P2GArgs> B) { const P2GArgs& A = B.a[blockIdx.y]; p2g_body<WRITE, GENERAL>(A.S, A.fr_cur, A.fr_next, A.T, A.pool_idx, A.G, A.agent, A.inj, A.act, A.f, A.GS); }
+__global__ FE_KALIGN __launch_bounds__(WG, GENERAL ? 3 : 4) void k_p2g_b(Batch<P2GArgs> B) { const P2GArgs& A = B.a[blockIdx.y]; p2g_body<WRITE, GENERAL>(A.S, A.fr_cur, A.fr_next, A.T, A.pool_idx, A.G, A.agent, A.inj, A.act, A.f, A.GS); }
 
 
 // agent.collide at particle level (mpm:418-422; AgentRigid.collide): every effector that carries a mesh, in order,
@@ -1022,7 +1029,7 @@ __device__ __forceinline__ float4 gather_slabs(const float4* __restrict__ slab, 
     // blocks are loaded unconditionally-shaped (16 independent loads in flight, zero when absent): summing inside a loop made
     // every load wait for the previous one, eight dependent L2/MALL round trips per node.  Blocks with more than two slabs
     // (> 512 particles) finish in the loop below.  The summation order stays fixed (source c ascending, slab ascending).
-    int a0[8], n[8];                                // node's element in the source block's first slab; that block's item count (0: none reaches this node)
+    int a0[8], n[8];                         // node's element in the source block's first slab; that block's item count (0: none reaches this node)
     float4 v0[8], v1[8];
 #pragma unroll
     for (int c = 0; c < 8; c++) {
@@ -1041,7 +1048,9 @@ __device__ __forceinline__ float4 gather_slabs(const float4* __restrict__ slab, 
         a0[c] = valid ? (NPL == 4 ? f * SLAB_N + si : f * (SLAB_N * 16) + si * 12) : 0;      // (element index / byte offset of a packed node)
     }
     // (the loads are unconditional from a clamped, always valid index and masked afterwards: a conditional float4
-    // load into an array element ended up in scratch; lanes without a source all read node 0 of slab 0, one broadcast line)
+    // load into an array element ended up in scratch; lanes without a source all read node 0 of slab 0, one broadcast line.
+    // Round 4: skipping the source blocks without items by wave-uniform branches around their loads -- where the water has come apart most
+    // of the eight are empty -- was slower in every phase, +1.7 us in k_grid and +1.2 in k_grid_grad: profiles/r04_ab_grid_gather_uniform_branches.txt)
     const __amdgpu_buffer_rsrc_t rs = wt_rsrc((void*)slab);
     auto ld = [&](int at) -> float4 {
         if (NPL == 4) return slab[at];
@@ -1182,9 +1191,9 @@ __device__ __forceinline__ void grid_body(SimP S, TableP T, const float4* __rest
 }
 struct GridArgs { SimP S; TableP T; const float4* slab; float* g_in; float4* g_out; const int* blk_list; const int* blk_count; int* blk_flag; GridStore GS; int f; int* frame_slow; StaticsP ST; AgentP agent; };
 template <bool KEEP, bool STATICS, bool DYN>
-__global__ __launch_bounds__(256, (STATICS || DYN) ? 2 : 4) void k_grid(SimP S, TableP T, const float4* slab, float* g_in, float4* g_out, const int* blk_list, const int* blk_count, int* blk_flag, GridStore GS, int f, int* frame_slow, StaticsP ST, AgentP agent) { grid_body<KEEP, STATICS, DYN>(S, T, slab, g_in, g_out, blk_list, blk_count, blk_flag, GS, f, frame_slow, ST, agent); }
+__global__ FE_KALIGN __launch_bounds__(256, (STATICS || DYN) ? 2 : 4) void k_grid(SimP S, TableP T, const float4* slab, float* g_in, float4* g_out, const int* blk_list, const int* blk_count, int* blk_flag, GridStore GS, int f, int* frame_slow, StaticsP ST, AgentP agent) { grid_body<KEEP, STATICS, DYN>(S, T, slab, g_in, g_out, blk_list, blk_count, blk_flag, GS, f, frame_slow, ST, agent); }
 template <bool KEEP, bool STATICS, bool DYN>
-__global__ __launch_bounds__(256, (STATICS || DYN) ? 2 : 4) void k_grid_b(Batch<GridArgs> B) { const GridArgs& A = B.a[blockIdx.y]; grid_body<KEEP, STATICS, DYN>(A.S, A.T, A.slab, A.g_in, A.g_out, A.blk_list, A.blk_count, A.blk_flag, A.GS, A.f, A.frame_slow, A.ST, A.agent); }
+__global__ FE_KALIGN __launch_bounds__(256, (STATICS || DYN) ? 2 : 4) void k_grid_b(Batch<GridArgs> B) { const GridArgs& A = B.a[blockIdx.y]; grid_body<KEEP, STATICS, DYN>(A.S, A.T, A.slab, A.g_in, A.g_out, A.blk_list, A.blk_count, A.blk_flag, A.GS, A.f, A.frame_slow, A.ST, A.agent); }
 
 
 // g2p (mpm:400-426) + advect_kernel (mpm:497-505) for one used particle; TILE: v_out staged in LDS (3 planes)
@@ -1310,9 +1319,9 @@ __device__ __forceinline__ void g2p_body(SimP S, float* fr_cur, float* fr_next, 
 }
 struct G2PArgs { SimP S; float* fr_cur; float* fr_next; TableP T; const float4* g_out; int* blk_count; int* slow; AgentP agent; int f; };
 template <bool COLLIDE>
-__global__ __launch_bounds__(WG) void k_g2p(SimP S, float* fr_cur, float* fr_next, TableP T, const float4* g_out, int* blk_count, int* slow, AgentP agent, int f) { g2p_body<COLLIDE>(S, fr_cur, fr_next, T, g_out, blk_count, slow, agent, f); }
+__global__ FE_KALIGN __launch_bounds__(WG) void k_g2p(SimP S, float* fr_cur, float* fr_next, TableP T, const float4* g_out, int* blk_count, int* slow, AgentP agent, int f) { g2p_body<COLLIDE>(S, fr_cur, fr_next, T, g_out, blk_count, slow, agent, f); }
 template <bool COLLIDE>
-__global__ __launch_bounds__(WG) void k_g2p_b(Batch<G2PArgs> B) { const G2PArgs& A = B.a[blockIdx.y]; g2p_body<COLLIDE>(A.S, A.fr_cur, A.fr_next, A.T, A.g_out, A.blk_count, A.slow, A.agent, A.f); }
+__global__ FE_KALIGN __launch_bounds__(WG) void k_g2p_b(Batch<G2PArgs> B) { const G2PArgs& A = B.a[blockIdx.y]; g2p_body<COLLIDE>(A.S, A.fr_cur, A.fr_next, A.T, A.g_out, A.blk_count, A.slow, A.agent, A.f); }
 
 
 // =========================================================================================
@@ -1817,9 +1826,9 @@ __device__ __forceinline__ void g2p_grad2_body(SimP S, float* fr_cur, float* Gn_
     }
 }
 template <int MINW>
-__global__ __launch_bounds__(WG, MINW) void k_g2p_grad2(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T, const float4* g_out, float* gg_out, float4* slab, int* slow, GridStore GS, int f, AgentP agent) { g2p_grad2_body<MINW>(S, fr_cur, Gn_, Gc_, T, g_out, gg_out, slab, slow, GS, f, agent); }
+__global__ FE_KALIGN __launch_bounds__(WG, MINW) void k_g2p_grad2(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T, const float4* g_out, float* gg_out, float4* slab, int* slow, GridStore GS, int f, AgentP agent) { g2p_grad2_body<MINW>(S, fr_cur, Gn_, Gc_, T, g_out, gg_out, slab, slow, GS, f, agent); }
 template <int MINW>
-__global__ __launch_bounds__(WG, MINW) void k_g2p_grad2_b(Batch<G2PGradArgs> B) { const G2PGradArgs& A = B.a[blockIdx.y]; g2p_grad2_body<MINW>(A.S, A.fr_cur, A.Gn_, A.Gc_, A.T, A.g_out, A.gg_out, A.slab, A.slow, A.GS, A.f, A.agent); }
+__global__ FE_KALIGN __launch_bounds__(WG, MINW) void k_g2p_grad2_b(Batch<G2PGradArgs> B) { const G2PGradArgs& A = B.a[blockIdx.y]; g2p_grad2_body<MINW>(A.S, A.fr_cur, A.Gn_, A.Gc_, A.T, A.g_out, A.gg_out, A.slab, A.slow, A.GS, A.f, A.agent); }
 
 
 // agent.collide's adjoint (mpm:418-422 in reverse) as a pass of its own, before k_g2p_grad.  Inlined into k_g2p_grad the
@@ -2057,9 +2066,9 @@ __device__ __forceinline__ void grid_grad_body(SimP S, TableP T, const float4* _
 }
 struct GridGradArgs { SimP S; TableP T; const float4* slab; float* g_in; float* gg_out; float4* gg_in; const int* blk_list; const int* blk_count; int* blk_flag; GridStore GS; int f; StaticsP ST; AgentP agent; NodeWork* work; int* work_count; };
 template <bool STATICS, bool DYN>
-__global__ __launch_bounds__(256, (STATICS || DYN) ? 2 : 4) void k_grid_grad(SimP S, TableP T, const float4* slab, float* g_in, float* gg_out, float4* gg_in, const int* blk_list, const int* blk_count, int* blk_flag, GridStore GS, int f, StaticsP ST, AgentP agent, NodeWork* work, int* work_count) { grid_grad_body<STATICS, DYN>(S, T, slab, g_in, gg_out, gg_in, blk_list, blk_count, blk_flag, GS, f, ST, agent, work, work_count); }
+__global__ FE_KALIGN __launch_bounds__(256, (STATICS || DYN) ? 2 : 4) void k_grid_grad(SimP S, TableP T, const float4* slab, float* g_in, float* gg_out, float4* gg_in, const int* blk_list, const int* blk_count, int* blk_flag, GridStore GS, int f, StaticsP ST, AgentP agent, NodeWork* work, int* work_count) { grid_grad_body<STATICS, DYN>(S, T, slab, g_in, gg_out, gg_in, blk_list, blk_count, blk_flag, GS, f, ST, agent, work, work_count); }
 template <bool STATICS, bool DYN>
-__global__ __launch_bounds__(256, (STATICS || DYN) ? 2 : 4) void k_grid_grad_b(Batch<GridGradArgs> B) { const GridGradArgs& A = B.a[blockIdx.y]; grid_grad_body<STATICS, DYN>(A.S, A.T, A.slab, A.g_in, A.gg_out, A.gg_in, A.blk_list, A.blk_count, A.blk_flag, A.GS, A.f, A.ST, A.agent, A.work, A.work_count); }
+__global__ FE_KALIGN __launch_bounds__(256, (STATICS || DYN) ? 2 : 4) void k_grid_grad_b(Batch<GridGradArgs> B) { const GridGradArgs& A = B.a[blockIdx.y]; grid_grad_body<STATICS, DYN>(A.S, A.T, A.slab, A.g_in, A.gg_out, A.gg_in, A.blk_list, A.blk_count, A.blk_flag, A.GS, A.f, A.ST, A.agent, A.work, A.work_count); }
 
 
 // second half of grid_op.grad for the nodes k_grid_grad<.., DYN> set aside: agent.collide's adjoint at the node (mpm:393-395 in
@@ -2375,9 +2384,9 @@ __device__ __forceinline__ void p2g_grad_body(SimP S, float* fr_cur, float* Gn_,
 }
 struct P2GGradArgs { SimP S; float* fr_cur; float* Gn_; float* Gc_; TableP T; const int* pool_idx; const float4* gg_in; int* blk_count; int* slow; AgentP agent; InjectP inj; int act; int f; float* Gd_; const int* to_slot; };
 template <bool GENERAL, int MINW>
-__global__ __launch_bounds__(WG, MINW) void k_p2g_grad(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T, const int* pool_idx, const float4* gg_in, int* blk_count, int* slow, AgentP agent, InjectP inj, int act, int f, float* Gd_, const int* to_slot) { p2g_grad_body<GENERAL, MINW>(S, fr_cur, Gn_, Gc_, T, pool_idx, gg_in, blk_count, slow, agent, inj, act, f, Gd_, to_slot); }
+__global__ FE_KALIGN __launch_bounds__(WG, MINW) void k_p2g_grad(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T, const int* pool_idx, const float4* gg_in, int* blk_count, int* slow, AgentP agent, InjectP inj, int act, int f, float* Gd_, const int* to_slot) { p2g_grad_body<GENERAL, MINW>(S, fr_cur, Gn_, Gc_, T, pool_idx, gg_in, blk_count, slow, agent, inj, act, f, Gd_, to_slot); }
 template <bool GENERAL, int MINW>
-__global__ __launch_bounds__(WG, MINW) void k_p2g_grad_b(Batch<P2GGradArgs> B) { const P2GGradArgs& A = B.a[blockIdx.y]; p2g_grad_body<GENERAL, MINW>(A.S, A.fr_cur, A.Gn_, A.Gc_, A.T, A.pool_idx, A.gg_in, A.blk_count, A.slow, A.agent, A.inj, A.act, A.f, A.Gd_, A.to_slot); }
+__global__ FE_KALIGN __launch_bounds__(WG, MINW) void k_p2g_grad_b(Batch<P2GGradArgs> B) { const P2GGradArgs& A = B.a[blockIdx.y]; p2g_grad_body<GENERAL, MINW>(A.S, A.fr_cur, A.Gn_, A.Gc_, A.T, A.pool_idx, A.gg_in, A.blk_count, A.slow, A.agent, A.inj, A.act, A.f, A.Gd_, A.to_slot); }
 
 
 // =========================================================================================
@@ -2477,9 +2486,21 @@ __global__ __launch_bounds__(256) void k_sort_count(SimP S, float* fr, int n_pwg
     }
     if (tid == 255 && hist[SORT_HB] > 0) atomicAdd(&bcnt[S.ncell >> 6], hist[SORT_HB]);
     __syncthreads();
-    for (int l = tid; l <= SORT_HB; l += 256) {
-        int c = hist[l];
-        if (c > 0) { const int cell = l == SORT_HB ? S.ncell : kmin + l; hist[l] = atomicAdd(&cnt[cell], c); }
+    {   // one returning global atomic per distinct cell of the window -- all of a thread's sixteen asked for before the first answer is
+        // waited for (in a loop every iteration that had a count in any lane was a round trip of its own: the keys of a workgroup
+        // cluster in a few blocks, i.e. in a few of the sixteen iterations, and those came back one after the other)
+        const int k0 = kmin;
+        int c[SORT_HB / 256], b[SORT_HB / 256];
+#pragma unroll
+        for (int i = 0; i < SORT_HB / 256; i++) c[i] = hist[tid + 256 * i];
+        const int ct = tid == 0 ? hist[SORT_HB] : 0;
+        int bt = 0;
+#pragma unroll
+        for (int i = 0; i < SORT_HB / 256; i++) { b[i] = 0; if (c[i] > 0) b[i] = atomicAdd(&cnt[k0 + tid + 256 * i], c[i]); }
+        if (ct > 0) bt = atomicAdd(&cnt[S.ncell], ct);
+#pragma unroll
+        for (int i = 0; i < SORT_HB / 256; i++) if (c[i] > 0) hist[tid + 256 * i] = b[i];
+        if (ct > 0) hist[SORT_HB] = bt;
     }
     __syncthreads();
     if (local) r += hist[rel];
@@ -2765,12 +2786,22 @@ __device__ __forceinline__ void build_units_dev(int gtid, int nth, int nb, int N
     if (gtid == 0) { meta[10] = (x + 3) >> 2; meta[13] = pack ? 1 : 0; }       // (fe_get_work_stats)
     build_unit_list(gtid, nth, N, xcd_on, items, pairs, singles, tail_start, L, pack, x, meta + 5, meta + 14, units, units_cap);
     build_unit_list(gtid, nth, N, xcd_on, items, pairs, singles, tail_start, L, false, 0, meta + 9, meta + 15, units_p, units_cap);
-    for (int t = gtid; t < n_active * 27; t += nth) {
-        const int e = t / 27, n = t - e * 27, b = active[e];
-        const int i2 = b / (nb * nb) + n / 9 - 1, j2 = (b / nb) % nb + (n / 3) % 3 - 1, k2 = b % nb + n % 3 - 1;
-        int2 v = make_int2(0, 0);
-        if ((unsigned)i2 < (unsigned)nb && (unsigned)j2 < (unsigned)nb && (unsigned)k2 < (unsigned)nb) v = blk_first[(i2 * nb + j2) * nb + k2];
-        nbr[t] = v;
+    // neighbour records, four entries of a thread at a time: their block numbers in one round trip, their item ranges in the next (one at
+    // a time this loop was two dependent round trips per entry, 5 ... 20 entries per thread -- the longest chain of the sort's last launch)
+    for (int t0 = gtid; t0 < n_active * 27; t0 += 4 * nth) {
+        int b[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int t = t0 + u * nth; b[u] = t < n_active * 27 ? active[t / 27] : 0; }
+        int2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int t = t0 + u * nth, n = t % 27;
+            const int i2 = b[u] / (nb * nb) + n / 9 - 1, j2 = (b[u] / nb) % nb + (n / 3) % 3 - 1, k2 = b[u] % nb + n % 3 - 1;
+            v[u] = make_int2(0, 0);
+            if (t < n_active * 27 && (unsigned)i2 < (unsigned)nb && (unsigned)j2 < (unsigned)nb && (unsigned)k2 < (unsigned)nb) v[u] = blk_first[(i2 * nb + j2) * nb + k2];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int t = t0 + u * nth; if (t < n_active * 27) nbr[t] = v[u]; }
     }
 }
 __global__ __launch_bounds__(256) void k_build_units(int nb, int N, int xcd_on, const int4* __restrict__ items, const int2* __restrict__ pairs,
@@ -2782,7 +2813,9 @@ __global__ __launch_bounds__(256) void k_build_units(int nb, int N, int xcd_on, 
 // The permutation itself, one pass: slot s of the old order goes to d = start[key] + rank -- its particle id, material record and
 // all 25 planes.  Reads are coalesced, writes land near s (the old order was sorted too: particles move less than a cell between
 // sorts), so the write combining of the L2 sees them almost in order.  (Round 1: index kernel, copy of the id table, gather kernel.)
+#ifndef SORT_UNIT_WGS
 #define SORT_UNIT_WGS 128
+#endif
 struct UnitsArgs { int* bcnt; int nb, xcd_on, quad_min_units, quad_fit, pack_units; const int4* items; const int2* pairs; const int* singles; const int2* blk_first; const int* active; int* meta; UnitRec* units; UnitRec* units_p; int units_cap; int2* nbr; };
 __global__ __launch_bounds__(256) void k_sort_apply(int N, size_t Np, int n_pwg, const int* __restrict__ key, const int* __restrict__ rank,
                                                     const int* __restrict__ start, const int* __restrict__ blk_base, const int* __restrict__ pid_old, int* pid_new, int* slot_of_pid,

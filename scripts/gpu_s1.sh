@@ -1,3 +1,3 @@
 OUT=gpurun_out/s1; mkdir -p $OUT; export TMPDIR=/tmp
-echo "== tests"; timeout 900 python -m pytest tests/test_hip_parity.py tests/test_hip_random_scenes.py -m gpu -x -q 2>&1 | tail -8 | tee $OUT/pytest.txt
-echo "== ab"; timeout 900 python scripts/ab_phases.py --windows 30 --reps 2 "lib=scripts/_bin/libfe_base.so" "" "fold_reorder=0" 2>&1 | grep -v amdgpu.ids > $OUT/ab.txt; python scripts/ab_table.py $OUT/ab.txt | tee $OUT/ab_table.txt
+echo "== tests"; timeout 900 python -m pytest tests/test_hip_parity.py tests/test_hip_random_scenes.py -m gpu -x -q 2>&1 | tail -4 | tee $OUT/pytest.txt
+echo "== ab"; timeout 900 python scripts/ab_phases.py --windows 30 --reps 2 "$@" 2>&1 | grep -v amdgpu.ids > $OUT/ab.txt; python scripts/ab_table.py $OUT/ab.txt | tee $OUT/ab_table.txt
