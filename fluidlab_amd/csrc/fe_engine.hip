@@ -2412,6 +2412,22 @@ __global__ FE_KALIGN __launch_bounds__(WG, MINW) void k_p2g_grad_b(Batch<P2GGrad
 // histogram + rank.  Keys of one workgroup's 256 slots are nearly always within a narrow range (the previous
 // order was sorted too), so ranks come from an LDS histogram (ds_add_rtn_u32) and only one global atomic per
 // distinct key per workgroup is issued; keys outside the window fall back to a global atomic.
+// Inclusive integer scans in DPP: over the 16 lanes of a row (row_shr 1, 2, 4, 8) and over the wavefront (+ row_bcast 15 into rows 1 and 3,
+// row_bcast 31 into rows 2 and 3) -- six VALU instructions.  (__shfl_up is ds_bpermute_b32 + s_waitcnt lgkmcnt(0): the 9 x 6 x 3 of
+// them in k_sort_blk_final came out as 162 LDS round trips one after the other, 9 of that kernel's 12.3 us.)
+__device__ __forceinline__ int row_iscan(int x) {
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false);
+    return x;
+}
+__device__ __forceinline__ int wave_iscan(int x) {
+    x = row_iscan(x);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
+    return x;
+}
 #define SORT_CLR_WGS 32
 __global__ __launch_bounds__(256) void k_sort_count(SimP S, float* fr, int n_pwg, int* key, int* rank, int* cnt, int* bcnt,
                                                     const int* __restrict__ clr_active, const int* __restrict__ clr_meta, int* clr_slot, int* nact) {
@@ -2429,8 +2445,8 @@ __global__ __launch_bounds__(256) void k_sort_count(SimP S, float* fr, int n_pwg
     int kk = S.ncell;                                        // sentinel: unused / outside -> tail
     if (valid) {
         FrameV cur = frame_view(fr, S.Np);
+        const float4 a0 = cur.A0[s];                         // (asked for together with the flag, not behind it)
         if (cur.used[s]) {
-            float4 a0 = cur.A0[s];
             float x[3] = {a0.x, a0.y, a0.z};
             Stencil st;
             stencil_make(x, S.inv_dx, st);
@@ -2471,17 +2487,15 @@ __global__ __launch_bounds__(256) void k_sort_count(SimP S, float* fr, int n_pwg
         }
     }
     __syncthreads();
-    // per-block counts of the window (it starts anywhere, so it overlaps up to 65 blocks; block nblk = the tail sentinel): 16 cells per
-    // thread, the four threads of a block add up across lanes (65 threads walking 64 cells each were a 64-deep LDS chain)
+    // per-block counts of the window (it starts anywhere, so it overlaps up to 65 blocks; block nblk = the tail sentinel): a wave takes
+    // a block at a time, a lane one cell -- consecutive LDS words -- and the sum comes out of a DPP scan (65 threads walking 64 cells each
+    // were a 64-deep chain of LDS reads; 16 cells per thread were 32-way bank conflicts)
     if (kmin != 0x7fffffff) {
-        const int k0 = kmin, base = k0 & ~63;
-        for (int t = tid; t < (SORT_HB + 64) / 16; t += 256) {
-            const int c0 = base + t * 16;
-            int n = 0;
-#pragma unroll
-            for (int u = 0; u < 16; u++) { const int l = c0 + u - k0; if (l >= 0 && l < SORT_HB) n += hist[l]; }
-            n += __shfl_xor(n, 1, 64); n += __shfl_xor(n, 2, 64);
-            if ((t & 3) == 0 && n > 0) atomicAdd(&bcnt[c0 >> 6], n);
+        const int k0 = kmin, base = k0 & ~63, lane = tid & 63;
+        for (int j = tid >> 6; j <= SORT_HB / 64; j += 4) {
+            const int l = base + j * 64 + lane - k0;
+            const int n = wave_iscan((l >= 0 && l < SORT_HB) ? hist[l] : 0);
+            if (lane == 63 && n > 0) atomicAdd(&bcnt[(base >> 6) + j], n);
         }
     }
     if (tid == 255 && hist[SORT_HB] > 0) atomicAdd(&bcnt[S.ncell >> 6], hist[SORT_HB]);
@@ -2550,14 +2564,17 @@ __device__ __forceinline__ void blk_accumulate(BlkSums& a, int n, int ITEM_MAX, 
     a.v[7] += (dense && w.left && !small) ? 1 : 0;
     a.v[8] += (dense && w.left && small) ? 1 : 0;
 }
-// the thread's four block counts and their sums
-__device__ __forceinline__ BlkSums blk_load4(int nblk, int ITEM_MAX, int loose_max, int quad_max, const int* __restrict__ bcnt, int n[4]) {
+// the thread's four block counts (one 16-byte load: blk_ask4) and their sums.  The counts of blocks past the grid read as 0 through a
+// SELECT, not a branch: the first use of the loaded registers is then unconditional and the one wait for the load sits right there --
+// under a branch every later use got its own `s_waitcnt vmcnt(0)`, which in k_sort_blk_final also drained the stores of the block
+// before (four store round trips one after the other).
+__device__ __forceinline__ int4 blk_ask4(const int* __restrict__ bcnt) { return *(const int4*)(bcnt + blockIdx.x * SORT_BLK_WG + threadIdx.x * 4); }
+__device__ __forceinline__ BlkSums blk_sums4(const int4 n4, int nblk, int ITEM_MAX, int loose_max, int quad_max, int n[4]) {
     const int b0 = blockIdx.x * SORT_BLK_WG + threadIdx.x * 4;
-    const int4 n4 = *(const int4*)(bcnt + b0);
-    n[0] = n4.x; n[1] = n4.y; n[2] = n4.z; n[3] = n4.w;
+    n[0] = b0 < nblk ? n4.x : 0; n[1] = b0 + 1 < nblk ? n4.y : 0; n[2] = b0 + 2 < nblk ? n4.z : 0; n[3] = b0 + 3 < nblk ? n4.w : 0;
     BlkSums m = {{0, 0, 0, 0, 0, 0, 0, 0, 0}};
 #pragma unroll
-    for (int u = 0; u < 4; u++) if (b0 + u < nblk) blk_accumulate(m, n[u], ITEM_MAX, loose_max, quad_max);
+    for (int u = 0; u < 4; u++) blk_accumulate(m, n[u], ITEM_MAX, loose_max, quad_max);
     return m;
 }
 // NSUM sums over the 256 threads of the workgroup: exclusive prefix of this thread in ex[], workgroup totals in tot[]
@@ -2565,9 +2582,7 @@ __device__ __forceinline__ void wg_scan6(const BlkSums& m, int (*sh)[NSUM], int 
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 #pragma unroll
     for (int k = 0; k < NSUM; k++) {
-        int incl = m.v[k];
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        const int incl = wave_iscan(m.v[k]);
         ex[k] = incl - m.v[k];
         if (lane == 63) sh[wave][k] = incl;
     }
@@ -2639,10 +2654,7 @@ __global__ __launch_bounds__(256) void k_sort_blk_partial(int nblk, int nb, int 
             if (!((occ >> (4 * i)) & 15u)) continue;
             const int b = g * 16 + i * 4 + (lane >> 4);
             const int s0 = c[i].x, s1 = s0 + c[i].y, s2 = s1 + c[i].z, s3 = s2 + c[i].w;
-            int incl = s3;
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) { const int t = __shfl_up(incl, o, 16); if ((lane & 15) >= o) incl += t; }
-            const int ex = incl - s3;
+            const int ex = row_iscan(s3) - s3;
             if (b < nblk && ((occ >> (4 * i + (lane >> 4))) & 1u)) {
                 *(int4*)(start + (size_t)b * 64 + (lane & 15) * 4) = make_int4(ex, ex + s0, ex + s1, ex + s2);
                 if (s3) *(int4*)(cnt + (size_t)b * 64 + (lane & 15) * 4) = make_int4(0, 0, 0, 0);      // ready for the next sort
@@ -2651,7 +2663,7 @@ __global__ __launch_bounds__(256) void k_sort_blk_partial(int nblk, int nb, int 
         return;
     }
     int n[4], ex[NSUM], tot[NSUM];
-    const BlkSums m = blk_load4(nblk, ITEM_MAX, loose_max, quad_max, bcnt, n);
+    const BlkSums m = blk_sums4(blk_ask4(bcnt), nblk, ITEM_MAX, loose_max, quad_max, n);
     wg_scan6(m, sh, ex, tot);
 #pragma unroll
     for (int k = 0; k < NSUM; k++) if ((int)threadIdx.x == k) partial[blockIdx.x * PART_STRIDE + k] = tot[k];      // (static indices: tot[threadIdx.x] sends the sums through memory)
@@ -2662,6 +2674,7 @@ __global__ __launch_bounds__(256) void k_sort_blk_final(int nblk, int ncell, int
                                                         const int* __restrict__ partial, int4* items, int2* pairs, int* singles, int2* blk_first, int* blk_base, const int* __restrict__ nact, int* meta) {
     __shared__ int sh[4][NSUM];
     const int tid = threadIdx.x;
+    const int4 n4 = blk_ask4(bcnt);                  // (on its way while the partial sums are read)
     // the partials of the workgroups before this one, and of all of them
     BlkSums pb = {{0, 0, 0, 0, 0, 0, 0, 0, 0}}, pa = {{0, 0, 0, 0, 0, 0, 0, 0, 0}};
     for (int w = tid; w < (int)gridDim.x; w += 256) {
@@ -2669,7 +2682,7 @@ __global__ __launch_bounds__(256) void k_sort_blk_final(int nblk, int ncell, int
         for (int k = 0; k < NSUM; k++) { const int t = partial[w * PART_STRIDE + k]; pa.v[k] += t; if (w < (int)blockIdx.x) pb.v[k] += t; }
     }
     int n[4], ex[NSUM], tot[NSUM];
-    const BlkSums m = blk_load4(nblk, ITEM_MAX, loose_max, quad_max, bcnt, n);
+    const BlkSums m = blk_sums4(n4, nblk, ITEM_MAX, loose_max, quad_max, n);
     int exb[NSUM], before[NSUM], exa[NSUM], total[NSUM];
     wg_scan6(pb, sh, exb, before);
     wg_scan6(pa, sh, exa, total);

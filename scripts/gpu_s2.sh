@@ -1,0 +1,9 @@
+OUT=gpurun_out/s2; mkdir -p $OUT; export TMPDIR=/tmp
+echo "== tests"; timeout 900 python -m pytest tests/test_hip_parity.py tests/test_hip_random_scenes.py -m gpu -x -q 2>&1 | tail -3 | tee $OUT/pytest.txt
+bash scripts/gpu_trace_short.sh tr 20 5 > $OUT/trace_short.txt 2>&1
+python - <<'P'
+import csv
+for r in csv.reader(open('gpurun_out/tr/profiles/tr_kernel_stats_timed_region.csv')):
+    if r[0] != 'Name': print(r[0][:30], r[1], r[3], r[5], r[6])
+P
+grep -o '"value": [0-9.]*' gpurun_out/tr/trace.log
