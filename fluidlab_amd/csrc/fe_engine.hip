@@ -2827,19 +2827,21 @@ __global__ __launch_bounds__(256) void k_build_units(int nb, int N, int xcd_on, 
 // all 25 planes.  Reads are coalesced, writes land near s (the old order was sorted too: particles move less than a cell between
 // sorts), so the write combining of the L2 sees them almost in order.  (Round 1: index kernel, copy of the id table, gather kernel.)
 #ifndef SORT_UNIT_WGS
-#define SORT_UNIT_WGS 128
+#define SORT_UNIT_WGS 512      // (128 until late in round 4: where the water has come apart the neighbour records were the launch's longest chain)
 #endif
 struct UnitsArgs { int* bcnt; int nb, xcd_on, quad_min_units, quad_fit, pack_units; const int4* items; const int2* pairs; const int* singles; const int2* blk_first; const int* active; int* meta; UnitRec* units; UnitRec* units_p; int units_cap; int2* nbr; };
 __global__ __launch_bounds__(256) void k_sort_apply(int N, size_t Np, int n_pwg, const int* __restrict__ key, const int* __restrict__ rank,
                                                     const int* __restrict__ start, const int* __restrict__ blk_base, const int* __restrict__ pid_old, int* pid_new, int* slot_of_pid,
                                                     const float4* __restrict__ pinfo, float4* info_new, float* dst_, float* src_, UnitsArgs U, int uni) {
-    if ((int)blockIdx.x >= n_pwg) {          // (independent of the permutation: both only need what the block scan's two launches left)
-        for (int i = (blockIdx.x - n_pwg) * 256 + threadIdx.x; i <= U.nb * U.nb * U.nb; i += SORT_UNIT_WGS * 256) U.bcnt[i] = 0;      // block counts: ready for the next sort
-        build_units_dev((blockIdx.x - n_pwg) * 256 + threadIdx.x, SORT_UNIT_WGS * 256, U.nb, N, U.xcd_on, U.quad_min_units, U.quad_fit, U.pack_units, U.items, U.pairs, U.singles, U.blk_first, U.active, U.meta,
+    // the first SORT_UNIT_WGS workgroups (dispatched first: theirs are the longer chains): unit lists and neighbour records
+    // (independent of the permutation: both only need what the block scan's two launches left)
+    if ((int)blockIdx.x < SORT_UNIT_WGS) {
+        for (int i = blockIdx.x * 256 + threadIdx.x; i <= U.nb * U.nb * U.nb; i += SORT_UNIT_WGS * 256) U.bcnt[i] = 0;      // block counts: ready for the next sort
+        build_units_dev(blockIdx.x * 256 + threadIdx.x, SORT_UNIT_WGS * 256, U.nb, N, U.xcd_on, U.quad_min_units, U.quad_fit, U.pack_units, U.items, U.pairs, U.singles, U.blk_first, U.active, U.meta,
                         U.units, U.units_p, U.units_cap, U.nbr);
         return;
     }
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = (blockIdx.x - SORT_UNIT_WGS) * blockDim.x + threadIdx.x;
     if (s >= N) return;
     const int kk = key[s];
     const int d = blk_base[kk >> 6] + start[kk] + rank[s];     // the block's first slot + the cell's start inside the block + the rank inside the cell
@@ -3265,6 +3267,7 @@ struct FeEngine {
     std::vector<Table> tables;
     std::vector<int> tbl_of_frame;                          // [L+1]
     int gtbl[2] = {-1, -1};                                 // order of each adjoint ring slot; -1 = all zero
+    int tbl_bank = 0, last_sorted_f = -1;                   // two banks of table ids, one per sweep over the window (sort_frame)
     int p2g_grad_waves = 4;                                 // occupancy target of the SVD-free p2g_grad build (tuning)
     int pack_units = 2;                                     // option "pack_units": 0 never, 1 pack the scatter list (no idle halves) when that brings it back into one round, 2 whenever it is more than one round
     int quad_fit = 1024;                                    // option "quad_fit": the workgroups of one resident round (set from the device in fe_create: 4 per CU); 0 = round 3's rule
@@ -3488,9 +3491,15 @@ int grad_order_for_frame(FeEngine* h, int f) {
 int use_static_table(FeEngine*, int) { return 0; }
 
 inline int quad_max(FeEngine* h) { return h->quad; }
-// counting sort of frame f by 4^3 block; the new order becomes table 1+f
+// counting sort of frame f by 4^3 block; the new order becomes table 1 + f of the current bank.  The bank changes whenever the frame
+// number does not grow (a new sweep over the window): the adjoint slots of the sweep before still name that sweep's tables -- until the
+// caller resets them, which fluidlab's solver does AFTER the next forward pass (solver.py:36) -- and with one bank the first sort of every
+// window found both slots "stored in the order about to be overwritten" and moved them to the identity order first: two k_perm_reorder
+// launches (21.6 us each) per window for adjoints nobody reads again.
 int sort_frame(FeEngine* h, int f) {
-    const int id_new = 1 + f, id_old = h->tbl_of_frame[f];
+    if (f <= h->last_sorted_f) h->tbl_bank ^= 1;
+    h->last_sorted_f = f;
+    const int id_new = 1 + f + h->tbl_bank * (h->L + 1), id_old = h->tbl_of_frame[f];
     if (ensure_table(h, id_new)) return 1;
     for (int slot = 0; slot < 2; slot++)            // an adjoint slot still stored in the order about to be overwritten
         if (h->gtbl[slot] == id_new && reorder_grad(h, slot, 0)) return 1;
