@@ -553,3 +553,23 @@ def test_adjoint_crosses_sort_boundaries_inside_p2g_grad(hiplib, oracle64, liqui
     tol_cos, tol_rel = (0.99999, 3e-3) if liquid_only else (0.999, 8e-2)
     for k in ('gx', 'gv', 'gC', 'gF'):
         assert S.cosine(runs['ranged, on'][1][k], gb[k]) >= tol_cos and S.rel_l2(runs['ranged, on'][1][k], gb[k]) <= tol_rel, k
+
+
+@pytest.mark.parametrize('n_grid', [12, 20, 28])
+def test_grid_sizes_with_an_odd_number_of_blocks_per_axis(hiplib, oracle64, n_grid):
+    """n / 4 blocks per axis, odd: the block count (27, 125, 343) is no multiple of the 16 blocks a wave of the sort's cell scan takes
+    (k_sort_blk_partial), nor of the 4 a thread of the block scan does -- the guards at the end of the block range, forward and backward
+    against the fp64 oracle with a sort every 3 substeps."""
+    rng = np.random.RandomState(n_grid)
+    N = 2500
+    sc = dict(S.water_block(n_grid=n_grid, n_particles=N, seed=n_grid, lo=0.15, hi=0.85), v=S.f32(rng.normal(0, 1.0, (N, 3))))
+    g = S.make_engine(hiplib, sc, options={'sort_interval': 3})
+    o = S.make_engine(oracle64, sc)
+    cot = S.random_cotangent(N, seed=2)
+    sa, ga = S.run_forward_backward(g, 8, cot, ranged=True)
+    sb, gb = S.run_forward_backward(o, 8, {k: v.astype(np.float64) for k, v in cot.items()})
+    ws = g.get_work_stats(7)
+    assert ws['n_items'] > 0 and ws['n_active_blocks'] > 0
+    assert np.abs(sa['x'] - sb['x']).max() <= 2e-6 and S.rel_l2(sa['v'], sb['v']) <= 1e-4
+    for k in ('gx', 'gv', 'gC', 'gF'):
+        assert S.cosine(ga[k], gb[k]) >= 0.99999 and S.rel_l2(ga[k], gb[k]) <= 1e-3, (k, S.rel_l2(ga[k], gb[k]))
