@@ -1,3 +1,4 @@
 OUT=gpurun_out/s1; mkdir -p $OUT; export TMPDIR=/tmp
+WIN=${WIN:-30}
 echo "== tests"; timeout 900 python -m pytest tests/test_hip_parity.py tests/test_hip_random_scenes.py -m gpu -x -q 2>&1 | tail -4 | tee $OUT/pytest.txt
-echo "== ab"; timeout 900 python scripts/ab_phases.py --windows 30 --reps 2 "$@" 2>&1 | grep -v amdgpu.ids > $OUT/ab.txt; python scripts/ab_table.py $OUT/ab.txt | tee $OUT/ab_table.txt
+echo "== ab"; timeout 1200 python scripts/ab_phases.py --windows $WIN --reps 2 "$@" 2>&1 | grep -v amdgpu.ids > $OUT/ab.txt; python scripts/ab_table.py $OUT/ab.txt | tee $OUT/ab_table.txt
