@@ -3,8 +3,8 @@
 config 3 -- LatteArt-v0 two-fluid at 128^3 (`quality=2`): the demo pour replayed on the HIP engine and on the fp32 oracle
             (the same scene and actions, the reference's 50-substep window so both see the same injection noise).
 config 5 -- elasto-plastic ICECREAM (PLASTO_ELASTIC, mpm:367-376) with a SmokeField stepping beside it (mpm:745-747, 765-767),
-            256^3 grid, 1M particles, forward + backward: properties at full size, the same composite against the fp64 oracle
-            at 32^3.
+            256^3 grid, 1M particles, forward + backward: at full size against the oracle's fp32 build (one step of 10 substeps) and
+            through properties (linearity, a central difference), the same composite against the fp64 oracle at 32^3.
 """
 import os
 import sys
@@ -115,14 +115,14 @@ def composite_scene(n_grid, n, seed=0):
     return sc
 
 
-def run_composite(elib, sc, res, cot, cot_v, *, n_steps=1, device=0, v0=None, smoke_v0=None, solver_iters=20):
+def run_composite(elib, sc, res, cot, cot_v, *, n_steps=1, device=0, v0=None, smoke_v0=None, solver_iters=20, options=None):
     """ICECREAM block + SmokeField with an AirCon, n_steps steps of (smoke_step, n_substeps substeps); loss = <cot, particle state>
     + <cot_v, smoke velocity> at the end; backward; returns final states and the adjoints at frame 0."""
     ns = sc['n_substeps']
     sc = dict(sc, horizon=n_steps)
     if v0 is not None:
         sc['v'] = v0
-    eng = S.make_engine(elib, sc, max_substeps_local=ns * n_steps, device=device)
+    eng = S.make_engine(elib, sc, max_substeps_local=ns * n_steps, device=device, options=options)
     e = eng.add_effector(type=FE_EFF_AIRCON, action_dim=8, action_scale_v=(1, 1, 1, 1, 1, 1, 40.0, 3.0), action_scale_p=(1,) * 8,
                          boundary=elib.make_boundary(), inject_v=(-0.3, 0.1, 1.0))
     st = eng.eff_get_state(e, 0)
@@ -210,3 +210,31 @@ def test_config5_composite_at_full_size(hiplib):
     # measured 0.4070 / 0.3952 (two runs, difference step 5e-3) vs 0.4112 / 0.4094: the difference of two fp32 sums over a million
     # particles carries ~1 % of noise itself
     assert abs(an) > 0.1 and abs(fd - an) <= 6e-2 * max(abs(fd), abs(an)), (fd, an)
+
+
+def test_config5_composite_matches_the_oracle_at_full_size(hiplib, oracle32):
+    """Config 5 at its size against the oracle ("property-only at size"): 256^3 grid, 1M ICECREAM particles (SVD, plastic
+    clamp, backward_svd), SmokeField at 128^3 with the AirCon, one step of 10 substeps forward and backward on the HIP engine and on the
+    oracle's fp32 build (16 OpenMP threads; its dense grids are 0.9 GB per frame).  dt as in composite_scene (Courant).  State within
+    fp32 rounding; the adjoints through backward_svd with F within 2e-3 of the identity carry the bounds of the 32^3 case."""
+    n, res = 1_000_000, 128
+    sc = composite_scene(256, n, seed=0)
+    cot = S.random_cotangent(n, seed=5)
+    cot_v = np.random.RandomState(7).normal(size=(res, res, res, 3))
+    a = run_composite(hiplib, sc, res, cot, cot_v)
+    b = run_composite(oracle32, sc, res, cot, cot_v, options={'threads': 16})
+    m = {k: (float(np.abs(a['final'][k].astype(np.float64) - b['final'][k]).max()), S.rel_l2(a['final'][k], b['final'][k])) for k in 'xvCF'}
+    g = {k: (S.cosine(a['g'][k], b['g'][k]), S.rel_l2(a['g'][k], b['g'][k])) for k in ('gx', 'gv', 'gC', 'gF')}
+    print('MEASURED config5 at full size vs oracle fp32: state max|d| / relL2', {k: (f'{v[0]:.2e}', f'{v[1]:.2e}') for k, v in m.items()},
+          'adjoints cos / relL2', {k: (f'1-{1 - v[0]:.1e}', f'{v[1]:.2e}') for k, v in g.items()},
+          'smoke v relL2', f"{S.rel_l2(a['smoke']['v'], b['smoke']['v']):.2e}", 'smoke adjoint relL2', f"{S.rel_l2(a['gsv'], b['gsv']):.2e}",
+          'action grad relL2', f"{S.rel_l2(a['action_grad'], b['action_grad']):.2e}")
+    assert (a['final']['used'] == b['final']['used']).all()
+    # measured (profiles/r04_pytest_gpu_measured.txt): x 9e-8, v relL2 6.8e-6, F 6.9e-7; adjoints cos 1 - 1.9e-4, relL2 1.2e-3 ... 1.9e-2 (fp32 on
+    # both sides of backward_svd with sigma within 2e-3 of each other); smoke 1e-7; bounds ~3x that
+    assert m['x'][0] <= 5e-7 and m['v'][1] <= 2e-5 and m['F'][1] <= 2e-6
+    assert S.rel_l2(a['smoke']['v'], b['smoke']['v']) <= 1e-6
+    for k in ('gx', 'gv', 'gC', 'gF'):
+        assert np.isfinite(a['g'][k]).all() and g[k][0] >= 0.9994 and g[k][1] <= (1e-2 if k in ('gx', 'gv') else 6e-2), (k, g[k])
+    assert S.rel_l2(a['gsv'], b['gsv']) <= 1e-6
+    assert S.rel_l2(a['action_grad'], b['action_grad']) <= 2e-5
