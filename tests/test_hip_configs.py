@@ -212,27 +212,31 @@ def test_config5_composite_at_full_size(hiplib):
     assert abs(an) > 0.1 and abs(fd - an) <= 6e-2 * max(abs(fd), abs(an)), (fd, an)
 
 
-def test_config5_composite_matches_the_oracle_at_full_size(hiplib, oracle32):
+@pytest.mark.parametrize('dt,n_sub', [(5e-5, 10), (2e-4, 3)])
+def test_config5_composite_matches_the_oracle_at_full_size(hiplib, oracle32, dt, n_sub):
     """Config 5 at its size against the oracle ("property-only at size"): 256^3 grid, 1M ICECREAM particles (SVD, plastic
     clamp, backward_svd), SmokeField at 128^3 with the AirCon, one step of 10 substeps forward and backward on the HIP engine and on the
-    oracle's fp32 build (16 OpenMP threads; its dense grids are 0.9 GB per frame).  dt as in composite_scene (Courant).  State within
-    fp32 rounding; the adjoints through backward_svd with F within 2e-3 of the identity carry the bounds of the 32^3 case."""
+    oracle's fp32 build (16 OpenMP threads; its dense grids are 0.9 GB per frame).  dt as in composite_scene (Courant), and -- three
+    substeps, before the instability of that Courant number has grown -- at the reference's own dt = 2e-4 (mpm:24): the same kernels
+    either way.  State within fp32 rounding; the adjoints through backward_svd with F within 2e-3 of the identity carry the bounds of
+    the 32^3 case."""
     n, res = 1_000_000, 128
-    sc = composite_scene(256, n, seed=0)
+    sc = dict(composite_scene(256, n, seed=0), dt=dt, n_substeps=n_sub)
     cot = S.random_cotangent(n, seed=5)
     cot_v = np.random.RandomState(7).normal(size=(res, res, res, 3))
     a = run_composite(hiplib, sc, res, cot, cot_v)
     b = run_composite(oracle32, sc, res, cot, cot_v, options={'threads': 16})
     m = {k: (float(np.abs(a['final'][k].astype(np.float64) - b['final'][k]).max()), S.rel_l2(a['final'][k], b['final'][k])) for k in 'xvCF'}
     g = {k: (S.cosine(a['g'][k], b['g'][k]), S.rel_l2(a['g'][k], b['g'][k])) for k in ('gx', 'gv', 'gC', 'gF')}
-    print('MEASURED config5 at full size vs oracle fp32: state max|d| / relL2', {k: (f'{v[0]:.2e}', f'{v[1]:.2e}') for k, v in m.items()},
+    print(f'MEASURED config5 at full size, dt {dt:g} x {n_sub} substeps, vs oracle fp32: state max|d| / relL2', {k: (f'{v[0]:.2e}', f'{v[1]:.2e}') for k, v in m.items()},
           'adjoints cos / relL2', {k: (f'1-{1 - v[0]:.1e}', f'{v[1]:.2e}') for k, v in g.items()},
           'smoke v relL2', f"{S.rel_l2(a['smoke']['v'], b['smoke']['v']):.2e}", 'smoke adjoint relL2', f"{S.rel_l2(a['gsv'], b['gsv']):.2e}",
           'action grad relL2', f"{S.rel_l2(a['action_grad'], b['action_grad']):.2e}")
     assert (a['final']['used'] == b['final']['used']).all()
     # measured (profiles/r04_pytest_gpu_measured.txt): x 9e-8, v relL2 6.8e-6, F 6.9e-7; adjoints cos 1 - 1.9e-4, relL2 1.2e-3 ... 1.9e-2 (fp32 on
     # both sides of backward_svd with sigma within 2e-3 of each other); smoke 1e-7; bounds ~3x that
-    assert m['x'][0] <= 5e-7 and m['v'][1] <= 2e-5 and m['F'][1] <= 2e-6
+    # (at dt = 2e-4, three substeps: x 3.6e-7, v relL2 3.6e-5 -- velocities have grown to 50 m/s by then --, F 3.7e-7, adjoints relL2 1e-4 ... 4.7e-4)
+    assert m['x'][0] <= 1e-6 and m['v'][1] <= 1e-4 and m['F'][1] <= 2e-6
     assert S.rel_l2(a['smoke']['v'], b['smoke']['v']) <= 1e-6
     for k in ('gx', 'gv', 'gC', 'gF'):
         assert np.isfinite(a['g'][k]).all() and g[k][0] >= 0.9994 and g[k][1] <= (1e-2 if k in ('gx', 'gv') else 6e-2), (k, g[k])
