@@ -2615,18 +2615,25 @@ __global__ __launch_bounds__(256) void k_sort_blk_partial(int nblk, int nb, int 
     if ((int)blockIdx.x >= blk_wgs + scan_wgs) {
         const int b = (blockIdx.x - blk_wgs - scan_wgs) * 256 + threadIdx.x;
         bool on = false;
-        if (b < nblk) {
-            const int bi = b / (nb * nb), bj = (b / nb) % nb, bk = b % nb;
+        {   // all 27 counts asked for at once, from clamped (always valid) indices, and masked afterwards: written as `on = on || bcnt[..] > 0 || ...`
+            // every load sat behind a branch on the one before it -- 27 dependent round trips per wave, the 8 us this launch (and round 3's
+            // k_sort_fill) took
+            const bool inb = b < nblk;
+            const int bb = inb ? b : 0;
+            const int bi = bb / (nb * nb), bj = (bb / nb) % nb, bk = bb % nb;
+            int v[27];
+            unsigned okm = 0;                                   // (the masks applied behind ALL the loads: a use right behind its load is a wait right there)
 #pragma unroll
-            for (int di = -1; di <= 1; di++)
+            for (int t = 0; t < 27; t++) {
+                const int i2 = bi + t / 9 - 1, j2 = bj + (t / 3) % 3 - 1, k2 = bk + t % 3 - 1;
+                const bool ok = (unsigned)i2 < (unsigned)nb && (unsigned)j2 < (unsigned)nb && (unsigned)k2 < (unsigned)nb;
+                okm |= (ok ? 1u : 0u) << t;
+                v[t] = bcnt[ok ? (i2 * nb + j2) * nb + k2 : bb];
+            }
+            int any = 0;
 #pragma unroll
-                for (int dj = -1; dj <= 1; dj++) {
-                    const int i2 = bi + di, j2 = bj + dj;
-                    if ((unsigned)i2 < (unsigned)nb && (unsigned)j2 < (unsigned)nb) {
-                        const int row = (i2 * nb + j2) * nb;
-                        on = on || bcnt[row + bk] > 0 || (bk > 0 && bcnt[row + bk - 1] > 0) || (bk + 1 < nb && bcnt[row + bk + 1] > 0);
-                    }
-                }
+            for (int t = 0; t < 27; t++) any |= ((okm >> t) & 1u) ? v[t] : 0;
+            on = inb && any > 0;
         }
         const unsigned long long wm = __ballot(on);
         if (wm) {                                                  // the wave's entries with ONE returning atomic on the list's length
