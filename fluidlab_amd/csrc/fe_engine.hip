@@ -497,8 +497,10 @@ __device__ __forceinline__ Unit unit_load(const TableP& T, int w) {
 // The six substep kernels start at multiples of FE_KALIGN_BYTES in the code object: where a kernel sat relative to the instruction
 // cache's lines and sets used to move with every edit of an UNRELATED kernel in front of it (k_grid: 12.2 <-> 12.6 us from a change
 // in the sort), which made A/B numbers of small changes unreadable.
+// (16 KB: the kernels then only move when the code in front of them grows past a 16 KB boundary.  With 1 KB the last edit of the round -- a sort
+// kernel 1 KB longer -- put k_p2g at ...e400 instead of ...e000 and cost it 0.4 us per launch, k_grid and k_g2p 0.2 each: profiles/r04_ab_kernel_alignment.txt)
 #ifndef FE_KALIGN_BYTES
-#define FE_KALIGN_BYTES 1024
+#define FE_KALIGN_BYTES 16384
 #endif
 #define FE_KALIGN __attribute__((aligned(FE_KALIGN_BYTES)))
 template <typename A> struct Batch { A a[FE_MAX_BATCH]; };
