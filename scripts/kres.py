@@ -47,6 +47,20 @@ def kernel_resources(lib=LIB):
             for n, r in zip(names, rows)}
 
 
+def kernel_addresses(lib=LIB):
+    """{kernel name (demangled, no argument list): (address, size)} of the gfx950 code object bundled into `lib` (where the kernels sit:
+    the substep kernels are aligned in the code object, fe_engine.hip FE_KALIGN)."""
+    with tempfile.TemporaryDirectory() as d:
+        fat, co = os.path.join(d, 'fat.bin'), os.path.join(d, 'code.co')
+        subprocess.check_call([f'{LLVM}/llvm-objcopy', '--dump-section', f'.hip_fatbin={fat}', lib, os.path.join(d, 'x.so')])
+        subprocess.check_call([f'{LLVM}/clang-offload-bundler', '--unbundle', '--type=o', f'--input={fat}', '--targets=hipv4-amdgcn-amd-amdhsa--gfx950', f'--output={co}'])
+        syms = subprocess.run([f'{LLVM}/llvm-readelf', '-s', '-W', co], capture_output=True, text=True, check=True).stdout
+    rows = [l.split() for l in syms.splitlines() if ' FUNC ' in l]
+    rows = [r for r in rows if len(r) >= 8]
+    names = _demangle([r[7] for r in rows])
+    return {n: (int(r[1], 16), int(r[2])) for n, r in zip(names, rows)}
+
+
 def compile_resources(defs):
     cmd = ['/opt/rocm/bin/hipcc'] + FLAGS + ['--cuda-device-only', '-Rpass-analysis=kernel-resource-usage', '-c', '-o', '/dev/null',
                                               os.path.join(ROOT, 'fluidlab_amd', 'csrc', 'fe_engine.hip')] + defs

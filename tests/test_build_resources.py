@@ -40,3 +40,18 @@ def test_substep_kernels_do_not_spill(resources):
 def test_substep_kernels_keep_their_occupancy(resources):
     over = {k: resources[k]['vgpr'] for k, cap in MAX_VGPR.items() if resources[k]['vgpr'] > cap}
     assert not over, f'more registers than the occupancy target allows: {over}'
+
+
+def test_substep_kernels_are_aligned_in_the_code_object():
+    """The six kernels of a substep pair start at multiples of 16 KB (FE_KALIGN, fe_engine.hip): where they sit relative to each other
+    moved their launch times by up to 0.5 us whenever an unrelated kernel in front of them changed size."""
+    import __graft_entry__ as g
+    g.build()
+    spec = importlib.util.spec_from_file_location('kres', os.path.join(ROOT, 'scripts', 'kres.py'))
+    kres = importlib.util.module_from_spec(spec); spec.loader.exec_module(kres)
+    addr = kres.kernel_addresses()
+    hot = ['k_p2g<true, false>', 'k_grid<false, false, false>', 'k_g2p<false>', 'k_g2p_grad2<4>', 'k_grid_grad<false, false>', 'k_p2g_grad<false, 4>']
+    missing = [k for k in hot if k not in addr]
+    assert not missing, missing
+    off = {k: hex(addr[k][0]) for k in hot if addr[k][0] % 16384}
+    assert not off, off
