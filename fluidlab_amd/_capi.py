@@ -69,7 +69,7 @@ ABI_SYMBOLS = [
     'fe_eff_get_vw', 'fe_eff_set_vw', 'fe_eff_get_sr', 'fe_eff_set_sr', 'fe_eff_set_action', 'fe_eff_set_action_grad',
     'fe_eff_apply_action_p', 'fe_eff_apply_action_p_grad', 'fe_eff_get_action_grad',
     'fe_agent_copy_frame', 'fe_agent_copy_grad', 'fe_agent_reset_grad_till_frame', 'fe_agent_set_collector', 'fe_mesh_sdf', 'fe_add_grad_dev', 'fe_loss_alloc', 'fe_loss_set_target',
-    'fe_loss_clear', 'fe_loss_step', 'fe_loss_step_grad', 'fe_loss_get', 'fe_get_stats', 'fe_get_work_stats',
+    'fe_loss_clear', 'fe_loss_step', 'fe_loss_step_grad', 'fe_loss_get', 'fe_get_stats', 'fe_get_work_stats', 'fe_get_work_stats_n',
     'fe_smoke_create', 'fe_smoke_step', 'fe_smoke_step_grad', 'fe_smoke_get_frame', 'fe_smoke_set_frame', 'fe_smoke_get_grad',
     'fe_smoke_add_grad', 'fe_smoke_copy_frame', 'fe_smoke_copy_grad', 'fe_smoke_reset_grad', 'fe_smoke_reset_grad_till_frame',
     'fe_timer_start', 'fe_timer_stop_ms', 'fe_profile_enable', 'fe_profile_read',
@@ -243,7 +243,7 @@ class Engine:
         self._ck(self.lib.fe_set_option(self.h, name.encode(), float(value)))
 
     OPTION_NAMES = ('sort_interval', 'item_max', 'grid_store', 'p2g_grad_waves', 'g2p_grad_v', 'loose_max', 'xcd_map', 'write_through',
-                    'wave_sort', 'fold_reorder', 'quad_min_units', 'quad_max', 'quad_fit', 'pack_units', 'wgrid_cap', 'wgrid_cap_g2p', 'wgrid_cap_pgg', 'ggrid_cap', 'collide_type')
+                    'wave_sort', 'lane_split', 'fold_reorder', 'quad_min_units', 'quad_max', 'quad_fit', 'pack_units', 'wgrid_cap', 'wgrid_cap_g2p', 'wgrid_cap_pgg', 'ggrid_cap', 'collide_type')
 
     def get_option(self, name):
         v = C.c_double(0.0)
@@ -571,7 +571,10 @@ class Engine:
 
     def get_work_stats(self, f):
         out = (C.c_longlong * 24)()
-        self._ck(self.lib.fe_get_work_stats(self.h, int(f), out))
+        if hasattr(self.lib, 'fe_get_work_stats_n'):         # (the counted form: an A/B library of an earlier round writes its own, shorter list)
+            self._ck(self.lib.fe_get_work_stats_n(self.h, int(f), out, 24))
+        else:
+            self._ck(self.lib.fe_get_work_stats(self.h, int(f), out))
         keys = ('n_items', 'tail_start', 'n_active_blocks', 'n_multi_item_workgroups', 'n_single_item_blocks')
         d = {k: int(out[i]) for i, k in enumerate(keys)}
         d['items_by_size'] = {k: int(out[5 + i]) for i, k in enumerate(('1', '2-4', '5-8', '9-16', '17-32', '33-64', '65-128'))}
@@ -582,6 +585,7 @@ class Engine:
         d['n_scatter_units'], d['n_gather_units'] = int(out[16]), int(out[17])     # work units of the two unit lists: the workgroups of a scatter / gather launch that have something to do
         d['packed'] = bool(out[18])                      # the scatter list has no idle halves (engine options pack_units, quad_fit)
         d['n_leftover_items'] = int(out[19]) + int(out[20])
+        d['n_split9_waves'], d['n_split3_waves'] = int(out[21]), int(out[22])      # waves of <= 7 / 8..21 particles: nine / three lanes per particle (engine option lane_split)
         return d
 
     def timer_start(self):

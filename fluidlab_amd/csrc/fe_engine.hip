@@ -141,6 +141,7 @@ struct SimP {
     int ncell;                               // nb^3 * 64: plane stride of the SoA accumulator grids
     int xcd;                                 // option "xcd_map": consecutive work items on the same XCD (shared L2)
     int wsort;                               // option "wave_sort": the scatter kernels regroup their lanes by stencil base before the scan (wave_sort_dest)
+    int lsplit;                              // option "lane_split": waves with at most 21 / 7 particles give every particle 3 / 9 lanes (lane_split)
     int wt;                                  // option "write_through": bulk outputs as sc1 stores (see wt_store16); bit 0 p2g, 1 g2p, 2 g2p_grad, 3 p2g_grad
     float dx, inv_dx, dt, stress_scale;     // stress_scale = -dt * p_vol * 4 * inv_dx^2 (mpm:343)
     int uni; float uinfo[4];                 // every particle has the same material record (mu, lam, mass, class | material): it travels here instead of 16 bytes per particle and kernel
@@ -370,8 +371,16 @@ struct TableP {
 };
 
 struct TileO { int ox, oy, oz; };
-__device__ __forceinline__ TileO tile_origin(int block, int nb) {
-    TileO t; t.ox = (block / (nb * nb)) * 4 - 1; t.oy = ((block / nb) % nb) * 4 - 1; t.oz = (block % nb) * 4 - 1; return t;
+// A work item names its block by its three coordinates, ten bits each (k_sort_blk_final packs them once per sort): the particle kernels used
+// to take the block NUMBER apart again in every unit -- three divisions by the run-time nb for the tile's origin and three more for the
+// 27 neighbour entries, ~60 VALU and ~100 SALU instructions per unit and kernel (scripts/valu_profile.py; a uniform integer division is a
+// v_rcp sequence on this part).
+#define BLK_PACK(bi, bj, bk) (((bi) << 20) | ((bj) << 10) | (bk))
+#define BLK_I(pk) ((pk) >> 20)
+#define BLK_J(pk) (((pk) >> 10) & 1023)
+#define BLK_K(pk) ((pk) & 1023)
+__device__ __forceinline__ TileO tile_origin(int pk) {
+    TileO t; t.ox = BLK_I(pk) * 4 - 1; t.oy = BLK_J(pk) * 4 - 1; t.oz = BLK_K(pk) * 4 - 1; return t;
 }
 // local index of the stencil base inside the tile, or -1 when the 3^3 stencil does not fit
 __device__ __forceinline__ int tile_base(const TileO& t, const Stencil& st) {
@@ -386,7 +395,7 @@ __device__ __forceinline__ bool tile_node(const TileO& t, int l, int n, int& i, 
 
 // What one half of a workgroup (a pair unit) or one wave of it (a quad unit) works on.  Uniform per wave.
 struct PairCtx {
-    int4 it;         // (block, first slot, count <= 128, 0) of this half's / wave's item; count 0 when it idles
+    int4 it;         // (block coordinates (BLK_PACK), first slot, count <= 128, 0) of this half's / wave's item; count 0 when it idles
     int  ti;         // LDS tile: 0, or 1 when the two items of a pair belong to different blocks; the wave's number in a quad
     int  slab;       // slab the tile is handed over in (the item's index; a shared tile goes to the first item's)
     int  nth, t0;    // the threads that load / zero / store this tile: all 256 from t0 = tid when shared, this half's 128, a quad's wave
@@ -398,7 +407,7 @@ struct PairCtx {
 // The kernels used to walk meta -> pairs[w] / singles[q] -> items[i] before they could ask for their particles: three dependent
 // round trips ahead of the first useful load in kernels that are one round of such chains.  Now workgroup w reads units[w] together
 // with meta.  The list is stored in XCD order (slot w holds work unit xcd_item(w): every XCD a contiguous eighth of the items).
-//   PAIR: a = (block, first slot, count, item index | same << 30), b likewise with b.w = -1 when there is no second item;
+//   PAIR: a = (block coordinates (BLK_PACK), first slot, count, item index | same << 30), b likewise with b.w = -1 when there is no second item;
 //         same: both items belong to one block and share tile and slab
 //   QUAD (a.w has QUAD_BIT): a, b, c, d = four items of at most QUAD_MAX particles, each the only item of its block -- one WAVE per
 //         item, four tiles per workgroup.  Where the water has come apart most items are of that kind, and a pair unit keeps two
@@ -549,12 +558,12 @@ __device__ __forceinline__ int stencil_regions(int lb) {
     return ((ax & 1) ? myz : 0) | ((ax & 2) ? myz << 9 : 0) | ((ax & 4) ? myz << 18 : 0);
 }
 // lane n < 27: the active-list entry of neighbour block n of `block` (-1 outside the grid / not on the list)
-__device__ __forceinline__ int neighbour_entry(const int* __restrict__ blk_slot, int nb, int block) {
+__device__ __forceinline__ int neighbour_entry(const int* __restrict__ blk_slot, int nb, int pk) {      // pk: the block's packed coordinates (BLK_PACK)
     int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane));          // (opaque: otherwise the three offsets below are hoisted out of the unit loop and live -- spilled -- across the whole kernel)
     int e = -1;
     if (lane < 27) {
-        const int i2 = block / (nb * nb) + lane / 9 - 1, j2 = (block / nb) % nb + (lane / 3) % 3 - 1, k2 = block % nb + lane % 3 - 1;
+        const int i2 = BLK_I(pk) + lane / 9 - 1, j2 = BLK_J(pk) + (lane / 3) % 3 - 1, k2 = BLK_K(pk) + lane % 3 - 1;
         if ((unsigned)i2 < (unsigned)nb && (unsigned)j2 < (unsigned)nb && (unsigned)k2 < (unsigned)nb) e = blk_slot[(i2 * nb + j2) * nb + k2];
     }
     return e;
@@ -592,7 +601,7 @@ __device__ __forceinline__ int tile_region(int t) { return (t + 3) >> 2; }      
 // Tile node l of a finished scatter tile: the inner 6^3 go to the item's slab; a shell node that received something is added to
 // the slow-path accumulator `acc` (NPL planes of ncell floats) and its block -- active-list entry from the item's 27 neighbour
 // entries, lane r of every wave holds neighbour r -- is marked dirty for the grid kernel.  Called by whole waves (shuffle).
-template <int NPL>
+template <int NPL, bool SHELL_ONLY = false>
 __device__ __forceinline__ void tile_handover(const SimP& S, float4* slab, int item, float* acc, const GridStore& GS, const TileO& to,
                                               int nbr_entry, int l, float4 v, int wt) {
     asm volatile("" : "+v"(l));             // (opaque, as in neighbour_entry: tz and its region are loop invariants otherwise)
@@ -601,13 +610,62 @@ __device__ __forceinline__ void tile_handover(const SimP& S, float4* slab, int i
     // (one condition, not three short-circuited ones: those became nested branches across which the pieces of the slab index were kept
     //  alive as 64-bit values -- and, in k_g2p_grad2, spilled)
     const bool inner = ((unsigned)(tx - 1) < (unsigned)SLAB_T) & ((unsigned)(ty - 1) < (unsigned)SLAB_T) & ((unsigned)(tz - 1) < (unsigned)SLAB_T);
-    if (inner)
-        slab_store<NPL>(slab, item, ((tx - 1) * SLAB_T + (ty - 1)) * SLAB_T + (tz - 1), v, wt);
-    else if (e >= 0 && (v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f)) {
+    if (inner) {
+        if (!SHELL_ONLY) slab_store<NPL>(slab, item, ((tx - 1) * SLAB_T + (ty - 1)) * SLAB_T + (tz - 1), v, wt);
+    } else if (e >= 0 && (v.x != 0.f || v.y != 0.f || v.z != 0.f || v.w != 0.f)) {
         float* dst = acc + cell_addr(to.ox + tx, to.oy + ty, to.oz + tz, S.nb);
         unsafeAtomicAdd(dst, v.x); unsafeAtomicAdd(dst + S.ncell, v.y); unsafeAtomicAdd(dst + 2 * S.ncell, v.z);
         if (NPL > 3) unsafeAtomicAdd(dst + 3 * S.ncell, v.w);
         GS.dirty[e] = GS.stamp;
+    }
+}
+
+#ifndef FE_LEAN_QUADS
+#define FE_LEAN_QUADS 1       // (A/B builds: 0 = a quad unit's wave walks all 512 tile nodes in its hand-over and tile load, as in round 4)
+#endif
+// does the 3^3 stencil with base index lb reach the tile's outer shell (tile index 0 or 7 on some axis: base 0 or 5)?
+__device__ __forceinline__ bool stencil_on_shell(int lb) {
+    const int bx = lb >> 6, by = (lb >> 3) & 7, bz = lb & 7;
+    return (bx == 0) | (bx == 5) | (by == 0) | (by == 5) | (bz == 0) | (bz == 5);
+}
+// A quad unit's wave hands its fixed-point tile over by itself, eight nodes per lane: round 4 walked all 512 nodes through tile_handover
+// (region of the node, cross-lane read of its entry, inner / shell decision: ~52 VALU instructions a node, 416 per wave -- as much as
+// half the 27-node loop, scripts/valu_profile.py) although the shell of a small item is rarely touched at all: only a particle whose
+// base has left its block since the sort reaches it.  Now the inner 6^3 nodes go straight to the slab (216 nodes: four rounds, no
+// decisions), and the walk over the shell only happens in a wave one of whose particles sits on it (`wshell`, wave-uniform).
+// acc: the wave's tile (words); inv_p / inv_m: back to floats (fix_scale), NPL planes.
+template <int NPL>
+__device__ __forceinline__ void quad_handover(const SimP& S, const int* acc, float inv_p, float inv_m, float4* slab, int item, float* accg,
+                                              const GridStore& GS, const TileO& to, int nbr_entry, bool wshell, int wt) {
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));          // (opaque: the node indices below are not to be kept across the unit loop)
+#if !FE_LEAN_QUADS
+    for (int k = 0; k < TILE_N / 64; k++) {                        // (A/B builds: round 4's walk over all 512 nodes)
+        const int l = lane + 64 * k;
+        tile_handover<NPL>(S, slab, item, accg, GS, to, nbr_entry, l, make_float4((float)acc[l] * inv_p, (float)acc[TILE_N + l] * inv_p, (float)acc[2 * TILE_N + l] * inv_p, NPL > 3 ? (float)acc[3 * TILE_N + l] * inv_m : 0.f), wt);
+    }
+    return;
+#endif
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int l6 = lane + 64 * k;                               // node of the slab: (tx, ty, tz) in 0..5 = tile indices 1..6
+        if (k < 3 || l6 < SLAB_N) {
+            const int tx = l6 / 36, r = l6 - 36 * tx, ty = r / 6, tz = r - 6 * ty;
+            const int l = ((tx + 1) * TILE_T + ty + 1) * TILE_T + tz + 1;
+            const float4 v = make_float4((float)acc[l] * inv_p, (float)acc[TILE_N + l] * inv_p, (float)acc[2 * TILE_N + l] * inv_p, NPL > 3 ? (float)acc[3 * TILE_N + l] * inv_m : 0.f);
+            slab_store<NPL>(slab, item, l6, v, wt);
+        }
+    }
+    if (wshell) {
+#pragma unroll 2
+        for (int k = 0; k < TILE_N / 64; k++) {
+            const int l = lane + 64 * k;
+            const int tx = l >> 6, ty = (l >> 3) & 7, tz = l & 7;
+            const bool inner = ((unsigned)(tx - 1) < (unsigned)SLAB_T) & ((unsigned)(ty - 1) < (unsigned)SLAB_T) & ((unsigned)(tz - 1) < (unsigned)SLAB_T);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!inner) v = make_float4((float)acc[l] * inv_p, (float)acc[TILE_N + l] * inv_p, (float)acc[2 * TILE_N + l] * inv_p, NPL > 3 ? (float)acc[3 * TILE_N + l] * inv_m : 0.f);
+            tile_handover<NPL, true>(S, slab, item, accg, GS, to, nbr_entry, l, v, wt);
+        }
     }
 }
 
@@ -672,16 +730,17 @@ __device__ __forceinline__ void p2g_load(const SimP& S, const FrameV& cur, int s
     load_F(cur, s, r.p.F);
     r.info = load_info(S, info_, s);
 }
+// `primary`: this lane is the particle's first one (a split wave has several: lane_split) -- the stores and the error count are its
 template <bool WRITE, bool GENERAL>
-__device__ __forceinline__ void p2g_compute(const SimP& S, const FrameV& nxt, int s, const P2GRaw& r, const GridW& G, P2GPrep& q) {
+__device__ __forceinline__ void p2g_compute(const SimP& S, const FrameV& nxt, int s, const P2GRaw& r, const GridW& G, P2GPrep& q, bool primary = true) {
     const PState& p = r.p;
     const PInfo& info = r.info;
     Constitutive k;
     constitutive_eval_t<GENERAL>(p.C, p.F, S.dt, info.mu, info.lam, info.mass, info.cls, S.stress_scale, k);
-    if (WRITE) store_F_used(nxt, s, k.Fnew, 1);
+    if (WRITE && primary) store_F_used(nxt, s, k.Fnew, 1);
     stencil_make(p.x, S.inv_dx, q.st);
     q.inside = stencil_inside(q.st, S.n);
-    if (!q.inside) atomicAdd(G.err, 1);
+    if (!q.inside && primary) atomicAdd(G.err, 1);
     q.m = info.mass;
     q.affine = k.affine;
     // momentum at the base node, then per-node increments: mom(o) = m v + A (o - fx) dx
@@ -776,12 +835,57 @@ __device__ __forceinline__ FixScale fix_scale(float M) {       // M wave-uniform
     return f;
 }
 
+// -----------------------------------------------------------------------------------------
+// Small waves split their stencils over the idle lanes (round 5; option "lane_split").
+// What a SIMD pays for is the instruction, not the lane: a wave that holds 5 particles issues the same 27-node loop as one that holds
+// 64, and where the water has come apart most waves are of that kind -- in windows 18-35 of the benchmark 40-55 % of the work items hold
+// at most 16 particles, 29 % of the timed region's VALU instructions ran on idle lanes (profiles/r04_pmc_issue_counters.txt).  A wave
+// whose item (its half of the item) has at most 21 particles therefore gives every particle THREE lanes, one per x offset of the
+// stencil: lane L works for particle L % 21 on the nine nodes of plane i = L / 21, all three ask for the particle's state (one address:
+// a broadcast) and run the constitutive model (the same instructions the wave issued anyway), and the node loop is nine nodes long
+// instead of 27.  At most 7 particles: NINE lanes each, one per (i, j) column of three nodes.  The segmented scan is the same (the key
+// carries the group, so lanes of different groups never merge), the sums are the same sums in the same accumulators; stores, slow
+// paths and counters belong to the particle's first lane (`primary`).  Gather loops (k_g2p_grad2's first pass) reduce their partial
+// sums over the particle's lanes with cross-lane reads.
+// -----------------------------------------------------------------------------------------
+#ifndef FE_SPLIT3_MAX
+#define FE_SPLIT3_MAX 21      // (A/B builds: 0 = never split)
+#endif
+#ifndef FE_SPLIT9_MAX
+#define FE_SPLIT9_MAX 7
+#endif
+struct LaneSplit { int G, p, gofs; bool ok, primary; };       // G: 1, 3, 9 (wave-uniform); p: the lane's particle within the wave; gofs: tile offset of its group's nodes
+__device__ __forceinline__ LaneSplit lane_split(int cnt, bool allowed) {      // cnt: particles of this wave (uniform)
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));          // (opaque: p and gofs are not to become loop invariants of the unit loop)
+    LaneSplit ls; ls.G = 1; ls.p = lane; ls.gofs = 0; ls.ok = true; ls.primary = true;
+    if (allowed && cnt > 0 && cnt <= FE_SPLIT3_MAX) {
+        if (cnt <= FE_SPLIT9_MAX) { const int g = lane / 7; ls.G = 9; ls.p = lane - 7 * g; ls.ok = g < 9; ls.primary = g == 0; const int gi = g / 3; ls.gofs = gi * (TILE_T * TILE_T) + (g - 3 * gi) * TILE_T; }
+        else { const int g = lane / 21; ls.G = 3; ls.p = lane - 21 * g; ls.ok = g < 3; ls.primary = g == 0; ls.gofs = g * (TILE_T * TILE_T); }
+    }
+    return ls;
+}
+// a value of every lane of the particle (lanes p, p + P, ...) summed into all of them; P = 21 (G = 3) or 7 (G = 9: first over the three
+// columns of a plane, then over the planes -- six cross-lane reads instead of nine).  All 64 lanes.
+template <int G>
+__device__ __forceinline__ float split_sum(float v, int gofs) {      // gofs: the lane's group as lane_split encodes it
+    if (G == 1) return v;
+    constexpr int P = G == 3 ? 21 : 7;
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));          // (opaque: the source lanes below are not to become invariants of the unit loop, held -- spilled -- across the kernel)
+    const int gi = gofs >> 6, gj = (gofs >> 3) & 7;
+    const int p = lane - P * (G == 3 ? gi : 3 * gi + gj);         // (lane 63 belongs to no particle: whatever it reads is not used)
+    if (G == 3) return __shfl(v, p, 64) + __shfl(v, p + P, 64) + __shfl(v, p + 2 * P, 64);
+    const float t = __shfl(v, p + P * (3 * gi), 64) + __shfl(v, p + P * (3 * gi + 1), 64) + __shfl(v, p + P * (3 * gi + 2), 64);
+    return __shfl(t, p + P * gj, 64) + __shfl(t, p + P * (3 + gj), 64) + __shfl(t, p + P * (6 + gj), 64);
+}
+
 // tile path, executed by ALL lanes of the wave: contributions of lanes with `in_tile` are summed over runs of equal
 // stencil base (seg_scan) and the last lane of each run adds the total into the LDS accumulators: fp64, or -- QUAD, `q` scaled by
-// the caller -- fixed point
-template <bool QUAD>
-__device__ __forceinline__ void p2g_scatter_tile(const SimP& S, P2GPrep& q, bool in_tile, int lb, int aofs) {
-    if (S.wsort) {
+// the caller -- fixed point.  G = 3 / 9: the lane works on the nodes of its group only (lane_split; gofs = their offset in the tile)
+template <bool QUAD, int G>
+__device__ __forceinline__ void p2g_scatter_tile(const SimP& S, P2GPrep& q, bool in_tile, int lb, int aofs, int gofs) {
+    if (G == 1 && S.wsort) {
         int key = in_tile ? lb : 0x3ff;                        // (lanes without a tile particle go to the end: they add nothing)
         if (wave_needs_sort(key)) {
             const int dest = wave_sort_dest(key);
@@ -796,15 +900,20 @@ __device__ __forceinline__ void p2g_scatter_tile(const SimP& S, P2GPrep& q, bool
             in_tile = key != 0x3ff; lb = in_tile ? key : 0;
         }
     }
-    const SegScan sc = seg_setup(in_tile ? lb : (0x40000000 | (int)threadIdx.x));
+    // (G > 1: the key carries the group's offset -- neighbouring lanes of different groups hold the same particle, i.e. the same base)
+    const SegScan sc = seg_setup(in_tile ? lb + (G > 1 ? gofs << 10 : 0) : (0x40000000 | (int)threadIdx.x));
     const bool issue = sc.tail && in_tile;
     const float live = in_tile ? 1.f : 0.f;
     const Stencil& st = q.st;
+    const int gi = gofs >> 6, gj = (gofs >> 3) & 7;            // this lane's x (and y) offset when the wave is split
+    const float wgi = G > 1 ? sel3(gi, st.w[0][0], st.w[1][0], st.w[2][0]) : 0.f, wgj = G == 9 ? sel3(gj, st.w[0][1], st.w[1][1], st.w[2][1]) : 0.f;
+    const int lg = lb + (G > 1 ? gofs : 0);
 #pragma unroll
     for (int ij = 0; ij < 9; ij++) {
         const int i = ij / 3, j = ij - 3 * i;
-        const float wij = live * STW(st, i, 0) * STW(st, j, 1);
-        const float ox = (float)i * S.dx, oy = (float)j * S.dx;
+        if ((G > 1 && i > 0) || (G == 9 && j > 0)) continue;      // (compile time: a split wave's lanes have their x (and y) offset from their group)
+        const float wij = live * (G > 1 ? wgi : STW(st, i, 0)) * (G == 9 ? wgj : STW(st, j, 1));
+        const float ox = (G > 1 ? (float)gi : (float)i) * S.dx, oy = (G == 9 ? (float)gj : (float)j) * S.dx;
         float mij[3];
 #pragma unroll
         for (int a = 0; a < 3; a++) mij[a] = q.mv[a] + q.affine.a[a][0] * ox + q.affine.a[a][1] * oy;
@@ -812,7 +921,7 @@ __device__ __forceinline__ void p2g_scatter_tile(const SimP& S, P2GPrep& q, bool
         for (int kk = 0; kk < 3; kk++) {
             const float weight = wij * st.w[kk][2];
             const float oz = (float)kk * S.dx;
-            const int l = lb + (i * TILE_T + j) * TILE_T + kk;
+            const int l = lg + ((G > 1 ? 0 : i) * TILE_T + (G == 9 ? 0 : j)) * TILE_T + kk;
             float c[4];
 #pragma unroll
             for (int a = 0; a < 3; a++) c[a] = weight * (mij[a] + q.affine.a[a][2] * oz);
@@ -827,6 +936,12 @@ __device__ __forceinline__ void p2g_scatter_tile(const SimP& S, P2GPrep& q, bool
             }
         }
     }
+}
+template <bool QUAD>
+__device__ __forceinline__ void p2g_scatter_tile_split(const SimP& S, P2GPrep& q, bool in_tile, int lb, int aofs, const LaneSplit& ls) {
+    if (ls.G == 1) p2g_scatter_tile<QUAD, 1>(S, q, in_tile, lb, aofs, 0);      // (wave-uniform choice between three loops, no branch per node)
+    else if (ls.G == 3) p2g_scatter_tile<QUAD, 3>(S, q, in_tile, lb, aofs, ls.gofs);
+    else p2g_scatter_tile<QUAD, 9>(S, q, in_tile, lb, aofs, ls.gofs);
 }
 
 // p2g (mpm:331-378) fused with compute_F_tmp + svd, advect_used + process_unused_particles, Injector.act and,
@@ -853,7 +968,7 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
             const PairCtx pc = unit_ctx(un);
             unit_enter(pc.quad, prev_quad);
             const int4 it = pc.it;
-            const TileO to = tile_origin(it.x, S.nb);
+            const TileO to = tile_origin(it.x);
             const int aofs = pc.ti * 4 * TILE_N;                 // (doubles of a pair's tile, words of a quad's)
             TL(S, 1);
             const int nbr_entry = neighbour_entry(T.blk_slot, S.nb, it.x);      // (in flight together with the particle loads)
@@ -861,9 +976,15 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
             else if (pc.live) for (int l = pc.t0; l < 4 * TILE_N; l += pc.nth) s_acc[aofs + l] = 0.0;
             unit_sync(pc.quad);
             FixScale fs_p = {1.f, 1.f}, fs_m = {1.f, 1.f};
+            bool wshell = false;                                 // (quad units) some particle of the wave reaches its tile's outer shell
             {                                                    // one pass: an item is <= 128 particles, one per lane of the half
-                const int i = pc.i, s = it.y + i;
-                const bool has = i < it.z;
+                // (a wave with few particles gives each of them three or nine lanes: lane_split.  Not while a collector takes particles
+                //  out of the frame: that decision has side effects and belongs to one lane)
+                const int wbase = pc.quad ? 0 : (pc.i & 64);         // this wave's first particle within the item
+                const int cnt = __builtin_amdgcn_readfirstlane(min(64, max(0, it.z - wbase)));
+                const LaneSplit ls = lane_split(cnt, S.lsplit != 0 && !(WRITE && act && agent.collector));
+                const int i = wbase + ls.p, s = it.y + i;
+                const bool has = ls.ok && i < it.z;
                 // (`used` is re-read rather than implied by the work list so host edits of a frame cannot desynchronise it)
                 // The state is asked for together with the flag (a slot of an item is valid memory either way): one round trip
                 // where `used` -> state were two.
@@ -878,7 +999,7 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
                 q.inside = false;
                 int lb = -1;
                 if (used) {
-                    p2g_compute<WRITE, GENERAL>(S, nxt, s, raw, G, q);
+                    p2g_compute<WRITE, GENERAL>(S, nxt, s, raw, G, q, ls.primary);
                     if (q.inside) lb = tile_base(to, q.st);
                 } else {
                     q.m = 0.f; q.affine = m3_zero(); q.mv[0] = q.mv[1] = q.mv[2] = 0.f;
@@ -887,11 +1008,12 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
                 }
                 TL(S, 2);
                 const bool in_tile = lb >= 0;
-                if (used && q.inside && !in_tile) { atomicAdd(G.slow, 1); p2g_scatter_global(S, q, G, GS, T.blk_slot); }   // drifted out of the tile (ahead of the tile path, which may pass q on to another lane: wave_sort)
+                if (used && q.inside && !in_tile && ls.primary) { atomicAdd(G.slow, 1); p2g_scatter_global(S, q, G, GS, T.blk_slot); }   // drifted out of the tile (ahead of the tile path, which may pass q on to another lane: wave_sort)
                 // a wave without any particle skips the 27-node scan altogether; the branch is wave-uniform, as the DPP scan requires
                 if (__any(in_tile)) {
                     touch_regions(in_tile ? stencil_regions(lb) : 0, nbr_entry, GS);
                     if (pc.quad) {
+                        wshell = __any(in_tile && stencil_on_shell(lb));
                         float bp = 0.f;
 #pragma unroll
                         for (int a = 0; a < 3; a++) bp = fmaxf(bp, fabsf(q.mv[a]) + 2.f * S.dx * (fabsf(q.affine.a[a][0]) + fabsf(q.affine.a[a][1]) + fabsf(q.affine.a[a][2])));
@@ -902,10 +1024,10 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
                         q.m *= in_tile ? fs_m.s : 1.f;
 #pragma unroll
                         for (int a = 0; a < 3; a++) { q.mv[a] *= sp; q.affine.a[a][0] *= sp; q.affine.a[a][1] *= sp; q.affine.a[a][2] *= sp; }
-                        p2g_scatter_tile<true>(S, q, in_tile, in_tile ? lb : 0, aofs);
-                    } else p2g_scatter_tile<false>(S, q, in_tile, in_tile ? lb : 0, aofs);
+                        p2g_scatter_tile_split<true>(S, q, in_tile, in_tile ? lb : 0, aofs, ls);
+                    } else p2g_scatter_tile_split<false>(S, q, in_tile, in_tile ? lb : 0, aofs, ls);
                 }
-                if (has && !used && !taken && WRITE) unused_particle_fwd(S, cur, nxt, s, T.pid_of_slot[s], pool_idx, agent, inj, f);
+                if (has && !used && !taken && WRITE && ls.primary) unused_particle_fwd(S, cur, nxt, s, T.pid_of_slot[s], pool_idx, agent, inj, f);
             }
             TL(S, 4);
             unit_sync(pc.quad);
@@ -913,20 +1035,7 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
             // hand the tile over: plain coalesced float4 stores into the item's slab.  No atomics, no waiting:
             // k_grid sums, per node, the slabs of the (at most 8) blocks whose tiles reach it, in a fixed order.
             if (pc.quad) {
-                const int* acc = (const int*)s_acc + aofs;
-                if (pc.live) {                                   // one wave, eight nodes per lane: all the tile reads first, then the stores
-#pragma unroll 1
-                    for (int k0 = 0; k0 < TILE_N / 64; k0 += QH) {
-                        float4 v[QH];
-#pragma unroll
-                        for (int k = 0; k < QH; k++) {
-                            const int l = pc.t0 + 64 * (k0 + k);
-                            v[k] = make_float4((float)acc[l] * fs_p.inv, (float)acc[TILE_N + l] * fs_p.inv, (float)acc[2 * TILE_N + l] * fs_p.inv, (float)acc[3 * TILE_N + l] * fs_m.inv);
-                        }
-#pragma unroll
-                        for (int k = 0; k < QH; k++) tile_handover<4>(S, G.slab, pc.slab, G.g_in, GS, to, nbr_entry, pc.t0 + 64 * (k0 + k), v[k], S.wt & 1);
-                    }
-                }
+                if (pc.live) quad_handover<4>(S, (const int*)s_acc + aofs, fs_p.inv, fs_m.inv, G.slab, pc.slab, G.g_in, GS, to, nbr_entry, wshell, S.wt & 1);
             } else if (pc.live) for (int l = pc.t0; l < TILE_N; l += pc.nth)
                 tile_handover<4>(S, G.slab, pc.slab, G.g_in, GS, to, nbr_entry, l,
                                  make_float4((float)s_acc[aofs + l], (float)s_acc[aofs + TILE_N + l], (float)s_acc[aofs + 2 * TILE_N + l], (float)s_acc[aofs + 3 * TILE_N + l]), S.wt & 1);
@@ -1299,7 +1408,7 @@ __device__ __forceinline__ void g2p_body(SimP S, float* fr_cur, float* fr_next, 
         if (un.a.z >= 0) {
             const PairCtx pc = pair_ctx(un);                     // (the gather kernels walk the pairs-only list)
             const int4 it = pc.it;
-            const TileO to = tile_origin(it.x, S.nb);
+            const TileO to = tile_origin(it.x);
             const int i = pc.i;
             const int s0 = it.y + (i < it.z ? i : 0);
             TL(S, 1);
@@ -1541,7 +1650,7 @@ __device__ __forceinline__ void g2p_grad_body(SimP S, float* fr_cur, float* Gn_,
         if (un.a.z >= 0) {
             const PairCtx pc = pair_ctx(un);
             const int4 it = pc.it;
-            const TileO to = tile_origin(it.x, S.nb);
+            const TileO to = tile_origin(it.x);
             const int tofs = pc.ti * 3 * TILE_N;
             // the particle loads go out ahead of the tile load and its barrier (see slot_g2p); an item is one pass of its half
             const int i = tid & (HALF - 1);
@@ -1620,12 +1729,34 @@ __device__ __forceinline__ void g2p_grad_load_tile2(const TileO& to, const SimP&
     }
 }
 
+// A quad unit's wave loads its tile of v_out by itself, eight nodes per lane (~58 VALU instructions a round: region, entry, record address).  When
+// none of its particles sits on the tile's shell -- known before the loads go out: the positions arrive with the neighbour entries -- only the
+// inner 6^3 nodes are ever read, and they take four rounds instead of eight (the shell's words stay whatever they were: the gather pass does
+// not touch them, and the accumulators that take the words over are zeroed as a whole).
+__device__ __forceinline__ void quad_load_vout_inner(const float4* __restrict__ st, int nbr_entry, float* gt) {
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));          // (opaque, as in quad_handover)
+#pragma unroll 1
+    for (int k = 0; k < 4; k++) {
+        const int l6 = lane + 64 * k;
+        const bool ok = l6 < SLAB_N;
+        const int c6 = ok ? l6 : 0;
+        const int x6 = c6 / 36, r = c6 - 36 * x6, y6 = r / 6, z6 = r - 6 * y6;        // slab coordinates 0..5 = tile indices 1..6: block B (0..3) or B + 1 (4, 5)
+        const int e = __shfl(nbr_entry, (x6 >> 2) * 9 + (y6 >> 2) * 3 + (z6 >> 2) + 13, 64);      // (all lanes: region (1 + x6 / 4, ..) = neighbour 13 + ..)
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ok && e >= 0) v = store_vout(st, e, ((x6 & 3) << 4) | ((y6 & 3) << 2) | (z6 & 3));
+        if (ok) { const int l = ((x6 + 1) * TILE_T + y6 + 1) * TILE_T + z6 + 1; gt[l] = v.x; gt[TILE_N + l] = v.y; gt[2 * TILE_N + l] = v.z; }
+    }
+}
+
 // executed by ALL lanes of the wave (`live` = this lane holds a used particle whose stencil fits the tile)
 // QUAD: the wave's own tile -- v_out in `gt`, which the fixed-point accumulators (words, see fix_scale) take over between the passes;
 // returns the factor that turns them back into floats.
-template <int MINW, bool QUAD>
+// G = 3 / 9: a split wave (lane_split) -- this lane works on the nodes of plane i = gi (column (gi, gj)) of its particle's stencil, the gather
+// pass' partial sums are added up over the particle's lanes, the position adjoint is stored by its first lane (`primary`).
+template <int MINW, bool QUAD, int G>
 __device__ __forceinline__ float g2p_grad_particle2(const SimP& S, const FrameV& Gn, const FrameV& Gc, int s, int lb, const Stencil& st,
-                                                    bool live, int tofs, const float* gt) {      // (lb, live: this lane's particle; from pass 2 on the particle it scatters for)
+                                                    bool live, int tofs, const float* gt, int gofs, bool primary) {      // (lb, live: this lane's particle; from pass 2 on the particle it scatters for)
     PState g;                                   // adjoints of x', v', C'
     if (live) load_xvC(Gn, s, g);
     else { g.x[0] = g.x[1] = g.x[2] = g.v[0] = g.v[1] = g.v[2] = 0.f; g.C = m3_zero(); }
@@ -1637,34 +1768,39 @@ __device__ __forceinline__ float g2p_grad_particle2(const SimP& S, const FrameV&
         qx[a] = c4 * g.C.a[a][0]; qy[a] = c4 * g.C.a[a][1]; qz[a] = c4 * g.C.a[a][2];
         qb[a] = (g.v[a] + S.dt * g.x[a]) - (qx[a] * st.fx[0] + qy[a] * st.fx[1] + qz[a] * st.fx[2]);
     }
-    const int l0 = tofs + lb;
-    gt += lb;
+    const int gi = gofs >> 6, gj = (gofs >> 3) & 7;           // a split wave: this lane's x (and y) offset
+    const int l0 = tofs + lb + (G > 1 ? gofs : 0);
+    gt += lb + (G > 1 ? gofs : 0);
     constexpr int UNR_X = MINW >= 4 ? 1 : 3;
+    constexpr int NI = G > 1 ? 1 : 3, NJ = G == 9 ? 1 : 3;
     // MINW = 4: the x offset of the stencil stays a rolled loop of three (nine nodes unrolled inside it, the x weights by register
     // select): the completely unrolled passes need 166 registers, this form fits the 128 of four waves per SIMD
     {   // ---- pass 1: gather.  gfx_d = sum_o dW/df_d (v_o . q_o),  nvw = sum_o W v_o
         const float dwz[3] = {stencil_dw(st, 0, 2), stencil_dw(st, 1, 2), stencil_dw(st, 2, 2)};      // (the x and y ones are one VALU each: made where used)
         float gfx[3] = {0.f, 0.f, 0.f}, nvw[3] = {0.f, 0.f, 0.f};
 #pragma unroll UNR_X
-        for (int i = 0; i < 3; i++) {
-            const float wi = MINW >= 4 ? STW(st, i, 0) : st.w[i][0], dwi = stencil_dw(st, i, 0);
+        for (int ii = 0; ii < NI; ii++) {
+            const int i = G > 1 ? gi : ii;
+            const float wi = (G > 1 || MINW >= 4) ? STW(st, i, 0) : st.w[ii][0], dwi = stencil_dw(st, i, 0);
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
+            for (int jj = 0; jj < NJ; jj++) {
+                const int j = G == 9 ? gj : jj;
+                const float wj = G == 9 ? STW(st, j, 1) : st.w[jj][1];
                 float qij[3];
 #pragma unroll
                 for (int a = 0; a < 3; a++) qij[a] = qb[a] + (float)i * qx[a] + (float)j * qy[a];
                 float T = 0.f, Tz = 0.f, P[3] = {0.f, 0.f, 0.f};
 #pragma unroll
                 for (int kk = 0; kk < 3; kk++) {
-                    const int l = (i * TILE_T + j) * TILE_T + kk;
+                    const int l = ((G > 1 ? 0 : ii) * TILE_T + (G == 9 ? 0 : jj)) * TILE_T + kk;
                     const float v0 = gt[l], v1 = gt[TILE_N + l], v2 = gt[2 * TILE_N + l];
                     const float sdot = v0 * (qij[0] + (float)kk * qz[0]) + v1 * (qij[1] + (float)kk * qz[1]) + v2 * (qij[2] + (float)kk * qz[2]);
                     const float wk = st.w[kk][2];
                     T += wk * sdot; Tz += dwz[kk] * sdot;
                     P[0] += wk * v0; P[1] += wk * v1; P[2] += wk * v2;
                 }
-                const float wiwj = wi * st.w[j][1];
-                gfx[0] += (dwi * st.w[j][1]) * T;
+                const float wiwj = wi * wj;
+                gfx[0] += (dwi * wj) * T;
                 gfx[1] += (wi * stencil_dw(st, j, 1)) * T;
                 gfx[2] += wiwj * Tz;
 #pragma unroll
@@ -1674,11 +1810,18 @@ __device__ __forceinline__ float g2p_grad_particle2(const SimP& S, const FrameV&
                 asm volatile("" : "+v"(gfx[0]), "+v"(gfx[1]), "+v"(gfx[2]), "+v"(nvw[0]), "+v"(nvw[1]), "+v"(nvw[2]));
             }
         }
+        if (G > 1) {                                          // the particle's lanes each hold a part of the sums
+#pragma unroll
+            for (int a = 0; a < 3; a++) {                     // (one value after the other: asked for together, the reads keep a register each)
+                gfx[a] = split_sum<G>(live ? gfx[a] : 0.f, gofs); NODE_FENCE();
+                nvw[a] = split_sum<G>(live ? nvw[a] : 0.f, gofs); NODE_FENCE();
+            }
+        }
         // sum_o W c4 (v_o^T gC)_b = (nvw^T c4 gC)_b enters with dpos_b = o_b - fx_b
         gfx[0] -= nvw[0] * qx[0] + nvw[1] * qx[1] + nvw[2] * qx[2];
         gfx[1] -= nvw[0] * qy[0] + nvw[1] * qy[1] + nvw[2] * qy[2];
         gfx[2] -= nvw[0] * qz[0] + nvw[1] * qz[1] + nvw[2] * qz[2];
-        if (live) pstore(Gc, Gc.A0, s, make_float4(g.x[0] + S.inv_dx * gfx[0], g.x[1] + S.inv_dx * gfx[1], g.x[2] + S.inv_dx * gfx[2], 0.f));
+        if (live && primary) pstore(Gc, Gc.A0, s, make_float4(g.x[0] + S.inv_dx * gfx[0], g.x[1] + S.inv_dx * gfx[1], g.x[2] + S.inv_dx * gfx[2], 0.f));
     }
     NODE_FENCE();
     float inv = 1.f;
@@ -1700,7 +1843,7 @@ __device__ __forceinline__ float g2p_grad_particle2(const SimP& S, const FrameV&
     // ---- pass 2: scatter d v_out(o) += W(o) q(o), summed over runs of equal stencil base before the LDS atomics
     Stencil sw = st;                                         // (the weights of the particle this lane scatters for: another lane's after wave_sort)
     int l0s = l0;
-    if (S.wsort) {
+    if (G == 1 && S.wsort) {
         int key = live ? lb : 0x3ff;
         if (wave_needs_sort(key)) {
             const int dest = wave_sort_dest(key);
@@ -1714,15 +1857,17 @@ __device__ __forceinline__ float g2p_grad_particle2(const SimP& S, const FrameV&
             live = key != 0x3ff; lb = live ? key : 0; l0s = tofs + lb;
         }
     }
-    const SegScan sc = seg_setup(live ? lb : (0x40000000 | (int)threadIdx.x));       // (only now: five registers less across pass 1)
+    const SegScan sc = seg_setup(live ? lb + (G > 1 ? gofs << 10 : 0) : (0x40000000 | (int)threadIdx.x));       // (only now: five registers less across pass 1; a split wave's key carries the group)
     const bool issue = sc.tail && live;
     const float livef = live ? 1.f : 0.f;
 #pragma unroll UNR_X
-    for (int i = 0; i < 3; i++) {
-        const float lwi = livef * (MINW >= 4 ? STW(sw, i, 0) : sw.w[i][0]);
+    for (int ii = 0; ii < NI; ii++) {
+        const int i = G > 1 ? gi : ii;
+        const float lwi = livef * ((G > 1 || MINW >= 4) ? STW(sw, i, 0) : sw.w[ii][0]);
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
-            const float lw = lwi * sw.w[j][1];
+        for (int jj = 0; jj < NJ; jj++) {
+            const int j = G == 9 ? gj : jj;
+            const float lw = lwi * (G == 9 ? STW(sw, j, 1) : sw.w[jj][1]);
             float qij[3];
 #pragma unroll
             for (int a = 0; a < 3; a++) qij[a] = qb[a] + (float)i * qx[a] + (float)j * qy[a];
@@ -1732,7 +1877,7 @@ __device__ __forceinline__ float g2p_grad_particle2(const SimP& S, const FrameV&
                 float c0 = weight * (qij[0] + (float)kk * qz[0]), c1 = weight * (qij[1] + (float)kk * qz[1]), c2 = weight * (qij[2] + (float)kk * qz[2]);
                 seg_scan3(sc, c0, c1, c2);
                 if (issue) {
-                    const int l = l0s + (i * TILE_T + j) * TILE_T + kk;
+                    const int l = l0s + ((G > 1 ? 0 : ii) * TILE_T + (G == 9 ? 0 : jj)) * TILE_T + kk;
                     if (QUAD) {
                         int* acc = (int*)s_acc3;
                         atomicAdd(acc + l, fix_round(c0));                   // ds_add_u32
@@ -1748,6 +1893,13 @@ __device__ __forceinline__ float g2p_grad_particle2(const SimP& S, const FrameV&
         }
     }
     return inv;
+}
+template <int MINW, bool QUAD>
+__device__ __forceinline__ float g2p_grad_particle2_split(const SimP& S, const FrameV& Gn, const FrameV& Gc, int s, int lb, const Stencil& st,
+                                                          bool live, int tofs, const float* gt, const LaneSplit& ls) {
+    if (ls.G == 1) return g2p_grad_particle2<MINW, QUAD, 1>(S, Gn, Gc, s, lb, st, live, tofs, gt, 0, true);      // (wave-uniform)
+    if (ls.G == 3) return g2p_grad_particle2<MINW, QUAD, 3>(S, Gn, Gc, s, lb, st, live, tofs, gt, ls.gofs, ls.primary);
+    return g2p_grad_particle2<MINW, QUAD, 9>(S, Gn, Gc, s, lb, st, live, tofs, gt, ls.gofs, ls.primary);
 }
 template <int MINW>
 __device__ __forceinline__ void g2p_grad2_body(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T,
@@ -1769,22 +1921,36 @@ __device__ __forceinline__ void g2p_grad2_body(SimP S, float* fr_cur, float* Gn_
             const PairCtx pc = unit_ctx(un);
             unit_enter(pc.quad, prev_quad);
             const int4 it = pc.it;
-            const TileO to = tile_origin(it.x, S.nb);
+            const TileO to = tile_origin(it.x);
             const int tofs = pc.ti * 3 * TILE_N;                 // (floats / doubles of a pair's tiles, words of a quad's one)
-            const int i = pc.i;
-            const int s = it.y + (i < it.z ? i : 0);
+            const int wbase = pc.quad ? 0 : (pc.i & 64);         // this wave's first particle within the item; few of them: three or nine lanes each (lane_split)
+            const int cnt = __builtin_amdgcn_readfirstlane(min(64, max(0, it.z - wbase)));
+            const LaneSplit ls = lane_split(cnt, S.lsplit != 0);
+            const int i = wbase + ls.p;
+            const bool has = ls.ok && i < it.z;
+            const int s = it.y + (has ? i : 0);
             const int nbr_entry = neighbour_entry(T.blk_slot, S.nb, it.x);      // (with the particle loads: one hop) tile load + shell hand-over
             const int u0 = cur.used[s];
             const float4 a00 = cur.A0[s];
             // a quad's wave keeps v_out where its accumulators will be (g2p_grad_particle2): four tiles of each do not fit side by side
             float* gt = pc.quad ? (float*)s_acc3 + tofs : s_tile3 + tofs;
-            g2p_grad_load_tile2(to, S, g_out, V.store, nbr_entry, pc, gt);
-            if (!pc.quad && pc.live) for (int l = pc.t0; l < 3 * TILE_N; l += pc.nth) s_acc3[tofs + l] = 0.0;
+            float inv = 1.f;
+            bool wshell = false;                                 // (quad units) some particle of the wave reaches its tile's outer shell
+            if (FE_LEAN_QUADS && pc.quad && V.store) {           // (the positions first: they tell whether the tile's shell is needed at all)
+                // (the stencil bases only, and nothing of it kept: the stencil proper is made behind the loads as before)
+                const bool u_ = has && u0 != 0;
+                const int l0_ = (int)(a00.x * S.inv_dx - 0.5f) - to.ox, l1_ = (int)(a00.y * S.inv_dx - 0.5f) - to.oy, l2_ = (int)(a00.z * S.inv_dx - 0.5f) - to.oz;
+                const bool in_ = u_ && (unsigned)l0_ <= TILE_T - 3 && (unsigned)l1_ <= TILE_T - 3 && (unsigned)l2_ <= TILE_T - 3;
+                wshell = __any(in_ && ((l0_ == 0) | (l0_ == 5) | (l1_ == 0) | (l1_ == 5) | (l2_ == 0) | (l2_ == 5)));
+                if (pc.live) { if (wshell) g2p_grad_load_tile2(to, S, g_out, V.store, nbr_entry, pc, gt); else quad_load_vout_inner(V.store, nbr_entry, gt); }
+            } else {
+                g2p_grad_load_tile2(to, S, g_out, V.store, nbr_entry, pc, gt);
+                if (!pc.quad && pc.live) for (int l = pc.t0; l < 3 * TILE_N; l += pc.nth) s_acc3[tofs + l] = 0.0;
+            }
             unit_sync(pc.quad);
             TL(S, 2);
-            float inv = 1.f;
             {
-                const bool used = i < it.z && u0 != 0;
+                const bool used = has && u0 != 0;
                 float x[3] = {0.f, 0.f, 0.f};
                 if (used) { x[0] = a00.x; x[1] = a00.y; x[2] = a00.z; }
                 Stencil st;
@@ -1792,30 +1958,21 @@ __device__ __forceinline__ void g2p_grad2_body(SimP S, float* fr_cur, float* Gn_
                 const bool inside = used && stencil_inside(st, S.n);
                 const int lb = inside ? tile_base(to, st) : -1;
                 const bool live = lb >= 0;
+                if (pc.quad && !(FE_LEAN_QUADS && V.store)) wshell = __any(live && stencil_on_shell(lb));
                 if (__any(live)) {                               // wave-uniform: empty waves skip the loops
-                    if (pc.quad) inv = g2p_grad_particle2<MINW, true>(S, Gn, Gc, s, live ? lb : 0, st, live, tofs, gt);
-                    else g2p_grad_particle2<MINW, false>(S, Gn, Gc, s, live ? lb : 0, st, live, tofs, gt);
+                    if (pc.quad) inv = g2p_grad_particle2_split<MINW, true>(S, Gn, Gc, s, live ? lb : 0, st, live, tofs, gt, ls);
+                    else g2p_grad_particle2_split<MINW, false>(S, Gn, Gc, s, live ? lb : 0, st, live, tofs, gt, ls);
                 } else if (pc.quad && pc.live) {                 // nothing scattered: the hand-over must not see v_out as sums
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     for (int l = pc.t0; l < 3 * TILE_N; l += pc.nth) ((int*)s_acc3)[tofs + l] = 0;
                 }
-                g2p_grad_wave_slow(S, Gn, Gc, s, a00, inside && !live, used && !inside, V, gg_out, slow, GS);      // (whole waves: wave-uniform loop)
+                g2p_grad_wave_slow(S, Gn, Gc, s, a00, inside && !live && ls.primary, used && !inside && ls.primary, V, gg_out, slow, GS);      // (whole waves: wave-uniform loop; a split wave's particles once each)
             }
             TL(S, 5);
             unit_sync(pc.quad);
             TL(S, 6);
             if (pc.quad) {
-                const int* acc = (const int*)s_acc3 + tofs;
-                if (pc.live) {                                   // (as in k_p2g: the reads of the wave's eight nodes per lane first)
-                    float4 v[TILE_N / 64];
-#pragma unroll
-                    for (int k = 0; k < TILE_N / 64; k++) {
-                        const int l = pc.t0 + 64 * k;
-                        v[k] = make_float4((float)acc[l] * inv, (float)acc[TILE_N + l] * inv, (float)acc[2 * TILE_N + l] * inv, 0.f);
-                    }
-#pragma unroll
-                    for (int k = 0; k < TILE_N / 64; k++) tile_handover<3>(S, slab, pc.slab, gg_out, GS, to, nbr_entry, pc.t0 + 64 * k, v[k], S.wt & 4);
-                }
+                if (pc.live) quad_handover<3>(S, (const int*)s_acc3 + tofs, inv, inv, slab, pc.slab, gg_out, GS, to, nbr_entry, wshell, S.wt & 4);      // (as in k_p2g)
             } else if (pc.live) for (int l = pc.t0; l < TILE_N; l += pc.nth)
                 tile_handover<3>(S, slab, pc.slab, gg_out, GS, to, nbr_entry, l,
                                  make_float4((float)s_acc3[tofs + l], (float)s_acc3[tofs + TILE_N + l], (float)s_acc3[tofs + 2 * TILE_N + l], 0.f), S.wt & 4);
@@ -2148,10 +2305,13 @@ template <> __device__ __forceinline__ float* Stash<true>::at() { return s_stash
 template <> __device__ __forceinline__ float* Stash<false>::at() { return s_stash_l; }
 // NOSTASH (a quad unit's wave, whose tile `tl` lies where the pair units keep their stash): C and F are read from the frame again behind
 // the loop -- 72 bytes per particle that the wave's own loads left in the L2 a few microseconds earlier
-template <bool TILE, bool GENERAL, bool PRE = false, bool NOSTASH = false>
+// G = 3 / 9 (tile path of the SVD-free build): a split wave (lane_split) -- this lane gathers the nodes of plane gi (column (gi, gj)) of its
+// particle's stencil, the fifteen sums are added up over the particle's lanes, the adjoint is stored by its first lane (`primary`).
+template <bool TILE, bool GENERAL, bool PRE = false, bool NOSTASH = false, int G = 1>
 __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const FrameV& cur, const FrameV& Gn, const FrameV& Gc, int s,
                                                        const float4* __restrict__ info_, const TileO& to,
-                                                       const float4* __restrict__ gg_in, int* slow, int tofs, const P2GRaw& pre, const GradDst& D, const float* tl = nullptr) {
+                                                       const float4* __restrict__ gg_in, int* slow, int tofs, const P2GRaw& pre, const GradDst& D, const float* tl = nullptr,
+                                                       int gofs = 0, bool primary = true) {
     PState p;
     PInfo info;
     if (PRE) { p = pre.p; info = pre.info; }                  // (asked for ahead of the tile load and its barrier: p2g_grad_body)
@@ -2163,8 +2323,12 @@ __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const Fram
     const bool inside = stencil_inside(st, S.n);
     const int lb = (TILE && inside) ? tile_base(to, st) : -1;
     if (TILE && inside && lb < 0) {            // drifted out of the tile: redo on the global path
+        if (!primary) return;                  // (a split wave: once per particle)
         atomicAdd(slow, 1);
-        used_particle_p2g_grad<false, GENERAL, false>(S, cur, Gn, Gc, s, info_, to, gg_in, slow, 0, pre, D);
+        // (NOSTASH travels along: a quad unit's wave has no stash column -- two of the quad's tiles lie where the pair units keep theirs
+        //  (p2g_grad_body), and a drifted particle that parked C and F there overwrote gathered nodes the other lanes were still reading.
+        //  ADVICE r4; tests/test_hip_parity.py::test_quad_units_with_drifted_particles_in_p2g_grad)
+        used_particle_p2g_grad<false, GENERAL, false, NOSTASH>(S, cur, Gn, Gc, s, info_, to, gg_in, slow, 0, pre, D);
         return;
     }
     float* stash = Stash<GENERAL>::at();
@@ -2193,9 +2357,13 @@ __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const Fram
         //   o_1 = j constant over the inner k loop (per-(i,j) partial sums T, Tz);
         //   sum W dx (A^T gin)_b = dx (A^T Gv)_b leaves the loop altogether.
         m3 M = m3_zero();
+        const int gi = gofs >> 6, gj = (gofs >> 3) & 7;          // a split wave: this lane's x (and y) offset
+        const int lg = lb + (G > 1 ? gofs : 0);
 #pragma unroll
         for (int ij = 0; ij < 9; ij++) {
-            const int i = ij / 3, j = ij - 3 * i;
+            const int ic = ij / 3, jc = ij - 3 * ic;
+            if ((G > 1 && ic > 0) || (G == 9 && jc > 0)) continue;      // (compile time)
+            const int i = G > 1 ? gi : ic, j = G == 9 ? gj : jc;
             const float wi = STW(st, i, 0), wj = STW(st, j, 1);
             const float wiwj = wi * wj, dwiwj = stencil_dw(st, i, 0) * wj, widwj = wi * stencil_dw(st, j, 1);
             const float ox = (float)i * S.dx, oy = (float)j * S.dx;
@@ -2207,10 +2375,10 @@ __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const Fram
             for (int kk = 0; kk < 3; kk++) {
                 float gin[3], gm;
                 if (TILE && NOSTASH) {
-                    const int l = lb + (i * TILE_T + j) * TILE_T + kk;
+                    const int l = lg + ((G > 1 ? 0 : ic) * TILE_T + (G == 9 ? 0 : jc)) * TILE_T + kk;
                     gin[0] = tl[l]; gin[1] = tl[TILE_N + l]; gin[2] = tl[2 * TILE_N + l]; gm = tl[3 * TILE_N + l];
                 } else if (TILE) {
-                    const int l = tofs + lb + (i * TILE_T + j) * TILE_T + kk;
+                    const int l = tofs + lg + ((G > 1 ? 0 : ic) * TILE_T + (G == 9 ? 0 : jc)) * TILE_T + kk;
                     gin[0] = s_tile[l]; gin[1] = s_tile[TILE_N + l]; gin[2] = s_tile[2 * TILE_N + l]; gm = s_tile[3 * TILE_N + l];
                 } else {
                     float4 gi = gg_in[cell_addr(st.base[0] + i, st.base[1] + j, st.base[2] + kk, S.nb)];
@@ -2236,6 +2404,15 @@ __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const Fram
             for (int a = 0; a < 3; a++) {
                 Gv[a] += T[a];
                 M.a[a][0] += (float)i * T[a]; M.a[a][1] += (float)j * T[a]; M.a[a][2] += Tz[a];
+            }
+        }
+        if (G > 1) {                                           // the particle's lanes each hold a part of the fifteen sums
+#pragma unroll
+            for (int a = 0; a < 3; a++) {                      // (one value after the other: asked for together, the cross-lane reads keep a register each)
+                Gv[a] = split_sum<G>(Gv[a], gofs); NODE_FENCE();
+                gfx[a] = split_sum<G>(gfx[a], gofs); NODE_FENCE();
+#pragma unroll
+                for (int b = 0; b < 3; b++) { M.a[a][b] = split_sum<G>(M.a[a][b], gofs); NODE_FENCE(); }
             }
         }
 #pragma unroll
@@ -2277,17 +2454,20 @@ __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const Fram
     float gvv[3] = {info.mass * Gv[0], info.mass * Gv[1], info.mass * Gv[2]};
     m3 gC, gF;
     constitutive_grad_t<GENERAL>(p.C, p.F, S.dt, info.mu, info.lam, info.mass, info.cls, S.stress_scale, k, GA, Fg2, gC, gF);
+    if (G > 1 && !primary) return;              // (a split wave: the particle's first lane stores)
     store_xvC(D.G, sd, gx, gvv, gC);
     store_F(D.G, sd, gF);
 }
 
-template <bool TILE, bool GENERAL, bool PRE = false, bool NOSTASH = false>
+template <bool TILE, bool GENERAL, bool PRE = false, bool NOSTASH = false, int G = 1>
 __device__ __forceinline__ void slot_p2g_grad(const SimP& S, const FrameV& cur, const FrameV& Gn, const FrameV& Gc, int s, const TableP& T,
                                               const int* __restrict__ pool_idx,
                                               const TileO& to, const float4* __restrict__ gg_in, int* slow, const AgentP& agent,
-                                              const InjectP& inj, int f, int tofs, int used, const P2GRaw& pre, const GradDst& D, const float* tl = nullptr) {
+                                              const InjectP& inj, int f, int tofs, int used, const P2GRaw& pre, const GradDst& D, const float* tl = nullptr,
+                                              int gofs = 0, bool primary = true) {
     if (!PRE) used = cur.used[s];
-    if (used) { used_particle_p2g_grad<TILE, GENERAL, PRE, NOSTASH>(S, cur, Gn, Gc, s, T.info, to, gg_in, slow, tofs, pre, D, tl); return; }
+    if (used) { used_particle_p2g_grad<TILE, GENERAL, PRE, NOSTASH, G>(S, cur, Gn, Gc, s, T.info, to, gg_in, slow, tofs, pre, D, tl, gofs, primary); return; }
+    if (G > 1 && !primary) return;              // (a split wave: once per particle)
     // the copy f -> f+1 of an unused particle passes its adjoint straight through (mpm:551)
     PState g; load_xvC(Gn, s, g); load_F(Gn, s, g.F);
     const int sd = D.slot(s);
@@ -2343,7 +2523,7 @@ __device__ __forceinline__ void p2g_grad_body(SimP S, float* fr_cur, float* Gn_,
             const PairCtx pc = unit_ctx(un);
             unit_enter(true, prev_quad);
             const int4 it = pc.it;
-            const TileO to = tile_origin(it.x, S.nb);
+            const TileO to = tile_origin(it.x);
             float* tl = pc.ti < 2 ? s_tile + pc.ti * 4 * TILE_N : s_stash_l + (pc.ti - 2) * 4 * TILE_N;
             if (pc.live) {
                 for (int l = pc.t0; l < TILE_N; l += 64) {
@@ -2355,7 +2535,15 @@ __device__ __forceinline__ void p2g_grad_body(SimP S, float* fr_cur, float* Gn_,
             }
             unit_sync(true);
             P2GRaw no_pre;
-            if (pc.i < it.z) slot_p2g_grad<true, GENERAL, false, true>(S, cur, Gn, Gc, it.y + pc.i, T, pool_idx, to, gg_in, slow, agent, inj, f, 0, 0, no_pre, D, tl);
+            {   // (a wave with few particles gives each of them three or nine lanes: lane_split)
+                const LaneSplit ls = lane_split(__builtin_amdgcn_readfirstlane(min(64, it.z)), S.lsplit != 0);
+                const int i = ls.p;
+                if (ls.ok && i < it.z) {
+                    if (ls.G == 1) slot_p2g_grad<true, GENERAL, false, true, 1>(S, cur, Gn, Gc, it.y + i, T, pool_idx, to, gg_in, slow, agent, inj, f, 0, 0, no_pre, D, tl);
+                    else if (ls.G == 3) slot_p2g_grad<true, GENERAL, false, true, 3>(S, cur, Gn, Gc, it.y + i, T, pool_idx, to, gg_in, slow, agent, inj, f, 0, 0, no_pre, D, tl, ls.gofs, ls.primary);
+                    else slot_p2g_grad<true, GENERAL, false, true, 9>(S, cur, Gn, Gc, it.y + i, T, pool_idx, to, gg_in, slow, agent, inj, f, 0, 0, no_pre, D, tl, ls.gofs, ls.primary);
+                }
+            }
             unit_sync(true);
             continue;
         }
@@ -2363,20 +2551,31 @@ __device__ __forceinline__ void p2g_grad_body(SimP S, float* fr_cur, float* Gn_,
             const PairCtx pc = QLIST ? unit_ctx(un) : pair_ctx(un);       // (a pair unit either way)
             if (QLIST) unit_enter(false, prev_quad);
             const int4 it = pc.it;
-            const TileO to = tile_origin(it.x, S.nb);
+            const TileO to = tile_origin(it.x);
             TL(S, 1);
             load_tile4(to, S, gg_in, pc);
             __syncthreads();
             TL(S, 2);
             // (asking for the particle's state ahead of the tile load and its barrier -- the PRE form of slot_p2g_grad -- was measured:
             // falling 15.8 -> 16.4 us, layer 20.5 -> 21.1, splash 30.0 -> 29.7; the same move pays in k_p2g, where nothing precedes it)
-            const int i = pc.i;
             P2GRaw no_pre;
-            if (i < it.z) slot_p2g_grad<true, GENERAL, false>(S, cur, Gn, Gc, it.y + i, T, pool_idx, to, gg_in, slow, agent, inj, f, pc.ti * 4 * TILE_N, 0, no_pre, D);
+            {   // (a wave with few particles gives each of them three or nine lanes: lane_split; the SVD build keeps one lane per particle)
+                const int wbase = pc.i & 64;                     // this wave's first particle within the item
+                const LaneSplit ls = lane_split(__builtin_amdgcn_readfirstlane(min(64, max(0, it.z - wbase))), !GENERAL && S.lsplit != 0);
+                const int i = wbase + ls.p, tofs = pc.ti * 4 * TILE_N;
+                if (ls.ok && i < it.z) {
+                    if (GENERAL || ls.G == 1) slot_p2g_grad<true, GENERAL, false, false, 1>(S, cur, Gn, Gc, it.y + i, T, pool_idx, to, gg_in, slow, agent, inj, f, tofs, 0, no_pre, D);
+                    else if (ls.G == 3) slot_p2g_grad<true, GENERAL, false, false, 3>(S, cur, Gn, Gc, it.y + i, T, pool_idx, to, gg_in, slow, agent, inj, f, tofs, 0, no_pre, D, nullptr, ls.gofs, ls.primary);
+                    else slot_p2g_grad<true, GENERAL, false, false, 9>(S, cur, Gn, Gc, it.y + i, T, pool_idx, to, gg_in, slow, agent, inj, f, tofs, 0, no_pre, D, nullptr, ls.gofs, ls.primary);
+                }
+            }
             TL(S, 3);
             __syncthreads();
             TL(S, 4);
         } else {
+            // a tail unit of THIS kernel does use LDS -- every used particle parks C and F in its stash column --, and two of a quad unit's tiles
+            // lie in the stash: behind a quad unit the workgroup meets at a barrier first, as before a pair unit
+            if (QLIST) unit_enter(false, prev_quad);
             const int s = un.a.y + tid;
             TileO none = {0, 0, 0};
             P2GRaw none_pre;
@@ -2679,7 +2878,7 @@ __global__ __launch_bounds__(256) void k_sort_blk_partial(int nblk, int nb, int 
 }
 // (one launch in which every workgroup goes over the whole array again instead of reading partial sums was tried: the six sums need
 // a division per block, 35 us for the launch against 18 for these two)
-__global__ __launch_bounds__(256) void k_sort_blk_final(int nblk, int ncell, int ITEM_MAX, int loose_max, int quad_max, const int* __restrict__ bcnt, int* cnt, int* start,
+__global__ __launch_bounds__(256) void k_sort_blk_final(int nblk, int nb, int ncell, int ITEM_MAX, int loose_max, int quad_max, const int* __restrict__ bcnt, int* cnt, int* start,
                                                         const int* __restrict__ partial, int4* items, int2* pairs, int* singles, int2* blk_first, int* blk_base, const int* __restrict__ nact, int* meta) {
     __shared__ int sh[4][NSUM];
     const int tid = threadIdx.x;
@@ -2723,7 +2922,8 @@ __global__ __launch_bounds__(256) void k_sort_blk_final(int nblk, int ncell, int
         if (w.single) { if (small) singles[p_ts++] = bi; else singles[p_tb++] = bi; }
         if (w.left) { if (small) singles[p_ls++] = bi + w.k - 1; else singles[p_lb++] = bi + w.k - 1; }
         for (int j = 0; j < w.full; j++) pairs[bm++] = make_int2(bi + 2 * j, bi + 2 * j + 1);
-        for (int o = 0; o < nn; o += ITEM_MAX) items[bi++] = make_int4(b, D + o, min(ITEM_MAX, nn - o), 0);
+        const int pk = BLK_PACK(b / (nb * nb), (b / nb) % nb, b % nb);       // (the block's coordinates: tile_origin, neighbour_entry)
+        for (int o = 0; o < nn; o += ITEM_MAX) items[bi++] = make_int4(pk, D + o, min(ITEM_MAX, nn - o), 0);
         D += nn;
     }
     *(int4*)(blk_base + b0) = make_int4(base[0], base[1], base[2], base[3]);        // (padded like bcnt)
@@ -3525,7 +3725,7 @@ int sort_frame(FeEngine* h, int f) {
     const int blk_wgs = (nblk + 1 + SORT_BLK_WG - 1) / SORT_BLK_WG, scan_wgs = (nblk + 63) / 64, act_wgs = (nblk + 255) / 256;
     hipLaunchKernelGGL(k_sort_blk_partial, dim3(blk_wgs + scan_wgs + act_wgs), dim3(256), 0, h->stream, nblk, h->nb, h->item_max, h->loose_max, quad_max(h), h->sort_bcnt, h->sort_partial,
                        blk_wgs, scan_wgs, h->sort_cnt, h->sort_start, h->sort_nact, tn.active, tn.blk_slot);
-    hipLaunchKernelGGL(k_sort_blk_final, dim3(blk_wgs), dim3(256), 0, h->stream, nblk, ncell, h->item_max, h->loose_max, quad_max(h), h->sort_bcnt, h->sort_cnt, h->sort_start, h->sort_partial,
+    hipLaunchKernelGGL(k_sort_blk_final, dim3(blk_wgs), dim3(256), 0, h->stream, nblk, h->nb, ncell, h->item_max, h->loose_max, quad_max(h), h->sort_bcnt, h->sort_cnt, h->sort_start, h->sort_partial,
                        tn.items, tn.pairs, tn.singles, tn.blk_first, h->sort_base, h->sort_nact, tn.meta);
     if (fine) { prof_end(h); prof_begin(h, KID_SORT_PERM); }
     // re-sorting a frame that is already in this table's order reads the id table it rewrites: stage it
@@ -3893,6 +4093,7 @@ int fe_real_size(void) { return 4; }
 FeEngine* fe_create(const FeConfig* cfg) {
     if (!cfg || cfg->struct_size != (int)sizeof(FeConfig)) { g_create_err = "FeConfig size mismatch"; return nullptr; }
     if (cfg->n_particles > 40000000) { g_create_err = "n_particles > 40M: a frame no longer fits 32-bit plane offsets"; return nullptr; }
+    if (cfg->n_grid > 4092) { g_create_err = "n_grid > 4092: a work item names its block by three 10-bit coordinates"; return nullptr; }
     if (cfg->n_grid < 4 || cfg->n_grid % 4 != 0 || cfg->n_particles < 0 || cfg->max_substeps_local < 1 || cfg->n_substeps < 1) {
         g_create_err = "invalid FeConfig (n_grid must be a multiple of 4)"; return nullptr;
     }
@@ -3903,6 +4104,7 @@ FeEngine* fe_create(const FeConfig* cfg) {
     if (const char* e = std::getenv("FE_SORT_INTERVAL")) h->sort_interval = std::atoi(e);     // tuning experiments (the option of the same name wins)
     if (const char* e = std::getenv("FE_QUAD_MIN_UNITS")) h->quad_min_units = std::atoi(e);   // (task-level A/B of the quad units: scripts/run_envs.py)
     if (const char* e = std::getenv("FE_G2P_GRAD_V")) h->g2p_grad_v = std::atoi(e);           // (the parity suite is run once per build of the G2P adjoint)
+    const char* env_lsplit = std::getenv("FE_LANE_SPLIT");                                    // (the parity suite with and without lane_split)
     h->cfg = *cfg; h->N = cfg->n_particles; h->L = cfg->max_substeps_local; h->n = cfg->n_grid; h->nb = cfg->n_grid / 4;
     h->Np = ((h->N + 63) / 64) * 64; if (h->Np == 0) h->Np = 64;
     h->device = cfg->device;
@@ -3922,6 +4124,7 @@ FeEngine* fe_create(const FeConfig* cfg) {
     S.xcd = 16;                                            // blocked-cyclic unit mapping (A/B in DESIGN.md section 6)
     S.uni = 0;
     S.wsort = 1;                                           // lanes regrouped by stencil base before the scan (A/B in DESIGN.md section 6)
+    S.lsplit = env_lsplit ? (std::atoi(env_lsplit) != 0) : 1;      // small waves give every particle three or nine lanes (lane_split)
     S.wt = 5;                                              // p2g and g2p_grad: their bulk stores come early (A/B in DESIGN.md section 6)
     S.N = h->N; S.Np = h->Np; S.n = h->n; S.nb = h->nb; S.ncell = h->nb * h->nb * h->nb * 64;
     S.dx = 1.0f / (float)h->n; S.inv_dx = (float)h->n; S.dt = cfg->dt;
@@ -4041,6 +4244,7 @@ int fe_set_option(FeEngine* h, const char* name, double value) {
     if (!std::strcmp(name, "xcd_map")) { if (value < 0 || value > 64) FAIL(h, "xcd_map must be 0 (none), 1 (contiguous eighths) or a run length 2..64"); h->S.xcd = (int)value; return 0; }
     if (!std::strcmp(name, "write_through")) { h->S.wt = (int)value; return 0; }
     if (!std::strcmp(name, "wave_sort")) { h->S.wsort = value != 0; return 0; }
+    if (!std::strcmp(name, "lane_split")) { h->S.lsplit = value != 0; return 0; }
     if (!std::strcmp(name, "fold_reorder")) { h->fold_reorder = value != 0; return 0; }
     if (!std::strcmp(name, "quad_min_units")) { h->quad_min_units = (int)value; return 0; }
     if (!std::strcmp(name, "pack_units")) { if (value < 0 || value > 2) FAIL(h, "pack_units must be 0, 1 or 2"); h->pack_units = (int)value; return 0; }
@@ -4061,7 +4265,7 @@ int fe_get_option(FeEngine* h, const char* name, double* value) {
         {"sort_interval", (double)h->sort_interval}, {"item_max", (double)h->item_max}, {"grid_store", h->gs_cap > 0 ? 1.0 : 0.0},
         {"p2g_grad_waves", (double)h->p2g_grad_waves}, {"g2p_grad_v", (double)h->g2p_grad_v}, {"loose_max", (double)h->loose_max},
         {"inject_till", (double)h->inject_till}, {"collide_min_y", (double)h->collide_min_y}, {"collide_type", (double)h->collide_type},
-        {"prof_fine", h->prof_fine ? 1.0 : 0.0}, {"xcd_map", (double)h->S.xcd}, {"write_through", (double)h->S.wt}, {"wave_sort", (double)h->S.wsort}, {"fold_reorder", h->fold_reorder ? 1.0 : 0.0},
+        {"prof_fine", h->prof_fine ? 1.0 : 0.0}, {"xcd_map", (double)h->S.xcd}, {"write_through", (double)h->S.wt}, {"wave_sort", (double)h->S.wsort}, {"lane_split", (double)h->S.lsplit}, {"fold_reorder", h->fold_reorder ? 1.0 : 0.0},
         {"quad_min_units", (double)h->quad_min_units}, {"quad_max", (double)h->quad}, {"quad_fit", (double)h->quad_fit}, {"pack_units", (double)h->pack_units},
         {"wgrid_cap", (double)h->wgrid_cap}, {"wgrid_cap_g2p", (double)h->wgrid_cap_g2p}, {"wgrid_cap_pgg", (double)h->wgrid_cap_pgg}, {"ggrid_cap", (double)h->ggrid_cap}, {"threads", 0.0}};
     for (const auto& t : tab) if (!std::strcmp(name, t.n)) { *value = t.v; return 0; }
@@ -4630,9 +4834,13 @@ int fe_get_stats(FeEngine* h, int f, FeStats* out) {
     out->n_slow_path = slow; out->bytes_state = (long long)h->bytes;
     return check_async(h);
 }
-int fe_get_work_stats(FeEngine* h, int f, long long out[24]) {
+int fe_get_work_stats(FeEngine* h, int f, long long out[FE_WORK_STATS]) { return fe_get_work_stats_n(h, f, out, FE_WORK_STATS); }
+int fe_get_work_stats_n(FeEngine* h, int f, long long* out_, int n_out) {
     FE_ENTRY(h);
     CHECK_FRAME(h, f);
+    if (!out_ || n_out < 0) FAIL(h, "fe_get_work_stats_n: bad output buffer");
+    long long out[FE_WORK_STATS];
+    struct Copy { long long* src; long long* dst; int n; ~Copy() { for (int i = 0; i < n && i < FE_WORK_STATS; i++) dst[i] = src[i]; } } copy_out{out, out_, n_out};
     for (int i = 0; i < 24; i++) out[i] = 0;
     const int t = h->tbl_of_frame[f];
     if (t < 0 || t >= (int)h->tables.size() || !h->tables[t].meta) return 0;
@@ -4655,6 +4863,9 @@ int fe_get_work_stats(FeEngine* h, int f, long long out[24]) {
         const int b = c <= 1 ? 0 : c <= 4 ? 1 : c <= 8 ? 2 : c <= 16 ? 3 : c <= 32 ? 4 : c <= 64 ? 5 : 6;
         out[5 + b]++;
         if (it.x != last_block) { out[12]++; last_block = it.x; }
+        if (h->S.lsplit) {                                    // the item's waves (64 particles each) that split their stencils over idle lanes (lane_split)
+            for (int w0 = 0; w0 < c; w0 += 64) { const int cnt = std::min(64, c - w0); if (cnt <= FE_SPLIT9_MAX) out[21]++; else if (cnt <= FE_SPLIT3_MAX) out[22]++; }
+        }
     }
     return check_async(h);
 }

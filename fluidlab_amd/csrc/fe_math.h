@@ -580,6 +580,35 @@ struct Constitutive {
     bool  full;       // SVD was needed (mu != 0 or a non-liquid class)
 };
 
+// J^(1/3) of the liquid's F update (mpm:359: ti.pow(J, 1/3), NaN for J < 0) and J^(-2/3) of its adjoint.  powf() is ~130 VALU
+// instructions of special-casing per call on gfx950 -- 7 % of what a wave of k_p2g issues per unit, 10 % of k_p2g_grad's
+// (scripts/valu_profile.py) -- for an argument that is within a few per cent of 1 in any state worth simulating.  In fp32 the root
+// comes from the hardware's log2 / exp2 (v_log_f32, v_exp_f32: ~1e-6 relative together) and ONE Newton step on c^3 = J, which squares
+// that error: the result is within an ulp of the correctly rounded root (tests/csrc/math_test.cpp checks the same code against pow in
+// fp64 on the host).  log2 of a negative J is NaN and stays NaN, J = 0 gives 0, like pow.  fp64 (host checks) keeps pow.
+FE_HD real fe_cbrt_pos(real J) {
+    if (sizeof(real) == 8) return pow(J, R_(1.0) / R_(3.0));
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float c0 = __builtin_amdgcn_exp2f(__builtin_amdgcn_logf((float)J) * (1.f / 3.f));
+    const float c2 = c0 * c0;
+    const float c1 = c0 - __builtin_fmaf(c2, c0, -(float)J) * __builtin_amdgcn_rcpf(3.f * c2);
+#else
+    const float c0 = exp2f(log2f((float)J) * (1.f / 3.f));
+    const float c2 = c0 * c0;
+    const float c1 = c0 - fmaf(c2, c0, -(float)J) / (3.f * c2);
+#endif
+    return (real)((float)J == 0.f ? 0.f : c1);
+}
+// J^(-2/3) = J^(1/3) / J
+FE_HD real fe_pow_m23(real J) {
+    if (sizeof(real) == 8) return pow(J, R_(1.0) / R_(3.0) - R_(1.0));
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (real)((float)fe_cbrt_pos(J) * __builtin_amdgcn_rcpf((float)J));
+#else
+    return fe_cbrt_pos(J) / J;
+#endif
+}
+
 // `scale` = -dt * p_vol * 4 * inv_dx^2 (mpm:343).  GENERAL=false is the specialisation the engine launches when
 // every particle of the scene is an inviscid liquid: the SVD path is compiled out (fewer registers, more waves).
 template <bool GENERAL>
@@ -605,7 +634,7 @@ FE_HD void constitutive_eval_t(const m3& C, const m3& F, real dt, real mu, real 
     stress.a[0][0] += iso; stress.a[1][1] += iso; stress.a[2][2] += iso;
     k.affine = m3_add(m3_scale(stress, scale), m3_scale(C, mass));
     if (cls == FE_MAT_LIQUID_) {
-        real c = pow(k.J, R_(1.0) / R_(3.0));           // NaN for J < 0, like ti.pow (mpm:359)
+        real c = fe_cbrt_pos(k.J);                       // pow(J, 1/3): NaN for J < 0, like ti.pow (mpm:359)
         k.Fnew = m3_zero(); k.Fnew.a[0][0] = k.Fnew.a[1][1] = k.Fnew.a[2][2] = c;
     } else if (cls == FE_MAT_ELASTIC_ || cls == FE_MAT_RIGID_) {
         k.Fnew = k.Ft;
@@ -636,7 +665,7 @@ FE_HD void constitutive_grad_t(const m3& C, const m3& F, real dt, real mu, real 
     m3 gs = m3_scale(GA, scale);                   // adjoint of the unscaled stress
     real gJ = lam * (R_(2.0) * k.J - R_(1.0)) * m3_trace(gs);
     m3 gFt;
-    if (cls == FE_MAT_LIQUID_) gJ += (R_(1.0) / R_(3.0)) * pow(k.J, R_(1.0) / R_(3.0) - R_(1.0)) * m3_trace(Fg);
+    if (cls == FE_MAT_LIQUID_) gJ += (R_(1.0) / R_(3.0)) * fe_pow_m23(k.J) * m3_trace(Fg);
     if (!GENERAL || !k.full) {
         // J = det F_tmp  =>  d J / d F_tmp = cof(F_tmp)
         gFt = m3_scale(m3_cof(k.Ft), gJ);

@@ -272,8 +272,13 @@ int fe_get_stats(FeEngine* h, int f, FeStats* out);
  * [4] single-item blocks, [5..11] items holding 1, 2-4, 5-8, 9-16, 17-32, 33-64, 65-128 particles, [12] occupied blocks,
  * [13] particles of blocks without a work item (option loose_max), [14] single-item blocks small enough for a quad unit (option quad_max),
  * [15] quad units in the order's scatter list, [16] / [17] work units (workgroups with something to do) of the scatter / gather unit list, [18] the scatter list is
- * packed (no idle halves: options pack_units, quad_fit), [19] / [20] big / small leftover items of odd item counts, [21..23] reserved. */
-int fe_get_work_stats(FeEngine* h, int f, long long out[24]);
+ * packed (no idle halves: options pack_units, quad_fit), [19] / [20] big / small leftover items of odd item counts, [21] / [22] waves of at
+ * most 7 / 8..21 particles, whose particles take nine / three lanes each (option lane_split; 0 when it is off), [23] reserved.
+ * fe_get_work_stats_n writes min(n, FE_WORK_STATS) entries: the list has grown from round to round, and a caller built against an
+ * earlier header passes a shorter buffer (fe_get_work_stats = the full FE_WORK_STATS entries). */
+#define FE_WORK_STATS 24
+int fe_get_work_stats_n(FeEngine* h, int f, long long* out, int n);
+int fe_get_work_stats(FeEngine* h, int f, long long out[FE_WORK_STATS]);
 /* HIP-event stopwatch on the engine's stream */
 int    fe_timer_start(FeEngine* h);
 double fe_timer_stop_ms(FeEngine* h);               /* records, waits, returns elapsed ms (<0 on error) */

@@ -2161,6 +2161,7 @@ int fe_mesh_sdf(int device, const float* verts, int nv, const int* faces, int nf
 }
 
 int fe_get_work_stats(FeEngine*, int, long long out[24]) { for (int i = 0; i < 24; i++) out[i] = 0; return 0; }   // no work lists here
+int fe_get_work_stats_n(FeEngine*, int, long long* out, int n) { for (int i = 0; i < n && i < 24; i++) out[i] = 0; return 0; }
 int fe_get_stats(FeEngine* h, int f, FeStats* out) {
     CHECK_FRAME(h, f);
     const int n = h->n, nb = (n + 3) / 4;

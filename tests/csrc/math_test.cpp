@@ -113,6 +113,19 @@ int main() {
         quat_from_w(aa, qw); quat_mul(qw, q, qo); quat_rotate(v, qo, vo);
         CHECK(fabs((double)vo[0] - 1) < 1e-5 && fabs((double)vo[1] - 2) < 1e-5 && fabs((double)vo[2] - 3) < 1e-5, "identity rotation");
     }
+    // ---- J^(1/3), J^(-2/3) of the liquid F update and its adjoint (fe_cbrt_pos: log2 / exp2 + one Newton step in fp32) against pow in fp64
+    {
+        double worst = 0, worst2 = 0;
+        for (int t = 0; t < 20000; t++) {
+            const double J = t < 10000 ? 1.0 + 0.2 * (urand() - 0.5) : exp(14.0 * (urand() - 0.5));      // near 1 (any sane state), then six decades
+            const real Jr = (real)J;
+            const double ulp = sizeof(real) == 4 ? 6e-8 : 1.2e-16;
+            worst = fmax(worst, fabs((double)fe_cbrt_pos(Jr) / pow((double)Jr, 1.0 / 3.0) - 1.0) / ulp);
+            worst2 = fmax(worst2, fabs((double)fe_pow_m23(Jr) / pow((double)Jr, -2.0 / 3.0) - 1.0) / ulp);
+        }
+        CHECK(worst <= 2.0 && worst2 <= (sizeof(real) == 4 ? 4.0 : 16.0), "fe_cbrt_pos %g ulp, fe_pow_m23 %g ulp", worst, worst2);      // (fp64: the exponent 1/3 - 1 itself is rounded)
+        CHECK(fe_cbrt_pos((real)0) == 0 && std::isnan((double)fe_cbrt_pos((real)-0.5)), "fe_cbrt_pos at 0 / below");
+    }
     printf("%s (%s): %d failures\n", fails ? "FAILED" : "OK", sizeof(real) == 8 ? "fp64" : "fp32", fails);
     return fails ? 1 : 0;
 }

@@ -302,6 +302,81 @@ def test_quad_units_agree_with_pair_units(hiplib):
         assert S.rel_l2(ga[k], gb[k]) <= 3e-4, (k, S.rel_l2(ga[k], gb[k]))
 
 
+@pytest.mark.parametrize('loose_max', [0, 2])
+def test_quad_units_with_drifted_particles_in_p2g_grad(hiplib, oracle64, loose_max):
+    """ADVICE r4.  k_p2g_grad's quad units keep two of their four gathered tiles where the pair units keep the stash of C and F:
+    (i) a particle of a quad unit that has left its tile since the sort is redone on the global path -- which must not park C and F in
+    the stash (it did: the recursion dropped NOSTASH and overwrote tile nodes other lanes were reading);  (ii) a TAIL unit that follows a
+    quad unit in one workgroup does use the stash, so the workgroup has to meet at a barrier in between (loose_max 2: the blocks with
+    one or two droplets have no item, their particles are the tail; 64-workgroup launches, so every workgroup walks quads, then tails).
+    Droplets all over the box, every one of them drifting 1.5 cells between the two sorts, quad units forced on."""
+    rng = np.random.RandomState(17)
+    N = 8000
+    sc = S.water_block(n_grid=64, n_particles=N, lo=0.10, hi=0.90, gravity=(0.0, 0.0, 0.0))
+    sc['x'][:1500] = S.f32(0.45 + rng.normal(0, 0.05, (1500, 3)))             # a cloud with items of 5-40 particles among the one-particle ones
+    sc['v'] = S.f32(rng.normal(0, 0.3, (N, 3)) + [12.0, -9.0, 4.0])
+    opts = {'sort_interval': 20, 'quad_min_units': 0, 'loose_max': loose_max, 'wgrid_cap': 64, 'wgrid_cap_pgg': 64, 'wgrid_cap_g2p': 64}
+    g = S.make_engine(hiplib, sc, options=opts)
+    o = S.make_engine(oracle64, sc)
+    cot = S.random_cotangent(N, seed=3)
+    (a, ga), (b, gb) = S.run_forward_backward(g, 20, cot), S.run_forward_backward(o, 20, {k: v.astype(np.float64) for k, v in cot.items()})
+    ws = g.get_work_stats(0)
+    assert ws['n_quad_units'] > 150 and g.get_stats(20)['n_slow_path'] > 1000, ws
+    if loose_max:
+        assert ws['n_loose_particles'] > 500, ws
+    assert (a['used'] == b['used']).all() and S.rel_l2(a['x'], b['x']) <= 1e-5 and S.rel_l2(a['v'], b['v']) <= 1e-3
+    print('MEASURED quad units, drifted particles:', {k: (round(1 - S.cosine(ga[k], gb[k]), 9), round(S.rel_l2(ga[k], gb[k]), 7)) for k in ga})
+    for k in ('gx', 'gv', 'gC', 'gF'):
+        assert S.cosine(ga[k], gb[k]) >= 0.99999 and S.rel_l2(ga[k], gb[k]) <= 3e-3, k
+
+
+@pytest.mark.parametrize('materials', ['water', 'mixed'])
+@pytest.mark.parametrize('quads', [0, 1])
+def test_lane_split_small_waves_match_the_oracle(hiplib, oracle64, quads, materials):
+    """Option lane_split (round 5): a wave with at most 21 / 7 particles gives every particle three / nine lanes, one per x plane /
+    (x, y) column of its stencil -- in k_p2g, both passes of k_g2p_grad2 and (liquids) k_p2g_grad, in pair units (quads 0) and in quad
+    units (quads 1: fixed-point tiles, the lean hand-over of the inner 6^3 nodes + the shell walk only where a particle sits on it).
+    Droplets (one or two per block), loose clusters (8-20 per block) and a dense clump (full items, never split) in one scene, drifting
+    0.4 cells per sort interval so that shells and a few slow-path particles take part: against the fp64 oracle, and against the same
+    engine with the option off."""
+    rng = np.random.RandomState(23)
+    n_drop, n_cl, n_dense = 3000, 2600, 1400
+    N = n_drop + n_cl + n_dense
+    sc = S.water_block(n_grid=64, n_particles=N, lo=0.40, hi=0.47)
+    sc['x'][:n_drop] = S.f32(rng.uniform(0.1, 0.9, (n_drop, 3)))
+    centres = rng.uniform(0.15, 0.85, (40, 3))
+    sc['x'][n_drop:n_drop + n_cl] = S.f32(np.clip(centres[rng.randint(0, 40, n_cl)] + rng.normal(0, 0.022, (n_cl, 3)), 0.08, 0.92))
+    sc['v'] = S.f32(rng.normal(0, 0.7, (N, 3)) + [3.0, -2.0, 1.0])
+    if materials == 'mixed':                                   # the SVD kernels (k_p2g<., true>; k_p2g_grad<true> keeps one lane per particle)
+        sc['mat'] = np.array([S.WATER, S.ELASTIC, S.ICECREAM], np.int32)[rng.randint(0, 3, N)]
+        sc['F'] = S.f32(np.eye(3)[None] + rng.normal(0, 1.0, (N, 3, 3)) * np.where(sc['mat'] == S.ICECREAM, 0.002, 0.03)[:, None, None])     # (as scenarios.mixed_materials)
+    cot = S.random_cotangent(N, seed=7)
+    out = {}
+    for split in (1, 0):
+        g = S.make_engine(hiplib, sc, options={'sort_interval': 5, 'quad_min_units': 0 if quads else 1 << 30, 'lane_split': split})
+        out[split] = S.run_forward_backward(g, 12, cot)
+        ws = g.get_work_stats(10)
+        if split:
+            assert ws['n_split9_waves'] > 500 and ws['n_split3_waves'] > 30 and ws['items_by_size']['65-128'] > 5, ws
+            assert (ws['n_quad_units'] > 100) == bool(quads), ws
+            assert g.get_stats(12)['n_slow_path'] > 0
+        else:
+            assert ws['n_split9_waves'] == 0 and ws['n_split3_waves'] == 0
+    o = S.make_engine(oracle64, sc)
+    b, gb = S.run_forward_backward(o, 12, {k: v.astype(np.float64) for k, v in cot.items()})
+    (a, ga), (c, gc) = out[1], out[0]
+    assert (a['used'] == b['used']).all()
+    print(f'MEASURED lane_split[{materials}, quads={quads}]: vs oracle x', np.abs(a['x'] - b['x']).max(), 'v', S.rel_l2(a['v'], b['v']),
+          {k: round(S.rel_l2(ga[k], gb[k]), 8) for k in ga}, '| on vs off x', np.abs(a['x'] - c['x']).max(), {k: round(S.rel_l2(ga[k], gc[k]), 8) for k in ga})
+    tol_g = 3e-3 if materials == 'water' else 2e-2
+    assert np.abs(a['x'] - b['x']).max() <= 5e-6 and S.rel_l2(a['v'], b['v']) <= 1e-3 and S.rel_l2(a['F'], b['F']) <= 1e-5
+    for k in ('gx', 'gv', 'gC', 'gF'):
+        assert np.isfinite(ga[k]).all() and S.cosine(ga[k], gb[k]) >= 0.999 and S.rel_l2(ga[k], gb[k]) <= tol_g, (k, S.rel_l2(ga[k], gb[k]))
+        # the option changes the order of the fp32 adds inside a run and nothing else: no further from the unsplit engine than fp32 rounding
+        assert S.rel_l2(ga[k], gc[k]) <= max(3e-4, 2.0 * S.rel_l2(gc[k], gb[k])), (k, S.rel_l2(ga[k], gc[k]))
+    assert np.abs(a['x'] - c['x']).max() <= 1e-6
+
+
 def test_dense_scene_with_small_items(hiplib, oracle64):
     """item_max = 64 on a box filled with water: every block holds 3-4 items, i.e. two pairs -- more pairs than half the items
     (the order's pair list used to be sized items / 2 and overflowed here).  Forward and backward against the oracle."""
