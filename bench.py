@@ -49,6 +49,22 @@ KERNEL_BYTES = {
     'sort': (0, 0), 'reorder_grad': (0, 0),          # overhead of the cell-sorted layout: no algorithmic bytes credited
 }
 FWD_KERNELS = ('p2g', 'grid_op', 'g2p')
+# The backward pass reads the particle state of frame f again (116 bytes per particle: SURVEY 8d books them on the recompute of grid[f]).
+# When the per-frame grid store spares that recompute, the read does not go away -- k_p2g_grad performs it (state 116 + adjoint in 96 +
+# adjoint out 96 + info = 308 bytes per particle all told) -- so the per-kernel figures credit it to the kernel that ran: a p2g_grad launch
+# without a p2g_recompute launch beside it moves (132 + 116) N + 16 Nc.  What is credited and never moved in such a frame is the grid part
+# of the recompute, 44 Nc (16 accumulate-write + 28 grid_op_keep): `pair_roofline.frac_executed` leaves it out.
+STATE_REREAD = 116
+GRID_RECOMPUTE = 44
+
+
+def launch_bytes(name, cnt, prof, n_used, nc):
+    """algorithmic bytes of `cnt` launches of kernel `name` in a window whose launch counts are `prof` ({name: (ms, launches)})"""
+    bp, bc = KERNEL_BYTES.get(name, (0, 0))
+    b = cnt * (bp * n_used + bc * nc)
+    if name == 'p2g_grad':
+        b += max(0, cnt - prof.get('p2g_recompute', (0.0, 0))[1]) * STATE_REREAD * n_used
+    return b
 METRIC = 'MPM substeps/sec (fwd+bwd), 128^3 grid / 200k particles'
 
 
@@ -80,10 +96,9 @@ def kernel_table(prof, n_used, nc):
     out = {}
     for name, (ms, cnt) in prof.items():
         if cnt:
-            bp, bc = KERNEL_BYTES.get(name, (0, 0))
             us = 1e3 * ms / cnt
-            b = bp * n_used + bc * nc
-            out[name] = {'avg_us': round(us, 3), 'launches': cnt, 'alg_bytes': b, 'GBps': round(b / (us * 1e-6) / 1e9, 1)}
+            b = launch_bytes(name, cnt, prof, n_used, nc) / cnt
+            out[name] = {'avg_us': round(us, 3), 'launches': cnt, 'alg_bytes': int(b), 'GBps': round(b / (us * 1e-6) / 1e9, 1)}
     return out
 
 
@@ -126,20 +141,24 @@ def fold_windows(rec, lo, hi):
     for r in ws:
         for name, (m, c) in r.get('prof', {}).items():
             if c:
-                bp, bc = KERNEL_BYTES.get(name, (0, 0))
                 ms[name] = ms.get(name, 0.0) + m; cnt[name] = cnt.get(name, 0) + c
-                byt[name] = byt.get(name, 0.0) + c * (bp * r['n_used'] + bc * r['nc'])
+                byt[name] = byt.get(name, 0.0) + launch_bytes(name, c, r['prof'], r['n_used'], r['nc'])
     kern = {k: {'avg_us': round(1e3 * ms[k] / cnt[k], 3), 'launches': cnt[k], 'alg_bytes': int(byt[k] / cnt[k]),
                 'GBps': round(byt[k] / (ms[k] * 1e-3) / 1e9, 1)} for k in ms}
     nc = float(np.mean([r['nc'] for r in ws]))
     n_used = ws[0]['n_used']
     out = {'substeps': [lo * CHUNK, hi * CHUNK], 'nc_mean': int(nc), 'nc_min': int(min(min(r['nc0'], r['nc1']) for r in ws)),
            'nc_max': int(max(max(r['nc0'], r['nc1']) for r in ws)), 'kernels': kern}
+    # share of the backward substeps whose grid[f] came from the per-frame store (no p2g_recompute / grid_op_keep launch)
+    stored = 1.0 - cnt.get('p2g_recompute', 0) / cnt['p2g_grad'] if cnt.get('p2g_grad') else None
+    out['bwd_frames_from_grid_store'] = None if stored is None else round(stored, 4)
     if plain:
         rate = len(plain) * CHUNK / sum(r['dt'] for r in plain)
         b_pair = 524 * n_used + 204 * nc
         out['pairs_per_s'] = round(rate, 1)
         out['pair_roofline_frac'] = round(b_pair * rate / 1e9 / HBM_PEAK_GBS, 4)
+        if stored is not None:
+            out['pair_roofline_frac_executed'] = round((b_pair - stored * GRID_RECOMPUTE * nc) * rate / 1e9 / HBM_PEAK_GBS, 4)
     return out
 
 
@@ -309,8 +328,13 @@ def run_single(args):
                            'rocprof_avg_launch_us': rocprof_us,
                            'frac_rocprof': round(kern[dom]['alg_bytes'] / (rocprof_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if rocprof_us else None,
                            'windows': f'HIP events over every second timed window (substeps {w0 * CHUNK}..{w1 * CHUNK}) of an untimed replay; bytes from those windows\' Nc'}
+        stored = tw.get('bwd_frames_from_grid_store') or 0.0
         out['pair_roofline'] = {'alg_bytes_per_pair': int(b_pair), 'achieved_GBps': round(b_pair * value / 1e9, 1),
                                 'frac': round(b_pair * value / 1e9 / HBM_PEAK_GBS, 4),
+                                # (the SURVEY figure credits the backward recompute of grid[f] in full; the per-frame grid store spared it in
+                                #  `bwd_frames_from_grid_store` of the frames: without those 44 Nc that nobody moved)
+                                'frac_executed': round((b_pair - stored * GRID_RECOMPUTE * tw['nc_mean']) * value / 1e9 / HBM_PEAK_GBS, 4),
+                                'bwd_frames_from_grid_store': tw.get('bwd_frames_from_grid_store'),
                                 'frac_of_measured_copy': round(b_pair * value / 1e9 / HBM_COPY_GBS, 4),
                                 'nc': 'mean over the timed windows (probe replay), not a post-region sample'}
         out['kernels'] = kern

@@ -141,7 +141,7 @@ struct SimP {
     int ncell;                               // nb^3 * 64: plane stride of the SoA accumulator grids
     int xcd;                                 // option "xcd_map": consecutive work items on the same XCD (shared L2)
     int wsort;                               // option "wave_sort": the scatter kernels regroup their lanes by stencil base before the scan (wave_sort_dest)
-    int lsplit;                              // option "lane_split": waves with at most 21 / 7 particles give every particle 3 / 9 lanes (lane_split)
+    int lsplit;                              // option "lane_split": waves with at most 21 / 7 particles give every particle 3 / 9 lanes (lane_split); bit 0 k_p2g, 1 k_g2p_grad2, 2 k_p2g_grad
     int wt;                                  // option "write_through": bulk outputs as sc1 stores (see wt_store16); bit 0 p2g, 1 g2p, 2 g2p_grad, 3 p2g_grad
     float dx, inv_dx, dt, stress_scale;     // stress_scale = -dt * p_vol * 4 * inv_dx^2 (mpm:343)
     int uni; float uinfo[4];                 // every particle has the same material record (mu, lam, mass, class | material): it travels here instead of 16 bytes per particle and kernel
@@ -809,10 +809,14 @@ __device__ __forceinline__ void p2g_scatter_global(const SimP& S, const P2GPrep&
 // fix_nonfinite: fmaxf ignores a NaN and fix_round(NaN) is 0, so a particle state that has blown up would vanish from the sums of a
 // quad unit while the fp64 tiles of a pair unit -- and the reference's atomics, mpm:346-353 -- carry it to the grid.  A wave that sees
 // a non-finite bound therefore hands its whole tile over as NaN: the divergence stays visible in losses and gradients.
-__device__ __forceinline__ float wave_max(float x) {           // all 64 lanes; x >= 0
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) x = fmaxf(x, __shfl_xor(x, o, 64));
-    return x;
+// (DPP: row_shr 1 2 4 8 leave a row's maximum in its last lane, row_bcast 15 / 31 carry it on into lane 63 -- six VALU instructions.  As six
+//  __shfl_xor steps it was six dependent ds_bpermute round trips, twice per quad unit and kernel: ~0.6 us of a small wave's chain)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_max(float x) { return fmaxf(x, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, ROW_MASK, 0xf, true))); }
+__device__ __forceinline__ float wave_max(float x) {           // all 64 lanes; x >= 0 (a lane without a source reads 0); wave-uniform result
+    x = dpp_max<0x111, 0xf>(x); x = dpp_max<0x112, 0xf>(x); x = dpp_max<0x114, 0xf>(x); x = dpp_max<0x118, 0xf>(x);
+    x = dpp_max<0x142, 0xa>(x); x = dpp_max<0x143, 0xc>(x);
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 63));
 }
 // round to nearest into the fixed-point word.  FIX_RPI: v_cvt_rpi_i32_f32 = floor(x + 0.5) in ONE instruction where rintf + the
 // conversion are two (108 / 81 of them per lane in the scatter loops of a quad unit); ties go up instead of to even, which is as
@@ -982,7 +986,7 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
                 //  out of the frame: that decision has side effects and belongs to one lane)
                 const int wbase = pc.quad ? 0 : (pc.i & 64);         // this wave's first particle within the item
                 const int cnt = __builtin_amdgcn_readfirstlane(min(64, max(0, it.z - wbase)));
-                const LaneSplit ls = lane_split(cnt, S.lsplit != 0 && !(WRITE && act && agent.collector));
+                const LaneSplit ls = lane_split(cnt, (S.lsplit & 1) != 0 && !(WRITE && act && agent.collector));
                 const int i = wbase + ls.p, s = it.y + i;
                 const bool has = ls.ok && i < it.z;
                 // (`used` is re-read rather than implied by the work list so host edits of a frame cannot desynchronise it)
@@ -1925,7 +1929,7 @@ __device__ __forceinline__ void g2p_grad2_body(SimP S, float* fr_cur, float* Gn_
             const int tofs = pc.ti * 3 * TILE_N;                 // (floats / doubles of a pair's tiles, words of a quad's one)
             const int wbase = pc.quad ? 0 : (pc.i & 64);         // this wave's first particle within the item; few of them: three or nine lanes each (lane_split)
             const int cnt = __builtin_amdgcn_readfirstlane(min(64, max(0, it.z - wbase)));
-            const LaneSplit ls = lane_split(cnt, S.lsplit != 0);
+            const LaneSplit ls = lane_split(cnt, (S.lsplit & 2) != 0);
             const int i = wbase + ls.p;
             const bool has = ls.ok && i < it.z;
             const int s = it.y + (has ? i : 0);
@@ -2536,7 +2540,7 @@ __device__ __forceinline__ void p2g_grad_body(SimP S, float* fr_cur, float* Gn_,
             unit_sync(true);
             P2GRaw no_pre;
             {   // (a wave with few particles gives each of them three or nine lanes: lane_split)
-                const LaneSplit ls = lane_split(__builtin_amdgcn_readfirstlane(min(64, it.z)), S.lsplit != 0);
+                const LaneSplit ls = lane_split(__builtin_amdgcn_readfirstlane(min(64, it.z)), (S.lsplit & 4) != 0);
                 const int i = ls.p;
                 if (ls.ok && i < it.z) {
                     if (ls.G == 1) slot_p2g_grad<true, GENERAL, false, true, 1>(S, cur, Gn, Gc, it.y + i, T, pool_idx, to, gg_in, slow, agent, inj, f, 0, 0, no_pre, D, tl);
@@ -2561,7 +2565,7 @@ __device__ __forceinline__ void p2g_grad_body(SimP S, float* fr_cur, float* Gn_,
             P2GRaw no_pre;
             {   // (a wave with few particles gives each of them three or nine lanes: lane_split; the SVD build keeps one lane per particle)
                 const int wbase = pc.i & 64;                     // this wave's first particle within the item
-                const LaneSplit ls = lane_split(__builtin_amdgcn_readfirstlane(min(64, max(0, it.z - wbase))), !GENERAL && S.lsplit != 0);
+                const LaneSplit ls = lane_split(__builtin_amdgcn_readfirstlane(min(64, max(0, it.z - wbase))), !GENERAL && (S.lsplit & 4) != 0);
                 const int i = wbase + ls.p, tofs = pc.ti * 4 * TILE_N;
                 if (ls.ok && i < it.z) {
                     if (GENERAL || ls.G == 1) slot_p2g_grad<true, GENERAL, false, false, 1>(S, cur, Gn, Gc, it.y + i, T, pool_idx, to, gg_in, slow, agent, inj, f, tofs, 0, no_pre, D);
@@ -2745,9 +2749,10 @@ __device__ __forceinline__ BlkWork block_work(int n, int ITEM_MAX) {
 // (A single workgroup walking thread-contiguous stretches was tried first: 70 us at 128^3 and 420 us at 256^3 -- every load and
 // store instruction of a wave touched 64 different cache lines.)
 #define SORT_BLK_WG 1024
-#define NSUM 9
+#define NSUM 11
 #define PART_STRIDE 16
-// dense particles, loose particles, items, full pairs, big singles, occupied blocks, small singles, big leftovers, small leftovers
+// dense particles, loose particles, items, full pairs, big singles, occupied blocks, small singles of more than 21 particles, big leftovers, small leftovers,
+// small singles of 8 .. 21 particles, small singles of at most 7
 struct BlkSums { int v[NSUM]; };
 // (straight-line selects: with early returns the sums lived in memory -- scratch, then LDS when a seventh one was added -- and the scan
 //  stage took 29 us instead of 18)
@@ -2761,7 +2766,12 @@ __device__ __forceinline__ void blk_accumulate(BlkSums& a, int n, int ITEM_MAX, 
     a.v[2] += dense ? w.k : 0;
     a.v[3] += dense ? w.full : 0;
     a.v[4] += (dense && w.single && !small) ? 1 : 0;
-    a.v[6] += (dense && w.single && small) ? 1 : 0;
+    // the small true singles by size: the quad units take the LAST entries of the order's `singles`, and a unit lasts as long as its
+    // slowest wave -- four items of one size class to a unit (lane_split: at most 7, at most 21 particles, the rest), not whatever
+    // four blocks follow each other in space
+    a.v[6] += (dense && w.single && small && w.last > FE_SPLIT3_MAX) ? 1 : 0;
+    a.v[9] += (dense && w.single && small && w.last <= FE_SPLIT3_MAX && w.last > FE_SPLIT9_MAX) ? 1 : 0;
+    a.v[10] += (dense && w.single && small && w.last <= FE_SPLIT9_MAX) ? 1 : 0;
     a.v[7] += (dense && w.left && !small) ? 1 : 0;
     a.v[8] += (dense && w.left && small) ? 1 : 0;
 }
@@ -2773,7 +2783,7 @@ __device__ __forceinline__ int4 blk_ask4(const int* __restrict__ bcnt) { return 
 __device__ __forceinline__ BlkSums blk_sums4(const int4 n4, int nblk, int ITEM_MAX, int loose_max, int quad_max, int n[4]) {
     const int b0 = blockIdx.x * SORT_BLK_WG + threadIdx.x * 4;
     n[0] = b0 < nblk ? n4.x : 0; n[1] = b0 + 1 < nblk ? n4.y : 0; n[2] = b0 + 2 < nblk ? n4.z : 0; n[3] = b0 + 3 < nblk ? n4.w : 0;
-    BlkSums m = {{0, 0, 0, 0, 0, 0, 0, 0, 0}};
+    BlkSums m = {{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
 #pragma unroll
     for (int u = 0; u < 4; u++) blk_accumulate(m, n[u], ITEM_MAX, loose_max, quad_max);
     return m;
@@ -2884,7 +2894,7 @@ __global__ __launch_bounds__(256) void k_sort_blk_final(int nblk, int nb, int nc
     const int tid = threadIdx.x;
     const int4 n4 = blk_ask4(bcnt);                  // (on its way while the partial sums are read)
     // the partials of the workgroups before this one, and of all of them
-    BlkSums pb = {{0, 0, 0, 0, 0, 0, 0, 0, 0}}, pa = {{0, 0, 0, 0, 0, 0, 0, 0, 0}};
+    BlkSums pb = {{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}}, pa = {{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
     for (int w = tid; w < (int)gridDim.x; w += 256) {
 #pragma unroll
         for (int k = 0; k < NSUM; k++) { const int t = partial[w * PART_STRIDE + k]; pa.v[k] += t; if (w < (int)blockIdx.x) pb.v[k] += t; }
@@ -2897,14 +2907,16 @@ __global__ __launch_bounds__(256) void k_sort_blk_final(int nblk, int nb, int nc
     wg_scan6(m, sh, ex, tot);
     // meta: [0] items, [1] first slot behind the dense blocks, [2] active blocks (k_sort_fill), [3] full pairs, [4] big singles, [5] / [9] slots
     // of the two unit lists, [6] occupied blocks, [7] first slot of the tail, [8] small singles, [10] quad units, [11] big / [12] small leftovers, [13] scatter list packed, [14] / [15] work units of the two lists
-    if (blockIdx.x == 0 && tid == 0) { meta[0] = total[2]; meta[1] = total[0]; meta[2] = *nact; meta[3] = total[3]; meta[4] = total[4]; meta[6] = total[5]; meta[7] = total[0] + total[1]; meta[8] = total[6];
+    if (blockIdx.x == 0 && tid == 0) { meta[0] = total[2]; meta[1] = total[0]; meta[2] = *nact; meta[3] = total[3]; meta[4] = total[4]; meta[6] = total[5]; meta[7] = total[0] + total[1]; meta[8] = total[6] + total[9] + total[10];
                                        meta[11] = total[7]; meta[12] = total[8]; }
     const int b0 = blockIdx.x * SORT_BLK_WG + tid * 4;
     if (b0 > nblk) return;
     int D = before[0] + ex[0], L = total[0] + before[1] + ex[1], bi = before[2] + ex[2], bm = before[3] + ex[3];
     // `singles` = [big singles][big leftovers][small leftovers][small singles]: the big ones, the small ones and the leftovers are each
     // one stretch of it, the true singles two (build_unit_list)
-    int p_tb = before[4] + ex[4], p_lb = total[4] + before[7] + ex[7], p_ls = total[4] + total[7] + before[8] + ex[8], p_ts = total[4] + total[7] + total[8] + before[6] + ex[6];
+    int p_tb = before[4] + ex[4], p_lb = total[4] + before[7] + ex[7], p_ls = total[4] + total[7] + before[8] + ex[8];
+    const int ts0 = total[4] + total[7] + total[8];               // the small true singles: [more than 21 particles][8 .. 21][at most 7]
+    int p_ts = ts0 + before[6] + ex[6], p_t3 = ts0 + total[6] + before[9] + ex[9], p_t9 = ts0 + total[6] + total[9] + before[10] + ex[10];
     int2 bf[4];
     int base[4] = {0, 0, 0, 0};                                 // first slot of the block's particles (its cells follow in order: k_sort_blk_partial's launch)
 #pragma unroll
@@ -2919,7 +2931,12 @@ __global__ __launch_bounds__(256) void k_sort_blk_final(int nblk, int nb, int nc
         bf[u] = make_int2(bi, w.k);
         base[u] = D;
         const bool small = w.last <= quad_max;
-        if (w.single) { if (small) singles[p_ts++] = bi; else singles[p_tb++] = bi; }
+        if (w.single) {
+            if (!small) singles[p_tb++] = bi;
+            else if (w.last > FE_SPLIT3_MAX) singles[p_ts++] = bi;
+            else if (w.last > FE_SPLIT9_MAX) singles[p_t3++] = bi;
+            else singles[p_t9++] = bi;
+        }
         if (w.left) { if (small) singles[p_ls++] = bi + w.k - 1; else singles[p_lb++] = bi + w.k - 1; }
         for (int j = 0; j < w.full; j++) pairs[bm++] = make_int2(bi + 2 * j, bi + 2 * j + 1);
         const int pk = BLK_PACK(b / (nb * nb), (b / nb) % nb, b % nb);       // (the block's coordinates: tile_origin, neighbour_entry)
@@ -3084,9 +3101,12 @@ __global__ __launch_bounds__(256) void k_perm_reorder(int N, size_t Np, float* d
     if (s >= N) return;
     const int o = inv_from[pid_to[s]];
     FrameV d = frame_view(dst_, Np), q = frame_view(src_, Np);
-    d.A0[s] = q.A0[o]; d.A1[s] = q.A1[o]; d.A2[s] = q.A2[o];
-    d.a3[s] = q.a3[o]; d.a4[s] = q.a4[o]; d.a5[s] = q.a5[o];
-    d.B0[s] = q.B0[o]; d.B1[s] = q.B1[o]; d.b2[s] = q.b2[o];
+    // (all nine planes asked for before the first store: written plane by plane -- dst[s] = src[o]; ... -- every load was waited for and stored
+    //  before the next one went out, 21.6 us for 40 MB: DESIGN section 11)
+    const float4 a0 = q.A0[o], a1 = q.A1[o], a2 = q.A2[o], b0 = q.B0[o], b1 = q.B1[o];
+    const float a3 = q.a3[o], a4 = q.a4[o], a5 = q.a5[o], b2 = q.b2[o];
+    d.A0[s] = a0; d.A1[s] = a1; d.A2[s] = a2; d.a3[s] = a3; d.a4[s] = a4; d.a5[s] = a5;
+    d.B0[s] = b0; d.B1[s] = b1; d.b2[s] = b2;
 }
 // dst[idx[s]] = src[s]
 __global__ __launch_bounds__(256) void k_perm_scatter(int N, size_t Np, float* dst_, float* src_, const int* __restrict__ idx) {
@@ -3366,17 +3386,21 @@ __global__ void k_loss_sum(float* chamfer_s, float* step_loss_s, float weight) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *step_loss_s += *chamfer_s * weight;
 }
 // adjoint of the two kernels above: x.grad[f,p] += 2 (x - tgt) * weight * step_loss.grad[s]
-__global__ __launch_bounds__(256) void k_loss_bwd(SimP S, float* fr, float* G_, const int* __restrict__ pid_of_slot,
+// The adjoint slot may be stored in another particle order than the frame (the reverse sweep leaves the adjoint of a call's first frame in
+// the order the NEXT call's first substep works in, substep_bwd): slot s of the adjoint belongs to particle pid_of_slot[s], whose state
+// sits in slot frame_slot_of_pid[pid] of the frame (nullptr: the same order).
+__global__ __launch_bounds__(256) void k_loss_bwd(SimP S, float* fr, float* G_, const int* __restrict__ pid_of_slot, const int* __restrict__ frame_slot_of_pid,
                                                   const float4* __restrict__ pinfo, const float* __restrict__ tgt,
                                                   int matching_mat, float g) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= S.N) return;
     FrameV cur = frame_view(fr, S.Np);
-    if (!cur.used[s]) return;
     const int pid = pid_of_slot[s];
+    const int sf = frame_slot_of_pid ? frame_slot_of_pid[pid] : s;
+    if (!cur.used[sf]) return;
     if (matching_mat >= 0 && load_info(pinfo, pid).mat != matching_mat) return;
     FrameV G = frame_view(G_, S.Np);
-    float4 a0 = cur.A0[s];
+    float4 a0 = cur.A0[sf];
     float4 g0 = G.A0[s];
     g0.x += 2.f * (a0.x - tgt[pid * 3]) * g;
     g0.y += 2.f * (a0.y - tgt[pid * 3 + 1]) * g;
@@ -3689,11 +3713,13 @@ int reorder_grad(FeEngine* h, int slot, int to) {
     return 0;
 }
 
-// the adjoint slot of frame f must be in the order frame f is stored in before anything accumulates into it
-int grad_order_for_frame(FeEngine* h, int f) {
-    const int t = h->tbl_of_frame[f];
-    if (h->gtbl[f & 1] < 0) { h->gtbl[f & 1] = t; return 0; }
-    return reorder_grad(h, f & 1, t);
+// The particle order the adjoint slot of frame f is stored in, for whatever accumulates into it (losses, fe_add_grad): a cleared slot
+// takes the frame's order; otherwise the slot keeps its own -- round 4 forced it back to the frame's here, one k_perm_reorder pass per
+// env step in fluidlab's step_grad flow (the loss of a step lands on the frame a sort follows), which the accumulating kernels can
+// do without: they address the slot through its own id table.
+int grad_table_for_frame(FeEngine* h, int f) {
+    if (h->gtbl[f & 1] < 0) h->gtbl[f & 1] = h->tbl_of_frame[f];
+    return h->gtbl[f & 1];
 }
 
 // (round 2 switched the blocks flagged "static" here, two launches; an order's active list is now recognised by its own blk_slot)
@@ -4124,7 +4150,7 @@ FeEngine* fe_create(const FeConfig* cfg) {
     S.xcd = 16;                                            // blocked-cyclic unit mapping (A/B in DESIGN.md section 6)
     S.uni = 0;
     S.wsort = 1;                                           // lanes regrouped by stencil base before the scan (A/B in DESIGN.md section 6)
-    S.lsplit = env_lsplit ? (std::atoi(env_lsplit) != 0) : 1;      // small waves give every particle three or nine lanes (lane_split)
+    S.lsplit = env_lsplit ? std::atoi(env_lsplit) : 7;            // small waves give every particle three or nine lanes (lane_split): in all three kernels
     S.wt = 5;                                              // p2g and g2p_grad: their bulk stores come early (A/B in DESIGN.md section 6)
     S.N = h->N; S.Np = h->Np; S.n = h->n; S.nb = h->nb; S.ncell = h->nb * h->nb * h->nb * 64;
     S.dx = 1.0f / (float)h->n; S.inv_dx = (float)h->n; S.dt = cfg->dt;
@@ -4244,7 +4270,7 @@ int fe_set_option(FeEngine* h, const char* name, double value) {
     if (!std::strcmp(name, "xcd_map")) { if (value < 0 || value > 64) FAIL(h, "xcd_map must be 0 (none), 1 (contiguous eighths) or a run length 2..64"); h->S.xcd = (int)value; return 0; }
     if (!std::strcmp(name, "write_through")) { h->S.wt = (int)value; return 0; }
     if (!std::strcmp(name, "wave_sort")) { h->S.wsort = value != 0; return 0; }
-    if (!std::strcmp(name, "lane_split")) { h->S.lsplit = value != 0; return 0; }
+    if (!std::strcmp(name, "lane_split")) { if (value < 0 || value > 7) FAIL(h, "lane_split is a bit set: 1 k_p2g, 2 k_g2p_grad2, 4 k_p2g_grad"); h->S.lsplit = (int)value; return 0; }
     if (!std::strcmp(name, "fold_reorder")) { h->fold_reorder = value != 0; return 0; }
     if (!std::strcmp(name, "quad_min_units")) { h->quad_min_units = (int)value; return 0; }
     if (!std::strcmp(name, "pack_units")) { if (value < 0 || value > 2) FAIL(h, "pack_units must be 0, 1 or 2"); h->pack_units = (int)value; return 0; }
@@ -4354,7 +4380,9 @@ int fe_step(FeEngine* h, int f0, int f_global0, int n, int act) {
 int fe_step_grad(FeEngine* h, int f0, int f_global0, int n, int act) {
     FE_ENTRY(h);
     if (f0 < 0 || f0 + n > h->L) FAIL(h, "step frames out of range");
-    for (int i = n - 1; i >= 0; i--) if (substep_bwd(h, f0 + i, f_global0 + i, act, i > 0 ? f0 + i - 1 : -1)) return 1;
+    // (the call's last substep leaves the adjoint of frame f0 in the order of frame f0 - 1: where the next call of the sweep starts --
+    //  fluidlab's step_grad is one call per env step, and with K = n_substeps a sort lies on every call boundary)
+    for (int i = n - 1; i >= 0; i--) if (substep_bwd(h, f0 + i, f_global0 + i, act, f0 + i > 0 ? f0 + i - 1 : -1)) return 1;
     return check_async(h);
 }
 int fe_step_batch(FeEngine** hs, int n_env, int f0, int f_global0, int n, int act) {
@@ -4503,17 +4531,16 @@ int fe_get_grad(FeEngine* h, int f, fe_real* gx, fe_real* gv, fe_real* gC, fe_re
 int fe_add_grad(FeEngine* h, int f, const fe_real* gx, const fe_real* gv, const fe_real* gC, const fe_real* gF) {
     FE_ENTRY(h);
     CHECK_FRAME(h, f);
-    if (grad_order_for_frame(h, f)) return 1;
-    return upload_planes(h, h->grad(f), h->pid_of(f), gx, gv, gC, gF, nullptr, 1);
+    return upload_planes(h, h->grad(f), h->tables[grad_table_for_frame(h, f)].pid, gx, gv, gC, gF, nullptr, 1);
 }
 // device-pointer variant (a loss evaluated on the GPU hands its adjoint over without crossing PCIe)
 int fe_add_grad_dev(FeEngine* h, int f, const fe_real* gx, const fe_real* gv, const fe_real* gC, const fe_real* gF) {
     FE_ENTRY(h);
     CHECK_FRAME(h, f);
-    if (grad_order_for_frame(h, f)) return 1;
+    const int gt = grad_table_for_frame(h, f);
     const int mask = (gx ? 1 : 0) | (gv ? 2 : 0) | (gC ? 4 : 0) | (gF ? 8 : 0);
     if (!mask || h->N == 0) return 0;
-    hipLaunchKernelGGL(k_pack, pgrid(h), dim3(256), 0, h->stream, h->N, (size_t)h->Np, h->grad(f), h->pid_of(f), gx, gv, gC, gF, (const int*)nullptr, mask, 1);
+    hipLaunchKernelGGL(k_pack, pgrid(h), dim3(256), 0, h->stream, h->N, (size_t)h->Np, h->grad(f), h->tables[gt].pid, gx, gv, gC, gF, (const int*)nullptr, mask, 1);
     HIPCK(h, hipStreamSynchronize(h->stream));
     return check_async(h);
 }
@@ -4781,8 +4808,8 @@ int fe_loss_step_grad(FeEngine* h, int s, int f, int matching_mat, fe_real weigh
     FE_ENTRY(h);
     if (s < 0 || s >= h->loss_steps) FAIL(h, "loss step out of range");
     CHECK_FRAME(h, f);
-    if (grad_order_for_frame(h, f)) return 1;
-    hipLaunchKernelGGL(k_loss_bwd, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->grad(f), h->pid_of(f), h->pinfo,
+    const int gt = grad_table_for_frame(h, f), ft = h->tbl_of_frame[f];
+    hipLaunchKernelGGL(k_loss_bwd, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->grad(f), h->tables[gt].pid, gt == ft ? (const int*)nullptr : h->tables[ft].slot_of_pid, h->pinfo,
                        h->tgt + (size_t)s * h->N * 3, matching_mat, weight * step_loss_grad);
     return check_async(h);
 }

@@ -321,7 +321,7 @@ def test_quad_units_with_drifted_particles_in_p2g_grad(hiplib, oracle64, loose_m
     cot = S.random_cotangent(N, seed=3)
     (a, ga), (b, gb) = S.run_forward_backward(g, 20, cot), S.run_forward_backward(o, 20, {k: v.astype(np.float64) for k, v in cot.items()})
     ws = g.get_work_stats(0)
-    assert ws['n_quad_units'] > 150 and g.get_stats(20)['n_slow_path'] > 1000, ws
+    assert ws['n_quad_units'] > 100 and g.get_stats(20)['n_slow_path'] > 1000, ws
     if loose_max:
         assert ws['n_loose_particles'] > 500, ws
     assert (a['used'] == b['used']).all() and S.rel_l2(a['x'], b['x']) <= 1e-5 and S.rel_l2(a['v'], b['v']) <= 1e-3
@@ -337,8 +337,8 @@ def test_lane_split_small_waves_match_the_oracle(hiplib, oracle64, quads, materi
     (x, y) column of its stencil -- in k_p2g, both passes of k_g2p_grad2 and (liquids) k_p2g_grad, in pair units (quads 0) and in quad
     units (quads 1: fixed-point tiles, the lean hand-over of the inner 6^3 nodes + the shell walk only where a particle sits on it).
     Droplets (one or two per block), loose clusters (8-20 per block) and a dense clump (full items, never split) in one scene, drifting
-    0.4 cells per sort interval so that shells and a few slow-path particles take part: against the fp64 oracle, and against the same
-    engine with the option off."""
+    1.2 cells per sort interval so that shells and a few slow-path particles take part: against the fp64 oracle, and against the same
+    engine with the option off (the option is a bit per kernel: 7 = all three)."""
     rng = np.random.RandomState(23)
     n_drop, n_cl, n_dense = 3000, 2600, 1400
     N = n_drop + n_cl + n_dense
@@ -346,14 +346,14 @@ def test_lane_split_small_waves_match_the_oracle(hiplib, oracle64, quads, materi
     sc['x'][:n_drop] = S.f32(rng.uniform(0.1, 0.9, (n_drop, 3)))
     centres = rng.uniform(0.15, 0.85, (40, 3))
     sc['x'][n_drop:n_drop + n_cl] = S.f32(np.clip(centres[rng.randint(0, 40, n_cl)] + rng.normal(0, 0.022, (n_cl, 3)), 0.08, 0.92))
-    sc['v'] = S.f32(rng.normal(0, 0.7, (N, 3)) + [3.0, -2.0, 1.0])
+    sc['v'] = S.f32(rng.normal(0, 0.7, (N, 3)) + [9.0, -6.0, 3.0])
     if materials == 'mixed':                                   # the SVD kernels (k_p2g<., true>; k_p2g_grad<true> keeps one lane per particle)
         sc['mat'] = np.array([S.WATER, S.ELASTIC, S.ICECREAM], np.int32)[rng.randint(0, 3, N)]
         sc['F'] = S.f32(np.eye(3)[None] + rng.normal(0, 1.0, (N, 3, 3)) * np.where(sc['mat'] == S.ICECREAM, 0.002, 0.03)[:, None, None])     # (as scenarios.mixed_materials)
     cot = S.random_cotangent(N, seed=7)
     out = {}
-    for split in (1, 0):
-        g = S.make_engine(hiplib, sc, options={'sort_interval': 5, 'quad_min_units': 0 if quads else 1 << 30, 'lane_split': split})
+    for split in (7, 0):
+        g = S.make_engine(hiplib, sc, options={'sort_interval': 10, 'quad_min_units': 0 if quads else 1 << 30, 'lane_split': split})
         out[split] = S.run_forward_backward(g, 12, cot)
         ws = g.get_work_stats(10)
         if split:
@@ -364,7 +364,7 @@ def test_lane_split_small_waves_match_the_oracle(hiplib, oracle64, quads, materi
             assert ws['n_split9_waves'] == 0 and ws['n_split3_waves'] == 0
     o = S.make_engine(oracle64, sc)
     b, gb = S.run_forward_backward(o, 12, {k: v.astype(np.float64) for k, v in cot.items()})
-    (a, ga), (c, gc) = out[1], out[0]
+    (a, ga), (c, gc) = out[7], out[0]
     assert (a['used'] == b['used']).all()
     print(f'MEASURED lane_split[{materials}, quads={quads}]: vs oracle x', np.abs(a['x'] - b['x']).max(), 'v', S.rel_l2(a['v'], b['v']),
           {k: round(S.rel_l2(ga[k], gb[k]), 8) for k in ga}, '| on vs off x', np.abs(a['x'] - c['x']).max(), {k: round(S.rel_l2(ga[k], gc[k]), 8) for k in ga})
