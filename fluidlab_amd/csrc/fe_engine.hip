@@ -621,7 +621,9 @@ __device__ __forceinline__ void tile_handover(const SimP& S, float4* slab, int i
 }
 
 #ifndef FE_LEAN_QUADS
-#define FE_LEAN_QUADS 1       // (A/B builds: 0 = a quad unit's wave walks all 512 tile nodes in its hand-over and tile load, as in round 4)
+#define FE_LEAN_QUADS 0       // (A/B builds: 1 = a quad unit's wave hands over / loads the inner 6^3 nodes of its tile and walks the shell only when a particle sits on it.
+                              //  Measured, round 5: nothing in the splash (149.9 vs 149.6 us per pair) and +0.8 us per pair over the timed region, where no quad unit runs --
+                              //  the larger kernels sit differently; profiles/r05_ab_lane_split.txt)
 #endif
 // does the 3^3 stencil with base index lb reach the tile's outer shell (tile index 0 or 7 on some axis: base 0 or 5)?
 __device__ __forceinline__ bool stencil_on_shell(int lb) {
@@ -2889,7 +2891,7 @@ __global__ __launch_bounds__(256) void k_sort_blk_partial(int nblk, int nb, int 
 // (one launch in which every workgroup goes over the whole array again instead of reading partial sums was tried: the six sums need
 // a division per block, 35 us for the launch against 18 for these two)
 __global__ __launch_bounds__(256) void k_sort_blk_final(int nblk, int nb, int ncell, int ITEM_MAX, int loose_max, int quad_max, const int* __restrict__ bcnt, int* cnt, int* start,
-                                                        const int* __restrict__ partial, int4* items, int2* pairs, int* singles, int2* blk_first, int* blk_base, const int* __restrict__ nact, int* meta) {
+                                                        const int* __restrict__ partial, int4* items, int2* pairs, int* singles, int* singles_c, int2* blk_first, int* blk_base, const int* __restrict__ nact, int* meta) {
     __shared__ int sh[4][NSUM];
     const int tid = threadIdx.x;
     const int4 n4 = blk_ask4(bcnt);                  // (on its way while the partial sums are read)
@@ -2915,8 +2917,11 @@ __global__ __launch_bounds__(256) void k_sort_blk_final(int nblk, int nb, int nc
     // `singles` = [big singles][big leftovers][small leftovers][small singles]: the big ones, the small ones and the leftovers are each
     // one stretch of it, the true singles two (build_unit_list)
     int p_tb = before[4] + ex[4], p_lb = total[4] + before[7] + ex[7], p_ls = total[4] + total[7] + before[8] + ex[8];
-    const int ts0 = total[4] + total[7] + total[8];               // the small true singles: [more than 21 particles][8 .. 21][at most 7]
+    // `singles` keeps the small true singles in block order (the gather kernels' pairs-only list: two spatial neighbours to a workgroup share most
+    // of the nodes their tiles load); `singles_c`, the same list for the scatter kernels, has them by size class: [more than 21 particles][8 .. 21][at most 7]
+    const int ts0 = total[4] + total[7] + total[8];
     int p_ts = ts0 + before[6] + ex[6], p_t3 = ts0 + total[6] + before[9] + ex[9], p_t9 = ts0 + total[6] + total[9] + before[10] + ex[10];
+    int p_bo = ts0 + before[6] + ex[6] + before[9] + ex[9] + before[10] + ex[10];
     int2 bf[4];
     int base[4] = {0, 0, 0, 0};                                 // first slot of the block's particles (its cells follow in order: k_sort_blk_partial's launch)
 #pragma unroll
@@ -2932,12 +2937,15 @@ __global__ __launch_bounds__(256) void k_sort_blk_final(int nblk, int nb, int nc
         base[u] = D;
         const bool small = w.last <= quad_max;
         if (w.single) {
-            if (!small) singles[p_tb++] = bi;
-            else if (w.last > FE_SPLIT3_MAX) singles[p_ts++] = bi;
-            else if (w.last > FE_SPLIT9_MAX) singles[p_t3++] = bi;
-            else singles[p_t9++] = bi;
+            if (!small) { singles[p_tb] = bi; singles_c[p_tb++] = bi; }
+            else {
+                singles[p_bo++] = bi;
+                if (w.last > FE_SPLIT3_MAX) singles_c[p_ts++] = bi;
+                else if (w.last > FE_SPLIT9_MAX) singles_c[p_t3++] = bi;
+                else singles_c[p_t9++] = bi;
+            }
         }
-        if (w.left) { if (small) singles[p_ls++] = bi + w.k - 1; else singles[p_lb++] = bi + w.k - 1; }
+        if (w.left) { if (small) { singles[p_ls] = bi + w.k - 1; singles_c[p_ls++] = bi + w.k - 1; } else { singles[p_lb] = bi + w.k - 1; singles_c[p_lb++] = bi + w.k - 1; } }
         for (int j = 0; j < w.full; j++) pairs[bm++] = make_int2(bi + 2 * j, bi + 2 * j + 1);
         const int pk = BLK_PACK(b / (nb * nb), (b / nb) % nb, b % nb);       // (the block's coordinates: tile_origin, neighbour_entry)
         for (int o = 0; o < nn; o += ITEM_MAX) items[bi++] = make_int4(pk, D + o, min(ITEM_MAX, nn - o), 0);
@@ -3008,7 +3016,7 @@ __device__ __forceinline__ void build_unit_list(int gtid, int nth, int N, int xc
 // 20.9 / 19.0 on the falling block).  There the list is now PACKED (no idle halves) and takes as many quads as it needs to fit one
 // round again, if that is enough.
 __device__ __forceinline__ void build_units_dev(int gtid, int nth, int nb, int N, int xcd_on, int quad_min_units, int quad_fit, int pack_units, const int4* __restrict__ items, const int2* __restrict__ pairs,
-                                                const int* __restrict__ singles, const int2* __restrict__ blk_first, const int* __restrict__ active,
+                                                const int* __restrict__ singles, const int* __restrict__ singles_c, const int2* __restrict__ blk_first, const int* __restrict__ active,
                                                 int* meta, UnitRec* units, UnitRec* units_p, int units_cap, int2* nbr) {
     const int tail_start = meta[1], n_active = meta[2];
     const UnitLists L = {meta[3], meta[4], meta[11], meta[12], meta[8]};
@@ -3023,7 +3031,7 @@ __device__ __forceinline__ void build_units_dev(int gtid, int nth, int nb, int N
         else pack = pack_units > 1;
     } else if (U0 > quad_min_units) x = L.tS;
     if (gtid == 0) { meta[10] = (x + 3) >> 2; meta[13] = pack ? 1 : 0; }       // (fe_get_work_stats)
-    build_unit_list(gtid, nth, N, xcd_on, items, pairs, singles, tail_start, L, pack, x, meta + 5, meta + 14, units, units_cap);
+    build_unit_list(gtid, nth, N, xcd_on, items, pairs, singles_c, tail_start, L, pack, x, meta + 5, meta + 14, units, units_cap);
     build_unit_list(gtid, nth, N, xcd_on, items, pairs, singles, tail_start, L, false, 0, meta + 9, meta + 15, units_p, units_cap);
     // neighbour records, four entries of a thread at a time: their block numbers in one round trip, their item ranges in the next (one at
     // a time this loop was two dependent round trips per entry, 5 ... 20 entries per thread -- the longest chain of the sort's last launch)
@@ -3046,7 +3054,7 @@ __device__ __forceinline__ void build_units_dev(int gtid, int nth, int nb, int N
 __global__ __launch_bounds__(256) void k_build_units(int nb, int N, int xcd_on, const int4* __restrict__ items, const int2* __restrict__ pairs,
                                                      const int* __restrict__ singles, const int2* __restrict__ blk_first, const int* __restrict__ active,
                                                      int* meta, UnitRec* units, UnitRec* units_p, int units_cap, int2* nbr) {
-    build_units_dev(blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, nb, N, xcd_on, 0x7fffffff, 0, 0, items, pairs, singles, blk_first, active, meta, units, units_p, units_cap, nbr);
+    build_units_dev(blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, nb, N, xcd_on, 0x7fffffff, 0, 0, items, pairs, singles, singles, blk_first, active, meta, units, units_p, units_cap, nbr);
 }
 
 // The permutation itself, one pass: slot s of the old order goes to d = start[key] + rank -- its particle id, material record and
@@ -3055,7 +3063,7 @@ __global__ __launch_bounds__(256) void k_build_units(int nb, int N, int xcd_on, 
 #ifndef SORT_UNIT_WGS
 #define SORT_UNIT_WGS 512      // (128 until late in round 4: where the water has come apart the neighbour records were the launch's longest chain)
 #endif
-struct UnitsArgs { int* bcnt; int nb, xcd_on, quad_min_units, quad_fit, pack_units; const int4* items; const int2* pairs; const int* singles; const int2* blk_first; const int* active; int* meta; UnitRec* units; UnitRec* units_p; int units_cap; int2* nbr; };
+struct UnitsArgs { int* bcnt; int nb, xcd_on, quad_min_units, quad_fit, pack_units; const int4* items; const int2* pairs; const int* singles; const int* singles_c; const int2* blk_first; const int* active; int* meta; UnitRec* units; UnitRec* units_p; int units_cap; int2* nbr; };
 __global__ __launch_bounds__(256) void k_sort_apply(int N, size_t Np, int n_pwg, const int* __restrict__ key, const int* __restrict__ rank,
                                                     const int* __restrict__ start, const int* __restrict__ blk_base, const int* __restrict__ pid_old, int* pid_new, int* slot_of_pid,
                                                     const float4* __restrict__ pinfo, float4* info_new, float* dst_, float* src_, UnitsArgs U, int uni) {
@@ -3063,7 +3071,7 @@ __global__ __launch_bounds__(256) void k_sort_apply(int N, size_t Np, int n_pwg,
     // (independent of the permutation: both only need what the block scan's two launches left)
     if ((int)blockIdx.x < SORT_UNIT_WGS) {
         for (int i = blockIdx.x * 256 + threadIdx.x; i <= U.nb * U.nb * U.nb; i += SORT_UNIT_WGS * 256) U.bcnt[i] = 0;      // block counts: ready for the next sort
-        build_units_dev(blockIdx.x * 256 + threadIdx.x, SORT_UNIT_WGS * 256, U.nb, N, U.xcd_on, U.quad_min_units, U.quad_fit, U.pack_units, U.items, U.pairs, U.singles, U.blk_first, U.active, U.meta,
+        build_units_dev(blockIdx.x * 256 + threadIdx.x, SORT_UNIT_WGS * 256, U.nb, N, U.xcd_on, U.quad_min_units, U.quad_fit, U.pack_units, U.items, U.pairs, U.singles, U.singles_c, U.blk_first, U.active, U.meta,
                         U.units, U.units_p, U.units_cap, U.nbr);
         return;
     }
@@ -3691,7 +3699,7 @@ int ensure_table(FeEngine* h, int id) {
     if (id == 0) t.info = h->pinfo;                            // identity order: slot == particle id
     else if (dev_alloc(h, &t.info, h->Np)) return 1;
     // (pairs: a block with k > 1 items makes ceil(k / 2) pairs -- two from three -- so the bound is the item count, not half of it)
-    if (dev_alloc(h, &t.pairs, h->items_cap) || dev_alloc(h, &t.singles, h->items_cap)) return 1;
+    if (dev_alloc(h, &t.pairs, h->items_cap) || dev_alloc(h, &t.singles, 2 * h->items_cap)) return 1;      // (singles: block order, then the same list by size class)
     if (dev_alloc(h, &t.pid, h->Np) || dev_alloc(h, &t.items, h->items_cap) || dev_alloc(h, &t.meta, 16) ||
         dev_alloc(h, &t.blk_first, nblk) || dev_alloc(h, &t.active, nblk) || dev_alloc(h, &t.blk_slot, nblk) || dev_alloc(h, &t.slot_of_pid, h->Np) ||
         dev_alloc(h, &t.units, h->units_cap, false) || dev_alloc(h, &t.units_p, h->units_cap, false) || dev_alloc(h, &t.nbr, nblk * 27, false)) return 1;
@@ -3752,11 +3760,11 @@ int sort_frame(FeEngine* h, int f) {
     hipLaunchKernelGGL(k_sort_blk_partial, dim3(blk_wgs + scan_wgs + act_wgs), dim3(256), 0, h->stream, nblk, h->nb, h->item_max, h->loose_max, quad_max(h), h->sort_bcnt, h->sort_partial,
                        blk_wgs, scan_wgs, h->sort_cnt, h->sort_start, h->sort_nact, tn.active, tn.blk_slot);
     hipLaunchKernelGGL(k_sort_blk_final, dim3(blk_wgs), dim3(256), 0, h->stream, nblk, h->nb, ncell, h->item_max, h->loose_max, quad_max(h), h->sort_bcnt, h->sort_cnt, h->sort_start, h->sort_partial,
-                       tn.items, tn.pairs, tn.singles, tn.blk_first, h->sort_base, h->sort_nact, tn.meta);
+                       tn.items, tn.pairs, tn.singles, tn.singles + h->items_cap, tn.blk_first, h->sort_base, h->sort_nact, tn.meta);
     if (fine) { prof_end(h); prof_begin(h, KID_SORT_PERM); }
     // re-sorting a frame that is already in this table's order reads the id table it rewrites: stage it
     int* pid_dst = id_old == id_new ? h->sort_pid : tn.pid;
-    const UnitsArgs U = {h->sort_bcnt, h->nb, h->S.xcd, h->quad_min_units, h->quad_fit, h->pack_units, tn.items, tn.pairs, tn.singles, tn.blk_first, tn.active, tn.meta, tn.units, tn.units_p, (int)h->units_cap, tn.nbr};
+    const UnitsArgs U = {h->sort_bcnt, h->nb, h->S.xcd, h->quad_min_units, h->quad_fit, h->pack_units, tn.items, tn.pairs, tn.singles, tn.singles + h->items_cap, tn.blk_first, tn.active, tn.meta, tn.units, tn.units_p, (int)h->units_cap, tn.nbr};
     hipLaunchKernelGGL(k_sort_apply, dim3(n_pwg + SORT_UNIT_WGS), dim3(256), 0, h->stream, h->N, (size_t)h->Np, n_pwg, h->sort_key, h->sort_rank, h->sort_start, h->sort_base,
                        h->tables[id_old].pid, pid_dst, tn.slot_of_pid, h->pinfo, tn.info, h->spare_frame(), h->frame(f), U, h->S.uni);
     if (id_old == id_new) HIPCK(h, hipMemcpyAsync(tn.pid, h->sort_pid, sizeof(int) * h->Np, hipMemcpyDeviceToDevice, h->stream));
@@ -4150,7 +4158,8 @@ FeEngine* fe_create(const FeConfig* cfg) {
     S.xcd = 16;                                            // blocked-cyclic unit mapping (A/B in DESIGN.md section 6)
     S.uni = 0;
     S.wsort = 1;                                           // lanes regrouped by stencil base before the scan (A/B in DESIGN.md section 6)
-    S.lsplit = env_lsplit ? std::atoi(env_lsplit) : 7;            // small waves give every particle three or nine lanes (lane_split): in all three kernels
+    S.lsplit = env_lsplit ? std::atoi(env_lsplit) : 3;            // small waves give every particle three or nine lanes (lane_split) in the two scatter kernels; in k_p2g_grad (bit 2)
+                                                                  // the fifteen sums' cross-lane reads cost what the shorter loop saves (profiles/r05_ab_lane_split.txt)
     S.wt = 5;                                              // p2g and g2p_grad: their bulk stores come early (A/B in DESIGN.md section 6)
     S.N = h->N; S.Np = h->Np; S.n = h->n; S.nb = h->nb; S.ncell = h->nb * h->nb * h->nb * 64;
     S.dx = 1.0f / (float)h->n; S.inv_dx = (float)h->n; S.dt = cfg->dt;
@@ -4179,7 +4188,11 @@ FeEngine* fe_create(const FeConfig* cfg) {
         // (round 1 clamped this to 4096 blocks: a block of water that has spread into a thin layer over the floor of a 128^3 box
         // has more active blocks than that, every frame lost its store and the backward pass recomputed P2G + grid_op throughout)
         size_t cap = nblk;
-        while (cap > 0 && (size_t)(h->L + 1) * cap * (GS_BLK * 16) > ((size_t)64 << 30)) cap /= 2;
+        // (FE_GRID_STORE_GIB: another budget for the store -- two LatteArt replicas at 128^3 fit one GPU with 32 GiB each, bench.py --envs-per-gpu 2;
+        //  a frame with more active blocks than the store has slots falls back to the recompute, as ever)
+        size_t budget_gib = 64;
+        if (const char* e = std::getenv("FE_GRID_STORE_GIB")) { const long v = std::atol(e); if (v >= 0 && v <= 256) budget_gib = (size_t)v; }
+        while (cap > 0 && (size_t)(h->L + 1) * cap * (GS_BLK * 16) > (budget_gib << 30)) cap /= 2;
         h->gs_cap = (int)cap;
         if (cap > 0 && (dev_alloc(h, &h->gstore, (size_t)(h->L + 1) * cap * GS_BLK, false) || dev_alloc(h, &h->gs_flag, h->L + 1) ||
                         dev_alloc(h, &h->gs_live, (size_t)(h->L + 1) * cap))) return fail("");

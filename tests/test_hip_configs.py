@@ -213,7 +213,7 @@ def test_config5_composite_at_full_size(hiplib):
 
 
 @pytest.mark.parametrize('dt,n_sub', [(5e-5, 10), (2e-4, 3)])
-def test_config5_composite_matches_the_oracle_at_full_size(hiplib, oracle32, dt, n_sub):
+def test_config5_composite_matches_the_oracle_at_full_size(hiplib, oracle32, oracle64, dt, n_sub):
     """Config 5 at its size against the oracle ("property-only at size"): 256^3 grid, 1M ICECREAM particles (SVD, plastic
     clamp, backward_svd), SmokeField at 128^3 with the AirCon, one step of 10 substeps forward and backward on the HIP engine and on the
     oracle's fp32 build (16 OpenMP threads; its dense grids are 0.9 GB per frame).  dt as in composite_scene (Courant), and -- three
@@ -240,5 +240,15 @@ def test_config5_composite_matches_the_oracle_at_full_size(hiplib, oracle32, dt,
     assert S.rel_l2(a['smoke']['v'], b['smoke']['v']) <= 1e-6
     for k in ('gx', 'gv', 'gC', 'gF'):
         assert np.isfinite(a['g'][k]).all() and g[k][0] >= 0.9994 and g[k][1] <= (1e-2 if k in ('gx', 'gv') else 6e-2), (k, g[k])
+    if n_sub == 10:
+        # Those absolute bounds are set by fp32 on both sides of backward_svd near sigma_i = sigma_j and would also pass a 1 % defect of the
+        # adjoint kernels.  Against the oracle's fp64 build the HIP engine must not be further off than the oracle's own fp32
+        # build is: twice its distance (the bound test_config2_splash_state_with_quad_units_matches_the_oracle uses).
+        c = run_composite(oracle64, sc, res, cot, cot_v, options={'threads': 16})
+        e_hip = {k: S.rel_l2(a['g'][k], c['g'][k]) for k in ('gx', 'gv', 'gC', 'gF')}
+        e_f32 = {k: S.rel_l2(b['g'][k], c['g'][k]) for k in ('gx', 'gv', 'gC', 'gF')}
+        print('MEASURED config5 at full size, adjoints relL2 vs the fp64 oracle: hip', {k: f'{v:.2e}' for k, v in e_hip.items()}, 'oracle fp32', {k: f'{v:.2e}' for k, v in e_f32.items()})
+        for k in e_hip:
+            assert e_hip[k] <= 2.0 * e_f32[k] + 1e-6, (k, e_hip[k], e_f32[k])
     assert S.rel_l2(a['gsv'], b['gsv']) <= 1e-6
     assert S.rel_l2(a['action_grad'], b['action_grad']) <= 2e-5
