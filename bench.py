@@ -35,8 +35,8 @@ HBM_COPY_GBS = 6290.0          # measured float4 copy on this part (DESIGN.md se
 # rocprofv3 --pmc passes of THIS command line (`--steps 20 --warmup 5`), sliced by window (scripts/phase_profile.py): the traffic of
 # the roofline kernel is read for the same windows it is timed in, or not at all
 # (the files also record the engine's source hash and the device they were taken on: numbers of another build or another GPU are not printed)
-PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r04_pmc_traffic.json')
-ROCPROF_TIMED = os.path.join(ROOT, 'profiles', 'r04_kernel_stats_timed_region.csv')
+PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r05_pmc_traffic.json')
+ROCPROF_TIMED = os.path.join(ROOT, 'profiles', 'r05_kernel_stats_timed_region.csv')
 SRC_HASH_FILE = os.path.join(ROOT, 'fluidlab_amd', 'csrc', 'libfluidengine_hip.so.srchash')
 # fixed substep windows of the evolving block, comparable across --steps and across rounds (window w = substeps [100 w, 100 w + 100))
 PHASES = {'falling': (5, 11), 'impact': (11, 18), 'splash': (26, 34), 'layer': (80, 90)}
@@ -267,6 +267,64 @@ def extra_evolving(elib, device, name, mat, dt, warm, n_windows, note):
     return out
 
 
+def c5_injected(elib, device, t0_steps=125, passes=4):
+    """BASELINE config 5 as SURVEY 8d C5 writes it: IceCreamDynamic-v0's scene at 256^3, a pool of 1,000,000 ICECREAM particles dispensed by the
+    BallInjector (flux 10 per substep), the Rigid cone's SDF collider, the reference's 40-substep window; dt = 5e-5 (the reference's 2e-4 is past
+    the solid's Courant limit on this grid: scripts/run_c5.py).  The demo policy runs `t0_steps` steps forward (50,000 particles in flight), then
+    ONE step is differentiated `passes` times through fluidlab's Solver (forward with the loss, backward, agent.get_grad); the rate is taken from
+    the Solver's own forward / backward clocks, which start after the state upload.  Never part of `value`."""
+    import contextlib
+    import io
+    from fluidlab_amd.envs import make
+    from fluidlab_amd.optimizer.policies import ActionsPolicy
+    from fluidlab_amd.optimizer.solver import Solver
+    out = {'workload': 'IceCreamDynamic-v0 scene at 256^3: 1M-particle ICECREAM pool, BallInjector flux 10, Rigid cone (analytic SDF), 40-substep window, dt 5e-5; '
+                       'one step fwd+bwd through Solver.forward_backward after %d steps of the demo pour' % t0_steps}
+    try:
+        base = dict(quality=4, n_pool=1_000_000, inject_till=10**9, max_substeps_local=40, ckpt_dest='gpu', dt=5e-5, loss_type='default', device=device)
+        quiet = lambda: contextlib.redirect_stdout(io.StringIO())
+        with quiet():
+            env = make('IceCreamDynamic-v0', seed=0, engine_lib=elib, loss=False, horizon=t0_steps + 1, **base)
+            te = env.taichi_env
+            table = env.demo_policy()
+            te.apply_agent_action_p(table.get_actions_p())
+            te.simulator.engine.sync(); t0 = time.perf_counter()
+            for i in range(t0_steps):
+                te.step(table.get_action_v(i))
+            te.simulator.engine.sync()
+        fwd_rate = t0_steps * te.simulator.n_substeps / (time.perf_counter() - t0)
+        state = te.get_state()['state']
+        te.simulator.engine.close()
+        used0 = state['used'] > 0
+        cone = np.asarray(state['agent'][1][:3], np.float64)
+        acts = np.asarray(table.actions_v[t0_steps:t0_steps + 1], np.float64)
+        tgt = state['x'] + np.random.RandomState(3).normal(0, 0.01, state['x'].shape)
+        tgt[~used0] = [0.5, 0.78, 0.5]
+        with quiet():
+            env = make('IceCreamDynamic-v0', seed=0, engine_lib=elib, loss=True, horizon=1, **base)
+            te = env.taichi_env
+            te.loss.set_target({'x': tgt[None].astype(np.float32)})
+            pol = ActionsPolicy(np.vstack([acts, (cone / np.asarray(te.agent.rigid.action_scale_p, np.float64)[:3])[None, :]]))
+            pol.freeze_till = 0
+            sol, secs, grad = Solver(env, None, None), [], None
+            for _ in range(passes):
+                info, grad = sol.forward_backward(state, pol, 1, 1)
+                secs.append(info['forward_s'] + info['backward_s'])
+        st = te.simulator.engine.get_stats(39)
+        te.simulator.engine.close()
+        ns = 40
+        rate = ns / min(secs[1:])
+        b_pair = 524 * st['n_used'] + 204 * st['n_cells_touched']
+        out.update({'forward_only_substeps_per_s_during_the_pour': round(fwd_rate, 1), 'particles_in_flight': int(used0.sum()), 'n_used_end': int(st['n_used']),
+                    'n_cells_touched': int(st['n_cells_touched']), 'pairs_per_s': round(rate, 1), 'pass_seconds': [round(x, 4) for x in secs],
+                    'state_finite': bool(np.isfinite(state['x'][used0]).all()), 'action_grad_finite': bool(np.isfinite(np.asarray(grad)).all()),
+                    'pair_roofline': {'alg_bytes_per_pair': int(b_pair), 'frac': round(b_pair * rate / 1e9 / HBM_PEAK_GBS, 4)},
+                    'note': 'a window of 40 substeps per host crossing (the reference\'s memory model) with 5 % of the pool in flight: the per-call host work weighs more than in the resident runs'})
+    except Exception as e:                                   # (never take the bench line down)
+        out['error'] = str(e)[:300]
+    return out
+
+
 def run_single(args):
     import torch
     torch.cuda.set_device(0)
@@ -441,6 +499,7 @@ def run_single(args):
         # within a hundred substeps on every implementation, the oracle included (DESIGN section 6 caveats).
         extra['general_128_200k'] = extra_evolving(elib, 0, 'ICECREAM (plasto-elastic, SVD + plastic clamp + backward_svd) block 128^3, 200k particles, fwd+bwd, evolving (rolling windows)',
                                                    S.ICECREAM, 1e-4, 5, 15, 'GENERAL kernel variants at the size the metric is quoted on; dt halved for stability (see DESIGN)')
+        extra['config5_injected_256_1M'] = c5_injected(elib, 0)
         extra['config5_water_256_1M'] = extra_block(elib, 0, 'water block 256^3, 1M particles, fwd+bwd', 256, 1_000_000, S.WATER, 40, 3)
         extra['config5_icecream_256_1M'] = extra_block(elib, 0, 'ICECREAM (plasto-elastic, SVD) block 256^3, 1M particles, fwd+bwd, 10 substeps', 256, 1_000_000, S.ICECREAM, 10, 3)
         out['extra'] = extra

@@ -860,6 +860,10 @@ __device__ __forceinline__ FixScale fix_scale(float M) {       // M wave-uniform
 #ifndef FE_SPLIT9_MAX
 #define FE_SPLIT9_MAX 7
 #endif
+#ifndef FE_SPLIT_PGG
+#define FE_SPLIT_PGG 0        // (A/B builds: 1 = k_p2g_grad splits its small waves too, option lane_split bit 2.  Measured, round 5: its fifteen sums cost
+#endif                        //  45 / 90 cross-lane reads per wave, which is what the shorter gather loop saves -- splash 26.8 vs 26.5 us, timed region 20.8 vs 21.0 --
+                              //  and the two extra instantiations double the kernel's code, 15.6k VALU instructions where it had 7.3k: profiles/r05_ab_lane_split.txt)
 struct LaneSplit { int G, p, gofs; bool ok, primary; };       // G: 1, 3, 9 (wave-uniform); p: the lane's particle within the wave; gofs: tile offset of its group's nodes
 __device__ __forceinline__ LaneSplit lane_split(int cnt, bool allowed) {      // cnt: particles of this wave (uniform)
     int lane = threadIdx.x & 63;
@@ -2542,7 +2546,7 @@ __device__ __forceinline__ void p2g_grad_body(SimP S, float* fr_cur, float* Gn_,
             unit_sync(true);
             P2GRaw no_pre;
             {   // (a wave with few particles gives each of them three or nine lanes: lane_split)
-                const LaneSplit ls = lane_split(__builtin_amdgcn_readfirstlane(min(64, it.z)), (S.lsplit & 4) != 0);
+                const LaneSplit ls = lane_split(__builtin_amdgcn_readfirstlane(min(64, it.z)), FE_SPLIT_PGG && (S.lsplit & 4) != 0);
                 const int i = ls.p;
                 if (ls.ok && i < it.z) {
                     if (ls.G == 1) slot_p2g_grad<true, GENERAL, false, true, 1>(S, cur, Gn, Gc, it.y + i, T, pool_idx, to, gg_in, slow, agent, inj, f, 0, 0, no_pre, D, tl);
@@ -2567,7 +2571,7 @@ __device__ __forceinline__ void p2g_grad_body(SimP S, float* fr_cur, float* Gn_,
             P2GRaw no_pre;
             {   // (a wave with few particles gives each of them three or nine lanes: lane_split; the SVD build keeps one lane per particle)
                 const int wbase = pc.i & 64;                     // this wave's first particle within the item
-                const LaneSplit ls = lane_split(__builtin_amdgcn_readfirstlane(min(64, max(0, it.z - wbase))), !GENERAL && (S.lsplit & 4) != 0);
+                const LaneSplit ls = lane_split(__builtin_amdgcn_readfirstlane(min(64, max(0, it.z - wbase))), FE_SPLIT_PGG && !GENERAL && (S.lsplit & 4) != 0);
                 const int i = wbase + ls.p, tofs = pc.ti * 4 * TILE_N;
                 if (ls.ok && i < it.z) {
                     if (GENERAL || ls.G == 1) slot_p2g_grad<true, GENERAL, false, false, 1>(S, cur, Gn, Gc, it.y + i, T, pool_idx, to, gg_in, slow, agent, inj, f, tofs, 0, no_pre, D);

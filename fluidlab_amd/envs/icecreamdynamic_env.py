@@ -3,7 +3,8 @@ while a controllable cone (Rigid + SDF mesh) moves underneath; the loss matches 
 swirl.  The scene BASELINE config 5 ("IceCream-v0") refers to.
 
 `quality`, `n_pool`, `horizon`, `inject_till` scale it for tests; defaults are the reference's (64^3, 100k pool particles,
-900 steps, injection until substep 7700).  The cone's collision mesh is an analytic stand-in (fluidengine/meshes.py:
+900 steps, injection until substep 7700).  `dt` (default: the reference's fixed 2e-4) is for BASELINE config 5's 256^3 grid, where the
+plasto-elastic solid is beyond its Courant limit at 2e-4 (tests/test_hip_configs.py, scripts/run_c5.py).  The cone's collision mesh is an analytic stand-in (fluidengine/meshes.py:
 sdf_cone_tip) because mesh -> SDF conversion is unavailable here.  With max_substeps_local=None the 9,000-substep
 trajectory of the default scene stays resident in HBM (~90 GB) instead of the reference's 40-substep checkpoint window."""
 import os
@@ -22,7 +23,7 @@ from .fluid_env import FluidEnv
 
 class IceCreamDynamicEnv(FluidEnv):
     def __init__(self, version=0, loss=True, loss_type='diff', seed=None, renderer_type=None, quality=1, n_pool=100000, horizon=900,
-                 inject_till=None, max_substeps_local=40, ckpt_dest='disk', target=None, engine_lib=None, device=0):
+                 inject_till=None, max_substeps_local=40, ckpt_dest='disk', target=None, engine_lib=None, device=0, dt=None):
         if seed is not None:
             self.seed(seed)
         self.horizon = horizon
@@ -36,7 +37,7 @@ class IceCreamDynamicEnv(FluidEnv):
         self.loss_type = loss_type
         self.action_range = np.array([-0.005, 0.005])
         self.taichi_env = TaichiEnv(dim=3, quality=quality, particle_density=1e6, max_substeps_local=max_substeps_local,
-                                    gravity=(0.0, -10.0, 0.0), horizon=self.horizon, ckpt_dest=ckpt_dest, engine_lib=engine_lib, device=device)
+                                    gravity=(0.0, -10.0, 0.0), horizon=self.horizon, ckpt_dest=ckpt_dest, engine_lib=engine_lib, device=device, dt=dt)
         self.build_env()
         self.gym_misc()
 

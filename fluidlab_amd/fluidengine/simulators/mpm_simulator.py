@@ -42,7 +42,7 @@ def _is_cuda_tensor(a):
 
 class MPMSimulator:
     def __init__(self, dim, quality, gravity, horizon, max_substeps_local, max_substeps_global, ckpt_dest,
-                 engine_lib=None, device=0):
+                 engine_lib=None, device=0, dt=None):
         assert dim == 3, 'the MI355X engine is 3-D'
         self.dim = dim
         self.ckpt_dest = ckpt_dest
@@ -52,12 +52,14 @@ class MPMSimulator:
         self.n_grid = int(64 * quality)                     # mpm:21
         self.dx = 1 / self.n_grid
         self.inv_dx = float(self.n_grid)
-        self.dt = 2e-4                                      # mpm:24
+        # mpm:24 fixes dt = 2e-4 for every grid.  `dt` (not in the reference) is for grids finer than the 64^3 it runs: the stiff materials are
+        # beyond their Courant limit there (ICECREAM at 256^3: 2.4) and leave the grid within a few hundred substeps on any implementation
+        self.dt = 2e-4 if dt is None else float(dt)
         self.p_vol = (self.dx * 0.5) ** 2                   # mpm:25 (sic: squared in 3-D)
         self.res = (self.n_grid,) * self.dim
         self.max_substeps_global = max_substeps_global
         self.horizon = horizon
-        self.n_substeps = int(2e-3 / self.dt)               # mpm:30
+        self.n_substeps = int(round(2e-3 / self.dt))        # mpm:30
         if max_substeps_local is None:                      # whole trajectory resident in HBM
             max_substeps_local = self.n_substeps * (horizon + 1)
         self.max_substeps_local = max_substeps_local

@@ -17,12 +17,12 @@ _NO_AGENT = 'Environment has no agent to execute action.'
 
 class TaichiEnv:
     def __init__(self, dim=3, quality=1, particle_density=1e6, max_substeps_local=50, max_substeps_global=100000,
-                 horizon=100, ckpt_dest='disk', gravity=(0.0, -10.0, 0.0), engine_lib=None, device=0):
+                 horizon=100, ckpt_dest='disk', gravity=(0.0, -10.0, 0.0), engine_lib=None, device=0, dt=None):
         self.dim, self.horizon, self.ckpt_dest = dim, horizon, ckpt_dest
         self.particle_density, self.max_substeps_global = particle_density, max_substeps_global
         self.simulator = MPMSimulator(dim=dim, quality=quality, horizon=horizon, max_substeps_local=max_substeps_local,
                                       max_substeps_global=max_substeps_global, gravity=gravity, ckpt_dest=ckpt_dest,
-                                      engine_lib=engine_lib, device=device)
+                                      engine_lib=engine_lib, device=device, dt=dt)
         self.max_substeps_local = self.simulator.max_substeps_local          # None (whole trajectory resident) is resolved there
         self.statics = Statics()
         self.particle_bodies = Bodies(dim=dim, particle_density=particle_density, elib=self.simulator.engine_library, device=device)

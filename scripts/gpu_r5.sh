@@ -29,3 +29,6 @@ if [ $# -gt 0 ]; then
   echo "== ab"; timeout 1200 python scripts/ab_phases.py --windows $WIN --reps 2 "$@" 2>&1 | grep -v amdgpu.ids > $OUT/ab.txt; python scripts/ab_table.py $OUT/ab.txt | tee $OUT/ab_table.txt
 fi
 echo "== bench (driver flags)"; timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-extras 2>&1 | tail -1 | tee $OUT/bench_driver.json | cut -c1-1500
+if [ -n "$C5_STEPS" ]; then
+  echo "== config 5 as SURVEY writes it (256^3, 1M pool, BallInjector)"; timeout 900 python scripts/run_c5.py $C5_STEPS 2>&1 | grep -v amdgpu.ids | tee $OUT/run_c5.txt | tail -20
+fi

@@ -55,3 +55,40 @@ def test_substep_kernels_are_aligned_in_the_code_object():
     assert not missing, missing
     off = {k: hex(addr[k][0]) for k in hot if addr[k][0] % 16384}
     assert not off, off
+
+
+# Static VALU instruction budgets of the particle kernels: what one wave issues for one work unit is the sum of the statements on
+# its path, and the statements below are the parts that grew unnoticed before -- powf() in the liquid's F update was 130 of p2g_compute's 227
+# instructions until round 5.  Counted per statement of the kernel's body from an assembly with line tables (scripts/valu_profile.py: debug line
+# info does not change the code), ~8 % above the round-5 build.
+VALU_BUDGET = {
+    ('k_p2g<true, false>', 'p2g_body'): {'total': 6400, 'p2g_compute<WRITE, GENERAL>(S, nxt, s, raw': 100, 'p2g_scatter_tile_split<false>': 1400, 'p2g_scatter_tile_split<true>': 1760},
+    ('k_g2p_grad2<4>', 'g2p_grad2_body'): {'total': 5250, 'g2p_grad_particle2_split<MINW, false>': 1570, 'g2p_grad_particle2_split<MINW, true>': 1940},
+    ('k_p2g_grad<false, 4>', 'p2g_grad_body'): {'total': 8000},
+    ('k_g2p<false>', 'g2p_body'): {'total': 1650},
+}
+
+
+def test_particle_kernels_stay_within_their_valu_budget(tmp_path):
+    import __graft_entry__ as g
+    spec = importlib.util.spec_from_file_location('valu_profile', os.path.join(ROOT, 'scripts', 'valu_profile.py'))
+    vp = importlib.util.module_from_spec(spec); spec.loader.exec_module(vp)
+    srcs = [os.path.join(g.CSRC, f) for f in ('fe_engine.hip', 'fe_math.h', 'fe_smoke.h', 'fe_mesh.h')] + [os.path.join(ROOT, 'include', 'fluidengine.h')]
+    asm = os.path.join('/tmp', f'fe_engine_lines_{g._source_hash(srcs)[:16]}.s')      # (one device compile with line tables, ~45 s, kept per source state)
+    if not os.path.exists(asm):
+        vp.compile_asm([], asm)
+    src_lines = open(vp.SRC).read().split('\n')
+    over = {}
+    for (kernel, body), budget in VALU_BUDGET.items():
+        name, total, by_stmt, _ = vp.profile(asm, kernel, body)
+        assert name == kernel, (kernel, name)
+        if total['VALU'] > budget['total']:
+            over[(kernel, 'total')] = (total['VALU'], budget['total'])
+        for key, cap in budget.items():
+            if key == 'total':
+                continue
+            hits = [c['VALU'] for (f, l), c in by_stmt.items() if f == body and 0 < l <= len(src_lines) and key in src_lines[l - 1]]
+            assert hits, f'statement not found in {kernel}: {key}'
+            if sum(hits) > cap:
+                over[(kernel, key)] = (sum(hits), cap)
+    assert not over, f'VALU instructions over budget (count, budget): {over}'

@@ -252,3 +252,64 @@ def test_config5_composite_matches_the_oracle_at_full_size(hiplib, oracle32, ora
             assert e_hip[k] <= 2.0 * e_f32[k] + 1e-6, (k, e_hip[k], e_f32[k])
     assert S.rel_l2(a['gsv'], b['gsv']) <= 1e-6
     assert S.rel_l2(a['action_grad'], b['action_grad']) <= 2e-5
+
+
+def test_config5_injected_stream_at_full_size(hiplib, oracle32):
+    """BASELINE config 5 as SURVEY 8d C5 writes it: IceCreamDynamic-v0's scene at 256^3 -- a pool of 1,000,000 ICECREAM particles
+    dispensed by the BallInjector (flux 10 per substep, agent_icecreamdynamic.yaml), the Rigid cone's SDF collider underneath, the reference's
+    40-substep window.  The HIP engine runs the demo policy for 125 steps (5,000 substeps: 50,000 particles in flight, the first of them on the
+    cone), both engines restart from that state (particles, injector act_id, cone pose) and run ONE step -- 40 substeps forward with the loss,
+    40 backward, agent.get_grad -- through Solver.forward_backward (solver.py:23-59).  dt = 5e-5: at the reference's fixed 2e-4 the stream
+    leaves the grid after 490 substeps on this grid (scripts/run_c5.py; ICECREAM's Courant number is 2.4 there)."""
+    from fluidlab_amd.envs import make
+    from fluidlab_amd.optimizer.policies import ActionsPolicy
+    from fluidlab_amd.optimizer.solver import Solver
+    H, T0 = 1, 125
+    base = dict(quality=4, n_pool=1_000_000, inject_till=10**9, max_substeps_local=40, ckpt_dest='cpu', dt=5e-5, loss_type='default')
+    env = make('IceCreamDynamic-v0', seed=0, engine_lib=hiplib, loss=False, horizon=T0 + H, **base)
+    te = env.taichi_env
+    assert te.simulator.n_grid == 256 and te.simulator.n_substeps == 40 and te.simulator.n_particles == 1_000_000
+    table = env.demo_policy()
+    te.apply_agent_action_p(table.get_actions_p())
+    for i in range(T0):
+        te.step(table.get_action_v(i))
+    state = te.get_state()['state']
+    te.simulator.engine.close()
+    used0 = state['used'] > 0
+    assert used0.sum() == T0 * 40 * 10 and np.isfinite(state['x'][used0]).all()
+    on_cone = int((state['x'][used0][:, 1] < 0.56).sum())
+    cone = np.asarray(state['agent'][1][:3], np.float64)
+    acts = np.asarray(table.actions_v[T0:T0 + H], np.float64)
+    n = len(state['x'])
+    tgt = state['x'] + np.random.RandomState(3).normal(0, 0.01, (n, 3))
+    tgt[~used0] = np.array([0.5, 0.78, 0.5]) + np.random.RandomState(4).normal(0, 0.02, (int((~used0).sum()), 3))      # (the pool waits at NOWHERE: the 400 particles the step dispenses aim below the nozzle)
+    tgt = tgt[None].astype(np.float32)
+
+    def run(lib):
+        env = make('IceCreamDynamic-v0', seed=0, engine_lib=lib, loss=True, horizon=H, **base)
+        te = env.taichi_env
+        if not lib.backend.startswith('hip'):
+            te.simulator.engine.set_option('threads', 16)
+        te.loss.set_target({'x': tgt})
+        scale_p = np.asarray(te.agent.rigid.action_scale_p, np.float64)[:3]
+        pol = ActionsPolicy(np.vstack([acts, (cone / scale_p)[None, :]]))
+        pol.freeze_till = 0
+        info, grad = Solver(env, None, None).forward_backward(state, pol, H, H)
+        gx = te.simulator.engine.get_grad(0)[0]
+        fin = S.get_state(te.simulator.engine, 40 * H)
+        te.simulator.engine.close()
+        return info['loss'], np.asarray(grad, np.float64), gx.astype(np.float64), fin
+
+    la, ga, xa, fa = run(hiplib)
+    lb, gb, xb, fb = run(oracle32)
+    used1 = fa['used'] > 0
+    print('MEASURED config5 injected stream at full size: in flight', int(used0.sum()), '->', int(used1.sum()), 'below y = 0.56 (at the cone)', on_cone,
+          'loss', la, lb, 'action-grad cos', S.cosine(ga, gb), 'relL2', S.rel_l2(ga, gb), 'x_bar[0] cos', S.cosine(xa, xb), 'relL2', S.rel_l2(xa, xb),
+          'x relL2', S.rel_l2(fa['x'][used1], fb['x'][used1]), 'max|dx|', float(np.abs(fa['x'][used1] - fb['x'][used1]).max()))
+    assert used1.sum() - used0.sum() == 10 * 40 * H and np.array_equal(fa['used'], fb['used'])
+    assert S.rel_l2(fa['x'][used1], fb['x'][used1]) <= 1e-5
+    assert np.isfinite(ga).all() and np.isfinite(xa).all() and ga.shape == (H + 1, 3)
+    assert abs(la - lb) <= 1e-4 * abs(lb)
+    assert np.abs(xb).max() > 0 and S.cosine(xa, xb) >= 0.999 and S.rel_l2(xa, xb) <= 2e-2
+    if np.abs(gb).max() > 0:                                  # (the cone's action gradient is non-zero once ice cream touches it)
+        assert S.cosine(ga, gb) >= 0.999 and S.rel_l2(ga, gb) <= 5e-2
