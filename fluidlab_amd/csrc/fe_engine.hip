@@ -2523,11 +2523,18 @@ __device__ __forceinline__ void p2g_grad_body(SimP S, float* fr_cur, float* Gn_,
     // so that where the water has come apart the launch is two rounds of workgroups instead of three or four.  The SVD build keeps the
     // pairs-only list (its stash holds U and V as well: 36 KB).
     constexpr bool QLIST = !GENERAL;
+    // (which of the two lists: the sort's decision, meta[16] -- the first unit of both is asked for together with it)
     Unit un = unit_load<!QLIST>(T, blockIdx.x);                     // this workgroup's first unit, asked for together with meta
-    const int n_slots = T.meta[QLIST ? 5 : 9];
+    bool useq = QLIST;
+    if (QLIST) {
+        const Unit un_p = unit_load<true>(T, blockIdx.x);
+        useq = T.meta[16] != 0;
+        if (!useq) un = un_p;
+    }
+    const int n_slots = T.meta[useq ? 5 : 9];
     bool prev_quad = false;                                   // (unit_enter)
     for (int wg = blockIdx.x; wg < n_slots; wg += gridDim.x) {
-        if (wg != (int)blockIdx.x) un = unit_load<!QLIST>(T, wg);
+        if (wg != (int)blockIdx.x) { if (useq) un = unit_load<false>(T, wg); else un = unit_load<true>(T, wg); }
         if (un.a.z == -2) continue;
         if (QLIST && un.a.z >= 0 && (un.a.w & QUAD_BIT)) {
             const PairCtx pc = unit_ctx(un);
@@ -3019,7 +3026,7 @@ __device__ __forceinline__ void build_unit_list(int gtid, int nth, int N, int xc
 // first 1,024 started when the first ones retired and the scatter kernels took two chains instead of one (31.8 / 32.3 us against
 // 20.9 / 19.0 on the falling block).  There the list is now PACKED (no idle halves) and takes as many quads as it needs to fit one
 // round again, if that is enough.
-__device__ __forceinline__ void build_units_dev(int gtid, int nth, int nb, int N, int xcd_on, int quad_min_units, int quad_fit, int pack_units, const int4* __restrict__ items, const int2* __restrict__ pairs,
+__device__ __forceinline__ void build_units_dev(int gtid, int nth, int nb, int N, int xcd_on, int quad_min_units, int quad_fit, int pack_units, int pgg_quad_min_units, const int4* __restrict__ items, const int2* __restrict__ pairs,
                                                 const int* __restrict__ singles, const int* __restrict__ singles_c, const int2* __restrict__ blk_first, const int* __restrict__ active,
                                                 int* meta, UnitRec* units, UnitRec* units_p, int units_cap, int2* nbr) {
     const int tail_start = meta[1], n_active = meta[2];
@@ -3035,6 +3042,9 @@ __device__ __forceinline__ void build_units_dev(int gtid, int nth, int nb, int N
         else pack = pack_units > 1;
     } else if (U0 > quad_min_units) x = L.tS;
     if (gtid == 0) { meta[10] = (x + 3) >> 2; meta[13] = pack ? 1 : 0; }       // (fe_get_work_stats)
+    // k_p2g_grad walks the scatter list only where quad units pay for IT (option "pgg_quad_min_units"): between ~1,400 and ~1,800 pair units the
+    // scatter kernels gain from quads what it loses (a quad's four tiles to load per workgroup) -- impact 21.5 vs 20.3 us, profiles/r05_ab_lane_split.txt
+    if (gtid == 0) meta[16] = (x > 0 && U0 > pgg_quad_min_units) ? 1 : 0;
     build_unit_list(gtid, nth, N, xcd_on, items, pairs, singles_c, tail_start, L, pack, x, meta + 5, meta + 14, units, units_cap);
     build_unit_list(gtid, nth, N, xcd_on, items, pairs, singles, tail_start, L, false, 0, meta + 9, meta + 15, units_p, units_cap);
     // neighbour records, four entries of a thread at a time: their block numbers in one round trip, their item ranges in the next (one at
@@ -3058,7 +3068,7 @@ __device__ __forceinline__ void build_units_dev(int gtid, int nth, int nb, int N
 __global__ __launch_bounds__(256) void k_build_units(int nb, int N, int xcd_on, const int4* __restrict__ items, const int2* __restrict__ pairs,
                                                      const int* __restrict__ singles, const int2* __restrict__ blk_first, const int* __restrict__ active,
                                                      int* meta, UnitRec* units, UnitRec* units_p, int units_cap, int2* nbr) {
-    build_units_dev(blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, nb, N, xcd_on, 0x7fffffff, 0, 0, items, pairs, singles, singles, blk_first, active, meta, units, units_p, units_cap, nbr);
+    build_units_dev(blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, nb, N, xcd_on, 0x7fffffff, 0, 0, 0x7fffffff, items, pairs, singles, singles, blk_first, active, meta, units, units_p, units_cap, nbr);
 }
 
 // The permutation itself, one pass: slot s of the old order goes to d = start[key] + rank -- its particle id, material record and
@@ -3067,7 +3077,7 @@ __global__ __launch_bounds__(256) void k_build_units(int nb, int N, int xcd_on, 
 #ifndef SORT_UNIT_WGS
 #define SORT_UNIT_WGS 512      // (128 until late in round 4: where the water has come apart the neighbour records were the launch's longest chain)
 #endif
-struct UnitsArgs { int* bcnt; int nb, xcd_on, quad_min_units, quad_fit, pack_units; const int4* items; const int2* pairs; const int* singles; const int* singles_c; const int2* blk_first; const int* active; int* meta; UnitRec* units; UnitRec* units_p; int units_cap; int2* nbr; };
+struct UnitsArgs { int* bcnt; int nb, xcd_on, quad_min_units, quad_fit, pack_units, pgg_quad_min_units; const int4* items; const int2* pairs; const int* singles; const int* singles_c; const int2* blk_first; const int* active; int* meta; UnitRec* units; UnitRec* units_p; int units_cap; int2* nbr; };
 __global__ __launch_bounds__(256) void k_sort_apply(int N, size_t Np, int n_pwg, const int* __restrict__ key, const int* __restrict__ rank,
                                                     const int* __restrict__ start, const int* __restrict__ blk_base, const int* __restrict__ pid_old, int* pid_new, int* slot_of_pid,
                                                     const float4* __restrict__ pinfo, float4* info_new, float* dst_, float* src_, UnitsArgs U, int uni) {
@@ -3075,7 +3085,7 @@ __global__ __launch_bounds__(256) void k_sort_apply(int N, size_t Np, int n_pwg,
     // (independent of the permutation: both only need what the block scan's two launches left)
     if ((int)blockIdx.x < SORT_UNIT_WGS) {
         for (int i = blockIdx.x * 256 + threadIdx.x; i <= U.nb * U.nb * U.nb; i += SORT_UNIT_WGS * 256) U.bcnt[i] = 0;      // block counts: ready for the next sort
-        build_units_dev(blockIdx.x * 256 + threadIdx.x, SORT_UNIT_WGS * 256, U.nb, N, U.xcd_on, U.quad_min_units, U.quad_fit, U.pack_units, U.items, U.pairs, U.singles, U.singles_c, U.blk_first, U.active, U.meta,
+        build_units_dev(blockIdx.x * 256 + threadIdx.x, SORT_UNIT_WGS * 256, U.nb, N, U.xcd_on, U.quad_min_units, U.quad_fit, U.pack_units, U.pgg_quad_min_units, U.items, U.pairs, U.singles, U.singles_c, U.blk_first, U.active, U.meta,
                         U.units, U.units_p, U.units_cap, U.nbr);
         return;
     }
@@ -3517,6 +3527,7 @@ struct FeEngine {
     int pack_units = 2;                                     // option "pack_units": 0 never, 1 pack the scatter list (no idle halves) when that brings it back into one round, 2 whenever it is more than one round
     int quad_fit = 1024;                                    // option "quad_fit": the workgroups of one resident round (set from the device in fe_create: 4 per CU); 0 = round 3's rule
     int quad_min_units = 1400;                              // option "quad_min_units": quad units only when pairs alone would be more workgroups than this (build_units_dev)
+    int pgg_quad_min_units = 1800;                          // option "pgg_quad_min_units": ... and k_p2g_grad takes them only beyond this many (else the pairs-only list)
     int quad = QUAD_MAX;                                    // option "quad_max": single-item blocks of at most this many particles go four to a workgroup (0: never)
     int g2p_grad_v = 3;                                     // build of the G2P adjoint: 3 = split passes, x offset rolled (k_g2p_grad2<4>, default); 2 = split, unrolled completely (<3>); 1 = fused rolled loop (k_g2p_grad)
     int item_max = ITEM_MAX_CAP;                            // particles per work item (<= ITEM_MAX_CAP = one half workgroup)
@@ -3704,7 +3715,7 @@ int ensure_table(FeEngine* h, int id) {
     else if (dev_alloc(h, &t.info, h->Np)) return 1;
     // (pairs: a block with k > 1 items makes ceil(k / 2) pairs -- two from three -- so the bound is the item count, not half of it)
     if (dev_alloc(h, &t.pairs, h->items_cap) || dev_alloc(h, &t.singles, 2 * h->items_cap)) return 1;      // (singles: block order, then the same list by size class)
-    if (dev_alloc(h, &t.pid, h->Np) || dev_alloc(h, &t.items, h->items_cap) || dev_alloc(h, &t.meta, 16) ||
+    if (dev_alloc(h, &t.pid, h->Np) || dev_alloc(h, &t.items, h->items_cap) || dev_alloc(h, &t.meta, 24) ||
         dev_alloc(h, &t.blk_first, nblk) || dev_alloc(h, &t.active, nblk) || dev_alloc(h, &t.blk_slot, nblk) || dev_alloc(h, &t.slot_of_pid, h->Np) ||
         dev_alloc(h, &t.units, h->units_cap, false) || dev_alloc(h, &t.units_p, h->units_cap, false) || dev_alloc(h, &t.nbr, nblk * 27, false)) return 1;
     HIPCK(h, hipMemsetAsync(t.blk_slot, 0xff, sizeof(int) * nblk, h->stream));
@@ -3768,7 +3779,7 @@ int sort_frame(FeEngine* h, int f) {
     if (fine) { prof_end(h); prof_begin(h, KID_SORT_PERM); }
     // re-sorting a frame that is already in this table's order reads the id table it rewrites: stage it
     int* pid_dst = id_old == id_new ? h->sort_pid : tn.pid;
-    const UnitsArgs U = {h->sort_bcnt, h->nb, h->S.xcd, h->quad_min_units, h->quad_fit, h->pack_units, tn.items, tn.pairs, tn.singles, tn.singles + h->items_cap, tn.blk_first, tn.active, tn.meta, tn.units, tn.units_p, (int)h->units_cap, tn.nbr};
+    const UnitsArgs U = {h->sort_bcnt, h->nb, h->S.xcd, h->quad_min_units, h->quad_fit, h->pack_units, h->pgg_quad_min_units, tn.items, tn.pairs, tn.singles, tn.singles + h->items_cap, tn.blk_first, tn.active, tn.meta, tn.units, tn.units_p, (int)h->units_cap, tn.nbr};
     hipLaunchKernelGGL(k_sort_apply, dim3(n_pwg + SORT_UNIT_WGS), dim3(256), 0, h->stream, h->N, (size_t)h->Np, n_pwg, h->sort_key, h->sort_rank, h->sort_start, h->sort_base,
                        h->tables[id_old].pid, pid_dst, tn.slot_of_pid, h->pinfo, tn.info, h->spare_frame(), h->frame(f), U, h->S.uni);
     if (id_old == id_new) HIPCK(h, hipMemcpyAsync(tn.pid, h->sort_pid, sizeof(int) * h->Np, hipMemcpyDeviceToDevice, h->stream));
@@ -4290,6 +4301,7 @@ int fe_set_option(FeEngine* h, const char* name, double value) {
     if (!std::strcmp(name, "lane_split")) { if (value < 0 || value > 7) FAIL(h, "lane_split is a bit set: 1 k_p2g, 2 k_g2p_grad2, 4 k_p2g_grad"); h->S.lsplit = (int)value; return 0; }
     if (!std::strcmp(name, "fold_reorder")) { h->fold_reorder = value != 0; return 0; }
     if (!std::strcmp(name, "quad_min_units")) { h->quad_min_units = (int)value; return 0; }
+    if (!std::strcmp(name, "pgg_quad_min_units")) { h->pgg_quad_min_units = (int)value; return 0; }
     if (!std::strcmp(name, "pack_units")) { if (value < 0 || value > 2) FAIL(h, "pack_units must be 0, 1 or 2"); h->pack_units = (int)value; return 0; }
     if (!std::strcmp(name, "quad_fit")) { if (value < 0) FAIL(h, "quad_fit must be >= 0"); h->quad_fit = (int)value; return 0; }
     if (!std::strcmp(name, "quad_max")) { if (value < 0 || value > QUAD_MAX) FAIL(h, "quad_max must be in [0, 64]"); h->quad = (int)value; return 0; }
@@ -4309,7 +4321,7 @@ int fe_get_option(FeEngine* h, const char* name, double* value) {
         {"p2g_grad_waves", (double)h->p2g_grad_waves}, {"g2p_grad_v", (double)h->g2p_grad_v}, {"loose_max", (double)h->loose_max},
         {"inject_till", (double)h->inject_till}, {"collide_min_y", (double)h->collide_min_y}, {"collide_type", (double)h->collide_type},
         {"prof_fine", h->prof_fine ? 1.0 : 0.0}, {"xcd_map", (double)h->S.xcd}, {"write_through", (double)h->S.wt}, {"wave_sort", (double)h->S.wsort}, {"lane_split", (double)h->S.lsplit}, {"fold_reorder", h->fold_reorder ? 1.0 : 0.0},
-        {"quad_min_units", (double)h->quad_min_units}, {"quad_max", (double)h->quad}, {"quad_fit", (double)h->quad_fit}, {"pack_units", (double)h->pack_units},
+        {"quad_min_units", (double)h->quad_min_units}, {"pgg_quad_min_units", (double)h->pgg_quad_min_units}, {"quad_max", (double)h->quad}, {"quad_fit", (double)h->quad_fit}, {"pack_units", (double)h->pack_units},
         {"wgrid_cap", (double)h->wgrid_cap}, {"wgrid_cap_g2p", (double)h->wgrid_cap_g2p}, {"wgrid_cap_pgg", (double)h->wgrid_cap_pgg}, {"ggrid_cap", (double)h->ggrid_cap}, {"threads", 0.0}};
     for (const auto& t : tab) if (!std::strcmp(name, t.n)) { *value = t.v; return 0; }
     FAIL(h, std::string("unknown option: ") + name);
