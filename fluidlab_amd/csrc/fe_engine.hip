@@ -4193,6 +4193,8 @@ FeEngine* fe_create(const FeConfig* cfg) {
         const size_t nblk = (size_t)h->nb * h->nb * h->nb;
         h->items_cap = (nblk < (size_t)h->Np ? nblk : (size_t)h->Np) + (size_t)h->Np / 64 + 2;      // item_max >= 64
         h->units_cap = h->items_cap + (size_t)h->Np / WG + 16 + 1024;                                      // work units: items (at worst one each) + tail workgroups, rounded up to 8
+        // (the slab gathers address a node of slab i as a signed 32-bit byte offset i * SLAB_N * 16 + ...: ADVICE r4)
+        if (h->items_cap * (size_t)SLAB_N * 16 >= ((size_t)1 << 31)) return fail("grid / particle count too large: the slab buffer no longer fits 32-bit byte offsets");
         if (dev_alloc(h, &h->sort_key, h->Np) || dev_alloc(h, &h->sort_rank, h->Np) || dev_alloc(h, &h->sort_cnt, ncell + 1) ||
             dev_alloc(h, &h->sort_start, ncell + 1) || dev_alloc(h, &h->sort_bcnt, ((nblk + 1 + SORT_BLK_WG - 1) / SORT_BLK_WG) * SORT_BLK_WG) || dev_alloc(h, &h->sort_partial, ((nblk + 1 + SORT_BLK_WG - 1) / SORT_BLK_WG) * PART_STRIDE) || dev_alloc(h, &h->sort_base, ((nblk + 1 + SORT_BLK_WG - 1) / SORT_BLK_WG) * SORT_BLK_WG) || dev_alloc(h, &h->sort_nact, 1) || dev_alloc(h, &h->sort_pid, h->Np) ||
             dev_alloc(h, &h->slow_dev, 1) || dev_alloc(h, &h->frame_slow_dev, 1) || dev_alloc(h, &h->slab, h->items_cap * SLAB_N, false)) return fail("");
@@ -4208,6 +4210,7 @@ FeEngine* fe_create(const FeConfig* cfg) {
         size_t budget_gib = 64;
         if (const char* e = std::getenv("FE_GRID_STORE_GIB")) { const long v = std::atol(e); if (v >= 0 && v <= 256) budget_gib = (size_t)v; }
         while (cap > 0 && (size_t)(h->L + 1) * cap * (GS_BLK * 16) > (budget_gib << 30)) cap /= 2;
+        while (cap * (size_t)(GS_BLK * 16) >= ((size_t)1 << 31)) cap /= 2;       // (store_vout: slot * 1,792 as a signed 32-bit byte offset into a frame's store)
         h->gs_cap = (int)cap;
         if (cap > 0 && (dev_alloc(h, &h->gstore, (size_t)(h->L + 1) * cap * GS_BLK, false) || dev_alloc(h, &h->gs_flag, h->L + 1) ||
                         dev_alloc(h, &h->gs_live, (size_t)(h->L + 1) * cap))) return fail("");

@@ -1,13 +1,13 @@
 #!/bin/bash
 # rocprofv3 of the 1M-particle block (scripts/prof_1m.py): kernel stats, HBM bytes and VALU instructions per launch -> gpurun_out/<tag>/r04_1m_*.txt
-TAG=${1:-m1}; OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
+TAG=${1:-m1}; export M1TAG=$TAG; OUT=$PWD/gpurun_out/$TAG; mkdir -p $OUT; export TMPDIR=/tmp
 CMD="python $PWD/scripts/prof_1m.py 4 water"
 (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $CMD > $OUT/trace.log 2>&1)
-cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/r04_kernel_stats_256_1M_water.csv; rm -rf $OUT/trace; grep n_used $OUT/trace.log
+cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_256_1M_water.csv; rm -rf $OUT/trace; grep n_used $OUT/trace.log
 for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVES"; do      # (FETCH_SIZE and WRITE_SIZE in passes of their own, as MI355X_MICROARCH.md prescribes)
   D=$OUT/pmc; (cd /tmp && timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $D -o p -- $CMD > $D.log 2>&1)
   F=$(find $D -name "*counter_collection.csv" | head -1)
-  [ -n "$F" ] && python - "$F" <<'P' | tee -a $OUT/r04_pmc_256_1M_water.txt
+  [ -n "$F" ] && python - "$F" <<'P' | tee -a $OUT/pmc_256_1M_water.txt
 import csv, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter(); seen = set()
 for r in csv.DictReader(open(sys.argv[1])):
@@ -24,6 +24,6 @@ P
 done
 python - <<'P'
 import csv
-for r in csv.reader(open('gpurun_out/m1/r04_kernel_stats_256_1M_water.csv')):
+for r in csv.reader(open('gpurun_out/'+__import__('os').environ.get('M1TAG','m1')+'/kernel_stats_256_1M_water.csv')):
     if r[0] != 'Name' and float(r[4]) > 0.5: print(r[0][:40], r[1], round(float(r[3]) / 1000, 1), 'us', r[4], '%')
 P
