@@ -618,3 +618,32 @@ def test_gathering_o_env(oracle32):
     island = te.statics.statics[0]
     outside0 = island.sdf(te.simulator.get_x(0)[mat == WATER]) > 0.005
     assert outside0.sum() > 1000 and (island.sdf(st['x'][mat == WATER])[outside0] > -0.01).all()
+
+
+def test_optional_dt_keeps_the_reference_relation_between_dt_and_substeps(oracle32):
+    """The reference fixes dt = 2e-4 and n_substeps = int(2e-3 / dt) (mpm:24, 30).  `dt` is this repository's addition for BASELINE config 5's 256^3
+    grid (the stiff materials are past their Courant limit there at 2e-4): the default is the reference's, an override keeps 2e-3 of simulated time
+    per step, and the injector dispenses `flux` particles per SUBSTEP either way (injector.py:80-105)."""
+    env = _icecream(oracle32, loss=False, max_substeps_local=None)
+    assert env.taichi_env.simulator.dt == 2e-4 and env.taichi_env.simulator.n_substeps == 10
+    kw = dict(ICE_MINI, horizon=4, inject_till=10**9)
+    env = make('IceCreamDynamic-v0', seed=0, loss=False, engine_lib=oracle32, max_substeps_local=40, ckpt_dest='cpu', dt=5e-5, **kw)
+    te = env.taichi_env
+    assert te.simulator.dt == 5e-5 and te.simulator.n_substeps == 40
+    pol = env.demo_policy()
+    te.apply_agent_action_p(pol.get_actions_p())
+    for i in range(2):
+        te.step(pol.get_action_v(i))
+    assert te.simulator.get_used().sum() == 2 * 40 * 10
+
+
+def test_work_stats_counted_form(oracle32):
+    """fe_get_work_stats_n writes min(n, FE_WORK_STATS) entries (the list grew under one symbol name); the oracle has no work lists: zeros"""
+    import ctypes as C
+    import scenarios as S
+    eng = S.make_engine(oracle32, S.water_block(n_grid=8, n_particles=64))
+    out = (C.c_longlong * 6)(*([7] * 6))
+    assert oracle32.lib.fe_get_work_stats_n(eng.h, 0, out, 4) == 0
+    assert list(out) == [0, 0, 0, 0, 7, 7]
+    ws = eng.get_work_stats(0)
+    assert ws['n_items'] == 0 and ws['n_split9_waves'] == 0 and ws['n_split3_waves'] == 0
