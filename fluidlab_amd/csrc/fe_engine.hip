@@ -55,6 +55,13 @@ __device__ __forceinline__ void wt_store4(void* base, unsigned byte_off, unsigne
 struct FrameV {
     Plane<float4> A0, A1, A2; Plane<float> a3, a4, a5; Plane<float4> B0, B1; Plane<float> b2; Plane<int> used;
     int wt;                                  // stores into this frame go through to memory (kernels that produce a whole frame)
+    // F stored compactly (round 5, option "compact_F"): of the nine words only b2 is valid.  An inviscid liquid's F is c I from its first substep on
+    // (mpm:359: F = J^(1/3) I) and the adjoint of such an F is isotropic too (IdtC^T cof(F_tmp) = det(IdtC) c^2 I), of which the next substep
+    // consumes the trace -- the SVD-free kernels read and write 4 bytes where the layout has 36: 64 bytes per particle less in k_p2g, up to 96 in
+    // k_p2g_grad, 32 in the sort.  The values are the ones the full planes held (c itself; the trace, summed where it used to be summed on reading):
+    // results are bit-identical.  1 = a state frame (b2 = c, F = c I); 2 = an adjoint frame (b2 = trace of the adjoint).  The host keeps the flags per
+    // frame / ring slot, API calls that hand F out expand the planes first (k_expand_F).
+    int iso;
 };
 __device__ __forceinline__ void pstore(const FrameV& fr, const Plane<float4>& p, int s, float4 v) {
     if (fr.wt) wt_store16(p.base, p.off + (unsigned)s * 16u, v); else p[s] = v;
@@ -65,9 +72,9 @@ __device__ __forceinline__ void pstore(const FrameV& fr, const Plane<float>& p, 
 __device__ __forceinline__ void pstore(const FrameV& fr, const Plane<int>& p, int s, int v) {
     if (fr.wt) wt_store4(p.base, p.off + (unsigned)s * 4u, (unsigned)v); else p[s] = v;
 }
-__host__ __device__ inline FrameV frame_view(float* base_, size_t Np_, int wt = 0) {
+__host__ __device__ inline FrameV frame_view(float* base_, size_t Np_, int wt = 0, int iso = 0) {
     FrameV v;
-    v.wt = wt;
+    v.wt = wt; v.iso = iso;
     char* base = (char*)base_;
     const unsigned Np = (unsigned)Np_;
     v.A0 = {base, 0u}; v.A1 = {base, 16u * Np}; v.A2 = {base, 32u * Np};
@@ -86,6 +93,12 @@ __device__ __forceinline__ void load_xvC(const FrameV& fr, int s, PState& p) {
     p.C.a[2][0] = fr.a3[s]; p.C.a[2][1] = fr.a4[s]; p.C.a[2][2] = fr.a5[s];
 }
 __device__ __forceinline__ void load_F(const FrameV& fr, int s, m3& F) {
+    if (fr.iso) {                            // (uniform) compact: c I of a state frame, or an adjoint's trace carried in the last entry
+        const float c = fr.b2[s];
+        const float d = fr.iso == 1 ? c : 0.f;
+        F.a[0][0] = d; F.a[0][1] = 0.f; F.a[0][2] = 0.f; F.a[1][0] = 0.f; F.a[1][1] = d; F.a[1][2] = 0.f; F.a[2][0] = 0.f; F.a[2][1] = 0.f; F.a[2][2] = c;
+        return;
+    }
     float4 b0 = fr.B0[s], b1 = fr.B1[s];
     F.a[0][0] = b0.x; F.a[0][1] = b0.y; F.a[0][2] = b0.z; F.a[1][0] = b0.w;
     F.a[1][1] = b1.x; F.a[1][2] = b1.y; F.a[2][0] = b1.z; F.a[2][1] = b1.w; F.a[2][2] = fr.b2[s];
@@ -103,6 +116,11 @@ __device__ __forceinline__ void store_xvC(const FrameV& fr, int s, const float x
     }
 }
 __device__ __forceinline__ void store_F(const FrameV& fr, int s, const m3& F) {
+    if (fr.iso) {                            // (uniform) compact: c of F = c I (the caller's business that it is), or the adjoint's trace
+        const float c = fr.iso == 1 ? F.a[2][2] : (F.a[0][0] + F.a[1][1]) + F.a[2][2];
+        if (fr.wt) wt_store4(fr.A0.base, fr.b2.off + (unsigned)s * 4u, __float_as_uint(c)); else fr.b2[s] = c;
+        return;
+    }
     const float4 b0 = make_float4(F.a[0][0], F.a[0][1], F.a[0][2], F.a[1][0]), b1 = make_float4(F.a[1][1], F.a[1][2], F.a[2][0], F.a[2][1]);
     if (fr.wt) {
         wt_store16(fr.A0.base, fr.B0.off + (unsigned)s * 16u, b0); wt_store16(fr.A0.base, fr.B1.off + (unsigned)s * 16u, b1);
@@ -111,6 +129,11 @@ __device__ __forceinline__ void store_F(const FrameV& fr, int s, const m3& F) {
 }
 // F and the `used` flag together (p2g: one branch for the whole group)
 __device__ __forceinline__ void store_F_used(const FrameV& fr, int s, const m3& F, int used) {
+    if (fr.iso) {
+        if (fr.wt) { wt_store4(fr.A0.base, fr.b2.off + (unsigned)s * 4u, __float_as_uint(F.a[2][2])); wt_store4(fr.A0.base, fr.used.off + (unsigned)s * 4u, (unsigned)used); }
+        else { fr.b2[s] = F.a[2][2]; fr.used[s] = used; }
+        return;
+    }
     const float4 b0 = make_float4(F.a[0][0], F.a[0][1], F.a[0][2], F.a[1][0]), b1 = make_float4(F.a[1][1], F.a[1][2], F.a[2][0], F.a[2][1]);
     if (fr.wt) {
         wt_store16(fr.A0.base, fr.B0.off + (unsigned)s * 16u, b0); wt_store16(fr.A0.base, fr.B1.off + (unsigned)s * 16u, b1);
@@ -675,6 +698,11 @@ struct GridW {            // everything a scattering particle needs of the globa
     float* g_in; float4* slab; int ncell; int* frame_slow; int* blk_flag; int* blk_list; int* blk_count; int* err; int* slow;
 };
 
+// An F that is carried over unchanged (an unused or collected particle) from a frame with full planes into a compact one: of an inviscid liquid's
+// F only the determinant is ever consumed (constitutive_eval_t), so c = det(F)^(1/3) stands for it exactly (F = I, the pool's state: c = 1)
+__device__ __forceinline__ void carry_F(const FrameV& cur, const FrameV& nxt, m3& F) {
+    if (nxt.iso == 1 && cur.iso != 1) { const float c = fe_cbrt_pos(m3_det(F)); F = m3_zero(); F.a[0][0] = F.a[1][1] = F.a[2][2] = c; }
+}
 // advect_used + process_unused_particles (mpm:304-316) + Injector.act (injector.py:80-105) for one unused slot
 __device__ __forceinline__ void unused_particle_fwd(const SimP& S, const FrameV& cur, const FrameV& nxt, int s, int pid,
                                                     const int* __restrict__ pool_idx, const AgentP& agent, const InjectP& inj, int f) {
@@ -702,6 +730,7 @@ __device__ __forceinline__ void unused_particle_fwd(const SimP& S, const FrameV&
         }
     }
     store_xvC(nxt, s, p.x, p.v, p.C);
+    carry_F(cur, nxt, p.F);
     store_F(nxt, s, p.F);
     pstore(nxt, nxt.used, s, used_next);
 }
@@ -717,6 +746,7 @@ __device__ __forceinline__ bool collector_takes(const SimP& S, const FrameV& cur
     load_F(cur, s, p.F);
     const float nowhere[3] = {-100.f, -100.f, -100.f};                    // macros.py:216
     store_xvC(nxt, s, nowhere, p.v, p.C);
+    carry_F(cur, nxt, p.F);
     store_F(nxt, s, p.F);
     cur.used[s] = 0; nxt.used[s] = 0;
     return true;
@@ -956,17 +986,18 @@ __device__ __forceinline__ void p2g_scatter_tile_split(const SimP& S, P2GPrep& q
 
 // p2g (mpm:331-378) fused with compute_F_tmp + svd, advect_used + process_unused_particles, Injector.act and,
 // on one thread, Effector.move_kernel.  WRITE=false is the backward pass' recompute of grid[f]: scatter only.
+// fiso: bit 0 = frame f's F is stored compactly, bit 1 = frame f + 1 is to be (FrameV::iso; the SVD-free kernels only)
 template <bool WRITE, bool GENERAL>
 __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, TableP T,
                                             const int* __restrict__ pool_idx, GridW G, AgentP agent, InjectP inj, int act, int f,
-                                            GridStore GS) {
+                                            GridStore GS, int fiso) {
     if (!WRITE && GS.cap > 0 && GS.flag[f]) return;      // backward: grid[f] was stored by the forward pass
     const int tid = threadIdx.x;
     if (WRITE && blockIdx.x == 0 && tid == 0 && act) {
         for (int i = 0; i < agent.n; i++) effector_move(agent.e[i], f);
     }
-    FrameV cur = frame_view(fr_cur, S.Np);
-    FrameV nxt = frame_view(fr_next, S.Np, S.wt & 1);
+    FrameV cur = frame_view(fr_cur, S.Np, 0, (!GENERAL && (fiso & 1)) ? 1 : 0);
+    FrameV nxt = frame_view(fr_next, S.Np, S.wt & 1, (!GENERAL && (fiso & 2)) ? 1 : 0);
     TL(S, 0);
     Unit un = unit_load(T, blockIdx.x);                       // this workgroup's first unit, asked for together with meta
     const int n_slots = T.meta[5];
@@ -1064,11 +1095,11 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
         }
     }
 }
-struct P2GArgs { SimP S; float* fr_cur; float* fr_next; TableP T; const int* pool_idx; GridW G; AgentP agent; InjectP inj; int act; int f; GridStore GS; };
+struct P2GArgs { SimP S; float* fr_cur; float* fr_next; TableP T; const int* pool_idx; GridW G; AgentP agent; InjectP inj; int act; int f; GridStore GS; int fiso; };
 template <bool WRITE, bool GENERAL>
-__global__ FE_KALIGN __launch_bounds__(WG, GENERAL ? 3 : 4) void k_p2g(SimP S, float* fr_cur, float* fr_next, TableP T, const int* pool_idx, GridW G, AgentP agent, InjectP inj, int act, int f, GridStore GS) { p2g_body<WRITE, GENERAL>(S, fr_cur, fr_next, T, pool_idx, G, agent, inj, act, f, GS); }
+__global__ FE_KALIGN __launch_bounds__(WG, GENERAL ? 3 : 4) void k_p2g(SimP S, float* fr_cur, float* fr_next, TableP T, const int* pool_idx, GridW G, AgentP agent, InjectP inj, int act, int f, GridStore GS, int fiso) { p2g_body<WRITE, GENERAL>(S, fr_cur, fr_next, T, pool_idx, G, agent, inj, act, f, GS, fiso); }
 template <bool WRITE, bool GENERAL>
-__global__ FE_KALIGN __launch_bounds__(WG, GENERAL ? 3 : 4) void k_p2g_b(Batch<P2GArgs> B) { const P2GArgs& A = B.a[blockIdx.y]; p2g_body<WRITE, GENERAL>(A.S, A.fr_cur, A.fr_next, A.T, A.pool_idx, A.G, A.agent, A.inj, A.act, A.f, A.GS); }
+__global__ FE_KALIGN __launch_bounds__(WG, GENERAL ? 3 : 4) void k_p2g_b(Batch<P2GArgs> B) { const P2GArgs& A = B.a[blockIdx.y]; p2g_body<WRITE, GENERAL>(A.S, A.fr_cur, A.fr_next, A.T, A.pool_idx, A.G, A.agent, A.inj, A.act, A.f, A.GS, A.fiso); }
 
 
 // agent.collide at particle level (mpm:418-422; AgentRigid.collide): every effector that carries a mesh, in order,
@@ -2480,6 +2511,8 @@ __device__ __forceinline__ void slot_p2g_grad(const SimP& S, const FrameV& cur, 
     if (G > 1 && !primary) return;              // (a split wave: once per particle)
     // the copy f -> f+1 of an unused particle passes its adjoint straight through (mpm:551)
     PState g; load_xvC(Gn, s, g); load_F(Gn, s, g.F);
+    // (compact adjoint in, full planes out: the adjoint of an isotropic F is isotropic -- a third of the trace on the diagonal)
+    if (Gn.iso == 2 && D.G.iso != 2) { const float t = g.F.a[2][2] * (1.f / 3.f); g.F.a[0][0] = g.F.a[1][1] = g.F.a[2][2] = t; }
     const int sd = D.slot(s);
     store_xvC(D.G, sd, g.x, g.v, g.C); store_F(D.G, sd, g.F);
     if (inj.on) {
@@ -2508,15 +2541,15 @@ template <bool GENERAL, int MINW>
 __device__ __forceinline__ void p2g_grad_body(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T,
                                                  const int* __restrict__ pool_idx,
                                                  const float4* __restrict__ gg_in, int* blk_count, int* slow, AgentP agent,
-                                                 InjectP inj, int act, int f, float* Gd_, const int* __restrict__ to_slot) {
+                                                 InjectP inj, int act, int f, float* Gd_, const int* __restrict__ to_slot, int fiso) {      // fiso: bit 0 frame f's F compact, bit 1 the incoming adjoint's, bit 2 the outgoing one's (FrameV::iso)
     const int tid = threadIdx.x;
     if (blockIdx.x == 0 && tid == 0) {
         *blk_count = 0;
         if (act) for (int i = agent.n - 1; i >= 0; i--) effector_move_grad(agent.e[i], f);
     }
-    FrameV cur = frame_view(fr_cur, S.Np);
-    FrameV Gn = frame_view(Gn_, S.Np), Gc = frame_view(Gc_, S.Np, S.wt & 8);
-    const GradDst D = {frame_view(Gd_, S.Np, S.wt & 8), to_slot, T.pid_of_slot};
+    FrameV cur = frame_view(fr_cur, S.Np, 0, (!GENERAL && (fiso & 1)) ? 1 : 0);
+    FrameV Gn = frame_view(Gn_, S.Np, 0, (!GENERAL && (fiso & 2)) ? 2 : 0), Gc = frame_view(Gc_, S.Np, S.wt & 8);
+    const GradDst D = {frame_view(Gd_, S.Np, S.wt & 8, (!GENERAL && (fiso & 4)) ? 2 : 0), to_slot, T.pid_of_slot};
     TL(S, 0);
     // The SVD-free build walks the scatter kernels' list, quad units included (round 4): a quad's wave has its own 8 KB tile -- the first two
     // in s_tile, the other two where the pair units keep their stash, whose part C and F are read from the frame again instead (NOSTASH) --,
@@ -2600,11 +2633,11 @@ __device__ __forceinline__ void p2g_grad_body(SimP S, float* fr_cur, float* Gn_,
         }
     }
 }
-struct P2GGradArgs { SimP S; float* fr_cur; float* Gn_; float* Gc_; TableP T; const int* pool_idx; const float4* gg_in; int* blk_count; int* slow; AgentP agent; InjectP inj; int act; int f; float* Gd_; const int* to_slot; };
+struct P2GGradArgs { SimP S; float* fr_cur; float* Gn_; float* Gc_; TableP T; const int* pool_idx; const float4* gg_in; int* blk_count; int* slow; AgentP agent; InjectP inj; int act; int f; float* Gd_; const int* to_slot; int fiso; };
 template <bool GENERAL, int MINW>
-__global__ FE_KALIGN __launch_bounds__(WG, MINW) void k_p2g_grad(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T, const int* pool_idx, const float4* gg_in, int* blk_count, int* slow, AgentP agent, InjectP inj, int act, int f, float* Gd_, const int* to_slot) { p2g_grad_body<GENERAL, MINW>(S, fr_cur, Gn_, Gc_, T, pool_idx, gg_in, blk_count, slow, agent, inj, act, f, Gd_, to_slot); }
+__global__ FE_KALIGN __launch_bounds__(WG, MINW) void k_p2g_grad(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T, const int* pool_idx, const float4* gg_in, int* blk_count, int* slow, AgentP agent, InjectP inj, int act, int f, float* Gd_, const int* to_slot, int fiso) { p2g_grad_body<GENERAL, MINW>(S, fr_cur, Gn_, Gc_, T, pool_idx, gg_in, blk_count, slow, agent, inj, act, f, Gd_, to_slot, fiso); }
 template <bool GENERAL, int MINW>
-__global__ FE_KALIGN __launch_bounds__(WG, MINW) void k_p2g_grad_b(Batch<P2GGradArgs> B) { const P2GGradArgs& A = B.a[blockIdx.y]; p2g_grad_body<GENERAL, MINW>(A.S, A.fr_cur, A.Gn_, A.Gc_, A.T, A.pool_idx, A.gg_in, A.blk_count, A.slow, A.agent, A.inj, A.act, A.f, A.Gd_, A.to_slot); }
+__global__ FE_KALIGN __launch_bounds__(WG, MINW) void k_p2g_grad_b(Batch<P2GGradArgs> B) { const P2GGradArgs& A = B.a[blockIdx.y]; p2g_grad_body<GENERAL, MINW>(A.S, A.fr_cur, A.Gn_, A.Gc_, A.T, A.pool_idx, A.gg_in, A.blk_count, A.slow, A.agent, A.inj, A.act, A.f, A.Gd_, A.to_slot, A.fiso); }
 
 
 // =========================================================================================
@@ -3080,7 +3113,7 @@ __global__ __launch_bounds__(256) void k_build_units(int nb, int N, int xcd_on, 
 struct UnitsArgs { int* bcnt; int nb, xcd_on, quad_min_units, quad_fit, pack_units, pgg_quad_min_units; const int4* items; const int2* pairs; const int* singles; const int* singles_c; const int2* blk_first; const int* active; int* meta; UnitRec* units; UnitRec* units_p; int units_cap; int2* nbr; };
 __global__ __launch_bounds__(256) void k_sort_apply(int N, size_t Np, int n_pwg, const int* __restrict__ key, const int* __restrict__ rank,
                                                     const int* __restrict__ start, const int* __restrict__ blk_base, const int* __restrict__ pid_old, int* pid_new, int* slot_of_pid,
-                                                    const float4* __restrict__ pinfo, float4* info_new, float* dst_, float* src_, UnitsArgs U, int uni) {
+                                                    const float4* __restrict__ pinfo, float4* info_new, float* dst_, float* src_, UnitsArgs U, int uni, int iso) {      // iso: the frame's F is compact (FrameV::iso): two planes less to move
     // the first SORT_UNIT_WGS workgroups (dispatched first: theirs are the longer chains): unit lists and neighbour records
     // (independent of the permutation: both only need what the block scan's two launches left)
     if ((int)blockIdx.x < SORT_UNIT_WGS) {
@@ -3095,14 +3128,17 @@ __global__ __launch_bounds__(256) void k_sort_apply(int N, size_t Np, int n_pwg,
     const int d = blk_base[kk >> 6] + start[kk] + rank[s];     // the block's first slot + the cell's start inside the block + the rank inside the cell
     const int pid = pid_old[s];
     FrameV q = frame_view(src_, Np), o = frame_view(dst_, Np);
-    const float4 a0 = q.A0[s], a1 = q.A1[s], a2 = q.A2[s], b0 = q.B0[s], b1 = q.B1[s];
+    const float4 a0 = q.A0[s], a1 = q.A1[s], a2 = q.A2[s];
+    float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+    if (!iso) { b0 = q.B0[s]; b1 = q.B1[s]; }
     const float a3 = q.a3[s], a4 = q.a4[s], a5 = q.a5[s], b2 = q.b2[s];
     const int u = q.used[s];
     pid_new[d] = pid;
     if (!uni) info_new[d] = pinfo[pid];                        // the order's slot-indexed material record (TableP::info); nobody reads it in a single-material scene
     slot_of_pid[pid] = d;
     o.A0[d] = a0; o.A1[d] = a1; o.A2[d] = a2; o.a3[d] = a3; o.a4[d] = a4; o.a5[d] = a5;
-    o.B0[d] = b0; o.B1[d] = b1; o.b2[d] = b2; o.used[d] = u;
+    if (!iso) { o.B0[d] = b0; o.B1[d] = b1; }
+    o.b2[d] = b2; o.used[d] = u;
 }
 
 // dst[s] = src[idx[s]] over all 24 planes (+ used when WITH_USED): coalesced writes, gathered 16-byte reads
@@ -3430,6 +3466,15 @@ __global__ __launch_bounds__(256) void k_loss_bwd(SimP S, float* fr, float* G_, 
     G.A0[s] = g0;
 }
 
+// a compact F (FrameV::iso) written out into the full planes: c I of a state frame (scale 1), a third of the trace on the diagonal of an adjoint
+// frame (scale 1/3: the adjoint of an isotropic F is isotropic).  Ahead of API calls that hand F out or add to it.
+__global__ __launch_bounds__(256) void k_expand_F(int N, size_t Np, float* planes, float scale) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= N) return;
+    FrameV fr = frame_view(planes, Np);
+    const float c = fr.b2[s] * scale;
+    fr.B0[s] = make_float4(c, 0.f, 0.f, 0.f); fr.B1[s] = make_float4(c, 0.f, 0.f, 0.f); fr.b2[s] = c;
+}
 // staging (caller's particle-id order, AoS) <-> planes (slot order).  mask bits: 1 x, 2 v, 4 C, 8 F, 16 used
 __global__ __launch_bounds__(256) void k_pack(int N, size_t Np, float* planes, const int* __restrict__ pid_of_slot,
                                               const float* sx, const float* sv, const float* sC, const float* sF,
@@ -3522,6 +3567,9 @@ struct FeEngine {
     std::vector<Table> tables;
     std::vector<int> tbl_of_frame;                          // [L+1]
     int gtbl[2] = {-1, -1};                                 // order of each adjoint ring slot; -1 = all zero
+    std::vector<char> fiso;                                 // [L+1] frame f's F is stored compactly (FrameV::iso = 1): written by the SVD-free k_p2g
+    bool gcompact[2] = {false, false};                      // ... and the adjoint of F in a ring slot (iso = 2): written by k_p2g_grad inside a ranged call
+    bool compact_F = true;                                  // option "compact_F"
     int tbl_bank = 0, last_sorted_f = -1;                   // two banks of table ids, one per sweep over the window (sort_frame)
     int p2g_grad_waves = 4;                                 // occupancy target of the SVD-free p2g_grad build (tuning)
     int pack_units = 2;                                     // option "pack_units": 0 never, 1 pack the scatter list (no idle halves) when that brings it back into one round, 2 whenever it is more than one round
@@ -3781,7 +3829,7 @@ int sort_frame(FeEngine* h, int f) {
     int* pid_dst = id_old == id_new ? h->sort_pid : tn.pid;
     const UnitsArgs U = {h->sort_bcnt, h->nb, h->S.xcd, h->quad_min_units, h->quad_fit, h->pack_units, h->pgg_quad_min_units, tn.items, tn.pairs, tn.singles, tn.singles + h->items_cap, tn.blk_first, tn.active, tn.meta, tn.units, tn.units_p, (int)h->units_cap, tn.nbr};
     hipLaunchKernelGGL(k_sort_apply, dim3(n_pwg + SORT_UNIT_WGS), dim3(256), 0, h->stream, h->N, (size_t)h->Np, n_pwg, h->sort_key, h->sort_rank, h->sort_start, h->sort_base,
-                       h->tables[id_old].pid, pid_dst, tn.slot_of_pid, h->pinfo, tn.info, h->spare_frame(), h->frame(f), U, h->S.uni);
+                       h->tables[id_old].pid, pid_dst, tn.slot_of_pid, h->pinfo, tn.info, h->spare_frame(), h->frame(f), U, h->S.uni, h->fiso[f] ? 1 : 0);
     if (id_old == id_new) HIPCK(h, hipMemcpyAsync(tn.pid, h->sort_pid, sizeof(int) * h->Np, hipMemcpyDeviceToDevice, h->stream));
     prof_end(h);
     std::swap(h->frame_ptr[f], h->spare_frame());
@@ -3815,6 +3863,9 @@ void launch_grid(FeEngine* h, const TableP& T, int f, const AgentP& ag) {
 #undef LAUNCH_GRID
 }
 
+// compact-F flags of a forward substep: bit 0 = frame f is stored compactly, bit 1 = frame f + 1 is going to be (the SVD-free kernel, option on)
+inline int fwd_iso(FeEngine* h, int f) { return (h->fiso[f] ? 1 : 0) | ((h->all_simple_liquid && h->compact_F) ? 2 : 0); }
+
 int substep_fwd(FeEngine* h, int f, int f_global, int act) {
     h->gs_host_valid = false;
     h->stamp++;                                           // p2g marks, grid_op reads (GridStore)
@@ -3825,14 +3876,16 @@ int substep_fwd(FeEngine* h, int f, int f_global, int act) {
     use_static_table(h, h->tbl_of_frame[f]);
     const TableP T = h->tableP(h->tbl_of_frame[f]);
     AgentP ag = agent_params(h);
+    const int fiso = fwd_iso(h, f);
     prof_begin(h, KID_P2G);
     if (h->all_simple_liquid)
         hipLaunchKernelGGL((k_p2g<true, false>), wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T,
-                           h->pool_idx, grid_w(h), ag, inj, act, f, grid_store(h));
+                           h->pool_idx, grid_w(h), ag, inj, act, f, grid_store(h), fiso);
     else
         hipLaunchKernelGGL((k_p2g<true, true>), wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T,
-                           h->pool_idx, grid_w(h), ag, inj, act, f, grid_store(h));
+                           h->pool_idx, grid_w(h), ag, inj, act, f, grid_store(h), 0);
     prof_end(h);
+    h->fiso[f + 1] = (fiso & 2) != 0;
     prof_begin(h, KID_GRID);
     launch_grid<false>(h, T, f, ag);
     prof_end(h);
@@ -3851,7 +3904,8 @@ int substep_fwd(FeEngine* h, int f, int f_global, int act) {
 
 // `next_f` >= 0: the caller goes on with substep next_f of the same sweep (fe_step_grad) -- when that one works in another particle order,
 // k_p2g_grad leaves the adjoint of frame f in that order right away (GradDst) instead of a reorder pass at the head of the next substep.
-int substep_bwd(FeEngine* h, int f, int f_global, int act, int next_f = -1) {
+// `compact_out`: the adjoint of frame f may be left with a compact F (nobody but the next substep of the same call reads it)
+int substep_bwd(FeEngine* h, int f, int f_global, int act, int next_f = -1, bool compact_out = false) {
     InjectP inj;
     if (make_inject(h, f, f_global, act, false, inj)) return 1;
     // grad[f+1] arrives in the order frame f+1 is stored in; substep f works in frame f's order
@@ -3873,10 +3927,10 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act, int next_f = -1) {
     prof_begin(h, KID_P2G_RE);
     if (h->all_simple_liquid)
         hipLaunchKernelGGL((k_p2g<false, false>), wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T,
-                           h->pool_idx, grid_w(h), ag, noinj, 0, f, grid_store(h));
+                           h->pool_idx, grid_w(h), ag, noinj, 0, f, grid_store(h), h->fiso[f] ? 1 : 0);
     else
         hipLaunchKernelGGL((k_p2g<false, true>), wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T,
-                           h->pool_idx, grid_w(h), ag, noinj, 0, f, grid_store(h));
+                           h->pool_idx, grid_w(h), ag, noinj, 0, f, grid_store(h), 0);
     prof_end(h);
     prof_begin(h, KID_GRID_KEEP);
     launch_grid<true>(h, T, f, ag);
@@ -3915,8 +3969,10 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act, int next_f = -1) {
     const bool fold = t_next != t && t_next >= 0;
     float* g_dst = fold ? h->grad_ptr[2] : h->grad(f);
     const int* to_slot = fold ? h->tables[t_next].slot_of_pid : nullptr;
+    const bool gc_out = compact_out && h->compact_F && h->all_simple_liquid;
+    const int giso = (h->fiso[f] ? 1 : 0) | (h->gcompact[(f + 1) & 1] ? 2 : 0) | (gc_out ? 4 : 0);
 #define LAUNCH_P2G_GRAD(G, W) hipLaunchKernelGGL((k_p2g_grad<G, W>), wgrid_pgg(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), \
-                           h->grad(f), T, h->pool_idx, h->gg_in, h->blk_count, h->slow_dev, ag, inj, act, f, g_dst, to_slot)
+                           h->grad(f), T, h->pool_idx, h->gg_in, h->blk_count, h->slow_dev, ag, inj, act, f, g_dst, to_slot, giso)
     if (h->all_simple_liquid) {
         if (h->p2g_grad_waves >= 4) LAUNCH_P2G_GRAD(false, 4);
         else if (h->p2g_grad_waves == 3) LAUNCH_P2G_GRAD(false, 3);
@@ -3925,6 +3981,7 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act, int next_f = -1) {
     prof_end(h);
     if (fold) std::swap(h->grad_ptr[2], h->grad_ptr[f & 1]);
     h->gtbl[f & 1] = fold ? t_next : t;
+    h->gcompact[f & 1] = gc_out;
     return 0;
 }
 
@@ -3981,7 +4038,9 @@ int substep_fwd_batch(FeEngine** hs, int B, int f, int f_global, int act) {
         use_static_table(h, h->tbl_of_frame[f]);
         const TableP T = h->tableP(h->tbl_of_frame[f]);
         const AgentP ag = agent_params(h);
-        bp.a[i] = P2GArgs{h->S, h->frame(f), h->frame(f + 1), T, h->pool_idx, grid_w(h), ag, inj, act, f, grid_store(h)};
+        const int fiso = fwd_iso(h, f);
+        bp.a[i] = P2GArgs{h->S, h->frame(f), h->frame(f + 1), T, h->pool_idx, grid_w(h), ag, inj, act, f, grid_store(h), h->all_simple_liquid ? fiso : 0};
+        h->fiso[f + 1] = h->all_simple_liquid && (fiso & 2) != 0;
         bg.a[i] = GridArgs{h->S, T, h->slab, h->g_in, h->g_out, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f, h->frame_slow_dev, statics_p(h), ag};
         bq.a[i] = G2PArgs{h->S, h->frame(f), h->frame(f + 1), T, h->g_out, h->blk_count, h->slow_dev, ag, f};
     }
@@ -4027,13 +4086,15 @@ int substep_bwd_batch(FeEngine** hs, int B, int f, int f_global, int act) {
         }
         all_stored = all_stored && h->gs_cap > 0 && h->gs_host[f] != 0;
         h->stamp++;                                       // recompute marks, then the adjoint scatter's (as in substep_bwd)
-        bp.a[i] = P2GArgs{h->S, h->frame(f), h->frame(f + 1), T, h->pool_idx, grid_w(h), ag, noinj, 0, f, grid_store(h)};
+        bp.a[i] = P2GArgs{h->S, h->frame(f), h->frame(f + 1), T, h->pool_idx, grid_w(h), ag, noinj, 0, f, grid_store(h), (h->all_simple_liquid && h->fiso[f]) ? 1 : 0};
         bg.a[i] = GridArgs{h->S, T, h->slab, h->g_in, h->g_out, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f, h->frame_slow_dev, statics_p(h), ag};
         h->stamp++;
         bq.a[i] = G2PGradArgs{h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag};
         bgg.a[i] = GridGradArgs{h->S, T, h->slab, h->g_in, h->gg_out, h->gg_in, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f, statics_p(h), ag, h->node_work, h->node_work_count};
-        bpg.a[i] = P2GGradArgs{h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->pool_idx, h->gg_in, h->blk_count, h->slow_dev, ag, inj, act, f, h->grad(f), nullptr};
+        bpg.a[i] = P2GGradArgs{h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->pool_idx, h->gg_in, h->blk_count, h->slow_dev, ag, inj, act, f, h->grad(f), nullptr,
+                               (h->fiso[f] ? 1 : 0) | (h->gcompact[(f + 1) & 1] ? 2 : 0)};      // (the batch writes full adjoints)
         h->gtbl[f & 1] = t;
+        h->gcompact[f & 1] = false;
     }
     }
     if (!all_stored) {                                    // (the kernels of an env whose frame is stored return at once)
@@ -4115,6 +4176,18 @@ int download_planes(FeEngine* h, float* planes, const int* pid, float* x, float*
     return check_async(h);
 }
 
+// API calls that hand F (or its adjoint) out, or add to it, see full planes: a compact F is written out first (FrameV::iso, k_expand_F)
+void full_F_of_frame(FeEngine* h, int f) {
+    if (!h->fiso[f]) return;
+    hipLaunchKernelGGL(k_expand_F, pgrid(h), dim3(256), 0, h->stream, h->N, (size_t)h->Np, h->frame(f), 1.f);
+    h->fiso[f] = 0;
+}
+void full_F_of_grad(FeEngine* h, int f) {
+    if (!h->gcompact[f & 1]) return;
+    hipLaunchKernelGGL(k_expand_F, pgrid(h), dim3(256), 0, h->stream, h->N, (size_t)h->Np, h->grad(f), 1.f / 3.f);
+    h->gcompact[f & 1] = false;
+}
+
 int check_device_errors(FeEngine* h) {
     int e = 0;
     HIPCK(h, hipMemcpyAsync(&e, h->err_dev, sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -4189,6 +4262,7 @@ FeEngine* fe_create(const FeConfig* cfg) {
     if (dev_alloc(h, &h->grads, 3 * h->grad_words())) return fail("");
     for (int i = 0; i < 3; i++) h->grad_ptr[i] = h->grads + (size_t)i * h->grad_words();
     h->tbl_of_frame.assign(h->L + 1, 0);
+    h->fiso.assign(h->L + 2, 0);
     {
         const size_t nblk = (size_t)h->nb * h->nb * h->nb;
         h->items_cap = (nblk < (size_t)h->Np ? nblk : (size_t)h->Np) + (size_t)h->Np / 64 + 2;      // item_max >= 64
@@ -4303,6 +4377,7 @@ int fe_set_option(FeEngine* h, const char* name, double value) {
     if (!std::strcmp(name, "wave_sort")) { h->S.wsort = value != 0; return 0; }
     if (!std::strcmp(name, "lane_split")) { if (value < 0 || value > 7) FAIL(h, "lane_split is a bit set: 1 k_p2g, 2 k_g2p_grad2, 4 k_p2g_grad"); h->S.lsplit = (int)value; return 0; }
     if (!std::strcmp(name, "fold_reorder")) { h->fold_reorder = value != 0; return 0; }
+    if (!std::strcmp(name, "compact_F")) { h->compact_F = value != 0; return 0; }
     if (!std::strcmp(name, "quad_min_units")) { h->quad_min_units = (int)value; return 0; }
     if (!std::strcmp(name, "pgg_quad_min_units")) { h->pgg_quad_min_units = (int)value; return 0; }
     if (!std::strcmp(name, "pack_units")) { if (value < 0 || value > 2) FAIL(h, "pack_units must be 0, 1 or 2"); h->pack_units = (int)value; return 0; }
@@ -4323,7 +4398,7 @@ int fe_get_option(FeEngine* h, const char* name, double* value) {
         {"sort_interval", (double)h->sort_interval}, {"item_max", (double)h->item_max}, {"grid_store", h->gs_cap > 0 ? 1.0 : 0.0},
         {"p2g_grad_waves", (double)h->p2g_grad_waves}, {"g2p_grad_v", (double)h->g2p_grad_v}, {"loose_max", (double)h->loose_max},
         {"inject_till", (double)h->inject_till}, {"collide_min_y", (double)h->collide_min_y}, {"collide_type", (double)h->collide_type},
-        {"prof_fine", h->prof_fine ? 1.0 : 0.0}, {"xcd_map", (double)h->S.xcd}, {"write_through", (double)h->S.wt}, {"wave_sort", (double)h->S.wsort}, {"lane_split", (double)h->S.lsplit}, {"fold_reorder", h->fold_reorder ? 1.0 : 0.0},
+        {"prof_fine", h->prof_fine ? 1.0 : 0.0}, {"xcd_map", (double)h->S.xcd}, {"write_through", (double)h->S.wt}, {"wave_sort", (double)h->S.wsort}, {"lane_split", (double)h->S.lsplit}, {"fold_reorder", h->fold_reorder ? 1.0 : 0.0}, {"compact_F", h->compact_F ? 1.0 : 0.0},
         {"quad_min_units", (double)h->quad_min_units}, {"pgg_quad_min_units", (double)h->pgg_quad_min_units}, {"quad_max", (double)h->quad}, {"quad_fit", (double)h->quad_fit}, {"pack_units", (double)h->pack_units},
         {"wgrid_cap", (double)h->wgrid_cap}, {"wgrid_cap_g2p", (double)h->wgrid_cap_g2p}, {"wgrid_cap_pgg", (double)h->wgrid_cap_pgg}, {"ggrid_cap", (double)h->ggrid_cap}, {"threads", 0.0}};
     for (const auto& t : tab) if (!std::strcmp(name, t.n)) { *value = t.v; return 0; }
@@ -4388,6 +4463,8 @@ int fe_init_particles(FeEngine* h, const fe_real* x, const int* used, const int*
     HIPCK(h, hipMemcpyAsync(h->pinfo, info.data(), sizeof(float4) * h->Np, hipMemcpyHostToDevice, h->stream));
     HIPCK(h, hipStreamSynchronize(h->stream));
     h->tbl_of_frame[0] = 0;
+    std::fill(h->fiso.begin(), h->fiso.end(), 0);
+    h->gcompact[0] = h->gcompact[1] = false;
     return upload_planes(h, h->frame(0), h->pid_of(0), x, v0.data(), C0.data(), F0.data(), used, 0);
 }
 
@@ -4414,7 +4491,8 @@ int fe_step_grad(FeEngine* h, int f0, int f_global0, int n, int act) {
     if (f0 < 0 || f0 + n > h->L) FAIL(h, "step frames out of range");
     // (the call's last substep leaves the adjoint of frame f0 in the order of frame f0 - 1: where the next call of the sweep starts --
     //  fluidlab's step_grad is one call per env step, and with K = n_substeps a sort lies on every call boundary)
-    for (int i = n - 1; i >= 0; i--) if (substep_bwd(h, f0 + i, f_global0 + i, act, f0 + i > 0 ? f0 + i - 1 : -1)) return 1;
+    // (i > 0: the adjoint of that frame is read by the next substep of this call and by nobody else -- its F may stay compact)
+    for (int i = n - 1; i >= 0; i--) if (substep_bwd(h, f0 + i, f_global0 + i, act, f0 + i > 0 ? f0 + i - 1 : -1, i > 0)) return 1;
     return check_async(h);
 }
 int fe_step_batch(FeEngine** hs, int n_env, int f0, int f_global0, int n, int act) {
@@ -4449,6 +4527,7 @@ int fe_step_grad_batch(FeEngine** hs, int n_env, int f0, int f_global0, int n, i
 int fe_get_frame(FeEngine* h, int f, fe_real* x, fe_real* v, fe_real* C, fe_real* F, int* used) {
     FE_ENTRY(h);
     CHECK_FRAME(h, f);
+    if (F) full_F_of_frame(h, f);
     if (download_planes(h, h->frame(f), h->pid_of(f), x, v, C, F, used)) return 1;
     return check_device_errors(h);
 }
@@ -4457,6 +4536,7 @@ int fe_set_frame(FeEngine* h, int f, const fe_real* x, const fe_real* v, const f
     CHECK_FRAME(h, f);
     h->gs_host_valid = false;
     if (h->gs_cap > 0) HIPCK(h, hipMemsetAsync(h->gs_flag + f, 0, sizeof(int), h->stream));     // the stored grid of this frame is stale now
+    if (F) h->fiso[f] = 0;                                    // (k_pack overwrites all nine words of F)
     return upload_planes(h, h->frame(f), h->pid_of(f), x, v, C, F, used, 0);
 }
 // device-pointer variants: k_unpack / k_pack work straight on the caller's device arrays, nothing crosses PCIe
@@ -4465,6 +4545,7 @@ int fe_get_frame_dev(FeEngine* h, int f, fe_real* x, fe_real* v, fe_real* C, fe_
     CHECK_FRAME(h, f);
     const int mask = (x ? 1 : 0) | (v ? 2 : 0) | (C ? 4 : 0) | (F ? 8 : 0) | (used ? 16 : 0);
     if (!mask || h->N == 0) return 0;
+    if (F) full_F_of_frame(h, f);
     hipLaunchKernelGGL(k_unpack, pgrid(h), dim3(256), 0, h->stream, h->N, (size_t)h->Np, h->frame(f), h->pid_of(f), x, v, C, F, used, mask);
     HIPCK(h, hipStreamSynchronize(h->stream));
     return check_device_errors(h);
@@ -4476,6 +4557,7 @@ int fe_set_frame_dev(FeEngine* h, int f, const fe_real* x, const fe_real* v, con
     if (h->gs_cap > 0) HIPCK(h, hipMemsetAsync(h->gs_flag + f, 0, sizeof(int), h->stream));
     const int mask = (x ? 1 : 0) | (v ? 2 : 0) | (C ? 4 : 0) | (F ? 8 : 0) | (used ? 16 : 0);
     if (!mask || h->N == 0) return 0;
+    if (F) h->fiso[f] = 0;
     hipLaunchKernelGGL(k_pack, pgrid(h), dim3(256), 0, h->stream, h->N, (size_t)h->Np, h->frame(f), h->pid_of(f), x, v, C, F, used, mask, 0);
     HIPCK(h, hipStreamSynchronize(h->stream));
     return check_async(h);
@@ -4486,6 +4568,7 @@ int fe_copy_frame(FeEngine* h, int src, int dst) {
     if (src == dst) return 0;
     HIPCK(h, hipMemcpyAsync(h->frame(dst), h->frame(src), sizeof(float) * h->frame_stride, hipMemcpyDeviceToDevice, h->stream));
     h->tbl_of_frame[dst] = h->tbl_of_frame[src];
+    h->fiso[dst] = h->fiso[src];
     h->gs_host_valid = false;
     if (h->gs_cap > 0) HIPCK(h, hipMemsetAsync(h->gs_flag + dst, 0, sizeof(int), h->stream));
     return 0;
@@ -4497,6 +4580,7 @@ int fe_copy_grad(FeEngine* h, int src, int dst) {
     if ((src & 1) != (dst & 1)) {
         HIPCK(h, hipMemcpyAsync(h->grad(dst), h->grad(src), sizeof(float) * GR_WORDS * h->Np, hipMemcpyDeviceToDevice, h->stream));
         h->gtbl[dst & 1] = h->gtbl[src & 1];
+        h->gcompact[dst & 1] = h->gcompact[src & 1];
     }
     if (src != dst) {
         FrameV s = frame_view(h->frame(src), h->Np), d = frame_view(h->frame(dst), h->Np);
@@ -4510,6 +4594,7 @@ int fe_reset_grad(FeEngine* h) {
     HIPCK(h, hipMemsetAsync(h->grad_ptr[0], 0, sizeof(float) * h->grad_words(), h->stream));
     HIPCK(h, hipMemsetAsync(h->grad_ptr[1], 0, sizeof(float) * h->grad_words(), h->stream));
     h->gtbl[0] = h->gtbl[1] = -1;
+    h->gcompact[0] = h->gcompact[1] = false;
     for (auto& E : h->effs) {
         const int Fm = h->L + 1, ad = E.p.action_dim > 0 ? E.p.action_dim : 1;
         HIPCK(h, hipMemsetAsync(E.p.gpos, 0, sizeof(float) * 3 * Fm, h->stream));
@@ -4558,11 +4643,13 @@ int fe_get_grad(FeEngine* h, int f, fe_real* gx, fe_real* gv, fe_real* gC, fe_re
     FE_ENTRY(h);
     CHECK_FRAME(h, f);
     const int t = h->gtbl[f & 1] < 0 ? 0 : h->gtbl[f & 1];
+    if (gF) full_F_of_grad(h, f);
     return download_planes(h, h->grad(f), h->tables[t].pid, gx, gv, gC, gF, nullptr);
 }
 int fe_add_grad(FeEngine* h, int f, const fe_real* gx, const fe_real* gv, const fe_real* gC, const fe_real* gF) {
     FE_ENTRY(h);
     CHECK_FRAME(h, f);
+    full_F_of_grad(h, f);                                     // (k_pack reads and rewrites all the planes)
     return upload_planes(h, h->grad(f), h->tables[grad_table_for_frame(h, f)].pid, gx, gv, gC, gF, nullptr, 1);
 }
 // device-pointer variant (a loss evaluated on the GPU hands its adjoint over without crossing PCIe)
@@ -4572,6 +4659,7 @@ int fe_add_grad_dev(FeEngine* h, int f, const fe_real* gx, const fe_real* gv, co
     const int gt = grad_table_for_frame(h, f);
     const int mask = (gx ? 1 : 0) | (gv ? 2 : 0) | (gC ? 4 : 0) | (gF ? 8 : 0);
     if (!mask || h->N == 0) return 0;
+    full_F_of_grad(h, f);
     hipLaunchKernelGGL(k_pack, pgrid(h), dim3(256), 0, h->stream, h->N, (size_t)h->Np, h->grad(f), h->tables[gt].pid, gx, gv, gC, gF, (const int*)nullptr, mask, 1);
     HIPCK(h, hipStreamSynchronize(h->stream));
     return check_async(h);

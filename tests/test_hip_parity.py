@@ -648,3 +648,81 @@ def test_grid_sizes_with_an_odd_number_of_blocks_per_axis(hiplib, oracle64, n_gr
     assert np.abs(sa['x'] - sb['x']).max() <= 2e-6 and S.rel_l2(sa['v'], sb['v']) <= 1e-4
     for k in ('gx', 'gv', 'gC', 'gF'):
         assert S.cosine(ga[k], gb[k]) >= 0.99999 and S.rel_l2(ga[k], gb[k]) <= 1e-3, (k, S.rel_l2(ga[k], gb[k]))
+
+
+def test_compact_F_of_liquids_changes_nothing(hiplib, oracle64):
+    """Option compact_F (round 5): the SVD-free kernels keep an inviscid liquid's F as the one number it is (F = c I from the first substep on,
+    mpm:359) -- k_p2g reads / writes 4 bytes of the 36, k_p2g_grad likewise and carries the adjoint's trace inside a ranged call -- and every API
+    call that hands F or its adjoint out expands the planes first.  The same trajectory with the option on and off: states of an intermediate and
+    of the last frame (F included) and all four adjoints of frame 0, through per-substep calls, a ranged call, and two ranged calls with a loss
+    seeded on the frame between them; a frame-0 F that is NOT isotropic, unused pool slots, an injected particle's F.  The option only changes
+    which bytes move: results agree to the order noise of the slow path's fp32 atomics (measured: identical), and with the fp64 oracle."""
+    rng = np.random.RandomState(5)
+    N = 5000
+    sc = S.water_block(n_grid=32, n_particles=N, seed=3, lo=0.3, hi=0.6)
+    sc['v'] = S.f32(rng.normal(0, 1.0, (N, 3)))
+    sc['F'] = S.f32(np.eye(3)[None] + rng.normal(0, 0.02, (N, 3, 3)))            # general at frame 0: only its determinant matters to a liquid
+    sc['used'] = (rng.rand(N) > 0.1).astype(np.int32)
+    cot, cot_mid = S.random_cotangent(N, seed=2), S.random_cotangent(N, seed=4)
+    n_sub, mid = 12, 7
+
+    def run(lib, opts, mode):
+        g = S.make_engine(lib, sc, options=opts)
+        S.run_forward(g, n_sub)
+        st_mid, st_end = S.get_state(g, mid), S.get_state(g, n_sub)
+        g.reset_grad()
+        g.add_grad(n_sub, cot['gx'], cot['gv'], cot['gC'], cot['gF'])
+        if mode == 'per substep':
+            for f in reversed(range(mid, n_sub)):
+                g.substep_grad(f, f, 0)
+        else:
+            g.step_grad(mid, mid, n_sub - mid, 0)
+        g.add_grad(mid, cot_mid['gx'], cot_mid['gv'], cot_mid['gC'], cot_mid['gF'])       # a loss on the frame between the two calls: F's adjoint included
+        if mode == 'per substep':
+            for f in reversed(range(mid)):
+                g.substep_grad(f, f, 0)
+        else:
+            g.step_grad(0, 0, mid, 0)
+        gx, gv, gC, gF = g.get_grad(0)
+        g.close()
+        return st_mid, st_end, dict(gx=gx, gv=gv, gC=gC, gF=gF)
+
+    base = {'sort_interval': 4}
+    ref = run(hiplib, dict(base, compact_F=0), 'ranged')
+    worst = 0.0
+    for mode in ('per substep', 'ranged'):
+        got = run(hiplib, dict(base, compact_F=1), mode)
+        for a, b in ((got[0], ref[0]), (got[1], ref[1])):
+            assert (a['used'] == b['used']).all()
+            u = b['used'] > 0
+            for k in 'xvCF':
+                m = u if k == 'F' else slice(None)
+                worst = max(worst, float(np.abs(a[k][m] - b[k][m]).max()))
+                assert np.abs(a[k][m] - b[k][m]).max() <= 1e-6 * max(1.0, np.abs(b[k][m]).max()), (mode, k)
+            # the one observable difference: an UNUSED liquid particle's general F is carried as det(F)^(1/3) I -- all that a liquid ever consumes of it
+            assert np.abs(np.linalg.det(a['F'][~u].astype(np.float64)) - np.linalg.det(b['F'][~u].astype(np.float64))).max() <= 1e-6
+        for k in ('gx', 'gv', 'gC', 'gF'):
+            worst = max(worst, S.rel_l2(got[2][k], ref[2][k]))
+            assert S.rel_l2(got[2][k], ref[2][k]) <= 2e-6, (mode, k, S.rel_l2(got[2][k], ref[2][k]))
+    used_mid = ref[0]['used'] > 0
+    Fm = ref[0]['F'][used_mid]
+    assert np.abs(Fm - Fm[:, :1, :1] * np.eye(3)).max() == 0.0                  # from the first substep on a liquid's F is c I
+    ob = run(oracle64, {}, 'per substep')
+    print('MEASURED compact_F on vs off: largest difference', worst, '| vs fp64 oracle', {k: round(S.rel_l2(ref[2][k], ob[2][k]), 8) for k in ref[2]})
+    for k in ('gx', 'gv', 'gC', 'gF'):
+        assert S.cosine(ref[2][k], ob[2][k]) >= 0.99999 and S.rel_l2(ref[2][k], ob[2][k]) <= 3e-3, k
+    assert np.abs(ref[1]['x'] - ob[1]['x']).max() <= 5e-6
+
+
+def test_compact_F_with_an_injector(hiplib, oracle64):
+    """... and through a LatteArt-like pass: pool particles wait unused (their F = I is carried, compactly, until the Injector uses them), milk is
+    injected, the loss is evaluated every step between the ranged backward calls."""
+    sc = S.latte_mini()
+    a = S.run_latte(hiplib, sc, options={'compact_F': 1, 'sort_interval': 3})
+    b = S.run_latte(hiplib, sc, options={'compact_F': 0, 'sort_interval': 3})
+    o = S.run_latte(oracle64, sc)
+    assert (a['final']['used'] == b['final']['used']).all()
+    for k in 'xvCF':
+        assert np.abs(a['final'][k] - b['final'][k]).max() <= 1e-6 * max(1.0, np.abs(b['final'][k]).max()), k
+    assert S.rel_l2(a['action_grad'], b['action_grad']) <= 1e-6 and S.rel_l2(a['step_loss'], b['step_loss']) <= 1e-6
+    assert S.cosine(a['action_grad'], o['action_grad']) >= 0.999999 and S.rel_l2(a['action_grad'], o['action_grad']) <= 1e-4
