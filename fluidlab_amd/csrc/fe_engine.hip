@@ -2510,11 +2510,19 @@ __device__ __forceinline__ void slot_p2g_grad(const SimP& S, const FrameV& cur, 
     if (used) { used_particle_p2g_grad<TILE, GENERAL, PRE, NOSTASH, G>(S, cur, Gn, Gc, s, T.info, to, gg_in, slow, tofs, pre, D, tl, gofs, primary); return; }
     if (G > 1 && !primary) return;              // (a split wave: once per particle)
     // the copy f -> f+1 of an unused particle passes its adjoint straight through (mpm:551)
-    PState g; load_xvC(Gn, s, g); load_F(Gn, s, g.F);
-    // (compact adjoint in, full planes out: the adjoint of an isotropic F is isotropic -- a third of the trace on the diagonal)
-    if (Gn.iso == 2 && D.G.iso != 2) { const float t = g.F.a[2][2] * (1.f / 3.f); g.F.a[0][0] = g.F.a[1][1] = g.F.a[2][2] = t; }
+    // Compact adjoints (FrameV::iso = 2) are a matter of the USED slots: what an unused particle passes on is whatever was seeded on it -- nothing says
+    // that is isotropic --, so the slots of particles unused in an adjoint's frame always hold all nine words.  The incoming slot is such a slot unless
+    // this very substep injects the particle (then frame f + 1 has it in use and the used path of substep f + 1 wrote the slot: a third of the trace
+    // on the diagonal is that adjoint exactly, the adjoint of an isotropic F being isotropic).
+    bool injected = false;
+    if (inj.on) { const int j = pool_idx[T.pid_of_slot[s]] - inj.act_id; injected = j >= 0 && j < inj.flux; }
+    FrameV Gn_f = Gn, Dg_f = D.G;
+    if (!injected) Gn_f.iso = 0;
+    Dg_f.iso = 0;
+    PState g; load_xvC(Gn, s, g); load_F(Gn_f, s, g.F);
+    if (Gn_f.iso == 2) { const float t = g.F.a[2][2] * (1.f / 3.f); g.F.a[0][0] = g.F.a[1][1] = g.F.a[2][2] = t; }
     const int sd = D.slot(s);
-    store_xvC(D.G, sd, g.x, g.v, g.C); store_F(D.G, sd, g.F);
+    store_xvC(D.G, sd, g.x, g.v, g.C); store_F(Dg_f, sd, g.F);
     if (inj.on) {
         int j = pool_idx[T.pid_of_slot[s]] - inj.act_id;
         if (j >= 0 && j < inj.flux) {                      // x[f+1,pid] = offset + pos[f] + R(q) inject_p
@@ -3468,9 +3476,13 @@ __global__ __launch_bounds__(256) void k_loss_bwd(SimP S, float* fr, float* G_, 
 
 // a compact F (FrameV::iso) written out into the full planes: c I of a state frame (scale 1), a third of the trace on the diagonal of an adjoint
 // frame (scale 1/3: the adjoint of an isotropic F is isotropic).  Ahead of API calls that hand F out or add to it.
-__global__ __launch_bounds__(256) void k_expand_F(int N, size_t Np, float* planes, float scale) {
+// `used` (adjoint frames): the flags of the frame the adjoint belongs to -- only the used slots are compact, an unused particle's adjoint is kept in full
+// (slot_p2g_grad); they are indexed by the FRAME's slots, which the adjoint's slot reaches through its own id table when the two orders differ.
+__global__ __launch_bounds__(256) void k_expand_F(int N, size_t Np, float* planes, float scale, const int* __restrict__ used, const int* __restrict__ pid_of_slot,
+                                                  const int* __restrict__ frame_slot_of_pid) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= N) return;
+    if (used && used[frame_slot_of_pid ? frame_slot_of_pid[pid_of_slot[s]] : s] == 0) return;
     FrameV fr = frame_view(planes, Np);
     const float c = fr.b2[s] * scale;
     fr.B0[s] = make_float4(c, 0.f, 0.f, 0.f); fr.B1[s] = make_float4(c, 0.f, 0.f, 0.f); fr.b2[s] = c;
@@ -4179,12 +4191,14 @@ int download_planes(FeEngine* h, float* planes, const int* pid, float* x, float*
 // API calls that hand F (or its adjoint) out, or add to it, see full planes: a compact F is written out first (FrameV::iso, k_expand_F)
 void full_F_of_frame(FeEngine* h, int f) {
     if (!h->fiso[f]) return;
-    hipLaunchKernelGGL(k_expand_F, pgrid(h), dim3(256), 0, h->stream, h->N, (size_t)h->Np, h->frame(f), 1.f);
+    hipLaunchKernelGGL(k_expand_F, pgrid(h), dim3(256), 0, h->stream, h->N, (size_t)h->Np, h->frame(f), 1.f, (const int*)nullptr, (const int*)nullptr, (const int*)nullptr);
     h->fiso[f] = 0;
 }
 void full_F_of_grad(FeEngine* h, int f) {
     if (!h->gcompact[f & 1]) return;
-    hipLaunchKernelGGL(k_expand_F, pgrid(h), dim3(256), 0, h->stream, h->N, (size_t)h->Np, h->grad(f), 1.f / 3.f);
+    const int gt = h->gtbl[f & 1] < 0 ? h->tbl_of_frame[f] : h->gtbl[f & 1], ft = h->tbl_of_frame[f];
+    hipLaunchKernelGGL(k_expand_F, pgrid(h), dim3(256), 0, h->stream, h->N, (size_t)h->Np, h->grad(f), 1.f / 3.f, (const int*)frame_view(h->frame(f), h->Np).used.ptr(),
+                       (const int*)h->tables[gt].pid, gt == ft ? (const int*)nullptr : (const int*)h->tables[ft].slot_of_pid);
     h->gcompact[f & 1] = false;
 }
 
