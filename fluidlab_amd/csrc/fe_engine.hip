@@ -984,19 +984,84 @@ __device__ __forceinline__ void p2g_scatter_tile_split(const SimP& S, P2GPrep& q
     else p2g_scatter_tile<QUAD, 9>(S, q, in_tile, lb, aofs, ls.gofs);
 }
 
+// The gather of g2p (mpm:400-417) for one particle: the new velocity and C from its 27 nodes.  TILE: v_out staged in LDS (3 planes from word
+// `tofs`) -- of s_gtile, or (ALIAS: k_g2p_p2g) of the bytes the unit's scatter tile is about to occupy.
+// ROLLED: the nine columns one after the other (k_g2p_p2g's path for drifted particles: unrolled, the 27 float4 loads of the global form are asked for
+// together -- 108 registers in a kernel that has none to spare; the sums are the same sums in the same order)
+template <bool TILE, bool ALIAS, bool ROLLED = false>
+__device__ __forceinline__ void g2p_gather(const SimP& S, int lb, const Stencil& st, const float4* __restrict__ g_out, int tofs, float nv[3], m3& nC) {
+    const float* gt = ALIAS ? (const float*)s_acc : s_gtile;
+    nv[0] = nv[1] = nv[2] = 0.f;
+    const float c4 = 4.f * S.inv_dx;
+    // new_C[a][b] = c4 sum W g[a] (o_b - fx_b) = c4 (M[a][b] - fx_b new_v[a]) with M[a][b] = sum W g[a] o_b; o_0 = i and o_1 = j are
+    // constant over the inner k loop, so the per-node work is the three products W g[a] and two partial sums.
+    m3 M = m3_zero();
+#pragma unroll ROLLED ? 1 : 9
+    for (int ij = 0; ij < 9; ij++) {
+        const int i = ij / 3, j = ij - 3 * i;
+        const float wij = STW(st, i, 0) * STW(st, j, 1);
+        float T[3] = {0.f, 0.f, 0.f}, Tz[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) {
+            const float weight = wij * st.w[kk][2];
+            float g0, g1, g2;
+            if (TILE) {
+                const int l = tofs + lb + (i * TILE_T + j) * TILE_T + kk;
+                g0 = gt[l]; g1 = gt[TILE_N + l]; g2 = gt[2 * TILE_N + l];
+            } else {
+                float4 gv = g_out[cell_addr(st.base[0] + i, st.base[1] + j, st.base[2] + kk, S.nb)];
+                g0 = gv.x; g1 = gv.y; g2 = gv.z;
+            }
+            const float gw[3] = {weight * g0, weight * g1, weight * g2};
+#pragma unroll
+            for (int a = 0; a < 3; a++) { T[a] += gw[a]; if (kk > 0) Tz[a] += (float)kk * gw[a]; }
+        }
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            nv[a] += T[a];
+            M.a[a][0] += (float)i * T[a]; M.a[a][1] += (float)j * T[a]; M.a[a][2] += Tz[a];
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) nC.a[a][b] = c4 * (M.a[a][b] - st.fx[b] * nv[a]);
+}
+// (ALIAS: into the bytes of the unit's scatter tile, from word `tofs` -- k_g2p_p2g)
+template <bool ALIAS = false>
+__device__ __forceinline__ void load_tile3(const TileO& to, const SimP& S, const float4* __restrict__ src, const PairCtx& pc, int tofs_alias = 0) {
+    if (!pc.live) return;
+    float* gt = ALIAS ? (float*)s_acc : s_gtile;
+    const int tofs = ALIAS ? tofs_alias : pc.ti * 3 * TILE_N;
+    for (int l = pc.t0; l < TILE_N; l += pc.nth) {
+        int i, j, k;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tile_node(to, l, S.n, i, j, k)) v = src[cell_addr(i, j, k, S.nb)];
+        gt[tofs + l] = v.x; gt[tofs + TILE_N + l] = v.y; gt[tofs + 2 * TILE_N + l] = v.z;
+    }
+}
+
 // p2g (mpm:331-378) fused with compute_F_tmp + svd, advect_used + process_unused_particles, Injector.act and,
 // on one thread, Effector.move_kernel.  WRITE=false is the backward pass' recompute of grid[f]: scatter only.
 // fiso: bit 0 = frame f's F is stored compactly, bit 1 = frame f + 1 is to be (FrameV::iso; the SVD-free kernels only)
-template <bool WRITE, bool GENERAL>
+// FUSED (k_g2p_p2g, option "fuse_g2p"): the unit first does the g2p of substep f - 1 for its particles -- v_out of that substep gathered into the bytes
+// its scatter tile is about to occupy, x' v' C' written to frame f and kept in registers -- and goes on with them: frame f's 60 bytes per particle are
+// not read back, and a substep is two launches instead of three.  FU names what the gather needs.  The host fuses where nothing comes between the two:
+// no sort at f, no mesh effector acting on particles, no rigid bodies (substep_fwd).
+struct FuseP { float* fr_prev; const float4* g_out; int* slow; int* blk_count_prev; };
+template <bool WRITE, bool GENERAL, bool FUSED = false>
 __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, TableP T,
                                             const int* __restrict__ pool_idx, GridW G, AgentP agent, InjectP inj, int act, int f,
-                                            GridStore GS, int fiso) {
+                                            GridStore GS, int fiso, FuseP FU = FuseP{nullptr, nullptr, nullptr, nullptr}) {
     if (!WRITE && GS.cap > 0 && GS.flag[f]) return;      // backward: grid[f] was stored by the forward pass
     const int tid = threadIdx.x;
     if (WRITE && blockIdx.x == 0 && tid == 0 && act) {
         for (int i = 0; i < agent.n; i++) effector_move(agent.e[i], f);
     }
+    if (FUSED && blockIdx.x == 0 && tid == 0) *FU.blk_count_prev = 0;      // (g2p_body: grid_op of substep f - 1 was the last reader of its list; this substep's has a counter of its own)
     FrameV cur = frame_view(fr_cur, S.Np, 0, (!GENERAL && (fiso & 1)) ? 1 : 0);
+    FrameV curw = frame_view(fr_cur, S.Np, 0);               // (FUSED: the g2p part's stores; plain ones, as k_g2p's are by default -- option write_through)
+    FrameV prev = frame_view(FUSED ? FU.fr_prev : fr_cur, S.Np);
     FrameV nxt = frame_view(fr_next, S.Np, S.wt & 1, (!GENERAL && (fiso & 2)) ? 1 : 0);
     TL(S, 0);
     Unit un = unit_load(T, blockIdx.x);                       // this workgroup's first unit, asked for together with meta
@@ -1013,9 +1078,11 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
             const int aofs = pc.ti * 4 * TILE_N;                 // (doubles of a pair's tile, words of a quad's)
             TL(S, 1);
             const int nbr_entry = neighbour_entry(T.blk_slot, S.nb, it.x);      // (in flight together with the particle loads)
-            if (pc.quad) { if (pc.live) for (int l = pc.t0; l < TILE_N; l += 64) ((int4*)((int*)s_acc + aofs))[l] = make_int4(0, 0, 0, 0); }      // (16 bytes per lane and store)
-            else if (pc.live) for (int l = pc.t0; l < 4 * TILE_N; l += pc.nth) s_acc[aofs + l] = 0.0;
-            unit_sync(pc.quad);
+            auto zero_tile = [&]() {
+                if (pc.quad) { if (pc.live) for (int l = pc.t0; l < TILE_N; l += 64) ((int4*)((int*)s_acc + aofs))[l] = make_int4(0, 0, 0, 0); }      // (16 bytes per lane and store)
+                else if (pc.live) for (int l = pc.t0; l < 4 * TILE_N; l += pc.nth) s_acc[aofs + l] = 0.0;
+            };
+            if (!FUSED) { zero_tile(); unit_sync(pc.quad); }
             FixScale fs_p = {1.f, 1.f}, fs_m = {1.f, 1.f};
             bool wshell = false;                                 // (quad units) some particle of the wave reaches its tile's outer shell
             {                                                    // one pass: an item is <= 128 particles, one per lane of the half
@@ -1023,7 +1090,7 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
                 //  out of the frame: that decision has side effects and belongs to one lane)
                 const int wbase = pc.quad ? 0 : (pc.i & 64);         // this wave's first particle within the item
                 const int cnt = __builtin_amdgcn_readfirstlane(min(64, max(0, it.z - wbase)));
-                const LaneSplit ls = lane_split(cnt, (S.lsplit & 1) != 0 && !(WRITE && act && agent.collector));
+                const LaneSplit ls = lane_split(cnt, (S.lsplit & 1) != 0 && !(WRITE && !FUSED && act && agent.collector));      // (FUSED: never with a collector, fusable_fwd)
                 const int i = wbase + ls.p, s = it.y + i;
                 const bool has = ls.ok && i < it.z;
                 // (`used` is re-read rather than implied by the work list so host edits of a frame cannot desynchronise it)
@@ -1032,10 +1099,33 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
                 const int s_ld = has ? s : it.y;
                 const int uflag = cur.used[s_ld];
                 P2GRaw raw;
-                p2g_load(S, cur, s_ld, T.info, raw);
+                if (FUSED) {
+                    // the g2p of substep f - 1 (g2p_body / slot_g2p) for this lane's particle; a split wave's lanes all gather their particle's 27 nodes
+                    const int gofs_w = pc.quad ? aofs : 2 * aofs;          // the tile's first word (a pair's tile is counted in doubles)
+                    const int uprev = prev.used[s_ld];
+                    const float4 a0 = prev.A0[s_ld];
+                    load_F(cur, s_ld, raw.p.F);
+                    raw.info = load_info(S, T.info, s_ld);
+                    load_tile3<true>(to, S, FU.g_out, pc, gofs_w);
+                    unit_sync(pc.quad);
+                    const float xp[3] = {a0.x, a0.y, a0.z};
+                    Stencil stp;
+                    stencil_make(xp, S.inv_dx, stp);
+                    if (has && uprev != 0 && stencil_inside(stp, S.n)) {      // (outside: counted in err by the p2g of substep f - 1, frame f keeps what it held)
+                        const int lbp = tile_base(to, stp);
+                        if (lbp >= 0) g2p_gather<true, true>(S, lbp, stp, FU.g_out, gofs_w, raw.p.v, raw.p.C);
+                        else { if (ls.primary) atomicAdd(FU.slow, 1); g2p_gather<false, true, true>(S, 0, stp, FU.g_out, 0, raw.p.v, raw.p.C); }
+#pragma unroll
+                        for (int a = 0; a < 3; a++) raw.p.x[a] = xp[a] + S.dt * raw.p.v[a];
+                        if (ls.primary) store_xvC(curw, s, raw.p.x, raw.p.v, raw.p.C);
+                    } else load_xvC(cur, s_ld, raw.p);                        // an unused slot, or a particle that entered in substep f - 1 (Injector.act): frame f holds its state
+                    unit_sync(pc.quad);                                       // every gather of the tile is through: its bytes become the scatter tile
+                    zero_tile();
+                    unit_sync(pc.quad);
+                } else p2g_load(S, cur, s_ld, T.info, raw);
                 bool used = has && uflag != 0;
                 bool taken = false;
-                if (WRITE && used && act && agent.collector) { taken = collector_takes(S, cur, nxt, s, T.info, agent); used = !taken; }
+                if (WRITE && !FUSED && used && act && agent.collector) { taken = collector_takes(S, cur, nxt, s, T.info, agent); used = !taken; }
                 P2GPrep q;
                 q.inside = false;
                 int lb = -1;
@@ -1085,10 +1175,26 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
         } else {
             const int s = un.a.y + tid;
             if (s < S.N) {
+                P2GRaw raw;
+                bool have = false;                                       // (FUSED) x v C of frame f are in raw
+                if (FUSED && prev.used[s]) {
+                    const float4 a0 = prev.A0[s];
+                    const float xp[3] = {a0.x, a0.y, a0.z};
+                    Stencil stp;
+                    stencil_make(xp, S.inv_dx, stp);
+                    if (stencil_inside(stp, S.n)) {
+                        g2p_gather<false, true, true>(S, 0, stp, FU.g_out, 0, raw.p.v, raw.p.C);
+#pragma unroll
+                        for (int a = 0; a < 3; a++) raw.p.x[a] = xp[a] + S.dt * raw.p.v[a];
+                        store_xvC(curw, s, raw.p.x, raw.p.v, raw.p.C);
+                        have = true;
+                    }
+                }
                 if (cur.used[s]) {
-                    if (WRITE && act && agent.collector && collector_takes(S, cur, nxt, s, T.info, agent)) continue;
+                    if (WRITE && !FUSED && act && agent.collector && collector_takes(S, cur, nxt, s, T.info, agent)) continue;
                     P2GPrep q;
-                    p2g_prepare<WRITE, GENERAL>(S, cur, nxt, s, T.info, G, q);
+                    if (FUSED && have) { load_F(cur, s, raw.p.F); raw.info = load_info(S, T.info, s); p2g_compute<WRITE, GENERAL>(S, nxt, s, raw, G, q); }
+                    else p2g_prepare<WRITE, GENERAL>(S, cur, nxt, s, T.info, G, q);
                     if (q.inside) p2g_scatter_global(S, q, G, GS, T.blk_slot);
                 } else if (WRITE) unused_particle_fwd(S, cur, nxt, s, T.pid_of_slot[s], pool_idx, agent, inj, f);
             }
@@ -1098,6 +1204,9 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
 struct P2GArgs { SimP S; float* fr_cur; float* fr_next; TableP T; const int* pool_idx; GridW G; AgentP agent; InjectP inj; int act; int f; GridStore GS; int fiso; };
 template <bool WRITE, bool GENERAL>
 __global__ FE_KALIGN __launch_bounds__(WG, GENERAL ? 3 : 4) void k_p2g(SimP S, float* fr_cur, float* fr_next, TableP T, const int* pool_idx, GridW G, AgentP agent, InjectP inj, int act, int f, GridStore GS, int fiso) { p2g_body<WRITE, GENERAL>(S, fr_cur, fr_next, T, pool_idx, G, agent, inj, act, f, GS, fiso); }
+// substep f's p2g with the g2p of substep f - 1 in front of it (p2g_body, FUSED)
+template <bool GENERAL>
+__global__ FE_KALIGN __launch_bounds__(WG, GENERAL ? 3 : 4) void k_g2p_p2g(SimP S, float* fr_cur, float* fr_next, TableP T, const int* pool_idx, GridW G, AgentP agent, InjectP inj, int act, int f, GridStore GS, int fiso, FuseP FU) { p2g_body<true, GENERAL, true>(S, fr_cur, fr_next, T, pool_idx, G, agent, inj, act, f, GS, fiso, FU); }
 template <bool WRITE, bool GENERAL>
 __global__ FE_KALIGN __launch_bounds__(WG, GENERAL ? 3 : 4) void k_p2g_b(Batch<P2GArgs> B) { const P2GArgs& A = B.a[blockIdx.y]; p2g_body<WRITE, GENERAL>(A.S, A.fr_cur, A.fr_next, A.T, A.pool_idx, A.G, A.agent, A.inj, A.act, A.f, A.GS, A.fiso); }
 
@@ -1348,62 +1457,19 @@ template <bool KEEP, bool STATICS, bool DYN>
 __global__ FE_KALIGN __launch_bounds__(256, (STATICS || DYN) ? 2 : 4) void k_grid_b(Batch<GridArgs> B) { const GridArgs& A = B.a[blockIdx.y]; grid_body<KEEP, STATICS, DYN>(A.S, A.T, A.slab, A.g_in, A.g_out, A.blk_list, A.blk_count, A.blk_flag, A.GS, A.f, A.frame_slow, A.ST, A.agent); }
 
 
-// g2p (mpm:400-426) + advect_kernel (mpm:497-505) for one used particle; TILE: v_out staged in LDS (3 planes)
+// g2p (mpm:400-426) + advect_kernel (mpm:497-505) for one used particle
 template <bool TILE, bool COLLIDE>
 __device__ __forceinline__ void used_particle_g2p(const SimP& S, const FrameV& cur, const FrameV& nxt, int s,
                                                   int lb, const Stencil& st, const float x[3],
                                                   const float4* __restrict__ g_out, const AgentP& agent, int f, int tofs = 0) {
-    float nv[3] = {0.f, 0.f, 0.f};
-    m3 nC = m3_zero();
-    const float c4 = 4.f * S.inv_dx;
-    // new_C[a][b] = c4 sum W g[a] (o_b - fx_b) = c4 (M[a][b] - fx_b new_v[a]) with M[a][b] = sum W g[a] o_b; o_0 = i and o_1 = j are
-    // constant over the inner k loop, so the per-node work is the three products W g[a] and two partial sums.
-    m3 M = m3_zero();
-#pragma unroll
-    for (int ij = 0; ij < 9; ij++) {
-        const int i = ij / 3, j = ij - 3 * i;
-        const float wij = STW(st, i, 0) * STW(st, j, 1);
-        float T[3] = {0.f, 0.f, 0.f}, Tz[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kk = 0; kk < 3; kk++) {
-            const float weight = wij * st.w[kk][2];
-            float g0, g1, g2;
-            if (TILE) {
-                const int l = tofs + lb + (i * TILE_T + j) * TILE_T + kk;
-                g0 = s_gtile[l]; g1 = s_gtile[TILE_N + l]; g2 = s_gtile[2 * TILE_N + l];
-            } else {
-                float4 gv = g_out[cell_addr(st.base[0] + i, st.base[1] + j, st.base[2] + kk, S.nb)];
-                g0 = gv.x; g1 = gv.y; g2 = gv.z;
-            }
-            const float gw[3] = {weight * g0, weight * g1, weight * g2};
-#pragma unroll
-            for (int a = 0; a < 3; a++) { T[a] += gw[a]; if (kk > 0) Tz[a] += (float)kk * gw[a]; }
-        }
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-            nv[a] += T[a];
-            M.a[a][0] += (float)i * T[a]; M.a[a][1] += (float)j * T[a]; M.a[a][2] += Tz[a];
-        }
-    }
-#pragma unroll
-    for (int a = 0; a < 3; a++)
-#pragma unroll
-        for (int b = 0; b < 3; b++) nC.a[a][b] = c4 * (M.a[a][b] - st.fx[b] * nv[a]);
+    float nv[3];
+    m3 nC;
+    g2p_gather<TILE, false>(S, lb, st, g_out, tofs, nv, nC);
     if (COLLIDE) agent.hit[(size_t)f * S.Np + s] = agent_collide_particle<false>(S, agent, f, x, nv) ? 1 : 0;      // mpm:418-422; the flag steers the backward pass
     float xn[3] = {x[0] + S.dt * nv[0], x[1] + S.dt * nv[1], x[2] + S.dt * nv[2]};
     store_xvC(nxt, s, xn, nv, nC);
 }
 
-__device__ __forceinline__ void load_tile3(const TileO& to, const SimP& S, const float4* __restrict__ src, const PairCtx& pc) {
-    if (!pc.live) return;
-    const int tofs = pc.ti * 3 * TILE_N;
-    for (int l = pc.t0; l < TILE_N; l += pc.nth) {
-        int i, j, k;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tile_node(to, l, S.n, i, j, k)) v = src[cell_addr(i, j, k, S.nb)];
-        s_gtile[tofs + l] = v.x; s_gtile[tofs + TILE_N + l] = v.y; s_gtile[tofs + 2 * TILE_N + l] = v.z;
-    }
-}
 __device__ __forceinline__ void load_tile4(const TileO& to, const SimP& S, const float4* __restrict__ src, const PairCtx& pc) {
     if (!pc.live) return;
     const int tofs = pc.ti * 4 * TILE_N;
@@ -3549,8 +3615,8 @@ __global__ __launch_bounds__(256) void k_stats_count(int ncells, unsigned char* 
 // =========================================================================================
 // host side
 // =========================================================================================
-enum { KID_P2G = 0, KID_GRID, KID_G2P, KID_P2G_RE, KID_GRID_KEEP, KID_G2P_GRAD, KID_GRID_GRAD, KID_P2G_GRAD, KID_SORT, KID_REORDER_GRAD, KID_SORT_COUNT, KID_SORT_SCAN, KID_SORT_ACTIVE, KID_SORT_PERM, KID_COUNT };
-static const char* KNAMES[KID_COUNT] = {"p2g", "grid_op", "g2p", "p2g_recompute", "grid_op_keep", "g2p_grad", "grid_op_grad", "p2g_grad", "sort", "reorder_grad", "sort_count", "sort_scan", "sort_active", "sort_perm"};
+enum { KID_P2G = 0, KID_GRID, KID_G2P, KID_P2G_RE, KID_GRID_KEEP, KID_G2P_GRAD, KID_GRID_GRAD, KID_P2G_GRAD, KID_SORT, KID_REORDER_GRAD, KID_SORT_COUNT, KID_SORT_SCAN, KID_SORT_ACTIVE, KID_SORT_PERM, KID_G2P_P2G, KID_COUNT };
+static const char* KNAMES[KID_COUNT] = {"p2g", "grid_op", "g2p", "p2g_recompute", "grid_op_keep", "g2p_grad", "grid_op_grad", "p2g_grad", "sort", "reorder_grad", "sort_count", "sort_scan", "sort_active", "sort_perm", "g2p_p2g"};
 
 struct EffHost {
     EffP p;
@@ -3582,6 +3648,7 @@ struct FeEngine {
     std::vector<char> fiso;                                 // [L+1] frame f's F is stored compactly (FrameV::iso = 1): written by the SVD-free k_p2g
     bool gcompact[2] = {false, false};                      // ... and the adjoint of F in a ring slot (iso = 2): written by k_p2g_grad inside a ranged call
     bool compact_F = true;                                  // option "compact_F"
+    bool fuse_g2p = false;                                  // option "fuse_g2p": inside a fe_step call the g2p of a substep runs at the head of the next substep's p2g launch (k_g2p_p2g)
     int tbl_bank = 0, last_sorted_f = -1;                   // two banks of table ids, one per sweep over the window (sort_frame)
     int p2g_grad_waves = 4;                                 // occupancy target of the SVD-free p2g_grad build (tuning)
     int pack_units = 2;                                     // option "pack_units": 0 never, 1 pack the scatter list (no idle halves) when that brings it back into one round, 2 whenever it is more than one round
@@ -3857,8 +3924,11 @@ GridStore grid_store(FeEngine* h) {
     return g;
 }
 
-GridW grid_w(FeEngine* h) {
-    GridW g; g.g_in = h->g_in; g.slab = h->slab; g.ncell = h->S.ncell; g.frame_slow = h->frame_slow_dev; g.blk_flag = h->blk_flag; g.blk_list = h->blk_list; g.blk_count = h->blk_count; g.err = h->err_dev; g.slow = h->slow_dev;
+// The length of substep f's dynamic block list: two counters, by the parity of f -- k_g2p_p2g adds to substep f's list and, in the same launch, clears
+// the one grid_op of substep f - 1 has just read (g2p_body's reset).  Every window of launches that uses a counter ends with the kernel that clears it.
+inline int* bcount(FeEngine* h, int f) { return h->blk_count + (f & 1); }
+GridW grid_w(FeEngine* h, int f) {
+    GridW g; g.g_in = h->g_in; g.slab = h->slab; g.ncell = h->S.ncell; g.frame_slow = h->frame_slow_dev; g.blk_flag = h->blk_flag; g.blk_list = h->blk_list; g.blk_count = bcount(h, f); g.err = h->err_dev; g.slow = h->slow_dev;
     return g;
 }
 
@@ -3869,7 +3939,7 @@ inline bool particle_collide(FeEngine* h) { return h->has_mesh_effector && (h->c
 template <bool KEEP>
 void launch_grid(FeEngine* h, const TableP& T, int f, const AgentP& ag) {
 #define LAUNCH_GRID(ST_, DY_) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid<KEEP, ST_, DY_>), ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, h->g_out, \
-                           h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f, h->frame_slow_dev, statics_p(h), ag)
+                           h->blk_list, bcount(h, f), h->blk_flag, grid_store(h), f, h->frame_slow_dev, statics_p(h), ag)
     if (grid_collide(h)) { if (h->statics_host.empty()) LAUNCH_GRID(false, true); else LAUNCH_GRID(true, true); }
     else { if (h->statics_host.empty()) LAUNCH_GRID(false, false); else LAUNCH_GRID(true, false); }
 #undef LAUNCH_GRID
@@ -3878,7 +3948,13 @@ void launch_grid(FeEngine* h, const TableP& T, int f, const AgentP& ag) {
 // compact-F flags of a forward substep: bit 0 = frame f is stored compactly, bit 1 = frame f + 1 is going to be (the SVD-free kernel, option on)
 inline int fwd_iso(FeEngine* h, int f) { return (h->fiso[f] ? 1 : 0) | ((h->all_simple_liquid && h->compact_F) ? 2 : 0); }
 
-int substep_fwd(FeEngine* h, int f, int f_global, int act) {
+// Can the g2p of substep f - 1 run at the head of substep f's p2g launch (k_g2p_p2g)?  Nothing may come between the two: no sort of frame f, no
+// effector mesh acting on the gathered velocities, no rigid-body pass over frame f, no collector reading the positions (option "fuse_g2p").
+inline bool fusable_fwd(FeEngine* h, int f) {
+    return h->fuse_g2p && f > 0 && !(h->sort_interval > 0 && f % h->sort_interval == 0) && !particle_collide(h) && !h->has_rigid && !h->has_collector;
+}
+// `g2p_pending`: the caller's last substep left its g2p to this one (fusable_fwd(h, f) held);  `defer_g2p`: leave this substep's to the next one
+int substep_fwd(FeEngine* h, int f, int f_global, int act, bool g2p_pending = false, bool defer_g2p = false) {
     h->gs_host_valid = false;
     h->stamp++;                                           // p2g marks, grid_op reads (GridStore)
     InjectP inj;
@@ -3889,23 +3965,36 @@ int substep_fwd(FeEngine* h, int f, int f_global, int act) {
     const TableP T = h->tableP(h->tbl_of_frame[f]);
     AgentP ag = agent_params(h);
     const int fiso = fwd_iso(h, f);
+    if (g2p_pending) {
+        const FuseP FU = {h->frame(f - 1), h->g_out, h->slow_dev, bcount(h, f - 1)};
+        prof_begin(h, KID_G2P_P2G);
+        if (h->all_simple_liquid)
+            hipLaunchKernelGGL((k_g2p_p2g<false>), wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T,
+                               h->pool_idx, grid_w(h, f), ag, inj, act, f, grid_store(h), fiso, FU);
+        else
+            hipLaunchKernelGGL((k_g2p_p2g<true>), wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T,
+                               h->pool_idx, grid_w(h, f), ag, inj, act, f, grid_store(h), 0, FU);
+        prof_end(h);
+    } else {
     prof_begin(h, KID_P2G);
     if (h->all_simple_liquid)
         hipLaunchKernelGGL((k_p2g<true, false>), wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T,
-                           h->pool_idx, grid_w(h), ag, inj, act, f, grid_store(h), fiso);
+                           h->pool_idx, grid_w(h, f), ag, inj, act, f, grid_store(h), fiso);
     else
         hipLaunchKernelGGL((k_p2g<true, true>), wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T,
-                           h->pool_idx, grid_w(h), ag, inj, act, f, grid_store(h), 0);
+                           h->pool_idx, grid_w(h, f), ag, inj, act, f, grid_store(h), 0);
     prof_end(h);
+    }
     h->fiso[f + 1] = (fiso & 2) != 0;
     prof_begin(h, KID_GRID);
     launch_grid<false>(h, T, f, ag);
     prof_end(h);
+    if (defer_g2p) return 0;                              // (fusable_fwd(h, f + 1): no rigid-body pass either)
     prof_begin(h, KID_G2P);
     if (particle_collide(h))
-        hipLaunchKernelGGL(k_g2p<true>, wgrid_g2p(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T, h->g_out, h->blk_count, h->slow_dev, ag, f);
+        hipLaunchKernelGGL(k_g2p<true>, wgrid_g2p(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T, h->g_out, bcount(h, f), h->slow_dev, ag, f);
     else
-        hipLaunchKernelGGL(k_g2p<false>, wgrid_g2p(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T, h->g_out, h->blk_count, h->slow_dev, ag, f);
+        hipLaunchKernelGGL(k_g2p<false>, wgrid_g2p(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T, h->g_out, bcount(h, f), h->slow_dev, ag, f);
     prof_end(h);
     if (h->has_rigid) {
         hipLaunchKernelGGL(k_rigid_body<false>, dim3(h->n_bodies), dim3(256), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), (float*)nullptr,
@@ -3939,10 +4028,10 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act, int next_f = -1, bool
     prof_begin(h, KID_P2G_RE);
     if (h->all_simple_liquid)
         hipLaunchKernelGGL((k_p2g<false, false>), wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T,
-                           h->pool_idx, grid_w(h), ag, noinj, 0, f, grid_store(h), h->fiso[f] ? 1 : 0);
+                           h->pool_idx, grid_w(h, f), ag, noinj, 0, f, grid_store(h), h->fiso[f] ? 1 : 0);
     else
         hipLaunchKernelGGL((k_p2g<false, true>), wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T,
-                           h->pool_idx, grid_w(h), ag, noinj, 0, f, grid_store(h), 0);
+                           h->pool_idx, grid_w(h, f), ag, noinj, 0, f, grid_store(h), 0);
     prof_end(h);
     prof_begin(h, KID_GRID_KEEP);
     launch_grid<true>(h, T, f, ag);
@@ -3966,7 +4055,7 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act, int next_f = -1, bool
     prof_end(h);
     prof_begin(h, KID_GRID_GRAD);
 #define LAUNCH_GRID_GRAD(ST_, DY_) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_grad<ST_, DY_>), ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, h->gg_out, \
-                           h->gg_in, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f, statics_p(h), ag, h->node_work, h->node_work_count)
+                           h->gg_in, h->blk_list, bcount(h, f), h->blk_flag, grid_store(h), f, statics_p(h), ag, h->node_work, h->node_work_count)
     if (grid_collide(h)) {
         if (!h->node_work && (dev_alloc(h, &h->node_work, (size_t)h->S.ncell, false) || dev_alloc(h, &h->node_work_count, 1))) return 1;
         HIPCK(h, hipMemsetAsync(h->node_work_count, 0, sizeof(int), h->stream));
@@ -3984,7 +4073,7 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act, int next_f = -1, bool
     const bool gc_out = compact_out && h->compact_F && h->all_simple_liquid;
     const int giso = (h->fiso[f] ? 1 : 0) | (h->gcompact[(f + 1) & 1] ? 2 : 0) | (gc_out ? 4 : 0);
 #define LAUNCH_P2G_GRAD(G, W) hipLaunchKernelGGL((k_p2g_grad<G, W>), wgrid_pgg(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), \
-                           h->grad(f), T, h->pool_idx, h->gg_in, h->blk_count, h->slow_dev, ag, inj, act, f, g_dst, to_slot, giso)
+                           h->grad(f), T, h->pool_idx, h->gg_in, bcount(h, f), h->slow_dev, ag, inj, act, f, g_dst, to_slot, giso)
     if (h->all_simple_liquid) {
         if (h->p2g_grad_waves >= 4) LAUNCH_P2G_GRAD(false, 4);
         else if (h->p2g_grad_waves == 3) LAUNCH_P2G_GRAD(false, 3);
@@ -4051,10 +4140,10 @@ int substep_fwd_batch(FeEngine** hs, int B, int f, int f_global, int act) {
         const TableP T = h->tableP(h->tbl_of_frame[f]);
         const AgentP ag = agent_params(h);
         const int fiso = fwd_iso(h, f);
-        bp.a[i] = P2GArgs{h->S, h->frame(f), h->frame(f + 1), T, h->pool_idx, grid_w(h), ag, inj, act, f, grid_store(h), h->all_simple_liquid ? fiso : 0};
+        bp.a[i] = P2GArgs{h->S, h->frame(f), h->frame(f + 1), T, h->pool_idx, grid_w(h, f), ag, inj, act, f, grid_store(h), h->all_simple_liquid ? fiso : 0};
         h->fiso[f + 1] = h->all_simple_liquid && (fiso & 2) != 0;
-        bg.a[i] = GridArgs{h->S, T, h->slab, h->g_in, h->g_out, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f, h->frame_slow_dev, statics_p(h), ag};
-        bq.a[i] = G2PArgs{h->S, h->frame(f), h->frame(f + 1), T, h->g_out, h->blk_count, h->slow_dev, ag, f};
+        bg.a[i] = GridArgs{h->S, T, h->slab, h->g_in, h->g_out, h->blk_list, bcount(h, f), h->blk_flag, grid_store(h), f, h->frame_slow_dev, statics_p(h), ag};
+        bq.a[i] = G2PArgs{h->S, h->frame(f), h->frame(f + 1), T, h->g_out, bcount(h, f), h->slow_dev, ag, f};
     }
     }
     prof_begin(h0, KID_P2G);
@@ -4098,12 +4187,12 @@ int substep_bwd_batch(FeEngine** hs, int B, int f, int f_global, int act) {
         }
         all_stored = all_stored && h->gs_cap > 0 && h->gs_host[f] != 0;
         h->stamp++;                                       // recompute marks, then the adjoint scatter's (as in substep_bwd)
-        bp.a[i] = P2GArgs{h->S, h->frame(f), h->frame(f + 1), T, h->pool_idx, grid_w(h), ag, noinj, 0, f, grid_store(h), (h->all_simple_liquid && h->fiso[f]) ? 1 : 0};
-        bg.a[i] = GridArgs{h->S, T, h->slab, h->g_in, h->g_out, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f, h->frame_slow_dev, statics_p(h), ag};
+        bp.a[i] = P2GArgs{h->S, h->frame(f), h->frame(f + 1), T, h->pool_idx, grid_w(h, f), ag, noinj, 0, f, grid_store(h), (h->all_simple_liquid && h->fiso[f]) ? 1 : 0};
+        bg.a[i] = GridArgs{h->S, T, h->slab, h->g_in, h->g_out, h->blk_list, bcount(h, f), h->blk_flag, grid_store(h), f, h->frame_slow_dev, statics_p(h), ag};
         h->stamp++;
         bq.a[i] = G2PGradArgs{h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag};
-        bgg.a[i] = GridGradArgs{h->S, T, h->slab, h->g_in, h->gg_out, h->gg_in, h->blk_list, h->blk_count, h->blk_flag, grid_store(h), f, statics_p(h), ag, h->node_work, h->node_work_count};
-        bpg.a[i] = P2GGradArgs{h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->pool_idx, h->gg_in, h->blk_count, h->slow_dev, ag, inj, act, f, h->grad(f), nullptr,
+        bgg.a[i] = GridGradArgs{h->S, T, h->slab, h->g_in, h->gg_out, h->gg_in, h->blk_list, bcount(h, f), h->blk_flag, grid_store(h), f, statics_p(h), ag, h->node_work, h->node_work_count};
+        bpg.a[i] = P2GGradArgs{h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->pool_idx, h->gg_in, bcount(h, f), h->slow_dev, ag, inj, act, f, h->grad(f), nullptr,
                                (h->fiso[f] ? 1 : 0) | (h->gcompact[(f + 1) & 1] ? 2 : 0)};      // (the batch writes full adjoints)
         h->gtbl[f & 1] = t;
         h->gcompact[f & 1] = false;
@@ -4240,6 +4329,7 @@ FeEngine* fe_create(const FeConfig* cfg) {
     if (const char* e = std::getenv("FE_SORT_INTERVAL")) h->sort_interval = std::atoi(e);     // tuning experiments (the option of the same name wins)
     if (const char* e = std::getenv("FE_QUAD_MIN_UNITS")) h->quad_min_units = std::atoi(e);   // (task-level A/B of the quad units: scripts/run_envs.py)
     if (const char* e = std::getenv("FE_G2P_GRAD_V")) h->g2p_grad_v = std::atoi(e);           // (the parity suite is run once per build of the G2P adjoint)
+    if (const char* e = std::getenv("FE_FUSE_G2P")) h->fuse_g2p = std::atoi(e) != 0;           // (the parity suite with and without the fused forward launch)
     const char* env_lsplit = std::getenv("FE_LANE_SPLIT");                                    // (the parity suite with and without lane_split)
     h->cfg = *cfg; h->N = cfg->n_particles; h->L = cfg->max_substeps_local; h->n = cfg->n_grid; h->nb = cfg->n_grid / 4;
     h->Np = ((h->N + 63) / 64) * 64; if (h->Np == 0) h->Np = 64;
@@ -4307,7 +4397,7 @@ FeEngine* fe_create(const FeConfig* cfg) {
     if (dev_alloc(h, &h->pinfo, h->Np) || dev_alloc(h, &h->pool_idx, h->Np)) return fail("");
     if (ensure_table(h, 0)) return fail("");                 // identity order: no items, everything is "tail"; its `info` is pinfo itself
     if (dev_alloc(h, &h->g_in, 4 * ncell) || dev_alloc(h, &h->g_out, ncell) || dev_alloc(h, &h->gg_out, 3 * ncell) || dev_alloc(h, &h->gg_in, ncell)) return fail("");
-    if (dev_alloc(h, &h->blk_flag, ncell / 64) || dev_alloc(h, &h->blk_list, ncell / 64) || dev_alloc(h, &h->blk_count, 1) || dev_alloc(h, &h->err_dev, 1)) return fail("");
+    if (dev_alloc(h, &h->blk_flag, ncell / 64) || dev_alloc(h, &h->blk_list, ncell / 64) || dev_alloc(h, &h->blk_count, 2) || dev_alloc(h, &h->err_dev, 1)) return fail("");
     if (dev_alloc(h, &h->stage_r, (size_t)24 * h->Np) || dev_alloc(h, &h->stage_i, h->Np)) return fail("");
     if (dev_alloc(h, &h->node_mark, ncell) || dev_alloc(h, &h->counters, 4)) return fail("");
     {   // identity particle order
@@ -4392,6 +4482,7 @@ int fe_set_option(FeEngine* h, const char* name, double value) {
     if (!std::strcmp(name, "lane_split")) { if (value < 0 || value > 7) FAIL(h, "lane_split is a bit set: 1 k_p2g, 2 k_g2p_grad2, 4 k_p2g_grad"); h->S.lsplit = (int)value; return 0; }
     if (!std::strcmp(name, "fold_reorder")) { h->fold_reorder = value != 0; return 0; }
     if (!std::strcmp(name, "compact_F")) { h->compact_F = value != 0; return 0; }
+    if (!std::strcmp(name, "fuse_g2p")) { h->fuse_g2p = value != 0; return 0; }
     if (!std::strcmp(name, "quad_min_units")) { h->quad_min_units = (int)value; return 0; }
     if (!std::strcmp(name, "pgg_quad_min_units")) { h->pgg_quad_min_units = (int)value; return 0; }
     if (!std::strcmp(name, "pack_units")) { if (value < 0 || value > 2) FAIL(h, "pack_units must be 0, 1 or 2"); h->pack_units = (int)value; return 0; }
@@ -4412,7 +4503,7 @@ int fe_get_option(FeEngine* h, const char* name, double* value) {
         {"sort_interval", (double)h->sort_interval}, {"item_max", (double)h->item_max}, {"grid_store", h->gs_cap > 0 ? 1.0 : 0.0},
         {"p2g_grad_waves", (double)h->p2g_grad_waves}, {"g2p_grad_v", (double)h->g2p_grad_v}, {"loose_max", (double)h->loose_max},
         {"inject_till", (double)h->inject_till}, {"collide_min_y", (double)h->collide_min_y}, {"collide_type", (double)h->collide_type},
-        {"prof_fine", h->prof_fine ? 1.0 : 0.0}, {"xcd_map", (double)h->S.xcd}, {"write_through", (double)h->S.wt}, {"wave_sort", (double)h->S.wsort}, {"lane_split", (double)h->S.lsplit}, {"fold_reorder", h->fold_reorder ? 1.0 : 0.0}, {"compact_F", h->compact_F ? 1.0 : 0.0},
+        {"prof_fine", h->prof_fine ? 1.0 : 0.0}, {"xcd_map", (double)h->S.xcd}, {"write_through", (double)h->S.wt}, {"wave_sort", (double)h->S.wsort}, {"lane_split", (double)h->S.lsplit}, {"fold_reorder", h->fold_reorder ? 1.0 : 0.0}, {"compact_F", h->compact_F ? 1.0 : 0.0}, {"fuse_g2p", h->fuse_g2p ? 1.0 : 0.0},
         {"quad_min_units", (double)h->quad_min_units}, {"pgg_quad_min_units", (double)h->pgg_quad_min_units}, {"quad_max", (double)h->quad}, {"quad_fit", (double)h->quad_fit}, {"pack_units", (double)h->pack_units},
         {"wgrid_cap", (double)h->wgrid_cap}, {"wgrid_cap_g2p", (double)h->wgrid_cap_g2p}, {"wgrid_cap_pgg", (double)h->wgrid_cap_pgg}, {"ggrid_cap", (double)h->ggrid_cap}, {"threads", 0.0}};
     for (const auto& t : tab) if (!std::strcmp(name, t.n)) { *value = t.v; return 0; }
@@ -4497,7 +4588,12 @@ int fe_substep_grad(FeEngine* h, int f, int f_global, int act) {
 int fe_step(FeEngine* h, int f0, int f_global0, int n, int act) {
     FE_ENTRY(h);
     if (f0 < 0 || f0 + n > h->L) FAIL(h, "step frames out of range");
-    for (int i = 0; i < n; i++) if (substep_fwd(h, f0 + i, f_global0 + i, act)) return 1;
+    bool pending = false;
+    for (int i = 0; i < n; i++) {
+        const bool defer = i + 1 < n && fusable_fwd(h, f0 + i + 1);
+        if (substep_fwd(h, f0 + i, f_global0 + i, act, pending, defer)) return 1;
+        pending = defer;
+    }
     return check_async(h);
 }
 int fe_step_grad(FeEngine* h, int f0, int f_global0, int n, int act) {

@@ -726,3 +726,124 @@ def test_compact_F_with_an_injector(hiplib, oracle64):
         assert np.abs(a['final'][k] - b['final'][k]).max() <= 1e-5 * max(1.0, np.abs(b['final'][k]).max()), k
     assert S.rel_l2(a['action_grad'], b['action_grad']) <= 2e-5 and S.rel_l2(a['step_loss'], b['step_loss']) <= 1e-6
     assert S.cosine(a['action_grad'], o['action_grad']) >= 0.999999 and S.rel_l2(a['action_grad'], o['action_grad']) <= 1e-4
+
+
+def _droplet_scene(materials, seed=23):
+    """(test_lane_split_small_waves_match_the_oracle's scene) droplets, loose clusters and a dense clump in a 64^3 box, drifting ~1.2 cells per sort interval"""
+    rng = np.random.RandomState(seed)
+    n_drop, n_cl, n_dense = 3000, 2600, 1400
+    N = n_drop + n_cl + n_dense
+    sc = S.water_block(n_grid=64, n_particles=N, lo=0.40, hi=0.47)
+    sc['x'][:n_drop] = S.f32(rng.uniform(0.1, 0.9, (n_drop, 3)))
+    centres = rng.uniform(0.15, 0.85, (40, 3))
+    sc['x'][n_drop:n_drop + n_cl] = S.f32(np.clip(centres[rng.randint(0, 40, n_cl)] + rng.normal(0, 0.022, (n_cl, 3)), 0.08, 0.92))
+    sc['v'] = S.f32(rng.normal(0, 0.7, (N, 3)) + [9.0, -6.0, 3.0])
+    if materials == 'mixed':
+        sc['mat'] = np.array([S.WATER, S.ELASTIC, S.ICECREAM], np.int32)[rng.randint(0, 3, N)]
+        sc['F'] = S.f32(np.eye(3)[None] + rng.normal(0, 1.0, (N, 3, 3)) * np.where(sc['mat'] == S.ICECREAM, 0.002, 0.03)[:, None, None])
+    sc['used'] = (rng.rand(N) > 0.05).astype(np.int32)
+    return sc
+
+
+@pytest.mark.parametrize('scene,opts', [('block', {}), ('block', {'compact_F': 0}), ('droplets-water', {'quad_min_units': 0}), ('droplets-water', {'quad_min_units': 1 << 30, 'loose_max': 3}),
+                                        ('droplets-mixed', {'quad_min_units': 0}), ('droplets-mixed', {'quad_min_units': 1 << 30, 'lane_split': 0, 'loose_max': 3})])
+def test_fused_g2p_p2g_launch_matches_separate_launches(hiplib, oracle64, scene, opts):
+    """Option fuse_g2p (round 5): inside a fe_step call the g2p of substep f - 1 runs at the head of substep f's p2g launch (k_g2p_p2g) -- same unit list, the
+    gathered x' v' C' written to frame f and kept in registers, v_out staged in the bytes of the unit's scatter tile.  Same trajectory as three launches per
+    substep: EVERY frame of the window compared (the fused launch is what writes frames 1 ... n - 1, k_g2p only the frames in front of a sort and the last one),
+    then the reverse sweep over the stored frames, against the unfused engine and the fp64 oracle.  Pair units, quad units (fixed-point tiles: the gather tile
+    aliases four of them), split waves, tail units of loose blocks (global gather + global scatter), unused slots, the SVD materials, compact and full F."""
+    if scene == 'block':
+        rng = np.random.RandomState(5)
+        N = 6000
+        sc = S.water_block(n_grid=32, n_particles=N, seed=3, lo=0.3, hi=0.6)
+        sc['v'] = S.f32(rng.normal(0, 1.0, (N, 3)) + [2.0, -3.0, 1.0])
+        sc['used'] = (rng.rand(N) > 0.1).astype(np.int32)
+        K = 4
+    else:
+        sc = _droplet_scene(scene.split('-')[1])
+        N = len(sc['used'])
+        K = 10
+    n_sub = 13
+    cot = S.random_cotangent(N, seed=7)
+
+    def run(lib, o, ranged):
+        g = S.make_engine(lib, sc, options=o)
+        if ranged:
+            g.step(0, 0, 6, 0)                                   # two calls: the boundary between them is an unfused g2p + p2g
+            g.step(6, 6, n_sub - 6, 0)
+        else:
+            for f in range(n_sub):
+                g.substep(f, f, 0)
+        frames = [S.get_state(g, f) for f in range(1, n_sub + 1)]
+        stats = g.get_stats(n_sub) if lib is hiplib else None
+        ws = g.get_work_stats(K) if lib is hiplib else None
+        g.reset_grad()
+        g.add_grad(n_sub, cot['gx'], cot['gv'], cot['gC'], cot['gF'])
+        g.step_grad(0, 0, n_sub, 0)
+        gx, gv, gC, gF = g.get_grad(0)
+        g.close()
+        return frames, dict(gx=gx, gv=gv, gC=gC, gF=gF), stats, ws
+
+    base = dict({'sort_interval': K}, **opts)
+    fa, ga, st, ws = run(hiplib, dict(base, fuse_g2p=1), True)
+    fb, gb, _, _ = run(hiplib, dict(base, fuse_g2p=0), True)
+    fc, gc, _, _ = run(hiplib, dict(base, fuse_g2p=0), True)           # the same engine once more: its own run-to-run noise
+    fo, go, _, _ = run(oracle64, {}, False)
+    if scene != 'block':
+        assert st['n_slow_path'] > 0, st
+        assert (ws['n_quad_units'] > 100) == (opts.get('quad_min_units') == 0), ws
+    # The engine is not bit-reproducible from run to run: the counting sort ranks the particles of a cell with returning atomics, so the lanes of a run of
+    # equal stencils change places, the fp32 segmented sums of the scatter change their order, and v' differs in the last bit from the first substep on
+    # (C', a difference of nearly equal sums times 4 / dx, by 2e-5 of its range).  These violent scenes amplify that from substep to substep.  The fused
+    # launch has to stay within that noise: no farther from the separate launches than those are from themselves (x4, + a few ulp).
+    worst = {k: 0.0 for k in 'xvCF'}
+    noise = {k: 0.0 for k in 'xvCF'}
+    general = scene.endswith('mixed')
+    for f, (a, b, c) in enumerate(zip(fa, fb, fc), start=1):
+        assert (a['used'] == b['used']).all(), f
+        u = b['used'] > 0
+        for k in 'xvCF':
+            scale = max(1.0, float(np.abs(b[k][u]).max()))
+            d, nz = float(np.abs(a[k][u] - b[k][u]).max()) / scale, float(np.abs(c[k][u] - b[k][u]).max()) / scale
+            worst[k] = max(worst[k], d); noise[k] = max(noise[k], nz)
+            assert d <= 4.0 * nz + {'x': 2.5e-7, 'v': 1e-6, 'C': 2e-5, 'F': 5e-7}[k], (f, k, d, nz)
+            assert (a[k][~u] == b[k][~u]).all() or k == 'F', (f, k)                # unused slots are carried, bit for bit
+    print(f'MEASURED fuse_g2p[{scene}, {opts}]: fused vs separate launches, largest relative state difference over {n_sub} frames', {k: float(f'{v:.2g}') for k, v in worst.items()},
+          'separate vs separate', {k: float(f'{v:.2g}') for k, v in noise.items()}, '| adjoints', {k: round(S.rel_l2(ga[k], gb[k]), 8) for k in ga}, 'separate vs separate',
+          {k: round(S.rel_l2(gc[k], gb[k]), 8) for k in ga}, '| vs fp64 oracle x', np.abs(fa[-1]['x'] - fo[-1]['x']).max(), {k: round(S.rel_l2(ga[k], go[k]), 8) for k in ga})
+    for k in ('gx', 'gv', 'gC', 'gF'):
+        assert np.isfinite(ga[k]).all()
+        # (the SVD materials' adjoints amplify the state noise with a heavy tail -- one pair of runs is no bound on the next: there, no farther than twice the fp32 engine's distance from the fp64 oracle)
+        assert S.rel_l2(ga[k], gb[k]) <= max(4.0 * S.rel_l2(gc[k], gb[k]) + 2e-6, 2.0 * S.rel_l2(gb[k], go[k]) if general else 0.0), (k, S.rel_l2(ga[k], gb[k]), S.rel_l2(gc[k], gb[k]))
+        assert S.cosine(ga[k], go[k]) >= 0.999 and S.rel_l2(ga[k], go[k]) <= (2e-2 if general else 3e-3), (k, S.rel_l2(ga[k], go[k]))
+    assert (fa[-1]['used'] == fo[-1]['used']).all()
+    assert np.abs(fa[-1]['x'] - fo[-1]['x']).max() <= 5e-6 and S.rel_l2(fa[-1]['v'], fo[-1]['v']) <= 1e-3
+
+
+def test_fused_g2p_p2g_launch_counts_and_fallbacks(hiplib):
+    """Which substeps fuse: inside one fe_step call, not across a sort, not in per-substep calls; never with a mesh effector at the particles, rigid bodies or
+    a collector (those put a pass between g2p and the next p2g)."""
+    sc = S.water_block(n_grid=32, n_particles=4000, seed=3, lo=0.3, hi=0.6)
+    g = S.make_engine(hiplib, sc, options={'sort_interval': 5, 'fuse_g2p': 1})
+    g.profile_enable(True)
+    g.step(0, 0, 12, 0)                  # sorts at 0, 5, 10: p2g at 0, 5, 10; fused at 1-4, 6-9, 11; g2p at 4, 9, 11
+    for f in range(12, 15):
+        g.substep(f, f, 0)               # per-substep calls never fuse
+    prof = g.profile_read()
+    g.close()
+    assert prof['g2p_p2g'][1] == 9 and prof['p2g'][1] == 3 + 3 and prof['g2p'][1] == 3 + 3 and prof['grid_op'][1] == 15, prof
+
+
+def test_fused_g2p_p2g_with_an_injector(hiplib, oracle64):
+    """... and through a LatteArt-like pass (ranged fe_step calls with act = 1): pool particles wait unused, milk is injected in the first substep of a step -- a
+    particle that entered in substep f - 1 has no g2p of that substep, the fused launch reads its state from frame f."""
+    sc = S.latte_mini()
+    a = S.run_latte(hiplib, sc, options={'fuse_g2p': 1, 'sort_interval': 3})
+    b = S.run_latte(hiplib, sc, options={'fuse_g2p': 0, 'sort_interval': 3})
+    o = S.run_latte(oracle64, sc)
+    assert (a['final']['used'] == b['final']['used']).all() and (a['final']['used'] == o['final']['used']).all()
+    for k in 'xvCF':
+        assert np.abs(a['final'][k] - b['final'][k]).max() <= 1e-5 * max(1.0, np.abs(b['final'][k]).max()), k
+    assert S.rel_l2(a['action_grad'], b['action_grad']) <= 2e-5 and S.rel_l2(a['step_loss'], b['step_loss']) <= 1e-6
+    assert S.cosine(a['action_grad'], o['action_grad']) >= 0.999999 and S.rel_l2(a['action_grad'], o['action_grad']) <= 1e-4
