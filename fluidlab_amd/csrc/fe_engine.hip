@@ -988,8 +988,47 @@ __device__ __forceinline__ void p2g_scatter_tile_split(const SimP& S, P2GPrep& q
 // `tofs`) -- of s_gtile, or (ALIAS: k_g2p_p2g) of the bytes the unit's scatter tile is about to occupy.
 // ROLLED: the nine columns one after the other (k_g2p_p2g's path for drifted particles: unrolled, the 27 float4 loads of the global form are asked for
 // together -- 108 registers in a kernel that has none to spare; the sums are the same sums in the same order)
+// The global form (drifted particles, tail units) with every product and sum spelled out and kept as written (contract off): it is inlined unrolled into
+// k_g2p and ROLLED into k_g2p_p2g, and left to itself the compiler fuses multiplies into adds differently in the two -- nothing for a particle among
+// others, but an isolated droplet's C' is the rounding residue of M - fx v' times 4 / dx (1e-3 at 64^3), an SVD material's adjoint amplifies it, and the
+// fused launch must not change what a trajectory computes.  fma(0, T, M) = M and fma(1, T, M) = M + T exactly: rolled and unrolled give the same bits.
+template <bool ROLLED>
+__device__ __forceinline__ void g2p_gather_global(const SimP& S, const Stencil& st, const float4* __restrict__ g_out, float nv[3], m3& nC) {
+#pragma clang fp contract(off)
+    nv[0] = nv[1] = nv[2] = 0.f;
+    const float c4 = 4.f * S.inv_dx;
+    m3 M = m3_zero();
+#pragma unroll ROLLED ? 1 : 9
+    for (int ij = 0; ij < 9; ij++) {
+        const int i = ij / 3, j = ij - 3 * i;
+        const float wij = STW(st, i, 0) * STW(st, j, 1);
+        float T[3], Tz[3];
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) {
+            const float weight = wij * st.w[kk][2];
+            const float4 gv = g_out[cell_addr(st.base[0] + i, st.base[1] + j, st.base[2] + kk, S.nb)];
+            const float gw[3] = {weight * gv.x, weight * gv.y, weight * gv.z};
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                if (kk == 0) T[a] = gw[a];
+                else { T[a] = T[a] + gw[a]; Tz[a] = kk == 1 ? gw[a] : __builtin_fmaf(2.f, gw[a], Tz[a]); }
+            }
+        }
+        const float fi = (float)i, fj = (float)j;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            nv[a] = nv[a] + T[a];
+            M.a[a][0] = __builtin_fmaf(fi, T[a], M.a[a][0]); M.a[a][1] = __builtin_fmaf(fj, T[a], M.a[a][1]); M.a[a][2] = M.a[a][2] + Tz[a];
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++) nC.a[a][b] = c4 * __builtin_fmaf(-st.fx[b], nv[a], M.a[a][b]);
+}
 template <bool TILE, bool ALIAS, bool ROLLED = false>
 __device__ __forceinline__ void g2p_gather(const SimP& S, int lb, const Stencil& st, const float4* __restrict__ g_out, int tofs, float nv[3], m3& nC) {
+    if (!TILE) { g2p_gather_global<true>(S, st, g_out, nv, nC); return; }      // (rolled everywhere: unrolled, its 27 float4 loads in flight took k_g2p from 80 registers to 123 -- the path of a few drifted particles)
     const float* gt = ALIAS ? (const float*)s_acc : s_gtile;
     nv[0] = nv[1] = nv[2] = 0.f;
     const float c4 = 4.f * S.inv_dx;
