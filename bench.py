@@ -45,6 +45,7 @@ PHASES = {'falling': (5, 11), 'impact': (11, 18), 'splash': (26, 34), 'layer': (
 # They sum to SURVEY 8d's B_fwd = 216 N + 72 Nc and B_bwd = 308 N + 132 Nc.
 KERNEL_BYTES = {
     'p2g': (156, 16), 'grid_op': (0, 44), 'g2p': (60, 12),
+    'g2p_p2g': (216, 28),                           # k_g2p_p2g: the g2p of one substep and the p2g of the next in one launch -- credited both (what it spares is the re-read of x' v' C')
     'p2g_recompute': (116, 16), 'grid_op_keep': (0, 28), 'g2p_grad': (60, 24), 'grid_op_grad': (0, 48), 'p2g_grad': (132, 16),
     'sort': (0, 0), 'reorder_grad': (0, 0),          # overhead of the cell-sorted layout: no algorithmic bytes credited
 }
@@ -56,6 +57,11 @@ FWD_KERNELS = ('p2g', 'grid_op', 'g2p')
 # of the recompute, 44 Nc (16 accumulate-write + 28 grid_op_keep): `pair_roofline.frac_executed` leaves it out.
 STATE_REREAD = 116
 GRID_RECOMPUTE = 44
+
+
+def fwd_substeps(prof):
+    """forward substeps in a profile: every one has exactly one p2g, alone or at the tail of a k_g2p_p2g launch"""
+    return prof.get('p2g', (0, 0))[1] + prof.get('g2p_p2g', (0, 0))[1]
 
 
 def launch_bytes(name, cnt, prof, n_used, nc):
@@ -260,7 +266,7 @@ def extra_evolving(elib, device, name, mat, dt, warm, n_windows, note):
                     'state_finite': bool(np.isfinite(x).all()),
                     'pair_roofline': {'alg_bytes_per_pair': int(b_pair), 'frac': round(b_pair * rate / 1e9 / HBM_PEAK_GBS, 4)},
                     'kernels': kernel_table(prof, int(st1['n_used']), int(st1['n_cells_touched'])),
-                    'sorts_per_pair': round(prof.get('sort', (0, 0))[1] / max(1, prof.get('p2g', (0, 1))[1]), 3)})
+                    'sorts_per_pair': round(prof.get('sort', (0, 0))[1] / max(1, fwd_substeps(prof)), 3)})
     except Exception as e:                                   # (a scene that leaves the grid must not take the bench line with it)
         out['error'] = str(e)[:200]
     eng.close()
@@ -401,7 +407,7 @@ def run_single(args):
                 traffic = int(pj['timed_region']['kernels'][dom]['traffic_bytes'])
                 # the committed rocprofv3 --kernel-trace of the same command, same windows (scripts/gpu_profile.sh wrote both files)
                 import csv
-                pre = {'p2g': 'k_p2g<true', 'g2p': 'k_g2p<', 'g2p_grad': 'k_g2p_grad', 'p2g_grad': 'k_p2g_grad', 'grid_op': 'k_grid<', 'grid_op_grad': 'k_grid_grad'}[dom]
+                pre = {'p2g': 'k_p2g<true', 'g2p': 'k_g2p<', 'g2p_p2g': 'k_g2p_p2g', 'g2p_grad': 'k_g2p_grad', 'p2g_grad': 'k_p2g_grad', 'grid_op': 'k_grid<', 'grid_op_grad': 'k_grid_grad'}[dom]
                 tot = cnt = 0
                 for r in csv.DictReader(open(ROCPROF_TIMED)):
                     if r['Name'].replace('void ', '').startswith(pre):
@@ -411,7 +417,7 @@ def run_single(args):
             pass
         b_pair = 524 * n_used + 204 * tw['nc_mean']
         sorts = kern.get('sort', {}).get('launches', 0)
-        fwd_launches = max(1, kern.get('p2g', {}).get('launches', 1))
+        fwd_launches = max(1, kern.get('p2g', {}).get('launches', 0) + kern.get('g2p_p2g', {}).get('launches', 0))
         out['config'].update({'nc_mean_timed': tw['nc_mean'], 'nc_min_timed': tw['nc_min'], 'nc_max_timed': tw['nc_max'],
                               'sorts_per_pair': round(sorts / fwd_launches, 3)})
         out['roofline'] = {'bound': 'hbm', 'kernel': dom, 'achieved': kern[dom]['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

@@ -3687,7 +3687,7 @@ struct FeEngine {
     std::vector<char> fiso;                                 // [L+1] frame f's F is stored compactly (FrameV::iso = 1): written by the SVD-free k_p2g
     bool gcompact[2] = {false, false};                      // ... and the adjoint of F in a ring slot (iso = 2): written by k_p2g_grad inside a ranged call
     bool compact_F = true;                                  // option "compact_F"
-    bool fuse_g2p = false;                                  // option "fuse_g2p": inside a fe_step call the g2p of a substep runs at the head of the next substep's p2g launch (k_g2p_p2g)
+    bool fuse_g2p = true;                                   // option "fuse_g2p": inside a fe_step call the g2p of a substep runs at the head of the next substep's p2g launch (k_g2p_p2g)
     int tbl_bank = 0, last_sorted_f = -1;                   // two banks of table ids, one per sweep over the window (sort_frame)
     int p2g_grad_waves = 4;                                 // occupancy target of the SVD-free p2g_grad build (tuning)
     int pack_units = 2;                                     // option "pack_units": 0 never, 1 pack the scatter list (no idle halves) when that brings it back into one round, 2 whenever it is more than one round

@@ -20,7 +20,7 @@ OUT = os.environ.get('PROFILE_OUT', 'profiles')          # (on the GPU box: a di
 
 CHUNK = 100
 BENCH_NAME = [('k_p2g_grad', 'p2g_grad'), ('k_g2p_grad', 'g2p_grad'), ('k_grid_grad', 'grid_op_grad'), ('k_p2g<true', 'p2g'), ('k_p2g<false', 'p2g_recompute'),
-              ('k_grid<false', 'grid_op'), ('k_grid<true', 'grid_op_keep'), ('k_g2p<', 'g2p')]
+              ('k_grid<false', 'grid_op'), ('k_grid<true', 'grid_op_keep'), ('k_g2p<', 'g2p'), ('k_g2p_p2g', 'g2p_p2g')]
 SORT_KERNELS = ('k_sort', 'k_scan', 'k_build', 'k_clear_slots', 'k_set_static', 'k_block')
 FIXED = {'falling': (5, 11), 'impact': (11, 18), 'splash': (18, 45), 'layer': (45, 10**9)}
 
@@ -58,7 +58,7 @@ def windows(names):
     out, n_fwd, forward = [], 0, True
     for nm in names:
         n = clean(nm)
-        if n.startswith('k_p2g<true'):
+        if n.startswith(('k_p2g<true', 'k_g2p_p2g')):          # a forward substep starts: its p2g, alone or behind the previous substep's g2p in one launch
             out.append(n_fwd // CHUNK); n_fwd += 1; forward = True
             continue
         if n.startswith(('k_g2p_grad', 'k_grid_grad', 'k_p2g_grad', 'k_p2g<false', 'k_grid<true', 'k_perm_reorder', 'k_loss_bwd')):
