@@ -243,7 +243,7 @@ class Engine:
         self._ck(self.lib.fe_set_option(self.h, name.encode(), float(value)))
 
     OPTION_NAMES = ('sort_interval', 'item_max', 'grid_store', 'p2g_grad_waves', 'g2p_grad_v', 'loose_max', 'xcd_map', 'write_through',
-                    'wave_sort', 'lane_split', 'fold_reorder', 'compact_F', 'fuse_g2p', 'quad_min_units', 'pgg_quad_min_units', 'quad_max', 'quad_fit', 'pack_units', 'wgrid_cap', 'wgrid_cap_g2p', 'wgrid_cap_pgg', 'ggrid_cap', 'collide_type')
+                    'wave_sort', 'lane_split', 'fold_reorder', 'compact_F', 'fuse_g2p', 'fuse_bwd', 'quad_min_units', 'pgg_quad_min_units', 'quad_max', 'quad_fit', 'pack_units', 'wgrid_cap', 'wgrid_cap_g2p', 'wgrid_cap_pgg', 'ggrid_cap', 'collide_type')
 
     def get_option(self, name):
         v = C.c_double(0.0)

@@ -85,6 +85,16 @@ __host__ __device__ inline FrameV frame_view(float* base_, size_t Np_, int wt = 
 }
 
 struct PState { float x[3], v[3]; m3 C, F; };
+// (field by field: the adjoint k_pgg_g2pg hands from its p2g_grad part to its g2p_grad part has no F -- a whole-struct copy would move 36 undefined bytes
+//  and kept the struct in scratch)
+__device__ __forceinline__ void copy_xvC(PState& d, const PState& s) {
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        d.x[a] = s.x[a]; d.v[a] = s.v[a];
+#pragma unroll
+        for (int b = 0; b < 3; b++) d.C.a[a][b] = s.C.a[a][b];
+    }
+}
 
 __device__ __forceinline__ void load_xvC(const FrameV& fr, int s, PState& p) {
     float4 a0 = fr.A0[s], a1 = fr.A1[s], a2 = fr.A2[s];
@@ -253,6 +263,21 @@ __shared__ float  s_gtile[2 * 3 * TILE_N];  // gathered v_out: k_g2p (3 planes)
 __shared__ double s_acc[2 * 4 * TILE_N];    // k_p2g
 __shared__ float  s_tile3[2 * 3 * TILE_N];  // k_g2p_grad: v_out ...
 __shared__ double s_acc3[2 * 3 * TILE_N];   // ... and d v_out (3 planes each: 36 KB per workgroup, four workgroups per CU)
+// k_p2g_grad's per-thread stash columns (used_particle_p2g_grad)
+#define STASH_GENERAL 36
+#define STASH_LIQUID 18
+__shared__ float s_stash_g[STASH_GENERAL * WG];
+__shared__ float s_stash_l[STASH_LIQUID * WG];
+// k_pgg_g2pg (substep f's p2g_grad, then substep f - 1's g2p_grad in one launch) works through both kernels' LDS one after the other: ONE arena of 36 KB that
+// the four arrays above are views of (AR = true), so that four workgroups per CU stay resident -- side by side they would be 70 KB.
+//   p2g_grad part, pair units: tiles [0, 8 TILE_N) floats, stash behind them (18 x 256 floats);  quad units: four 4-plane tiles, two of them where the stash is
+//   g2p_grad part, pair units: v_out tiles [0, 6 TILE_N) floats, the fp64 accumulators behind them; quad units: the wave's words in the accumulators' bytes
+__shared__ __attribute__((aligned(16))) float s_bw[18 * TILE_N];
+template <bool AR> __device__ __forceinline__ float* lds_tile4() { if constexpr (AR) return s_bw; else return s_tile; }
+template <bool AR> __device__ __forceinline__ float* lds_stash_l() { if constexpr (AR) return s_bw + 8 * TILE_N; else return s_stash_l; }
+template <bool AR> __device__ __forceinline__ float* lds_tile3() { if constexpr (AR) return s_bw; else return s_tile3; }
+template <bool AR> __device__ __forceinline__ double* lds_acc3() { if constexpr (AR) return (double*)(s_bw + 6 * TILE_N); else return s_acc3; }
+template <bool GENERAL, bool AR = false> struct Stash { static __device__ __forceinline__ float* at() { if constexpr (GENERAL) return s_stash_g; else return lds_stash_l<AR>(); } };
 // Effector pose adjoints of the workgroup's particles in contact (agent.collide's adjoint): summed here first -- every
 // contact particle adds to the same 14 numbers per effector, and same-address global atomics serialise.
 #define FE_MAX_EFF 4
@@ -1606,12 +1631,13 @@ __device__ __forceinline__ float4 vout_at(const SimP& S, const VoutSrc& V, int i
 // TILE=true is executed by ALL lanes of the wave (`live` = this lane holds a used particle whose stencil fits the
 // tile); the d v_out contributions are summed over runs of equal stencil base before the LDS atomics (seg_scan).
 // (agent.collide's adjoint has already been folded into Gn's x/v adjoints by k_collide_grad)
-template <bool TILE>
+template <bool TILE, bool GPRE = false>
 __device__ __forceinline__ void used_particle_g2p_grad(const SimP& S, const FrameV& Gn, const FrameV& Gc, int s,
                                                        int lb, const Stencil& st, const VoutSrc& V, float* gg_out,
-                                                       bool live, const SegScan& sc, int tofs = 0) {
+                                                       bool live, const SegScan& sc, int tofs = 0, const PState* gpre = nullptr) {
     PState g;                                   // adjoints of x', v', C'
-    if (!TILE || live) load_xvC(Gn, s, g);
+    if (GPRE) copy_xvC(g, *gpre);               // (k_pgg_g2pg: in registers, not in Gn)
+    else if (!TILE || live) load_xvC(Gn, s, g);
     else { g.x[0] = g.x[1] = g.x[2] = g.v[0] = g.v[1] = g.v[2] = 0.f; g.C = m3_zero(); }
     const bool issue = TILE && sc.tail && live;
     const float livef = (!TILE || live) ? 1.f : 0.f;
@@ -1678,17 +1704,22 @@ __device__ __forceinline__ void used_particle_g2p_grad(const SimP& S, const Fram
 }
 
 // one slot on the global path (tail / sort_interval = 0)
+template <bool GPRE = false>
 __device__ __forceinline__ void g2p_grad_slot_global(const SimP& S, const FrameV& cur, const FrameV& Gn, const FrameV& Gc, int s,
-                                                     const VoutSrc& V, float* gg_out, const AgentP& agent, int f, const GridStore& GS) {
+                                                     const VoutSrc& V, float* gg_out, const AgentP& agent, int f, const GridStore& GS, const PState* gpre = nullptr) {
     if (!cur.used[s]) return;
     float4 a0 = cur.A0[s];
     float x[3] = {a0.x, a0.y, a0.z};
     Stencil st;
     stencil_make(x, S.inv_dx, st);
-    if (!stencil_inside(st, S.n)) { float4 gx = Gn.A0[s]; Gc.A0[s] = make_float4(gx.x, gx.y, gx.z, 0.f); return; }
+    if (!stencil_inside(st, S.n)) {
+        if (GPRE) Gc.A0[s] = make_float4(gpre->x[0], gpre->x[1], gpre->x[2], 0.f);
+        else { float4 gx = Gn.A0[s]; Gc.A0[s] = make_float4(gx.x, gx.y, gx.z, 0.f); }
+        return;
+    }
     SegScan none;
     none.f1 = none.f2 = none.f4 = none.f8 = 0.f; none.tail = true;
-    used_particle_g2p_grad<false>(S, Gn, Gc, s, 0, st, V, gg_out, true, none);
+    used_particle_g2p_grad<false, GPRE>(S, Gn, Gc, s, 0, st, V, gg_out, true, none, 0, gpre);
     for (int bx = st.base[0] >> 2; bx <= (st.base[0] + 2) >> 2; bx++)              // the (up to 8) blocks whose gg_out planes now hold atomics
         for (int by = st.base[1] >> 2; by <= (st.base[1] + 2) >> 2; by++)
             for (int bz = st.base[2] >> 2; bz <= (st.base[2] + 2) >> 2; bz++) mark_dirty(GS, V.blk_slot, (bx * S.nb + by) * S.nb + bz);
@@ -1700,13 +1731,16 @@ __device__ __forceinline__ void g2p_grad_slot_global(const SimP& S, const FrameV
 // and with it its workgroup's tile hand-over -- waits.  The block hitting the floor has ~60 such particles per substep, enough to
 // make their workgroups the launch's tail: k_g2p_grad 28.7 us where a fresh order takes 23.4 (k_p2g's slow path is fire-and-forget
 // atomics and costs it 1.4 us).  Here the 27 fetches are in flight together and the sums meet through cross-lane adds.
+// (gpre: the particle's adjoint in registers, uniform -- k_pgg_g2pg, where Gn does not hold it)
+template <bool GPRE = false>
 __device__ __forceinline__ void g2p_grad_drifted(const SimP& S, const FrameV& Gn, const FrameV& Gc, int s, const float x[3],
-                                                 const VoutSrc& V, float* gg_out, const GridStore& GS) {
+                                                 const VoutSrc& V, float* gg_out, const GridStore& GS, const PState* gpre = nullptr) {
     const int lane = threadIdx.x & 63;
     Stencil st;
     stencil_make(x, S.inv_dx, st);
     PState g;
-    load_xvC(Gn, s, g);                                       // (one address for all lanes)
+    if (GPRE) copy_xvC(g, *gpre);
+    else load_xvC(Gn, s, g);                                  // (one address for all lanes)
     const float c4 = 4.f * S.inv_dx;
     float qb[3], qx[3], qy[3], qz[3];
 #pragma unroll
@@ -1745,17 +1779,32 @@ __device__ __forceinline__ void g2p_grad_drifted(const SimP& S, const FrameV& Gn
 }
 // the lanes of a tile unit's wave whose particles drifted out of the tile (`drifted`: used, stencil on the grid, not on the tile;
 // `outside`: used, stencil off the grid -- passed through untouched, as the per-lane road does); a00 = the lane's (x, .) plane, s its slot
+// (gpre: the lane's own adjoint of x', v', C' in registers -- k_pgg_g2pg; a drifted lane's is then broadcast to the wave)
+template <bool GPRE = false>
 __device__ __forceinline__ void g2p_grad_wave_slow(const SimP& S, const FrameV& Gn, const FrameV& Gc, int s, const float4 a00, bool drifted, bool outside,
-                                                   const VoutSrc& V, float* gg_out, int* slow, const GridStore& GS) {
-    if (outside) { const float4 gx = Gn.A0[s]; Gc.A0[s] = make_float4(gx.x, gx.y, gx.z, 0.f); }
+                                                   const VoutSrc& V, float* gg_out, int* slow, const GridStore& GS, const PState* gpre = nullptr) {
+    if (outside) {
+        if (GPRE) pstore(Gc, Gc.A0, s, make_float4(gpre->x[0], gpre->x[1], gpre->x[2], 0.f));
+        else { const float4 gx = Gn.A0[s]; Gc.A0[s] = make_float4(gx.x, gx.y, gx.z, 0.f); }
+    }
     unsigned long long todo = __ballot(drifted);
     if (todo && (threadIdx.x & 63) == 0) atomicAdd(slow, __popcll(todo));
     while (todo) {
         const int L = __builtin_ctzll(todo);
         todo &= todo - 1;
-        const float x[3] = {__int_as_float(__builtin_amdgcn_readlane(__float_as_int(a00.x), L)), __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a00.y), L)),
-                            __int_as_float(__builtin_amdgcn_readlane(__float_as_int(a00.z), L))};
-        g2p_grad_drifted(S, Gn, Gc, __builtin_amdgcn_readlane(s, L), x, V, gg_out, GS);
+#define LANE_F(v) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), L))
+        const float x[3] = {LANE_F(a00.x), LANE_F(a00.y), LANE_F(a00.z)};
+        if (GPRE) {
+            PState gu;
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                gu.x[a] = LANE_F(gpre->x[a]); gu.v[a] = LANE_F(gpre->v[a]);
+#pragma unroll
+                for (int b = 0; b < 3; b++) gu.C.a[a][b] = LANE_F(gpre->C.a[a][b]);
+            }
+            g2p_grad_drifted<true>(S, Gn, Gc, __builtin_amdgcn_readlane(s, L), x, V, gg_out, GS, &gu);
+        } else g2p_grad_drifted(S, Gn, Gc, __builtin_amdgcn_readlane(s, L), x, V, gg_out, GS);
+#undef LANE_F
     }
 }
 
@@ -1900,11 +1949,15 @@ __device__ __forceinline__ void quad_load_vout_inner(const float4* __restrict__ 
 // returns the factor that turns them back into floats.
 // G = 3 / 9: a split wave (lane_split) -- this lane works on the nodes of plane i = gi (column (gi, gj)) of its particle's stencil, the gather
 // pass' partial sums are added up over the particle's lanes, the position adjoint is stored by its first lane (`primary`).
-template <int MINW, bool QUAD, int G>
+// AR: the accumulators as k_pgg_g2pg's arena has them; gpre (that kernel): the adjoints of x', v', C' come in registers instead of from Gn.
+template <int MINW, bool QUAD, int G, bool AR = false>
 __device__ __forceinline__ float g2p_grad_particle2(const SimP& S, const FrameV& Gn, const FrameV& Gc, int s, int lb, const Stencil& st,
-                                                    bool live, int tofs, const float* gt, int gofs, bool primary) {      // (lb, live: this lane's particle; from pass 2 on the particle it scatters for)
+                                                    bool live, int tofs, const float* gt, int gofs, bool primary, const PState* gpre = nullptr) {      // (lb, live: this lane's particle; from pass 2 on the particle it scatters for)
     PState g;                                   // adjoints of x', v', C'
-    if (live) load_xvC(Gn, s, g);
+    double* const acc3 = lds_acc3<AR>();
+    // (AR decides, not a test of the pointer: a comparison of a stack object's address with null is a use the optimiser cannot see through, and the object stays in scratch)
+    if (AR && live) copy_xvC(g, *gpre);
+    else if (!AR && live) load_xvC(Gn, s, g);
     else { g.x[0] = g.x[1] = g.x[2] = g.v[0] = g.v[1] = g.v[2] = 0.f; g.C = m3_zero(); }
     const float c4 = 4.f * S.inv_dx;
     // q(o) = gv + c4 gC (o - fx), gv = v'_bar + dt x'_bar  (x' = x + dt v')
@@ -1975,7 +2028,7 @@ __device__ __forceinline__ float g2p_grad_particle2(const SimP& S, const FrameV&
         // the tile changes hands: every read of v_out is done (the wave's LDS operations complete in order), the words are zeroed and
         // the coefficients of q scaled for the fixed-point sums
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        int* acc = (int*)s_acc3 + tofs;
+        int* acc = (int*)acc3 + tofs;
         for (int l = threadIdx.x & 63; l < 3 * TILE_N / 4; l += 64) ((int4*)acc)[l] = make_int4(0, 0, 0, 0);
         asm volatile("" ::: "memory");
         float b = 0.f;
@@ -2025,14 +2078,14 @@ __device__ __forceinline__ float g2p_grad_particle2(const SimP& S, const FrameV&
                 if (issue) {
                     const int l = l0s + ((G > 1 ? 0 : ii) * TILE_T + (G == 9 ? 0 : jj)) * TILE_T + kk;
                     if (QUAD) {
-                        int* acc = (int*)s_acc3;
+                        int* acc = (int*)acc3;
                         atomicAdd(acc + l, fix_round(c0));                   // ds_add_u32
                         atomicAdd(acc + TILE_N + l, fix_round(c1));
                         atomicAdd(acc + 2 * TILE_N + l, fix_round(c2));
                     } else {
-                        atomicAdd(&s_acc3[l], (double)c0);                    // ds_add_f64
-                        atomicAdd(&s_acc3[TILE_N + l], (double)c1);
-                        atomicAdd(&s_acc3[2 * TILE_N + l], (double)c2);
+                        atomicAdd(&acc3[l], (double)c0);                      // ds_add_f64
+                        atomicAdd(&acc3[TILE_N + l], (double)c1);
+                        atomicAdd(&acc3[2 * TILE_N + l], (double)c2);
                     }
                 }
             }
@@ -2040,12 +2093,12 @@ __device__ __forceinline__ float g2p_grad_particle2(const SimP& S, const FrameV&
     }
     return inv;
 }
-template <int MINW, bool QUAD>
+template <int MINW, bool QUAD, bool AR = false>
 __device__ __forceinline__ float g2p_grad_particle2_split(const SimP& S, const FrameV& Gn, const FrameV& Gc, int s, int lb, const Stencil& st,
-                                                          bool live, int tofs, const float* gt, const LaneSplit& ls) {
-    if (ls.G == 1) return g2p_grad_particle2<MINW, QUAD, 1>(S, Gn, Gc, s, lb, st, live, tofs, gt, 0, true);      // (wave-uniform)
-    if (ls.G == 3) return g2p_grad_particle2<MINW, QUAD, 3>(S, Gn, Gc, s, lb, st, live, tofs, gt, ls.gofs, ls.primary);
-    return g2p_grad_particle2<MINW, QUAD, 9>(S, Gn, Gc, s, lb, st, live, tofs, gt, ls.gofs, ls.primary);
+                                                          bool live, int tofs, const float* gt, const LaneSplit& ls, const PState* gpre = nullptr) {
+    if (ls.G == 1) return g2p_grad_particle2<MINW, QUAD, 1, AR>(S, Gn, Gc, s, lb, st, live, tofs, gt, 0, true, gpre);      // (wave-uniform)
+    if (ls.G == 3) return g2p_grad_particle2<MINW, QUAD, 3, AR>(S, Gn, Gc, s, lb, st, live, tofs, gt, ls.gofs, ls.primary, gpre);
+    return g2p_grad_particle2<MINW, QUAD, 9, AR>(S, Gn, Gc, s, lb, st, live, tofs, gt, ls.gofs, ls.primary, gpre);
 }
 template <int MINW>
 __device__ __forceinline__ void g2p_grad2_body(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T,
@@ -2442,22 +2495,18 @@ struct GradDst {
     FrameV G; const int* __restrict__ to_slot; const int* __restrict__ pid_of_slot;
     __device__ __forceinline__ int slot(int s) const { return to_slot ? to_slot[pid_of_slot[s]] : s; }
 };
-#define STASH_GENERAL 36     // C, F, U, V; the singular values and J stay in registers: 36 KB + 16 KB of tile = three workgroups per CU
-#define STASH_LIQUID 18
-template <bool GENERAL> struct Stash { static __device__ __forceinline__ float* at(); };
-__shared__ float s_stash_g[STASH_GENERAL * WG];
-__shared__ float s_stash_l[STASH_LIQUID * WG];
-template <> __device__ __forceinline__ float* Stash<true>::at() { return s_stash_g; }
-template <> __device__ __forceinline__ float* Stash<false>::at() { return s_stash_l; }
+// (STASH_GENERAL = 36: C, F, U, V; the singular values and J stay in registers: 36 KB + 16 KB of tile = three workgroups per CU.  Declared with the tiles.)
 // NOSTASH (a quad unit's wave, whose tile `tl` lies where the pair units keep their stash): C and F are read from the frame again behind
 // the loop -- 72 bytes per particle that the wave's own loads left in the L2 a few microseconds earlier
 // G = 3 / 9 (tile path of the SVD-free build): a split wave (lane_split) -- this lane gathers the nodes of plane gi (column (gi, gj)) of its
 // particle's stencil, the fifteen sums are added up over the particle's lanes, the adjoint is stored by its first lane (`primary`).
-template <bool TILE, bool GENERAL, bool PRE = false, bool NOSTASH = false, int G = 1>
+// AR: the LDS views of k_pgg_g2pg's arena.  KEEP (that kernel): the adjoints of x, v and C are handed back in `keep` instead of being stored -- the g2p_grad
+// part of the same launch consumes them from registers, and stores them itself for the few particles whose adjoint somebody else reads (p2g_grad_g2p_grad_body).
+template <bool TILE, bool GENERAL, bool PRE = false, bool NOSTASH = false, int G = 1, bool AR = false, bool KEEP = false>
 __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const FrameV& cur, const FrameV& Gn, const FrameV& Gc, int s,
                                                        const float4* __restrict__ info_, const TileO& to,
                                                        const float4* __restrict__ gg_in, int* slow, int tofs, const P2GRaw& pre, const GradDst& D, const float* tl = nullptr,
-                                                       int gofs = 0, bool primary = true) {
+                                                       int gofs = 0, bool primary = true, PState* keep = nullptr) {
     PState p;
     PInfo info;
     if (PRE) { p = pre.p; info = pre.info; }                  // (asked for ahead of the tile load and its barrier: p2g_grad_body)
@@ -2469,15 +2518,15 @@ __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const Fram
     const bool inside = stencil_inside(st, S.n);
     const int lb = (TILE && inside) ? tile_base(to, st) : -1;
     if (TILE && inside && lb < 0) {            // drifted out of the tile: redo on the global path
-        if (!primary) return;                  // (a split wave: once per particle)
-        atomicAdd(slow, 1);
+        if (!primary && !KEEP) return;         // (a split wave: once per particle -- unless every lane is to hold the result)
+        if (primary) atomicAdd(slow, 1);
         // (NOSTASH travels along: a quad unit's wave has no stash column -- two of the quad's tiles lie where the pair units keep theirs
         //  (p2g_grad_body), and a drifted particle that parked C and F there overwrote gathered nodes the other lanes were still reading.
         //  ADVICE r4; tests/test_hip_parity.py::test_quad_units_with_drifted_particles_in_p2g_grad)
-        used_particle_p2g_grad<false, GENERAL, false, NOSTASH>(S, cur, Gn, Gc, s, info_, to, gg_in, slow, 0, pre, D);
+        used_particle_p2g_grad<false, GENERAL, false, NOSTASH, 1, AR, KEEP>(S, cur, Gn, Gc, s, info_, to, gg_in, slow, 0, pre, D, nullptr, 0, primary, keep);
         return;
     }
-    float* stash = Stash<GENERAL>::at();
+    float* stash = Stash<GENERAL, AR>::at();
     int col = threadIdx.x;
     if (!NOSTASH) {
 #pragma unroll
@@ -2525,7 +2574,8 @@ __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const Fram
                     gin[0] = tl[l]; gin[1] = tl[TILE_N + l]; gin[2] = tl[2 * TILE_N + l]; gm = tl[3 * TILE_N + l];
                 } else if (TILE) {
                     const int l = tofs + lg + ((G > 1 ? 0 : ic) * TILE_T + (G == 9 ? 0 : jc)) * TILE_T + kk;
-                    gin[0] = s_tile[l]; gin[1] = s_tile[TILE_N + l]; gin[2] = s_tile[2 * TILE_N + l]; gm = s_tile[3 * TILE_N + l];
+                    const float* t4 = lds_tile4<AR>();
+                    gin[0] = t4[l]; gin[1] = t4[TILE_N + l]; gin[2] = t4[2 * TILE_N + l]; gm = t4[3 * TILE_N + l];
                 } else {
                     float4 gi = gg_in[cell_addr(st.base[0] + i, st.base[1] + j, st.base[2] + kk, S.nb)];
                     gin[0] = gi.x; gin[1] = gi.y; gin[2] = gi.z; gm = gi.w;
@@ -2600,20 +2650,31 @@ __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const Fram
     float gvv[3] = {info.mass * Gv[0], info.mass * Gv[1], info.mass * Gv[2]};
     m3 gC, gF;
     constitutive_grad_t<GENERAL>(p.C, p.F, S.dt, info.mu, info.lam, info.mass, info.cls, S.stress_scale, k, GA, Fg2, gC, gF);
+    if (KEEP) {                                 // (every lane of a split wave: the g2p_grad part works with the particle's adjoint in all of them)
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            keep->x[a] = gx[a]; keep->v[a] = gvv[a];
+#pragma unroll
+            for (int b = 0; b < 3; b++) keep->C.a[a][b] = gC.a[a][b];
+        }
+        if (primary) store_F(D.G, sd, gF);
+        return;
+    }
     if (G > 1 && !primary) return;              // (a split wave: the particle's first lane stores)
     store_xvC(D.G, sd, gx, gvv, gC);
     store_F(D.G, sd, gF);
 }
 
-template <bool TILE, bool GENERAL, bool PRE = false, bool NOSTASH = false, int G = 1>
-__device__ __forceinline__ void slot_p2g_grad(const SimP& S, const FrameV& cur, const FrameV& Gn, const FrameV& Gc, int s, const TableP& T,
+// Returns whether the slot holds a used particle (KEEP: its adjoint is then in `keep`, not in memory).
+template <bool TILE, bool GENERAL, bool PRE = false, bool NOSTASH = false, int G = 1, bool AR = false, bool KEEP = false>
+__device__ __forceinline__ bool slot_p2g_grad(const SimP& S, const FrameV& cur, const FrameV& Gn, const FrameV& Gc, int s, const TableP& T,
                                               const int* __restrict__ pool_idx,
                                               const TileO& to, const float4* __restrict__ gg_in, int* slow, const AgentP& agent,
                                               const InjectP& inj, int f, int tofs, int used, const P2GRaw& pre, const GradDst& D, const float* tl = nullptr,
-                                              int gofs = 0, bool primary = true) {
+                                              int gofs = 0, bool primary = true, PState* keep = nullptr) {
     if (!PRE) used = cur.used[s];
-    if (used) { used_particle_p2g_grad<TILE, GENERAL, PRE, NOSTASH, G>(S, cur, Gn, Gc, s, T.info, to, gg_in, slow, tofs, pre, D, tl, gofs, primary); return; }
-    if (G > 1 && !primary) return;              // (a split wave: once per particle)
+    if (used) { used_particle_p2g_grad<TILE, GENERAL, PRE, NOSTASH, G, AR, KEEP>(S, cur, Gn, Gc, s, T.info, to, gg_in, slow, tofs, pre, D, tl, gofs, primary, keep); return true; }
+    if ((G > 1 || KEEP) && !primary) return false;      // (a split wave: once per particle)
     // the copy f -> f+1 of an unused particle passes its adjoint straight through (mpm:551)
     // Compact adjoints (FrameV::iso = 2) are a matter of the USED slots: what an unused particle passes on is whatever was seeded on it -- nothing says
     // that is isotropic --, so the slots of particles unused in an adjoint's frame always hold all nine words.  The incoming slot is such a slot unless
@@ -2646,6 +2707,7 @@ __device__ __forceinline__ void slot_p2g_grad(const SimP& S, const FrameV& cur, 
             }
         }
     }
+    return false;
 }
 
 // p2g.grad + svd_grad + compute_F_tmp.grad + AgentInjector.act_kernel.grad + process_unused_particles.grad (mpm:551)
@@ -2751,6 +2813,140 @@ template <bool GENERAL, int MINW>
 __global__ FE_KALIGN __launch_bounds__(WG, MINW) void k_p2g_grad(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T, const int* pool_idx, const float4* gg_in, int* blk_count, int* slow, AgentP agent, InjectP inj, int act, int f, float* Gd_, const int* to_slot, int fiso) { p2g_grad_body<GENERAL, MINW>(S, fr_cur, Gn_, Gc_, T, pool_idx, gg_in, blk_count, slow, agent, inj, act, f, Gd_, to_slot, fiso); }
 template <bool GENERAL, int MINW>
 __global__ FE_KALIGN __launch_bounds__(WG, MINW) void k_p2g_grad_b(Batch<P2GGradArgs> B) { const P2GGradArgs& A = B.a[blockIdx.y]; p2g_grad_body<GENERAL, MINW>(A.S, A.fr_cur, A.Gn_, A.Gc_, A.T, A.pool_idx, A.gg_in, A.blk_count, A.slow, A.agent, A.inj, A.act, A.f, A.Gd_, A.to_slot, A.fiso); }
+
+// -----------------------------------------------------------------------------------------
+// k_pgg_g2pg (option "fuse_bwd"): substep f's p2g_grad and, behind it in the same launch, substep f - 1's g2p_grad -- the reverse sweep's mirror of k_g2p_p2g.
+// The adjoints of x, v and C of frame f are produced by the first and consumed by the second: they stay in registers (60 bytes per particle not written,
+// 60 not read back; F's adjoint is stored, the next launch's p2g_grad part reads it), and a backward substep is two launches instead of three.  Same unit
+// list as k_g2p_grad2 (quad units, split waves: every lane of a split particle runs the p2g_grad part and holds the result); the two parts work through
+// ONE 36 KB arena of LDS one after the other (s_bw).  The SVD-free build only; the host fuses where nothing lies between the two kernels and the forward
+// pass stored grid[f - 1] (substep_bwd).  x v C of frame f's adjoint go to memory only where somebody else reads them: a particle that was not in use in
+// frame f - 1 (Injector.act's adjoint reads it in the next launch) or whose stencil there is off the grid.
+// -----------------------------------------------------------------------------------------
+struct BwdFuseP { float* fr_prev; float* Gp_; const float4* g_out; float* gg_out; float4* slab; };
+template <int MINW>
+__device__ __forceinline__ void p2g_grad_g2p_grad_body(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T, const int* __restrict__ pool_idx,
+                                                         const float4* __restrict__ gg_in, int* blk_count, int* slow, AgentP agent, InjectP inj, int act, int f,
+                                                         int fiso, BwdFuseP B, GridStore GS) {
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0 && tid == 0) {
+        *blk_count = 0;                                       // (substep f's list; substep f - 1's has a counter of its own: bcount)
+        if (act) for (int i = agent.n - 1; i >= 0; i--) effector_move_grad(agent.e[i], f);
+    }
+    VoutSrc V; V.g_out = B.g_out; V.store = GS.data + (size_t)(f - 1) * GS.cap * GS_BLK; V.blk_slot = T.blk_slot;
+    FrameV cur = frame_view(fr_cur, S.Np, 0, (fiso & 1) ? 1 : 0), prev = frame_view(B.fr_prev, S.Np);
+    FrameV Gn = frame_view(Gn_, S.Np, 0, (fiso & 2) ? 2 : 0);
+    FrameV Gc = frame_view(Gc_, S.Np, S.wt & 8, (fiso & 4) ? 2 : 0);      // the adjoint of frame f: its position part so far is read, F (and, where needed, x v C) written
+    FrameV Gp = frame_view(B.Gp_, S.Np, S.wt & 4);                           // the adjoint of frame f - 1: the position part g2p_grad leaves
+    const GradDst D = {Gc, nullptr, T.pid_of_slot};
+    float* const t4 = lds_tile4<true>();
+    double* const acc3 = lds_acc3<true>();
+    Unit un = unit_load(T, blockIdx.x);
+    const int n_slots = T.meta[5];
+    bool prev_quad = false;
+    for (int wg = blockIdx.x; wg < n_slots; wg += gridDim.x) {
+        if (wg != (int)blockIdx.x) un = unit_load(T, wg);
+        if (un.a.z == -2) continue;
+        if (un.a.z >= 0) {
+            const PairCtx pc = unit_ctx(un);
+            unit_enter(pc.quad, prev_quad);
+            const int4 it = pc.it;
+            const TileO to = tile_origin(it.x);
+            const int wbase = pc.quad ? 0 : (pc.i & 64);
+            const int cnt = __builtin_amdgcn_readfirstlane(min(64, max(0, it.z - wbase)));
+            const LaneSplit ls = lane_split(cnt, (S.lsplit & 2) != 0);
+            const int i = wbase + ls.p;
+            const bool has = ls.ok && i < it.z;
+            const int s = it.y + (has ? i : 0);
+            const int nbr_entry = neighbour_entry(T.blk_slot, S.nb, it.x);
+            // ---- part 1: p2g_grad of substep f (p2g_grad_body), one lane per particle -- all the lanes of a split particle
+            float* tl = t4 + pc.ti * 4 * TILE_N;                 // (a quad's third and fourth tile lie where the pair units keep their stash, as in k_p2g_grad)
+            if (pc.live) {
+                for (int l = pc.t0; l < TILE_N; l += pc.nth) {
+                    int ni, nj, nk;
+                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (tile_node(to, l, S.n, ni, nj, nk)) v = gg_in[cell_addr(ni, nj, nk, S.nb)];
+                    tl[l] = v.x; tl[TILE_N + l] = v.y; tl[2 * TILE_N + l] = v.z; tl[3 * TILE_N + l] = v.w;
+                }
+            }
+            unit_sync(pc.quad);
+            PState g;
+            bool kept = false;
+            P2GRaw no_pre;
+            if (has) {
+                if (pc.quad) kept = slot_p2g_grad<true, false, false, true, 1, true, true>(S, cur, Gn, Gc, s, T, pool_idx, to, gg_in, slow, agent, inj, f, 0, 0, no_pre, D, tl, 0, ls.primary, &g);
+                else kept = slot_p2g_grad<true, false, false, false, 1, true, true>(S, cur, Gn, Gc, s, T, pool_idx, to, gg_in, slow, agent, inj, f, pc.ti * 4 * TILE_N, 0, no_pre, D, nullptr, 0, ls.primary, &g);
+            }
+            if (!kept) {                                         // (behind the call, not in front of it: fifteen zeros would otherwise be kept through the whole p2g_grad part)
+#pragma unroll
+                for (int a = 0; a < 3; a++) { g.x[a] = 0.f; g.v[a] = 0.f; }
+                g.C = m3_zero();
+            }
+            // (pinned: the adjoint is fifteen values HERE -- left alone, the arithmetic that makes them sinks towards its uses in the g2p_grad part and its
+            //  forty inputs stay live, i.e. spilled, across the tile load in between)
+            asm volatile("" : "+v"(g.x[0]), "+v"(g.x[1]), "+v"(g.x[2]), "+v"(g.v[0]), "+v"(g.v[1]), "+v"(g.v[2]));
+            asm volatile("" : "+v"(g.C.a[0][0]), "+v"(g.C.a[0][1]), "+v"(g.C.a[0][2]), "+v"(g.C.a[1][0]), "+v"(g.C.a[1][1]), "+v"(g.C.a[1][2]), "+v"(g.C.a[2][0]), "+v"(g.C.a[2][1]), "+v"(g.C.a[2][2]));
+            unit_sync(pc.quad);                                  // the gathered tile and the stash are done with: the arena changes hands
+            // ---- part 2: g2p_grad of substep f - 1 (g2p_grad2_body) with frame f's adjoint in `g`
+            // (a quad's wave meets no barrier: its words of the g2p_grad part lie INSIDE the tile it gathered from in the p2g_grad part -- floats
+            //  [4 ti TILE_N, + 3 TILE_N) of the arena, a negative offset from the accumulators' base for the first two waves -- never in another wave's)
+            const int tofs = pc.quad ? pc.ti * 4 * TILE_N - 6 * TILE_N : pc.ti * 3 * TILE_N;      // (floats / doubles of a pair's tiles, words of a quad's one)
+            const int u0 = prev.used[s];
+            const float4 a00 = prev.A0[s];
+            float* gt = pc.quad ? (float*)acc3 + tofs : lds_tile3<true>() + tofs;
+            g2p_grad_load_tile2(to, S, B.g_out, V.store, nbr_entry, pc, gt);
+            if (!pc.quad && pc.live) for (int l = pc.t0; l < 3 * TILE_N; l += pc.nth) acc3[tofs + l] = 0.0;
+            unit_sync(pc.quad);
+            float inv = 1.f;
+            bool wshell = false;
+            {
+                const bool used = has && u0 != 0;
+                float x[3] = {0.f, 0.f, 0.f};
+                if (used) { x[0] = a00.x; x[1] = a00.y; x[2] = a00.z; }
+                Stencil st;
+                stencil_make(x, S.inv_dx, st);
+                const bool inside = used && stencil_inside(st, S.n);
+                const int lb = inside ? tile_base(to, st) : -1;
+                const bool live = lb >= 0;
+                if (has && kept && ls.primary && !inside) store_xvC(Gc, s, g.x, g.v, g.C);      // (not in use in frame f - 1, or off the grid there: read from memory by the next launch)
+                if (pc.quad) wshell = __any(live && stencil_on_shell(lb));
+                if (__any(live)) {
+                    if (pc.quad) inv = g2p_grad_particle2_split<MINW, true, true>(S, Gc, Gp, s, live ? lb : 0, st, live, tofs, gt, ls, &g);
+                    else g2p_grad_particle2_split<MINW, false, true>(S, Gc, Gp, s, live ? lb : 0, st, live, tofs, gt, ls, &g);
+                } else if (pc.quad && pc.live) {                 // nothing scattered: the hand-over must not see v_out as sums
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    for (int l = pc.t0; l < 3 * TILE_N; l += pc.nth) ((int*)acc3)[tofs + l] = 0;
+                }
+                g2p_grad_wave_slow<true>(S, Gc, Gp, s, a00, inside && !live && ls.primary, used && !inside && ls.primary, V, B.gg_out, slow, GS, &g);
+            }
+            unit_sync(pc.quad);
+            if (pc.quad) {
+                if (pc.live) quad_handover<3>(S, (const int*)acc3 + tofs, inv, inv, B.slab, pc.slab, B.gg_out, GS, to, nbr_entry, wshell, S.wt & 4);
+            } else if (pc.live) for (int l = pc.t0; l < TILE_N; l += pc.nth)
+                tile_handover<3>(S, B.slab, pc.slab, B.gg_out, GS, to, nbr_entry, l,
+                                 make_float4((float)acc3[tofs + l], (float)acc3[tofs + TILE_N + l], (float)acc3[tofs + 2 * TILE_N + l], 0.f), S.wt & 4);
+            unit_sync(pc.quad);
+        } else {
+            unit_enter(false, prev_quad);                        // (the stash columns of a tail unit lie where a quad's tiles do)
+            const int s = un.a.y + tid;
+            TileO none = {0, 0, 0};
+            P2GRaw none_pre;
+            if (s < S.N) {
+                PState g;
+                const bool kept = slot_p2g_grad<false, false, false, false, 1, true, true>(S, cur, Gn, Gc, s, T, pool_idx, none, gg_in, slow, agent, inj, f, 0, 0, none_pre, D, nullptr, 0, true, &g);
+                if (kept) {
+                    if (!prev.used[s]) store_xvC(Gc, s, g.x, g.v, g.C);
+                    else g2p_grad_slot_global<true>(S, prev, Gc, Gp, s, V, B.gg_out, agent, f - 1, GS, &g);
+                }
+            }
+        }
+    }
+}
+#ifndef FE_FB_WAVES_LESS
+#define FE_FB_WAVES_LESS 0      // (scripts/kres.py -DFE_FB_WAVES_LESS=1: the kernel's register peak when the launch bound leaves it room)
+#endif
+template <int MINW>
+__global__ FE_KALIGN __launch_bounds__(WG, MINW - FE_FB_WAVES_LESS) void k_pgg_g2pg(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T, const int* pool_idx, const float4* gg_in, int* blk_count, int* slow, AgentP agent, InjectP inj, int act, int f, int fiso, BwdFuseP B, GridStore GS) { p2g_grad_g2p_grad_body<MINW>(S, fr_cur, Gn_, Gc_, T, pool_idx, gg_in, blk_count, slow, agent, inj, act, f, fiso, B, GS); }
 
 
 // =========================================================================================
@@ -3654,8 +3850,8 @@ __global__ __launch_bounds__(256) void k_stats_count(int ncells, unsigned char* 
 // =========================================================================================
 // host side
 // =========================================================================================
-enum { KID_P2G = 0, KID_GRID, KID_G2P, KID_P2G_RE, KID_GRID_KEEP, KID_G2P_GRAD, KID_GRID_GRAD, KID_P2G_GRAD, KID_SORT, KID_REORDER_GRAD, KID_SORT_COUNT, KID_SORT_SCAN, KID_SORT_ACTIVE, KID_SORT_PERM, KID_G2P_P2G, KID_COUNT };
-static const char* KNAMES[KID_COUNT] = {"p2g", "grid_op", "g2p", "p2g_recompute", "grid_op_keep", "g2p_grad", "grid_op_grad", "p2g_grad", "sort", "reorder_grad", "sort_count", "sort_scan", "sort_active", "sort_perm", "g2p_p2g"};
+enum { KID_P2G = 0, KID_GRID, KID_G2P, KID_P2G_RE, KID_GRID_KEEP, KID_G2P_GRAD, KID_GRID_GRAD, KID_P2G_GRAD, KID_SORT, KID_REORDER_GRAD, KID_SORT_COUNT, KID_SORT_SCAN, KID_SORT_ACTIVE, KID_SORT_PERM, KID_G2P_P2G, KID_PGG_G2PG, KID_COUNT };
+static const char* KNAMES[KID_COUNT] = {"p2g", "grid_op", "g2p", "p2g_recompute", "grid_op_keep", "g2p_grad", "grid_op_grad", "p2g_grad", "sort", "reorder_grad", "sort_count", "sort_scan", "sort_active", "sort_perm", "g2p_p2g", "pgg_g2pg"};
 
 struct EffHost {
     EffP p;
@@ -3687,6 +3883,7 @@ struct FeEngine {
     std::vector<char> fiso;                                 // [L+1] frame f's F is stored compactly (FrameV::iso = 1): written by the SVD-free k_p2g
     bool gcompact[2] = {false, false};                      // ... and the adjoint of F in a ring slot (iso = 2): written by k_p2g_grad inside a ranged call
     bool compact_F = true;                                  // option "compact_F"
+    bool fuse_bwd = false;                                  // option "fuse_bwd": inside a fe_step_grad call a substep's p2g_grad takes the next substep's g2p_grad along (k_pgg_g2pg)
     bool fuse_g2p = true;                                   // option "fuse_g2p": inside a fe_step call the g2p of a substep runs at the head of the next substep's p2g launch (k_g2p_p2g)
     int tbl_bank = 0, last_sorted_f = -1;                   // two banks of table ids, one per sweep over the window (sort_frame)
     int p2g_grad_waves = 4;                                 // occupancy target of the SVD-free p2g_grad build (tuning)
@@ -4045,7 +4242,16 @@ int substep_fwd(FeEngine* h, int f, int f_global, int act, bool g2p_pending = fa
 // `next_f` >= 0: the caller goes on with substep next_f of the same sweep (fe_step_grad) -- when that one works in another particle order,
 // k_p2g_grad leaves the adjoint of frame f in that order right away (GradDst) instead of a reorder pass at the head of the next substep.
 // `compact_out`: the adjoint of frame f may be left with a compact F (nobody but the next substep of the same call reads it)
-int substep_bwd(FeEngine* h, int f, int f_global, int act, int next_f = -1, bool compact_out = false) {
+// Can substep f's p2g_grad take the g2p_grad of substep f - 1 along (k_pgg_g2pg)?  Nothing may lie between the two: the same particle order in frames
+// f - 1 and f (no reorder), no collide / rigid-body adjoint pass, no collector; the SVD-free build with its default kernels; and grid[f - 1] in the
+// per-frame store (a recompute would have to run first).  Option "fuse_bwd".
+inline bool fusable_bwd(FeEngine* h, int f) {
+    return h->fuse_bwd && f > 0 && h->all_simple_liquid && h->g2p_grad_v == 3 && h->p2g_grad_waves >= 4 && !particle_collide(h) && !h->has_rigid && !h->has_collector &&
+           h->tbl_of_frame[f - 1] == h->tbl_of_frame[f] && h->tbl_of_frame[f] >= 0 && h->gs_cap > 0 && h->gs_host_valid && h->gs_host[f - 1] != 0;
+}
+// `g2p_done`: the g2p_grad of this substep ran at the tail of the last launch of substep f + 1 (k_pgg_g2pg).  `fuse_next`: this substep's p2g_grad
+// takes the g2p_grad of substep f - 1 along (fusable_bwd(h, f) held and the caller goes on with f - 1).
+int substep_bwd(FeEngine* h, int f, int f_global, int act, int next_f = -1, bool compact_out = false, bool g2p_done = false, bool fuse_next = false) {
     InjectP inj;
     if (make_inject(h, f, f_global, act, false, inj)) return 1;
     // grad[f+1] arrives in the order frame f+1 is stored in; substep f works in frame f's order
@@ -4062,6 +4268,7 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act, int next_f = -1, bool
         h->gs_host_valid = true;
     }
     const bool stored = h->gs_cap > 0 && h->gs_host[f] != 0;
+    if (!g2p_done) {
     if (!stored) {
     h->stamp++;                                           // marks of the recompute (p2g -> grid_op)
     prof_begin(h, KID_P2G_RE);
@@ -4092,6 +4299,7 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act, int next_f = -1, bool
     else if (h->g2p_grad_v != 1) hipLaunchKernelGGL(k_g2p_grad2<4>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag);
     else hipLaunchKernelGGL(k_g2p_grad, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag);
     prof_end(h);
+    }                                                     // (!g2p_done; the marks of its scatter carry the stamp of the launch it ran in: no stamp++ since)
     prof_begin(h, KID_GRID_GRAD);
 #define LAUNCH_GRID_GRAD(ST_, DY_) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_grad<ST_, DY_>), ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, h->gg_out, \
                            h->gg_in, h->blk_list, bcount(h, f), h->blk_flag, grid_store(h), f, statics_p(h), ag, h->node_work, h->node_work_count)
@@ -4104,7 +4312,6 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act, int next_f = -1, bool
         else hipLaunchKernelGGL(k_grid_collide_grad<true>, wg, dim3(256), 0, h->stream, h->S, h->gg_in, f, statics_p(h), ag, h->node_work, h->node_work_count);
     } else { if (h->statics_host.empty()) LAUNCH_GRID_GRAD(false, false); else LAUNCH_GRID_GRAD(true, false); }
     prof_end(h);
-    prof_begin(h, KID_P2G_GRAD);
     const int t_next = (h->fold_reorder && next_f >= 0) ? h->tbl_of_frame[next_f] : t;
     const bool fold = t_next != t && t_next >= 0;
     float* g_dst = fold ? h->grad_ptr[2] : h->grad(f);
@@ -4113,7 +4320,14 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act, int next_f = -1, bool
     const int giso = (h->fiso[f] ? 1 : 0) | (h->gcompact[(f + 1) & 1] ? 2 : 0) | (gc_out ? 4 : 0);
 #define LAUNCH_P2G_GRAD(G, W) hipLaunchKernelGGL((k_p2g_grad<G, W>), wgrid_pgg(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), \
                            h->grad(f), T, h->pool_idx, h->gg_in, bcount(h, f), h->slow_dev, ag, inj, act, f, g_dst, to_slot, giso)
-    if (h->all_simple_liquid) {
+    if (!fuse_next) prof_begin(h, KID_P2G_GRAD);
+    if (fuse_next) {                                      // (same order in frames f - 1 and f: no fold; the SVD-free build)
+        h->stamp++;                                       // marks of substep f - 1's adjoint scatter (the launch's g2p_grad part -> its grid_op.grad)
+        const BwdFuseP B = {h->frame(f - 1), h->grad(f - 1), h->g_out, h->gg_out, h->slab};
+        prof_begin(h, KID_PGG_G2PG);
+        hipLaunchKernelGGL(k_pgg_g2pg<4>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->pool_idx, h->gg_in, bcount(h, f), h->slow_dev,
+                           ag, inj, act, f, giso, B, grid_store(h));
+    } else if (h->all_simple_liquid) {
         if (h->p2g_grad_waves >= 4) LAUNCH_P2G_GRAD(false, 4);
         else if (h->p2g_grad_waves == 3) LAUNCH_P2G_GRAD(false, 3);
         else LAUNCH_P2G_GRAD(false, 2);
@@ -4368,6 +4582,7 @@ FeEngine* fe_create(const FeConfig* cfg) {
     if (const char* e = std::getenv("FE_SORT_INTERVAL")) h->sort_interval = std::atoi(e);     // tuning experiments (the option of the same name wins)
     if (const char* e = std::getenv("FE_QUAD_MIN_UNITS")) h->quad_min_units = std::atoi(e);   // (task-level A/B of the quad units: scripts/run_envs.py)
     if (const char* e = std::getenv("FE_G2P_GRAD_V")) h->g2p_grad_v = std::atoi(e);           // (the parity suite is run once per build of the G2P adjoint)
+    if (const char* e = std::getenv("FE_FUSE_BWD")) h->fuse_bwd = std::atoi(e) != 0;
     if (const char* e = std::getenv("FE_FUSE_G2P")) h->fuse_g2p = std::atoi(e) != 0;           // (the parity suite with and without the fused forward launch)
     const char* env_lsplit = std::getenv("FE_LANE_SPLIT");                                    // (the parity suite with and without lane_split)
     h->cfg = *cfg; h->N = cfg->n_particles; h->L = cfg->max_substeps_local; h->n = cfg->n_grid; h->nb = cfg->n_grid / 4;
@@ -4522,6 +4737,7 @@ int fe_set_option(FeEngine* h, const char* name, double value) {
     if (!std::strcmp(name, "fold_reorder")) { h->fold_reorder = value != 0; return 0; }
     if (!std::strcmp(name, "compact_F")) { h->compact_F = value != 0; return 0; }
     if (!std::strcmp(name, "fuse_g2p")) { h->fuse_g2p = value != 0; return 0; }
+    if (!std::strcmp(name, "fuse_bwd")) { h->fuse_bwd = value != 0; return 0; }
     if (!std::strcmp(name, "quad_min_units")) { h->quad_min_units = (int)value; return 0; }
     if (!std::strcmp(name, "pgg_quad_min_units")) { h->pgg_quad_min_units = (int)value; return 0; }
     if (!std::strcmp(name, "pack_units")) { if (value < 0 || value > 2) FAIL(h, "pack_units must be 0, 1 or 2"); h->pack_units = (int)value; return 0; }
@@ -4542,7 +4758,7 @@ int fe_get_option(FeEngine* h, const char* name, double* value) {
         {"sort_interval", (double)h->sort_interval}, {"item_max", (double)h->item_max}, {"grid_store", h->gs_cap > 0 ? 1.0 : 0.0},
         {"p2g_grad_waves", (double)h->p2g_grad_waves}, {"g2p_grad_v", (double)h->g2p_grad_v}, {"loose_max", (double)h->loose_max},
         {"inject_till", (double)h->inject_till}, {"collide_min_y", (double)h->collide_min_y}, {"collide_type", (double)h->collide_type},
-        {"prof_fine", h->prof_fine ? 1.0 : 0.0}, {"xcd_map", (double)h->S.xcd}, {"write_through", (double)h->S.wt}, {"wave_sort", (double)h->S.wsort}, {"lane_split", (double)h->S.lsplit}, {"fold_reorder", h->fold_reorder ? 1.0 : 0.0}, {"compact_F", h->compact_F ? 1.0 : 0.0}, {"fuse_g2p", h->fuse_g2p ? 1.0 : 0.0},
+        {"prof_fine", h->prof_fine ? 1.0 : 0.0}, {"xcd_map", (double)h->S.xcd}, {"write_through", (double)h->S.wt}, {"wave_sort", (double)h->S.wsort}, {"lane_split", (double)h->S.lsplit}, {"fold_reorder", h->fold_reorder ? 1.0 : 0.0}, {"compact_F", h->compact_F ? 1.0 : 0.0}, {"fuse_g2p", h->fuse_g2p ? 1.0 : 0.0}, {"fuse_bwd", h->fuse_bwd ? 1.0 : 0.0},
         {"quad_min_units", (double)h->quad_min_units}, {"pgg_quad_min_units", (double)h->pgg_quad_min_units}, {"quad_max", (double)h->quad}, {"quad_fit", (double)h->quad_fit}, {"pack_units", (double)h->pack_units},
         {"wgrid_cap", (double)h->wgrid_cap}, {"wgrid_cap_g2p", (double)h->wgrid_cap_g2p}, {"wgrid_cap_pgg", (double)h->wgrid_cap_pgg}, {"ggrid_cap", (double)h->ggrid_cap}, {"threads", 0.0}};
     for (const auto& t : tab) if (!std::strcmp(name, t.n)) { *value = t.v; return 0; }
@@ -4641,7 +4857,13 @@ int fe_step_grad(FeEngine* h, int f0, int f_global0, int n, int act) {
     // (the call's last substep leaves the adjoint of frame f0 in the order of frame f0 - 1: where the next call of the sweep starts --
     //  fluidlab's step_grad is one call per env step, and with K = n_substeps a sort lies on every call boundary)
     // (i > 0: the adjoint of that frame is read by the next substep of this call and by nobody else -- its F may stay compact)
-    for (int i = n - 1; i >= 0; i--) if (substep_bwd(h, f0 + i, f_global0 + i, act, f0 + i > 0 ? f0 + i - 1 : -1, i > 0)) return 1;
+    bool done = false;
+    for (int i = n - 1; i >= 0; i--) {
+        // (the flags of the grid store are fetched by the first substep_bwd of a sweep: the first substep of a call never fuses ahead of them being known)
+        const bool fuse = i > 0 && fusable_bwd(h, f0 + i);
+        if (substep_bwd(h, f0 + i, f_global0 + i, act, f0 + i > 0 ? f0 + i - 1 : -1, i > 0, done, fuse)) return 1;
+        done = fuse;
+    }
     return check_async(h);
 }
 int fe_step_batch(FeEngine** hs, int n_env, int f0, int f_global0, int n, int act) {

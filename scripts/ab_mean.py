@@ -13,4 +13,4 @@ for ph in ('falling', 'impact', 'esplash', 'timed', 'splash', 'layer', 'all'):
     for c, ds in agg.items():
         us = sum(d['us_per_pair'] for d in ds) / len(ds)
         ks = {k: sum(d['us'].get(k, 0.0) for d in ds) / len(ds) for k in ds[0]['us']}
-        print(f"{c[:40]:40s} {1e6 / us:7.0f} p/s {us:7.1f} us | " + ' '.join(f"{k[:8]}={v:5.1f}" for k, v in ks.items() if k in ('p2g', 'g2p_p2g', 'grid_op', 'g2p', 'g2p_grad', 'grid_op_grad', 'p2g_grad', 'sort')))
+        print(f"{c[:40]:40s} {1e6 / us:7.0f} p/s {us:7.1f} us | " + ' '.join(f"{k[:8]}={v:5.1f}" for k, v in ks.items() if k in ('p2g', 'g2p_p2g', 'grid_op', 'g2p', 'g2p_grad', 'grid_op_grad', 'p2g_grad', 'pgg_g2pg', 'sort')))

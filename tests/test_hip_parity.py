@@ -847,3 +847,84 @@ def test_fused_g2p_p2g_with_an_injector(hiplib, oracle64):
         assert np.abs(a['final'][k] - b['final'][k]).max() <= 1e-5 * max(1.0, np.abs(b['final'][k]).max()), k
     assert S.rel_l2(a['action_grad'], b['action_grad']) <= 2e-5 and S.rel_l2(a['step_loss'], b['step_loss']) <= 1e-6
     assert S.cosine(a['action_grad'], o['action_grad']) >= 0.999999 and S.rel_l2(a['action_grad'], o['action_grad']) <= 1e-4
+
+
+@pytest.mark.parametrize('scene,opts', [('block', {}), ('block', {'compact_F': 0}), ('block', {'grid_store': 0}), ('droplets-water', {'quad_min_units': 0}),
+                                        ('droplets-water', {'quad_min_units': 0, 'lane_split': 0}), ('droplets-water', {'quad_min_units': 1 << 30, 'loose_max': 3})])
+def test_fused_p2g_grad_g2p_grad_launch_matches_separate_launches(hiplib, oracle64, scene, opts):
+    """Option fuse_bwd (round 5): inside a fe_step_grad call substep f's p2g_grad takes substep f - 1's g2p_grad along (k_pgg_g2pg) -- the adjoints of x, v, C of
+    frame f go from one to the other in registers and reach memory only for particles somebody else reads them of.  The same reverse sweep as three launches per
+    substep: two ranged calls with a loss seeded on the frame between them (the call boundary and every sort boundary are unfused substeps), against the unfused
+    engine run twice (its own noise) and the fp64 oracle.  Pair units, quad units (the wave's words of the g2p_grad part inside the tile it gathered from), split
+    waves, tail units, unused slots, drifted particles on both slow paths; without the per-frame grid store nothing fuses (the recompute comes first)."""
+    if scene == 'block':
+        rng = np.random.RandomState(5)
+        N = 6000
+        sc = S.water_block(n_grid=32, n_particles=N, seed=3, lo=0.3, hi=0.6)
+        sc['v'] = S.f32(rng.normal(0, 1.0, (N, 3)) + [2.0, -3.0, 1.0])
+        sc['used'] = (rng.rand(N) > 0.1).astype(np.int32)
+        K = 4
+    else:
+        sc = _droplet_scene(scene.split('-')[1])
+        N = len(sc['used'])
+        K = 10
+    n_sub, mid = 13, 6
+    cot, cot_mid = S.random_cotangent(N, seed=7), S.random_cotangent(N, seed=9)
+
+    def run(lib, o, ranged):
+        g = S.make_engine(lib, sc, options=o)
+        if lib is hiplib:
+            g.profile_enable(True)
+        g.step(0, 0, n_sub, 0) if ranged else [g.substep(f, f, 0) for f in range(n_sub)]
+        g.reset_grad()
+        g.add_grad(n_sub, cot['gx'], cot['gv'], cot['gC'], cot['gF'])
+        if ranged:
+            g.step_grad(mid, mid, n_sub - mid, 0)
+        else:
+            [g.substep_grad(f, f, 0) for f in reversed(range(mid, n_sub))]
+        at_mid = dict(zip(('gx', 'gv', 'gC', 'gF'), g.get_grad(mid)))
+        g.add_grad(mid, cot_mid['gx'], cot_mid['gv'], cot_mid['gC'], cot_mid['gF'])
+        if ranged:
+            g.step_grad(0, 0, mid, 0)
+        else:
+            [g.substep_grad(f, f, 0) for f in reversed(range(mid))]
+        out = dict(zip(('gx', 'gv', 'gC', 'gF'), g.get_grad(0)))
+        prof = g.profile_read() if lib is hiplib else None
+        stats = g.get_stats(n_sub) if lib is hiplib else None
+        g.close()
+        return at_mid, out, prof, stats
+
+    base = dict({'sort_interval': K}, **opts)
+    ma, ga, pa, st = run(hiplib, dict(base, fuse_bwd=1), True)
+    mb, gb, pb, _ = run(hiplib, dict(base, fuse_bwd=0), True)
+    mc, gc, _, _ = run(hiplib, dict(base, fuse_bwd=0), True)
+    mo, go, _, _ = run(oracle64, {}, False)
+    n_fused = pa.get('pgg_g2pg', (0, 0))[1]
+    if opts.get('grid_store', 1) == 0:
+        assert n_fused == 0
+    else:
+        # fused: every backward substep f whose predecessor f - 1 lies in the same call and the same sort interval
+        want = sum(1 for lo, hi in ((mid, n_sub), (0, mid)) for f in range(lo + 1, hi) if f % K != 0)
+        # (a frame whose grid store is incomplete -- a drifted particle reached a block outside the order's active list -- is recomputed, and its substep does not fuse)
+        assert (n_fused == want if scene == 'block' else want - 3 <= n_fused <= want) and pa['p2g_grad'][1] == n_sub - n_fused and pa['g2p_grad'][1] == n_sub - n_fused, (pa, want)
+    assert pb.get('pgg_g2pg', (0, 0))[1] == 0
+    if scene != 'block':
+        assert st['n_slow_path'] > 0, st
+    print(f'MEASURED fuse_bwd[{scene}, {opts}]: {n_fused} fused launches; fused vs separate', {k: round(S.rel_l2(ga[k], gb[k]), 9) for k in ga}, 'separate vs separate',
+          {k: round(S.rel_l2(gc[k], gb[k]), 9) for k in ga}, '| at the call boundary', {k: round(S.rel_l2(ma[k], mb[k]), 9) for k in ma}, '| vs fp64 oracle', {k: round(S.rel_l2(ga[k], go[k]), 8) for k in ga})
+    for got, ref, noise, orc in ((ma, mb, mc, mo), (ga, gb, gc, go)):
+        for k in ('gx', 'gv', 'gC', 'gF'):
+            assert np.isfinite(got[k]).all()
+            assert S.rel_l2(got[k], ref[k]) <= 4.0 * S.rel_l2(noise[k], ref[k]) + 2e-6, (k, S.rel_l2(got[k], ref[k]), S.rel_l2(noise[k], ref[k]))
+            assert S.cosine(got[k], orc[k]) >= 0.999 and S.rel_l2(got[k], orc[k]) <= 3e-3, (k, S.rel_l2(got[k], orc[k]))
+
+
+def test_fused_p2g_grad_g2p_grad_with_an_injector(hiplib, oracle64):
+    """... through a LatteArt-like pass: a particle injected in substep f - 1 is in use in frame f and not in frame f - 1 -- the fused launch stores its adjoint
+    (Injector.act's adjoint reads it in the next launch); pool particles pass theirs through untouched."""
+    sc = S.latte_mini()
+    a = S.run_latte(hiplib, sc, options={'fuse_bwd': 1, 'sort_interval': 3})
+    b = S.run_latte(hiplib, sc, options={'fuse_bwd': 0, 'sort_interval': 3})
+    o = S.run_latte(oracle64, sc)
+    assert S.rel_l2(a['action_grad'], b['action_grad']) <= 2e-5 and S.rel_l2(a['step_loss'], b['step_loss']) <= 1e-6
+    assert S.cosine(a['action_grad'], o['action_grad']) >= 0.999999 and S.rel_l2(a['action_grad'], o['action_grad']) <= 1e-4
