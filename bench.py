@@ -47,6 +47,7 @@ KERNEL_BYTES = {
     'p2g': (156, 16), 'grid_op': (0, 44), 'g2p': (60, 12),
     'g2p_p2g': (216, 28),                           # k_g2p_p2g: the g2p of one substep and the p2g of the next in one launch -- credited both (what it spares is the re-read of x' v' C')
     'p2g_recompute': (116, 16), 'grid_op_keep': (0, 28), 'g2p_grad': (60, 24), 'grid_op_grad': (0, 48), 'p2g_grad': (132, 16),
+    'pgg_g2pg': (192, 40),                          # k_pgg_g2pg: a substep's p2g_grad and the next one's g2p_grad in one launch -- credited both (spared: the round trip of the adjoints of x, v, C)
     'sort': (0, 0), 'reorder_grad': (0, 0),          # overhead of the cell-sorted layout: no algorithmic bytes credited
 }
 FWD_KERNELS = ('p2g', 'grid_op', 'g2p')
@@ -70,6 +71,8 @@ def launch_bytes(name, cnt, prof, n_used, nc):
     b = cnt * (bp * n_used + bc * nc)
     if name == 'p2g_grad':
         b += max(0, cnt - prof.get('p2g_recompute', (0.0, 0))[1]) * STATE_REREAD * n_used
+    if name == 'pgg_g2pg':                           # (fused only where the grid store spared the recompute: its p2g_grad part reads the state)
+        b += cnt * STATE_REREAD * n_used
     return b
 METRIC = 'MPM substeps/sec (fwd+bwd), 128^3 grid / 200k particles'
 
@@ -156,7 +159,8 @@ def fold_windows(rec, lo, hi):
     out = {'substeps': [lo * CHUNK, hi * CHUNK], 'nc_mean': int(nc), 'nc_min': int(min(min(r['nc0'], r['nc1']) for r in ws)),
            'nc_max': int(max(max(r['nc0'], r['nc1']) for r in ws)), 'kernels': kern}
     # share of the backward substeps whose grid[f] came from the per-frame store (no p2g_recompute / grid_op_keep launch)
-    stored = 1.0 - cnt.get('p2g_recompute', 0) / cnt['p2g_grad'] if cnt.get('p2g_grad') else None
+    n_bwd = cnt.get('p2g_grad', 0) + cnt.get('pgg_g2pg', 0)          # backward substeps: every one has exactly one p2g_grad, alone or at the head of a k_pgg_g2pg launch
+    stored = 1.0 - cnt.get('p2g_recompute', 0) / n_bwd if n_bwd else None
     out['bwd_frames_from_grid_store'] = None if stored is None else round(stored, 4)
     if plain:
         rate = len(plain) * CHUNK / sum(r['dt'] for r in plain)
@@ -407,7 +411,7 @@ def run_single(args):
                 traffic = int(pj['timed_region']['kernels'][dom]['traffic_bytes'])
                 # the committed rocprofv3 --kernel-trace of the same command, same windows (scripts/gpu_profile.sh wrote both files)
                 import csv
-                pre = {'p2g': 'k_p2g<true', 'g2p': 'k_g2p<', 'g2p_p2g': 'k_g2p_p2g', 'g2p_grad': 'k_g2p_grad', 'p2g_grad': 'k_p2g_grad', 'grid_op': 'k_grid<', 'grid_op_grad': 'k_grid_grad'}[dom]
+                pre = {'p2g': 'k_p2g<true', 'g2p': 'k_g2p<', 'g2p_p2g': 'k_g2p_p2g', 'pgg_g2pg': 'k_pgg_g2pg', 'g2p_grad': 'k_g2p_grad', 'p2g_grad': 'k_p2g_grad', 'grid_op': 'k_grid<', 'grid_op_grad': 'k_grid_grad'}[dom]
                 tot = cnt = 0
                 for r in csv.DictReader(open(ROCPROF_TIMED)):
                     if r['Name'].replace('void ', '').startswith(pre):

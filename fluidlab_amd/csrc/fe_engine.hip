@@ -2554,7 +2554,9 @@ __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const Fram
         m3 M = m3_zero();
         const int gi = gofs >> 6, gj = (gofs >> 3) & 7;          // a split wave: this lane's x (and y) offset
         const int lg = lb + (G > 1 ? gofs : 0);
-#pragma unroll
+        // (k_pgg_g2pg's road for drifted particles and tail units walks the nine columns one after the other: unrolled, its 27 float4 loads are in flight
+        //  together and the kernel, which has no register to spare, spills around them)
+#pragma unroll (!TILE && KEEP) ? 1 : 9
         for (int ij = 0; ij < 9; ij++) {
             const int ic = ij / 3, jc = ij - 3 * ic;
             if ((G > 1 && ic > 0) || (G == 9 && jc > 0)) continue;      // (compile time)
@@ -2666,6 +2668,8 @@ __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const Fram
 }
 
 // Returns whether the slot holds a used particle (KEEP: its adjoint is then in `keep`, not in memory).
+// (KEEP && TILE: a slot of a work item that is not in use was taken out of use by the host since the sort -- the sort puts unused particles behind the
+//  items, and a particle the Injector is about to use waits there: no Injector.act adjoint on this road, which keeps its code out of k_pgg_g2pg's unit loop)
 template <bool TILE, bool GENERAL, bool PRE = false, bool NOSTASH = false, int G = 1, bool AR = false, bool KEEP = false>
 __device__ __forceinline__ bool slot_p2g_grad(const SimP& S, const FrameV& cur, const FrameV& Gn, const FrameV& Gc, int s, const TableP& T,
                                               const int* __restrict__ pool_idx,
@@ -2681,7 +2685,7 @@ __device__ __forceinline__ bool slot_p2g_grad(const SimP& S, const FrameV& cur, 
     // this very substep injects the particle (then frame f + 1 has it in use and the used path of substep f + 1 wrote the slot: a third of the trace
     // on the diagonal is that adjoint exactly, the adjoint of an isotropic F being isotropic).
     bool injected = false;
-    if (inj.on) { const int j = pool_idx[T.pid_of_slot[s]] - inj.act_id; injected = j >= 0 && j < inj.flux; }
+    if (!(KEEP && TILE) && inj.on) { const int j = pool_idx[T.pid_of_slot[s]] - inj.act_id; injected = j >= 0 && j < inj.flux; }
     FrameV Gn_f = Gn, Dg_f = D.G;
     if (!injected) Gn_f.iso = 0;
     Dg_f.iso = 0;
@@ -2689,7 +2693,7 @@ __device__ __forceinline__ bool slot_p2g_grad(const SimP& S, const FrameV& cur, 
     if (Gn_f.iso == 2) { const float t = g.F.a[2][2] * (1.f / 3.f); g.F.a[0][0] = g.F.a[1][1] = g.F.a[2][2] = t; }
     const int sd = D.slot(s);
     store_xvC(D.G, sd, g.x, g.v, g.C); store_F(Dg_f, sd, g.F);
-    if (inj.on) {
+    if (!(KEEP && TILE) && inj.on) {
         int j = pool_idx[T.pid_of_slot[s]] - inj.act_id;
         if (j >= 0 && j < inj.flux) {                      // x[f+1,pid] = offset + pos[f] + R(q) inject_p
             const EffP& e = agent.e[agent.inj];
@@ -2818,7 +2822,7 @@ __global__ FE_KALIGN __launch_bounds__(WG, MINW) void k_p2g_grad_b(Batch<P2GGrad
 // k_pgg_g2pg (option "fuse_bwd"): substep f's p2g_grad and, behind it in the same launch, substep f - 1's g2p_grad -- the reverse sweep's mirror of k_g2p_p2g.
 // The adjoints of x, v and C of frame f are produced by the first and consumed by the second: they stay in registers (60 bytes per particle not written,
 // 60 not read back; F's adjoint is stored, the next launch's p2g_grad part reads it), and a backward substep is two launches instead of three.  Same unit
-// list as k_g2p_grad2 (quad units, split waves: every lane of a split particle runs the p2g_grad part and holds the result); the two parts work through
+// list as k_g2p_grad2 (quad units; waves are not split here -- option lane_split's bit 2 is k_g2p_grad2's); the two parts work through
 // ONE 36 KB arena of LDS one after the other (s_bw).  The SVD-free build only; the host fuses where nothing lies between the two kernels and the forward
 // pass stored grid[f - 1] (substep_bwd).  x v C of frame f's adjoint go to memory only where somebody else reads them: a particle that was not in use in
 // frame f - 1 (Injector.act's adjoint reads it in the next launch) or whose stencil there is off the grid.
@@ -2841,11 +2845,13 @@ __device__ __forceinline__ void p2g_grad_g2p_grad_body(SimP S, float* fr_cur, fl
     const GradDst D = {Gc, nullptr, T.pid_of_slot};
     float* const t4 = lds_tile4<true>();
     double* const acc3 = lds_acc3<true>();
-    Unit un = unit_load(T, blockIdx.x);
+    // (every unit's record is asked for at the head of its own round -- the first one together with the list's length, as in the other kernels, the one behind
+    //  the last unit in vain: carried into the loop from in front of it, the record's twelve words lived in vector registers across the whole loop, spilled)
     const int n_slots = T.meta[5];
-    bool prev_quad = false;
-    for (int wg = blockIdx.x; wg < n_slots; wg += gridDim.x) {
-        if (wg != (int)blockIdx.x) un = unit_load(T, wg);
+    bool prev_quad = false, any_tail = false;
+    for (int wg = blockIdx.x; ; wg += gridDim.x) {
+        const Unit un = unit_load(T, wg);
+        if (wg >= n_slots) break;
         if (un.a.z == -2) continue;
         if (un.a.z >= 0) {
             const PairCtx pc = unit_ctx(un);
@@ -2854,7 +2860,7 @@ __device__ __forceinline__ void p2g_grad_g2p_grad_body(SimP S, float* fr_cur, fl
             const TileO to = tile_origin(it.x);
             const int wbase = pc.quad ? 0 : (pc.i & 64);
             const int cnt = __builtin_amdgcn_readfirstlane(min(64, max(0, it.z - wbase)));
-            const LaneSplit ls = lane_split(cnt, (S.lsplit & 2) != 0);
+            const LaneSplit ls = lane_split(cnt, false);
             const int i = wbase + ls.p;
             const bool has = ls.ok && i < it.z;
             const int s = it.y + (has ? i : 0);
@@ -2911,8 +2917,8 @@ __device__ __forceinline__ void p2g_grad_g2p_grad_body(SimP S, float* fr_cur, fl
                 if (has && kept && ls.primary && !inside) store_xvC(Gc, s, g.x, g.v, g.C);      // (not in use in frame f - 1, or off the grid there: read from memory by the next launch)
                 if (pc.quad) wshell = __any(live && stencil_on_shell(lb));
                 if (__any(live)) {
-                    if (pc.quad) inv = g2p_grad_particle2_split<MINW, true, true>(S, Gc, Gp, s, live ? lb : 0, st, live, tofs, gt, ls, &g);
-                    else g2p_grad_particle2_split<MINW, false, true>(S, Gc, Gp, s, live ? lb : 0, st, live, tofs, gt, ls, &g);
+                    if (pc.quad) inv = g2p_grad_particle2<MINW, true, 1, true>(S, Gc, Gp, s, live ? lb : 0, st, live, tofs, gt, 0, true, &g);
+                    else g2p_grad_particle2<MINW, false, 1, true>(S, Gc, Gp, s, live ? lb : 0, st, live, tofs, gt, 0, true, &g);
                 } else if (pc.quad && pc.live) {                 // nothing scattered: the hand-over must not see v_out as sums
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     for (int l = pc.t0; l < 3 * TILE_N; l += pc.nth) ((int*)acc3)[tofs + l] = 0;
@@ -2926,9 +2932,19 @@ __device__ __forceinline__ void p2g_grad_g2p_grad_body(SimP S, float* fr_cur, fl
                 tile_handover<3>(S, B.slab, pc.slab, B.gg_out, GS, to, nbr_entry, l,
                                  make_float4((float)acc3[tofs + l], (float)acc3[tofs + TILE_N + l], (float)acc3[tofs + 2 * TILE_N + l], 0.f), S.wt & 4);
             unit_sync(pc.quad);
-        } else {
-            unit_enter(false, prev_quad);                        // (the stash columns of a tail unit lie where a quad's tiles do)
-            const int s = un.a.y + tid;
+        } else any_tail = true;
+    }
+    // The tail units (slots behind the items: loose blocks' particles, unused slots) in a loop of their own behind the tile units: in ONE loop what the two kinds of
+    // unit keep in registers is alive across both, and the kernel has none to spare.  (The list has them last; a workgroup walks its few units twice.)
+    if (!any_tail) return;
+    __syncthreads();                                          // (the stash columns lie where the last unit's tiles do)
+    for (int wg = blockIdx.x; wg < n_slots; wg += gridDim.x) {
+        const Unit un = unit_load(T, wg);
+        if (un.a.z != -1) continue;
+        {
+            int t_ = tid;
+            asm volatile("" : "+v"(t_));
+            const int s = un.a.y + t_;
             TileO none = {0, 0, 0};
             P2GRaw none_pre;
             if (s < S.N) {
@@ -3883,7 +3899,7 @@ struct FeEngine {
     std::vector<char> fiso;                                 // [L+1] frame f's F is stored compactly (FrameV::iso = 1): written by the SVD-free k_p2g
     bool gcompact[2] = {false, false};                      // ... and the adjoint of F in a ring slot (iso = 2): written by k_p2g_grad inside a ranged call
     bool compact_F = true;                                  // option "compact_F"
-    bool fuse_bwd = false;                                  // option "fuse_bwd": inside a fe_step_grad call a substep's p2g_grad takes the next substep's g2p_grad along (k_pgg_g2pg)
+    bool fuse_bwd = true;                                   // option "fuse_bwd": inside a fe_step_grad call a substep's p2g_grad takes the next substep's g2p_grad along (k_pgg_g2pg)
     bool fuse_g2p = true;                                   // option "fuse_g2p": inside a fe_step call the g2p of a substep runs at the head of the next substep's p2g launch (k_g2p_p2g)
     int tbl_bank = 0, last_sorted_f = -1;                   // two banks of table ids, one per sweep over the window (sort_frame)
     int p2g_grad_waves = 4;                                 // occupancy target of the SVD-free p2g_grad build (tuning)

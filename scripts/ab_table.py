@@ -1,7 +1,7 @@
 """pretty-print the json lines of scripts/ab_phases.py.  usage: ab_table.py <ab.txt>"""
 import json, sys
 rows = [json.loads(l) for l in open(sys.argv[1]) if l.startswith('{')]
-ks = ['p2g', 'g2p_p2g', 'grid_op', 'g2p', 'g2p_grad', 'grid_op_grad', 'p2g_grad', 'sort', 'reorder_grad', 'sort_count', 'sort_scan', 'sort_active', 'sort_perm']
+ks = ['p2g', 'g2p_p2g', 'grid_op', 'g2p', 'g2p_grad', 'grid_op_grad', 'p2g_grad', 'pgg_g2pg', 'sort', 'reorder_grad', 'sort_count', 'sort_scan', 'sort_active', 'sort_perm']
 for ph in ('falling', 'impact', 'esplash', 'timed', 'splash', 'layer', 'all'):
     print('==', ph)
     for r in rows:

@@ -20,7 +20,7 @@ OUT = os.environ.get('PROFILE_OUT', 'profiles')          # (on the GPU box: a di
 
 CHUNK = 100
 BENCH_NAME = [('k_p2g_grad', 'p2g_grad'), ('k_g2p_grad', 'g2p_grad'), ('k_grid_grad', 'grid_op_grad'), ('k_p2g<true', 'p2g'), ('k_p2g<false', 'p2g_recompute'),
-              ('k_grid<false', 'grid_op'), ('k_grid<true', 'grid_op_keep'), ('k_g2p<', 'g2p'), ('k_g2p_p2g', 'g2p_p2g')]
+              ('k_grid<false', 'grid_op'), ('k_grid<true', 'grid_op_keep'), ('k_g2p<', 'g2p'), ('k_g2p_p2g', 'g2p_p2g'), ('k_pgg_g2pg', 'pgg_g2pg')]
 SORT_KERNELS = ('k_sort', 'k_scan', 'k_build', 'k_clear_slots', 'k_set_static', 'k_block')
 FIXED = {'falling': (5, 11), 'impact': (11, 18), 'splash': (18, 45), 'layer': (45, 10**9)}
 
@@ -61,7 +61,7 @@ def windows(names):
         if n.startswith(('k_p2g<true', 'k_g2p_p2g')):          # a forward substep starts: its p2g, alone or behind the previous substep's g2p in one launch
             out.append(n_fwd // CHUNK); n_fwd += 1; forward = True
             continue
-        if n.startswith(('k_g2p_grad', 'k_grid_grad', 'k_p2g_grad', 'k_p2g<false', 'k_grid<true', 'k_perm_reorder', 'k_loss_bwd')):
+        if n.startswith(('k_g2p_grad', 'k_grid_grad', 'k_p2g_grad', 'k_pgg_g2pg', 'k_p2g<false', 'k_grid<true', 'k_perm_reorder', 'k_loss_bwd')):
             forward = False
         if forward and n.startswith(SORT_KERNELS):
             out.append(n_fwd // CHUNK)                       # the sort ahead of the substep that is about to start
@@ -96,7 +96,7 @@ def stats(tag, path, steps, warmup):
                 mean = sum(v) / len(v)
                 sd = math.sqrt(sum((x - mean) ** 2 for x in v) / len(v))
                 wr.writerow([nm, len(v), sum(v), round(mean, 3), round(100 * sum(v) / total, 2), min(v), max(v), round(sd, 3)])
-        pairs = sum(len(v) for nm, v in dur.items() if clean(nm).startswith('k_p2g_grad'))
+        pairs = sum(len(v) for nm, v in dur.items() if clean(nm).startswith(('k_p2g_grad', 'k_pgg_g2pg')))      # a backward substep has one p2g_grad, alone or at the head of a k_pgg_g2pg launch
         print(f'{out}: windows [{a},{b}) = substeps {a * CHUNK}..{b * CHUNK}, {pairs} backward substeps, kernel time {1e-3 * total / max(1, pairs):.1f} us per pair')
         for nm, v in sorted(dur.items(), key=lambda kv: -sum(kv[1]))[:8]:
             print(f'    {clean(nm)[:44]:46s} {len(v):6d} x {1e-3 * sum(v) / len(v):7.2f} us')

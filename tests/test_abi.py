@@ -62,4 +62,5 @@ def test_bench_byte_accounting_matches_the_survey():
     assert (sum(p for p, _ in bwd), sum(c for _, c in bwd)) == (308, 132)
     assert kb['sort'] == (0, 0) and kb['reorder_grad'] == (0, 0)            # layout overhead is never credited
     assert kb['g2p_p2g'] == (kb['g2p'][0] + kb['p2g'][0], kb['g2p'][1] + kb['p2g'][1])      # the fused forward launch does both kernels' work
+    assert kb['pgg_g2pg'] == (kb['p2g_grad'][0] + kb['g2p_grad'][0], kb['p2g_grad'][1] + kb['g2p_grad'][1])      # ... and the fused backward launch
     assert bench.HBM_PEAK_GBS == 8000.0 and bench.N_GRID == 128 and bench.N_PARTICLES == 200000

@@ -16,8 +16,12 @@ NO_SCRATCH = [
     'k_p2g_b<true, false>', 'k_grid_b<false, false, false>', 'k_g2p_b<false>', 'k_g2p_grad2_b<4>', 'k_grid_grad_b<false, false>', 'k_p2g_grad_b<false, 4>',
     'k_sort_count', 'k_sort_blk_partial', 'k_sort_blk_final', 'k_sort_apply', 'k_perm_reorder',
 ]
+# k_pgg_g2pg (the fused backward launch) holds the fifteen adjoints it hands from its p2g_grad part to its g2p_grad part on top of what k_p2g_grad needs at its
+# peak: a dozen single-register spills around the gather loop are left (48 bytes; measured: no difference in time to the build that had 112) -- bounded here so
+# that it does not grow back to the 192 the first build had (a stack object the optimiser could not see through, and the unit record carried across the loop).
+SCRATCH_CAP = {'k_pgg_g2pg<4>': 64}
 # occupancy the launch bounds promise: VGPRs per lane at most 512 / waves per SIMD
-MAX_VGPR = {'k_p2g<true, false>': 128, 'k_g2p_p2g<false>': 128, 'k_g2p_p2g<true>': 168, 'k_g2p<false>': 84, 'k_g2p_grad2<4>': 128, 'k_p2g_grad<false, 4>': 128, 'k_grid<false, false, false>': 128,
+MAX_VGPR = {'k_p2g<true, false>': 128, 'k_pgg_g2pg<4>': 128, 'k_g2p_p2g<false>': 128, 'k_g2p_p2g<true>': 168, 'k_g2p<false>': 84, 'k_g2p_grad2<4>': 128, 'k_p2g_grad<false, 4>': 128, 'k_grid<false, false, false>': 128,
             'k_grid_grad<false, false>': 128, 'k_p2g<true, true>': 168, 'k_p2g_grad<true, 1>': 168}
 
 
@@ -35,6 +39,8 @@ def test_substep_kernels_do_not_spill(resources):
     assert not missing, f'kernels not found in the code object: {missing} (have: {sorted(resources)[:8]} ...)'
     bad = {k: resources[k] for k in NO_SCRATCH if resources[k]['scratch'] != 0 or resources[k]['vgpr_spills'] != 0}
     assert not bad, f'scratch / VGPR spills in substep kernels: {bad}'
+    over = {k: resources[k]['scratch'] for k, cap in SCRATCH_CAP.items() if resources[k]['scratch'] > cap}
+    assert not over, f'more scratch than accounted for: {over}'
 
 
 def test_substep_kernels_keep_their_occupancy(resources):
@@ -50,7 +56,7 @@ def test_substep_kernels_are_aligned_in_the_code_object():
     spec = importlib.util.spec_from_file_location('kres', os.path.join(ROOT, 'scripts', 'kres.py'))
     kres = importlib.util.module_from_spec(spec); spec.loader.exec_module(kres)
     addr = kres.kernel_addresses()
-    hot = ['k_p2g<true, false>', 'k_g2p_p2g<false>', 'k_grid<false, false, false>', 'k_g2p<false>', 'k_g2p_grad2<4>', 'k_grid_grad<false, false>', 'k_p2g_grad<false, 4>']
+    hot = ['k_p2g<true, false>', 'k_g2p_p2g<false>', 'k_pgg_g2pg<4>', 'k_grid<false, false, false>', 'k_g2p<false>', 'k_g2p_grad2<4>', 'k_grid_grad<false, false>', 'k_p2g_grad<false, 4>']
     missing = [k for k in hot if k not in addr]
     assert not missing, missing
     off = {k: hex(addr[k][0]) for k in hot if addr[k][0] % 16384}
