@@ -4258,6 +4258,16 @@ int substep_fwd(FeEngine* h, int f, int f_global, int act, bool g2p_pending = fa
 // `next_f` >= 0: the caller goes on with substep next_f of the same sweep (fe_step_grad) -- when that one works in another particle order,
 // k_p2g_grad leaves the adjoint of frame f in that order right away (GradDst) instead of a reorder pass at the head of the next substep.
 // `compact_out`: the adjoint of frame f may be left with a compact F (nobody but the next substep of the same call reads it)
+// one small D2H per backward sweep: which frames have a stored grid
+int fetch_gs_flags(FeEngine* h) {
+    if (h->gs_cap > 0 && !h->gs_host_valid) {
+        h->gs_host.resize(h->L + 1);
+        HIPCK(h, hipMemcpyAsync(h->gs_host.data(), h->gs_flag, sizeof(int) * (h->L + 1), hipMemcpyDeviceToHost, h->stream));
+        HIPCK(h, hipStreamSynchronize(h->stream));
+        h->gs_host_valid = true;
+    }
+    return 0;
+}
 // Can substep f's p2g_grad take the g2p_grad of substep f - 1 along (k_pgg_g2pg)?  Nothing may lie between the two: the same particle order in frames
 // f - 1 and f (no reorder), no collide / rigid-body adjoint pass, no collector; the SVD-free build with its default kernels; and grid[f - 1] in the
 // per-frame store (a recompute would have to run first).  Option "fuse_bwd".
@@ -4277,12 +4287,7 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act, int next_f = -1, bool
     const TableP T = h->tableP(t);
     AgentP ag = agent_params(h);
     InjectP noinj = {0, 0, 0, 0};
-    if (h->gs_cap > 0 && !h->gs_host_valid) {            // one small D2H per backward sweep: which frames have a stored grid
-        h->gs_host.resize(h->L + 1);
-        HIPCK(h, hipMemcpyAsync(h->gs_host.data(), h->gs_flag, sizeof(int) * (h->L + 1), hipMemcpyDeviceToHost, h->stream));
-        HIPCK(h, hipStreamSynchronize(h->stream));
-        h->gs_host_valid = true;
-    }
+    if (fetch_gs_flags(h)) return 1;
     const bool stored = h->gs_cap > 0 && h->gs_host[f] != 0;
     if (!g2p_done) {
     if (!stored) {
@@ -4874,8 +4879,8 @@ int fe_step_grad(FeEngine* h, int f0, int f_global0, int n, int act) {
     //  fluidlab's step_grad is one call per env step, and with K = n_substeps a sort lies on every call boundary)
     // (i > 0: the adjoint of that frame is read by the next substep of this call and by nobody else -- its F may stay compact)
     bool done = false;
+    if (n > 1 && fetch_gs_flags(h)) return 1;            // (fusable_bwd asks which frames have their grid stored)
     for (int i = n - 1; i >= 0; i--) {
-        // (the flags of the grid store are fetched by the first substep_bwd of a sweep: the first substep of a call never fuses ahead of them being known)
         const bool fuse = i > 0 && fusable_bwd(h, f0 + i);
         if (substep_bwd(h, f0 + i, f_global0 + i, act, f0 + i > 0 ? f0 + i - 1 : -1, i > 0, done, fuse)) return 1;
         done = fuse;

@@ -8,7 +8,7 @@ echo "== pytest -m gpu -s"; timeout 1500 python -m pytest tests -m gpu -q -s 2>&
 echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
 bash scripts/gpu_profile.sh $TAG 20 5 2>&1 | tail -30
 cp gpurun_out/$TAG/profiles/* profiles/
-bash scripts/gpu_pmc_icache.sh ${TAG}ic > gpurun_out/$TAG/pmc_issue_counters.txt 2>&1; grep -E "k_p2g|k_g2p|k_grid" gpurun_out/$TAG/pmc_issue_counters.txt | grep VALU | cut -c1-250
+bash scripts/gpu_pmc_icache.sh ${TAG}ic > gpurun_out/$TAG/pmc_issue_counters.txt 2>&1; grep -E "k_p2g|k_g2p|k_grid|k_pgg" gpurun_out/$TAG/pmc_issue_counters.txt | grep VALU | cut -c1-250
 echo "== work list by window"; timeout 300 python scripts/work_probe.py 35 2>&1 | grep -v amdgpu.ids > gpurun_out/$TAG/work_list_by_window.txt; tail -3 gpurun_out/$TAG/work_list_by_window.txt
 bash scripts/gpu_final.sh ${TAG}f
 bash scripts/gpu_prof_1m.sh ${TAG}m1 2>&1 | tail -12
