@@ -1265,12 +1265,14 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
         }
     }
 }
-struct P2GArgs { SimP S; float* fr_cur; float* fr_next; TableP T; const int* pool_idx; GridW G; AgentP agent; InjectP inj; int act; int f; GridStore GS; int fiso; };
+struct P2GArgs { SimP S; float* fr_cur; float* fr_next; TableP T; const int* pool_idx; GridW G; AgentP agent; InjectP inj; int act; int f; GridStore GS; int fiso; FuseP FU; };      // (FU: k_g2p_p2g_b)
 template <bool WRITE, bool GENERAL>
 __global__ FE_KALIGN __launch_bounds__(WG, GENERAL ? 3 : 4) void k_p2g(SimP S, float* fr_cur, float* fr_next, TableP T, const int* pool_idx, GridW G, AgentP agent, InjectP inj, int act, int f, GridStore GS, int fiso) { p2g_body<WRITE, GENERAL>(S, fr_cur, fr_next, T, pool_idx, G, agent, inj, act, f, GS, fiso); }
 // substep f's p2g with the g2p of substep f - 1 in front of it (p2g_body, FUSED)
 template <bool GENERAL>
 __global__ FE_KALIGN __launch_bounds__(WG, GENERAL ? 3 : 4) void k_g2p_p2g(SimP S, float* fr_cur, float* fr_next, TableP T, const int* pool_idx, GridW G, AgentP agent, InjectP inj, int act, int f, GridStore GS, int fiso, FuseP FU) { p2g_body<true, GENERAL, true>(S, fr_cur, fr_next, T, pool_idx, G, agent, inj, act, f, GS, fiso, FU); }
+template <bool GENERAL>
+__global__ FE_KALIGN __launch_bounds__(WG, GENERAL ? 3 : 4) void k_g2p_p2g_b(Batch<P2GArgs> B) { const P2GArgs& A = B.a[blockIdx.y]; p2g_body<true, GENERAL, true>(A.S, A.fr_cur, A.fr_next, A.T, A.pool_idx, A.G, A.agent, A.inj, A.act, A.f, A.GS, A.fiso, A.FU); }
 template <bool WRITE, bool GENERAL>
 __global__ FE_KALIGN __launch_bounds__(WG, GENERAL ? 3 : 4) void k_p2g_b(Batch<P2GArgs> B) { const P2GArgs& A = B.a[blockIdx.y]; p2g_body<WRITE, GENERAL>(A.S, A.fr_cur, A.fr_next, A.T, A.pool_idx, A.G, A.agent, A.inj, A.act, A.f, A.GS, A.fiso); }
 
@@ -2554,9 +2556,10 @@ __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const Fram
         m3 M = m3_zero();
         const int gi = gofs >> 6, gj = (gofs >> 3) & 7;          // a split wave: this lane's x (and y) offset
         const int lg = lb + (G > 1 ? gofs : 0);
+        constexpr int UNR_IJ = (!TILE && KEEP) ? 1 : 9;
         // (k_pgg_g2pg's road for drifted particles and tail units walks the nine columns one after the other: unrolled, its 27 float4 loads are in flight
         //  together and the kernel, which has no register to spare, spills around them)
-#pragma unroll (!TILE && KEEP) ? 1 : 9
+#pragma unroll UNR_IJ
         for (int ij = 0; ij < 9; ij++) {
             const int ic = ij / 3, jc = ij - 3 * ic;
             if ((G > 1 && ic > 0) || (G == 9 && jc > 0)) continue;      // (compile time)
@@ -2958,11 +2961,14 @@ __device__ __forceinline__ void p2g_grad_g2p_grad_body(SimP S, float* fr_cur, fl
         }
     }
 }
+struct PggArgs { SimP S; float* fr_cur; float* Gn_; float* Gc_; TableP T; const int* pool_idx; const float4* gg_in; int* blk_count; int* slow; AgentP agent; InjectP inj; int act; int f; int fiso; BwdFuseP B; GridStore GS; };
 #ifndef FE_FB_WAVES_LESS
 #define FE_FB_WAVES_LESS 0      // (scripts/kres.py -DFE_FB_WAVES_LESS=1: the kernel's register peak when the launch bound leaves it room)
 #endif
 template <int MINW>
 __global__ FE_KALIGN __launch_bounds__(WG, MINW - FE_FB_WAVES_LESS) void k_pgg_g2pg(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T, const int* pool_idx, const float4* gg_in, int* blk_count, int* slow, AgentP agent, InjectP inj, int act, int f, int fiso, BwdFuseP B, GridStore GS) { p2g_grad_g2p_grad_body<MINW>(S, fr_cur, Gn_, Gc_, T, pool_idx, gg_in, blk_count, slow, agent, inj, act, f, fiso, B, GS); }
+template <int MINW>
+__global__ FE_KALIGN __launch_bounds__(WG, MINW - FE_FB_WAVES_LESS) void k_pgg_g2pg_b(Batch<PggArgs> Bt) { const PggArgs& A = Bt.a[blockIdx.y]; p2g_grad_g2p_grad_body<MINW>(A.S, A.fr_cur, A.Gn_, A.Gc_, A.T, A.pool_idx, A.gg_in, A.blk_count, A.slow, A.agent, A.inj, A.act, A.f, A.fiso, A.B, A.GS); }
 
 
 // =========================================================================================
@@ -4394,7 +4400,7 @@ void batch_join(FeEngine** hs, int B) {
     }
 }
 
-int substep_fwd_batch(FeEngine** hs, int B, int f, int f_global, int act) {
+int substep_fwd_batch(FeEngine** hs, int B, int f, int f_global, int act, bool g2p_pending = false, bool defer_g2p = false) {      // (g2p_pending / defer_g2p: as in substep_fwd)
     FeEngine* h0 = hs[0];
     Batch<P2GArgs> bp; Batch<GridArgs> bg; Batch<G2PArgs> bq;
     const bool sorting = h0->sort_interval > 0 && f % h0->sort_interval == 0;     // (batchable: the same interval in every engine)
@@ -4414,28 +4420,37 @@ int substep_fwd_batch(FeEngine** hs, int B, int f, int f_global, int act) {
         const TableP T = h->tableP(h->tbl_of_frame[f]);
         const AgentP ag = agent_params(h);
         const int fiso = fwd_iso(h, f);
-        bp.a[i] = P2GArgs{h->S, h->frame(f), h->frame(f + 1), T, h->pool_idx, grid_w(h, f), ag, inj, act, f, grid_store(h), h->all_simple_liquid ? fiso : 0};
+        bp.a[i] = P2GArgs{h->S, h->frame(f), h->frame(f + 1), T, h->pool_idx, grid_w(h, f), ag, inj, act, f, grid_store(h), h->all_simple_liquid ? fiso : 0,
+                           g2p_pending ? FuseP{h->frame(f - 1), h->g_out, h->slow_dev, bcount(h, f - 1)} : FuseP{nullptr, nullptr, nullptr, nullptr}};
         h->fiso[f + 1] = h->all_simple_liquid && (fiso & 2) != 0;
         bg.a[i] = GridArgs{h->S, T, h->slab, h->g_in, h->g_out, h->blk_list, bcount(h, f), h->blk_flag, grid_store(h), f, h->frame_slow_dev, statics_p(h), ag};
         bq.a[i] = G2PArgs{h->S, h->frame(f), h->frame(f + 1), T, h->g_out, bcount(h, f), h->slow_dev, ag, f};
     }
     }
+    if (g2p_pending) {
+        prof_begin(h0, KID_G2P_P2G);
+        if (h0->all_simple_liquid) hipLaunchKernelGGL((k_g2p_p2g_b<false>), wgrid_b(hs, B), dim3(WG), 0, h0->stream, bp);
+        else hipLaunchKernelGGL((k_g2p_p2g_b<true>), wgrid_b(hs, B), dim3(WG), 0, h0->stream, bp);
+        prof_end(h0);
+    } else {
     prof_begin(h0, KID_P2G);
     if (h0->all_simple_liquid) hipLaunchKernelGGL((k_p2g_b<true, false>), wgrid_b(hs, B), dim3(WG), 0, h0->stream, bp);
     else hipLaunchKernelGGL((k_p2g_b<true, true>), wgrid_b(hs, B), dim3(WG), 0, h0->stream, bp);
     prof_end(h0);
+    }
     prof_begin(h0, KID_GRID);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_b<false, false, false>), dim3(ggrid(h0).x, B), dim3(256), 0, h0->stream, bg);
     prof_end(h0);
+    if (defer_g2p) return 0;
     prof_begin(h0, KID_G2P);
     hipLaunchKernelGGL(k_g2p_b<false>, wgrid_b(hs, B), dim3(WG), 0, h0->stream, bq);
     prof_end(h0);
     return 0;
 }
 
-int substep_bwd_batch(FeEngine** hs, int B, int f, int f_global, int act) {
+int substep_bwd_batch(FeEngine** hs, int B, int f, int f_global, int act, bool g2p_done = false, bool fuse_next = false) {      // (g2p_done / fuse_next: as in substep_bwd)
     FeEngine* h0 = hs[0];
-    Batch<P2GArgs> bp; Batch<GridArgs> bg; Batch<G2PGradArgs> bq; Batch<GridGradArgs> bgg; Batch<P2GGradArgs> bpg;
+    Batch<P2GArgs> bp; Batch<GridArgs> bg; Batch<G2PGradArgs> bq; Batch<GridGradArgs> bgg; Batch<P2GGradArgs> bpg; Batch<PggArgs> bf;
     const InjectP noinj = {0, 0, 0, 0};
     bool all_stored = true;
     bool reordering = false;                               // some engine's adjoint crosses a sort here
@@ -4453,25 +4468,26 @@ int substep_bwd_batch(FeEngine** hs, int B, int f, int f_global, int act) {
         use_static_table(h, t);
         const TableP T = h->tableP(t);
         const AgentP ag = agent_params(h);
-        if (h->gs_cap > 0 && !h->gs_host_valid) {
-            h->gs_host.resize(h->L + 1);
-            HIPCK(h, hipMemcpyAsync(h->gs_host.data(), h->gs_flag, sizeof(int) * (h->L + 1), hipMemcpyDeviceToHost, h->stream));
-            HIPCK(h, hipStreamSynchronize(h->stream));
-            h->gs_host_valid = true;
-        }
+        if (fetch_gs_flags(h)) return 1;
         all_stored = all_stored && h->gs_cap > 0 && h->gs_host[f] != 0;
-        h->stamp++;                                       // recompute marks, then the adjoint scatter's (as in substep_bwd)
-        bp.a[i] = P2GArgs{h->S, h->frame(f), h->frame(f + 1), T, h->pool_idx, grid_w(h, f), ag, noinj, 0, f, grid_store(h), (h->all_simple_liquid && h->fiso[f]) ? 1 : 0};
+        if (!g2p_done) h->stamp++;                        // recompute marks, then the adjoint scatter's (as in substep_bwd; g2p_done: the scatter's marks carry the stamp of the launch it ran in)
+        bp.a[i] = P2GArgs{h->S, h->frame(f), h->frame(f + 1), T, h->pool_idx, grid_w(h, f), ag, noinj, 0, f, grid_store(h), (h->all_simple_liquid && h->fiso[f]) ? 1 : 0, FuseP{nullptr, nullptr, nullptr, nullptr}};
         bg.a[i] = GridArgs{h->S, T, h->slab, h->g_in, h->g_out, h->blk_list, bcount(h, f), h->blk_flag, grid_store(h), f, h->frame_slow_dev, statics_p(h), ag};
-        h->stamp++;
+        if (!g2p_done) h->stamp++;
         bq.a[i] = G2PGradArgs{h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag};
         bgg.a[i] = GridGradArgs{h->S, T, h->slab, h->g_in, h->gg_out, h->gg_in, h->blk_list, bcount(h, f), h->blk_flag, grid_store(h), f, statics_p(h), ag, h->node_work, h->node_work_count};
         bpg.a[i] = P2GGradArgs{h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->pool_idx, h->gg_in, bcount(h, f), h->slow_dev, ag, inj, act, f, h->grad(f), nullptr,
                                (h->fiso[f] ? 1 : 0) | (h->gcompact[(f + 1) & 1] ? 2 : 0)};      // (the batch writes full adjoints)
+        if (fuse_next) {
+            h->stamp++;                                   // marks of substep f - 1's adjoint scatter (the fused launch's g2p_grad part -> its grid_op.grad)
+            bf.a[i] = PggArgs{h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->pool_idx, h->gg_in, bcount(h, f), h->slow_dev, ag, inj, act, f,
+                              (h->fiso[f] ? 1 : 0) | (h->gcompact[(f + 1) & 1] ? 2 : 0), BwdFuseP{h->frame(f - 1), h->grad(f - 1), h->g_out, h->gg_out, h->slab}, grid_store(h)};
+        }
         h->gtbl[f & 1] = t;
         h->gcompact[f & 1] = false;
     }
     }
+    if (!g2p_done) {
     if (!all_stored) {                                    // (the kernels of an env whose frame is stored return at once)
         prof_begin(h0, KID_P2G_RE);
         if (h0->all_simple_liquid) hipLaunchKernelGGL((k_p2g_b<false, false>), wgrid_b(hs, B), dim3(WG), 0, h0->stream, bp);
@@ -4486,9 +4502,16 @@ int substep_bwd_batch(FeEngine** hs, int B, int f, int f_global, int act) {
     else if (h0->g2p_grad_v != 1) hipLaunchKernelGGL(k_g2p_grad2_b<4>, wgrid_b(hs, B), dim3(WG), 0, h0->stream, bq);
     else hipLaunchKernelGGL(k_g2p_grad_b, wgrid_b(hs, B), dim3(WG), 0, h0->stream, bq);
     prof_end(h0);
+    }                                                     // (!g2p_done)
     prof_begin(h0, KID_GRID_GRAD);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_grad_b<false, false>), dim3(ggrid(h0).x, B), dim3(256), 0, h0->stream, bgg);
     prof_end(h0);
+    if (fuse_next) {
+        prof_begin(h0, KID_PGG_G2PG);
+        hipLaunchKernelGGL(k_pgg_g2pg_b<4>, wgrid_b(hs, B), dim3(WG), 0, h0->stream, bf);
+        prof_end(h0);
+        return 0;
+    }
     prof_begin(h0, KID_P2G_GRAD);
     if (h0->all_simple_liquid) {                          // (batchable: the same p2g_grad_waves in every engine)
         if (h0->p2g_grad_waves >= 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_p2g_grad_b<false, 4>), wgrid_b(hs, B), dim3(WG), 0, h0->stream, bpg);
@@ -4898,7 +4921,13 @@ int fe_step_batch(FeEngine** hs, int n_env, int f0, int f_global0, int n, int ac
     }
     if (f0 < 0 || f0 + n > h->L) FAIL(h, "step frames out of range");
     BatchStreams bs(hs, n_env);
-    for (int i = 0; i < n; i++) if (substep_fwd_batch(hs, n_env, f0 + i, f_global0 + i, act)) { for (int e = 1; e < n_env; e++) if (!hs[e]->err.empty()) h->err = hs[e]->err; return 1; }
+    bool pending = false;
+    for (int i = 0; i < n; i++) {
+        bool defer = i + 1 < n;
+        for (int e = 0; e < n_env && defer; e++) defer = fusable_fwd(hs[e], f0 + i + 1);
+        if (substep_fwd_batch(hs, n_env, f0 + i, f_global0 + i, act, pending, defer)) { for (int e = 1; e < n_env; e++) if (!hs[e]->err.empty()) h->err = hs[e]->err; return 1; }
+        pending = defer;
+    }
     return check_async(h);
 }
 int fe_step_grad_batch(FeEngine** hs, int n_env, int f0, int f_global0, int n, int act) {
@@ -4912,7 +4941,14 @@ int fe_step_grad_batch(FeEngine** hs, int n_env, int f0, int f_global0, int n, i
     }
     if (f0 < 0 || f0 + n > h->L) FAIL(h, "step frames out of range");
     BatchStreams bs(hs, n_env);
-    for (int i = n - 1; i >= 0; i--) if (substep_bwd_batch(hs, n_env, f0 + i, f_global0 + i, act)) { for (int e = 1; e < n_env; e++) if (!hs[e]->err.empty()) h->err = hs[e]->err; return 1; }
+    bool done = false;
+    if (n > 1) for (int e = 0; e < n_env; e++) if (fetch_gs_flags(hs[e])) { h->err = hs[e]->err; return 1; }
+    for (int i = n - 1; i >= 0; i--) {
+        bool fuse = i > 0;
+        for (int e = 0; e < n_env && fuse; e++) fuse = fusable_bwd(hs[e], f0 + i);
+        if (substep_bwd_batch(hs, n_env, f0 + i, f_global0 + i, act, done, fuse)) { for (int e = 1; e < n_env; e++) if (!hs[e]->err.empty()) h->err = hs[e]->err; return 1; }
+        done = fuse;
+    }
     return check_async(h);
 }
 

@@ -511,10 +511,15 @@ def test_batched_envs_match_individual_runs(hiplib):
         solo.append(finish(eng, cot))
         eng.close()
     engs = [S.make_engine(hiplib, sc, max_substeps_local=L) for sc in scenes]
+    engs[0].profile_enable(True)                           # (a batch's launches are the leader's)
     type(engs[0]).step_batch(engs, 0, 0, L, 0)
     for eng, cot in zip(engs, cots):
         eng.reset_grad(); eng.add_grad(L, cot['gx'], cot['gv'], cot['gC'], cot['gF'])
     type(engs[0]).step_grad_batch(engs, 0, 0, L, 0)
+    prof = engs[0].profile_read()
+    engs[0].profile_enable(False)
+    # the batch runs the fused launches too (k_g2p_p2g_b, k_pgg_g2pg_b): every substep but the heads and tails of the sort intervals (K = 10: 0, 10, 20) and of the call
+    assert prof['g2p_p2g'][1] == L - 3 and prof['p2g'][1] == 3 and prof['pgg_g2pg'][1] == L - 3 and prof['p2g_grad'][1] == 3 and prof['grid_op'][1] == L, prof
     for eng, cot, (st0, g0) in zip(engs, cots, solo):
         st, g = finish(eng, cot)
         assert np.array_equal(st['used'], st0['used'])
