@@ -13,13 +13,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 NO_SCRATCH = [
     'k_p2g<true, false>', 'k_g2p_p2g<false>', 'k_grid<false, false, false>', 'k_g2p<false>', 'k_g2p_grad2<4>', 'k_grid_grad<false, false>', 'k_p2g_grad<false, 4>',
     'k_p2g<true, true>', 'k_g2p_p2g<true>', 'k_p2g_grad<true, 1>', 'k_p2g<false, false>', 'k_p2g<false, true>', 'k_grid<true, false, false>',
-    'k_p2g_b<true, false>', 'k_grid_b<false, false, false>', 'k_g2p_b<false>', 'k_g2p_grad2_b<4>', 'k_grid_grad_b<false, false>', 'k_p2g_grad_b<false, 4>',
+    'k_p2g_b<true, false>', 'k_g2p_p2g_b<false>', 'k_grid_b<false, false, false>', 'k_g2p_b<false>', 'k_g2p_grad2_b<4>', 'k_grid_grad_b<false, false>', 'k_p2g_grad_b<false, 4>',
     'k_sort_count', 'k_sort_blk_partial', 'k_sort_blk_final', 'k_sort_apply', 'k_perm_reorder',
 ]
 # k_pgg_g2pg (the fused backward launch) holds the fifteen adjoints it hands from its p2g_grad part to its g2p_grad part on top of what k_p2g_grad needs at its
-# peak: a dozen single-register spills around the gather loop are left (48 bytes; measured: no difference in time to the build that had 112) -- bounded here so
+# peak: two single-register spills are left (16 bytes; the builds that had 112 and 48 measured the same time) -- bounded here so
 # that it does not grow back to the 192 the first build had (a stack object the optimiser could not see through, and the unit record carried across the loop).
-SCRATCH_CAP = {'k_pgg_g2pg<4>': 64}
+SCRATCH_CAP = {'k_pgg_g2pg<4>': 64, 'k_pgg_g2pg_b<4>': 64}
 # occupancy the launch bounds promise: VGPRs per lane at most 512 / waves per SIMD
 MAX_VGPR = {'k_p2g<true, false>': 128, 'k_pgg_g2pg<4>': 128, 'k_g2p_p2g<false>': 128, 'k_g2p_p2g<true>': 168, 'k_g2p<false>': 84, 'k_g2p_grad2<4>': 128, 'k_p2g_grad<false, 4>': 128, 'k_grid<false, false, false>': 128,
             'k_grid_grad<false, false>': 128, 'k_p2g<true, true>': 168, 'k_p2g_grad<true, 1>': 168}
