@@ -424,7 +424,9 @@ def run_single(args):
         fwd_launches = max(1, kern.get('p2g', {}).get('launches', 0) + kern.get('g2p_p2g', {}).get('launches', 0))
         out['config'].update({'nc_mean_timed': tw['nc_mean'], 'nc_min_timed': tw['nc_min'], 'nc_max_timed': tw['nc_max'],
                               'sorts_per_pair': round(sorts / fwd_launches, 3)})
-        out['roofline'] = {'bound': 'hbm', 'kernel': dom, 'achieved': kern[dom]['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+        desc = {'pgg_g2pg': "k_pgg_g2pg: substep f's p2g_grad and substep f-1's g2p_grad in one launch; credited both kernels' SURVEY bytes (192 N + 40 Nc + the 116 N state read)",
+                'g2p_p2g': "k_g2p_p2g: substep f-1's g2p and substep f's p2g in one launch; credited both kernels' SURVEY bytes (216 N + 28 Nc)"}.get(dom)
+        out['roofline'] = {'bound': 'hbm', 'kernel': dom, **({'kernel_is': desc} if desc else {}), 'achieved': kern[dom]['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                            'frac': round(kern[dom]['GBps'] / HBM_PEAK_GBS, 4), 'frac_of_measured_copy': round(kern[dom]['GBps'] / HBM_COPY_GBS, 4),
                            'traffic': traffic, 'alg_bytes_per_launch': kern[dom]['alg_bytes'], 'avg_launch_us': kern[dom]['avg_us'],
                            # (an event bracket serialises the launches around it: the profiled windows run ~13 % slower than the timed ones, so
