@@ -272,12 +272,15 @@ __shared__ float s_stash_l[STASH_LIQUID * WG];
 // the four arrays above are views of (AR = true), so that four workgroups per CU stay resident -- side by side they would be 70 KB.
 //   p2g_grad part, pair units: tiles [0, 8 TILE_N) floats, stash behind them (18 x 256 floats);  quad units: four 4-plane tiles, two of them where the stash is
 //   g2p_grad part, pair units: v_out tiles [0, 6 TILE_N) floats, the fp64 accumulators behind them; quad units: the wave's words in the accumulators' bytes
+// AR: 0 = the kernels' own arrays, 1 = the arena of the SVD-free k_pgg_g2pg, 2 = the SVD build's (tiles + its 36 KB stash: 52 KB, three workgroups per CU as k_p2g_grad<true>)
 __shared__ __attribute__((aligned(16))) float s_bw[18 * TILE_N];
-template <bool AR> __device__ __forceinline__ float* lds_tile4() { if constexpr (AR) return s_bw; else return s_tile; }
-template <bool AR> __device__ __forceinline__ float* lds_stash_l() { if constexpr (AR) return s_bw + 8 * TILE_N; else return s_stash_l; }
-template <bool AR> __device__ __forceinline__ float* lds_tile3() { if constexpr (AR) return s_bw; else return s_tile3; }
-template <bool AR> __device__ __forceinline__ double* lds_acc3() { if constexpr (AR) return (double*)(s_bw + 6 * TILE_N); else return s_acc3; }
-template <bool GENERAL, bool AR = false> struct Stash { static __device__ __forceinline__ float* at() { if constexpr (GENERAL) return s_stash_g; else return lds_stash_l<AR>(); } };
+__shared__ __attribute__((aligned(16))) float s_bwg[26 * TILE_N];
+template <int AR> __device__ __forceinline__ float* lds_tile4() { if constexpr (AR == 1) return s_bw; else if constexpr (AR == 2) return s_bwg; else return s_tile; }
+template <int AR> __device__ __forceinline__ float* lds_stash_l() { if constexpr (AR == 1) return s_bw + 8 * TILE_N; else return s_stash_l; }
+template <int AR> __device__ __forceinline__ float* lds_stash_g() { if constexpr (AR == 2) return s_bwg + 8 * TILE_N; else return s_stash_g; }
+template <int AR> __device__ __forceinline__ float* lds_tile3() { if constexpr (AR == 1) return s_bw; else if constexpr (AR == 2) return s_bwg; else return s_tile3; }
+template <int AR> __device__ __forceinline__ double* lds_acc3() { if constexpr (AR == 1) return (double*)(s_bw + 6 * TILE_N); else if constexpr (AR == 2) return (double*)(s_bwg + 6 * TILE_N); else return s_acc3; }
+template <bool GENERAL, int AR = 0> struct Stash { static __device__ __forceinline__ float* at() { if constexpr (GENERAL) return lds_stash_g<AR>(); else return lds_stash_l<AR>(); } };
 // Effector pose adjoints of the workgroup's particles in contact (agent.collide's adjoint): summed here first -- every
 // contact particle adds to the same 14 numbers per effector, and same-address global atomics serialise.
 #define FE_MAX_EFF 4
@@ -1952,7 +1955,7 @@ __device__ __forceinline__ void quad_load_vout_inner(const float4* __restrict__ 
 // G = 3 / 9: a split wave (lane_split) -- this lane works on the nodes of plane i = gi (column (gi, gj)) of its particle's stencil, the gather
 // pass' partial sums are added up over the particle's lanes, the position adjoint is stored by its first lane (`primary`).
 // AR: the accumulators as k_pgg_g2pg's arena has them; gpre (that kernel): the adjoints of x', v', C' come in registers instead of from Gn.
-template <int MINW, bool QUAD, int G, bool AR = false>
+template <int MINW, bool QUAD, int G, int AR = 0>
 __device__ __forceinline__ float g2p_grad_particle2(const SimP& S, const FrameV& Gn, const FrameV& Gc, int s, int lb, const Stencil& st,
                                                     bool live, int tofs, const float* gt, int gofs, bool primary, const PState* gpre = nullptr) {      // (lb, live: this lane's particle; from pass 2 on the particle it scatters for)
     PState g;                                   // adjoints of x', v', C'
@@ -2095,7 +2098,7 @@ __device__ __forceinline__ float g2p_grad_particle2(const SimP& S, const FrameV&
     }
     return inv;
 }
-template <int MINW, bool QUAD, bool AR = false>
+template <int MINW, bool QUAD, int AR = 0>
 __device__ __forceinline__ float g2p_grad_particle2_split(const SimP& S, const FrameV& Gn, const FrameV& Gc, int s, int lb, const Stencil& st,
                                                           bool live, int tofs, const float* gt, const LaneSplit& ls, const PState* gpre = nullptr) {
     if (ls.G == 1) return g2p_grad_particle2<MINW, QUAD, 1, AR>(S, Gn, Gc, s, lb, st, live, tofs, gt, 0, true, gpre);      // (wave-uniform)
@@ -2504,7 +2507,7 @@ struct GradDst {
 // particle's stencil, the fifteen sums are added up over the particle's lanes, the adjoint is stored by its first lane (`primary`).
 // AR: the LDS views of k_pgg_g2pg's arena.  KEEP (that kernel): the adjoints of x, v and C are handed back in `keep` instead of being stored -- the g2p_grad
 // part of the same launch consumes them from registers, and stores them itself for the few particles whose adjoint somebody else reads (p2g_grad_g2p_grad_body).
-template <bool TILE, bool GENERAL, bool PRE = false, bool NOSTASH = false, int G = 1, bool AR = false, bool KEEP = false>
+template <bool TILE, bool GENERAL, bool PRE = false, bool NOSTASH = false, int G = 1, int AR = 0, bool KEEP = false>
 __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const FrameV& cur, const FrameV& Gn, const FrameV& Gc, int s,
                                                        const float4* __restrict__ info_, const TileO& to,
                                                        const float4* __restrict__ gg_in, int* slow, int tofs, const P2GRaw& pre, const GradDst& D, const float* tl = nullptr,
@@ -2673,7 +2676,7 @@ __device__ __forceinline__ void used_particle_p2g_grad(const SimP& S, const Fram
 // Returns whether the slot holds a used particle (KEEP: its adjoint is then in `keep`, not in memory).
 // (KEEP && TILE: a slot of a work item that is not in use was taken out of use by the host since the sort -- the sort puts unused particles behind the
 //  items, and a particle the Injector is about to use waits there: no Injector.act adjoint on this road, which keeps its code out of k_pgg_g2pg's unit loop)
-template <bool TILE, bool GENERAL, bool PRE = false, bool NOSTASH = false, int G = 1, bool AR = false, bool KEEP = false>
+template <bool TILE, bool GENERAL, bool PRE = false, bool NOSTASH = false, int G = 1, int AR = 0, bool KEEP = false>
 __device__ __forceinline__ bool slot_p2g_grad(const SimP& S, const FrameV& cur, const FrameV& Gn, const FrameV& Gc, int s, const TableP& T,
                                               const int* __restrict__ pool_idx,
                                               const TileO& to, const float4* __restrict__ gg_in, int* slow, const AgentP& agent,
@@ -2831,7 +2834,8 @@ __global__ FE_KALIGN __launch_bounds__(WG, MINW) void k_p2g_grad_b(Batch<P2GGrad
 // frame f - 1 (Injector.act's adjoint reads it in the next launch) or whose stencil there is off the grid.
 // -----------------------------------------------------------------------------------------
 struct BwdFuseP { float* fr_prev; float* Gp_; const float4* g_out; float* gg_out; float4* slab; };
-template <int MINW>
+// GENERAL: the SVD build -- the pairs-only list (its p2g_grad part has no quad units: the stash holds U and V as well), arena 2.
+template <int MINW, bool GENERAL = false>
 __device__ __forceinline__ void p2g_grad_g2p_grad_body(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T, const int* __restrict__ pool_idx,
                                                          const float4* __restrict__ gg_in, int* blk_count, int* slow, AgentP agent, InjectP inj, int act, int f,
                                                          int fiso, BwdFuseP B, GridStore GS) {
@@ -2841,23 +2845,24 @@ __device__ __forceinline__ void p2g_grad_g2p_grad_body(SimP S, float* fr_cur, fl
         if (act) for (int i = agent.n - 1; i >= 0; i--) effector_move_grad(agent.e[i], f);
     }
     VoutSrc V; V.g_out = B.g_out; V.store = GS.data + (size_t)(f - 1) * GS.cap * GS_BLK; V.blk_slot = T.blk_slot;
-    FrameV cur = frame_view(fr_cur, S.Np, 0, (fiso & 1) ? 1 : 0), prev = frame_view(B.fr_prev, S.Np);
-    FrameV Gn = frame_view(Gn_, S.Np, 0, (fiso & 2) ? 2 : 0);
-    FrameV Gc = frame_view(Gc_, S.Np, S.wt & 8, (fiso & 4) ? 2 : 0);      // the adjoint of frame f: its position part so far is read, F (and, where needed, x v C) written
+    constexpr int AR = GENERAL ? 2 : 1;
+    FrameV cur = frame_view(fr_cur, S.Np, 0, (!GENERAL && (fiso & 1)) ? 1 : 0), prev = frame_view(B.fr_prev, S.Np);
+    FrameV Gn = frame_view(Gn_, S.Np, 0, (!GENERAL && (fiso & 2)) ? 2 : 0);
+    FrameV Gc = frame_view(Gc_, S.Np, S.wt & 8, (!GENERAL && (fiso & 4)) ? 2 : 0);      // the adjoint of frame f: its position part so far is read, F (and, where needed, x v C) written
     FrameV Gp = frame_view(B.Gp_, S.Np, S.wt & 4);                           // the adjoint of frame f - 1: the position part g2p_grad leaves
     const GradDst D = {Gc, nullptr, T.pid_of_slot};
-    float* const t4 = lds_tile4<true>();
-    double* const acc3 = lds_acc3<true>();
+    float* const t4 = lds_tile4<AR>();
+    double* const acc3 = lds_acc3<AR>();
     // (every unit's record is asked for at the head of its own round -- the first one together with the list's length, as in the other kernels, the one behind
     //  the last unit in vain: carried into the loop from in front of it, the record's twelve words lived in vector registers across the whole loop, spilled)
-    const int n_slots = T.meta[5];
+    const int n_slots = T.meta[GENERAL ? 9 : 5];
     bool prev_quad = false, any_tail = false;
     for (int wg = blockIdx.x; ; wg += gridDim.x) {
-        const Unit un = unit_load(T, wg);
+        const Unit un = unit_load<GENERAL>(T, wg);
         if (wg >= n_slots) break;
         if (un.a.z == -2) continue;
         if (un.a.z >= 0) {
-            const PairCtx pc = unit_ctx(un);
+            const PairCtx pc = GENERAL ? pair_ctx(un) : unit_ctx(un);
             unit_enter(pc.quad, prev_quad);
             const int4 it = pc.it;
             const TileO to = tile_origin(it.x);
@@ -2883,8 +2888,8 @@ __device__ __forceinline__ void p2g_grad_g2p_grad_body(SimP S, float* fr_cur, fl
             bool kept = false;
             P2GRaw no_pre;
             if (has) {
-                if (pc.quad) kept = slot_p2g_grad<true, false, false, true, 1, true, true>(S, cur, Gn, Gc, s, T, pool_idx, to, gg_in, slow, agent, inj, f, 0, 0, no_pre, D, tl, 0, ls.primary, &g);
-                else kept = slot_p2g_grad<true, false, false, false, 1, true, true>(S, cur, Gn, Gc, s, T, pool_idx, to, gg_in, slow, agent, inj, f, pc.ti * 4 * TILE_N, 0, no_pre, D, nullptr, 0, ls.primary, &g);
+                if (pc.quad) kept = slot_p2g_grad<true, GENERAL, false, true, 1, AR, true>(S, cur, Gn, Gc, s, T, pool_idx, to, gg_in, slow, agent, inj, f, 0, 0, no_pre, D, tl, 0, ls.primary, &g);
+                else kept = slot_p2g_grad<true, GENERAL, false, false, 1, AR, true>(S, cur, Gn, Gc, s, T, pool_idx, to, gg_in, slow, agent, inj, f, pc.ti * 4 * TILE_N, 0, no_pre, D, nullptr, 0, ls.primary, &g);
             }
             if (!kept) {                                         // (behind the call, not in front of it: fifteen zeros would otherwise be kept through the whole p2g_grad part)
 #pragma unroll
@@ -2902,7 +2907,7 @@ __device__ __forceinline__ void p2g_grad_g2p_grad_body(SimP S, float* fr_cur, fl
             const int tofs = pc.quad ? pc.ti * 4 * TILE_N - 6 * TILE_N : pc.ti * 3 * TILE_N;      // (floats / doubles of a pair's tiles, words of a quad's one)
             const int u0 = prev.used[s];
             const float4 a00 = prev.A0[s];
-            float* gt = pc.quad ? (float*)acc3 + tofs : lds_tile3<true>() + tofs;
+            float* gt = pc.quad ? (float*)acc3 + tofs : lds_tile3<AR>() + tofs;
             g2p_grad_load_tile2(to, S, B.g_out, V.store, nbr_entry, pc, gt);
             if (!pc.quad && pc.live) for (int l = pc.t0; l < 3 * TILE_N; l += pc.nth) acc3[tofs + l] = 0.0;
             unit_sync(pc.quad);
@@ -2920,8 +2925,8 @@ __device__ __forceinline__ void p2g_grad_g2p_grad_body(SimP S, float* fr_cur, fl
                 if (has && kept && ls.primary && !inside) store_xvC(Gc, s, g.x, g.v, g.C);      // (not in use in frame f - 1, or off the grid there: read from memory by the next launch)
                 if (pc.quad) wshell = __any(live && stencil_on_shell(lb));
                 if (__any(live)) {
-                    if (pc.quad) inv = g2p_grad_particle2<MINW, true, 1, true>(S, Gc, Gp, s, live ? lb : 0, st, live, tofs, gt, 0, true, &g);
-                    else g2p_grad_particle2<MINW, false, 1, true>(S, Gc, Gp, s, live ? lb : 0, st, live, tofs, gt, 0, true, &g);
+                    if (pc.quad) inv = g2p_grad_particle2<4, true, 1, AR>(S, Gc, Gp, s, live ? lb : 0, st, live, tofs, gt, 0, true, &g);
+                    else g2p_grad_particle2<4, false, 1, AR>(S, Gc, Gp, s, live ? lb : 0, st, live, tofs, gt, 0, true, &g);
                 } else if (pc.quad && pc.live) {                 // nothing scattered: the hand-over must not see v_out as sums
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     for (int l = pc.t0; l < 3 * TILE_N; l += pc.nth) ((int*)acc3)[tofs + l] = 0;
@@ -2942,7 +2947,7 @@ __device__ __forceinline__ void p2g_grad_g2p_grad_body(SimP S, float* fr_cur, fl
     if (!any_tail) return;
     __syncthreads();                                          // (the stash columns lie where the last unit's tiles do)
     for (int wg = blockIdx.x; wg < n_slots; wg += gridDim.x) {
-        const Unit un = unit_load(T, wg);
+        const Unit un = unit_load<GENERAL>(T, wg);
         if (un.a.z != -1) continue;
         {
             int t_ = tid;
@@ -2952,7 +2957,7 @@ __device__ __forceinline__ void p2g_grad_g2p_grad_body(SimP S, float* fr_cur, fl
             P2GRaw none_pre;
             if (s < S.N) {
                 PState g;
-                const bool kept = slot_p2g_grad<false, false, false, false, 1, true, true>(S, cur, Gn, Gc, s, T, pool_idx, none, gg_in, slow, agent, inj, f, 0, 0, none_pre, D, nullptr, 0, true, &g);
+                const bool kept = slot_p2g_grad<false, GENERAL, false, false, 1, AR, true>(S, cur, Gn, Gc, s, T, pool_idx, none, gg_in, slow, agent, inj, f, 0, 0, none_pre, D, nullptr, 0, true, &g);
                 if (kept) {
                     if (!prev.used[s]) store_xvC(Gc, s, g.x, g.v, g.C);
                     else g2p_grad_slot_global<true>(S, prev, Gc, Gp, s, V, B.gg_out, agent, f - 1, GS, &g);
@@ -2965,8 +2970,8 @@ struct PggArgs { SimP S; float* fr_cur; float* Gn_; float* Gc_; TableP T; const 
 #ifndef FE_FB_WAVES_LESS
 #define FE_FB_WAVES_LESS 0      // (scripts/kres.py -DFE_FB_WAVES_LESS=1: the kernel's register peak when the launch bound leaves it room)
 #endif
-template <int MINW>
-__global__ FE_KALIGN __launch_bounds__(WG, MINW - FE_FB_WAVES_LESS) void k_pgg_g2pg(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T, const int* pool_idx, const float4* gg_in, int* blk_count, int* slow, AgentP agent, InjectP inj, int act, int f, int fiso, BwdFuseP B, GridStore GS) { p2g_grad_g2p_grad_body<MINW>(S, fr_cur, Gn_, Gc_, T, pool_idx, gg_in, blk_count, slow, agent, inj, act, f, fiso, B, GS); }
+template <int MINW, bool GENERAL = false>
+__global__ FE_KALIGN __launch_bounds__(WG, MINW - FE_FB_WAVES_LESS) void k_pgg_g2pg(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T, const int* pool_idx, const float4* gg_in, int* blk_count, int* slow, AgentP agent, InjectP inj, int act, int f, int fiso, BwdFuseP B, GridStore GS) { p2g_grad_g2p_grad_body<MINW, GENERAL>(S, fr_cur, Gn_, Gc_, T, pool_idx, gg_in, blk_count, slow, agent, inj, act, f, fiso, B, GS); }
 template <int MINW>
 __global__ FE_KALIGN __launch_bounds__(WG, MINW - FE_FB_WAVES_LESS) void k_pgg_g2pg_b(Batch<PggArgs> Bt) { const PggArgs& A = Bt.a[blockIdx.y]; p2g_grad_g2p_grad_body<MINW>(A.S, A.fr_cur, A.Gn_, A.Gc_, A.T, A.pool_idx, A.gg_in, A.blk_count, A.slow, A.agent, A.inj, A.act, A.f, A.fiso, A.B, A.GS); }
 
@@ -4278,7 +4283,7 @@ int fetch_gs_flags(FeEngine* h) {
 // f - 1 and f (no reorder), no collide / rigid-body adjoint pass, no collector; the SVD-free build with its default kernels; and grid[f - 1] in the
 // per-frame store (a recompute would have to run first).  Option "fuse_bwd".
 inline bool fusable_bwd(FeEngine* h, int f) {
-    return h->fuse_bwd && f > 0 && h->all_simple_liquid && h->g2p_grad_v == 3 && h->p2g_grad_waves >= 4 && !particle_collide(h) && !h->has_rigid && !h->has_collector &&
+    return h->fuse_bwd && f > 0 && h->g2p_grad_v == 3 && (h->p2g_grad_waves >= 4 || !h->all_simple_liquid) && !particle_collide(h) && !h->has_rigid && !h->has_collector &&
            h->tbl_of_frame[f - 1] == h->tbl_of_frame[f] && h->tbl_of_frame[f] >= 0 && h->gs_cap > 0 && h->gs_host_valid && h->gs_host[f - 1] != 0;
 }
 // `g2p_done`: the g2p_grad of this substep ran at the tail of the last launch of substep f + 1 (k_pgg_g2pg).  `fuse_next`: this substep's p2g_grad
@@ -4352,8 +4357,12 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act, int next_f = -1, bool
         h->stamp++;                                       // marks of substep f - 1's adjoint scatter (the launch's g2p_grad part -> its grid_op.grad)
         const BwdFuseP B = {h->frame(f - 1), h->grad(f - 1), h->g_out, h->gg_out, h->slab};
         prof_begin(h, KID_PGG_G2PG);
-        hipLaunchKernelGGL(k_pgg_g2pg<4>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->pool_idx, h->gg_in, bcount(h, f), h->slow_dev,
-                           ag, inj, act, f, giso, B, grid_store(h));
+        if (h->all_simple_liquid)
+            hipLaunchKernelGGL(k_pgg_g2pg<4>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->pool_idx, h->gg_in, bcount(h, f), h->slow_dev,
+                               ag, inj, act, f, giso, B, grid_store(h));
+        else                                              // (the SVD build: three workgroups per CU, as k_p2g_grad<true>)
+            hipLaunchKernelGGL((k_pgg_g2pg<3, true>), wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->pool_idx, h->gg_in, bcount(h, f), h->slow_dev,
+                               ag, inj, act, f, 0, B, grid_store(h));
     } else if (h->all_simple_liquid) {
         if (h->p2g_grad_waves >= 4) LAUNCH_P2G_GRAD(false, 4);
         else if (h->p2g_grad_waves == 3) LAUNCH_P2G_GRAD(false, 3);
@@ -4945,7 +4954,7 @@ int fe_step_grad_batch(FeEngine** hs, int n_env, int f0, int f_global0, int n, i
     if (n > 1) for (int e = 0; e < n_env; e++) if (fetch_gs_flags(hs[e])) { h->err = hs[e]->err; return 1; }
     for (int i = n - 1; i >= 0; i--) {
         bool fuse = i > 0;
-        for (int e = 0; e < n_env && fuse; e++) fuse = fusable_bwd(hs[e], f0 + i);
+        for (int e = 0; e < n_env && fuse; e++) fuse = hs[e]->all_simple_liquid && fusable_bwd(hs[e], f0 + i);      // (the batch has the SVD-free fused kernel only)
         if (substep_bwd_batch(hs, n_env, f0 + i, f_global0 + i, act, done, fuse)) { for (int e = 1; e < n_env; e++) if (!hs[e]->err.empty()) h->err = hs[e]->err; return 1; }
         done = fuse;
     }

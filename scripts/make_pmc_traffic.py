@@ -8,7 +8,7 @@ NAMES = {'void k_p2g<true, false>': 'p2g', 'void k_p2g<false, false>': 'p2g_reco
          'void k_grid<true>': 'grid_op_keep', 'k_g2p': 'g2p', 'k_g2p_grad': 'g2p_grad', 'k_grid_grad': 'grid_op_grad', 'void k_g2p<false>': 'g2p', 'void k_g2p_grad<false>': 'g2p_grad',
          'void k_grid<false, false>': 'grid_op', 'void k_grid<true, false>': 'grid_op_keep', 'void k_grid_grad<false>': 'grid_op_grad',
          'void k_grid<false, false, false>': 'grid_op', 'void k_grid<true, false, false>': 'grid_op_keep', 'void k_grid_grad<false, false>': 'grid_op_grad',
-         'void k_p2g_grad<false, 4>': 'p2g_grad', 'void k_g2p_p2g<false>': 'g2p_p2g', 'void k_pgg_g2pg<4>': 'pgg_g2pg', 'void k_p2g<true, true>': 'p2g_general', 'void k_p2g_grad<true, 4>': 'p2g_grad_general'}
+         'void k_p2g_grad<false, 4>': 'p2g_grad', 'void k_g2p_p2g<false>': 'g2p_p2g', 'void k_pgg_g2pg<4, false>': 'pgg_g2pg', 'void k_p2g<true, true>': 'p2g_general', 'void k_p2g_grad<true, 4>': 'p2g_grad_general'}
 
 
 def parse(path):

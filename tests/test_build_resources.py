@@ -19,9 +19,9 @@ NO_SCRATCH = [
 # k_pgg_g2pg (the fused backward launch) holds the fifteen adjoints it hands from its p2g_grad part to its g2p_grad part on top of what k_p2g_grad needs at its
 # peak: two single-register spills are left (16 bytes; the builds that had 112 and 48 measured the same time) -- bounded here so
 # that it does not grow back to the 192 the first build had (a stack object the optimiser could not see through, and the unit record carried across the loop).
-SCRATCH_CAP = {'k_pgg_g2pg<4>': 64, 'k_pgg_g2pg_b<4>': 64}
+SCRATCH_CAP = {'k_pgg_g2pg<4, false>': 64, 'k_pgg_g2pg<3, true>': 64, 'k_pgg_g2pg_b<4>': 64}
 # occupancy the launch bounds promise: VGPRs per lane at most 512 / waves per SIMD
-MAX_VGPR = {'k_p2g<true, false>': 128, 'k_pgg_g2pg<4>': 128, 'k_g2p_p2g<false>': 128, 'k_g2p_p2g<true>': 168, 'k_g2p<false>': 84, 'k_g2p_grad2<4>': 128, 'k_p2g_grad<false, 4>': 128, 'k_grid<false, false, false>': 128,
+MAX_VGPR = {'k_p2g<true, false>': 128, 'k_pgg_g2pg<4, false>': 128, 'k_pgg_g2pg<3, true>': 168, 'k_g2p_p2g<false>': 128, 'k_g2p_p2g<true>': 168, 'k_g2p<false>': 84, 'k_g2p_grad2<4>': 128, 'k_p2g_grad<false, 4>': 128, 'k_grid<false, false, false>': 128,
             'k_grid_grad<false, false>': 128, 'k_p2g<true, true>': 168, 'k_p2g_grad<true, 1>': 168}
 
 
@@ -56,7 +56,7 @@ def test_substep_kernels_are_aligned_in_the_code_object():
     spec = importlib.util.spec_from_file_location('kres', os.path.join(ROOT, 'scripts', 'kres.py'))
     kres = importlib.util.module_from_spec(spec); spec.loader.exec_module(kres)
     addr = kres.kernel_addresses()
-    hot = ['k_p2g<true, false>', 'k_g2p_p2g<false>', 'k_pgg_g2pg<4>', 'k_grid<false, false, false>', 'k_g2p<false>', 'k_g2p_grad2<4>', 'k_grid_grad<false, false>', 'k_p2g_grad<false, 4>']
+    hot = ['k_p2g<true, false>', 'k_g2p_p2g<false>', 'k_pgg_g2pg<4, false>', 'k_grid<false, false, false>', 'k_g2p<false>', 'k_g2p_grad2<4>', 'k_grid_grad<false, false>', 'k_p2g_grad<false, 4>']
     missing = [k for k in hot if k not in addr]
     assert not missing, missing
     off = {k: hex(addr[k][0]) for k in hot if addr[k][0] % 16384}

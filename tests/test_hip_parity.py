@@ -733,6 +733,15 @@ def test_compact_F_with_an_injector(hiplib, oracle64):
     assert S.cosine(a['action_grad'], o['action_grad']) >= 0.999999 and S.rel_l2(a['action_grad'], o['action_grad']) <= 1e-4
 
 
+def _pct_off(a, b, q):
+    """q-th percentile over the particles of |a - b| relative to the field's RMS: the SVD materials' adjoints amplify rounding noise without bound in the few
+    particles whose singular values nearly coincide (backward_svd divides by their difference), which an L2 norm over all particles is then a measure of; a defect
+    in a kernel shows in the median"""
+    a = np.asarray(a, np.float64).reshape(len(a), -1); b = np.asarray(b, np.float64).reshape(len(b), -1)
+    rms = np.sqrt((b ** 2).sum(1).mean())
+    return float(np.percentile(np.sqrt(((a - b) ** 2).sum(1)), q) / rms)
+
+
 def _droplet_scene(materials, seed=23):
     """(test_lane_split_small_waves_match_the_oracle's scene) droplets, loose clusters and a dense clump in a 64^3 box, drifting ~1.2 cells per sort interval"""
     rng = np.random.RandomState(seed)
@@ -819,8 +828,12 @@ def test_fused_g2p_p2g_launch_matches_separate_launches(hiplib, oracle64, scene,
           {k: round(S.rel_l2(gc[k], gb[k]), 8) for k in ga}, '| vs fp64 oracle x', np.abs(fa[-1]['x'] - fo[-1]['x']).max(), {k: round(S.rel_l2(ga[k], go[k]), 8) for k in ga})
     for k in ('gx', 'gv', 'gC', 'gF'):
         assert np.isfinite(ga[k]).all()
-        # (the SVD materials' adjoints amplify the state noise with a heavy tail -- one pair of runs is no bound on the next: there, no farther than twice the fp32 engine's distance from the fp64 oracle)
-        assert S.rel_l2(ga[k], gb[k]) <= max(4.0 * S.rel_l2(gc[k], gb[k]) + 2e-5, 2.0 * S.rel_l2(gb[k], go[k]) if general else 0.0), (k, S.rel_l2(ga[k], gb[k]), S.rel_l2(gc[k], gb[k]))
+        # (the SVD materials' adjoints amplify the state noise with a heavy tail -- one pair of runs is no bound on the next: there, by the median and the 95th percentile over the particles, _pct_off)
+        if general:
+            assert _pct_off(ga[k], gb[k], 50) <= 4.0 * _pct_off(gc[k], gb[k], 50) + 1e-5 and _pct_off(ga[k], gb[k], 95) <= 4.0 * _pct_off(gc[k], gb[k], 95) + 1e-3, \
+                (k, [_pct_off(ga[k], gb[k], q) for q in (50, 95)], [_pct_off(gc[k], gb[k], q) for q in (50, 95)])
+        else:
+            assert S.rel_l2(ga[k], gb[k]) <= 4.0 * S.rel_l2(gc[k], gb[k]) + 2e-5, (k, S.rel_l2(ga[k], gb[k]), S.rel_l2(gc[k], gb[k]))
         assert S.cosine(ga[k], go[k]) >= 0.999 and S.rel_l2(ga[k], go[k]) <= (2e-2 if general else 3e-3), (k, S.rel_l2(ga[k], go[k]))
     assert (fa[-1]['used'] == fo[-1]['used']).all()
     assert np.abs(fa[-1]['x'] - fo[-1]['x']).max() <= 5e-6 and S.rel_l2(fa[-1]['v'], fo[-1]['v']) <= 1e-3
@@ -855,7 +868,8 @@ def test_fused_g2p_p2g_with_an_injector(hiplib, oracle64):
 
 
 @pytest.mark.parametrize('scene,opts', [('block', {}), ('block', {'compact_F': 0}), ('block', {'grid_store': 0}), ('droplets-water', {'quad_min_units': 0}),
-                                        ('droplets-water', {'quad_min_units': 0, 'lane_split': 0}), ('droplets-water', {'quad_min_units': 1 << 30, 'loose_max': 3})])
+                                        ('droplets-water', {'quad_min_units': 0, 'lane_split': 0}), ('droplets-water', {'quad_min_units': 1 << 30, 'loose_max': 3}),
+                                        ('droplets-mixed', {}), ('droplets-mixed', {'loose_max': 3})])
 def test_fused_p2g_grad_g2p_grad_launch_matches_separate_launches(hiplib, oracle64, scene, opts):
     """Option fuse_bwd (round 5): inside a fe_step_grad call substep f's p2g_grad takes substep f - 1's g2p_grad along (k_pgg_g2pg) -- the adjoints of x, v, C of
     frame f go from one to the other in registers and reach memory only for particles somebody else reads them of.  The same reverse sweep as three launches per
@@ -916,12 +930,20 @@ def test_fused_p2g_grad_g2p_grad_launch_matches_separate_launches(hiplib, oracle
     if scene != 'block':
         assert st['n_slow_path'] > 0, st
     print(f'MEASURED fuse_bwd[{scene}, {opts}]: {n_fused} fused launches; fused vs separate', {k: round(S.rel_l2(ga[k], gb[k]), 9) for k in ga}, 'separate vs separate',
-          {k: round(S.rel_l2(gc[k], gb[k]), 9) for k in ga}, '| at the call boundary', {k: round(S.rel_l2(ma[k], mb[k]), 9) for k in ma}, '| vs fp64 oracle', {k: round(S.rel_l2(ga[k], go[k]), 8) for k in ga})
+          {k: round(S.rel_l2(gc[k], gb[k]), 9) for k in ga}, '| at the call boundary', {k: round(S.rel_l2(ma[k], mb[k]), 9) for k in ma}, '| vs fp64 oracle', {k: round(S.rel_l2(ga[k], go[k]), 8) for k in ga},
+          '| median / 95th percentile over the particles, fused vs separate', {k: [float(f'{_pct_off(ga[k], gb[k], q):.2g}') for q in (50, 95)] for k in ga}, 'separate vs separate',
+          {k: [float(f'{_pct_off(gc[k], gb[k], q):.2g}') for q in (50, 95)] for k in ga})
+    general = scene.endswith('mixed')                          # (the SVD build: k_pgg_g2pg<3, true> on the pairs-only list, its own 52 KB arena)
     for got, ref, noise, orc in ((ma, mb, mc, mo), (ga, gb, gc, go)):
         for k in ('gx', 'gv', 'gC', 'gF'):
             assert np.isfinite(got[k]).all()
-            assert S.rel_l2(got[k], ref[k]) <= 4.0 * S.rel_l2(noise[k], ref[k]) + 2e-5, (k, S.rel_l2(got[k], ref[k]), S.rel_l2(noise[k], ref[k]))
-            assert S.cosine(got[k], orc[k]) >= 0.999 and S.rel_l2(got[k], orc[k]) <= 3e-3, (k, S.rel_l2(got[k], orc[k]))
+            # (the SVD materials: by the median and the 95th percentile over the particles, _pct_off)
+            if general:
+                assert _pct_off(got[k], ref[k], 50) <= 4.0 * _pct_off(noise[k], ref[k], 50) + 1e-5 and _pct_off(got[k], ref[k], 95) <= 4.0 * _pct_off(noise[k], ref[k], 95) + 1e-3, \
+                    (k, [_pct_off(got[k], ref[k], q) for q in (50, 95)], [_pct_off(noise[k], ref[k], q) for q in (50, 95)])
+            else:
+                assert S.rel_l2(got[k], ref[k]) <= 4.0 * S.rel_l2(noise[k], ref[k]) + 2e-5, (k, S.rel_l2(got[k], ref[k]), S.rel_l2(noise[k], ref[k]))
+            assert S.cosine(got[k], orc[k]) >= 0.999 and S.rel_l2(got[k], orc[k]) <= (2e-2 if general else 3e-3), (k, S.rel_l2(got[k], orc[k]))
 
 
 def test_fused_p2g_grad_g2p_grad_with_an_injector(hiplib, oracle64):
