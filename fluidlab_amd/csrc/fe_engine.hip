@@ -3910,7 +3910,7 @@ struct FeEngine {
     std::vector<char> fiso;                                 // [L+1] frame f's F is stored compactly (FrameV::iso = 1): written by the SVD-free k_p2g
     bool gcompact[2] = {false, false};                      // ... and the adjoint of F in a ring slot (iso = 2): written by k_p2g_grad inside a ranged call
     bool compact_F = true;                                  // option "compact_F"
-    bool fuse_bwd = true;                                   // option "fuse_bwd": inside a fe_step_grad call a substep's p2g_grad takes the next substep's g2p_grad along (k_pgg_g2pg)
+    int fuse_bwd = 1;                                       // option "fuse_bwd": inside a fe_step_grad call a substep's p2g_grad takes the next substep's g2p_grad along (k_pgg_g2pg)
     bool fuse_g2p = true;                                   // option "fuse_g2p": inside a fe_step call the g2p of a substep runs at the head of the next substep's p2g launch (k_g2p_p2g)
     int tbl_bank = 0, last_sorted_f = -1;                   // two banks of table ids, one per sweep over the window (sort_frame)
     int p2g_grad_waves = 4;                                 // occupancy target of the SVD-free p2g_grad build (tuning)
@@ -4283,6 +4283,9 @@ int fetch_gs_flags(FeEngine* h) {
 // f - 1 and f (no reorder), no collide / rigid-body adjoint pass, no collector; the SVD-free build with its default kernels; and grid[f - 1] in the
 // per-frame store (a recompute would have to run first).  Option "fuse_bwd".
 inline bool fusable_bwd(FeEngine* h, int f) {
+    // (the SVD build's fused kernel keeps three workgroups per CU where k_g2p_grad2 keeps four: it pays while a launch is a round or two of workgroups -- +0.6 % at 200k particles --
+    //  and costs where the kernels are bound by what they issue: 155.8 us against 61.3 + 77.6 at 1M.  fuse_bwd = 1 fuses it up to two rounds' worth of particles, 2 always)
+    if (!h->all_simple_liquid && h->fuse_bwd < 2 && h->Np / 256 > 2 * 3 * (size_t)(h->quad_fit / 4)) return false;      // (quad_fit = 4 x the device's CUs)
     return h->fuse_bwd && f > 0 && h->g2p_grad_v == 3 && (h->p2g_grad_waves >= 4 || !h->all_simple_liquid) && !particle_collide(h) && !h->has_rigid && !h->has_collector &&
            h->tbl_of_frame[f - 1] == h->tbl_of_frame[f] && h->tbl_of_frame[f] >= 0 && h->gs_cap > 0 && h->gs_host_valid && h->gs_host[f - 1] != 0;
 }
@@ -4635,7 +4638,7 @@ FeEngine* fe_create(const FeConfig* cfg) {
     if (const char* e = std::getenv("FE_SORT_INTERVAL")) h->sort_interval = std::atoi(e);     // tuning experiments (the option of the same name wins)
     if (const char* e = std::getenv("FE_QUAD_MIN_UNITS")) h->quad_min_units = std::atoi(e);   // (task-level A/B of the quad units: scripts/run_envs.py)
     if (const char* e = std::getenv("FE_G2P_GRAD_V")) h->g2p_grad_v = std::atoi(e);           // (the parity suite is run once per build of the G2P adjoint)
-    if (const char* e = std::getenv("FE_FUSE_BWD")) h->fuse_bwd = std::atoi(e) != 0;
+    if (const char* e = std::getenv("FE_FUSE_BWD")) h->fuse_bwd = std::atoi(e);
     if (const char* e = std::getenv("FE_FUSE_G2P")) h->fuse_g2p = std::atoi(e) != 0;           // (the parity suite with and without the fused forward launch)
     const char* env_lsplit = std::getenv("FE_LANE_SPLIT");                                    // (the parity suite with and without lane_split)
     h->cfg = *cfg; h->N = cfg->n_particles; h->L = cfg->max_substeps_local; h->n = cfg->n_grid; h->nb = cfg->n_grid / 4;
@@ -4790,7 +4793,7 @@ int fe_set_option(FeEngine* h, const char* name, double value) {
     if (!std::strcmp(name, "fold_reorder")) { h->fold_reorder = value != 0; return 0; }
     if (!std::strcmp(name, "compact_F")) { h->compact_F = value != 0; return 0; }
     if (!std::strcmp(name, "fuse_g2p")) { h->fuse_g2p = value != 0; return 0; }
-    if (!std::strcmp(name, "fuse_bwd")) { h->fuse_bwd = value != 0; return 0; }
+    if (!std::strcmp(name, "fuse_bwd")) { h->fuse_bwd = (int)value; return 0; }
     if (!std::strcmp(name, "quad_min_units")) { h->quad_min_units = (int)value; return 0; }
     if (!std::strcmp(name, "pgg_quad_min_units")) { h->pgg_quad_min_units = (int)value; return 0; }
     if (!std::strcmp(name, "pack_units")) { if (value < 0 || value > 2) FAIL(h, "pack_units must be 0, 1 or 2"); h->pack_units = (int)value; return 0; }
@@ -4811,7 +4814,7 @@ int fe_get_option(FeEngine* h, const char* name, double* value) {
         {"sort_interval", (double)h->sort_interval}, {"item_max", (double)h->item_max}, {"grid_store", h->gs_cap > 0 ? 1.0 : 0.0},
         {"p2g_grad_waves", (double)h->p2g_grad_waves}, {"g2p_grad_v", (double)h->g2p_grad_v}, {"loose_max", (double)h->loose_max},
         {"inject_till", (double)h->inject_till}, {"collide_min_y", (double)h->collide_min_y}, {"collide_type", (double)h->collide_type},
-        {"prof_fine", h->prof_fine ? 1.0 : 0.0}, {"xcd_map", (double)h->S.xcd}, {"write_through", (double)h->S.wt}, {"wave_sort", (double)h->S.wsort}, {"lane_split", (double)h->S.lsplit}, {"fold_reorder", h->fold_reorder ? 1.0 : 0.0}, {"compact_F", h->compact_F ? 1.0 : 0.0}, {"fuse_g2p", h->fuse_g2p ? 1.0 : 0.0}, {"fuse_bwd", h->fuse_bwd ? 1.0 : 0.0},
+        {"prof_fine", h->prof_fine ? 1.0 : 0.0}, {"xcd_map", (double)h->S.xcd}, {"write_through", (double)h->S.wt}, {"wave_sort", (double)h->S.wsort}, {"lane_split", (double)h->S.lsplit}, {"fold_reorder", h->fold_reorder ? 1.0 : 0.0}, {"compact_F", h->compact_F ? 1.0 : 0.0}, {"fuse_g2p", h->fuse_g2p ? 1.0 : 0.0}, {"fuse_bwd", (double)h->fuse_bwd},
         {"quad_min_units", (double)h->quad_min_units}, {"pgg_quad_min_units", (double)h->pgg_quad_min_units}, {"quad_max", (double)h->quad}, {"quad_fit", (double)h->quad_fit}, {"pack_units", (double)h->pack_units},
         {"wgrid_cap", (double)h->wgrid_cap}, {"wgrid_cap_g2p", (double)h->wgrid_cap_g2p}, {"wgrid_cap_pgg", (double)h->wgrid_cap_pgg}, {"ggrid_cap", (double)h->ggrid_cap}, {"threads", 0.0}};
     for (const auto& t : tab) if (!std::strcmp(name, t.n)) { *value = t.v; return 0; }
