@@ -180,6 +180,8 @@ struct SimP {
     int uni; float uinfo[4];                 // every particle has the same material record (mu, lam, mass, class | material): it travels here instead of 16 bytes per particle and kernel
     float g[3];
     BoundaryP bnd;
+    unsigned fg_base;                        // option "fuse_grid": what the `started` counters of the fused grid pass read before this launch (FgDev)
+    int fg_nowait;                           // ... its waves never wait (tests: every entry takes the skipped road)
 };
 
 struct EffP {
@@ -217,11 +219,12 @@ __device__ __forceinline__ PInfo load_info(const SimP& S, const float4* info, in
 // the orders keep their own tables, so forward and backward substeps of any frame agree without re-flagging anything (round 2
 // kept the value 2 in blk_flag on exactly one order's list and switched it with two launches whenever backward crossed a sort).
 // blk_flag only says whether a block OUTSIDE that list is on the substep's dynamic list already (1).
-__device__ __forceinline__ void mark_dynamic(int b, int* blk_flag, int* blk_list, int* blk_count) {
+__device__ __forceinline__ bool mark_dynamic(int b, int* blk_flag, int* blk_list, int* blk_count) {      // true: this call put the block on the list
     const int fl = blk_flag[b];
     if (fl != 1) {
-        if (atomicCAS(&blk_flag[b], fl, 1) == fl) { int i = atomicAdd(blk_count, 1); blk_list[i] = b; }
+        if (atomicCAS(&blk_flag[b], fl, 1) == fl) { int i = atomicAdd(blk_count, 1); __hip_atomic_store(blk_list + i, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return true; }
     }
+    return false;
 }
 
 // -----------------------------------------------------------------------------------------
@@ -419,6 +422,7 @@ struct TableP {
     const int2* nbr;           // [n_active * 27] (first item, item count) of the 27 neighbours of each active-list entry's block
     const int*  active;        // blocks within one block of an occupied block: every block a tile can reach
     const int*  blk_slot;      // [nblk] index of a block in `active`, or -1
+    unsigned long long* arrive;// [nblk] arrival word of every active-list entry (fused grid pass, FG_* below), then int expected[nblk]
 };
 
 struct TileO { int ox, oy, oz; };
@@ -622,16 +626,117 @@ __device__ __forceinline__ int neighbour_entry(const int* __restrict__ blk_slot,
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int dpp_or(int x) { return x | __builtin_amdgcn_update_dpp(0, x, CTRL, ROW_MASK, 0xf, true); }
 // all lanes of the wave: the union of the lanes' region sets, then one lane per region marks its entry
-__device__ __forceinline__ void touch_regions(int mask, int entry, const GridStore& GS) {
+// (FG kernels: nothing is stored -- the union travels with the tile's arrival, fg_unit_end; returns it)
+template <bool FG = false>
+__device__ __forceinline__ int touch_regions(int mask, int entry, const GridStore& GS) {
     mask = dpp_or<0x111, 0xf>(mask); mask = dpp_or<0x112, 0xf>(mask); mask = dpp_or<0x114, 0xf>(mask); mask = dpp_or<0x118, 0xf>(mask);   // row_shr 1 2 4 8
     mask = dpp_or<0x142, 0xa>(mask); mask = dpp_or<0x143, 0xc>(mask);                                   // row_bcast 15, 31: lane 63 holds the union
     mask = __builtin_amdgcn_readlane(mask, 63);
-    if (entry >= 0 && ((mask >> (threadIdx.x & 63)) & 1)) GS.touched[entry] = GS.stamp;
+    if (!FG && entry >= 0 && ((mask >> (threadIdx.x & 63)) & 1)) GS.touched[entry] = GS.stamp;
+    return mask;
 }
 // a slow-path particle deposited into block b with global atomics
 __device__ __forceinline__ void mark_dirty(const GridStore& GS, const int* __restrict__ blk_slot, int b) {
     const int e = blk_slot[b];
     if (e >= 0) GS.dirty[e] = GS.stamp;
+}
+
+// -----------------------------------------------------------------------------------------
+// The grid pass inside the scatter launches (option "fuse_grid", round 6; kernels with FG = true).
+// k_grid / k_grid_grad are a launch boundary, a ramp, a chain of two or three dependent round trips per block and a drain: 20.8 us of a
+// substep pair for 7 % of its bytes (a third of the pair where the water has come apart), and nothing in them needs the WHOLE scatter to
+// be over -- a block's grid_op needs the slabs of the (at most 27) blocks whose tiles reach it.  So the scatter launch does the grid pass
+// itself, as a dataflow step:
+//   * every active-list entry has an ARRIVAL WORD (TableP::arrive): a count of the tiles handed over around it so far, and how many of them
+//     deposited into it (`touched`) or left something in its slow-path accumulator (`dirty`) -- what GridStore::touched / dirty say in
+//     the two-launch form.  A tile's hand-over ends with ONE non-returning 64-bit atomic per neighbour entry (27 lanes of one wave), issued
+//     after the slab's write-through (sc1) stores and the shell's atomics have completed (s_waitcnt vmcnt(0); no fence: MI355X_MICROARCH.md,
+//     "sc1 payload -> vmcnt(0) -> flag").  How many arrivals an entry waits for is known at sort time (`expected`: the slabs of its
+//     27 neighbours, build_units_dev).
+//   * every entry has an OWNER: wave static_entry(w) + k * (waves of the launch), the mapping of k_grid.  A wave that is through with its
+//     units polls the words of its entries (sc1 loads) and runs grid_op (fg_fwd_block) / its adjoint (fg_bwd_block) on each as it
+//     completes -- the same gather in the same fixed order as k_grid (results are bit-identical), outputs written through.  All waves of
+//     all workgroups own entries, so the pass is as parallel as the separate launch was, without its boundary, ramp and first round trip.
+//   * WAITING is only allowed when it cannot deadlock: a wave waits for an entry only if every workgroup of the launch has started (the
+//     `started` counters against SimP::fg_base + gridDim.x): then every unit loop is running or done, and unit loops never wait.  Otherwise
+//     (more workgroups than the chip holds at once: a shared GPU) the wave marks its incomplete entries as SKIPPED and goes; they fall to
+//     the launch's FINAL wave.
+//   * the FINAL wave is the one whose workgroup is the last to finish its unit loops (a sharded returning counter, asked for before the
+//     owner's work and read behind it).  It finds out from the same word whether anything RARE happened and, if so, does what needs every
+//     unit loop over: skipped entries; blocks outside the order's active list (the dynamic list of the slow path); and LATE deposits -- a
+//     slow-path particle whose target is an active entry OUTSIDE the 27 neighbours of its own unit's block (it moved more than a block
+//     between two sorts, or sits in a tail unit) is ordered by nobody's arrival, so its deposit goes to accumulator planes of its own
+//     (FgDev::late) and the final wave adds it to what the owner stored (forward: the grid store's (p, m) totals; backward: grid_op's
+//     adjoint is linear in d v_out).  None of this is on the path of a launch without such particles.
+// Because a launch now reads the grid of the substep before (its gather part) while its owners write the one of its own substep, g_out and
+// gg_in are double-buffered by the parity of f.  Host side: fuse_grid_ok() says which launches take this form.
+// -----------------------------------------------------------------------------------------
+#define FG_SH 32                 // shards of the done / finished counters (a returning atomic on ONE word goes at ~88 per us: 1,024 workgroups would queue for 12 us)
+#define FG_LINE 32               // a counter per 128-byte line
+enum { FGC_STARTED = 0 /* 8 */, FGC_DONE = 8 /* FG_SH */, FGC_FIN = FGC_DONE + FG_SH /* FG_SH */, FGC_TOP = FGC_FIN + FG_SH, FGC_LATE, FGC_SKIP, FGC_ERR, FGC_N };
+struct FgDev {                   // device-resident (one pointer in the kernel arguments)
+    float* late;                 // [4 * ncell] accumulator planes of the late deposits (the adjoint pass uses three)
+    int* late_flag; int* late_list;   // [nblk] entries with late deposits (flag: on the list already)
+    unsigned char* skipm;        // [nblk] entries their owner could not wait for (the launch's stamp)
+    int* ctr;                    // [FGC_N * FG_LINE]
+};
+struct FgArgs {                  // what the grid pass of one launch works with (uniform)
+    const FgDev* F; const float4* slab; float* acc; float4* out; int* blk_list; int* blk_count; int* blk_flag; int f;
+};
+#define FG_CNT(a) ((int)((a) & 0x1fffffull))
+#define FG_TCH(a) ((int)(((a) >> 21) & 0x1fffffull))
+#define FG_DRT(a) ((int)((a) >> 42))
+__shared__ int s_fg[10];         // pair units: (touched, dirty) region sets of the workgroup's tiles [0..7]; waves through with their unit loops [8], with their entries [9]
+template <bool BWD> __device__ __forceinline__ void fg_owner_phase(const SimP& S, const TableP& T, const GridStore& GS, const FgArgs& A);
+__device__ __forceinline__ void fg_rare(const FgDev* F) { (void)__hip_atomic_fetch_or(F->ctr + FGC_TOP * FG_LINE, 1 << 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }      // (the word's low half counts the shards that are done: fg_owner_phase)
+// entry e received a deposit that no arrival orders
+__device__ __forceinline__ void fg_mark_late(const FgDev* F, int e) {
+    int* fl = F->late_flag + e;
+    const int v = __hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v != 1 && atomicCAS(fl, v, 1) == v) {
+        const int i = atomicAdd(F->ctr + FGC_LATE * FG_LINE, 1);
+        __hip_atomic_store(F->late_list + i, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fg_rare(F);
+    }
+}
+// the launch begins: this workgroup has started (thread 0), the workgroup's words are cleared
+__device__ __forceinline__ void fg_begin(const FgDev* F) {
+    if (threadIdx.x == 0) (void)__hip_atomic_fetch_add(F->ctr + (FGC_STARTED + (blockIdx.x & 7)) * FG_LINE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x < 10) s_fg[threadIdx.x] = 0;
+    __syncthreads();
+}
+__device__ __forceinline__ int wave_or(int mask) {             // all 64 lanes; wave-uniform result
+    mask = dpp_or<0x111, 0xf>(mask); mask = dpp_or<0x112, 0xf>(mask); mask = dpp_or<0x114, 0xf>(mask); mask = dpp_or<0x118, 0xf>(mask);
+    mask = dpp_or<0x142, 0xa>(mask); mask = dpp_or<0x143, 0xc>(mask);
+    return __builtin_amdgcn_readlane(mask, 63);
+}
+// A tile has been handed over (its slab stored write-through, its shell's atomics issued, all of it completed: the caller waited): one lane per
+// neighbour entry of the tile's block counts it in, with what the tile did there.  All 64 lanes of the tile's first wave.
+__device__ __forceinline__ void fg_arrive(const TableP& T, int nbr_entry, int tmask, int dmask) {
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));
+    if (lane < 27 && nbr_entry >= 0) {
+        const unsigned long long add = 1ull | ((unsigned long long)((tmask >> lane) & 1) << 21) | ((unsigned long long)((dmask >> lane) & 1) << 42);
+        (void)__hip_atomic_fetch_add(T.arrive + nbr_entry, add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// the end of a tile unit of an FG kernel: region sets of the tile's waves merged (pair units: through LDS), everything the tile's waves stored waited for,
+// then the arrival by the tile's first wave.  fg_t: the wave's touched set (uniform), fg_d: this lane's dirtied regions.  Contains the unit's closing unit_sync.
+__device__ __forceinline__ void fg_unit_end(const TableP& T, const PairCtx& pc, int nbr_entry, int fg_t, int fg_d) {
+    int tm = fg_t, dm = wave_or(fg_d);
+    if (!pc.quad && (threadIdx.x & 63) == 0) {
+        if (tm) atomicOr(&s_fg[2 * pc.ti], tm);
+        if (dm) atomicOr(&s_fg[2 * pc.ti + 1], dm);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's slab stores (sc1: through to memory) and atomics have completed
+    unit_sync(pc.quad);
+    if (pc.live && pc.t0 < 64) {                                // (wave-uniform: the first wave of the tile)
+        if (!pc.quad) {
+            tm = s_fg[2 * pc.ti]; dm = s_fg[2 * pc.ti + 1];
+            if ((threadIdx.x & 63) == 0) { s_fg[2 * pc.ti] = 0; s_fg[2 * pc.ti + 1] = 0; }      // (the next unit's waves add to them behind its first barrier, which this wave takes part in)
+        }
+        fg_arrive(T, nbr_entry, tm, dm);
+    }
 }
 
 // one node of a slab (the slab index is wave-uniform: the descriptor of the write-through form is built over the slab itself).
@@ -652,12 +757,14 @@ __device__ __forceinline__ int tile_region(int t) { return (t + 3) >> 2; }      
 // Tile node l of a finished scatter tile: the inner 6^3 go to the item's slab; a shell node that received something is added to
 // the slow-path accumulator `acc` (NPL planes of ncell floats) and its block -- active-list entry from the item's 27 neighbour
 // entries, lane r of every wave holds neighbour r -- is marked dirty for the grid kernel.  Called by whole waves (shuffle).
-template <int NPL, bool SHELL_ONLY = false>
+// FG (the grid pass rides on this launch): a shell deposit's region is noted in fg_d, for the tile's arrival, instead of a mark in GS.dirty
+template <int NPL, bool SHELL_ONLY = false, bool FG = false>
 __device__ __forceinline__ void tile_handover(const SimP& S, float4* slab, int item, float* acc, const GridStore& GS, const TileO& to,
-                                              int nbr_entry, int l, float4 v, int wt) {
+                                              int nbr_entry, int l, float4 v, int wt, int& fg_d) {
     asm volatile("" : "+v"(l));             // (opaque, as in neighbour_entry: tz and its region are loop invariants otherwise)
     const int tx = l >> 6, ty = (l >> 3) & 7, tz = l & 7;
-    const int e = __shfl(nbr_entry, tile_region(tx) * 9 + tile_region(ty) * 3 + tile_region(tz), 64);
+    const int reg = tile_region(tx) * 9 + tile_region(ty) * 3 + tile_region(tz);
+    const int e = __shfl(nbr_entry, reg, 64);
     // (one condition, not three short-circuited ones: those became nested branches across which the pieces of the slab index were kept
     //  alive as 64-bit values -- and, in k_g2p_grad2, spilled)
     const bool inner = ((unsigned)(tx - 1) < (unsigned)SLAB_T) & ((unsigned)(ty - 1) < (unsigned)SLAB_T) & ((unsigned)(tz - 1) < (unsigned)SLAB_T);
@@ -667,8 +774,14 @@ __device__ __forceinline__ void tile_handover(const SimP& S, float4* slab, int i
         float* dst = acc + cell_addr(to.ox + tx, to.oy + ty, to.oz + tz, S.nb);
         unsafeAtomicAdd(dst, v.x); unsafeAtomicAdd(dst + S.ncell, v.y); unsafeAtomicAdd(dst + 2 * S.ncell, v.z);
         if (NPL > 3) unsafeAtomicAdd(dst + 3 * S.ncell, v.w);
-        GS.dirty[e] = GS.stamp;
+        if (FG) fg_d |= 1 << reg; else GS.dirty[e] = GS.stamp;
     }
+}
+template <int NPL, bool SHELL_ONLY = false>
+__device__ __forceinline__ void tile_handover(const SimP& S, float4* slab, int item, float* acc, const GridStore& GS, const TileO& to,
+                                              int nbr_entry, int l, float4 v, int wt) {
+    int none = 0;
+    tile_handover<NPL, SHELL_ONLY, false>(S, slab, item, acc, GS, to, nbr_entry, l, v, wt, none);
 }
 
 #ifndef FE_LEAN_QUADS
@@ -687,15 +800,15 @@ __device__ __forceinline__ bool stencil_on_shell(int lb) {
 // base has left its block since the sort reaches it.  Now the inner 6^3 nodes go straight to the slab (216 nodes: four rounds, no
 // decisions), and the walk over the shell only happens in a wave one of whose particles sits on it (`wshell`, wave-uniform).
 // acc: the wave's tile (words); inv_p / inv_m: back to floats (fix_scale), NPL planes.
-template <int NPL>
+template <int NPL, bool FG = false>
 __device__ __forceinline__ void quad_handover(const SimP& S, const int* acc, float inv_p, float inv_m, float4* slab, int item, float* accg,
-                                              const GridStore& GS, const TileO& to, int nbr_entry, bool wshell, int wt) {
+                                              const GridStore& GS, const TileO& to, int nbr_entry, bool wshell, int wt, int& fg_d) {
     int lane = threadIdx.x & 63;
     asm volatile("" : "+v"(lane));          // (opaque: the node indices below are not to be kept across the unit loop)
 #if !FE_LEAN_QUADS
     for (int k = 0; k < TILE_N / 64; k++) {                        // (A/B builds: round 4's walk over all 512 nodes)
         const int l = lane + 64 * k;
-        tile_handover<NPL>(S, slab, item, accg, GS, to, nbr_entry, l, make_float4((float)acc[l] * inv_p, (float)acc[TILE_N + l] * inv_p, (float)acc[2 * TILE_N + l] * inv_p, NPL > 3 ? (float)acc[3 * TILE_N + l] * inv_m : 0.f), wt);
+        tile_handover<NPL, false, FG>(S, slab, item, accg, GS, to, nbr_entry, l, make_float4((float)acc[l] * inv_p, (float)acc[TILE_N + l] * inv_p, (float)acc[2 * TILE_N + l] * inv_p, NPL > 3 ? (float)acc[3 * TILE_N + l] * inv_m : 0.f), wt, fg_d);
     }
     return;
 #endif
@@ -717,13 +830,20 @@ __device__ __forceinline__ void quad_handover(const SimP& S, const int* acc, flo
             const bool inner = ((unsigned)(tx - 1) < (unsigned)SLAB_T) & ((unsigned)(ty - 1) < (unsigned)SLAB_T) & ((unsigned)(tz - 1) < (unsigned)SLAB_T);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (!inner) v = make_float4((float)acc[l] * inv_p, (float)acc[TILE_N + l] * inv_p, (float)acc[2 * TILE_N + l] * inv_p, NPL > 3 ? (float)acc[3 * TILE_N + l] * inv_m : 0.f);
-            tile_handover<NPL, true>(S, slab, item, accg, GS, to, nbr_entry, l, v, wt);
+            tile_handover<NPL, true, FG>(S, slab, item, accg, GS, to, nbr_entry, l, v, wt, fg_d);
         }
     }
+}
+template <int NPL>
+__device__ __forceinline__ void quad_handover(const SimP& S, const int* acc, float inv_p, float inv_m, float4* slab, int item, float* accg,
+                                              const GridStore& GS, const TileO& to, int nbr_entry, bool wshell, int wt) {
+    int none = 0;
+    quad_handover<NPL, false>(S, acc, inv_p, inv_m, slab, item, accg, GS, to, nbr_entry, wshell, wt, none);
 }
 
 struct GridW {            // everything a scattering particle needs of the global grid
     float* g_in; float4* slab; int ncell; int* frame_slow; int* blk_flag; int* blk_list; int* blk_count; int* err; int* slow;
+    const FgDev* fg; float4* g_out;      // FG kernels: the grid pass' device block, and where grid_op leaves this substep's v_out
 };
 
 // An F that is carried over unchanged (an unused or collected particle) from a frame with full planes into a compact one: of an inviscid liquid's
@@ -817,13 +937,38 @@ __device__ __forceinline__ void p2g_prepare(const SimP& S, const FrameV& cur, co
 }
 
 // global path: 108 scattered global atomics + active-block marking
-__device__ __forceinline__ void p2g_scatter_global(const SimP& S, const P2GPrep& q, const GridW& G, const GridStore& GS, const int* __restrict__ blk_slot) {
+// FG (the grid pass rides on this launch): `pk` = the block of the particle's own unit (-1: a tail unit).  A deposit into a block among that block's 27
+// neighbours is ordered by the unit's arrival (its region goes into fg_d); one into an active entry further away is LATE -- into the planes of its own,
+// and the entry on the late list; blocks outside the active list go on the dynamic list as ever (both: the launch's final wave, fg_final).
+template <bool FG = false>
+__device__ __forceinline__ void p2g_scatter_global(const SimP& S, const P2GPrep& q, const GridW& G, const GridStore& GS, const int* __restrict__ blk_slot, int pk, int& fg_d) {
     const Stencil& st = q.st;
+    // the (up to 8) 4^3 blocks this stencil touches: lower and upper block per axis (equal when the three nodes sit in one
+    // block).  All flags and list entries are asked for at once (a rolled triple loop made this up to eight rounds of two
+    // dependent round trips per particle -- nothing for a few drifted particles, too much for the loose ones).
+    const int bl[3] = {st.base[0] >> 2, st.base[1] >> 2, st.base[2] >> 2};
+    const int bh[3] = {(st.base[0] + 2) >> 2, (st.base[1] + 2) >> 2, (st.base[2] + 2) >> 2};
+    // FG: the corners whose block no arrival of this unit reaches (bit c: further than a block from the unit's own) -- their deposits go to the planes of the late
+    // deposits, whether the block is an entry of the active list (-> the late list) or not (-> the dynamic list: a block off the list is never within a block of
+    // an occupied one, so everything it ever gets arrives this way).  Geometry only: nothing is asked for ahead of the deposits.
+    int late = 0;
+    float* acc_late = G.g_in;
+    auto region = [&](int c, bool& near) {
+        const int d0 = ((c & 1) ? bh[0] : bl[0]) - BLK_I(pk), d1 = ((c & 2) ? bh[1] : bl[1]) - BLK_J(pk), d2 = ((c & 4) ? bh[2] : bl[2]) - BLK_K(pk);
+        near = pk >= 0 && (unsigned)(d0 + 1) <= 2u && (unsigned)(d1 + 1) <= 2u && (unsigned)(d2 + 1) <= 2u;
+        return (d0 + 1) * 9 + (d1 + 1) * 3 + d2 + 1;
+    };
+    if (FG) {
+        acc_late = G.fg->late;
+#pragma unroll
+        for (int c = 0; c < 8; c++) { bool near; (void)region(c, near); if (!near) late |= 1 << c; }
+    }
 #pragma unroll 1
     for (int ij = 0; ij < 9; ij++) {
         const int i = ij / 3, j = ij - 3 * i;
         const float wij = STW(st, i, 0) * STW(st, j, 1);
         const float ox = (float)i * S.dx, oy = (float)j * S.dx;
+        const int cij = ((((st.base[0] + i) >> 2) != bl[0]) ? 1 : 0) | ((((st.base[1] + j) >> 2) != bl[1]) ? 2 : 0);
         float mij[3];
 #pragma unroll
         for (int a = 0; a < 3; a++) mij[a] = q.mv[a] + q.affine.a[a][0] * ox + q.affine.a[a][1] * oy;
@@ -831,17 +976,14 @@ __device__ __forceinline__ void p2g_scatter_global(const SimP& S, const P2GPrep&
         for (int kk = 0; kk < 3; kk++) {
             const float weight = wij * st.w[kk][2];
             const float oz = (float)kk * S.dx;
-            float* dst = G.g_in + cell_addr(st.base[0] + i, st.base[1] + j, st.base[2] + kk, S.nb);
+            float* acc = G.g_in;
+            if (FG) { const int c = cij | ((((st.base[2] + kk) >> 2) != bl[2]) ? 4 : 0); acc = ((late >> c) & 1) ? acc_late : G.g_in; }
+            float* dst = acc + cell_addr(st.base[0] + i, st.base[1] + j, st.base[2] + kk, S.nb);
 #pragma unroll
             for (int a = 0; a < 3; a++) unsafeAtomicAdd(dst + a * S.ncell, weight * (mij[a] + q.affine.a[a][2] * oz));
             unsafeAtomicAdd(dst + 3 * S.ncell, weight * q.m);
         }
     }
-    // mark the (up to 8) 4^3 blocks this stencil touches: lower and upper block per axis (equal when the three nodes sit in one
-    // block).  All flags and list entries are asked for at once (a rolled triple loop made this up to eight rounds of two
-    // dependent round trips per particle -- nothing for a few drifted particles, too much for the loose ones).
-    const int bl[3] = {st.base[0] >> 2, st.base[1] >> 2, st.base[2] >> 2};
-    const int bh[3] = {(st.base[0] + 2) >> 2, (st.base[1] + 2) >> 2, (st.base[2] + 2) >> 2};
     int ent[8];
 #pragma unroll
     for (int c = 0; c < 8; c++) {
@@ -850,13 +992,21 @@ __device__ __forceinline__ void p2g_scatter_global(const SimP& S, const P2GPrep&
     }
 #pragma unroll
     for (int c = 0; c < 8; c++) {
-        if (ent[c] >= 0) GS.dirty[ent[c]] = GS.stamp;                                      // a block of the order's active list
-        else {
+        if (ent[c] >= 0) {                                                                  // a block of the order's active list
+            if (!FG) GS.dirty[ent[c]] = GS.stamp;
+            else if ((late >> c) & 1) fg_mark_late(G.fg, ent[c]);
+            else { bool near; fg_d |= 1 << region(c, near); }
+        } else {
             const int b = (((c & 1) ? bh[0] : bl[0]) * S.nb + ((c & 2) ? bh[1] : bl[1])) * S.nb + ((c & 4) ? bh[2] : bl[2]);
-            mark_dynamic(b, G.blk_flag, G.blk_list, G.blk_count);
-            *G.frame_slow = 1;                                                              // store incomplete for this frame
+            const bool first = mark_dynamic(b, G.blk_flag, G.blk_list, G.blk_count);
+            if (FG) { if (first) fg_rare(G.fg); }
+            else *G.frame_slow = 1;                                                         // store incomplete for this frame
         }
     }
+}
+__device__ __forceinline__ void p2g_scatter_global(const SimP& S, const P2GPrep& q, const GridW& G, const GridStore& GS, const int* __restrict__ blk_slot) {
+    int none = 0;
+    p2g_scatter_global<false>(S, q, G, GS, blk_slot, -1, none);
 }
 
 // Fixed-point accumulators of a quad unit's tiles.  Four fp64 tiles (16 KB each) do not fit beside each other at four workgroups per
@@ -1116,7 +1266,9 @@ __device__ __forceinline__ void load_tile3(const TileO& to, const SimP& S, const
 // not read back, and a substep is two launches instead of three.  FU names what the gather needs.  The host fuses where nothing comes between the two:
 // no sort at f, no mesh effector acting on particles, no rigid bodies (substep_fwd).
 struct FuseP { float* fr_prev; const float4* g_out; int* slow; int* blk_count_prev; };
-template <bool WRITE, bool GENERAL, bool FUSED = false>
+// FG (option "fuse_grid"): grid_op of substep f rides on this launch (the fused grid pass above): tiles arrive at their neighbour entries, and every wave
+// ends with the entries it owns -- no k_grid launch follows.  G.g_out = where v_out of THIS substep goes (FU.g_out: the substep before's, the other buffer).
+template <bool WRITE, bool GENERAL, bool FUSED = false, bool FG = false>
 __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, TableP T,
                                             const int* __restrict__ pool_idx, GridW G, AgentP agent, InjectP inj, int act, int f,
                                             GridStore GS, int fiso, FuseP FU = FuseP{nullptr, nullptr, nullptr, nullptr}) {
@@ -1125,17 +1277,25 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
     if (WRITE && blockIdx.x == 0 && tid == 0 && act) {
         for (int i = 0; i < agent.n; i++) effector_move(agent.e[i], f);
     }
+    if (FG) {
+        if (blockIdx.x == 0 && tid == 0 && GS.cap > 0) __hip_atomic_store(GS.flag + f, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (fg_final takes it back when a block outside the active list got something)
+        fg_begin(G.fg);
+    }
     if (FUSED && blockIdx.x == 0 && tid == 0) *FU.blk_count_prev = 0;      // (g2p_body: grid_op of substep f - 1 was the last reader of its list; this substep's has a counter of its own)
     FrameV cur = frame_view(fr_cur, S.Np, 0, (!GENERAL && (fiso & 1)) ? 1 : 0);
     FrameV curw = frame_view(fr_cur, S.Np, 0);               // (FUSED: the g2p part's stores; plain ones, as k_g2p's are by default -- option write_through)
     FrameV prev = frame_view(FUSED ? FU.fr_prev : fr_cur, S.Np);
     FrameV nxt = frame_view(fr_next, S.Np, S.wt & 1, (!GENERAL && (fiso & 2)) ? 1 : 0);
+    const int slab_wt = FG ? 1 : (S.wt & 1);                  // (FG: the owners of the neighbour entries read the slab in this very launch -- through to memory)
     TL(S, 0);
     Unit un = unit_load(T, blockIdx.x);                       // this workgroup's first unit, asked for together with meta
     const int n_slots = T.meta[5];
     bool prev_quad = false;                                   // (unit_enter)
-    for (int wg = blockIdx.x; wg < n_slots; wg += gridDim.x) {
-        if (wg != (int)blockIdx.x) un = unit_load(T, wg);
+    // (FG: every unit's record is asked for at the head of its own round, as in k_pgg_g2pg -- with the owners' part behind the loop the allocator
+    //  kept the record of the first unit, twelve words, in vector registers across the whole loop: spilled and reloaded per unit)
+    for (int wg = blockIdx.x; FG || wg < n_slots; wg += gridDim.x) {
+        if (FG || wg != (int)blockIdx.x) un = unit_load(T, wg);
+        if (FG && wg >= n_slots) break;
         if (un.a.z == -2) continue;
         if (un.a.z >= 0) {
             const PairCtx pc = unit_ctx(un);
@@ -1143,6 +1303,7 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
             const int4 it = pc.it;
             const TileO to = tile_origin(it.x);
             const int aofs = pc.ti * 4 * TILE_N;                 // (doubles of a pair's tile, words of a quad's)
+            int fg_t = 0, fg_d = 0;                              // FG: the regions this wave's particles deposit into (uniform) / this lane left something in the slow-path accumulator of
             TL(S, 1);
             const int nbr_entry = neighbour_entry(T.blk_slot, S.nb, it.x);      // (in flight together with the particle loads)
             auto zero_tile = [&]() {
@@ -1206,10 +1367,10 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
                 }
                 TL(S, 2);
                 const bool in_tile = lb >= 0;
-                if (used && q.inside && !in_tile && ls.primary) { atomicAdd(G.slow, 1); p2g_scatter_global(S, q, G, GS, T.blk_slot); }   // drifted out of the tile (ahead of the tile path, which may pass q on to another lane: wave_sort)
+                if (used && q.inside && !in_tile && ls.primary) { atomicAdd(G.slow, 1); p2g_scatter_global<FG>(S, q, G, GS, T.blk_slot, it.x, fg_d); }   // drifted out of the tile (ahead of the tile path, which may pass q on to another lane: wave_sort)
                 // a wave without any particle skips the 27-node scan altogether; the branch is wave-uniform, as the DPP scan requires
                 if (__any(in_tile)) {
-                    touch_regions(in_tile ? stencil_regions(lb) : 0, nbr_entry, GS);
+                    fg_t = touch_regions<FG>(in_tile ? stencil_regions(lb) : 0, nbr_entry, GS);
                     if (pc.quad) {
                         wshell = __any(in_tile && stencil_on_shell(lb));
                         float bp = 0.f;
@@ -1233,11 +1394,12 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
             // hand the tile over: plain coalesced float4 stores into the item's slab.  No atomics, no waiting:
             // k_grid sums, per node, the slabs of the (at most 8) blocks whose tiles reach it, in a fixed order.
             if (pc.quad) {
-                if (pc.live) quad_handover<4>(S, (const int*)s_acc + aofs, fs_p.inv, fs_m.inv, G.slab, pc.slab, G.g_in, GS, to, nbr_entry, wshell, S.wt & 1);
+                if (pc.live) quad_handover<4, FG>(S, (const int*)s_acc + aofs, fs_p.inv, fs_m.inv, G.slab, pc.slab, G.g_in, GS, to, nbr_entry, wshell, slab_wt, fg_d);
             } else if (pc.live) for (int l = pc.t0; l < TILE_N; l += pc.nth)
-                tile_handover<4>(S, G.slab, pc.slab, G.g_in, GS, to, nbr_entry, l,
-                                 make_float4((float)s_acc[aofs + l], (float)s_acc[aofs + TILE_N + l], (float)s_acc[aofs + 2 * TILE_N + l], (float)s_acc[aofs + 3 * TILE_N + l]), S.wt & 1);
-            unit_sync(pc.quad);
+                tile_handover<4, false, FG>(S, G.slab, pc.slab, G.g_in, GS, to, nbr_entry, l,
+                                 make_float4((float)s_acc[aofs + l], (float)s_acc[aofs + TILE_N + l], (float)s_acc[aofs + 2 * TILE_N + l], (float)s_acc[aofs + 3 * TILE_N + l]), slab_wt, fg_d);
+            if (FG) fg_unit_end(T, pc, nbr_entry, fg_t, fg_d);      // (with the unit's closing unit_sync inside)
+            else unit_sync(pc.quad);
             TL(S, 6);
         } else {
             const int s = un.a.y + tid;
@@ -1262,11 +1424,13 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
                     P2GPrep q;
                     if (FUSED && have) { load_F(cur, s, raw.p.F); raw.info = load_info(S, T.info, s); p2g_compute<WRITE, GENERAL>(S, nxt, s, raw, G, q); }
                     else p2g_prepare<WRITE, GENERAL>(S, cur, nxt, s, T.info, G, q);
-                    if (q.inside) p2g_scatter_global(S, q, G, GS, T.blk_slot);
+                    int none = 0;
+                    if (q.inside) p2g_scatter_global<FG>(S, q, G, GS, T.blk_slot, -1, none);       // (FG: a tail unit has no tile and no arrival -- whatever it deposits into an active entry is late)
                 } else if (WRITE) unused_particle_fwd(S, cur, nxt, s, T.pid_of_slot[s], pool_idx, agent, inj, f);
             }
         }
     }
+    // (FG: the owners' part follows in the kernel, k_p2g_fg / k_g2p_p2g_fg, with the arguments read afresh)
 }
 struct P2GArgs { SimP S; float* fr_cur; float* fr_next; TableP T; const int* pool_idx; GridW G; AgentP agent; InjectP inj; int act; int f; GridStore GS; int fiso; FuseP FU; };      // (FU: k_g2p_p2g_b)
 template <bool WRITE, bool GENERAL>
@@ -1274,6 +1438,30 @@ __global__ FE_KALIGN __launch_bounds__(WG, GENERAL ? 3 : 4) void k_p2g(SimP S, f
 // substep f's p2g with the g2p of substep f - 1 in front of it (p2g_body, FUSED)
 template <bool GENERAL>
 __global__ FE_KALIGN __launch_bounds__(WG, GENERAL ? 3 : 4) void k_g2p_p2g(SimP S, float* fr_cur, float* fr_next, TableP T, const int* pool_idx, GridW G, AgentP agent, InjectP inj, int act, int f, GridStore GS, int fiso, FuseP FU) { p2g_body<true, GENERAL, true>(S, fr_cur, fr_next, T, pool_idx, G, agent, inj, act, f, GS, fiso, FU); }
+// ... and with grid_op of substep f behind it (p2g_body, FG): the launches of a forward substep under option "fuse_grid"
+// The arguments are ONE struct, and the owners' part reads what it needs of them from the kernel-argument segment again, through a pointer the optimiser cannot see
+// through: handed on as values, S / T / GS / G stayed live -- in scalar registers, i.e. spilled to vector lanes and from there to scratch -- across the unit loop
+// (first build: 279 spilled scalar registers and 180 bytes of scratch in k_p2g_fg).
+template <typename ARGS>
+__device__ __forceinline__ const ARGS* fg_args_again() {
+    const ARGS* p = (const ARGS*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+template <bool GENERAL>
+__global__ FE_KALIGN __launch_bounds__(WG, GENERAL ? 3 : 4) void k_p2g_fg(P2GArgs A) {
+    p2g_body<true, GENERAL, false, true>(A.S, A.fr_cur, A.fr_next, A.T, A.pool_idx, A.G, A.agent, A.inj, A.act, A.f, A.GS, A.fiso);
+    const P2GArgs* B = fg_args_again<P2GArgs>();
+    TL(B->S, 3);
+    fg_owner_phase<false>(B->S, B->T, B->GS, FgArgs{B->G.fg, B->G.slab, B->G.g_in, B->G.g_out, B->G.blk_list, B->G.blk_count, B->G.blk_flag, B->f});
+}
+template <bool GENERAL>
+__global__ FE_KALIGN __launch_bounds__(WG, GENERAL ? 3 : 4) void k_g2p_p2g_fg(P2GArgs A) {
+    p2g_body<true, GENERAL, true, true>(A.S, A.fr_cur, A.fr_next, A.T, A.pool_idx, A.G, A.agent, A.inj, A.act, A.f, A.GS, A.fiso, A.FU);
+    const P2GArgs* B = fg_args_again<P2GArgs>();
+    TL(B->S, 3);
+    fg_owner_phase<false>(B->S, B->T, B->GS, FgArgs{B->G.fg, B->G.slab, B->G.g_in, B->G.g_out, B->G.blk_list, B->G.blk_count, B->G.blk_flag, B->f});
+}
 template <bool GENERAL>
 __global__ FE_KALIGN __launch_bounds__(WG, GENERAL ? 3 : 4) void k_g2p_p2g_b(Batch<P2GArgs> B) { const P2GArgs& A = B.a[blockIdx.y]; p2g_body<true, GENERAL, true>(A.S, A.fr_cur, A.fr_next, A.T, A.pool_idx, A.G, A.agent, A.inj, A.act, A.f, A.GS, A.fiso, A.FU); }
 template <bool WRITE, bool GENERAL>
@@ -1524,6 +1712,295 @@ template <bool KEEP, bool STATICS, bool DYN>
 __global__ FE_KALIGN __launch_bounds__(256, (STATICS || DYN) ? 2 : 4) void k_grid(SimP S, TableP T, const float4* slab, float* g_in, float4* g_out, const int* blk_list, const int* blk_count, int* blk_flag, GridStore GS, int f, int* frame_slow, StaticsP ST, AgentP agent) { grid_body<KEEP, STATICS, DYN>(S, T, slab, g_in, g_out, blk_list, blk_count, blk_flag, GS, f, frame_slow, ST, agent); }
 template <bool KEEP, bool STATICS, bool DYN>
 __global__ FE_KALIGN __launch_bounds__(256, (STATICS || DYN) ? 2 : 4) void k_grid_b(Batch<GridArgs> B) { const GridArgs& A = B.a[blockIdx.y]; grid_body<KEEP, STATICS, DYN>(A.S, A.T, A.slab, A.g_in, A.g_out, A.blk_list, A.blk_count, A.blk_flag, A.GS, A.f, A.frame_slow, A.ST, A.agent); }
+
+// -----------------------------------------------------------------------------------------
+// the fused grid pass (FG kernels): what a wave does with an entry, the owners' loop, the final wave
+// -----------------------------------------------------------------------------------------
+__device__ __forceinline__ float4 fg_load16(const void* base, unsigned byte_off) {                 // 16 bytes past the vector L1 (sc1)
+    const u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(wt_rsrc((void*)base), (int)byte_off, 0, 16);
+    return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+}
+// v_out of a node from its (p, m) totals -- grid_op without colliders (the FG kernels' scenes have none: fuse_grid_ok)
+__device__ __forceinline__ float4 fg_node_out(const SimP& S, const float4 gi, int b, int lane, float kmul[3]) {
+    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+    kmul[0] = kmul[1] = kmul[2] = 0.f;
+    if (gi.w > FE_EPS) {
+        const int bi = b / (S.nb * S.nb), bj = (b / S.nb) % S.nb, bk = b % S.nb;
+        float vo[3];
+        node_velocity<false, false>(S, StaticsP{0, nullptr}, gi, bi * 4 + (lane >> 4), bj * 4 + ((lane >> 2) & 3), bk * 4 + (lane & 3), vo, kmul);
+        out = make_float4(vo[0], vo[1], vo[2], 0.f);
+    }
+    return out;
+}
+// what the forward pass leaves of a block: v_out for the gather, and the frame's record in the grid store ((p, m) totals, v_out packed) -- written through
+__device__ __forceinline__ void fg_fwd_store(const GridStore& GS, const FgArgs& A, int e, int c, int lane, const float4 gi, const float4 out) {
+    wt_store16(A.out, (unsigned)c * 16u, out);
+    if (e >= 0 && e < GS.cap) {
+        float4* dst = GS.data + ((size_t)A.f * GS.cap + e) * GS_BLK;
+        wt_store16(dst, (unsigned)lane * 16u, gi);
+        const u32x3 u = {__float_as_uint(out.x), __float_as_uint(out.y), __float_as_uint(out.z)};
+        __builtin_amdgcn_raw_buffer_store_b96(u, wt_rsrc(dst), 1024 + lane * 12, 0, 16);
+    }
+}
+// grid_op (mpm:380-398) of active-list entry e, one wave: grid_body's one_block -- the same sums in the same order
+// (b: the entry's block; nbr: lane n < 27 holds the item range of neighbour n -- asked for by the caller, ahead of time where it can)
+__device__ __forceinline__ void fg_fwd_block(const SimP& S, const GridStore& GS, const FgArgs& A, int e, int b, const int2 nbr, bool touched, bool dirty) {
+    const int lane = threadIdx.x & 63;
+    const int c = (b << 6) | lane;
+    float4 gi = make_float4(0.f, 0.f, 0.f, 0.f);
+    // (a returning exchange: the read happens where the depositing atomics did, and leaves the zero the next substep expects)
+    if (dirty) gi = make_float4(atomicExch(A.acc + c, 0.f), atomicExch(A.acc + S.ncell + c, 0.f), atomicExch(A.acc + 2 * S.ncell + c, 0.f), atomicExch(A.acc + 3 * S.ncell + c, 0.f));
+    if (touched) { const float4 t = gather_slabs<4>(A.slab, nbr, lane); gi.x += t.x; gi.y += t.y; gi.z += t.z; gi.w += t.w; }
+    float kmul[3];
+    const float4 out = fg_node_out(S, gi, b, lane, kmul);
+    fg_fwd_store(GS, A, e, c, lane, gi, out);
+}
+// grid_op.grad (mpm:539) of entry e for a frame whose grid the forward pass stored: grid_grad_body's one_block
+__device__ __forceinline__ float4 fg_grad_out(const float4 gi, const float4 go, const float kmul[3]) {
+    float4 out = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (gi.w > FE_EPS) {
+        const float inv = 1.f / gi.w;
+        const float g0 = go.x * kmul[0], g1 = go.y * kmul[1], g2 = go.z * kmul[2];
+        out.x = g0 * inv; out.y = g1 * inv; out.z = g2 * inv;
+        out.w = -(gi.x * g0 + gi.y * g1 + gi.z * g2) * inv * inv;
+    }
+    return out;
+}
+__device__ __forceinline__ void fg_bwd_block(const SimP& S, const GridStore& GS, const FgArgs& A, int e, int b, const int2 nbr, bool dirty) {
+    const int lane = threadIdx.x & 63;
+    const int c = (b << 6) | lane;
+    const float4 gi = GS.data[((size_t)A.f * GS.cap + e) * GS_BLK + lane];
+    float4 go = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (dirty) go = make_float4(atomicExch(A.acc + c, 0.f), atomicExch(A.acc + S.ncell + c, 0.f), atomicExch(A.acc + 2 * S.ncell + c, 0.f), 0.f);
+    { const float4 t = gather_slabs<3>(A.slab, nbr, lane); go.x += t.x; go.y += t.y; go.z += t.z; }
+    float kmul[3];
+    (void)fg_node_out(S, gi, b, lane, kmul);
+    wt_store16(A.out, (unsigned)c * 16u, fg_grad_out(gi, go, kmul));
+}
+// (one address for the whole wave; the value into scalar registers)
+__device__ __forceinline__ unsigned long long fg_word(const unsigned long long* p) {
+    const unsigned long long a = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32)) << 32);
+}
+__device__ __forceinline__ int fg_int(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int fg_int_u(const int* p) { return __builtin_amdgcn_readfirstlane(fg_int(p)); }      // (one address for the whole wave)
+// a wave gives up on a wait that cannot end (a bug, or counters left over from an aborted launch): the error is reported by fe_sync, nothing hangs
+#define FG_SPIN_MAX (1 << 22)
+__device__ __forceinline__ void fg_give_up(const FgDev* F) { if ((threadIdx.x & 63) == 0) atomicAdd(F->ctr + FGC_ERR * FG_LINE, 1); }
+// entry e is complete (its word `a` says what arrived): what the final wave does with a skipped one (the owners: fg_owner_phase)
+template <bool BWD>
+__device__ __forceinline__ void fg_entry(const SimP& S, const TableP& T, const GridStore& GS, const FgArgs& A, int e, unsigned long long a) {
+    const int lane = threadIdx.x & 63;
+    const bool touched = FG_TCH(a) != 0, dirty = FG_DRT(a) != 0;
+    if (lane == 0) __hip_atomic_store(T.arrive + e, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+    const int b = T.active[e];
+    const int2 nbr = nbr_record(T, e, lane);
+    if (!BWD) {
+        // (this launch's entries, recorded for the adjoint pass: an entry nothing arrived in has no mass, passes no adjoint on, and no particle reads it)
+        if (lane == 0 && e < GS.cap) __hip_atomic_store(GS.live + (size_t)A.f * GS.cap + e, (unsigned char)((touched || dirty) ? 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (touched || dirty) fg_fwd_block(S, GS, A, e, b, nbr, touched, dirty);
+    } else {
+        if (GS.live[(size_t)A.f * GS.cap + e] != 0) fg_bwd_block(S, GS, A, e, b, nbr, dirty);
+    }
+}
+// The launch's last workgroup has finished its unit loops -- every deposit of the launch is in memory -- and something rare was registered:
+// blocks outside the active list, entries their owners could not wait for, late deposits.  One wave.
+template <bool BWD>
+__device__ __forceinline__ void fg_final(const SimP& S, const TableP& T, const GridStore& GS, const FgArgs& A) {
+    const int lane = threadIdx.x & 63;
+    const FgDev* F = A.F;
+    int* const ctr = F->ctr;
+    const int n_static = T.meta[2];
+    const int* __restrict__ expected = (const int*)(T.arrive + S.nb * S.nb * S.nb);
+    const int n_dyn = BWD ? 0 : fg_int_u(A.blk_count), n_skip = fg_int_u(ctr + FGC_SKIP * FG_LINE), n_late = fg_int_u(ctr + FGC_LATE * FG_LINE);
+    if (!BWD && n_dyn > 0) {                                  // the slow path's blocks outside the order's active list: no slabs, no entry in the store
+        for (int d = 0; d < n_dyn; d++) {
+            const int b = fg_int_u(A.blk_list + d), c = (b << 6) | lane;         // (a block off the list only ever gets late deposits: p2g_scatter_global)
+            const float4 gi = make_float4(atomicExch(F->late + c, 0.f), atomicExch(F->late + S.ncell + c, 0.f), atomicExch(F->late + 2 * S.ncell + c, 0.f), atomicExch(F->late + 3 * S.ncell + c, 0.f));
+            float kmul[3];
+            fg_fwd_store(GS, A, -1, c, lane, gi, fg_node_out(S, gi, b, lane, kmul));
+            if (lane == 0) __hip_atomic_store(A.blk_flag + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) {
+            __hip_atomic_store(A.blk_count, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (GS.cap > 0) __hip_atomic_store(GS.flag + A.f, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the frame's store is incomplete: the adjoint pass recomputes its grid
+        }
+    }
+    if (n_skip > 0) {                                         // every unit loop is over: they are complete now
+        for (int e0 = 0; e0 < n_static; e0 += 64) {
+            const int e = e0 + lane;
+            unsigned long long todo = __ballot(e < n_static && __hip_atomic_load(F->skipm + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == GS.stamp);
+            while (todo) {
+                const int k = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const int ek = e0 + k;
+                if (lane == 0) __hip_atomic_store(F->skipm + ek, (unsigned char)0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long a = fg_word(T.arrive + ek);
+                if (FG_CNT(a) != expected[ek]) fg_give_up(F);
+                fg_entry<BWD>(S, T, GS, A, ek, a);
+            }
+        }
+        if (lane == 0) __hip_atomic_store(ctr + FGC_SKIP * FG_LINE, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (n_late > 0) {
+        // the owners' results are what the late deposits are added to: every workgroup through with its entries first
+        for (int it = 0; ; it++) {
+            int v = lane < FG_SH ? fg_int(ctr + (FGC_FIN + lane) * FG_LINE) : 0;
+#pragma unroll
+            for (int o = 16; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+            if ((unsigned)__builtin_amdgcn_readfirstlane(v) - S.fg_base == gridDim.x) break;
+            if (it > FG_SPIN_MAX) { fg_give_up(F); break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        for (int i = 0; i < n_late; i++) {
+            const int e = fg_int_u(F->late_list + i);
+            const int b = T.active[e], c = (b << 6) | lane;
+            if (lane == 0) __hip_atomic_store(F->late_flag + e, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            float4 lt = make_float4(atomicExch(F->late + c, 0.f), atomicExch(F->late + S.ncell + c, 0.f), atomicExch(F->late + 2 * S.ncell + c, 0.f), 0.f);
+            float kmul[3];
+            if (!BWD) {
+                lt.w = atomicExch(F->late + 3 * S.ncell + c, 0.f);
+                // (p, m) as the owner stored them (nothing, if nothing had arrived), plus the late part: grid_op again
+                const bool live = e < GS.cap && __hip_atomic_load(GS.live + (size_t)A.f * GS.cap + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+                float4 gi = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (live) gi = fg_load16(GS.data + ((size_t)A.f * GS.cap + e) * GS_BLK, (unsigned)lane * 16u);
+                gi.x += lt.x; gi.y += lt.y; gi.z += lt.z; gi.w += lt.w;
+                fg_fwd_store(GS, A, e, c, lane, gi, fg_node_out(S, gi, b, lane, kmul));
+                if (lane == 0 && e < GS.cap) __hip_atomic_store(GS.live + (size_t)A.f * GS.cap + e, (unsigned char)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else if (GS.live[(size_t)A.f * GS.cap + e] != 0) {
+                // grid_op's adjoint is linear in d v_out: the late part's image is added to what the owner wrote
+                const float4 gi = GS.data[((size_t)A.f * GS.cap + e) * GS_BLK + lane];
+                (void)fg_node_out(S, gi, b, lane, kmul);
+                const float4 d = fg_grad_out(gi, lt, kmul), o = fg_load16(A.out, (unsigned)c * 16u);
+                wt_store16(A.out, (unsigned)c * 16u, make_float4(o.x + d.x, o.y + d.y, o.z + d.z, o.w + d.w));
+            }
+        }
+        if (lane == 0) __hip_atomic_store(ctr + FGC_LATE * FG_LINE, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// Every wave of an FG kernel, behind its unit loop (all 64 lanes; no workgroup barrier in here: a quad unit's waves come when they come).
+// The wave's entries are e_k = static_entry(wave) + k W (W = the launch's waves): lane k looks after entry k -- its word, its expected count and its block
+// number are asked for by 64 lanes at once, the words polled with ONE load instruction per round, and an entry nothing arrived in (most of them where the
+// water has come apart) is done by its lane alone.  The others are worked on by the whole wave one after the other, in the order they complete, the next
+// one's neighbour record asked for ahead; the records of the first eight are on their way before the first poll (first form: poll -> block number and
+// record -> slabs -> accumulator, four dependent round trips per entry and five entries per wave in the splash: +40 us on k_g2p_p2g where k_grid took 21).
+#define FG_NPF 2
+template <bool BWD>
+__device__ __forceinline__ void fg_owner_phase(const SimP& S, const TableP& T, const GridStore& GS, const FgArgs& A) {
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const FgDev* F = A.F;
+    int* const ctr = F->ctr;
+    const int G_ = gridDim.x, W = 4 * G_;
+    const int es = static_entry(wave);
+    const int n_static = T.meta[2];
+    const int* __restrict__ expected = (const int*)(T.arrive + S.nb * S.nb * S.nb);
+    // this lane's entry of the wave's first 64, and what is known of it before anything arrives
+    const int e_l = es + lane * W;
+    const bool have = e_l < n_static;
+    const int exp_l = have ? expected[e_l] : 0, b_l = have ? T.active[e_l] : 0;
+    const unsigned char live_l = (BWD && have) ? GS.live[(size_t)A.f * GS.cap + e_l] : (unsigned char)0;
+    int2 pf[FG_NPF];                                          // the neighbour records of the first entries: lane n < 27 holds neighbour n
+#pragma unroll
+    for (int j = 0; j < FG_NPF; j++) pf[j] = (es + j * W < n_static) ? nbr_record(T, es + j * W, lane) : make_int2(0, 0);
+    // may this wave wait?  Only when every workgroup of the launch has started: all of them are then running or done, and unit loops wait for nothing
+    int st = lane < 8 ? fg_int(ctr + (FGC_STARTED + lane) * FG_LINE) : 0;
+    st += __shfl_xor(st, 1, 64); st += __shfl_xor(st, 2, 64); st += __shfl_xor(st, 4, 64);
+    const bool wait = (unsigned)__builtin_amdgcn_readfirstlane(st) - S.fg_base == (unsigned)G_ && !S.fg_nowait;
+    unsigned long long a_l = have ? __hip_atomic_load(T.arrive + e_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    unsigned long long pending = __ballot(have);
+    if (!wait) {                                              // ... else the entries that are not complete by now are the final wave's
+        const bool skip = have && FG_CNT(a_l) != exp_l;
+        if (skip) __hip_atomic_store(F->skipm + e_l, GS.stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int nskip = __popcll(__ballot(skip));
+        for (int e = es + 64 * W; e < n_static; e += W) { if (lane == 0) __hip_atomic_store(F->skipm + e, GS.stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); nskip++; }      // (beyond the wave's first 64: not looked at)
+        if (nskip && lane == 0) { atomicAdd(ctr + FGC_SKIP * FG_LINE, nskip); fg_rare(F); }
+        pending &= ~__ballot(skip);
+    }
+    // this wave's unit loops are over, and what it stored and registered has completed; the workgroup's last wave signs the workgroup off
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int r1 = -1;
+    bool signs = false;
+    if (lane == 0 && atomicAdd(&s_fg[8], 1) == 3) { signs = true; r1 = atomicAdd(ctr + (FGC_DONE + (int)(blockIdx.x % FG_SH)) * FG_LINE, 1); }      // (asked for now, read behind the entries)
+    signs = __builtin_amdgcn_readfirstlane(signs ? 1 : 0) != 0;
+    // the wave's first 64 entries, in the order they complete
+    for (int it = 0; pending; it++) {
+        const bool mine_pending = (pending >> lane) & 1ull;
+        const bool done = mine_pending && FG_CNT(a_l) == exp_l;
+        const unsigned long long done_now = __ballot(done);
+        if (!done_now) {
+            if (it > FG_SPIN_MAX) { fg_give_up(F); break; }
+            __builtin_amdgcn_s_sleep(2);
+            if (mine_pending) a_l = __hip_atomic_load(T.arrive + e_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
+        }
+        TL(S, 5);
+        const bool touched = FG_TCH(a_l) != 0, dirty = FG_DRT(a_l) != 0;
+        bool heavy = false;
+        if (done) {                                           // the lane's own part: the word back to zero for the next launch, the entry's record for the adjoint pass
+            __hip_atomic_store(T.arrive + e_l, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!BWD) {
+                heavy = touched || dirty;
+                if (e_l < GS.cap) __hip_atomic_store(GS.live + (size_t)A.f * GS.cap + e_l, (unsigned char)(heavy ? 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else heavy = live_l != 0;
+        }
+        unsigned long long todo = __ballot(heavy);
+        const unsigned long long dirty_set = __ballot(dirty), touched_set = __ballot(touched);
+        pending &= ~done_now;
+        if ((pending >> lane) & 1ull) a_l = __hip_atomic_load(T.arrive + e_l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (the next poll: on its way while the wave works)
+        auto record = [&](int kk) -> int2 {                   // (kk uniform) the prefetched ones by register select, the others from memory
+            if (kk < FG_NPF) {
+                int2 r = pf[0];
+#pragma unroll
+                for (int j = 1; j < FG_NPF; j++) if (kk == j) r = pf[j];
+                return r;
+            }
+            return nbr_record(T, es + kk * W, lane);
+        };
+        int k = todo ? __builtin_ctzll(todo) : -1;
+        int2 nbr = k >= 0 ? record(k) : make_int2(0, 0);
+        while (k >= 0) {                                      // the whole wave on one entry after the other, the next one's neighbour record asked for ahead
+            todo &= todo - 1;
+            const int k_next = todo ? __builtin_ctzll(todo) : -1;
+            const int2 nbr_next = k_next >= 0 ? record(k_next) : make_int2(0, 0);
+            const int e = es + k * W, b = __builtin_amdgcn_readlane(b_l, k);
+            if (!BWD) fg_fwd_block(S, GS, A, e, b, nbr, (touched_set >> k) & 1ull, (dirty_set >> k) & 1ull);
+            else fg_bwd_block(S, GS, A, e, b, nbr, (dirty_set >> k) & 1ull);
+            k = k_next; nbr = nbr_next;
+        }
+    }
+    // (more than 64 entries per wave -- a grid of 256^3 and up that is active all over: one after the other)
+    if (wait) for (int e = es + 64 * W; e < n_static; e += W) {
+        const int exp_e = expected[e];
+        unsigned long long a = fg_word(T.arrive + e);
+        for (int it = 0; FG_CNT(a) != exp_e; it++) {
+            if (it > FG_SPIN_MAX) { fg_give_up(F); break; }
+            __builtin_amdgcn_s_sleep(2);
+            a = fg_word(T.arrive + e);
+        }
+        fg_entry<BWD>(S, T, GS, A, e, a);
+    }
+    // through with its entries (everything stored has completed): the workgroup's last wave counts the workgroup as finished
+    TL(S, 4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TL(S, 7);
+    if (lane == 0 && atomicAdd(&s_fg[9], 1) == 3) (void)__hip_atomic_fetch_add(ctr + (FGC_FIN + (int)(blockIdx.x % FG_SH)) * FG_LINE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!signs) return;
+    // was this the launch's last workgroup to finish its unit loops?  (last of its shard, then last shard)
+    r1 = __builtin_amdgcn_readfirstlane(r1);
+    const int sh = blockIdx.x % FG_SH, n_sh = (G_ - sh + FG_SH - 1) / FG_SH;
+    if (r1 != n_sh - 1) return;
+    int r2 = 0;
+    if (lane == 0) {
+        __hip_atomic_store(ctr + (FGC_DONE + sh) * FG_LINE, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (the shard is complete: ready for the next launch)
+        r2 = atomicAdd(ctr + FGC_TOP * FG_LINE, 1);
+    }
+    r2 = __builtin_amdgcn_readfirstlane(r2);
+    if ((r2 & 0xffff) != (G_ < FG_SH ? G_ : FG_SH) - 1) return;
+    if (lane == 0) __hip_atomic_store(ctr + FGC_TOP * FG_LINE, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((r2 >> 16) != 0) fg_final<BWD>(S, T, GS, A);
+}
 
 
 // g2p (mpm:400-426) + advect_kernel (mpm:497-505) for one used particle
@@ -3397,7 +3874,7 @@ __device__ __forceinline__ void build_unit_list(int gtid, int nth, int N, int xc
 // round again, if that is enough.
 __device__ __forceinline__ void build_units_dev(int gtid, int nth, int nb, int N, int xcd_on, int quad_min_units, int quad_fit, int pack_units, int pgg_quad_min_units, const int4* __restrict__ items, const int2* __restrict__ pairs,
                                                 const int* __restrict__ singles, const int* __restrict__ singles_c, const int2* __restrict__ blk_first, const int* __restrict__ active,
-                                                int* meta, UnitRec* units, UnitRec* units_p, int units_cap, int2* nbr) {
+                                                int* meta, UnitRec* units, UnitRec* units_p, int units_cap, int2* nbr, int* expected) {
     const int tail_start = meta[1], n_active = meta[2];
     const UnitLists L = {meta[3], meta[4], meta[11], meta[12], meta[8]};
     const int n_tail = (N - tail_start + WG - 1) / WG;
@@ -3433,11 +3910,27 @@ __device__ __forceinline__ void build_units_dev(int gtid, int nth, int nb, int N
 #pragma unroll
         for (int u = 0; u < 4; u++) { const int t = t0 + u * nth; if (t < n_active * 27) nbr[t] = v[u]; }
     }
+    // the fused grid pass (FG kernels): how many tiles are handed over around each entry -- the slabs of its block's 27 neighbours (a block's items pair up from
+    // its first one: gather_slabs) -- is what its arrival word counts up to
+    for (int e = gtid; e < n_active; e += nth) {
+        const int b = active[e], bi = b / (nb * nb), bj = (b / nb) % nb, bk = b % nb;
+        int cnt[27];
+#pragma unroll
+        for (int n = 0; n < 27; n++) {                      // (all 27 asked for together, masked behind the loads: k_sort_blk_partial's active list)
+            const int i2 = bi + n / 9 - 1, j2 = bj + (n / 3) % 3 - 1, k2 = bk + n % 3 - 1;
+            const bool ok = (unsigned)i2 < (unsigned)nb && (unsigned)j2 < (unsigned)nb && (unsigned)k2 < (unsigned)nb;
+            cnt[n] = ok ? blk_first[(i2 * nb + j2) * nb + k2].y : 0;
+        }
+        int sum = 0;
+#pragma unroll
+        for (int n = 0; n < 27; n++) sum += (cnt[n] + 1) >> 1;
+        expected[e] = sum;
+    }
 }
 __global__ __launch_bounds__(256) void k_build_units(int nb, int N, int xcd_on, const int4* __restrict__ items, const int2* __restrict__ pairs,
                                                      const int* __restrict__ singles, const int2* __restrict__ blk_first, const int* __restrict__ active,
-                                                     int* meta, UnitRec* units, UnitRec* units_p, int units_cap, int2* nbr) {
-    build_units_dev(blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, nb, N, xcd_on, 0x7fffffff, 0, 0, 0x7fffffff, items, pairs, singles, singles, blk_first, active, meta, units, units_p, units_cap, nbr);
+                                                     int* meta, UnitRec* units, UnitRec* units_p, int units_cap, int2* nbr, int* expected) {
+    build_units_dev(blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x, nb, N, xcd_on, 0x7fffffff, 0, 0, 0x7fffffff, items, pairs, singles, singles, blk_first, active, meta, units, units_p, units_cap, nbr, expected);
 }
 
 // The permutation itself, one pass: slot s of the old order goes to d = start[key] + rank -- its particle id, material record and
@@ -3446,7 +3939,7 @@ __global__ __launch_bounds__(256) void k_build_units(int nb, int N, int xcd_on, 
 #ifndef SORT_UNIT_WGS
 #define SORT_UNIT_WGS 512      // (128 until late in round 4: where the water has come apart the neighbour records were the launch's longest chain)
 #endif
-struct UnitsArgs { int* bcnt; int nb, xcd_on, quad_min_units, quad_fit, pack_units, pgg_quad_min_units; const int4* items; const int2* pairs; const int* singles; const int* singles_c; const int2* blk_first; const int* active; int* meta; UnitRec* units; UnitRec* units_p; int units_cap; int2* nbr; };
+struct UnitsArgs { int* bcnt; int nb, xcd_on, quad_min_units, quad_fit, pack_units, pgg_quad_min_units; const int4* items; const int2* pairs; const int* singles; const int* singles_c; const int2* blk_first; const int* active; int* meta; UnitRec* units; UnitRec* units_p; int units_cap; int2* nbr; int* expected; };
 __global__ __launch_bounds__(256) void k_sort_apply(int N, size_t Np, int n_pwg, const int* __restrict__ key, const int* __restrict__ rank,
                                                     const int* __restrict__ start, const int* __restrict__ blk_base, const int* __restrict__ pid_old, int* pid_new, int* slot_of_pid,
                                                     const float4* __restrict__ pinfo, float4* info_new, float* dst_, float* src_, UnitsArgs U, int uni, int iso) {      // iso: the frame's F is compact (FrameV::iso): two planes less to move
@@ -3455,7 +3948,7 @@ __global__ __launch_bounds__(256) void k_sort_apply(int N, size_t Np, int n_pwg,
     if ((int)blockIdx.x < SORT_UNIT_WGS) {
         for (int i = blockIdx.x * 256 + threadIdx.x; i <= U.nb * U.nb * U.nb; i += SORT_UNIT_WGS * 256) U.bcnt[i] = 0;      // block counts: ready for the next sort
         build_units_dev(blockIdx.x * 256 + threadIdx.x, SORT_UNIT_WGS * 256, U.nb, N, U.xcd_on, U.quad_min_units, U.quad_fit, U.pack_units, U.pgg_quad_min_units, U.items, U.pairs, U.singles, U.singles_c, U.blk_first, U.active, U.meta,
-                        U.units, U.units_p, U.units_cap, U.nbr);
+                        U.units, U.units_p, U.units_cap, U.nbr, U.expected);
         return;
     }
     const int s = (blockIdx.x - SORT_UNIT_WGS) * blockDim.x + threadIdx.x;
@@ -3897,7 +4390,7 @@ struct FeEngine {
     float* grads = nullptr;                                 // 3 x (GR_WORDS*Np + Np) floats: ring of two + 1 spare
     float* grad_ptr[3] = {nullptr, nullptr, nullptr};
     // particle orders ("tables"): id 0 = identity; id 1+f = order produced by the sort at frame f
-    struct Table { int* pid = nullptr; float4* info = nullptr; int2* pairs = nullptr; int* singles = nullptr; int4* items = nullptr; int* meta = nullptr; int2* blk_first = nullptr; int* active = nullptr; int* blk_slot = nullptr; int* slot_of_pid = nullptr; UnitRec* units = nullptr; UnitRec* units_p = nullptr; int2* nbr = nullptr; };
+    struct Table { int* pid = nullptr; float4* info = nullptr; int2* pairs = nullptr; int* singles = nullptr; int4* items = nullptr; int* meta = nullptr; int2* blk_first = nullptr; int* active = nullptr; int* blk_slot = nullptr; int* slot_of_pid = nullptr; UnitRec* units = nullptr; UnitRec* units_p = nullptr; int2* nbr = nullptr; unsigned long long* arrive = nullptr; /* [nblk] arrival words, then int expected[nblk] (fused grid pass) */ };
     int loose_max = 0;                                      // blocks with <= this many particles get no work item (option "loose_max")
     std::vector<int> gs_host; bool gs_host_valid = false;   // host copy of gs_flag, refreshed once per backward sweep
     float4* gstore = nullptr; int* gs_flag = nullptr; int gs_cap = 0;     // forward grid store (see GridStore)
@@ -3912,6 +4405,11 @@ struct FeEngine {
     bool compact_F = true;                                  // option "compact_F"
     int fuse_bwd = 1;                                       // option "fuse_bwd": inside a fe_step_grad call a substep's p2g_grad takes the next substep's g2p_grad along (k_pgg_g2pg)
     bool fuse_g2p = true;                                   // option "fuse_g2p": inside a fe_step call the g2p of a substep runs at the head of the next substep's p2g launch (k_g2p_p2g)
+    int fuse_grid = 0;                                      // option "fuse_grid": grid_op rides on the forward scatter launches (FG kernels, fused grid pass); 0 = off (default: measured slower),
+                                                            // 1 = where nothing slow is expected (fuse_grid_ok), 2 = wherever it is possible; + 4 = its waves never wait (every entry goes the skipped road: tests)
+    FgDev fg_host = {nullptr, nullptr, nullptr, nullptr, nullptr}; FgDev* fg_dev = nullptr;     // the pass' device block
+    unsigned fg_started = 0;                                // workgroups of all FG launches so far: what the pass' monotonic counters read before the next one (SimP::fg_base)
+    bool tail_used = true;                                  // used particles may sit behind the work items of the current order: injected or edited by the host since the last sort (-> late deposits, fg_final)
     int tbl_bank = 0, last_sorted_f = -1;                   // two banks of table ids, one per sweep over the window (sort_frame)
     int p2g_grad_waves = 4;                                 // occupancy target of the SVD-free p2g_grad build (tuning)
     int pack_units = 2;                                     // option "pack_units": 0 never, 1 pack the scatter list (no idle halves) when that brings it back into one round, 2 whenever it is more than one round
@@ -3971,7 +4469,8 @@ struct FeEngine {
     float*& spare_frame() { return frame_ptr[L + 1]; }
     float* grad(int f) { return grad_ptr[f & 1]; }
     size_t grad_words() const { return (size_t)GR_WORDS * Np + Np; }
-    TableP tableP(int id) const { TableP t; t.pid_of_slot = tables[id].pid; t.info = tables[id].info; t.meta = tables[id].meta; t.active = tables[id].active; t.blk_slot = tables[id].blk_slot; t.units = tables[id].units; t.units_p = tables[id].units_p; t.units_cap = (int)units_cap; t.nbr = tables[id].nbr; return t; }
+    TableP tableP(int id) const { TableP t; t.pid_of_slot = tables[id].pid; t.info = tables[id].info; t.meta = tables[id].meta; t.active = tables[id].active; t.blk_slot = tables[id].blk_slot; t.units = tables[id].units; t.units_p = tables[id].units_p; t.units_cap = (int)units_cap; t.nbr = tables[id].nbr; t.arrive = tables[id].arrive; return t; }
+    int* expected_of(int id) const { return (int*)(tables[id].arrive + (size_t)nb * nb * nb); }
     const int* pid_of(int f) const { return tables[tbl_of_frame[f]].pid; }
 };
 
@@ -4094,7 +4593,7 @@ int check_async(FeEngine* h);
 
 void build_units(FeEngine* h, FeEngine::Table& t) {
     hipLaunchKernelGGL(k_build_units, dim3(256), dim3(256), 0, h->stream, h->nb, h->N, h->S.xcd, t.items, t.pairs, t.singles, t.blk_first, t.active, t.meta,
-                       t.units, t.units_p, (int)h->units_cap, t.nbr);
+                       t.units, t.units_p, (int)h->units_cap, t.nbr, (int*)(t.arrive + (size_t)h->nb * h->nb * h->nb));
 }
 int ensure_table(FeEngine* h, int id) {
     if ((int)h->tables.size() <= id) h->tables.resize(id + 1);
@@ -4107,7 +4606,8 @@ int ensure_table(FeEngine* h, int id) {
     if (dev_alloc(h, &t.pairs, h->items_cap) || dev_alloc(h, &t.singles, 2 * h->items_cap)) return 1;      // (singles: block order, then the same list by size class)
     if (dev_alloc(h, &t.pid, h->Np) || dev_alloc(h, &t.items, h->items_cap) || dev_alloc(h, &t.meta, 24) ||
         dev_alloc(h, &t.blk_first, nblk) || dev_alloc(h, &t.active, nblk) || dev_alloc(h, &t.blk_slot, nblk) || dev_alloc(h, &t.slot_of_pid, h->Np) ||
-        dev_alloc(h, &t.units, h->units_cap, false) || dev_alloc(h, &t.units_p, h->units_cap, false) || dev_alloc(h, &t.nbr, nblk * 27, false)) return 1;
+        dev_alloc(h, &t.units, h->units_cap, false) || dev_alloc(h, &t.units_p, h->units_cap, false) || dev_alloc(h, &t.nbr, nblk * 27, false) ||
+        dev_alloc(h, &t.arrive, nblk + (nblk + 1) / 2)) return 1;       // (arrival words: zero between launches -- the owner of an entry clears it; then `expected`, ints)
     HIPCK(h, hipMemsetAsync(t.blk_slot, 0xff, sizeof(int) * nblk, h->stream));
     if (id == 0) build_units(h, t);                            // the identity order: no items, every slot on the tail
     return 0;
@@ -4169,7 +4669,7 @@ int sort_frame(FeEngine* h, int f) {
     if (fine) { prof_end(h); prof_begin(h, KID_SORT_PERM); }
     // re-sorting a frame that is already in this table's order reads the id table it rewrites: stage it
     int* pid_dst = id_old == id_new ? h->sort_pid : tn.pid;
-    const UnitsArgs U = {h->sort_bcnt, h->nb, h->S.xcd, h->quad_min_units, h->quad_fit, h->pack_units, h->pgg_quad_min_units, tn.items, tn.pairs, tn.singles, tn.singles + h->items_cap, tn.blk_first, tn.active, tn.meta, tn.units, tn.units_p, (int)h->units_cap, tn.nbr};
+    const UnitsArgs U = {h->sort_bcnt, h->nb, h->S.xcd, h->quad_min_units, h->quad_fit, h->pack_units, h->pgg_quad_min_units, tn.items, tn.pairs, tn.singles, tn.singles + h->items_cap, tn.blk_first, tn.active, tn.meta, tn.units, tn.units_p, (int)h->units_cap, tn.nbr, (int*)(tn.arrive + (size_t)nblk)};
     hipLaunchKernelGGL(k_sort_apply, dim3(n_pwg + SORT_UNIT_WGS), dim3(256), 0, h->stream, h->N, (size_t)h->Np, n_pwg, h->sort_key, h->sort_rank, h->sort_start, h->sort_base,
                        h->tables[id_old].pid, pid_dst, tn.slot_of_pid, h->pinfo, tn.info, h->spare_frame(), h->frame(f), U, h->S.uni, h->fiso[f] ? 1 : 0);
     if (id_old == id_new) HIPCK(h, hipMemcpyAsync(tn.pid, h->sort_pid, sizeof(int) * h->Np, hipMemcpyDeviceToDevice, h->stream));
@@ -4190,8 +4690,12 @@ GridStore grid_store(FeEngine* h) {
 // The length of substep f's dynamic block list: two counters, by the parity of f -- k_g2p_p2g adds to substep f's list and, in the same launch, clears
 // the one grid_op of substep f - 1 has just read (g2p_body's reset).  Every window of launches that uses a counter ends with the kernel that clears it.
 inline int* bcount(FeEngine* h, int f) { return h->blk_count + (f & 1); }
+// v_out of substep f / the adjoint grid (d v_in, d m) of substep f: two buffers each, by the parity of f (fused grid pass, FG kernels)
+inline float4* gout(FeEngine* h, int f) { return h->g_out + (size_t)(f & 1) * h->S.ncell; }
+inline float4* ggin(FeEngine* h, int f) { return h->gg_in + (size_t)(f & 1) * h->S.ncell; }
 GridW grid_w(FeEngine* h, int f) {
     GridW g; g.g_in = h->g_in; g.slab = h->slab; g.ncell = h->S.ncell; g.frame_slow = h->frame_slow_dev; g.blk_flag = h->blk_flag; g.blk_list = h->blk_list; g.blk_count = bcount(h, f); g.err = h->err_dev; g.slow = h->slow_dev;
+    g.fg = h->fg_dev; g.g_out = gout(h, f);
     return g;
 }
 
@@ -4201,7 +4705,7 @@ inline bool particle_collide(FeEngine* h) { return h->has_mesh_effector && (h->c
 
 template <bool KEEP>
 void launch_grid(FeEngine* h, const TableP& T, int f, const AgentP& ag) {
-#define LAUNCH_GRID(ST_, DY_) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid<KEEP, ST_, DY_>), ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, h->g_out, \
+#define LAUNCH_GRID(ST_, DY_) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid<KEEP, ST_, DY_>), ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, gout(h, f), \
                            h->blk_list, bcount(h, f), h->blk_flag, grid_store(h), f, h->frame_slow_dev, statics_p(h), ag)
     if (grid_collide(h)) { if (h->statics_host.empty()) LAUNCH_GRID(false, true); else LAUNCH_GRID(true, true); }
     else { if (h->statics_host.empty()) LAUNCH_GRID(false, false); else LAUNCH_GRID(true, false); }
@@ -4216,22 +4720,41 @@ inline int fwd_iso(FeEngine* h, int f) { return (h->fiso[f] ? 1 : 0) | ((h->all_
 inline bool fusable_fwd(FeEngine* h, int f) {
     return h->fuse_g2p && f > 0 && !(h->sort_interval > 0 && f % h->sort_interval == 0) && !particle_collide(h) && !h->has_rigid && !h->has_collector;
 }
+// Does grid_op of substep f ride on its scatter launch (the fused grid pass, FG kernels; option "fuse_grid")?  What the pass cannot do: colliders at the
+// nodes (the lean grid_op only), blocks without work items (nobody arrives for them), a store that does not hold every entry (late deposits are added to what the
+// owner stored), the identity order (no entries at all).  What it can do but slowly (the launch's final wave, alone): used particles behind the work items --
+// the injector's, or the host's edits since the last sort -- so with fuse_grid = 1 such launches keep the separate k_grid.
+inline bool fuse_grid_possible(FeEngine* h, int t) {
+    return (h->fuse_grid & 3) != 0 && h->sort_interval > 0 && t > 0 && h->loose_max == 0 && h->statics_host.empty() && !h->has_mesh_effector &&
+           h->gs_cap == h->nb * h->nb * h->nb;
+}
+inline bool fuse_grid_ok(FeEngine* h, int f) { return fuse_grid_possible(h, h->tbl_of_frame[f]) && ((h->fuse_grid & 3) >= 2 || !h->tail_used); }
+// an FG launch: the pass' `started` / `finished` counters are monotonic (nothing to reset between launches); they read fg_started before it and fg_started + workgroups behind it
+inline void fg_launch_begin(FeEngine* h) { h->S.fg_base = h->fg_started; h->S.fg_nowait = (h->fuse_grid & 4) ? 1 : 0; }
+inline void fg_launch_end(FeEngine* h, dim3 grid) { h->fg_started += grid.x; }
 // `g2p_pending`: the caller's last substep left its g2p to this one (fusable_fwd(h, f) held);  `defer_g2p`: leave this substep's to the next one
 int substep_fwd(FeEngine* h, int f, int f_global, int act, bool g2p_pending = false, bool defer_g2p = false) {
     h->gs_host_valid = false;
     h->stamp++;                                           // p2g marks, grid_op reads (GridStore)
     InjectP inj;
     if (make_inject(h, f, f_global, act, true, inj)) return 1;
-    if (h->sort_interval > 0 && f % h->sort_interval == 0 && sort_frame(h, f)) return 1;
+    if (h->sort_interval > 0 && f % h->sort_interval == 0) { if (sort_frame(h, f)) return 1; h->tail_used = false; }
     h->tbl_of_frame[f + 1] = h->tbl_of_frame[f];        // a substep keeps the slot order
     use_static_table(h, h->tbl_of_frame[f]);
     const TableP T = h->tableP(h->tbl_of_frame[f]);
     AgentP ag = agent_params(h);
     const int fiso = fwd_iso(h, f);
+    const bool fg = fuse_grid_ok(h, f);                   // (before this substep's injection counts: its particles are used from frame f + 1 on)
+    if (inj.on) h->tail_used = true;
+    if (fg) fg_launch_begin(h);
     if (g2p_pending) {
-        const FuseP FU = {h->frame(f - 1), h->g_out, h->slow_dev, bcount(h, f - 1)};
+        const FuseP FU = {h->frame(f - 1), gout(h, f - 1), h->slow_dev, bcount(h, f - 1)};
         prof_begin(h, KID_G2P_P2G);
-        if (h->all_simple_liquid)
+        if (fg) {
+            const P2GArgs A = {h->S, h->frame(f), h->frame(f + 1), T, h->pool_idx, grid_w(h, f), ag, inj, act, f, grid_store(h), h->all_simple_liquid ? fiso : 0, FU};
+            if (h->all_simple_liquid) hipLaunchKernelGGL((k_g2p_p2g_fg<false>), wgrid(h), dim3(WG), 0, h->stream, A);
+            else hipLaunchKernelGGL((k_g2p_p2g_fg<true>), wgrid(h), dim3(WG), 0, h->stream, A);
+        } else if (h->all_simple_liquid)
             hipLaunchKernelGGL((k_g2p_p2g<false>), wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T,
                                h->pool_idx, grid_w(h, f), ag, inj, act, f, grid_store(h), fiso, FU);
         else
@@ -4240,7 +4763,11 @@ int substep_fwd(FeEngine* h, int f, int f_global, int act, bool g2p_pending = fa
         prof_end(h);
     } else {
     prof_begin(h, KID_P2G);
-    if (h->all_simple_liquid)
+    if (fg) {
+        const P2GArgs A = {h->S, h->frame(f), h->frame(f + 1), T, h->pool_idx, grid_w(h, f), ag, inj, act, f, grid_store(h), h->all_simple_liquid ? fiso : 0, FuseP{nullptr, nullptr, nullptr, nullptr}};
+        if (h->all_simple_liquid) hipLaunchKernelGGL((k_p2g_fg<false>), wgrid(h), dim3(WG), 0, h->stream, A);
+        else hipLaunchKernelGGL((k_p2g_fg<true>), wgrid(h), dim3(WG), 0, h->stream, A);
+    } else if (h->all_simple_liquid)
         hipLaunchKernelGGL((k_p2g<true, false>), wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T,
                            h->pool_idx, grid_w(h, f), ag, inj, act, f, grid_store(h), fiso);
     else
@@ -4248,16 +4775,19 @@ int substep_fwd(FeEngine* h, int f, int f_global, int act, bool g2p_pending = fa
                            h->pool_idx, grid_w(h, f), ag, inj, act, f, grid_store(h), 0);
     prof_end(h);
     }
+    if (fg) fg_launch_end(h, wgrid(h));
     h->fiso[f + 1] = (fiso & 2) != 0;
+    if (!fg) {
     prof_begin(h, KID_GRID);
     launch_grid<false>(h, T, f, ag);
     prof_end(h);
+    }
     if (defer_g2p) return 0;                              // (fusable_fwd(h, f + 1): no rigid-body pass either)
     prof_begin(h, KID_G2P);
     if (particle_collide(h))
-        hipLaunchKernelGGL(k_g2p<true>, wgrid_g2p(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T, h->g_out, bcount(h, f), h->slow_dev, ag, f);
+        hipLaunchKernelGGL(k_g2p<true>, wgrid_g2p(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T, gout(h, f), bcount(h, f), h->slow_dev, ag, f);
     else
-        hipLaunchKernelGGL(k_g2p<false>, wgrid_g2p(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T, h->g_out, bcount(h, f), h->slow_dev, ag, f);
+        hipLaunchKernelGGL(k_g2p<false>, wgrid_g2p(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T, gout(h, f), bcount(h, f), h->slow_dev, ag, f);
     prof_end(h);
     if (h->has_rigid) {
         hipLaunchKernelGGL(k_rigid_body<false>, dim3(h->n_bodies), dim3(256), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), (float*)nullptr,
@@ -4327,24 +4857,24 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act, int next_f = -1, bool
     if (particle_collide(h)) {
         HIPCK(h, hipMemsetAsync(h->hit_count, 0, sizeof(int), h->stream));
         hipLaunchKernelGGL(k_collide_list, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), f, ag, h->hit_list, h->hit_count);
-        hipLaunchKernelGGL(k_collide_grad, dim3(std::min((h->N + 15) / 16, 2048)), dim3(256), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->g_out, T, grid_store(h), f, ag,
+        hipLaunchKernelGGL(k_collide_grad, dim3(std::min((h->N + 15) / 16, 2048)), dim3(256), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), gout(h, f), T, grid_store(h), f, ag,
                            h->hit_list, h->hit_count);
     }
-    if (h->g2p_grad_v == 2) hipLaunchKernelGGL(k_g2p_grad2<3>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag);
-    else if (h->g2p_grad_v != 1) hipLaunchKernelGGL(k_g2p_grad2<4>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag);
-    else hipLaunchKernelGGL(k_g2p_grad, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag);
+    if (h->g2p_grad_v == 2) hipLaunchKernelGGL(k_g2p_grad2<3>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, gout(h, f), h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag);
+    else if (h->g2p_grad_v != 1) hipLaunchKernelGGL(k_g2p_grad2<4>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, gout(h, f), h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag);
+    else hipLaunchKernelGGL(k_g2p_grad, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, gout(h, f), h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag);
     prof_end(h);
     }                                                     // (!g2p_done; the marks of its scatter carry the stamp of the launch it ran in: no stamp++ since)
     prof_begin(h, KID_GRID_GRAD);
 #define LAUNCH_GRID_GRAD(ST_, DY_) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_grad<ST_, DY_>), ggrid(h), dim3(256), 0, h->stream, h->S, T, h->slab, h->g_in, h->gg_out, \
-                           h->gg_in, h->blk_list, bcount(h, f), h->blk_flag, grid_store(h), f, statics_p(h), ag, h->node_work, h->node_work_count)
+                           ggin(h, f), h->blk_list, bcount(h, f), h->blk_flag, grid_store(h), f, statics_p(h), ag, h->node_work, h->node_work_count)
     if (grid_collide(h)) {
         if (!h->node_work && (dev_alloc(h, &h->node_work, (size_t)h->S.ncell, false) || dev_alloc(h, &h->node_work_count, 1))) return 1;
         HIPCK(h, hipMemsetAsync(h->node_work_count, 0, sizeof(int), h->stream));
         if (h->statics_host.empty()) LAUNCH_GRID_GRAD(false, true); else LAUNCH_GRID_GRAD(true, true);
         const dim3 wg((unsigned)std::min((h->S.ncell + 15) / 16, 1024));
-        if (h->statics_host.empty()) hipLaunchKernelGGL(k_grid_collide_grad<false>, wg, dim3(256), 0, h->stream, h->S, h->gg_in, f, statics_p(h), ag, h->node_work, h->node_work_count);
-        else hipLaunchKernelGGL(k_grid_collide_grad<true>, wg, dim3(256), 0, h->stream, h->S, h->gg_in, f, statics_p(h), ag, h->node_work, h->node_work_count);
+        if (h->statics_host.empty()) hipLaunchKernelGGL(k_grid_collide_grad<false>, wg, dim3(256), 0, h->stream, h->S, ggin(h, f), f, statics_p(h), ag, h->node_work, h->node_work_count);
+        else hipLaunchKernelGGL(k_grid_collide_grad<true>, wg, dim3(256), 0, h->stream, h->S, ggin(h, f), f, statics_p(h), ag, h->node_work, h->node_work_count);
     } else { if (h->statics_host.empty()) LAUNCH_GRID_GRAD(false, false); else LAUNCH_GRID_GRAD(true, false); }
     prof_end(h);
     const int t_next = (h->fold_reorder && next_f >= 0) ? h->tbl_of_frame[next_f] : t;
@@ -4354,17 +4884,17 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act, int next_f = -1, bool
     const bool gc_out = compact_out && h->compact_F && h->all_simple_liquid;
     const int giso = (h->fiso[f] ? 1 : 0) | (h->gcompact[(f + 1) & 1] ? 2 : 0) | (gc_out ? 4 : 0);
 #define LAUNCH_P2G_GRAD(G, W) hipLaunchKernelGGL((k_p2g_grad<G, W>), wgrid_pgg(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), \
-                           h->grad(f), T, h->pool_idx, h->gg_in, bcount(h, f), h->slow_dev, ag, inj, act, f, g_dst, to_slot, giso)
+                           h->grad(f), T, h->pool_idx, ggin(h, f), bcount(h, f), h->slow_dev, ag, inj, act, f, g_dst, to_slot, giso)
     if (!fuse_next) prof_begin(h, KID_P2G_GRAD);
     if (fuse_next) {                                      // (same order in frames f - 1 and f: no fold; the SVD-free build)
         h->stamp++;                                       // marks of substep f - 1's adjoint scatter (the launch's g2p_grad part -> its grid_op.grad)
-        const BwdFuseP B = {h->frame(f - 1), h->grad(f - 1), h->g_out, h->gg_out, h->slab};
+        const BwdFuseP B = {h->frame(f - 1), h->grad(f - 1), gout(h, f - 1), h->gg_out, h->slab};
         prof_begin(h, KID_PGG_G2PG);
         if (h->all_simple_liquid)
-            hipLaunchKernelGGL(k_pgg_g2pg<4>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->pool_idx, h->gg_in, bcount(h, f), h->slow_dev,
+            hipLaunchKernelGGL(k_pgg_g2pg<4>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->pool_idx, ggin(h, f), bcount(h, f), h->slow_dev,
                                ag, inj, act, f, giso, B, grid_store(h));
         else                                              // (the SVD build: three workgroups per CU, as k_p2g_grad<true>)
-            hipLaunchKernelGGL((k_pgg_g2pg<3, true>), wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->pool_idx, h->gg_in, bcount(h, f), h->slow_dev,
+            hipLaunchKernelGGL((k_pgg_g2pg<3, true>), wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->pool_idx, ggin(h, f), bcount(h, f), h->slow_dev,
                                ag, inj, act, f, 0, B, grid_store(h));
     } else if (h->all_simple_liquid) {
         if (h->p2g_grad_waves >= 4) LAUNCH_P2G_GRAD(false, 4);
@@ -4433,10 +4963,10 @@ int substep_fwd_batch(FeEngine** hs, int B, int f, int f_global, int act, bool g
         const AgentP ag = agent_params(h);
         const int fiso = fwd_iso(h, f);
         bp.a[i] = P2GArgs{h->S, h->frame(f), h->frame(f + 1), T, h->pool_idx, grid_w(h, f), ag, inj, act, f, grid_store(h), h->all_simple_liquid ? fiso : 0,
-                           g2p_pending ? FuseP{h->frame(f - 1), h->g_out, h->slow_dev, bcount(h, f - 1)} : FuseP{nullptr, nullptr, nullptr, nullptr}};
+                           g2p_pending ? FuseP{h->frame(f - 1), gout(h, f - 1), h->slow_dev, bcount(h, f - 1)} : FuseP{nullptr, nullptr, nullptr, nullptr}};
         h->fiso[f + 1] = h->all_simple_liquid && (fiso & 2) != 0;
-        bg.a[i] = GridArgs{h->S, T, h->slab, h->g_in, h->g_out, h->blk_list, bcount(h, f), h->blk_flag, grid_store(h), f, h->frame_slow_dev, statics_p(h), ag};
-        bq.a[i] = G2PArgs{h->S, h->frame(f), h->frame(f + 1), T, h->g_out, bcount(h, f), h->slow_dev, ag, f};
+        bg.a[i] = GridArgs{h->S, T, h->slab, h->g_in, gout(h, f), h->blk_list, bcount(h, f), h->blk_flag, grid_store(h), f, h->frame_slow_dev, statics_p(h), ag};
+        bq.a[i] = G2PArgs{h->S, h->frame(f), h->frame(f + 1), T, gout(h, f), bcount(h, f), h->slow_dev, ag, f};
     }
     }
     if (g2p_pending) {
@@ -4484,16 +5014,16 @@ int substep_bwd_batch(FeEngine** hs, int B, int f, int f_global, int act, bool g
         all_stored = all_stored && h->gs_cap > 0 && h->gs_host[f] != 0;
         if (!g2p_done) h->stamp++;                        // recompute marks, then the adjoint scatter's (as in substep_bwd; g2p_done: the scatter's marks carry the stamp of the launch it ran in)
         bp.a[i] = P2GArgs{h->S, h->frame(f), h->frame(f + 1), T, h->pool_idx, grid_w(h, f), ag, noinj, 0, f, grid_store(h), (h->all_simple_liquid && h->fiso[f]) ? 1 : 0, FuseP{nullptr, nullptr, nullptr, nullptr}};
-        bg.a[i] = GridArgs{h->S, T, h->slab, h->g_in, h->g_out, h->blk_list, bcount(h, f), h->blk_flag, grid_store(h), f, h->frame_slow_dev, statics_p(h), ag};
+        bg.a[i] = GridArgs{h->S, T, h->slab, h->g_in, gout(h, f), h->blk_list, bcount(h, f), h->blk_flag, grid_store(h), f, h->frame_slow_dev, statics_p(h), ag};
         if (!g2p_done) h->stamp++;
-        bq.a[i] = G2PGradArgs{h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->g_out, h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag};
-        bgg.a[i] = GridGradArgs{h->S, T, h->slab, h->g_in, h->gg_out, h->gg_in, h->blk_list, bcount(h, f), h->blk_flag, grid_store(h), f, statics_p(h), ag, h->node_work, h->node_work_count};
-        bpg.a[i] = P2GGradArgs{h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->pool_idx, h->gg_in, bcount(h, f), h->slow_dev, ag, inj, act, f, h->grad(f), nullptr,
+        bq.a[i] = G2PGradArgs{h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, gout(h, f), h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag};
+        bgg.a[i] = GridGradArgs{h->S, T, h->slab, h->g_in, h->gg_out, ggin(h, f), h->blk_list, bcount(h, f), h->blk_flag, grid_store(h), f, statics_p(h), ag, h->node_work, h->node_work_count};
+        bpg.a[i] = P2GGradArgs{h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->pool_idx, ggin(h, f), bcount(h, f), h->slow_dev, ag, inj, act, f, h->grad(f), nullptr,
                                (h->fiso[f] ? 1 : 0) | (h->gcompact[(f + 1) & 1] ? 2 : 0)};      // (the batch writes full adjoints)
         if (fuse_next) {
             h->stamp++;                                   // marks of substep f - 1's adjoint scatter (the fused launch's g2p_grad part -> its grid_op.grad)
-            bf.a[i] = PggArgs{h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->pool_idx, h->gg_in, bcount(h, f), h->slow_dev, ag, inj, act, f,
-                              (h->fiso[f] ? 1 : 0) | (h->gcompact[(f + 1) & 1] ? 2 : 0), BwdFuseP{h->frame(f - 1), h->grad(f - 1), h->g_out, h->gg_out, h->slab}, grid_store(h)};
+            bf.a[i] = PggArgs{h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, h->pool_idx, ggin(h, f), bcount(h, f), h->slow_dev, ag, inj, act, f,
+                              (h->fiso[f] ? 1 : 0) | (h->gcompact[(f + 1) & 1] ? 2 : 0), BwdFuseP{h->frame(f - 1), h->grad(f - 1), gout(h, f - 1), h->gg_out, h->slab}, grid_store(h)};
         }
         h->gtbl[f & 1] = t;
         h->gcompact[f & 1] = false;
@@ -4608,6 +5138,15 @@ int check_device_errors(FeEngine* h) {
         (void)hipMemsetAsync(h->err_dev, 0, sizeof(int), h->stream);
         FAIL(h, "particle stencil left the grid (p2g)");
     }
+    if (h->fg_started) {                                      // a wave of the fused grid pass gave up on a wait (fg_give_up): results of that launch are incomplete
+        int ge = 0;
+        HIPCK(h, hipMemcpyAsync(&ge, h->fg_host.ctr + FGC_ERR * FG_LINE, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCK(h, hipStreamSynchronize(h->stream));
+        if (ge) {
+            (void)hipMemsetAsync(h->fg_host.ctr + FGC_ERR * FG_LINE, 0, sizeof(int), h->stream);
+            FAIL(h, "fused grid pass: a wait did not end (option fuse_grid = 0 runs the grid kernels as launches of their own)");
+        }
+    }
     return 0;
 }
 
@@ -4640,6 +5179,7 @@ FeEngine* fe_create(const FeConfig* cfg) {
     if (const char* e = std::getenv("FE_G2P_GRAD_V")) h->g2p_grad_v = std::atoi(e);           // (the parity suite is run once per build of the G2P adjoint)
     if (const char* e = std::getenv("FE_FUSE_BWD")) h->fuse_bwd = std::atoi(e);
     if (const char* e = std::getenv("FE_FUSE_G2P")) h->fuse_g2p = std::atoi(e) != 0;           // (the parity suite with and without the fused forward launch)
+    if (const char* e = std::getenv("FE_FUSE_GRID")) h->fuse_grid = std::atoi(e);              // (... with and without the fused grid pass; 2 = wherever possible, late deposits included)
     const char* env_lsplit = std::getenv("FE_LANE_SPLIT");                                    // (the parity suite with and without lane_split)
     h->cfg = *cfg; h->N = cfg->n_particles; h->L = cfg->max_substeps_local; h->n = cfg->n_grid; h->nb = cfg->n_grid / 4;
     h->Np = ((h->N + 63) / 64) * 64; if (h->Np == 0) h->Np = 64;
@@ -4658,7 +5198,7 @@ FeEngine* fe_create(const FeConfig* cfg) {
     h->own_stream = h->stream;
     SimP& S = h->S;
     S.xcd = 16;                                            // blocked-cyclic unit mapping (A/B in DESIGN.md section 6)
-    S.uni = 0;
+    S.uni = 0; S.fg_base = 0; S.fg_nowait = 0;
     S.wsort = 1;                                           // lanes regrouped by stencil base before the scan (A/B in DESIGN.md section 6)
     S.lsplit = env_lsplit ? std::atoi(env_lsplit) : 3;            // small waves give every particle three or nine lanes (lane_split) in the two scatter kernels; in k_p2g_grad (bit 2)
                                                                   // the fifteen sums' cross-lane reads cost what the shorter loop saves (profiles/r05_ab_lane_split.txt)
@@ -4706,8 +5246,15 @@ FeEngine* fe_create(const FeConfig* cfg) {
     }
     if (dev_alloc(h, &h->pinfo, h->Np) || dev_alloc(h, &h->pool_idx, h->Np)) return fail("");
     if (ensure_table(h, 0)) return fail("");                 // identity order: no items, everything is "tail"; its `info` is pinfo itself
-    if (dev_alloc(h, &h->g_in, 4 * ncell) || dev_alloc(h, &h->g_out, ncell) || dev_alloc(h, &h->gg_out, 3 * ncell) || dev_alloc(h, &h->gg_in, ncell)) return fail("");
+    // (v_out and the adjoint grid twice, by the parity of the substep: a launch with the grid pass on board reads the substep before's while its owners write its own)
+    if (dev_alloc(h, &h->g_in, 4 * ncell) || dev_alloc(h, &h->g_out, 2 * ncell) || dev_alloc(h, &h->gg_out, 3 * ncell) || dev_alloc(h, &h->gg_in, 2 * ncell)) return fail("");
     if (dev_alloc(h, &h->blk_flag, ncell / 64) || dev_alloc(h, &h->blk_list, ncell / 64) || dev_alloc(h, &h->blk_count, 2) || dev_alloc(h, &h->err_dev, 1)) return fail("");
+    {   // the fused grid pass (FG kernels)
+        const size_t nblk = ncell / 64;
+        if (dev_alloc(h, &h->fg_host.late, 4 * ncell) || dev_alloc(h, &h->fg_host.late_flag, nblk) || dev_alloc(h, &h->fg_host.late_list, nblk) ||
+            dev_alloc(h, &h->fg_host.skipm, nblk) || dev_alloc(h, &h->fg_host.ctr, FGC_N * FG_LINE) || dev_alloc(h, &h->fg_dev, 1)) return fail("");
+        if (hipMemcpyOnStream(h, h->fg_dev, &h->fg_host, sizeof(FgDev), hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy failed");
+    }
     if (dev_alloc(h, &h->stage_r, (size_t)24 * h->Np) || dev_alloc(h, &h->stage_i, h->Np)) return fail("");
     if (dev_alloc(h, &h->node_mark, ncell) || dev_alloc(h, &h->counters, 4)) return fail("");
     {   // identity particle order
@@ -4728,9 +5275,10 @@ void fe_destroy(FeEngine* h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     smoke_destroy(h);
     for (auto& t : h->tables) { if (t.info && t.info != h->pinfo) (void)hipFree(t.info);
-        for (void* q : {(void*)t.pairs, (void*)t.singles, (void*)t.pid, (void*)t.items, (void*)t.meta, (void*)t.blk_first, (void*)t.active, (void*)t.blk_slot, (void*)t.slot_of_pid, (void*)t.units, (void*)t.units_p, (void*)t.nbr}) if (q) (void)hipFree(q); }
+        for (void* q : {(void*)t.pairs, (void*)t.singles, (void*)t.pid, (void*)t.items, (void*)t.meta, (void*)t.blk_first, (void*)t.active, (void*)t.blk_slot, (void*)t.slot_of_pid, (void*)t.units, (void*)t.units_p, (void*)t.nbr, (void*)t.arrive}) if (q) (void)hipFree(q); }
     void* ptrs[] = {h->frames, h->grads, h->sort_key, h->sort_rank, h->sort_cnt, h->sort_start, h->sort_bcnt, h->sort_partial, h->sort_base, h->sort_nact, h->sort_pid, h->slow_dev, h->frame_slow_dev, h->gstore, h->gs_flag, h->gs_live, h->ent_touched, h->ent_dirty, h->cur_live, h->slab, h->effs_dev, h->pinfo, h->pool_idx, h->g_in, h->g_out, h->gg_out, h->gg_in,
                     h->blk_flag, h->blk_list, h->blk_count, h->err_dev, h->stage_r, h->stage_i, h->node_mark, h->counters,
+                    h->fg_host.late, h->fg_host.late_flag, h->fg_host.late_list, h->fg_host.skipm, h->fg_host.ctr, h->fg_dev,
                     h->tgt, h->chamfer, h->step_loss, h->body_start, h->body_pids, h->bodies_dev, h->statics_dev, h->collector_dev, h->hit_dev, h->hit_list, h->hit_count, h->node_work, h->node_work_count};
     for (float* v : h->statics_vox) if (v) (void)hipFree(v);
     for (float* v : h->mesh_vox) if (v) (void)hipFree(v);
@@ -4794,6 +5342,7 @@ int fe_set_option(FeEngine* h, const char* name, double value) {
     if (!std::strcmp(name, "compact_F")) { h->compact_F = value != 0; return 0; }
     if (!std::strcmp(name, "fuse_g2p")) { h->fuse_g2p = value != 0; return 0; }
     if (!std::strcmp(name, "fuse_bwd")) { h->fuse_bwd = (int)value; return 0; }
+    if (!std::strcmp(name, "fuse_grid")) { if (value < 0 || value > 6 || ((int)value & 3) == 3) FAIL(h, "fuse_grid must be 0 (separate grid kernels), 1 (fused where nothing slow is expected) or 2 (wherever possible), + 4: never wait"); h->fuse_grid = (int)value; return 0; }
     if (!std::strcmp(name, "quad_min_units")) { h->quad_min_units = (int)value; return 0; }
     if (!std::strcmp(name, "pgg_quad_min_units")) { h->pgg_quad_min_units = (int)value; return 0; }
     if (!std::strcmp(name, "pack_units")) { if (value < 0 || value > 2) FAIL(h, "pack_units must be 0, 1 or 2"); h->pack_units = (int)value; return 0; }
@@ -4814,7 +5363,7 @@ int fe_get_option(FeEngine* h, const char* name, double* value) {
         {"sort_interval", (double)h->sort_interval}, {"item_max", (double)h->item_max}, {"grid_store", h->gs_cap > 0 ? 1.0 : 0.0},
         {"p2g_grad_waves", (double)h->p2g_grad_waves}, {"g2p_grad_v", (double)h->g2p_grad_v}, {"loose_max", (double)h->loose_max},
         {"inject_till", (double)h->inject_till}, {"collide_min_y", (double)h->collide_min_y}, {"collide_type", (double)h->collide_type},
-        {"prof_fine", h->prof_fine ? 1.0 : 0.0}, {"xcd_map", (double)h->S.xcd}, {"write_through", (double)h->S.wt}, {"wave_sort", (double)h->S.wsort}, {"lane_split", (double)h->S.lsplit}, {"fold_reorder", h->fold_reorder ? 1.0 : 0.0}, {"compact_F", h->compact_F ? 1.0 : 0.0}, {"fuse_g2p", h->fuse_g2p ? 1.0 : 0.0}, {"fuse_bwd", (double)h->fuse_bwd},
+        {"prof_fine", h->prof_fine ? 1.0 : 0.0}, {"xcd_map", (double)h->S.xcd}, {"write_through", (double)h->S.wt}, {"wave_sort", (double)h->S.wsort}, {"lane_split", (double)h->S.lsplit}, {"fold_reorder", h->fold_reorder ? 1.0 : 0.0}, {"compact_F", h->compact_F ? 1.0 : 0.0}, {"fuse_g2p", h->fuse_g2p ? 1.0 : 0.0}, {"fuse_bwd", (double)h->fuse_bwd}, {"fuse_grid", (double)h->fuse_grid},
         {"quad_min_units", (double)h->quad_min_units}, {"pgg_quad_min_units", (double)h->pgg_quad_min_units}, {"quad_max", (double)h->quad}, {"quad_fit", (double)h->quad_fit}, {"pack_units", (double)h->pack_units},
         {"wgrid_cap", (double)h->wgrid_cap}, {"wgrid_cap_g2p", (double)h->wgrid_cap_g2p}, {"wgrid_cap_pgg", (double)h->wgrid_cap_pgg}, {"ggrid_cap", (double)h->ggrid_cap}, {"threads", 0.0}};
     for (const auto& t : tab) if (!std::strcmp(name, t.n)) { *value = t.v; return 0; }
@@ -4879,6 +5428,7 @@ int fe_init_particles(FeEngine* h, const fe_real* x, const int* used, const int*
     HIPCK(h, hipMemcpyAsync(h->pinfo, info.data(), sizeof(float4) * h->Np, hipMemcpyHostToDevice, h->stream));
     HIPCK(h, hipStreamSynchronize(h->stream));
     h->tbl_of_frame[0] = 0;
+    h->tail_used = true;
     std::fill(h->fiso.begin(), h->fiso.end(), 0);
     h->gcompact[0] = h->gcompact[1] = false;
     return upload_planes(h, h->frame(0), h->pid_of(0), x, v0.data(), C0.data(), F0.data(), used, 0);
@@ -4974,6 +5524,7 @@ int fe_get_frame(FeEngine* h, int f, fe_real* x, fe_real* v, fe_real* C, fe_real
 int fe_set_frame(FeEngine* h, int f, const fe_real* x, const fe_real* v, const fe_real* C, const fe_real* F, const int* used) {
     FE_ENTRY(h);
     CHECK_FRAME(h, f);
+    h->tail_used = true;                                      // (the host may have put particles in use behind the order's work items: fuse_grid_ok)
     h->gs_host_valid = false;
     if (h->gs_cap > 0) HIPCK(h, hipMemsetAsync(h->gs_flag + f, 0, sizeof(int), h->stream));     // the stored grid of this frame is stale now
     if (F) h->fiso[f] = 0;                                    // (k_pack overwrites all nine words of F)
@@ -4993,6 +5544,7 @@ int fe_get_frame_dev(FeEngine* h, int f, fe_real* x, fe_real* v, fe_real* C, fe_
 int fe_set_frame_dev(FeEngine* h, int f, const fe_real* x, const fe_real* v, const fe_real* C, const fe_real* F, const int* used) {
     FE_ENTRY(h);
     CHECK_FRAME(h, f);
+    h->tail_used = true;                                      // (the host may have put particles in use behind the order's work items: fuse_grid_ok)
     h->gs_host_valid = false;
     if (h->gs_cap > 0) HIPCK(h, hipMemsetAsync(h->gs_flag + f, 0, sizeof(int), h->stream));
     const int mask = (x ? 1 : 0) | (v ? 2 : 0) | (C ? 4 : 0) | (F ? 8 : 0) | (used ? 16 : 0);
@@ -5009,6 +5561,7 @@ int fe_copy_frame(FeEngine* h, int src, int dst) {
     HIPCK(h, hipMemcpyAsync(h->frame(dst), h->frame(src), sizeof(float) * h->frame_stride, hipMemcpyDeviceToDevice, h->stream));
     h->tbl_of_frame[dst] = h->tbl_of_frame[src];
     h->fiso[dst] = h->fiso[src];
+    h->tail_used = true;
     h->gs_host_valid = false;
     if (h->gs_cap > 0) HIPCK(h, hipMemsetAsync(h->gs_flag + dst, 0, sizeof(int), h->stream));
     return 0;

@@ -24,7 +24,10 @@ PHASES = {
     'g2p_grad': ['start', 'item', 'tile+barrier', 'phase A', 'zero+barriers', 'columns', 'barrier', 'slab stored'],
     'p2g_grad': ['start', 'item', 'tile+barrier', 'particles', 'barrier'],
 }
-KNAMES = ['p2g', 'grid_op', 'g2p', 'p2g_recompute', 'grid_op_keep', 'g2p_grad', 'grid_op_grad', 'p2g_grad']
+KNAMES = ['p2g', 'grid_op', 'g2p', 'p2g_recompute', 'grid_op_keep', 'g2p_grad', 'grid_op_grad', 'p2g_grad', 'sort', 'reorder_grad', 'sort_count', 'sort_scan', 'sort_active', 'sort_perm', 'g2p_p2g', 'pgg_g2pg']
+# (FG kernels, option fuse_grid: stamp 3 = the workgroup's unit loop is over, 5 = wave 0 found an entry of its own complete (the last time), 4 = its entries worked on, 7 = their stores completed)
+PHASES['g2p_p2g'] = ['start', 'item', 'loaded+constitutive', 'FG owner phase begins', 'FG entries done', 'FG entry found complete', 'slab stored', 'FG stores completed']
+PHASES['pgg_g2pg'] = ['start', '1', '2', 'FG owner phase begins', 'FG entries done', 'FG entry found complete', '6', 'FG stores completed']
 
 
 def main():
@@ -34,6 +37,9 @@ def main():
     sc = water_block(n_grid=n_grid, n_particles=n_part, seed=0)
     L = 24
     eng = make_engine(elib, sc, max_substeps_local=L, device=0)
+    for o in os.environ.get('TL_OPTS', '').split(','):
+        if o:
+            eng.set_option(o.split('=')[0], float(o.split('=')[1]))
     eng.loss_alloc(1)
     eng.loss_set_target(0, sc['x'])
     for _ in range(int(sys.argv[3]) if len(sys.argv) > 3 else 0):         # let the block fall / splash first

@@ -955,3 +955,97 @@ def test_fused_p2g_grad_g2p_grad_with_an_injector(hiplib, oracle64):
     o = S.run_latte(oracle64, sc)
     assert S.rel_l2(a['action_grad'], b['action_grad']) <= 2e-5 and S.rel_l2(a['step_loss'], b['step_loss']) <= 1e-6
     assert S.cosine(a['action_grad'], o['action_grad']) >= 0.999999 and S.rel_l2(a['action_grad'], o['action_grad']) <= 1e-4
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# option fuse_grid (round 6): grid_op inside the forward scatter launches (the fused grid pass, FG kernels) -- off by default (measured
+# slower than the launch it replaces: DESIGN.md section 10), kept as an option and held to the same parity as the separate k_grid
+# ---------------------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('fuse_grid', [2, 6])            # 2 = wherever possible (late deposits included), 6 = ... and no wave ever waits: every entry takes the skipped road
+@pytest.mark.parametrize('scene,opts', [('block', {}), ('droplets-water', {'quad_min_units': 0}), ('droplets-mixed', {'quad_min_units': 1 << 30, 'lane_split': 0}), ('fast', {})])
+def test_fused_grid_pass_matches_separate_grid_kernel(hiplib, oracle64, scene, opts, fuse_grid):
+    """The forward trajectory with grid_op riding on k_p2g / k_g2p_p2g (tile arrivals, owners, the final wave) against the same engine with k_grid as a launch of
+    its own and against the fp64 oracle; then the reverse sweep over the frames the pass stored (its records are what the adjoint kernels read).
+    'fast': a coherent drift of 1.5 cells and more between two sorts -- slow-path deposits outside the 27 neighbours of the particle's own block are LATE
+    (ordered by no arrival): their planes, the late list, the final wave's fix-up of what the owners stored."""
+    if scene == 'block':
+        rng = np.random.RandomState(5)
+        N = 6000
+        sc = S.water_block(n_grid=32, n_particles=N, seed=3, lo=0.3, hi=0.6)
+        sc['v'] = S.f32(rng.normal(0, 1.0, (N, 3)) + [2.0, -3.0, 1.0])
+        sc['used'] = (rng.rand(N) > 0.1).astype(np.int32)
+        K, n_sub = 4, 13
+    elif scene == 'fast':
+        N = 4000
+        sc = S.water_block(n_grid=32, n_particles=N, lo=0.3, hi=0.5, gravity=(0.0, 0.0, 0.0))
+        sc['v'] = S.f32(np.tile([30.0, -22.0, 10.0], (N, 1)))          # 30 m/s * 16 substeps * 2e-4 s * 32 = 3 cells between two sorts
+        K, n_sub = 16, 16
+    else:
+        sc = _droplet_scene(scene.split('-')[1])
+        N = len(sc['used'])
+        K, n_sub = 10, 13
+    cot = S.random_cotangent(N, seed=7)
+
+    def run(lib, o):
+        g = S.make_engine(lib, sc, options=o)
+        if lib is hiplib:
+            g.profile_enable(True)
+            g.step(0, 0, 6, 0)
+            g.step(6, 6, n_sub - 6, 0)
+        else:
+            for f in range(n_sub):
+                g.substep(f, f, 0)
+        frames = [S.get_state(g, f) for f in range(1, n_sub + 1)]
+        g.reset_grad()
+        g.add_grad(n_sub, cot['gx'], cot['gv'], cot['gC'], cot['gF'])
+        g.step_grad(0, 0, n_sub, 0)
+        gx, gv, gC, gF = g.get_grad(0)
+        prof = g.profile_read() if lib is hiplib else None
+        g.sync()                                                    # (a wait of the pass that did not end is reported here)
+        g.close()
+        return frames, dict(gx=gx, gv=gv, gC=gC, gF=gF), prof
+
+    base = dict({'sort_interval': K}, **opts)
+    fa, ga, pa = run(hiplib, dict(base, fuse_grid=fuse_grid))
+    fb, gb, pb = run(hiplib, dict(base, fuse_grid=0))
+    fc, gc, _ = run(hiplib, dict(base, fuse_grid=0))                # the same engine once more: its own run-to-run noise
+    fo, go, _ = run(oracle64, {})
+    assert pa['grid_op'][1] == 0 and pb['grid_op'][1] == n_sub, (pa, pb)      # every forward substep of the window took the fused form
+    if scene != 'fast':                                             # (there the front of the block runs into blocks off the order's active list: those frames are recomputed)
+        assert pa['grid_op_keep'][1] == 0, pa                       # ... and left a complete record in the grid store: nothing recomputed on the way back
+    general = scene.endswith('mixed')
+    worst = {k: 0.0 for k in 'xvCF'}
+    for f, (a, b, c) in enumerate(zip(fa, fb, fc), start=1):
+        assert (a['used'] == b['used']).all(), f
+        u = b['used'] > 0
+        for k in 'xvCF':
+            scale = max(1.0, float(np.abs(b[k][u]).max()))
+            d, nz = float(np.abs(a[k][u] - b[k][u]).max()) / scale, float(np.abs(c[k][u] - b[k][u]).max()) / scale
+            worst[k] = max(worst[k], d)
+            assert d <= 4.0 * nz + {'x': 5e-7, 'v': 4e-6, 'C': 8e-5, 'F': 4e-6}[k], (f, k, d, nz)
+    print(f'MEASURED fuse_grid={fuse_grid}[{scene}]: fused vs separate grid kernel, largest relative state difference', {k: float(f'{v:.2g}') for k, v in worst.items()},
+          '| adjoints', {k: round(S.rel_l2(ga[k], gb[k]), 8) for k in ga}, '| vs fp64 oracle x', np.abs(fa[-1]['x'] - fo[-1]['x']).max(), {k: round(S.rel_l2(ga[k], go[k]), 8) for k in ga})
+    for k in ('gx', 'gv', 'gC', 'gF'):
+        assert np.isfinite(ga[k]).all()
+        if general:
+            assert _pct_off(ga[k], gb[k], 50) <= 4.0 * _pct_off(gc[k], gb[k], 50) + 1e-5 and _pct_off(ga[k], gb[k], 95) <= 4.0 * _pct_off(gc[k], gb[k], 95) + 1e-3, k
+        else:
+            assert S.rel_l2(ga[k], gb[k]) <= 4.0 * S.rel_l2(gc[k], gb[k]) + 2e-5, (k, S.rel_l2(ga[k], gb[k]), S.rel_l2(gc[k], gb[k]))
+        assert S.cosine(ga[k], go[k]) >= 0.999 and S.rel_l2(ga[k], go[k]) <= (2e-2 if general else 1e-2), (k, S.rel_l2(ga[k], go[k]))
+    assert (fa[-1]['used'] == fo[-1]['used']).all()
+    assert np.abs(fa[-1]['x'] - fo[-1]['x']).max() <= 5e-6 and S.rel_l2(fa[-1]['v'], fo[-1]['v']) <= 1e-3
+
+
+@pytest.mark.parametrize('fuse_grid', [1, 2])
+def test_fused_grid_pass_with_an_injector(hiplib, oracle64, fuse_grid):
+    """The injector's particles sit behind the order's work items until the next sort: with fuse_grid = 1 the substeps behind an injection keep the separate
+    k_grid (fuse_grid_ok), with 2 their deposits are late ones.  Either way the LatteArt-like pass and its action gradient are those of the unfused engine."""
+    sc = S.latte_mini()
+    a = S.run_latte(hiplib, sc, options={'fuse_grid': fuse_grid, 'sort_interval': 3})
+    b = S.run_latte(hiplib, sc, options={'fuse_grid': 0, 'sort_interval': 3})
+    o = S.run_latte(oracle64, sc)
+    assert (a['final']['used'] == b['final']['used']).all() and (a['final']['used'] == o['final']['used']).all()
+    for k in 'xvCF':
+        assert np.abs(a['final'][k] - b['final'][k]).max() <= 1e-5 * max(1.0, np.abs(b['final'][k]).max()), k
+    assert S.rel_l2(a['action_grad'], b['action_grad']) <= 2e-5 and S.rel_l2(a['step_loss'], b['step_loss']) <= 1e-6
+    assert S.cosine(a['action_grad'], o['action_grad']) >= 0.999999 and S.rel_l2(a['action_grad'], o['action_grad']) <= 1e-4
