@@ -4402,6 +4402,9 @@ struct FeEngine {
     int gtbl[2] = {-1, -1};                                 // order of each adjoint ring slot; -1 = all zero
     std::vector<char> fiso;                                 // [L+1] frame f's F is stored compactly (FrameV::iso = 1): written by the SVD-free k_p2g
     bool gcompact[2] = {false, false};                      // ... and the adjoint of F in a ring slot (iso = 2): written by k_p2g_grad inside a ranged call
+    bool gpartial[2] = {false, false};                      // the slot's x, v, C planes were passed on in registers by a fused launch (k_pgg_g2pg) and never stored: only F's adjoint is in memory.
+                                                            // After fe_step_grad(f0, n > 1) that is the state of frame f0 + 1's slot; the API refuses to hand it out
+    int n_cus = 256;                                        // compute units of the device (fe_create)
     bool compact_F = true;                                  // option "compact_F"
     int fuse_bwd = 1;                                       // option "fuse_bwd": inside a fe_step_grad call a substep's p2g_grad takes the next substep's g2p_grad along (k_pgg_g2pg)
     bool fuse_g2p = true;                                   // option "fuse_g2p": inside a fe_step call the g2p of a substep runs at the head of the next substep's p2g launch (k_g2p_p2g)
@@ -4815,7 +4818,7 @@ int fetch_gs_flags(FeEngine* h) {
 inline bool fusable_bwd(FeEngine* h, int f) {
     // (the SVD build's fused kernel keeps three workgroups per CU where k_g2p_grad2 keeps four: it pays while a launch is a round or two of workgroups -- +0.6 % at 200k particles --
     //  and costs where the kernels are bound by what they issue: 155.8 us against 61.3 + 77.6 at 1M.  fuse_bwd = 1 fuses it up to two rounds' worth of particles, 2 always)
-    if (!h->all_simple_liquid && h->fuse_bwd < 2 && h->Np / 256 > 2 * 3 * (size_t)(h->quad_fit / 4)) return false;      // (quad_fit = 4 x the device's CUs)
+    if (!h->all_simple_liquid && h->fuse_bwd < 2 && h->Np / 256 > 2 * 3 * (size_t)h->n_cus) return false;      // (two rounds of three workgroups per CU; the tuning option quad_fit has no say in this: ADVICE r5)
     return h->fuse_bwd && f > 0 && h->g2p_grad_v == 3 && (h->p2g_grad_waves >= 4 || !h->all_simple_liquid) && !particle_collide(h) && !h->has_rigid && !h->has_collector &&
            h->tbl_of_frame[f - 1] == h->tbl_of_frame[f] && h->tbl_of_frame[f] >= 0 && h->gs_cap > 0 && h->gs_host_valid && h->gs_host[f - 1] != 0;
 }
@@ -4826,6 +4829,7 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act, int next_f = -1, bool
     if (make_inject(h, f, f_global, act, false, inj)) return 1;
     // grad[f+1] arrives in the order frame f+1 is stored in; substep f works in frame f's order
     const int t = h->tbl_of_frame[f];
+    if (!g2p_done && h->gpartial[(f + 1) & 1]) FAIL(h, "the adjoint of frame f + 1 is incomplete: a fused fe_step_grad passed it on in registers (only the adjoint of a call's first frame is defined afterwards; option fuse_bwd = 0 keeps every frame's)");
     if (reorder_grad(h, (f + 1) & 1, t)) return 1;
     use_static_table(h, t);
     const TableP T = h->tableP(t);
@@ -4881,7 +4885,8 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act, int next_f = -1, bool
     const bool fold = t_next != t && t_next >= 0;
     float* g_dst = fold ? h->grad_ptr[2] : h->grad(f);
     const int* to_slot = fold ? h->tables[t_next].slot_of_pid : nullptr;
-    const bool gc_out = compact_out && h->compact_F && h->all_simple_liquid;
+    // (not with a collector: collector_takes clears `used` of a frame after the fact, and the slot of a particle not in use holds all nine words of F's adjoint -- ADVICE r5)
+    const bool gc_out = compact_out && h->compact_F && h->all_simple_liquid && !h->has_collector;
     const int giso = (h->fiso[f] ? 1 : 0) | (h->gcompact[(f + 1) & 1] ? 2 : 0) | (gc_out ? 4 : 0);
 #define LAUNCH_P2G_GRAD(G, W) hipLaunchKernelGGL((k_p2g_grad<G, W>), wgrid_pgg(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), \
                            h->grad(f), T, h->pool_idx, ggin(h, f), bcount(h, f), h->slow_dev, ag, inj, act, f, g_dst, to_slot, giso)
@@ -4905,6 +4910,7 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act, int next_f = -1, bool
     if (fold) std::swap(h->grad_ptr[2], h->grad_ptr[f & 1]);
     h->gtbl[f & 1] = fold ? t_next : t;
     h->gcompact[f & 1] = gc_out;
+    h->gpartial[f & 1] = fuse_next;                       // (k_pgg_g2pg stores x v C of frame f's adjoint only for the particles somebody else reads them of)
     return 0;
 }
 
@@ -5027,6 +5033,7 @@ int substep_bwd_batch(FeEngine** hs, int B, int f, int f_global, int act, bool g
         }
         h->gtbl[f & 1] = t;
         h->gcompact[f & 1] = false;
+        h->gpartial[f & 1] = fuse_next;
     }
     }
     if (!g2p_done) {
@@ -5193,7 +5200,7 @@ FeEngine* fe_create(const FeConfig* cfg) {
         // larger launch: its extra workgroups fill whatever slot frees first, which is worth 3.7 % on LatteArt at 128^3 (1,995 units of
         // full 128-particle items: 8,216 -> 8,520 pairs/s) and costs the water block 0.2 ... 0.4 % (`r04_ab_wgrid_caps_latteart.txt`).
         int cus = 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) { h->quad_fit = 4 * cus; h->wgrid_cap = 4 * cus; h->wgrid_cap_pgg = 8 * cus; h->wgrid_cap_g2p = 6 * cus; }
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cus > 0) { h->n_cus = cus; h->quad_fit = 4 * cus; h->wgrid_cap = 4 * cus; h->wgrid_cap_pgg = 8 * cus; h->wgrid_cap_g2p = 6 * cus; }
     }
     h->own_stream = h->stream;
     SimP& S = h->S;
@@ -5431,6 +5438,7 @@ int fe_init_particles(FeEngine* h, const fe_real* x, const int* used, const int*
     h->tail_used = true;
     std::fill(h->fiso.begin(), h->fiso.end(), 0);
     h->gcompact[0] = h->gcompact[1] = false;
+    h->gpartial[0] = h->gpartial[1] = false;
     return upload_planes(h, h->frame(0), h->pid_of(0), x, v0.data(), C0.data(), F0.data(), used, 0);
 }
 
@@ -5570,10 +5578,12 @@ int fe_copy_grad(FeEngine* h, int src, int dst) {
     FE_ENTRY(h);
     CHECK_FRAME(h, src); CHECK_FRAME(h, dst);
     // adjoint frames are a ring of two (slot = f & 1); the `used` copy of mpm:604 is a frame copy
+    if (h->gpartial[src & 1]) FAIL(h, "this frame's adjoint was passed on in registers inside a fused fe_step_grad call and is not in memory (after fe_step_grad(f0, n) only the adjoint of frame f0 is defined; option fuse_bwd = 0 keeps every frame's)");
     if ((src & 1) != (dst & 1)) {
         HIPCK(h, hipMemcpyAsync(h->grad(dst), h->grad(src), sizeof(float) * GR_WORDS * h->Np, hipMemcpyDeviceToDevice, h->stream));
         h->gtbl[dst & 1] = h->gtbl[src & 1];
         h->gcompact[dst & 1] = h->gcompact[src & 1];
+        h->gpartial[dst & 1] = false;
     }
     if (src != dst) {
         FrameV s = frame_view(h->frame(src), h->Np), d = frame_view(h->frame(dst), h->Np);
@@ -5588,6 +5598,7 @@ int fe_reset_grad(FeEngine* h) {
     HIPCK(h, hipMemsetAsync(h->grad_ptr[1], 0, sizeof(float) * h->grad_words(), h->stream));
     h->gtbl[0] = h->gtbl[1] = -1;
     h->gcompact[0] = h->gcompact[1] = false;
+    h->gpartial[0] = h->gpartial[1] = false;
     for (auto& E : h->effs) {
         const int Fm = h->L + 1, ad = E.p.action_dim > 0 ? E.p.action_dim : 1;
         HIPCK(h, hipMemsetAsync(E.p.gpos, 0, sizeof(float) * 3 * Fm, h->stream));
@@ -5635,6 +5646,7 @@ int fe_agent_reset_grad_till_frame(FeEngine* h, int f) {
 int fe_get_grad(FeEngine* h, int f, fe_real* gx, fe_real* gv, fe_real* gC, fe_real* gF) {
     FE_ENTRY(h);
     CHECK_FRAME(h, f);
+    if (h->gpartial[f & 1]) FAIL(h, "this frame's adjoint was passed on in registers inside a fused fe_step_grad call and is not in memory (after fe_step_grad(f0, n) only the adjoint of frame f0 is defined; option fuse_bwd = 0 keeps every frame's)");
     const int t = h->gtbl[f & 1] < 0 ? 0 : h->gtbl[f & 1];
     if (gF) full_F_of_grad(h, f);
     return download_planes(h, h->grad(f), h->tables[t].pid, gx, gv, gC, gF, nullptr);
@@ -5642,6 +5654,7 @@ int fe_get_grad(FeEngine* h, int f, fe_real* gx, fe_real* gv, fe_real* gC, fe_re
 int fe_add_grad(FeEngine* h, int f, const fe_real* gx, const fe_real* gv, const fe_real* gC, const fe_real* gF) {
     FE_ENTRY(h);
     CHECK_FRAME(h, f);
+    if (h->gpartial[f & 1]) FAIL(h, "this frame's adjoint was passed on in registers inside a fused fe_step_grad call and is not in memory (after fe_step_grad(f0, n) only the adjoint of frame f0 is defined; option fuse_bwd = 0 keeps every frame's)");
     full_F_of_grad(h, f);                                     // (k_pack reads and rewrites all the planes)
     return upload_planes(h, h->grad(f), h->tables[grad_table_for_frame(h, f)].pid, gx, gv, gC, gF, nullptr, 1);
 }
@@ -5649,6 +5662,7 @@ int fe_add_grad(FeEngine* h, int f, const fe_real* gx, const fe_real* gv, const 
 int fe_add_grad_dev(FeEngine* h, int f, const fe_real* gx, const fe_real* gv, const fe_real* gC, const fe_real* gF) {
     FE_ENTRY(h);
     CHECK_FRAME(h, f);
+    if (h->gpartial[f & 1]) FAIL(h, "this frame's adjoint was passed on in registers inside a fused fe_step_grad call and is not in memory (after fe_step_grad(f0, n) only the adjoint of frame f0 is defined; option fuse_bwd = 0 keeps every frame's)");
     const int gt = grad_table_for_frame(h, f);
     const int mask = (gx ? 1 : 0) | (gv ? 2 : 0) | (gC ? 4 : 0) | (gF ? 8 : 0);
     if (!mask || h->N == 0) return 0;
@@ -5921,6 +5935,7 @@ int fe_loss_step_grad(FeEngine* h, int s, int f, int matching_mat, fe_real weigh
     FE_ENTRY(h);
     if (s < 0 || s >= h->loss_steps) FAIL(h, "loss step out of range");
     CHECK_FRAME(h, f);
+    if (h->gpartial[f & 1]) FAIL(h, "this frame's adjoint was passed on in registers inside a fused fe_step_grad call and is not in memory (after fe_step_grad(f0, n) only the adjoint of frame f0 is defined; option fuse_bwd = 0 keeps every frame's)");
     const int gt = grad_table_for_frame(h, f), ft = h->tbl_of_frame[f];
     hipLaunchKernelGGL(k_loss_bwd, pgrid(h), dim3(256), 0, h->stream, h->S, h->frame(f), h->grad(f), h->tables[gt].pid, gt == ft ? (const int*)nullptr : h->tables[ft].slot_of_pid, h->pinfo,
                        h->tgt + (size_t)s * h->N * 3, matching_mat, weight * step_loss_grad);

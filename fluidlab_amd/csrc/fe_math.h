@@ -597,7 +597,9 @@ FE_HD real fe_cbrt_pos(real J) {
     const float c2 = c0 * c0;
     const float c1 = c0 - fmaf(c2, c0, -(float)J) / (3.f * c2);
 #endif
-    return (real)((float)J == 0.f ? 0.f : c1);
+    // (the Newton step needs a finite, non-zero first guess: a denormal J -- log2 flushes it: c0 = 0 -- and J = inf -- c0 = inf -- keep c0, as pow would
+    //  give ~0 and inf there; the states of a collapse or a blow-up, but no NaN of the engine's own making.  ADVICE r5)
+    return (real)((float)J == 0.f ? 0.f : ((c0 > 0.f && c0 < 3.0e38f) ? c1 : c0));
 }
 // J^(-2/3) = J^(1/3) / J
 FE_HD real fe_pow_m23(real J) {

@@ -117,7 +117,11 @@ int fe_init_particles(FeEngine* h, const fe_real* x, const int* used, const int*
 int fe_substep(FeEngine* h, int f, int f_global, int act);
 int fe_substep_grad(FeEngine* h, int f, int f_global, int act);
 /* n consecutive substeps in one crossing: the loops at mpm:749-751 / mpm:761-763.
- * fe_step walks f0, f0+1, ...; fe_step_grad walks f0+n-1 down to f0. */
+ * fe_step walks f0, f0+1, ...; fe_step_grad walks f0+n-1 down to f0.
+ * Particle adjoints live in a ring of two frames (slot f & 1), not in L+1 of them: after fe_step_grad(f0, n) the adjoint of frame f0 is
+ * defined and nothing else is -- the HIP engine hands the adjoints of the frames in between from one substep to the next in registers
+ * (option fuse_bwd), so the slot of frame f0 + 1 is left incomplete, and fe_get_grad / fe_add_grad / fe_copy_grad / fe_loss_step_grad on a
+ * frame whose slot is in that state FAIL rather than return it. */
 int fe_step(FeEngine* h, int f0, int f_global0, int n, int act);
 int fe_step_grad(FeEngine* h, int f0, int f_global0, int n, int act);
 /* Batched environments (BASELINE's "batched envs"; the reference steps one env per process, fluidlab/optimizer/solver.py:23-59):

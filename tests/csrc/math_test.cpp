@@ -125,6 +125,9 @@ int main() {
         }
         CHECK(worst <= 2.0 && worst2 <= (sizeof(real) == 4 ? 4.0 : 16.0), "fe_cbrt_pos %g ulp, fe_pow_m23 %g ulp", worst, worst2);      // (fp64: the exponent 1/3 - 1 itself is rounded)
         CHECK(fe_cbrt_pos((real)0) == 0 && std::isnan((double)fe_cbrt_pos((real)-0.5)), "fe_cbrt_pos at 0 / below");
+        // the ends of the range: a denormal determinant (the host's log2f does not flush it: the root; the device's does: 0 -- neither is inf or NaN) and an infinite one
+        CHECK(std::isfinite((double)fe_cbrt_pos((real)1e-42f)) && (double)fe_cbrt_pos((real)1e-42f) >= 0.0 && (double)fe_cbrt_pos((real)1e-42f) < 1e-10, "fe_cbrt_pos of a denormal: %g", (double)fe_cbrt_pos((real)1e-42f));
+        CHECK(std::isinf((double)fe_cbrt_pos((real)INFINITY)) && (double)fe_cbrt_pos((real)INFINITY) > 0, "fe_cbrt_pos of inf: %g", (double)fe_cbrt_pos((real)INFINITY));
     }
     printf("%s (%s): %d failures\n", fails ? "FAILED" : "OK", sizeof(real) == 8 ? "fp64" : "fp32", fails);
     return fails ? 1 : 0;

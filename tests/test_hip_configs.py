@@ -274,11 +274,35 @@ def test_config5_injected_stream_at_full_size(hiplib, oracle32):
     for i in range(T0):
         te.step(table.get_action_v(i))
     state = te.get_state()['state']
+    mesh = te.agent.rigid.mesh
+    vox, Tm = np.asarray(mesh.sdf_voxels_np, np.float64), np.asarray(mesh.T_mesh_to_voxels_np, np.float64)
     te.simulator.engine.close()
     used0 = state['used'] > 0
     assert used0.sum() == T0 * 40 * 10 and np.isfinite(state['x'][used0]).all()
     on_cone = int((state['x'][used0][:, 1] < 0.56).sum())
     cone = np.asarray(state['agent'][1][:3], np.float64)
+    # The stream has not reached the cone after 125 steps (round 5: the cone's action gradient was identically zero on both engines and the assertion on it
+    # vacuous).  The differentiated step therefore starts with the cone RAISED into the head of the stream -- the lowest height at which a few
+    # hundred particles are within the collider's reach (signed distance below ln(10) / softness: dynamic.py:74-76) and none is more than a voxel inside it.
+    xs = state['x'][used0].astype(np.float64)
+
+    def signed_distance(pos):                                 # t_sdf_sample at the voxel below the point (fe_math.h; the cone does not turn: action_dim 3)
+        pv = (xs - pos) @ Tm[:3, :3].T + Tm[:3, 3]
+        b = np.floor(pv).astype(np.int64)
+        ok = ((b >= 0) & (b < vox.shape[0] - 1)).all(axis=1)
+        sd = np.ones(len(xs))
+        sd[ok] = vox[b[ok, 0], b[ok, 1], b[ok, 2]]
+        return sd
+    reach = np.log(10.0) / float(mesh.softness)
+    lifted, n_touch = None, 0
+    for dy in np.arange(0.0, 0.5, 0.004):
+        sd = signed_distance(cone + [0.0, dy, 0.0])
+        touch = int(((sd < reach) & (xs[:, 1] > 0.25)).sum())
+        if touch >= 300 and (sd < -0.006).sum() == 0:
+            lifted, n_touch = cone + [0.0, dy, 0.0], touch
+            break
+    assert lifted is not None, 'no cone height puts it in touch with the stream'
+    cone = lifted
     acts = np.asarray(table.actions_v[T0:T0 + H], np.float64)
     n = len(state['x'])
     tgt = state['x'] + np.random.RandomState(3).normal(0, 0.01, (n, 3))
@@ -303,7 +327,7 @@ def test_config5_injected_stream_at_full_size(hiplib, oracle32):
     la, ga, xa, fa = run(hiplib)
     lb, gb, xb, fb = run(oracle32)
     used1 = fa['used'] > 0
-    print('MEASURED config5 injected stream at full size: in flight', int(used0.sum()), '->', int(used1.sum()), 'below y = 0.56 (at the cone)', on_cone,
+    print('MEASURED config5 injected stream at full size: in flight', int(used0.sum()), '->', int(used1.sum()), 'below y = 0.56', on_cone, 'within the raised cone\'s reach', n_touch, 'cone at', [round(float(c), 3) for c in cone],
           'loss', la, lb, 'action-grad cos', S.cosine(ga, gb), 'relL2', S.rel_l2(ga, gb), 'x_bar[0] cos', S.cosine(xa, xb), 'relL2', S.rel_l2(xa, xb),
           'x relL2', S.rel_l2(fa['x'][used1], fb['x'][used1]), 'max|dx|', float(np.abs(fa['x'][used1] - fb['x'][used1]).max()))
     assert used1.sum() - used0.sum() == 10 * 40 * H and np.array_equal(fa['used'], fb['used'])
@@ -311,5 +335,6 @@ def test_config5_injected_stream_at_full_size(hiplib, oracle32):
     assert np.isfinite(ga).all() and np.isfinite(xa).all() and ga.shape == (H + 1, 3)
     assert abs(la - lb) <= 1e-4 * abs(lb)
     assert np.abs(xb).max() > 0 and S.cosine(xa, xb) >= 0.999 and S.rel_l2(xa, xb) <= 2e-2
-    if np.abs(gb).max() > 0:                                  # (the cone's action gradient is non-zero once ice cream touches it)
-        assert S.cosine(ga, gb) >= 0.999 and S.rel_l2(ga, gb) <= 5e-2
+    # the cone is in touch with the stream: its action gradient -- the Rigid effector's adjoint through contact at 256^3 / 1M -- is there on both engines
+    assert np.abs(gb).max() > 0 and np.abs(ga).max() > 0, (n_touch, ga, gb)
+    assert S.cosine(ga, gb) >= 0.999 and S.rel_l2(ga, gb) <= 5e-2, (S.cosine(ga, gb), S.rel_l2(ga, gb))
