@@ -1244,18 +1244,48 @@ __device__ __forceinline__ void g2p_gather(const SimP& S, int lb, const Stencil&
 #pragma unroll
         for (int b = 0; b < 3; b++) nC.a[a][b] = c4 * (M.a[a][b] - st.fx[b] * nv[a]);
 }
+// The nodes of a tile that one thread loads: l = t0, t0 + nth, ... -- 2 of them when the whole workgroup loads the tile (nth = 256), 4 for a half, 8 for a quad
+// unit's wave.  ALL of them are asked for before the first is waited for (round 6).  Written as `for (l = t0; l < TILE_N; l += nth) { if (in the grid) v = src[..];
+// lds[l] = v; }` -- the form every tile load had until then -- the stride is a run-time value, the loop stays rolled, and each round is load -> s_waitcnt vmcnt(0)
+// -> ds_write: 2 / 4 / 8 DEPENDENT memory round trips of ~1-2 us each at the head of every unit (the in-kernel timeline showed the units of two small blocks, two
+// half tiles, spending 11 us between their unit record and their first arithmetic where the shared tiles took 4.8: profiles/r06_timeline_tail.txt).
+// `ld(l)` returns the node's value without branching (clamped address + select); `st(l, v)` writes it to LDS.
+template <int NIT, typename LD, typename ST>
+__device__ __forceinline__ void tile_nodes_n(int t0, int nth, LD&& ld, ST&& st) {
+    float4 v[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; it++) v[it] = ld(t0 + it * nth);
+#pragma unroll
+    for (int it = 0; it < NIT; it++) st(t0 + it * nth, v[it]);
+}
+// (MAXIT: at most that many in flight at a time -- where the registers are taken, k_pgg_g2pg's second tile, a thread's nodes come in rounds of MAXIT)
+template <bool QUADS = true, int MAXIT = 8, typename LD, typename ST>
+__device__ __forceinline__ void tile_nodes(int t0, int nth, LD&& ld, ST&& st) {      // (nth: 256, 128 or -- QUADS: the kernel walks a list with quad units -- 64; uniform; t0 < nth)
+    if (nth == WG) tile_nodes_n<2>(t0, nth, ld, st);
+    else if (!QUADS || nth == HALF) {
+        if constexpr (MAXIT >= 4) tile_nodes_n<4>(t0, nth, ld, st);
+        else { tile_nodes_n<2>(t0, nth, ld, st); tile_nodes_n<2>(t0 + 2 * nth, nth, ld, st); }
+    } else {
+        if constexpr (MAXIT >= 8) tile_nodes_n<8>(t0, nth, ld, st);
+        else if constexpr (MAXIT >= 4) { tile_nodes_n<4>(t0, nth, ld, st); tile_nodes_n<4>(t0 + 4 * nth, nth, ld, st); }
+        else { for (int r = 0; r < 4; r++) tile_nodes_n<2>(t0 + 2 * r * nth, nth, ld, st); }
+    }
+}
+// node l of the tile at `to`, read from a grid of float4 per node (zero outside the grid)
+__device__ __forceinline__ float4 tile_node_load(const TileO& to, const SimP& S, const float4* __restrict__ src, int l) {
+    int i, j, k;
+    const bool ok = tile_node(to, l, S.n, i, j, k);
+    const float4 v = src[ok ? cell_addr(i, j, k, S.nb) : 0];
+    return make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
+}
 // (ALIAS: into the bytes of the unit's scatter tile, from word `tofs` -- k_g2p_p2g)
 template <bool ALIAS = false>
 __device__ __forceinline__ void load_tile3(const TileO& to, const SimP& S, const float4* __restrict__ src, const PairCtx& pc, int tofs_alias = 0) {
     if (!pc.live) return;
     float* gt = ALIAS ? (float*)s_acc : s_gtile;
     const int tofs = ALIAS ? tofs_alias : pc.ti * 3 * TILE_N;
-    for (int l = pc.t0; l < TILE_N; l += pc.nth) {
-        int i, j, k;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tile_node(to, l, S.n, i, j, k)) v = src[cell_addr(i, j, k, S.nb)];
-        gt[tofs + l] = v.x; gt[tofs + TILE_N + l] = v.y; gt[tofs + 2 * TILE_N + l] = v.z;
-    }
+    tile_nodes<ALIAS>(pc.t0, pc.nth, [&](int l) { return tile_node_load(to, S, src, l); },      // (k_g2p walks the pairs-only list)
+                      [&](int l, const float4 v) { gt[tofs + l] = v.x; gt[tofs + TILE_N + l] = v.y; gt[tofs + 2 * TILE_N + l] = v.z; });
 }
 
 // p2g (mpm:331-378) fused with compute_F_tmp + svd, advect_used + process_unused_particles, Injector.act and,
@@ -2019,12 +2049,8 @@ __device__ __forceinline__ void used_particle_g2p(const SimP& S, const FrameV& c
 __device__ __forceinline__ void load_tile4(const TileO& to, const SimP& S, const float4* __restrict__ src, const PairCtx& pc) {
     if (!pc.live) return;
     const int tofs = pc.ti * 4 * TILE_N;
-    for (int l = pc.t0; l < TILE_N; l += pc.nth) {
-        int i, j, k;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tile_node(to, l, S.n, i, j, k)) v = src[cell_addr(i, j, k, S.nb)];
-        s_tile[tofs + l] = v.x; s_tile[tofs + TILE_N + l] = v.y; s_tile[tofs + 2 * TILE_N + l] = v.z; s_tile[tofs + 3 * TILE_N + l] = v.w;
-    }
+    tile_nodes<false>(pc.t0, pc.nth, [&](int l) { return tile_node_load(to, S, src, l); },      // (pair units only: p2g_grad_body loads a quad's tile itself)
+                      [&](int l, const float4 v) { s_tile[tofs + l] = v.x; s_tile[tofs + TILE_N + l] = v.y; s_tile[tofs + 2 * TILE_N + l] = v.z; s_tile[tofs + 3 * TILE_N + l] = v.w; });
 }
 
 // (u, a0): the slot's `used` flag and first state plane, loaded by the caller -- in the item path before the tile load and
@@ -2309,6 +2335,7 @@ __device__ __forceinline__ void pose_flush(const AgentP& agent, int f) {
     __syncthreads();
 }
 
+template <bool QUADS = true, int MAXIT = 8>
 __device__ __forceinline__ void g2p_grad_load_tile2(const TileO& to, const SimP& S, const float4* __restrict__ g_out, const float4* __restrict__ st, int nbr_entry, const PairCtx& pc, float* gt);
 __device__ __forceinline__ void g2p_grad_body(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T,
                                                  const float4* __restrict__ g_out, float* gg_out, float4* slab, int* slow,
@@ -2335,7 +2362,7 @@ __device__ __forceinline__ void g2p_grad_body(SimP S, float* fr_cur, float* Gn_,
             const int nbr_entry = neighbour_entry(T.blk_slot, S.nb, it.x);
             const int u0 = cur.used[s];
             const float4 a00 = cur.A0[s];
-            g2p_grad_load_tile2(to, S, g_out, V.store, nbr_entry, pc, s_tile3 + tofs);        // (through the 27 neighbour entries: one hop)
+            g2p_grad_load_tile2<false>(to, S, g_out, V.store, nbr_entry, pc, s_tile3 + tofs);        // (through the 27 neighbour entries: one hop)
             if (pc.live) for (int l = pc.t0; l < 3 * TILE_N; l += pc.nth) s_acc3[tofs + l] = 0.0;
             __syncthreads();
             TL(S, 2);
@@ -2389,21 +2416,19 @@ __global__ __launch_bounds__(WG, 4) void k_g2p_grad_b(Batch<G2PGradArgs> B) { co
 // The tile of v_out comes through the 27 neighbour entries of the item's block, fetched by 27 lanes together with the particle
 // state (k_p2g's neighbour_entry): round 2 looked every tile node's block up in blk_slot first (two dependent hops per node).
 // -----------------------------------------------------------------------------------------
+template <bool QUADS, int MAXIT>
 __device__ __forceinline__ void g2p_grad_load_tile2(const TileO& to, const SimP& S, const float4* __restrict__ g_out,
                                                     const float4* __restrict__ st, int nbr_entry, const PairCtx& pc, float* gt) {
     if (!pc.live) return;                                    // (whole waves: the shuffles below see all 64 lanes)
-    for (int l = pc.t0; l < TILE_N; l += pc.nth) {
-        const int tx = l >> 6, ty = (l >> 3) & 7, tz = l & 7;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (st) {
+    auto put = [&](int l, const float4 v) { gt[l] = v.x; gt[TILE_N + l] = v.y; gt[2 * TILE_N + l] = v.z; };
+    if (st) {                                                 // (uniform) the frame's record in the grid store, through the item's 27 neighbour entries
+        tile_nodes<QUADS, MAXIT>(pc.t0, pc.nth, [&](int l) {
+            const int tx = l >> 6, ty = (l >> 3) & 7, tz = l & 7;
             const int e = __shfl(nbr_entry, tile_region(tx) * 9 + tile_region(ty) * 3 + tile_region(tz), 64);
-            if (e >= 0) v = store_vout(st, e, (((tx + 3) & 3) << 4) | (((ty + 3) & 3) << 2) | ((tz + 3) & 3));
-        } else {
-            int i, j, k;
-            if (tile_node(to, l, S.n, i, j, k)) v = g_out[cell_addr(i, j, k, S.nb)];
-        }
-        gt[l] = v.x; gt[TILE_N + l] = v.y; gt[2 * TILE_N + l] = v.z;
-    }
+            const float4 v = store_vout(st, e >= 0 ? e : 0, (((tx + 3) & 3) << 4) | (((ty + 3) & 3) << 2) | ((tz + 3) & 3));      // (a block off the list: entry 0's record is read and dropped)
+            return make_float4(e >= 0 ? v.x : 0.f, e >= 0 ? v.y : 0.f, e >= 0 ? v.z : 0.f, 0.f);
+        }, put);
+    } else for (int l = pc.t0; l < TILE_N; l += pc.nth) put(l, tile_node_load(to, S, g_out, l));      // (the recompute road -- a frame without a record in the store: rolled, one node after the other)
 }
 
 // A quad unit's wave loads its tile of v_out by itself, eight nodes per lane (~58 VALU instructions a round: region, entry, record address).  When
@@ -3237,14 +3262,8 @@ __device__ __forceinline__ void p2g_grad_body(SimP S, float* fr_cur, float* Gn_,
             const int4 it = pc.it;
             const TileO to = tile_origin(it.x);
             float* tl = pc.ti < 2 ? s_tile + pc.ti * 4 * TILE_N : s_stash_l + (pc.ti - 2) * 4 * TILE_N;
-            if (pc.live) {
-                for (int l = pc.t0; l < TILE_N; l += 64) {
-                    int i, j, k;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (tile_node(to, l, S.n, i, j, k)) v = gg_in[cell_addr(i, j, k, S.nb)];
-                    tl[l] = v.x; tl[TILE_N + l] = v.y; tl[2 * TILE_N + l] = v.z; tl[3 * TILE_N + l] = v.w;
-                }
-            }
+            if (pc.live) tile_nodes_n<8>(pc.t0, 64, [&](int l) { return tile_node_load(to, S, gg_in, l); },
+                                         [&](int l, const float4 v) { tl[l] = v.x; tl[TILE_N + l] = v.y; tl[2 * TILE_N + l] = v.z; tl[3 * TILE_N + l] = v.w; });
             unit_sync(true);
             P2GRaw no_pre;
             {   // (a wave with few particles gives each of them three or nine lanes: lane_split)
@@ -3352,14 +3371,8 @@ __device__ __forceinline__ void p2g_grad_g2p_grad_body(SimP S, float* fr_cur, fl
             const int nbr_entry = neighbour_entry(T.blk_slot, S.nb, it.x);
             // ---- part 1: p2g_grad of substep f (p2g_grad_body), one lane per particle -- all the lanes of a split particle
             float* tl = t4 + pc.ti * 4 * TILE_N;                 // (a quad's third and fourth tile lie where the pair units keep their stash, as in k_p2g_grad)
-            if (pc.live) {
-                for (int l = pc.t0; l < TILE_N; l += pc.nth) {
-                    int ni, nj, nk;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (tile_node(to, l, S.n, ni, nj, nk)) v = gg_in[cell_addr(ni, nj, nk, S.nb)];
-                    tl[l] = v.x; tl[TILE_N + l] = v.y; tl[2 * TILE_N + l] = v.z; tl[3 * TILE_N + l] = v.w;
-                }
-            }
+            if (pc.live) tile_nodes<!GENERAL>(pc.t0, pc.nth, [&](int l) { return tile_node_load(to, S, gg_in, l); },
+                                              [&](int l, const float4 v) { tl[l] = v.x; tl[TILE_N + l] = v.y; tl[2 * TILE_N + l] = v.z; tl[3 * TILE_N + l] = v.w; });
             unit_sync(pc.quad);
             PState g;
             bool kept = false;
@@ -3385,7 +3398,7 @@ __device__ __forceinline__ void p2g_grad_g2p_grad_body(SimP S, float* fr_cur, fl
             const int u0 = prev.used[s];
             const float4 a00 = prev.A0[s];
             float* gt = pc.quad ? (float*)acc3 + tofs : lds_tile3<AR>() + tofs;
-            g2p_grad_load_tile2(to, S, B.g_out, V.store, nbr_entry, pc, gt);
+            g2p_grad_load_tile2<!GENERAL, GENERAL ? 2 : 4>(to, S, B.g_out, V.store, nbr_entry, pc, gt);      // (fifteen adjoints are live across this load: fewer nodes in flight at a time)
             if (!pc.quad && pc.live) for (int l = pc.t0; l < 3 * TILE_N; l += pc.nth) acc3[tofs + l] = 0.0;
             unit_sync(pc.quad);
             float inv = 1.f;

@@ -63,6 +63,8 @@ def main():
         raw[name] = buf.copy()
         t = buf[:2048 * 8].reshape(2048, 8).astype(np.float64)
         ok = t[:, 0] > 0
+        if not ok.any():
+            continue
         t0 = t[ok, 0].min()
         print(f'== {name}: {int(ok.sum())} workgroups stamped; start spread {1e-2 * (t[ok, 0].max() - t0):.2f} us')
         for k, ph in enumerate(PHASES[name]):

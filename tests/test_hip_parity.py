@@ -873,7 +873,7 @@ def test_fused_g2p_p2g_launch_counts_and_fallbacks(hiplib):
     """Which substeps fuse: inside one fe_step call, not across a sort, not in per-substep calls; never with a mesh effector at the particles, rigid bodies or
     a collector (those put a pass between g2p and the next p2g)."""
     sc = S.water_block(n_grid=32, n_particles=4000, seed=3, lo=0.3, hi=0.6)
-    g = S.make_engine(hiplib, sc, options={'sort_interval': 5, 'fuse_g2p': 1})
+    g = S.make_engine(hiplib, sc, options={'sort_interval': 5, 'fuse_g2p': 1, 'fuse_grid': 0})
     g.profile_enable(True)
     g.step(0, 0, 12, 0)                  # sorts at 0, 5, 10: p2g at 0, 5, 10; fused at 1-4, 6-9, 11; g2p at 4, 9, 11
     for f in range(12, 15):
