@@ -1170,13 +1170,18 @@ __device__ __forceinline__ void p2g_scatter_tile_split(const SimP& S, P2GPrep& q
 // k_g2p and ROLLED into k_g2p_p2g, and left to itself the compiler fuses multiplies into adds differently in the two -- nothing for a particle among
 // others, but an isolated droplet's C' is the rounding residue of M - fx v' times 4 / dx (1e-3 at 64^3), an SVD material's adjoint amplifies it, and the
 // fused launch must not change what a trajectory computes.  fma(0, T, M) = M and fma(1, T, M) = M + T exactly: rolled and unrolled give the same bits.
-template <bool ROLLED>
+// (UNR: columns in flight at a time on the ROLLED road.  One column at a time a wave with a drifted particle spends nine dependent round trips in here; three at a
+//  time -- nine loads in flight -- was measured in round 6 and is no faster anywhere, k_g2p_p2g +0.2 us: profiles/r06_ab_slow_paths.txt.  A/B builds: -DFE_SLOW_UNR=3)
+#ifndef FE_SLOW_UNR
+#define FE_SLOW_UNR 1
+#endif
+template <bool ROLLED, int UNR = 1>
 __device__ __forceinline__ void g2p_gather_global(const SimP& S, const Stencil& st, const float4* __restrict__ g_out, float nv[3], m3& nC) {
 #pragma clang fp contract(off)
     nv[0] = nv[1] = nv[2] = 0.f;
     const float c4 = 4.f * S.inv_dx;
     m3 M = m3_zero();
-#pragma unroll ROLLED ? 1 : 9
+#pragma unroll ROLLED ? UNR : 9
     for (int ij = 0; ij < 9; ij++) {
         const int i = ij / 3, j = ij - 3 * i;
         const float wij = STW(st, i, 0) * STW(st, j, 1);
@@ -1206,7 +1211,7 @@ __device__ __forceinline__ void g2p_gather_global(const SimP& S, const Stencil& 
 }
 template <bool TILE, bool ALIAS, bool ROLLED = false>
 __device__ __forceinline__ void g2p_gather(const SimP& S, int lb, const Stencil& st, const float4* __restrict__ g_out, int tofs, float nv[3], m3& nC) {
-    if (!TILE) { g2p_gather_global<true>(S, st, g_out, nv, nC); return; }      // (rolled everywhere: unrolled, its 27 float4 loads in flight took k_g2p from 80 registers to 123 -- the path of a few drifted particles)
+    if (!TILE) { g2p_gather_global<true, ALIAS ? FE_SLOW_UNR : 1>(S, st, g_out, nv, nC); return; }      // (k_g2p_p2g: three columns in flight; k_g2p keeps its 64 registers)      // (rolled everywhere: unrolled, its 27 float4 loads in flight took k_g2p from 80 registers to 123 -- the path of a few drifted particles)
     const float* gt = ALIAS ? (const float*)s_acc : s_gtile;
     nv[0] = nv[1] = nv[2] = 0.f;
     const float c4 = 4.f * S.inv_dx;
@@ -1396,6 +1401,14 @@ __device__ __forceinline__ void p2g_body(SimP S, float* fr_cur, float* fr_next, 
                     stencil_make(zero, S.inv_dx, q.st);
                 }
                 TL(S, 2);
+#ifdef FE_DUMMY_VALU       // (sensitivity probe, scripts/build_variant.sh -DFE_DUMMY_VALU=N: N more VALU instructions per wave and unit -- what does a tenth more arithmetic cost?)
+                {
+                    float dmy = q.m;
+#pragma unroll
+                    for (int i_ = 0; i_ < FE_DUMMY_VALU; i_++) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(dmy));
+                    asm volatile("" :: "v"(dmy));
+                }
+#endif
                 const bool in_tile = lb >= 0;
                 if (used && q.inside && !in_tile && ls.primary) { atomicAdd(G.slow, 1); p2g_scatter_global<FG>(S, q, G, GS, T.blk_slot, it.x, fg_d); }   // drifted out of the tile (ahead of the tile path, which may pass q on to another lane: wave_sort)
                 // a wave without any particle skips the 27-node scan altogether; the branch is wave-uniform, as the DPP scan requires
@@ -2240,9 +2253,12 @@ __device__ __forceinline__ void g2p_grad_slot_global(const SimP& S, const FrameV
 // make their workgroups the launch's tail: k_g2p_grad 28.7 us where a fresh order takes 23.4 (k_p2g's slow path is fire-and-forget
 // atomics and costs it 1.4 us).  Here the 27 fetches are in flight together and the sums meet through cross-lane adds.
 // (gpre: the particle's adjoint in registers, uniform -- k_pgg_g2pg, where Gn does not hold it)
+// (pk, nbr_entry: the block of the particle's unit and -- lane r < 27 -- the active-list entries of its 27 neighbours: a node among them finds its record in the
+//  frame's store through a cross-lane read instead of the block table -- one memory round trip per drifted particle instead of two, round 6; a particle that has
+//  left its tile is seldom further than a block away)
 template <bool GPRE = false>
 __device__ __forceinline__ void g2p_grad_drifted(const SimP& S, const FrameV& Gn, const FrameV& Gc, int s, const float x[3],
-                                                 const VoutSrc& V, float* gg_out, const GridStore& GS, const PState* gpre = nullptr) {
+                                                 const VoutSrc& V, float* gg_out, const GridStore& GS, const PState* gpre = nullptr, int pk = -1, int nbr_entry = -1) {
     const int lane = threadIdx.x & 63;
     Stencil st;
     stencil_make(x, S.inv_dx, st);
@@ -2260,7 +2276,17 @@ __device__ __forceinline__ void g2p_grad_drifted(const SimP& S, const FrameV& Gn
     const int n = node ? lane : 0, i = n / 9, j = (n / 3) % 3, k = n % 3;
     const float wi = STW(st, i, 0), wj = STW(st, j, 1), wk = STW(st, k, 2);
     const float dwi = stencil_dw(st, i, 0), dwj = stencil_dw(st, j, 1), dwk = stencil_dw(st, k, 2);
-    const float4 vo = vout_at(S, V, st.base[0] + i, st.base[1] + j, st.base[2] + k);
+    float4 vo;
+    if (V.store) {                                            // (uniform)
+        const int nx = st.base[0] + i, ny = st.base[1] + j, nz = st.base[2] + k;
+        const int d0 = (nx >> 2) - BLK_I(pk) + 1, d1 = (ny >> 2) - BLK_J(pk) + 1, d2 = (nz >> 2) - BLK_K(pk) + 1;
+        const bool near = pk >= 0 && (unsigned)d0 <= 2u && (unsigned)d1 <= 2u && (unsigned)d2 <= 2u;
+        const int e_near = __shfl(nbr_entry, near ? d0 * 9 + d1 * 3 + d2 : 0, 64);
+        int slot = e_near;
+        if (!near) slot = V.blk_slot[(((nx >> 2) * S.nb) + (ny >> 2)) * S.nb + (nz >> 2)];
+        vo = store_vout(V.store, slot >= 0 ? slot : 0, ((nx & 3) << 4) | ((ny & 3) << 2) | (nz & 3));
+        if (slot < 0) vo = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else vo = vout_at(S, V, st.base[0] + i, st.base[1] + j, st.base[2] + k);
     float q[3];
 #pragma unroll
     for (int a = 0; a < 3; a++) q[a] = qb[a] + (float)i * qx[a] + (float)j * qy[a] + (float)k * qz[a];
@@ -2290,7 +2316,7 @@ __device__ __forceinline__ void g2p_grad_drifted(const SimP& S, const FrameV& Gn
 // (gpre: the lane's own adjoint of x', v', C' in registers -- k_pgg_g2pg; a drifted lane's is then broadcast to the wave)
 template <bool GPRE = false>
 __device__ __forceinline__ void g2p_grad_wave_slow(const SimP& S, const FrameV& Gn, const FrameV& Gc, int s, const float4 a00, bool drifted, bool outside,
-                                                   const VoutSrc& V, float* gg_out, int* slow, const GridStore& GS, const PState* gpre = nullptr) {
+                                                   const VoutSrc& V, float* gg_out, int* slow, const GridStore& GS, const PState* gpre = nullptr, int pk = -1, int nbr_entry = -1) {
     if (outside) {
         if (GPRE) pstore(Gc, Gc.A0, s, make_float4(gpre->x[0], gpre->x[1], gpre->x[2], 0.f));
         else { const float4 gx = Gn.A0[s]; Gc.A0[s] = make_float4(gx.x, gx.y, gx.z, 0.f); }
@@ -2310,8 +2336,8 @@ __device__ __forceinline__ void g2p_grad_wave_slow(const SimP& S, const FrameV& 
 #pragma unroll
                 for (int b = 0; b < 3; b++) gu.C.a[a][b] = LANE_F(gpre->C.a[a][b]);
             }
-            g2p_grad_drifted<true>(S, Gn, Gc, __builtin_amdgcn_readlane(s, L), x, V, gg_out, GS, &gu);
-        } else g2p_grad_drifted(S, Gn, Gc, __builtin_amdgcn_readlane(s, L), x, V, gg_out, GS);
+            g2p_grad_drifted<true>(S, Gn, Gc, __builtin_amdgcn_readlane(s, L), x, V, gg_out, GS, &gu, pk, nbr_entry);
+        } else g2p_grad_drifted(S, Gn, Gc, __builtin_amdgcn_readlane(s, L), x, V, gg_out, GS, nullptr, pk, nbr_entry);
 #undef LANE_F
     }
 }
@@ -2672,7 +2698,7 @@ __device__ __forceinline__ void g2p_grad2_body(SimP S, float* fr_cur, float* Gn_
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     for (int l = pc.t0; l < 3 * TILE_N; l += pc.nth) ((int*)s_acc3)[tofs + l] = 0;
                 }
-                g2p_grad_wave_slow(S, Gn, Gc, s, a00, inside && !live && ls.primary, used && !inside && ls.primary, V, gg_out, slow, GS);      // (whole waves: wave-uniform loop; a split wave's particles once each)
+                g2p_grad_wave_slow(S, Gn, Gc, s, a00, inside && !live && ls.primary, used && !inside && ls.primary, V, gg_out, slow, GS, nullptr, it.x, nbr_entry);      // (whole waves: wave-uniform loop; a split wave's particles once each)
             }
             TL(S, 5);
             unit_sync(pc.quad);
@@ -3421,7 +3447,7 @@ __device__ __forceinline__ void p2g_grad_g2p_grad_body(SimP S, float* fr_cur, fl
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     for (int l = pc.t0; l < 3 * TILE_N; l += pc.nth) ((int*)acc3)[tofs + l] = 0;
                 }
-                g2p_grad_wave_slow<true>(S, Gc, Gp, s, a00, inside && !live && ls.primary, used && !inside && ls.primary, V, B.gg_out, slow, GS, &g);
+                g2p_grad_wave_slow<true>(S, Gc, Gp, s, a00, inside && !live && ls.primary, used && !inside && ls.primary, V, B.gg_out, slow, GS, &g, it.x, nbr_entry);
             }
             unit_sync(pc.quad);
             if (pc.quad) {
