@@ -1713,20 +1713,25 @@ __device__ __forceinline__ void grid_body(SimP S, TableP T, const float4* __rest
             if (tm || dm) one_block(es, blk_s, true, tm, dm, nbr_s);      // (entries without a mark: nothing arrived, and no particle reads those nodes)
         }
     } else {
-        // Longer lists: wave w takes the entries w, w + W, w + 2 W, ... (W = the launch's waves), eight at a time.  The marks of the
-        // eight come in one round trip; the marked ones are then worked on one after the other, the next one's block number and
-        // neighbour record on their way meanwhile.  Marked entries come in clusters (the list is in block order: water in one corner
-        // of the box): dealt out in contiguous ranges -- round 2 -- some workgroups had all of their 28 entries to work on and
-        // most had none (the splash: 25 us for 10,000 blocks); strided, every wave gets its share of every cluster.
+        // Longer lists: wave w takes the entries w, w + W, w + 2 W, ... (W = the launch's waves), eight at a time.  Marked entries come in
+        // clusters (the list is in block order: water in one corner of the box): dealt out in contiguous ranges -- round 2 -- some workgroups
+        // had all of their 28 entries to work on and most had none (the splash: 25 us for 10,000 blocks); strided, every wave gets its share.
+        // Round 6: the marks, the block numbers AND the neighbour records of all eight are asked for together -- one round trip, then one per marked
+        // entry for its slabs (rounds 3-5: the marks first, the first marked entry's block number and record behind them, the next one's while the wave
+        // works).  Splash 21.5 -> 20.8 us, early splash 16.6 -> 16.2; the same change cost k_grid_grad 4 us (133 registers: three waves per SIMD) and was
+        // not kept there: profiles/r06_ab_grid_long_list_one_trip.txt.
         const int W = 4 * (int)gridDim.x;
         for (int e0 = es; e0 < n_static; e0 += 8 * W) {
             unsigned tm = 0, dm = 0;
+            int blk8[8]; int2 nbr8[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const int e = e0 + k * W;
                 const bool ok = e < n_static;
-                const unsigned char t = ok ? GS.touched[e] : (unsigned char)0, d = ok ? GS.dirty[e] : (unsigned char)0;
-                tm |= (t == GS.stamp ? 1u : 0u) << k; dm |= (d == GS.stamp ? 1u : 0u) << k;
+                const int ec = ok ? e : e0;                   // (a valid entry either way: the loads are unconditional, the marks masked)
+                const unsigned char t = GS.touched[ec], d = GS.dirty[ec];
+                blk8[k] = T.active[ec]; nbr8[k] = nbr_record(T, ec, lane);
+                tm |= ((ok && t == GS.stamp) ? 1u : 0u) << k; dm |= ((ok && d == GS.stamp) ? 1u : 0u) << k;
             }
             tm = __builtin_amdgcn_readfirstlane(tm); dm = __builtin_amdgcn_readfirstlane(dm);
             if (lane < 8 && e0 + lane * W < n_static) {       // this launch's entries, recorded for k_grid_grad
@@ -1735,16 +1740,13 @@ __device__ __forceinline__ void grid_body(SimP S, TableP T, const float4* __rest
                 else if (e < GS.cap) GS.live[(size_t)f * GS.cap + e] = ((tm | dm) >> lane) & 1;
             }
             unsigned todo = tm | dm;                          // (entries without a mark: nothing arrived, and no particle reads those nodes)
-            int k = todo ? __builtin_ctz(todo) : -1;
-            int blk = k >= 0 ? T.active[e0 + k * W] : 0;
-            int2 nbr = k >= 0 ? nbr_record(T, e0 + k * W, lane) : make_int2(0, 0);
-            while (k >= 0) {
+            while (todo) {
+                const int k = __builtin_ctz(todo);
                 todo &= todo - 1;
-                const int k_next = todo ? __builtin_ctz(todo) : -1;
-                const int blk_next = k_next >= 0 ? T.active[e0 + k_next * W] : 0;
-                const int2 nbr_next = k_next >= 0 ? nbr_record(T, e0 + k_next * W, lane) : make_int2(0, 0);
-                one_block(e0 + k * W, blk, true, (tm >> k) & 1, (dm >> k) & 1, nbr);
-                k = k_next; blk = blk_next; nbr = nbr_next;
+                int blk = blk8[0]; int2 nbr = nbr8[0];
+#pragma unroll
+                for (int j = 1; j < 8; j++) if (k == j) { blk = blk8[j]; nbr = nbr8[j]; }      // (k is uniform: scalar branches)
+                one_block(e0 + k * W, __builtin_amdgcn_readfirstlane(blk), true, (tm >> k) & 1, (dm >> k) & 1, nbr);
             }
         }
     }
