@@ -35,8 +35,8 @@ HBM_COPY_GBS = 6290.0          # measured float4 copy on this part (DESIGN.md se
 # rocprofv3 --pmc passes of THIS command line (`--steps 20 --warmup 5`), sliced by window (scripts/phase_profile.py): the traffic of
 # the roofline kernel is read for the same windows it is timed in, or not at all
 # (the files also record the engine's source hash and the device they were taken on: numbers of another build or another GPU are not printed)
-PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r05_pmc_traffic.json')
-ROCPROF_TIMED = os.path.join(ROOT, 'profiles', 'r05_kernel_stats_timed_region.csv')
+PMC_TRAFFIC = os.path.join(ROOT, 'profiles', 'r06_pmc_traffic.json')
+ROCPROF_TIMED = os.path.join(ROOT, 'profiles', 'r06_kernel_stats_timed_region.csv')
 SRC_HASH_FILE = os.path.join(ROOT, 'fluidlab_amd', 'csrc', 'libfluidengine_hip.so.srchash')
 # fixed substep windows of the evolving block, comparable across --steps and across rounds (window w = substeps [100 w, 100 w + 100))
 PHASES = {'falling': (5, 11), 'impact': (11, 18), 'splash': (26, 34), 'layer': (80, 90)}
@@ -426,7 +426,11 @@ def run_single(args):
                               'sorts_per_pair': round(sorts / fwd_launches, 3)})
         desc = {'pgg_g2pg': "k_pgg_g2pg: substep f's p2g_grad and substep f-1's g2p_grad in one launch; credited both kernels' SURVEY bytes (192 N + 40 Nc + the 116 N state read)",
                 'g2p_p2g': "k_g2p_p2g: substep f-1's g2p and substep f's p2g in one launch; credited both kernels' SURVEY bytes (216 N + 28 Nc)"}.get(dom)
+        # (`achieved` is what the contract defines: ALGORITHMIC bytes -- SURVEY 8d's per-unit figure x the launch's units -- over the launch's time, i.e. an
+        #  EFFECTIVE bandwidth: the fused launches are credited with both constituent kernels' bytes although they no longer move the 60 + 120 B per particle the
+        #  fusion spares, nor the 64-96 B that compact_F does.  `traffic` is what the counters saw move.  ADVICE r5)
         out['roofline'] = {'bound': 'hbm', 'kernel': dom, **({'kernel_is': desc} if desc else {}), 'achieved': kern[dom]['GBps'], 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                           'achieved_is': 'effective: algorithmic bytes per launch / launch time (bytes the fusions and compact_F no longer move are still credited); see traffic',
                            'frac': round(kern[dom]['GBps'] / HBM_PEAK_GBS, 4), 'frac_of_measured_copy': round(kern[dom]['GBps'] / HBM_COPY_GBS, 4),
                            'traffic': traffic, 'alg_bytes_per_launch': kern[dom]['alg_bytes'], 'avg_launch_us': kern[dom]['avg_us'],
                            # (an event bracket serialises the launches around it: the profiled windows run ~13 % slower than the timed ones, so

@@ -2052,12 +2052,12 @@ __device__ __forceinline__ void fg_owner_phase(const SimP& S, const TableP& T, c
 template <bool TILE, bool COLLIDE>
 __device__ __forceinline__ void used_particle_g2p(const SimP& S, const FrameV& cur, const FrameV& nxt, int s,
                                                   int lb, const Stencil& st, const float x[3],
-                                                  const float4* __restrict__ g_out, const AgentP& agent, int f, int tofs = 0) {
+                                                  const float4* __restrict__ g_out, const AgentP& agent, int f, int tofs, float xn[3]) {
     float nv[3];
     m3 nC;
     g2p_gather<TILE, false>(S, lb, st, g_out, tofs, nv, nC);
     if (COLLIDE) agent.hit[(size_t)f * S.Np + s] = agent_collide_particle<false>(S, agent, f, x, nv) ? 1 : 0;      // mpm:418-422; the flag steers the backward pass
-    float xn[3] = {x[0] + S.dt * nv[0], x[1] + S.dt * nv[1], x[2] + S.dt * nv[2]};
+    xn[0] = x[0] + S.dt * nv[0]; xn[1] = x[1] + S.dt * nv[1]; xn[2] = x[2] + S.dt * nv[2];
     store_xvC(nxt, s, xn, nv, nC);
 }
 
@@ -2071,32 +2071,106 @@ __device__ __forceinline__ void load_tile4(const TileO& to, const SimP& S, const
 // (u, a0): the slot's `used` flag and first state plane, loaded by the caller -- in the item path before the tile load and
 // its barrier, so that the particle loads do not queue up behind them (a substep kernel at this size is one workgroup's chain of
 // dependent HBM round trips: table -> item -> tile -> barrier -> particle -> ...)
+// Returns whether the particle was moved: xn = its new position (the sort's key, SORTKEY kernels).
 template <bool COLLIDE>
-__device__ __forceinline__ void slot_g2p(const SimP& S, const FrameV& cur, const FrameV& nxt, int s, bool use_tile,
+__device__ __forceinline__ bool slot_g2p(const SimP& S, const FrameV& cur, const FrameV& nxt, int s, bool use_tile,
                                          const TileO& to, const float4* __restrict__ g_out, int* slow, const AgentP& agent, int f,
-                                         int u, const float4 a0, int tofs = 0) {
-    if (!u) return;
+                                         int u, const float4 a0, int tofs, float xn[3]) {
+    if (!u) return false;
     float x[3] = {a0.x, a0.y, a0.z};
     Stencil st;
     stencil_make(x, S.inv_dx, st);
-    if (!stencil_inside(st, S.n)) return;                   // already counted in err by p2g
+    if (!stencil_inside(st, S.n)) return false;             // already counted in err by p2g
     const int lb = use_tile ? tile_base(to, st) : -1;
-    if (lb >= 0) used_particle_g2p<true, COLLIDE>(S, cur, nxt, s, lb, st, x, g_out, agent, f, tofs);
-    else { if (use_tile) atomicAdd(slow, 1); used_particle_g2p<false, COLLIDE>(S, cur, nxt, s, 0, st, x, g_out, agent, f); }
+    if (lb >= 0) used_particle_g2p<true, COLLIDE>(S, cur, nxt, s, lb, st, x, g_out, agent, f, tofs, xn);
+    else { if (use_tile) atomicAdd(slow, 1); used_particle_g2p<false, COLLIDE>(S, cur, nxt, s, 0, st, x, g_out, agent, f, 0, xn); }
+    return true;
+}
+
+// -----------------------------------------------------------------------------------------
+// The sort's counting stage inside k_g2p (SORTKEY kernels, round 6).  The frame a sort works on is written by the k_g2p launch in front of it (the head of a sort
+// interval is never a fused launch), and k_sort_count did nothing but read that frame again: the stencil base of every slot -> key, the slot's rank among the slots
+// of its key (returning atomics on the cell counts), the block counts -- 14 us of kernel and a launch boundary for values k_g2p has in registers.  Here every wave
+// groups its lanes by key (a loop over the DISTINCT keys of the wave: a dozen, the order being nearly sorted), one lane per key asks for the key's range with one
+// returning atomic -- all of a wave's in flight together --, the same for its blocks; the sentinel key (slots not in use / off the grid: the tail) is counted per
+// WORKGROUP in the tail units, where every lane carries it.  What the sort's other stages read (key, rank, cnt, bcnt) is what k_sort_count left.
+// (k_sort_count's side job -- forgetting the block slots of the table about to be rebuilt -- is not needed any more: k_sort_blk_partial's active-list stage visits
+//  every block of the grid and now writes the slot of the blocks that are NOT on the new list as well.)
+// -----------------------------------------------------------------------------------------
+#define SORT_CLR_WGS 32
+struct SortKeyP { int* key; int* rank; int* cnt; int* bcnt; int* nact; };
+__shared__ int s_sk[8];
+// the key of a position: the blocked cell address of its stencil base, or the sentinel (off the grid)
+__device__ __forceinline__ int sort_key_of(const SimP& S, const float x[3]) {
+    Stencil st;
+    stencil_make(x, S.inv_dx, st);
+    return stencil_inside(st, S.n) ? cell_addr(st.base[0], st.base[1], st.base[2], S.nb) : S.ncell;
+}
+// all 64 lanes; `has`: this lane has a slot `s` with key `kk`.  WG_TAIL: a tail unit -- all 256 threads are here, most of them with the sentinel key.
+template <bool WG_TAIL>
+__device__ __forceinline__ void sort_key_rank(const SimP& S, const SortKeyP& K, bool has, int s, int kk) {
+    int lane = threadIdx.x & 63;
+    asm volatile("" : "+v"(lane));
+    const unsigned long long below = (1ull << lane) - 1ull;
+    int r_tail = -1;
+    if (WG_TAIL) {                                            // the sentinel, counted by the workgroup: one atomic on the tail's word instead of one per wave
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const unsigned long long mt = __ballot(has && kk == S.ncell);
+        if (lane == 0) s_sk[wave] = __popcll(mt);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int tot = s_sk[0] + s_sk[1] + s_sk[2] + s_sk[3];
+            int base = 0;
+            if (tot > 0) { base = atomicAdd(K.cnt + S.ncell, tot); atomicAdd(K.bcnt + (S.ncell >> 6), tot); }
+            s_sk[4] = base;
+        }
+        __syncthreads();
+        int before = 0;
+        for (int w = 0; w < wave; w++) before += s_sk[w];
+        if (has && kk == S.ncell) r_tail = s_sk[4] + before + __popcll(mt & below);
+        __syncthreads();                                      // (the words are the next unit's)
+        has = has && kk != S.ncell;
+    }
+    // the wave's lanes by key: leader (the first lane of the key), index within the key, size of the group
+    unsigned long long rem = __ballot(has);
+    int leader = lane, idx = 0, size = 0;
+    while (rem) {
+        const int L = __builtin_ctzll(rem);
+        const int k = __builtin_amdgcn_readlane(kk, L);
+        const unsigned long long m = __ballot(has && kk == k);
+        if ((m >> lane) & 1ull) { leader = L; idx = __popcll(m & below); size = __popcll(m); }
+        rem &= ~m;
+    }
+    int base = 0;
+    if (has && lane == leader) base = atomicAdd(K.cnt + kk, size);                // (one returning atomic per distinct key, all of them in flight together)
+    // ... and by block, for the block counts
+    rem = __ballot(has);
+    while (rem) {
+        const int L = __builtin_ctzll(rem);
+        const int b = __builtin_amdgcn_readlane(kk >> 6, L);
+        const unsigned long long m = __ballot(has && (kk >> 6) == b);
+        if (lane == L) atomicAdd(K.bcnt + b, __popcll(m));
+        rem &= ~m;
+    }
+    const int r = __shfl(base, leader, 64) + idx;
+    if (has) { K.key[s] = kk; K.rank[s] = r; }
+    else if (WG_TAIL && r_tail >= 0) { K.key[s] = S.ncell; K.rank[s] = r_tail; }
 }
 
 // COLLIDE: some effector carries a mesh (Rigid): agent.collide runs on the gathered velocity
-template <bool COLLIDE>
+// SORTKEY: frame f + 1 is sorted next -- the kernel leaves the sort's keys, ranks and counts (sort_key_rank, above)
+template <bool COLLIDE, bool SORTKEY = false>
 __device__ __forceinline__ void g2p_body(SimP S, float* fr_cur, float* fr_next, TableP T, const float4* __restrict__ g_out,
-                                            int* blk_count, int* slow, AgentP agent, int f) {
+                                            int* blk_count, int* slow, AgentP agent, int f, SortKeyP K = SortKeyP{nullptr, nullptr, nullptr, nullptr, nullptr}) {
     const int tid = threadIdx.x;
-    if (blockIdx.x == 0 && tid == 0) *blk_count = 0;          // grid_op was the last reader of the active list
+    if (blockIdx.x == 0 && tid == 0) { *blk_count = 0; if (SORTKEY) *K.nact = 0; }          // grid_op was the last reader of the active list
+    const int n_wg = gridDim.x;
     FrameV cur = frame_view(fr_cur, S.Np);
     FrameV nxt = frame_view(fr_next, S.Np, S.wt & 2);
     TL(S, 0);
     Unit un = unit_load<true>(T, blockIdx.x);                       // this workgroup's first unit, asked for together with meta
     const int n_slots = T.meta[9];
-    for (int wg = blockIdx.x; wg < n_slots; wg += gridDim.x) {
+    for (int wg = blockIdx.x; wg < n_slots; wg += n_wg) {
         if (wg != (int)blockIdx.x) un = unit_load<true>(T, wg);
         if (un.a.z == -2) continue;
         if (un.a.z >= 0) {
@@ -2111,20 +2185,39 @@ __device__ __forceinline__ void g2p_body(SimP S, float* fr_cur, float* fr_next, 
             load_tile3(to, S, g_out, pc);
             __syncthreads();
             TL(S, 2);
-            if (i < it.z) slot_g2p<COLLIDE>(S, cur, nxt, s0, true, to, g_out, slow, agent, f, u, a0, pc.ti * 3 * TILE_N);
+            float xn[3] = {0.f, 0.f, 0.f};
+            bool moved = false;
+            if (i < it.z) moved = slot_g2p<COLLIDE>(S, cur, nxt, s0, true, to, g_out, slow, agent, f, u, a0, pc.ti * 3 * TILE_N, xn);
+            if (SORTKEY) {
+                int kk = S.ncell;                                // (not in use, or off the grid: the tail)
+                if (moved) kk = sort_key_of(S, xn);
+                else if (i < it.z && !u && nxt.used[s0]) { const float4 n0 = nxt.A0[s0]; const float xi[3] = {n0.x, n0.y, n0.z}; kk = sort_key_of(S, xi); }      // (entered in this substep: Injector.act wrote its state)
+                sort_key_rank<false>(S, K, i < it.z, s0, kk);
+            }
             TL(S, 3);
             __syncthreads();
             TL(S, 4);
         } else {
             const int s = un.a.y + tid;
             TileO none = {0, 0, 0};
-            if (s < S.N) slot_g2p<COLLIDE>(S, cur, nxt, s, false, none, g_out, slow, agent, f, cur.used[s], cur.A0[s]);
+            float xn[3] = {0.f, 0.f, 0.f};
+            bool moved = false;
+            int u = 0;
+            if (s < S.N) { u = cur.used[s]; moved = slot_g2p<COLLIDE>(S, cur, nxt, s, false, none, g_out, slow, agent, f, u, cur.A0[s], 0, xn); }
+            if (SORTKEY) {
+                int kk = S.ncell;
+                if (moved) kk = sort_key_of(S, xn);
+                else if (s < S.N && !u && nxt.used[s]) { const float4 n0 = nxt.A0[s]; const float xi[3] = {n0.x, n0.y, n0.z}; kk = sort_key_of(S, xi); }
+                sort_key_rank<true>(S, K, s < S.N, s, kk);
+            }
         }
     }
 }
 struct G2PArgs { SimP S; float* fr_cur; float* fr_next; TableP T; const float4* g_out; int* blk_count; int* slow; AgentP agent; int f; };
 template <bool COLLIDE>
 __global__ FE_KALIGN __launch_bounds__(WG) void k_g2p(SimP S, float* fr_cur, float* fr_next, TableP T, const float4* g_out, int* blk_count, int* slow, AgentP agent, int f) { g2p_body<COLLIDE>(S, fr_cur, fr_next, T, g_out, blk_count, slow, agent, f); }
+template <bool COLLIDE>
+__global__ FE_KALIGN __launch_bounds__(WG) void k_g2p_sortkey(SimP S, float* fr_cur, float* fr_next, TableP T, const float4* g_out, int* blk_count, int* slow, AgentP agent, int f, SortKeyP K) { g2p_body<COLLIDE, true>(S, fr_cur, fr_next, T, g_out, blk_count, slow, agent, f, K); }
 template <bool COLLIDE>
 __global__ FE_KALIGN __launch_bounds__(WG) void k_g2p_b(Batch<G2PArgs> B) { const G2PArgs& A = B.a[blockIdx.y]; g2p_body<COLLIDE>(A.S, A.fr_cur, A.fr_next, A.T, A.g_out, A.blk_count, A.slow, A.agent, A.f); }
 
@@ -3533,7 +3626,6 @@ __device__ __forceinline__ int wave_iscan(int x) {
     x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false);
     return x;
 }
-#define SORT_CLR_WGS 32
 __global__ __launch_bounds__(256) void k_sort_count(SimP S, float* fr, int n_pwg, int* key, int* rank, int* cnt, int* bcnt,
                                                     const int* __restrict__ clr_active, const int* __restrict__ clr_meta, int* clr_slot, int* nact) {
     __shared__ int hist[SORT_HB + 1];       // + the sentinel's slot
@@ -3753,6 +3845,9 @@ __global__ __launch_bounds__(256) void k_sort_blk_partial(int nblk, int nb, int 
             base = __shfl(base, 0, 64);
             if (on) { const int e = base + __popcll(wm & ((1ull << lane) - 1ull)); active[e] = b; blk_slot[b] = e; }
         }
+        // (every block of the grid passes here: the ones that are not on the new list lose whatever slot the table's previous life gave them -- k_sort_count's
+        //  trailing workgroups used to walk the old list for that; with the keys counted inside k_g2p there is no launch to carry them)
+        if (!on && b < nblk) blk_slot[b] = -1;
         return;
     }
     if ((int)blockIdx.x >= blk_wgs) {
@@ -4455,6 +4550,9 @@ struct FeEngine {
     unsigned fg_started = 0;                                // workgroups of all FG launches so far: what the pass' monotonic counters read before the next one (SimP::fg_base)
     bool tail_used = true;                                  // used particles may sit behind the work items of the current order: injected or edited by the host since the last sort (-> late deposits, fg_final)
     int tbl_bank = 0, last_sorted_f = -1;                   // two banks of table ids, one per sweep over the window (sort_frame)
+    int sort_keys_in_g2p = 1;                               // option "sort_keys_in_g2p": the k_g2p launch in front of a sort counts the sort's keys (k_g2p_sortkey), the sort skips k_sort_count
+    int keys_frame = -1;                                    // the frame whose keys / ranks / counts the sort's scratch arrays hold (written by k_g2p_sortkey), or -1
+    bool sort_scratch_dirty = false;                        // ... they hold counts no sort has consumed yet
     int p2g_grad_waves = 4;                                 // occupancy target of the SVD-free p2g_grad build (tuning)
     int pack_units = 2;                                     // option "pack_units": 0 never, 1 pack the scatter list (no idle halves) when that brings it back into one round, 2 whenever it is more than one round
     int quad_fit = 1024;                                    // option "quad_fit": the workgroups of one resident round (set from the device in fe_create: 4 per CU); 0 = round 3's rule
@@ -4702,6 +4800,14 @@ int sort_frame(FeEngine* h, int f) {
     const int n_pwg = (int)pgrid(h).x;
     const int nblk = h->nb * h->nb * h->nb;
     if (fine) prof_begin(h, KID_SORT_COUNT);
+    // (the keys, ranks and counts of this very frame may be there already: the k_g2p launch that wrote it counted them -- k_g2p_sortkey)
+    const bool have_keys = h->keys_frame == f && h->sort_scratch_dirty;
+    if (!have_keys && h->sort_scratch_dirty) {                // counts of a frame that was never sorted (the caller went elsewhere): back to zero first
+        HIPCK(h, hipMemsetAsync(h->sort_cnt, 0, sizeof(int) * ((size_t)ncell + 1), h->stream));
+        HIPCK(h, hipMemsetAsync(h->sort_bcnt, 0, sizeof(int) * (size_t)(((nblk + 1 + SORT_BLK_WG - 1) / SORT_BLK_WG) * SORT_BLK_WG), h->stream));
+    }
+    h->keys_frame = -1; h->sort_scratch_dirty = false;
+    if (!have_keys)
     hipLaunchKernelGGL(k_sort_count, dim3(n_pwg + SORT_CLR_WGS), dim3(256), 0, h->stream, h->S, h->frame(f), n_pwg, h->sort_key, h->sort_rank, h->sort_cnt, h->sort_bcnt,
                        tn.active, tn.meta, tn.blk_slot, h->sort_nact);
     if (fine) { prof_end(h); prof_begin(h, KID_SORT_SCAN); }
@@ -4828,7 +4934,21 @@ int substep_fwd(FeEngine* h, int f, int f_global, int act, bool g2p_pending = fa
     }
     if (defer_g2p) return 0;                              // (fusable_fwd(h, f + 1): no rigid-body pass either)
     prof_begin(h, KID_G2P);
-    if (particle_collide(h))
+    // frame f + 1 is a frame the order is rebuilt on: this launch counts the sort's keys as it writes the positions (the sort then skips k_sort_count).
+    // Not with rigid bodies (their particles are moved again behind this launch).
+    const bool sortkey = h->sort_keys_in_g2p && h->sort_interval > 0 && (f + 1) % h->sort_interval == 0 && !h->has_rigid;
+    if (sortkey) {
+        if (h->sort_scratch_dirty) {                          // (counts of a frame that was never sorted)
+            HIPCK(h, hipMemsetAsync(h->sort_cnt, 0, sizeof(int) * ((size_t)h->S.ncell + 1), h->stream));
+            HIPCK(h, hipMemsetAsync(h->sort_bcnt, 0, sizeof(int) * (size_t)((((size_t)h->nb * h->nb * h->nb + 1 + SORT_BLK_WG - 1) / SORT_BLK_WG) * SORT_BLK_WG), h->stream));
+        }
+        const SortKeyP K = {h->sort_key, h->sort_rank, h->sort_cnt, h->sort_bcnt, h->sort_nact};
+        if (particle_collide(h))
+            hipLaunchKernelGGL(k_g2p_sortkey<true>, wgrid_g2p(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T, gout(h, f), bcount(h, f), h->slow_dev, ag, f, K);
+        else
+            hipLaunchKernelGGL(k_g2p_sortkey<false>, wgrid_g2p(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T, gout(h, f), bcount(h, f), h->slow_dev, ag, f, K);
+        h->keys_frame = f + 1; h->sort_scratch_dirty = true;
+    } else if (particle_collide(h))
         hipLaunchKernelGGL(k_g2p<true>, wgrid_g2p(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T, gout(h, f), bcount(h, f), h->slow_dev, ag, f);
     else
         hipLaunchKernelGGL(k_g2p<false>, wgrid_g2p(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->frame(f + 1), T, gout(h, f), bcount(h, f), h->slow_dev, ag, f);
@@ -5389,6 +5509,7 @@ int fe_set_option(FeEngine* h, const char* name, double value) {
     if (!std::strcmp(name, "fold_reorder")) { h->fold_reorder = value != 0; return 0; }
     if (!std::strcmp(name, "compact_F")) { h->compact_F = value != 0; return 0; }
     if (!std::strcmp(name, "fuse_g2p")) { h->fuse_g2p = value != 0; return 0; }
+    if (!std::strcmp(name, "sort_keys_in_g2p")) { h->sort_keys_in_g2p = value != 0; return 0; }
     if (!std::strcmp(name, "fuse_bwd")) { h->fuse_bwd = (int)value; return 0; }
     if (!std::strcmp(name, "fuse_grid")) { if (value < 0 || value > 6 || ((int)value & 3) == 3) FAIL(h, "fuse_grid must be 0 (separate grid kernels), 1 (fused where nothing slow is expected) or 2 (wherever possible), + 4: never wait"); h->fuse_grid = (int)value; return 0; }
     if (!std::strcmp(name, "quad_min_units")) { h->quad_min_units = (int)value; return 0; }
@@ -5411,7 +5532,7 @@ int fe_get_option(FeEngine* h, const char* name, double* value) {
         {"sort_interval", (double)h->sort_interval}, {"item_max", (double)h->item_max}, {"grid_store", h->gs_cap > 0 ? 1.0 : 0.0},
         {"p2g_grad_waves", (double)h->p2g_grad_waves}, {"g2p_grad_v", (double)h->g2p_grad_v}, {"loose_max", (double)h->loose_max},
         {"inject_till", (double)h->inject_till}, {"collide_min_y", (double)h->collide_min_y}, {"collide_type", (double)h->collide_type},
-        {"prof_fine", h->prof_fine ? 1.0 : 0.0}, {"xcd_map", (double)h->S.xcd}, {"write_through", (double)h->S.wt}, {"wave_sort", (double)h->S.wsort}, {"lane_split", (double)h->S.lsplit}, {"fold_reorder", h->fold_reorder ? 1.0 : 0.0}, {"compact_F", h->compact_F ? 1.0 : 0.0}, {"fuse_g2p", h->fuse_g2p ? 1.0 : 0.0}, {"fuse_bwd", (double)h->fuse_bwd}, {"fuse_grid", (double)h->fuse_grid},
+        {"prof_fine", h->prof_fine ? 1.0 : 0.0}, {"xcd_map", (double)h->S.xcd}, {"write_through", (double)h->S.wt}, {"wave_sort", (double)h->S.wsort}, {"lane_split", (double)h->S.lsplit}, {"fold_reorder", h->fold_reorder ? 1.0 : 0.0}, {"compact_F", h->compact_F ? 1.0 : 0.0}, {"fuse_g2p", h->fuse_g2p ? 1.0 : 0.0}, {"fuse_bwd", (double)h->fuse_bwd}, {"fuse_grid", (double)h->fuse_grid}, {"sort_keys_in_g2p", (double)h->sort_keys_in_g2p},
         {"quad_min_units", (double)h->quad_min_units}, {"pgg_quad_min_units", (double)h->pgg_quad_min_units}, {"quad_max", (double)h->quad}, {"quad_fit", (double)h->quad_fit}, {"pack_units", (double)h->pack_units},
         {"wgrid_cap", (double)h->wgrid_cap}, {"wgrid_cap_g2p", (double)h->wgrid_cap_g2p}, {"wgrid_cap_pgg", (double)h->wgrid_cap_pgg}, {"ggrid_cap", (double)h->ggrid_cap}, {"threads", 0.0}};
     for (const auto& t : tab) if (!std::strcmp(name, t.n)) { *value = t.v; return 0; }
@@ -5477,6 +5598,7 @@ int fe_init_particles(FeEngine* h, const fe_real* x, const int* used, const int*
     HIPCK(h, hipStreamSynchronize(h->stream));
     h->tbl_of_frame[0] = 0;
     h->tail_used = true;
+    h->keys_frame = -1;
     std::fill(h->fiso.begin(), h->fiso.end(), 0);
     h->gcompact[0] = h->gcompact[1] = false;
     h->gpartial[0] = h->gpartial[1] = false;
@@ -5573,6 +5695,7 @@ int fe_get_frame(FeEngine* h, int f, fe_real* x, fe_real* v, fe_real* C, fe_real
 int fe_set_frame(FeEngine* h, int f, const fe_real* x, const fe_real* v, const fe_real* C, const fe_real* F, const int* used) {
     FE_ENTRY(h);
     CHECK_FRAME(h, f);
+    if (f == h->keys_frame) h->keys_frame = -1;                  // (the sort's pre-counted keys describe what the frame held)
     h->tail_used = true;                                      // (the host may have put particles in use behind the order's work items: fuse_grid_ok)
     h->gs_host_valid = false;
     if (h->gs_cap > 0) HIPCK(h, hipMemsetAsync(h->gs_flag + f, 0, sizeof(int), h->stream));     // the stored grid of this frame is stale now
@@ -5593,6 +5716,7 @@ int fe_get_frame_dev(FeEngine* h, int f, fe_real* x, fe_real* v, fe_real* C, fe_
 int fe_set_frame_dev(FeEngine* h, int f, const fe_real* x, const fe_real* v, const fe_real* C, const fe_real* F, const int* used) {
     FE_ENTRY(h);
     CHECK_FRAME(h, f);
+    if (f == h->keys_frame) h->keys_frame = -1;                  // (the sort's pre-counted keys describe what the frame held)
     h->tail_used = true;                                      // (the host may have put particles in use behind the order's work items: fuse_grid_ok)
     h->gs_host_valid = false;
     if (h->gs_cap > 0) HIPCK(h, hipMemsetAsync(h->gs_flag + f, 0, sizeof(int), h->stream));
@@ -5611,6 +5735,8 @@ int fe_copy_frame(FeEngine* h, int src, int dst) {
     h->tbl_of_frame[dst] = h->tbl_of_frame[src];
     h->fiso[dst] = h->fiso[src];
     h->tail_used = true;
+    if (dst == h->keys_frame) h->keys_frame = -1;
+    if (src == h->keys_frame) h->keys_frame = dst;             // (the copy holds the same particles in the same slots: the pre-counted keys are its as well -- fluidlab's window wraps frame L to frame 0 and sorts it)
     h->gs_host_valid = false;
     if (h->gs_cap > 0) HIPCK(h, hipMemsetAsync(h->gs_flag + dst, 0, sizeof(int), h->stream));
     return 0;

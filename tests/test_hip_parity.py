@@ -1105,3 +1105,52 @@ def test_incomplete_adjoint_slots_are_refused(hiplib):
         else:
             g.get_grad(3)
         g.close()
+
+
+def test_sort_keys_counted_in_g2p(hiplib):
+    """Option sort_keys_in_g2p (round 6): the k_g2p launch in front of a sort frame counts the sort's keys, ranks and block counts while it writes the positions, and
+    the sort skips k_sort_count.  The pre-counted keys describe ONE frame: they follow a copy of it (fluidlab's window wraps frame L to frame 0 and sorts that),
+    they are dropped when the host rewrites the frame, and counts that no sort ever consumed are cleared before the next count.  Every road against the engine
+    that always runs k_sort_count: the orders may differ in the ranks of a cell's particles, the trajectories only by the noise of the scatter's sums."""
+    rng = np.random.RandomState(11)
+    N = 6000
+    sc = S.water_block(n_grid=32, n_particles=N, seed=3, lo=0.3, hi=0.6)
+    sc['v'] = S.f32(rng.normal(0, 1.0, (N, 3)) + [2.0, -3.0, 1.0])
+    sc['used'] = (rng.rand(N) > 0.1).astype(np.int32)
+
+    def run(pre, road):
+        g = S.make_engine(hiplib, sc, options={'sort_interval': 5, 'sort_keys_in_g2p': pre})
+        g.profile_enable(True)
+        g.step(0, 0, 10, 0)                                      # sorts at 0 and 5; substeps 4 and 9 end in a k_g2p in front of a sort frame
+        if road == 'wrap':                                       # frame 10 becomes frame 0 and is sorted there
+            g.copy_frame(10, 0)
+            g.step(0, 0, 10, 0)
+            out = S.get_state(g, 10)
+        elif road == 'edit':                                     # the host moves particles of frame 10: its pre-counted keys are stale
+            st = S.get_state(g, 10)
+            x = st['x'].copy()
+            x[::7] += np.float32(0.11)
+            g.set_frame(10, x=np.clip(x, 0.1, 0.9).astype(np.float32))
+            g.step(10, 10, 10, 0)
+            out = S.get_state(g, 20)
+        else:                                                    # the caller goes on somewhere else: the counts of frame 10 are never consumed
+            st = S.get_state(g, 7)
+            g.set_frame(30, x=st['x'], v=st['v'], C_=st['C'], F=st['F'], used=st['used'])
+            g.step(30, 30, 10, 0)
+            out = S.get_state(g, 40)
+        prof = g.profile_read()
+        g.sync()
+        g.close()
+        return out, prof
+
+    for road in ('wrap', 'edit', 'elsewhere'):
+        a, pa = run(1, road)
+        b, _ = run(0, road)
+        c, _ = run(0, road)
+        assert (a['used'] == b['used']).all(), road
+        u = b['used'] > 0
+        for k in 'xvCF':
+            scale = max(1.0, float(np.abs(b[k][u]).max()))
+            d, nz = float(np.abs(a[k][u] - b[k][u]).max()) / scale, float(np.abs(c[k][u] - b[k][u]).max()) / scale
+            assert d <= 4.0 * nz + {'x': 5e-7, 'v': 4e-6, 'C': 8e-5, 'F': 4e-6}[k], (road, k, d, nz)
+        assert pa['sort'][1] == 4, (road, pa['sort'])
