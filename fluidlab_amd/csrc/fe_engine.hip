@@ -4048,7 +4048,8 @@ __device__ __forceinline__ void build_units_dev(int gtid, int nth, int nb, int N
     }
     // the fused grid pass (FG kernels): how many tiles are handed over around each entry -- the slabs of its block's 27 neighbours (a block's items pair up from
     // its first one: gather_slabs) -- is what its arrival word counts up to
-    for (int e = gtid; e < n_active; e += nth) {
+    // (only for tables built while the option fuse_grid is on: 27 loads per entry, ~5 us of k_sort_apply at 128^3 / 200k)
+    if (expected) for (int e = gtid; e < n_active; e += nth) {
         const int b = active[e], bi = b / (nb * nb), bj = (b / nb) % nb, bk = b % nb;
         int cnt[27];
 #pragma unroll
@@ -4526,7 +4527,7 @@ struct FeEngine {
     float* grads = nullptr;                                 // 3 x (GR_WORDS*Np + Np) floats: ring of two + 1 spare
     float* grad_ptr[3] = {nullptr, nullptr, nullptr};
     // particle orders ("tables"): id 0 = identity; id 1+f = order produced by the sort at frame f
-    struct Table { int* pid = nullptr; float4* info = nullptr; int2* pairs = nullptr; int* singles = nullptr; int4* items = nullptr; int* meta = nullptr; int2* blk_first = nullptr; int* active = nullptr; int* blk_slot = nullptr; int* slot_of_pid = nullptr; UnitRec* units = nullptr; UnitRec* units_p = nullptr; int2* nbr = nullptr; unsigned long long* arrive = nullptr; /* [nblk] arrival words, then int expected[nblk] (fused grid pass) */ };
+    struct Table { int* pid = nullptr; float4* info = nullptr; int2* pairs = nullptr; int* singles = nullptr; int4* items = nullptr; int* meta = nullptr; int2* blk_first = nullptr; int* active = nullptr; int* blk_slot = nullptr; int* slot_of_pid = nullptr; UnitRec* units = nullptr; UnitRec* units_p = nullptr; int2* nbr = nullptr; unsigned long long* arrive = nullptr; /* [nblk] arrival words, then int expected[nblk] (fused grid pass) */ bool has_expected = false; /* built while fuse_grid was on */ };
     int loose_max = 0;                                      // blocks with <= this many particles get no work item (option "loose_max")
     std::vector<int> gs_host; bool gs_host_valid = false;   // host copy of gs_flag, refreshed once per backward sweep
     float4* gstore = nullptr; int* gs_flag = nullptr; int gs_cap = 0;     // forward grid store (see GridStore)
@@ -4735,7 +4736,8 @@ int check_async(FeEngine* h);
 
 void build_units(FeEngine* h, FeEngine::Table& t) {
     hipLaunchKernelGGL(k_build_units, dim3(256), dim3(256), 0, h->stream, h->nb, h->N, h->S.xcd, t.items, t.pairs, t.singles, t.blk_first, t.active, t.meta,
-                       t.units, t.units_p, (int)h->units_cap, t.nbr, (int*)(t.arrive + (size_t)h->nb * h->nb * h->nb));
+                       t.units, t.units_p, (int)h->units_cap, t.nbr, (h->fuse_grid & 3) ? (int*)(t.arrive + (size_t)h->nb * h->nb * h->nb) : (int*)nullptr);
+    t.has_expected = (h->fuse_grid & 3) != 0;
 }
 int ensure_table(FeEngine* h, int id) {
     if ((int)h->tables.size() <= id) h->tables.resize(id + 1);
@@ -4819,7 +4821,8 @@ int sort_frame(FeEngine* h, int f) {
     if (fine) { prof_end(h); prof_begin(h, KID_SORT_PERM); }
     // re-sorting a frame that is already in this table's order reads the id table it rewrites: stage it
     int* pid_dst = id_old == id_new ? h->sort_pid : tn.pid;
-    const UnitsArgs U = {h->sort_bcnt, h->nb, h->S.xcd, h->quad_min_units, h->quad_fit, h->pack_units, h->pgg_quad_min_units, tn.items, tn.pairs, tn.singles, tn.singles + h->items_cap, tn.blk_first, tn.active, tn.meta, tn.units, tn.units_p, (int)h->units_cap, tn.nbr, (int*)(tn.arrive + (size_t)nblk)};
+    const UnitsArgs U = {h->sort_bcnt, h->nb, h->S.xcd, h->quad_min_units, h->quad_fit, h->pack_units, h->pgg_quad_min_units, tn.items, tn.pairs, tn.singles, tn.singles + h->items_cap, tn.blk_first, tn.active, tn.meta, tn.units, tn.units_p, (int)h->units_cap, tn.nbr, (h->fuse_grid & 3) ? (int*)(tn.arrive + (size_t)nblk) : (int*)nullptr};
+    tn.has_expected = (h->fuse_grid & 3) != 0;
     hipLaunchKernelGGL(k_sort_apply, dim3(n_pwg + SORT_UNIT_WGS), dim3(256), 0, h->stream, h->N, (size_t)h->Np, n_pwg, h->sort_key, h->sort_rank, h->sort_start, h->sort_base,
                        h->tables[id_old].pid, pid_dst, tn.slot_of_pid, h->pinfo, tn.info, h->spare_frame(), h->frame(f), U, h->S.uni, h->fiso[f] ? 1 : 0);
     if (id_old == id_new) HIPCK(h, hipMemcpyAsync(tn.pid, h->sort_pid, sizeof(int) * h->Np, hipMemcpyDeviceToDevice, h->stream));
@@ -4876,7 +4879,7 @@ inline bool fusable_fwd(FeEngine* h, int f) {
 // the injector's, or the host's edits since the last sort -- so with fuse_grid = 1 such launches keep the separate k_grid.
 inline bool fuse_grid_possible(FeEngine* h, int t) {
     return (h->fuse_grid & 3) != 0 && h->sort_interval > 0 && t > 0 && h->loose_max == 0 && h->statics_host.empty() && !h->has_mesh_effector &&
-           h->gs_cap == h->nb * h->nb * h->nb;
+           h->gs_cap == h->nb * h->nb * h->nb && h->tables[t].has_expected;      // (a table sorted before the option was switched on has no arrival counts: separate grid kernels until the next sort)
 }
 inline bool fuse_grid_ok(FeEngine* h, int f) { return fuse_grid_possible(h, h->tbl_of_frame[f]) && ((h->fuse_grid & 3) >= 2 || !h->tail_used); }
 // an FG launch: the pass' `started` / `finished` counters are monotonic (nothing to reset between launches); they read fg_started before it and fg_started + workgroups behind it
