@@ -3811,9 +3811,11 @@ __device__ __forceinline__ void wg_scan6(const BlkSums& m, int (*sh)[NSUM], int 
 //                                      order's active list: every block some tile or some loose particle's stencil can reach (asking
 //                                      costs 27 cached loads per block and one atomic per wave, and the list comes out nearly in block
 //                                      order; round 2 pushed instead -- 200,000 returning atomics on 25,000 words, 36 us).
-__global__ __launch_bounds__(256) void k_sort_blk_partial(int nblk, int nb, int ITEM_MAX, int loose_max, int quad_max, const int* __restrict__ bcnt, int* partial,
-                                                          int blk_wgs, int scan_wgs, int* cnt, int* start, int* nact, int* active, int* blk_slot) {
-    __shared__ int sh[4][NSUM];
+// The side jobs (cell starts, active list): true when the workgroup was one of theirs.  ONE (k_sort_blk_scan): the last workgroup of the active-list job to finish
+// leaves the list's length in meta[2] (its counter `act_done` is monotonic: it reads act_target - 1 when all the others of this sort have passed).
+template <bool ONE>
+__device__ __forceinline__ bool sort_side_jobs(int nblk, int nb, const int* __restrict__ bcnt, int blk_wgs, int scan_wgs, int* cnt, int* start, int* nact, int* active, int* blk_slot,
+                                               int* act_done, int act_target, int* meta) {
     const int lane = threadIdx.x & 63;
     if ((int)blockIdx.x >= blk_wgs + scan_wgs) {
         const int b = (blockIdx.x - blk_wgs - scan_wgs) * 256 + threadIdx.x;
@@ -3848,13 +3850,20 @@ __global__ __launch_bounds__(256) void k_sort_blk_partial(int nblk, int nb, int 
         // (every block of the grid passes here: the ones that are not on the new list lose whatever slot the table's previous life gave them -- k_sort_count's
         //  trailing workgroups used to walk the old list for that; with the keys counted inside k_g2p there is no launch to carry them)
         if (!on && b < nblk) blk_slot[b] = -1;
-        return;
+        if (ONE) {
+            // (no fences: a release fence at agent scope writes the XCD's whole L2 back -- 13 us per sort when this was written with __threadfence().  A wave's atomic on
+            //  the length has returned its value before the wave gets here; the counter and the length are read and written at agent scope, past the L2)
+            __syncthreads();
+            if (threadIdx.x == 0 && __hip_atomic_fetch_add(act_done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == act_target - 1)
+                meta[2] = __hip_atomic_load(nact, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return true;
     }
     if ((int)blockIdx.x >= blk_wgs) {
         const int g = (blockIdx.x - blk_wgs) * 4 + (threadIdx.x >> 6);         // this wave's 16 blocks: [16 g, 16 g + 16)
         const int bl = g * 16 + (lane & 15);
         const unsigned occ = (unsigned)__ballot(lane < 16 && bl < nblk && bcnt[bl] > 0);
-        if (!occ) return;
+        if (!occ) return true;
         int4 c[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {                                          // the loads of all four groups before the first scan
@@ -3873,8 +3882,14 @@ __global__ __launch_bounds__(256) void k_sort_blk_partial(int nblk, int nb, int 
                 if (s3) *(int4*)(cnt + (size_t)b * 64 + (lane & 15) * 4) = make_int4(0, 0, 0, 0);      // ready for the next sort
             }
         }
-        return;
+        return true;
     }
+    return false;
+}
+__global__ __launch_bounds__(256) void k_sort_blk_partial(int nblk, int nb, int ITEM_MAX, int loose_max, int quad_max, const int* __restrict__ bcnt, int* partial,
+                                                          int blk_wgs, int scan_wgs, int* cnt, int* start, int* nact, int* active, int* blk_slot) {
+    __shared__ int sh[4][NSUM];
+    if (sort_side_jobs<false>(nblk, nb, bcnt, blk_wgs, scan_wgs, cnt, start, nact, active, blk_slot, nullptr, 0, nullptr)) return;
     int n[4], ex[NSUM], tot[NSUM];
     const BlkSums m = blk_sums4(blk_ask4(bcnt), nblk, ITEM_MAX, loose_max, quad_max, n);
     wg_scan6(m, sh, ex, tot);
@@ -3883,17 +3898,11 @@ __global__ __launch_bounds__(256) void k_sort_blk_partial(int nblk, int nb, int 
 }
 // (one launch in which every workgroup goes over the whole array again instead of reading partial sums was tried: the six sums need
 // a division per block, 35 us for the launch against 18 for these two)
-__global__ __launch_bounds__(256) void k_sort_blk_final(int nblk, int nb, int ncell, int ITEM_MAX, int loose_max, int quad_max, const int* __restrict__ bcnt, int* cnt, int* start,
-                                                        const int* __restrict__ partial, int4* items, int2* pairs, int* singles, int* singles_c, int2* blk_first, int* blk_base, const int* __restrict__ nact, int* meta) {
-    __shared__ int sh[4][NSUM];
+// the scan proper, from this thread's four counts and its share of the workgroups' partial sums (pb: of the workgroups before this one, pa: of all).  nact: where the
+// active list's length is read for meta[2], or null (k_sort_blk_scan: the active-list job's last workgroup writes it).
+__device__ __forceinline__ void sort_blk_final_body(int (*sh)[NSUM], const int4 n4, const BlkSums& pb, const BlkSums& pa, int nblk, int nb, int ncell, int ITEM_MAX, int loose_max, int quad_max,
+                                                    int* cnt, int* start, int4* items, int2* pairs, int* singles, int* singles_c, int2* blk_first, int* blk_base, const int* __restrict__ nact, int* meta) {
     const int tid = threadIdx.x;
-    const int4 n4 = blk_ask4(bcnt);                  // (on its way while the partial sums are read)
-    // the partials of the workgroups before this one, and of all of them
-    BlkSums pb = {{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}}, pa = {{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
-    for (int w = tid; w < (int)gridDim.x; w += 256) {
-#pragma unroll
-        for (int k = 0; k < NSUM; k++) { const int t = partial[w * PART_STRIDE + k]; pa.v[k] += t; if (w < (int)blockIdx.x) pb.v[k] += t; }
-    }
     int n[4], ex[NSUM], tot[NSUM];
     const BlkSums m = blk_sums4(n4, nblk, ITEM_MAX, loose_max, quad_max, n);
     int exb[NSUM], before[NSUM], exa[NSUM], total[NSUM];
@@ -3902,7 +3911,7 @@ __global__ __launch_bounds__(256) void k_sort_blk_final(int nblk, int nb, int nc
     wg_scan6(m, sh, ex, tot);
     // meta: [0] items, [1] first slot behind the dense blocks, [2] active blocks (k_sort_fill), [3] full pairs, [4] big singles, [5] / [9] slots
     // of the two unit lists, [6] occupied blocks, [7] first slot of the tail, [8] small singles, [10] quad units, [11] big / [12] small leftovers, [13] scatter list packed, [14] / [15] work units of the two lists
-    if (blockIdx.x == 0 && tid == 0) { meta[0] = total[2]; meta[1] = total[0]; meta[2] = *nact; meta[3] = total[3]; meta[4] = total[4]; meta[6] = total[5]; meta[7] = total[0] + total[1]; meta[8] = total[6] + total[9] + total[10];
+    if (blockIdx.x == 0 && tid == 0) { meta[0] = total[2]; meta[1] = total[0]; if (nact) meta[2] = *nact; meta[3] = total[3]; meta[4] = total[4]; meta[6] = total[5]; meta[7] = total[0] + total[1]; meta[8] = total[6] + total[9] + total[10];
                                        meta[11] = total[7]; meta[12] = total[8]; }
     const int b0 = blockIdx.x * SORT_BLK_WG + tid * 4;
     if (b0 > nblk) return;
@@ -3947,6 +3956,55 @@ __global__ __launch_bounds__(256) void k_sort_blk_final(int nblk, int nb, int nc
     *(int4*)(blk_base + b0) = make_int4(base[0], base[1], base[2], base[3]);        // (padded like bcnt)
     if (b0 + 3 < nblk) { *(int4*)(blk_first + b0) = make_int4(bf[0].x, bf[0].y, bf[1].x, bf[1].y); *(int4*)(blk_first + b0 + 2) = make_int4(bf[2].x, bf[2].y, bf[3].x, bf[3].y); }
     else for (int u = 0; u < 4; u++) if (b0 + u < nblk) blk_first[b0 + u] = bf[u];
+}
+__global__ __launch_bounds__(256) void k_sort_blk_final(int nblk, int nb, int ncell, int ITEM_MAX, int loose_max, int quad_max, const int* __restrict__ bcnt, int* cnt, int* start,
+                                                        const int* __restrict__ partial, int4* items, int2* pairs, int* singles, int* singles_c, int2* blk_first, int* blk_base, const int* __restrict__ nact, int* meta) {
+    __shared__ int sh[4][NSUM];
+    const int tid = threadIdx.x;
+    const int4 n4 = blk_ask4(bcnt);                  // (on its way while the partial sums are read)
+    // the partials of the workgroups before this one, and of all of them
+    BlkSums pb = {{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}}, pa = {{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
+    for (int w = tid; w < (int)gridDim.x; w += 256) {
+#pragma unroll
+        for (int k = 0; k < NSUM; k++) { const int t = partial[w * PART_STRIDE + k]; pa.v[k] += t; if (w < (int)blockIdx.x) pb.v[k] += t; }
+    }
+    sort_blk_final_body(sh, n4, pb, pa, nblk, nb, ncell, ITEM_MAX, loose_max, quad_max, cnt, start, items, pairs, singles, singles_c, blk_first, blk_base, nact, meta);
+}
+// Round 6: the two launches as ONE (option sort_one_scan, default OFF -- built because VERDICT r5 asked for it, measured: 33.2 us per sort against 32.6 ... 33.3 for the two
+// launches at 128^3 / 200k, 114 against 106 at 256^3 / 1M, profiles/r06_ab_sort_one_scan.txt: what the kernel boundary cost, the wait for the counter costs -- one hop to
+// publish, one to see it; the first version with __threadfence() cost 13 us per sort, the fence writes the XCD's L2 back --, while the scan's workgroups -- the launch's first ones -- are few enough to be resident together: at most two per CU; 257 at 256^3).
+// A scan workgroup publishes its eleven sums (agent-scope stores, waited for; one agent-scope atomic on a counter), waits until the counter says that all
+// blk_wgs of this sort have (the counter is monotonic: `ready_target` = what it reads then), reads everybody's sums past the L2 (agent-scope loads: the other XCDs' stores)
+// and goes on with the scan from the counts it still holds.  One kernel boundary and the second pass over the counts less per sort; the active list's length reaches
+// meta[2] through the last workgroup of that job (sort_side_jobs<true>).
+struct SortScanSync { int* ready; int ready_target; int* act_done; int act_target; };
+__global__ __launch_bounds__(256) void k_sort_blk_scan(int nblk, int nb, int ncell, int ITEM_MAX, int loose_max, int quad_max, const int* __restrict__ bcnt, int* partial, int blk_wgs, int scan_wgs,
+                                                       int* cnt, int* start, int* nact, int* active, int* blk_slot, int4* items, int2* pairs, int* singles, int* singles_c, int2* blk_first,
+                                                       int* blk_base, int* meta, SortScanSync Y) {
+    __shared__ int sh[4][NSUM];
+    if (sort_side_jobs<true>(nblk, nb, bcnt, blk_wgs, scan_wgs, cnt, start, nact, active, blk_slot, Y.act_done, Y.act_target, meta)) return;
+    const int tid = threadIdx.x;
+    const int4 n4 = blk_ask4(bcnt);
+    {
+        int n[4], ex[NSUM], tot[NSUM];
+        const BlkSums m = blk_sums4(n4, nblk, ITEM_MAX, loose_max, quad_max, n);
+        wg_scan6(m, sh, ex, tot);
+#pragma unroll
+        for (int k = 0; k < NSUM; k++) if (tid == k) __hip_atomic_store(partial + blockIdx.x * PART_STRIDE + k, tot[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // (the sums went through to memory: agent-scope stores; no fence -- see sort_side_jobs)
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_fetch_add(Y.ready, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while ((int)(__hip_atomic_load(Y.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - Y.ready_target) < 0) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+    BlkSums pb = {{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}}, pa = {{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
+    for (int w = tid; w < blk_wgs; w += 256) {
+#pragma unroll
+        for (int k = 0; k < NSUM; k++) { const int t = __hip_atomic_load(partial + w * PART_STRIDE + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); pa.v[k] += t; if (w < (int)blockIdx.x) pb.v[k] += t; }
+    }
+    sort_blk_final_body(sh, n4, pb, pa, nblk, nb, ncell, ITEM_MAX, loose_max, quad_max, cnt, start, items, pairs, singles, singles_c, blk_first, blk_base, nullptr, meta);
 }
 
 // What the substep kernels would otherwise look up through chains of dependent loads, laid out once per sort: the unit list of
@@ -4565,6 +4623,7 @@ struct FeEngine {
     int sort_interval = 10;                                 // K: re-sort every K substeps (0 = never: global path only)
     size_t items_cap = 0, units_cap = 0;
     int *sort_key = nullptr, *sort_rank = nullptr, *sort_cnt = nullptr, *sort_start = nullptr, *sort_pid = nullptr, *sort_bcnt = nullptr, *sort_partial = nullptr, *sort_base = nullptr, *sort_nact = nullptr;
+    int sort_one_scan = 0, scan_ready = 0, scan_act = 0;    // option sort_one_scan (default off: it measured the same at 128^3 and 8 % slower per sort at 256^3): the sort's two scan launches as one (k_sort_blk_scan); what its two monotonic counters read after the last sort
     int* slow_dev = nullptr;
     int* frame_slow_dev = nullptr;                          // set by a slow-path scatter of the current forward substep
     float4* pinfo = nullptr; int* pool_idx = nullptr;
@@ -4814,10 +4873,18 @@ int sort_frame(FeEngine* h, int f) {
                        tn.active, tn.meta, tn.blk_slot, h->sort_nact);
     if (fine) { prof_end(h); prof_begin(h, KID_SORT_SCAN); }
     const int blk_wgs = (nblk + 1 + SORT_BLK_WG - 1) / SORT_BLK_WG, scan_wgs = (nblk + 63) / 64, act_wgs = (nblk + 255) / 256;
-    hipLaunchKernelGGL(k_sort_blk_partial, dim3(blk_wgs + scan_wgs + act_wgs), dim3(256), 0, h->stream, nblk, h->nb, h->item_max, h->loose_max, quad_max(h), h->sort_bcnt, h->sort_partial,
-                       blk_wgs, scan_wgs, h->sort_cnt, h->sort_start, h->sort_nact, tn.active, tn.blk_slot);
-    hipLaunchKernelGGL(k_sort_blk_final, dim3(blk_wgs), dim3(256), 0, h->stream, nblk, h->nb, ncell, h->item_max, h->loose_max, quad_max(h), h->sort_bcnt, h->sort_cnt, h->sort_start, h->sort_partial,
-                       tn.items, tn.pairs, tn.singles, tn.singles + h->items_cap, tn.blk_first, h->sort_base, h->sort_nact, tn.meta);
+    if (h->sort_one_scan && blk_wgs <= 2 * h->n_cus) {    // (the scan's workgroups wait for each other: all of them resident -- the launch's first ones, three fit a CU at the kernel's 142 registers)
+        h->scan_ready += blk_wgs; h->scan_act += act_wgs;
+        const SortScanSync Y = {h->sort_nact + 1, h->scan_ready, h->sort_nact + 2, h->scan_act};
+        hipLaunchKernelGGL(k_sort_blk_scan, dim3(blk_wgs + scan_wgs + act_wgs), dim3(256), 0, h->stream, nblk, h->nb, ncell, h->item_max, h->loose_max, quad_max(h), h->sort_bcnt, h->sort_partial,
+                           blk_wgs, scan_wgs, h->sort_cnt, h->sort_start, h->sort_nact, tn.active, tn.blk_slot, tn.items, tn.pairs, tn.singles, tn.singles + h->items_cap, tn.blk_first,
+                           h->sort_base, tn.meta, Y);
+    } else {
+        hipLaunchKernelGGL(k_sort_blk_partial, dim3(blk_wgs + scan_wgs + act_wgs), dim3(256), 0, h->stream, nblk, h->nb, h->item_max, h->loose_max, quad_max(h), h->sort_bcnt, h->sort_partial,
+                           blk_wgs, scan_wgs, h->sort_cnt, h->sort_start, h->sort_nact, tn.active, tn.blk_slot);
+        hipLaunchKernelGGL(k_sort_blk_final, dim3(blk_wgs), dim3(256), 0, h->stream, nblk, h->nb, ncell, h->item_max, h->loose_max, quad_max(h), h->sort_bcnt, h->sort_cnt, h->sort_start, h->sort_partial,
+                           tn.items, tn.pairs, tn.singles, tn.singles + h->items_cap, tn.blk_first, h->sort_base, h->sort_nact, tn.meta);
+    }
     if (fine) { prof_end(h); prof_begin(h, KID_SORT_PERM); }
     // re-sorting a frame that is already in this table's order reads the id table it rewrites: stage it
     int* pid_dst = id_old == id_new ? h->sort_pid : tn.pid;
@@ -5395,7 +5462,7 @@ FeEngine* fe_create(const FeConfig* cfg) {
         // (the slab gathers address a node of slab i as a signed 32-bit byte offset i * SLAB_N * 16 + ...: ADVICE r4)
         if (h->items_cap * (size_t)SLAB_N * 16 >= ((size_t)1 << 31)) return fail("grid / particle count too large: the slab buffer no longer fits 32-bit byte offsets");
         if (dev_alloc(h, &h->sort_key, h->Np) || dev_alloc(h, &h->sort_rank, h->Np) || dev_alloc(h, &h->sort_cnt, ncell + 1) ||
-            dev_alloc(h, &h->sort_start, ncell + 1) || dev_alloc(h, &h->sort_bcnt, ((nblk + 1 + SORT_BLK_WG - 1) / SORT_BLK_WG) * SORT_BLK_WG) || dev_alloc(h, &h->sort_partial, ((nblk + 1 + SORT_BLK_WG - 1) / SORT_BLK_WG) * PART_STRIDE) || dev_alloc(h, &h->sort_base, ((nblk + 1 + SORT_BLK_WG - 1) / SORT_BLK_WG) * SORT_BLK_WG) || dev_alloc(h, &h->sort_nact, 1) || dev_alloc(h, &h->sort_pid, h->Np) ||
+            dev_alloc(h, &h->sort_start, ncell + 1) || dev_alloc(h, &h->sort_bcnt, ((nblk + 1 + SORT_BLK_WG - 1) / SORT_BLK_WG) * SORT_BLK_WG) || dev_alloc(h, &h->sort_partial, ((nblk + 1 + SORT_BLK_WG - 1) / SORT_BLK_WG) * PART_STRIDE) || dev_alloc(h, &h->sort_base, ((nblk + 1 + SORT_BLK_WG - 1) / SORT_BLK_WG) * SORT_BLK_WG) || dev_alloc(h, &h->sort_nact, 4)      /* [0] the active list's length, [1] / [2] k_sort_blk_scan's counters */ || dev_alloc(h, &h->sort_pid, h->Np) ||
             dev_alloc(h, &h->slow_dev, 1) || dev_alloc(h, &h->frame_slow_dev, 1) || dev_alloc(h, &h->slab, h->items_cap * SLAB_N, false)) return fail("");
     }
     if (dev_alloc(h, &h->effs_dev, FE_MAX_EFF)) return fail("");
@@ -5513,6 +5580,7 @@ int fe_set_option(FeEngine* h, const char* name, double value) {
     if (!std::strcmp(name, "compact_F")) { h->compact_F = value != 0; return 0; }
     if (!std::strcmp(name, "fuse_g2p")) { h->fuse_g2p = value != 0; return 0; }
     if (!std::strcmp(name, "sort_keys_in_g2p")) { h->sort_keys_in_g2p = value != 0; return 0; }
+    if (!std::strcmp(name, "sort_one_scan")) { h->sort_one_scan = value != 0; return 0; }
     if (!std::strcmp(name, "fuse_bwd")) { h->fuse_bwd = (int)value; return 0; }
     if (!std::strcmp(name, "fuse_grid")) { if (value < 0 || value > 6 || ((int)value & 3) == 3) FAIL(h, "fuse_grid must be 0 (separate grid kernels), 1 (fused where nothing slow is expected) or 2 (wherever possible), + 4: never wait"); h->fuse_grid = (int)value; return 0; }
     if (!std::strcmp(name, "quad_min_units")) { h->quad_min_units = (int)value; return 0; }
@@ -5535,7 +5603,7 @@ int fe_get_option(FeEngine* h, const char* name, double* value) {
         {"sort_interval", (double)h->sort_interval}, {"item_max", (double)h->item_max}, {"grid_store", h->gs_cap > 0 ? 1.0 : 0.0},
         {"p2g_grad_waves", (double)h->p2g_grad_waves}, {"g2p_grad_v", (double)h->g2p_grad_v}, {"loose_max", (double)h->loose_max},
         {"inject_till", (double)h->inject_till}, {"collide_min_y", (double)h->collide_min_y}, {"collide_type", (double)h->collide_type},
-        {"prof_fine", h->prof_fine ? 1.0 : 0.0}, {"xcd_map", (double)h->S.xcd}, {"write_through", (double)h->S.wt}, {"wave_sort", (double)h->S.wsort}, {"lane_split", (double)h->S.lsplit}, {"fold_reorder", h->fold_reorder ? 1.0 : 0.0}, {"compact_F", h->compact_F ? 1.0 : 0.0}, {"fuse_g2p", h->fuse_g2p ? 1.0 : 0.0}, {"fuse_bwd", (double)h->fuse_bwd}, {"fuse_grid", (double)h->fuse_grid}, {"sort_keys_in_g2p", (double)h->sort_keys_in_g2p},
+        {"prof_fine", h->prof_fine ? 1.0 : 0.0}, {"xcd_map", (double)h->S.xcd}, {"write_through", (double)h->S.wt}, {"wave_sort", (double)h->S.wsort}, {"lane_split", (double)h->S.lsplit}, {"fold_reorder", h->fold_reorder ? 1.0 : 0.0}, {"compact_F", h->compact_F ? 1.0 : 0.0}, {"fuse_g2p", h->fuse_g2p ? 1.0 : 0.0}, {"fuse_bwd", (double)h->fuse_bwd}, {"fuse_grid", (double)h->fuse_grid}, {"sort_keys_in_g2p", (double)h->sort_keys_in_g2p}, {"sort_one_scan", (double)h->sort_one_scan},
         {"quad_min_units", (double)h->quad_min_units}, {"pgg_quad_min_units", (double)h->pgg_quad_min_units}, {"quad_max", (double)h->quad}, {"quad_fit", (double)h->quad_fit}, {"pack_units", (double)h->pack_units},
         {"wgrid_cap", (double)h->wgrid_cap}, {"wgrid_cap_g2p", (double)h->wgrid_cap_g2p}, {"wgrid_cap_pgg", (double)h->wgrid_cap_pgg}, {"ggrid_cap", (double)h->ggrid_cap}, {"threads", 0.0}};
     for (const auto& t : tab) if (!std::strcmp(name, t.n)) { *value = t.v; return 0; }

@@ -1154,3 +1154,38 @@ def test_sort_keys_counted_in_g2p(hiplib):
             d, nz = float(np.abs(a[k][u] - b[k][u]).max()) / scale, float(np.abs(c[k][u] - b[k][u]).max()) / scale
             assert d <= 4.0 * nz + {'x': 5e-7, 'v': 4e-6, 'C': 8e-5, 'F': 4e-6}[k], (road, k, d, nz)
         assert pa['sort'][1] == 4, (road, pa['sort'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n_grid', [32, 64])
+def test_sort_one_scan_launch_matches_two(hiplib, oracle64, n_grid):
+    """Option sort_one_scan (round 6): the sort's two scan launches as one -- the scan's workgroups publish their partial sums, wait for each other on a counter and go on
+    (k_sort_blk_scan), the active list's length reaches the table through the last workgroup of that job.  64^3: five scan workgroups that wait for each other (32^3: one).
+    A dense core among droplets (pairs, leftovers, singles of every size class), three sorts: the work lists of the two roads are identical, both follow the fp64 oracle
+    (the launches themselves: profiles/r06_kernel_stats_*.csv list k_sort_blk_scan and neither k_sort_blk_partial nor k_sort_blk_final)."""
+    rng = np.random.RandomState(41)
+    core = np.concatenate([(4 * np.array([3 + bi, 3 + bj, 3 + bk]) + 0.5) / 32 + rng.uniform(0.02, 0.98, (int(rng.randint(140, 500)), 3)) * (4 / 32)
+                           for bi in range(2) for bj in range(3) for bk in range(2)])
+    drops = np.concatenate([c + rng.uniform(-r, r, (20, 3)) for c, r in zip(rng.uniform(0.15, 0.85, (60, 3)), rng.choice([0.01, 0.02, 0.04], 60))])
+    x = S.f32(np.clip(np.concatenate([core, drops]), 0.08, 0.92))
+    N = len(x)
+    sc = dict(S.water_block(n_grid=n_grid, n_particles=N, seed=3), x=x, v=S.f32(rng.normal(0, 0.4, (N, 3))))
+    cot = S.random_cotangent(N, seed=4)
+    res = {}
+    for one in (1, 0):
+        g = S.make_engine(hiplib, sc, options={'sort_interval': 4, 'sort_one_scan': one})
+        g.profile_enable(True)
+        sa, ga = S.run_forward_backward(g, 9, cot)
+        prof = g.profile_read()
+        res[one] = (sa, ga, [g.get_work_stats(f) for f in (0, 4, 8)], prof['sort'][1])
+        g.close()
+    o = S.make_engine(oracle64, sc)
+    sb, gb = S.run_forward_backward(o, 9, {k: v.astype(np.float64) for k, v in cot.items()})
+    assert res[1][2] == res[0][2], (res[1][2], res[0][2])          # the same items, pairs, singles, units and active blocks, sort by sort
+    assert res[1][2][2]['n_active_blocks'] > 0 and res[1][2][2]['n_items'] > 40
+    assert res[1][3] == 3 and res[0][3] == 3, (res[1][3], res[0][3])              # three sorts each (frames 0, 4, 8)
+    for one in (1, 0):
+        sa, ga = res[one][0], res[one][1]
+        assert np.abs(sa['x'] - sb['x']).max() <= 2e-6 and S.rel_l2(sa['v'], sb['v']) <= 1e-4, one
+        for k in ('gx', 'gv', 'gC', 'gF'):
+            assert S.cosine(ga[k], gb[k]) >= 0.99999 and S.rel_l2(ga[k], gb[k]) <= 1e-3, (one, k, S.rel_l2(ga[k], gb[k]))
