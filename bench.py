@@ -626,6 +626,38 @@ def run_replicas(args, rank, local_rank, world):
             with quiet():
                 solver.forward_backward(init['state'], policy, env.horizon, env.horizon_action)      # ONE replica, as `--gpus 1 --replicas` would run it
             eng.sync(); n1_rate = sub / B / (time.perf_counter() - a)
+    # Where the host's time goes in that flow (is a rank host-bound?): one more pass of rank 0 with every C-ABI call timed.  Calls that wait for the GPU
+    # (fe_sync, the read-backs) are `blocked`; everything else the host does -- the calls that only enqueue, and the Python between calls -- is what a faster GPU could not shorten.
+    host_us = None
+    if rank == 0 and B == 1:
+        acc = {}
+
+        class TimedLib:
+            def __init__(self, lib): self._lib = lib
+            def __getattr__(self, name):
+                f = getattr(self._lib, name)
+                if not name.startswith('fe_'):
+                    return f
+                def call(*a):
+                    t = time.perf_counter(); r = f(*a); acc[name] = acc.get(name, 0.0) + time.perf_counter() - t
+                    return r
+                return call
+        real = eng.lib
+        eng.lib = TimedLib(real)
+        try:
+            eng.sync(); a = time.perf_counter()
+            with quiet():
+                solver.forward_backward(init['state'], policy, env.horizon, env.horizon_action)
+            eng.sync(); wall1 = time.perf_counter() - a
+        finally:
+            eng.lib = real
+        waits = lambda n: n == 'fe_sync' or '_get' in n or n in ('fe_last_error',)
+        blocked = sum(v for k, v in acc.items() if waits(k)); enq = sum(v for k, v in acc.items() if not waits(k))
+        per = 1e6 / (sub / B)
+        host_us = {'wall': round(wall1 * per, 1), 'enqueue_calls': round(enq * per, 1), 'python_between_calls': round((wall1 - blocked - enq) * per, 1),
+                   'blocked_waiting_for_the_gpu': round(blocked * per, 1),
+                   'largest_calls': {k: round(v * per, 1) for k, v in sorted(acc.items(), key=lambda kv: -kv[1])[:6]},
+                   'note': 'us per substep pair, one Solver pass of rank 0 with every fe_* call timed; host-bound would read blocked ~ 0'}
     barrier()
     for _ in range(args.warmup):
         one_pass()
@@ -682,6 +714,7 @@ def run_replicas(args, rank, local_rank, world):
             'weak_scaling_efficiency_vs_rank_compute': round(value / sum(per_rank), 4),
             'host': {'rss_gb_per_rank': [round(float(a[3]), 2) for a in allr], 'cores_per_rank': [int(a[5]) for a in allr],
                      'hbm_state_gb_per_rank': [round(float(a[4]), 1) for a in allr], 'cpus_visible': os.cpu_count()},
+            'host_time_per_pair_us': host_us,
             'allreduce_us': {'warm_latency': round(ar_us, 1), 'per_pass_median_incl_wait': [round(float(a[1]), 1) for a in allr]},
             'passes_skipped_nonfinite_grad': int(sum(float(a[2]) for a in allr)),
             'actions_identical_across_ranks': all(float(a[6]) == float(allr[0][6]) and float(a[7]) == float(allr[0][7]) for a in allr),

@@ -20,7 +20,7 @@ OUT = os.environ.get('PROFILE_OUT', 'profiles')          # (on the GPU box: a di
 
 CHUNK = 100
 BENCH_NAME = [('k_p2g_grad', 'p2g_grad'), ('k_g2p_grad', 'g2p_grad'), ('k_grid_grad', 'grid_op_grad'), ('k_p2g<true', 'p2g'), ('k_p2g<false', 'p2g_recompute'),
-              ('k_grid<false', 'grid_op'), ('k_grid<true', 'grid_op_keep'), ('k_g2p<', 'g2p'), ('k_g2p_p2g', 'g2p_p2g'), ('k_pgg_g2pg', 'pgg_g2pg')]
+              ('k_grid<false', 'grid_op'), ('k_grid<true', 'grid_op_keep'), ('k_g2p<', 'g2p'), ('k_g2p_sortkey', 'g2p'), ('k_g2p_p2g', 'g2p_p2g'), ('k_pgg_g2pg', 'pgg_g2pg')]
 SORT_KERNELS = ('k_sort', 'k_scan', 'k_build', 'k_clear_slots', 'k_set_static', 'k_block')
 FIXED = {'falling': (5, 11), 'impact': (11, 18), 'splash': (18, 45), 'layer': (45, 10**9)}
 

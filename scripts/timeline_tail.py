@@ -10,6 +10,8 @@ for name in sys.argv[2:]:
     hw = z[name][2048 * 8:]
     ok = t[:, 0] > 0
     idx = np.where(ok)[0]
+    if not ok.any():
+        print(f"== {name}: no stamps"); continue
     t0 = t[ok, 0].min()
     d = (t[ok] - t0) * 1e-2
     d[t[ok] == 0] = np.nan
