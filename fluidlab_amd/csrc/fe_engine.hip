@@ -264,7 +264,7 @@ __shared__ float  s_gtile[2 * 3 * TILE_N];  // gathered v_out: k_g2p (3 planes)
 // ~1.6 T and ds_add_u64 ~2.8 T in this access pattern (profiles/r01_ubench_lds_types.txt); fp64 also makes the
 // in-tile sum insensitive to the order of the atomics.
 __shared__ double s_acc[2 * 4 * TILE_N];    // k_p2g
-__shared__ float  s_tile3[2 * 3 * TILE_N];  // k_g2p_grad: v_out ...
+__shared__ float  s_tile3[2 * 3 * TILE_N];  // k_g2p_grad2: v_out ...
 __shared__ double s_acc3[2 * 3 * TILE_N];   // ... and d v_out (3 planes each: 36 KB per workgroup, four workgroups per CU)
 // k_p2g_grad's per-thread stash columns (used_particle_p2g_grad)
 #define STASH_GENERAL 36
@@ -2242,21 +2242,15 @@ __device__ __forceinline__ float4 vout_at(const SimP& S, const VoutSrc& V, int i
     return slot >= 0 ? store_vout(V.store, slot, ((i & 3) << 4) | ((j & 3) << 2) | (k & 3)) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-// advect_kernel.grad + g2p.grad (mpm:443, 538) for one used particle: scatters d/d(v_out), leaves the
-// position adjoint (so far) in Gc.A0.xyz.  TILE: v_out read from / d v_out accumulated into LDS (3+3 planes)
-// TILE=true is executed by ALL lanes of the wave (`live` = this lane holds a used particle whose stencil fits the
-// tile); the d v_out contributions are summed over runs of equal stencil base before the LDS atomics (seg_scan).
+// advect_kernel.grad + g2p.grad (mpm:443, 538) for one used particle on the GLOBAL path (drifted out of its tile, a tail unit, sort_interval = 0): scatters d/d(v_out)
+// with global atomics, leaves the position adjoint (so far) in Gc.A0.xyz.  (The tile form of this loop was round 2's k_g2p_grad; the tile kernels are g2p_grad_particle2's.)
 // (agent.collide's adjoint has already been folded into Gn's x/v adjoints by k_collide_grad)
-template <bool TILE, bool GPRE = false>
-__device__ __forceinline__ void used_particle_g2p_grad(const SimP& S, const FrameV& Gn, const FrameV& Gc, int s,
-                                                       int lb, const Stencil& st, const VoutSrc& V, float* gg_out,
-                                                       bool live, const SegScan& sc, int tofs = 0, const PState* gpre = nullptr) {
+template <bool GPRE = false>
+__device__ __forceinline__ void used_particle_g2p_grad(const SimP& S, const FrameV& Gn, const FrameV& Gc, int s, const Stencil& st, const VoutSrc& V, float* gg_out,
+                                                       const PState* gpre = nullptr) {
     PState g;                                   // adjoints of x', v', C'
     if (GPRE) copy_xvC(g, *gpre);               // (k_pgg_g2pg: in registers, not in Gn)
-    else if (!TILE || live) load_xvC(Gn, s, g);
-    else { g.x[0] = g.x[1] = g.x[2] = g.v[0] = g.v[1] = g.v[2] = 0.f; g.C = m3_zero(); }
-    const bool issue = TILE && sc.tail && live;
-    const float livef = (!TILE || live) ? 1.f : 0.f;
+    else load_xvC(Gn, s, g);
     // x' = x + dt v'  =>  v'_bar += dt x'_bar
     float gv[3] = {g.v[0] + S.dt * g.x[0], g.v[1] + S.dt * g.x[1], g.v[2] + S.dt * g.x[2]};
     const float c4 = 4.f * S.inv_dx;
@@ -2274,37 +2268,23 @@ __device__ __forceinline__ void used_particle_g2p_grad(const SimP& S, const Fram
         const int i = ij / 3, j = ij - 3 * i;
         const float wi = STW(st, i, 0), wj = STW(st, j, 1);
         const float wiwj = wi * wj, dwiwj = stencil_dw(st, i, 0) * wj, widwj = wi * stencil_dw(st, j, 1);
-        const float lw = livef * wiwj;
         float qij[3];
 #pragma unroll
         for (int a = 0; a < 3; a++) qij[a] = qb[a] + c4 * (g.C.a[a][0] * (float)i + g.C.a[a][1] * (float)j);
 #pragma unroll
         for (int kk = 0; kk < 3; kk++) {
             const float wk = st.w[kk][2];
-            const float weight = lw * wk;
+            const float weight = wiwj * wk;
             float q[3];
 #pragma unroll
             for (int a = 0; a < 3; a++) q[a] = kk == 0 ? qij[a] : qij[a] + (float)kk * qz[a];
-            float v0, v1, v2;
-            if (TILE) {
-                const int l = tofs + lb + (i * TILE_T + j) * TILE_T + kk;
-                v0 = s_tile3[l]; v1 = s_tile3[TILE_N + l]; v2 = s_tile3[2 * TILE_N + l];
-                float c0 = weight * q[0], c1 = weight * q[1], c2 = weight * q[2];
-                seg_scan3(sc, c0, c1, c2);
-                if (issue) {
-                    atomicAdd(&s_acc3[l], (double)c0);                        // ds_add_f64
-                    atomicAdd(&s_acc3[TILE_N + l], (double)c1);
-                    atomicAdd(&s_acc3[2 * TILE_N + l], (double)c2);
-                }
-            } else {
-                const int c = cell_addr(st.base[0] + i, st.base[1] + j, st.base[2] + kk, S.nb);
-                float4 vo = vout_at(S, V, st.base[0] + i, st.base[1] + j, st.base[2] + kk);
-                v0 = vo.x; v1 = vo.y; v2 = vo.z;
-                float* dst = gg_out + c;
-                unsafeAtomicAdd(dst, weight * q[0]);
-                unsafeAtomicAdd(dst + S.ncell, weight * q[1]);
-                unsafeAtomicAdd(dst + 2 * S.ncell, weight * q[2]);
-            }
+            const int c = cell_addr(st.base[0] + i, st.base[1] + j, st.base[2] + kk, S.nb);
+            const float4 vo = vout_at(S, V, st.base[0] + i, st.base[1] + j, st.base[2] + kk);
+            const float v0 = vo.x, v1 = vo.y, v2 = vo.z;
+            float* dst = gg_out + c;
+            unsafeAtomicAdd(dst, weight * q[0]);
+            unsafeAtomicAdd(dst + S.ncell, weight * q[1]);
+            unsafeAtomicAdd(dst + 2 * S.ncell, weight * q[2]);
             const float sdot = v0 * q[0] + v1 * q[1] + v2 * q[2];
             const float w3 = wiwj * wk;
             nvw[0] += w3 * v0; nvw[1] += w3 * v1; nvw[2] += w3 * v2;
@@ -2316,7 +2296,7 @@ __device__ __forceinline__ void used_particle_g2p_grad(const SimP& S, const Fram
     }
 #pragma unroll
     for (int b = 0; b < 3; b++) gfx[b] -= c4 * (nvw[0] * g.C.a[0][b] + nvw[1] * g.C.a[1][b] + nvw[2] * g.C.a[2][b]);     // dpos_b = o_b - fx_b
-    if (!TILE || live) pstore(Gc, Gc.A0, s, make_float4(g.x[0] + S.inv_dx * gfx[0], g.x[1] + S.inv_dx * gfx[1], g.x[2] + S.inv_dx * gfx[2], 0.f));
+    pstore(Gc, Gc.A0, s, make_float4(g.x[0] + S.inv_dx * gfx[0], g.x[1] + S.inv_dx * gfx[1], g.x[2] + S.inv_dx * gfx[2], 0.f));
 }
 
 // one slot on the global path (tail / sort_interval = 0)
@@ -2333,9 +2313,7 @@ __device__ __forceinline__ void g2p_grad_slot_global(const SimP& S, const FrameV
         else { float4 gx = Gn.A0[s]; Gc.A0[s] = make_float4(gx.x, gx.y, gx.z, 0.f); }
         return;
     }
-    SegScan none;
-    none.f1 = none.f2 = none.f4 = none.f8 = 0.f; none.tail = true;
-    used_particle_g2p_grad<false, GPRE>(S, Gn, Gc, s, 0, st, V, gg_out, true, none, 0, gpre);
+    used_particle_g2p_grad<GPRE>(S, Gn, Gc, s, st, V, gg_out, gpre);
     for (int bx = st.base[0] >> 2; bx <= (st.base[0] + 2) >> 2; bx++)              // the (up to 8) blocks whose gg_out planes now hold atomics
         for (int by = st.base[1] >> 2; by <= (st.base[1] + 2) >> 2; by++)
             for (int bz = st.base[2] >> 2; bz <= (st.base[2] + 2) >> 2; bz++) mark_dirty(GS, V.blk_slot, (bx * S.nb + by) * S.nb + bz);
@@ -2458,72 +2436,11 @@ __device__ __forceinline__ void pose_flush(const AgentP& agent, int f) {
 
 template <bool QUADS = true, int MAXIT = 8>
 __device__ __forceinline__ void g2p_grad_load_tile2(const TileO& to, const SimP& S, const float4* __restrict__ g_out, const float4* __restrict__ st, int nbr_entry, const PairCtx& pc, float* gt);
-__device__ __forceinline__ void g2p_grad_body(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T,
-                                                 const float4* __restrict__ g_out, float* gg_out, float4* slab, int* slow,
-                                                 GridStore GS, int f, AgentP agent) {
-    const int tid = threadIdx.x;
-    const bool stored = GS.cap > 0 && GS.flag[f];
-    VoutSrc V; V.g_out = g_out; V.store = stored ? GS.data + (size_t)f * GS.cap * GS_BLK : nullptr; V.blk_slot = T.blk_slot;
-    FrameV cur = frame_view(fr_cur, S.Np);
-    FrameV Gn = frame_view(Gn_, S.Np), Gc = frame_view(Gc_, S.Np, S.wt & 4);
-    TL(S, 0);
-    Unit un = unit_load<true>(T, blockIdx.x);                       // this workgroup's first unit, asked for together with meta
-    const int n_slots = T.meta[9];
-    for (int wg = blockIdx.x; wg < n_slots; wg += gridDim.x) {
-        if (wg != (int)blockIdx.x) un = unit_load<true>(T, wg);
-        if (un.a.z == -2) continue;
-        if (un.a.z >= 0) {
-            const PairCtx pc = pair_ctx(un);
-            const int4 it = pc.it;
-            const TileO to = tile_origin(it.x);
-            const int tofs = pc.ti * 3 * TILE_N;
-            // the particle loads go out ahead of the tile load and its barrier (see slot_g2p); an item is one pass of its half
-            const int i = tid & (HALF - 1);
-            const int s = it.y + (i < it.z ? i : 0);
-            const int nbr_entry = neighbour_entry(T.blk_slot, S.nb, it.x);
-            const int u0 = cur.used[s];
-            const float4 a00 = cur.A0[s];
-            g2p_grad_load_tile2<false>(to, S, g_out, V.store, nbr_entry, pc, s_tile3 + tofs);        // (through the 27 neighbour entries: one hop)
-            if (pc.live) for (int l = pc.t0; l < 3 * TILE_N; l += pc.nth) s_acc3[tofs + l] = 0.0;
-            __syncthreads();
-            TL(S, 2);
-            {
-                const bool used = i < it.z && u0 != 0;
-                float x[3] = {0.f, 0.f, 0.f};
-                if (used) { x[0] = a00.x; x[1] = a00.y; x[2] = a00.z; }
-                Stencil st;
-                stencil_make(x, S.inv_dx, st);
-                const bool inside = used && stencil_inside(st, S.n);
-                const int lb = inside ? tile_base(to, st) : -1;
-                const bool live = lb >= 0;
-                if (__any(live)) {                               // wave-uniform: empty waves skip the scan
-                    const SegScan sc = seg_setup(live ? lb : (0x40000000 | tid));
-                    used_particle_g2p_grad<true>(S, Gn, Gc, s, live ? lb : 0, st, V, gg_out, live, sc, tofs);
-                }
-                if (used && !live) {
-                    if (inside) atomicAdd(slow, 1);
-                    g2p_grad_slot_global(S, cur, Gn, Gc, s, V, gg_out, agent, f, GS);
-                }
-            }
-            TL(S, 5);
-            __syncthreads();
-            TL(S, 6);
-            if (pc.live) for (int l = pc.t0; l < TILE_N; l += pc.nth)
-                tile_handover<3>(S, slab, pc.slab, gg_out, GS, to, nbr_entry, l,
-                                 make_float4((float)s_acc3[tofs + l], (float)s_acc3[tofs + TILE_N + l], (float)s_acc3[tofs + 2 * TILE_N + l], 0.f), S.wt & 4);
-            __syncthreads();
-            TL(S, 7);
-        } else {
-            const int s = un.a.y + tid;
-            if (s < S.N) g2p_grad_slot_global(S, cur, Gn, Gc, s, V, gg_out, agent, f, GS);
-        }
-    }
-}
+// (round 2's one-loop build of this adjoint -- k_g2p_grad, option g2p_grad_v = 1: 109 registers, 3 ... 8 us slower than the two-pass build since round 3 -- was removed in round 6;
+//  the option value is still accepted and means the default)
 struct G2PGradArgs { SimP S; float* fr_cur; float* Gn_; float* Gc_; TableP T; const float4* g_out; float* gg_out; float4* slab; int* slow; GridStore GS; int f; AgentP agent; };
 
-__global__ __launch_bounds__(WG, 4) void k_g2p_grad(SimP S, float* fr_cur, float* Gn_, float* Gc_, TableP T, const float4* g_out, float* gg_out, float4* slab, int* slow, GridStore GS, int f, AgentP agent) { g2p_grad_body(S, fr_cur, Gn_, Gc_, T, g_out, gg_out, slab, slow, GS, f, agent); }
 
-__global__ __launch_bounds__(WG, 4) void k_g2p_grad_b(Batch<G2PGradArgs> B) { const G2PGradArgs& A = B.a[blockIdx.y]; g2p_grad_body(A.S, A.fr_cur, A.Gn_, A.Gc_, A.T, A.g_out, A.gg_out, A.slab, A.slow, A.GS, A.f, A.agent); }
 
 
 // -----------------------------------------------------------------------------------------
@@ -4618,7 +4535,7 @@ struct FeEngine {
     int quad_min_units = 1400;                              // option "quad_min_units": quad units only when pairs alone would be more workgroups than this (build_units_dev)
     int pgg_quad_min_units = 1800;                          // option "pgg_quad_min_units": ... and k_p2g_grad takes them only beyond this many (else the pairs-only list)
     int quad = QUAD_MAX;                                    // option "quad_max": single-item blocks of at most this many particles go four to a workgroup (0: never)
-    int g2p_grad_v = 3;                                     // build of the G2P adjoint: 3 = split passes, x offset rolled (k_g2p_grad2<4>, default); 2 = split, unrolled completely (<3>); 1 = fused rolled loop (k_g2p_grad)
+    int g2p_grad_v = 3;                                     // build of the G2P adjoint: 3 = split passes, x offset rolled (k_g2p_grad2<4>, default); 2 = split, unrolled completely (<3>) (1, round 2's one-loop kernel, was removed in round 6)
     int item_max = ITEM_MAX_CAP;                            // particles per work item (<= ITEM_MAX_CAP = one half workgroup)
     int sort_interval = 10;                                 // K: re-sort every K substeps (0 = never: global path only)
     size_t items_cap = 0, units_cap = 0;
@@ -5096,8 +5013,7 @@ int substep_bwd(FeEngine* h, int f, int f_global, int act, int next_f = -1, bool
                            h->hit_list, h->hit_count);
     }
     if (h->g2p_grad_v == 2) hipLaunchKernelGGL(k_g2p_grad2<3>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, gout(h, f), h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag);
-    else if (h->g2p_grad_v != 1) hipLaunchKernelGGL(k_g2p_grad2<4>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, gout(h, f), h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag);
-    else hipLaunchKernelGGL(k_g2p_grad, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, gout(h, f), h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag);
+    else hipLaunchKernelGGL(k_g2p_grad2<4>, wgrid(h), dim3(WG), 0, h->stream, h->S, h->frame(f), h->grad(f + 1), h->grad(f), T, gout(h, f), h->gg_out, h->slab, h->slow_dev, grid_store(h), f, ag);
     prof_end(h);
     }                                                     // (!g2p_done; the marks of its scatter carry the stamp of the launch it ran in: no stamp++ since)
     prof_begin(h, KID_GRID_GRAD);
@@ -5279,8 +5195,7 @@ int substep_bwd_batch(FeEngine** hs, int B, int f, int f_global, int act, bool g
     }
     prof_begin(h0, KID_G2P_GRAD);
     if (h0->g2p_grad_v == 2) hipLaunchKernelGGL(k_g2p_grad2_b<3>, wgrid_b(hs, B), dim3(WG), 0, h0->stream, bq);
-    else if (h0->g2p_grad_v != 1) hipLaunchKernelGGL(k_g2p_grad2_b<4>, wgrid_b(hs, B), dim3(WG), 0, h0->stream, bq);
-    else hipLaunchKernelGGL(k_g2p_grad_b, wgrid_b(hs, B), dim3(WG), 0, h0->stream, bq);
+    else hipLaunchKernelGGL(k_g2p_grad2_b<4>, wgrid_b(hs, B), dim3(WG), 0, h0->stream, bq);
     prof_end(h0);
     }                                                     // (!g2p_done)
     prof_begin(h0, KID_GRID_GRAD);
@@ -5414,7 +5329,7 @@ FeEngine* fe_create(const FeConfig* cfg) {
     FeEngine* h = new FeEngine();
     if (const char* e = std::getenv("FE_SORT_INTERVAL")) h->sort_interval = std::atoi(e);     // tuning experiments (the option of the same name wins)
     if (const char* e = std::getenv("FE_QUAD_MIN_UNITS")) h->quad_min_units = std::atoi(e);   // (task-level A/B of the quad units: scripts/run_envs.py)
-    if (const char* e = std::getenv("FE_G2P_GRAD_V")) h->g2p_grad_v = std::atoi(e);           // (the parity suite is run once per build of the G2P adjoint)
+    if (const char* e = std::getenv("FE_G2P_GRAD_V")) h->g2p_grad_v = std::atoi(e) == 2 ? 2 : 3;           // (the parity suite is run once per build of the G2P adjoint)
     if (const char* e = std::getenv("FE_FUSE_BWD")) h->fuse_bwd = std::atoi(e);
     if (const char* e = std::getenv("FE_FUSE_G2P")) h->fuse_g2p = std::atoi(e) != 0;           // (the parity suite with and without the fused forward launch)
     if (const char* e = std::getenv("FE_FUSE_GRID")) h->fuse_grid = std::atoi(e);              // (... with and without the fused grid pass; 2 = wherever possible, late deposits included)
@@ -5561,7 +5476,7 @@ int fe_set_option(FeEngine* h, const char* name, double value) {
         return 0;
     }
     if (!std::strcmp(name, "p2g_grad_waves")) { h->p2g_grad_waves = (int)value; return 0; }
-    if (!std::strcmp(name, "g2p_grad_v")) { h->g2p_grad_v = (int)value; return 0; }
+    if (!std::strcmp(name, "g2p_grad_v")) { h->g2p_grad_v = (int)value == 2 ? 2 : 3; return 0; }      // (1, round 2's one-loop kernel, is gone: the default)
     if (!std::strcmp(name, "loose_max")) { if (value < 0 || value > ITEM_MAX_CAP) FAIL(h, "loose_max must be in [0, 128]"); h->loose_max = (int)value; return 0; }
     if (!std::strcmp(name, "inject_till")) { h->inject_till = (int)value; return 0; }
     if (!std::strcmp(name, "collide_min_y")) { h->collide_min_y = (float)value; return 0; }
