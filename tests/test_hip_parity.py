@@ -504,13 +504,13 @@ def test_batched_envs_match_individual_runs(hiplib):
 
     solo = []
     for sc, cot in zip(scenes, cots):
-        eng = S.make_engine(hiplib, sc, max_substeps_local=L)
+        eng = S.make_engine(hiplib, sc, max_substeps_local=L, options={'fuse_g2p': 1, 'fuse_bwd': 1, 'fuse_grid': 0})
         eng.step(0, 0, L, 0)
         eng.reset_grad(); eng.add_grad(L, cot['gx'], cot['gv'], cot['gC'], cot['gF'])
         eng.step_grad(0, 0, L, 0)
         solo.append(finish(eng, cot))
         eng.close()
-    engs = [S.make_engine(hiplib, sc, max_substeps_local=L) for sc in scenes]
+    engs = [S.make_engine(hiplib, sc, max_substeps_local=L, options={'fuse_g2p': 1, 'fuse_bwd': 1, 'fuse_grid': 0}) for sc in scenes]      # (the launch counts asserted below are the fused launches': pinned against FE_* overrides)
     engs[0].profile_enable(True)                           # (a batch's launches are the leader's)
     type(engs[0]).step_batch(engs, 0, 0, L, 0)
     for eng, cot in zip(engs, cots):
@@ -553,7 +553,7 @@ def test_packed_unit_list_matches_the_oracle(hiplib, oracle64, pack_units, quad_
     x = S.f32(np.clip(np.concatenate([core, drops]), 0.08, 0.92))
     N = len(x)
     sc = dict(S.water_block(n_grid=32, n_particles=N, seed=3), x=x, v=S.f32(rng.normal(0, 0.4, (N, 3))))
-    opts = {'sort_interval': 4, 'pack_units': pack_units, 'quad_fit': quad_fit, 'item_max': 128}
+    opts = {'sort_interval': 4, 'pack_units': pack_units, 'quad_fit': quad_fit, 'item_max': 128, 'quad_min_units': 1400}      # (the threshold pinned: FE_QUAD_MIN_UNITS=0 runs of the suite force quads elsewhere)
     g = S.make_engine(hiplib, sc, options=opts)
     o = S.make_engine(oracle64, sc)
     cot = S.random_cotangent(N, seed=4)
